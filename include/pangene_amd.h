@@ -1,0 +1,196 @@
+/*
+ * pangene_amd.h -- public C surface of the MI355X-native pangene graph-construction path.
+ *
+ * Drop-in boundary.  The reference has no plugin/FFI layer; its boundary *is* pangene.h:126-141, called
+ * by main.c:117-142 in a fixed order.  This header re-declares that surface with identical struct
+ * layouts (sizes checked by tests/test_abi.py: opt 128, hit 88, exon 8, prot 32, gene 16, ctg 16,
+ * genome 56, data 72, seg 32, arc 32, graph 56) and identical function names and argument meaning, so a
+ * program written against pangene.h links against libpangene_amd.so unchanged.
+ *
+ *   entry point            replaces (reference file:line)
+ *   pg_opt_init            option.c:6-26
+ *   pg_data_init/destroy   read.c:10-32
+ *   pg_read_paf            read.c:107-262   (parse only; the per-genome filters of read.c:243-260 are
+ *                                            deferred to pg_post_process and run on the GPU -- exact,
+ *                                            SURVEY.md 9.5; nothing can observe the difference because
+ *                                            main.c calls pg_post_process next)
+ *   pg_post_process        graph.c:7-32     (+ the deferred read.c:243-260) -> HIP kernels
+ *   pg_graph_init/gen/destroy graph.c:34-47, 280-322 -> HIP kernels + host round driver
+ *   pg_write_bed/graph/walk format.c:113-225
+ *   pg_read_list_dict, pg_dict_destroy  read.c:305-318, dict.c:38-49 (main.c:73-75,140-142 need them)
+ *
+ * Additions (not in the reference) are at the end: the exchange hook used to shard genomes across
+ * GPUs/processes, id-only scanning of PAFs owned by another shard, and error reporting.
+ */
+#ifndef PANGENE_AMD_H
+#define PANGENE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_VERSION "1.1-r231-mi355x"
+
+/* pg_opt_t::flag bits (values as in pangene.h:8-17) */
+#define PG_F_WRITE_BED_RAW   0x1
+#define PG_F_WRITE_BED_WALK  0x2
+#define PG_F_WRITE_BED_FLAG  0x4
+#define PG_F_WRITE_NO_WALK   0x8
+#define PG_F_WRITE_VTX_SEL   0x10
+#define PG_F_FRAG_MODE       0x20
+#define PG_F_NO_JOINT_PSEUDO 0x40
+#define PG_F_ORI_FOR_BRANCH  0x80
+#define PG_F_CHECK_STRAND    0x100
+#define PG_F_DROP_SGL_EXON   0x200
+
+typedef struct { uint64_t x, y; } pg128_t;
+
+/* options; layout of pangene.h:23-42 */
+typedef struct {
+	uint32_t flag;
+	int32_t  gene_delim;          /* -d */
+	double   min_prot_ratio;      /* -l */
+	double   min_prot_iden;       /* -e */
+	double   score_adj_coef;      /* -m */
+	double   min_ov_ratio;        /* -f */
+	double   min_vertex_ratio;    /* -p */
+	double   branch_diff;         /* -b */
+	double   branch_diff_dist;    /* -y */
+	double   branch_diff_cut;     /* -B */
+	int32_t  max_avg_occ;         /* -c */
+	int32_t  max_degree;          /* -g */
+	int32_t  max_dist_loci;       /* -r */
+	int32_t  n_branch_flt;        /* -T */
+	int32_t  min_arc_cnt;         /* -a */
+	int32_t  local_dist;          /* -D */
+	int32_t  local_count;         /* -C */
+	void    *excl, *incl, *preferred; /* opaque name sets from pg_read_list_dict (-X -I -P) */
+} pg_opt_t;
+
+typedef struct { int32_t os, oe; } pg_exon_t;       /* exon [os,oe) relative to pg_hit_t::cs */
+
+typedef struct {
+	const char *name;
+	int32_t len, gid;
+	int32_t rep;
+	int32_t n, avg_score_adj, max_score_ori;
+} pg_prot_t;
+
+typedef struct {
+	const char *name;
+	uint32_t len:30, preferred:1, included:1;
+	int32_t rep_pid;
+} pg_gene_t;
+
+typedef struct {                                     /* 88 bytes; cs@64 cm@72 ce@80 */
+	int32_t pid;
+	int32_t qs, qe;
+	int32_t cid;
+	int32_t mlen, blen, lof;
+	int32_t rank;
+	int32_t score_ori, score_adj, score_dom;
+	int32_t n_exon, off_exon;
+	int32_t pid_dom, pid_dom0;
+	uint32_t rev:1, flt:1, flt_iso_sub_self:1, flt_iso_ov:1, flt_chain:1, pseudo:1, vtx:1, shadow:1, rep:1, weak_br:2;
+	int64_t cs, cm, ce;
+} pg_hit_t;
+
+typedef struct { const char *name; int64_t len; } pg_ctg_t;
+
+typedef struct {
+	int32_t n_ctg, m_ctg;   pg_ctg_t *ctg;
+	int32_t n_hit, m_hit;   pg_hit_t *hit;
+	int32_t n_exon, m_exon; pg_exon_t *exon;
+	char *label;
+} pg_genome_t;
+
+typedef struct {
+	void *d_ctg, *d_gene, *d_prot;
+	int32_t n_genome, m_genome; pg_genome_t *genome;
+	int32_t n_gene, m_gene;     pg_gene_t *gene;
+	int32_t n_prot, m_prot;     pg_prot_t *prot;
+} pg_data_t;
+
+typedef struct {
+	int32_t gid, n_dom, n_sub;
+	int32_t n_genome;
+	int32_t tot_cnt;
+	uint32_t del:1, dummy:31;
+	int32_t n_dist_loci[2];
+} pg_seg_t;
+
+typedef struct {
+	uint64_t x;                  /* v<<32|w with v = segment<<1|strand */
+	int32_t n_genome;
+	int32_t tot_cnt;
+	int32_t avg_dist;
+	int32_t s1, s2;
+	uint32_t del:1, weak_br:2, dummy:29;
+} pg_arc_t;
+
+typedef struct {
+	pg_data_t *d;
+	int32_t *g2s;
+	int32_t n_seg, m_seg; pg_seg_t *seg;
+	int32_t n_arc, m_arc; pg_arc_t *arc;
+	uint64_t *idx;
+} pg_graph_t;
+
+extern int pg_verbose;
+
+void       pg_opt_init(pg_opt_t *opt);
+pg_data_t *pg_data_init(void);
+void       pg_data_destroy(pg_data_t *d);
+int32_t    pg_read_paf(const pg_opt_t *opt, pg_data_t *d, const char *fn);   /* -1 if fn cannot be opened */
+void       pg_post_process(const pg_opt_t *opt, pg_data_t *d);
+pg_graph_t *pg_graph_init(pg_data_t *d);
+void       pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q);
+void       pg_graph_destroy(pg_graph_t *g);
+void       pg_write_bed(const pg_data_t *d, int32_t is_walk);
+void       pg_write_graph(const pg_graph_t *g);
+void       pg_write_walk(pg_graph_t *g);
+void      *pg_read_list_dict(const char *o);
+void       pg_dict_destroy(void *h);
+
+/* ---------------------------------------------------------------------------------------------
+ * Additions
+ * ------------------------------------------------------------------------------------------- */
+
+/* Last error of the path (0 = none).  The reference aborts on invariant violations; this library
+ * records a status instead, prints one line to stderr, and leaves the graph empty. */
+int         pg_last_error(void);
+const char *pg_last_error_str(void);
+
+/* Redirect what the writers would print to stdout into a file descriptor-less sink:
+ * pg_set_output(path) makes pg_write_* append to `path` (NULL restores stdout). */
+int pg_set_output(const char *path);
+
+/* Register the gene/protein names (and lengths) of a PAF whose hits belong to ANOTHER shard, so that
+ * first-seen id numbering (read.c:151-168) is identical on every rank.  Adds an empty genome. */
+int32_t pg_scan_paf_ids(const pg_opt_t *opt, pg_data_t *d, const char *fn);
+
+/* Exchange hook: genomes shard across processes (one per GPU); the only communication is a handful
+ * of small integer reductions / gathers per round.  NULL (default) = single process. */
+enum { PG_X_I32 = 0, PG_X_I64 = 1 };
+enum { PG_X_SUM = 0, PG_X_MAX = 1 };
+typedef struct {
+	int32_t rank, world;
+	void *user;
+	/* in-place all-reduce of `count` elements; is_device: buf is HBM (use RCCL) else host memory */
+	int (*allreduce)(void *user, void *buf, int64_t count, int32_t dtype, int32_t op, int32_t is_device);
+	/* all-gather `nbytes` from every rank into out[world*nbytes] */
+	int (*allgather)(void *user, const void *in, void *out, int64_t nbytes, int32_t is_device);
+} pg_exchange_t;
+void pg_set_exchange(const pg_exchange_t *x);
+
+/* Wall-clock seconds spent inside the last pg_post_process + pg_graph_gen (stages A+B+C), and the
+ * number of hits they processed (local shard). */
+double  pg_last_path_seconds(void);
+int64_t pg_last_path_hits(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

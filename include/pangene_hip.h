@@ -1,0 +1,206 @@
+/*
+ * pangene_hip.h -- thin C ABI between the host side of the graph-construction path and the code that
+ * owns the per-hit data ("backend").  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * The reference (lh3/pangene v1.1-r231) has no FFI layer: its per-hit work is reached through
+ * pg_read_paf()'s tail (read.c:243-260), pg_post_process() (graph.c:7-32) and pg_graph_gen()
+ * (graph.c:280-322).  Each entry point below replaces the per-hit loops named in its comment; the
+ * S/A-sized logic between them (vertex greedy, branch marking, pruning, formatting) stays on the host
+ * (pangene_amd.h).
+ *
+ * Two implementations of this ABI exist:
+ *   pga_*  (libpangene_amd.so)  hand-written HIP kernels for gfx950 -- the product; fails loudly
+ *                               without a GPU, has no CPU fallback.
+ *   pgo_*  (oracle/liboracle.so) plain-C restatement -- TEST INFRASTRUCTURE ONLY (checker).
+ * Both export the same functions (prefix differs) and a vtable (pga_backend()/pgo_backend()).
+ *
+ * Memory spaces: pointers handed IN are host memory unless stated.  Pointers handed OUT through a
+ * `**` argument live in the backend's space (HBM for pga_*, host for pgo_*) and stay valid until the
+ * next call of the same function or pga_destroy(); they are what the exchange (all-reduce /
+ * all-gather over RCCL) operates on.  Use fetch() to copy them to the host.
+ *
+ * Canonical order: X = hits sorted by (genome, contig, cs, file index);
+ * Y = hits sorted by (genome, contig, cm, X position).  Both are computed once; keys never change.
+ */
+#ifndef PANGENE_HIP_H
+#define PANGENE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* per-hit flag word: same bit positions as the bitfield at pangene.h:70 (rev:1 flt:1 ... weak_br:2) */
+#define PGA_F_REV        0x001u
+#define PGA_F_FLT        0x002u
+#define PGA_F_ISO_SUB    0x004u  /* flt_iso_sub_self */
+#define PGA_F_ISO_OV     0x008u  /* flt_iso_ov */
+#define PGA_F_CHAIN      0x010u  /* flt_chain */
+#define PGA_F_PSEUDO     0x020u
+#define PGA_F_VTX        0x040u
+#define PGA_F_SHADOW     0x080u
+#define PGA_F_REP        0x100u
+#define PGA_F_WEAK_SHIFT 9
+#define PGA_F_WEAK_MASK  0x600u
+
+/* which field PG_SET_FILTER (pgpriv.h:109-116) tests */
+enum { PGA_FLT_PSEUDO = 0, PGA_FLT_VTX0 = 1, PGA_FLT_WEAK2 = 2, PGA_FLT_SHADOW = 3 };
+
+/* status codes: 0 ok; negative = error (never aborts the process) */
+enum {
+	PGA_OK = 0,
+	PGA_ERR_NO_DEVICE = -1,   /* no usable MI355X / HIP runtime error */
+	PGA_ERR_RANGE = -2,       /* a coordinate or id does not fit the device layout */
+	PGA_ERR_ARG = -3,
+	PGA_ERR_NOMEM = -4,
+	PGA_ERR_INVARIANT = -5    /* an invariant the reference asserts (e.g. vertex.c:38) was violated */
+};
+
+/* One shard = a set of genomes with all their hits, structure-of-arrays, FILE order inside a genome.
+ * (pg_hit_t pangene.h:61-72, pg_exon_t 44-46, pg_genome_t 79-87) */
+typedef struct {
+	int32_t n_genome;            /* genomes in this shard (may include genomes with 0 hits) */
+	int32_t n_genome_global;     /* G of the whole run (all shards) */
+	const int32_t *genome_global;/* [n_genome] global genome index of each local genome */
+	int32_t n_prot, n_gene;      /* global table sizes (ids are assigned on the host before upload) */
+	int64_t n_hit, n_exon;
+	const int64_t *hit_off;      /* [n_genome+1] */
+	const int32_t *n_ctg;        /* [n_genome] contigs per genome */
+	const int32_t *pid, *cid, *rank, *score_ori, *score_adj, *n_exon_of, *off_exon; /* [n_hit] */
+	const int32_t *cs, *ce, *cm; /* [n_hit] contig coordinates; must be < 2^31 */
+	const uint8_t *rev;          /* [n_hit] */
+	const int32_t *exon_os, *exon_oe; /* [n_exon] relative to cs, ascending (pangene.h:44-46) */
+	const int32_t *prot_gid;     /* [n_prot] */
+	const uint8_t *gene_pref;    /* [n_gene] pg_gene_t::preferred */
+} pga_shard_t;
+
+typedef struct {
+	double  min_ov_ratio;        /* pg_opt_t::min_ov_ratio (overlap.c:136) */
+	int32_t check_strand;        /* PG_F_CHECK_STRAND */
+	int32_t drop_sgl_exon;       /* PG_F_DROP_SGL_EXON (hit.c:180) -- evaluated on the host, kept for reference */
+	int32_t reserved[4];
+} pga_params_t;
+
+/* per-hit state, FILE order, host memory (any pointer may be NULL = not wanted) */
+typedef struct {
+	uint32_t *flags;             /* PGA_F_* */
+	int32_t *rank, *score_dom, *pid_dom, *pid_dom0;
+	int32_t *pos_x;              /* position of the hit inside its genome in X (cs) order */
+	int32_t *pos_y;              /* position of the hit inside its genome in Y (cm) order */
+} pga_hit_state_t;
+
+/* one partially reduced arc: sums over the LOCAL genomes of the per-genome collapsed values
+ * (graph.c:128-145 then the integer part of 153-169); final roundings are done on the host after
+ * the cross-shard merge */
+typedef struct {
+	uint64_t x;                  /* v<<32|w, v = sid<<1|rev */
+	int32_t  n_genome, tot_cnt;
+	uint64_t sum_dist;           /* sum over genomes of dist_genome * n_genome_local_count */
+	int64_t  sum_s1, sum_s2;     /* sum over genomes of per-genome max s1 / s2 */
+} pga_arc_part_t;
+
+typedef struct pga_ctx pga_ctx_t;
+
+/* hazard counters: situations in which the reference's unstable sort could make its
+ * output depend on tie order.  0 everywhere = canonical order provably gives the reference's result. */
+typedef struct {
+	int64_t h1_head_tie;         /* index-0 quirk outcome depends on who sits at index 0 */
+	int64_t h2_cm_tie;           /* two walkable hits share (contig, cm) */
+	int64_t h2_cs_tie;           /* two walkable hits share (contig, cs) (perturbs pg_gen_rep_pos's r) */
+	int64_t h3_dom_tie;          /* dominator arg-max tie / subopt-isoform tie at equal (contig, cs) */
+} pga_hazard_t;
+
+#define PGA_DECLARE(pfx) \
+	/* upload a shard; packs SoA, computes cds lengths, X and Y orders (pg_hit_sort hit.c:29-64) */ \
+	int  pfx##_create(pga_ctx_t **ctx, const pga_shard_t *sh, const pga_params_t *par); \
+	void pfx##_destroy(pga_ctx_t *ctx); \
+	/* stage A, read.c:243-260: pg_flag_pseudo, PG_SET_FILTER(pseudo), sort, pg_shadow(cal_dom_sc=1), \
+	 * pid_dom0/reset, pg_flt_ov_isoform, pg_flt_chain_shadow, pg_flt_subopt_isoform. \
+	 * stats: [n_genome*4] n_pseudo, n_flt_ov_iso, n_flt_chain, n_flt_subopt (host; may be NULL) */ \
+	int  pfx##_ingest(pga_ctx_t *ctx, int32_t *stats); \
+	/* stage B partials: max_ori[P] = max score_ori over all hits (hit.c:230-238); sums[6P] = \
+	 * {sum score_adj, count} of rank-0 non-flt hits (hit.c:196-204) and c0,c1,s0,s1 (hit.c:158-169), \
+	 * stored as six planes of P int64 */ \
+	int  pfx##_post_partials(pga_ctx_t *ctx, int32_t **max_ori, int64_t **sums); \
+	/* cap score_dom (hit.c:239-246, using the reduced max_ori still in backend memory), hit.rep \
+	 * (hit.c:219-224), joint pseudo flag for single-exon hits of proteins with prot_pj[pid] (hit.c:170-184) */ \
+	int  pfx##_post_apply(pga_ctx_t *ctx, const uint8_t *prot_rep, const uint8_t *prot_pj, int64_t *n_pseudo); \
+	/* pg_shadow (overlap.c:101-178) over every genome. stats: [n_genome*2] {#non-flt, #shadowed} or NULL */ \
+	int  pfx##_shadow(pga_ctx_t *ctx, int32_t cal_dom_sc, int32_t *stats); \
+	/* PG_SET_FILTER (pgpriv.h:109-116) */ \
+	int  pfx##_set_filter(pga_ctx_t *ctx, int32_t which); \
+	/* pg_gen_vtx per-genome part (vertex.c:28-51): cnt[2Q] = n_dom[Q] then n_sub[Q]; triples = \
+	 * genome_global<<40 | sub_gene<<20 | dom_gene for every (genome, gene) that is sub-ordinate to a \
+	 * gene which is dominant in that genome (the only entries the greedy vertex.c:60-80 can observe) */ \
+	int  pfx##_vtx_partials(pga_ctx_t *ctx, int32_t **cnt, uint64_t **triples, int64_t *n_triples); \
+	/* pg_graph_flag_vtx (graph.c:61-69); g2s: [n_gene] host */ \
+	int  pfx##_flag_vtx(pga_ctx_t *ctx, const int32_t *g2s, int32_t n_seg); \
+	/* per-genome part of pg_gen_arc (graph.c:97-146) + local reduce-by-key of its global part. \
+	 * seg_cnt[2S] = n_genome[S] then tot_cnt[S] (graph.c:125-126); arcs sorted by x */ \
+	int  pfx##_arc_round(pga_ctx_t *ctx, int32_t use_ori, int32_t **seg_cnt, pga_arc_part_t **arcs, int64_t *n_arcs); \
+	/* pg_gen_rep_pos (branch.c:6-29) kept in backend memory */ \
+	int  pfx##_rep_pos(pga_ctx_t *ctx); \
+	/* pg_n_local (branch.c:31-46) for n gene pairs (pairs[2i], pairs[2i+1]) summed over local genomes */ \
+	int  pfx##_n_local(pga_ctx_t *ctx, const int32_t *pairs, int64_t n, int32_t local_dist, int32_t local_count, \
+	                   int32_t frag_mode, int32_t **cnt); \
+	/* pg_mark_branch_flt_hit (branch.c:108-145); arcs sorted by x with their weak_br (0 allowed) */ \
+	int  pfx##_mark_hits(pga_ctx_t *ctx, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked); \
+	/* copy backend memory to the host / host to backend / backend to backend */ \
+	int  pfx##_fetch(pga_ctx_t *ctx, void *dst_host, const void *src_backend, size_t nbytes); \
+	int  pfx##_put(pga_ctx_t *ctx, void *dst_backend, const void *src_host, size_t nbytes); \
+	int  pfx##_copy(pga_ctx_t *ctx, void *dst_backend, const void *src_backend, size_t nbytes); \
+	/* one reusable scratch buffer in backend memory (staging area for padded all-gathers); a second \
+	 * call invalidates the first pointer */ \
+	int  pfx##_scratch(pga_ctx_t *ctx, size_t nbytes, void **ptr); \
+	/* per-hit state in file order */ \
+	int  pfx##_download(pga_ctx_t *ctx, const pga_hit_state_t *out); \
+	int  pfx##_hazards(pga_ctx_t *ctx, pga_hazard_t *out); \
+	/* 1 if `**` pointers are device memory (exchange must use the device collective) */ \
+	int  pfx##_is_device(void); \
+	const char *pfx##_strerror(int code);
+
+PGA_DECLARE(pga)
+
+/* the same ABI as a table, so the host driver is written once */
+typedef struct {
+	const char *name;
+	int  (*create)(pga_ctx_t **, const pga_shard_t *, const pga_params_t *);
+	void (*destroy)(pga_ctx_t *);
+	int  (*ingest)(pga_ctx_t *, int32_t *);
+	int  (*post_partials)(pga_ctx_t *, int32_t **, int64_t **);
+	int  (*post_apply)(pga_ctx_t *, const uint8_t *, const uint8_t *, int64_t *);
+	int  (*shadow)(pga_ctx_t *, int32_t, int32_t *);
+	int  (*set_filter)(pga_ctx_t *, int32_t);
+	int  (*vtx_partials)(pga_ctx_t *, int32_t **, uint64_t **, int64_t *);
+	int  (*flag_vtx)(pga_ctx_t *, const int32_t *, int32_t);
+	int  (*arc_round)(pga_ctx_t *, int32_t, int32_t **, pga_arc_part_t **, int64_t *);
+	int  (*rep_pos)(pga_ctx_t *);
+	int  (*n_local)(pga_ctx_t *, const int32_t *, int64_t, int32_t, int32_t, int32_t, int32_t **);
+	int  (*mark_hits)(pga_ctx_t *, const uint64_t *, const uint8_t *, int64_t, int64_t *);
+	int  (*fetch)(pga_ctx_t *, void *, const void *, size_t);
+	int  (*put)(pga_ctx_t *, void *, const void *, size_t);
+	int  (*copy)(pga_ctx_t *, void *, const void *, size_t);
+	int  (*scratch)(pga_ctx_t *, size_t, void **);
+	int  (*download)(pga_ctx_t *, const pga_hit_state_t *);
+	int  (*hazards)(pga_ctx_t *, pga_hazard_t *);
+	int  (*is_device)(void);
+	const char *(*strerror)(int);
+} pga_backend_t;
+
+const pga_backend_t *pga_backend(void);
+
+/* Optional: run every kernel on this hipStream_t instead of the library's own stream (lets a host
+ * framework order its collectives with the kernels without extra synchronisation). */
+int pga_set_stream(pga_ctx_t *ctx, void *hip_stream);
+
+/* Kernel timing hooks for bench.py: HIP events bracket every launch of the named kernel class on the
+ * library's stream.  which: 0 = "k1" (stage A sweep, the hit-filter+overlap kernel). */
+int pga_timing_reset(pga_ctx_t *ctx);
+int pga_timing_get(pga_ctx_t *ctx, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

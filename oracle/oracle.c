@@ -1,0 +1,728 @@
+/*
+ * oracle.c -- TEST INFRASTRUCTURE ONLY.  Plain-C (C99) restatement of the per-hit part of
+ * lh3/pangene v1.1-r231's graph-construction path, behind the same C ABI as the HIP product
+ * (include/pangene_hip.h, prefix pgo_ instead of pga_).  It is the checker the parity tests compare
+ * the kernels against and the partner of the host driver in the CPU-only tests; nothing in the product
+ * links, imports or executes it.
+ *
+ * Pinning: tests/test_oracle_vs_ref.py runs the host driver on top of this file over every fixture in
+ * tests/golden/ and requires the GFA / BED bytes to equal the outputs of the untouched reference
+ * (oracle/_ref/pangene_ref, built by oracle/Makefile from the sources under /root/reference).
+ *
+ * Each function cites the reference lines it follows.  Order of hits: canonical X = (contig, cs, file
+ * index) and Y = (contig, cm, X position) per genome, i.e. what the reference's pg_hit_sort
+ * (hit.c:29-64) would give with a stable sort (its radix sort is unstable).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "pangene_hip.h"
+
+PGA_DECLARE(pgo)
+const pga_backend_t *pgo_backend(void);
+
+#define MALLOC(type, n) ((type*)malloc((size_t)((n) > 0 ? (n) : 1) * sizeof(type)))
+#define CALLOC(type, n) ((type*)calloc((size_t)((n) > 0 ? (n) : 1), sizeof(type)))
+
+struct pga_ctx {
+	int32_t n_genome, n_genome_global, n_prot, n_gene;
+	int64_t n_hit, n_exon;
+	int64_t *off;             /* [n_genome+1] */
+	int32_t *genome_global, *n_ctg;
+	/* per hit, X order (genome-major) */
+	int32_t *fidx;            /* file index inside the genome */
+	int32_t *pid, *gid, *cid, *rank, *score_ori, *score_adj, *score_dom, *n_exon_of, *off_exon, *cs, *ce, *cm, *cds;
+	int32_t *pid_dom, *pid_dom0;
+	uint32_t *flags;
+	int32_t *yo;              /* Y order: yo[off[j]+k] = X position (global) of the k-th hit in cm order */
+	int32_t *exon_os, *exon_oe;
+	int32_t *prot_gid;
+	uint8_t *gene_pref;
+	pga_params_t par;
+	/* exchange buffers */
+	int32_t *max_ori; int64_t *sums;
+	int32_t *vtx_cnt; uint64_t *triples; int64_t n_triples, m_triples;
+	int32_t *g2s; int32_t n_seg;
+	int32_t *seg_cnt; pga_arc_part_t *arcs; int64_t n_arcs, m_arcs;
+	/* rep_pos: per local genome, per gene */
+	int64_t *rp_x; int32_t *rp_y;  /* rp_x = cid<<32|r or -1 */
+	int32_t *nl_cnt;
+	pga_hazard_t hz;
+	void *scratch; size_t m_scratch;
+};
+
+int pgo_is_device(void) { return 0; }
+
+const char *pgo_strerror(int code)
+{
+	switch (code) {
+	case PGA_OK: return "ok";
+	case PGA_ERR_NO_DEVICE: return "no device";
+	case PGA_ERR_RANGE: return "value out of range for the device layout";
+	case PGA_ERR_ARG: return "bad argument";
+	case PGA_ERR_NOMEM: return "out of memory";
+	case PGA_ERR_INVARIANT: return "reference invariant violated";
+	}
+	return "unknown";
+}
+
+/* ---- small helpers ---- */
+
+/* pg_hash_uint32, pgpriv.h:88-97 (the score tie-breaker) */
+static inline uint32_t hash32(uint32_t key)
+{
+	key += ~(key << 15);
+	key ^=  (key >> 10);
+	key +=  (key << 3);
+	key ^=  (key >> 6);
+	key += ~(key << 11);
+	key ^=  (key >> 16);
+	return key;
+}
+
+typedef struct { int64_t k1, k2; int32_t k3, v; } skey_t;
+
+static int skey_cmp(const void *a_, const void *b_)
+{
+	const skey_t *a = (const skey_t*)a_, *b = (const skey_t*)b_;
+	if (a->k1 != b->k1) return a->k1 < b->k1 ? -1 : 1;
+	if (a->k2 != b->k2) return a->k2 < b->k2 ? -1 : 1;
+	if (a->k3 != b->k3) return a->k3 < b->k3 ? -1 : 1;
+	return 0;
+}
+
+static inline int is_flt(const pga_ctx_t *c, int64_t i) { return (c->flags[i] & PGA_F_FLT) != 0; }
+static inline int weak_of(const pga_ctx_t *c, int64_t i) { return (c->flags[i] & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT; }
+
+/* pg_hit_overlap, overlap.c:6-42: CDS intersection length of two hits on one contig (union unused) */
+static int32_t cds_inter(const pga_ctx_t *c, int64_t a, int64_t b)
+{
+	int32_t ia = 0, ib = 0, na = c->n_exon_of[a], nb = c->n_exon_of[b];
+	const int32_t *as = c->exon_os + c->off_exon[a], *ae = c->exon_oe + c->off_exon[a];
+	const int32_t *bs = c->exon_os + c->off_exon[b], *be = c->exon_oe + c->off_exon[b];
+	int64_t ca = c->cs[a], cb = c->cs[b], inter = 0;
+	if (c->cid[a] != c->cid[b] || !(c->cs[a] < c->ce[b] && c->ce[a] > c->cs[b])) return 0; /* overlap.c:12 */
+	while (ia < na && ib < nb) { /* two-pointer merge, overlap.c:17-33 */
+		int64_t s0 = ca + as[ia], e0 = ca + ae[ia], s1 = cb + bs[ib], e1 = cb + be[ib];
+		if (s0 < s1) { /* x = a */
+			if (e0 < e1) { int64_t o = e0 - s1; inter += o > 0 ? o : 0; ++ia; }
+			else { inter += e1 - s1; ++ib; }
+		} else { /* x = b */
+			if (e1 < e0) { int64_t o = e1 - s0; inter += o > 0 ? o : 0; ++ib; }
+			else { inter += e0 - s0; ++ia; }
+		}
+	}
+	return (int32_t)inter;
+}
+
+/* 64-bit comparison score, overlap.c:137-138 */
+static inline uint64_t score64(const pga_ctx_t *c, int64_t i)
+{
+	return (uint64_t)c->score_adj[i] << 33 | (uint64_t)c->gene_pref[c->gid[i]] << 32 | hash32((uint32_t)c->pid[i]);
+}
+
+void pgo_destroy(pga_ctx_t *c)
+{
+	if (c == 0) return;
+	free(c->off); free(c->genome_global); free(c->n_ctg); free(c->fidx);
+	free(c->pid); free(c->gid); free(c->cid); free(c->rank); free(c->score_ori); free(c->score_adj); free(c->score_dom);
+	free(c->n_exon_of); free(c->off_exon); free(c->cs); free(c->ce); free(c->cm); free(c->cds);
+	free(c->pid_dom); free(c->pid_dom0); free(c->flags); free(c->yo); free(c->exon_os); free(c->exon_oe);
+	free(c->prot_gid); free(c->gene_pref); free(c->max_ori); free(c->sums); free(c->vtx_cnt); free(c->triples);
+	free(c->g2s); free(c->seg_cnt); free(c->arcs); free(c->rp_x); free(c->rp_y); free(c->nl_cnt); free(c->scratch);
+	free(c);
+}
+
+/* upload + pg_hit_sort (hit.c:29-64) in canonical order + pg_cds_len (overlap.c:45-51) */
+int pgo_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
+{
+	pga_ctx_t *c;
+	int64_t N = sh->n_hit, i, k;
+	int32_t j;
+	skey_t *key;
+	if (out == 0 || sh == 0 || par == 0) return PGA_ERR_ARG;
+	c = CALLOC(pga_ctx_t, 1);
+	c->n_genome = sh->n_genome, c->n_genome_global = sh->n_genome_global, c->n_prot = sh->n_prot, c->n_gene = sh->n_gene;
+	c->n_hit = N, c->n_exon = sh->n_exon, c->par = *par;
+	c->off = MALLOC(int64_t, sh->n_genome + 1); memcpy(c->off, sh->hit_off, (sh->n_genome + 1) * sizeof(int64_t));
+	c->genome_global = MALLOC(int32_t, sh->n_genome); memcpy(c->genome_global, sh->genome_global, sh->n_genome * sizeof(int32_t));
+	c->n_ctg = MALLOC(int32_t, sh->n_genome); memcpy(c->n_ctg, sh->n_ctg, sh->n_genome * sizeof(int32_t));
+	c->exon_os = MALLOC(int32_t, sh->n_exon); memcpy(c->exon_os, sh->exon_os, sh->n_exon * sizeof(int32_t));
+	c->exon_oe = MALLOC(int32_t, sh->n_exon); memcpy(c->exon_oe, sh->exon_oe, sh->n_exon * sizeof(int32_t));
+	c->prot_gid = MALLOC(int32_t, sh->n_prot); memcpy(c->prot_gid, sh->prot_gid, sh->n_prot * sizeof(int32_t));
+	c->gene_pref = MALLOC(uint8_t, sh->n_gene); memcpy(c->gene_pref, sh->gene_pref, sh->n_gene);
+	c->fidx = MALLOC(int32_t, N); c->pid = MALLOC(int32_t, N); c->gid = MALLOC(int32_t, N); c->cid = MALLOC(int32_t, N);
+	c->rank = MALLOC(int32_t, N); c->score_ori = MALLOC(int32_t, N); c->score_adj = MALLOC(int32_t, N);
+	c->score_dom = CALLOC(int32_t, N); c->n_exon_of = MALLOC(int32_t, N); c->off_exon = MALLOC(int32_t, N);
+	c->cs = MALLOC(int32_t, N); c->ce = MALLOC(int32_t, N); c->cm = MALLOC(int32_t, N); c->cds = MALLOC(int32_t, N);
+	c->pid_dom = MALLOC(int32_t, N); c->pid_dom0 = CALLOC(int32_t, N); c->flags = CALLOC(uint32_t, N);
+	c->yo = MALLOC(int32_t, N);
+	key = MALLOC(skey_t, N);
+	for (j = 0; j < sh->n_genome; ++j) { /* X order */
+		int64_t st = sh->hit_off[j], en = sh->hit_off[j + 1];
+		for (i = st; i < en; ++i) key[i].k1 = sh->cid[i], key[i].k2 = sh->cs[i], key[i].k3 = (int32_t)(i - st), key[i].v = (int32_t)(i - st);
+		qsort(key + st, (size_t)(en - st), sizeof(skey_t), skey_cmp);
+		for (i = st; i < en; ++i) {
+			int64_t s = st + key[i].v;
+			int32_t e, len = 0;
+			c->fidx[i] = key[i].v;
+			c->pid[i] = sh->pid[s], c->cid[i] = sh->cid[s], c->rank[i] = sh->rank[s];
+			c->score_ori[i] = sh->score_ori[s], c->score_adj[i] = sh->score_adj[s];
+			c->n_exon_of[i] = sh->n_exon_of[s], c->off_exon[i] = sh->off_exon[s];
+			c->cs[i] = sh->cs[s], c->ce[i] = sh->ce[s], c->cm[i] = sh->cm[s];
+			c->gid[i] = sh->prot_gid[sh->pid[s]];
+			c->flags[i] = sh->rev[s] ? PGA_F_REV : 0;
+			c->pid_dom[i] = -1; /* read.c:134 */
+			for (e = 0; e < sh->n_exon_of[s]; ++e)
+				len += sh->exon_oe[sh->off_exon[s] + e] - sh->exon_os[sh->off_exon[s] + e];
+			c->cds[i] = len;
+		}
+	}
+	for (j = 0; j < sh->n_genome; ++j) { /* Y order */
+		int64_t st = c->off[j], en = c->off[j + 1];
+		for (i = st; i < en; ++i) key[i].k1 = c->cid[i], key[i].k2 = c->cm[i], key[i].k3 = (int32_t)(i - st), key[i].v = (int32_t)i;
+		qsort(key + st, (size_t)(en - st), sizeof(skey_t), skey_cmp);
+		for (k = st; k < en; ++k) c->yo[k] = key[k].v;
+	}
+	free(key);
+	c->max_ori = CALLOC(int32_t, c->n_prot);
+	c->sums = CALLOC(int64_t, 6 * (int64_t)c->n_prot);
+	c->vtx_cnt = CALLOC(int32_t, 2 * (int64_t)c->n_gene);
+	c->g2s = MALLOC(int32_t, c->n_gene);
+	for (i = 0; i < c->n_gene; ++i) c->g2s[i] = -1;
+	*out = c;
+	return PGA_OK;
+}
+
+/* pg_flag_pseudo, hit.c:66-105, one genome.  Keys (pid, rank) are unique inside a genome so the
+ * result does not depend on the order of the hit array. */
+static int32_t flag_pseudo(pga_ctx_t *c, int32_t j, int32_t *maxn, int32_t *minn, int32_t *r1)
+{
+	int64_t st = c->off[j], en = c->off[j + 1], i;
+	int32_t n_pseudo = 0;
+	for (i = st; i < en; ++i) maxn[c->pid[i]] = 0, minn[c->pid[i]] = INT32_MAX, r1[c->pid[i]] = INT32_MAX;
+	for (i = st; i < en; ++i) { /* hit.c:78-83 */
+		int32_t p = c->pid[i], ne = c->n_exon_of[i];
+		if (ne > maxn[p]) maxn[p] = ne;
+		if (ne < minn[p]) minn[p] = ne;
+	}
+	for (i = st; i < en; ++i) { /* hit.c:84-92 */
+		int32_t p = c->pid[i], ne = c->n_exon_of[i];
+		if (!(maxn[p] > 1 && (minn[p] == 1 || minn[p] * 2 <= maxn[p]))) continue;
+		if (ne == 1 || ne * 2 <= maxn[p]) c->flags[i] |= PGA_F_PSEUDO, ++n_pseudo;
+		else if (c->rank[i] < r1[p]) r1[p] = c->rank[i]; /* j1 = first non-pseudo in rank order */
+	}
+	for (i = st; i < en; ++i) { /* promote the first multi-exon hit to rank 0, hit.c:94-98 */
+		int32_t p = c->pid[i];
+		if (!(maxn[p] > 1 && (minn[p] == 1 || minn[p] * 2 <= maxn[p]))) continue;
+		if (r1[p] == INT32_MAX || r1[p] == 0) continue;
+		if (c->rank[i] < r1[p]) c->rank[i]++;
+		else if (c->rank[i] == r1[p]) c->rank[i] = 0;
+	}
+	return n_pseudo;
+}
+
+typedef struct { uint64_t score; int64_t aid; int32_t ov_len; } shadow_aux_t;
+
+/* pg_shadow, overlap.c:101-178, one genome (array in cs order).  Returns #shadowed non-flt hits. */
+static int32_t shadow_genome(pga_ctx_t *c, int32_t j, int cal_dom_sc, int32_t *n_tot)
+{
+	int64_t st = c->off[j], en = c->off[j + 1], i, i0, jj;
+	int32_t n_shadow = 0, tot = 0;
+	shadow_aux_t *tmp = CALLOC(shadow_aux_t, en - st);
+	for (i = st + 1, i0 = st; i < en; ++i) { /* overlap.c:108: starts at 1 => index 0 is never reset */
+		int32_t li, gi;
+		uint64_t si;
+		if (is_flt(c, i)) continue;
+		c->flags[i] &= ~PGA_F_SHADOW;
+		while (i0 < i && !(c->cid[i0] == c->cid[i] && c->ce[i0] > c->cs[i])) ++i0; /* overlap.c:114-115 */
+		gi = c->gid[i], li = c->cds[i], si = score64(c, i);
+		for (jj = i0; jj < i; ++jj) {
+			int32_t x, lj, gj, sh;
+			double cov_short;
+			uint64_t sj;
+			if (c->ce[jj] <= c->cs[i]) continue;
+			if (is_flt(c, jj)) continue;
+			if (c->par.check_strand && ((c->flags[i] ^ c->flags[jj]) & PGA_F_REV)) continue;
+			gj = c->gid[jj];
+			x = cds_inter(c, jj, i);
+			if (x == 0) continue; /* overlap.c:132 */
+			lj = c->cds[jj];
+			cov_short = (double)x / (li < lj ? li : lj);
+			if (gi != gj && cov_short < c->par.min_ov_ratio) continue; /* overlap.c:136 */
+			sj = score64(c, jj);
+			if (gi == gj || weak_of(c, i) == weak_of(c, jj)) /* overlap.c:139-142 */
+				sh = (si < sj || (si == sj && c->rank[i] > c->rank[jj])) ? 0 : 1;
+			else if (weak_of(c, i) > weak_of(c, jj)) sh = 0;
+			else sh = 1;
+			if (sh == 0) { /* overlap.c:148-154 */
+				c->flags[i] |= PGA_F_SHADOW;
+				if (tmp[i - st].score == sj && sj > 0) c->hz.h3_dom_tie++;
+				if (tmp[i - st].score < sj) tmp[i - st].score = sj, tmp[i - st].aid = jj, tmp[i - st].ov_len = x;
+			} else {
+				c->flags[jj] |= PGA_F_SHADOW;
+				if (tmp[jj - st].score == si && si > 0) c->hz.h3_dom_tie++;
+				if (tmp[jj - st].score < si) tmp[jj - st].score = si, tmp[jj - st].aid = i, tmp[jj - st].ov_len = x;
+			}
+		}
+	}
+	for (i = st; i < en; ++i) { /* overlap.c:157-175 */
+		if (is_flt(c, i)) continue;
+		++tot;
+		c->pid_dom[i] = -1;
+		if (cal_dom_sc) c->score_dom[i] = -1;
+		if (tmp[i - st].score > 0) {
+			int64_t a = tmp[i - st].aid;
+			c->pid_dom[i] = c->pid[a];
+			if (cal_dom_sc) {
+				int32_t li = c->cds[i], lj = c->cds[a];
+				c->score_dom[i] = (int32_t)(c->score_ori[i] * (1.0 - (double)tmp[i - st].ov_len / li)
+				                            + c->score_ori[a] * ((double)tmp[i - st].ov_len / lj) + .499);
+			}
+		}
+		if (c->flags[i] & PGA_F_SHADOW) ++n_shadow;
+	}
+	free(tmp);
+	if (n_tot) *n_tot = tot;
+	return n_shadow;
+}
+
+/* pg_flt_ov_isoform, overlap.c:58-93, one genome */
+static int32_t flt_ov_isoform(pga_ctx_t *c, int32_t j)
+{
+	int64_t st = c->off[j], en = c->off[j + 1], i, i0, jj;
+	int32_t n_flt = 0;
+	for (i = st + 1, i0 = st; i < en; ++i) {
+		uint64_t si;
+		if (is_flt(c, i)) continue;
+		while (i0 < i && !(c->cid[i0] == c->cid[i] && c->ce[i0] > c->cs[i])) ++i0;
+		si = score64(c, i);
+		for (jj = i0; jj < i; ++jj) {
+			uint64_t sj;
+			if (is_flt(c, jj) || c->ce[jj] <= c->cs[i]) continue;
+			if (c->gid[i] != c->gid[jj]) continue;
+			if (c->par.check_strand && ((c->flags[i] ^ c->flags[jj]) & PGA_F_REV)) continue;
+			if (cds_inter(c, jj, i) == 0) continue;
+			sj = score64(c, jj);
+			if (si < sj || (si == sj && c->rank[i] > c->rank[jj])) c->flags[i] |= PGA_F_ISO_OV;
+			else c->flags[jj] |= PGA_F_ISO_OV;
+		}
+	}
+	for (i = st; i < en; ++i)
+		if (c->flags[i] & PGA_F_ISO_OV) c->flags[i] |= PGA_F_FLT, ++n_flt;
+	return n_flt;
+}
+
+/* pg_flt_chain_shadow, hit.c:130-146, one genome; flag[] has n_prot entries, all 1 on entry and exit */
+static int32_t flt_chain_shadow(pga_ctx_t *c, int32_t j, int8_t *flag)
+{
+	int64_t st = c->off[j], en = c->off[j + 1], i;
+	int32_t n_flt = 0;
+	for (i = st; i < en; ++i)
+		if (!(c->flags[i] & PGA_F_ISO_OV)) flag[c->pid[i]] = 0;
+	for (i = st; i < en; ++i)
+		if (c->pid_dom0[i] >= 0 && flag[c->pid_dom0[i]])
+			c->flags[i] |= PGA_F_FLT | PGA_F_CHAIN, ++n_flt;
+	for (i = st; i < en; ++i) flag[c->pid[i]] = 1;
+	return n_flt;
+}
+
+/* pg_flt_subopt_isoform, hit.c:107-128, one genome; best[] has n_gene zeroed entries on entry and exit */
+static int32_t flt_subopt_isoform(pga_ctx_t *c, int32_t j, uint64_t *best)
+{
+	int64_t st = c->off[j], en = c->off[j + 1], i;
+	int32_t n_flt = 0;
+	for (i = st; i < en; ++i) {
+		if (is_flt(c, i) || c->rank[i] > 0) continue;
+		if (c->score_adj[i] > 0 && (uint64_t)c->score_adj[i] > best[c->gid[i]] >> 32) { /* hit.c:116; the cast there makes negatives huge */
+			best[c->gid[i]] = (uint64_t)c->score_adj[i] << 32 | (uint32_t)c->pid[i];
+		} else if (c->score_adj[i] < 0) { /* (int32 > uint64) promotes to unsigned: a negative score_adj always wins */
+			best[c->gid[i]] = (uint64_t)c->score_adj[i] << 32 | (uint32_t)c->pid[i];
+		}
+	}
+	for (i = st; i < en; ++i) {
+		if (is_flt(c, i)) continue;
+		if (c->pid[i] != (int32_t)best[c->gid[i]])
+			c->flags[i] |= PGA_F_FLT | PGA_F_ISO_SUB, ++n_flt;
+	}
+	for (i = st; i < en; ++i) best[c->gid[i]] = 0;
+	return n_flt;
+}
+
+/* stage A, read.c:243-260 */
+int pgo_ingest(pga_ctx_t *c, int32_t *stats)
+{
+	int32_t j, *maxn, *minn, *r1;
+	int8_t *flag;
+	uint64_t *best;
+	int64_t i;
+	maxn = CALLOC(int32_t, c->n_prot), minn = CALLOC(int32_t, c->n_prot), r1 = CALLOC(int32_t, c->n_prot);
+	flag = MALLOC(int8_t, c->n_prot);
+	for (i = 0; i < c->n_prot; ++i) flag[i] = 1;
+	best = CALLOC(uint64_t, c->n_gene);
+	for (j = 0; j < c->n_genome; ++j) {
+		int32_t n_pseudo, n_ov, n_chain, n_sub;
+		n_pseudo = flag_pseudo(c, j, maxn, minn, r1);
+		for (i = c->off[j]; i < c->off[j + 1]; ++i) /* PG_SET_FILTER(d, pseudo == 1), read.c:246 */
+			if (c->flags[i] & PGA_F_PSEUDO) c->flags[i] |= PGA_F_FLT;
+		shadow_genome(c, j, 1, 0); /* read.c:248 */
+		for (i = c->off[j]; i < c->off[j + 1]; ++i) { /* read.c:249-253 */
+			c->pid_dom0[i] = c->pid_dom[i];
+			c->pid_dom[i] = -1, c->flags[i] &= ~PGA_F_SHADOW;
+		}
+		n_ov = flt_ov_isoform(c, j);
+		n_chain = flt_chain_shadow(c, j, flag);
+		n_sub = flt_subopt_isoform(c, j, best);
+		if (stats) stats[j*4] = n_pseudo, stats[j*4+1] = n_ov, stats[j*4+2] = n_chain, stats[j*4+3] = n_sub;
+	}
+	free(maxn); free(minn); free(r1); free(flag); free(best);
+	return PGA_OK;
+}
+
+/* partial reductions of pg_cap_score_dom (hit.c:230-238), pg_flag_representative (hit.c:196-204),
+ * pg_flag_pseudo_joint (hit.c:158-169) */
+int pgo_post_partials(pga_ctx_t *c, int32_t **max_ori, int64_t **sums)
+{
+	int64_t i, P = c->n_prot;
+	memset(c->max_ori, 0, P * sizeof(int32_t));
+	memset(c->sums, 0, 6 * P * sizeof(int64_t));
+	for (i = 0; i < c->n_hit; ++i) {
+		int32_t p = c->pid[i];
+		if (c->score_ori[i] > c->max_ori[p]) c->max_ori[p] = c->score_ori[i];
+		if (c->rank[i] == 0 && !is_flt(c, i)) {
+			int w = c->n_exon_of[i] == 1 ? 0 : 1;
+			c->sums[0*P + p] += c->score_adj[i];
+			c->sums[1*P + p] += 1;
+			c->sums[(2 + w)*P + p] += 1;
+			c->sums[(4 + w)*P + p] += c->score_ori[i];
+		}
+	}
+	*max_ori = c->max_ori, *sums = c->sums;
+	return PGA_OK;
+}
+
+int pgo_post_apply(pga_ctx_t *c, const uint8_t *prot_rep, const uint8_t *prot_pj, int64_t *n_pseudo)
+{
+	int64_t i, n = 0;
+	for (i = 0; i < c->n_hit; ++i) {
+		int32_t p = c->pid[i];
+		if (c->score_dom[i] > c->max_ori[p]) c->score_dom[i] = c->max_ori[p]; /* hit.c:243-244 */
+		if (prot_rep[p]) c->flags[i] |= PGA_F_REP; else c->flags[i] &= ~PGA_F_REP; /* hit.c:202,222-223 */
+		if (!is_flt(c, i) && !(c->flags[i] & PGA_F_PSEUDO) && c->n_exon_of[i] == 1 && prot_pj[p]) /* hit.c:175-182 */
+			c->flags[i] |= PGA_F_PSEUDO, ++n;
+	}
+	if (n_pseudo) *n_pseudo = n;
+	return PGA_OK;
+}
+
+int pgo_shadow(pga_ctx_t *c, int32_t cal_dom_sc, int32_t *stats)
+{
+	int32_t j;
+	for (j = 0; j < c->n_genome; ++j) {
+		int32_t tot, ns = shadow_genome(c, j, cal_dom_sc, &tot);
+		if (stats) stats[2*j] = tot, stats[2*j+1] = ns;
+	}
+	return PGA_OK;
+}
+
+int pgo_set_filter(pga_ctx_t *c, int32_t which)
+{
+	int64_t i;
+	for (i = 0; i < c->n_hit; ++i) {
+		uint32_t f = c->flags[i];
+		int hit = which == PGA_FLT_PSEUDO ? (f & PGA_F_PSEUDO) != 0
+		        : which == PGA_FLT_VTX0 ? (f & PGA_F_VTX) == 0
+		        : which == PGA_FLT_WEAK2 ? ((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT) == 2
+		        : which == PGA_FLT_SHADOW ? (f & PGA_F_SHADOW) != 0 : 0;
+		if (hit) c->flags[i] |= PGA_F_FLT;
+	}
+	return PGA_OK;
+}
+
+/* per-genome part of pg_gen_vtx, vertex.c:21-51 */
+int pgo_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **triples, int64_t *n_triples)
+{
+	int32_t j, Q = c->n_gene;
+	uint32_t *aux = MALLOC(uint32_t, Q);
+	int8_t *flag = MALLOC(int8_t, Q);
+	int64_t i;
+	memset(c->vtx_cnt, 0, 2 * (size_t)Q * sizeof(int32_t));
+	c->n_triples = 0;
+	for (j = 0; j < c->n_genome; ++j) {
+		int32_t g;
+		for (g = 0; g < Q; ++g) aux[g] = (uint32_t)(Q + 1) << 1;
+		memset(flag, 0, Q);
+		for (i = c->off[j]; i < c->off[j + 1]; ++i) {
+			int32_t gid;
+			if (c->rank[i] != 0 || is_flt(c, i)) continue;
+			gid = c->gid[i];
+			if (c->flags[i] & PGA_F_SHADOW) {
+				if (c->pid_dom[i] < 0) { free(aux); free(flag); return PGA_ERR_INVARIANT; } /* vertex.c:38 */
+				flag[gid] |= 2;
+				if (aux[gid] == (uint32_t)(Q + 1) << 1) aux[gid] = (uint32_t)c->prot_gid[c->pid_dom[i]] << 1;
+			} else {
+				flag[gid] |= 1;
+				aux[gid] = (uint32_t)Q << 1;
+			}
+		}
+		for (g = 0; g < Q; ++g) {
+			if (flag[g] & 1) c->vtx_cnt[g]++;
+			else if (flag[g] & 2) {
+				uint32_t D = aux[g] >> 1;
+				c->vtx_cnt[Q + g]++;
+				if (aux[D] >> 1 == (uint32_t)Q) { /* only entries the greedy can observe */
+					if (c->n_triples == c->m_triples) {
+						c->m_triples = c->m_triples ? c->m_triples * 2 : 1024;
+						c->triples = (uint64_t*)realloc(c->triples, c->m_triples * sizeof(uint64_t));
+					}
+					c->triples[c->n_triples++] = (uint64_t)c->genome_global[j] << 40 | (uint64_t)g << 20 | D;
+				}
+			}
+		}
+	}
+	free(aux); free(flag);
+	*cnt = c->vtx_cnt, *triples = c->triples, *n_triples = c->n_triples;
+	return PGA_OK;
+}
+
+/* pg_graph_flag_vtx, graph.c:61-69 */
+int pgo_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg)
+{
+	int64_t i;
+	memcpy(c->g2s, g2s, c->n_gene * sizeof(int32_t));
+	c->n_seg = n_seg;
+	for (i = 0; i < c->n_hit; ++i) {
+		if (g2s[c->gid[i]] >= 0) c->flags[i] |= PGA_F_VTX;
+		else c->flags[i] &= ~PGA_F_VTX;
+	}
+	return PGA_OK;
+}
+
+typedef struct { uint64_t x; int32_t n, dist, s1, s2; } tmparc_t;
+
+static int tmparc_cmp(const void *a, const void *b)
+{
+	uint64_t x = ((const tmparc_t*)a)->x, y = ((const tmparc_t*)b)->x;
+	return x < y ? -1 : x > y;
+}
+
+/* pg_get_score, graph.c:82-85 */
+static inline int32_t get_score(const pga_ctx_t *c, int64_t i, int ori)
+{
+	return ori || c->score_ori[i] > c->score_dom[i] || c->pid_dom0[i] < 0 || c->g2s[c->prot_gid[c->pid_dom0[i]]] >= 0
+		? c->score_ori[i] : c->score_dom[i];
+}
+
+/* pg_gen_arc, graph.c:87-177, over the local genomes, without the final roundings of 170-172 */
+int pgo_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int64_t *n_arcs_out)
+{
+	int32_t j, S = c->n_seg, *cnt;
+	int64_t n_arc = 0, m_arc = 0, n1, m1 = 0, i, i0, k;
+	tmparc_t *arc = 0, *arc1 = 0;
+	free(c->seg_cnt);
+	c->seg_cnt = CALLOC(int32_t, 2 * (int64_t)S);
+	cnt = MALLOC(int32_t, S);
+	for (j = 0; j < c->n_genome; ++j) {
+		uint32_t w, v = (uint32_t)-1;
+		int32_t vpos = -1, vcid = -1, si = -1;
+		shadow_genome(c, j, 0, 0); /* graph.c:102 */
+		n1 = 0;
+		memset(cnt, 0, S * sizeof(int32_t));
+		for (k = c->off[j]; k < c->off[j + 1]; ++k) { /* cm order, graph.c:103-122 */
+			int64_t a = c->yo[k];
+			int32_t sid, sc;
+			if (c->flags[a] & (PGA_F_FLT | PGA_F_SHADOW)) continue;
+			sid = c->g2s[c->gid[a]];
+			if (sid < 0) { free(cnt); free(arc); free(arc1); return PGA_ERR_INVARIANT; } /* graph.c:111 */
+			w = (uint32_t)sid << 1 | (c->flags[a] & PGA_F_REV ? 1 : 0);
+			++cnt[sid];
+			if (c->cid[a] != vcid) v = (uint32_t)-1, vpos = -1;
+			sc = get_score(c, a, use_ori);
+			if (v != (uint32_t)-1) {
+				if (n1 + 2 > m1) { m1 = m1 ? m1 * 2 : 1024; arc1 = (tmparc_t*)realloc(arc1, m1 * sizeof(tmparc_t)); }
+				arc1[n1].x = (uint64_t)v << 32 | w, arc1[n1].dist = c->cm[a] - vpos, arc1[n1].s1 = si, arc1[n1].s2 = sc, arc1[n1].n = 0, ++n1;
+				arc1[n1].x = (uint64_t)(w^1) << 32 | (v^1), arc1[n1].dist = c->cm[a] - vpos, arc1[n1].s1 = sc, arc1[n1].s2 = si, arc1[n1].n = 0, ++n1;
+			}
+			v = w, vpos = c->cm[a], vcid = c->cid[a], si = sc;
+		}
+		for (i = 0; i < S; ++i) /* graph.c:125-126 */
+			c->seg_cnt[i] += cnt[i] > 0, c->seg_cnt[S + i] += cnt[i];
+		qsort(arc1, (size_t)n1, sizeof(tmparc_t), tmparc_cmp);
+		for (i = 1, i0 = 0; i <= n1; ++i) { /* per-genome collapse, graph.c:128-145 */
+			if (i == n1 || arc1[i0].x != arc1[i].x) {
+				int32_t max_s1 = 0, max_s2 = 0;
+				uint64_t dist = 0;
+				for (k = i0; k < i; ++k) {
+					dist += arc1[k].dist;
+					max_s1 = max_s1 > arc1[k].s1 ? max_s1 : arc1[k].s1;
+					max_s2 = max_s2 > arc1[k].s2 ? max_s2 : arc1[k].s2;
+				}
+				if (n_arc == m_arc) { m_arc = m_arc ? m_arc * 2 : 4096; arc = (tmparc_t*)realloc(arc, m_arc * sizeof(tmparc_t)); }
+				arc[n_arc].x = arc1[i0].x, arc[n_arc].n = (int32_t)(i - i0);
+				arc[n_arc].dist = (int32_t)((double)dist / (i - i0) + .499);
+				arc[n_arc].s1 = max_s1, arc[n_arc].s2 = max_s2, ++n_arc;
+				i0 = i;
+			}
+		}
+	}
+	free(arc1); free(cnt);
+	qsort(arc, (size_t)n_arc, sizeof(tmparc_t), tmparc_cmp); /* graph.c:151 */
+	c->n_arcs = 0;
+	for (i0 = 0, i = 1; i <= n_arc; ++i) { /* integer part of graph.c:153-169 */
+		if (i == n_arc || arc[i].x != arc[i0].x) {
+			pga_arc_part_t *p;
+			if (c->n_arcs == c->m_arcs) { c->m_arcs = c->m_arcs ? c->m_arcs * 2 : 4096; c->arcs = (pga_arc_part_t*)realloc(c->arcs, c->m_arcs * sizeof(pga_arc_part_t)); }
+			p = &c->arcs[c->n_arcs++];
+			memset(p, 0, sizeof(*p));
+			p->x = arc[i0].x, p->n_genome = (int32_t)(i - i0);
+			for (k = i0; k < i; ++k) {
+				p->tot_cnt += arc[k].n;
+				p->sum_dist += (uint64_t)arc[k].dist * arc[k].n;
+				p->sum_s1 += arc[k].s1, p->sum_s2 += arc[k].s2;
+			}
+			i0 = i;
+		}
+	}
+	free(arc);
+	*seg_cnt_out = c->seg_cnt, *arcs_out = c->arcs, *n_arcs_out = c->n_arcs;
+	return PGA_OK;
+}
+
+/* pg_gen_rep_pos, branch.c:6-29 */
+int pgo_rep_pos(pga_ctx_t *c)
+{
+	int64_t Q = c->n_gene, i, n = Q * c->n_genome;
+	int32_t j;
+	if (c->rp_x == 0) c->rp_x = MALLOC(int64_t, n), c->rp_y = MALLOC(int32_t, n);
+	for (i = 0; i < n; ++i) c->rp_x[i] = -1, c->rp_y[i] = 0;
+	for (j = 0; j < c->n_genome; ++j) {
+		int32_t r = 0;
+		for (i = c->off[j]; i < c->off[j + 1]; ++i) {
+			if (c->flags[i] & (PGA_F_FLT | PGA_F_SHADOW)) continue;
+			if (i > c->off[j]) { /* hazard H2b bookkeeping: previous walkable hit with the same (cid, cs) */
+				int64_t p = i - 1;
+				while (p >= c->off[j] && (c->flags[p] & (PGA_F_FLT | PGA_F_SHADOW))) --p;
+				if (p >= c->off[j] && c->cid[p] == c->cid[i] && c->cs[p] == c->cs[i]) c->hz.h2_cs_tie++;
+			}
+			c->rp_x[j * Q + c->gid[i]] = (int64_t)c->cid[i] << 32 | r;
+			c->rp_y[j * Q + c->gid[i]] = c->cm[i];
+			++r;
+		}
+	}
+	return PGA_OK;
+}
+
+/* pg_n_local, branch.c:31-46, summed over the local genomes */
+int pgo_n_local(pga_ctx_t *c, const int32_t *pairs, int64_t n, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt)
+{
+	int64_t Q = c->n_gene, k;
+	int32_t j;
+	if (c->rp_x == 0) return PGA_ERR_ARG;
+	free(c->nl_cnt);
+	c->nl_cnt = CALLOC(int32_t, n);
+	for (k = 0; k < n; ++k) {
+		int32_t g1 = pairs[2*k], g2 = pairs[2*k+1], n_local = 0;
+		for (j = 0; j < c->n_genome; ++j) {
+			int64_t x1 = c->rp_x[j * Q + g1], x2 = c->rp_x[j * Q + g2], d;
+			int32_t cc;
+			if (x1 == -1 || x2 == -1) continue;
+			if (!frag_mode && x1 >> 32 != x2 >> 32) continue;
+			d = (int64_t)c->rp_y[j * Q + g1] - (int64_t)c->rp_y[j * Q + g2];
+			cc = (int32_t)x1 - (int32_t)x2;
+			if ((d >= -local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count)) ++n_local;
+		}
+		c->nl_cnt[k] = n_local;
+	}
+	*cnt = c->nl_cnt;
+	return PGA_OK;
+}
+
+static int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) /* pg_get_arc, pgpriv.h:99-107 */
+{
+	int64_t lo = 0, hi = n;
+	while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ax[mid] < x) lo = mid + 1; else hi = mid; }
+	return lo < n && ax[lo] == x ? aw[lo] : 0;
+}
+
+/* pg_mark_branch_flt_hit, branch.c:108-145 */
+int pgo_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_w, int64_t n_arc, int64_t *n_marked)
+{
+	int32_t j;
+	int64_t k, n = 0;
+	for (j = 0; j < c->n_genome; ++j) {
+		uint32_t v = (uint32_t)-1, w;
+		int64_t vi = -1;
+		for (k = c->off[j]; k < c->off[j + 1]; ++k) {
+			int64_t a = c->yo[k];
+			int32_t sid, e, cur;
+			if (c->flags[a] & (PGA_F_FLT | PGA_F_SHADOW)) continue;
+			sid = c->g2s[c->gid[a]];
+			if (vi >= 0 && c->cid[a] != c->cid[vi]) v = (uint32_t)-1;
+			if (vi >= 0 && c->cid[a] == c->cid[vi] && c->cm[a] == c->cm[vi]) c->hz.h2_cm_tie++;
+			w = (uint32_t)sid << 1 | (c->flags[a] & PGA_F_REV ? 1 : 0);
+			if (v != (uint32_t)-1) {
+				e = arc_weak(arc_x, arc_w, n_arc, (uint64_t)v << 32 | w);
+				cur = weak_of(c, vi);
+				if (e > cur) c->flags[vi] = (c->flags[vi] & ~PGA_F_WEAK_MASK) | (uint32_t)e << PGA_F_WEAK_SHIFT;
+				e = arc_weak(arc_x, arc_w, n_arc, (uint64_t)(w^1) << 32 | (v^1));
+				cur = weak_of(c, a);
+				if (e > cur) c->flags[a] = (c->flags[a] & ~PGA_F_WEAK_MASK) | (uint32_t)e << PGA_F_WEAK_SHIFT;
+			}
+			v = w, vi = a;
+		}
+		for (k = c->off[j]; k < c->off[j + 1]; ++k)
+			if (c->flags[k] & PGA_F_WEAK_MASK) ++n;
+	}
+	if (n_marked) *n_marked = n;
+	return PGA_OK;
+}
+
+int pgo_fetch(pga_ctx_t *c, void *dst, const void *src, size_t nbytes)
+{
+	(void)c;
+	memcpy(dst, src, nbytes);
+	return PGA_OK;
+}
+
+int pgo_put(pga_ctx_t *c, void *dst, const void *src, size_t nbytes) { (void)c; memcpy(dst, src, nbytes); return PGA_OK; }
+int pgo_copy(pga_ctx_t *c, void *dst, const void *src, size_t nbytes) { (void)c; memmove(dst, src, nbytes); return PGA_OK; }
+int pgo_scratch(pga_ctx_t *c, size_t nbytes, void **ptr)
+{
+	if (nbytes > c->m_scratch) { free(c->scratch); c->scratch = malloc(nbytes); c->m_scratch = nbytes; }
+	*ptr = c->scratch;
+	return c->scratch ? PGA_OK : PGA_ERR_NOMEM;
+}
+
+int pgo_download(pga_ctx_t *c, const pga_hit_state_t *o)
+{
+	int32_t j;
+	int64_t i, k;
+	for (j = 0; j < c->n_genome; ++j) {
+		int64_t st = c->off[j];
+		for (i = st; i < c->off[j + 1]; ++i) {
+			int64_t f = st + c->fidx[i];
+			if (o->flags) o->flags[f] = c->flags[i];
+			if (o->rank) o->rank[f] = c->rank[i];
+			if (o->score_dom) o->score_dom[f] = c->score_dom[i];
+			if (o->pid_dom) o->pid_dom[f] = c->pid_dom[i];
+			if (o->pid_dom0) o->pid_dom0[f] = c->pid_dom0[i];
+			if (o->pos_x) o->pos_x[f] = (int32_t)(i - st);
+		}
+		if (o->pos_y)
+			for (k = st; k < c->off[j + 1]; ++k)
+				o->pos_y[st + c->fidx[c->yo[k]]] = (int32_t)(k - st);
+	}
+	return PGA_OK;
+}
+
+int pgo_hazards(pga_ctx_t *c, pga_hazard_t *out) { *out = c->hz; return PGA_OK; }
+
+const pga_backend_t *pgo_backend(void)
+{
+	static const pga_backend_t b = {
+		"oracle", pgo_create, pgo_destroy, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
+		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_rep_pos, pgo_n_local, pgo_mark_hits, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
+		pgo_hazards, pgo_is_device, pgo_strerror
+	};
+	return &b;
+}

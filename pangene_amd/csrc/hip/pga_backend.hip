@@ -1,0 +1,1307 @@
+// pga_backend.hip -- the MI355X (gfx950) implementation of the thin device ABI in
+// include/pangene_hip.h.  All per-hit work of the pangene graph-construction path runs here as
+// hand-written HIP kernels over a structure-of-arrays shard that stays resident in HBM for the whole
+// run (upload once, 19 interval-dominance sweeps, 17 arc rounds, 15 branch rounds, one download).
+//
+// Data layout (DESIGN.md "HBM layout"): hits are physically stored in X order = (genome, contig, cs,
+// file index), one 32-bit array per field, so a wave reads 256 B contiguous per field and the sweep's
+// neighbours are adjacent in memory.  `seg` is the dense (genome, contig) id, `pm` the per-contig
+// running maximum of ce (bounds the look-back of the sweep), `yperm` the cm order as a permutation of
+// X positions.  Keys never change, so the two sorts the reference repeats 67 times per genome
+// (hit.c:29-64) are done exactly once.
+//
+// Everything is integer work except three IEEE-double expressions (overlap.c:134,170) -- compile with
+// -ffp-contract=off.  No MFMA: this path is HBM/latency bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include "pangene_hip.h"
+#include "dev_prims.hpp"
+
+using namespace pgd;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+	fprintf(stderr, "[E::pga] %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return PGA_ERR_NO_DEVICE; } } while (0)
+
+#define F_HEAD 0x80000000u   // static: first hit of its genome in X order (index-0 quirk, overlap.c:108)
+#define F_PUBLIC 0x7ffu
+
+static inline unsigned nblk(int64_t n, int per = BLOCK) { return (unsigned)((n + per - 1) / per); }
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct DevPool { // persistent, grow-only device temporaries keyed by slot
+	std::vector<void *> p; std::vector<size_t> cap;
+	void *get(int slot, size_t bytes)
+	{
+		if ((int)p.size() <= slot) p.resize(slot + 1, nullptr), cap.resize(slot + 1, 0);
+		if (bytes == 0) bytes = 16;
+		if (cap[slot] < bytes) {
+			if (p[slot]) (void)hipFree(p[slot]);
+			size_t want = bytes + bytes / 4 + 256;
+			if (hipMalloc(&p[slot], want) != hipSuccess) { p[slot] = nullptr; cap[slot] = 0; return nullptr; }
+			cap[slot] = want;
+		}
+		return p[slot];
+	}
+	void release() { for (void *q : p) if (q) (void)hipFree(q); p.clear(); cap.clear(); }
+};
+
+enum { // pool slots
+	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
+	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
+	S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
+	S_COUNT
+};
+
+struct TimedLaunch { hipEvent_t a, b; int which; int64_t units; };
+
+struct pga_ctx {
+	hipStream_t st = nullptr; bool own_stream = false;
+	int32_t n_genome = 0, n_genome_global = 0, P = 0, Q = 0, n_seg_ctg = 0;
+	int32_t N = 0, E = 0;
+	pga_params_t par;
+	std::vector<int32_t> h_goff, h_ggl;
+	// static per hit (X order)
+	int32_t *fidx = 0, *gnm = 0, *seg = 0, *pid = 0, *gid = 0, *cs = 0, *ce = 0, *cm = 0, *cds = 0, *nex = 0, *offx = 0, *sori = 0, *sadj = 0, *pm = 0;
+	uint64_t *sc64 = 0;
+	// dynamic per hit
+	int32_t *rank = 0, *sdom = 0, *pdom = 0, *pdom0 = 0; uint32_t *flags = 0;
+	int32_t *yperm = 0, *goff = 0, *ggl = 0;
+	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
+	// exchange vectors
+	int32_t *max_ori = 0; int64_t *sums = 0; int32_t *vtx_cnt = 0; int32_t *g2s = 0; int32_t n_seg = 0;
+	int64_t *dcnt = 0;      // device counters: [0] triples [1] arcs-temp [2] misc [3] invariant flag, [4..7] hazards
+	int64_t *h_cnt = 0;     // pinned mirror
+	DevPool pool;
+	std::vector<TimedLaunch> timed;
+	std::vector<void *> owned;
+};
+
+template <class T> static int dalloc(pga_ctx *c, T **p, size_t n)
+{
+	void *q = nullptr;
+	if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return PGA_ERR_NOMEM;
+	*p = (T *)q;
+	c->owned.push_back(q);
+	return 0;
+}
+
+extern "C" int pga_is_device(void) { return 1; }
+
+extern "C" const char *pga_strerror(int code)
+{
+	switch (code) {
+	case PGA_OK: return "ok";
+	case PGA_ERR_NO_DEVICE: return "no usable HIP device / HIP runtime error (this library has no CPU fallback)";
+	case PGA_ERR_RANGE: return "value out of range for the device layout";
+	case PGA_ERR_ARG: return "bad argument";
+	case PGA_ERR_NOMEM: return "out of device memory";
+	case PGA_ERR_INVARIANT: return "reference invariant violated";
+	}
+	return "unknown";
+}
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash_u32(uint32_t key) // pg_hash_uint32, pgpriv.h:88-97
+{
+	key += ~(key << 15);
+	key ^=  (key >> 10);
+	key +=  (key << 3);
+	key ^=  (key >> 6);
+	key += ~(key << 11);
+	key ^=  (key >> 16);
+	return key;
+}
+
+__global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+
+__device__ __forceinline__ int genome_of(const int32_t *goff, int n_genome, int i) // last g with goff[g] <= i
+{
+	int lo = 0, hi = n_genome;
+	while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (goff[mid] <= i) lo = mid; else hi = mid; }
+	return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// create: derive per-hit constants in file order, sort into X order, gather, pm, Y order
+// ------------------------------------------------------------------------------------------------
+struct FileHits { const int32_t *pid, *cid, *rank, *sori, *sadj, *nex, *offx, *cs, *ce, *cm; const uint8_t *rev; };
+
+__global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int32_t *goff, int n_genome, const int32_t *ctg_base,
+                                                     const int2 *exon, const int32_t *prot_gid, const uint8_t *gene_pref,
+                                                     int cs_bits, int32_t *gnm_f, int32_t *seg_f, int32_t *gid_f, int32_t *cds_f,
+                                                     uint64_t *sc64_f, uint64_t *key, uint32_t *val)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	int g = genome_of(goff, n_genome, i);
+	// skip empty genomes that share the same offset: genome_of returns the LAST g with goff[g] <= i, which is the owner
+	int sg = ctg_base[g] + f.cid[i];
+	int gid = prot_gid[f.pid[i]];
+	int len = 0, ne = f.nex[i], ox = f.offx[i];
+	for (int e = 0; e < ne; ++e) { int2 x = exon[ox + e]; len += x.y - x.x; } // pg_cds_len, overlap.c:45-51
+	gnm_f[i] = g, seg_f[i] = sg, gid_f[i] = gid, cds_f[i] = len;
+	sc64_f[i] = (uint64_t)(int64_t)f.sadj[i] << 33 | (uint64_t)gene_pref[gid] << 32 | hash_u32((uint32_t)f.pid[i]); // overlap.c:137
+	key[i] = (uint64_t)sg << cs_bits | (uint32_t)f.cs[i];
+	val[i] = (uint32_t)i;
+}
+
+struct HitArrays {
+	int32_t *fidx, *gnm, *seg, *pid, *gid, *cs, *ce, *cm, *cds, *nex, *offx, *sori, *sadj, *rank, *sdom, *pdom, *pdom0;
+	uint64_t *sc64; uint32_t *flags;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_gather(FileHits f, const int32_t *gnm_f, const int32_t *seg_f, const int32_t *gid_f, const int32_t *cds_f,
+                                                    const uint64_t *sc64_f, const uint32_t *perm, int n, const int32_t *goff, HitArrays o)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int s = (int)perm[h];
+	int g = gnm_f[s];
+	o.fidx[h] = s - goff[g], o.gnm[h] = g, o.seg[h] = seg_f[s], o.pid[h] = f.pid[s], o.gid[h] = gid_f[s];
+	o.cs[h] = f.cs[s], o.ce[h] = f.ce[s], o.cm[h] = f.cm[s], o.cds[h] = cds_f[s], o.nex[h] = f.nex[s], o.offx[h] = f.offx[s];
+	o.sori[h] = f.sori[s], o.sadj[h] = f.sadj[s], o.rank[h] = f.rank[s], o.sc64[h] = sc64_f[s];
+	o.sdom[h] = 0, o.pdom[h] = -1, o.pdom0[h] = 0; // read.c:133-134
+	o.flags[h] = (f.rev[s] ? PGA_F_REV : 0u) | (h == goff[g] ? F_HEAD : 0u);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_ykey(const int32_t *seg, const int32_t *cm, int n, int cm_bits, uint64_t *key, uint32_t *val)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	key[h] = (uint64_t)seg[h] << cm_bits | (uint32_t)cm[h];
+	val[h] = (uint32_t)h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pg_flag_pseudo (hit.c:66-105) with a (genome, protein) table instead of a sort by pid<<32|rank
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_pseudo1(const int32_t *gnm, const int32_t *pid, const int32_t *nex, int n, int P, int32_t *tmax, int32_t *tmin)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int64_t t = (int64_t)gnm[h] * P + pid[h];
+	atomicMax(&tmax[t], nex[h]);
+	atomicMin(&tmin[t], nex[h]);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pseudo2(const int32_t *gnm, const int32_t *pid, const int32_t *nex, const int32_t *rank, uint32_t *flags,
+                                                     int n, int P, const int32_t *tmax, const int32_t *tmin, int32_t *tr1, int32_t *stats)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int64_t t = (int64_t)gnm[h] * P + pid[h];
+	int mx = tmax[t], mn = tmin[t], ne = nex[h];
+	if (!(mx > 1 && (mn == 1 || mn * 2 <= mx))) return; // hit.c:84
+	if (ne == 1 || ne * 2 <= mx) {
+		flags[h] |= PGA_F_PSEUDO | PGA_F_FLT; // hit.c:89 + PG_SET_FILTER(pseudo), read.c:246
+		atomicAdd(&stats[gnm[h] * 4 + 0], 1);
+	} else atomicMin(&tr1[t], rank[h]);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pseudo3(const int32_t *gnm, const int32_t *pid, int32_t *rank, int n, int P,
+                                                     const int32_t *tmax, const int32_t *tmin, const int32_t *tr1)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int64_t t = (int64_t)gnm[h] * P + pid[h];
+	int mx = tmax[t], mn = tmin[t], r1 = tr1[t];
+	if (!(mx > 1 && (mn == 1 || mn * 2 <= mx)) || r1 == INT32_MAX || r1 == 0) return;
+	int r = rank[h];
+	if (r < r1) rank[h] = r + 1; // hit.c:95-97
+	else if (r == r1) rank[h] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the interval-dominance sweep: pg_shadow (overlap.c:101-178) and pg_flt_ov_isoform (58-93)
+// ------------------------------------------------------------------------------------------------
+struct SweepView {
+	const int32_t *seg, *cs, *ce, *pm, *gid, *rank, *cds, *nex, *offx, *pid, *sori;
+	const uint64_t *sc64; const int2 *exon;
+	uint32_t *flags; int32_t *pdom, *sdom;
+	int n; double min_ov; int check_strand;
+	int64_t *hz;
+};
+
+// CDS intersection of hit a (exons ea[na], start ca) and hit b: pg_hit_overlap, overlap.c:6-42
+__device__ __forceinline__ int cds_inter(const int2 *__restrict__ ex, int oa, int na, int ca, int ea_end, int ob, int nb, int cb, int eb_end)
+{
+	if (!(ca < eb_end && ea_end > cb)) return 0;
+	if (na == 1 && nb == 1) { // single-exon x single-exon: plain interval intersection
+		int s = ca > cb ? ca : cb, e = ea_end < eb_end ? ea_end : eb_end;
+		return e > s ? e - s : 0;
+	}
+	int ia = 0, ib = 0, inter = 0;
+	int2 xa = ex[oa], xb = ex[ob];
+	while (true) {
+		int s0 = ca + xa.x, e0 = ca + xa.y, s1 = cb + xb.x, e1 = cb + xb.y;
+		bool adv_a;
+		if (s0 < s1) {
+			if (e0 < e1) { int o = e0 - s1; inter += o > 0 ? o : 0; adv_a = true; }
+			else { inter += e1 - s1; adv_a = false; }
+		} else {
+			if (e1 < e0) { int o = e1 - s0; inter += o > 0 ? o : 0; adv_a = false; }
+			else { inter += e0 - s0; adv_a = true; }
+		}
+		if (adv_a) { if (++ia >= na) break; xa = ex[oa + ia]; }
+		else { if (++ib >= nb) break; xb = ex[ob + ib]; }
+	}
+	return inter;
+}
+
+// MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_sweep(SweepView v)
+{
+	const int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= v.n) return;
+	const uint32_t fl = v.flags[h];
+	if (fl & PGA_F_FLT) return; // filtered hits keep stale shadow/pid_dom (overlap.c:112)
+	const int sg = v.seg[h], cs_h = v.cs[h], ce_h = v.ce[h], g_h = v.gid[h], rk_h = v.rank[h], ln_h = v.cds[h];
+	const int ne_h = v.nex[h], ox_h = v.offx[h], wk_h = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
+	const uint64_t s_h = v.sc64[h];
+	bool lose = false;
+	uint64_t best = 0;
+	int best_j = -1, best_ov = 0;
+	// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a
+	// contig, so the scan stops at the first j whose pm is <= cs_h.
+	for (int j = h - 1; j >= 0; --j) {
+		if (v.seg[j] != sg || v.pm[j] <= cs_h) break;
+		const int ce_j = v.ce[j];
+		if (ce_j <= cs_h) continue;
+		const uint32_t fj = v.flags[j];
+		if (fj & PGA_F_FLT) continue;
+		if (v.check_strand && ((fj ^ fl) & PGA_F_REV)) continue;
+		const int g_j = v.gid[j];
+		if (MODE == 2 && g_j != g_h) continue;
+		const int x = cds_inter(v.exon, v.offx[j], v.nex[j], v.cs[j], ce_j, ox_h, ne_h, cs_h, ce_h);
+		if (x == 0) continue;
+		const uint64_t s_j = v.sc64[j];
+		bool h_loses; // h plays "i" of the reference (the later hit)
+		if (MODE == 2) h_loses = s_h < s_j || (s_h == s_j && rk_h > v.rank[j]);
+		else {
+			const int ln_j = v.cds[j];
+			const double cov = (double)x / (ln_h < ln_j ? ln_h : ln_j);
+			if (g_h != g_j && cov < v.min_ov) continue;
+			const int wk_j = (int)((fj & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
+			if (g_h == g_j || wk_h == wk_j) h_loses = s_h < s_j || (s_h == s_j && rk_h > v.rank[j]);
+			else h_loses = wk_h > wk_j;
+		}
+		if (h_loses) {
+			lose = true;
+			if (MODE != 2 && s_j > 0 && s_j >= best) { // descending j: on equal score the smaller index wins (overlap.c:150)
+				if (s_j == best) atomicAdd((unsigned long long *)&v.hz[3], 1ull);
+				best = s_j, best_j = j, best_ov = x;
+			}
+		}
+	}
+	// partners after h: every i with cs_i < ce_h
+	for (int i = h + 1; i < v.n; ++i) {
+		if (v.seg[i] != sg) break;
+		const int cs_i = v.cs[i];
+		if (cs_i >= ce_h) break;
+		const uint32_t fi = v.flags[i];
+		if (fi & PGA_F_FLT) continue;
+		if (v.check_strand && ((fi ^ fl) & PGA_F_REV)) continue;
+		const int g_i = v.gid[i];
+		if (MODE == 2 && g_i != g_h) continue;
+		const int x = cds_inter(v.exon, ox_h, ne_h, cs_h, ce_h, v.offx[i], v.nex[i], cs_i, v.ce[i]);
+		if (x == 0) continue;
+		const uint64_t s_i = v.sc64[i];
+		bool i_loses; // h plays "j" (the earlier hit)
+		if (MODE == 2) i_loses = s_i < s_h || (s_i == s_h && v.rank[i] > rk_h);
+		else {
+			const int ln_i = v.cds[i];
+			const double cov = (double)x / (ln_i < ln_h ? ln_i : ln_h);
+			if (g_h != g_i && cov < v.min_ov) continue;
+			const int wk_i = (int)((fi & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
+			if (g_h == g_i || wk_h == wk_i) i_loses = s_i < s_h || (s_i == s_h && v.rank[i] > rk_h);
+			else i_loses = wk_i > wk_h;
+		}
+		if (!i_loses) {
+			lose = true;
+			if (MODE != 2 && s_i > best) best = s_i, best_j = i, best_ov = x;
+			else if (MODE != 2 && s_i == best && s_i > 0) atomicAdd((unsigned long long *)&v.hz[3], 1ull);
+		}
+	}
+	if (MODE == 2) {
+		if (lose) v.flags[h] = fl | PGA_F_ISO_OV;
+		return;
+	}
+	// epilogue, overlap.c:157-175.  The first hit of a genome is never reset (loop starts at 1, overlap.c:108).
+	uint32_t nf = (fl & F_HEAD) ? fl : (fl & ~PGA_F_SHADOW);
+	if (lose) nf |= PGA_F_SHADOW;
+	if (nf != fl) v.flags[h] = nf;
+	int pd = -1;
+	if (best > 0) pd = v.pid[best_j];
+	v.pdom[h] = pd;
+	if (MODE == 1) {
+		int sd = -1;
+		if (best > 0) {
+			const int ln_j = v.cds[best_j];
+			sd = (int32_t)(v.sori[h] * (1.0 - (double)best_ov / ln_h) + v.sori[best_j] * ((double)best_ov / ln_j) + .499); // overlap.c:170
+		}
+		v.sdom[h] = sd;
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void k_count_shadow(const uint32_t *flags, const int32_t *gnm, int n, int32_t *stats)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h];
+	if (f & PGA_F_FLT) return;
+	atomicAdd(&stats[gnm[h] * 2], 1);
+	if (f & PGA_F_SHADOW) atomicAdd(&stats[gnm[h] * 2 + 1], 1);
+}
+
+// read.c:249-253
+__global__ __launch_bounds__(BLOCK) void k_ingest_reset(uint32_t *flags, int32_t *pdom, int32_t *pdom0, int n)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	pdom0[h] = pdom[h];
+	pdom[h] = -1;
+	flags[h] &= ~PGA_F_SHADOW;
+}
+
+// tail of pg_flt_ov_isoform (overlap.c:89-91) + first loop of pg_flt_chain_shadow (hit.c:136-138)
+__global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int32_t *gnm, const int32_t *pid, int n, int P, int32_t *tiso, int32_t *stats)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h];
+	if (f & PGA_F_ISO_OV) {
+		flags[h] = f | PGA_F_FLT;
+		atomicAdd(&stats[gnm[h] * 4 + 1], 1);
+	} else tiso[(int64_t)gnm[h] * P + pid[h]] = 0;
+}
+
+// second loop of pg_flt_chain_shadow (hit.c:139-143)
+__global__ __launch_bounds__(BLOCK) void k_chain(uint32_t *flags, const int32_t *gnm, const int32_t *pdom0, int n, int P, const int32_t *tiso, int32_t *stats)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int p0 = pdom0[h];
+	if (p0 >= 0 && tiso[(int64_t)gnm[h] * P + p0]) {
+		flags[h] |= PGA_F_FLT | PGA_F_CHAIN;
+		atomicAdd(&stats[gnm[h] * 4 + 2], 1);
+	}
+}
+
+// pg_flt_subopt_isoform (hit.c:107-128).  best[gene] of one genome = first maximum of score_adj in
+// array order; the (int32 > uint64) comparison of hit.c:116 lets a negative score_adj always win, the
+// last one in array order staying.
+__global__ __launch_bounds__(BLOCK) void k_subopt1(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *sadj,
+                                                     const int32_t *goff, int n, int Q, unsigned long long *tbest)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	if ((flags[h] & PGA_F_FLT) || rank[h] > 0) return;
+	int s = sadj[h], g = gnm[h];
+	uint32_t pos = (uint32_t)(h - goff[g]);
+	unsigned long long k;
+	if (s > 0) k = (unsigned long long)(uint32_t)s << 32 | (0xffffffffu - pos);
+	else if (s < 0) k = 1ull << 63 | pos;
+	else return;
+	atomicMax(&tbest[(int64_t)g * Q + gid[h]], k);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_subopt2(uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *pid, const int32_t *goff, int n, int Q,
+                                                     const unsigned long long *tbest, int32_t *stats)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h];
+	if (f & PGA_F_FLT) return;
+	int g = gnm[h];
+	unsigned long long k = tbest[(int64_t)g * Q + gid[h]];
+	int best_pid = 0; // hit.c:111: calloc'ed best => pid 0 when the gene has no candidate
+	if (k) {
+		uint32_t pos = (k >> 63) ? (uint32_t)k : 0xffffffffu - (uint32_t)k;
+		best_pid = pid[goff[g] + (int)pos];
+	}
+	if (pid[h] != best_pid) {
+		flags[h] = f | PGA_F_FLT | PGA_F_ISO_SUB;
+		atomicAdd(&stats[g * 4 + 3], 1);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage B (hit.c:153-247)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_post_part(const uint32_t *flags, const int32_t *pid, const int32_t *rank, const int32_t *sori, const int32_t *sadj,
+                                                       const int32_t *nex, int n, int P, int32_t *max_ori, unsigned long long *sums)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int p = pid[h];
+	atomicMax(&max_ori[p], sori[h]);
+	if (rank[h] == 0 && !(flags[h] & PGA_F_FLT)) {
+		int w = nex[h] == 1 ? 0 : 1;
+		atomicAdd(&sums[p], (unsigned long long)(long long)sadj[h]);
+		atomicAdd(&sums[(int64_t)P + p], 1ull);
+		atomicAdd(&sums[(int64_t)(2 + w) * P + p], 1ull);
+		atomicAdd(&sums[(int64_t)(4 + w) * P + p], (unsigned long long)(long long)sori[h]);
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void k_post_apply(uint32_t *flags, const int32_t *pid, const int32_t *nex, int32_t *sdom, int n,
+                                                        const int32_t *max_ori, const uint8_t *rep, const uint8_t *pj, int64_t *cnt)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int p = pid[h];
+	int mo = max_ori[p];
+	if (sdom[h] > mo) sdom[h] = mo; // hit.c:243-244
+	uint32_t f = flags[h], nf = rep[p] ? (f | PGA_F_REP) : (f & ~PGA_F_REP);
+	if (!(f & (PGA_F_FLT | PGA_F_PSEUDO)) && nex[h] == 1 && pj[p]) { // hit.c:175-182
+		nf |= PGA_F_PSEUDO;
+		atomicAdd((unsigned long long *)cnt, 1ull);
+	}
+	if (nf != f) flags[h] = nf;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_set_filter(uint32_t *flags, int n, int which) // pgpriv.h:109-116
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h];
+	bool hit = which == PGA_FLT_PSEUDO ? (f & PGA_F_PSEUDO) != 0
+	         : which == PGA_FLT_VTX0 ? (f & PGA_F_VTX) == 0
+	         : which == PGA_FLT_WEAK2 ? ((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT) == 2
+	         : (f & PGA_F_SHADOW) != 0;
+	if (hit && !(f & PGA_F_FLT)) flags[h] = f | PGA_F_FLT;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pg_gen_vtx, per-genome part (vertex.c:28-51)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_vtx1(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *pdom,
+                                                  int n, int Q, int32_t *cnt, uint32_t *dombits, int64_t words_per_genome, int64_t *dcnt)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h];
+	if ((f & PGA_F_FLT) || rank[h] != 0) return;
+	int g = gid[h];
+	if (f & PGA_F_SHADOW) {
+		if (pdom[h] < 0) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // vertex.c:38
+		atomicAdd(&cnt[Q + g], 1);
+	} else {
+		atomicAdd(&cnt[g], 1);
+		uint32_t old = atomicOr(&dombits[(int64_t)gnm[h] * words_per_genome + (g >> 5)], 1u << (g & 31));
+		if (old & (1u << (g & 31))) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // two rank-0 hits of one gene: cannot happen after hit.c:107-128
+	}
+}
+
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(BLOCK) void k_vtx2(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *pdom,
+                                                  const int32_t *prot_gid, const int32_t *ggl, int n, const uint32_t *dombits, int64_t words_per_genome,
+                                                  uint64_t *triples, int64_t *dcnt)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h];
+	if ((f & PGA_F_FLT) || rank[h] != 0 || !(f & PGA_F_SHADOW) || pdom[h] < 0) return;
+	int j = gnm[h], D = prot_gid[pdom[h]];
+	if (!(dombits[(int64_t)j * words_per_genome + (D >> 5)] >> (D & 31) & 1u)) return;
+	unsigned long long slot = atomicAdd((unsigned long long *)&dcnt[0], 1ull);
+	if (!COUNT_ONLY) triples[slot] = (uint64_t)ggl[j] << 40 | (uint64_t)gid[h] << 20 | (uint64_t)D;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32_t *gid, int n, const int32_t *g2s) // graph.c:61-69
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h], nf = g2s[gid[h]] >= 0 ? (f | PGA_F_VTX) : (f & ~PGA_F_VTX);
+	if (nf != f) flags[h] = nf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pg_gen_arc, per-genome part (graph.c:97-146)
+// ------------------------------------------------------------------------------------------------
+// walkable = !flt && !shadow; val[y] = y if the y-th hit in cm order is walkable else -1
+__global__ __launch_bounds__(BLOCK) void k_walk_mark(const uint32_t *flags, const int32_t *yperm, int n, int32_t *val)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y >= n) return;
+	val[y] = (flags[yperm[y]] & (PGA_F_FLT | PGA_F_SHADOW)) ? -1 : y;
+}
+
+struct InWalk { const int32_t *val; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{val[i]}; } };
+struct OutPrev { int32_t *prev; __device__ __forceinline__ void operator()(int64_t i, I32, I32 ex) const { prev[i] = ex.v; } };
+
+// has_arc[y] = 1 if walkable y has a walkable predecessor on the same contig; also per-segment counts
+// (graph.c:113,125-126) and hazard H2a (equal cm of two consecutive walkable hits)
+__global__ __launch_bounds__(BLOCK) void k_arc_flag(const int32_t *val, const int32_t *prev, const int32_t *yperm, const int32_t *seg, const int32_t *gid,
+                                                      const int32_t *gnm, const int32_t *cm, const int32_t *g2s, int n, int S, int32_t *has, int32_t *seg_cnt,
+                                                      uint32_t *seen, int64_t words_per_genome, int64_t *dcnt)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y >= n) return;
+	int out = 0;
+	if (val[y] >= 0) {
+		int a = yperm[y], sid = g2s[gid[a]];
+		if (sid < 0) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // graph.c:111
+		else {
+			atomicAdd(&seg_cnt[S + sid], 1);
+			uint32_t old = atomicOr(&seen[(int64_t)gnm[a] * words_per_genome + (sid >> 5)], 1u << (sid & 31));
+			if (!(old >> (sid & 31) & 1u)) atomicAdd(&seg_cnt[sid], 1);
+		}
+		int p = prev[y];
+		if (p >= 0) {
+			int b = yperm[p];
+			if (seg[b] == seg[a]) {
+				out = 1;
+				if (cm[b] == cm[a]) atomicAdd((unsigned long long *)&dcnt[5], 1ull);
+			}
+		}
+	}
+	has[y] = out;
+}
+
+__device__ __forceinline__ int arc_score(int a, int ori, const int32_t *sori, const int32_t *sdom, const int32_t *pdom0, const int32_t *prot_gid, const int32_t *g2s)
+{ // pg_get_score, graph.c:82-85
+	int so = sori[a], sd = sdom[a], p0 = pdom0[a];
+	return (ori || so > sd || p0 < 0 || g2s[prot_gid[p0]] >= 0) ? so : sd;
+}
+
+struct ArcEmit {
+	const int32_t *has, *slot, *prev, *yperm, *gid, *gnm, *cm, *sori, *sdom, *pdom0, *prot_gid, *g2s; const uint32_t *flags;
+	uint64_t *key; uint32_t *idx; int32_t *dist, *s1, *s2, *gen;
+	int n, ori, vbits;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_arc_emit(ArcEmit e)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y >= e.n || !e.has[y]) return;
+	int a = e.yperm[y], b = e.yperm[e.prev[y]];
+	uint32_t w = (uint32_t)e.g2s[e.gid[a]] << 1 | (e.flags[a] & PGA_F_REV ? 1u : 0u);
+	uint32_t v = (uint32_t)e.g2s[e.gid[b]] << 1 | (e.flags[b] & PGA_F_REV ? 1u : 0u);
+	int sa = arc_score(a, e.ori, e.sori, e.sdom, e.pdom0, e.prot_gid, e.g2s);
+	int sb = arc_score(b, e.ori, e.sori, e.sdom, e.pdom0, e.prot_gid, e.g2s);
+	int d = e.cm[a] - e.cm[b], g = e.gnm[a];
+	int64_t o = (int64_t)e.slot[y] * 2;
+	e.key[o] = (uint64_t)v << e.vbits | w;           e.idx[o] = (uint32_t)o;         // v -> w      (graph.c:117)
+	e.dist[o] = d, e.s1[o] = sb, e.s2[o] = sa, e.gen[o] = g;
+	e.key[o + 1] = (uint64_t)(w ^ 1) << e.vbits | (v ^ 1); e.idx[o + 1] = (uint32_t)(o + 1); // w^1 -> v^1 (graph.c:119)
+	e.dist[o + 1] = d, e.s1[o + 1] = sa, e.s2[o + 1] = sb, e.gen[o + 1] = g;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_arc_gather(const uint32_t *idx, int64_t m, const int32_t *dist, const int32_t *s1, const int32_t *s2, const int32_t *gen,
+                                                        int32_t *odist, int32_t *os1, int32_t *os2, int32_t *ogen)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= m) return;
+	uint32_t s = idx[i];
+	odist[i] = dist[s], os1[i] = s1[s], os2[i] = s2[s], ogen[i] = gen[s];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_arc_head(const uint64_t *key, int64_t m, int32_t *head)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= m) return;
+	head[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+}
+
+// one thread per distinct arc key: walks its run (sorted by key, genome-major inside the key because the
+// sort is stable and arcs are emitted genome by genome), collapses per genome (graph.c:128-145) and sums
+// the per-genome values (integer part of graph.c:153-169)
+__global__ __launch_bounds__(BLOCK) void k_arc_reduce(const uint64_t *key, const int32_t *head, const int32_t *slot, int64_t m, const int32_t *dist,
+                                                        const int32_t *s1, const int32_t *s2, const int32_t *gen, int vbits, pga_arc_part_t *out)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= m || !head[i]) return;
+	const uint64_t k = key[i];
+	pga_arc_part_t r;
+	r.x = (k >> vbits) << 32 | (k & ((1ull << vbits) - 1));
+	r.n_genome = 0, r.tot_cnt = 0, r.sum_dist = 0, r.sum_s1 = 0, r.sum_s2 = 0;
+	int64_t j = i;
+	while (j < m && key[j] == k) {
+		const int g = gen[j];
+		int n = 0, m1 = 0, m2 = 0;
+		uint64_t sd = 0;
+		while (j < m && key[j] == k && gen[j] == g) {
+			sd += (uint64_t)(int64_t)dist[j];
+			m1 = m1 > s1[j] ? m1 : s1[j];
+			m2 = m2 > s2[j] ? m2 : s2[j];
+			++n, ++j;
+		}
+		const int dg = (int32_t)((double)sd / n + .499); // graph.c:141
+		r.n_genome += 1, r.tot_cnt += n;
+		r.sum_dist += (uint64_t)(int64_t)dg * (uint64_t)n;
+		r.sum_s1 += m1, r.sum_s2 += m2;
+	}
+	out[slot[i]] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// branch.c on device: pg_gen_rep_pos (6-29), pg_n_local (31-46), pg_mark_branch_flt_hit (108-145)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_walk_x(const uint32_t *flags, int n, int32_t *wk)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	wk[h] = (flags[h] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1;
+}
+
+// the last walkable hit of a gene in array order wins (branch.c:22-23 overwrite)
+__global__ __launch_bounds__(BLOCK) void k_rep_last(const int32_t *wk, const int32_t *gnm, const int32_t *gid, int n, int GL, int32_t *rp_pos)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n || !wk[h]) return;
+	atomicMax(&rp_pos[(int64_t)gid[h] * GL + gnm[h]], h + 1);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rep_fill(const int32_t *rp_pos, int64_t n_ent, int GL, const int32_t *seg, const int32_t *cm, const int32_t *rx,
+                                                      const int32_t *goff, int32_t *rp_seg, int32_t *rp_r, int32_t *rp_cm)
+{
+	int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (e >= n_ent) return;
+	int p = rp_pos[e];
+	if (p == 0) { rp_seg[e] = -1, rp_r[e] = 0, rp_cm[e] = 0; return; }
+	int h = p - 1, j = (int)(e % GL);
+	rp_seg[e] = seg[h], rp_cm[e] = cm[h];
+	rp_r[e] = rx[h] - rx[goff[j]]; // rank among the walkable hits of this genome (exclusive prefix count)
+}
+
+// one wave per gene pair, lanes over the local genomes
+__global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const int32_t *rp_seg, const int32_t *rp_r, const int32_t *rp_cm,
+                                                     int local_dist, int local_count, int frag_mode, int32_t *cnt)
+{
+	const int64_t k = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (k >= n_pair) return;
+	const int64_t b1 = (int64_t)pairs[2 * k] * GL, b2 = (int64_t)pairs[2 * k + 1] * GL;
+	int c = 0;
+	for (int j = lane; j < GL; j += WAVE) {
+		const int s1 = rp_seg[b1 + j], s2 = rp_seg[b2 + j];
+		if (s1 < 0 || s2 < 0) continue;
+		if (!frag_mode && s1 != s2) continue;
+		const int64_t d = (int64_t)rp_cm[b1 + j] - (int64_t)rp_cm[b2 + j];
+		const int cc = rp_r[b1 + j] - rp_r[b2 + j];
+		if ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count)) ++c;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, WAVE);
+	if (lane == 0) cnt[k] = c;
+}
+
+__device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107
+{
+	int64_t lo = 0, hi = n;
+	while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ax[mid] < x) lo = mid + 1; else hi = mid; }
+	return (lo < n && ax[lo] == x) ? aw[lo] : 0;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mark_hits(const int32_t *val, const int32_t *prev, const int32_t *yperm, const int32_t *seg, const int32_t *gid,
+                                                       const uint32_t *flags, const int32_t *g2s, int n, const uint64_t *ax, const uint8_t *aw, int64_t n_arc,
+                                                       int32_t *weak_new)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y >= n || val[y] < 0) return;
+	int p = prev[y];
+	if (p < 0) return;
+	int a = yperm[y], b = yperm[p];
+	if (seg[a] != seg[b]) return; // branch.c:124
+	uint32_t w = (uint32_t)g2s[gid[a]] << 1 | (flags[a] & PGA_F_REV ? 1u : 0u);
+	uint32_t v = (uint32_t)g2s[gid[b]] << 1 | (flags[b] & PGA_F_REV ? 1u : 0u);
+	int e1 = arc_weak(ax, aw, n_arc, (uint64_t)v << 32 | w);           // branch.c:128-130: marks the earlier hit
+	if (e1) atomicMax(&weak_new[b], e1);
+	int e2 = arc_weak(ax, aw, n_arc, (uint64_t)(w ^ 1) << 32 | (v ^ 1)); // branch.c:131-133: marks this hit
+	if (e2) atomicMax(&weak_new[a], e2);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_weak_merge(uint32_t *flags, const int32_t *weak_new, int n, int64_t *cnt)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h];
+	int cur = (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), nw = weak_new[h];
+	if (nw > cur) { cur = nw; flags[h] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT; }
+	if (cur) atomicAdd((unsigned long long *)cnt, 1ull);
+}
+
+// hazard H2b: two consecutive walkable hits (cs order) share (contig, cs)
+__global__ __launch_bounds__(BLOCK) void k_hz_cs(const int32_t *wk, const int32_t *seg, const int32_t *cs, int n, int64_t *dcnt)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n || h == 0 || !wk[h]) return;
+	for (int j = h - 1; j >= 0 && seg[j] == seg[h] && cs[j] == cs[h]; --j)
+		if (wk[j]) { atomicAdd((unsigned long long *)&dcnt[6], 1ull); break; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// download: per-hit state back to file order
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_to_file(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, const uint32_t *flags, const int32_t *rank,
+                                                     const int32_t *sdom, const int32_t *pdom, const int32_t *pdom0, const int32_t *yperm, int n,
+                                                     uint32_t *oflags, int32_t *orank, int32_t *osdom, int32_t *opdom, int32_t *opdom0, int32_t *opx, int32_t *opy)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int g = gnm[h], f = goff[g] + fidx[h];
+	oflags[f] = flags[h] & F_PUBLIC, orank[f] = rank[h], osdom[f] = sdom[h], opdom[f] = pdom[h], opdom0[f] = pdom0[h];
+	opx[f] = h - goff[g];
+	int x = yperm[h]; // h doubles as a Y position here
+	opy[goff[gnm[x]] + fidx[x]] = h - goff[gnm[x]];
+}
+
+// ================================================================================================
+// host side of the ABI
+// ================================================================================================
+static int sync_st(pga_ctx *c) { HIPCHK(hipStreamSynchronize(c->st)); return 0; }
+
+static int bits_for(uint32_t maxv) { int b = 1; while (b < 32 && (maxv >> b)) ++b; return b; }
+
+static int make_sweep_view(pga_ctx *c, SweepView *v)
+{
+	v->seg = c->seg, v->cs = c->cs, v->ce = c->ce, v->pm = c->pm, v->gid = c->gid, v->rank = c->rank, v->cds = c->cds, v->nex = c->nex;
+	v->offx = c->offx, v->pid = c->pid, v->sori = c->sori, v->sc64 = c->sc64, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
+	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4;
+	return 0;
+}
+
+template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
+{
+	SweepView v;
+	make_sweep_view(c, &v);
+	if (c->N == 0) return 0;
+	TimedLaunch t; t.which = timed_which; t.units = c->N;
+	if (timed_which >= 0) {
+		HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
+		HIPCHK(hipEventRecord(t.a, c->st));
+	}
+	hipLaunchKernelGGL((k_sweep<MODE>), dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, v);
+	if (timed_which >= 0) { HIPCHK(hipEventRecord(t.b, c->st)); c->timed.push_back(t); }
+	return 0;
+}
+
+static int radix_sort_pool(pga_ctx *c, uint64_t *keys, uint32_t *vals, int64_t n, int n_bits, uint64_t **kres, uint32_t **vres)
+{
+	RadixBufs b;
+	if (n > 2 * (int64_t)c->N) return PGA_ERR_ARG; // work buffers are sized once, in create, for 2N items
+	b.k_alt = (uint64_t *)c->pool.get(S_KEY_B, 0);
+	b.v_alt = (uint32_t *)c->pool.get(S_VAL_B, 0);
+	b.table = (uint32_t *)c->pool.get(S_TABLE, 0);
+	b.tile_buf = (int32_t *)c->pool.get(S_TILE, 0);
+	if (!b.k_alt || !b.v_alt || !b.table || !b.tile_buf) return PGA_ERR_NOMEM;
+	device_radix_sort(keys, vals, n, n_bits, b, kres, vres, c->st);
+	return 0;
+}
+
+extern "C" void pga_destroy(pga_ctx_t *c)
+{
+	if (c == nullptr) return;
+	if (c->st) (void)hipStreamSynchronize(c->st);
+	for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+	for (void *q : c->owned) (void)hipFree(q);
+	c->pool.release();
+	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
+	delete c;
+}
+
+extern "C" int pga_set_stream(pga_ctx_t *c, void *hip_stream)
+{
+	if (c == nullptr) return PGA_ERR_ARG;
+	if (c->st) HIPCHK(hipStreamSynchronize(c->st));
+	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
+	c->st = (hipStream_t)hip_stream, c->own_stream = false;
+	return 0;
+}
+
+template <class T> static int upload(pga_ctx *c, T *dst, const T *src, size_t n)
+{
+	if (n == 0) return 0;
+	HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, c->st));
+	return 0;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static int create_impl(pga_ctx *c, const pga_shard_t *sh)
+{
+	const int N = c->N, E = c->E, GL = c->n_genome;
+	HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+	c->own_stream = true;
+	HIPCHK(hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(int64_t), hipHostMallocDefault));
+	TRY(dalloc(c, &c->dcnt, 16));
+	HIPCHK(hipMemsetAsync(c->dcnt, 0, 16 * sizeof(int64_t), c->st));
+	// persistent arrays
+	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
+	TRY(dalloc(c, &c->cs, N)); TRY(dalloc(c, &c->ce, N)); TRY(dalloc(c, &c->cm, N)); TRY(dalloc(c, &c->cds, N)); TRY(dalloc(c, &c->nex, N));
+	TRY(dalloc(c, &c->offx, N)); TRY(dalloc(c, &c->sori, N)); TRY(dalloc(c, &c->sadj, N)); TRY(dalloc(c, &c->pm, N)); TRY(dalloc(c, &c->sc64, N));
+	TRY(dalloc(c, &c->rank, N)); TRY(dalloc(c, &c->sdom, N)); TRY(dalloc(c, &c->pdom, N)); TRY(dalloc(c, &c->pdom0, N)); TRY(dalloc(c, &c->flags, N));
+	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->exon, E));
+	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q));
+	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
+	if (c->Q) hipLaunchKernelGGL(k_fill_i32, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, (int64_t)c->Q, -1);
+
+	// host-side small tables
+	std::vector<int32_t> ctg_base((size_t)GL + 1, 0);
+	c->h_goff.resize((size_t)GL + 1);
+	for (int g = 0; g <= GL; ++g) c->h_goff[(size_t)g] = (int32_t)sh->hit_off[g];
+	for (int g = 0; g < GL; ++g) ctg_base[(size_t)g + 1] = ctg_base[(size_t)g] + sh->n_ctg[g];
+	c->n_seg_ctg = ctg_base[(size_t)GL];
+	c->h_ggl.assign(sh->genome_global, sh->genome_global + GL);
+	uint32_t max_cs = 0, max_cm = 0;
+	for (int i = 0; i < N; ++i) {
+		if (sh->cs[i] < 0 || sh->ce[i] < sh->cs[i] || sh->cm[i] < 0 || sh->cid[i] < 0) return PGA_ERR_RANGE;
+		max_cs = std::max(max_cs, (uint32_t)sh->cs[i]), max_cm = std::max(max_cm, (uint32_t)sh->cm[i]);
+	}
+	const int cs_bits = bits_for(max_cs), cm_bits = bits_for(max_cm), seg_bits = bits_for((uint32_t)std::max(1, c->n_seg_ctg));
+	std::vector<int2> hex((size_t)E);
+	for (int e = 0; e < E; ++e) hex[(size_t)e] = make_int2(sh->exon_os[e], sh->exon_oe[e]);
+
+	// file-order staging (freed with the pool entries being reused later)
+	int32_t *up = (int32_t *)c->pool.get(S_UPLOAD, sizeof(int32_t) * (size_t)N * 16 + 64);
+	int32_t *d_ctg_base = (int32_t *)c->pool.get(S_MISC, sizeof(int32_t) * ((size_t)GL + 1));
+	if (!up || !d_ctg_base) return PGA_ERR_NOMEM;
+	int32_t *f_pid = up, *f_cid = up + (size_t)N, *f_rank = up + 2 * (size_t)N, *f_sori = up + 3 * (size_t)N, *f_sadj = up + 4 * (size_t)N, *f_nex = up + 5 * (size_t)N,
+		*f_offx = up + 6 * (size_t)N, *f_cs = up + 7 * (size_t)N, *f_ce = up + 8 * (size_t)N, *f_cm = up + 9 * (size_t)N,
+		*f_gnm = up + 10 * (size_t)N, *f_seg = up + 11 * (size_t)N, *f_gid = up + 12 * (size_t)N, *f_cds = up + 13 * (size_t)N;
+	uint8_t *f_rev = (uint8_t *)(up + 14 * (size_t)N);
+	TRY(upload(c, f_pid, sh->pid, N)); TRY(upload(c, f_cid, sh->cid, N)); TRY(upload(c, f_rank, sh->rank, N)); TRY(upload(c, f_sori, sh->score_ori, N));
+	TRY(upload(c, f_sadj, sh->score_adj, N)); TRY(upload(c, f_nex, sh->n_exon_of, N)); TRY(upload(c, f_offx, sh->off_exon, N));
+	TRY(upload(c, f_cs, sh->cs, N)); TRY(upload(c, f_ce, sh->ce, N)); TRY(upload(c, f_cm, sh->cm, N)); TRY(upload(c, f_rev, sh->rev, N));
+	TRY(upload(c, c->goff, c->h_goff.data(), (size_t)GL + 1)); TRY(upload(c, c->ggl, c->h_ggl.data(), GL));
+	TRY(upload(c, d_ctg_base, ctg_base.data(), (size_t)GL + 1));
+	TRY(upload(c, c->exon, hex.data(), E)); TRY(upload(c, c->prot_gid, sh->prot_gid, c->P)); TRY(upload(c, c->gene_pref, sh->gene_pref, c->Q));
+	if (N == 0) return sync_st(c);
+
+	{ // work buffers shared by every sort / scan of the run: sized for the largest input (2N temp arcs)
+		const int64_t W = 2 * (int64_t)N + 2;
+		if (!c->pool.get(S_KEY_B, sizeof(uint64_t) * (size_t)W) || !c->pool.get(S_VAL_B, sizeof(uint32_t) * (size_t)W) ||
+		    !c->pool.get(S_TABLE, sizeof(uint32_t) * (size_t)rs_table_len(W)) ||
+		    !c->pool.get(S_TILE, sizeof(int64_t) * (size_t)(scan_tiles(std::max<int64_t>(rs_table_len(W), W)) + 8))) return PGA_ERR_NOMEM;
+	}
+	uint64_t *sc64_f = (uint64_t *)c->pool.get(S_TAB_A, sizeof(uint64_t) * (size_t)N);
+	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, sizeof(uint64_t) * (size_t)N);
+	uint32_t *val = (uint32_t *)c->pool.get(S_VAL_A, sizeof(uint32_t) * (size_t)N);
+	if (!sc64_f || !key || !val) return PGA_ERR_NOMEM;
+	FileHits f = { f_pid, f_cid, f_rank, f_sori, f_sadj, f_nex, f_offx, f_cs, f_ce, f_cm, f_rev };
+	hipLaunchKernelGGL(k_prepare, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, N, c->goff, GL, d_ctg_base, c->exon, c->prot_gid, c->gene_pref,
+	                   cs_bits, f_gnm, f_seg, f_gid, f_cds, sc64_f, key, val);
+	// X order: pg_hit_sort(g, 0), hit.c:29-64, for every genome at once; stable => ties keep file order
+	uint64_t *ks; uint32_t *vs;
+	TRY(radix_sort_pool(c, key, val, N, cs_bits + seg_bits, &ks, &vs));
+	HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->sc64, c->flags };
+	hipLaunchKernelGGL(k_gather, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, f_gnm, f_seg, f_gid, f_cds, sc64_f, vs, N, c->goff, o);
+	// running max of ce per contig
+	SegMax *tile = (SegMax *)c->pool.get(S_TILE, 0);
+	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
+	// Y order: pg_hit_sort(g, 1); ties keep X order
+	hipLaunchKernelGGL(k_ykey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->seg, c->cm, N, cm_bits, key, val);
+	TRY(radix_sort_pool(c, key, val, N, cm_bits + seg_bits, &ks, &vs));
+	HIPCHK(hipMemcpyAsync(c->yperm, vs, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToDevice, c->st));
+	return sync_st(c);
+}
+
+extern "C" int pga_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
+{
+	if (out == nullptr || sh == nullptr || par == nullptr) return PGA_ERR_ARG;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		fprintf(stderr, "[E::pga_create] no HIP device is visible; libpangene_amd has no CPU fallback\n");
+		return PGA_ERR_NO_DEVICE;
+	}
+	if (sh->n_hit >= INT32_MAX || sh->n_exon >= INT32_MAX || sh->n_gene >= (1 << 20) || sh->n_genome_global >= (1 << 24)) return PGA_ERR_RANGE;
+	pga_ctx *c = new pga_ctx();
+	c->n_genome = sh->n_genome, c->n_genome_global = sh->n_genome_global, c->P = sh->n_prot, c->Q = sh->n_gene;
+	c->N = (int32_t)sh->n_hit, c->E = (int32_t)sh->n_exon, c->par = *par;
+	int rc = create_impl(c, sh);
+	if (rc) { pga_destroy(c); return rc; }
+	*out = c;
+	return 0;
+}
+
+// stage A (read.c:243-260) for all genomes of the shard
+extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
+{
+	const int N = c->N, GL = c->n_genome, P = c->P, Q = c->Q;
+	int32_t *d_stats = (int32_t *)c->pool.get(S_STATS, sizeof(int32_t) * 4 * (size_t)GL + 16);
+	if (!d_stats) return PGA_ERR_NOMEM;
+	HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(int32_t) * 4 * (size_t)GL + 16, c->st));
+	if (N) {
+		const int64_t TP = (int64_t)GL * P, TQ = (int64_t)GL * Q;
+		int32_t *tmax = (int32_t *)c->pool.get(S_TAB_A, sizeof(int32_t) * (size_t)TP);
+		int32_t *tmin = (int32_t *)c->pool.get(S_TAB_B, sizeof(int32_t) * (size_t)TP);
+		int32_t *tr1 = (int32_t *)c->pool.get(S_TAB_C, sizeof(int32_t) * (size_t)TP);
+		unsigned long long *tbest = (unsigned long long *)c->pool.get(S_TAB_D, sizeof(uint64_t) * (size_t)TQ);
+		if (!tmax || !tmin || !tr1 || !tbest) return PGA_ERR_NOMEM;
+		HIPCHK(hipMemsetAsync(tmax, 0, sizeof(int32_t) * (size_t)TP, c->st));
+		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tmin, TP, INT32_MAX);
+		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tr1, TP, INT32_MAX);
+		hipLaunchKernelGGL(k_pseudo1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, N, P, tmax, tmin);
+		hipLaunchKernelGGL(k_pseudo2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, c->rank, c->flags, N, P, tmax, tmin, tr1, d_stats);
+		hipLaunchKernelGGL(k_pseudo3, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->rank, N, P, tmax, tmin, tr1);
+		TRY(launch_sweep<1>(c, 0)); // pg_shadow(cal_dom_sc=1), read.c:248 -- "K1", the hit-filter+overlap kernel
+		hipLaunchKernelGGL(k_ingest_reset, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->pdom, c->pdom0, N);
+		TRY(launch_sweep<2>(c, 1)); // pg_flt_ov_isoform, read.c:254
+		int32_t *tiso = tmax; // reuse: 1 = every hit of (genome, protein) carries flt_iso_ov
+		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tiso, TP, 1);
+		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, N, P, tiso, d_stats);
+		hipLaunchKernelGGL(k_chain, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pdom0, N, P, tiso, d_stats);
+		HIPCHK(hipMemsetAsync(tbest, 0, sizeof(uint64_t) * (size_t)TQ, c->st));
+		hipLaunchKernelGGL(k_subopt1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->sadj, c->goff, N, Q, tbest);
+		hipLaunchKernelGGL(k_subopt2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->pid, c->goff, N, Q, tbest, d_stats);
+	}
+	if (stats) {
+		HIPCHK(hipMemcpyAsync(stats, d_stats, sizeof(int32_t) * 4 * (size_t)GL, hipMemcpyDeviceToHost, c->st));
+		return sync_st(c);
+	}
+	return 0;
+}
+
+extern "C" int pga_post_partials(pga_ctx_t *c, int32_t **max_ori, int64_t **sums)
+{
+	HIPCHK(hipMemsetAsync(c->max_ori, 0, sizeof(int32_t) * (size_t)std::max(1, c->P), c->st));
+	HIPCHK(hipMemsetAsync(c->sums, 0, sizeof(int64_t) * 6 * (size_t)std::max(1, c->P), c->st));
+	if (c->N) hipLaunchKernelGGL(k_post_part, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->rank, c->sori, c->sadj, c->nex, c->N, c->P,
+	                             c->max_ori, (unsigned long long *)c->sums);
+	*max_ori = c->max_ori, *sums = c->sums;
+	return sync_st(c); // the exchange may run on another stream
+}
+
+extern "C" int pga_post_apply(pga_ctx_t *c, const uint8_t *prot_rep, const uint8_t *prot_pj, int64_t *n_pseudo)
+{
+	uint8_t *d = (uint8_t *)c->pool.get(S_MISC, 2 * (size_t)c->P + 16);
+	if (!d) return PGA_ERR_NOMEM;
+	TRY(upload(c, d, prot_rep, (size_t)c->P)); TRY(upload(c, d + c->P, prot_pj, (size_t)c->P));
+	HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
+	if (c->N) hipLaunchKernelGGL(k_post_apply, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->nex, c->sdom, c->N, c->max_ori, d, d + c->P, c->dcnt + 2);
+	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	TRY(sync_st(c));
+	if (n_pseudo) *n_pseudo = c->h_cnt[2];
+	return 0;
+}
+
+extern "C" int pga_shadow(pga_ctx_t *c, int32_t cal_dom_sc, int32_t *stats)
+{
+	if (cal_dom_sc) TRY(launch_sweep<1>(c, -1)); else TRY(launch_sweep<0>(c, 2));
+	if (stats) {
+		int32_t *d_stats = (int32_t *)c->pool.get(S_STATS, sizeof(int32_t) * 4 * (size_t)c->n_genome + 16);
+		if (!d_stats) return PGA_ERR_NOMEM;
+		HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(int32_t) * 2 * (size_t)c->n_genome + 16, c->st));
+		if (c->N) hipLaunchKernelGGL(k_count_shadow, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->N, d_stats);
+		HIPCHK(hipMemcpyAsync(stats, d_stats, sizeof(int32_t) * 2 * (size_t)c->n_genome, hipMemcpyDeviceToHost, c->st));
+		return sync_st(c);
+	}
+	return 0;
+}
+
+extern "C" int pga_set_filter(pga_ctx_t *c, int32_t which)
+{
+	if (which < 0 || which > 3) return PGA_ERR_ARG;
+	if (c->N) hipLaunchKernelGGL(k_set_filter, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->N, which);
+	return 0;
+}
+
+static int check_invariant(pga_ctx *c)
+{
+	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	TRY(sync_st(c));
+	return c->h_cnt[3] ? PGA_ERR_INVARIANT : 0;
+}
+
+extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **triples, int64_t *n_triples)
+{
+	const int N = c->N, Q = c->Q, GL = c->n_genome;
+	const int64_t wpg = (Q + 31) / 32;
+	uint32_t *bits = (uint32_t *)c->pool.get(S_BITS, sizeof(uint32_t) * (size_t)(wpg * GL) + 16);
+	if (!bits) return PGA_ERR_NOMEM;
+	HIPCHK(hipMemsetAsync(bits, 0, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->st));
+	HIPCHK(hipMemsetAsync(c->vtx_cnt, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, Q), c->st));
+	HIPCHK(hipMemsetAsync(c->dcnt, 0, sizeof(int64_t), c->st));
+	*n_triples = 0, *triples = nullptr, *cnt = c->vtx_cnt;
+	if (N == 0) return sync_st(c);
+	hipLaunchKernelGGL(k_vtx1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt);
+	hipLaunchKernelGGL((k_vtx2<true>), dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, c->prot_gid, c->ggl, N, bits, wpg,
+	                   (uint64_t *)nullptr, c->dcnt);
+	TRY(check_invariant(c));
+	const int64_t nt = c->h_cnt[0];
+	uint64_t *tri = (uint64_t *)c->pool.get(S_TRIPLES, sizeof(uint64_t) * (size_t)nt + 16);
+	if (!tri) return PGA_ERR_NOMEM;
+	HIPCHK(hipMemsetAsync(c->dcnt, 0, sizeof(int64_t), c->st));
+	hipLaunchKernelGGL((k_vtx2<false>), dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, c->prot_gid, c->ggl, N, bits, wpg, tri, c->dcnt);
+	*triples = tri, *n_triples = nt;
+	return sync_st(c);
+}
+
+extern "C" int pga_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg)
+{
+	TRY(upload(c, c->g2s, g2s, (size_t)c->Q));
+	c->n_seg = n_seg;
+	if (c->N) hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, c->N, c->g2s);
+	return sync_st(c); // g2s is caller memory: make the copy complete before returning
+}
+
+// walkable marks in cm order + predecessor; shared by arc_round and mark_hits
+static int walk_prev(pga_ctx *c, int32_t **val_out, int32_t **prev_out)
+{
+	const int N = c->N;
+	int32_t *val = (int32_t *)c->pool.get(S_I32_A, sizeof(int32_t) * (size_t)N);
+	int32_t *prev = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
+	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+	if (!val || !prev || !tile) return PGA_ERR_NOMEM;
+	hipLaunchKernelGGL(k_walk_mark, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->yperm, N, val);
+	device_scan<I32>(InWalk{val}, OutPrev{prev}, N, tile, OpMax{}, I32{-1}, c->st); // exclusive running max = previous walkable
+	*val_out = val, *prev_out = prev;
+	return 0;
+}
+
+extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int64_t *n_arcs_out)
+{
+	const int N = c->N, S = c->n_seg, GL = c->n_genome;
+	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, sizeof(int32_t) * 2 * (size_t)std::max(1, S));
+	if (!seg_cnt) return PGA_ERR_NOMEM;
+	HIPCHK(hipMemsetAsync(seg_cnt, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, S), c->st));
+	*seg_cnt_out = seg_cnt, *arcs_out = nullptr, *n_arcs_out = 0;
+	if (N == 0) return sync_st(c);
+	TRY(launch_sweep<0>(c, 2)); // graph.c:102
+	int32_t *val, *prev;
+	TRY(walk_prev(c, &val, &prev));
+	const int64_t wpg = (S + 31) / 32;
+	uint32_t *seen = (uint32_t *)c->pool.get(S_BITS, sizeof(uint32_t) * (size_t)(wpg * GL) + 16);
+	int32_t *has = (int32_t *)c->pool.get(S_I32_C, sizeof(int32_t) * (size_t)N);
+	int32_t *slot = (int32_t *)c->pool.get(S_SLOT, sizeof(int32_t) * (size_t)(2 * (int64_t)N + 2));
+	if (!seen || !has || !slot) return PGA_ERR_NOMEM;
+	HIPCHK(hipMemsetAsync(seen, 0, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->st));
+	hipLaunchKernelGGL(k_arc_flag, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yperm, c->seg, c->gid, c->gnm, c->cm, c->g2s, N, S, has, seg_cnt, seen, wpg, c->dcnt);
+	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+	device_scan<I32>(InI32{has}, OutExclI32{slot}, N, tile, OpSum{}, I32{0}, c->st);
+	// number of adjacencies = slot[N-1] + has[N-1]
+	int32_t tail[2];
+	HIPCHK(hipMemcpyAsync(&tail[0], slot + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(&tail[1], has + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+	TRY(check_invariant(c));
+	const int64_t M = 2 * ((int64_t)tail[0] + tail[1]);
+	if (M == 0) return sync_st(c);
+	const int vbits = bits_for((uint32_t)(2 * std::max(1, S)));
+	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, sizeof(uint64_t) * (size_t)M);
+	uint32_t *idx = (uint32_t *)c->pool.get(S_VAL_A, sizeof(uint32_t) * (size_t)M);
+	int32_t *tdist = (int32_t *)c->pool.get(S_TDIST, sizeof(int32_t) * (size_t)M), *ts1 = (int32_t *)c->pool.get(S_TS1, sizeof(int32_t) * (size_t)M);
+	int32_t *ts2 = (int32_t *)c->pool.get(S_TS2, sizeof(int32_t) * (size_t)M), *tgen = (int32_t *)c->pool.get(S_TGEN, sizeof(int32_t) * (size_t)M);
+	int32_t *sdist = (int32_t *)c->pool.get(S_SDIST, sizeof(int32_t) * (size_t)M), *ss1 = (int32_t *)c->pool.get(S_SS1, sizeof(int32_t) * (size_t)M);
+	int32_t *ss2 = (int32_t *)c->pool.get(S_SS2, sizeof(int32_t) * (size_t)M), *sgen = (int32_t *)c->pool.get(S_SGEN, sizeof(int32_t) * (size_t)M);
+	int32_t *head = (int32_t *)c->pool.get(S_HEAD, sizeof(int32_t) * (size_t)M);
+	if (!key || !idx || !tdist || !ts1 || !ts2 || !tgen || !sdist || !ss1 || !ss2 || !sgen || !head) return PGA_ERR_NOMEM;
+	ArcEmit e = { has, slot, prev, c->yperm, c->gid, c->gnm, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->g2s, c->flags, key, idx, tdist, ts1, ts2, tgen, N, use_ori, vbits };
+	hipLaunchKernelGGL(k_arc_emit, dim3(nblk(N)), dim3(BLOCK), 0, c->st, e);
+	uint64_t *ks; uint32_t *vs;
+	TRY(radix_sort_pool(c, key, idx, M, 2 * vbits, &ks, &vs)); // graph.c:127 and :151 in one stable sort
+	hipLaunchKernelGGL(k_arc_gather, dim3(nblk(M)), dim3(BLOCK), 0, c->st, vs, M, tdist, ts1, ts2, tgen, sdist, ss1, ss2, sgen);
+	hipLaunchKernelGGL(k_arc_head, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, M, head);
+	tile = (I32 *)c->pool.get(S_TILE, 0);
+	device_scan<I32>(InI32{head}, OutExclI32{slot}, M, tile, OpSum{}, I32{0}, c->st);
+	HIPCHK(hipMemcpyAsync(&tail[0], slot + (M - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(&tail[1], head + (M - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+	TRY(sync_st(c));
+	const int64_t A = (int64_t)tail[0] + tail[1];
+	pga_arc_part_t *arcs = (pga_arc_part_t *)c->pool.get(S_ARCS, sizeof(pga_arc_part_t) * (size_t)A);
+	if (!arcs) return PGA_ERR_NOMEM;
+	hipLaunchKernelGGL(k_arc_reduce, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, head, slot, M, sdist, ss1, ss2, sgen, vbits, arcs);
+	*arcs_out = arcs, *n_arcs_out = A;
+	return sync_st(c);
+}
+
+extern "C" int pga_rep_pos(pga_ctx_t *c)
+{
+	const int N = c->N, GL = c->n_genome, Q = c->Q;
+	const int64_t n_ent = (int64_t)Q * GL;
+	int32_t *rp_pos = (int32_t *)c->pool.get(S_RP_POS, sizeof(int32_t) * (size_t)n_ent);
+	int32_t *rp_seg = (int32_t *)c->pool.get(S_RP_SEG, sizeof(int32_t) * (size_t)n_ent);
+	int32_t *rp_r = (int32_t *)c->pool.get(S_RP_R, sizeof(int32_t) * (size_t)n_ent);
+	int32_t *rp_cm = (int32_t *)c->pool.get(S_RP_CM, sizeof(int32_t) * (size_t)n_ent);
+	if (!rp_pos || !rp_seg || !rp_r || !rp_cm) return PGA_ERR_NOMEM;
+	HIPCHK(hipMemsetAsync(rp_pos, 0, sizeof(int32_t) * (size_t)n_ent, c->st));
+	if (N) {
+		int32_t *wk = (int32_t *)c->pool.get(S_I32_A, sizeof(int32_t) * (size_t)N);
+		int32_t *rx = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
+		I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+		if (!wk || !rx || !tile) return PGA_ERR_NOMEM;
+		hipLaunchKernelGGL(k_walk_x, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, N, wk);
+		device_scan<I32>(InI32{wk}, OutExclI32{rx}, N, tile, OpSum{}, I32{0}, c->st);
+		hipLaunchKernelGGL(k_rep_last, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->gnm, c->gid, N, GL, rp_pos);
+		hipLaunchKernelGGL(k_hz_cs, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->seg, c->cs, N, c->dcnt);
+		if (n_ent) hipLaunchKernelGGL(k_rep_fill, dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, rp_seg, rp_r, rp_cm);
+	} else if (n_ent) {
+		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_seg, n_ent, -1);
+	}
+	return 0;
+}
+
+extern "C" int pga_n_local(pga_ctx_t *c, const int32_t *pairs, int64_t n, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt)
+{
+	int32_t *d_pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)n + 16);
+	int32_t *d_cnt = (int32_t *)c->pool.get(S_NLCNT, sizeof(int32_t) * (size_t)n + 16);
+	int32_t *rp_seg = (int32_t *)c->pool.get(S_RP_SEG, 0), *rp_r = (int32_t *)c->pool.get(S_RP_R, 0), *rp_cm = (int32_t *)c->pool.get(S_RP_CM, 0);
+	if (!d_pairs || !d_cnt || !rp_seg || !rp_r || !rp_cm) return PGA_ERR_NOMEM;
+	*cnt = d_cnt;
+	if (n == 0) return 0;
+	TRY(upload(c, d_pairs, pairs, 2 * (size_t)n));
+	hipLaunchKernelGGL(k_n_local, dim3(nblk(n, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, rp_seg, rp_r, rp_cm, local_dist, local_count, frag_mode, d_cnt);
+	return sync_st(c); // pairs is caller memory; the exchange may run on another stream
+}
+
+extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked)
+{
+	const int N = c->N;
+	if (n_marked) *n_marked = 0;
+	if (N == 0) return 0;
+	uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, sizeof(uint64_t) * (size_t)n_arc + 16);
+	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, (size_t)n_arc + 16);
+	int32_t *wn = (int32_t *)c->pool.get(S_WEAKNEW, sizeof(int32_t) * (size_t)N);
+	if (!ax || !aw || !wn) return PGA_ERR_NOMEM;
+	TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, aw, arc_weak, (size_t)n_arc));
+	HIPCHK(hipMemsetAsync(wn, 0, sizeof(int32_t) * (size_t)N, c->st));
+	HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
+	int32_t *val, *prev;
+	TRY(walk_prev(c, &val, &prev));
+	hipLaunchKernelGGL(k_mark_hits, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yperm, c->seg, c->gid, c->flags, c->g2s, N, ax, aw, n_arc, wn);
+	hipLaunchKernelGGL(k_weak_merge, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, wn, N, c->dcnt + 2);
+	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	TRY(sync_st(c));
+	if (n_marked) *n_marked = c->h_cnt[2];
+	return 0;
+}
+
+extern "C" int pga_fetch(pga_ctx_t *c, void *dst_host, const void *src_backend, size_t nbytes)
+{
+	if (nbytes == 0) return 0;
+	HIPCHK(hipMemcpyAsync(dst_host, src_backend, nbytes, hipMemcpyDeviceToHost, c->st));
+	return sync_st(c);
+}
+
+extern "C" int pga_put(pga_ctx_t *c, void *dst_backend, const void *src_host, size_t nbytes)
+{
+	if (nbytes == 0) return 0;
+	HIPCHK(hipMemcpyAsync(dst_backend, src_host, nbytes, hipMemcpyHostToDevice, c->st));
+	return sync_st(c);
+}
+
+extern "C" int pga_copy(pga_ctx_t *c, void *dst_backend, const void *src_backend, size_t nbytes)
+{
+	if (nbytes == 0) return 0;
+	HIPCHK(hipMemcpyAsync(dst_backend, src_backend, nbytes, hipMemcpyDeviceToDevice, c->st));
+	return sync_st(c);
+}
+
+extern "C" int pga_scratch(pga_ctx_t *c, size_t nbytes, void **ptr)
+{
+	*ptr = c->pool.get(S_SCRATCH, nbytes);
+	return *ptr ? 0 : PGA_ERR_NOMEM;
+}
+
+extern "C" int pga_download(pga_ctx_t *c, const pga_hit_state_t *o)
+{
+	const int N = c->N;
+	if (N == 0) return 0;
+	int32_t *dl = (int32_t *)c->pool.get(S_DL, sizeof(int32_t) * 7 * (size_t)N);
+	if (!dl) return PGA_ERR_NOMEM;
+	hipLaunchKernelGGL(k_to_file, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, c->flags, c->rank, c->sdom, c->pdom, c->pdom0, c->yperm, N,
+	                   (uint32_t *)dl, dl + (size_t)N, dl + 2 * (size_t)N, dl + 3 * (size_t)N, dl + 4 * (size_t)N, dl + 5 * (size_t)N, dl + 6 * (size_t)N);
+	void *dst[7] = { o->flags, o->rank, o->score_dom, o->pid_dom, o->pid_dom0, o->pos_x, o->pos_y };
+	for (int k = 0; k < 7; ++k)
+		if (dst[k]) HIPCHK(hipMemcpyAsync(dst[k], dl + (size_t)k * N, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, c->st));
+	return sync_st(c);
+}
+
+extern "C" int pga_hazards(pga_ctx_t *c, pga_hazard_t *out)
+{
+	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	TRY(sync_st(c));
+	out->h1_head_tie = c->h_cnt[4], out->h2_cm_tie = c->h_cnt[5], out->h2_cs_tie = c->h_cnt[6], out->h3_dom_tie = c->h_cnt[7];
+	return 0;
+}
+
+extern "C" int pga_timing_reset(pga_ctx_t *c)
+{
+	TRY(sync_st(c));
+	for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+	c->timed.clear();
+	return 0;
+}
+
+extern "C" int pga_timing_get(pga_ctx_t *c, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units)
+{
+	TRY(sync_st(c));
+	double ms = 0; int64_t n = 0, u = 0;
+	for (auto &t : c->timed) {
+		if (t.which != which) continue;
+		float f = 0;
+		HIPCHK(hipEventElapsedTime(&f, t.a, t.b));
+		ms += f, ++n, u += t.units;
+	}
+	if (total_ms) *total_ms = ms;
+	if (n_launch) *n_launch = n;
+	if (units) *units = u;
+	return 0;
+}
+
+extern "C" const pga_backend_t *pga_backend(void)
+{
+	static const pga_backend_t b = {
+		"hip-gfx950", pga_create, pga_destroy, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
+		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_rep_pos, pga_n_local, pga_mark_hits, pga_fetch, pga_put, pga_copy, pga_scratch,
+		pga_download, pga_hazards, pga_is_device, pga_strerror
+	};
+	return &b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// self-test hooks for the device primitives (tests/test_prims_gpu.py): sort / scan arbitrary host data
+// ------------------------------------------------------------------------------------------------
+extern "C" int pga_selftest_sort(uint64_t *keys, uint32_t *vals, int64_t n, int32_t n_bits)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PGA_ERR_NO_DEVICE;
+	uint64_t *ka, *kb; uint32_t *va, *vb, *table; int32_t *tile;
+	HIPCHK(hipMalloc((void **)&ka, sizeof(uint64_t) * (size_t)(n + 1))); HIPCHK(hipMalloc((void **)&kb, sizeof(uint64_t) * (size_t)(n + 1)));
+	HIPCHK(hipMalloc((void **)&va, sizeof(uint32_t) * (size_t)(n + 1))); HIPCHK(hipMalloc((void **)&vb, sizeof(uint32_t) * (size_t)(n + 1)));
+	HIPCHK(hipMalloc((void **)&table, sizeof(uint32_t) * (size_t)(rs_table_len(n) + 1)));
+	HIPCHK(hipMalloc((void **)&tile, sizeof(int64_t) * (size_t)(scan_tiles(std::max<int64_t>(rs_table_len(n), n)) + 8)));
+	HIPCHK(hipMemcpy(ka, keys, sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(va, vals, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+	RadixBufs b = { kb, vb, table, tile };
+	uint64_t *kr; uint32_t *vr;
+	device_radix_sort(ka, va, n, n_bits, b, &kr, &vr, 0);
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(keys, kr, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(vals, vr, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+	(void)hipFree(ka); (void)hipFree(kb); (void)hipFree(va); (void)hipFree(vb); (void)hipFree(table); (void)hipFree(tile);
+	return 0;
+}
+
+// mode 0: exclusive sum; 1: exclusive max (identity -1); 2: segmented inclusive max with seg[]
+extern "C" int pga_selftest_scan(const int32_t *in, const int32_t *seg, int32_t *out, int64_t n, int32_t mode)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PGA_ERR_NO_DEVICE;
+	int32_t *di, *ds, *dout; int64_t *tile;
+	HIPCHK(hipMalloc((void **)&di, sizeof(int32_t) * (size_t)(n + 1))); HIPCHK(hipMalloc((void **)&ds, sizeof(int32_t) * (size_t)(n + 1)));
+	HIPCHK(hipMalloc((void **)&dout, sizeof(int32_t) * (size_t)(n + 1))); HIPCHK(hipMalloc((void **)&tile, sizeof(int64_t) * (size_t)(scan_tiles(n) + 8)));
+	HIPCHK(hipMemcpy(di, in, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+	if (seg) HIPCHK(hipMemcpy(ds, seg, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+	if (mode == 0) device_scan<I32>(InI32{di}, OutExclI32{dout}, n, (I32 *)tile, OpSum{}, I32{0}, 0);
+	else if (mode == 1) device_scan<I32>(InI32{di}, OutExclI32{dout}, n, (I32 *)tile, OpMax{}, I32{-1}, 0);
+	else device_scan<SegMax>(InSegMax{ds, di}, OutSegMax{dout}, n, (SegMax *)tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, 0);
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(out, dout, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+	(void)hipFree(di); (void)hipFree(ds); (void)hipFree(dout); (void)hipFree(tile);
+	return 0;
+}

@@ -1,0 +1,638 @@
+// graph_driver.cpp -- host side of the graph-construction path: packs the parsed hits into one
+// structure-of-arrays shard, hands it to the backend (HIP kernels; include/pangene_hip.h) and drives
+// the rounds of the reference's pg_post_process (graph.c:7-32) and pg_graph_gen (graph.c:280-322).
+// Everything hit-sized happens behind the backend ABI; this file only touches P-, Q-, S- and A-sized
+// data (proteins, genes, segments, arcs): the representative-isoform sort (hit.c:205-217), the greedy
+// vertex selection (vertex.c:54-97), branch marking (branch.c:48-106), pruning (graph.c:179-263).
+// With an exchange hook installed (pg_set_exchange) the same code runs on every rank of a sharded run:
+// partial vectors are all-reduced / all-gathered in backend memory (RCCL) and every rank then takes
+// the identical host-side decisions, so no broadcast is needed.
+#include <sys/time.h>
+#include <sys/resource.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include "pg_internal.hpp"
+#include "ksort_exact.hpp"
+
+int pg_verbose = 3;
+
+namespace pgx {
+
+pg_exchange_t g_xchg; bool g_has_xchg = false;
+static int g_err = 0; static char g_errstr[256] = "";
+static double g_path_sec = 0.0; static int64_t g_path_hits = 0;
+
+void set_error(int code, const char *where)
+{
+	g_err = code;
+	std::snprintf(g_errstr, sizeof(g_errstr), "%s: backend status %d", where, code);
+	std::fprintf(stderr, "[E::pangene_amd] %s\n", g_errstr);
+}
+
+double now_sec()
+{
+	struct timeval tp;
+	gettimeofday(&tp, nullptr);
+	return tp.tv_sec + tp.tv_usec * 1e-6;
+}
+
+const char *stamp() // "<real>*<cpu/real>", the reference's pg_timestamp (sys.c:131-138)
+{
+	static char buf[64];
+	static double t0 = -1.0;
+	double t = now_sec();
+	if (t0 < 0) t0 = t;
+	struct rusage r;
+	getrusage(RUSAGE_SELF, &r);
+	double cpu = r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+	std::snprintf(buf, sizeof(buf), "%.3f*%.2f", t - t0, (cpu + 1e-6) / (t - t0 + 1e-6));
+	return buf;
+}
+
+static inline bool sharded() { return g_has_xchg && g_xchg.world > 1; }
+
+#define BE_CALL(expr, where) do { int rc__ = (expr); if (rc__ != 0) { set_error(rc__, where); return rc__; } } while (0)
+
+static int xreduce(const pga_backend_t *be, void *buf, int64_t count, int32_t dtype, int32_t op)
+{
+	if (!sharded() || count == 0) return 0;
+	return g_xchg.allreduce(g_xchg.user, buf, count, dtype, op, be->is_device());
+}
+
+// all-gather of a variable-length array living in backend memory -> host vector (rank order)
+template <class T>
+static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int64_t n, std::vector<T> &out)
+{
+	if (!sharded()) {
+		out.resize((size_t)n);
+		return n ? be->fetch(ctx, out.data(), local, (size_t)n * sizeof(T)) : 0;
+	}
+	const int W = g_xchg.world;
+	void *scr;
+	std::vector<int64_t> cnt((size_t)W);
+	BE_CALL(be->scratch(ctx, sizeof(int64_t) * (size_t)(W + 1), &scr), "scratch");
+	BE_CALL(be->put(ctx, scr, &n, sizeof(int64_t)), "put");
+	BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + sizeof(int64_t), sizeof(int64_t), be->is_device()), "allgather(count)");
+	BE_CALL(be->fetch(ctx, cnt.data(), (char *)scr + sizeof(int64_t), sizeof(int64_t) * (size_t)W), "fetch");
+	int64_t mx = *std::max_element(cnt.begin(), cnt.end()), tot = 0;
+	for (int64_t c : cnt) tot += c;
+	out.clear();
+	if (mx == 0) return 0;
+	size_t slot = (size_t)mx * sizeof(T);
+	BE_CALL(be->scratch(ctx, slot * (size_t)(W + 1), &scr), "scratch");
+	if (n) BE_CALL(be->copy(ctx, scr, local, (size_t)n * sizeof(T)), "copy");
+	BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + slot, (int64_t)slot, be->is_device()), "allgather(data)");
+	std::vector<T> all((size_t)mx * (size_t)W);
+	BE_CALL(be->fetch(ctx, all.data(), (char *)scr + slot, slot * (size_t)W), "fetch");
+	out.reserve((size_t)tot);
+	for (int r = 0; r < W; ++r)
+		out.insert(out.end(), all.begin() + (size_t)r * (size_t)mx, all.begin() + (size_t)r * (size_t)mx + (size_t)cnt[(size_t)r]);
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shard packing: host AoS (pg_hit_t, 88 B) -> SoA for the local genomes, file order
+// ---------------------------------------------------------------------------------------------
+static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
+{
+	ext->be = backend_default();
+	ext->local_genomes.clear();
+	ext->is_local.resize((size_t)d->n_genome, 1);
+	ext->hits_sorted.assign((size_t)d->n_genome, 0);
+	for (int32_t j = 0; j < d->n_genome; ++j)
+		if (ext->is_local[(size_t)j]) ext->local_genomes.push_back(j);
+	const int32_t nl = (int32_t)ext->local_genomes.size();
+	int64_t N = 0, E = 0;
+	ext->hit_off.assign((size_t)nl + 1, 0);
+	for (int32_t k = 0; k < nl; ++k) {
+		const pg_genome_t *g = &d->genome[ext->local_genomes[(size_t)k]];
+		N += g->n_hit, E += g->n_exon;
+		ext->hit_off[(size_t)k + 1] = N;
+	}
+	if (d->n_gene >= (1 << 20) || d->n_genome >= (1 << 24) || E >= INT32_MAX || N >= INT32_MAX) return PGA_ERR_RANGE;
+	std::vector<int32_t> pid((size_t)N), cid((size_t)N), rank((size_t)N), sori((size_t)N), sadj((size_t)N), nex((size_t)N), offx((size_t)N),
+		cs((size_t)N), ce((size_t)N), cm((size_t)N), eos((size_t)E), eoe((size_t)E), nctg((size_t)nl), pgid((size_t)d->n_prot);
+	std::vector<uint8_t> rev((size_t)N), gpref((size_t)d->n_gene);
+	int64_t i = 0, ebase = 0;
+	for (int32_t k = 0; k < nl; ++k) {
+		const pg_genome_t *g = &d->genome[ext->local_genomes[(size_t)k]];
+		nctg[(size_t)k] = g->n_ctg;
+		for (int32_t h = 0; h < g->n_hit; ++h, ++i) {
+			const pg_hit_t *a = &g->hit[h];
+			if (a->cs < 0 || a->ce >= INT32_MAX || a->cm < 0 || a->cm >= INT32_MAX || a->ce < a->cs) return PGA_ERR_RANGE;
+			pid[(size_t)i] = a->pid, cid[(size_t)i] = a->cid, rank[(size_t)i] = a->rank, sori[(size_t)i] = a->score_ori, sadj[(size_t)i] = a->score_adj;
+			nex[(size_t)i] = a->n_exon, offx[(size_t)i] = (int32_t)(ebase + a->off_exon);
+			cs[(size_t)i] = (int32_t)a->cs, ce[(size_t)i] = (int32_t)a->ce, cm[(size_t)i] = (int32_t)a->cm, rev[(size_t)i] = a->rev;
+		}
+		for (int32_t e = 0; e < g->n_exon; ++e) eos[(size_t)(ebase + e)] = g->exon[e].os, eoe[(size_t)(ebase + e)] = g->exon[e].oe;
+		ebase += g->n_exon;
+	}
+	for (int32_t p = 0; p < d->n_prot; ++p) pgid[(size_t)p] = d->prot[p].gid;
+	for (int32_t q = 0; q < d->n_gene; ++q) gpref[(size_t)q] = d->gene[q].preferred;
+	pga_shard_t sh;
+	std::memset(&sh, 0, sizeof(sh));
+	sh.n_genome = nl, sh.n_genome_global = d->n_genome, sh.genome_global = ext->local_genomes.data();
+	sh.n_prot = d->n_prot, sh.n_gene = d->n_gene, sh.n_hit = N, sh.n_exon = E;
+	sh.hit_off = ext->hit_off.data(), sh.n_ctg = nctg.data();
+	sh.pid = pid.data(), sh.cid = cid.data(), sh.rank = rank.data(), sh.score_ori = sori.data(), sh.score_adj = sadj.data();
+	sh.n_exon_of = nex.data(), sh.off_exon = offx.data(), sh.cs = cs.data(), sh.ce = ce.data(), sh.cm = cm.data(), sh.rev = rev.data();
+	sh.exon_os = eos.data(), sh.exon_oe = eoe.data(), sh.prot_gid = pgid.data(), sh.gene_pref = gpref.data();
+	pga_params_t par;
+	std::memset(&par, 0, sizeof(par));
+	par.min_ov_ratio = opt->min_ov_ratio;
+	par.check_strand = !!(opt->flag & PG_F_CHECK_STRAND);
+	par.drop_sgl_exon = !!(opt->flag & PG_F_DROP_SGL_EXON);
+	if (ext->ctx) ext->be->destroy(ext->ctx), ext->ctx = nullptr;
+	ext->n_hit_local = N;
+	return ext->be->create(&ext->ctx, &sh, &par);
+}
+
+// Pull per-hit state back and (first time) put the host arrays into cs order, which is how the
+// reference leaves them (hit.c:57-63 replaces g->hit on every sort).
+int sync_host(pg_data_t *d)
+{
+	DataExt *ext = ext_of(d, false);
+	if (ext == nullptr || ext->ctx == nullptr || !ext->host_stale) return g_err;
+	const int64_t N = ext->n_hit_local;
+	std::vector<uint32_t> flags((size_t)N);
+	std::vector<int32_t> rank((size_t)N), sdom((size_t)N), pdom((size_t)N), pdom0((size_t)N), px((size_t)N), py((size_t)N);
+	pga_hit_state_t st = { flags.data(), rank.data(), sdom.data(), pdom.data(), pdom0.data(), px.data(), py.data() };
+	BE_CALL(ext->be->download(ext->ctx, &st), "download");
+	ext->y_order.resize((size_t)d->n_genome);
+	for (size_t k = 0; k < ext->local_genomes.size(); ++k) {
+		int32_t j = ext->local_genomes[k];
+		pg_genome_t *g = &d->genome[j];
+		const int64_t off = ext->hit_off[k];
+		// host order -> file index: identity before the first sync, afterwards the inverse of pos_x
+		if (!ext->hits_sorted[(size_t)j]) {
+			pg_hit_t *a = (pg_hit_t *)std::malloc(sizeof(pg_hit_t) * (size_t)(g->n_hit > 0 ? g->n_hit : 1));
+			for (int32_t f = 0; f < g->n_hit; ++f) a[px[(size_t)(off + f)]] = g->hit[f];
+			std::free(g->hit);
+			g->hit = a, g->m_hit = g->n_hit;
+			ext->hits_sorted[(size_t)j] = 1;
+		}
+		ext->y_order[(size_t)j].assign((size_t)g->n_hit, 0);
+		for (int32_t f = 0; f < g->n_hit; ++f) {
+			const size_t s = (size_t)(off + f);
+			pg_hit_t *h = &g->hit[px[s]];
+			const uint32_t fl = flags[s];
+			h->flt = !!(fl & PGA_F_FLT), h->flt_iso_sub_self = !!(fl & PGA_F_ISO_SUB), h->flt_iso_ov = !!(fl & PGA_F_ISO_OV);
+			h->flt_chain = !!(fl & PGA_F_CHAIN), h->pseudo = !!(fl & PGA_F_PSEUDO), h->vtx = !!(fl & PGA_F_VTX);
+			h->shadow = !!(fl & PGA_F_SHADOW), h->rep = !!(fl & PGA_F_REP), h->weak_br = (fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT;
+			h->rank = rank[s], h->score_dom = sdom[s], h->pid_dom = pdom[s], h->pid_dom0 = pdom0[s];
+			ext->y_order[(size_t)j][(size_t)py[s]] = px[s];
+		}
+	}
+	ext->host_stale = false;
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage A + B
+// ---------------------------------------------------------------------------------------------
+static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
+{
+	DataExt *ext = ext_of(d, true);
+	BE_CALL(build_backend(opt, d, ext), "create");
+	const pga_backend_t *be = ext->be;
+	pga_ctx_t *ctx = ext->ctx;
+	const int32_t nl = (int32_t)ext->local_genomes.size(), P = d->n_prot;
+	if (pg_verbose >= 3)
+		std::fprintf(stderr, "[M::%s::%s] %d genes and %d proteins; %ld hits of %d genomes on backend '%s'\n", __func__, stamp(),
+		             d->n_gene, d->n_prot, (long)ext->n_hit_local, nl, be->name);
+
+	std::vector<int32_t> st4((size_t)nl * 4);
+	BE_CALL(be->ingest(ctx, st4.data()), "ingest"); // read.c:243-260 for every local genome
+	if (pg_verbose >= 3)
+		for (int32_t k = 0; k < nl; ++k) {
+			const pg_genome_t *g = &d->genome[ext->local_genomes[(size_t)k]];
+			std::fprintf(stderr, "[M::pg_read_paf::%s] [%d] %s: %d kept and %d+%d+%d+%d filtered\n", stamp(), ext->local_genomes[(size_t)k],
+			             g->label ? g->label : "-", g->n_hit, st4[(size_t)k*4], st4[(size_t)k*4+1], st4[(size_t)k*4+2], st4[(size_t)k*4+3]);
+		}
+
+	int32_t *b_max; int64_t *b_sum;
+	BE_CALL(be->post_partials(ctx, &b_max, &b_sum), "post_partials");
+	BE_CALL(xreduce(be, b_max, P, PG_X_I32, PG_X_MAX), "allreduce(max_score_ori)");
+	BE_CALL(xreduce(be, b_sum, 6 * (int64_t)P, PG_X_I64, PG_X_SUM), "allreduce(protein sums)");
+	std::vector<int32_t> mx((size_t)P);
+	std::vector<int64_t> sm((size_t)P * 6);
+	if (P) {
+		BE_CALL(be->fetch(ctx, mx.data(), b_max, sizeof(int32_t) * (size_t)P), "fetch");
+		BE_CALL(be->fetch(ctx, sm.data(), b_sum, sizeof(int64_t) * (size_t)P * 6), "fetch");
+	}
+	// pg_cap_score_dom's table (hit.c:230-238) and pg_flag_representative's protein part (hit.c:205-217)
+	std::vector<pg128_t> z((size_t)P);
+	for (int32_t i = 0; i < d->n_gene; ++i) d->gene[i].rep_pid = -1;
+	for (int32_t i = 0; i < P; ++i) {
+		d->prot[i].max_score_ori = mx[(size_t)i];
+		d->prot[i].rep = 0;
+		z[(size_t)i].x = ((uint64_t)sm[(size_t)i] << 32) + (uint64_t)sm[(size_t)P + (size_t)i];
+		z[(size_t)i].y = (uint64_t)i;
+		d->prot[i].n = (int32_t)(uint32_t)z[(size_t)i].x;
+		d->prot[i].avg_score_adj = d->prot[i].n ? (int32_t)((double)(z[(size_t)i].x >> 32) / d->prot[i].n + .499) : 0;
+	}
+	ksort_exact(z.data(), z.size(), [](const pg128_t &a) { return a.x; }); // unstable in the reference; ties reach LN/pp
+	for (int32_t i = P - 1; i >= 0; --i) {
+		int32_t pid = (int32_t)z[(size_t)i].y, gid = d->prot[pid].gid;
+		if (d->gene[gid].rep_pid < 0) d->gene[gid].rep_pid = pid, d->prot[pid].rep = 1;
+	}
+	std::vector<uint8_t> rep((size_t)P), pj((size_t)P, 0);
+	for (int32_t i = 0; i < P; ++i) rep[(size_t)i] = (uint8_t)d->prot[i].rep;
+	if (!(opt->flag & PG_F_NO_JOINT_PSEUDO)) { // per-protein predicate of hit.c:176-181 (doubles, no contraction)
+		for (int32_t i = 0; i < P; ++i) {
+			const int64_t c0 = sm[2 * (size_t)P + (size_t)i], c1 = sm[3 * (size_t)P + (size_t)i];
+			const int64_t s0 = sm[4 * (size_t)P + (size_t)i], s1 = sm[5 * (size_t)P + (size_t)i];
+			const int32_t ic1 = (int32_t)c1, ic0 = (int32_t)c0;
+			bool a = ic1 > 0 && ic1 >= d->n_genome * opt->min_vertex_ratio && ((double)s1 / ic1) / ((double)s0 / ic0) >= 0.99;
+			bool b = (ic1 == 0 || ic1 <= d->n_genome * opt->min_vertex_ratio) && (opt->flag & PG_F_DROP_SGL_EXON);
+			pj[(size_t)i] = a || b;
+		}
+	}
+	int64_t n_pj = 0;
+	BE_CALL(be->post_apply(ctx, rep.data(), pj.data(), &n_pj), "post_apply");
+	if (!(opt->flag & PG_F_NO_JOINT_PSEUDO) && pg_verbose >= 3)
+		std::fprintf(stderr, "[M::%s::%s] %ld pseudogene hits identified jointly\n", __func__, stamp(), (long)n_pj);
+	std::vector<int32_t> st2((size_t)nl * 2);
+	BE_CALL(be->shadow(ctx, 0, st2.data()), "shadow"); // graph.c:20-28
+	if (pg_verbose >= 3)
+		for (int32_t k = 0; k < nl; ++k) {
+			const pg_genome_t *g = &d->genome[ext->local_genomes[(size_t)k]];
+			std::fprintf(stderr, "[M::%s::%s] genome[%d]: %s; %d hits remain, of which %d are shadowed\n", __func__, stamp(),
+			             ext->local_genomes[(size_t)k], g->label ? g->label : "-", st2[(size_t)k*2], st2[(size_t)k*2+1]);
+		}
+	ext->host_stale = true;
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage C helpers (S/A-sized, host)
+// ---------------------------------------------------------------------------------------------
+static void gen_g2s(pg_graph_t *q) // graph.c:49-59
+{
+	const pg_data_t *d = q->d;
+	std::free(q->g2s);
+	q->g2s = (int32_t *)std::malloc(sizeof(int32_t) * (size_t)(d->n_gene > 0 ? d->n_gene : 1));
+	for (int32_t i = 0; i < d->n_gene; ++i) q->g2s[i] = -1;
+	for (int32_t i = 0; i < q->n_seg; ++i) q->g2s[q->seg[i].gid] = i;
+}
+
+static void arc_index(pg_graph_t *q) // graph.c:202-217
+{
+	std::free(q->idx);
+	q->idx = (uint64_t *)std::calloc((size_t)(q->n_seg > 0 ? q->n_seg * 2 : 1), sizeof(uint64_t));
+	for (int32_t i0 = 0, i = 1; i <= q->n_arc; ++i)
+		if (i == q->n_arc || q->arc[i].x >> 32 != q->arc[i0].x >> 32)
+			q->idx[q->arc[i0].x >> 32] = (uint64_t)i0 << 32 | (uint32_t)(i - i0), i0 = i;
+}
+
+// pg_gen_vtx (vertex.c:6-100): counts and sub->dom triples come from the backend, the order-sensitive
+// greedy stays here
+static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
+{
+	pg_data_t *d = q->d;
+	const pga_backend_t *be = ext->be;
+	const int32_t Q = d->n_gene, G = d->n_genome;
+	int32_t *b_cnt; uint64_t *b_tri; int64_t n_tri;
+	BE_CALL(be->vtx_partials(ext->ctx, &b_cnt, &b_tri, &n_tri), "vtx_partials");
+	BE_CALL(xreduce(be, b_cnt, 2 * (int64_t)Q, PG_X_I32, PG_X_SUM), "allreduce(n_dom,n_sub)");
+	std::vector<int32_t> cntv((size_t)Q * 2);
+	if (Q) BE_CALL(be->fetch(ext->ctx, cntv.data(), b_cnt, sizeof(int32_t) * (size_t)Q * 2), "fetch");
+	std::vector<uint64_t> tri;
+	BE_CALL(xgather(be, ext->ctx, b_tri, n_tri, tri), "allgather(triples)");
+
+	// (genome, dom gene) pairs get dense ids; per sub gene the list of pair ids it would mark
+	const uint64_t m20 = (1u << 20) - 1;
+	std::vector<uint64_t> key(tri.size());
+	for (size_t i = 0; i < tri.size(); ++i) key[i] = (tri[i] >> 40) << 20 | (tri[i] & m20);
+	std::vector<uint64_t> uniq(key);
+	std::sort(uniq.begin(), uniq.end());
+	uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+	std::vector<int64_t> sub_off((size_t)Q + 1, 0);
+	for (uint64_t t : tri) ++sub_off[(size_t)((t >> 20) & m20) + 1];
+	for (int32_t g = 0; g < Q; ++g) sub_off[(size_t)g + 1] += sub_off[(size_t)g];
+	std::vector<int32_t> sub_pair(tri.size());
+	{
+		std::vector<int64_t> cur(sub_off.begin(), sub_off.end() - 1);
+		for (size_t i = 0; i < tri.size(); ++i) {
+			int32_t g = (int32_t)((tri[i] >> 20) & m20);
+			sub_pair[(size_t)cur[(size_t)g]++] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), key[i]) - uniq.begin());
+		}
+	}
+	std::vector<uint8_t> marked(uniq.size(), 0);
+	std::vector<int32_t> ycnt((size_t)Q, 0); // #genomes where the gene is dominant and already marked
+
+	std::vector<pg128_t> cnt((size_t)Q);
+	for (int32_t i = 0; i < Q; ++i) { // vertex.c:18-19,47-56
+		cnt[(size_t)i].x = (uint64_t)(int64_t)d->prot[d->gene[i].rep_pid].avg_score_adj;
+		cnt[(size_t)i].y = (uint64_t)i;
+		cnt[(size_t)i].x += (uint64_t)cntv[(size_t)i] << 32;
+		cnt[(size_t)i].y += (uint64_t)cntv[(size_t)Q + (size_t)i] << 32;
+		if (d->gene[i].preferred) cnt[(size_t)i].x |= 1ULL << 63;
+	}
+	ksort_exact(cnt.data(), cnt.size(), [](const pg128_t &a) { return a.x; }); // vertex.c:59, tie order matters
+	q->n_seg = 0;
+	FILE *fp = out_stream();
+	for (int32_t i = Q - 1; i >= 0; --i) { // vertex.c:60-80
+		const int32_t n_dom = (int32_t)(cnt[(size_t)i].x << 1 >> 33), n_sub = (int32_t)(cnt[(size_t)i].y >> 32);
+		const int32_t gid = (int32_t)cnt[(size_t)i].y;
+		const int32_t x = cntv[(size_t)gid], y = ycnt[(size_t)gid];
+		if (opt->flag & PG_F_WRITE_VTX_SEL)
+			std::fprintf(fp, "g\t%s\t%d\t%d\t%d\t%d\t%c\t%c\n", d->gene[gid].name, (int32_t)cnt[(size_t)i].x, x, y, n_sub,
+			             "NY"[d->gene[gid].included], "NY"[d->gene[gid].preferred]);
+		if (d->gene[gid].included || (n_dom >= G * opt->min_vertex_ratio && y < x)) {
+			if (q->n_seg >= q->m_seg) {
+				int32_t old = q->m_seg;
+				q->m_seg = q->n_seg + 1; q->m_seg += (q->m_seg >> 1) + 16;
+				q->seg = (pg_seg_t *)std::realloc(q->seg, sizeof(pg_seg_t) * (size_t)q->m_seg);
+				std::memset((void *)(q->seg + old), 0, sizeof(pg_seg_t) * (size_t)(q->m_seg - old));
+			}
+			pg_seg_t *p = &q->seg[q->n_seg++];
+			p->gid = gid, p->n_dom = n_dom, p->n_sub = n_sub;
+			if (x > 0)
+				for (int64_t k = sub_off[(size_t)gid]; k < sub_off[(size_t)gid + 1]; ++k) {
+					int32_t id = sub_pair[(size_t)k];
+					if (!marked[(size_t)id]) marked[(size_t)id] = 1, ++ycnt[(size_t)(uniq[(size_t)id] & m20)];
+				}
+		}
+	}
+	// segments by gene id (vertex.c:85-94; keys unique, any sort gives the reference's order)
+	std::sort(q->seg, q->seg + q->n_seg, [](const pg_seg_t &a, const pg_seg_t &b) { return a.gid < b.gid; });
+	gen_g2s(q);
+	if (pg_verbose >= 3)
+		std::fprintf(stderr, "[M::%s::%s] selected %d vertices out of %d genes\n", "pg_gen_vtx", stamp(), q->n_seg, Q);
+	return 0;
+}
+
+// pg_gen_arc (graph.c:87-177): per-genome work + local reduce on the backend, cross-shard merge and
+// the three double roundings of graph.c:170-172 here
+static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
+{
+	const pga_backend_t *be = ext->be;
+	const int32_t S = q->n_seg;
+	int32_t *b_seg; pga_arc_part_t *b_arc; int64_t n_loc;
+	BE_CALL(be->arc_round(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), &b_seg, &b_arc, &n_loc), "arc_round");
+	BE_CALL(xreduce(be, b_seg, 2 * (int64_t)S, PG_X_I32, PG_X_SUM), "allreduce(seg counts)");
+	std::vector<int32_t> sc((size_t)S * 2);
+	if (S) BE_CALL(be->fetch(ext->ctx, sc.data(), b_seg, sizeof(int32_t) * (size_t)S * 2), "fetch");
+	for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
+	std::vector<pga_arc_part_t> part;
+	BE_CALL(xgather(be, ext->ctx, b_arc, n_loc, part), "allgather(arcs)");
+	if (sharded()) { // reduce-by-key across shards; sums are integers, so order-independent
+		std::stable_sort(part.begin(), part.end(), [](const pga_arc_part_t &a, const pga_arc_part_t &b) { return a.x < b.x; });
+		size_t k = 0;
+		for (size_t i = 0; i < part.size(); ++i) {
+			if (k > 0 && part[k - 1].x == part[i].x) {
+				part[k - 1].n_genome += part[i].n_genome, part[k - 1].tot_cnt += part[i].tot_cnt;
+				part[k - 1].sum_dist += part[i].sum_dist, part[k - 1].sum_s1 += part[i].sum_s1, part[k - 1].sum_s2 += part[i].sum_s2;
+			} else part[k++] = part[i];
+		}
+		part.resize(k);
+	}
+	if ((int64_t)part.size() > q->m_arc) {
+		q->m_arc = (int32_t)part.size() + ((int32_t)part.size() >> 1) + 16;
+		q->arc = (pg_arc_t *)std::realloc(q->arc, sizeof(pg_arc_t) * (size_t)q->m_arc);
+	}
+	q->n_arc = (int32_t)part.size();
+	for (size_t i = 0; i < part.size(); ++i) {
+		pg_arc_t *p = &q->arc[i];
+		std::memset(p, 0, sizeof(*p));
+		p->x = part[i].x, p->n_genome = part[i].n_genome, p->tot_cnt = part[i].tot_cnt;
+		p->avg_dist = (int32_t)(int64_t)((double)(int64_t)part[i].sum_dist / part[i].tot_cnt + .499);
+		p->s1 = (int32_t)((double)part[i].sum_s1 / part[i].n_genome + .499);
+		p->s2 = (int32_t)((double)part[i].sum_s2 / part[i].n_genome + .499);
+	}
+	return 0;
+}
+
+static int flag_vtx(pg_graph_t *q, DataExt *ext) { return ext->be->flag_vtx(ext->ctx, q->g2s, q->n_seg); }
+
+// pg_flt_high_occ + pg_hard_delete (graph.c:219-263)
+static int flt_high_occ(int32_t max_avg_occ, int32_t max_degree, int32_t max_dist_loci, pg_graph_t *q, DataExt *ext)
+{
+	int32_t n_high_occ = 0, n_high_deg = 0, n_high_loci = 0;
+	for (int32_t i = 0; i < q->n_seg; ++i)
+		if (q->seg[i].tot_cnt > max_avg_occ * q->d->n_genome) q->seg[i].del = 1, ++n_high_occ;
+	for (int32_t i0 = 0, i = 1; i <= q->n_arc; ++i)
+		if (i == q->n_arc || q->arc[i].x >> 32 != q->arc[i0].x >> 32) {
+			int32_t sid = (int32_t)(q->arc[i0].x >> 32 >> 1);
+			if (i - i0 > max_degree && !q->seg[sid].del) q->seg[sid].del = 1, ++n_high_deg;
+			i0 = i;
+		}
+	for (int32_t i = 0; i < q->n_seg; ++i) {
+		pg_seg_t *s = &q->seg[i];
+		int32_t m = s->n_dist_loci[0] > s->n_dist_loci[1] ? s->n_dist_loci[0] : s->n_dist_loci[1];
+		if (m > max_dist_loci && !s->del) s->del = 1, ++n_high_loci;
+	}
+	if (pg_verbose >= 3)
+		std::fprintf(stderr, "[M::%s::%s] filtered %d high-occurrence segments, %d high-degree segments and %d segments connecting distant loci\n",
+		             "pg_flt_high_occ", stamp(), n_high_occ, n_high_deg, n_high_loci);
+	int32_t k = 0;
+	for (int32_t i = 0; i < q->n_seg; ++i) {
+		if (!q->seg[i].del) q->seg[k++] = q->seg[i];
+		else if (pg_verbose >= 3)
+			std::fprintf(stderr, "#del\t%s\tavg_occ=%.1f\tdist_deg=%d,%d\n", q->d->gene[q->seg[i].gid].name,
+			             (double)q->seg[i].tot_cnt / q->d->n_genome, q->seg[i].n_dist_loci[0], q->seg[i].n_dist_loci[1]);
+	}
+	q->n_seg = k;
+	gen_g2s(q);
+	return flag_vtx(q, ext);
+}
+
+// pg_mark_branch_flt_arc (branch.c:48-106).  The reference calls pg_n_local (O(#genomes)) once per
+// candidate pair; here all pairs of the round are collected first, counted by one backend call over
+// the local genomes (+ one all-reduce), then the marking logic replays over the counts.
+static int mark_branch_flt_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
+{
+	const pga_backend_t *be = ext->be;
+	const uint32_t n_vtx = (uint32_t)q->n_seg * 2;
+	uint32_t n_flt1 = 0, n_flt2 = 0;
+	const int32_t frag_mode = !!(opt->flag & PG_F_FRAG_MODE);
+	BE_CALL(be->rep_pos(ext->ctx), "rep_pos");
+	for (int32_t j = 0; j < q->n_seg; ++j) q->seg[j].n_dist_loci[0] = q->seg[j].n_dist_loci[1] = 0;
+	std::vector<int32_t> pairs, max_gid;
+	auto seg_gid = [&](const pg_arc_t &a) { return q->seg[(uint32_t)a.x >> 1].gid; };
+	for (int pass = 0; pass < 2; ++pass) {
+		std::vector<int32_t> cnt;
+		size_t cur = 0;
+		if (pass == 1) {
+			int32_t *b_cnt;
+			const int64_t np = (int64_t)pairs.size() / 2;
+			BE_CALL(be->n_local(ext->ctx, pairs.data(), np, opt->local_dist, opt->local_count, frag_mode, &b_cnt), "n_local");
+			BE_CALL(xreduce(be, b_cnt, np, PG_X_I32, PG_X_SUM), "allreduce(n_local)");
+			cnt.resize((size_t)np);
+			if (np) BE_CALL(be->fetch(ext->ctx, cnt.data(), b_cnt, sizeof(int32_t) * (size_t)np), "fetch");
+		}
+		auto n_local = [&](int32_t g1, int32_t g2) -> int32_t {
+			if (pass == 0) { pairs.push_back(g1), pairs.push_back(g2); return 0; }
+			return cnt[cur++];
+		};
+		for (uint32_t v = 0; v < n_vtx; ++v) {
+			const int32_t n = (int32_t)q->idx[v];
+			pg_arc_t *a = &q->arc[q->idx[v] >> 32];
+			if (n < 2) continue;
+			int32_t max_s1 = 0;
+			for (int32_t i = 0; i < n; ++i) max_s1 = max_s1 > a[i].s1 ? max_s1 : a[i].s1;
+			max_gid.clear();
+			for (int32_t i = 0; i < n; ++i)
+				if (a[i].s1 == max_s1) max_gid.push_back(seg_gid(a[i]));
+			for (int32_t i = 0; i < n; ++i) {
+				double r = 1.0 - (double)a[i].s1 / max_s1;
+				if (r > opt->branch_diff) {
+					int32_t nl = 0, gid = seg_gid(a[i]);
+					for (int32_t g : max_gid) nl += n_local(g, gid);
+					if (pass == 1) {
+						if ((nl == 0 && r > opt->branch_diff_dist) || r > opt->branch_diff_cut) a[i].weak_br = 2, ++n_flt2;
+						else a[i].weak_br = 1, ++n_flt1;
+					}
+				}
+			}
+			// n_dist_loci (branch.c:81-90): pg_n_local is evaluated for every i<j before the tmp[j]==0 test
+			std::vector<int32_t> grp((size_t)n, 0);
+			int32_t n_group = 0;
+			for (int32_t i = 0; i < n; ++i) {
+				if (grp[(size_t)i] == 0) grp[(size_t)i] = ++n_group;
+				for (int32_t j = i + 1; j < n; ++j)
+					if (n_local(seg_gid(a[i]), seg_gid(a[j])) > 0 && grp[(size_t)j] == 0) grp[(size_t)j] = grp[(size_t)i];
+			}
+			if (pass == 1) q->seg[v >> 1].n_dist_loci[v & 1] = n_group;
+		}
+	}
+	if (pg_verbose >= 3)
+		std::fprintf(stderr, "[M::%s::%s] marked %u locally diverged branches and %u distantly diverged branches\n", "pg_mark_branch_flt_arc", stamp(), n_flt1, n_flt2);
+	return 0;
+}
+
+static int mark_branch_flt_hit(pg_graph_t *q, DataExt *ext) // branch.c:108-145
+{
+	std::vector<uint64_t> ax((size_t)q->n_arc);
+	std::vector<uint8_t> aw((size_t)q->n_arc);
+	for (int32_t i = 0; i < q->n_arc; ++i) ax[(size_t)i] = q->arc[i].x, aw[(size_t)i] = (uint8_t)q->arc[i].weak_br;
+	int64_t n = 0;
+	BE_CALL(ext->be->mark_hits(ext->ctx, ax.data(), aw.data(), q->n_arc, &n), "mark_hits");
+	if (pg_verbose >= 3)
+		std::fprintf(stderr, "[M::%s::%s] marked %ld diverged hits\n", "pg_mark_branch_flt_hit", stamp(), (long)n);
+	return 0;
+}
+
+static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
+{
+	DataExt *ext = ext_of(q->d, false);
+	if (ext == nullptr || ext->ctx == nullptr) { set_error(PGA_ERR_ARG, "pg_graph_gen: pg_post_process has not run"); return PGA_ERR_ARG; }
+	const pga_backend_t *be = ext->be;
+	pga_ctx_t *ctx = ext->ctx;
+	// graph 1: initial vertices (graph.c:284-291)
+	BE_CALL(be->set_filter(ctx, PGA_FLT_PSEUDO), "set_filter");
+	BE_CALL(gen_vtx(opt, q, ext), "gen_vtx");
+	BE_CALL(flag_vtx(q, ext), "flag_vtx");
+	BE_CALL(be->set_filter(ctx, PGA_FLT_VTX0), "set_filter");
+	BE_CALL(gen_arc(opt, q, ext), "gen_arc");
+	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-1 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
+	// graph 2: after removing high-occurrence vertices (graph.c:293-298)
+	BE_CALL(flt_high_occ(opt->max_avg_occ * 2, opt->max_degree * 2, opt->max_dist_loci, q, ext), "flt_high_occ");
+	BE_CALL(be->set_filter(ctx, PGA_FLT_VTX0), "set_filter");
+	BE_CALL(gen_arc(opt, q, ext), "gen_arc");
+	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-2 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
+	// graph 3: branch filtering (graph.c:300-315)
+	for (int32_t i = 0; i < opt->n_branch_flt; ++i) {
+		double r = 1.0 + (double)(opt->n_branch_flt - 1 - i) / opt->n_branch_flt;
+		int32_t max_avg_occ = (int32_t)(opt->max_avg_occ * r + .499);
+		int32_t max_degree = (int32_t)(opt->max_degree * r + .499);
+		int32_t max_dist_loci = (int32_t)(opt->max_dist_loci * r + .499);
+		arc_index(q);
+		BE_CALL(mark_branch_flt_arc(opt, q, ext), "mark_branch_flt_arc");
+		BE_CALL(mark_branch_flt_hit(q, ext), "mark_branch_flt_hit");
+		BE_CALL(be->set_filter(ctx, PGA_FLT_WEAK2), "set_filter");
+		if (i > 0) {
+			BE_CALL(flt_high_occ(max_avg_occ, max_degree, max_dist_loci, q, ext), "flt_high_occ");
+			BE_CALL(be->set_filter(ctx, PGA_FLT_VTX0), "set_filter");
+		}
+		BE_CALL(gen_arc(opt, q, ext), "gen_arc");
+	}
+	BE_CALL(be->set_filter(ctx, PGA_FLT_SHADOW), "set_filter"); // graph.c:316
+	if (opt->min_arc_cnt > 1) { // graph.c:191-200
+		int32_t k = 0, n_aflt = 0;
+		for (int32_t i = 0; i < q->n_arc; ++i) {
+			if (q->arc[i].n_genome < opt->min_arc_cnt) { ++n_aflt; continue; }
+			q->arc[k++] = q->arc[i];
+		}
+		q->n_arc = k;
+		if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] filtered %d low-occurrence arcs\n", "pg_graph_cut_low_arc", stamp(), n_aflt);
+	}
+	arc_index(q);
+	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-3 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
+	ext->host_stale = true;
+	pga_hazard_t hz;
+	if (be->hazards(ctx, &hz) == 0 && (hz.h1_head_tie | hz.h2_cm_tie | hz.h3_dom_tie) && pg_verbose >= 2)
+		std::fprintf(stderr, "[W::%s] tie-order hazards seen (head-tie %ld, cm-tie %ld, dominator-tie %ld): output may differ from the reference's unstable sort order\n",
+		             "pg_graph_gen", (long)hz.h1_head_tie, (long)hz.h2_cm_tie, (long)hz.h3_dom_tie);
+	return sync_host(q->d);
+}
+
+} // namespace pgx
+
+using namespace pgx;
+
+extern "C" {
+
+void pg_opt_init(pg_opt_t *opt) // defaults of option.c:9-25
+{
+	std::memset(opt, 0, sizeof(*opt));
+	opt->gene_delim = ':';
+	opt->min_prot_iden = 0.5, opt->min_prot_ratio = 0.5, opt->score_adj_coef = 2.0;
+	opt->min_ov_ratio = 0.5, opt->min_vertex_ratio = 0.05;
+	opt->max_avg_occ = 10, opt->max_degree = 15, opt->max_dist_loci = 3;
+	opt->n_branch_flt = 15, opt->min_arc_cnt = 1;
+	opt->local_dist = 2000000, opt->local_count = 10;
+	opt->branch_diff = 0.02, opt->branch_diff_dist = 0.05, opt->branch_diff_cut = 0.5;
+}
+
+void pg_post_process(const pg_opt_t *opt, pg_data_t *d)
+{
+	g_err = 0;
+	double t = now_sec();
+	post_process_impl(opt, d);
+	g_path_sec = now_sec() - t;
+	DataExt *ext = ext_of(d, false);
+	g_path_hits = ext ? ext->n_hit_local : 0;
+	int32_t n_pref = 0;
+	for (int32_t i = 0; i < d->n_gene; ++i) n_pref += d->gene[i].preferred;
+	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s] there are %d preferred genes\n", __func__, n_pref);
+}
+
+pg_graph_t *pg_graph_init(pg_data_t *d) // graph.c:34-41
+{
+	pg_graph_t *g = (pg_graph_t *)std::calloc(1, sizeof(pg_graph_t));
+	g->d = d;
+	g->m_seg = d->n_gene > 0 ? d->n_gene : 1;
+	g->seg = (pg_seg_t *)std::calloc((size_t)g->m_seg, sizeof(pg_seg_t));
+	return g;
+}
+
+void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
+{
+	double t = now_sec();
+	if (g_err == 0 && graph_gen_impl(opt, q) != 0) q->n_arc = 0;
+	g_path_sec += now_sec() - t;
+}
+
+void pg_graph_destroy(pg_graph_t *q) // graph.c:43-47
+{
+	if (q == nullptr) return;
+	std::free(q->g2s); std::free(q->seg); std::free(q->arc); std::free(q->idx);
+	std::free(q);
+}
+
+int pg_last_error(void) { return g_err; }
+const char *pg_last_error_str(void) { return g_errstr; }
+double pg_last_path_seconds(void) { return g_path_sec; }
+int64_t pg_last_path_hits(void) { return g_path_hits; }
+
+void pg_set_exchange(const pg_exchange_t *x)
+{
+	if (x) g_xchg = *x, g_has_xchg = true;
+	else g_has_xchg = false;
+}
+
+} // extern "C"

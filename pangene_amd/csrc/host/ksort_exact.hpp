@@ -1,0 +1,67 @@
+// ksort_exact.hpp -- order-exact restatement of the reference's 64-bit-key sort (ksort.h:34-87):
+// an in-place MSD ("American flag") radix sort on 8-bit digits starting at the top byte, which hands
+// any bucket of <= 64 elements to a stable insertion sort.  The sort is UNSTABLE for bigger inputs and
+// the order it leaves among equal keys reaches the GFA through two host-side sorts (proteins by
+// sum-score, hit.c:209; genes by preferred|n_dom|avg_score, vertex.c:59), so those two call sites must
+// reproduce it exactly.  Same element moves as the reference, own formulation.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <utility>
+
+namespace pgx {
+
+template <class T, class KeyFn>
+static void ks_insertion(T *a, size_t n, KeyFn key)
+{
+	for (size_t i = 1; i < n; ++i) {
+		if (key(a[i]) < key(a[i - 1])) {
+			T t = a[i];
+			size_t j = i;
+			while (j > 0 && key(t) < key(a[j - 1])) { a[j] = a[j - 1]; --j; }
+			a[j] = t;
+		}
+	}
+}
+
+template <class T, class KeyFn>
+static void ks_flag_pass(T *a, size_t n, int shift, KeyFn key)
+{
+	size_t head[256], tail[256], cnt[256] = {0};
+	for (size_t i = 0; i < n; ++i) ++cnt[(key(a[i]) >> shift) & 0xff];
+	size_t acc = 0;
+	for (int b = 0; b < 256; ++b) { head[b] = acc; acc += cnt[b]; tail[b] = acc; }
+	// cycle-leader permutation: the element carried out of bucket k is dropped at the write cursor of
+	// its own bucket, whatever sits there is carried on, until something that belongs to k comes back
+	for (int k = 0; k < 256;) {
+		if (head[k] == tail[k]) { ++k; continue; }
+		unsigned l = (unsigned)((key(a[head[k]]) >> shift) & 0xff);
+		if ((int)l == k) { ++head[k]; continue; }
+		T carry = a[head[k]];
+		do {
+			std::swap(carry, a[head[l]]);
+			++head[l];
+			l = (unsigned)((key(carry) >> shift) & 0xff);
+		} while ((int)l != k);
+		a[head[k]++] = carry;
+	}
+	if (shift == 0) return;
+	int next = shift > 8 ? shift - 8 : 0;
+	size_t st = 0;
+	for (int b = 0; b < 256; ++b) {
+		size_t m = cnt[b];
+		if (m > 64) ks_flag_pass(a + st, m, next, key);
+		else if (m > 1) ks_insertion(a + st, m, key);
+		st += m;
+	}
+}
+
+// sorts [a, a+n) ascending by the uint64_t key(a[i]) with exactly the reference's tie order
+template <class T, class KeyFn>
+static void ksort_exact(T *a, size_t n, KeyFn key)
+{
+	if (n <= 64) ks_insertion(a, n, key);
+	else ks_flag_pass(a, n, 56, key);
+}
+
+} // namespace pgx

@@ -1,0 +1,350 @@
+// paf_reader.cpp -- host-side PAF ingest for the drop-in surface: pg_data_init/destroy, pg_read_paf,
+// pg_scan_paf_ids, pg_read_list_dict.  Text parsing is outside the accelerated path (SURVEY.md section 2:
+// "must be rebuilt on host"); what matters here is that ids, ranks, exon lists, cm and score_adj come
+// out exactly as the reference's reader produces them (read.c:107-236, hit.c:14-27), because
+// pg_hash_uint32(pid) and the first-seen numbering are score-relevant downstream.
+#include <zlib.h>
+#include <cctype>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include "pg_internal.hpp"
+
+namespace pgx {
+
+static std::unordered_map<const pg_data_t *, DataExt *> g_ext;
+static std::mutex g_ext_mu;
+
+DataExt *ext_of(const pg_data_t *d, bool create)
+{
+	std::lock_guard<std::mutex> lk(g_ext_mu);
+	auto it = g_ext.find(d);
+	if (it != g_ext.end()) return it->second;
+	if (!create) return nullptr;
+	DataExt *e = new DataExt();
+	g_ext.emplace(d, e);
+	return e;
+}
+
+void ext_drop(const pg_data_t *d)
+{
+	std::lock_guard<std::mutex> lk(g_ext_mu);
+	auto it = g_ext.find(d);
+	if (it == g_ext.end()) return;
+	DataExt *e = it->second;
+	if (e->ctx && e->be) e->be->destroy(e->ctx);
+	delete e;
+	g_ext.erase(it);
+}
+
+// gz-or-plain line source (zlib reads plain files transparently, as the reference's gzopen does)
+class LineSource {
+public:
+	explicit LineSource(const char *fn) {
+		fp_ = (fn && std::strcmp(fn, "-") != 0) ? gzopen(fn, "r") : gzdopen(0, "r");
+		if (fp_) gzbuffer(fp_, 1 << 18);
+		buf_.resize(1 << 16);
+	}
+	~LineSource() { if (fp_) gzclose(fp_); }
+	bool ok() const { return fp_ != nullptr; }
+	// next line without the '\n'; a trailing '\r' is dropped when the line is longer than one char
+	bool next(std::string &line) {
+		line.clear();
+		if (eof_ && beg_ >= end_) return false;
+		bool got = false;
+		for (;;) {
+			if (beg_ >= end_) {
+				if (eof_) break;
+				int n = gzread(fp_, buf_.data(), (unsigned)buf_.size());
+				beg_ = 0, end_ = n > 0 ? n : 0;
+				if (end_ < (int)buf_.size()) eof_ = true;
+				if (end_ == 0) break;
+			}
+			const char *p = (const char *)std::memchr(buf_.data() + beg_, '\n', end_ - beg_);
+			int stop = p ? (int)(p - buf_.data()) : end_;
+			line.append(buf_.data() + beg_, stop - beg_);
+			got = true;
+			beg_ = stop + 1;
+			if (p) break;
+		}
+		if (!got) return false;
+		if (line.size() > 1 && line.back() == '\r') line.pop_back();
+		return true;
+	}
+private:
+	gzFile fp_ = nullptr;
+	std::vector<char> buf_;
+	int beg_ = 0, end_ = 0;
+	bool eof_ = false;
+};
+
+// grow helpers keeping the reference's malloc/realloc ownership (pg_data_destroy frees with free())
+template <class T> static void grow0(T *&ptr, int32_t idx, int32_t &cap)
+{
+	if (idx < cap) return;
+	int32_t old = cap;
+	cap = idx + 1;
+	cap += (cap >> 1) + 16;
+	ptr = (T *)std::realloc(ptr, sizeof(T) * (size_t)cap);
+	std::memset((void *)(ptr + old), 0, sizeof(T) * (size_t)(cap - old));
+}
+
+// coordinate of the middle CDS base (hit.c:14-27)
+static int64_t middle_cds(int64_t cs, const pg_exon_t *e, int32_t n)
+{
+	int32_t tot = 0;
+	for (int32_t i = 0; i < n; ++i) tot += e[i].oe - e[i].os;
+	int32_t half = tot >> 1, acc = 0;
+	for (int32_t i = 0; i < n; ++i) {
+		int32_t l = e[i].oe - e[i].os;
+		if (acc <= half && half < acc + l) return cs + e[i].os + half - acc;
+		acc += l;
+	}
+	return -1; // zero-length CDS; the reference aborts here (hit.c:25)
+}
+
+// miniprot CIGAR -> exon list in ascending contig coordinates (read.c:47-90).  Returns false when the
+// CIGAR does not span ce-cs (the reference asserts, read.c:75).
+static bool cigar_to_exons(const char *cg, bool rev, int64_t span, std::vector<pg_exon_t> &ex, int32_t *n_fs)
+{
+	ex.clear();
+	ex.push_back(pg_exon_t{0, 0});
+	int64_t x = 0;
+	int32_t fs = 0;
+	const char *p = cg;
+	while (*p) {
+		char *r;
+		int64_t l = std::strtol(p, &r, 10);
+		char op = *r;
+		if (op == 'N' || op == 'U' || op == 'V') {
+			int64_t st, en;
+			if (op == 'N') st = x, en = x + l;
+			else if (op == 'U') st = x + 1, en = x + l - 2;
+			else st = x + 2, en = x + l - 1;
+			ex.back().oe = (int32_t)st;
+			ex.push_back(pg_exon_t{(int32_t)en, (int32_t)en});
+			x += l;
+		} else if (op == 'M' || op == 'X' || op == '=' || op == 'D') {
+			x += l * 3;
+		} else if (op == 'F' || op == 'G') {
+			x += l, ++fs;
+		}
+		if (op == 0) break;
+		p = r + 1;
+	}
+	ex.back().oe = (int32_t)x;
+	*n_fs = fs;
+	if (x != span) return false;
+	if (rev) { // flip to ascending contig coordinates
+		std::vector<pg_exon_t> t(ex.size());
+		for (size_t i = 0; i < ex.size(); ++i) {
+			const pg_exon_t &s = ex[ex.size() - 1 - i];
+			t[i].os = (int32_t)(x - s.oe), t[i].oe = (int32_t)(x - s.os);
+		}
+		ex.swap(t);
+	}
+	return true;
+}
+
+static char *file_label(const char *fn) // read.c:92-105
+{
+	if (fn == nullptr) return nullptr;
+	int32_t len = (int32_t)std::strlen(fn), en = len, st;
+	int32_t i = len - 1;
+	while (i >= 0 && fn[i] != '/') --i;
+	st = i + 1;
+	if (en >= 3 && std::strncmp(fn + en - 3, ".gz", 3) == 0) en -= 3;
+	if (en >= 4 && std::strncmp(fn + en - 4, ".paf", 4) == 0) en -= 4;
+	if (st >= en) return nullptr;
+	char *label = (char *)std::calloc((size_t)(en - st + 1), 1);
+	std::memcpy(label, fn + st, (size_t)(en - st));
+	return label;
+}
+
+static int32_t read_paf_impl(const pg_opt_t *opt, pg_data_t *d, const char *fn, bool ids_only)
+{
+	LineSource src(fn);
+	if (!src.ok()) return -1;
+	NameDict *dg = (NameDict *)d->d_gene, *dp = (NameDict *)d->d_prot, *dc = (NameDict *)d->d_ctg;
+	const NameDict *excl = (const NameDict *)opt->excl, *incl = (const NameDict *)opt->incl, *pref = (const NameDict *)opt->preferred;
+	DataExt *ext = ext_of(d, true);
+
+	grow0(d->genome, d->n_genome, d->m_genome);
+	pg_genome_t *g = &d->genome[d->n_genome++];
+	std::memset(g, 0, sizeof(*g));
+	g->label = file_label(fn);
+	ext->is_local.resize(d->n_genome, 0);
+	ext->hits_sorted.resize(d->n_genome, 0);
+	ext->is_local[d->n_genome - 1] = ids_only ? 0 : 1;
+
+	std::unordered_map<std::string_view, int32_t> file_ctg; // contig ids are first-seen per file (read.c:190-198)
+	std::vector<int32_t> rank_of;                            // per protein: lines seen in this file (read.c:170)
+	std::vector<int32_t> rank_touched;
+	std::vector<pg_exon_t> ex;
+	std::string line;
+	int32_t n_tot = 0;
+	while (src.next(line)) {
+		++n_tot;
+		pg_hit_t hit;
+		std::memset(&hit, 0, sizeof(hit));
+		hit.pid = hit.pid_dom = hit.cid = hit.off_exon = hit.n_exon = -1;
+		int32_t pid = -1, gid = -1, n_fs = -1, n_stop = -1, cig_fs = 0;
+		bool have_exons = false;
+		char *s = line.data();
+		char *q = s;
+		int32_t col = 0;
+		bool dropped = false;
+		for (char *p = s;; ++p) {
+			if (*p != '\t' && *p != 0) continue;
+			char term = *p;
+			*p = 0;
+			if (col == 0) { // query name: gene<delim>protein (read.c:139-171)
+				char *r = q;
+				while (r < p && *r != opt->gene_delim) ++r;
+				if (excl && excl->get(q) >= 0) { dropped = true; break; }
+				bool has_delim = false;
+				if (*r == opt->gene_delim && r < p) has_delim = true, *r = 0;
+				if (excl && excl->get(q) >= 0) { dropped = true; break; }
+				int32_t is_pref = pref && pref->get(q) >= 0, is_incl = incl && incl->get(q) >= 0;
+				bool absent;
+				gid = dg->put(q, &absent);
+				if (has_delim) *r = (char)opt->gene_delim;
+				if (absent) { d->n_gene++; grow0(d->gene, gid, d->m_gene); }
+				d->gene[gid].name = dg->name(gid);
+				d->gene[gid].preferred = is_pref, d->gene[gid].included = is_incl;
+				pid = dp->put(q, &absent);
+				if (absent) { d->n_prot++; grow0(d->prot, pid, d->m_prot); }
+				d->prot[pid].name = dp->name(pid);
+				d->prot[pid].gid = gid;
+				d->prot[pid].len = 0;
+				hit.pid = pid;
+				if ((int32_t)rank_of.size() <= pid) rank_of.resize((size_t)pid + 1 + (pid >> 1), -1);
+				if (rank_of[pid] < 0) rank_touched.push_back(pid);
+				hit.rank = ++rank_of[pid];
+			} else if (col == 1) {
+				int32_t len = (int32_t)std::strtol(q, nullptr, 10);
+				d->prot[pid].len = len;
+				if ((int32_t)d->gene[gid].len < len) d->gene[gid].len = (uint32_t)len;
+				if (ids_only) { dropped = true; break; }
+			} else if (col == 2) hit.qs = (int32_t)std::strtol(q, nullptr, 10);
+			else if (col == 3) {
+				hit.qe = (int32_t)std::strtol(q, nullptr, 10);
+				if (hit.qe - hit.qs < d->prot[pid].len * opt->min_prot_ratio) { dropped = true; break; }
+			} else if (col == 4) {
+				if (*q != '+' && *q != '-') { dropped = true; break; }
+				hit.rev = *q == '+' ? 0 : 1;
+			} else if (col == 5) {
+				auto it = file_ctg.find(std::string_view(q));
+				if (it == file_ctg.end()) {
+					bool a2;
+					int32_t gc = dc->put(q, &a2);
+					grow0(g->ctg, g->n_ctg, g->m_ctg);
+					g->ctg[g->n_ctg].name = dc->name(gc);
+					it = file_ctg.emplace(std::string_view(dc->name(gc)), g->n_ctg).first;
+					g->n_ctg++;
+				}
+				hit.cid = it->second;
+			} else if (col == 6) g->ctg[hit.cid].len = std::strtol(q, nullptr, 10);
+			else if (col == 7) hit.cs = std::strtol(q, nullptr, 10);
+			else if (col == 8) hit.ce = std::strtol(q, nullptr, 10);
+			else if (col == 9) hit.mlen = (int32_t)std::strtol(q, nullptr, 10);
+			else if (col == 10) {
+				hit.blen = (int32_t)std::strtol(q, nullptr, 10);
+				if (hit.mlen < hit.blen * opt->min_prot_iden) { dropped = true; break; }
+			} else if (col >= 12) {
+				if (std::strncmp(q, "ms:i:", 5) == 0) { // read.c:212-216: long double exp, then truncation
+					double div = 1.0 - (double)hit.mlen / hit.blen;
+					double uncov = 1.0 - (double)(hit.qe - hit.qs) / d->prot[pid].len;
+					hit.score_ori = (int32_t)std::strtol(q + 5, nullptr, 10);
+					hit.score_adj = (int32_t)(hit.score_ori * expl(-opt->score_adj_coef * (div + uncov)) + .499);
+				} else if (std::strncmp(q, "fs:i:", 5) == 0) n_fs = (int32_t)std::strtol(q + 5, nullptr, 10);
+				else if (std::strncmp(q, "st:i:", 5) == 0) n_stop = (int32_t)std::strtol(q + 5, nullptr, 10);
+				else if (std::strncmp(q, "cg:Z:", 5) == 0) {
+					if (cigar_to_exons(q + 5, hit.rev, hit.ce - hit.cs, ex, &cig_fs)) {
+						grow0(g->exon, g->n_exon + (int32_t)ex.size() - 1, g->m_exon);
+						std::memcpy(g->exon + g->n_exon, ex.data(), ex.size() * sizeof(pg_exon_t));
+						hit.n_exon = (int32_t)ex.size(), hit.off_exon = g->n_exon, hit.lof = cig_fs;
+						g->n_exon += (int32_t)ex.size();
+						have_exons = true;
+					} else if (pg_verbose >= 1) {
+						std::fprintf(stderr, "[W::%s] CIGAR of line %d in '%s' does not span the alignment; hit dropped\n", __func__, n_tot, fn ? fn : "-");
+					}
+				}
+			}
+			q = p + 1, ++col;
+			if (term == 0) break;
+		}
+		if (dropped || !have_exons || hit.n_exon < 1) continue;
+		int32_t lof = (n_fs > 0 ? n_fs : 0) + (n_stop > 0 ? n_stop : 0); // read.c:230-231
+		if (hit.lof < lof) hit.lof = lof;
+		hit.cm = middle_cds(hit.cs, g->exon + hit.off_exon, hit.n_exon);
+		if (hit.cm < 0) continue;
+		grow0(g->hit, g->n_hit, g->m_hit);
+		g->hit[g->n_hit++] = hit;
+	}
+	if (pg_verbose >= 3)
+		std::fprintf(stderr, "[M::%s::%s] [%d] %s: %d lines parsed, %d hits kept%s\n", __func__, stamp(), d->n_genome - 1,
+		             g->label ? g->label : "-", n_tot, g->n_hit, ids_only ? " (ids only; hits owned by another shard)" : "");
+	return 0;
+}
+
+} // namespace pgx
+
+using namespace pgx;
+
+extern "C" {
+
+pg_data_t *pg_data_init(void)
+{
+	pg_data_t *d = (pg_data_t *)std::calloc(1, sizeof(pg_data_t));
+	d->d_ctg = new NameDict(), d->d_gene = new NameDict(), d->d_prot = new NameDict();
+	return d;
+}
+
+void pg_data_destroy(pg_data_t *d)
+{
+	if (d == nullptr) return;
+	ext_drop(d);
+	for (int32_t i = 0; i < d->n_genome; ++i) {
+		pg_genome_t *g = &d->genome[i];
+		std::free(g->ctg); std::free(g->hit); std::free(g->exon); std::free(g->label);
+	}
+	std::free(d->genome); std::free(d->gene); std::free(d->prot);
+	delete (NameDict *)d->d_ctg; delete (NameDict *)d->d_gene; delete (NameDict *)d->d_prot;
+	std::free(d);
+}
+
+int32_t pg_read_paf(const pg_opt_t *opt, pg_data_t *d, const char *fn) { return read_paf_impl(opt, d, fn, false); }
+int32_t pg_scan_paf_ids(const pg_opt_t *opt, pg_data_t *d, const char *fn) { return read_paf_impl(opt, d, fn, true); }
+
+// "-X a,b,c" or "-X @file" (first token of each line) -> name set (read.c:265-318)
+void *pg_read_list_dict(const char *o)
+{
+	NameDict *nd = new NameDict();
+	if (o == nullptr) return nd;
+	if (*o != '@') {
+		const char *q = o;
+		for (const char *p = o;; ++p) {
+			if (*p == ',' || *p == ' ' || *p == '\t' || *p == 0) {
+				if (p > q) nd->put(std::string_view(q, (size_t)(p - q)), nullptr);
+				if (*p == 0) break;
+				q = p + 1;
+			}
+		}
+	} else {
+		LineSource src(o + 1);
+		if (!src.ok()) { delete nd; return nullptr; }
+		std::string line;
+		while (src.next(line)) {
+			size_t n = 0;
+			while (n < line.size() && !std::isspace((unsigned char)line[n])) ++n;
+			nd->put(std::string_view(line.data(), n), nullptr);
+		}
+	}
+	return nd;
+}
+
+void pg_dict_destroy(void *h) { delete (NameDict *)h; }
+
+} // extern "C"

@@ -1,0 +1,69 @@
+// pg_internal.hpp -- host-side internals shared by the reader, the writers and the round driver.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <deque>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+#include "pangene_amd.h"
+#include "pangene_hip.h"
+
+namespace pgx {
+
+// name -> first-seen id map that owns its strings (the reference's dict.c:29-91; ids are insertion
+// order, which is what read.c:151-168 relies on).  c_str() pointers stay valid for the dict's life.
+class NameDict {
+public:
+	int32_t size() const { return (int32_t)names_.size(); }
+	int32_t get(std::string_view s) const {
+		auto it = map_.find(s);
+		return it == map_.end() ? -1 : it->second;
+	}
+	// returns id; *absent tells whether the name was new
+	int32_t put(std::string_view s, bool *absent) {
+		auto it = map_.find(s);
+		if (it != map_.end()) { if (absent) *absent = false; return it->second; }
+		names_.emplace_back(s);
+		int32_t id = (int32_t)names_.size() - 1;
+		map_.emplace(std::string_view(names_.back()), id);
+		if (absent) *absent = true;
+		return id;
+	}
+	const char *name(int32_t id) const { return names_[id].c_str(); }
+private:
+	std::deque<std::string> names_;
+	std::unordered_map<std::string_view, int32_t> map_;
+};
+
+// host-private companion of a pg_data_t (struct layout of pg_data_t itself must not change)
+struct DataExt {
+	std::vector<uint8_t> is_local;     // per genome: hits live in this process
+	std::vector<uint8_t> hits_sorted;  // per genome: host AoS already in X (cs) order
+	const pga_backend_t *be = nullptr;
+	pga_ctx_t *ctx = nullptr;          // backend context (owns the HBM-resident shard)
+	std::vector<int32_t> local_genomes; // global index of each genome in the shard
+	std::vector<int64_t> hit_off;      // shard hit offsets
+	std::vector<std::vector<int32_t>> y_order; // per genome: host index of the k-th hit in cm order
+	bool host_stale = false;           // per-hit flags on the host are older than the backend's
+	int64_t n_hit_local = 0;
+};
+
+DataExt *ext_of(const pg_data_t *d, bool create);
+void ext_drop(const pg_data_t *d);
+
+const pga_backend_t *backend_default();   // link-time selected (HIP in the product)
+
+extern pg_exchange_t g_xchg; extern bool g_has_xchg;
+void set_error(int code, const char *where);
+
+FILE *out_stream();
+
+double now_sec();
+const char *stamp();
+
+// bring the host AoS (flags, rank, dominators, order) up to date with the backend
+int sync_host(pg_data_t *d);
+
+} // namespace pgx

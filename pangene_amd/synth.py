@@ -1,0 +1,403 @@
+"""Seeded synthetic miniprot-PAF generators for the pangene graph-construction path.
+
+The reference ships no benchmark inputs besides test/C4, so the shapes named in
+BASELINE.json are produced here:
+
+  bact(G, P)      : bacterial pangenome -- one contig per genome, single-exon hits, paralog families whose
+                    members have equal length (=> many hits with identical (cs, ce): tie groups),
+                    core/accessory genes, inversions.  bact(100, 5000) ~ 1.0 M hits = BASELINE configs[1].
+  human(G, Q, iso): human-shaped -- multi-exon genes with N/U/V introns, isoforms that share exons,
+                    tandem CNV, tandem paralog pairs, processed single-exon copies, nested genes,
+                    frameshifts, `sample#hap#ctg` contig names (stand-in for HPRC; real HPRC PAFs are
+                    not available offline).
+  fuzz(seed)      : tiny adversarial sets on a coarse coordinate grid (exercises every tie channel of
+                    SURVEY.md section 9.1).
+
+Every generator yields (file_name, text) per genome; RNG stream = f(seed, genome index), so any
+sub-range of genomes can be produced independently (needed for sharding across ranks).
+Only the PAF columns and tags pangene reads are emitted (read.c:128-236 of the reference lists them:
+cols 1-11, ms:i, fs:i, st:i, cg:Z).
+"""
+from __future__ import annotations
+
+import gzip
+import os
+from typing import Iterator, List, Tuple
+
+import numpy as np
+
+__all__ = ["bact", "human", "fuzz", "write_files"]
+
+
+def _rng(seed: int, *stream: int) -> np.random.Generator:
+    return np.random.default_rng([int(seed)] + [int(s) + 1000003 for s in stream])
+
+
+# ----------------------------------------------------------------------------------------------
+# bacterial shape
+# ----------------------------------------------------------------------------------------------
+class _BactModel:
+    """Genome-independent part of bact(G, P): protein lengths, families, base order, gaps."""
+
+    def __init__(self, P: int, seed: int):
+        r = _rng(seed, -1)
+        self.P = P
+        # families: sizes drawn so that mean hits/protein/genome ~ 2.0 (each member of a size-s family
+        # hits all s loci when they are present)
+        fam = np.empty(P, dtype=np.int64)
+        sizes = []
+        i = 0
+        while i < P:
+            u = r.random()
+            s = 1 if u < 0.66 else int(r.integers(2, 7))
+            s = min(s, P - i)
+            fam[i:i + s] = len(sizes)
+            sizes.append(s)
+            i += s
+        self.fam = fam
+        self.n_fam = len(sizes)
+        fam_len = r.integers(80, 601, size=self.n_fam)
+        self.L = fam_len[fam]                                  # aa; equal inside a family
+        # pairwise similarity of paralogs inside one family (one scalar per family)
+        self.fam_sim = r.uniform(0.972, 0.999, size=self.n_fam)
+        self.order = r.permutation(P)                          # shared base gene order
+        self.strand = r.integers(0, 2, size=P)                 # per-gene strand in the base order
+        core = r.random(P) < 0.8
+        self.freq = np.where(core, 1.0, r.uniform(0.05, 0.95, size=P))
+        gap = r.integers(20, 301, size=P)
+        u = r.random(P)
+        gap = np.where(u < 0.10, -r.integers(1, 12, size=P), gap)        # short overlaps, like real operons
+        big = u > 0.985                                                   # substantial overlaps (30-70 %)
+        gap = np.where(big, -(self.L * 3 * r.uniform(0.3, 0.7, size=P)).astype(np.int64), gap)
+        self.gap = gap
+        self.names = np.array(["P%06d" % i for i in range(P)])
+        # members of each family, for fast lookup
+        o = np.argsort(fam, kind="stable")
+        self.fam_members_sorted = o
+        self.fam_start = np.searchsorted(fam[o], np.arange(self.n_fam + 1))
+
+
+def _bact_genome(m: _BactModel, seed: int, j: int) -> str:
+    r = _rng(seed, j)
+    P = m.P
+    present = r.random(P) < m.freq
+    order = m.order[present[m.order]]
+    strand = m.strand[order].copy()
+    n = len(order)
+    for _ in range(int(r.integers(0, 4))):                     # 0-3 inversions of 2-200 genes
+        if n < 4:
+            break
+        ln = int(min(n - 1, r.integers(2, 201)))
+        a = int(r.integers(0, n - ln))
+        order[a:a + ln] = order[a:a + ln][::-1].copy()
+        strand[a:a + ln] = 1 - strand[a:a + ln][::-1]
+    L3 = m.L[order] * 3
+    gap = m.gap[order] + r.integers(-2, 3, size=n)
+    gap = np.maximum(gap, -(L3 * 7 // 10))
+    step = L3 + gap
+    step = np.maximum(step, 1)                                 # keep starts strictly increasing
+    cs = int(r.integers(1000, 5000)) + np.concatenate(([0], np.cumsum(step[:-1])))
+    ce = cs + L3
+    ctg_len = int(ce.max() + r.integers(1000, 5000))
+    ctg = "g%d#0#chr1" % j
+    div = r.uniform(0.0, 0.15)
+    iden_locus = np.clip(1.0 - div * r.uniform(0.5, 1.5, size=n), 0.55, 1.0)
+    locus_of_gene = np.full(P, -1, dtype=np.int64)
+    locus_of_gene[order] = np.arange(n)
+
+    # hits: every protein p (present or not) x every present locus of its family
+    fam_loci_gene = order                                       # gene sitting at each locus
+    fam_of_locus = m.fam[fam_loci_gene]
+    # loci grouped by family
+    lo = np.argsort(fam_of_locus, kind="stable")
+    lstart = np.searchsorted(fam_of_locus[lo], np.arange(m.n_fam + 1))
+    lines: List[str] = []
+    noise = r.uniform(0.985, 1.0, size=4 * n + 16)
+    ni = 0
+    for f in range(m.n_fam):
+        loci = lo[lstart[f]:lstart[f + 1]]
+        if len(loci) == 0:
+            continue
+        members = m.fam_members_sorted[m.fam_start[f]:m.fam_start[f + 1]]
+        for p in members:
+            L = int(m.L[p])
+            hits = []
+            for q in loci:
+                own = fam_loci_gene[q] == p
+                idn = iden_locus[q] if own else iden_locus[q] * m.fam_sim[f] * noise[ni % len(noise)]
+                ni += 1
+                hits.append((idn, int(q)))
+            best = max(h[0] for h in hits)
+            hits = [h for h in hits if h[0] >= 0.97 * best]
+            hits.sort(key=lambda h: (-h[0], h[1]))
+            name = m.names[p]
+            for idn, q in hits:
+                blen = 3 * L
+                mlen = int(blen * idn)
+                ms = int(1.6 * mlen)
+                lines.append("%s\t%d\t0\t%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t0\tms:i:%d\tcg:Z:%dM\n" % (
+                    name, L, L, "+-"[strand[q]], ctg, ctg_len, cs[q], ce[q], mlen, blen, ms, L))
+    return "".join(lines)
+
+
+def bact(G: int, P: int, seed: int = 1, first: int = 0, last: int | None = None) -> Iterator[Tuple[str, str]]:
+    """Yield (file name, PAF text) for genomes first..last-1 of the bact(G, P) set."""
+    m = _BactModel(P, seed)
+    last = G if last is None else last
+    for j in range(first, last):
+        yield ("g%05d.paf" % j, _bact_genome(m, seed, j))
+
+
+# ----------------------------------------------------------------------------------------------
+# human shape
+# ----------------------------------------------------------------------------------------------
+class _HumanModel:
+    def __init__(self, Q: int, iso: float, seed: int, n_chr: int = 24):
+        r = _rng(seed, -2)
+        self.Q, self.n_chr = Q, n_chr
+        self.genes = []
+        chr_of = r.integers(0, n_chr, size=Q)
+        for gid in range(Q):
+            ne = int(min(40, 1 + r.exponential(8.0)))
+            if r.random() < 0.003:
+                ne = int(r.integers(100, 140))
+            ex = r.integers(15, 91, size=ne)                                 # aa per exon
+            intr = r.integers(90, 4001, size=max(ne - 1, 0))
+            ityp = r.integers(0, 3, size=max(ne - 1, 0))                     # 0:N 1:U 2:V
+            n_iso = int(min(8, 1 + r.poisson(max(iso - 1.0, 0.0))))
+            isos = [list(range(ne))]
+            for _ in range(n_iso - 1):
+                keep = list(range(ne))
+                if ne >= 3:
+                    for __ in range(int(r.integers(1, 3))):
+                        if len(keep) > 2:
+                            k = int(r.integers(1, len(keep) - 1))
+                            if r.random() < 0.3:
+                                k = 0                                         # alternative first exon
+                            keep.pop(k)
+                isos.append(keep)
+            self.genes.append(dict(
+                chr=int(chr_of[gid]), strand=int(r.integers(0, 2)), ex=ex, intr=intr, ityp=ityp, isos=isos,
+                spacer=int(r.integers(2000, 50001)),
+                nested=bool(r.random() < 0.02) and gid > 0,
+                paralog=bool(r.random() < 0.04),                             # tandem near-identical pair with next gene
+                processed=bool(r.random() < 0.04 and ne > 1),                # single-exon processed copy elsewhere
+                pp_chr=int(r.integers(0, n_chr)), pp_pos=int(r.integers(10_000, 3_000_000)),
+                sim=float(r.uniform(0.93, 0.995)),
+                name="G%05d" % gid))
+
+
+def _cigar_and_span(ex, intr, ityp, keep, strand, fs_at=-1):
+    """CIGAR in transcript order + genomic (start offset, span) of isoform `keep` of a gene."""
+    # genomic layout of the full gene (forward coordinates): exon i starts at gs[i]
+    ne = len(ex)
+    gs = np.zeros(ne, dtype=np.int64)
+    x = 0
+    for i in range(ne):
+        gs[i] = x
+        x += 3 * int(ex[i])
+        if i < ne - 1:
+            x += int(intr[i])
+    ge = gs + 3 * ex.astype(np.int64)
+    ops = []
+    first, lastx = keep[0], keep[-1]
+    for a, i in enumerate(keep):
+        ops.append("%dM" % int(ex[i]))
+        if a == fs_at:
+            ops.append("1F")
+        if a + 1 < len(keep):
+            nxt = keep[a + 1]
+            gapnt = int(gs[nxt] - ge[i])
+            t = int(ityp[i]) if i < len(ityp) else 0
+            if t == 0 or gapnt < 8:
+                ops.append("%dN" % gapnt)
+            else:                                               # split codon: borrow 3 nt from the intron
+                ops.append("%d%s" % (gapnt, "UV"[t - 1]))
+    span = int(ge[lastx] - gs[first]) + (1 if fs_at >= 0 else 0)
+    if strand:
+        ops = ops[::-1]
+    return "".join(ops), int(gs[first]), span
+
+
+def _human_genome(m: _HumanModel, seed: int, j: int, frag: bool) -> str:
+    r = _rng(seed, j)
+    hap = j % 2 + 1
+    sample = "S%04d" % (j // 2)
+    div = r.uniform(0.0, 0.03)
+    pos = [int(r.integers(5000, 50000)) for _ in range(m.n_chr)]
+    # per-chromosome fragment boundaries
+    lines: List[str] = []
+    chr_len = [0] * m.n_chr
+    recs = []                                                   # (gid, chr, gene start, strand, iden, copy#)
+    prev_locus = None
+    for gid, g in enumerate(m.genes):
+        if r.random() < 0.02:
+            continue                                            # gene absent in this genome
+        c = g["chr"]
+        full_span = int(3 * g["ex"].sum() + g["intr"].sum())
+        if g["nested"] and prev_locus is not None and prev_locus[0] == c and prev_locus[2] > full_span + 200:
+            start = prev_locus[1] + int(r.integers(50, prev_locus[2] - full_span - 50))   # inside previous gene
+        else:
+            start = pos[c] + g["spacer"] + int(r.integers(-500, 501))
+            pos[c] = start + full_span
+        idn = float(np.clip(1.0 - div * r.uniform(0.2, 2.0), 0.6, 1.0))
+        recs.append((gid, c, start, g["strand"], idn, 0))
+        prev_locus = (c, start, full_span)
+        if r.random() < 0.03:                                   # tandem CNV: second copy right after
+            s2 = pos[c] + int(r.integers(1000, 5000))
+            pos[c] = s2 + full_span
+            recs.append((gid, c, s2, g["strand"], idn * float(r.uniform(0.985, 1.0)), 1))
+    for c in range(m.n_chr):
+        chr_len[c] = pos[c] + 100_000
+    nfrag = int(r.integers(8, 20)) if frag else 1
+
+    def ctg_of(c, x, span):
+        if nfrag == 1:
+            return "%s#%d#chr%d" % (sample, hap, c + 1), x, chr_len[c]
+        fl = chr_len[c] // nfrag + 1
+        k = x // fl
+        if (x + span) // fl != k:                               # hit would straddle a break: keep it in fragment k
+            return "%s#%d#chr%d_%d" % (sample, hap, c + 1, k), x - k * fl, fl + span
+        return "%s#%d#chr%d_%d" % (sample, hap, c + 1, k), x - k * fl, fl + span
+
+    by_prot = {}                                                # (gid, iso) -> list of hit tuples
+    order_keys = []
+
+    def add(gid, k, tup):
+        key = (gid, k)
+        if key not in by_prot:
+            by_prot[key] = []
+            order_keys.append(key)
+        by_prot[key].append(tup)
+
+    for (gid, c, start, strand, idn, cp) in recs:
+        g = m.genes[gid]
+        targets = [(gid, 1.0)]
+        if g["paralog"] and gid + 1 < m.Q and len(m.genes[gid + 1]["ex"]) == len(g["ex"]):
+            targets.append((gid + 1, g["sim"]))                 # proteins of the next gene also hit here
+        if gid > 0 and m.genes[gid - 1]["paralog"] and len(m.genes[gid - 1]["ex"]) == len(g["ex"]):
+            targets.append((gid - 1, m.genes[gid - 1]["sim"]))
+        for (tg, sim) in targets:
+            tgene = m.genes[tg]
+            for k, keep in enumerate(tgene["isos"]):
+                if tg != gid:                                   # paralog protein on this locus: use this locus' exon frame
+                    keep = [e for e in keep if e < len(g["ex"])]
+                    if not keep:
+                        continue
+                fs = int(r.integers(0, len(keep))) if r.random() < 0.01 else -1
+                cg, off, span = _cigar_and_span(g["ex"], g["intr"], g["ityp"], keep, strand, fs)
+                plen = int(sum(int(tgene["ex"][e]) for e in tgene["isos"][k]))
+                alen = int(sum(int(g["ex"][e]) for e in keep))
+                qs, qe = 0, min(plen, alen)
+                if r.random() < 0.03:
+                    qe = int(plen * r.uniform(0.4, 0.9))
+                    qe = max(1, min(qe, alen))
+                ii = idn * sim * float(r.uniform(0.995, 1.0))
+                if r.random() < 0.01:
+                    ii *= float(r.uniform(0.4, 0.6))            # junk, filtered by -e
+                blen = 3 * alen + (1 if fs >= 0 else 0)
+                mlen = int(3 * alen * ii)
+                ms = int(1.7 * mlen) - 11 * (len(keep) - 1)
+                name, x, cl = ctg_of(c, start + off, span)
+                add(tg, k, (ms, "%s:T%d\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t0\tms:i:%d\tfs:i:%d\tst:i:0\tcg:Z:%s\n" % (
+                    tgene["name"], k, plen, qs, qe, "+-"[strand], name, cl, x, x + span, mlen, blen, max(ms, 1),
+                    1 if fs >= 0 else 0, cg)))
+    # processed single-exon copies
+    for gid, g in enumerate(m.genes):
+        if not g["processed"] or r.random() < 0.3:
+            continue
+        c = g["pp_chr"]
+        for k, keep in enumerate(g["isos"]):
+            plen = int(sum(int(g["ex"][e]) for e in keep))
+            x = g["pp_pos"] + int(r.integers(-3, 4)) * 3
+            ii = 0.90 * float(r.uniform(0.97, 1.0))
+            mlen = int(3 * plen * ii)
+            ms = int(1.7 * mlen)
+            name, xx, cl = ctg_of(c, x, 3 * plen)
+            add(gid, k, (ms, "%s:T%d\t%d\t0\t%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t0\tms:i:%d\tfs:i:0\tst:i:0\tcg:Z:%dM\n" % (
+                g["name"], k, plen, plen, "+-"[int(r.integers(0, 2))], name, cl, xx, xx + 3 * plen, mlen, 3 * plen, ms, plen)))
+    for key in order_keys:
+        hs = by_prot[key]
+        hs.sort(key=lambda t: -t[0])
+        lines.extend(t[1] for t in hs)
+    return "".join(lines)
+
+
+def human(G: int, Q: int, iso: float = 1.0, seed: int = 1, first: int = 0, last: int | None = None,
+          frag: bool = False, n_chr: int = 24) -> Iterator[Tuple[str, str]]:
+    m = _HumanModel(Q, iso, seed, n_chr)
+    last = G if last is None else last
+    for j in range(first, last):
+        yield ("h%05d.paf" % j, _human_genome(m, seed, j, frag))
+
+
+# ----------------------------------------------------------------------------------------------
+# adversarial fuzz
+# ----------------------------------------------------------------------------------------------
+def fuzz(seed: int, harsh: bool = True) -> Iterator[Tuple[str, str]]:
+    """3-8 genomes, 12-40 genes x 1-3 isoforms x 0-4 hits on a 300-bp grid (SURVEY.md section 10 iii)."""
+    r = _rng(seed, -3)
+    G = int(r.integers(3, 9))
+    n_gene = int(r.integers(12, 41))
+    n_ctg = int(r.integers(1, 3))
+    grid = int(r.integers(25, 201))
+    lens = [30, 60, 100] if harsh else list(range(30, 200, 7))
+    idens = [1.0, 0.9, 0.8] if harsh else [x / 100 for x in range(70, 101)]
+    genes = []
+    for g in range(n_gene):
+        n_iso = int(r.integers(1, 4))
+        ne = int(r.integers(1, 5))
+        genes.append((n_iso, ne))
+    for j in range(G):
+        rj = _rng(seed, j)
+        lines = []
+        for g, (n_iso, ne) in enumerate(genes):
+            base = int(rj.integers(0, grid)) * 300 + 1000
+            c = int(rj.integers(0, n_ctg))
+            strand = int(rj.integers(0, 2))
+            for k in range(n_iso):
+                nh = int(rj.integers(0, 5))
+                hits = []
+                for h in range(nh):
+                    e = int(rj.integers(1, ne + 1)) if rj.random() < 0.7 else 1
+                    ex = [int(rj.choice(lens)) for _ in range(e)]
+                    intr = [int(rj.choice([90, 300, 600])) for _ in range(e - 1)]
+                    if h == 0:
+                        x = base + (0 if rj.random() < 0.6 else int(rj.integers(0, 4)) * 300)
+                        cc, ss = c, strand
+                    else:
+                        x = int(rj.integers(0, grid)) * 300 + 1000
+                        cc, ss = int(rj.integers(0, n_ctg)), int(rj.integers(0, 2))
+                    ops = []
+                    span = 0
+                    for a in range(e):
+                        ops.append("%dM" % ex[a]); span += 3 * ex[a]
+                        if a + 1 < e:
+                            t = int(rj.integers(0, 3))
+                            ops.append("%d%s" % (intr[a], "NUV"[t])); span += intr[a]
+                    if ss:
+                        ops = ops[::-1]
+                    plen = sum(ex)
+                    idn = float(rj.choice(idens))
+                    mlen = int(3 * plen * idn)
+                    ms = int(float(rj.choice([1.5, 1.6, 1.6])) * mlen)
+                    hits.append((ms, "G%03d:T%d\t%d\t0\t%d\t%s\tS%d#1#c%d\t%d\t%d\t%d\t%d\t%d\t0\tms:i:%d\tcg:Z:%s\n" % (
+                        g, k, plen, plen, "+-"[ss], j, cc, 400000, x, x + span, mlen, 3 * plen, ms, "".join(ops))))
+                hits.sort(key=lambda t: -t[0])
+                lines.extend(t[1] for t in hits)
+        yield ("f%02d.paf" % j, "".join(lines))
+
+
+def write_files(gen: Iterator[Tuple[str, str]], out_dir: str, gz: bool = False) -> List[str]:
+    os.makedirs(out_dir, exist_ok=True)
+    paths = []
+    for name, text in gen:
+        p = os.path.join(out_dir, name + (".gz" if gz else ""))
+        if gz:
+            with gzip.open(p, "wt", compresslevel=6) as f:
+                f.write(text)
+        else:
+            with open(p, "w") as f:
+                f.write(text)
+        paths.append(p)
+    return paths
