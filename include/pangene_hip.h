@@ -147,6 +147,13 @@ typedef struct {
 	                   int32_t frag_mode, int32_t **cnt); \
 	/* pg_mark_branch_flt_hit (branch.c:108-145); arcs sorted by x with their weak_br (0 allowed) */ \
 	int  pfx##_mark_hits(pga_ctx_t *ctx, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked); \
+	/* Replace the order inside contig segments by the exact order the reference's unstable radix sort \
+	 * (ksort.h:52-87) leaves there (computed by the host).  which 0 = cs order (the \
+	 * physical array order: index 0 of a genome, first-wins ties), 1 = cm order.  Segment s covers the \
+	 * positions [seg_start[s], seg_start[s] + seg_off[s+1]-seg_off[s]) of local genome seg_genome[s]; \
+	 * file_idx lists the hits to put there by their FILE index inside the genome. */ \
+	int  pfx##_override_order(pga_ctx_t *ctx, int32_t which, int32_t n_seg, const int32_t *seg_genome, const int32_t *seg_start, \
+	                          const int64_t *seg_off, const int32_t *file_idx); \
 	/* copy backend memory to the host / host to backend / backend to backend */ \
 	int  pfx##_fetch(pga_ctx_t *ctx, void *dst_host, const void *src_backend, size_t nbytes); \
 	int  pfx##_put(pga_ctx_t *ctx, void *dst_backend, const void *src_host, size_t nbytes); \
@@ -179,6 +186,7 @@ typedef struct {
 	int  (*rep_pos)(pga_ctx_t *);
 	int  (*n_local)(pga_ctx_t *, const int32_t *, int64_t, int32_t, int32_t, int32_t, int32_t **);
 	int  (*mark_hits)(pga_ctx_t *, const uint64_t *, const uint8_t *, int64_t, int64_t *);
+	int  (*override_order)(pga_ctx_t *, int32_t, int32_t, const int32_t *, const int32_t *, const int64_t *, const int32_t *);
 	int  (*fetch)(pga_ctx_t *, void *, const void *, size_t);
 	int  (*put)(pga_ctx_t *, void *, const void *, size_t);
 	int  (*copy)(pga_ctx_t *, void *, const void *, size_t);

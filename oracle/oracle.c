@@ -677,6 +677,40 @@ int pgo_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_w, int
 	return PGA_OK;
 }
 
+/* exact-order override (see pangene_hip.h): re-permute one contig segment of the X-ordered arrays, or
+ * rewrite a slice of the Y order */
+int pgo_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, const int32_t *seg_genome, const int32_t *seg_start,
+                       const int64_t *seg_off, const int32_t *file_idx)
+{
+	int32_t s;
+	for (s = 0; s < n_seg; ++s) {
+		int32_t j = seg_genome[s];
+		int64_t st = c->off[j], en = c->off[j + 1], p0 = st + seg_start[s], n = seg_off[s + 1] - seg_off[s], i, k;
+		const int32_t *fl = file_idx + seg_off[s];
+		int64_t *inv = MALLOC(int64_t, en - st); /* file index -> current X position */
+		for (i = st; i < en; ++i) inv[c->fidx[i]] = i;
+		if (which == 1) {
+			for (k = 0; k < n; ++k) c->yo[p0 + k] = (int32_t)inv[fl[k]];
+		} else {
+			int32_t *remap = MALLOC(int32_t, en - st);
+#define PERM_ARR(type, arr) do { type *t_ = MALLOC(type, n); for (k = 0; k < n; ++k) t_[k] = c->arr[inv[fl[k]]]; \
+				for (k = 0; k < n; ++k) c->arr[p0 + k] = t_[k]; free(t_); } while (0)
+			for (i = st; i < en; ++i) remap[i - st] = (int32_t)i;
+			for (k = 0; k < n; ++k) remap[inv[fl[k]] - st] = (int32_t)(p0 + k);
+			PERM_ARR(int32_t, pid); PERM_ARR(int32_t, gid); PERM_ARR(int32_t, cid); PERM_ARR(int32_t, rank);
+			PERM_ARR(int32_t, score_ori); PERM_ARR(int32_t, score_adj); PERM_ARR(int32_t, score_dom); PERM_ARR(int32_t, n_exon_of);
+			PERM_ARR(int32_t, off_exon); PERM_ARR(int32_t, cs); PERM_ARR(int32_t, ce); PERM_ARR(int32_t, cm); PERM_ARR(int32_t, cds);
+			PERM_ARR(int32_t, pid_dom); PERM_ARR(int32_t, pid_dom0); PERM_ARR(uint32_t, flags);
+			PERM_ARR(int32_t, fidx); /* last: inv[] was built from it */
+#undef PERM_ARR
+			for (i = st; i < en; ++i) c->yo[i] = remap[c->yo[i] - st];
+			free(remap);
+		}
+		free(inv);
+	}
+	return PGA_OK;
+}
+
 int pgo_fetch(pga_ctx_t *c, void *dst, const void *src, size_t nbytes)
 {
 	(void)c;
@@ -721,7 +755,7 @@ const pga_backend_t *pgo_backend(void)
 {
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
-		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_rep_pos, pgo_n_local, pgo_mark_hits, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
+		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_rep_pos, pgo_n_local, pgo_mark_hits, pgo_override_order, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
 		pgo_hazards, pgo_is_device, pgo_strerror
 	};
 	return &b;

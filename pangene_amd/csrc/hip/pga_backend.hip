@@ -1257,7 +1257,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 {
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
-		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_rep_pos, pga_n_local, pga_mark_hits, pga_fetch, pga_put, pga_copy, pga_scratch,
+		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_rep_pos, pga_n_local, pga_mark_hits, pga_override_order, pga_fetch, pga_put, pga_copy, pga_scratch,
 		pga_download, pga_hazards, pga_is_device, pga_strerror
 	};
 	return &b;
