@@ -189,6 +189,21 @@ void pg_set_exchange(const pg_exchange_t *x);
  * number of hits they processed (local shard). */
 double  pg_last_path_seconds(void);
 int64_t pg_last_path_hits(void);
+double  pg_last_upload_seconds(void);   /* host pack + H2D copy of the last pg_post_process (not part of the path time) */
+
+/* Tie-order policy (see DESIGN.md "bit-identity"): 0 canonical stable order everywhere; 1 (default,
+ * env PANGENE_EXACT=auto) replay the reference's unstable sort for the first contig of genomes whose
+ * leading tie group has >= 2 hits; 2 (PANGENE_EXACT=all) replay it for every contig. */
+void pg_set_exact_mode(int mode);
+
+/* Benchmark support: make the next pg_post_process(opt, d) restart stages A+B+C on the shard that is
+ * already resident in HBM (no re-pack, no PCIe upload).  The host hit arrays are left as they are. */
+int pg_rerun_resident(pg_data_t *d);
+
+/* HIP-event timing of kernel classes of the last run(s): which 0 = stage-A sweep pg_shadow(cal_dom_sc=1)
+ * ("K1", the hit-filter+overlap kernel), 1 = pg_flt_ov_isoform sweep, 2 = the other pg_shadow sweeps. */
+int pg_kernel_timing(pg_data_t *d, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
+int pg_kernel_timing_reset(pg_data_t *d);
 
 #ifdef __cplusplus
 }

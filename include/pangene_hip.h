@@ -113,9 +113,13 @@ typedef struct {
 } pga_hazard_t;
 
 #define PGA_DECLARE(pfx) \
-	/* upload a shard; packs SoA, computes cds lengths, X and Y orders (pg_hit_sort hit.c:29-64) */ \
+	/* copy a shard (file order) into backend memory; nothing is computed yet */ \
 	int  pfx##_create(pga_ctx_t **ctx, const pga_shard_t *sh, const pga_params_t *par); \
 	void pfx##_destroy(pga_ctx_t *ctx); \
+	/* (re)start a run on the resident shard: per-hit constants (gene id, CDS length pg_cds_len \
+	 * overlap.c:45-51, 64-bit score), X and Y orders (pg_hit_sort hit.c:29-64), all state reset to what \
+	 * read.c:133-134 leaves after parsing.  May be called again to repeat the run without re-uploading. */ \
+	int  pfx##_begin(pga_ctx_t *ctx); \
 	/* stage A, read.c:243-260: pg_flag_pseudo, PG_SET_FILTER(pseudo), sort, pg_shadow(cal_dom_sc=1), \
 	 * pid_dom0/reset, pg_flt_ov_isoform, pg_flt_chain_shadow, pg_flt_subopt_isoform. \
 	 * stats: [n_genome*4] n_pseudo, n_flt_ov_iso, n_flt_chain, n_flt_subopt (host; may be NULL) */ \
@@ -175,6 +179,7 @@ typedef struct {
 	const char *name;
 	int  (*create)(pga_ctx_t **, const pga_shard_t *, const pga_params_t *);
 	void (*destroy)(pga_ctx_t *);
+	int  (*begin)(pga_ctx_t *);
 	int  (*ingest)(pga_ctx_t *, int32_t *);
 	int  (*post_partials)(pga_ctx_t *, int32_t **, int64_t **);
 	int  (*post_apply)(pga_ctx_t *, const uint8_t *, const uint8_t *, int64_t *);
@@ -195,6 +200,8 @@ typedef struct {
 	int  (*hazards)(pga_ctx_t *, pga_hazard_t *);
 	int  (*is_device)(void);
 	const char *(*strerror)(int);
+	int  (*timing_reset)(pga_ctx_t *);  /* may be NULL */
+	int  (*timing_get)(pga_ctx_t *, int32_t, double *, int64_t *, int64_t *);
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);

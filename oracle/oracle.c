@@ -49,6 +49,8 @@ struct pga_ctx {
 	int32_t *nl_cnt;
 	pga_hazard_t hz;
 	void *scratch; size_t m_scratch;
+	/* raw shard, file order (kept so that begin() can restart the run) */
+	int32_t *r_pid, *r_cid, *r_rank, *r_sori, *r_sadj, *r_nex, *r_offx, *r_cs, *r_ce, *r_cm; uint8_t *r_rev;
 };
 
 int pgo_is_device(void) { return 0; }
@@ -130,67 +132,81 @@ void pgo_destroy(pga_ctx_t *c)
 	free(c->pid_dom); free(c->pid_dom0); free(c->flags); free(c->yo); free(c->exon_os); free(c->exon_oe);
 	free(c->prot_gid); free(c->gene_pref); free(c->max_ori); free(c->sums); free(c->vtx_cnt); free(c->triples);
 	free(c->g2s); free(c->seg_cnt); free(c->arcs); free(c->rp_x); free(c->rp_y); free(c->nl_cnt); free(c->scratch);
+	free(c->r_pid); free(c->r_cid); free(c->r_rank); free(c->r_sori); free(c->r_sadj); free(c->r_nex); free(c->r_offx); free(c->r_cs); free(c->r_ce); free(c->r_cm); free(c->r_rev);
 	free(c);
 }
 
-/* upload + pg_hit_sort (hit.c:29-64) in canonical order + pg_cds_len (overlap.c:45-51) */
+#define DUP(type, dst, src, n) do { dst = MALLOC(type, n); memcpy(dst, src, (size_t)(n) * sizeof(type)); } while (0)
+
+/* copy the shard (file order) */
 int pgo_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
 {
 	pga_ctx_t *c;
-	int64_t N = sh->n_hit, i, k;
-	int32_t j;
-	skey_t *key;
+	int64_t N = sh->n_hit, i;
 	if (out == 0 || sh == 0 || par == 0) return PGA_ERR_ARG;
 	c = CALLOC(pga_ctx_t, 1);
 	c->n_genome = sh->n_genome, c->n_genome_global = sh->n_genome_global, c->n_prot = sh->n_prot, c->n_gene = sh->n_gene;
 	c->n_hit = N, c->n_exon = sh->n_exon, c->par = *par;
-	c->off = MALLOC(int64_t, sh->n_genome + 1); memcpy(c->off, sh->hit_off, (sh->n_genome + 1) * sizeof(int64_t));
-	c->genome_global = MALLOC(int32_t, sh->n_genome); memcpy(c->genome_global, sh->genome_global, sh->n_genome * sizeof(int32_t));
-	c->n_ctg = MALLOC(int32_t, sh->n_genome); memcpy(c->n_ctg, sh->n_ctg, sh->n_genome * sizeof(int32_t));
-	c->exon_os = MALLOC(int32_t, sh->n_exon); memcpy(c->exon_os, sh->exon_os, sh->n_exon * sizeof(int32_t));
-	c->exon_oe = MALLOC(int32_t, sh->n_exon); memcpy(c->exon_oe, sh->exon_oe, sh->n_exon * sizeof(int32_t));
-	c->prot_gid = MALLOC(int32_t, sh->n_prot); memcpy(c->prot_gid, sh->prot_gid, sh->n_prot * sizeof(int32_t));
-	c->gene_pref = MALLOC(uint8_t, sh->n_gene); memcpy(c->gene_pref, sh->gene_pref, sh->n_gene);
+	DUP(int64_t, c->off, sh->hit_off, sh->n_genome + 1);
+	DUP(int32_t, c->genome_global, sh->genome_global, sh->n_genome);
+	DUP(int32_t, c->n_ctg, sh->n_ctg, sh->n_genome);
+	DUP(int32_t, c->exon_os, sh->exon_os, sh->n_exon); DUP(int32_t, c->exon_oe, sh->exon_oe, sh->n_exon);
+	DUP(int32_t, c->prot_gid, sh->prot_gid, sh->n_prot); DUP(uint8_t, c->gene_pref, sh->gene_pref, sh->n_gene);
+	DUP(int32_t, c->r_pid, sh->pid, N); DUP(int32_t, c->r_cid, sh->cid, N); DUP(int32_t, c->r_rank, sh->rank, N);
+	DUP(int32_t, c->r_sori, sh->score_ori, N); DUP(int32_t, c->r_sadj, sh->score_adj, N); DUP(int32_t, c->r_nex, sh->n_exon_of, N);
+	DUP(int32_t, c->r_offx, sh->off_exon, N); DUP(int32_t, c->r_cs, sh->cs, N); DUP(int32_t, c->r_ce, sh->ce, N); DUP(int32_t, c->r_cm, sh->cm, N);
+	DUP(uint8_t, c->r_rev, sh->rev, N);
 	c->fidx = MALLOC(int32_t, N); c->pid = MALLOC(int32_t, N); c->gid = MALLOC(int32_t, N); c->cid = MALLOC(int32_t, N);
 	c->rank = MALLOC(int32_t, N); c->score_ori = MALLOC(int32_t, N); c->score_adj = MALLOC(int32_t, N);
 	c->score_dom = CALLOC(int32_t, N); c->n_exon_of = MALLOC(int32_t, N); c->off_exon = MALLOC(int32_t, N);
 	c->cs = MALLOC(int32_t, N); c->ce = MALLOC(int32_t, N); c->cm = MALLOC(int32_t, N); c->cds = MALLOC(int32_t, N);
 	c->pid_dom = MALLOC(int32_t, N); c->pid_dom0 = CALLOC(int32_t, N); c->flags = CALLOC(uint32_t, N);
 	c->yo = MALLOC(int32_t, N);
-	key = MALLOC(skey_t, N);
-	for (j = 0; j < sh->n_genome; ++j) { /* X order */
-		int64_t st = sh->hit_off[j], en = sh->hit_off[j + 1];
-		for (i = st; i < en; ++i) key[i].k1 = sh->cid[i], key[i].k2 = sh->cs[i], key[i].k3 = (int32_t)(i - st), key[i].v = (int32_t)(i - st);
-		qsort(key + st, (size_t)(en - st), sizeof(skey_t), skey_cmp);
-		for (i = st; i < en; ++i) {
-			int64_t s = st + key[i].v;
-			int32_t e, len = 0;
-			c->fidx[i] = key[i].v;
-			c->pid[i] = sh->pid[s], c->cid[i] = sh->cid[s], c->rank[i] = sh->rank[s];
-			c->score_ori[i] = sh->score_ori[s], c->score_adj[i] = sh->score_adj[s];
-			c->n_exon_of[i] = sh->n_exon_of[s], c->off_exon[i] = sh->off_exon[s];
-			c->cs[i] = sh->cs[s], c->ce[i] = sh->ce[s], c->cm[i] = sh->cm[s];
-			c->gid[i] = sh->prot_gid[sh->pid[s]];
-			c->flags[i] = sh->rev[s] ? PGA_F_REV : 0;
-			c->pid_dom[i] = -1; /* read.c:134 */
-			for (e = 0; e < sh->n_exon_of[s]; ++e)
-				len += sh->exon_oe[sh->off_exon[s] + e] - sh->exon_os[sh->off_exon[s] + e];
-			c->cds[i] = len;
-		}
-	}
-	for (j = 0; j < sh->n_genome; ++j) { /* Y order */
-		int64_t st = c->off[j], en = c->off[j + 1];
-		for (i = st; i < en; ++i) key[i].k1 = c->cid[i], key[i].k2 = c->cm[i], key[i].k3 = (int32_t)(i - st), key[i].v = (int32_t)i;
-		qsort(key + st, (size_t)(en - st), sizeof(skey_t), skey_cmp);
-		for (k = st; k < en; ++k) c->yo[k] = key[k].v;
-	}
-	free(key);
 	c->max_ori = CALLOC(int32_t, c->n_prot);
 	c->sums = CALLOC(int64_t, 6 * (int64_t)c->n_prot);
 	c->vtx_cnt = CALLOC(int32_t, 2 * (int64_t)c->n_gene);
 	c->g2s = MALLOC(int32_t, c->n_gene);
 	for (i = 0; i < c->n_gene; ++i) c->g2s[i] = -1;
 	*out = c;
+	return PGA_OK;
+}
+
+/* pg_hit_sort (hit.c:29-64) in canonical order + pg_cds_len (overlap.c:45-51); state as read.c:133-134 */
+int pgo_begin(pga_ctx_t *c)
+{
+	int64_t N = c->n_hit, i, k;
+	int32_t j;
+	skey_t *key = MALLOC(skey_t, N);
+	memset(&c->hz, 0, sizeof(c->hz));
+	for (i = 0; i < c->n_gene; ++i) c->g2s[i] = -1;
+	c->n_seg = 0;
+	for (j = 0; j < c->n_genome; ++j) { /* X order */
+		int64_t st = c->off[j], en = c->off[j + 1];
+		for (i = st; i < en; ++i) key[i].k1 = c->r_cid[i], key[i].k2 = c->r_cs[i], key[i].k3 = (int32_t)(i - st), key[i].v = (int32_t)(i - st);
+		qsort(key + st, (size_t)(en - st), sizeof(skey_t), skey_cmp);
+		for (i = st; i < en; ++i) {
+			int64_t s = st + key[i].v;
+			int32_t e, len = 0;
+			c->fidx[i] = key[i].v;
+			c->pid[i] = c->r_pid[s], c->cid[i] = c->r_cid[s], c->rank[i] = c->r_rank[s];
+			c->score_ori[i] = c->r_sori[s], c->score_adj[i] = c->r_sadj[s];
+			c->n_exon_of[i] = c->r_nex[s], c->off_exon[i] = c->r_offx[s];
+			c->cs[i] = c->r_cs[s], c->ce[i] = c->r_ce[s], c->cm[i] = c->r_cm[s];
+			c->gid[i] = c->prot_gid[c->r_pid[s]];
+			c->flags[i] = c->r_rev[s] ? PGA_F_REV : 0;
+			c->pid_dom[i] = -1, c->pid_dom0[i] = 0, c->score_dom[i] = 0; /* read.c:133-134 */
+			for (e = 0; e < c->r_nex[s]; ++e)
+				len += c->exon_oe[c->r_offx[s] + e] - c->exon_os[c->r_offx[s] + e];
+			c->cds[i] = len;
+		}
+	}
+	for (j = 0; j < c->n_genome; ++j) { /* Y order */
+		int64_t st = c->off[j], en = c->off[j + 1];
+		for (i = st; i < en; ++i) key[i].k1 = c->cid[i], key[i].k2 = c->cm[i], key[i].k3 = (int32_t)(i - st), key[i].v = (int32_t)i;
+		qsort(key + st, (size_t)(en - st), sizeof(skey_t), skey_cmp);
+		for (k = st; k < en; ++k) c->yo[k] = key[k].v;
+	}
+	free(key);
 	return PGA_OK;
 }
 
@@ -693,8 +709,12 @@ int pgo_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, const int32_t
 			for (k = 0; k < n; ++k) c->yo[p0 + k] = (int32_t)inv[fl[k]];
 		} else {
 			int32_t *remap = MALLOC(int32_t, en - st);
-#define PERM_ARR(type, arr) do { type *t_ = MALLOC(type, n); for (k = 0; k < n; ++k) t_[k] = c->arr[inv[fl[k]]]; \
-				for (k = 0; k < n; ++k) c->arr[p0 + k] = t_[k]; free(t_); } while (0)
+#define PERM_ARR(type, arr) do { \
+				type *t_ = MALLOC(type, n); \
+				for (k = 0; k < n; ++k) { t_[k] = c->arr[inv[fl[k]]]; } \
+				for (k = 0; k < n; ++k) { c->arr[p0 + k] = t_[k]; } \
+				free(t_); \
+			} while (0)
 			for (i = st; i < en; ++i) remap[i - st] = (int32_t)i;
 			for (k = 0; k < n; ++k) remap[inv[fl[k]] - st] = (int32_t)(p0 + k);
 			PERM_ARR(int32_t, pid); PERM_ARR(int32_t, gid); PERM_ARR(int32_t, cid); PERM_ARR(int32_t, rank);
@@ -754,9 +774,9 @@ int pgo_hazards(pga_ctx_t *c, pga_hazard_t *out) { *out = c->hz; return PGA_OK; 
 const pga_backend_t *pgo_backend(void)
 {
 	static const pga_backend_t b = {
-		"oracle", pgo_create, pgo_destroy, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
+		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
 		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_rep_pos, pgo_n_local, pgo_mark_hits, pgo_override_order, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
-		pgo_hazards, pgo_is_device, pgo_strerror
+		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0
 	};
 	return &b;
 }

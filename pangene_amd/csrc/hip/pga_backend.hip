@@ -54,7 +54,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
+	S_PERM, S_OVPOS, S_OVFILE, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
 	S_COUNT
 };
 
@@ -71,7 +71,8 @@ struct pga_ctx {
 	uint64_t *sc64 = 0;
 	// dynamic per hit
 	int32_t *rank = 0, *sdom = 0, *pdom = 0, *pdom0 = 0; uint32_t *flags = 0;
-	int32_t *yperm = 0, *goff = 0, *ggl = 0;
+	int32_t *yperm = 0, *goff = 0, *ggl = 0, *ctg_base = 0;
+	int cs_bits = 1, cm_bits = 1, seg_bits = 1;
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors
 	int32_t *max_ori = 0; int64_t *sums = 0; int32_t *vtx_cnt = 0; int32_t *g2s = 0; int32_t n_seg = 0;
@@ -760,6 +761,59 @@ __global__ __launch_bounds__(BLOCK) void k_to_file(const int32_t *fidx, const in
 	opy[goff[gnm[x]] + fidx[x]] = h - goff[gnm[x]];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// exact-order overrides (pangene_hip.h): re-permute contig segments of the physical (X) order, or
+// rewrite slices of the Y permutation.  Rare (a few calls per run), not tuned.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_ov_inv(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, int n, int32_t *inv, int32_t *remap)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	inv[goff[gnm[h]] + fidx[h]] = h;
+	remap[h] = h;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_ov_sety(const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv, int32_t *yperm)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i < t) yperm[ov_pos[i]] = inv[ov_file[i]];
+}
+
+struct PermArrays { int32_t *a[16]; uint64_t *sc64; };
+
+__global__ __launch_bounds__(BLOCK) void k_ov_gather(PermArrays p, const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv,
+                                                       int32_t *tmp, uint64_t *tmp64, int32_t *remap)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= t) return;
+	int src = inv[ov_file[i]];
+	remap[src] = ov_pos[i];
+#pragma unroll
+	for (int k = 0; k < 16; ++k) tmp[(int64_t)k * t + i] = p.a[k][src];
+	tmp64[i] = p.sc64[src];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_t *ov_pos, int64_t t, const int32_t *tmp, const uint64_t *tmp64,
+                                                        const int32_t *gnm, const int32_t *goff)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= t) return;
+	int pos = ov_pos[i];
+#pragma unroll
+	for (int k = 0; k < 15; ++k) p.a[k][pos] = tmp[(int64_t)k * t + i];
+	uint32_t f = (uint32_t)tmp[(int64_t)15 * t + i] & ~F_HEAD; // a[15] = flags; the head mark is positional
+	if (pos == goff[gnm[pos]]) f |= F_HEAD;
+	p.a[15][pos] = (int32_t)f;
+	p.sc64[pos] = tmp64[i];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_ov_remap_y(int32_t *yperm, int n, const int32_t *remap)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y < n) yperm[y] = remap[yperm[y]];
+}
+
 // ================================================================================================
 // host side of the ABI
 // ================================================================================================
@@ -840,16 +894,14 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->own_stream = true;
 	HIPCHK(hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(int64_t), hipHostMallocDefault));
 	TRY(dalloc(c, &c->dcnt, 16));
-	HIPCHK(hipMemsetAsync(c->dcnt, 0, 16 * sizeof(int64_t), c->st));
 	// persistent arrays
 	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
 	TRY(dalloc(c, &c->cs, N)); TRY(dalloc(c, &c->ce, N)); TRY(dalloc(c, &c->cm, N)); TRY(dalloc(c, &c->cds, N)); TRY(dalloc(c, &c->nex, N));
 	TRY(dalloc(c, &c->offx, N)); TRY(dalloc(c, &c->sori, N)); TRY(dalloc(c, &c->sadj, N)); TRY(dalloc(c, &c->pm, N)); TRY(dalloc(c, &c->sc64, N));
 	TRY(dalloc(c, &c->rank, N)); TRY(dalloc(c, &c->sdom, N)); TRY(dalloc(c, &c->pdom, N)); TRY(dalloc(c, &c->pdom0, N)); TRY(dalloc(c, &c->flags, N));
-	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->exon, E));
+	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->ctg_base, GL + 1)); TRY(dalloc(c, &c->exon, E));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q));
 	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
-	if (c->Q) hipLaunchKernelGGL(k_fill_i32, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, (int64_t)c->Q, -1);
 
 	// host-side small tables
 	std::vector<int32_t> ctg_base((size_t)GL + 1, 0);
@@ -863,52 +915,65 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		if (sh->cs[i] < 0 || sh->ce[i] < sh->cs[i] || sh->cm[i] < 0 || sh->cid[i] < 0) return PGA_ERR_RANGE;
 		max_cs = std::max(max_cs, (uint32_t)sh->cs[i]), max_cm = std::max(max_cm, (uint32_t)sh->cm[i]);
 	}
-	const int cs_bits = bits_for(max_cs), cm_bits = bits_for(max_cm), seg_bits = bits_for((uint32_t)std::max(1, c->n_seg_ctg));
+	c->cs_bits = bits_for(max_cs), c->cm_bits = bits_for(max_cm), c->seg_bits = bits_for((uint32_t)std::max(1, c->n_seg_ctg));
 	std::vector<int2> hex((size_t)E);
 	for (int e = 0; e < E; ++e) hex[(size_t)e] = make_int2(sh->exon_os[e], sh->exon_oe[e]);
 
-	// file-order staging (freed with the pool entries being reused later)
+	// the shard in file order stays resident (S_UPLOAD) so that begin() can restart a run without PCIe traffic
 	int32_t *up = (int32_t *)c->pool.get(S_UPLOAD, sizeof(int32_t) * (size_t)N * 16 + 64);
-	int32_t *d_ctg_base = (int32_t *)c->pool.get(S_MISC, sizeof(int32_t) * ((size_t)GL + 1));
-	if (!up || !d_ctg_base) return PGA_ERR_NOMEM;
+	if (!up) return PGA_ERR_NOMEM;
+	TRY(upload(c, up, sh->pid, N)); TRY(upload(c, up + (size_t)N, sh->cid, N)); TRY(upload(c, up + 2 * (size_t)N, sh->rank, N));
+	TRY(upload(c, up + 3 * (size_t)N, sh->score_ori, N)); TRY(upload(c, up + 4 * (size_t)N, sh->score_adj, N));
+	TRY(upload(c, up + 5 * (size_t)N, sh->n_exon_of, N)); TRY(upload(c, up + 6 * (size_t)N, sh->off_exon, N));
+	TRY(upload(c, up + 7 * (size_t)N, sh->cs, N)); TRY(upload(c, up + 8 * (size_t)N, sh->ce, N)); TRY(upload(c, up + 9 * (size_t)N, sh->cm, N));
+	TRY(upload(c, (uint8_t *)(up + 14 * (size_t)N), sh->rev, N));
+	TRY(upload(c, c->goff, c->h_goff.data(), (size_t)GL + 1)); TRY(upload(c, c->ggl, c->h_ggl.data(), GL));
+	TRY(upload(c, c->ctg_base, ctg_base.data(), (size_t)GL + 1));
+	TRY(upload(c, c->exon, hex.data(), E)); TRY(upload(c, c->prot_gid, sh->prot_gid, c->P)); TRY(upload(c, c->gene_pref, sh->gene_pref, c->Q));
+	{ // work buffers shared by every sort / scan of the run: sized for the largest input (2N temp arcs)
+		const int64_t W = 2 * (int64_t)N + 2;
+		if (!c->pool.get(S_KEY_A, sizeof(uint64_t) * (size_t)W) || !c->pool.get(S_VAL_A, sizeof(uint32_t) * (size_t)W) ||
+		    !c->pool.get(S_KEY_B, sizeof(uint64_t) * (size_t)W) || !c->pool.get(S_VAL_B, sizeof(uint32_t) * (size_t)W) ||
+		    !c->pool.get(S_TABLE, sizeof(uint32_t) * (size_t)rs_table_len(W)) ||
+		    !c->pool.get(S_TILE, sizeof(int64_t) * (size_t)(scan_tiles(std::max<int64_t>(rs_table_len(W), W)) + 8))) return PGA_ERR_NOMEM;
+	}
+	return sync_st(c);
+}
+
+// per-hit constants in file order, X order (sort + gather), running max of ce, Y order; resets all state
+extern "C" int pga_begin(pga_ctx_t *c)
+{
+	const int N = c->N, GL = c->n_genome;
+	HIPCHK(hipMemsetAsync(c->dcnt, 0, 16 * sizeof(int64_t), c->st));
+	if (c->Q) hipLaunchKernelGGL(k_fill_i32, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, (int64_t)c->Q, -1);
+	c->n_seg = 0;
+	if (N == 0) return sync_st(c);
+	int32_t *up = (int32_t *)c->pool.get(S_UPLOAD, 0);
 	int32_t *f_pid = up, *f_cid = up + (size_t)N, *f_rank = up + 2 * (size_t)N, *f_sori = up + 3 * (size_t)N, *f_sadj = up + 4 * (size_t)N, *f_nex = up + 5 * (size_t)N,
 		*f_offx = up + 6 * (size_t)N, *f_cs = up + 7 * (size_t)N, *f_ce = up + 8 * (size_t)N, *f_cm = up + 9 * (size_t)N,
 		*f_gnm = up + 10 * (size_t)N, *f_seg = up + 11 * (size_t)N, *f_gid = up + 12 * (size_t)N, *f_cds = up + 13 * (size_t)N;
 	uint8_t *f_rev = (uint8_t *)(up + 14 * (size_t)N);
-	TRY(upload(c, f_pid, sh->pid, N)); TRY(upload(c, f_cid, sh->cid, N)); TRY(upload(c, f_rank, sh->rank, N)); TRY(upload(c, f_sori, sh->score_ori, N));
-	TRY(upload(c, f_sadj, sh->score_adj, N)); TRY(upload(c, f_nex, sh->n_exon_of, N)); TRY(upload(c, f_offx, sh->off_exon, N));
-	TRY(upload(c, f_cs, sh->cs, N)); TRY(upload(c, f_ce, sh->ce, N)); TRY(upload(c, f_cm, sh->cm, N)); TRY(upload(c, f_rev, sh->rev, N));
-	TRY(upload(c, c->goff, c->h_goff.data(), (size_t)GL + 1)); TRY(upload(c, c->ggl, c->h_ggl.data(), GL));
-	TRY(upload(c, d_ctg_base, ctg_base.data(), (size_t)GL + 1));
-	TRY(upload(c, c->exon, hex.data(), E)); TRY(upload(c, c->prot_gid, sh->prot_gid, c->P)); TRY(upload(c, c->gene_pref, sh->gene_pref, c->Q));
-	if (N == 0) return sync_st(c);
-
-	{ // work buffers shared by every sort / scan of the run: sized for the largest input (2N temp arcs)
-		const int64_t W = 2 * (int64_t)N + 2;
-		if (!c->pool.get(S_KEY_B, sizeof(uint64_t) * (size_t)W) || !c->pool.get(S_VAL_B, sizeof(uint32_t) * (size_t)W) ||
-		    !c->pool.get(S_TABLE, sizeof(uint32_t) * (size_t)rs_table_len(W)) ||
-		    !c->pool.get(S_TILE, sizeof(int64_t) * (size_t)(scan_tiles(std::max<int64_t>(rs_table_len(W), W)) + 8))) return PGA_ERR_NOMEM;
-	}
 	uint64_t *sc64_f = (uint64_t *)c->pool.get(S_TAB_A, sizeof(uint64_t) * (size_t)N);
-	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, sizeof(uint64_t) * (size_t)N);
-	uint32_t *val = (uint32_t *)c->pool.get(S_VAL_A, sizeof(uint32_t) * (size_t)N);
-	if (!sc64_f || !key || !val) return PGA_ERR_NOMEM;
+	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, 0);
+	uint32_t *val = (uint32_t *)c->pool.get(S_VAL_A, 0);
+	if (!up || !sc64_f || !key || !val) return PGA_ERR_NOMEM;
 	FileHits f = { f_pid, f_cid, f_rank, f_sori, f_sadj, f_nex, f_offx, f_cs, f_ce, f_cm, f_rev };
-	hipLaunchKernelGGL(k_prepare, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, N, c->goff, GL, d_ctg_base, c->exon, c->prot_gid, c->gene_pref,
-	                   cs_bits, f_gnm, f_seg, f_gid, f_cds, sc64_f, key, val);
+	hipLaunchKernelGGL(k_prepare, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, N, c->goff, GL, c->ctg_base, c->exon, c->prot_gid, c->gene_pref,
+	                   c->cs_bits, f_gnm, f_seg, f_gid, f_cds, sc64_f, key, val);
 	// X order: pg_hit_sort(g, 0), hit.c:29-64, for every genome at once; stable => ties keep file order
 	uint64_t *ks; uint32_t *vs;
-	TRY(radix_sort_pool(c, key, val, N, cs_bits + seg_bits, &ks, &vs));
+	TRY(radix_sort_pool(c, key, val, N, c->cs_bits + c->seg_bits, &ks, &vs));
 	HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->sc64, c->flags };
 	hipLaunchKernelGGL(k_gather, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, f_gnm, f_seg, f_gid, f_cds, sc64_f, vs, N, c->goff, o);
 	// running max of ce per contig
 	SegMax *tile = (SegMax *)c->pool.get(S_TILE, 0);
 	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
 	// Y order: pg_hit_sort(g, 1); ties keep X order
-	hipLaunchKernelGGL(k_ykey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->seg, c->cm, N, cm_bits, key, val);
-	TRY(radix_sort_pool(c, key, val, N, cm_bits + seg_bits, &ks, &vs));
+	key = (uint64_t *)c->pool.get(S_KEY_A, 0), val = (uint32_t *)c->pool.get(S_VAL_A, 0);
+	hipLaunchKernelGGL(k_ykey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->seg, c->cm, N, c->cm_bits, key, val);
+	TRY(radix_sort_pool(c, key, val, N, c->cm_bits + c->seg_bits, &ks, &vs));
 	HIPCHK(hipMemcpyAsync(c->yperm, vs, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToDevice, c->st));
-	return sync_st(c);
+	return 0;
 }
 
 extern "C" int pga_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
@@ -1180,6 +1245,41 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 	return 0;
 }
 
+
+extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, const int32_t *seg_genome, const int32_t *seg_start,
+                                  const int64_t *seg_off, const int32_t *file_idx)
+{
+	const int N = c->N;
+	if (n_seg <= 0 || N == 0) return 0;
+	const int64_t T = seg_off[n_seg];
+	if (T == 0) return 0;
+	std::vector<int32_t> pos((size_t)T), fil((size_t)T);
+	for (int32_t s = 0; s < n_seg; ++s) {
+		const int32_t g = seg_genome[s], base = c->h_goff[(size_t)g];
+		for (int64_t k = seg_off[s]; k < seg_off[s + 1]; ++k)
+			pos[(size_t)k] = base + seg_start[s] + (int32_t)(k - seg_off[s]), fil[(size_t)k] = base + file_idx[k];
+	}
+	int32_t *d_pos = (int32_t *)c->pool.get(S_OVPOS, sizeof(int32_t) * (size_t)T), *d_fil = (int32_t *)c->pool.get(S_OVFILE, sizeof(int32_t) * (size_t)T);
+	int32_t *inv = (int32_t *)c->pool.get(S_I32_A, sizeof(int32_t) * (size_t)N), *remap = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
+	if (!d_pos || !d_fil || !inv || !remap) return PGA_ERR_NOMEM;
+	TRY(upload(c, d_pos, pos.data(), (size_t)T)); TRY(upload(c, d_fil, fil.data(), (size_t)T));
+	hipLaunchKernelGGL(k_ov_inv, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, inv, remap);
+	if (which == 1) {
+		hipLaunchKernelGGL(k_ov_sety, dim3(nblk(T)), dim3(BLOCK), 0, c->st, d_pos, d_fil, T, inv, c->yperm);
+		return sync_st(c);
+	}
+	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * 18 * (size_t)T + 64);
+	if (!tmp) return PGA_ERR_NOMEM;
+	uint64_t *tmp64 = (uint64_t *)(tmp + 16 * (size_t)T);
+	PermArrays p = { { c->fidx, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, (int32_t *)c->flags }, c->sc64 };
+	hipLaunchKernelGGL(k_ov_gather, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, inv, tmp, tmp64, remap);
+	hipLaunchKernelGGL(k_ov_scatter, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, T, tmp, tmp64, c->gnm, c->goff);
+	hipLaunchKernelGGL(k_ov_remap_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, N, remap);
+	SegMax *tile = (SegMax *)c->pool.get(S_TILE, 0);
+	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
+	return sync_st(c);
+}
+
 extern "C" int pga_fetch(pga_ctx_t *c, void *dst_host, const void *src_backend, size_t nbytes)
 {
 	if (nbytes == 0) return 0;
@@ -1256,9 +1356,9 @@ extern "C" int pga_timing_get(pga_ctx_t *c, int32_t which, double *total_ms, int
 extern "C" const pga_backend_t *pga_backend(void)
 {
 	static const pga_backend_t b = {
-		"hip-gfx950", pga_create, pga_destroy, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
+		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_rep_pos, pga_n_local, pga_mark_hits, pga_override_order, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get
 	};
 	return &b;
 }

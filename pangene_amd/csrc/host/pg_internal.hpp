@@ -37,6 +37,16 @@ private:
 	std::unordered_map<std::string_view, int32_t> map_;
 };
 
+// one contig segment whose exact (reference, unstable-sort) order is replayed on the host, exact_order.cpp
+struct ExactSeg {
+	int32_t k = 0, start = 0;             // local genome index; offset of the contig inside the genome
+	std::vector<int32_t> file;            // file index of each hit of the contig, in file order
+	std::vector<uint64_t> cs, cm;         // sort keys, aligned with `file`
+	std::vector<int32_t> cur, last_x;     // current array order / previous cs order (indices into `file`)
+	std::vector<int32_t> pushed[2];       // order the backend currently holds for cs (0) and cm (1)
+	bool stable = false;
+};
+
 // host-private companion of a pg_data_t (struct layout of pg_data_t itself must not change)
 struct DataExt {
 	std::vector<uint8_t> is_local;     // per genome: hits live in this process
@@ -46,6 +56,8 @@ struct DataExt {
 	std::vector<int32_t> local_genomes; // global index of each genome in the shard
 	std::vector<int64_t> hit_off;      // shard hit offsets
 	std::vector<std::vector<int32_t>> y_order; // per genome: host index of the k-th hit in cm order
+	std::vector<ExactSeg> xsegs;
+	bool rerun = false;                // pg_rerun_resident(): keep the backend context, skip pack + upload
 	bool host_stale = false;           // per-hit flags on the host are older than the backend's
 	int64_t n_hit_local = 0;
 };
@@ -65,5 +77,10 @@ const char *stamp();
 
 // bring the host AoS (flags, rank, dominators, order) up to date with the backend
 int sync_host(pg_data_t *d);
+
+int exact_mode();
+void exact_init(const pg_data_t *d, DataExt *ext);
+void exact_begin(DataExt *ext);
+int exact_sort(DataExt *ext, int by_cm);
 
 } // namespace pgx
