@@ -1,0 +1,73 @@
+"""torch.distributed plumbing for the library's exchange hook (pg_set_exchange, include/pangene_amd.h).
+
+One process per GPU; genomes are sharded across ranks; the library asks for a handful of small integer
+all-reduces / all-gathers per round on buffers that live in its own memory: HBM for the
+HIP backend (-> RCCL over xGMI through the "nccl" backend) or host memory for the oracle backend used
+by the CPU tests (-> gloo).  This module only wraps those raw pointers as tensors and calls
+torch.distributed; it never touches the data.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+_DT = {0: (torch.int32, np.int32, 4), 1: (torch.int64, np.int64, 8)}
+
+
+class _DevPtr:
+    """Minimal __cuda_array_interface__ holder so torch can alias library-owned HBM without a copy."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _tensor(ptr: int, nbytes: int, is_device: int, device) -> torch.Tensor:
+    if is_device:
+        return torch.as_tensor(_DevPtr(ptr, nbytes), device=device)
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    return torch.from_numpy(np.frombuffer(buf, dtype=np.uint8))
+
+
+def install(lib: C.CDLL, device=None, group=None):
+    """Registers the exchange callbacks on `lib`; returns an object that must be kept alive."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allreduce(user, buf, count, dtype, op, is_device):
+        try:
+            tdt, _, sz = _DT[dtype]
+            t = _tensor(buf, count * sz, is_device, device).view(tdt)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=group)
+            if is_device:
+                torch.cuda.current_stream(device).synchronize()
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("[pangene_amd.exchange] allreduce failed:", e, flush=True)
+            return -1
+
+    def allgather(user, src, dst, nbytes, is_device):
+        try:
+            tin = _tensor(src, nbytes, is_device, device)
+            tout = _tensor(dst, nbytes * world, is_device, device)
+            dist.all_gather_into_tensor(tout, tin, group=group)
+            if is_device:
+                torch.cuda.current_stream(device).synchronize()
+            return 0
+        except Exception as e:
+            print("[pangene_amd.exchange] allgather failed:", e, flush=True)
+            return -1
+
+    x = capi.pg_exchange_t()
+    x.rank, x.world, x.user = rank, world, None
+    keep = (capi.ALLREDUCE_CB(allreduce), capi.ALLGATHER_CB(allgather))
+    x.allreduce, x.allgather = keep
+    lib.pg_set_exchange(C.byref(x))
+    return (x, keep)
+
+
+def uninstall(lib: C.CDLL):
+    lib.pg_set_exchange(None)

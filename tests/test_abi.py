@@ -1,0 +1,70 @@
+"""C-ABI checks that need no GPU: struct layouts equal the reference's pangene.h, and the product
+library loads and exports every symbol that include/*.h declares."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+from conftest import ROOT
+
+SIZES = {"pg_opt_t": 128, "pg_hit_t": 88, "pg_exon_t": 8, "pg_prot_t": 32, "pg_gene_t": 16, "pg_ctg_t": 16, "pg_genome_t": 56,
+         "pg_data_t": 72, "pg_seg_t": 32, "pg_arc_t": 32, "pg_graph_t": 56, "pg128_t": 16, "pga_arc_part_t": 40}
+
+
+def test_struct_sizes_and_offsets():
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "pangene_amd.h"\n#include "pangene_hip.h"\nint main(void){\n'
+    for k in SIZES:
+        src += 'printf("%s %%zu\\n", sizeof(%s));\n' % (k, k)
+    src += 'printf("cs %zu cm %zu ce %zu\\n", offsetof(pg_hit_t, cs), offsetof(pg_hit_t, cm), offsetof(pg_hit_t, ce));\n'
+    src += 'pg_hit_t h; unsigned *w = (unsigned*)((char*)&h + 60); *w = 0; h.weak_br = 3; h.rev = 1; h.shadow = 1; printf("bits %u\\n", *w);\nreturn 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "a.c")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), c, "-o", os.path.join(td, "a")], check=True)
+        out = subprocess.run([os.path.join(td, "a")], stdout=subprocess.PIPE, check=True, text=True).stdout.split("\n")
+    got = dict(l.split()[:2] for l in out if l and l.split()[0] in SIZES)
+    assert {k: int(v) for k, v in got.items()} == SIZES
+    assert "cs 64 cm 72 ce 80" in out
+    assert "bits %d" % (0x1 | 0x80 | 0x600) in out  # bit positions of pangene.h:70 == PGA_F_*
+
+
+def _declared(header, prefix_re):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(prefix_re, txt)))
+
+
+def test_product_library_exports_every_declared_symbol(built):
+    lib = C.CDLL(os.path.join(ROOT, "pangene_amd", "lib", "libpangene_amd.so"))
+    names = _declared("pangene_amd.h", r"\b(pg_[a-z_0-9]+)\s*\(")
+    names = [n for n in names if n not in ("pg_exchange_t",)]
+    pfx = _declared("pangene_hip.h", r"pfx##_([a-z_]+)\(")
+    names += ["pga_" + n for n in pfx] + ["pga_backend", "pga_set_stream", "pga_timing_reset", "pga_timing_get"]
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert C.c_int.in_dll(lib, "pg_verbose").value == 3
+
+
+def test_oracle_exports_the_same_abi(built):
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    pfx = _declared("pangene_hip.h", r"pfx##_([a-z_]+)\(")
+    missing = [n for n in pfx if not hasattr(lib, "pgo_" + n)]
+    assert not missing, missing
+
+
+def test_product_fails_loudly_without_gpu(built):
+    """No CPU fallback: on a machine without a GPU the path reports an error instead of computing."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    from pangene_amd import capi
+    from conftest import golden_files
+    lib = capi.load()
+    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    try:
+        capi.run(lib, golden_files("C4"), [])
+    except RuntimeError as e:
+        assert "backend status" in str(e)
+    else:
+        raise AssertionError("the product path produced output without a GPU")

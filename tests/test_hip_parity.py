@@ -1,0 +1,104 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI of
+libpangene_amd.so; the oracle (host driver + plain-C backend) and the committed reference md5s are the
+checkers."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, all_cases, golden_files
+from pangene_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(built):
+    lib = capi.load()
+    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ora(built):
+    lib = capi.load(oracle_host=True)
+    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    return lib
+
+
+def test_device_primitives(hip):
+    raw = C.CDLL(capi.LIB_HIP)
+    rng = np.random.default_rng(1)
+    for n, nb in [(1, 8), (63, 16), (2048, 24), (2049, 24), (5000, 40), (1_000_003, 37)]:
+        k = rng.integers(0, 1 << nb, size=n, dtype=np.uint64)
+        k[: n // 3] &= np.uint64(0xFF)  # many ties: stability matters
+        v = np.arange(n, dtype=np.uint32)
+        k2, v2 = k.copy(), v.copy()
+        assert raw.pga_selftest_sort(k2.ctypes.data_as(C.c_void_p), v2.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int32(nb)) == 0
+        o = np.argsort(k, kind="stable")
+        assert np.array_equal(k2, k[o]) and np.array_equal(v2, v[o])
+    for n in [1, 100, 1024, 1025, 300000, 2_000_001]:
+        a = rng.integers(-5, 50, size=n).astype(np.int32)
+        seg = np.sort(rng.integers(0, max(1, n // 7), size=n)).astype(np.int32)
+        out = np.zeros(n, dtype=np.int32)
+        for mode in (0, 1, 2):
+            assert raw.pga_selftest_scan(a.ctypes.data_as(C.c_void_p), seg.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                         C.c_int64(n), C.c_int32(mode)) == 0
+            if mode == 0:
+                exp = np.concatenate(([0], np.cumsum(a[:-1].astype(np.int64)))).astype(np.int32)
+            elif mode == 1:
+                exp = np.concatenate(([-1], np.maximum.accumulate(np.maximum(a, -1))[:-1])).astype(np.int32)
+            else:
+                exp = a.copy()
+                start = np.concatenate(([True], seg[1:] != seg[:-1]))
+                for i in range(1, n):
+                    if not start[i] and exp[i - 1] > exp[i]:
+                        exp[i] = exp[i - 1]
+            assert np.array_equal(out, exp), (n, mode)
+
+
+@pytest.mark.parametrize("name,variant", all_cases())
+def test_hip_equals_reference_md5(hip, expected, name, variant):
+    """exact mode 'all': bytes equal to the untouched reference's, --bed line order included"""
+    hip.pg_set_exact_mode(2)
+    out = capi.run(hip, golden_files(name), variant.split())
+    assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
+
+
+@pytest.mark.parametrize("name,variant", all_cases())
+@pytest.mark.parametrize("mode", [0, 1])
+def test_hip_equals_oracle(hip, ora, name, variant, mode):
+    """same canonical order on both sides (modes off / auto): identical bytes, hazards or not"""
+    hip.pg_set_exact_mode(mode), ora.pg_set_exact_mode(mode)
+    assert capi.run(hip, golden_files(name), variant.split()) == capi.run(ora, golden_files(name), variant.split())
+
+
+def test_config2_full_size_against_reference(hip, tmp_path):
+    """BASELINE configs[1]: bact(100, 5000), ~1 M hits: GFA bit-identical to the reference binary; rerun on
+    the HBM-resident shard is idempotent."""
+    files = synth.write_files(synth.bact(100, 5000, seed=1), str(tmp_path / "c2"))
+    hip.pg_set_exact_mode(1)
+    a = capi.run(hip, files, [])
+    ref = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
+    if os.path.exists(ref):
+        want = subprocess.run([ref] + files, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        assert a == want
+    b = capi.run(hip, files, [])
+    assert a == b
+    s = sum(1 for l in a.split(b"\n") if l[:1] == b"S")
+    assert 4000 < s <= 5000
+
+
+def test_empty_and_degenerate_inputs(hip, ora, tmp_path):
+    p = tmp_path / "e"
+    p.mkdir()
+    (p / "a.paf").write_text("")
+    (p / "b.paf").write_text("g1\t100\t0\t100\t+\tc1\t1000\t10\t310\t300\t300\t0\tms:i:400\tcg:Z:100M\n")
+    (p / "c.paf").write_text("g1\t100\t0\t100\t-\tc1\t1000\t10\t310\t300\t300\t0\tms:i:400\tcg:Z:100M\n"
+                             "g2\t100\t0\t100\t+\tc1\t1000\t400\t700\t300\t300\t0\tms:i:410\tcg:Z:100M\n")
+    files = [str(p / x) for x in ("a.paf", "b.paf", "c.paf")]
+    for args in ([], ["-p0"], ["--bed=raw"]):
+        assert capi.run(hip, files, args) == capi.run(ora, files, args)
