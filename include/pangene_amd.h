@@ -205,6 +205,10 @@ int pg_rerun_resident(pg_data_t *d);
 int pg_kernel_timing(pg_data_t *d, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
 int pg_kernel_timing_reset(pg_data_t *d);
 
+/* wall seconds the host driver spent per phase of the last run (names via pg_phase_name) */
+int pg_phase_times(double *out, int n);
+const char *pg_phase_name(int i);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,6 +158,10 @@ typedef struct {
 	 * file_idx lists the hits to put there by their FILE index inside the genome. */ \
 	int  pfx##_override_order(pga_ctx_t *ctx, int32_t which, int32_t n_seg, const int32_t *seg_genome, const int32_t *seg_start, \
 	                          const int64_t *seg_off, const int32_t *file_idx); \
+	/* Index-0 channel only (cheap form of override_order): head_file[g] = FILE index of the hit the \
+	 * reference has at array index 0 of local genome g (the one pg_shadow never resets, overlap.c:108); \
+	 * -1 = the first hit of the canonical order */ \
+	int  pfx##_set_head(pga_ctx_t *ctx, const int32_t *head_file); \
 	/* copy backend memory to the host / host to backend / backend to backend */ \
 	int  pfx##_fetch(pga_ctx_t *ctx, void *dst_host, const void *src_backend, size_t nbytes); \
 	int  pfx##_put(pga_ctx_t *ctx, void *dst_backend, const void *src_host, size_t nbytes); \
@@ -192,6 +196,7 @@ typedef struct {
 	int  (*n_local)(pga_ctx_t *, const int32_t *, int64_t, int32_t, int32_t, int32_t, int32_t **);
 	int  (*mark_hits)(pga_ctx_t *, const uint64_t *, const uint8_t *, int64_t, int64_t *);
 	int  (*override_order)(pga_ctx_t *, int32_t, int32_t, const int32_t *, const int32_t *, const int64_t *, const int32_t *);
+	int  (*set_head)(pga_ctx_t *, const int32_t *);
 	int  (*fetch)(pga_ctx_t *, void *, const void *, size_t);
 	int  (*put)(pga_ctx_t *, void *, const void *, size_t);
 	int  (*copy)(pga_ctx_t *, void *, const void *, size_t);

@@ -49,6 +49,7 @@ struct pga_ctx {
 	int32_t *nl_cnt;
 	pga_hazard_t hz;
 	void *scratch; size_t m_scratch;
+	int64_t *head;            /* [n_genome] X position of the hit that plays "index 0" (never reset by pg_shadow) */
 	/* raw shard, file order (kept so that begin() can restart the run) */
 	int32_t *r_pid, *r_cid, *r_rank, *r_sori, *r_sadj, *r_nex, *r_offx, *r_cs, *r_ce, *r_cm; uint8_t *r_rev;
 };
@@ -131,7 +132,7 @@ void pgo_destroy(pga_ctx_t *c)
 	free(c->n_exon_of); free(c->off_exon); free(c->cs); free(c->ce); free(c->cm); free(c->cds);
 	free(c->pid_dom); free(c->pid_dom0); free(c->flags); free(c->yo); free(c->exon_os); free(c->exon_oe);
 	free(c->prot_gid); free(c->gene_pref); free(c->max_ori); free(c->sums); free(c->vtx_cnt); free(c->triples);
-	free(c->g2s); free(c->seg_cnt); free(c->arcs); free(c->rp_x); free(c->rp_y); free(c->nl_cnt); free(c->scratch);
+	free(c->g2s); free(c->seg_cnt); free(c->arcs); free(c->rp_x); free(c->rp_y); free(c->nl_cnt); free(c->scratch); free(c->head);
 	free(c->r_pid); free(c->r_cid); free(c->r_rank); free(c->r_sori); free(c->r_sadj); free(c->r_nex); free(c->r_offx); free(c->r_cs); free(c->r_ce); free(c->r_cm); free(c->r_rev);
 	free(c);
 }
@@ -162,6 +163,7 @@ int pgo_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
 	c->cs = MALLOC(int32_t, N); c->ce = MALLOC(int32_t, N); c->cm = MALLOC(int32_t, N); c->cds = MALLOC(int32_t, N);
 	c->pid_dom = MALLOC(int32_t, N); c->pid_dom0 = CALLOC(int32_t, N); c->flags = CALLOC(uint32_t, N);
 	c->yo = MALLOC(int32_t, N);
+	c->head = MALLOC(int64_t, sh->n_genome);
 	c->max_ori = CALLOC(int32_t, c->n_prot);
 	c->sums = CALLOC(int64_t, 6 * (int64_t)c->n_prot);
 	c->vtx_cnt = CALLOC(int32_t, 2 * (int64_t)c->n_gene);
@@ -178,6 +180,7 @@ int pgo_begin(pga_ctx_t *c)
 	int32_t j;
 	skey_t *key = MALLOC(skey_t, N);
 	memset(&c->hz, 0, sizeof(c->hz));
+	for (j = 0; j < c->n_genome; ++j) c->head[j] = c->off[j];
 	for (i = 0; i < c->n_gene; ++i) c->g2s[i] = -1;
 	c->n_seg = 0;
 	for (j = 0; j < c->n_genome; ++j) { /* X order */
@@ -246,11 +249,11 @@ static int32_t shadow_genome(pga_ctx_t *c, int32_t j, int cal_dom_sc, int32_t *n
 	int64_t st = c->off[j], en = c->off[j + 1], i, i0, jj;
 	int32_t n_shadow = 0, tot = 0;
 	shadow_aux_t *tmp = CALLOC(shadow_aux_t, en - st);
-	for (i = st + 1, i0 = st; i < en; ++i) { /* overlap.c:108: starts at 1 => index 0 is never reset */
+	for (i = st, i0 = st; i < en; ++i) { /* overlap.c:108: the loop starts at 1 => the hit at index 0 is never reset */
 		int32_t li, gi;
 		uint64_t si;
 		if (is_flt(c, i)) continue;
-		c->flags[i] &= ~PGA_F_SHADOW;
+		if (i != c->head[j]) c->flags[i] &= ~PGA_F_SHADOW;
 		while (i0 < i && !(c->cid[i0] == c->cid[i] && c->ce[i0] > c->cs[i])) ++i0; /* overlap.c:114-115 */
 		gi = c->gid[i], li = c->cds[i], si = score64(c, i);
 		for (jj = i0; jj < i; ++jj) {
@@ -725,8 +728,22 @@ int pgo_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, const int32_t
 #undef PERM_ARR
 			for (i = st; i < en; ++i) c->yo[i] = remap[c->yo[i] - st];
 			free(remap);
+			c->head[j] = st;
 		}
 		free(inv);
+	}
+	return PGA_OK;
+}
+
+int pgo_set_head(pga_ctx_t *c, const int32_t *head_file)
+{
+	int32_t j;
+	for (j = 0; j < c->n_genome; ++j) {
+		int64_t i;
+		c->head[j] = c->off[j];
+		if (head_file[j] < 0) continue;
+		for (i = c->off[j]; i < c->off[j + 1]; ++i)
+			if (c->fidx[i] == head_file[j]) { c->head[j] = i; break; }
 	}
 	return PGA_OK;
 }
@@ -775,7 +792,7 @@ const pga_backend_t *pgo_backend(void)
 {
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
-		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_rep_pos, pgo_n_local, pgo_mark_hits, pgo_override_order, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
+		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_rep_pos, pgo_n_local, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
 		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0
 	};
 	return &b;

@@ -71,7 +71,7 @@ struct pga_ctx {
 	uint64_t *sc64 = 0;
 	// dynamic per hit
 	int32_t *rank = 0, *sdom = 0, *pdom = 0, *pdom0 = 0; uint32_t *flags = 0;
-	int32_t *yperm = 0, *goff = 0, *ggl = 0, *ctg_base = 0;
+	int32_t *yperm = 0, *goff = 0, *ggl = 0, *ctg_base = 0, *inv = 0, *headpos = 0;
 	int cs_bits = 1, cm_bits = 1, seg_bits = 1;
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors
@@ -357,14 +357,28 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepView v)
 	}
 }
 
+// log-only counters (graph.c:23-27).  Hits are genome-major, so a workgroup mostly sees one genome: count
+// that genome in LDS and add once; stragglers of the next genome go to global memory directly.
 __global__ __launch_bounds__(BLOCK) void k_count_shadow(const uint32_t *flags, const int32_t *gnm, int n, int32_t *stats)
 {
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	uint32_t f = flags[h];
-	if (f & PGA_F_FLT) return;
-	atomicAdd(&stats[gnm[h] * 2], 1);
-	if (f & PGA_F_SHADOW) atomicAdd(&stats[gnm[h] * 2 + 1], 1);
+	__shared__ int s_cnt[2];
+	__shared__ int s_g;
+	const int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (threadIdx.x == 0) s_cnt[0] = s_cnt[1] = 0, s_g = gnm[blockIdx.x * BLOCK];
+	__syncthreads();
+	if (h < n) {
+		const uint32_t f = flags[h];
+		if (!(f & PGA_F_FLT)) {
+			const int g = gnm[h];
+			if (g == s_g) { atomicAdd(&s_cnt[0], 1); if (f & PGA_F_SHADOW) atomicAdd(&s_cnt[1], 1); }
+			else { atomicAdd(&stats[g * 2], 1); if (f & PGA_F_SHADOW) atomicAdd(&stats[g * 2 + 1], 1); }
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (s_cnt[0]) atomicAdd(&stats[s_g * 2], s_cnt[0]);
+		if (s_cnt[1]) atomicAdd(&stats[s_g * 2 + 1], s_cnt[1]);
+	}
 }
 
 // read.c:249-253
@@ -729,11 +743,13 @@ __global__ __launch_bounds__(BLOCK) void k_mark_hits(const int32_t *val, const i
 __global__ __launch_bounds__(BLOCK) void k_weak_merge(uint32_t *flags, const int32_t *weak_new, int n, int64_t *cnt)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
+	const bool in = h < n;
+	if (!in) h = n - 1;
 	uint32_t f = flags[h];
-	int cur = (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), nw = weak_new[h];
+	int cur = in ? (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT) : 0, nw = in ? weak_new[h] : 0;
 	if (nw > cur) { cur = nw; flags[h] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT; }
-	if (cur) atomicAdd((unsigned long long *)cnt, 1ull);
+	const unsigned long long m = __ballot(cur != 0); // one atomic per wave, not per hit
+	if (m && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd((unsigned long long *)cnt, (unsigned long long)__popcll(m));
 }
 
 // hazard H2b: two consecutive walkable hits (cs order) share (contig, cs)
@@ -778,6 +794,24 @@ __global__ __launch_bounds__(BLOCK) void k_ov_sety(const int32_t *ov_pos, const 
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (i < t) yperm[ov_pos[i]] = inv[ov_file[i]];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_inv_only(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, int n, int32_t *inv)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h < n) inv[goff[gnm[h]] + fidx[h]] = h;
+}
+
+// move the "index 0" mark of each genome to the hit the reference has there (overlap.c:108)
+__global__ __launch_bounds__(BLOCK) void k_set_head(const int32_t *head_file, const int32_t *goff, const int32_t *inv, int n_genome, int32_t *headpos, uint32_t *flags)
+{
+	int g = blockIdx.x * BLOCK + threadIdx.x;
+	if (g >= n_genome || goff[g] == goff[g + 1]) return;
+	int np = head_file[g] < 0 ? goff[g] : inv[goff[g] + head_file[g]], op = headpos[g];
+	if (np == op) return;
+	flags[op] &= ~F_HEAD;
+	flags[np] |= F_HEAD;
+	headpos[g] = np;
 }
 
 struct PermArrays { int32_t *a[16]; uint64_t *sc64; };
@@ -899,7 +933,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(dalloc(c, &c->cs, N)); TRY(dalloc(c, &c->ce, N)); TRY(dalloc(c, &c->cm, N)); TRY(dalloc(c, &c->cds, N)); TRY(dalloc(c, &c->nex, N));
 	TRY(dalloc(c, &c->offx, N)); TRY(dalloc(c, &c->sori, N)); TRY(dalloc(c, &c->sadj, N)); TRY(dalloc(c, &c->pm, N)); TRY(dalloc(c, &c->sc64, N));
 	TRY(dalloc(c, &c->rank, N)); TRY(dalloc(c, &c->sdom, N)); TRY(dalloc(c, &c->pdom, N)); TRY(dalloc(c, &c->pdom0, N)); TRY(dalloc(c, &c->flags, N));
-	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->ctg_base, GL + 1)); TRY(dalloc(c, &c->exon, E));
+	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->ctg_base, GL + 1)); TRY(dalloc(c, &c->inv, N)); TRY(dalloc(c, &c->headpos, GL + 1)); TRY(dalloc(c, &c->exon, E));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q));
 	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
 
@@ -965,6 +999,8 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	TRY(radix_sort_pool(c, key, val, N, c->cs_bits + c->seg_bits, &ks, &vs));
 	HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->sc64, c->flags };
 	hipLaunchKernelGGL(k_gather, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, f_gnm, f_seg, f_gid, f_cds, sc64_f, vs, N, c->goff, o);
+	hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv);
+	HIPCHK(hipMemcpyAsync(c->headpos, c->goff, sizeof(int32_t) * ((size_t)GL + 1), hipMemcpyDeviceToDevice, c->st));
 	// running max of ce per contig
 	SegMax *tile = (SegMax *)c->pool.get(S_TILE, 0);
 	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
@@ -1277,7 +1313,19 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	hipLaunchKernelGGL(k_ov_remap_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, N, remap);
 	SegMax *tile = (SegMax *)c->pool.get(S_TILE, 0);
 	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
+	hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv);
 	return sync_st(c);
+}
+
+extern "C" int pga_set_head(pga_ctx_t *c, const int32_t *head_file)
+{
+	const int GL = c->n_genome;
+	if (GL == 0 || c->N == 0) return 0;
+	int32_t *d = (int32_t *)c->pool.get(S_OVFILE, sizeof(int32_t) * (size_t)GL);
+	if (!d) return PGA_ERR_NOMEM;
+	TRY(upload(c, d, head_file, (size_t)GL));
+	hipLaunchKernelGGL(k_set_head, dim3(nblk(GL)), dim3(BLOCK), 0, c->st, d, c->goff, c->inv, GL, c->headpos, c->flags);
+	return sync_st(c); // head_file is caller memory
 }
 
 extern "C" int pga_fetch(pga_ctx_t *c, void *dst_host, const void *src_backend, size_t nbytes)
@@ -1357,7 +1405,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 {
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
-		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_rep_pos, pga_n_local, pga_mark_hits, pga_override_order, pga_fetch, pga_put, pga_copy, pga_scratch,
+		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_rep_pos, pga_n_local, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
 		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get
 	};
 	return &b;

@@ -73,9 +73,10 @@ void exact_begin(DataExt *ext) // start of a run: arrays are in file order (read
 	for (ExactSeg &s : ext->xsegs) {
 		s.cur.resize(s.file.size());
 		for (size_t i = 0; i < s.file.size(); ++i) s.cur[i] = (int32_t)i; // indices into s.file / s.cs / s.cm
-		s.last_x.clear(), s.pushed[0].clear(), s.pushed[1].clear();
-		s.stable = false;
+		s.hx.clear(), s.hy.clear(), s.pushed[0].clear(), s.pushed[1].clear();
+		s.cyc_start = -1, s.period = 0, s.n_sort[0] = s.n_sort[1] = 0;
 	}
+	ext->head_file.assign(ext->local_genomes.size(), -1);
 }
 
 static void emulate(ExactSeg &s, int by_cm) // one pg_hit_sort of this contig segment
@@ -87,16 +88,33 @@ static void emulate(ExactSeg &s, int by_cm) // one pg_hit_sort of this contig se
 	for (size_t i = 0; i < s.cur.size(); ++i) s.cur[i] = (int32_t)t[i].y;
 }
 
-// Replay one pg_hit_sort(g, by_cm) of every tracked segment and push the orders that changed.
+// advance one segment by one sort.  The sequence X1 -cm-> Y1 -cs-> X2 -cm-> Y2 ... is a deterministic map on a
+// finite set, so it becomes periodic; once a cs order repeats, later orders are read from the history.
+static void advance(ExactSeg &s, int by_cm, bool keep_y)
+{
+	const int t = ++s.n_sort[by_cm]; // 1-based index of this sort among the sorts of its kind
+	if (s.cyc_start > 0) {
+		const std::vector<std::vector<int32_t>> &h = by_cm ? s.hy : s.hx;
+		if (by_cm && !keep_y) return; // order not needed by the caller
+		s.cur = h[(size_t)(s.cyc_start - 1 + (t - s.cyc_start) % s.period)];
+		return;
+	}
+	emulate(s, by_cm);
+	if (by_cm) { if (keep_y) s.hy.push_back(s.cur); return; }
+	for (size_t i = 0; i < s.hx.size(); ++i)
+		if (s.hx[i] == s.cur) { s.cyc_start = (int)i + 1, s.period = t - s.cyc_start; return; }
+	s.hx.push_back(s.cur);
+}
+
+// Replay one pg_hit_sort(g, by_cm) of every tracked segment and hand what changed to the backend.
 int exact_sort(DataExt *ext, int by_cm)
 {
 	if (ext->xsegs.empty()) return 0;
+	const bool all = exact_mode() == 2;
 	std::vector<ExactSeg *> todo;
-	for (ExactSeg &s : ext->xsegs) if (!s.stable) todo.push_back(&s);
-	if (todo.empty()) return 0;
-	auto work = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) emulate(*todo[i], by_cm); };
 	size_t tot = 0;
-	for (ExactSeg *s : todo) tot += s->cur.size();
+	for (ExactSeg &s : ext->xsegs) { todo.push_back(&s); if (s.cyc_start < 0) tot += s.cur.size(); }
+	auto work = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) advance(*todo[i], by_cm, all); };
 	unsigned nt = tot > 200000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
 	if (nt > todo.size()) nt = (unsigned)todo.size();
 	if (nt <= 1) work(0, todo.size());
@@ -105,13 +123,18 @@ int exact_sort(DataExt *ext, int by_cm)
 		for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, todo.size() * t / nt, todo.size() * (t + 1) / nt);
 		for (auto &x : th) x.join();
 	}
+	if (!all) { // auto: only the identity of the hit at array index 0 matters, and only for the cs order
+		if (by_cm) return 0;
+		bool changed = false;
+		for (ExactSeg *s : todo) {
+			const int32_t h = s->file[(size_t)s->cur[0]];
+			if (ext->head_file[(size_t)s->k] != h) ext->head_file[(size_t)s->k] = h, changed = true;
+		}
+		return changed ? ext->be->set_head(ext->ctx, ext->head_file.data()) : 0;
+	}
 	std::vector<int32_t> sg, ss, fi;
 	std::vector<int64_t> so(1, 0);
 	for (ExactSeg *s : todo) {
-		if (!by_cm) { // fixed point: the cs order repeats => every later cm/cs order repeats too
-			if (s->cur == s->last_x) s->stable = true;
-			s->last_x = s->cur;
-		}
 		if (s->cur == s->pushed[by_cm]) continue;
 		s->pushed[by_cm] = s->cur;
 		sg.push_back(s->k), ss.push_back(s->start);

@@ -21,6 +21,7 @@ int pg_verbose = 3;
 namespace pgx {
 
 pg_exchange_t g_xchg; bool g_has_xchg = false;
+double g_phase[PH_COUNT];
 static int g_err = 0; static char g_errstr[256] = "";
 static double g_path_sec = 0.0, g_upload_sec = 0.0, g_t_path0 = 0.0; static int64_t g_path_hits = 0;
 
@@ -155,6 +156,7 @@ int sync_host(pg_data_t *d)
 {
 	DataExt *ext = ext_of(d, false);
 	if (ext == nullptr || ext->ctx == nullptr || !ext->host_stale) return g_err;
+	Phase ph(PH_SYNC_HOST);
 	const int64_t N = ext->n_hit_local;
 	std::vector<uint32_t> flags((size_t)N);
 	std::vector<int32_t> rank((size_t)N), sdom((size_t)N), pdom((size_t)N), pdom0((size_t)N), px((size_t)N), py((size_t)N);
@@ -205,16 +207,17 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 	const pga_backend_t *be = ext->be;
 	pga_ctx_t *ctx = ext->ctx;
 	g_t_path0 = now_sec();
-	BE_CALL(be->begin(ctx), "begin");
-	exact_begin(ext);
-	BE_CALL(exact_sort(ext, 0), "override_order"); // pg_hit_sort(g, 0), read.c:247
+	for (int i = 0; i < PH_COUNT; ++i) g_phase[i] = 0;
+	{ Phase ph(PH_BEGIN); BE_CALL(be->begin(ctx), "begin"); }
+	{ Phase ph(PH_EXACT); exact_begin(ext); BE_CALL(exact_sort(ext, 0), "override_order"); } // pg_hit_sort(g, 0), read.c:247
 	const int32_t nl = (int32_t)ext->local_genomes.size(), P = d->n_prot;
 	if (pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] %d genes and %d proteins; %ld hits of %d genomes on backend '%s'\n", __func__, stamp(),
 		             d->n_gene, d->n_prot, (long)ext->n_hit_local, nl, be->name);
 
 	std::vector<int32_t> st4((size_t)nl * 4);
-	BE_CALL(be->ingest(ctx, st4.data()), "ingest"); // read.c:243-260 for every local genome
+	{ Phase ph(PH_INGEST); BE_CALL(be->ingest(ctx, pg_verbose >= 3 ? st4.data() : nullptr), "ingest"); } // read.c:243-260 for every local genome
+	Phase ph_post(PH_POST);
 	if (pg_verbose >= 3)
 		for (int32_t k = 0; k < nl; ++k) {
 			const pg_genome_t *g = &d->genome[ext->local_genomes[(size_t)k]];
@@ -265,7 +268,7 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 	if (!(opt->flag & PG_F_NO_JOINT_PSEUDO) && pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] %ld pseudogene hits identified jointly\n", __func__, stamp(), (long)n_pj);
 	std::vector<int32_t> st2((size_t)nl * 2);
-	BE_CALL(be->shadow(ctx, 0, st2.data()), "shadow"); // graph.c:20-28
+	BE_CALL(be->shadow(ctx, 0, pg_verbose >= 3 ? st2.data() : nullptr), "shadow"); // graph.c:20-28
 	if (pg_verbose >= 3)
 		for (int32_t k = 0; k < nl; ++k) {
 			const pg_genome_t *g = &d->genome[ext->local_genomes[(size_t)k]];
@@ -304,6 +307,7 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	pg_data_t *d = q->d;
 	const pga_backend_t *be = ext->be;
 	const int32_t Q = d->n_gene, G = d->n_genome;
+	Phase ph_vtx(PH_VTX);
 	int32_t *b_cnt; uint64_t *b_tri; int64_t n_tri;
 	BE_CALL(be->vtx_partials(ext->ctx, &b_cnt, &b_tri, &n_tri), "vtx_partials");
 	BE_CALL(xreduce(be, b_cnt, 2 * (int64_t)Q, PG_X_I32, PG_X_SUM), "allreduce(n_dom,n_sub)");
@@ -382,9 +386,10 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	const pga_backend_t *be = ext->be;
 	const int32_t S = q->n_seg;
 	int32_t *b_seg; pga_arc_part_t *b_arc; int64_t n_loc;
-	BE_CALL(exact_sort(ext, 1), "override_order"); // graph.c:103
-	BE_CALL(be->arc_round(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), &b_seg, &b_arc, &n_loc), "arc_round");
-	BE_CALL(exact_sort(ext, 0), "override_order"); // graph.c:123
+	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 1), "override_order"); } // graph.c:103
+	{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), &b_seg, &b_arc, &n_loc), "arc_round"); }
+	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
+	Phase ph_host(PH_ARC_HOST);
 	BE_CALL(xreduce(be, b_seg, 2 * (int64_t)S, PG_X_I32, PG_X_SUM), "allreduce(seg counts)");
 	std::vector<int32_t> sc((size_t)S * 2);
 	if (S) BE_CALL(be->fetch(ext->ctx, sc.data(), b_seg, sizeof(int32_t) * (size_t)S * 2), "fetch");
@@ -423,6 +428,7 @@ static int flag_vtx(pg_graph_t *q, DataExt *ext) { return ext->be->flag_vtx(ext-
 // pg_flt_high_occ + pg_hard_delete (graph.c:219-263)
 static int flt_high_occ(int32_t max_avg_occ, int32_t max_degree, int32_t max_dist_loci, pg_graph_t *q, DataExt *ext)
 {
+	Phase ph(PH_FLT);
 	int32_t n_high_occ = 0, n_high_deg = 0, n_high_loci = 0;
 	for (int32_t i = 0; i < q->n_seg; ++i)
 		if (q->seg[i].tot_cnt > max_avg_occ * q->d->n_genome) q->seg[i].del = 1, ++n_high_occ;
@@ -461,6 +467,7 @@ static int mark_branch_flt_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	const uint32_t n_vtx = (uint32_t)q->n_seg * 2;
 	uint32_t n_flt1 = 0, n_flt2 = 0;
 	const int32_t frag_mode = !!(opt->flag & PG_F_FRAG_MODE);
+	Phase ph_all(PH_BRANCH_HOST);
 	BE_CALL(be->rep_pos(ext->ctx), "rep_pos");
 	for (int32_t j = 0; j < q->n_seg; ++j) q->seg[j].n_dist_loci[0] = q->seg[j].n_dist_loci[1] = 0;
 	std::vector<int32_t> pairs, max_gid;
@@ -471,10 +478,12 @@ static int mark_branch_flt_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 		if (pass == 1) {
 			int32_t *b_cnt;
 			const int64_t np = (int64_t)pairs.size() / 2;
+			Phase ph(PH_NLOCAL);
 			BE_CALL(be->n_local(ext->ctx, pairs.data(), np, opt->local_dist, opt->local_count, frag_mode, &b_cnt), "n_local");
 			BE_CALL(xreduce(be, b_cnt, np, PG_X_I32, PG_X_SUM), "allreduce(n_local)");
 			cnt.resize((size_t)np);
 			if (np) BE_CALL(be->fetch(ext->ctx, cnt.data(), b_cnt, sizeof(int32_t) * (size_t)np), "fetch");
+			g_phase[PH_BRANCH_HOST] -= now_sec() - ph.t0; // counted under PH_NLOCAL
 		}
 		auto n_local = [&](int32_t g1, int32_t g2) -> int32_t {
 			if (pass == 0) { pairs.push_back(g1), pairs.push_back(g2); return 0; }
@@ -522,9 +531,9 @@ static int mark_branch_flt_hit(pg_graph_t *q, DataExt *ext) // branch.c:108-145
 	std::vector<uint8_t> aw((size_t)q->n_arc);
 	for (int32_t i = 0; i < q->n_arc; ++i) ax[(size_t)i] = q->arc[i].x, aw[(size_t)i] = (uint8_t)q->arc[i].weak_br;
 	int64_t n = 0;
-	BE_CALL(exact_sort(ext, 1), "override_order"); // branch.c:116
-	BE_CALL(ext->be->mark_hits(ext->ctx, ax.data(), aw.data(), q->n_arc, &n), "mark_hits");
-	BE_CALL(exact_sort(ext, 0), "override_order"); // branch.c:140
+	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 1), "override_order"); } // branch.c:116
+	{ Phase ph(PH_MARK_HITS); BE_CALL(ext->be->mark_hits(ext->ctx, ax.data(), aw.data(), q->n_arc, &n), "mark_hits"); }
+	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // branch.c:140
 	if (pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] marked %ld diverged hits\n", "pg_mark_branch_flt_hit", stamp(), (long)n);
 	return 0;
@@ -643,6 +652,19 @@ int pg_last_error(void) { return g_err; }
 const char *pg_last_error_str(void) { return g_errstr; }
 double pg_last_path_seconds(void) { return g_path_sec; }
 double pg_last_upload_seconds(void) { return g_upload_sec; }
+
+int pg_phase_times(double *out, int n) // seconds per driver phase of the last run; returns the number of phases
+{
+	for (int i = 0; i < n && i < PH_COUNT; ++i) out[i] = g_phase[i];
+	return PH_COUNT;
+}
+
+const char *pg_phase_name(int i)
+{
+	static const char *nm[PH_COUNT] = { "begin(sort)", "exact_order(host)", "ingest", "post", "vtx", "arc_round(device)", "arc_merge(host)",
+	                                    "branch_mark(host)", "n_local", "mark_hits", "flt_high_occ", "sync_host(download)" };
+	return i >= 0 && i < PH_COUNT ? nm[i] : "?";
+}
 
 int pg_rerun_resident(pg_data_t *d) // next pg_post_process restarts on the shard already in HBM
 {

@@ -42,9 +42,11 @@ struct ExactSeg {
 	int32_t k = 0, start = 0;             // local genome index; offset of the contig inside the genome
 	std::vector<int32_t> file;            // file index of each hit of the contig, in file order
 	std::vector<uint64_t> cs, cm;         // sort keys, aligned with `file`
-	std::vector<int32_t> cur, last_x;     // current array order / previous cs order (indices into `file`)
+	std::vector<int32_t> cur;             // current array order (indices into `file`)
+	std::vector<std::vector<int32_t>> hx, hy; // history of cs / cm orders until the sequence becomes periodic
+	int cyc_start = -1, period = 0;       // X_t == X_{cyc_start + (t - cyc_start) % period} for t >= cyc_start (1-based)
+	int n_sort[2] = {0, 0};               // cs / cm sorts replayed so far
 	std::vector<int32_t> pushed[2];       // order the backend currently holds for cs (0) and cm (1)
-	bool stable = false;
 };
 
 // host-private companion of a pg_data_t (struct layout of pg_data_t itself must not change)
@@ -57,6 +59,7 @@ struct DataExt {
 	std::vector<int64_t> hit_off;      // shard hit offsets
 	std::vector<std::vector<int32_t>> y_order; // per genome: host index of the k-th hit in cm order
 	std::vector<ExactSeg> xsegs;
+	std::vector<int32_t> head_file;    // per local genome: file index of the hit at array index 0 (-1 canonical)
 	bool rerun = false;                // pg_rerun_resident(): keep the backend context, skip pack + upload
 	bool host_stale = false;           // per-hit flags on the host are older than the backend's
 	int64_t n_hit_local = 0;
@@ -82,5 +85,10 @@ int exact_mode();
 void exact_init(const pg_data_t *d, DataExt *ext);
 void exact_begin(DataExt *ext);
 int exact_sort(DataExt *ext, int by_cm);
+
+// phase accounting of the host driver (seconds, accumulated over the last run)
+enum { PH_BEGIN, PH_EXACT, PH_INGEST, PH_POST, PH_VTX, PH_ARC_DEV, PH_ARC_HOST, PH_BRANCH_HOST, PH_NLOCAL, PH_MARK_HITS, PH_FLT, PH_SYNC_HOST, PH_COUNT };
+extern double g_phase[PH_COUNT];
+struct Phase { int id; double t0; explicit Phase(int i) : id(i), t0(now_sec()) {} ~Phase() { g_phase[id] += now_sec() - t0; } };
 
 } // namespace pgx
