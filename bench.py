@@ -45,6 +45,10 @@ def main():
     ap.add_argument("--keep", action="store_true", help="keep the generated PAF files")
     a = ap.parse_args()
 
+    # RCCL / HIP print banners on fd 1; the contract is ONE JSON line on stdout: park fd 1 on stderr until the end
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from pangene_amd import capi, synth
@@ -62,7 +66,11 @@ def main():
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     lib.pg_set_exact_mode({"off": 0, "auto": 1, "all": 2}[a.exact])
     keep = None
-    if world > 1:
+    force_x = os.environ.get("PANGENE_FORCE_EXCHANGE") == "1"
+    if world > 1 or force_x:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
         from pangene_amd import exchange
         keep = exchange.install(lib, device=dev)
@@ -194,9 +202,9 @@ def main():
                           "pack_and_upload_s": round(t_upload, 3), "path_only_ms_per_step": round(path_sec / a.steps * 1e3, 3)},
             "host_phases_ms_per_step": {lib.pg_phase_name(i).decode(): round(v / a.steps * 1e3, 3) for i, v in enumerate(phases or [])},
         }
-        print(json.dumps(res), flush=True)
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     lib.pg_data_destroy(d)
-    if world > 1:
+    if world > 1 or force_x:
         dist.barrier()
         dist.destroy_process_group()
     del keep

@@ -149,6 +149,17 @@ typedef struct {
 	/* pg_n_local (branch.c:31-46) for n gene pairs (pairs[2i], pairs[2i+1]) summed over local genomes */ \
 	int  pfx##_n_local(pga_ctx_t *ctx, const int32_t *pairs, int64_t n, int32_t local_dist, int32_t local_count, \
 	                   int32_t frag_mode, int32_t **cnt); \
+	/* pg_mark_branch_flt_arc (branch.c:48-106), split in two so that the counts can be all-reduced in between. \
+	 * branch_pairs: arcs sorted by x with their s1, seg_gid[S] = gene of each segment.  For every oriented vertex \
+	 * with >= 2 arcs it lists the gene pairs the reference hands to pg_n_local -- the (best-scoring target, weaker \
+	 * target) pairs of branch.c:70-75, then every i<j pair of 83-88 -- and counts each over the local genomes \
+	 * (needs rep_pos): cnt[n_pairs] in backend memory.  branch_decide (after the all-reduce of cnt): branch.c:76-77 \
+	 * and 82-90 -> weak_br per arc (host, n_arc bytes) and n_dist_loci (host, 2S).  The arcs and their weak_br stay \
+	 * resident: mark_hits(NULL, NULL, n_arc) uses them. */ \
+	int  pfx##_branch_pairs(pga_ctx_t *ctx, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg, \
+	                        double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs); \
+	int  pfx##_branch_decide(pga_ctx_t *ctx, double branch_diff, double branch_diff_dist, double branch_diff_cut, uint8_t *arc_weak, \
+	                         int32_t *n_dist_loci, int64_t *n_flt1, int64_t *n_flt2); \
 	/* pg_mark_branch_flt_hit (branch.c:108-145); arcs sorted by x with their weak_br (0 allowed) */ \
 	int  pfx##_mark_hits(pga_ctx_t *ctx, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked); \
 	/* Replace the order inside contig segments by the exact order the reference's unstable radix sort \
@@ -194,6 +205,8 @@ typedef struct {
 	int  (*arc_round)(pga_ctx_t *, int32_t, int32_t **, pga_arc_part_t **, int64_t *);
 	int  (*rep_pos)(pga_ctx_t *);
 	int  (*n_local)(pga_ctx_t *, const int32_t *, int64_t, int32_t, int32_t, int32_t, int32_t **);
+	int  (*branch_pairs)(pga_ctx_t *, const uint64_t *, const int32_t *, int64_t, const int32_t *, int32_t, double, int32_t, int32_t, int32_t, int32_t **, int64_t *);
+	int  (*branch_decide)(pga_ctx_t *, double, double, double, uint8_t *, int32_t *, int64_t *, int64_t *);
 	int  (*mark_hits)(pga_ctx_t *, const uint64_t *, const uint8_t *, int64_t, int64_t *);
 	int  (*override_order)(pga_ctx_t *, int32_t, int32_t, const int32_t *, const int32_t *, const int64_t *, const int32_t *);
 	int  (*set_head)(pga_ctx_t *, const int32_t *);

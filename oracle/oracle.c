@@ -49,6 +49,8 @@ struct pga_ctx {
 	int32_t *nl_cnt;
 	pga_hazard_t hz;
 	void *scratch; size_t m_scratch;
+	/* branch state kept between branch_pairs and branch_decide / mark_hits */
+	uint64_t *br_x; int32_t *br_s1, *br_gid, *br_pairs; uint8_t *br_weak; int64_t br_n, br_np; int32_t br_S;
 	int64_t *head;            /* [n_genome] X position of the hit that plays "index 0" (never reset by pg_shadow) */
 	/* raw shard, file order (kept so that begin() can restart the run) */
 	int32_t *r_pid, *r_cid, *r_rank, *r_sori, *r_sadj, *r_nex, *r_offx, *r_cs, *r_ce, *r_cm; uint8_t *r_rev;
@@ -133,6 +135,7 @@ void pgo_destroy(pga_ctx_t *c)
 	free(c->pid_dom); free(c->pid_dom0); free(c->flags); free(c->yo); free(c->exon_os); free(c->exon_oe);
 	free(c->prot_gid); free(c->gene_pref); free(c->max_ori); free(c->sums); free(c->vtx_cnt); free(c->triples);
 	free(c->g2s); free(c->seg_cnt); free(c->arcs); free(c->rp_x); free(c->rp_y); free(c->nl_cnt); free(c->scratch); free(c->head);
+	free(c->br_x); free(c->br_s1); free(c->br_gid); free(c->br_pairs); free(c->br_weak);
 	free(c->r_pid); free(c->r_cid); free(c->r_rank); free(c->r_sori); free(c->r_sadj); free(c->r_nex); free(c->r_offx); free(c->r_cs); free(c->r_ce); free(c->r_cm); free(c->r_rev);
 	free(c);
 }
@@ -656,6 +659,90 @@ int pgo_n_local(pga_ctx_t *c, const int32_t *pairs, int64_t n, int32_t local_dis
 	return PGA_OK;
 }
 
+
+/* enumerate (and, with cnt != 0, consume) the pg_n_local calls of pg_mark_branch_flt_arc for one vertex, in the
+ * reference's order (branch.c:64-90).  a0 = first arc, n = #arcs. */
+static int64_t branch_vertex(pga_ctx_t *c, int64_t a0, int32_t n, double branch_diff, int32_t *pairs, const int32_t *cnt,
+                             double bdist, double bcut, int32_t *n_group_out, int64_t *flt1, int64_t *flt2)
+{
+	int32_t i, j, max_s1 = 0, n_group = 0;
+	int64_t k = 0;
+	int32_t *tmp = CALLOC(int32_t, n);
+	for (i = 0; i < n; ++i) max_s1 = max_s1 > c->br_s1[a0 + i] ? max_s1 : c->br_s1[a0 + i];
+	for (i = 0; i < n; ++i) {
+		double r = 1.0 - (double)c->br_s1[a0 + i] / max_s1; /* branch.c:71 */
+		if (r > branch_diff) {
+			int32_t n_local = 0;
+			for (j = 0; j < n; ++j) {
+				if (c->br_s1[a0 + j] != max_s1) continue; /* max_gid[], branch.c:66-68 */
+				if (pairs) pairs[2*k] = c->br_gid[a0 + j], pairs[2*k+1] = c->br_gid[a0 + i];
+				if (cnt) n_local += cnt[k];
+				++k;
+			}
+			if (cnt) { /* branch.c:76-77 */
+				if ((n_local == 0 && r > bdist) || r > bcut) c->br_weak[a0 + i] = 2, ++*flt2;
+				else c->br_weak[a0 + i] = 1, ++*flt1;
+			}
+		}
+	}
+	for (i = 0; i < n; ++i) { /* branch.c:82-90: pg_n_local is evaluated before the tmp[j]==0 test */
+		if (tmp[i] == 0) tmp[i] = ++n_group;
+		for (j = i + 1; j < n; ++j) {
+			if (pairs) pairs[2*k] = c->br_gid[a0 + i], pairs[2*k+1] = c->br_gid[a0 + j];
+			if (cnt && cnt[k] > 0 && tmp[j] == 0) tmp[j] = tmp[i];
+			++k;
+		}
+	}
+	free(tmp);
+	if (n_group_out) *n_group_out = n_group;
+	return k;
+}
+
+int pgo_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg,
+                     double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs)
+{
+	int64_t i, i0, np = 0, k;
+	int pass, rc;
+	free(c->br_x); free(c->br_s1); free(c->br_gid); free(c->br_weak); free(c->br_pairs);
+	c->br_x = MALLOC(uint64_t, n_arc); c->br_s1 = MALLOC(int32_t, n_arc); c->br_gid = MALLOC(int32_t, n_arc); c->br_weak = CALLOC(uint8_t, n_arc);
+	memcpy(c->br_x, arc_x, n_arc * sizeof(uint64_t)); memcpy(c->br_s1, arc_s1, n_arc * sizeof(int32_t));
+	for (i = 0; i < n_arc; ++i) c->br_gid[i] = seg_gid[(uint32_t)arc_x[i] >> 1];
+	c->br_n = n_arc, c->br_S = n_seg, c->br_pairs = 0;
+	for (pass = 0; pass < 2; ++pass) {
+		k = 0;
+		for (i0 = 0, i = 1; i <= n_arc; ++i)
+			if (i == n_arc || arc_x[i] >> 32 != arc_x[i0] >> 32) {
+				if (i - i0 >= 2) k += branch_vertex(c, i0, (int32_t)(i - i0), branch_diff, pass ? c->br_pairs + 2 * k : 0, 0, 0, 0, 0, 0, 0);
+				i0 = i;
+			}
+		if (pass == 0) np = k, c->br_pairs = MALLOC(int32_t, 2 * np);
+	}
+	c->br_np = np;
+	rc = pgo_n_local(c, c->br_pairs, np, local_dist, local_count, frag_mode, cnt);
+	*n_pairs = np;
+	return rc;
+}
+
+int pgo_branch_decide(pga_ctx_t *c, double branch_diff, double branch_diff_dist, double branch_diff_cut, uint8_t *arc_weak,
+                      int32_t *n_dist_loci, int64_t *n_flt1, int64_t *n_flt2)
+{
+	int64_t i, i0, k = 0, f1 = 0, f2 = 0;
+	memset(n_dist_loci, 0, 2 * (size_t)c->br_S * sizeof(int32_t));
+	for (i0 = 0, i = 1; i <= c->br_n; ++i)
+		if (i == c->br_n || c->br_x[i] >> 32 != c->br_x[i0] >> 32) {
+			if (i - i0 >= 2) {
+				int32_t ng;
+				k += branch_vertex(c, i0, (int32_t)(i - i0), branch_diff, 0, c->nl_cnt + k, branch_diff_dist, branch_diff_cut, &ng, &f1, &f2);
+				n_dist_loci[c->br_x[i0] >> 32] = ng;
+			}
+			i0 = i;
+		}
+	memcpy(arc_weak, c->br_weak, c->br_n);
+	if (n_flt1) *n_flt1 = f1;
+	if (n_flt2) *n_flt2 = f2;
+	return PGA_OK;
+}
+
 static int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) /* pg_get_arc, pgpriv.h:99-107 */
 {
 	int64_t lo = 0, hi = n;
@@ -668,6 +755,7 @@ int pgo_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_w, int
 {
 	int32_t j;
 	int64_t k, n = 0;
+	if (arc_x == 0) arc_x = c->br_x, arc_w = c->br_weak, n_arc = c->br_n; /* the arcs of the last branch_pairs/decide */
 	for (j = 0; j < c->n_genome; ++j) {
 		uint32_t v = (uint32_t)-1, w;
 		int64_t vi = -1;
@@ -792,7 +880,7 @@ const pga_backend_t *pgo_backend(void)
 {
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
-		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_rep_pos, pgo_n_local, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
+		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
 		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0
 	};
 	return &b;

@@ -54,7 +54,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_PERM, S_OVPOS, S_OVFILE, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
+	S_PERM, S_OVPOS, S_OVFILE, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
 	S_COUNT
 };
 
@@ -79,6 +79,7 @@ struct pga_ctx {
 	int64_t *dcnt = 0;      // device counters: [0] triples [1] arcs-temp [2] misc [3] invariant flag, [4..7] hazards
 	int64_t *h_cnt = 0;     // pinned mirror
 	DevPool pool;
+	int64_t br_n = 0, br_np = 0; int32_t br_S = 0; // arcs / pairs / segments of the last branch_pairs
 	std::vector<TimedLaunch> timed;
 	std::vector<void *> owned;
 };
@@ -715,6 +716,62 @@ __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t
 	if (lane == 0) cnt[k] = c;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// pg_mark_branch_flt_arc (branch.c:48-106) on the arc table: one thread per oriented vertex
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_br_prep(const uint64_t *ax, int64_t n_arc, const int32_t *seg_gid, int32_t *agid, int32_t *vs, int32_t *ve)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n_arc) return;
+	const uint64_t x = ax[i];
+	const uint32_t v = (uint32_t)(x >> 32);
+	agid[i] = seg_gid[(uint32_t)x >> 1];
+	if (i == 0 || (uint32_t)(ax[i - 1] >> 32) != v) vs[v] = (int32_t)i;
+	if (i == n_arc - 1 || (uint32_t)(ax[i + 1] >> 32) != v) ve[v] = (int32_t)i + 1;
+}
+
+// MODE 0: count the pg_n_local calls of vertex v; 1: write their gene pairs; 2: consume the counts and decide
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_br_vertex(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1, const int32_t *agid, double bd,
+                                                       int32_t *pc, const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
+                                                       uint8_t *weak, int32_t *grp, int32_t *ndl, int64_t *dcnt)
+{
+	const int v = blockIdx.x * BLOCK + threadIdx.x;
+	if (v >= n_vtx) return;
+	const int a0 = vs[v], n = ve[v] - a0;
+	if (n < 2) { if (MODE == 0) pc[v] = 0; return; }
+	int max_s1 = 0;
+	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[a0 + i] ? max_s1 : s1[a0 + i];
+	int64_t k = MODE == 0 ? 0 : poff[v];
+	for (int i = 0; i < n; ++i) {
+		const double r = 1.0 - (double)s1[a0 + i] / max_s1; // branch.c:71
+		if (!(r > bd)) continue;
+		int n_local = 0;
+		for (int j = 0; j < n; ++j) {
+			if (s1[a0 + j] != max_s1) continue; // max_gid[], branch.c:66-68
+			if (MODE == 1) pairs[2 * k] = agid[a0 + j], pairs[2 * k + 1] = agid[a0 + i];
+			if (MODE == 2) n_local += cnt[k];
+			++k;
+		}
+		if (MODE == 2) { // branch.c:76-77
+			if ((n_local == 0 && r > bdist) || r > bcut) weak[a0 + i] = 2, atomicAdd((unsigned long long *)&dcnt[9], 1ull);
+			else weak[a0 + i] = 1, atomicAdd((unsigned long long *)&dcnt[8], 1ull);
+		}
+	}
+	int n_group = 0;
+	for (int i = 0; i < n; ++i) { // branch.c:82-90
+		if (MODE == 2 && grp[a0 + i] == 0) grp[a0 + i] = ++n_group;
+		for (int j = i + 1; j < n; ++j) {
+			if (MODE == 1) pairs[2 * k] = agid[a0 + i], pairs[2 * k + 1] = agid[a0 + j];
+			if (MODE == 2 && cnt[k] > 0 && grp[a0 + j] == 0) grp[a0 + j] = grp[a0 + i];
+			++k;
+		}
+	}
+	if (MODE == 0) pc[v] = (int32_t)k;
+	if (MODE == 2) ndl[v] = n_group;
+}
+
 __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107
 {
 	int64_t lo = 0, hi = n;
@@ -1246,17 +1303,86 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 	return 0;
 }
 
+static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt)
+{
+	int32_t *d_cnt = (int32_t *)c->pool.get(S_NLCNT, sizeof(int32_t) * (size_t)n + 16);
+	int32_t *rp_seg = (int32_t *)c->pool.get(S_RP_SEG, 0), *rp_r = (int32_t *)c->pool.get(S_RP_R, 0), *rp_cm = (int32_t *)c->pool.get(S_RP_CM, 0);
+	if (!d_cnt || !rp_seg || !rp_r || !rp_cm) return PGA_ERR_NOMEM;
+	*cnt = d_cnt;
+	if (n) hipLaunchKernelGGL(k_n_local, dim3(nblk(n, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, rp_seg, rp_r, rp_cm, local_dist, local_count, frag_mode, d_cnt);
+	return 0;
+}
+
 extern "C" int pga_n_local(pga_ctx_t *c, const int32_t *pairs, int64_t n, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt)
 {
 	int32_t *d_pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)n + 16);
-	int32_t *d_cnt = (int32_t *)c->pool.get(S_NLCNT, sizeof(int32_t) * (size_t)n + 16);
-	int32_t *rp_seg = (int32_t *)c->pool.get(S_RP_SEG, 0), *rp_r = (int32_t *)c->pool.get(S_RP_R, 0), *rp_cm = (int32_t *)c->pool.get(S_RP_CM, 0);
-	if (!d_pairs || !d_cnt || !rp_seg || !rp_r || !rp_cm) return PGA_ERR_NOMEM;
-	*cnt = d_cnt;
-	if (n == 0) return 0;
-	TRY(upload(c, d_pairs, pairs, 2 * (size_t)n));
-	hipLaunchKernelGGL(k_n_local, dim3(nblk(n, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, rp_seg, rp_r, rp_cm, local_dist, local_count, frag_mode, d_cnt);
+	if (!d_pairs) return PGA_ERR_NOMEM;
+	if (n) TRY(upload(c, d_pairs, pairs, 2 * (size_t)n));
+	TRY(n_local_dev(c, d_pairs, n, local_dist, local_count, frag_mode, cnt));
 	return sync_st(c); // pairs is caller memory; the exchange may run on another stream
+}
+
+extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg,
+                                double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs)
+{
+	const int n_vtx = 2 * n_seg;
+	uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, sizeof(uint64_t) * (size_t)n_arc + 16);
+	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, (size_t)n_arc + 16);
+	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, sizeof(int32_t) * (size_t)n_arc + 16), *agid = (int32_t *)c->pool.get(S_BR_GID, sizeof(int32_t) * (size_t)n_arc + 16);
+	int32_t *vs = (int32_t *)c->pool.get(S_BR_VS, sizeof(int32_t) * (size_t)n_vtx + 16), *ve = (int32_t *)c->pool.get(S_BR_VE, sizeof(int32_t) * (size_t)n_vtx + 16);
+	int32_t *pc = (int32_t *)c->pool.get(S_BR_PC, sizeof(int32_t) * (size_t)n_vtx + 16), *poff = (int32_t *)c->pool.get(S_BR_POFF, sizeof(int32_t) * (size_t)n_vtx + 16);
+	int32_t *sg = (int32_t *)c->pool.get(S_BR_SEGGID, sizeof(int32_t) * (size_t)n_seg + 16);
+	if (!ax || !aw || !s1 || !agid || !vs || !ve || !pc || !poff || !sg) return PGA_ERR_NOMEM;
+	c->br_n = n_arc, c->br_S = n_seg, c->br_np = 0;
+	*n_pairs = 0, *cnt = (int32_t *)c->pool.get(S_NLCNT, 16);
+	if (n_arc == 0 || n_vtx == 0) return sync_st(c);
+	TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, s1, arc_s1, (size_t)n_arc)); TRY(upload(c, sg, seg_gid, (size_t)n_seg));
+	HIPCHK(hipMemsetAsync(vs, 0, sizeof(int32_t) * (size_t)n_vtx, c->st)); HIPCHK(hipMemsetAsync(ve, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
+	HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st));
+	hipLaunchKernelGGL(k_br_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, ax, n_arc, sg, agid, vs, ve);
+	hipLaunchKernelGGL((k_br_vertex<0>), dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, (const int32_t *)nullptr, (int32_t *)nullptr,
+	                   (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt);
+	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+	device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
+	int32_t tail[2];
+	HIPCHK(hipMemcpyAsync(&tail[0], poff + (n_vtx - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(&tail[1], pc + (n_vtx - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+	TRY(sync_st(c));
+	const int64_t np = (int64_t)tail[0] + tail[1];
+	c->br_np = np, *n_pairs = np;
+	int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)np + 16);
+	if (!pairs) return PGA_ERR_NOMEM;
+	if (np) hipLaunchKernelGGL((k_br_vertex<1>), dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, poff, pairs,
+	                           (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt);
+	TRY(n_local_dev(c, pairs, np, local_dist, local_count, frag_mode, cnt));
+	return sync_st(c); // the exchange may run on another stream
+}
+
+extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch_diff_dist, double branch_diff_cut, uint8_t *arc_weak,
+                                 int32_t *n_dist_loci, int64_t *n_flt1, int64_t *n_flt2)
+{
+	const int n_vtx = 2 * c->br_S;
+	const int64_t n_arc = c->br_n;
+	if (n_flt1) *n_flt1 = 0;
+	if (n_flt2) *n_flt2 = 0;
+	if (n_vtx) memset(n_dist_loci, 0, sizeof(int32_t) * (size_t)n_vtx);
+	if (n_arc == 0 || n_vtx == 0) return 0;
+	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, 0);
+	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, 0), *agid = (int32_t *)c->pool.get(S_BR_GID, 0), *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0);
+	int32_t *pc = (int32_t *)c->pool.get(S_BR_PC, 0), *poff = (int32_t *)c->pool.get(S_BR_POFF, 0), *cnt = (int32_t *)c->pool.get(S_NLCNT, 0);
+	int32_t *grp = (int32_t *)c->pool.get(S_BR_GRP, sizeof(int32_t) * (size_t)n_arc + 16), *ndl = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
+	if (!grp || !ndl) return PGA_ERR_NOMEM;
+	HIPCHK(hipMemsetAsync(grp, 0, sizeof(int32_t) * (size_t)n_arc, c->st)); HIPCHK(hipMemsetAsync(ndl, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
+	HIPCHK(hipMemsetAsync(c->dcnt + 8, 0, 2 * sizeof(int64_t), c->st));
+	hipLaunchKernelGGL((k_br_vertex<2>), dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, poff, (int32_t *)nullptr, cnt,
+	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt);
+	HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(n_dist_loci, ndl, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	TRY(sync_st(c));
+	if (n_flt1) *n_flt1 = c->h_cnt[8];
+	if (n_flt2) *n_flt2 = c->h_cnt[9];
+	return 0;
 }
 
 extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked)
@@ -1264,11 +1390,12 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 	const int N = c->N;
 	if (n_marked) *n_marked = 0;
 	if (N == 0) return 0;
-	uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, sizeof(uint64_t) * (size_t)n_arc + 16);
-	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, (size_t)n_arc + 16);
+	if (arc_x == nullptr) n_arc = c->br_n; // the arcs (and weak_br) left resident by branch_pairs / branch_decide
+	uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, arc_x ? sizeof(uint64_t) * (size_t)n_arc + 16 : 0);
+	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, arc_x ? (size_t)n_arc + 16 : 0);
 	int32_t *wn = (int32_t *)c->pool.get(S_WEAKNEW, sizeof(int32_t) * (size_t)N);
 	if (!ax || !aw || !wn) return PGA_ERR_NOMEM;
-	TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, aw, arc_weak, (size_t)n_arc));
+	if (arc_x) { TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, aw, arc_weak, (size_t)n_arc)); }
 	HIPCHK(hipMemsetAsync(wn, 0, sizeof(int32_t) * (size_t)N, c->st));
 	HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
 	int32_t *val, *prev;
@@ -1405,7 +1532,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 {
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
-		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_rep_pos, pga_n_local, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
+		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
 		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get
 	};
 	return &b;

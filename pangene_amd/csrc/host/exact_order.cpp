@@ -142,6 +142,7 @@ int exact_sort(DataExt *ext, int by_cm)
 		so.push_back((int64_t)fi.size());
 	}
 	if (sg.empty()) return 0;
+	ext->pos_valid = false; // the backend's orders change: the host copy of them is stale
 	return ext->be->override_order(ext->ctx, by_cm, (int32_t)sg.size(), sg.data(), ss.data(), so.data(), fi.data());
 }
 

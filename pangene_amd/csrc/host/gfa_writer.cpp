@@ -77,7 +77,7 @@ int pg_set_output(const char *path)
 
 void pg_write_bed(const pg_data_t *d, int32_t is_walk) // format.c:96-118
 {
-	if (sync_host(const_cast<pg_data_t *>(d)) != 0) return;
+	if (sync_host(const_cast<pg_data_t *>(d), true) != 0) return;
 	FILE *fp = out_stream();
 	std::string o;
 	for (int32_t j = 0; j < d->n_genome; ++j) {
@@ -126,7 +126,7 @@ void pg_write_graph(const pg_graph_t *q) // format.c:120-157
 void pg_write_walk(pg_graph_t *q)
 {
 	pg_data_t *d = q->d;
-	if (sync_host(d) != 0) return;
+	if (sync_host(d, false) != 0) return;
 	DataExt *ext = ext_of(d, true);
 	FILE *fp = out_stream();
 	std::string o, sample;

@@ -52,7 +52,14 @@ const char *stamp() // "<real>*<cpu/real>", the reference's pg_timestamp (sys.c:
 	return buf;
 }
 
-static inline bool sharded() { return g_has_xchg && g_xchg.world > 1; }
+// PANGENE_FORCE_EXCHANGE=1 routes a single-process run through the exchange callbacks too (lets one GPU
+// exercise the RCCL plumbing; results are unchanged because every collective is then an identity)
+static inline bool sharded()
+{
+	static int force = -1;
+	if (force < 0) { const char *e = std::getenv("PANGENE_FORCE_EXCHANGE"); force = e && *e == '1'; }
+	return g_has_xchg && (g_xchg.world > 1 || force);
+}
 
 #define BE_CALL(expr, where) do { int rc__ = (expr); if (rc__ != 0) { set_error(rc__, where); return rc__; } } while (0)
 
@@ -102,6 +109,7 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	ext->local_genomes.clear();
 	ext->is_local.resize((size_t)d->n_genome, 1);
 	ext->hits_sorted.assign((size_t)d->n_genome, 0);
+	ext->pos_valid = false, ext->host_full = false;
 	for (int32_t j = 0; j < d->n_genome; ++j)
 		if (ext->is_local[(size_t)j]) ext->local_genomes.push_back(j);
 	const int32_t nl = (int32_t)ext->local_genomes.size();
@@ -151,31 +159,50 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 }
 
 // Pull per-hit state back and (first time) put the host arrays into cs order, which is how the
-// reference leaves them (hit.c:57-63 replaces g->hit on every sort).
-int sync_host(pg_data_t *d)
+// reference leaves them (hit.c:57-63 replaces g->hit on every sort).  full = false fetches only what the
+// GFA writers read (the flag word; the two orders once per order epoch); full = true also rank, score_dom and
+// the dominators (BED writers).
+int sync_host(pg_data_t *d, bool full)
 {
 	DataExt *ext = ext_of(d, false);
-	if (ext == nullptr || ext->ctx == nullptr || !ext->host_stale) return g_err;
+	if (ext == nullptr || ext->ctx == nullptr) return g_err;
+	if (!ext->host_stale && !(full && !ext->host_full)) return g_err;
 	Phase ph(PH_SYNC_HOST);
 	const int64_t N = ext->n_hit_local;
+	const bool need_pos = !ext->pos_valid;
 	std::vector<uint32_t> flags((size_t)N);
-	std::vector<int32_t> rank((size_t)N), sdom((size_t)N), pdom((size_t)N), pdom0((size_t)N), px((size_t)N), py((size_t)N);
-	pga_hit_state_t st = { flags.data(), rank.data(), sdom.data(), pdom.data(), pdom0.data(), px.data(), py.data() };
+	std::vector<int32_t> rank, sdom, pdom, pdom0, py;
+	if (full) rank.resize((size_t)N), sdom.resize((size_t)N), pdom.resize((size_t)N), pdom0.resize((size_t)N);
+	if (need_pos) ext->pos_x.resize((size_t)N), py.resize((size_t)N);
+	pga_hit_state_t st = { flags.data(), full ? rank.data() : nullptr, full ? sdom.data() : nullptr, full ? pdom.data() : nullptr,
+	                       full ? pdom0.data() : nullptr, need_pos ? ext->pos_x.data() : nullptr, need_pos ? py.data() : nullptr };
 	BE_CALL(ext->be->download(ext->ctx, &st), "download");
+	const int32_t *px = ext->pos_x.data();
 	ext->y_order.resize((size_t)d->n_genome);
 	for (size_t k = 0; k < ext->local_genomes.size(); ++k) {
 		int32_t j = ext->local_genomes[k];
 		pg_genome_t *g = &d->genome[j];
 		const int64_t off = ext->hit_off[k];
-		// host order -> file index: identity before the first sync, afterwards the inverse of pos_x
-		if (!ext->hits_sorted[(size_t)j]) {
+		if (need_pos) {
+			// the host array is in file order before the first sync and in the PREVIOUS cs order afterwards
 			pg_hit_t *a = (pg_hit_t *)std::malloc(sizeof(pg_hit_t) * (size_t)(g->n_hit > 0 ? g->n_hit : 1));
-			for (int32_t f = 0; f < g->n_hit; ++f) a[px[(size_t)(off + f)]] = g->hit[f];
+			if (!ext->hits_sorted[(size_t)j]) {
+				for (int32_t f = 0; f < g->n_hit; ++f) a[px[(size_t)(off + f)]] = g->hit[f];
+			} else {
+				const int32_t *old = ext->file_of_host[(size_t)j].data(); // host index -> file index
+				for (int32_t h = 0; h < g->n_hit; ++h) a[px[(size_t)(off + old[h])]] = g->hit[h];
+			}
 			std::free(g->hit);
 			g->hit = a, g->m_hit = g->n_hit;
 			ext->hits_sorted[(size_t)j] = 1;
+			ext->file_of_host.resize((size_t)d->n_genome);
+			ext->file_of_host[(size_t)j].assign((size_t)g->n_hit, 0);
+			ext->y_order[(size_t)j].assign((size_t)g->n_hit, 0);
+			for (int32_t f = 0; f < g->n_hit; ++f) {
+				ext->file_of_host[(size_t)j][(size_t)px[(size_t)(off + f)]] = f;
+				ext->y_order[(size_t)j][(size_t)py[(size_t)(off + f)]] = px[(size_t)(off + f)];
+			}
 		}
-		ext->y_order[(size_t)j].assign((size_t)g->n_hit, 0);
 		for (int32_t f = 0; f < g->n_hit; ++f) {
 			const size_t s = (size_t)(off + f);
 			pg_hit_t *h = &g->hit[px[s]];
@@ -183,11 +210,12 @@ int sync_host(pg_data_t *d)
 			h->flt = !!(fl & PGA_F_FLT), h->flt_iso_sub_self = !!(fl & PGA_F_ISO_SUB), h->flt_iso_ov = !!(fl & PGA_F_ISO_OV);
 			h->flt_chain = !!(fl & PGA_F_CHAIN), h->pseudo = !!(fl & PGA_F_PSEUDO), h->vtx = !!(fl & PGA_F_VTX);
 			h->shadow = !!(fl & PGA_F_SHADOW), h->rep = !!(fl & PGA_F_REP), h->weak_br = (fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT;
-			h->rank = rank[s], h->score_dom = sdom[s], h->pid_dom = pdom[s], h->pid_dom0 = pdom0[s];
-			ext->y_order[(size_t)j][(size_t)py[s]] = px[s];
+			if (full) h->rank = rank[s], h->score_dom = sdom[s], h->pid_dom = pdom[s], h->pid_dom0 = pdom0[s];
 		}
 	}
+	ext->pos_valid = true;
 	ext->host_stale = false;
+	ext->host_full = full;
 	return 0;
 }
 
@@ -316,25 +344,18 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	std::vector<uint64_t> tri;
 	BE_CALL(xgather(be, ext->ctx, b_tri, n_tri, tri), "allgather(triples)");
 
-	// (genome, dom gene) pairs get dense ids; per sub gene the list of pair ids it would mark
+	// per sub gene: the (genome, dom gene) cells it would mark; cells are addressed genome*Q + gene
 	const uint64_t m20 = (1u << 20) - 1;
-	std::vector<uint64_t> key(tri.size());
-	for (size_t i = 0; i < tri.size(); ++i) key[i] = (tri[i] >> 40) << 20 | (tri[i] & m20);
-	std::vector<uint64_t> uniq(key);
-	std::sort(uniq.begin(), uniq.end());
-	uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
 	std::vector<int64_t> sub_off((size_t)Q + 1, 0);
 	for (uint64_t t : tri) ++sub_off[(size_t)((t >> 20) & m20) + 1];
 	for (int32_t g = 0; g < Q; ++g) sub_off[(size_t)g + 1] += sub_off[(size_t)g];
-	std::vector<int32_t> sub_pair(tri.size());
+	std::vector<int64_t> sub_cell(tri.size());
 	{
 		std::vector<int64_t> cur(sub_off.begin(), sub_off.end() - 1);
-		for (size_t i = 0; i < tri.size(); ++i) {
-			int32_t g = (int32_t)((tri[i] >> 20) & m20);
-			sub_pair[(size_t)cur[(size_t)g]++] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), key[i]) - uniq.begin());
-		}
+		for (uint64_t t : tri)
+			sub_cell[(size_t)cur[(size_t)((t >> 20) & m20)]++] = (int64_t)(t >> 40) * Q + (int64_t)(t & m20);
 	}
-	std::vector<uint8_t> marked(uniq.size(), 0);
+	std::vector<uint8_t> marked((size_t)G * (size_t)Q, 0);
 	std::vector<int32_t> ycnt((size_t)Q, 0); // #genomes where the gene is dominant and already marked
 
 	std::vector<pg128_t> cnt((size_t)Q);
@@ -366,8 +387,8 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 			p->gid = gid, p->n_dom = n_dom, p->n_sub = n_sub;
 			if (x > 0)
 				for (int64_t k = sub_off[(size_t)gid]; k < sub_off[(size_t)gid + 1]; ++k) {
-					int32_t id = sub_pair[(size_t)k];
-					if (!marked[(size_t)id]) marked[(size_t)id] = 1, ++ycnt[(size_t)(uniq[(size_t)id] & m20)];
+					const int64_t cell = sub_cell[(size_t)k];
+					if (!marked[(size_t)cell]) marked[(size_t)cell] = 1, ++ycnt[(size_t)(cell % Q)];
 				}
 		}
 	}
@@ -458,81 +479,40 @@ static int flt_high_occ(int32_t max_avg_occ, int32_t max_degree, int32_t max_dis
 	return flag_vtx(q, ext);
 }
 
-// pg_mark_branch_flt_arc (branch.c:48-106).  The reference calls pg_n_local (O(#genomes)) once per
-// candidate pair; here all pairs of the round are collected first, counted by one backend call over
-// the local genomes (+ one all-reduce), then the marking logic replays over the counts.
+// pg_mark_branch_flt_arc (branch.c:48-106).  The reference calls pg_n_local (O(#genomes)) once per candidate gene
+// pair; here the backend enumerates all pairs of the round from the arc table, counts them over the local genomes
+// in one launch, the counts are all-reduced, and a second launch applies the marking logic per vertex.
 static int mark_branch_flt_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 {
 	const pga_backend_t *be = ext->be;
-	const uint32_t n_vtx = (uint32_t)q->n_seg * 2;
-	uint32_t n_flt1 = 0, n_flt2 = 0;
-	const int32_t frag_mode = !!(opt->flag & PG_F_FRAG_MODE);
 	Phase ph_all(PH_BRANCH_HOST);
 	BE_CALL(be->rep_pos(ext->ctx), "rep_pos");
-	for (int32_t j = 0; j < q->n_seg; ++j) q->seg[j].n_dist_loci[0] = q->seg[j].n_dist_loci[1] = 0;
-	std::vector<int32_t> pairs, max_gid;
-	auto seg_gid = [&](const pg_arc_t &a) { return q->seg[(uint32_t)a.x >> 1].gid; };
-	for (int pass = 0; pass < 2; ++pass) {
-		std::vector<int32_t> cnt;
-		size_t cur = 0;
-		if (pass == 1) {
-			int32_t *b_cnt;
-			const int64_t np = (int64_t)pairs.size() / 2;
-			Phase ph(PH_NLOCAL);
-			BE_CALL(be->n_local(ext->ctx, pairs.data(), np, opt->local_dist, opt->local_count, frag_mode, &b_cnt), "n_local");
-			BE_CALL(xreduce(be, b_cnt, np, PG_X_I32, PG_X_SUM), "allreduce(n_local)");
-			cnt.resize((size_t)np);
-			if (np) BE_CALL(be->fetch(ext->ctx, cnt.data(), b_cnt, sizeof(int32_t) * (size_t)np), "fetch");
-			g_phase[PH_BRANCH_HOST] -= now_sec() - ph.t0; // counted under PH_NLOCAL
-		}
-		auto n_local = [&](int32_t g1, int32_t g2) -> int32_t {
-			if (pass == 0) { pairs.push_back(g1), pairs.push_back(g2); return 0; }
-			return cnt[cur++];
-		};
-		for (uint32_t v = 0; v < n_vtx; ++v) {
-			const int32_t n = (int32_t)q->idx[v];
-			pg_arc_t *a = &q->arc[q->idx[v] >> 32];
-			if (n < 2) continue;
-			int32_t max_s1 = 0;
-			for (int32_t i = 0; i < n; ++i) max_s1 = max_s1 > a[i].s1 ? max_s1 : a[i].s1;
-			max_gid.clear();
-			for (int32_t i = 0; i < n; ++i)
-				if (a[i].s1 == max_s1) max_gid.push_back(seg_gid(a[i]));
-			for (int32_t i = 0; i < n; ++i) {
-				double r = 1.0 - (double)a[i].s1 / max_s1;
-				if (r > opt->branch_diff) {
-					int32_t nl = 0, gid = seg_gid(a[i]);
-					for (int32_t g : max_gid) nl += n_local(g, gid);
-					if (pass == 1) {
-						if ((nl == 0 && r > opt->branch_diff_dist) || r > opt->branch_diff_cut) a[i].weak_br = 2, ++n_flt2;
-						else a[i].weak_br = 1, ++n_flt1;
-					}
-				}
-			}
-			// n_dist_loci (branch.c:81-90): pg_n_local is evaluated for every i<j before the tmp[j]==0 test
-			std::vector<int32_t> grp((size_t)n, 0);
-			int32_t n_group = 0;
-			for (int32_t i = 0; i < n; ++i) {
-				if (grp[(size_t)i] == 0) grp[(size_t)i] = ++n_group;
-				for (int32_t j = i + 1; j < n; ++j)
-					if (n_local(seg_gid(a[i]), seg_gid(a[j])) > 0 && grp[(size_t)j] == 0) grp[(size_t)j] = grp[(size_t)i];
-			}
-			if (pass == 1) q->seg[v >> 1].n_dist_loci[v & 1] = n_group;
-		}
+	std::vector<uint64_t> ax((size_t)q->n_arc);
+	std::vector<int32_t> s1((size_t)q->n_arc), sgid((size_t)q->n_seg), ndl((size_t)q->n_seg * 2 + 1);
+	std::vector<uint8_t> aw((size_t)q->n_arc + 1);
+	for (int32_t i = 0; i < q->n_arc; ++i) ax[(size_t)i] = q->arc[i].x, s1[(size_t)i] = q->arc[i].s1;
+	for (int32_t i = 0; i < q->n_seg; ++i) sgid[(size_t)i] = q->seg[i].gid;
+	int32_t *b_cnt; int64_t np = 0, n_flt1 = 0, n_flt2 = 0;
+	{
+		Phase ph(PH_NLOCAL);
+		BE_CALL(be->branch_pairs(ext->ctx, ax.data(), s1.data(), q->n_arc, sgid.data(), q->n_seg, opt->branch_diff, opt->local_dist, opt->local_count,
+		                         !!(opt->flag & PG_F_FRAG_MODE), &b_cnt, &np), "branch_pairs");
+		BE_CALL(xreduce(be, b_cnt, np, PG_X_I32, PG_X_SUM), "allreduce(n_local)");
+		BE_CALL(be->branch_decide(ext->ctx, opt->branch_diff, opt->branch_diff_dist, opt->branch_diff_cut, aw.data(), ndl.data(), &n_flt1, &n_flt2), "branch_decide");
+		g_phase[PH_BRANCH_HOST] -= now_sec() - ph.t0; // counted under PH_NLOCAL
 	}
+	for (int32_t i = 0; i < q->n_arc; ++i) q->arc[i].weak_br = aw[(size_t)i];
+	for (int32_t j = 0; j < q->n_seg; ++j) q->seg[j].n_dist_loci[0] = ndl[(size_t)j * 2], q->seg[j].n_dist_loci[1] = ndl[(size_t)j * 2 + 1];
 	if (pg_verbose >= 3)
-		std::fprintf(stderr, "[M::%s::%s] marked %u locally diverged branches and %u distantly diverged branches\n", "pg_mark_branch_flt_arc", stamp(), n_flt1, n_flt2);
+		std::fprintf(stderr, "[M::%s::%s] marked %ld locally diverged branches and %ld distantly diverged branches\n", "pg_mark_branch_flt_arc", stamp(), (long)n_flt1, (long)n_flt2);
 	return 0;
 }
 
-static int mark_branch_flt_hit(pg_graph_t *q, DataExt *ext) // branch.c:108-145
+static int mark_branch_flt_hit(pg_graph_t *q, DataExt *ext) // branch.c:108-145; the arcs and their weak_br are already resident
 {
-	std::vector<uint64_t> ax((size_t)q->n_arc);
-	std::vector<uint8_t> aw((size_t)q->n_arc);
-	for (int32_t i = 0; i < q->n_arc; ++i) ax[(size_t)i] = q->arc[i].x, aw[(size_t)i] = (uint8_t)q->arc[i].weak_br;
 	int64_t n = 0;
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 1), "override_order"); } // branch.c:116
-	{ Phase ph(PH_MARK_HITS); BE_CALL(ext->be->mark_hits(ext->ctx, ax.data(), aw.data(), q->n_arc, &n), "mark_hits"); }
+	{ Phase ph(PH_MARK_HITS); BE_CALL(ext->be->mark_hits(ext->ctx, nullptr, nullptr, q->n_arc, &n), "mark_hits"); }
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // branch.c:140
 	if (pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] marked %ld diverged hits\n", "pg_mark_branch_flt_hit", stamp(), (long)n);
@@ -591,7 +571,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	if (be->hazards(ctx, &hz) == 0 && (hz.h1_head_tie | hz.h2_cm_tie | hz.h3_dom_tie) && pg_verbose >= 2)
 		std::fprintf(stderr, "[W::%s] tie-order hazards seen (head-tie %ld, cm-tie %ld, dominator-tie %ld): output may differ from the reference's unstable sort order\n",
 		             "pg_graph_gen", (long)hz.h1_head_tie, (long)hz.h2_cm_tie, (long)hz.h3_dom_tie);
-	return sync_host(q->d);
+	return sync_host(q->d, false);
 }
 
 } // namespace pgx

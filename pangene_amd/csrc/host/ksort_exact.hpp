@@ -60,8 +60,15 @@ static void ks_flag_pass(T *a, size_t n, int shift, KeyFn key)
 template <class T, class KeyFn>
 static void ksort_exact(T *a, size_t n, KeyFn key)
 {
-	if (n <= 64) ks_insertion(a, n, key);
-	else ks_flag_pass(a, n, 56, key);
+	if (n <= 64) { ks_insertion(a, n, key); return; }
+	// A pass in which every key has the same digit moves nothing (each element is already "home") and then
+	// recurses on the whole array with the next digit: start directly at the highest byte that varies.
+	uint64_t diff = 0, k0 = key(a[0]);
+	for (size_t i = 1; i < n; ++i) diff |= key(a[i]) ^ k0;
+	if (diff == 0) return;
+	int top = 63;
+	while (!(diff >> top & 1)) --top;
+	ks_flag_pass(a, n, top / 8 * 8, key);
 }
 
 } // namespace pgx

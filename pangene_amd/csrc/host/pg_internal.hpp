@@ -61,6 +61,10 @@ struct DataExt {
 	std::vector<ExactSeg> xsegs;
 	std::vector<int32_t> head_file;    // per local genome: file index of the hit at array index 0 (-1 canonical)
 	bool rerun = false;                // pg_rerun_resident(): keep the backend context, skip pack + upload
+	bool host_full = false;            // the last sync also fetched rank / score_dom / dominators
+	bool pos_valid = false;            // pos_x / y_order on the host match the backend's current orders
+	std::vector<int32_t> pos_x;        // per local hit (file order): position inside its genome in cs order
+	std::vector<std::vector<int32_t>> file_of_host; // per genome: host array index -> file index
 	bool host_stale = false;           // per-hit flags on the host are older than the backend's
 	int64_t n_hit_local = 0;
 };
@@ -79,7 +83,7 @@ double now_sec();
 const char *stamp();
 
 // bring the host AoS (flags, rank, dominators, order) up to date with the backend
-int sync_host(pg_data_t *d);
+int sync_host(pg_data_t *d, bool full);
 
 int exact_mode();
 void exact_init(const pg_data_t *d, DataExt *ext);

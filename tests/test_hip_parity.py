@@ -102,3 +102,40 @@ def test_empty_and_degenerate_inputs(hip, ora, tmp_path):
     files = [str(p / x) for x in ("a.paf", "b.paf", "c.paf")]
     for args in ([], ["-p0"], ["--bed=raw"]):
         assert capi.run(hip, files, args) == capi.run(ora, files, args)
+
+
+def test_exchange_aliases_device_memory():
+    """the exchange hook must operate IN PLACE on library-owned HBM: torch.as_tensor on a raw pointer may not copy"""
+    import torch
+    from pangene_amd import exchange
+    base = torch.arange(64, dtype=torch.int32, device="cuda")
+    t = exchange._tensor(base.data_ptr(), 64 * 4, 1, base.device).view(torch.int32)
+    t.add_(5)
+    torch.cuda.synchronize()
+    assert base[3].item() == 8 and t.data_ptr() == base.data_ptr()
+
+
+def test_forced_exchange_single_rank_nccl(built, tmp_path):
+    """one GPU, world size 1, every collective routed through torch.distributed/nccl (RCCL): same GFA"""
+    import sys
+    files = synth.write_files(synth.bact(10, 300, seed=3), str(tmp_path / "x"))
+    code = r'''
+import sys, os, ctypes as C
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from pangene_amd import capi, exchange
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", PANGENE_FORCE_EXCHANGE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+lib = capi.load(); C.c_int.in_dll(lib, "pg_verbose").value = 0
+keep = exchange.install(lib, device=torch.device("cuda", 0))
+out = capi.run(lib, sys.argv[2:], [])
+open(sys.argv[1], 'wb').write(out)
+dist.destroy_process_group()
+''' % ROOT
+    outp = str(tmp_path / "x.gfa")
+    r = subprocess.run([sys.executable, "-c", code, outp] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lib = capi.load()
+    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    assert open(outp, "rb").read() == capi.run(lib, files, [])
