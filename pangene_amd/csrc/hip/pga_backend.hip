@@ -731,26 +731,36 @@ __global__ __launch_bounds__(BLOCK) void k_br_prep(const uint64_t *ax, int64_t n
 	if (i == n_arc - 1 || (uint32_t)(ax[i + 1] >> 32) != v) ve[v] = (int32_t)i + 1;
 }
 
-// MODE 0: count the pg_n_local calls of vertex v; 1: write their gene pairs; 2: consume the counts and decide
+// MODE 0: count the pg_n_local calls of vertex v; 1: write their gene pairs; 2: consume the counts and decide.
+// The arcs of a vertex (scores, target genes, group marks) are staged in an LDS row per thread so that the
+// O(n^2) loops run out of LDS; vertices with more than BR_MAXDEG arcs fall back to global memory.
+constexpr int BR_MAXDEG = 32;
+constexpr int BR_BLOCK = 128;
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_br_vertex(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1, const int32_t *agid, double bd,
-                                                       int32_t *pc, const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
-                                                       uint8_t *weak, int32_t *grp, int32_t *ndl, int64_t *dcnt)
+__global__ __launch_bounds__(BR_BLOCK) void k_br_vertex(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
+                                                          int32_t *pc, const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
+                                                          uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt)
 {
-	const int v = blockIdx.x * BLOCK + threadIdx.x;
+	__shared__ int32_t l_s1[BR_BLOCK][BR_MAXDEG + 1], l_gid[BR_BLOCK][BR_MAXDEG + 1], l_grp[BR_BLOCK][BR_MAXDEG + 1];
+	const int v = blockIdx.x * BR_BLOCK + threadIdx.x;
 	if (v >= n_vtx) return;
 	const int a0 = vs[v], n = ve[v] - a0;
 	if (n < 2) { if (MODE == 0) pc[v] = 0; return; }
+	const bool lds = n <= BR_MAXDEG;
+	int32_t *s1 = lds ? l_s1[threadIdx.x] : const_cast<int32_t *>(s1g) + a0;
+	int32_t *agid = lds ? l_gid[threadIdx.x] : const_cast<int32_t *>(agidg) + a0;
+	int32_t *grp = lds ? l_grp[threadIdx.x] : grpg + a0; // grpg is zeroed by the caller
+	if (lds) for (int i = 0; i < n; ++i) s1[i] = s1g[a0 + i], agid[i] = agidg[a0 + i], grp[i] = 0;
 	int max_s1 = 0;
-	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[a0 + i] ? max_s1 : s1[a0 + i];
+	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[i] ? max_s1 : s1[i];
 	int64_t k = MODE == 0 ? 0 : poff[v];
 	for (int i = 0; i < n; ++i) {
-		const double r = 1.0 - (double)s1[a0 + i] / max_s1; // branch.c:71
+		const double r = 1.0 - (double)s1[i] / max_s1; // branch.c:71
 		if (!(r > bd)) continue;
 		int n_local = 0;
 		for (int j = 0; j < n; ++j) {
-			if (s1[a0 + j] != max_s1) continue; // max_gid[], branch.c:66-68
-			if (MODE == 1) pairs[2 * k] = agid[a0 + j], pairs[2 * k + 1] = agid[a0 + i];
+			if (s1[j] != max_s1) continue; // max_gid[], branch.c:66-68
+			if (MODE == 1) pairs[2 * k] = agid[j], pairs[2 * k + 1] = agid[i];
 			if (MODE == 2) n_local += cnt[k];
 			++k;
 		}
@@ -761,10 +771,10 @@ __global__ __launch_bounds__(BLOCK) void k_br_vertex(int n_vtx, const int32_t *v
 	}
 	int n_group = 0;
 	for (int i = 0; i < n; ++i) { // branch.c:82-90
-		if (MODE == 2 && grp[a0 + i] == 0) grp[a0 + i] = ++n_group;
+		if (MODE == 2 && grp[i] == 0) grp[i] = ++n_group;
 		for (int j = i + 1; j < n; ++j) {
-			if (MODE == 1) pairs[2 * k] = agid[a0 + i], pairs[2 * k + 1] = agid[a0 + j];
-			if (MODE == 2 && cnt[k] > 0 && grp[a0 + j] == 0) grp[a0 + j] = grp[a0 + i];
+			if (MODE == 1) pairs[2 * k] = agid[i], pairs[2 * k + 1] = agid[j];
+			if (MODE == 2 && cnt[k] > 0 && grp[j] == 0) grp[j] = grp[i];
 			++k;
 		}
 	}
@@ -1340,7 +1350,7 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	HIPCHK(hipMemsetAsync(vs, 0, sizeof(int32_t) * (size_t)n_vtx, c->st)); HIPCHK(hipMemsetAsync(ve, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
 	HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st));
 	hipLaunchKernelGGL(k_br_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, ax, n_arc, sg, agid, vs, ve);
-	hipLaunchKernelGGL((k_br_vertex<0>), dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, (const int32_t *)nullptr, (int32_t *)nullptr,
+	hipLaunchKernelGGL((k_br_vertex<0>), dim3(nblk(n_vtx, BR_BLOCK)), dim3(BR_BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, (const int32_t *)nullptr, (int32_t *)nullptr,
 	                   (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
@@ -1352,7 +1362,7 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	c->br_np = np, *n_pairs = np;
 	int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)np + 16);
 	if (!pairs) return PGA_ERR_NOMEM;
-	if (np) hipLaunchKernelGGL((k_br_vertex<1>), dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, poff, pairs,
+	if (np) hipLaunchKernelGGL((k_br_vertex<1>), dim3(nblk(n_vtx, BR_BLOCK)), dim3(BR_BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, poff, pairs,
 	                           (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt);
 	TRY(n_local_dev(c, pairs, np, local_dist, local_count, frag_mode, cnt));
 	return sync_st(c); // the exchange may run on another stream
@@ -1374,7 +1384,7 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	if (!grp || !ndl) return PGA_ERR_NOMEM;
 	HIPCHK(hipMemsetAsync(grp, 0, sizeof(int32_t) * (size_t)n_arc, c->st)); HIPCHK(hipMemsetAsync(ndl, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
 	HIPCHK(hipMemsetAsync(c->dcnt + 8, 0, 2 * sizeof(int64_t), c->st));
-	hipLaunchKernelGGL((k_br_vertex<2>), dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, poff, (int32_t *)nullptr, cnt,
+	hipLaunchKernelGGL((k_br_vertex<2>), dim3(nblk(n_vtx, BR_BLOCK)), dim3(BR_BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, poff, (int32_t *)nullptr, cnt,
 	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt);
 	HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(n_dist_loci, ndl, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));

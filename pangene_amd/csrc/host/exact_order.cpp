@@ -14,6 +14,7 @@
 // Modes (env PANGENE_EXACT or pg_set_exact_mode): "auto" (default) tracks the first non-empty contig of
 // each genome when its leading cs tie group has >= 2 hits (the index-0 channel); "all" tracks every contig
 // (then even --bed line order equals the reference's); "off" keeps the canonical stable order everywhere.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -74,7 +75,7 @@ void exact_begin(DataExt *ext) // start of a run: arrays are in file order (read
 		s.cur.resize(s.file.size());
 		for (size_t i = 0; i < s.file.size(); ++i) s.cur[i] = (int32_t)i; // indices into s.file / s.cs / s.cm
 		s.hx.clear(), s.hy.clear(), s.pushed[0].clear(), s.pushed[1].clear();
-		s.cyc_start = -1, s.period = 0, s.n_sort[0] = s.n_sort[1] = 0;
+		s.cyc_start = -1, s.period = 0, s.n_sort[0] = s.n_sort[1] = 0, s.view = &s.cur;
 	}
 	ext->head_file.assign(ext->local_genomes.size(), -1);
 }
@@ -93,12 +94,12 @@ static void emulate(ExactSeg &s, int by_cm) // one pg_hit_sort of this contig se
 static void advance(ExactSeg &s, int by_cm, bool keep_y)
 {
 	const int t = ++s.n_sort[by_cm]; // 1-based index of this sort among the sorts of its kind
-	if (s.cyc_start > 0) {
-		const std::vector<std::vector<int32_t>> &h = by_cm ? s.hy : s.hx;
+	if (s.cyc_start > 0) { // periodic: point at the stored order instead of copying it
 		if (by_cm && !keep_y) return; // order not needed by the caller
-		s.cur = h[(size_t)(s.cyc_start - 1 + (t - s.cyc_start) % s.period)];
+		s.view = &(by_cm ? s.hy : s.hx)[(size_t)(s.cyc_start - 1 + (t - s.cyc_start) % s.period)];
 		return;
 	}
+	s.view = &s.cur;
 	emulate(s, by_cm);
 	if (by_cm) { if (keep_y) s.hy.push_back(s.cur); return; }
 	for (size_t i = 0; i < s.hx.size(); ++i)
@@ -127,7 +128,7 @@ int exact_sort(DataExt *ext, int by_cm)
 		if (by_cm) return 0;
 		bool changed = false;
 		for (ExactSeg *s : todo) {
-			const int32_t h = s->file[(size_t)s->cur[0]];
+			const int32_t h = s->file[(size_t)(*s->view)[0]];
 			if (ext->head_file[(size_t)s->k] != h) ext->head_file[(size_t)s->k] = h, changed = true;
 		}
 		return changed ? ext->be->set_head(ext->ctx, ext->head_file.data()) : 0;
@@ -135,10 +136,10 @@ int exact_sort(DataExt *ext, int by_cm)
 	std::vector<int32_t> sg, ss, fi;
 	std::vector<int64_t> so(1, 0);
 	for (ExactSeg *s : todo) {
-		if (s->cur == s->pushed[by_cm]) continue;
-		s->pushed[by_cm] = s->cur;
+		if (*s->view == s->pushed[by_cm]) continue;
+		s->pushed[by_cm] = *s->view;
 		sg.push_back(s->k), ss.push_back(s->start);
-		for (int32_t i : s->cur) fi.push_back(s->file[(size_t)i]);
+		for (int32_t i : *s->view) fi.push_back(s->file[(size_t)i]);
 		so.push_back((int64_t)fi.size());
 	}
 	if (sg.empty()) return 0;

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include "pg_internal.hpp"
 #include "ksort_exact.hpp"
 
@@ -179,7 +180,8 @@ int sync_host(pg_data_t *d, bool full)
 	BE_CALL(ext->be->download(ext->ctx, &st), "download");
 	const int32_t *px = ext->pos_x.data();
 	ext->y_order.resize((size_t)d->n_genome);
-	for (size_t k = 0; k < ext->local_genomes.size(); ++k) {
+	ext->file_of_host.resize((size_t)d->n_genome);
+	auto do_genome = [&](size_t k) {
 		int32_t j = ext->local_genomes[k];
 		pg_genome_t *g = &d->genome[j];
 		const int64_t off = ext->hit_off[k];
@@ -195,7 +197,6 @@ int sync_host(pg_data_t *d, bool full)
 			std::free(g->hit);
 			g->hit = a, g->m_hit = g->n_hit;
 			ext->hits_sorted[(size_t)j] = 1;
-			ext->file_of_host.resize((size_t)d->n_genome);
 			ext->file_of_host[(size_t)j].assign((size_t)g->n_hit, 0);
 			ext->y_order[(size_t)j].assign((size_t)g->n_hit, 0);
 			for (int32_t f = 0; f < g->n_hit; ++f) {
@@ -211,6 +212,18 @@ int sync_host(pg_data_t *d, bool full)
 			h->flt_chain = !!(fl & PGA_F_CHAIN), h->pseudo = !!(fl & PGA_F_PSEUDO), h->vtx = !!(fl & PGA_F_VTX);
 			h->shadow = !!(fl & PGA_F_SHADOW), h->rep = !!(fl & PGA_F_REP), h->weak_br = (fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT;
 			if (full) h->rank = rank[s], h->score_dom = sdom[s], h->pid_dom = pdom[s], h->pid_dom0 = pdom0[s];
+		}
+	};
+	{ // genomes are independent and the 88-byte records are scattered: spread them over host threads
+		const size_t ng = ext->local_genomes.size();
+		unsigned nt = N > 200000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+		if (nt > ng) nt = (unsigned)ng;
+		if (nt <= 1) { for (size_t k = 0; k < ng; ++k) do_genome(k); }
+		else {
+			std::vector<std::thread> th;
+			for (unsigned t = 0; t < nt; ++t)
+				th.emplace_back([&, t]() { for (size_t k = ng * t / nt; k < ng * (t + 1) / nt; ++k) do_genome(k); });
+			for (auto &x : th) x.join();
 		}
 	}
 	ext->pos_valid = true;

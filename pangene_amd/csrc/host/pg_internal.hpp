@@ -43,6 +43,7 @@ struct ExactSeg {
 	std::vector<int32_t> file;            // file index of each hit of the contig, in file order
 	std::vector<uint64_t> cs, cm;         // sort keys, aligned with `file`
 	std::vector<int32_t> cur;             // current array order (indices into `file`)
+	const std::vector<int32_t> *view = nullptr; // the order after the last replayed sort (cur, or a stored one once periodic)
 	std::vector<std::vector<int32_t>> hx, hy; // history of cs / cm orders until the sequence becomes periodic
 	int cyc_start = -1, period = 0;       // X_t == X_{cyc_start + (t - cyc_start) % period} for t >= cyc_start (1-based)
 	int n_sort[2] = {0, 0};               // cs / cm sorts replayed so far
