@@ -54,7 +54,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_PERM, S_OVPOS, S_OVFILE, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
+	S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
 	S_COUNT
 };
 
@@ -633,35 +633,58 @@ __global__ __launch_bounds__(BLOCK) void k_arc_head(const uint64_t *key, int64_t
 	head[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
 }
 
-// one thread per distinct arc key: walks its run (sorted by key, genome-major inside the key because the
-// sort is stable and arcs are emitted genome by genome), collapses per genome (graph.c:128-145) and sums
-// the per-genome values (integer part of graph.c:153-169)
-__global__ __launch_bounds__(BLOCK) void k_arc_reduce(const uint64_t *key, const int32_t *head, const int32_t *slot, int64_t m, const int32_t *dist,
-                                                        const int32_t *s1, const int32_t *s2, const int32_t *gen, int vbits, pga_arc_part_t *out)
+// Two-level collapse of the sorted temp arcs (graph.c:128-175).  Equal keys are adjacent and, inside one key,
+// grouped by genome (stable sort of a genome-major emission).
+// level 1: the first element of every (key, genome) run collapses its run -- almost always a single element --
+//          into (n, rounded mean dist * n, max s1, max s2) stored at its own position; other positions hold zeros;
+// level 2: one wave per distinct key sums those records over the key's run with coalesced strided reads.
+__global__ __launch_bounds__(BLOCK) void k_arc_l1(const uint64_t *key, int64_t m, const int32_t *dist, const int32_t *s1, const int32_t *s2, const int32_t *gen,
+                                                    const int32_t *head, const int32_t *slot, int32_t *run_start, int32_t *o_n, uint64_t *o_dn, int32_t *o_s1, int32_t *o_s2)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= m || !head[i]) return;
+	if (i >= m) return;
 	const uint64_t k = key[i];
-	pga_arc_part_t r;
-	r.x = (k >> vbits) << 32 | (k & ((1ull << vbits) - 1));
-	r.n_genome = 0, r.tot_cnt = 0, r.sum_dist = 0, r.sum_s1 = 0, r.sum_s2 = 0;
-	int64_t j = i;
-	while (j < m && key[j] == k) {
-		const int g = gen[j];
-		int n = 0, m1 = 0, m2 = 0;
-		uint64_t sd = 0;
-		while (j < m && key[j] == k && gen[j] == g) {
-			sd += (uint64_t)(int64_t)dist[j];
-			m1 = m1 > s1[j] ? m1 : s1[j];
-			m2 = m2 > s2[j] ? m2 : s2[j];
-			++n, ++j;
-		}
-		const int dg = (int32_t)((double)sd / n + .499); // graph.c:141
-		r.n_genome += 1, r.tot_cnt += n;
-		r.sum_dist += (uint64_t)(int64_t)dg * (uint64_t)n;
-		r.sum_s1 += m1, r.sum_s2 += m2;
+	const int g = gen[i];
+	if (head[i]) run_start[slot[i]] = (int32_t)i;
+	if (i > 0 && key[i - 1] == k && gen[i - 1] == g) { o_n[i] = 0, o_dn[i] = 0, o_s1[i] = 0, o_s2[i] = 0; return; }
+	int n = 0, m1 = 0, m2 = 0;
+	uint64_t sd = 0;
+	for (int64_t j = i; j < m && key[j] == k && gen[j] == g; ++j) {
+		sd += (uint64_t)(int64_t)dist[j];
+		m1 = m1 > s1[j] ? m1 : s1[j];
+		m2 = m2 > s2[j] ? m2 : s2[j];
+		++n;
 	}
-	out[slot[i]] = r;
+	const int dg = (int32_t)((double)sd / n + .499); // graph.c:141
+	o_n[i] = n, o_dn[i] = (uint64_t)(int64_t)dg * (uint64_t)n, o_s1[i] = m1, o_s2[i] = m2;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_arc_l2(const uint64_t *key, int64_t m, int64_t n_run, const int32_t *run_start, const int32_t *c_n, const uint64_t *c_dn,
+                                                    const int32_t *c_s1, const int32_t *c_s2, int vbits, pga_arc_part_t *out)
+{
+	const int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (w >= n_run) return;
+	const int64_t st = run_start[w], en = w + 1 < n_run ? run_start[w + 1] : m;
+	int ng = 0, tot = 0;
+	uint64_t sd = 0;
+	int64_t a1 = 0, a2 = 0;
+	for (int64_t j = st + lane; j < en; j += WAVE) {
+		const int n = c_n[j];
+		ng += n > 0, tot += n, sd += c_dn[j], a1 += c_s1[j], a2 += c_s2[j];
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		ng += __shfl_xor(ng, o, WAVE), tot += __shfl_xor(tot, o, WAVE);
+		sd += (uint64_t)__shfl_xor((long long)sd, o, WAVE), a1 += __shfl_xor((long long)a1, o, WAVE), a2 += __shfl_xor((long long)a2, o, WAVE);
+	}
+	if (lane == 0) {
+		const uint64_t k = key[st];
+		pga_arc_part_t r;
+		r.x = (k >> vbits) << 32 | (k & ((1ull << vbits) - 1));
+		r.n_genome = ng, r.tot_cnt = tot, r.sum_dist = sd, r.sum_s1 = a1, r.sum_s2 = a2;
+		out[w] = r;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -731,55 +754,115 @@ __global__ __launch_bounds__(BLOCK) void k_br_prep(const uint64_t *ax, int64_t n
 	if (i == n_arc - 1 || (uint32_t)(ax[i + 1] >> 32) != v) ve[v] = (int32_t)i + 1;
 }
 
-// MODE 0: count the pg_n_local calls of vertex v; 1: write their gene pairs; 2: consume the counts and decide.
-// The arcs of a vertex (scores, target genes, group marks) are staged in an LDS row per thread so that the
-// O(n^2) loops run out of LDS; vertices with more than BR_MAXDEG arcs fall back to global memory.
-constexpr int BR_MAXDEG = 32;
-constexpr int BR_BLOCK = 128;
-template <int MODE>
-__global__ __launch_bounds__(BR_BLOCK) void k_br_vertex(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
-                                                          int32_t *pc, const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
-                                                          uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt)
+// number of pg_n_local calls of vertex v: n_max * n_weak (branch.c:70-75) + n(n-1)/2 (branch.c:83-88)
+__global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1, double bd, int32_t *pc)
 {
-	__shared__ int32_t l_s1[BR_BLOCK][BR_MAXDEG + 1], l_gid[BR_BLOCK][BR_MAXDEG + 1], l_grp[BR_BLOCK][BR_MAXDEG + 1];
-	const int v = blockIdx.x * BR_BLOCK + threadIdx.x;
+	const int v = blockIdx.x * BLOCK + threadIdx.x;
 	if (v >= n_vtx) return;
 	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2) { if (MODE == 0) pc[v] = 0; return; }
-	const bool lds = n <= BR_MAXDEG;
-	int32_t *s1 = lds ? l_s1[threadIdx.x] : const_cast<int32_t *>(s1g) + a0;
-	int32_t *agid = lds ? l_gid[threadIdx.x] : const_cast<int32_t *>(agidg) + a0;
-	int32_t *grp = lds ? l_grp[threadIdx.x] : grpg + a0; // grpg is zeroed by the caller
-	if (lds) for (int i = 0; i < n; ++i) s1[i] = s1g[a0 + i], agid[i] = agidg[a0 + i], grp[i] = 0;
-	int max_s1 = 0;
-	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[i] ? max_s1 : s1[i];
-	int64_t k = MODE == 0 ? 0 : poff[v];
+	if (n < 2) { pc[v] = 0; return; }
+	int max_s1 = 0, n_max = 0, n_weak = 0;
+	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[a0 + i] ? max_s1 : s1[a0 + i];
 	for (int i = 0; i < n; ++i) {
-		const double r = 1.0 - (double)s1[i] / max_s1; // branch.c:71
+		n_max += s1[a0 + i] == max_s1;
+		n_weak += (1.0 - (double)s1[a0 + i] / max_s1) > bd; // branch.c:71-72
+	}
+	pc[v] = n_max * n_weak + n * (n - 1) / 2;
+}
+
+// sequential form (one lane), used for vertices with more than 64 arcs.  MODE 1: write pairs; 2: decide.
+template <int MODE>
+__device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *agid, double bd, int64_t k, int32_t *pairs, const int32_t *cnt,
+                              double bdist, double bcut, uint8_t *weak, int32_t *grp, int32_t *ndl_out, int64_t *dcnt)
+{
+	int max_s1 = 0;
+	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[a0 + i] ? max_s1 : s1[a0 + i];
+	for (int i = 0; i < n; ++i) {
+		const double r = 1.0 - (double)s1[a0 + i] / max_s1;
 		if (!(r > bd)) continue;
 		int n_local = 0;
 		for (int j = 0; j < n; ++j) {
-			if (s1[j] != max_s1) continue; // max_gid[], branch.c:66-68
-			if (MODE == 1) pairs[2 * k] = agid[j], pairs[2 * k + 1] = agid[i];
+			if (s1[a0 + j] != max_s1) continue;
+			if (MODE == 1) pairs[2 * k] = agid[a0 + j], pairs[2 * k + 1] = agid[a0 + i];
 			if (MODE == 2) n_local += cnt[k];
 			++k;
 		}
-		if (MODE == 2) { // branch.c:76-77
+		if (MODE == 2) {
 			if ((n_local == 0 && r > bdist) || r > bcut) weak[a0 + i] = 2, atomicAdd((unsigned long long *)&dcnt[9], 1ull);
 			else weak[a0 + i] = 1, atomicAdd((unsigned long long *)&dcnt[8], 1ull);
 		}
 	}
 	int n_group = 0;
-	for (int i = 0; i < n; ++i) { // branch.c:82-90
-		if (MODE == 2 && grp[i] == 0) grp[i] = ++n_group;
+	for (int i = 0; i < n; ++i) {
+		if (MODE == 2 && grp[a0 + i] == 0) grp[a0 + i] = ++n_group;
 		for (int j = i + 1; j < n; ++j) {
-			if (MODE == 1) pairs[2 * k] = agid[i], pairs[2 * k + 1] = agid[j];
-			if (MODE == 2 && cnt[k] > 0 && grp[j] == 0) grp[j] = grp[i];
+			if (MODE == 1) pairs[2 * k] = agid[a0 + i], pairs[2 * k + 1] = agid[a0 + j];
+			if (MODE == 2 && cnt[k] > 0 && grp[a0 + j] == 0) grp[a0 + j] = grp[a0 + i];
 			++k;
 		}
 	}
-	if (MODE == 0) pc[v] = (int32_t)k;
-	if (MODE == 2) ndl[v] = n_group;
+	if (MODE == 2) *ndl_out = n_group;
+}
+
+// One WAVE per oriented vertex; lane j holds arc j (score, target gene, group mark) in registers and arcs are
+// broadcast with shuffles, so the O(n^2) pair loops of branch.c:70-90 touch memory only for the pair list
+// (coalesced stores, MODE 1) or the all-reduced counts (coalesced loads, MODE 2).
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
+                                                     const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
+                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt)
+{
+	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (v >= n_vtx) return;
+	const int a0 = vs[v], n = ve[v] - a0;
+	if (n < 2) return;
+	const int64_t k0 = poff[v];
+	if (n > WAVE) {
+		if (lane == 0) { int32_t g = 0; br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt); if (MODE == 2) ndl[v] = g; }
+		return;
+	}
+	const bool in = lane < n;
+	const int my_s1 = in ? s1g[a0 + lane] : 0, my_gid = in ? agidg[a0 + lane] : 0;
+	int max_s1 = my_s1;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(max_s1, o, WAVE); max_s1 = max_s1 > t ? max_s1 : t; }
+	const double r = in ? 1.0 - (double)my_s1 / max_s1 : 0.0; // branch.c:71
+	const bool is_weak = in && r > bd, is_max = in && my_s1 == max_s1;
+	const unsigned long long m_weak = __ballot(is_weak), m_max = __ballot(is_max);
+	const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	const int n_max = __popcll(m_max), mrank = __popcll(m_max & lt);
+	// part 1 (branch.c:70-77): for every weak arc i (ascending), one pair per best-scoring arc j (ascending)
+	int wb = 0;
+	for (unsigned long long m = m_weak; m; m &= m - 1, ++wb) {
+		const int i = __ffsll((long long)m) - 1;
+		const int gid_i = __shfl(my_gid, i, WAVE);
+		const int64_t k = k0 + (int64_t)wb * n_max + mrank;
+		if (MODE == 1) { if (is_max) pairs[2 * k] = my_gid, pairs[2 * k + 1] = gid_i; }
+		else {
+			int c = is_max ? cnt[k] : 0;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
+			if (lane == i) {
+				if ((c == 0 && r > bdist) || r > bcut) weak[a0 + i] = 2, atomicAdd((unsigned long long *)&dcnt[9], 1ull);
+				else weak[a0 + i] = 1, atomicAdd((unsigned long long *)&dcnt[8], 1ull);
+			}
+		}
+	}
+	// part 2 (branch.c:82-90): all i<j pairs, row i starts after i*n - i(i+1)/2 earlier pairs
+	const int64_t k2 = k0 + (int64_t)n_max * __popcll(m_weak);
+	int grp = 0, n_group = 0;
+	for (int i = 0; i < n; ++i) {
+		const int64_t k = k2 + (int64_t)i * n - (int64_t)i * (i + 1) / 2 + (lane - i - 1);
+		if (MODE == 1) {
+			const int gid_i = __shfl(my_gid, i, WAVE);
+			if (lane > i && in) pairs[2 * k] = gid_i, pairs[2 * k + 1] = my_gid;
+		} else {
+			int gi = __shfl(grp, i, WAVE);
+			if (gi == 0) { gi = ++n_group; if (lane == i) grp = gi; } // uniform: every lane sees the same gi
+			if (lane > i && in && grp == 0 && cnt[k] > 0) grp = gi;
+		}
+	}
+	if (MODE == 2 && lane == 0) ndl[v] = n_group;
 }
 
 __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107
@@ -1282,7 +1365,14 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	const int64_t A = (int64_t)tail[0] + tail[1];
 	pga_arc_part_t *arcs = (pga_arc_part_t *)c->pool.get(S_ARCS, sizeof(pga_arc_part_t) * (size_t)A);
 	if (!arcs) return PGA_ERR_NOMEM;
-	hipLaunchKernelGGL(k_arc_reduce, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, head, slot, M, sdist, ss1, ss2, sgen, vbits, arcs);
+	{
+		int32_t *run_start = (int32_t *)c->pool.get(S_RUNSTART, sizeof(int32_t) * (size_t)A + 16);
+		int32_t *c_n = tdist, *c_s1 = ts1, *c_s2 = ts2; // the unsorted payload arrays are free again: reuse them
+		uint64_t *c_dn = (uint64_t *)c->pool.get(S_CDN, sizeof(uint64_t) * (size_t)M);
+		if (!run_start || !c_dn) return PGA_ERR_NOMEM;
+		hipLaunchKernelGGL(k_arc_l1, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, M, sdist, ss1, ss2, sgen, head, slot, run_start, c_n, c_dn, c_s1, c_s2);
+		hipLaunchKernelGGL(k_arc_l2, dim3(nblk(A, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, ks, M, A, run_start, c_n, c_dn, c_s1, c_s2, vbits, arcs);
+	}
 	*arcs_out = arcs, *n_arcs_out = A;
 	return sync_st(c);
 }
@@ -1350,8 +1440,7 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	HIPCHK(hipMemsetAsync(vs, 0, sizeof(int32_t) * (size_t)n_vtx, c->st)); HIPCHK(hipMemsetAsync(ve, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
 	HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st));
 	hipLaunchKernelGGL(k_br_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, ax, n_arc, sg, agid, vs, ve);
-	hipLaunchKernelGGL((k_br_vertex<0>), dim3(nblk(n_vtx, BR_BLOCK)), dim3(BR_BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, (const int32_t *)nullptr, (int32_t *)nullptr,
-	                   (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt);
+	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
 	int32_t tail[2];
@@ -1362,7 +1451,7 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	c->br_np = np, *n_pairs = np;
 	int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)np + 16);
 	if (!pairs) return PGA_ERR_NOMEM;
-	if (np) hipLaunchKernelGGL((k_br_vertex<1>), dim3(nblk(n_vtx, BR_BLOCK)), dim3(BR_BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, poff, pairs,
+	if (np) hipLaunchKernelGGL((k_br_wave<1>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, pairs,
 	                           (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt);
 	TRY(n_local_dev(c, pairs, np, local_dist, local_count, frag_mode, cnt));
 	return sync_st(c); // the exchange may run on another stream
@@ -1384,7 +1473,7 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	if (!grp || !ndl) return PGA_ERR_NOMEM;
 	HIPCHK(hipMemsetAsync(grp, 0, sizeof(int32_t) * (size_t)n_arc, c->st)); HIPCHK(hipMemsetAsync(ndl, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
 	HIPCHK(hipMemsetAsync(c->dcnt + 8, 0, 2 * sizeof(int64_t), c->st));
-	hipLaunchKernelGGL((k_br_vertex<2>), dim3(nblk(n_vtx, BR_BLOCK)), dim3(BR_BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, pc, poff, (int32_t *)nullptr, cnt,
+	hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, cnt,
 	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt);
 	HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(n_dist_loci, ndl, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
