@@ -69,6 +69,7 @@ struct pga_ctx {
 	// static per hit (X order)
 	int32_t *fidx = 0, *gnm = 0, *seg = 0, *pid = 0, *gid = 0, *cs = 0, *ce = 0, *cm = 0, *cds = 0, *nex = 0, *offx = 0, *sori = 0, *sadj = 0, *pm = 0;
 	uint64_t *sc64 = 0;
+	int4 *recA = 0, *recB = 0, *recC = 0; // packed sweep records (derived from the arrays above, see k_pack_rec)
 	// dynamic per hit
 	int32_t *rank = 0, *sdom = 0, *pdom = 0, *pdom0 = 0; uint32_t *flags = 0;
 	int32_t *yperm = 0, *goff = 0, *ggl = 0, *ctg_base = 0, *inv = 0, *headpos = 0;
@@ -126,6 +127,13 @@ __global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (i < n) p[i] = v;
+}
+
+// mailbox[k] = a[0] + b[0]: totals of a scan land in the device mailbox so that one 128-byte copy brings every
+// size the host needs (one round trip instead of one per value)
+__global__ void k_mail_sum(const int32_t *a, const int32_t *b, int64_t *box)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) *box = (int64_t)a[0] + b[0];
 }
 
 __device__ __forceinline__ int genome_of(const int32_t *goff, int n_genome, int i) // last g with goff[g] <= i
@@ -228,9 +236,22 @@ __global__ __launch_bounds__(BLOCK) void k_pseudo3(const int32_t *gnm, const int
 // ------------------------------------------------------------------------------------------------
 // the interval-dominance sweep: pg_shadow (overlap.c:101-178) and pg_flt_ov_isoform (58-93)
 // ------------------------------------------------------------------------------------------------
+// Packed per-hit records for the sweep: a partner costs three 16-byte loads instead of a dozen 4-byte ones.
+//   A = {seg, cs, ce, pm}   B = {sc64.lo, sc64.hi, gid, cds}   C = {rank, n_exon, off_exon, pid}
+__global__ __launch_bounds__(BLOCK) void k_pack_rec(const int32_t *seg, const int32_t *cs, const int32_t *ce, const int32_t *pm, const uint64_t *sc64,
+                                                      const int32_t *gid, const int32_t *cds, const int32_t *rank, const int32_t *nex, const int32_t *offx,
+                                                      const int32_t *pid, int n, int4 *A, int4 *B, int4 *C)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	const uint64_t s = sc64[h];
+	A[h] = make_int4(seg[h], cs[h], ce[h], pm[h]);
+	B[h] = make_int4((int)(uint32_t)s, (int)(uint32_t)(s >> 32), gid[h], cds[h]);
+	C[h] = make_int4(rank[h], nex[h], offx[h], pid[h]);
+}
+
 struct SweepView {
-	const int32_t *seg, *cs, *ce, *pm, *gid, *rank, *cds, *nex, *offx, *pid, *sori;
-	const uint64_t *sc64; const int2 *exon;
+	const int4 *A, *B, *C; const int32_t *sori; const int2 *exon;
 	uint32_t *flags; int32_t *pdom, *sdom;
 	int n; double min_ov; int check_strand;
 	int64_t *hz;
@@ -262,78 +283,96 @@ __device__ __forceinline__ int cds_inter(const int2 *__restrict__ ex, int oa, in
 	return inter;
 }
 
+// The interval-dominance sweep, LDS-staged.  A workgroup owns SW_TILE consecutive hits (cs order) and stages
+// their records plus SW_HALO neighbours on each side in LDS (52 B/hit, coalesced 16-byte loads); every thread
+// then walks its partners in both directions out of LDS and only falls back to global memory for partners
+// beyond the halo (hits spanning more than SW_HALO others).  Pairs are symmetric, so each hit derives its own
+// shadow flag and dominator without atomics.
 // MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform
+constexpr int SW_TILE = 256, SW_HALO = 64, SW_LDS = SW_TILE + 2 * SW_HALO;
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_sweep(SweepView v)
+__global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 {
-	const int h = blockIdx.x * BLOCK + threadIdx.x;
+	__shared__ int4 sA[SW_LDS], sB[SW_LDS], sC[SW_LDS];
+	__shared__ uint32_t sF[SW_LDS];
+	const int base = blockIdx.x * SW_TILE - SW_HALO;
+	for (int l = threadIdx.x; l < SW_LDS; l += SW_TILE) {
+		const int g = base + l;
+		if (g >= 0 && g < v.n) sA[l] = v.A[g], sB[l] = v.B[g], sC[l] = v.C[g], sF[l] = v.flags[g];
+		else sA[l] = make_int4(-2, 0, 0, 0), sF[l] = PGA_F_FLT;
+	}
+	__syncthreads();
+	const int h = blockIdx.x * SW_TILE + threadIdx.x;
 	if (h >= v.n) return;
-	const uint32_t fl = v.flags[h];
+	const int lh = threadIdx.x + SW_HALO;
+	const uint32_t fl = sF[lh];
 	if (fl & PGA_F_FLT) return; // filtered hits keep stale shadow/pid_dom (overlap.c:112)
-	const int sg = v.seg[h], cs_h = v.cs[h], ce_h = v.ce[h], g_h = v.gid[h], rk_h = v.rank[h], ln_h = v.cds[h];
-	const int ne_h = v.nex[h], ox_h = v.offx[h], wk_h = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
-	const uint64_t s_h = v.sc64[h];
+	const int4 a_h = sA[lh], b_h = sB[lh], c_h = sC[lh];
+	const int sg = a_h.x, cs_h = a_h.y, ce_h = a_h.z, g_h = b_h.z, ln_h = b_h.w, rk_h = c_h.x, ne_h = c_h.y, ox_h = c_h.z;
+	const int wk_h = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
+	const uint64_t s_h = (uint64_t)(uint32_t)b_h.x | (uint64_t)(uint32_t)b_h.y << 32;
 	bool lose = false;
 	uint64_t best = 0;
-	int best_j = -1, best_ov = 0;
-	// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a
-	// contig, so the scan stops at the first j whose pm is <= cs_h.
+	int best_j = -1, best_ov = 0, best_pid = -1, best_cds = 0;
+	// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so
+	// the scan stops at the first j whose pm is <= cs_h.
 	for (int j = h - 1; j >= 0; --j) {
-		if (v.seg[j] != sg || v.pm[j] <= cs_h) break;
-		const int ce_j = v.ce[j];
-		if (ce_j <= cs_h) continue;
-		const uint32_t fj = v.flags[j];
+		const int lj = j - base;
+		const int4 a_j = lj >= 0 ? sA[lj] : v.A[j];
+		if (a_j.x != sg || a_j.w <= cs_h) break;
+		if (a_j.z <= cs_h) continue;
+		const uint32_t fj = lj >= 0 ? sF[lj] : v.flags[j];
 		if (fj & PGA_F_FLT) continue;
 		if (v.check_strand && ((fj ^ fl) & PGA_F_REV)) continue;
-		const int g_j = v.gid[j];
-		if (MODE == 2 && g_j != g_h) continue;
-		const int x = cds_inter(v.exon, v.offx[j], v.nex[j], v.cs[j], ce_j, ox_h, ne_h, cs_h, ce_h);
+		const int4 b_j = lj >= 0 ? sB[lj] : v.B[j];
+		if (MODE == 2 && b_j.z != g_h) continue;
+		const int4 c_j = lj >= 0 ? sC[lj] : v.C[j];
+		const int x = cds_inter(v.exon, c_j.z, c_j.y, a_j.y, a_j.z, ox_h, ne_h, cs_h, ce_h);
 		if (x == 0) continue;
-		const uint64_t s_j = v.sc64[j];
+		const uint64_t s_j = (uint64_t)(uint32_t)b_j.x | (uint64_t)(uint32_t)b_j.y << 32;
 		bool h_loses; // h plays "i" of the reference (the later hit)
-		if (MODE == 2) h_loses = s_h < s_j || (s_h == s_j && rk_h > v.rank[j]);
+		if (MODE == 2) h_loses = s_h < s_j || (s_h == s_j && rk_h > c_j.x);
 		else {
-			const int ln_j = v.cds[j];
-			const double cov = (double)x / (ln_h < ln_j ? ln_h : ln_j);
-			if (g_h != g_j && cov < v.min_ov) continue;
+			const double cov = (double)x / (ln_h < b_j.w ? ln_h : b_j.w);
+			if (g_h != b_j.z && cov < v.min_ov) continue;
 			const int wk_j = (int)((fj & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
-			if (g_h == g_j || wk_h == wk_j) h_loses = s_h < s_j || (s_h == s_j && rk_h > v.rank[j]);
+			if (g_h == b_j.z || wk_h == wk_j) h_loses = s_h < s_j || (s_h == s_j && rk_h > c_j.x);
 			else h_loses = wk_h > wk_j;
 		}
 		if (h_loses) {
 			lose = true;
 			if (MODE != 2 && s_j > 0 && s_j >= best) { // descending j: on equal score the smaller index wins (overlap.c:150)
 				if (s_j == best) atomicAdd((unsigned long long *)&v.hz[3], 1ull);
-				best = s_j, best_j = j, best_ov = x;
+				best = s_j, best_j = j, best_ov = x, best_pid = c_j.w, best_cds = b_j.w;
 			}
 		}
 	}
 	// partners after h: every i with cs_i < ce_h
 	for (int i = h + 1; i < v.n; ++i) {
-		if (v.seg[i] != sg) break;
-		const int cs_i = v.cs[i];
-		if (cs_i >= ce_h) break;
-		const uint32_t fi = v.flags[i];
+		const int li = i - base;
+		const int4 a_i = li < SW_LDS ? sA[li] : v.A[i];
+		if (a_i.x != sg || a_i.y >= ce_h) break;
+		const uint32_t fi = li < SW_LDS ? sF[li] : v.flags[i];
 		if (fi & PGA_F_FLT) continue;
 		if (v.check_strand && ((fi ^ fl) & PGA_F_REV)) continue;
-		const int g_i = v.gid[i];
-		if (MODE == 2 && g_i != g_h) continue;
-		const int x = cds_inter(v.exon, ox_h, ne_h, cs_h, ce_h, v.offx[i], v.nex[i], cs_i, v.ce[i]);
+		const int4 b_i = li < SW_LDS ? sB[li] : v.B[i];
+		if (MODE == 2 && b_i.z != g_h) continue;
+		const int4 c_i = li < SW_LDS ? sC[li] : v.C[i];
+		const int x = cds_inter(v.exon, ox_h, ne_h, cs_h, ce_h, c_i.z, c_i.y, a_i.y, a_i.z);
 		if (x == 0) continue;
-		const uint64_t s_i = v.sc64[i];
+		const uint64_t s_i = (uint64_t)(uint32_t)b_i.x | (uint64_t)(uint32_t)b_i.y << 32;
 		bool i_loses; // h plays "j" (the earlier hit)
-		if (MODE == 2) i_loses = s_i < s_h || (s_i == s_h && v.rank[i] > rk_h);
+		if (MODE == 2) i_loses = s_i < s_h || (s_i == s_h && c_i.x > rk_h);
 		else {
-			const int ln_i = v.cds[i];
-			const double cov = (double)x / (ln_i < ln_h ? ln_i : ln_h);
-			if (g_h != g_i && cov < v.min_ov) continue;
+			const double cov = (double)x / (b_i.w < ln_h ? b_i.w : ln_h);
+			if (g_h != b_i.z && cov < v.min_ov) continue;
 			const int wk_i = (int)((fi & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
-			if (g_h == g_i || wk_h == wk_i) i_loses = s_i < s_h || (s_i == s_h && v.rank[i] > rk_h);
+			if (g_h == b_i.z || wk_h == wk_i) i_loses = s_i < s_h || (s_i == s_h && c_i.x > rk_h);
 			else i_loses = wk_i > wk_h;
 		}
 		if (!i_loses) {
 			lose = true;
-			if (MODE != 2 && s_i > best) best = s_i, best_j = i, best_ov = x;
+			if (MODE != 2 && s_i > best) best = s_i, best_j = i, best_ov = x, best_pid = c_i.w, best_cds = b_i.w;
 			else if (MODE != 2 && s_i == best && s_i > 0) atomicAdd((unsigned long long *)&v.hz[3], 1ull);
 		}
 	}
@@ -341,19 +380,15 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepView v)
 		if (lose) v.flags[h] = fl | PGA_F_ISO_OV;
 		return;
 	}
-	// epilogue, overlap.c:157-175.  The first hit of a genome is never reset (loop starts at 1, overlap.c:108).
+	// epilogue, overlap.c:157-175.  The hit at index 0 of a genome is never reset (loop starts at 1, overlap.c:108).
 	uint32_t nf = (fl & F_HEAD) ? fl : (fl & ~PGA_F_SHADOW);
 	if (lose) nf |= PGA_F_SHADOW;
 	if (nf != fl) v.flags[h] = nf;
-	int pd = -1;
-	if (best > 0) pd = v.pid[best_j];
-	v.pdom[h] = pd;
+	v.pdom[h] = best > 0 ? best_pid : -1;
 	if (MODE == 1) {
 		int sd = -1;
-		if (best > 0) {
-			const int ln_j = v.cds[best_j];
-			sd = (int32_t)(v.sori[h] * (1.0 - (double)best_ov / ln_h) + v.sori[best_j] * ((double)best_ov / ln_j) + .499); // overlap.c:170
-		}
+		if (best > 0)
+			sd = (int32_t)(v.sori[h] * (1.0 - (double)best_ov / ln_h) + v.sori[best_j] * ((double)best_ov / best_cds) + .499); // overlap.c:170
 		v.sdom[h] = sd;
 	}
 }
@@ -788,8 +823,7 @@ __device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *a
 			++k;
 		}
 		if (MODE == 2) {
-			if ((n_local == 0 && r > bdist) || r > bcut) weak[a0 + i] = 2, atomicAdd((unsigned long long *)&dcnt[9], 1ull);
-			else weak[a0 + i] = 1, atomicAdd((unsigned long long *)&dcnt[8], 1ull);
+			weak[a0 + i] = ((n_local == 0 && r > bdist) || r > bcut) ? 2 : 1;
 		}
 	}
 	int n_group = 0;
@@ -843,8 +877,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
 			if (lane == i) {
-				if ((c == 0 && r > bdist) || r > bcut) weak[a0 + i] = 2, atomicAdd((unsigned long long *)&dcnt[9], 1ull);
-				else weak[a0 + i] = 1, atomicAdd((unsigned long long *)&dcnt[8], 1ull);
+				weak[a0 + i] = ((c == 0 && r > bdist) || r > bcut) ? 2 : 1;
 			}
 		}
 	}
@@ -898,8 +931,10 @@ __global__ __launch_bounds__(BLOCK) void k_weak_merge(uint32_t *flags, const int
 	uint32_t f = flags[h];
 	int cur = in ? (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT) : 0, nw = in ? weak_new[h] : 0;
 	if (nw > cur) { cur = nw; flags[h] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT; }
-	const unsigned long long m = __ballot(cur != 0); // one atomic per wave, not per hit
-	if (m && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd((unsigned long long *)cnt, (unsigned long long)__popcll(m));
+	if (cnt) { // log-only counter (branch.c:137-139): one atomic per wave, and only when somebody asks
+		const unsigned long long m = __ballot(cur != 0);
+		if (m && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd((unsigned long long *)cnt, (unsigned long long)__popcll(m));
+	}
 }
 
 // hazard H2b: two consecutive walkable hits (cs order) share (contig, cs)
@@ -1007,10 +1042,15 @@ static int bits_for(uint32_t maxv) { int b = 1; while (b < 32 && (maxv >> b)) ++
 
 static int make_sweep_view(pga_ctx *c, SweepView *v)
 {
-	v->seg = c->seg, v->cs = c->cs, v->ce = c->ce, v->pm = c->pm, v->gid = c->gid, v->rank = c->rank, v->cds = c->cds, v->nex = c->nex;
-	v->offx = c->offx, v->pid = c->pid, v->sori = c->sori, v->sc64 = c->sc64, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
+	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->sori = c->sori, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
 	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4;
 	return 0;
+}
+
+static void pack_records(pga_ctx *c)
+{
+	if (c->N) hipLaunchKernelGGL(k_pack_rec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->seg, c->cs, c->ce, c->pm, c->sc64, c->gid, c->cds, c->rank, c->nex, c->offx,
+	                             c->pid, c->N, c->recA, c->recB, c->recC);
 }
 
 template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
@@ -1023,7 +1063,7 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 		HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
 		HIPCHK(hipEventRecord(t.a, c->st));
 	}
-	hipLaunchKernelGGL((k_sweep<MODE>), dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, v);
+	hipLaunchKernelGGL((k_sweep<MODE>), dim3(nblk(c->N, SW_TILE)), dim3(SW_TILE), 0, c->st, v);
 	if (timed_which >= 0) { HIPCHK(hipEventRecord(t.b, c->st)); c->timed.push_back(t); }
 	return 0;
 }
@@ -1081,7 +1121,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	// persistent arrays
 	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
 	TRY(dalloc(c, &c->cs, N)); TRY(dalloc(c, &c->ce, N)); TRY(dalloc(c, &c->cm, N)); TRY(dalloc(c, &c->cds, N)); TRY(dalloc(c, &c->nex, N));
-	TRY(dalloc(c, &c->offx, N)); TRY(dalloc(c, &c->sori, N)); TRY(dalloc(c, &c->sadj, N)); TRY(dalloc(c, &c->pm, N)); TRY(dalloc(c, &c->sc64, N));
+	TRY(dalloc(c, &c->offx, N)); TRY(dalloc(c, &c->sori, N)); TRY(dalloc(c, &c->sadj, N)); TRY(dalloc(c, &c->pm, N)); TRY(dalloc(c, &c->sc64, N)); TRY(dalloc(c, &c->recA, N)); TRY(dalloc(c, &c->recB, N)); TRY(dalloc(c, &c->recC, N));
 	TRY(dalloc(c, &c->rank, N)); TRY(dalloc(c, &c->sdom, N)); TRY(dalloc(c, &c->pdom, N)); TRY(dalloc(c, &c->pdom0, N)); TRY(dalloc(c, &c->flags, N));
 	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->ctg_base, GL + 1)); TRY(dalloc(c, &c->inv, N)); TRY(dalloc(c, &c->headpos, GL + 1)); TRY(dalloc(c, &c->exon, E));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q));
@@ -1154,6 +1194,7 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	// running max of ce per contig
 	SegMax *tile = (SegMax *)c->pool.get(S_TILE, 0);
 	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
+	pack_records(c);
 	// Y order: pg_hit_sort(g, 1); ties keep X order
 	key = (uint64_t *)c->pool.get(S_KEY_A, 0), val = (uint32_t *)c->pool.get(S_VAL_A, 0);
 	hipLaunchKernelGGL(k_ykey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->seg, c->cm, N, c->cm_bits, key, val);
@@ -1200,6 +1241,7 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 		hipLaunchKernelGGL(k_pseudo1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, N, P, tmax, tmin);
 		hipLaunchKernelGGL(k_pseudo2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, c->rank, c->flags, N, P, tmax, tmin, tr1, d_stats);
 		hipLaunchKernelGGL(k_pseudo3, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->rank, N, P, tmax, tmin, tr1);
+		pack_records(c); // rank changed
 		TRY(launch_sweep<1>(c, 0)); // pg_shadow(cal_dom_sc=1), read.c:248 -- "K1", the hit-filter+overlap kernel
 		hipLaunchKernelGGL(k_ingest_reset, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->pdom, c->pdom0, N);
 		TRY(launch_sweep<2>(c, 1)); // pg_flt_ov_isoform, read.c:254
@@ -1336,11 +1378,9 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{has}, OutExclI32{slot}, N, tile, OpSum{}, I32{0}, c->st);
 	// number of adjacencies = slot[N-1] + has[N-1]
-	int32_t tail[2];
-	HIPCHK(hipMemcpyAsync(&tail[0], slot + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(&tail[1], has + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, slot + (N - 1), has + (N - 1), c->dcnt + 10);
 	TRY(check_invariant(c));
-	const int64_t M = 2 * ((int64_t)tail[0] + tail[1]);
+	const int64_t M = 2 * c->h_cnt[10];
 	if (M == 0) return sync_st(c);
 	const int vbits = bits_for((uint32_t)(2 * std::max(1, S)));
 	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, sizeof(uint64_t) * (size_t)M);
@@ -1359,10 +1399,10 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	hipLaunchKernelGGL(k_arc_head, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, M, head);
 	tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{head}, OutExclI32{slot}, M, tile, OpSum{}, I32{0}, c->st);
-	HIPCHK(hipMemcpyAsync(&tail[0], slot + (M - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(&tail[1], head + (M - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, slot + (M - 1), head + (M - 1), c->dcnt + 10);
+	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
 	TRY(sync_st(c));
-	const int64_t A = (int64_t)tail[0] + tail[1];
+	const int64_t A = c->h_cnt[10];
 	pga_arc_part_t *arcs = (pga_arc_part_t *)c->pool.get(S_ARCS, sizeof(pga_arc_part_t) * (size_t)A);
 	if (!arcs) return PGA_ERR_NOMEM;
 	{
@@ -1443,11 +1483,10 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
-	int32_t tail[2];
-	HIPCHK(hipMemcpyAsync(&tail[0], poff + (n_vtx - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(&tail[1], pc + (n_vtx - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, poff + (n_vtx - 1), pc + (n_vtx - 1), c->dcnt + 10);
+	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
 	TRY(sync_st(c));
-	const int64_t np = (int64_t)tail[0] + tail[1];
+	const int64_t np = c->h_cnt[10];
 	c->br_np = np, *n_pairs = np;
 	int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)np + 16);
 	if (!pairs) return PGA_ERR_NOMEM;
@@ -1472,15 +1511,15 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	int32_t *grp = (int32_t *)c->pool.get(S_BR_GRP, sizeof(int32_t) * (size_t)n_arc + 16), *ndl = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
 	if (!grp || !ndl) return PGA_ERR_NOMEM;
 	HIPCHK(hipMemsetAsync(grp, 0, sizeof(int32_t) * (size_t)n_arc, c->st)); HIPCHK(hipMemsetAsync(ndl, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
-	HIPCHK(hipMemsetAsync(c->dcnt + 8, 0, 2 * sizeof(int64_t), c->st));
 	hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, cnt,
 	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt);
 	HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(n_dist_loci, ndl, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
 	TRY(sync_st(c));
-	if (n_flt1) *n_flt1 = c->h_cnt[8];
-	if (n_flt2) *n_flt2 = c->h_cnt[9];
+	int64_t f1 = 0, f2 = 0;
+	for (int64_t i = 0; i < n_arc; ++i) f1 += arc_weak[i] == 1, f2 += arc_weak[i] == 2;
+	if (n_flt1) *n_flt1 = f1;
+	if (n_flt2) *n_flt2 = f2;
 	return 0;
 }
 
@@ -1500,10 +1539,12 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 	int32_t *val, *prev;
 	TRY(walk_prev(c, &val, &prev));
 	hipLaunchKernelGGL(k_mark_hits, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yperm, c->seg, c->gid, c->flags, c->g2s, N, ax, aw, n_arc, wn);
-	hipLaunchKernelGGL(k_weak_merge, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, wn, N, c->dcnt + 2);
-	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
-	TRY(sync_st(c));
-	if (n_marked) *n_marked = c->h_cnt[2];
+	hipLaunchKernelGGL(k_weak_merge, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, wn, N, n_marked ? c->dcnt + 2 : (int64_t *)nullptr);
+	if (n_marked) {
+		HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+		TRY(sync_st(c));
+		*n_marked = c->h_cnt[2];
+	}
 	return 0;
 }
 
@@ -1540,6 +1581,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	SegMax *tile = (SegMax *)c->pool.get(S_TILE, 0);
 	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
 	hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv);
+	pack_records(c);
 	return sync_st(c);
 }
 

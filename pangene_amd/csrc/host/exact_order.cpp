@@ -83,10 +83,15 @@ void exact_begin(DataExt *ext) // start of a run: arrays are in file order (read
 static void emulate(ExactSeg &s, int by_cm) // one pg_hit_sort of this contig segment
 {
 	const std::vector<uint64_t> &key = by_cm ? s.cm : s.cs;
-	std::vector<pg128_t> t(s.cur.size());
-	for (size_t i = 0; i < s.cur.size(); ++i) t[i].x = key[(size_t)s.cur[i]], t[i].y = (uint64_t)s.cur[i];
-	ksort_exact(t.data(), t.size(), [](const pg128_t &a) { return a.x; });
-	for (size_t i = 0; i < s.cur.size(); ++i) s.cur[i] = (int32_t)t[i].y;
+	static thread_local std::vector<pg128_t> tls; // reused: a fresh 160 KB vector per call would be mmap'ed and page-faulted each time
+	if (tls.size() < s.cur.size()) tls.resize(s.cur.size());
+	pg128_t *t = tls.data();
+	const size_t n = s.cur.size();
+	const uint64_t *kp = key.data();
+	int32_t *cur = s.cur.data();
+	for (size_t i = 0; i < n; ++i) t[i].x = kp[(size_t)cur[i]], t[i].y = (uint64_t)cur[i];
+	ksort_exact(t, n, [](const pg128_t &a) { return a.x; });
+	for (size_t i = 0; i < n; ++i) cur[i] = (int32_t)t[i].y;
 }
 
 // advance one segment by one sort.  The sequence X1 -cm-> Y1 -cs-> X2 -cm-> Y2 ... is a deterministic map on a

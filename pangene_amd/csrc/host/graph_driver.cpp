@@ -525,7 +525,7 @@ static int mark_branch_flt_hit(pg_graph_t *q, DataExt *ext) // branch.c:108-145;
 {
 	int64_t n = 0;
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 1), "override_order"); } // branch.c:116
-	{ Phase ph(PH_MARK_HITS); BE_CALL(ext->be->mark_hits(ext->ctx, nullptr, nullptr, q->n_arc, &n), "mark_hits"); }
+	{ Phase ph(PH_MARK_HITS); BE_CALL(ext->be->mark_hits(ext->ctx, nullptr, nullptr, q->n_arc, pg_verbose >= 3 ? &n : nullptr), "mark_hits"); }
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // branch.c:140
 	if (pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] marked %ld diverged hits\n", "pg_mark_branch_flt_hit", stamp(), (long)n);

@@ -7,6 +7,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <utility>
 
 namespace pgx {
@@ -27,29 +28,44 @@ static void ks_insertion(T *a, size_t n, KeyFn key)
 template <class T, class KeyFn>
 static void ks_flag_pass(T *a, size_t n, int shift, KeyFn key)
 {
-	size_t head[256], tail[256], cnt[256] = {0};
-	for (size_t i = 0; i < n; ++i) ++cnt[(key(a[i]) >> shift) & 0xff];
+	// The reference walks all 256 buckets; empty ones are skipped there without effect, so only the occupied
+	// digits (kept in a 256-bit set) are visited here -- same element moves, far fewer iterations for the small
+	// buckets that dominate the recursion.
+	uint32_t cnt[256];
+	size_t head[256], tail[256];
+	uint64_t occ[4] = {0, 0, 0, 0};
+	std::memset(cnt, 0, sizeof(cnt));
+	for (size_t i = 0; i < n; ++i) {
+		unsigned d = (unsigned)((key(a[i]) >> shift) & 0xff);
+		++cnt[d];
+		occ[d >> 6] |= 1ULL << (d & 63);
+	}
+	unsigned digits[256];
+	int nd = 0;
+	for (int w = 0; w < 4; ++w)
+		for (uint64_t m = occ[w]; m; m &= m - 1) digits[nd++] = (unsigned)(w * 64 + __builtin_ctzll(m));
 	size_t acc = 0;
-	for (int b = 0; b < 256; ++b) { head[b] = acc; acc += cnt[b]; tail[b] = acc; }
-	// cycle-leader permutation: the element carried out of bucket k is dropped at the write cursor of
-	// its own bucket, whatever sits there is carried on, until something that belongs to k comes back
-	for (int k = 0; k < 256;) {
-		if (head[k] == tail[k]) { ++k; continue; }
+	for (int t = 0; t < nd; ++t) { unsigned b = digits[t]; head[b] = acc; acc += cnt[b]; tail[b] = acc; }
+	// cycle-leader permutation: the element carried out of bucket k is dropped at the write cursor of its own
+	// bucket, whatever sits there is carried on, until something that belongs to k comes back
+	for (int t = 0; t < nd;) {
+		const unsigned k = digits[t];
+		if (head[k] == tail[k]) { ++t; continue; }
 		unsigned l = (unsigned)((key(a[head[k]]) >> shift) & 0xff);
-		if ((int)l == k) { ++head[k]; continue; }
+		if (l == k) { ++head[k]; continue; }
 		T carry = a[head[k]];
 		do {
 			std::swap(carry, a[head[l]]);
 			++head[l];
 			l = (unsigned)((key(carry) >> shift) & 0xff);
-		} while ((int)l != k);
+		} while (l != k);
 		a[head[k]++] = carry;
 	}
 	if (shift == 0) return;
 	int next = shift > 8 ? shift - 8 : 0;
 	size_t st = 0;
-	for (int b = 0; b < 256; ++b) {
-		size_t m = cnt[b];
+	for (int t = 0; t < nd; ++t) {
+		size_t m = cnt[digits[t]];
 		if (m > 64) ks_flag_pass(a + st, m, next, key);
 		else if (m > 1) ks_insertion(a + st, m, key);
 		st += m;
