@@ -191,6 +191,11 @@ double  pg_last_path_seconds(void);
 int64_t pg_last_path_hits(void);
 double  pg_last_upload_seconds(void);   /* host pack + H2D copy of the last pg_post_process (not part of the path time) */
 
+/* pg_post_process / pg_graph_gen leave the per-hit FLAG fields of the host records (flt, shadow, rank, ...) on the
+ * device until a writer needs them: pg_write_graph/pg_write_walk only fetch one flt bit per hit, pg_write_bed
+ * fetches everything.  A caller that reads d->genome[j].hit[i] itself calls this first. */
+int pg_sync_host(pg_data_t *d);
+
 /* Tie-order policy (see DESIGN.md "bit-identity"): 0 canonical stable order everywhere; 1 (default,
  * env PANGENE_EXACT=auto) replay the reference's unstable sort for the first contig of genomes whose
  * leading tie group has >= 2 hits; 2 (PANGENE_EXACT=all) replay it for every contig. */

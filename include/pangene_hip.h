@@ -89,6 +89,7 @@ typedef struct {
 	int32_t *rank, *score_dom, *pid_dom, *pid_dom0;
 	int32_t *pos_x;              /* position of the hit inside its genome in X (cs) order */
 	int32_t *pos_y;              /* position of the hit inside its genome in Y (cm) order */
+	uint64_t *flt_x_bits;        /* [(n_hit+63)/64] bit (hit_off[g] + pos_x) = flt of that hit: all the W-line writer needs */
 } pga_hit_state_t;
 
 /* one partially reduced arc: sums over the LOCAL genomes of the per-genome collapsed values

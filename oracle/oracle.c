@@ -856,6 +856,11 @@ int pgo_download(pga_ctx_t *c, const pga_hit_state_t *o)
 {
 	int32_t j;
 	int64_t i, k;
+	if (o->flt_x_bits) {
+		memset(o->flt_x_bits, 0, (size_t)((c->n_hit + 63) / 64) * sizeof(uint64_t));
+		for (i = 0; i < c->n_hit; ++i)
+			if (c->flags[i] & PGA_F_FLT) o->flt_x_bits[i >> 6] |= 1ULL << (i & 63);
+	}
 	for (j = 0; j < c->n_genome; ++j) {
 		int64_t st = c->off[j];
 		for (i = st; i < c->off[j + 1]; ++i) {

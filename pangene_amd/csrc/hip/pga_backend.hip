@@ -1033,6 +1033,13 @@ __global__ __launch_bounds__(BLOCK) void k_ov_remap_y(int32_t *yperm, int n, con
 	if (y < n) yperm[y] = remap[yperm[y]];
 }
 
+__global__ __launch_bounds__(BLOCK) void k_flt_bits(const uint32_t *flags, int n, unsigned long long *bits)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	const unsigned long long m = __ballot(h < n && (flags[h < n ? h : n - 1] & PGA_F_FLT));
+	if ((threadIdx.x & 63) == 0 && h < n) bits[h >> 6] = m;
+}
+
 // ================================================================================================
 // host side of the ABI
 // ================================================================================================
@@ -1627,6 +1634,13 @@ extern "C" int pga_download(pga_ctx_t *c, const pga_hit_state_t *o)
 {
 	const int N = c->N;
 	if (N == 0) return 0;
+	if (o->flt_x_bits) {
+		unsigned long long *bits = (unsigned long long *)c->pool.get(S_MISC, sizeof(uint64_t) * (size_t)((N + 63) / 64) + 16);
+		if (!bits) return PGA_ERR_NOMEM;
+		hipLaunchKernelGGL(k_flt_bits, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, N, bits);
+		HIPCHK(hipMemcpyAsync(o->flt_x_bits, bits, sizeof(uint64_t) * (size_t)((N + 63) / 64), hipMemcpyDeviceToHost, c->st));
+		if (!o->flags && !o->rank && !o->score_dom && !o->pid_dom && !o->pid_dom0 && !o->pos_x && !o->pos_y) return sync_st(c);
+	}
 	int32_t *dl = (int32_t *)c->pool.get(S_DL, sizeof(int32_t) * 7 * (size_t)N);
 	if (!dl) return PGA_ERR_NOMEM;
 	hipLaunchKernelGGL(k_to_file, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, c->flags, c->rank, c->sdom, c->pdom, c->pdom0, c->yperm, N,

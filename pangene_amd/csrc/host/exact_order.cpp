@@ -69,88 +69,115 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 	}
 }
 
-void exact_begin(DataExt *ext) // start of a run: arrays are in file order (read.c:232-234)
-{
-	for (ExactSeg &s : ext->xsegs) {
-		s.cur.resize(s.file.size());
-		for (size_t i = 0; i < s.file.size(); ++i) s.cur[i] = (int32_t)i; // indices into s.file / s.cs / s.cm
-		s.hx.clear(), s.hy.clear(), s.pushed[0].clear(), s.pushed[1].clear();
-		s.cyc_start = -1, s.period = 0, s.n_sort[0] = s.n_sort[1] = 0, s.view = &s.cur;
-	}
-	ext->head_file.assign(ext->local_genomes.size(), -1);
-}
-
-static void emulate(ExactSeg &s, int by_cm) // one pg_hit_sort of this contig segment
+static void emulate(ExactSeg &s, std::vector<int32_t> &curv, int by_cm) // one pg_hit_sort of this contig segment
 {
 	const std::vector<uint64_t> &key = by_cm ? s.cm : s.cs;
-	static thread_local std::vector<pg128_t> tls; // reused: a fresh 160 KB vector per call would be mmap'ed and page-faulted each time
-	if (tls.size() < s.cur.size()) tls.resize(s.cur.size());
+	static thread_local std::vector<pg128_t> tls; // reused: a fresh vector per call would be mmap'ed and page-faulted each time
+	if (tls.size() < curv.size()) tls.resize(curv.size());
 	pg128_t *t = tls.data();
-	const size_t n = s.cur.size();
+	const size_t n = curv.size();
 	const uint64_t *kp = key.data();
-	int32_t *cur = s.cur.data();
+	int32_t *cur = curv.data();
 	for (size_t i = 0; i < n; ++i) t[i].x = kp[(size_t)cur[i]], t[i].y = (uint64_t)cur[i];
 	ksort_exact(t, n, [](const pg128_t &a) { return a.x; });
 	for (size_t i = 0; i < n; ++i) cur[i] = (int32_t)t[i].y;
 }
 
-// advance one segment by one sort.  The sequence X1 -cm-> Y1 -cs-> X2 -cm-> Y2 ... is a deterministic map on a
-// finite set, so it becomes periodic; once a cs order repeats, later orders are read from the history.
-static void advance(ExactSeg &s, int by_cm, bool keep_y)
+// Replay the whole sort sequence of one segment: file order -cs-> X1 -cm-> Y1 -cs-> X2 ...  It is a deterministic
+// map on a finite set, so it becomes periodic; the replay stops when a cs order repeats (normally after 2-4
+// sorts; the reference performs 67) or after MAX_SORTS.  keep_orders: store every order (mode "all"), else only
+// the hit at array index 0 of each cs order (mode "auto").
+static const int MAX_SORTS = 40;
+static void replay(ExactSeg &s, bool keep_orders)
 {
-	const int t = ++s.n_sort[by_cm]; // 1-based index of this sort among the sorts of its kind
-	if (s.cyc_start > 0) { // periodic: point at the stored order instead of copying it
-		if (by_cm && !keep_y) return; // order not needed by the caller
-		s.view = &(by_cm ? s.hy : s.hx)[(size_t)(s.cyc_start - 1 + (t - s.cyc_start) % s.period)];
-		return;
+	std::vector<int32_t> cur(s.file.size());
+	for (size_t i = 0; i < cur.size(); ++i) cur[i] = (int32_t)i;
+	std::vector<std::vector<int32_t>> hist;
+	s.hx.clear(), s.hy.clear(), s.heads.clear();
+	s.cyc_start = -1, s.period = 0;
+	for (int t = 1; t <= MAX_SORTS; ++t) {
+		emulate(s, cur, 0);
+		for (size_t i = 0; i < hist.size(); ++i)
+			if (hist[i] == cur) { s.cyc_start = (int)i + 1, s.period = t - s.cyc_start; break; }
+		if (s.cyc_start > 0) break;
+		hist.push_back(cur);
+		s.heads.push_back(s.file[(size_t)cur[0]]);
+		emulate(s, cur, 1);
+		if (keep_orders) s.hy.push_back(cur);
 	}
-	s.view = &s.cur;
-	emulate(s, by_cm);
-	if (by_cm) { if (keep_y) s.hy.push_back(s.cur); return; }
-	for (size_t i = 0; i < s.hx.size(); ++i)
-		if (s.hx[i] == s.cur) { s.cyc_start = (int)i + 1, s.period = t - s.cyc_start; return; }
-	s.hx.push_back(s.cur);
+	if (keep_orders) s.hx.swap(hist);
 }
 
-// Replay one pg_hit_sort(g, by_cm) of every tracked segment and hand what changed to the backend.
+static inline size_t order_index(const ExactSeg &s, int t, size_t n_stored) // which stored order the t-th sort (1-based) produced
+{
+	size_t i = (s.cyc_start > 0 && t >= s.cyc_start) ? (size_t)(s.cyc_start - 1 + (t - s.cyc_start) % s.period) : (size_t)(t - 1);
+	return i < n_stored ? i : n_stored - 1;
+}
+
+static void exact_wait(DataExt *ext)
+{
+	for (std::thread &t : ext->xworkers) t.join();
+	ext->xworkers.clear();
+}
+
+// start of a run: the arrays are in file order (read.c:232-234).  The replay depends on the keys only, so it runs
+// on background threads while the GPU does stage A and B; the first consumer joins them.
+void exact_begin(DataExt *ext)
+{
+	exact_wait(ext);
+	ext->head_file.assign(ext->local_genomes.size(), -1);
+	ext->x_sorts[0] = ext->x_sorts[1] = 0;
+	for (ExactSeg &s : ext->xsegs) s.pushed[0].clear(), s.pushed[1].clear();
+	if (ext->xsegs.empty()) return;
+	const bool all = exact_mode() == 2;
+	size_t tot = 0;
+	for (const ExactSeg &s : ext->xsegs) tot += s.file.size();
+	unsigned nt = tot > 50000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+	if (nt > ext->xsegs.size()) nt = (unsigned)ext->xsegs.size();
+	ext->xnext.store(0);
+	for (unsigned t = 0; t < nt; ++t)
+		ext->xworkers.emplace_back([ext, all]() {
+			for (;;) {
+				size_t i = ext->xnext.fetch_add(1);
+				if (i >= ext->xsegs.size()) break;
+				replay(ext->xsegs[i], all);
+			}
+		});
+}
+
+// One pg_hit_sort(g, by_cm) of the reference happened: hand the orders that changed to the backend.
 int exact_sort(DataExt *ext, int by_cm)
 {
 	if (ext->xsegs.empty()) return 0;
-	const bool all = exact_mode() == 2;
-	std::vector<ExactSeg *> todo;
-	size_t tot = 0;
-	for (ExactSeg &s : ext->xsegs) { todo.push_back(&s); if (s.cyc_start < 0) tot += s.cur.size(); }
-	auto work = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) advance(*todo[i], by_cm, all); };
-	unsigned nt = tot > 200000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
-	if (nt > todo.size()) nt = (unsigned)todo.size();
-	if (nt <= 1) work(0, todo.size());
-	else {
-		std::vector<std::thread> th;
-		for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, todo.size() * t / nt, todo.size() * (t + 1) / nt);
-		for (auto &x : th) x.join();
-	}
-	if (!all) { // auto: only the identity of the hit at array index 0 matters, and only for the cs order
+	exact_wait(ext);
+	const int t = ++ext->x_sorts[by_cm];
+	if (exact_mode() != 2) { // auto: only the identity of the hit at array index 0 matters, and only for the cs order
 		if (by_cm) return 0;
 		bool changed = false;
-		for (ExactSeg *s : todo) {
-			const int32_t h = s->file[(size_t)(*s->view)[0]];
-			if (ext->head_file[(size_t)s->k] != h) ext->head_file[(size_t)s->k] = h, changed = true;
+		for (ExactSeg &s : ext->xsegs) {
+			const int32_t h = s.heads[order_index(s, t, s.heads.size())];
+			if (ext->head_file[(size_t)s.k] != h) ext->head_file[(size_t)s.k] = h, changed = true;
 		}
 		return changed ? ext->be->set_head(ext->ctx, ext->head_file.data()) : 0;
 	}
 	std::vector<int32_t> sg, ss, fi;
 	std::vector<int64_t> so(1, 0);
-	for (ExactSeg *s : todo) {
-		if (*s->view == s->pushed[by_cm]) continue;
-		s->pushed[by_cm] = *s->view;
-		sg.push_back(s->k), ss.push_back(s->start);
-		for (int32_t i : *s->view) fi.push_back(s->file[(size_t)i]);
+	for (ExactSeg &s : ext->xsegs) {
+		const std::vector<std::vector<int32_t>> &h = by_cm ? s.hy : s.hx;
+		if (h.empty()) continue;
+		const std::vector<int32_t> &ord = h[order_index(s, t, h.size())];
+		if (ord == s.pushed[by_cm]) continue;
+		s.pushed[by_cm] = ord;
+		sg.push_back(s.k), ss.push_back(s.start);
+		for (int32_t i : ord) fi.push_back(s.file[(size_t)i]);
 		so.push_back((int64_t)fi.size());
 	}
 	if (sg.empty()) return 0;
 	ext->pos_valid = false; // the backend's orders change: the host copy of them is stale
 	return ext->be->override_order(ext->ctx, by_cm, (int32_t)sg.size(), sg.data(), ss.data(), so.data(), fi.data());
 }
+
+void exact_shutdown(DataExt *ext) { exact_wait(ext); }
 
 } // namespace pgx
 

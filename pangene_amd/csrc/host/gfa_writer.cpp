@@ -134,6 +134,12 @@ void pg_write_walk(pg_graph_t *q)
 		const pg_genome_t *g = &d->genome[j];
 		if (g->n_hit == 0) continue;
 		const int32_t *yo = ext->y_order[j].data();
+		// flt comes from the bit vector of the last sync (the flag fields of the host records are only refreshed by a
+		// full sync); the shard offset of genome j is found through its position among the local genomes
+		int64_t goff = -1;
+		for (size_t k = 0; k < ext->local_genomes.size(); ++k) if (ext->local_genomes[k] == j) { goff = ext->hit_off[k]; break; }
+		const uint64_t *fb = ext->flt_bits.data();
+		auto is_flt = [&](int32_t host_idx) { const int64_t b = goff + host_idx; return (fb[b >> 6] >> (b & 63) & 1) != 0; };
 		for (int32_t i0 = 0, i = 1; i <= g->n_hit; ++i) {
 			if (i != g->n_hit && g->hit[yo[i]].cid == g->hit[yo[i0]].cid) continue;
 			int32_t cid = g->hit[yo[i0]].cid, n = 0;
@@ -145,7 +151,7 @@ void pg_write_walk(pg_graph_t *q)
 			o += '\t'; o += g->ctg[cid].name; o += "\t*\t*\t";
 			for (int32_t k = i0; k < i; ++k) {
 				const pg_hit_t *a = &g->hit[yo[k]];
-				if (a->flt) continue;
+				if (is_flt(yo[k])) continue;
 				o += "><"[a->rev]; o += d->gene[d->prot[a->pid].gid].name;
 				++n;
 			}
@@ -153,7 +159,7 @@ void pg_write_walk(pg_graph_t *q)
 				o += "\tlf:B:i";
 				for (int32_t k = i0; k < i; ++k) {
 					const pg_hit_t *a = &g->hit[yo[k]];
-					if (a->flt) continue;
+					if (is_flt(yo[k])) continue;
 					o += ','; put_i32(o, a->lof);
 				}
 				o += '\n';

@@ -159,10 +159,11 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	return ext->be->create(&ext->ctx, &sh, &par);
 }
 
-// Pull per-hit state back and (first time) put the host arrays into cs order, which is how the
-// reference leaves them (hit.c:57-63 replaces g->hit on every sort).  full = false fetches only what the
-// GFA writers read (the flag word; the two orders once per order epoch); full = true also rank, score_dom and
-// the dominators (BED writers).
+// Pull per-hit state back and (first time) put the host arrays into cs order, which is how the reference
+// leaves them (hit.c:57-63 replaces g->hit on every sort).
+//   full = false: what the GFA writers need -- one flt bit per hit (DataExt::flt_bits) and, once per order epoch,
+//                 the two orders; the flag fields of the host records are NOT refreshed;
+//   full = true : every per-hit field of the host records (BED writers, pg_sync_host()).
 int sync_host(pg_data_t *d, bool full)
 {
 	DataExt *ext = ext_of(d, false);
@@ -171,12 +172,13 @@ int sync_host(pg_data_t *d, bool full)
 	Phase ph(PH_SYNC_HOST);
 	const int64_t N = ext->n_hit_local;
 	const bool need_pos = !ext->pos_valid;
-	std::vector<uint32_t> flags((size_t)N);
+	std::vector<uint32_t> flags;
 	std::vector<int32_t> rank, sdom, pdom, pdom0, py;
-	if (full) rank.resize((size_t)N), sdom.resize((size_t)N), pdom.resize((size_t)N), pdom0.resize((size_t)N);
+	if (full) flags.resize((size_t)N), rank.resize((size_t)N), sdom.resize((size_t)N), pdom.resize((size_t)N), pdom0.resize((size_t)N);
 	if (need_pos) ext->pos_x.resize((size_t)N), py.resize((size_t)N);
-	pga_hit_state_t st = { flags.data(), full ? rank.data() : nullptr, full ? sdom.data() : nullptr, full ? pdom.data() : nullptr,
-	                       full ? pdom0.data() : nullptr, need_pos ? ext->pos_x.data() : nullptr, need_pos ? py.data() : nullptr };
+	ext->flt_bits.resize((size_t)((N + 63) / 64) + 1);
+	pga_hit_state_t st = { full ? flags.data() : nullptr, full ? rank.data() : nullptr, full ? sdom.data() : nullptr, full ? pdom.data() : nullptr,
+	                       full ? pdom0.data() : nullptr, need_pos ? ext->pos_x.data() : nullptr, need_pos ? py.data() : nullptr, ext->flt_bits.data() };
 	BE_CALL(ext->be->download(ext->ctx, &st), "download");
 	const int32_t *px = ext->pos_x.data();
 	ext->y_order.resize((size_t)d->n_genome);
@@ -204,6 +206,7 @@ int sync_host(pg_data_t *d, bool full)
 				ext->y_order[(size_t)j][(size_t)py[(size_t)(off + f)]] = px[(size_t)(off + f)];
 			}
 		}
+		if (!full) return;
 		for (int32_t f = 0; f < g->n_hit; ++f) {
 			const size_t s = (size_t)(off + f);
 			pg_hit_t *h = &g->hit[px[s]];
@@ -211,10 +214,10 @@ int sync_host(pg_data_t *d, bool full)
 			h->flt = !!(fl & PGA_F_FLT), h->flt_iso_sub_self = !!(fl & PGA_F_ISO_SUB), h->flt_iso_ov = !!(fl & PGA_F_ISO_OV);
 			h->flt_chain = !!(fl & PGA_F_CHAIN), h->pseudo = !!(fl & PGA_F_PSEUDO), h->vtx = !!(fl & PGA_F_VTX);
 			h->shadow = !!(fl & PGA_F_SHADOW), h->rep = !!(fl & PGA_F_REP), h->weak_br = (fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT;
-			if (full) h->rank = rank[s], h->score_dom = sdom[s], h->pid_dom = pdom[s], h->pid_dom0 = pdom0[s];
+			h->rank = rank[s], h->score_dom = sdom[s], h->pid_dom = pdom[s], h->pid_dom0 = pdom0[s];
 		}
 	};
-	{ // genomes are independent and the 88-byte records are scattered: spread them over host threads
+	if (need_pos || full) { // genomes are independent and the 88-byte records are scattered: spread them over host threads
 		const size_t ng = ext->local_genomes.size();
 		unsigned nt = N > 200000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
 		if (nt > ng) nt = (unsigned)ng;
@@ -249,8 +252,12 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 	pga_ctx_t *ctx = ext->ctx;
 	g_t_path0 = now_sec();
 	for (int i = 0; i < PH_COUNT; ++i) g_phase[i] = 0;
+	exact_begin(ext); // background replay of the reference's sort sequence (keys only), overlaps stages A and B
 	{ Phase ph(PH_BEGIN); BE_CALL(be->begin(ctx), "begin"); }
-	{ Phase ph(PH_EXACT); exact_begin(ext); BE_CALL(exact_sort(ext, 0), "override_order"); } // pg_hit_sort(g, 0), read.c:247
+	// pg_hit_sort(g, 0), read.c:247.  Mode "all" needs the exact S1 order for stage A (first-wins ties); in mode "auto"
+	// only array index 0 matters and it is inert while every shadow flag is 0 (read.c:252, i.e. until the sweep of
+	// round 1), so the hand-over waits until pg_graph_gen and the replay overlaps stages A and B.
+	if (exact_mode() == 2) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); }
 	const int32_t nl = (int32_t)ext->local_genomes.size(), P = d->n_prot;
 	if (pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] %d genes and %d proteins; %ld hits of %d genomes on backend '%s'\n", __func__, stamp(),
@@ -538,6 +545,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	if (ext == nullptr || ext->ctx == nullptr) { set_error(PGA_ERR_ARG, "pg_graph_gen: pg_post_process has not run"); return PGA_ERR_ARG; }
 	const pga_backend_t *be = ext->be;
 	pga_ctx_t *ctx = ext->ctx;
+	if (exact_mode() != 2) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "set_head"); } // index 0 of the S1 order, see post_process_impl
 	// graph 1: initial vertices (graph.c:284-291)
 	BE_CALL(be->set_filter(ctx, PGA_FLT_PSEUDO), "set_filter");
 	BE_CALL(gen_vtx(opt, q, ext), "gen_vtx");
@@ -645,6 +653,8 @@ int pg_last_error(void) { return g_err; }
 const char *pg_last_error_str(void) { return g_errstr; }
 double pg_last_path_seconds(void) { return g_path_sec; }
 double pg_last_upload_seconds(void) { return g_upload_sec; }
+
+int pg_sync_host(pg_data_t *d) { return sync_host(d, true); } // refresh every per-hit field of the host records
 
 int pg_phase_times(double *out, int n) // seconds per driver phase of the last run; returns the number of phases
 {

@@ -33,6 +33,7 @@ void ext_drop(const pg_data_t *d)
 	auto it = g_ext.find(d);
 	if (it == g_ext.end()) return;
 	DataExt *e = it->second;
+	exact_shutdown(e);
 	if (e->ctx && e->be) e->be->destroy(e->ctx);
 	delete e;
 	g_ext.erase(it);

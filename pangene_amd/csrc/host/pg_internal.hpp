@@ -4,7 +4,9 @@
 #include <cstdio>
 #include <deque>
 #include <string>
+#include <atomic>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include "pangene_amd.h"
@@ -42,11 +44,9 @@ struct ExactSeg {
 	int32_t k = 0, start = 0;             // local genome index; offset of the contig inside the genome
 	std::vector<int32_t> file;            // file index of each hit of the contig, in file order
 	std::vector<uint64_t> cs, cm;         // sort keys, aligned with `file`
-	std::vector<int32_t> cur;             // current array order (indices into `file`)
-	const std::vector<int32_t> *view = nullptr; // the order after the last replayed sort (cur, or a stored one once periodic)
-	std::vector<std::vector<int32_t>> hx, hy; // history of cs / cm orders until the sequence becomes periodic
+	std::vector<std::vector<int32_t>> hx, hy; // mode all: the cs / cm orders X_1.., Y_1.. until the sequence becomes periodic
+	std::vector<int32_t> heads;           // file index of the hit at array index 0 of X_1, X_2, ...
 	int cyc_start = -1, period = 0;       // X_t == X_{cyc_start + (t - cyc_start) % period} for t >= cyc_start (1-based)
-	int n_sort[2] = {0, 0};               // cs / cm sorts replayed so far
 	std::vector<int32_t> pushed[2];       // order the backend currently holds for cs (0) and cm (1)
 };
 
@@ -60,10 +60,14 @@ struct DataExt {
 	std::vector<int64_t> hit_off;      // shard hit offsets
 	std::vector<std::vector<int32_t>> y_order; // per genome: host index of the k-th hit in cm order
 	std::vector<ExactSeg> xsegs;
+	std::vector<std::thread> xworkers; // background replay of the reference's sort sequence
+	std::atomic<size_t> xnext{0};
+	int x_sorts[2] = {0, 0};           // cs / cm sorts of the reference seen so far in this run
 	std::vector<int32_t> head_file;    // per local genome: file index of the hit at array index 0 (-1 canonical)
 	bool rerun = false;                // pg_rerun_resident(): keep the backend context, skip pack + upload
 	bool host_full = false;            // the last sync also fetched rank / score_dom / dominators
 	bool pos_valid = false;            // pos_x / y_order on the host match the backend's current orders
+	std::vector<uint64_t> flt_bits;    // bit (shard hit offset of the genome + host index) = flt, refreshed by every sync
 	std::vector<int32_t> pos_x;        // per local hit (file order): position inside its genome in cs order
 	std::vector<std::vector<int32_t>> file_of_host; // per genome: host array index -> file index
 	bool host_stale = false;           // per-hit flags on the host are older than the backend's
@@ -90,6 +94,7 @@ int exact_mode();
 void exact_init(const pg_data_t *d, DataExt *ext);
 void exact_begin(DataExt *ext);
 int exact_sort(DataExt *ext, int by_cm);
+void exact_shutdown(DataExt *ext);
 
 // phase accounting of the host driver (seconds, accumulated over the last run)
 enum { PH_BEGIN, PH_EXACT, PH_INGEST, PH_POST, PH_VTX, PH_ARC_DEV, PH_ARC_HOST, PH_BRANCH_HOST, PH_NLOCAL, PH_MARK_HITS, PH_FLT, PH_SYNC_HOST, PH_COUNT };
