@@ -145,6 +145,11 @@ typedef struct {
 	/* per-genome part of pg_gen_arc (graph.c:97-146) + local reduce-by-key of its global part. \
 	 * seg_cnt[2S] = n_genome[S] then tot_cnt[S] (graph.c:125-126); arcs sorted by x */ \
 	int  pfx##_arc_round(pga_ctx_t *ctx, int32_t use_ori, int32_t **seg_cnt, pga_arc_part_t **arcs, int64_t *n_arcs); \
+	/* cross-shard reduce-by-key of the locally reduced arc tables after their all-gather: `gathered` (backend memory) \
+	 * holds W slots of `slot` entries, count[r] (host) of them valid in slot r, each slot sorted by x.  Sums the \
+	 * integer fields of equal x (graph.c:153-169 is a sum, so the order of the shards is irrelevant). */ \
+	int  pfx##_arc_merge(pga_ctx_t *ctx, const pga_arc_part_t *gathered, const int64_t *count, int32_t W, int64_t slot, \
+	                     pga_arc_part_t **out, int64_t *n_out); \
 	/* pg_gen_rep_pos (branch.c:6-29) kept in backend memory */ \
 	int  pfx##_rep_pos(pga_ctx_t *ctx); \
 	/* pg_n_local (branch.c:31-46) for n gene pairs (pairs[2i], pairs[2i+1]) summed over local genomes */ \
@@ -204,6 +209,7 @@ typedef struct {
 	int  (*vtx_partials)(pga_ctx_t *, int32_t **, uint64_t **, int64_t *);
 	int  (*flag_vtx)(pga_ctx_t *, const int32_t *, int32_t);
 	int  (*arc_round)(pga_ctx_t *, int32_t, int32_t **, pga_arc_part_t **, int64_t *);
+	int  (*arc_merge)(pga_ctx_t *, const pga_arc_part_t *, const int64_t *, int32_t, int64_t, pga_arc_part_t **, int64_t *);
 	int  (*rep_pos)(pga_ctx_t *);
 	int  (*n_local)(pga_ctx_t *, const int32_t *, int64_t, int32_t, int32_t, int32_t, int32_t **);
 	int  (*branch_pairs)(pga_ctx_t *, const uint64_t *, const int32_t *, int64_t, const int32_t *, int32_t, double, int32_t, int32_t, int32_t, int32_t **, int64_t *);

@@ -610,6 +610,34 @@ int pgo_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_
 	return PGA_OK;
 }
 
+static int arcpart_cmp(const void *a, const void *b)
+{
+	uint64_t x = ((const pga_arc_part_t*)a)->x, y = ((const pga_arc_part_t*)b)->x;
+	return x < y ? -1 : x > y;
+}
+
+/* cross-shard reduce-by-key (the sums of graph.c:153-169 over the shards) */
+int pgo_arc_merge(pga_ctx_t *c, const pga_arc_part_t *gathered, const int64_t *count, int32_t W, int64_t slot, pga_arc_part_t **out, int64_t *n_out)
+{
+	int64_t tot = 0, i, k = 0;
+	int32_t r;
+	pga_arc_part_t *t;
+	for (r = 0; r < W; ++r) tot += count[r];
+	t = MALLOC(pga_arc_part_t, tot);
+	for (r = 0, i = 0; r < W; ++r) { memcpy(t + i, gathered + (int64_t)r * slot, count[r] * sizeof(pga_arc_part_t)); i += count[r]; }
+	qsort(t, (size_t)tot, sizeof(pga_arc_part_t), arcpart_cmp);
+	for (i = 0; i < tot; ++i) {
+		if (k > 0 && t[k-1].x == t[i].x) {
+			t[k-1].n_genome += t[i].n_genome, t[k-1].tot_cnt += t[i].tot_cnt;
+			t[k-1].sum_dist += t[i].sum_dist, t[k-1].sum_s1 += t[i].sum_s1, t[k-1].sum_s2 += t[i].sum_s2;
+		} else t[k++] = t[i];
+	}
+	free(c->arcs);
+	c->arcs = t, c->n_arcs = k, c->m_arcs = tot;
+	*out = t, *n_out = k;
+	return PGA_OK;
+}
+
 /* pg_gen_rep_pos, branch.c:6-29 */
 int pgo_rep_pos(pga_ctx_t *c)
 {
@@ -885,7 +913,7 @@ const pga_backend_t *pgo_backend(void)
 {
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
-		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
+		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_arc_merge, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
 		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0
 	};
 	return &b;

@@ -54,7 +54,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
+	S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
 	S_COUNT
 };
 
@@ -722,6 +722,55 @@ __global__ __launch_bounds__(BLOCK) void k_arc_l2(const uint64_t *key, int64_t m
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// cross-shard merge of arc tables (after the all-gather): gather valid entries, sort by x, wave-per-run sums
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_mg_keys(const pga_arc_part_t *g, const int32_t *src, int64_t tot, uint64_t *key, uint32_t *val)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= tot) return;
+	key[i] = g[src[i]].x; // x = v<<32|w with v,w < 2^21: 53 significant bits at most
+	val[i] = (uint32_t)src[i];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mg_head(const uint64_t *key, int64_t m, int32_t *head)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i < m) head[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mg_runstart(const int32_t *head, const int32_t *slot, int64_t m, int32_t *run_start)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i < m && head[i]) run_start[slot[i]] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mg_sum(const pga_arc_part_t *g, const uint32_t *val, int64_t m, int64_t n_run, const int32_t *run_start, pga_arc_part_t *out)
+{
+	const int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (w >= n_run) return;
+	const int64_t st = run_start[w], en = w + 1 < n_run ? run_start[w + 1] : m;
+	int ng = 0, tot = 0;
+	uint64_t sd = 0, x = 0;
+	int64_t a1 = 0, a2 = 0;
+	for (int64_t j = st + lane; j < en; j += WAVE) {
+		const pga_arc_part_t p = g[val[j]];
+		x = p.x, ng += p.n_genome, tot += p.tot_cnt, sd += p.sum_dist, a1 += p.sum_s1, a2 += p.sum_s2;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		ng += __shfl_xor(ng, o, WAVE), tot += __shfl_xor(tot, o, WAVE);
+		sd += (uint64_t)__shfl_xor((long long)sd, o, WAVE), a1 += __shfl_xor((long long)a1, o, WAVE), a2 += __shfl_xor((long long)a2, o, WAVE);
+	}
+	if (lane == 0) { // lane 0 always owns element st
+		pga_arc_part_t r;
+		r.x = x, r.n_genome = ng, r.tot_cnt = tot, r.sum_dist = sd, r.sum_s1 = a1, r.sum_s2 = a2;
+		out[w] = r;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // branch.c on device: pg_gen_rep_pos (6-29), pg_n_local (31-46), pg_mark_branch_flt_hit (108-145)
 // ------------------------------------------------------------------------------------------------
@@ -741,39 +790,37 @@ __global__ __launch_bounds__(BLOCK) void k_rep_last(const int32_t *wk, const int
 }
 
 __global__ __launch_bounds__(BLOCK) void k_rep_fill(const int32_t *rp_pos, int64_t n_ent, int GL, const int32_t *seg, const int32_t *cm, const int32_t *rx,
-                                                      const int32_t *goff, int32_t *rp_seg, int32_t *rp_r, int32_t *rp_cm)
+                                                      const int32_t *goff, int4 *rp)
 {
 	int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (e >= n_ent) return;
 	int p = rp_pos[e];
-	if (p == 0) { rp_seg[e] = -1, rp_r[e] = 0, rp_cm[e] = 0; return; }
+	if (p == 0) { rp[e] = make_int4(-1, 0, 0, 0); return; }
 	int h = p - 1, j = (int)(e % GL);
-	rp_seg[e] = seg[h], rp_cm[e] = cm[h];
-	rp_r[e] = rx[h] - rx[goff[j]]; // rank among the walkable hits of this genome (exclusive prefix count)
+	rp[e] = make_int4(seg[h], rx[h] - rx[goff[j]], cm[h], 0); // {contig, rank among the walkable hits of the genome, cm}
 }
 
-// one wave per gene pair, lanes over the local genomes
-__global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const int32_t *rp_seg, const int32_t *rp_r, const int32_t *rp_cm,
+// one wave per gene pair, lanes over the local genomes; one 16-byte record per (gene, genome)
+__global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const int4 *rp,
                                                      int local_dist, int local_count, int frag_mode, int32_t *cnt)
 {
 	const int64_t k = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
 	if (k >= n_pair) return;
-	const int64_t b1 = (int64_t)pairs[2 * k] * GL, b2 = (int64_t)pairs[2 * k + 1] * GL;
+	const int4 *r1 = rp + (int64_t)pairs[2 * k] * GL, *r2 = rp + (int64_t)pairs[2 * k + 1] * GL;
 	int c = 0;
 	for (int j = lane; j < GL; j += WAVE) {
-		const int s1 = rp_seg[b1 + j], s2 = rp_seg[b2 + j];
-		if (s1 < 0 || s2 < 0) continue;
-		if (!frag_mode && s1 != s2) continue;
-		const int64_t d = (int64_t)rp_cm[b1 + j] - (int64_t)rp_cm[b2 + j];
-		const int cc = rp_r[b1 + j] - rp_r[b2 + j];
+		const int4 a = r1[j], b = r2[j];
+		if (a.x < 0 || b.x < 0) continue;
+		if (!frag_mode && a.x != b.x) continue;
+		const int64_t d = (int64_t)a.z - (int64_t)b.z;
+		const int cc = a.y - b.y;
 		if ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count)) ++c;
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, WAVE);
 	if (lane == 0) cnt[k] = c;
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // pg_mark_branch_flt_arc (branch.c:48-106) on the arc table: one thread per oriented vertex
@@ -1424,15 +1471,59 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	return sync_st(c);
 }
 
+
+extern "C" int pga_arc_merge(pga_ctx_t *c, const pga_arc_part_t *gathered, const int64_t *count, int32_t W, int64_t slot_sz,
+                             pga_arc_part_t **out, int64_t *n_out)
+{
+	int64_t tot = 0;
+	for (int r = 0; r < W; ++r) tot += count[r];
+	*out = nullptr, *n_out = 0;
+	if (tot == 0) return 0;
+	std::vector<int32_t> src((size_t)tot);
+	{
+		int64_t i = 0;
+		for (int r = 0; r < W; ++r) for (int64_t k = 0; k < count[r]; ++k) src[(size_t)i++] = (int32_t)(r * slot_sz + k);
+	}
+	int32_t *d_src = (int32_t *)c->pool.get(S_MG_SRC, sizeof(int32_t) * (size_t)tot);
+	uint64_t *key = (uint64_t *)c->pool.get(S_MG_KEY, sizeof(uint64_t) * 2 * (size_t)tot + 64);
+	uint32_t *val = (uint32_t *)c->pool.get(S_MG_VAL, sizeof(uint32_t) * 2 * (size_t)tot + 64);
+	int32_t *head = (int32_t *)c->pool.get(S_MG_HEAD, sizeof(int32_t) * (size_t)tot), *slot = (int32_t *)c->pool.get(S_MG_SLOT, sizeof(int32_t) * (size_t)tot);
+	uint32_t *table = (uint32_t *)c->pool.get(S_TABLE, 0);
+	int32_t *tile = (int32_t *)c->pool.get(S_TILE, 0);
+	if (!d_src || !key || !val || !head || !slot || !table || !tile) return PGA_ERR_NOMEM;
+	if (tot > 2 * (int64_t)c->N + 2 && (rs_table_len(tot) > rs_table_len(2 * (int64_t)c->N + 2))) { // work buffers are sized for 2N items
+		table = (uint32_t *)c->pool.get(S_TABLE, sizeof(uint32_t) * (size_t)rs_table_len(tot));
+		tile = (int32_t *)c->pool.get(S_TILE, sizeof(int64_t) * (size_t)(scan_tiles(std::max<int64_t>(rs_table_len(tot), tot)) + 8));
+		if (!table || !tile) return PGA_ERR_NOMEM;
+	}
+	TRY(upload(c, d_src, src.data(), (size_t)tot));
+	hipLaunchKernelGGL(k_mg_keys, dim3(nblk(tot)), dim3(BLOCK), 0, c->st, gathered, d_src, tot, key, val);
+	RadixBufs b = { key + tot, val + tot, table, tile };
+	uint64_t *ks; uint32_t *vs;
+	const int vb = bits_for((uint32_t)(2 * std::max(1, c->n_seg)));
+	device_radix_sort(key, val, tot, 32 + vb, b, &ks, &vs, c->st);
+	hipLaunchKernelGGL(k_mg_head, dim3(nblk(tot)), dim3(BLOCK), 0, c->st, ks, tot, head);
+	device_scan<I32>(InI32{head}, OutExclI32{slot}, tot, (I32 *)tile, OpSum{}, I32{0}, c->st);
+	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, slot + (tot - 1), head + (tot - 1), c->dcnt + 10);
+	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	TRY(sync_st(c));
+	const int64_t A = c->h_cnt[10];
+	int32_t *run_start = (int32_t *)c->pool.get(S_MG_RUN, sizeof(int32_t) * (size_t)A + 16);
+	pga_arc_part_t *res = (pga_arc_part_t *)c->pool.get(S_MG_OUT, sizeof(pga_arc_part_t) * (size_t)A + 16);
+	if (!run_start || !res) return PGA_ERR_NOMEM;
+	hipLaunchKernelGGL(k_mg_runstart, dim3(nblk(tot)), dim3(BLOCK), 0, c->st, head, slot, tot, run_start);
+	hipLaunchKernelGGL(k_mg_sum, dim3(nblk(A, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gathered, vs, tot, A, run_start, res);
+	*out = res, *n_out = A;
+	return 0;
+}
+
 extern "C" int pga_rep_pos(pga_ctx_t *c)
 {
 	const int N = c->N, GL = c->n_genome, Q = c->Q;
 	const int64_t n_ent = (int64_t)Q * GL;
 	int32_t *rp_pos = (int32_t *)c->pool.get(S_RP_POS, sizeof(int32_t) * (size_t)n_ent);
-	int32_t *rp_seg = (int32_t *)c->pool.get(S_RP_SEG, sizeof(int32_t) * (size_t)n_ent);
-	int32_t *rp_r = (int32_t *)c->pool.get(S_RP_R, sizeof(int32_t) * (size_t)n_ent);
-	int32_t *rp_cm = (int32_t *)c->pool.get(S_RP_CM, sizeof(int32_t) * (size_t)n_ent);
-	if (!rp_pos || !rp_seg || !rp_r || !rp_cm) return PGA_ERR_NOMEM;
+	int4 *rp = (int4 *)c->pool.get(S_RP_SEG, sizeof(int4) * (size_t)n_ent);
+	if (!rp_pos || !rp) return PGA_ERR_NOMEM;
 	HIPCHK(hipMemsetAsync(rp_pos, 0, sizeof(int32_t) * (size_t)n_ent, c->st));
 	if (N) {
 		int32_t *wk = (int32_t *)c->pool.get(S_I32_A, sizeof(int32_t) * (size_t)N);
@@ -1443,9 +1534,9 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		device_scan<I32>(InI32{wk}, OutExclI32{rx}, N, tile, OpSum{}, I32{0}, c->st);
 		hipLaunchKernelGGL(k_rep_last, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->gnm, c->gid, N, GL, rp_pos);
 		hipLaunchKernelGGL(k_hz_cs, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->seg, c->cs, N, c->dcnt);
-		if (n_ent) hipLaunchKernelGGL(k_rep_fill, dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, rp_seg, rp_r, rp_cm);
+		if (n_ent) hipLaunchKernelGGL(k_rep_fill, dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, rp);
 	} else if (n_ent) {
-		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_seg, n_ent, -1);
+		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(4 * n_ent)), dim3(BLOCK), 0, c->st, (int32_t *)rp, 4 * n_ent, -1);
 	}
 	return 0;
 }
@@ -1453,10 +1544,10 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt)
 {
 	int32_t *d_cnt = (int32_t *)c->pool.get(S_NLCNT, sizeof(int32_t) * (size_t)n + 16);
-	int32_t *rp_seg = (int32_t *)c->pool.get(S_RP_SEG, 0), *rp_r = (int32_t *)c->pool.get(S_RP_R, 0), *rp_cm = (int32_t *)c->pool.get(S_RP_CM, 0);
-	if (!d_cnt || !rp_seg || !rp_r || !rp_cm) return PGA_ERR_NOMEM;
+	int4 *rp = (int4 *)c->pool.get(S_RP_SEG, 0);
+	if (!d_cnt || !rp) return PGA_ERR_NOMEM;
 	*cnt = d_cnt;
-	if (n) hipLaunchKernelGGL(k_n_local, dim3(nblk(n, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, rp_seg, rp_r, rp_cm, local_dist, local_count, frag_mode, d_cnt);
+	if (n) hipLaunchKernelGGL(k_n_local, dim3(nblk(n, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, rp, local_dist, local_count, frag_mode, d_cnt);
 	return 0;
 }
 
@@ -1687,7 +1778,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 {
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
-		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
+		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
 		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get
 	};
 	return &b;

@@ -70,6 +70,29 @@ static int xreduce(const pga_backend_t *be, void *buf, int64_t count, int32_t dt
 	return g_xchg.allreduce(g_xchg.user, buf, count, dtype, op, be->is_device());
 }
 
+// all-gather of a variable-length array living in backend memory: every rank's n entries end up in backend
+// memory as W slots of *slot_entries entries (pointer *gathered), cnt[r] of them valid
+template <class T>
+static int xgather_raw(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int64_t n, std::vector<int64_t> &cnt, int64_t *slot_entries, T **gathered)
+{
+	const int W = g_xchg.world;
+	void *scr;
+	cnt.assign((size_t)W, 0);
+	BE_CALL(be->scratch(ctx, sizeof(int64_t) * (size_t)(W + 1), &scr), "scratch");
+	BE_CALL(be->put(ctx, scr, &n, sizeof(int64_t)), "put");
+	BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + sizeof(int64_t), sizeof(int64_t), be->is_device()), "allgather(count)");
+	BE_CALL(be->fetch(ctx, cnt.data(), (char *)scr + sizeof(int64_t), sizeof(int64_t) * (size_t)W), "fetch");
+	const int64_t mx = *std::max_element(cnt.begin(), cnt.end());
+	*slot_entries = mx, *gathered = nullptr;
+	if (mx == 0) return 0;
+	const size_t slot = (size_t)mx * sizeof(T);
+	BE_CALL(be->scratch(ctx, slot * (size_t)(W + 1), &scr), "scratch");
+	if (n) BE_CALL(be->copy(ctx, scr, local, (size_t)n * sizeof(T)), "copy");
+	BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + slot, (int64_t)slot, be->is_device()), "allgather(data)");
+	*gathered = (T *)((char *)scr + slot);
+	return 0;
+}
+
 // all-gather of a variable-length array living in backend memory -> host vector (rank order)
 template <class T>
 static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int64_t n, std::vector<T> &out)
@@ -436,17 +459,17 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	if (S) BE_CALL(be->fetch(ext->ctx, sc.data(), b_seg, sizeof(int32_t) * (size_t)S * 2), "fetch");
 	for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
 	std::vector<pga_arc_part_t> part;
-	BE_CALL(xgather(be, ext->ctx, b_arc, n_loc, part), "allgather(arcs)");
-	if (sharded()) { // reduce-by-key across shards; sums are integers, so order-independent
-		std::stable_sort(part.begin(), part.end(), [](const pga_arc_part_t &a, const pga_arc_part_t &b) { return a.x < b.x; });
-		size_t k = 0;
-		for (size_t i = 0; i < part.size(); ++i) {
-			if (k > 0 && part[k - 1].x == part[i].x) {
-				part[k - 1].n_genome += part[i].n_genome, part[k - 1].tot_cnt += part[i].tot_cnt;
-				part[k - 1].sum_dist += part[i].sum_dist, part[k - 1].sum_s1 += part[i].sum_s1, part[k - 1].sum_s2 += part[i].sum_s2;
-			} else part[k++] = part[i];
-		}
-		part.resize(k);
+	if (sharded()) { // all-gather the local tables (RCCL) and reduce by key on the backend; integer sums => order-independent
+		std::vector<int64_t> cnt;
+		int64_t slot = 0, n_mg = 0;
+		pga_arc_part_t *gathered = nullptr, *merged = nullptr;
+		BE_CALL(xgather_raw(be, ext->ctx, b_arc, n_loc, cnt, &slot, &gathered), "allgather(arcs)");
+		if (slot) BE_CALL(be->arc_merge(ext->ctx, gathered, cnt.data(), g_xchg.world, slot, &merged, &n_mg), "arc_merge");
+		part.resize((size_t)n_mg);
+		if (n_mg) BE_CALL(be->fetch(ext->ctx, part.data(), merged, sizeof(pga_arc_part_t) * (size_t)n_mg), "fetch");
+	} else {
+		part.resize((size_t)n_loc);
+		if (n_loc) BE_CALL(be->fetch(ext->ctx, part.data(), b_arc, sizeof(pga_arc_part_t) * (size_t)n_loc), "fetch");
 	}
 	if ((int64_t)part.size() > q->m_arc) {
 		q->m_arc = (int32_t)part.size() + ((int32_t)part.size() >> 1) + 16;
