@@ -562,14 +562,25 @@ __global__ __launch_bounds__(BLOCK) void k_vtx2(const uint32_t *flags, const int
                                                   const int32_t *prot_gid, const int32_t *ggl, int n, const uint32_t *dombits, int64_t words_per_genome,
                                                   uint64_t *triples, int64_t *dcnt)
 {
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	uint32_t f = flags[h];
-	if ((f & PGA_F_FLT) || rank[h] != 0 || !(f & PGA_F_SHADOW) || pdom[h] < 0) return;
-	int j = gnm[h], D = prot_gid[pdom[h]];
-	if (!(dombits[(int64_t)j * words_per_genome + (D >> 5)] >> (D & 31) & 1u)) return;
-	unsigned long long slot = atomicAdd((unsigned long long *)&dcnt[0], 1ull);
-	if (!COUNT_ONLY) triples[slot] = (uint64_t)ggl[j] << 40 | (uint64_t)gid[h] << 20 | (uint64_t)D;
+	const int h0 = blockIdx.x * BLOCK + threadIdx.x, h = h0 < n ? h0 : n - 1;
+	const uint32_t f = flags[h];
+	bool emit = h0 < n && !(f & PGA_F_FLT) && rank[h] == 0 && (f & PGA_F_SHADOW) && pdom[h] >= 0;
+	int j = 0, D = 0;
+	if (emit) {
+		j = gnm[h], D = prot_gid[pdom[h]];
+		emit = (dombits[(int64_t)j * words_per_genome + (D >> 5)] >> (D & 31) & 1u) != 0;
+	}
+	// one atomic per wave: the leader reserves a range, lanes fill it in lane order
+	const unsigned long long m = __ballot(emit);
+	if (m == 0) return;
+	const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+	unsigned long long base = 0;
+	if (lane == leader) base = atomicAdd((unsigned long long *)&dcnt[0], (unsigned long long)__popcll(m));
+	base = __shfl(base, leader, WAVE);
+	if (!COUNT_ONLY && emit) {
+		const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+		triples[base + __popcll(m & lt)] = (uint64_t)ggl[j] << 40 | (uint64_t)gid[h] << 20 | (uint64_t)D;
+	}
 }
 
 __global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32_t *gid, int n, const int32_t *g2s) // graph.c:61-69
@@ -583,6 +594,16 @@ __global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32
 // ------------------------------------------------------------------------------------------------
 // pg_gen_arc, per-genome part (graph.c:97-146)
 // ------------------------------------------------------------------------------------------------
+constexpr int SEGCNT_COPIES = 64;
+__global__ __launch_bounds__(BLOCK) void k_segcnt_sum(int32_t *seg_cnt, int n2s)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n2s) return;
+	int t = 0;
+	for (int k = 0; k < SEGCNT_COPIES; ++k) t += seg_cnt[(int64_t)k * n2s + i];
+	seg_cnt[i] = t;
+}
+
 // walkable = !flt && !shadow; val[y] = y if the y-th hit in cm order is walkable else -1
 __global__ __launch_bounds__(BLOCK) void k_walk_mark(const uint32_t *flags, const int32_t *yperm, int n, int32_t *val)
 {
@@ -607,9 +628,10 @@ __global__ __launch_bounds__(BLOCK) void k_arc_flag(const int32_t *val, const in
 		int a = yperm[y], sid = g2s[gid[a]];
 		if (sid < 0) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // graph.c:111
 		else {
-			atomicAdd(&seg_cnt[S + sid], 1);
+			int32_t *copy = seg_cnt + (int64_t)(blockIdx.x & (SEGCNT_COPIES - 1)) * 2 * S; // 64 copies: 64x less contention per address
+			atomicAdd(&copy[S + sid], 1);
 			uint32_t old = atomicOr(&seen[(int64_t)gnm[a] * words_per_genome + (sid >> 5)], 1u << (sid & 31));
-			if (!(old >> (sid & 31) & 1u)) atomicAdd(&seg_cnt[sid], 1);
+			if (!(old >> (sid & 31) & 1u)) atomicAdd(&copy[sid], 1);
 		}
 		int p = prev[y];
 		if (p >= 0) {
@@ -631,7 +653,7 @@ __device__ __forceinline__ int arc_score(int a, int ori, const int32_t *sori, co
 
 struct ArcEmit {
 	const int32_t *has, *slot, *prev, *yperm, *gid, *gnm, *cm, *sori, *sdom, *pdom0, *prot_gid, *g2s; const uint32_t *flags;
-	uint64_t *key; uint32_t *idx; int32_t *dist, *s1, *s2, *gen;
+	uint64_t *key; uint32_t *idx; int4 *pay; // payload {dist, s1, s2, genome}
 	int n, ori, vbits;
 };
 
@@ -647,18 +669,15 @@ __global__ __launch_bounds__(BLOCK) void k_arc_emit(ArcEmit e)
 	int d = e.cm[a] - e.cm[b], g = e.gnm[a];
 	int64_t o = (int64_t)e.slot[y] * 2;
 	e.key[o] = (uint64_t)v << e.vbits | w;           e.idx[o] = (uint32_t)o;         // v -> w      (graph.c:117)
-	e.dist[o] = d, e.s1[o] = sb, e.s2[o] = sa, e.gen[o] = g;
+	e.pay[o] = make_int4(d, sb, sa, g);
 	e.key[o + 1] = (uint64_t)(w ^ 1) << e.vbits | (v ^ 1); e.idx[o + 1] = (uint32_t)(o + 1); // w^1 -> v^1 (graph.c:119)
-	e.dist[o + 1] = d, e.s1[o + 1] = sa, e.s2[o + 1] = sb, e.gen[o + 1] = g;
+	e.pay[o + 1] = make_int4(d, sa, sb, g);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_arc_gather(const uint32_t *idx, int64_t m, const int32_t *dist, const int32_t *s1, const int32_t *s2, const int32_t *gen,
-                                                        int32_t *odist, int32_t *os1, int32_t *os2, int32_t *ogen)
+__global__ __launch_bounds__(BLOCK) void k_arc_gather(const uint32_t *idx, int64_t m, const int4 *pay, int4 *opay)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= m) return;
-	uint32_t s = idx[i];
-	odist[i] = dist[s], os1[i] = s1[s], os2[i] = s2[s], ogen[i] = gen[s];
+	if (i < m) opay[i] = pay[idx[i]]; // one random 16-byte read per temp arc
 }
 
 __global__ __launch_bounds__(BLOCK) void k_arc_head(const uint64_t *key, int64_t m, int32_t *head)
@@ -673,21 +692,24 @@ __global__ __launch_bounds__(BLOCK) void k_arc_head(const uint64_t *key, int64_t
 // level 1: the first element of every (key, genome) run collapses its run -- almost always a single element --
 //          into (n, rounded mean dist * n, max s1, max s2) stored at its own position; other positions hold zeros;
 // level 2: one wave per distinct key sums those records over the key's run with coalesced strided reads.
-__global__ __launch_bounds__(BLOCK) void k_arc_l1(const uint64_t *key, int64_t m, const int32_t *dist, const int32_t *s1, const int32_t *s2, const int32_t *gen,
-                                                    const int32_t *head, const int32_t *slot, int32_t *run_start, int32_t *o_n, uint64_t *o_dn, int32_t *o_s1, int32_t *o_s2)
+__global__ __launch_bounds__(BLOCK) void k_arc_l1(const uint64_t *key, int64_t m, const int4 *pay, const int32_t *head, const int32_t *slot, int32_t *run_start,
+                                                    int32_t *o_n, uint64_t *o_dn, int32_t *o_s1, int32_t *o_s2)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= m) return;
 	const uint64_t k = key[i];
-	const int g = gen[i];
+	const int4 p = pay[i];
+	const int g = p.w;
 	if (head[i]) run_start[slot[i]] = (int32_t)i;
-	if (i > 0 && key[i - 1] == k && gen[i - 1] == g) { o_n[i] = 0, o_dn[i] = 0, o_s1[i] = 0, o_s2[i] = 0; return; }
-	int n = 0, m1 = 0, m2 = 0;
-	uint64_t sd = 0;
-	for (int64_t j = i; j < m && key[j] == k && gen[j] == g; ++j) {
-		sd += (uint64_t)(int64_t)dist[j];
-		m1 = m1 > s1[j] ? m1 : s1[j];
-		m2 = m2 > s2[j] ? m2 : s2[j];
+	if (i > 0 && key[i - 1] == k && pay[i - 1].w == g) { o_n[i] = 0, o_dn[i] = 0, o_s1[i] = 0, o_s2[i] = 0; return; }
+	int n = 1, m1 = p.y, m2 = p.z;
+	uint64_t sd = (uint64_t)(int64_t)p.x;
+	for (int64_t j = i + 1; j < m && key[j] == k; ++j) { // almost always empty: one adjacency per (arc, genome)
+		const int4 q = pay[j];
+		if (q.w != g) break;
+		sd += (uint64_t)(int64_t)q.x;
+		m1 = m1 > q.y ? m1 : q.y;
+		m2 = m2 > q.z ? m2 : q.z;
 		++n;
 	}
 	const int dg = (int32_t)((double)sd / n + .499); // graph.c:141
@@ -952,9 +974,17 @@ __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, i
 	return (lo < n && ax[lo] == x) ? aw[lo] : 0;
 }
 
+// pg_get_arc as in the reference (pgpriv.h:99-107): scan the few arcs leaving v; vs/ve = arc range of each vertex
+__device__ __forceinline__ int arc_weak_v(const uint64_t *ax, const uint8_t *aw, const int32_t *vs, const int32_t *ve, uint32_t v, uint32_t w)
+{
+	for (int i = vs[v], e = ve[v]; i < e; ++i)
+		if ((uint32_t)ax[i] == w) return aw[i];
+	return 0;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_mark_hits(const int32_t *val, const int32_t *prev, const int32_t *yperm, const int32_t *seg, const int32_t *gid,
                                                        const uint32_t *flags, const int32_t *g2s, int n, const uint64_t *ax, const uint8_t *aw, int64_t n_arc,
-                                                       int32_t *weak_new)
+                                                       const int32_t *vs, const int32_t *ve, int32_t *weak_new)
 {
 	int y = blockIdx.x * BLOCK + threadIdx.x;
 	if (y >= n || val[y] < 0) return;
@@ -964,9 +994,9 @@ __global__ __launch_bounds__(BLOCK) void k_mark_hits(const int32_t *val, const i
 	if (seg[a] != seg[b]) return; // branch.c:124
 	uint32_t w = (uint32_t)g2s[gid[a]] << 1 | (flags[a] & PGA_F_REV ? 1u : 0u);
 	uint32_t v = (uint32_t)g2s[gid[b]] << 1 | (flags[b] & PGA_F_REV ? 1u : 0u);
-	int e1 = arc_weak(ax, aw, n_arc, (uint64_t)v << 32 | w);           // branch.c:128-130: marks the earlier hit
+	int e1 = vs ? arc_weak_v(ax, aw, vs, ve, v, w) : arc_weak(ax, aw, n_arc, (uint64_t)v << 32 | w);                       // branch.c:128-130: marks the earlier hit
 	if (e1) atomicMax(&weak_new[b], e1);
-	int e2 = arc_weak(ax, aw, n_arc, (uint64_t)(w ^ 1) << 32 | (v ^ 1)); // branch.c:131-133: marks this hit
+	int e2 = vs ? arc_weak_v(ax, aw, vs, ve, w ^ 1, v ^ 1) : arc_weak(ax, aw, n_arc, (uint64_t)(w ^ 1) << 32 | (v ^ 1)); // branch.c:131-133: marks this hit
 	if (e2) atomicMax(&weak_new[a], e2);
 }
 
@@ -1414,9 +1444,9 @@ static int walk_prev(pga_ctx *c, int32_t **val_out, int32_t **prev_out)
 extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int64_t *n_arcs_out)
 {
 	const int N = c->N, S = c->n_seg, GL = c->n_genome;
-	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, sizeof(int32_t) * 2 * (size_t)std::max(1, S));
+	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES);
 	if (!seg_cnt) return PGA_ERR_NOMEM;
-	HIPCHK(hipMemsetAsync(seg_cnt, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, S), c->st));
+	HIPCHK(hipMemsetAsync(seg_cnt, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES, c->st));
 	*seg_cnt_out = seg_cnt, *arcs_out = nullptr, *n_arcs_out = 0;
 	if (N == 0) return sync_st(c);
 	TRY(launch_sweep<0>(c, 2)); // graph.c:102
@@ -1429,6 +1459,7 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	if (!seen || !has || !slot) return PGA_ERR_NOMEM;
 	HIPCHK(hipMemsetAsync(seen, 0, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->st));
 	hipLaunchKernelGGL(k_arc_flag, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yperm, c->seg, c->gid, c->gnm, c->cm, c->g2s, N, S, has, seg_cnt, seen, wpg, c->dcnt);
+	if (S) hipLaunchKernelGGL(k_segcnt_sum, dim3(nblk(2 * S)), dim3(BLOCK), 0, c->st, seg_cnt, 2 * S);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{has}, OutExclI32{slot}, N, tile, OpSum{}, I32{0}, c->st);
 	// number of adjacencies = slot[N-1] + has[N-1]
@@ -1439,17 +1470,14 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	const int vbits = bits_for((uint32_t)(2 * std::max(1, S)));
 	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, sizeof(uint64_t) * (size_t)M);
 	uint32_t *idx = (uint32_t *)c->pool.get(S_VAL_A, sizeof(uint32_t) * (size_t)M);
-	int32_t *tdist = (int32_t *)c->pool.get(S_TDIST, sizeof(int32_t) * (size_t)M), *ts1 = (int32_t *)c->pool.get(S_TS1, sizeof(int32_t) * (size_t)M);
-	int32_t *ts2 = (int32_t *)c->pool.get(S_TS2, sizeof(int32_t) * (size_t)M), *tgen = (int32_t *)c->pool.get(S_TGEN, sizeof(int32_t) * (size_t)M);
-	int32_t *sdist = (int32_t *)c->pool.get(S_SDIST, sizeof(int32_t) * (size_t)M), *ss1 = (int32_t *)c->pool.get(S_SS1, sizeof(int32_t) * (size_t)M);
-	int32_t *ss2 = (int32_t *)c->pool.get(S_SS2, sizeof(int32_t) * (size_t)M), *sgen = (int32_t *)c->pool.get(S_SGEN, sizeof(int32_t) * (size_t)M);
+	int4 *tpay = (int4 *)c->pool.get(S_TDIST, sizeof(int4) * (size_t)M), *spay = (int4 *)c->pool.get(S_SDIST, sizeof(int4) * (size_t)M);
 	int32_t *head = (int32_t *)c->pool.get(S_HEAD, sizeof(int32_t) * (size_t)M);
-	if (!key || !idx || !tdist || !ts1 || !ts2 || !tgen || !sdist || !ss1 || !ss2 || !sgen || !head) return PGA_ERR_NOMEM;
-	ArcEmit e = { has, slot, prev, c->yperm, c->gid, c->gnm, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->g2s, c->flags, key, idx, tdist, ts1, ts2, tgen, N, use_ori, vbits };
+	if (!key || !idx || !tpay || !spay || !head) return PGA_ERR_NOMEM;
+	ArcEmit e = { has, slot, prev, c->yperm, c->gid, c->gnm, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->g2s, c->flags, key, idx, tpay, N, use_ori, vbits };
 	hipLaunchKernelGGL(k_arc_emit, dim3(nblk(N)), dim3(BLOCK), 0, c->st, e);
 	uint64_t *ks; uint32_t *vs;
 	TRY(radix_sort_pool(c, key, idx, M, 2 * vbits, &ks, &vs)); // graph.c:127 and :151 in one stable sort
-	hipLaunchKernelGGL(k_arc_gather, dim3(nblk(M)), dim3(BLOCK), 0, c->st, vs, M, tdist, ts1, ts2, tgen, sdist, ss1, ss2, sgen);
+	hipLaunchKernelGGL(k_arc_gather, dim3(nblk(M)), dim3(BLOCK), 0, c->st, vs, M, tpay, spay);
 	hipLaunchKernelGGL(k_arc_head, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, M, head);
 	tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{head}, OutExclI32{slot}, M, tile, OpSum{}, I32{0}, c->st);
@@ -1461,10 +1489,10 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	if (!arcs) return PGA_ERR_NOMEM;
 	{
 		int32_t *run_start = (int32_t *)c->pool.get(S_RUNSTART, sizeof(int32_t) * (size_t)A + 16);
-		int32_t *c_n = tdist, *c_s1 = ts1, *c_s2 = ts2; // the unsorted payload arrays are free again: reuse them
+		int32_t *c_n = (int32_t *)tpay, *c_s1 = c_n + (size_t)M, *c_s2 = c_n + 2 * (size_t)M; // the unsorted payload is free again: reuse it
 		uint64_t *c_dn = (uint64_t *)c->pool.get(S_CDN, sizeof(uint64_t) * (size_t)M);
 		if (!run_start || !c_dn) return PGA_ERR_NOMEM;
-		hipLaunchKernelGGL(k_arc_l1, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, M, sdist, ss1, ss2, sgen, head, slot, run_start, c_n, c_dn, c_s1, c_s2);
+		hipLaunchKernelGGL(k_arc_l1, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, M, spay, head, slot, run_start, c_n, c_dn, c_s1, c_s2);
 		hipLaunchKernelGGL(k_arc_l2, dim3(nblk(A, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, ks, M, A, run_start, c_n, c_dn, c_s1, c_s2, vbits, arcs);
 	}
 	*arcs_out = arcs, *n_arcs_out = A;
@@ -1636,7 +1664,8 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 	HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
 	int32_t *val, *prev;
 	TRY(walk_prev(c, &val, &prev));
-	hipLaunchKernelGGL(k_mark_hits, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yperm, c->seg, c->gid, c->flags, c->g2s, N, ax, aw, n_arc, wn);
+	const int32_t *vs = arc_x ? nullptr : (const int32_t *)c->pool.get(S_BR_VS, 0), *ve = arc_x ? nullptr : (const int32_t *)c->pool.get(S_BR_VE, 0);
+	hipLaunchKernelGGL(k_mark_hits, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yperm, c->seg, c->gid, c->flags, c->g2s, N, ax, aw, n_arc, vs, ve, wn);
 	hipLaunchKernelGGL(k_weak_merge, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, wn, N, n_marked ? c->dcnt + 2 : (int64_t *)nullptr);
 	if (n_marked) {
 		HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
