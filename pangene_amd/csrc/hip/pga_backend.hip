@@ -285,11 +285,56 @@ __device__ __forceinline__ int cds_inter(const int2 *__restrict__ ex, int oa, in
 
 // The interval-dominance sweep, LDS-staged.  A workgroup owns SW_TILE consecutive hits (cs order) and stages
 // their records plus SW_HALO neighbours on each side in LDS (52 B/hit, coalesced 16-byte loads); every thread
-// then walks its partners in both directions out of LDS and only falls back to global memory for partners
-// beyond the halo (hits spanning more than SW_HALO others).  Pairs are symmetric, so each hit derives its own
-// shadow flag and dominator without atomics.
+// then walks its partners in both directions out of LDS and only continues in global memory for partners
+// beyond the halo (hits spanning more than SW_HALO others).  The LDS and the global walks are separate loops on
+// purpose: a per-access "LDS or global" select makes the compiler emit flat loads, which are far slower than
+// ds_read.  Pairs are symmetric, so each hit derives its own shadow flag and dominator without atomics.
 // MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform
-constexpr int SW_TILE = 256, SW_HALO = 64, SW_LDS = SW_TILE + 2 * SW_HALO;
+constexpr int SW_TILE = 512, SW_HALO = 32, SW_LDS = SW_TILE + 2 * SW_HALO;
+
+struct SwHit { // the hit a thread works for
+	int sg, cs, ce, gid, cds, rank, nex, offx, weak; uint32_t fl; uint64_t sc;
+};
+struct SwBest { bool lose; uint64_t best; int j, ov, pid, cds; };
+
+// one partner p (record a/b/c, flags fp, array index pi) of hit t; EARLIER: p precedes t in the array.
+// overlap.c:126-154 (pg_shadow) / 76-87 (pg_flt_ov_isoform)
+template <int MODE, bool EARLIER>
+__device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBest &r, const int4 a, const uint32_t fp, const int4 b, const int4 c, int pi)
+{
+	if (fp & PGA_F_FLT) return;
+	if (v.check_strand && ((fp ^ t.fl) & PGA_F_REV)) return;
+	if (MODE == 2 && b.z != t.gid) return;
+	const int x = EARLIER ? cds_inter(v.exon, c.z, c.y, a.y, a.z, t.offx, t.nex, t.cs, t.ce)
+	                      : cds_inter(v.exon, t.offx, t.nex, t.cs, t.ce, c.z, c.y, a.y, a.z);
+	if (x == 0) return; // overlap.c:132
+	const uint64_t sp = (uint64_t)(uint32_t)b.x | (uint64_t)(uint32_t)b.y << 32;
+	// "i" of the reference is the later hit of the pair: i loses if (si < sj || (si == sj && rank_i > rank_j))
+	const uint64_t s_i = EARLIER ? t.sc : sp, s_j = EARLIER ? sp : t.sc;
+	const int rk_i = EARLIER ? t.rank : c.x, rk_j = EARLIER ? c.x : t.rank;
+	bool i_loses = s_i < s_j || (s_i == s_j && rk_i > rk_j);
+	if (MODE != 2 && b.z != t.gid) {
+		const int m = t.cds < b.w ? t.cds : b.w;
+		// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < m: x/m is within
+		// 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
+		const bool too_short = v.min_ov == 0.5 ? 2 * (int64_t)x < (int64_t)m : (double)x / m < v.min_ov;
+		if (too_short) return;
+		const int wk_p = (int)((fp & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
+		const int wk_i = EARLIER ? t.weak : wk_p, wk_j = EARLIER ? wk_p : t.weak;
+		if (wk_i != wk_j) i_loses = wk_i > wk_j; // overlap.c:141-147
+	}
+	const bool t_loses = EARLIER ? i_loses : !i_loses;
+	if (!t_loses) return;
+	r.lose = true;
+	if (MODE == 2) return;
+	// dominator = best-scoring winner, first in array order on ties (overlap.c:150,153).  Earlier partners are visited in
+	// DEscending index order, so an equal score replaces; later partners in ascending order, so it does not.
+	if (EARLIER ? (sp > 0 && sp >= r.best) : (sp > r.best)) {
+		if (EARLIER && sp == r.best) atomicAdd((unsigned long long *)&v.hz[3], 1ull);
+		r.best = sp, r.j = pi, r.ov = x, r.pid = c.w, r.cds = b.w;
+	} else if (!EARLIER && sp == r.best && sp > 0) atomicAdd((unsigned long long *)&v.hz[3], 1ull);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 {
@@ -307,88 +352,60 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 	const int lh = threadIdx.x + SW_HALO;
 	const uint32_t fl = sF[lh];
 	if (fl & PGA_F_FLT) return; // filtered hits keep stale shadow/pid_dom (overlap.c:112)
-	const int4 a_h = sA[lh], b_h = sB[lh], c_h = sC[lh];
-	const int sg = a_h.x, cs_h = a_h.y, ce_h = a_h.z, g_h = b_h.z, ln_h = b_h.w, rk_h = c_h.x, ne_h = c_h.y, ox_h = c_h.z;
-	const int wk_h = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
-	const uint64_t s_h = (uint64_t)(uint32_t)b_h.x | (uint64_t)(uint32_t)b_h.y << 32;
-	bool lose = false;
-	uint64_t best = 0;
-	int best_j = -1, best_ov = 0, best_pid = -1, best_cds = 0;
-	// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so
-	// the scan stops at the first j whose pm is <= cs_h.
-	for (int j = h - 1; j >= 0; --j) {
-		const int lj = j - base;
-		const int4 a_j = lj >= 0 ? sA[lj] : v.A[j];
-		if (a_j.x != sg || a_j.w <= cs_h) break;
-		if (a_j.z <= cs_h) continue;
-		const uint32_t fj = lj >= 0 ? sF[lj] : v.flags[j];
-		if (fj & PGA_F_FLT) continue;
-		if (v.check_strand && ((fj ^ fl) & PGA_F_REV)) continue;
-		const int4 b_j = lj >= 0 ? sB[lj] : v.B[j];
-		if (MODE == 2 && b_j.z != g_h) continue;
-		const int4 c_j = lj >= 0 ? sC[lj] : v.C[j];
-		const int x = cds_inter(v.exon, c_j.z, c_j.y, a_j.y, a_j.z, ox_h, ne_h, cs_h, ce_h);
-		if (x == 0) continue;
-		const uint64_t s_j = (uint64_t)(uint32_t)b_j.x | (uint64_t)(uint32_t)b_j.y << 32;
-		bool h_loses; // h plays "i" of the reference (the later hit)
-		if (MODE == 2) h_loses = s_h < s_j || (s_h == s_j && rk_h > c_j.x);
-		else {
-			const double cov = (double)x / (ln_h < b_j.w ? ln_h : b_j.w);
-			if (g_h != b_j.z && cov < v.min_ov) continue;
-			const int wk_j = (int)((fj & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
-			if (g_h == b_j.z || wk_h == wk_j) h_loses = s_h < s_j || (s_h == s_j && rk_h > c_j.x);
-			else h_loses = wk_h > wk_j;
+	SwHit t;
+	{
+		const int4 a = sA[lh], b = sB[lh], c = sC[lh];
+		t.sg = a.x, t.cs = a.y, t.ce = a.z, t.gid = b.z, t.cds = b.w, t.rank = c.x, t.nex = c.y, t.offx = c.z;
+		t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
+		t.sc = (uint64_t)(uint32_t)b.x | (uint64_t)(uint32_t)b.y << 32;
+	}
+	SwBest r = { false, 0, -1, 0, -1, 0 };
+	// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so the
+	// walk stops at the first j whose pm is <= cs_h.
+	{
+		int l = lh - 1;
+		bool open = true;
+		for (; l >= 0; --l) { // LDS part
+			const int4 a = sA[l];
+			if (a.x != t.sg || a.w <= t.cs) { open = false; break; }
+			if (a.z > t.cs) sw_pair<MODE, true>(v, t, r, a, sF[l], sB[l], sC[l], base + l);
 		}
-		if (h_loses) {
-			lose = true;
-			if (MODE != 2 && s_j > 0 && s_j >= best) { // descending j: on equal score the smaller index wins (overlap.c:150)
-				if (s_j == best) atomicAdd((unsigned long long *)&v.hz[3], 1ull);
-				best = s_j, best_j = j, best_ov = x, best_pid = c_j.w, best_cds = b_j.w;
+		if (open)
+			for (int j = base - 1; j >= 0; --j) { // beyond the halo: global memory
+				const int4 a = v.A[j];
+				if (a.x != t.sg || a.w <= t.cs) break;
+				if (a.z > t.cs) sw_pair<MODE, true>(v, t, r, a, v.flags[j], v.B[j], v.C[j], j);
 			}
-		}
 	}
 	// partners after h: every i with cs_i < ce_h
-	for (int i = h + 1; i < v.n; ++i) {
-		const int li = i - base;
-		const int4 a_i = li < SW_LDS ? sA[li] : v.A[i];
-		if (a_i.x != sg || a_i.y >= ce_h) break;
-		const uint32_t fi = li < SW_LDS ? sF[li] : v.flags[i];
-		if (fi & PGA_F_FLT) continue;
-		if (v.check_strand && ((fi ^ fl) & PGA_F_REV)) continue;
-		const int4 b_i = li < SW_LDS ? sB[li] : v.B[i];
-		if (MODE == 2 && b_i.z != g_h) continue;
-		const int4 c_i = li < SW_LDS ? sC[li] : v.C[i];
-		const int x = cds_inter(v.exon, ox_h, ne_h, cs_h, ce_h, c_i.z, c_i.y, a_i.y, a_i.z);
-		if (x == 0) continue;
-		const uint64_t s_i = (uint64_t)(uint32_t)b_i.x | (uint64_t)(uint32_t)b_i.y << 32;
-		bool i_loses; // h plays "j" (the earlier hit)
-		if (MODE == 2) i_loses = s_i < s_h || (s_i == s_h && c_i.x > rk_h);
-		else {
-			const double cov = (double)x / (b_i.w < ln_h ? b_i.w : ln_h);
-			if (g_h != b_i.z && cov < v.min_ov) continue;
-			const int wk_i = (int)((fi & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
-			if (g_h == b_i.z || wk_h == wk_i) i_loses = s_i < s_h || (s_i == s_h && c_i.x > rk_h);
-			else i_loses = wk_i > wk_h;
+	{
+		int l = lh + 1;
+		bool open = true;
+		for (; l < SW_LDS; ++l) {
+			const int4 a = sA[l];
+			if (a.x != t.sg || a.y >= t.ce) { open = false; break; }
+			sw_pair<MODE, false>(v, t, r, a, sF[l], sB[l], sC[l], base + l);
 		}
-		if (!i_loses) {
-			lose = true;
-			if (MODE != 2 && s_i > best) best = s_i, best_j = i, best_ov = x, best_pid = c_i.w, best_cds = b_i.w;
-			else if (MODE != 2 && s_i == best && s_i > 0) atomicAdd((unsigned long long *)&v.hz[3], 1ull);
-		}
+		if (open)
+			for (int i = base + SW_LDS; i < v.n; ++i) {
+				const int4 a = v.A[i];
+				if (a.x != t.sg || a.y >= t.ce) break;
+				sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i);
+			}
 	}
 	if (MODE == 2) {
-		if (lose) v.flags[h] = fl | PGA_F_ISO_OV;
+		if (r.lose) v.flags[h] = fl | PGA_F_ISO_OV;
 		return;
 	}
 	// epilogue, overlap.c:157-175.  The hit at index 0 of a genome is never reset (loop starts at 1, overlap.c:108).
 	uint32_t nf = (fl & F_HEAD) ? fl : (fl & ~PGA_F_SHADOW);
-	if (lose) nf |= PGA_F_SHADOW;
+	if (r.lose) nf |= PGA_F_SHADOW;
 	if (nf != fl) v.flags[h] = nf;
-	v.pdom[h] = best > 0 ? best_pid : -1;
+	v.pdom[h] = r.best > 0 ? r.pid : -1;
 	if (MODE == 1) {
 		int sd = -1;
-		if (best > 0)
-			sd = (int32_t)(v.sori[h] * (1.0 - (double)best_ov / ln_h) + v.sori[best_j] * ((double)best_ov / best_cds) + .499); // overlap.c:170
+		if (r.best > 0)
+			sd = (int32_t)(v.sori[h] * (1.0 - (double)r.ov / t.cds) + v.sori[r.j] * ((double)r.ov / r.cds) + .499); // overlap.c:170
 		v.sdom[h] = sd;
 	}
 }
