@@ -365,10 +365,12 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 	{
 		int l = lh - 1;
 		bool open = true;
-		for (; l >= 0; --l) { // LDS part
-			const int4 a = sA[l];
+		for (; l >= 0; --l) { // LDS part; the four reads are issued together (one wait per partner instead of four)
+			const int4 a = sA[l], b = sB[l], c = sC[l];
+			const uint32_t f = sF[l];
+			asm volatile("" :: "v"(b.x), "v"(c.x), "v"(f)); // keep the loads at the loop head
 			if (a.x != t.sg || a.w <= t.cs) { open = false; break; }
-			if (a.z > t.cs) sw_pair<MODE, true>(v, t, r, a, sF[l], sB[l], sC[l], base + l);
+			if (a.z > t.cs) sw_pair<MODE, true>(v, t, r, a, f, b, c, base + l);
 		}
 		if (open)
 			for (int j = base - 1; j >= 0; --j) { // beyond the halo: global memory
@@ -382,9 +384,11 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 		int l = lh + 1;
 		bool open = true;
 		for (; l < SW_LDS; ++l) {
-			const int4 a = sA[l];
+			const int4 a = sA[l], b = sB[l], c = sC[l];
+			const uint32_t f = sF[l];
+			asm volatile("" :: "v"(b.x), "v"(c.x), "v"(f));
 			if (a.x != t.sg || a.y >= t.ce) { open = false; break; }
-			sw_pair<MODE, false>(v, t, r, a, sF[l], sB[l], sC[l], base + l);
+			sw_pair<MODE, false>(v, t, r, a, f, b, c, base + l);
 		}
 		if (open)
 			for (int i = base + SW_LDS; i < v.n; ++i) {
