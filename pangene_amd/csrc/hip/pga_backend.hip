@@ -298,41 +298,51 @@ struct SwHit { // the hit a thread works for
 struct SwBest { bool lose; uint64_t best; int j, ov, pid, cds; };
 
 // one partner p (record a/b/c, flags fp, array index pi) of hit t; EARLIER: p precedes t in the array.
-// overlap.c:126-154 (pg_shadow) / 76-87 (pg_flt_ov_isoform)
+// overlap.c:126-154 (pg_shadow) / 76-87 (pg_flt_ov_isoform).  Written with predicates and selects instead of early
+// returns: every divergent branch costs several scalar instructions (exec save/restore) and the CU has ONE scalar
+// unit for its four SIMDs -- the first version of this kernel was scalar-issue bound (profiles/r01_pmc_*).
 template <int MODE, bool EARLIER>
-__device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBest &r, const int4 a, const uint32_t fp, const int4 b, const int4 c, int pi)
+__device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBest &r, const int4 a, const uint32_t fp, const int4 b, const int4 c, int pi, bool ok)
 {
-	if (fp & PGA_F_FLT) return;
-	if (v.check_strand && ((fp ^ t.fl) & PGA_F_REV)) return;
-	if (MODE == 2 && b.z != t.gid) return;
-	const int x = EARLIER ? cds_inter(v.exon, c.z, c.y, a.y, a.z, t.offx, t.nex, t.cs, t.ce)
-	                      : cds_inter(v.exon, t.offx, t.nex, t.cs, t.ce, c.z, c.y, a.y, a.z);
-	if (x == 0) return; // overlap.c:132
+	ok = ok && !(fp & PGA_F_FLT);
+	if (v.check_strand) ok = ok && !((fp ^ t.fl) & PGA_F_REV); // uniform condition: scalar branch
+	const bool same_gene = b.z == t.gid;
+	if (MODE == 2) ok = ok && same_gene;
+	int x;
+	if (__ballot(ok && (c.y != 1 || t.nex != 1)) == 0) { // whole wave single-exon x single-exon: interval intersection
+		const int s0 = a.y > t.cs ? a.y : t.cs, e0 = a.z < t.ce ? a.z : t.ce;
+		x = e0 > s0 ? e0 - s0 : 0;
+	} else {
+		x = !ok ? 0 : EARLIER ? cds_inter(v.exon, c.z, c.y, a.y, a.z, t.offx, t.nex, t.cs, t.ce)
+		                      : cds_inter(v.exon, t.offx, t.nex, t.cs, t.ce, c.z, c.y, a.y, a.z);
+	}
+	ok = ok && x > 0; // overlap.c:132
 	const uint64_t sp = (uint64_t)(uint32_t)b.x | (uint64_t)(uint32_t)b.y << 32;
 	// "i" of the reference is the later hit of the pair: i loses if (si < sj || (si == sj && rank_i > rank_j))
 	const uint64_t s_i = EARLIER ? t.sc : sp, s_j = EARLIER ? sp : t.sc;
 	const int rk_i = EARLIER ? t.rank : c.x, rk_j = EARLIER ? c.x : t.rank;
 	bool i_loses = s_i < s_j || (s_i == s_j && rk_i > rk_j);
-	if (MODE != 2 && b.z != t.gid) {
+	if (MODE != 2) {
 		const int m = t.cds < b.w ? t.cds : b.w;
 		// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < m: x/m is within
 		// 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
-		const bool too_short = v.min_ov == 0.5 ? 2 * (int64_t)x < (int64_t)m : (double)x / m < v.min_ov;
-		if (too_short) return;
+		bool too_short;
+		if (v.min_ov == 0.5) too_short = 2 * (int64_t)x < (int64_t)m;
+		else too_short = (double)x / (m > 0 ? m : 1) < v.min_ov;
+		ok = ok && (same_gene || !too_short);
 		const int wk_p = (int)((fp & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
 		const int wk_i = EARLIER ? t.weak : wk_p, wk_j = EARLIER ? wk_p : t.weak;
-		if (wk_i != wk_j) i_loses = wk_i > wk_j; // overlap.c:141-147
+		i_loses = (!same_gene && wk_i != wk_j) ? wk_i > wk_j : i_loses; // overlap.c:139-147
 	}
-	const bool t_loses = EARLIER ? i_loses : !i_loses;
-	if (!t_loses) return;
-	r.lose = true;
+	const bool t_loses = ok && (EARLIER ? i_loses : !i_loses);
+	r.lose = r.lose || t_loses;
 	if (MODE == 2) return;
 	// dominator = best-scoring winner, first in array order on ties (overlap.c:150,153).  Earlier partners are visited in
 	// DEscending index order, so an equal score replaces; later partners in ascending order, so it does not.
-	if (EARLIER ? (sp > 0 && sp >= r.best) : (sp > r.best)) {
-		if (EARLIER && sp == r.best) atomicAdd((unsigned long long *)&v.hz[3], 1ull);
-		r.best = sp, r.j = pi, r.ov = x, r.pid = c.w, r.cds = b.w;
-	} else if (!EARLIER && sp == r.best && sp > 0) atomicAdd((unsigned long long *)&v.hz[3], 1ull);
+	const bool upd = t_loses && (EARLIER ? (sp > 0 && sp >= r.best) : (sp > r.best));
+	const bool tie = t_loses && sp == r.best && sp > 0;
+	if (__ballot(tie)) { if (tie) atomicAdd((unsigned long long *)&v.hz[3], 1ull); } // hazard H3, rare
+	r.best = upd ? sp : r.best, r.j = upd ? pi : r.j, r.ov = upd ? x : r.ov, r.pid = upd ? c.w : r.pid, r.cds = upd ? b.w : r.cds;
 }
 
 template <int MODE>
@@ -370,13 +380,13 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 			const uint32_t f = sF[l];
 			asm volatile("" :: "v"(b.x), "v"(c.x), "v"(f)); // keep the loads at the loop head
 			if (a.x != t.sg || a.w <= t.cs) { open = false; break; }
-			if (a.z > t.cs) sw_pair<MODE, true>(v, t, r, a, f, b, c, base + l);
+			sw_pair<MODE, true>(v, t, r, a, f, b, c, base + l, a.z > t.cs);
 		}
 		if (open)
 			for (int j = base - 1; j >= 0; --j) { // beyond the halo: global memory
 				const int4 a = v.A[j];
 				if (a.x != t.sg || a.w <= t.cs) break;
-				if (a.z > t.cs) sw_pair<MODE, true>(v, t, r, a, v.flags[j], v.B[j], v.C[j], j);
+				sw_pair<MODE, true>(v, t, r, a, v.flags[j], v.B[j], v.C[j], j, a.z > t.cs);
 			}
 	}
 	// partners after h: every i with cs_i < ce_h
@@ -388,13 +398,13 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 			const uint32_t f = sF[l];
 			asm volatile("" :: "v"(b.x), "v"(c.x), "v"(f));
 			if (a.x != t.sg || a.y >= t.ce) { open = false; break; }
-			sw_pair<MODE, false>(v, t, r, a, f, b, c, base + l);
+			sw_pair<MODE, false>(v, t, r, a, f, b, c, base + l, true);
 		}
 		if (open)
 			for (int i = base + SW_LDS; i < v.n; ++i) {
 				const int4 a = v.A[i];
 				if (a.x != t.sg || a.y >= t.ce) break;
-				sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i);
+				sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i, true);
 			}
 	}
 	if (MODE == 2) {
