@@ -162,7 +162,10 @@ def main():
     ms, nl, units = C.c_double(), C.c_int64(), C.c_int64()
     lib.pg_kernel_timing(d, 0, C.byref(ms), C.byref(nl), C.byref(units))
     E = 1.0  # exons per hit of the bacterial shape
-    bytes_per_hit = 72 + 8 * E  # SURVEY.md 8(d), B_K1
+    # algorithmic bytes of THIS kernel (the stage-A sweep, not the whole of stage A): SURVEY.md 8(d) gives 56 + 8E B/hit for a
+    # pg_shadow sweep (reads cs ce cid pid gid score_adj rank flags n/off_exon + exons, writes flags pid_dom); the
+    # cal_dom_sc=1 flavour also reads score_ori and writes score_dom => 64 + 8E
+    bytes_per_hit = 64 + 8 * E
     roof = None
     if nl.value:
         avg_ms = ms.value / nl.value
