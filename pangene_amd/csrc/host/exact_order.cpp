@@ -24,9 +24,13 @@
 namespace pgx {
 
 static int g_exact_mode = -1; // -1: read the environment
+static int g_exact_override = -1; // set while a run is being repeated with every contig tracked (hazard escalation)
+
+void exact_override(int m) { g_exact_override = m; }
 
 int exact_mode()
 {
+	if (g_exact_override >= 0) return g_exact_override;
 	if (g_exact_mode < 0) {
 		const char *e = std::getenv("PANGENE_EXACT");
 		g_exact_mode = (e == nullptr || std::strcmp(e, "auto") == 0) ? 1 : std::strcmp(e, "all") == 0 ? 2 : std::strcmp(e, "off") == 0 ? 0 : 1;
@@ -49,6 +53,13 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 		for (int32_t c = 0; c < g->n_ctg; ++c) cnt[(size_t)c + 1] += cnt[(size_t)c];
 		int32_t c0 = 0;
 		while (c0 < g->n_ctg && cnt[(size_t)c0 + 1] == cnt[(size_t)c0]) ++c0;
+		// host index of every hit in FILE order (the host array is in cs order once a sync has happened)
+		const int32_t j = ext->local_genomes[k];
+		std::vector<int32_t> host_of_file((size_t)g->n_hit);
+		if ((size_t)j < ext->hits_sorted.size() && ext->hits_sorted[(size_t)j])
+			for (int32_t h = 0; h < g->n_hit; ++h) host_of_file[(size_t)ext->file_of_host[(size_t)j][(size_t)h]] = h;
+		else
+			for (int32_t h = 0; h < g->n_hit; ++h) host_of_file[(size_t)h] = h;
 		for (int32_t c = c0; c < g->n_ctg; ++c) {
 			const int32_t n = cnt[(size_t)c + 1] - cnt[(size_t)c];
 			if (n < 2) { if (mode == 1) break; else continue; }
@@ -57,7 +68,7 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 			s.file.reserve((size_t)n);
 			int64_t min_cs = INT64_MAX; int32_t n_min = 0;
 			for (int32_t i = 0; i < g->n_hit; ++i) {
-				const pg_hit_t *a = &g->hit[i];
+				const pg_hit_t *a = &g->hit[host_of_file[(size_t)i]];
 				if (a->cid != c) continue;
 				s.file.push_back(i), s.cs.push_back((uint64_t)a->cs), s.cm.push_back((uint64_t)a->cm);
 				if (a->cs < min_cs) min_cs = a->cs, n_min = 1; else if (a->cs == min_cs) ++n_min;

@@ -268,6 +268,11 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 	if (!(ext->rerun && ext->ctx)) {
 		BE_CALL(build_backend(opt, d, ext), "create"); // pack + H2D, outside the timed path
 		exact_init(d, ext);
+		ext->exact_mode_of_segs = exact_mode();
+	} else if (ext->exact_mode_of_segs != exact_mode()) {
+		exact_shutdown(ext);
+		exact_init(d, ext);
+		ext->exact_mode_of_segs = exact_mode();
 	}
 	ext->rerun = false;
 	g_upload_sec = now_sec() - t0;
@@ -411,14 +416,17 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	}
 	ksort_exact(cnt.data(), cnt.size(), [](const pg128_t &a) { return a.x; }); // vertex.c:59, tie order matters
 	q->n_seg = 0;
-	FILE *fp = out_stream();
+	ext->vtx_sel_text.clear();
 	for (int32_t i = Q - 1; i >= 0; --i) { // vertex.c:60-80
 		const int32_t n_dom = (int32_t)(cnt[(size_t)i].x << 1 >> 33), n_sub = (int32_t)(cnt[(size_t)i].y >> 32);
 		const int32_t gid = (int32_t)cnt[(size_t)i].y;
 		const int32_t x = cntv[(size_t)gid], y = ycnt[(size_t)gid];
-		if (opt->flag & PG_F_WRITE_VTX_SEL)
-			std::fprintf(fp, "g\t%s\t%d\t%d\t%d\t%d\t%c\t%c\n", d->gene[gid].name, (int32_t)cnt[(size_t)i].x, x, y, n_sub,
-			             "NY"[d->gene[gid].included], "NY"[d->gene[gid].preferred]);
+		if (opt->flag & PG_F_WRITE_VTX_SEL) { // -G (vertex.c:66-67); buffered: a hazard escalation repeats the run
+			char line[512];
+			std::snprintf(line, sizeof(line), "g\t%s\t%d\t%d\t%d\t%d\t%c\t%c\n", d->gene[gid].name, (int32_t)cnt[(size_t)i].x, x, y, n_sub,
+			              "NY"[d->gene[gid].included], "NY"[d->gene[gid].preferred]);
+			ext->vtx_sel_text += line;
+		}
 		if (d->gene[gid].included || (n_dom >= G * opt->min_vertex_ratio && y < x)) {
 			if (q->n_seg >= q->m_seg) {
 				int32_t old = q->m_seg;
@@ -612,7 +620,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	BE_CALL(exact_sort(ext, 1), "override_order"); // the cm order pg_write_walk will see (format.c:190)
 	ext->host_stale = true;
 	pga_hazard_t hz;
-	if (be->hazards(ctx, &hz) == 0 && (hz.h1_head_tie | hz.h2_cm_tie | hz.h3_dom_tie) && pg_verbose >= 2)
+	if (exact_mode() == 0 && be->hazards(ctx, &hz) == 0 && (hz.h1_head_tie | hz.h2_cm_tie | hz.h3_dom_tie) && pg_verbose >= 2)
 		std::fprintf(stderr, "[W::%s] tie-order hazards seen (head-tie %ld, cm-tie %ld, dominator-tie %ld): output may differ from the reference's unstable sort order\n",
 		             "pg_graph_gen", (long)hz.h1_head_tie, (long)hz.h2_cm_tie, (long)hz.h3_dom_tie);
 	return sync_host(q->d, false);
@@ -658,10 +666,50 @@ pg_graph_t *pg_graph_init(pg_data_t *d) // graph.c:34-41
 	return g;
 }
 
+// Did a tie-order channel other than array index 0 open during the run (two walkable hits sharing
+// (contig, cm); two equal-score dominators)?  Collective: every rank gets the same answer.
+static int hazards_seen(DataExt *ext, bool *seen)
+{
+	pga_hazard_t hz;
+	BE_CALL(ext->be->hazards(ext->ctx, &hz), "hazards");
+	int64_t n = hz.h2_cm_tie + hz.h3_dom_tie;
+	if (sharded()) {
+		void *scr;
+		int32_t v = n > 0;
+		BE_CALL(ext->be->scratch(ext->ctx, 16, &scr), "scratch");
+		BE_CALL(ext->be->put(ext->ctx, scr, &v, sizeof(v)), "put");
+		BE_CALL(xreduce(ext->be, scr, 1, PG_X_I32, PG_X_MAX), "allreduce(hazard)");
+		BE_CALL(ext->be->fetch(ext->ctx, &v, scr, sizeof(v)), "fetch");
+		n = v;
+	}
+	*seen = n > 0;
+	return 0;
+}
+
 void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 {
 	double t = now_sec();
 	if (g_err == 0 && graph_gen_impl(opt, q) != 0) q->n_arc = 0;
+	DataExt *ext = ext_of(q->d, false);
+	bool seen = false;
+	if (g_err == 0 && ext && exact_mode() == 1 && hazards_seen(ext, &seen) == 0 && seen) {
+		// The canonical order is only guaranteed to reproduce the reference when no such tie occurred: repeat the run on
+		// the resident shard with the reference's exact order replayed for EVERY contig (mode "all").
+		if (pg_verbose >= 2)
+			std::fprintf(stderr, "[M::%s::%s] tie-order hazard seen: repeating stages A-C with the reference's exact hit order on every contig\n", __func__, stamp());
+		exact_override(2);
+		q->n_seg = 0, q->n_arc = 0;
+		std::memset((void *)q->seg, 0, sizeof(pg_seg_t) * (size_t)q->m_seg);
+		ext->rerun = true;
+		if (post_process_impl(opt, q->d) != 0 || graph_gen_impl(opt, q) != 0) q->n_arc = 0;
+		exact_override(-1);
+		exact_shutdown(ext);
+		exact_init(q->d, ext), ext->exact_mode_of_segs = exact_mode(); // back to the cheap tracking for a later rerun
+	}
+	if (ext && !ext->vtx_sel_text.empty()) {
+		std::fwrite(ext->vtx_sel_text.data(), 1, ext->vtx_sel_text.size(), out_stream());
+		ext->vtx_sel_text.clear();
+	}
 	g_path_sec += now_sec() - t;
 }
 

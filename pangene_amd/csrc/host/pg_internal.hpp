@@ -60,6 +60,8 @@ struct DataExt {
 	std::vector<int64_t> hit_off;      // shard hit offsets
 	std::vector<std::vector<int32_t>> y_order; // per genome: host index of the k-th hit in cm order
 	std::vector<ExactSeg> xsegs;
+	std::string vtx_sel_text;          // -G output of the current run (printed when pg_graph_gen returns)
+	int exact_mode_of_segs = -1;       // mode xsegs was built for
 	std::vector<std::thread> xworkers; // background replay of the reference's sort sequence
 	std::atomic<size_t> xnext{0};
 	int x_sorts[2] = {0, 0};           // cs / cm sorts of the reference seen so far in this run
@@ -91,6 +93,7 @@ const char *stamp();
 int sync_host(pg_data_t *d, bool full);
 
 int exact_mode();
+void exact_override(int m);
 void exact_init(const pg_data_t *d, DataExt *ext);
 void exact_begin(DataExt *ext);
 int exact_sort(DataExt *ext, int by_cm);

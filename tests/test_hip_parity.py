@@ -69,6 +69,18 @@ def test_hip_equals_reference_md5(hip, expected, name, variant):
 
 
 @pytest.mark.parametrize("name,variant", all_cases())
+def test_hip_default_mode_equals_reference(hip, expected, name, variant):
+    """default mode (auto + hazard escalation): GFA bytes equal the reference's; --bed compared as a set of lines"""
+    hip.pg_set_exact_mode(1)
+    out = capi.run(hip, golden_files(name), variant.split())
+    e = expected[name][variant]
+    if "md5_sorted" in e:
+        assert hashlib.md5(b"\n".join(sorted(out.split(b"\n")))).hexdigest() == e["md5_sorted"]
+    else:
+        assert hashlib.md5(out).hexdigest() == e["md5"]
+
+
+@pytest.mark.parametrize("name,variant", all_cases())
 @pytest.mark.parametrize("mode", [0, 1])
 def test_hip_equals_oracle(hip, ora, name, variant, mode):
     """same canonical order on both sides (modes off / auto): identical bytes, hazards or not"""
