@@ -998,6 +998,121 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 	if (MODE == 2 && lane == 0) ndl[v] = n_group;
 }
 
+
+// pg_n_local for all the pairs of one oriented vertex (branch.c:70-90 call pg_n_local, branch.c:31-46, once per pair and
+// each call walks every genome).  One workgroup per vertex: the (contig, rank, cm) records of its n <= NLV_MAXN target
+// genes are staged in LDS for a chunk of genomes, then every thread owns pairs and counts them over the chunk out
+// of LDS -- a gene row is read from HBM once per vertex instead of once per pair (n-1 times less traffic).  The
+// pair order is exactly the one k_br_wave<2> consumes.  Rows are padded to NLV_GC+1 records so that threads reading
+// different rows at the same genome hit different LDS banks.
+constexpr int NLV_MAXN = 64, NLV_GC = 64, NLV_ROW = NLV_GC + 1;
+__global__ __launch_bounds__(BLOCK) void k_n_local_v(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
+                                                       const int32_t *poff, int GL, const int4 *rp, int local_dist, int local_count, int frag_mode, int32_t *cnt,
+                                                       int rows /* LDS rows provided: min(NLV_MAXN, largest degree) */)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int v = blockIdx.x;
+	const int a0 = vs[v], n = ve[v] - a0;
+	if (n < 2) return;
+	const int64_t k0 = poff[v];
+	const int tid = threadIdx.x, lane = tid & 63;
+	if (n > rows) { // rare (degree filter keeps n <= 30): pairs straight from global memory, sequential enumeration per thread
+		int max_s1 = 0;
+		for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1g[a0 + i] ? max_s1 : s1g[a0 + i];
+		int64_t k = k0;
+		for (int part = 0; part < 2; ++part)
+			for (int i = 0; i < n; ++i) {
+				if (part == 0 && !((1.0 - (double)s1g[a0 + i] / max_s1) > bd)) continue;
+				for (int j = part ? i + 1 : 0; j < n; ++j) {
+					if (part == 0 && s1g[a0 + j] != max_s1) continue;
+					if ((k - k0) % BLOCK == tid) {
+						const int g1 = part ? agidg[a0 + i] : agidg[a0 + j], g2 = part ? agidg[a0 + j] : agidg[a0 + i];
+						const int4 *r1 = rp + (int64_t)g1 * GL, *r2 = rp + (int64_t)g2 * GL;
+						int c = 0;
+						for (int q = 0; q < GL; ++q) {
+							const int4 a = r1[q], b = r2[q];
+							if (a.x < 0 || b.x < 0 || (!frag_mode && a.x != b.x)) continue;
+							const int64_t d = (int64_t)a.z - (int64_t)b.z;
+							const int cc = a.y - b.y;
+							c += (d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count);
+						}
+						cnt[k] = c;
+					}
+					++k;
+				}
+			}
+		return;
+	}
+	int4 *tile = (int4 *)smem;                                   // [rows][NLV_ROW]
+	int32_t *l_gid = (int32_t *)(tile + rows * NLV_ROW);          // [NLV_MAXN]
+	uint16_t *lp = (uint16_t *)(l_gid + NLV_MAXN);                // pair list: ia | ib << 8, up to rows^2 + rows^2/2 entries
+	__shared__ int s_np, s_n1;
+	if (tid < WAVE) { // wave 0 classifies the arcs exactly as k_br_wave does
+		const bool in = lane < n;
+		const int my_s1 = in ? s1g[a0 + lane] : 0;
+		if (in) l_gid[lane] = agidg[a0 + lane];
+		int max_s1 = my_s1;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(max_s1, o, WAVE); max_s1 = max_s1 > t ? max_s1 : t; }
+		const double r = in ? 1.0 - (double)my_s1 / max_s1 : 0.0;
+		const bool is_weak = in && r > bd, is_max = in && my_s1 == max_s1;
+		const unsigned long long m_weak = __ballot(is_weak), m_max = __ballot(is_max);
+		const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+		const int n_max = __popcll(m_max), n_weak = __popcll(m_weak), mrank = __popcll(m_max & lt);
+		const int n1 = n_max * n_weak;
+		if (lane == 0) s_n1 = n1, s_np = n1 + n * (n - 1) / 2;
+		// part 1: weak arc i (wb-th) x best arc j (mrank-th) -> slot wb * n_max + mrank holds (j, i)
+		int wb = 0;
+		for (unsigned long long m = m_weak; m; m &= m - 1, ++wb) {
+			const int i = __ffsll((long long)m) - 1;
+			if (is_max) lp[wb * n_max + mrank] = (uint16_t)(lane | i << 8);
+		}
+	}
+	__syncthreads();
+	const int n1 = s_n1, np = s_np;
+	for (int t = tid; t < n * n; t += BLOCK) { // part 2: (i, j), j > i, row i starts after i*n - i(i+1)/2 pairs
+		const int i = t / n, j = t - i * n;
+		if (j > i) lp[n1 + i * n - i * (i + 1) / 2 + (j - i - 1)] = (uint16_t)(i | j << 8);
+	}
+	__syncthreads();
+	constexpr int PPT = 9; // pairs per thread: 64*63/2 + 64*64 = 6112 <= 256 * 24 in the worst case; typical np <= 600
+	for (int pb = 0; pb < np; pb += BLOCK * PPT) {
+		int acc[PPT];
+#pragma unroll
+		for (int u = 0; u < PPT; ++u) acc[u] = 0;
+		for (int g0 = 0; g0 < GL; g0 += NLV_GC) {
+			const int gc = GL - g0 < NLV_GC ? GL - g0 : NLV_GC;
+			__syncthreads();
+			for (int t = tid; t < n * NLV_GC; t += BLOCK) { // stage: coalesced 16-byte loads along each gene row
+				const int row = t / NLV_GC, q = t - row * NLV_GC;
+				tile[row * NLV_ROW + q] = q < gc ? rp[(int64_t)l_gid[row] * GL + g0 + q] : make_int4(-1, 0, 0, 0);
+			}
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < PPT; ++u) {
+				const int p = pb + u * BLOCK + tid;
+				if (p >= np) break;
+				const int code = lp[p];
+				const int4 *r1 = tile + (code & 255) * NLV_ROW, *r2 = tile + (code >> 8) * NLV_ROW;
+				int c = 0;
+				for (int q = 0; q < gc; ++q) {
+					const int4 a = r1[q], b = r2[q];
+					const bool both = a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x);
+					const int64_t d = (int64_t)a.z - (int64_t)b.z;
+					const int cc = a.y - b.y;
+					c += both && ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+				}
+				acc[u] += c;
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < PPT; ++u) {
+			const int p = pb + u * BLOCK + tid;
+			if (p < np) cnt[k0 + p] = acc[u];
+		}
+	}
+}
+
 __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107
 {
 	int64_t lo = 0, hi = n;
@@ -1645,11 +1760,20 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	TRY(sync_st(c));
 	const int64_t np = c->h_cnt[10];
 	c->br_np = np, *n_pairs = np;
-	int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)np + 16);
-	if (!pairs) return PGA_ERR_NOMEM;
-	if (np) hipLaunchKernelGGL((k_br_wave<1>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, pairs,
-	                           (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt);
-	TRY(n_local_dev(c, pairs, np, local_dist, local_count, frag_mode, cnt));
+	int32_t *d_cnt = (int32_t *)c->pool.get(S_NLCNT, sizeof(int32_t) * (size_t)np + 16);
+	int4 *rp = (int4 *)c->pool.get(S_RP_SEG, 0);
+	if (!d_cnt || !rp) return PGA_ERR_NOMEM;
+	*cnt = d_cnt;
+	if (np) { // one workgroup per oriented vertex: gene rows staged in LDS, pairs counted out of LDS
+		int max_deg = 1, run = 1; // arcs are sorted by x = v<<32|w: the longest run of equal v is the largest degree
+		for (int64_t i = 1; i < n_arc; ++i) { run = (arc_x[i] >> 32) == (arc_x[i - 1] >> 32) ? run + 1 : 1; if (run > max_deg) max_deg = run; }
+		const int rows = std::max(2, std::min(NLV_MAXN, max_deg));
+		const size_t lds = sizeof(int4) * (size_t)rows * NLV_ROW + sizeof(int32_t) * NLV_MAXN + sizeof(uint16_t) * (size_t)(rows * rows + rows * rows / 2 + 8);
+		static size_t attr_lds = 0;
+		if (lds > attr_lds) { HIPCHK(hipFuncSetAttribute((const void *)k_n_local_v, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_lds = lds; }
+		hipLaunchKernelGGL(k_n_local_v, dim3((unsigned)n_vtx), dim3(BLOCK), lds, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, c->n_genome, rp,
+		                   local_dist, local_count, frag_mode, d_cnt, rows);
+	}
 	return sync_st(c); // the exchange may run on another stream
 }
 
