@@ -1075,11 +1075,17 @@ __global__ __launch_bounds__(BLOCK) void k_n_local_v(int n_vtx, const int32_t *v
 		if (j > i) lp[n1 + i * n - i * (i + 1) / 2 + (j - i - 1)] = (uint16_t)(i | j << 8);
 	}
 	__syncthreads();
-	constexpr int PPT = 9; // pairs per thread: 64*63/2 + 64*64 = 6112 <= 256 * 24 in the worst case; typical np <= 600
-	for (int pb = 0; pb < np; pb += BLOCK * PPT) {
-		int acc[PPT];
-#pragma unroll
-		for (int u = 0; u < PPT; ++u) acc[u] = 0;
+	// Most vertices have far fewer pairs than the workgroup has threads, so a chunk of npc <= BLOCK pairs is spread over
+	// all threads: thread t works for pair t % npc on the genomes t / npc, t / npc + nsub, ... of the staged chunk and
+	// the partial counts meet in an LDS accumulator.
+	__shared__ int s_acc[BLOCK];
+	for (int pb = 0; pb < np; pb += BLOCK) {
+		const int npc = np - pb < BLOCK ? np - pb : BLOCK, nsub = BLOCK / npc;
+		const int pl = tid % npc, sub = tid / npc;
+		const int code = lp[pb + pl];
+		const int4 *r1 = tile + (code & 255) * NLV_ROW, *r2 = tile + (code >> 8) * NLV_ROW;
+		int acc = 0;
+		s_acc[tid] = 0;
 		for (int g0 = 0; g0 < GL; g0 += NLV_GC) {
 			const int gc = GL - g0 < NLV_GC ? GL - g0 : NLV_GC;
 			__syncthreads();
@@ -1088,28 +1094,19 @@ __global__ __launch_bounds__(BLOCK) void k_n_local_v(int n_vtx, const int32_t *v
 				tile[row * NLV_ROW + q] = q < gc ? rp[(int64_t)l_gid[row] * GL + g0 + q] : make_int4(-1, 0, 0, 0);
 			}
 			__syncthreads();
-#pragma unroll
-			for (int u = 0; u < PPT; ++u) {
-				const int p = pb + u * BLOCK + tid;
-				if (p >= np) break;
-				const int code = lp[p];
-				const int4 *r1 = tile + (code & 255) * NLV_ROW, *r2 = tile + (code >> 8) * NLV_ROW;
-				int c = 0;
-				for (int q = 0; q < gc; ++q) {
+			if (sub < nsub)
+				for (int q = sub; q < gc; q += nsub) {
 					const int4 a = r1[q], b = r2[q];
 					const bool both = a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x);
 					const int64_t d = (int64_t)a.z - (int64_t)b.z;
 					const int cc = a.y - b.y;
-					c += both && ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+					acc += both && ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
 				}
-				acc[u] += c;
-			}
 		}
-#pragma unroll
-		for (int u = 0; u < PPT; ++u) {
-			const int p = pb + u * BLOCK + tid;
-			if (p < np) cnt[k0 + p] = acc[u];
-		}
+		if (sub < nsub && acc) atomicAdd(&s_acc[pl], acc);
+		__syncthreads();
+		if (tid < npc) cnt[k0 + pb + tid] = s_acc[tid];
+		__syncthreads();
 	}
 }
 
