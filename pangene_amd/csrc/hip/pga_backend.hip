@@ -859,7 +859,7 @@ __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t
 {
 	const int64_t k = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
-	if (k >= n_pair) return;
+	if (k >= n_pair || pairs[2 * k] < 0) return; // < 0: the pair belongs to a vertex counted by k_n_local_v
 	const int4 *r1 = rp + (int64_t)pairs[2 * k] * GL, *r2 = rp + (int64_t)pairs[2 * k + 1] * GL;
 	int c = 0;
 	for (int j = lane; j < GL; j += WAVE) {
@@ -944,12 +944,12 @@ __device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *a
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
                                                      const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
-                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt)
+                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, int min_n)
 {
 	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (v >= n_vtx) return;
 	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2) return;
+	if (n < 2 || n <= min_n) return;
 	const int64_t k0 = poff[v];
 	if (n > WAVE) {
 		if (lane == 0) { int32_t g = 0; br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt); if (MODE == 2) ndl[v] = g; }
@@ -1016,33 +1016,7 @@ __global__ __launch_bounds__(BLOCK) void k_n_local_v(int n_vtx, const int32_t *v
 	if (n < 2) return;
 	const int64_t k0 = poff[v];
 	const int tid = threadIdx.x, lane = tid & 63;
-	if (n > rows) { // rare (degree filter keeps n <= 30): pairs straight from global memory, sequential enumeration per thread
-		int max_s1 = 0;
-		for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1g[a0 + i] ? max_s1 : s1g[a0 + i];
-		int64_t k = k0;
-		for (int part = 0; part < 2; ++part)
-			for (int i = 0; i < n; ++i) {
-				if (part == 0 && !((1.0 - (double)s1g[a0 + i] / max_s1) > bd)) continue;
-				for (int j = part ? i + 1 : 0; j < n; ++j) {
-					if (part == 0 && s1g[a0 + j] != max_s1) continue;
-					if ((k - k0) % BLOCK == tid) {
-						const int g1 = part ? agidg[a0 + i] : agidg[a0 + j], g2 = part ? agidg[a0 + j] : agidg[a0 + i];
-						const int4 *r1 = rp + (int64_t)g1 * GL, *r2 = rp + (int64_t)g2 * GL;
-						int c = 0;
-						for (int q = 0; q < GL; ++q) {
-							const int4 a = r1[q], b = r2[q];
-							if (a.x < 0 || b.x < 0 || (!frag_mode && a.x != b.x)) continue;
-							const int64_t d = (int64_t)a.z - (int64_t)b.z;
-							const int cc = a.y - b.y;
-							c += (d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count);
-						}
-						cnt[k] = c;
-					}
-					++k;
-				}
-			}
-		return;
-	}
+	if (n > rows) return; // larger vertices: explicit pair list + k_n_local (one wave per pair)
 	int4 *tile = (int4 *)smem;                                   // [rows][NLV_ROW]
 	int32_t *l_gid = (int32_t *)(tile + rows * NLV_ROW);          // [NLV_MAXN]
 	uint16_t *lp = (uint16_t *)(l_gid + NLV_MAXN);                // pair list: ia | ib << 8, up to rows^2 + rows^2/2 entries
@@ -1764,12 +1738,20 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	if (np) { // one workgroup per oriented vertex: gene rows staged in LDS, pairs counted out of LDS
 		int max_deg = 1, run = 1; // arcs are sorted by x = v<<32|w: the longest run of equal v is the largest degree
 		for (int64_t i = 1; i < n_arc; ++i) { run = (arc_x[i] >> 32) == (arc_x[i - 1] >> 32) ? run + 1 : 1; if (run > max_deg) max_deg = run; }
-		const int rows = std::max(2, std::min(NLV_MAXN, max_deg));
+		const int rows = std::max(2, std::min(32, max_deg)); // LDS rows; bigger vertices take the pair-list path
 		const size_t lds = sizeof(int4) * (size_t)rows * NLV_ROW + sizeof(int32_t) * NLV_MAXN + sizeof(uint16_t) * (size_t)(rows * rows + rows * rows / 2 + 8);
 		static size_t attr_lds = 0;
 		if (lds > attr_lds) { HIPCHK(hipFuncSetAttribute((const void *)k_n_local_v, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_lds = lds; }
 		hipLaunchKernelGGL(k_n_local_v, dim3((unsigned)n_vtx), dim3(BLOCK), lds, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, c->n_genome, rp,
 		                   local_dist, local_count, frag_mode, d_cnt, rows);
+		if (max_deg > rows) { // the few big vertices: write their pairs (others stay -1) and count them one wave per pair
+			int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)np + 16);
+			if (!pairs) return PGA_ERR_NOMEM;
+			HIPCHK(hipMemsetAsync(pairs, 0xff, sizeof(int32_t) * 2 * (size_t)np, c->st));
+			hipLaunchKernelGGL((k_br_wave<1>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, pairs,
+			                   (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt, rows);
+			hipLaunchKernelGGL(k_n_local, dim3(nblk(np, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, pairs, np, c->n_genome, rp, local_dist, local_count, frag_mode, d_cnt);
+		}
 	}
 	return sync_st(c); // the exchange may run on another stream
 }
@@ -1790,7 +1772,7 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	if (!grp || !ndl) return PGA_ERR_NOMEM;
 	HIPCHK(hipMemsetAsync(grp, 0, sizeof(int32_t) * (size_t)n_arc, c->st)); HIPCHK(hipMemsetAsync(ndl, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
 	hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, cnt,
-	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt);
+	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt, 0);
 	HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(n_dist_loci, ndl, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
 	TRY(sync_st(c));
