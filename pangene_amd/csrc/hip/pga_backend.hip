@@ -1005,22 +1005,19 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 // of LDS -- a gene row is read from HBM once per vertex instead of once per pair (n-1 times less traffic).  The
 // pair order is exactly the one k_br_wave<2> consumes.  Rows are padded to NLV_GC+1 records so that threads reading
 // different rows at the same genome hit different LDS banks.
-constexpr int NLV_MAXN = 64, NLV_GC = 64, NLV_ROW = NLV_GC + 1;
+constexpr int NLV_MAXN = 32, NLV_CAP = 2048 + NLV_MAXN; // LDS tile: NLV_CAP records of 16 B; a vertex with n arcs stages (NLV_CAP - n) / n genomes at a time
 __global__ __launch_bounds__(BLOCK) void k_n_local_v(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
-                                                       const int32_t *poff, int GL, const int4 *rp, int local_dist, int local_count, int frag_mode, int32_t *cnt,
-                                                       int rows /* LDS rows provided: min(NLV_MAXN, largest degree) */)
+                                                       const int32_t *poff, int GL, const int4 *rp, int local_dist, int local_count, int frag_mode, int32_t *cnt)
 {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
+	__shared__ int4 tile[NLV_CAP];
+	__shared__ int32_t l_gid[NLV_MAXN];
+	__shared__ uint16_t lp[NLV_MAXN * NLV_MAXN + NLV_MAXN * NLV_MAXN / 2]; // pair list: ia | ib << 8
+	__shared__ int s_np, s_n1, s_acc[BLOCK];
 	const int v = blockIdx.x;
 	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2) return;
+	if (n < 2 || n > NLV_MAXN) return; // larger vertices: explicit pair list + k_n_local (one wave per pair)
 	const int64_t k0 = poff[v];
 	const int tid = threadIdx.x, lane = tid & 63;
-	if (n > rows) return; // larger vertices: explicit pair list + k_n_local (one wave per pair)
-	int4 *tile = (int4 *)smem;                                   // [rows][NLV_ROW]
-	int32_t *l_gid = (int32_t *)(tile + rows * NLV_ROW);          // [NLV_MAXN]
-	uint16_t *lp = (uint16_t *)(l_gid + NLV_MAXN);                // pair list: ia | ib << 8, up to rows^2 + rows^2/2 entries
-	__shared__ int s_np, s_n1;
 	if (tid < WAVE) { // wave 0 classifies the arcs exactly as k_br_wave does
 		const bool in = lane < n;
 		const int my_s1 = in ? s1g[a0 + lane] : 0;
@@ -1049,23 +1046,23 @@ __global__ __launch_bounds__(BLOCK) void k_n_local_v(int n_vtx, const int32_t *v
 		if (j > i) lp[n1 + i * n - i * (i + 1) / 2 + (j - i - 1)] = (uint16_t)(i | j << 8);
 	}
 	__syncthreads();
+	const int gcw = (NLV_CAP - n) / n, row = gcw + 1; // genomes staged per round; rows padded by one record (bank spread)
 	// Most vertices have far fewer pairs than the workgroup has threads, so a chunk of npc <= BLOCK pairs is spread over
 	// all threads: thread t works for pair t % npc on the genomes t / npc, t / npc + nsub, ... of the staged chunk and
 	// the partial counts meet in an LDS accumulator.
-	__shared__ int s_acc[BLOCK];
 	for (int pb = 0; pb < np; pb += BLOCK) {
 		const int npc = np - pb < BLOCK ? np - pb : BLOCK, nsub = BLOCK / npc;
 		const int pl = tid % npc, sub = tid / npc;
 		const int code = lp[pb + pl];
-		const int4 *r1 = tile + (code & 255) * NLV_ROW, *r2 = tile + (code >> 8) * NLV_ROW;
+		const int4 *r1 = tile + (code & 255) * row, *r2 = tile + (code >> 8) * row;
 		int acc = 0;
 		s_acc[tid] = 0;
-		for (int g0 = 0; g0 < GL; g0 += NLV_GC) {
-			const int gc = GL - g0 < NLV_GC ? GL - g0 : NLV_GC;
+		for (int g0 = 0; g0 < GL; g0 += gcw) {
+			const int gc = GL - g0 < gcw ? GL - g0 : gcw;
 			__syncthreads();
-			for (int t = tid; t < n * NLV_GC; t += BLOCK) { // stage: coalesced 16-byte loads along each gene row
-				const int row = t / NLV_GC, q = t - row * NLV_GC;
-				tile[row * NLV_ROW + q] = q < gc ? rp[(int64_t)l_gid[row] * GL + g0 + q] : make_int4(-1, 0, 0, 0);
+			for (int r = 0; r < n; ++r) { // stage: coalesced 16-byte loads along each gene row
+				const int4 *src = rp + (int64_t)l_gid[r] * GL + g0;
+				for (int q = tid; q < gc; q += BLOCK) tile[r * row + q] = src[q];
 			}
 			__syncthreads();
 			if (sub < nsub)
@@ -1738,12 +1735,9 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	if (np) { // one workgroup per oriented vertex: gene rows staged in LDS, pairs counted out of LDS
 		int max_deg = 1, run = 1; // arcs are sorted by x = v<<32|w: the longest run of equal v is the largest degree
 		for (int64_t i = 1; i < n_arc; ++i) { run = (arc_x[i] >> 32) == (arc_x[i - 1] >> 32) ? run + 1 : 1; if (run > max_deg) max_deg = run; }
-		const int rows = std::max(2, std::min(32, max_deg)); // LDS rows; bigger vertices take the pair-list path
-		const size_t lds = sizeof(int4) * (size_t)rows * NLV_ROW + sizeof(int32_t) * NLV_MAXN + sizeof(uint16_t) * (size_t)(rows * rows + rows * rows / 2 + 8);
-		static size_t attr_lds = 0;
-		if (lds > attr_lds) { HIPCHK(hipFuncSetAttribute((const void *)k_n_local_v, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_lds = lds; }
-		hipLaunchKernelGGL(k_n_local_v, dim3((unsigned)n_vtx), dim3(BLOCK), lds, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, c->n_genome, rp,
-		                   local_dist, local_count, frag_mode, d_cnt, rows);
+		const int rows = NLV_MAXN; // vertices with more arcs take the pair-list path
+		hipLaunchKernelGGL(k_n_local_v, dim3((unsigned)n_vtx), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, c->n_genome, rp,
+		                   local_dist, local_count, frag_mode, d_cnt);
 		if (max_deg > rows) { // the few big vertices: write their pairs (others stay -1) and count them one wave per pair
 			int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)np + 16);
 			if (!pairs) return PGA_ERR_NOMEM;
