@@ -859,7 +859,7 @@ __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t
 {
 	const int64_t k = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
-	if (k >= n_pair || pairs[2 * k] < 0) return; // < 0: the pair belongs to a vertex counted by k_n_local_v
+	if (k >= n_pair) return;
 	const int4 *r1 = rp + (int64_t)pairs[2 * k] * GL, *r2 = rp + (int64_t)pairs[2 * k + 1] * GL;
 	int c = 0;
 	for (int j = lane; j < GL; j += WAVE) {
@@ -944,12 +944,12 @@ __device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *a
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
                                                      const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
-                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, int min_n)
+                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt)
 {
 	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (v >= n_vtx) return;
 	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2 || n <= min_n) return;
+	if (n < 2) return;
 	const int64_t k0 = poff[v];
 	if (n > WAVE) {
 		if (lane == 0) { int32_t g = 0; br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt); if (MODE == 2) ndl[v] = g; }
@@ -996,89 +996,6 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 		}
 	}
 	if (MODE == 2 && lane == 0) ndl[v] = n_group;
-}
-
-
-// pg_n_local for all the pairs of one oriented vertex (branch.c:70-90 call pg_n_local, branch.c:31-46, once per pair and
-// each call walks every genome).  One workgroup per vertex: the (contig, rank, cm) records of its n <= NLV_MAXN target
-// genes are staged in LDS for a chunk of genomes, then every thread owns pairs and counts them over the chunk out
-// of LDS -- a gene row is read from HBM once per vertex instead of once per pair (n-1 times less traffic).  The
-// pair order is exactly the one k_br_wave<2> consumes.  Rows are padded to NLV_GC+1 records so that threads reading
-// different rows at the same genome hit different LDS banks.
-constexpr int NLV_MAXN = 32, NLV_CAP = 2048 + NLV_MAXN; // LDS tile: NLV_CAP records of 16 B; a vertex with n arcs stages (NLV_CAP - n) / n genomes at a time
-__global__ __launch_bounds__(BLOCK) void k_n_local_v(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
-                                                       const int32_t *poff, int GL, const int4 *rp, int local_dist, int local_count, int frag_mode, int32_t *cnt)
-{
-	__shared__ int4 tile[NLV_CAP];
-	__shared__ int32_t l_gid[NLV_MAXN];
-	__shared__ uint16_t lp[NLV_MAXN * NLV_MAXN + NLV_MAXN * NLV_MAXN / 2]; // pair list: ia | ib << 8
-	__shared__ int s_np, s_n1, s_acc[BLOCK];
-	const int v = blockIdx.x;
-	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2 || n > NLV_MAXN) return; // larger vertices: explicit pair list + k_n_local (one wave per pair)
-	const int64_t k0 = poff[v];
-	const int tid = threadIdx.x, lane = tid & 63;
-	if (tid < WAVE) { // wave 0 classifies the arcs exactly as k_br_wave does
-		const bool in = lane < n;
-		const int my_s1 = in ? s1g[a0 + lane] : 0;
-		if (in) l_gid[lane] = agidg[a0 + lane];
-		int max_s1 = my_s1;
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(max_s1, o, WAVE); max_s1 = max_s1 > t ? max_s1 : t; }
-		const double r = in ? 1.0 - (double)my_s1 / max_s1 : 0.0;
-		const bool is_weak = in && r > bd, is_max = in && my_s1 == max_s1;
-		const unsigned long long m_weak = __ballot(is_weak), m_max = __ballot(is_max);
-		const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-		const int n_max = __popcll(m_max), n_weak = __popcll(m_weak), mrank = __popcll(m_max & lt);
-		const int n1 = n_max * n_weak;
-		if (lane == 0) s_n1 = n1, s_np = n1 + n * (n - 1) / 2;
-		// part 1: weak arc i (wb-th) x best arc j (mrank-th) -> slot wb * n_max + mrank holds (j, i)
-		int wb = 0;
-		for (unsigned long long m = m_weak; m; m &= m - 1, ++wb) {
-			const int i = __ffsll((long long)m) - 1;
-			if (is_max) lp[wb * n_max + mrank] = (uint16_t)(lane | i << 8);
-		}
-	}
-	__syncthreads();
-	const int n1 = s_n1, np = s_np;
-	for (int t = tid; t < n * n; t += BLOCK) { // part 2: (i, j), j > i, row i starts after i*n - i(i+1)/2 pairs
-		const int i = t / n, j = t - i * n;
-		if (j > i) lp[n1 + i * n - i * (i + 1) / 2 + (j - i - 1)] = (uint16_t)(i | j << 8);
-	}
-	__syncthreads();
-	const int gcw = (NLV_CAP - n) / n, row = gcw + 1; // genomes staged per round; rows padded by one record (bank spread)
-	// Most vertices have far fewer pairs than the workgroup has threads, so a chunk of npc <= BLOCK pairs is spread over
-	// all threads: thread t works for pair t % npc on the genomes t / npc, t / npc + nsub, ... of the staged chunk and
-	// the partial counts meet in an LDS accumulator.
-	for (int pb = 0; pb < np; pb += BLOCK) {
-		const int npc = np - pb < BLOCK ? np - pb : BLOCK, nsub = BLOCK / npc;
-		const int pl = tid % npc, sub = tid / npc;
-		const int code = lp[pb + pl];
-		const int4 *r1 = tile + (code & 255) * row, *r2 = tile + (code >> 8) * row;
-		int acc = 0;
-		s_acc[tid] = 0;
-		for (int g0 = 0; g0 < GL; g0 += gcw) {
-			const int gc = GL - g0 < gcw ? GL - g0 : gcw;
-			__syncthreads();
-			for (int r = 0; r < n; ++r) { // stage: coalesced 16-byte loads along each gene row
-				const int4 *src = rp + (int64_t)l_gid[r] * GL + g0;
-				for (int q = tid; q < gc; q += BLOCK) tile[r * row + q] = src[q];
-			}
-			__syncthreads();
-			if (sub < nsub)
-				for (int q = sub; q < gc; q += nsub) {
-					const int4 a = r1[q], b = r2[q];
-					const bool both = a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x);
-					const int64_t d = (int64_t)a.z - (int64_t)b.z;
-					const int cc = a.y - b.y;
-					acc += both && ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
-				}
-		}
-		if (sub < nsub && acc) atomicAdd(&s_acc[pl], acc);
-		__syncthreads();
-		if (tid < npc) cnt[k0 + pb + tid] = s_acc[tid];
-		__syncthreads();
-	}
 }
 
 __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107
@@ -1728,25 +1645,11 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	TRY(sync_st(c));
 	const int64_t np = c->h_cnt[10];
 	c->br_np = np, *n_pairs = np;
-	int32_t *d_cnt = (int32_t *)c->pool.get(S_NLCNT, sizeof(int32_t) * (size_t)np + 16);
-	int4 *rp = (int4 *)c->pool.get(S_RP_SEG, 0);
-	if (!d_cnt || !rp) return PGA_ERR_NOMEM;
-	*cnt = d_cnt;
-	if (np) { // one workgroup per oriented vertex: gene rows staged in LDS, pairs counted out of LDS
-		int max_deg = 1, run = 1; // arcs are sorted by x = v<<32|w: the longest run of equal v is the largest degree
-		for (int64_t i = 1; i < n_arc; ++i) { run = (arc_x[i] >> 32) == (arc_x[i - 1] >> 32) ? run + 1 : 1; if (run > max_deg) max_deg = run; }
-		const int rows = NLV_MAXN; // vertices with more arcs take the pair-list path
-		hipLaunchKernelGGL(k_n_local_v, dim3((unsigned)n_vtx), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, c->n_genome, rp,
-		                   local_dist, local_count, frag_mode, d_cnt);
-		if (max_deg > rows) { // the few big vertices: write their pairs (others stay -1) and count them one wave per pair
-			int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)np + 16);
-			if (!pairs) return PGA_ERR_NOMEM;
-			HIPCHK(hipMemsetAsync(pairs, 0xff, sizeof(int32_t) * 2 * (size_t)np, c->st));
-			hipLaunchKernelGGL((k_br_wave<1>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, pairs,
-			                   (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt, rows);
-			hipLaunchKernelGGL(k_n_local, dim3(nblk(np, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, pairs, np, c->n_genome, rp, local_dist, local_count, frag_mode, d_cnt);
-		}
-	}
+	int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)np + 16);
+	if (!pairs) return PGA_ERR_NOMEM;
+	if (np) hipLaunchKernelGGL((k_br_wave<1>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, pairs,
+	                           (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt);
+	TRY(n_local_dev(c, pairs, np, local_dist, local_count, frag_mode, cnt));
 	return sync_st(c); // the exchange may run on another stream
 }
 
@@ -1766,7 +1669,7 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	if (!grp || !ndl) return PGA_ERR_NOMEM;
 	HIPCHK(hipMemsetAsync(grp, 0, sizeof(int32_t) * (size_t)n_arc, c->st)); HIPCHK(hipMemsetAsync(ndl, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
 	hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, cnt,
-	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt, 0);
+	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt);
 	HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(n_dist_loci, ndl, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
 	TRY(sync_st(c));
