@@ -150,6 +150,12 @@ typedef struct {
 	 * integer fields of equal x (graph.c:153-169 is a sum, so the order of the shards is irrelevant). */ \
 	int  pfx##_arc_merge(pga_ctx_t *ctx, const pga_arc_part_t *gathered, const int64_t *count, int32_t W, int64_t slot, \
 	                     pga_arc_part_t **out, int64_t *n_out); \
+	/* Declare which arc table in backend memory (the output of arc_round, or of arc_merge when sharded) is the graph's \
+	 * arc table of this round.  The backend derives what the following steps read -- per-arc s1 (the double rounding \
+	 * of graph.c:171), target gene, the arc range of every oriented vertex -- and keeps it resident, so the arcs only \
+	 * travel to the host once, after the last round: branch_pairs(arc_x = NULL), mark_hits(arc_x = NULL) use it. \
+	 * deg (host, [2*n_seg]) receives the out-degree of every oriented vertex (pg_flt_high_occ, graph.c:243-250). */ \
+	int  pfx##_arc_set_current(pga_ctx_t *ctx, const pga_arc_part_t *arcs, int64_t n_arc, int32_t n_seg, int32_t *deg); \
 	/* pg_gen_rep_pos (branch.c:6-29) kept in backend memory */ \
 	int  pfx##_rep_pos(pga_ctx_t *ctx); \
 	/* pg_n_local (branch.c:31-46) for n gene pairs (pairs[2i], pairs[2i+1]) summed over local genomes */ \
@@ -159,7 +165,7 @@ typedef struct {
 	 * branch_pairs: arcs sorted by x with their s1, seg_gid[S] = gene of each segment.  For every oriented vertex \
 	 * with >= 2 arcs it lists the gene pairs the reference hands to pg_n_local -- the (best-scoring target, weaker \
 	 * target) pairs of branch.c:70-75, then every i<j pair of 83-88 -- and counts each over the local genomes \
-	 * (needs rep_pos): cnt[n_pairs] in backend memory.  branch_decide (after the all-reduce of cnt): branch.c:76-77 \
+	 * (needs rep_pos): cnt[n_pairs] in backend memory.  arc_x = NULL: the table of arc_set_current.  branch_decide (after the all-reduce of cnt): branch.c:76-77 \
 	 * and 82-90 -> weak_br per arc (host, n_arc bytes) and n_dist_loci (host, 2S).  The arcs and their weak_br stay \
 	 * resident: mark_hits(NULL, NULL, n_arc) uses them. */ \
 	int  pfx##_branch_pairs(pga_ctx_t *ctx, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg, \
@@ -210,6 +216,7 @@ typedef struct {
 	int  (*flag_vtx)(pga_ctx_t *, const int32_t *, int32_t);
 	int  (*arc_round)(pga_ctx_t *, int32_t, int32_t **, pga_arc_part_t **, int64_t *);
 	int  (*arc_merge)(pga_ctx_t *, const pga_arc_part_t *, const int64_t *, int32_t, int64_t, pga_arc_part_t **, int64_t *);
+	int  (*arc_set_current)(pga_ctx_t *, const pga_arc_part_t *, int64_t, int32_t, int32_t *);
 	int  (*rep_pos)(pga_ctx_t *);
 	int  (*n_local)(pga_ctx_t *, const int32_t *, int64_t, int32_t, int32_t, int32_t, int32_t **);
 	int  (*branch_pairs)(pga_ctx_t *, const uint64_t *, const int32_t *, int64_t, const int32_t *, int32_t, double, int32_t, int32_t, int32_t, int32_t **, int64_t *);

@@ -726,16 +726,43 @@ static int64_t branch_vertex(pga_ctx_t *c, int64_t a0, int32_t n, double branch_
 	return k;
 }
 
+/* the round's arc table: s1 (graph.c:171), target genes, out-degrees (graph.c:243-250) */
+int pgo_arc_set_current(pga_ctx_t *c, const pga_arc_part_t *arcs, int64_t n_arc, int32_t n_seg, int32_t *deg)
+{
+	int64_t i;
+	int32_t g, *seg_gid = CALLOC(int32_t, n_seg);
+	for (g = 0; g < c->n_gene; ++g) if (c->g2s[g] >= 0 && c->g2s[g] < n_seg) seg_gid[c->g2s[g]] = g;
+	free(c->br_x); free(c->br_s1); free(c->br_gid); free(c->br_weak);
+	c->br_x = MALLOC(uint64_t, n_arc); c->br_s1 = MALLOC(int32_t, n_arc); c->br_gid = MALLOC(int32_t, n_arc); c->br_weak = CALLOC(uint8_t, n_arc);
+	memset(deg, 0, 2 * (size_t)n_seg * sizeof(int32_t));
+	for (i = 0; i < n_arc; ++i) {
+		c->br_x[i] = arcs[i].x;
+		c->br_s1[i] = (int32_t)((double)arcs[i].sum_s1 / arcs[i].n_genome + .499);
+		c->br_gid[i] = seg_gid[(uint32_t)arcs[i].x >> 1];
+		deg[arcs[i].x >> 32]++;
+	}
+	c->br_n = n_arc, c->br_S = n_seg;
+	free(seg_gid);
+	return PGA_OK;
+}
+
 int pgo_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg,
                      double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs)
 {
 	int64_t i, i0, np = 0, k;
 	int pass, rc;
-	free(c->br_x); free(c->br_s1); free(c->br_gid); free(c->br_weak); free(c->br_pairs);
-	c->br_x = MALLOC(uint64_t, n_arc); c->br_s1 = MALLOC(int32_t, n_arc); c->br_gid = MALLOC(int32_t, n_arc); c->br_weak = CALLOC(uint8_t, n_arc);
-	memcpy(c->br_x, arc_x, n_arc * sizeof(uint64_t)); memcpy(c->br_s1, arc_s1, n_arc * sizeof(int32_t));
-	for (i = 0; i < n_arc; ++i) c->br_gid[i] = seg_gid[(uint32_t)arc_x[i] >> 1];
-	c->br_n = n_arc, c->br_S = n_seg, c->br_pairs = 0;
+	if (arc_x) {
+		free(c->br_x); free(c->br_s1); free(c->br_gid); free(c->br_weak);
+		c->br_x = MALLOC(uint64_t, n_arc); c->br_s1 = MALLOC(int32_t, n_arc); c->br_gid = MALLOC(int32_t, n_arc); c->br_weak = CALLOC(uint8_t, n_arc);
+		memcpy(c->br_x, arc_x, n_arc * sizeof(uint64_t)); memcpy(c->br_s1, arc_s1, n_arc * sizeof(int32_t));
+		for (i = 0; i < n_arc; ++i) c->br_gid[i] = seg_gid[(uint32_t)arc_x[i] >> 1];
+		c->br_n = n_arc, c->br_S = n_seg;
+	} else { /* the table of arc_set_current */
+		arc_x = c->br_x, n_arc = c->br_n, n_seg = c->br_S;
+		memset(c->br_weak, 0, n_arc);
+	}
+	free(c->br_pairs);
+	c->br_pairs = 0;
 	for (pass = 0; pass < 2; ++pass) {
 		k = 0;
 		for (i0 = 0, i = 1; i <= n_arc; ++i)
@@ -765,7 +792,7 @@ int pgo_branch_decide(pga_ctx_t *c, double branch_diff, double branch_diff_dist,
 			}
 			i0 = i;
 		}
-	memcpy(arc_weak, c->br_weak, c->br_n);
+	if (arc_weak) memcpy(arc_weak, c->br_weak, c->br_n);
 	if (n_flt1) *n_flt1 = f1;
 	if (n_flt2) *n_flt2 = f2;
 	return PGA_OK;
@@ -913,7 +940,7 @@ const pga_backend_t *pgo_backend(void)
 {
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
-		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_arc_merge, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
+		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_arc_merge, pgo_arc_set_current, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
 		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0
 	};
 	return &b;

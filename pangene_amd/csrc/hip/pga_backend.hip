@@ -889,6 +889,33 @@ __global__ __launch_bounds__(BLOCK) void k_br_prep(const uint64_t *ax, int64_t n
 	if (i == n_arc - 1 || (uint32_t)(ax[i + 1] >> 32) != v) ve[v] = (int32_t)i + 1;
 }
 
+// the round's arc table -> what branch marking reads (see pga_arc_set_current)
+__global__ __launch_bounds__(BLOCK) void k_seg_gid(const int32_t *g2s, int Q, int n_seg, int32_t *seg_gid)
+{
+	int g = blockIdx.x * BLOCK + threadIdx.x;
+	if (g < Q) { int s = g2s[g]; if (s >= 0 && s < n_seg) seg_gid[s] = g; }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cur_prep(const pga_arc_part_t *arcs, int64_t n_arc, const int32_t *seg_gid, uint64_t *ax, int32_t *s1, int32_t *agid,
+                                                      int32_t *vs, int32_t *ve)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n_arc) return;
+	const pga_arc_part_t a = arcs[i];
+	const uint32_t v = (uint32_t)(a.x >> 32);
+	ax[i] = a.x;
+	s1[i] = (int32_t)((double)a.sum_s1 / a.n_genome + .499); // graph.c:171
+	agid[i] = seg_gid[(uint32_t)a.x >> 1];
+	if (i == 0 || (uint32_t)(arcs[i - 1].x >> 32) != v) vs[v] = (int32_t)i;
+	if (i == n_arc - 1 || (uint32_t)(arcs[i + 1].x >> 32) != v) ve[v] = (int32_t)i + 1;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_deg(const int32_t *vs, const int32_t *ve, int n_vtx, int32_t *deg)
+{
+	int v = blockIdx.x * BLOCK + threadIdx.x;
+	if (v < n_vtx) deg[v] = ve[v] - vs[v];
+}
+
 // number of pg_n_local calls of vertex v: n_max * n_weak (branch.c:70-75) + n(n-1)/2 (branch.c:83-88)
 __global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1, double bd, int32_t *pc)
 {
@@ -1576,6 +1603,30 @@ extern "C" int pga_arc_merge(pga_ctx_t *c, const pga_arc_part_t *gathered, const
 	return 0;
 }
 
+
+extern "C" int pga_arc_set_current(pga_ctx_t *c, const pga_arc_part_t *arcs, int64_t n_arc, int32_t n_seg, int32_t *deg)
+{
+	const int n_vtx = 2 * n_seg;
+	c->br_n = n_arc, c->br_S = n_seg, c->br_np = 0;
+	if (n_vtx) memset(deg, 0, sizeof(int32_t) * (size_t)n_vtx);
+	uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, sizeof(uint64_t) * (size_t)n_arc + 16);
+	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, (size_t)n_arc + 16);
+	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, sizeof(int32_t) * (size_t)n_arc + 16), *agid = (int32_t *)c->pool.get(S_BR_GID, sizeof(int32_t) * (size_t)n_arc + 16);
+	int32_t *vs = (int32_t *)c->pool.get(S_BR_VS, sizeof(int32_t) * (size_t)n_vtx + 16), *ve = (int32_t *)c->pool.get(S_BR_VE, sizeof(int32_t) * (size_t)n_vtx + 16);
+	int32_t *sg = (int32_t *)c->pool.get(S_BR_SEGGID, sizeof(int32_t) * (size_t)n_seg + 16), *dg = (int32_t *)c->pool.get(S_BR_PC, sizeof(int32_t) * (size_t)n_vtx + 16);
+	if (!ax || !aw || !s1 || !agid || !vs || !ve || !sg || !dg) return PGA_ERR_NOMEM;
+	if (n_vtx == 0) return 0;
+	HIPCHK(hipMemsetAsync(vs, 0, sizeof(int32_t) * (size_t)n_vtx, c->st)); HIPCHK(hipMemsetAsync(ve, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
+	if (n_arc) {
+		HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st));
+		hipLaunchKernelGGL(k_seg_gid, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, c->Q, n_seg, sg);
+		hipLaunchKernelGGL(k_cur_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, arcs, n_arc, sg, ax, s1, agid, vs, ve);
+	}
+	hipLaunchKernelGGL(k_deg, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, vs, ve, n_vtx, dg);
+	HIPCHK(hipMemcpyAsync(deg, dg, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
+	return sync_st(c);
+}
+
 extern "C" int pga_rep_pos(pga_ctx_t *c)
 {
 	const int N = c->N, GL = c->n_genome, Q = c->Q;
@@ -1622,6 +1673,7 @@ extern "C" int pga_n_local(pga_ctx_t *c, const int32_t *pairs, int64_t n, int32_
 extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg,
                                 double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs)
 {
+	if (arc_x == nullptr) n_arc = c->br_n, n_seg = c->br_S; // the table of pga_arc_set_current
 	const int n_vtx = 2 * n_seg;
 	uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, sizeof(uint64_t) * (size_t)n_arc + 16);
 	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, (size_t)n_arc + 16);
@@ -1633,10 +1685,12 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	c->br_n = n_arc, c->br_S = n_seg, c->br_np = 0;
 	*n_pairs = 0, *cnt = (int32_t *)c->pool.get(S_NLCNT, 16);
 	if (n_arc == 0 || n_vtx == 0) return sync_st(c);
-	TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, s1, arc_s1, (size_t)n_arc)); TRY(upload(c, sg, seg_gid, (size_t)n_seg));
-	HIPCHK(hipMemsetAsync(vs, 0, sizeof(int32_t) * (size_t)n_vtx, c->st)); HIPCHK(hipMemsetAsync(ve, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
+	if (arc_x) {
+		TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, s1, arc_s1, (size_t)n_arc)); TRY(upload(c, sg, seg_gid, (size_t)n_seg));
+		HIPCHK(hipMemsetAsync(vs, 0, sizeof(int32_t) * (size_t)n_vtx, c->st)); HIPCHK(hipMemsetAsync(ve, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
+		hipLaunchKernelGGL(k_br_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, ax, n_arc, sg, agid, vs, ve);
+	}
 	HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st));
-	hipLaunchKernelGGL(k_br_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, ax, n_arc, sg, agid, vs, ve);
 	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
@@ -1670,11 +1724,11 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	HIPCHK(hipMemsetAsync(grp, 0, sizeof(int32_t) * (size_t)n_arc, c->st)); HIPCHK(hipMemsetAsync(ndl, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
 	hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, cnt,
 	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt);
-	HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
+	if (arc_weak) HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(n_dist_loci, ndl, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
 	TRY(sync_st(c));
 	int64_t f1 = 0, f2 = 0;
-	for (int64_t i = 0; i < n_arc; ++i) f1 += arc_weak[i] == 1, f2 += arc_weak[i] == 2;
+	if (arc_weak) for (int64_t i = 0; i < n_arc; ++i) f1 += arc_weak[i] == 1, f2 += arc_weak[i] == 2;
 	if (n_flt1) *n_flt1 = f1;
 	if (n_flt2) *n_flt2 = f2;
 	return 0;
@@ -1838,7 +1892,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 {
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
-		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
+		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
 		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get
 	};
 	return &b;

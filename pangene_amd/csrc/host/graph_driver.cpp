@@ -466,24 +466,34 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	std::vector<int32_t> sc((size_t)S * 2);
 	if (S) BE_CALL(be->fetch(ext->ctx, sc.data(), b_seg, sizeof(int32_t) * (size_t)S * 2), "fetch");
 	for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
-	std::vector<pga_arc_part_t> part;
+	// The arc table stays in backend memory (after the cross-shard merge when sharded): branch marking, hit marking and the
+	// degree filter read it there; it travels to the host once, after the last round (fetch_arcs).
+	const pga_arc_part_t *cur = b_arc;
+	int64_t n_cur = n_loc;
 	if (sharded()) { // all-gather the local tables (RCCL) and reduce by key on the backend; integer sums => order-independent
 		std::vector<int64_t> cnt;
 		int64_t slot = 0, n_mg = 0;
 		pga_arc_part_t *gathered = nullptr, *merged = nullptr;
 		BE_CALL(xgather_raw(be, ext->ctx, b_arc, n_loc, cnt, &slot, &gathered), "allgather(arcs)");
 		if (slot) BE_CALL(be->arc_merge(ext->ctx, gathered, cnt.data(), g_xchg.world, slot, &merged, &n_mg), "arc_merge");
-		part.resize((size_t)n_mg);
-		if (n_mg) BE_CALL(be->fetch(ext->ctx, part.data(), merged, sizeof(pga_arc_part_t) * (size_t)n_mg), "fetch");
-	} else {
-		part.resize((size_t)n_loc);
-		if (n_loc) BE_CALL(be->fetch(ext->ctx, part.data(), b_arc, sizeof(pga_arc_part_t) * (size_t)n_loc), "fetch");
+		cur = merged, n_cur = n_mg;
 	}
+	ext->deg.assign((size_t)S * 2 + 1, 0);
+	BE_CALL(be->arc_set_current(ext->ctx, cur, n_cur, S, ext->deg.data()), "arc_set_current");
+	ext->cur_arcs = cur, q->n_arc = (int32_t)n_cur;
+	return 0;
+}
+
+// bring the round's arc table to the host and apply the three double roundings of graph.c:170-172
+static int fetch_arcs(pg_graph_t *q, DataExt *ext)
+{
+	Phase ph_host(PH_ARC_HOST);
+	std::vector<pga_arc_part_t> part((size_t)q->n_arc);
+	if (q->n_arc) BE_CALL(ext->be->fetch(ext->ctx, part.data(), ext->cur_arcs, sizeof(pga_arc_part_t) * part.size()), "fetch");
 	if ((int64_t)part.size() > q->m_arc) {
 		q->m_arc = (int32_t)part.size() + ((int32_t)part.size() >> 1) + 16;
 		q->arc = (pg_arc_t *)std::realloc(q->arc, sizeof(pg_arc_t) * (size_t)q->m_arc);
 	}
-	q->n_arc = (int32_t)part.size();
 	for (size_t i = 0; i < part.size(); ++i) {
 		pg_arc_t *p = &q->arc[i];
 		std::memset(p, 0, sizeof(*p));
@@ -504,12 +514,8 @@ static int flt_high_occ(int32_t max_avg_occ, int32_t max_degree, int32_t max_dis
 	int32_t n_high_occ = 0, n_high_deg = 0, n_high_loci = 0;
 	for (int32_t i = 0; i < q->n_seg; ++i)
 		if (q->seg[i].tot_cnt > max_avg_occ * q->d->n_genome) q->seg[i].del = 1, ++n_high_occ;
-	for (int32_t i0 = 0, i = 1; i <= q->n_arc; ++i)
-		if (i == q->n_arc || q->arc[i].x >> 32 != q->arc[i0].x >> 32) {
-			int32_t sid = (int32_t)(q->arc[i0].x >> 32 >> 1);
-			if (i - i0 > max_degree && !q->seg[sid].del) q->seg[sid].del = 1, ++n_high_deg;
-			i0 = i;
-		}
+	for (int32_t v = 0; v < 2 * q->n_seg; ++v) // out-degree of every oriented vertex of the round's arc table (graph.c:243-250)
+		if (ext->deg[(size_t)v] > max_degree && !q->seg[v >> 1].del) q->seg[v >> 1].del = 1, ++n_high_deg;
 	for (int32_t i = 0; i < q->n_seg; ++i) {
 		pg_seg_t *s = &q->seg[i];
 		int32_t m = s->n_dist_loci[0] > s->n_dist_loci[1] ? s->n_dist_loci[0] : s->n_dist_loci[1];
@@ -538,21 +544,17 @@ static int mark_branch_flt_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	const pga_backend_t *be = ext->be;
 	Phase ph_all(PH_BRANCH_HOST);
 	BE_CALL(be->rep_pos(ext->ctx), "rep_pos");
-	std::vector<uint64_t> ax((size_t)q->n_arc);
-	std::vector<int32_t> s1((size_t)q->n_arc), sgid((size_t)q->n_seg), ndl((size_t)q->n_seg * 2 + 1);
-	std::vector<uint8_t> aw((size_t)q->n_arc + 1);
-	for (int32_t i = 0; i < q->n_arc; ++i) ax[(size_t)i] = q->arc[i].x, s1[(size_t)i] = q->arc[i].s1;
-	for (int32_t i = 0; i < q->n_seg; ++i) sgid[(size_t)i] = q->seg[i].gid;
+	std::vector<int32_t> ndl((size_t)q->n_seg * 2 + 1);
 	int32_t *b_cnt; int64_t np = 0, n_flt1 = 0, n_flt2 = 0;
 	{
 		Phase ph(PH_NLOCAL);
-		BE_CALL(be->branch_pairs(ext->ctx, ax.data(), s1.data(), q->n_arc, sgid.data(), q->n_seg, opt->branch_diff, opt->local_dist, opt->local_count,
+		BE_CALL(be->branch_pairs(ext->ctx, nullptr, nullptr, 0, nullptr, q->n_seg, opt->branch_diff, opt->local_dist, opt->local_count,
 		                         !!(opt->flag & PG_F_FRAG_MODE), &b_cnt, &np), "branch_pairs");
 		BE_CALL(xreduce(be, b_cnt, np, PG_X_I32, PG_X_SUM), "allreduce(n_local)");
-		BE_CALL(be->branch_decide(ext->ctx, opt->branch_diff, opt->branch_diff_dist, opt->branch_diff_cut, aw.data(), ndl.data(), &n_flt1, &n_flt2), "branch_decide");
+		std::vector<uint8_t> aw(pg_verbose >= 3 ? (size_t)q->n_arc + 1 : 0); // per-arc weak_br only feeds the log line; it stays resident for mark_hits
+		BE_CALL(be->branch_decide(ext->ctx, opt->branch_diff, opt->branch_diff_dist, opt->branch_diff_cut, aw.empty() ? nullptr : aw.data(), ndl.data(), &n_flt1, &n_flt2), "branch_decide");
 		g_phase[PH_BRANCH_HOST] -= now_sec() - ph.t0; // counted under PH_NLOCAL
 	}
-	for (int32_t i = 0; i < q->n_arc; ++i) q->arc[i].weak_br = aw[(size_t)i];
 	for (int32_t j = 0; j < q->n_seg; ++j) q->seg[j].n_dist_loci[0] = ndl[(size_t)j * 2], q->seg[j].n_dist_loci[1] = ndl[(size_t)j * 2 + 1];
 	if (pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] marked %ld locally diverged branches and %ld distantly diverged branches\n", "pg_mark_branch_flt_arc", stamp(), (long)n_flt1, (long)n_flt2);
@@ -595,7 +597,6 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 		int32_t max_avg_occ = (int32_t)(opt->max_avg_occ * r + .499);
 		int32_t max_degree = (int32_t)(opt->max_degree * r + .499);
 		int32_t max_dist_loci = (int32_t)(opt->max_dist_loci * r + .499);
-		arc_index(q);
 		BE_CALL(mark_branch_flt_arc(opt, q, ext), "mark_branch_flt_arc");
 		BE_CALL(mark_branch_flt_hit(q, ext), "mark_branch_flt_hit");
 		BE_CALL(be->set_filter(ctx, PGA_FLT_WEAK2), "set_filter");
@@ -606,6 +607,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 		BE_CALL(gen_arc(opt, q, ext), "gen_arc");
 	}
 	BE_CALL(be->set_filter(ctx, PGA_FLT_SHADOW), "set_filter"); // graph.c:316
+	BE_CALL(fetch_arcs(q, ext), "fetch_arcs");
 	if (opt->min_arc_cnt > 1) { // graph.c:191-200
 		int32_t k = 0, n_aflt = 0;
 		for (int32_t i = 0; i < q->n_arc; ++i) {

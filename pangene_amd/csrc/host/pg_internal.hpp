@@ -60,6 +60,8 @@ struct DataExt {
 	std::vector<int64_t> hit_off;      // shard hit offsets
 	std::vector<std::vector<int32_t>> y_order; // per genome: host index of the k-th hit in cm order
 	std::vector<ExactSeg> xsegs;
+	std::vector<int32_t> deg;          // out-degree of every oriented vertex of the round's arc table
+	const pga_arc_part_t *cur_arcs = nullptr; // the round's arc table, in backend memory
 	std::string vtx_sel_text;          // -G output of the current run (printed when pg_graph_gen returns)
 	int exact_mode_of_segs = -1;       // mode xsegs was built for
 	std::vector<std::thread> xworkers; // background replay of the reference's sort sequence
