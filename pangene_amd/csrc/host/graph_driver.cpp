@@ -578,10 +578,10 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	if (ext == nullptr || ext->ctx == nullptr) { set_error(PGA_ERR_ARG, "pg_graph_gen: pg_post_process has not run"); return PGA_ERR_ARG; }
 	const pga_backend_t *be = ext->be;
 	pga_ctx_t *ctx = ext->ctx;
-	if (exact_mode() != 2) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "set_head"); } // index 0 of the S1 order, see post_process_impl
 	// graph 1: initial vertices (graph.c:284-291)
 	BE_CALL(be->set_filter(ctx, PGA_FLT_PSEUDO), "set_filter");
 	BE_CALL(gen_vtx(opt, q, ext), "gen_vtx");
+	if (exact_mode() != 2) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "set_head"); } // index 0 of the S1 order, needed from the first sweep of stage C on (see post_process_impl)
 	BE_CALL(flag_vtx(q, ext), "flag_vtx");
 	BE_CALL(be->set_filter(ctx, PGA_FLT_VTX0), "set_filter");
 	BE_CALL(gen_arc(opt, q, ext), "gen_arc");
