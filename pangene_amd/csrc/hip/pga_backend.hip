@@ -54,7 +54,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
+	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
 	S_COUNT
 };
 
@@ -80,6 +80,7 @@ struct pga_ctx {
 	int64_t *dcnt = 0;      // device counters: [0] triples [1] arcs-temp [2] misc [3] invariant flag, [4..7] hazards
 	int64_t *h_cnt = 0;     // pinned mirror
 	DevPool pool;
+	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
 	int64_t br_n = 0, br_np = 0; int32_t br_S = 0; // arcs / pairs / segments of the last branch_pairs
 	std::vector<TimedLaunch> timed;
 	std::vector<void *> owned;
@@ -1205,6 +1206,7 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 		HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
 		HIPCHK(hipEventRecord(t.a, c->st));
 	}
+	c->walk_valid = false;
 	hipLaunchKernelGGL((k_sweep<MODE>), dim3(nblk(c->N, SW_TILE)), dim3(SW_TILE), 0, c->st, v);
 	if (timed_which >= 0) { HIPCHK(hipEventRecord(t.b, c->st)); c->timed.push_back(t); }
 	return 0;
@@ -1310,6 +1312,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 extern "C" int pga_begin(pga_ctx_t *c)
 {
 	const int N = c->N, GL = c->n_genome;
+	c->walk_valid = false;
 	HIPCHK(hipMemsetAsync(c->dcnt, 0, 16 * sizeof(int64_t), c->st));
 	if (c->Q) hipLaunchKernelGGL(k_fill_i32, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, (int64_t)c->Q, -1);
 	c->n_seg = 0;
@@ -1416,6 +1419,7 @@ extern "C" int pga_post_apply(pga_ctx_t *c, const uint8_t *prot_rep, const uint8
 {
 	uint8_t *d = (uint8_t *)c->pool.get(S_MISC, 2 * (size_t)c->P + 16);
 	if (!d) return PGA_ERR_NOMEM;
+	c->walk_valid = false;
 	TRY(upload(c, d, prot_rep, (size_t)c->P)); TRY(upload(c, d + c->P, prot_pj, (size_t)c->P));
 	HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
 	if (c->N) hipLaunchKernelGGL(k_post_apply, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->nex, c->sdom, c->N, c->max_ori, d, d + c->P, c->dcnt + 2);
@@ -1442,6 +1446,7 @@ extern "C" int pga_shadow(pga_ctx_t *c, int32_t cal_dom_sc, int32_t *stats)
 extern "C" int pga_set_filter(pga_ctx_t *c, int32_t which)
 {
 	if (which < 0 || which > 3) return PGA_ERR_ARG;
+	c->walk_valid = false;
 	if (c->N) hipLaunchKernelGGL(k_set_filter, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->N, which);
 	return 0;
 }
@@ -1489,13 +1494,15 @@ extern "C" int pga_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg)
 static int walk_prev(pga_ctx *c, int32_t **val_out, int32_t **prev_out)
 {
 	const int N = c->N;
-	int32_t *val = (int32_t *)c->pool.get(S_I32_A, sizeof(int32_t) * (size_t)N);
-	int32_t *prev = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
+	int32_t *val = (int32_t *)c->pool.get(S_WALK_VAL, sizeof(int32_t) * (size_t)N);
+	int32_t *prev = (int32_t *)c->pool.get(S_WALK_PREV, sizeof(int32_t) * (size_t)N);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	if (!val || !prev || !tile) return PGA_ERR_NOMEM;
+	*val_out = val, *prev_out = prev;
+	if (c->walk_valid) return 0; // pg_mark_branch_flt_hit walks exactly what the pg_gen_arc before it walked: nothing changed in between
 	hipLaunchKernelGGL(k_walk_mark, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->yperm, N, val);
 	device_scan<I32>(InWalk{val}, OutPrev{prev}, N, tile, OpMax{}, I32{-1}, c->st); // exclusive running max = previous walkable
-	*val_out = val, *prev_out = prev;
+	c->walk_valid = true;
 	return 0;
 }
 
@@ -1765,6 +1772,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
                                   const int64_t *seg_off, const int32_t *file_idx)
 {
 	const int N = c->N;
+	c->walk_valid = false;
 	if (n_seg <= 0 || N == 0) return 0;
 	const int64_t T = seg_off[n_seg];
 	if (T == 0) return 0;
