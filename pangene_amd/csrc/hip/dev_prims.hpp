@@ -185,16 +185,44 @@ __global__ __launch_bounds__(BLOCK) void rs_hist(const uint64_t *__restrict__ ke
 	table[(int64_t)threadIdx.x * n_tile + blockIdx.x] = h[threadIdx.x];
 }
 
+// exclusive scan of each digit's row of per-tile counts (one workgroup per digit) + the digit totals.  Together with the
+// 256-entry prefix every scatter workgroup computes for itself this replaces a general scan of the 256 x n_tile table
+// (three launches) by one launch.
+__global__ __launch_bounds__(BLOCK) void rs_rowscan(uint32_t *__restrict__ table, int n_tile, uint32_t *__restrict__ digit_total)
+{
+	__shared__ I32 wave_tot[BLOCK / WAVE];
+	__shared__ uint32_t carry_s;
+	uint32_t *row = table + (int64_t)blockIdx.x * n_tile;
+	if (threadIdx.x == 0) carry_s = 0;
+	__syncthreads();
+	for (int base = 0; base < n_tile; base += BLOCK) {
+		const int i = base + threadIdx.x;
+		const I32 v{i < n_tile ? (int32_t)row[i] : 0};
+		I32 tot;
+		const I32 excl = block_scan_excl(v, OpSum{}, I32{0}, wave_tot, &tot);
+		const uint32_t carry = carry_s;
+		if (i < n_tile) row[i] = carry + (uint32_t)excl.v;
+		__syncthreads();
+		if (threadIdx.x == 0) carry_s = carry + (uint32_t)tot.v;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) digit_total[blockIdx.x] = carry_s;
+}
+
 __global__ __launch_bounds__(BLOCK) void rs_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                      uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n, int shift,
-                                                     const uint32_t *__restrict__ table, int n_tile)
+                                                     const uint32_t *__restrict__ table, int n_tile, const uint32_t *__restrict__ digit_total)
 {
 	__shared__ uint32_t whist[BLOCK / WAVE][256];
 	__shared__ uint32_t gbase[256];
+	__shared__ I32 wave_tot[BLOCK / WAVE];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
 	for (int k = 0; k < BLOCK / WAVE; ++k) whist[k][threadIdx.x] = 0;
-	gbase[threadIdx.x] = table[(int64_t)threadIdx.x * n_tile + blockIdx.x];
+	{ // base of digit d = keys with a smaller digit (prefix over the 256 totals) + keys with digit d in earlier tiles
+		const I32 excl = block_scan_excl(I32{(int32_t)digit_total[threadIdx.x]}, OpSum{}, I32{0}, wave_tot, (I32 *)nullptr);
+		gbase[threadIdx.x] = (uint32_t)excl.v + table[(int64_t)threadIdx.x * n_tile + blockIdx.x];
+	}
 	__syncthreads();
 	const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (WAVE * RS_ITEMS);
 	const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -256,11 +284,10 @@ static inline void device_radix_sort(uint64_t *keys, uint32_t *vals, int64_t n, 
 	uint32_t *vi = vals, *vo = b.v_alt;
 	if (n > 0) {
 		const int n_tile = (int)rs_tiles(n);
-		const int64_t tl = 256 * (int64_t)n_tile;
 		for (int shift = 0; shift < n_bits; shift += 8) {
 			hipLaunchKernelGGL(rs_hist, dim3((unsigned)n_tile), dim3(BLOCK), 0, st, ki, n, shift, b.table, n_tile);
-			device_scan<I32>(InU32{b.table}, OutExclU32{b.table}, tl, (I32 *)b.tile_buf, OpSum{}, I32{0}, st);
-			hipLaunchKernelGGL(rs_scatter, dim3((unsigned)n_tile), dim3(BLOCK), 0, st, ki, vi, ko, vo, n, shift, b.table, n_tile);
+			hipLaunchKernelGGL(rs_rowscan, dim3(256), dim3(BLOCK), 0, st, b.table, n_tile, (uint32_t *)b.tile_buf);
+			hipLaunchKernelGGL(rs_scatter, dim3((unsigned)n_tile), dim3(BLOCK), 0, st, ki, vi, ko, vo, n, shift, b.table, n_tile, (const uint32_t *)b.tile_buf);
 			uint64_t *tk = ki; ki = ko; ko = tk;
 			uint32_t *tv = vi; vi = vo; vo = tv;
 		}
