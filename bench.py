@@ -96,8 +96,7 @@ def main():
     opt = capi.parse_args(lib, [])
     d = lib.pg_data_init()
     t0 = time.time()
-    for j, f in enumerate(files):
-        (lib.pg_read_paf if lo <= j < hi else lib.pg_scan_paf_ids)(C.byref(opt), d, f.encode())
+    capi.read_files(lib, opt, d, files, [not (lo <= j < hi) for j in range(G)])  # host threads; ids as in sequential reads
     t_parse = time.time() - t0
 
     def one_pass(first):

@@ -171,6 +171,11 @@ int pg_set_output(const char *path);
  * first-seen id numbering (read.c:151-168) is identical on every rank.  Adds an empty genome. */
 int32_t pg_scan_paf_ids(const pg_opt_t *opt, pg_data_t *d, const char *fn);
 
+/* Parse n PAFs on host threads (n_threads <= 0: up to 16) and append them in the given order; gene / protein / contig
+ * ids come out exactly as after n sequential pg_read_paf calls.  ids_only (may be NULL): per file, non-zero = register
+ * the names only, as pg_scan_paf_ids does.  Returns minus the number of files that could not be opened. */
+int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const char *const *fns, const uint8_t *ids_only, int32_t n_threads);
+
 /* Exchange hook: genomes shard across processes (one per GPU); the only communication is a handful
  * of small integer reductions / gathers per round.  NULL (default) = single process. */
 enum { PG_X_I32 = 0, PG_X_I64 = 1 };

@@ -44,6 +44,7 @@ _API = {
     "pg_data_destroy": (None, [C.c_void_p]),
     "pg_read_paf": (C.c_int32, [C.POINTER(pg_opt_t), C.c_void_p, C.c_char_p]),
     "pg_scan_paf_ids": (C.c_int32, [C.POINTER(pg_opt_t), C.c_void_p, C.c_char_p]),
+    "pg_read_paf_batch": (C.c_int32, [C.POINTER(pg_opt_t), C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint8), C.c_int32]),
     "pg_post_process": (None, [C.POINTER(pg_opt_t), C.c_void_p]),
     "pg_graph_init": (C.c_void_p, [C.c_void_p]),
     "pg_graph_gen": (None, [C.POINTER(pg_opt_t), C.c_void_p]),
@@ -123,7 +124,21 @@ def parse_args(lib: C.CDLL, argv: Sequence[str]) -> pg_opt_t:
     return opt
 
 
-def run(lib: C.CDLL, files: Sequence[str], argv: Sequence[str] = (), scan_only: Sequence[bool] | None = None) -> bytes:
+def read_files(lib: C.CDLL, opt, d, files: Sequence[str], scan_only: Sequence[bool] | None = None, n_threads: int = 0, batch: bool = True) -> int:
+    """main.c:121-122 for all files: parsed on host threads (pg_read_paf_batch) or one pg_read_paf / pg_scan_paf_ids per file."""
+    n = len(files)
+    if not batch:
+        rc = 0
+        for k, f in enumerate(files):
+            fn = lib.pg_scan_paf_ids if scan_only is not None and scan_only[k] else lib.pg_read_paf
+            rc += min(0, fn(C.byref(opt), d, f.encode()))
+        return rc
+    fns = (C.c_char_p * max(n, 1))(*[f.encode() for f in files])
+    mask = (C.c_uint8 * max(n, 1))(*[1 if scan_only is not None and scan_only[k] else 0 for k in range(n)])
+    return lib.pg_read_paf_batch(C.byref(opt), d, n, fns, mask, n_threads)
+
+
+def run(lib: C.CDLL, files: Sequence[str], argv: Sequence[str] = (), scan_only: Sequence[bool] | None = None, batch: bool = True) -> bytes:
     """main.c:117-142 in-process: returns what the command line would print to stdout."""
     opt = parse_args(lib, argv)
     fd, out = tempfile.mkstemp(prefix="pangene_", suffix=".out")
@@ -131,11 +146,7 @@ def run(lib: C.CDLL, files: Sequence[str], argv: Sequence[str] = (), scan_only: 
     lib.pg_set_output(out.encode())
     d = lib.pg_data_init()
     try:
-        for k, f in enumerate(files):
-            if scan_only is not None and scan_only[k]:
-                lib.pg_scan_paf_ids(C.byref(opt), d, f.encode())
-            else:
-                lib.pg_read_paf(C.byref(opt), d, f.encode())
+        read_files(lib, opt, d, files, scan_only, batch=batch)
         lib.pg_post_process(C.byref(opt), d)
         if lib.pg_last_error():
             raise RuntimeError("pangene_amd: " + lib.pg_last_error_str().decode())

@@ -100,7 +100,7 @@ int main(int argc, char *argv[])
 	}
 	if (argc - optind < 1) return usage(stderr, &opt);
 	pg_data_t *d = pg_data_init();
-	for (int i = optind; i < argc; ++i) pg_read_paf(&opt, d, argv[i]);
+	pg_read_paf_batch(&opt, d, argc - optind, argv + optind, nullptr, 0); // parallel parse, ids as in sequential pg_read_paf calls
 	pg_post_process(&opt, d);
 	int rc = 0;
 	if (pg_last_error()) rc = 2;

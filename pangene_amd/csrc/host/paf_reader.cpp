@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include "pg_internal.hpp"
 
 namespace pgx {
@@ -163,30 +165,34 @@ static char *file_label(const char *fn) // read.c:92-105
 	return label;
 }
 
-static int32_t read_paf_impl(const pg_opt_t *opt, pg_data_t *d, const char *fn, bool ids_only)
+// One parsed PAF file, self-contained (no global ids yet): parsing is thread-safe and files can be parsed in
+// parallel; commit_file() then assigns the global ids sequentially in command-line order, which reproduces the
+// reference's first-seen numbering (read.c:151-168) -- pg_hash_uint32(pid) makes the numbering score-relevant.
+struct FileParse {
+	bool opened = false, ids_only = false;
+	char *label = nullptr;
+	int32_t n_tot = 0;
+	NameDict genes, prots, ctgs;              // local first-seen ids
+	std::vector<uint8_t> g_pref, g_incl;      // per local gene (read.c:147-150,158-159)
+	std::vector<int32_t> g_len, p_gene, p_len; // gene.len = max protein len (read.c:177); prot.gid, prot.len of the last line
+	std::vector<int64_t> ctg_len;
+	std::vector<pg_hit_t> hits;               // pid / cid are LOCAL ids
+	std::vector<pg_exon_t> exons;
+};
+
+static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileParse &fp)
 {
 	LineSource src(fn);
-	if (!src.ok()) return -1;
-	NameDict *dg = (NameDict *)d->d_gene, *dp = (NameDict *)d->d_prot, *dc = (NameDict *)d->d_ctg;
+	fp.ids_only = ids_only;
+	if (!src.ok()) return;
+	fp.opened = true;
+	fp.label = file_label(fn);
 	const NameDict *excl = (const NameDict *)opt->excl, *incl = (const NameDict *)opt->incl, *pref = (const NameDict *)opt->preferred;
-	DataExt *ext = ext_of(d, true);
-
-	grow0(d->genome, d->n_genome, d->m_genome);
-	pg_genome_t *g = &d->genome[d->n_genome++];
-	std::memset(g, 0, sizeof(*g));
-	g->label = file_label(fn);
-	ext->is_local.resize(d->n_genome, 0);
-	ext->hits_sorted.resize(d->n_genome, 0);
-	ext->is_local[d->n_genome - 1] = ids_only ? 0 : 1;
-
-	std::unordered_map<std::string_view, int32_t> file_ctg; // contig ids are first-seen per file (read.c:190-198)
-	std::vector<int32_t> rank_of;                            // per protein: lines seen in this file (read.c:170)
-	std::vector<int32_t> rank_touched;
+	std::vector<int32_t> rank_of; // per local protein: lines seen in this file (read.c:170)
 	std::vector<pg_exon_t> ex;
 	std::string line;
-	int32_t n_tot = 0;
 	while (src.next(line)) {
-		++n_tot;
+		++fp.n_tot;
 		pg_hit_t hit;
 		std::memset(&hit, 0, sizeof(hit));
 		hit.pid = hit.pid_dom = hit.cid = hit.off_exon = hit.n_exon = -1;
@@ -209,44 +215,33 @@ static int32_t read_paf_impl(const pg_opt_t *opt, pg_data_t *d, const char *fn, 
 				if (excl && excl->get(q) >= 0) { dropped = true; break; }
 				int32_t is_pref = pref && pref->get(q) >= 0, is_incl = incl && incl->get(q) >= 0;
 				bool absent;
-				gid = dg->put(q, &absent);
+				gid = fp.genes.put(q, &absent);
 				if (has_delim) *r = (char)opt->gene_delim;
-				if (absent) { d->n_gene++; grow0(d->gene, gid, d->m_gene); }
-				d->gene[gid].name = dg->name(gid);
-				d->gene[gid].preferred = is_pref, d->gene[gid].included = is_incl;
-				pid = dp->put(q, &absent);
-				if (absent) { d->n_prot++; grow0(d->prot, pid, d->m_prot); }
-				d->prot[pid].name = dp->name(pid);
-				d->prot[pid].gid = gid;
-				d->prot[pid].len = 0;
+				if (absent) fp.g_pref.push_back(0), fp.g_incl.push_back(0), fp.g_len.push_back(0);
+				fp.g_pref[(size_t)gid] = (uint8_t)is_pref, fp.g_incl[(size_t)gid] = (uint8_t)is_incl;
+				pid = fp.prots.put(q, &absent);
+				if (absent) fp.p_gene.push_back(0), fp.p_len.push_back(0), rank_of.push_back(-1);
+				fp.p_gene[(size_t)pid] = gid;
+				fp.p_len[(size_t)pid] = 0; // read.c:168
 				hit.pid = pid;
-				if ((int32_t)rank_of.size() <= pid) rank_of.resize((size_t)pid + 1 + (pid >> 1), -1);
-				if (rank_of[pid] < 0) rank_touched.push_back(pid);
-				hit.rank = ++rank_of[pid];
+				hit.rank = ++rank_of[(size_t)pid];
 			} else if (col == 1) {
 				int32_t len = (int32_t)std::strtol(q, nullptr, 10);
-				d->prot[pid].len = len;
-				if ((int32_t)d->gene[gid].len < len) d->gene[gid].len = (uint32_t)len;
+				fp.p_len[(size_t)pid] = len;
+				if (fp.g_len[(size_t)gid] < len) fp.g_len[(size_t)gid] = len;
 				if (ids_only) { dropped = true; break; }
 			} else if (col == 2) hit.qs = (int32_t)std::strtol(q, nullptr, 10);
 			else if (col == 3) {
 				hit.qe = (int32_t)std::strtol(q, nullptr, 10);
-				if (hit.qe - hit.qs < d->prot[pid].len * opt->min_prot_ratio) { dropped = true; break; }
+				if (hit.qe - hit.qs < fp.p_len[(size_t)pid] * opt->min_prot_ratio) { dropped = true; break; }
 			} else if (col == 4) {
 				if (*q != '+' && *q != '-') { dropped = true; break; }
 				hit.rev = *q == '+' ? 0 : 1;
-			} else if (col == 5) {
-				auto it = file_ctg.find(std::string_view(q));
-				if (it == file_ctg.end()) {
-					bool a2;
-					int32_t gc = dc->put(q, &a2);
-					grow0(g->ctg, g->n_ctg, g->m_ctg);
-					g->ctg[g->n_ctg].name = dc->name(gc);
-					it = file_ctg.emplace(std::string_view(dc->name(gc)), g->n_ctg).first;
-					g->n_ctg++;
-				}
-				hit.cid = it->second;
-			} else if (col == 6) g->ctg[hit.cid].len = std::strtol(q, nullptr, 10);
+			} else if (col == 5) { // contig ids are first-seen per file (read.c:190-198)
+				bool a2;
+				hit.cid = fp.ctgs.put(q, &a2);
+				if (a2) fp.ctg_len.push_back(0);
+			} else if (col == 6) fp.ctg_len[(size_t)hit.cid] = std::strtol(q, nullptr, 10);
 			else if (col == 7) hit.cs = std::strtol(q, nullptr, 10);
 			else if (col == 8) hit.ce = std::strtol(q, nullptr, 10);
 			else if (col == 9) hit.mlen = (int32_t)std::strtol(q, nullptr, 10);
@@ -256,20 +251,18 @@ static int32_t read_paf_impl(const pg_opt_t *opt, pg_data_t *d, const char *fn, 
 			} else if (col >= 12) {
 				if (std::strncmp(q, "ms:i:", 5) == 0) { // read.c:212-216: long double exp, then truncation
 					double div = 1.0 - (double)hit.mlen / hit.blen;
-					double uncov = 1.0 - (double)(hit.qe - hit.qs) / d->prot[pid].len;
+					double uncov = 1.0 - (double)(hit.qe - hit.qs) / fp.p_len[(size_t)pid];
 					hit.score_ori = (int32_t)std::strtol(q + 5, nullptr, 10);
 					hit.score_adj = (int32_t)(hit.score_ori * expl(-opt->score_adj_coef * (div + uncov)) + .499);
 				} else if (std::strncmp(q, "fs:i:", 5) == 0) n_fs = (int32_t)std::strtol(q + 5, nullptr, 10);
 				else if (std::strncmp(q, "st:i:", 5) == 0) n_stop = (int32_t)std::strtol(q + 5, nullptr, 10);
 				else if (std::strncmp(q, "cg:Z:", 5) == 0) {
 					if (cigar_to_exons(q + 5, hit.rev, hit.ce - hit.cs, ex, &cig_fs)) {
-						grow0(g->exon, g->n_exon + (int32_t)ex.size() - 1, g->m_exon);
-						std::memcpy(g->exon + g->n_exon, ex.data(), ex.size() * sizeof(pg_exon_t));
-						hit.n_exon = (int32_t)ex.size(), hit.off_exon = g->n_exon, hit.lof = cig_fs;
-						g->n_exon += (int32_t)ex.size();
+						hit.n_exon = (int32_t)ex.size(), hit.off_exon = (int32_t)fp.exons.size(), hit.lof = cig_fs;
+						fp.exons.insert(fp.exons.end(), ex.begin(), ex.end());
 						have_exons = true;
 					} else if (pg_verbose >= 1) {
-						std::fprintf(stderr, "[W::%s] CIGAR of line %d in '%s' does not span the alignment; hit dropped\n", __func__, n_tot, fn ? fn : "-");
+						std::fprintf(stderr, "[W::%s] CIGAR of line %d in '%s' does not span the alignment; hit dropped\n", __func__, fp.n_tot, fn ? fn : "-");
 					}
 				}
 			}
@@ -279,15 +272,73 @@ static int32_t read_paf_impl(const pg_opt_t *opt, pg_data_t *d, const char *fn, 
 		if (dropped || !have_exons || hit.n_exon < 1) continue;
 		int32_t lof = (n_fs > 0 ? n_fs : 0) + (n_stop > 0 ? n_stop : 0); // read.c:230-231
 		if (hit.lof < lof) hit.lof = lof;
-		hit.cm = middle_cds(hit.cs, g->exon + hit.off_exon, hit.n_exon);
+		hit.cm = middle_cds(hit.cs, fp.exons.data() + hit.off_exon, hit.n_exon);
 		if (hit.cm < 0) continue;
-		grow0(g->hit, g->n_hit, g->m_hit);
-		g->hit[g->n_hit++] = hit;
+		fp.hits.push_back(hit);
+	}
+}
+
+// sequential part: global ids in first-seen order, genome appended to `d`
+static int32_t commit_file(pg_data_t *d, FileParse &fp)
+{
+	if (!fp.opened) return -1;
+	NameDict *dg = (NameDict *)d->d_gene, *dp = (NameDict *)d->d_prot, *dc = (NameDict *)d->d_ctg;
+	DataExt *ext = ext_of(d, true);
+	grow0(d->genome, d->n_genome, d->m_genome);
+	pg_genome_t *g = &d->genome[d->n_genome++];
+	std::memset(g, 0, sizeof(*g));
+	g->label = fp.label, fp.label = nullptr;
+	ext->is_local.resize((size_t)d->n_genome, 0);
+	ext->hits_sorted.resize((size_t)d->n_genome, 0);
+	ext->is_local[(size_t)d->n_genome - 1] = fp.ids_only ? 0 : 1;
+	// genes then proteins, each in the order this file saw them first: the same numbering as per-line dict_put calls
+	std::vector<int32_t> gmap((size_t)fp.genes.size()), pmap((size_t)fp.prots.size());
+	for (int32_t i = 0; i < fp.genes.size(); ++i) {
+		bool absent;
+		const int32_t gid = dg->put(fp.genes.name(i), &absent);
+		if (absent) { d->n_gene++; grow0(d->gene, gid, d->m_gene); }
+		d->gene[gid].name = dg->name(gid);
+		d->gene[gid].preferred = fp.g_pref[(size_t)i], d->gene[gid].included = fp.g_incl[(size_t)i];
+		if ((int32_t)d->gene[gid].len < fp.g_len[(size_t)i]) d->gene[gid].len = (uint32_t)fp.g_len[(size_t)i];
+		gmap[(size_t)i] = gid;
+	}
+	for (int32_t i = 0; i < fp.prots.size(); ++i) {
+		bool absent;
+		const int32_t pid = dp->put(fp.prots.name(i), &absent);
+		if (absent) { d->n_prot++; grow0(d->prot, pid, d->m_prot); }
+		d->prot[pid].name = dp->name(pid);
+		d->prot[pid].gid = gmap[(size_t)fp.p_gene[(size_t)i]];
+		d->prot[pid].len = fp.p_len[(size_t)i];
+		pmap[(size_t)i] = pid;
+	}
+	if (!fp.ids_only) {
+		g->n_ctg = g->m_ctg = fp.ctgs.size();
+		g->ctg = (pg_ctg_t *)std::calloc((size_t)(g->n_ctg > 0 ? g->n_ctg : 1), sizeof(pg_ctg_t));
+		for (int32_t c = 0; c < g->n_ctg; ++c) {
+			bool a2;
+			g->ctg[c].name = dc->name(dc->put(fp.ctgs.name(c), &a2));
+			g->ctg[c].len = fp.ctg_len[(size_t)c];
+		}
+		g->n_hit = g->m_hit = (int32_t)fp.hits.size();
+		g->hit = (pg_hit_t *)std::malloc(sizeof(pg_hit_t) * (size_t)(g->n_hit > 0 ? g->n_hit : 1));
+		for (int32_t i = 0; i < g->n_hit; ++i) { g->hit[i] = fp.hits[(size_t)i]; g->hit[i].pid = pmap[(size_t)fp.hits[(size_t)i].pid]; }
+		g->n_exon = g->m_exon = (int32_t)fp.exons.size();
+		g->exon = (pg_exon_t *)std::malloc(sizeof(pg_exon_t) * (size_t)(g->n_exon > 0 ? g->n_exon : 1));
+		if (g->n_exon) std::memcpy(g->exon, fp.exons.data(), sizeof(pg_exon_t) * (size_t)g->n_exon);
 	}
 	if (pg_verbose >= 3)
-		std::fprintf(stderr, "[M::%s::%s] [%d] %s: %d lines parsed, %d hits kept%s\n", __func__, stamp(), d->n_genome - 1,
-		             g->label ? g->label : "-", n_tot, g->n_hit, ids_only ? " (ids only; hits owned by another shard)" : "");
+		std::fprintf(stderr, "[M::%s::%s] [%d] %s: %d lines parsed, %d hits kept%s\n", "pg_read_paf", stamp(), d->n_genome - 1,
+		             g->label ? g->label : "-", fp.n_tot, g->n_hit, fp.ids_only ? " (ids only; hits owned by another shard)" : "");
 	return 0;
+}
+
+static int32_t read_paf_impl(const pg_opt_t *opt, pg_data_t *d, const char *fn, bool ids_only)
+{
+	FileParse fp;
+	parse_file(opt, fn, ids_only, fp);
+	int32_t rc = commit_file(d, fp);
+	std::free(fp.label);
+	return rc;
 }
 
 } // namespace pgx
@@ -318,6 +369,25 @@ void pg_data_destroy(pg_data_t *d)
 
 int32_t pg_read_paf(const pg_opt_t *opt, pg_data_t *d, const char *fn) { return read_paf_impl(opt, d, fn, false); }
 int32_t pg_scan_paf_ids(const pg_opt_t *opt, pg_data_t *d, const char *fn) { return read_paf_impl(opt, d, fn, true); }
+
+// parse many PAFs on host threads, commit them in command-line order (ids identical to n sequential
+// pg_read_paf / pg_scan_paf_ids calls).  ids_only[i] != 0: register names only (the hits belong to another shard).
+int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const char *const *fns, const uint8_t *ids_only, int32_t n_threads)
+{
+	if (n <= 0) return 0;
+	if (n_threads <= 0) n_threads = (int32_t)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+	if (n_threads > n) n_threads = n;
+	std::vector<FileParse> fp((size_t)n);
+	std::atomic<int32_t> next{0};
+	auto work = [&]() { for (;;) { int32_t i = next.fetch_add(1); if (i >= n) break; parse_file(opt, fns[i], ids_only && ids_only[i], fp[(size_t)i]); } };
+	std::vector<std::thread> th;
+	for (int32_t t = 1; t < n_threads; ++t) th.emplace_back(work);
+	work();
+	for (auto &x : th) x.join();
+	int32_t n_fail = 0;
+	for (int32_t i = 0; i < n; ++i) { if (commit_file(d, fp[(size_t)i]) != 0) ++n_fail; std::free(fp[(size_t)i].label); }
+	return -n_fail;
+}
 
 // "-X a,b,c" or "-X @file" (first token of each line) -> name set (read.c:265-318)
 void *pg_read_list_dict(const char *o)

@@ -68,3 +68,12 @@ def test_live_against_reference_binary(ora, tmp_path, seed):
             mine = capi.run(ora, fs, args)
             want = subprocess.run([ref] + args + fs, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
             assert mine == want
+
+
+@pytest.mark.parametrize("name", ["C4", "bact20", "human8f", "fuzz3"])
+def test_batch_reader_equals_sequential_reader(built, name):
+    """pg_read_paf_batch (threads + ordered commit) numbers genes/proteins exactly like per-file pg_read_paf calls."""
+    ora = capi.load(oracle_host=True)
+    fs = golden_files(name)
+    for args in ([], ["-w"], ["--bed=flag"]):
+        assert capi.run(ora, fs, args, batch=True) == capi.run(ora, fs, args, batch=False)

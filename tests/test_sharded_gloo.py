@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT, golden_files
 
 
-def _worker(rank, world, port, files, variant, q):
+def _worker(rank, world, port, files, variant, q, cuts=None):
     import ctypes as C
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -23,7 +23,7 @@ def _worker(rank, world, port, files, variant, q):
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     keep = exchange.install(lib)
     n = len(files)
-    lo, hi = n * rank // world, n * (rank + 1) // world
+    lo, hi = (cuts[rank], cuts[rank + 1]) if cuts else (n * rank // world, n * (rank + 1) // world)
     out = capi.run(lib, files, variant, scan_only=[not (lo <= k < hi) for k in range(n)])
     q.put((rank, out))
     dist.barrier()
@@ -39,23 +39,32 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8", ""), ("C4", ""), ("human8f", "-p0 -a1"), ("fuzz2", "-F")])
-def test_two_ranks_equal_single_process(built, expected, name, variant):
-    files = golden_files(name)
+def _sharded(files, variant, world, cuts=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, files, variant.split(), q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, files, variant.split(), q, cuts)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    import gzip
+    return res
+
+
+@pytest.mark.parametrize("name,variant,world,cuts", [
+    ("bact20", "", 2, None), ("human8", "", 2, None), ("C4", "", 2, None), ("human8f", "-p0 -a1", 2, None), ("fuzz2", "-F", 2, None),
+    ("bact20", "", 3, None),             # uneven shards
+    ("bact20", "", 2, [0, 20, 20]),      # a rank that owns no genome still takes part in every exchange
+    ("human8", "", 3, [0, 0, 5, 8]),
+])
+def test_ranks_equal_single_process(built, expected, name, variant, world, cuts):
+    files = golden_files(name)
+    res = _sharded(files, variant, world, cuts)
     gold = expected[name][variant]
-    sl = [b"\n".join(l for l in res[r].split(b"\n") if l[:1] in (b"S", b"L")) for r in (0, 1)]
-    assert sl[0] == sl[1]
-    w = b"\n".join(l for r in (0, 1) for l in res[r].split(b"\n") if l[:1] == b"W")
+    sl = [b"\n".join(l for l in res[r].split(b"\n") if l[:1] in (b"S", b"L")) for r in range(world)]
+    assert all(x == sl[0] for x in sl)
+    w = b"\n".join(l for r in range(world) for l in res[r].split(b"\n") if l[:1] == b"W")
     whole = sl[0] + b"\n" + w + b"\n"
     assert hashlib.md5(whole).hexdigest() == gold["md5"], "sharded output differs from the reference's single-process GFA"
