@@ -346,31 +346,12 @@ __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBe
 	r.best = upd ? sp : r.best, r.j = upd ? pi : r.j, r.ov = upd ? x : r.ov, r.pid = upd ? c.w : r.pid, r.cds = upd ? b.w : r.cds;
 }
 
+// Slow path of the sweep: thread-per-hit walk over all partners of hit t in both directions (LDS window first, then
+// global memory).  Used for hits whose partners reach beyond the staged window and for tiles whose pair list does
+// not fit in LDS.
 template <int MODE>
-__global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
+__device__ __forceinline__ void sw_walk(const SweepView &v, const SwHit &t, SwBest &r, const int4 *sA, const int4 *sB, const int4 *sC, const uint32_t *sF, int base, int lh)
 {
-	__shared__ int4 sA[SW_LDS], sB[SW_LDS], sC[SW_LDS];
-	__shared__ uint32_t sF[SW_LDS];
-	const int base = blockIdx.x * SW_TILE - SW_HALO;
-	for (int l = threadIdx.x; l < SW_LDS; l += SW_TILE) {
-		const int g = base + l;
-		if (g >= 0 && g < v.n) sA[l] = v.A[g], sB[l] = v.B[g], sC[l] = v.C[g], sF[l] = v.flags[g];
-		else sA[l] = make_int4(-2, 0, 0, 0), sF[l] = PGA_F_FLT;
-	}
-	__syncthreads();
-	const int h = blockIdx.x * SW_TILE + threadIdx.x;
-	if (h >= v.n) return;
-	const int lh = threadIdx.x + SW_HALO;
-	const uint32_t fl = sF[lh];
-	if (fl & PGA_F_FLT) return; // filtered hits keep stale shadow/pid_dom (overlap.c:112)
-	SwHit t;
-	{
-		const int4 a = sA[lh], b = sB[lh], c = sC[lh];
-		t.sg = a.x, t.cs = a.y, t.ce = a.z, t.gid = b.z, t.cds = b.w, t.rank = c.x, t.nex = c.y, t.offx = c.z;
-		t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
-		t.sc = (uint64_t)(uint32_t)b.x | (uint64_t)(uint32_t)b.y << 32;
-	}
-	SwBest r = { false, 0, -1, 0, -1, 0 };
 	// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so the
 	// walk stops at the first j whose pm is <= cs_h.
 	{
@@ -407,6 +388,174 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 				if (a.x != t.sg || a.y >= t.ce) break;
 				sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i, true);
 			}
+	}
+}
+
+// One overlapping pair out of LDS, evaluated ONCE for both members: slot l precedes slot m in the array (l is "j",
+// m is "i" of overlap.c:126-154 / 76-87).  Returns 0 if the pair does not count, else 2 | (the later hit loses).
+template <int MODE>
+__device__ __forceinline__ uint32_t sw_pair_once(const SweepView &v, const int4 *sA, const int4 *sB, const int4 *sC, const uint32_t *sF, int l, int m)
+{
+	const uint32_t fj = sF[l], fi = sF[m];
+	const int4 aj = sA[l], ai = sA[m], bj = sB[l], bi = sB[m], cj = sC[l], ci = sC[m];
+	bool ok = !((fj | fi) & PGA_F_FLT);
+	if (v.check_strand) ok = ok && !((fj ^ fi) & PGA_F_REV);
+	const bool same_gene = bj.z == bi.z;
+	if (MODE == 2) ok = ok && same_gene;
+	int x;
+	if (__ballot(ok && (cj.y != 1 || ci.y != 1)) == 0) { // every pair of the wave single-exon x single-exon
+		const int s0 = aj.y > ai.y ? aj.y : ai.y, e0 = aj.z < ai.z ? aj.z : ai.z;
+		x = e0 > s0 ? e0 - s0 : 0;
+	} else {
+		x = ok ? cds_inter(v.exon, cj.z, cj.y, aj.y, aj.z, ci.z, ci.y, ai.y, ai.z) : 0;
+	}
+	ok = ok && x > 0; // overlap.c:132
+	const uint64_t s_j = (uint64_t)(uint32_t)bj.x | (uint64_t)(uint32_t)bj.y << 32, s_i = (uint64_t)(uint32_t)bi.x | (uint64_t)(uint32_t)bi.y << 32;
+	bool i_loses = s_i < s_j || (s_i == s_j && ci.x > cj.x);
+	if (MODE != 2) {
+		const int mn = bi.w < bj.w ? bi.w : bj.w;
+		bool too_short; // cov_short < min_ov_ratio, overlap.c:134-136 (see sw_pair for the exact integer form)
+		if (v.min_ov == 0.5) too_short = 2 * (int64_t)x < (int64_t)mn;
+		else too_short = (double)x / (mn > 0 ? mn : 1) < v.min_ov;
+		ok = ok && (same_gene || !too_short);
+		const int wk_i = (int)((fi & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), wk_j = (int)((fj & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
+		i_loses = (!same_gene && wk_i != wk_j) ? wk_i > wk_j : i_loses; // overlap.c:139-147
+	}
+	return ok ? 2u | (i_loses ? 1u : 0u) : 0u;
+}
+
+// The interval-dominance sweep as an LDS pair list.  A workgroup owns SW_TILE consecutive hits (cs order) and stages
+// their records plus SW_HALO neighbours on each side.  Because hits are cs-sorted inside a contig, the later partners
+// of a hit are a contiguous run; the runs are counted, prefix-summed over the workgroup and expanded into a list of
+// (earlier, later) slot pairs with at least one member in the tile.  The list is then evaluated with one pair per
+// lane (full lanes, every pair once -- a thread-per-hit walk evaluates each pair twice and runs as long as the
+// busiest lane of the wave).  Outcomes go to the loser through LDS atomics: a lose flag, the 64-bit max of the
+// winner's score key, then the smallest winner slot among those with that key ("first in array order", overlap.c:150).
+// Pairs across a tile border are evaluated by both tiles, each updating only its own hit, so there are no global atomics.
+constexpr int SW_CAP = 4096;
+
+template <int MODE>
+__global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
+{
+	__shared__ int4 sA[SW_LDS], sB[SW_LDS], sC[SW_LDS];
+	__shared__ uint32_t sF[SW_LDS];
+	__shared__ uint32_t sPair[SW_CAP];
+	__shared__ unsigned long long sBest[SW_TILE];
+	__shared__ uint32_t sIdx[SW_TILE];
+	__shared__ uint8_t sLose[SW_TILE];
+	__shared__ int sWave[SW_TILE / 64];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int base = blockIdx.x * SW_TILE - SW_HALO;
+	for (int l = tid; l < SW_LDS; l += SW_TILE) {
+		const int g = base + l;
+		if (g >= 0 && g < v.n) sA[l] = v.A[g], sB[l] = v.B[g], sC[l] = v.C[g], sF[l] = v.flags[g];
+		else sA[l] = make_int4(-2, 0, 0, 0), sF[l] = PGA_F_FLT;
+	}
+	sBest[tid] = 0, sIdx[tid] = 0xffffffffu, sLose[tid] = 0;
+	__syncthreads();
+	// later partners of a slot: the run (l, l+n]; only the part that has a member inside the tile is listed
+	int first[2] = { 0, 0 }, cnt[2] = { 0, 0 };
+#pragma unroll
+	for (int k = 0; k < 2; ++k) {
+		const int l = k == 0 ? tid : tid + SW_HALO; // k == 0: left-halo slot (first SW_HALO threads); k == 1: this thread's tile slot
+		if (k == 0 && tid >= SW_HALO) continue;
+		const int4 a = sA[l];
+		if (sF[l] & PGA_F_FLT) continue;
+		int m = l + 1;
+		for (; m < SW_LDS; ++m) {
+			const int2 q = *(const int2 *)&sA[m];
+			if (q.x != a.x || q.y >= a.z) break;
+		}
+		first[k] = k == 0 ? SW_HALO : l + 1;
+		cnt[k] = m > first[k] ? m - first[k] : 0;
+	}
+	const int c = cnt[0] + cnt[1];
+	int inc = c;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const int y = __shfl_up(inc, d);
+		if (lane >= d) inc += y;
+	}
+	if (lane == 63) sWave[wave] = inc;
+	__syncthreads();
+	int off = inc - c, tot = 0;
+#pragma unroll
+	for (int w = 0; w < SW_TILE / 64; ++w) {
+		const int x = sWave[w];
+		off += w < wave ? x : 0, tot += x;
+	}
+	const bool listed = tot <= SW_CAP; // uniform
+	if (listed) {
+		for (int k = 0; k < cnt[0]; ++k) sPair[off + k] = (uint32_t)tid << 10 | (uint32_t)(first[0] + k);
+		off += cnt[0];
+		for (int k = 0; k < cnt[1]; ++k) sPair[off + k] = (uint32_t)(tid + SW_HALO) << 10 | (uint32_t)(first[1] + k);
+		__syncthreads();
+		for (int p = tid; p < tot; p += SW_TILE) {
+			const uint32_t w = sPair[p];
+			const int l = (int)(w >> 10), m = (int)(w & 1023u);
+			const uint32_t res = sw_pair_once<MODE>(v, sA, sB, sC, sF, l, m);
+			if (res) {
+				const int L = (res & 1) ? m : l, W = (res & 1) ? l : m, Lt = L - SW_HALO;
+				if ((unsigned)Lt < (unsigned)SW_TILE) {
+					sLose[Lt] = 1;
+					if (MODE != 2) {
+						const int4 bw = sB[W];
+						const unsigned long long sp = (unsigned long long)(uint32_t)bw.x | (unsigned long long)(uint32_t)bw.y << 32;
+						if (sp > 0) atomicMax(&sBest[Lt], sp);
+					}
+				}
+			}
+			if (MODE != 2) sPair[p] = w | res << 20;
+		}
+		if (MODE != 2) {
+			__syncthreads();
+			for (int p = tid; p < tot; p += SW_TILE) {
+				const uint32_t w = sPair[p], res = w >> 20;
+				if (!res) continue;
+				const int l = (int)(w >> 10 & 1023u), m = (int)(w & 1023u);
+				const int L = (res & 1) ? m : l, W = (res & 1) ? l : m, Lt = L - SW_HALO;
+				if ((unsigned)Lt >= (unsigned)SW_TILE) continue;
+				const int4 bw = sB[W];
+				const unsigned long long sp = (unsigned long long)(uint32_t)bw.x | (unsigned long long)(uint32_t)bw.y << 32;
+				if (sp > 0 && sp == sBest[Lt]) {
+					const uint32_t old = atomicMin(&sIdx[Lt], (uint32_t)W);
+					if (old != 0xffffffffu) atomicAdd((unsigned long long *)&v.hz[3], 1ull); // hazard H3: two winners with the best key
+				}
+			}
+		}
+		__syncthreads();
+	}
+	const int h = blockIdx.x * SW_TILE + tid;
+	if (h >= v.n) return;
+	const int lh = tid + SW_HALO;
+	const uint32_t fl = sF[lh];
+	if (fl & PGA_F_FLT) return; // filtered hits keep stale shadow/pid_dom (overlap.c:112)
+	SwHit t;
+	{
+		const int4 a = sA[lh], b = sB[lh], c2 = sC[lh];
+		t.sg = a.x, t.cs = a.y, t.ce = a.z, t.gid = b.z, t.cds = b.w, t.rank = c2.x, t.nex = c2.y, t.offx = c2.z;
+		t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
+		t.sc = (uint64_t)(uint32_t)b.x | (uint64_t)(uint32_t)b.y << 32;
+	}
+	SwBest r = { false, 0, -1, 0, -1, 0 };
+	// partners outside the staged window?  (pm = running max of ce is non-decreasing inside a contig)
+	const int4 w0 = sA[0], w1 = sA[SW_LDS - 1];
+	const bool open = (w0.x == t.sg && w0.w > t.cs) || (w1.x == t.sg && w1.y < t.ce);
+	if (!listed || open) {
+		sw_walk<MODE>(v, t, r, sA, sB, sC, sF, base, lh);
+	} else {
+		r.lose = sLose[tid] != 0;
+		if (MODE != 2) {
+			r.best = sBest[tid];
+			if (r.best > 0) {
+				const int W = (int)sIdx[tid];
+				const int4 aw = sA[W], bw = sB[W], cw = sC[W];
+				r.j = base + W, r.pid = cw.w, r.cds = bw.w;
+				if (MODE == 1)
+					r.ov = W < lh ? cds_inter(v.exon, cw.z, cw.y, aw.y, aw.z, t.offx, t.nex, t.cs, t.ce)
+					              : cds_inter(v.exon, t.offx, t.nex, t.cs, t.ce, cw.z, cw.y, aw.y, aw.z);
+			}
+		}
 	}
 	if (MODE == 2) {
 		if (r.lose) v.flags[h] = fl | PGA_F_ISO_OV;
