@@ -27,6 +27,7 @@ using namespace pgd;
 	fprintf(stderr, "[E::pga] %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return PGA_ERR_NO_DEVICE; } } while (0)
 
 #define F_HEAD 0x80000000u   // static: first hit of its genome in X order (index-0 quirk, overlap.c:108)
+#define F_MULTI 0x40000000u  // static: the hit has more than one exon (lets the sweep skip the exon records)
 #define F_PUBLIC 0x7ffu
 
 static inline unsigned nblk(int64_t n, int per = BLOCK) { return (unsigned)((n + per - 1) / per); }
@@ -54,7 +55,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC,
+	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC, S_SLOW,
 	S_COUNT
 };
 
@@ -64,6 +65,8 @@ struct pga_ctx {
 	hipStream_t st = nullptr; bool own_stream = false;
 	int32_t n_genome = 0, n_genome_global = 0, P = 0, Q = 0, n_seg_ctg = 0;
 	int32_t N = 0, E = 0;
+	int n_cu = 256;
+	uint32_t sweep_seq = 0; // parity selects the slow-list counter (dcnt[12] / dcnt[13])
 	pga_params_t par;
 	std::vector<int32_t> h_goff, h_ggl;
 	// static per hit (X order)
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(FileHits f, const int32_t *gnm
 	o.cs[h] = f.cs[s], o.ce[h] = f.ce[s], o.cm[h] = f.cm[s], o.cds[h] = cds_f[s], o.nex[h] = f.nex[s], o.offx[h] = f.offx[s];
 	o.sori[h] = f.sori[s], o.sadj[h] = f.sadj[s], o.rank[h] = f.rank[s], o.sc64[h] = sc64_f[s];
 	o.sdom[h] = 0, o.pdom[h] = -1, o.pdom0[h] = 0; // read.c:133-134
-	o.flags[h] = (f.rev[s] ? PGA_F_REV : 0u) | (h == goff[g] ? F_HEAD : 0u);
+	o.flags[h] = (f.rev[s] ? PGA_F_REV : 0u) | (h == goff[g] ? F_HEAD : 0u) | (f.nex[s] != 1 ? F_MULTI : 0u);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_ykey(const int32_t *seg, const int32_t *cm, int n, int cm_bits, uint64_t *key, uint32_t *val)
@@ -256,6 +259,8 @@ struct SweepView {
 	uint32_t *flags; int32_t *pdom, *sdom;
 	int n; double min_ov; int check_strand;
 	int64_t *hz;
+	int64_t *slow_cnt; int32_t *slow_list; // work list for k_sweep_slow
+	long long *prof; // PGA_SW_PROFILE builds only
 };
 
 // CDS intersection of hit a (exons ea[na], start ca) and hit b: pg_hit_overlap, overlap.c:6-42
@@ -284,14 +289,7 @@ __device__ __forceinline__ int cds_inter(const int2 *__restrict__ ex, int oa, in
 	return inter;
 }
 
-// The interval-dominance sweep, LDS-staged.  A workgroup owns SW_TILE consecutive hits (cs order) and stages
-// their records plus SW_HALO neighbours on each side in LDS (52 B/hit, coalesced 16-byte loads); every thread
-// then walks its partners in both directions out of LDS and only continues in global memory for partners
-// beyond the halo (hits spanning more than SW_HALO others).  The LDS and the global walks are separate loops on
-// purpose: a per-access "LDS or global" select makes the compiler emit flat loads, which are far slower than
-// ds_read.  Pairs are symmetric, so each hit derives its own shadow flag and dominator without atomics.
-// MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform
-constexpr int SW_TILE = 512, SW_HALO = 32, SW_LDS = SW_TILE + 2 * SW_HALO;
+constexpr int SW_HALO = 32;
 
 struct SwHit { // the hit a thread works for
 	int sg, cs, ce, gid, cds, rank, nex, offx, weak; uint32_t fl; uint64_t sc;
@@ -346,231 +344,307 @@ __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBe
 	r.best = upd ? sp : r.best, r.j = upd ? pi : r.j, r.ov = upd ? x : r.ov, r.pid = upd ? c.w : r.pid, r.cds = upd ? b.w : r.cds;
 }
 
-// Slow path of the sweep: thread-per-hit walk over all partners of hit t in both directions (LDS window first, then
-// global memory).  Used for hits whose partners reach beyond the staged window and for tiles whose pair list does
-// not fit in LDS.
-template <int MODE>
-__device__ __forceinline__ void sw_walk(const SweepView &v, const SwHit &t, SwBest &r, const int4 *sA, const int4 *sB, const int4 *sC, const uint32_t *sF, int base, int lh)
-{
-	// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so the
-	// walk stops at the first j whose pm is <= cs_h.
-	{
-		int l = lh - 1;
-		bool open = true;
-		for (; l >= 0; --l) { // LDS part; the four reads are issued together (one wait per partner instead of four)
-			const int4 a = sA[l], b = sB[l], c = sC[l];
-			const uint32_t f = sF[l];
-			asm volatile("" :: "v"(b.x), "v"(c.x), "v"(f)); // keep the loads at the loop head
-			if (a.x != t.sg || a.w <= t.cs) { open = false; break; }
-			sw_pair<MODE, true>(v, t, r, a, f, b, c, base + l, a.z > t.cs);
-		}
-		if (open)
-			for (int j = base - 1; j >= 0; --j) { // beyond the halo: global memory
-				const int4 a = v.A[j];
-				if (a.x != t.sg || a.w <= t.cs) break;
-				sw_pair<MODE, true>(v, t, r, a, v.flags[j], v.B[j], v.C[j], j, a.z > t.cs);
-			}
-	}
-	// partners after h: every i with cs_i < ce_h
-	{
-		int l = lh + 1;
-		bool open = true;
-		for (; l < SW_LDS; ++l) {
-			const int4 a = sA[l], b = sB[l], c = sC[l];
-			const uint32_t f = sF[l];
-			asm volatile("" :: "v"(b.x), "v"(c.x), "v"(f));
-			if (a.x != t.sg || a.y >= t.ce) { open = false; break; }
-			sw_pair<MODE, false>(v, t, r, a, f, b, c, base + l, true);
-		}
-		if (open)
-			for (int i = base + SW_LDS; i < v.n; ++i) {
-				const int4 a = v.A[i];
-				if (a.x != t.sg || a.y >= t.ce) break;
-				sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i, true);
-			}
-	}
-}
-
 // One overlapping pair out of LDS, evaluated ONCE for both members: slot l precedes slot m in the array (l is "j",
-// m is "i" of overlap.c:126-154 / 76-87).  Returns 0 if the pair does not count, else 2 | (the later hit loses).
+// m is "i" of overlap.c:126-154 / 76-87).  Returns 0 if the pair does not count, else 2 | (the later hit loses);
+// *sp_w = score key of the winner.  Reads 28 B per member; the exon records and the ranks only when some pair of
+// the wave needs them (multi-exon hits; equal score keys, i.e. two hits of one protein with the same score).
 template <int MODE>
-__device__ __forceinline__ uint32_t sw_pair_once(const SweepView &v, const int4 *sA, const int4 *sB, const int4 *sC, const uint32_t *sF, int l, int m)
+__device__ __forceinline__ uint32_t sw_pair_once(const SweepView &v, const int4 *sA, const int4 *sB, const int4 *sC, const uint32_t *sF, int l, int m, unsigned long long *sp_w)
 {
 	const uint32_t fj = sF[l], fi = sF[m];
-	const int4 aj = sA[l], ai = sA[m], bj = sB[l], bi = sB[m], cj = sC[l], ci = sC[m];
+	const int2 aj = *(const int2 *)&sA[l].y, ai = *(const int2 *)&sA[m].y; // (cs, ce)
+	const int4 bj = sB[l], bi = sB[m];
 	bool ok = !((fj | fi) & PGA_F_FLT);
 	if (v.check_strand) ok = ok && !((fj ^ fi) & PGA_F_REV);
 	const bool same_gene = bj.z == bi.z;
 	if (MODE == 2) ok = ok && same_gene;
 	int x;
-	if (__ballot(ok && (cj.y != 1 || ci.y != 1)) == 0) { // every pair of the wave single-exon x single-exon
-		const int s0 = aj.y > ai.y ? aj.y : ai.y, e0 = aj.z < ai.z ? aj.z : ai.z;
-		x = e0 > s0 ? e0 - s0 : 0;
-	} else {
-		x = ok ? cds_inter(v.exon, cj.z, cj.y, aj.y, aj.z, ci.z, ci.y, ai.y, ai.z) : 0;
+	{
+		const int s0 = aj.x > ai.x ? aj.x : ai.x, e0 = aj.y < ai.y ? aj.y : ai.y;
+		x = e0 > s0 ? e0 - s0 : 0; // single-exon x single-exon: the CDS intersection is the interval intersection
+	}
+	if (__ballot(ok && ((fj | fi) & F_MULTI))) {
+		if (ok && ((fj | fi) & F_MULTI)) {
+			const int4 cj = sC[l], ci = sC[m];
+			x = cds_inter(v.exon, cj.z, cj.y, aj.x, aj.y, ci.z, ci.y, ai.x, ai.y);
+		}
 	}
 	ok = ok && x > 0; // overlap.c:132
 	const uint64_t s_j = (uint64_t)(uint32_t)bj.x | (uint64_t)(uint32_t)bj.y << 32, s_i = (uint64_t)(uint32_t)bi.x | (uint64_t)(uint32_t)bi.y << 32;
-	bool i_loses = s_i < s_j || (s_i == s_j && ci.x > cj.x);
+	bool i_loses = s_i < s_j;
+	if (__ballot(ok && s_i == s_j)) {
+		if (s_i == s_j) i_loses = sC[m].x > sC[l].x; // rank_i > rank_j
+	}
 	if (MODE != 2) {
 		const int mn = bi.w < bj.w ? bi.w : bj.w;
-		bool too_short; // cov_short < min_ov_ratio, overlap.c:134-136 (see sw_pair for the exact integer form)
-		if (v.min_ov == 0.5) too_short = 2 * (int64_t)x < (int64_t)mn;
+		// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < min(cds): x/m is within
+		// 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
+		bool too_short;
+		if (v.min_ov == 0.5) too_short = 2u * (uint32_t)x < (uint32_t)mn;
 		else too_short = (double)x / (mn > 0 ? mn : 1) < v.min_ov;
 		ok = ok && (same_gene || !too_short);
-		const int wk_i = (int)((fi & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), wk_j = (int)((fj & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
+		const uint32_t wk_i = fi & PGA_F_WEAK_MASK, wk_j = fj & PGA_F_WEAK_MASK;
 		i_loses = (!same_gene && wk_i != wk_j) ? wk_i > wk_j : i_loses; // overlap.c:139-147
 	}
+	*sp_w = i_loses ? s_j : s_i;
 	return ok ? 2u | (i_loses ? 1u : 0u) : 0u;
 }
 
-// The interval-dominance sweep as an LDS pair list.  A workgroup owns SW_TILE consecutive hits (cs order) and stages
-// their records plus SW_HALO neighbours on each side.  Because hits are cs-sorted inside a contig, the later partners
-// of a hit are a contiguous run; the runs are counted, prefix-summed over the workgroup and expanded into a list of
-// (earlier, later) slot pairs with at least one member in the tile.  The list is then evaluated with one pair per
-// lane (full lanes, every pair once -- a thread-per-hit walk evaluates each pair twice and runs as long as the
-// busiest lane of the wave).  Outcomes go to the loser through LDS atomics: a lose flag, the 64-bit max of the
-// winner's score key, then the smallest winner slot among those with that key ("first in array order", overlap.c:150).
-// Pairs across a tile border are evaluated by both tiles, each updating only its own hit, so there are no global atomics.
-constexpr int SW_CAP = 4096;
+// exclusive prefix sum over the wave of a small count (c < 256), one ballot per bit: no LDS traffic, no cross-lane moves
+__device__ __forceinline__ int wave_scan_small(int c, int *total)
+{
+	int off = 0, tot = 0;
+#pragma unroll
+	for (int b = 0; b < 8; ++b) {
+		const unsigned long long mk = __ballot((c >> b) & 1);
+		off += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u)) << b;
+		tot += __popcll(mk) << b;
+	}
+	*total = tot;
+	return off;
+}
+
+__device__ __forceinline__ void wave_sync() // LDS hand-over between lanes of ONE wave (the LDS queue of a wave is in order)
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The interval-dominance sweep as an LDS pair list.
+//
+// A workgroup stages SW_TILE consecutive hits (cs order) plus SW_HALO neighbours on each side (52-56 B/hit, coalesced
+// 16-byte loads) and after ONE barrier its waves work independently: a wave owns 64 hits and looks at a window of
+// SW_HALO more slots on each side.  Because hits are cs-sorted inside a contig, the later partners of a hit are a
+// contiguous run; the runs are counted, prefix-summed over the wave and expanded into a list of (earlier, later) slot
+// pairs with at least one member among the wave's hits.  The list is evaluated one pair per lane (full lanes, every
+// pair once -- a thread-per-hit walk evaluates each pair twice and runs as long as the busiest lane).  Outcomes reach
+// the loser through LDS atomics: a lose flag, the 64-bit max of the winner's score key, then the smallest winner
+// slot among those with that key ("first in array order", overlap.c:150).  Pairs across a wave or tile border are
+// evaluated by both sides, each updating only its own hit: no global atomics, no inter-wave synchronisation.
+// Hits whose partners reach beyond the window, and waves whose list overflows, go to a work list for k_sweep_slow.
+// MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform
+constexpr int SW_TILE = 256, SW_LDS = SW_TILE + 2 * SW_HALO, SW_WCAP = 512, SW_NW = SW_TILE / 64;
+
+struct SwStage { int4 a, b, c; uint32_t f; int32_t o; };
+
+#ifdef PGA_SW_PROFILE // tuning build: s_memtime stamps of lane 0 of every wave at the phase boundaries
+#define SW_STAMP(k) do { if (v.prof && (threadIdx.x & 63) == 0) v.prof[((long long)blockIdx.x * SW_NW + (threadIdx.x >> 6)) * 8 + (k)] = clock64(); } while (0)
+#else
+#define SW_STAMP(k) do { } while (0)
+#endif
+
+template <int MODE>
+__device__ __forceinline__ void sw_fetch(const SweepView &v, int g, SwStage &s)
+{
+	s.a = make_int4(-2, 0, 0, 0), s.b = s.c = make_int4(0, 0, 0, 0), s.f = PGA_F_FLT, s.o = 0;
+	if (g >= 0 && g < v.n) {
+		s.a = v.A[g], s.b = v.B[g], s.c = v.C[g], s.f = v.flags[g];
+		if (MODE == 1) s.o = v.sori[g];
+	}
+}
+
+// epilogue of a hit, overlap.c:157-175.  The hit at index 0 of a genome is never reset (loop starts at 1, overlap.c:108).
+template <int MODE>
+__device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl, bool lose, bool has_dom, int pid_w, int ov, int cds_h, int cds_w, int sori_h, int sori_w)
+{
+	if (MODE == 2) {
+		if (lose) v.flags[h] = fl | PGA_F_ISO_OV;
+		return;
+	}
+	uint32_t nf = (fl & F_HEAD) ? fl : (fl & ~PGA_F_SHADOW);
+	if (lose) nf |= PGA_F_SHADOW;
+	if (nf != fl) v.flags[h] = nf;
+	v.pdom[h] = has_dom ? pid_w : -1;
+	if (MODE == 1) {
+		int sd = -1;
+		if (has_dom) sd = (int32_t)(sori_h * (1.0 - (double)ov / cds_h) + sori_w * ((double)ov / cds_w) + .499); // overlap.c:170
+		v.sdom[h] = sd;
+	}
+}
 
 template <int MODE>
 __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 {
+	static_assert(2 * SW_HALO <= 64 && SW_LDS <= 1024, "halo slots are staged by the first wave; slot ids are packed in 10 bits");
 	__shared__ int4 sA[SW_LDS], sB[SW_LDS], sC[SW_LDS];
 	__shared__ uint32_t sF[SW_LDS];
-	__shared__ uint32_t sPair[SW_CAP];
-	__shared__ unsigned long long sBest[SW_TILE];
-	__shared__ uint32_t sIdx[SW_TILE];
-	__shared__ uint8_t sLose[SW_TILE];
-	__shared__ int sWave[SW_TILE / 64];
+	__shared__ int32_t sOri[MODE == 1 ? SW_LDS : 1]; // score_ori, for score_dom (overlap.c:170)
+	__shared__ uint32_t sPairAll[SW_NW][SW_WCAP];
+	__shared__ unsigned long long sBestAll[SW_NW][64];
+	__shared__ uint32_t sIdxAll[SW_NW][64];
+	__shared__ uint8_t sLoseAll[SW_NW][64];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int base = blockIdx.x * SW_TILE - SW_HALO;
-	for (int l = tid; l < SW_LDS; l += SW_TILE) {
-		const int g = base + l;
-		if (g >= 0 && g < v.n) sA[l] = v.A[g], sB[l] = v.B[g], sC[l] = v.C[g], sF[l] = v.flags[g];
-		else sA[l] = make_int4(-2, 0, 0, 0), sF[l] = PGA_F_FLT;
-	}
-	sBest[tid] = 0, sIdx[tid] = 0xffffffffu, sLose[tid] = 0;
-	__syncthreads();
-	// later partners of a slot: the run (l, l+n]; only the part that has a member inside the tile is listed
-	int first[2] = { 0, 0 }, cnt[2] = { 0, 0 };
-#pragma unroll
-	for (int k = 0; k < 2; ++k) {
-		const int l = k == 0 ? tid : tid + SW_HALO; // k == 0: left-halo slot (first SW_HALO threads); k == 1: this thread's tile slot
-		if (k == 0 && tid >= SW_HALO) continue;
-		const int4 a = sA[l];
-		if (sF[l] & PGA_F_FLT) continue;
-		int m = l + 1;
-		for (; m < SW_LDS; ++m) {
-			const int2 q = *(const int2 *)&sA[m];
-			if (q.x != a.x || q.y >= a.z) break;
+	uint32_t *sPair = sPairAll[wave];
+	unsigned long long *sBest = sBestAll[wave];
+	uint32_t *sIdx = sIdxAll[wave];
+	uint8_t *sLose = sLoseAll[wave];
+	const bool extra = tid < 2 * SW_HALO; // the first wave also stages the slots past SW_TILE
+	const int tile = blockIdx.x;
+	SW_STAMP(0);
+	{
+		SwStage s0, s1;
+		const int base = tile * SW_TILE - SW_HALO;
+		sw_fetch<MODE>(v, base + tid, s0);
+		if (extra) sw_fetch<MODE>(v, base + SW_TILE + tid, s1);
+		sA[tid] = s0.a, sB[tid] = s0.b, sC[tid] = s0.c, sF[tid] = s0.f;
+		if (MODE == 1) sOri[tid] = s0.o;
+		if (extra) {
+			sA[SW_TILE + tid] = s1.a, sB[SW_TILE + tid] = s1.b, sC[SW_TILE + tid] = s1.c, sF[SW_TILE + tid] = s1.f;
+			if (MODE == 1) sOri[SW_TILE + tid] = s1.o;
 		}
-		first[k] = k == 0 ? SW_HALO : l + 1;
-		cnt[k] = m > first[k] ? m - first[k] : 0;
+		sBest[lane] = 0, sIdx[lane] = 0xffffffffu, sLose[lane] = 0;
 	}
-	const int c = cnt[0] + cnt[1];
-	int inc = c;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const int y = __shfl_up(inc, d);
-		if (lane >= d) inc += y;
-	}
-	if (lane == 63) sWave[wave] = inc;
+	SW_STAMP(1);
 	__syncthreads();
-	int off = inc - c, tot = 0;
+	SW_STAMP(2);
+	{
+		// ---- from here on every wave is on its own ----
+		const int lo = SW_HALO + wave * 64, wend = lo + 64 + SW_HALO; // own slots [lo, lo+64), window [lo-SW_HALO, wend)
+		// later partners of a slot: the run (l, l+n]; only the part that has a member among the wave's hits is listed
+		int first[2] = { 0, 0 }, cnt[2] = { 0, 0 };
 #pragma unroll
-	for (int w = 0; w < SW_TILE / 64; ++w) {
-		const int x = sWave[w];
-		off += w < wave ? x : 0, tot += x;
-	}
-	const bool listed = tot <= SW_CAP; // uniform
-	if (listed) {
-		for (int k = 0; k < cnt[0]; ++k) sPair[off + k] = (uint32_t)tid << 10 | (uint32_t)(first[0] + k);
-		off += cnt[0];
-		for (int k = 0; k < cnt[1]; ++k) sPair[off + k] = (uint32_t)(tid + SW_HALO) << 10 | (uint32_t)(first[1] + k);
-		__syncthreads();
-		for (int p = tid; p < tot; p += SW_TILE) {
-			const uint32_t w = sPair[p];
-			const int l = (int)(w >> 10), m = (int)(w & 1023u);
-			const uint32_t res = sw_pair_once<MODE>(v, sA, sB, sC, sF, l, m);
-			if (res) {
-				const int L = (res & 1) ? m : l, W = (res & 1) ? l : m, Lt = L - SW_HALO;
-				if ((unsigned)Lt < (unsigned)SW_TILE) {
-					sLose[Lt] = 1;
-					if (MODE != 2) {
-						const int4 bw = sB[W];
-						const unsigned long long sp = (unsigned long long)(uint32_t)bw.x | (unsigned long long)(uint32_t)bw.y << 32;
-						if (sp > 0) atomicMax(&sBest[Lt], sp);
+		for (int k = 0; k < 2; ++k) {
+			const int l = k == 0 ? lo - SW_HALO + lane : lo + lane; // k == 0: a slot of the left context (first SW_HALO lanes)
+			if (k == 0 && lane >= SW_HALO) continue;
+			const int2 a = *(const int2 *)&sA[l].x; // (seg, cs)
+			const int ce = sA[l].z;
+			if (sF[l] & PGA_F_FLT) continue;
+			// a context slot's run reaches the wave's hits iff it reaches the first of them: start there
+			int m = k == 0 ? lo : l + 1;
+			first[k] = m;
+			for (;;) { // four candidates per round trip to LDS
+				int2 q[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) q[u] = *(const int2 *)&sA[m + u < SW_LDS ? m + u : SW_LDS - 1];
+				int nq = 0;
+				bool go = true;
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					go = go && m + u < wend && q[u].x == a.x && q[u].y < ce;
+					nq += go ? 1 : 0;
+				}
+				m += nq;
+				if (nq < 4) break;
+			}
+			cnt[k] = m - first[k];
+		}
+		int tot;
+		int off = wave_scan_small(cnt[0] + cnt[1], &tot);
+		SW_STAMP(3);
+		const bool listed = tot <= SW_WCAP; // wave-uniform
+		if (listed) {
+#pragma nounroll
+			for (int k = 0; k < cnt[0]; ++k) sPair[off + k] = (uint32_t)(lo - SW_HALO + lane) << 10 | (uint32_t)(first[0] + k);
+			off += cnt[0];
+#pragma nounroll
+			for (int k = 0; k < cnt[1]; ++k) sPair[off + k] = (uint32_t)(lo + lane) << 10 | (uint32_t)(first[1] + k);
+			wave_sync();
+			SW_STAMP(4);
+			for (int p = lane; p < tot; p += 64) {
+				const uint32_t w = sPair[p];
+				const int l = (int)(w >> 10), m = (int)(w & 1023u);
+				unsigned long long sp;
+				const uint32_t res = sw_pair_once<MODE>(v, sA, sB, sC, sF, l, m, &sp);
+				if (res) {
+					const int Lt = ((res & 1) ? m : l) - lo;
+					if ((unsigned)Lt < 64u) {
+						sLose[Lt] = 1;
+						if (MODE != 2 && sp > 0) atomicMax(&sBest[Lt], sp);
+					}
+				}
+				if (MODE != 2) sPair[p] = w | res << 20;
+			}
+			SW_STAMP(5);
+			if (MODE != 2) {
+				wave_sync();
+				for (int p = lane; p < tot; p += 64) {
+					const uint32_t w = sPair[p], res = w >> 20;
+					if (!res) continue;
+					const int l = (int)(w >> 10 & 1023u), m = (int)(w & 1023u);
+					const int W = (res & 1) ? l : m, Lt = ((res & 1) ? m : l) - lo;
+					if ((unsigned)Lt >= 64u) continue;
+					const int2 bw = *(const int2 *)&sB[W];
+					const unsigned long long sp = (unsigned long long)(uint32_t)bw.x | (unsigned long long)(uint32_t)bw.y << 32;
+					if (sp > 0 && sp == sBest[Lt]) {
+						const uint32_t old = atomicMin(&sIdx[Lt], (uint32_t)W); // smallest winner slot
+						if (old != 0xffffffffu) atomicAdd((unsigned long long *)&v.hz[3], 1ull); // hazard H3: two winners with the best key
 					}
 				}
 			}
-			if (MODE != 2) sPair[p] = w | res << 20;
+			wave_sync();
 		}
-		if (MODE != 2) {
-			__syncthreads();
-			for (int p = tid; p < tot; p += SW_TILE) {
-				const uint32_t w = sPair[p], res = w >> 20;
-				if (!res) continue;
-				const int l = (int)(w >> 10 & 1023u), m = (int)(w & 1023u);
-				const int L = (res & 1) ? m : l, W = (res & 1) ? l : m, Lt = L - SW_HALO;
-				if ((unsigned)Lt >= (unsigned)SW_TILE) continue;
-				const int4 bw = sB[W];
-				const unsigned long long sp = (unsigned long long)(uint32_t)bw.x | (unsigned long long)(uint32_t)bw.y << 32;
-				if (sp > 0 && sp == sBest[Lt]) {
-					const uint32_t old = atomicMin(&sIdx[Lt], (uint32_t)W);
-					if (old != 0xffffffffu) atomicAdd((unsigned long long *)&v.hz[3], 1ull); // hazard H3: two winners with the best key
+		SW_STAMP(6);
+		{
+			const int h = tile * SW_TILE + wave * 64 + lane, lh = lo + lane;
+			const uint32_t fl = sF[lh];
+			if (h < v.n && !(fl & PGA_F_FLT)) { // filtered hits keep stale shadow/pid_dom (overlap.c:112)
+				const int4 a = sA[lh], b = sB[lh], c2 = sC[lh];
+				// partners outside the window?  (pm = running max of ce is non-decreasing inside a contig)
+				const int4 w0 = sA[lo - SW_HALO], w1 = sA[wend - 1];
+				const bool open = (w0.x == a.x && w0.w > a.y) || (w1.x == a.x && w1.y < a.z);
+				if (!listed || open) {
+					const unsigned long long at = atomicAdd((unsigned long long *)v.slow_cnt, 1ull);
+					v.slow_list[at] = h;
+				} else {
+					const unsigned long long best = MODE == 2 ? 0 : sBest[lane];
+					const bool lose = sLose[lane] != 0;
+					int pid_w = -1, ov = 0, cds_w = 1, so_w = 0;
+					if (MODE != 2 && best > 0) {
+						const int W = (int)sIdx[lane];
+						const int4 aw = sA[W], bw = sB[W], cw = sC[W];
+						pid_w = cw.w, cds_w = bw.w;
+						if (MODE == 1) {
+							so_w = sOri[W];
+							const int s0 = aw.y > a.y ? aw.y : a.y, e0 = aw.z < a.z ? aw.z : a.z;
+							ov = e0 > s0 ? e0 - s0 : 0;
+							if ((fl | sF[W]) & F_MULTI) { // the earlier hit goes first, as in the pair evaluation
+								const bool wf = W < lh;
+								ov = cds_inter(v.exon, wf ? cw.z : c2.z, wf ? cw.y : c2.y, wf ? aw.y : a.y, wf ? aw.z : a.z,
+								               wf ? c2.z : cw.z, wf ? c2.y : cw.y, wf ? a.y : aw.y, wf ? a.z : aw.z);
+							}
+						}
+					}
+					sw_finish<MODE>(v, h, fl, lose, MODE != 2 && best > 0, pid_w, ov, b.w, cds_w, MODE == 1 ? sOri[lh] : 0, so_w);
 				}
 			}
 		}
-		__syncthreads();
+		SW_STAMP(7);
 	}
-	const int h = blockIdx.x * SW_TILE + tid;
-	if (h >= v.n) return;
-	const int lh = tid + SW_HALO;
-	const uint32_t fl = sF[lh];
-	if (fl & PGA_F_FLT) return; // filtered hits keep stale shadow/pid_dom (overlap.c:112)
-	SwHit t;
-	{
-		const int4 a = sA[lh], b = sB[lh], c2 = sC[lh];
-		t.sg = a.x, t.cs = a.y, t.ce = a.z, t.gid = b.z, t.cds = b.w, t.rank = c2.x, t.nex = c2.y, t.offx = c2.z;
-		t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
-		t.sc = (uint64_t)(uint32_t)b.x | (uint64_t)(uint32_t)b.y << 32;
-	}
-	SwBest r = { false, 0, -1, 0, -1, 0 };
-	// partners outside the staged window?  (pm = running max of ce is non-decreasing inside a contig)
-	const int4 w0 = sA[0], w1 = sA[SW_LDS - 1];
-	const bool open = (w0.x == t.sg && w0.w > t.cs) || (w1.x == t.sg && w1.y < t.ce);
-	if (!listed || open) {
-		sw_walk<MODE>(v, t, r, sA, sB, sC, sF, base, lh);
-	} else {
-		r.lose = sLose[tid] != 0;
-		if (MODE != 2) {
-			r.best = sBest[tid];
-			if (r.best > 0) {
-				const int W = (int)sIdx[tid];
-				const int4 aw = sA[W], bw = sB[W], cw = sC[W];
-				r.j = base + W, r.pid = cw.w, r.cds = bw.w;
-				if (MODE == 1)
-					r.ov = W < lh ? cds_inter(v.exon, cw.z, cw.y, aw.y, aw.z, t.offx, t.nex, t.cs, t.ce)
-					              : cds_inter(v.exon, t.offx, t.nex, t.cs, t.ce, cw.z, cw.y, aw.y, aw.z);
-			}
+}
+
+// The rare hits k_sweep could not finish inside its LDS window: one thread per listed hit walks all its partners in
+// global memory, in both directions (the original thread-per-hit formulation of the sweep).
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *next_cnt)
+{
+	const long long n_slow = *v.slow_cnt;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *next_cnt = 0; // the counter the NEXT sweep will use (ping-pong; nobody reads it now)
+	for (long long q = blockIdx.x * (long long)BLOCK + threadIdx.x; q < n_slow; q += (long long)gridDim.x * BLOCK) {
+		const int h = v.slow_list[q];
+		const uint32_t fl = v.flags[h];
+		SwHit t;
+		{
+			const int4 a = v.A[h], b = v.B[h], c = v.C[h];
+			t.sg = a.x, t.cs = a.y, t.ce = a.z, t.gid = b.z, t.cds = b.w, t.rank = c.x, t.nex = c.y, t.offx = c.z;
+			t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
+			t.sc = (uint64_t)(uint32_t)b.x | (uint64_t)(uint32_t)b.y << 32;
 		}
-	}
-	if (MODE == 2) {
-		if (r.lose) v.flags[h] = fl | PGA_F_ISO_OV;
-		return;
-	}
-	// epilogue, overlap.c:157-175.  The hit at index 0 of a genome is never reset (loop starts at 1, overlap.c:108).
-	uint32_t nf = (fl & F_HEAD) ? fl : (fl & ~PGA_F_SHADOW);
-	if (r.lose) nf |= PGA_F_SHADOW;
-	if (nf != fl) v.flags[h] = nf;
-	v.pdom[h] = r.best > 0 ? r.pid : -1;
-	if (MODE == 1) {
-		int sd = -1;
-		if (r.best > 0)
-			sd = (int32_t)(v.sori[h] * (1.0 - (double)r.ov / t.cds) + v.sori[r.j] * ((double)r.ov / r.cds) + .499); // overlap.c:170
-		v.sdom[h] = sd;
+		SwBest r = { false, 0, -1, 0, -1, 0 };
+		// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so the
+		// walk stops at the first j whose pm is <= cs_h.
+		for (int j = h - 1; j >= 0; --j) {
+			const int4 a = v.A[j];
+			if (a.x != t.sg || a.w <= t.cs) break;
+			sw_pair<MODE, true>(v, t, r, a, v.flags[j], v.B[j], v.C[j], j, a.z > t.cs);
+		}
+		// partners after h: every i with cs_i < ce_h
+		for (int i = h + 1; i < v.n; ++i) {
+			const int4 a = v.A[i];
+			if (a.x != t.sg || a.y >= t.ce) break;
+			sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i, true);
+		}
+		sw_finish<MODE>(v, h, fl, r.lose, r.best > 0, r.pid, r.ov, t.cds, r.cds, MODE == 1 ? v.sori[h] : 0, MODE == 1 && r.best > 0 ? v.sori[r.j] : 0);
 	}
 }
 
@@ -1336,6 +1410,8 @@ static int make_sweep_view(pga_ctx *c, SweepView *v)
 {
 	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->sori = c->sori, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
 	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4;
+	v->slow_cnt = nullptr, v->slow_list = (int32_t *)c->pool.get(S_SLOW, sizeof(int32_t) * (size_t)c->N);
+	if (!v->slow_list) return PGA_ERR_NOMEM;
 	return 0;
 }
 
@@ -1348,15 +1424,39 @@ static void pack_records(pga_ctx *c)
 template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 {
 	SweepView v;
-	make_sweep_view(c, &v);
 	if (c->N == 0) return 0;
+	{ const int rc = make_sweep_view(c, &v); if (rc) return rc; }
 	TimedLaunch t; t.which = timed_which; t.units = c->N;
 	if (timed_which >= 0) {
 		HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
 		HIPCHK(hipEventRecord(t.a, c->st));
 	}
 	c->walk_valid = false;
-	hipLaunchKernelGGL((k_sweep<MODE>), dim3(nblk(c->N, SW_TILE)), dim3(SW_TILE), 0, c->st, v);
+	static const int reps = [] { const char *e = getenv("PGA_SW_REPS"); return e && atoi(e) > 0 ? atoi(e) : 1; }(); // tuning aid: the sweep is idempotent
+	const int nt = (int)nblk(c->N, SW_TILE);
+	v.prof = nullptr;
+#ifdef PGA_SW_PROFILE
+	HIPCHK(hipMalloc((void **)&v.prof, sizeof(long long) * 8 * SW_NW * (size_t)nt));
+#endif
+	for (int rep = 0; rep < reps; ++rep) {
+		v.slow_cnt = c->dcnt + 12 + (c->sweep_seq & 1);
+		hipLaunchKernelGGL((k_sweep<MODE>), dim3(nt), dim3(SW_TILE), 0, c->st, v);
+		hipLaunchKernelGGL((k_sweep_slow<MODE>), dim3(64), dim3(BLOCK), 0, c->st, v, (long long *)(c->dcnt + 12 + ((c->sweep_seq + 1) & 1)));
+		++c->sweep_seq;
+	}
+#ifdef PGA_SW_PROFILE
+	{
+		std::vector<long long> hp((size_t)8 * SW_NW * nt);
+		HIPCHK(hipStreamSynchronize(c->st));
+		HIPCHK(hipMemcpy(hp.data(), v.prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+		(void)hipFree(v.prof);
+		double d[8] = { 0 };
+		for (size_t w = 0; w < (size_t)SW_NW * nt; ++w)
+			for (int k = 1; k < 8; ++k) d[k] += (double)(hp[w * 8 + k] - hp[w * 8 + k - 1]);
+		fprintf(stderr, "[sweep<%d> profile, cycles/wave] load+put %.0f | barrier %.0f | count+scan %.0f | list %.0f | eval %.0f | argmin %.0f | finish %.0f\n", MODE,
+		        d[1] / (SW_NW * nt), d[2] / (SW_NW * nt), d[3] / (SW_NW * nt), d[4] / (SW_NW * nt), d[5] / (SW_NW * nt), d[6] / (SW_NW * nt), d[7] / (SW_NW * nt));
+	}
+#endif
 	if (timed_which >= 0) { HIPCHK(hipEventRecord(t.b, c->st)); c->timed.push_back(t); }
 	return 0;
 }
@@ -1408,6 +1508,10 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 {
 	const int N = c->N, E = c->E, GL = c->n_genome;
 	HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+	{
+		int dev = 0, ncu = 0;
+		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) c->n_cu = ncu;
+	}
 	c->own_stream = true;
 	HIPCHK(hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(int64_t), hipHostMallocDefault));
 	TRY(dalloc(c, &c->dcnt, 16));
