@@ -71,7 +71,9 @@ struct pga_ctx {
 	std::vector<int32_t> h_goff, h_ggl;
 	// static per hit (X order)
 	int32_t *fidx = 0, *gnm = 0, *seg = 0, *pid = 0, *gid = 0, *cs = 0, *ce = 0, *cm = 0, *cds = 0, *nex = 0, *offx = 0, *sori = 0, *sadj = 0, *pm = 0;
-	uint64_t *sc64 = 0;
+	int32_t *rk = 0;        // dense rank of the score key (score_adj, preferred, hash(pid)) of overlap.c:137 over the shard; 0 = key 0
+	int sc_bits = 64;       // significant bits of that key
+	bool any_multi = true;  // some hit has more than one exon
 	int4 *recA = 0, *recB = 0, *recC = 0; // packed sweep records (derived from the arrays above, see k_pack_rec)
 	// dynamic per hit
 	int32_t *rank = 0, *sdom = 0, *pdom = 0, *pdom0 = 0; uint32_t *flags = 0;
@@ -154,8 +156,7 @@ struct FileHits { const int32_t *pid, *cid, *rank, *sori, *sadj, *nex, *offx, *c
 
 __global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int32_t *goff, int n_genome, const int32_t *ctg_base,
                                                      const int2 *exon, const int32_t *prot_gid, const uint8_t *gene_pref,
-                                                     int cs_bits, int32_t *gnm_f, int32_t *seg_f, int32_t *gid_f, int32_t *cds_f,
-                                                     uint64_t *sc64_f, uint64_t *key, uint32_t *val)
+                                                     int32_t *gnm_f, int32_t *seg_f, int32_t *gid_f, int32_t *cds_f, uint64_t *key, uint32_t *val)
 {
 	int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
@@ -166,18 +167,32 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int3
 	int len = 0, ne = f.nex[i], ox = f.offx[i];
 	for (int e = 0; e < ne; ++e) { int2 x = exon[ox + e]; len += x.y - x.x; } // pg_cds_len, overlap.c:45-51
 	gnm_f[i] = g, seg_f[i] = sg, gid_f[i] = gid, cds_f[i] = len;
-	sc64_f[i] = (uint64_t)(int64_t)f.sadj[i] << 33 | (uint64_t)gene_pref[gid] << 32 | hash_u32((uint32_t)f.pid[i]); // overlap.c:137
-	key[i] = (uint64_t)sg << cs_bits | (uint32_t)f.cs[i];
+	key[i] = (uint64_t)(int64_t)f.sadj[i] << 33 | (uint64_t)gene_pref[gid] << 32 | hash_u32((uint32_t)f.pid[i]); // the score key of overlap.c:137
 	val[i] = (uint32_t)i;
+}
+
+// The sweep only ever COMPARES score keys, so every hit gets the dense rank of its key over the shard (one sort per
+// run): 32-bit compares instead of 64-bit ones, and rank and partner slot fit one 64-bit word for a single LDS
+// atomicMax ("best winner, first in array order").  Key 0 keeps rank 0: such a hit never becomes a dominator.
+__global__ __launch_bounds__(BLOCK) void k_rank_scatter(const uint64_t *ks, const uint32_t *vs, const int32_t *incl, int n, int32_t *rk_f)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n) rk_f[vs[i]] = ks[i] == 0 ? 0 : incl[i]; // incl >= 1; when key 0 exists it owns rank value 1, which then stays unused
+}
+
+__global__ __launch_bounds__(BLOCK) void k_xkey(const int32_t *seg_f, const int32_t *cs_f, int n, int cs_bits, uint64_t *key, uint32_t *val)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n) key[i] = (uint64_t)seg_f[i] << cs_bits | (uint32_t)cs_f[i], val[i] = (uint32_t)i;
 }
 
 struct HitArrays {
 	int32_t *fidx, *gnm, *seg, *pid, *gid, *cs, *ce, *cm, *cds, *nex, *offx, *sori, *sadj, *rank, *sdom, *pdom, *pdom0;
-	uint64_t *sc64; uint32_t *flags;
+	int32_t *rk; uint32_t *flags;
 };
 
 __global__ __launch_bounds__(BLOCK) void k_gather(FileHits f, const int32_t *gnm_f, const int32_t *seg_f, const int32_t *gid_f, const int32_t *cds_f,
-                                                    const uint64_t *sc64_f, const uint32_t *perm, int n, const int32_t *goff, HitArrays o)
+                                                    const int32_t *rk_f, const uint32_t *perm, int n, const int32_t *goff, HitArrays o)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(FileHits f, const int32_t *gnm
 	int g = gnm_f[s];
 	o.fidx[h] = s - goff[g], o.gnm[h] = g, o.seg[h] = seg_f[s], o.pid[h] = f.pid[s], o.gid[h] = gid_f[s];
 	o.cs[h] = f.cs[s], o.ce[h] = f.ce[s], o.cm[h] = f.cm[s], o.cds[h] = cds_f[s], o.nex[h] = f.nex[s], o.offx[h] = f.offx[s];
-	o.sori[h] = f.sori[s], o.sadj[h] = f.sadj[s], o.rank[h] = f.rank[s], o.sc64[h] = sc64_f[s];
+	o.sori[h] = f.sori[s], o.sadj[h] = f.sadj[s], o.rank[h] = f.rank[s], o.rk[h] = rk_f[s];
 	o.sdom[h] = 0, o.pdom[h] = -1, o.pdom0[h] = 0; // read.c:133-134
 	o.flags[h] = (f.rev[s] ? PGA_F_REV : 0u) | (h == goff[g] ? F_HEAD : 0u) | (f.nex[s] != 1 ? F_MULTI : 0u);
 }
@@ -240,24 +255,25 @@ __global__ __launch_bounds__(BLOCK) void k_pseudo3(const int32_t *gnm, const int
 // ------------------------------------------------------------------------------------------------
 // the interval-dominance sweep: pg_shadow (overlap.c:101-178) and pg_flt_ov_isoform (58-93)
 // ------------------------------------------------------------------------------------------------
-// Packed per-hit records for the sweep: a partner costs three 16-byte loads instead of a dozen 4-byte ones.
-//   A = {seg, cs, ce, pm}   B = {sc64.lo, sc64.hi, gid, cds}   C = {rank, n_exon, off_exon, pid}
-__global__ __launch_bounds__(BLOCK) void k_pack_rec(const int32_t *seg, const int32_t *cs, const int32_t *ce, const int32_t *pm, const uint64_t *sc64,
+// Packed per-hit records for the sweep: a partner costs 16-byte loads instead of a dozen 4-byte ones.
+//   A = {seg, cs, ce, pm}   B = {rk, gid, cds, pid}   C = {rank, n_exon, off_exon, score_ori}
+// C is only needed for multi-exon hits, for two hits with the same score key and for score_dom.
+__global__ __launch_bounds__(BLOCK) void k_pack_rec(const int32_t *seg, const int32_t *cs, const int32_t *ce, const int32_t *pm, const int32_t *rk,
                                                       const int32_t *gid, const int32_t *cds, const int32_t *rank, const int32_t *nex, const int32_t *offx,
-                                                      const int32_t *pid, int n, int4 *A, int4 *B, int4 *C)
+                                                      const int32_t *pid, const int32_t *sori, int n, int4 *A, int4 *B, int4 *C)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
-	const uint64_t s = sc64[h];
 	A[h] = make_int4(seg[h], cs[h], ce[h], pm[h]);
-	B[h] = make_int4((int)(uint32_t)s, (int)(uint32_t)(s >> 32), gid[h], cds[h]);
-	C[h] = make_int4(rank[h], nex[h], offx[h], pid[h]);
+	B[h] = make_int4(rk[h], gid[h], cds[h], pid[h]);
+	C[h] = make_int4(rank[h], nex[h], offx[h], sori[h]);
 }
 
 struct SweepView {
-	const int4 *A, *B, *C; const int32_t *sori; const int2 *exon;
+	const int4 *A, *B, *C; const int2 *exon;
 	uint32_t *flags; int32_t *pdom, *sdom;
 	int n; double min_ov; int check_strand;
+	int stage_c; // some hit of the shard has several exons: stage the C records with the others
 	int64_t *hz;
 	int64_t *slow_cnt; int32_t *slow_list; // work list for k_sweep_slow
 	long long *prof; // PGA_SW_PROFILE builds only
@@ -289,44 +305,34 @@ __device__ __forceinline__ int cds_inter(const int2 *__restrict__ ex, int oa, in
 	return inter;
 }
 
-constexpr int SW_HALO = 32;
-
 struct SwHit { // the hit a thread works for
-	int sg, cs, ce, gid, cds, rank, nex, offx, weak; uint32_t fl; uint64_t sc;
+	int sg, cs, ce, gid, cds, rank, nex, offx, weak; uint32_t fl; uint32_t sc;
 };
-struct SwBest { bool lose; uint64_t best; int j, ov, pid, cds; };
+struct SwBest { bool lose; uint32_t best; int j, ov, pid, cds; };
 
-// one partner p (record a/b/c, flags fp, array index pi) of hit t; EARLIER: p precedes t in the array.
-// overlap.c:126-154 (pg_shadow) / 76-87 (pg_flt_ov_isoform).  Written with predicates and selects instead of early
-// returns: every divergent branch costs several scalar instructions (exec save/restore) and the CU has ONE scalar
-// unit for its four SIMDs -- the first version of this kernel was scalar-issue bound (profiles/r01_pmc_*).
+// Thread-per-hit form of one pair, used by k_sweep_slow: partner p (records a/b/c, flags fp, array index pi) of hit t;
+// EARLIER: p precedes t in the array.  overlap.c:126-154 (pg_shadow) / 76-87 (pg_flt_ov_isoform).
 template <int MODE, bool EARLIER>
 __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBest &r, const int4 a, const uint32_t fp, const int4 b, const int4 c, int pi, bool ok)
 {
 	ok = ok && !(fp & PGA_F_FLT);
-	if (v.check_strand) ok = ok && !((fp ^ t.fl) & PGA_F_REV); // uniform condition: scalar branch
-	const bool same_gene = b.z == t.gid;
+	if (v.check_strand) ok = ok && !((fp ^ t.fl) & PGA_F_REV);
+	const bool same_gene = b.y == t.gid;
 	if (MODE == 2) ok = ok && same_gene;
-	int x;
-	if (__ballot(ok && (c.y != 1 || t.nex != 1)) == 0) { // whole wave single-exon x single-exon: interval intersection
-		const int s0 = a.y > t.cs ? a.y : t.cs, e0 = a.z < t.ce ? a.z : t.ce;
-		x = e0 > s0 ? e0 - s0 : 0;
-	} else {
-		x = !ok ? 0 : EARLIER ? cds_inter(v.exon, c.z, c.y, a.y, a.z, t.offx, t.nex, t.cs, t.ce)
-		                      : cds_inter(v.exon, t.offx, t.nex, t.cs, t.ce, c.z, c.y, a.y, a.z);
-	}
+	const int x = !ok ? 0 : EARLIER ? cds_inter(v.exon, c.z, c.y, a.y, a.z, t.offx, t.nex, t.cs, t.ce)
+	                                : cds_inter(v.exon, t.offx, t.nex, t.cs, t.ce, c.z, c.y, a.y, a.z);
 	ok = ok && x > 0; // overlap.c:132
-	const uint64_t sp = (uint64_t)(uint32_t)b.x | (uint64_t)(uint32_t)b.y << 32;
+	const uint32_t sp = (uint32_t)b.x;
 	// "i" of the reference is the later hit of the pair: i loses if (si < sj || (si == sj && rank_i > rank_j))
-	const uint64_t s_i = EARLIER ? t.sc : sp, s_j = EARLIER ? sp : t.sc;
+	const uint32_t s_i = EARLIER ? t.sc : sp, s_j = EARLIER ? sp : t.sc;
 	const int rk_i = EARLIER ? t.rank : c.x, rk_j = EARLIER ? c.x : t.rank;
 	bool i_loses = s_i < s_j || (s_i == s_j && rk_i > rk_j);
 	if (MODE != 2) {
-		const int m = t.cds < b.w ? t.cds : b.w;
+		const int m = t.cds < b.z ? t.cds : b.z;
 		// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < m: x/m is within
 		// 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
 		bool too_short;
-		if (v.min_ov == 0.5) too_short = 2 * (int64_t)x < (int64_t)m;
+		if (v.min_ov == 0.5) too_short = 2u * (uint32_t)x < (uint32_t)m;
 		else too_short = (double)x / (m > 0 ? m : 1) < v.min_ov;
 		ok = ok && (same_gene || !too_short);
 		const int wk_p = (int)((fp & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
@@ -339,55 +345,15 @@ __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBe
 	// dominator = best-scoring winner, first in array order on ties (overlap.c:150,153).  Earlier partners are visited in
 	// DEscending index order, so an equal score replaces; later partners in ascending order, so it does not.
 	const bool upd = t_loses && (EARLIER ? (sp > 0 && sp >= r.best) : (sp > r.best));
-	const bool tie = t_loses && sp == r.best && sp > 0;
-	if (__ballot(tie)) { if (tie) atomicAdd((unsigned long long *)&v.hz[3], 1ull); } // hazard H3, rare
-	r.best = upd ? sp : r.best, r.j = upd ? pi : r.j, r.ov = upd ? x : r.ov, r.pid = upd ? c.w : r.pid, r.cds = upd ? b.w : r.cds;
+	if (t_loses && sp == r.best && sp > 0) atomicAdd((unsigned long long *)&v.hz[3], 1ull); // hazard H3, rare
+	r.best = upd ? sp : r.best, r.j = upd ? pi : r.j, r.ov = upd ? x : r.ov, r.pid = upd ? b.w : r.pid, r.cds = upd ? b.z : r.cds;
 }
 
-// One overlapping pair out of LDS, evaluated ONCE for both members: slot l precedes slot m in the array (l is "j",
-// m is "i" of overlap.c:126-154 / 76-87).  Returns 0 if the pair does not count, else 2 | (the later hit loses);
-// *sp_w = score key of the winner.  Reads 28 B per member; the exon records and the ranks only when some pair of
-// the wave needs them (multi-exon hits; equal score keys, i.e. two hits of one protein with the same score).
-template <int MODE>
-__device__ __forceinline__ uint32_t sw_pair_once(const SweepView &v, const int4 *sA, const int4 *sB, const int4 *sC, const uint32_t *sF, int l, int m, unsigned long long *sp_w)
+__device__ __forceinline__ void wave_sync() // LDS hand-over between lanes of ONE wave (the LDS queue of a wave is in order)
 {
-	const uint32_t fj = sF[l], fi = sF[m];
-	const int2 aj = *(const int2 *)&sA[l].y, ai = *(const int2 *)&sA[m].y; // (cs, ce)
-	const int4 bj = sB[l], bi = sB[m];
-	bool ok = !((fj | fi) & PGA_F_FLT);
-	if (v.check_strand) ok = ok && !((fj ^ fi) & PGA_F_REV);
-	const bool same_gene = bj.z == bi.z;
-	if (MODE == 2) ok = ok && same_gene;
-	int x;
-	{
-		const int s0 = aj.x > ai.x ? aj.x : ai.x, e0 = aj.y < ai.y ? aj.y : ai.y;
-		x = e0 > s0 ? e0 - s0 : 0; // single-exon x single-exon: the CDS intersection is the interval intersection
-	}
-	if (__ballot(ok && ((fj | fi) & F_MULTI))) {
-		if (ok && ((fj | fi) & F_MULTI)) {
-			const int4 cj = sC[l], ci = sC[m];
-			x = cds_inter(v.exon, cj.z, cj.y, aj.x, aj.y, ci.z, ci.y, ai.x, ai.y);
-		}
-	}
-	ok = ok && x > 0; // overlap.c:132
-	const uint64_t s_j = (uint64_t)(uint32_t)bj.x | (uint64_t)(uint32_t)bj.y << 32, s_i = (uint64_t)(uint32_t)bi.x | (uint64_t)(uint32_t)bi.y << 32;
-	bool i_loses = s_i < s_j;
-	if (__ballot(ok && s_i == s_j)) {
-		if (s_i == s_j) i_loses = sC[m].x > sC[l].x; // rank_i > rank_j
-	}
-	if (MODE != 2) {
-		const int mn = bi.w < bj.w ? bi.w : bj.w;
-		// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < min(cds): x/m is within
-		// 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
-		bool too_short;
-		if (v.min_ov == 0.5) too_short = 2u * (uint32_t)x < (uint32_t)mn;
-		else too_short = (double)x / (mn > 0 ? mn : 1) < v.min_ov;
-		ok = ok && (same_gene || !too_short);
-		const uint32_t wk_i = fi & PGA_F_WEAK_MASK, wk_j = fj & PGA_F_WEAK_MASK;
-		i_loses = (!same_gene && wk_i != wk_j) ? wk_i > wk_j : i_loses; // overlap.c:139-147
-	}
-	*sp_w = i_loses ? s_j : s_i;
-	return ok ? 2u | (i_loses ? 1u : 0u) : 0u;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // exclusive prefix sum over the wave of a small count (c < 256), one ballot per bit: no LDS traffic, no cross-lane moves
@@ -404,45 +370,27 @@ __device__ __forceinline__ int wave_scan_small(int c, int *total)
 	return off;
 }
 
-__device__ __forceinline__ void wave_sync() // LDS hand-over between lanes of ONE wave (the LDS queue of a wave is in order)
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // The interval-dominance sweep as an LDS pair list.
 //
-// A workgroup stages SW_TILE consecutive hits (cs order) plus SW_HALO neighbours on each side (52-56 B/hit, coalesced
-// 16-byte loads) and after ONE barrier its waves work independently: a wave owns 64 hits and looks at a window of
-// SW_HALO more slots on each side.  Because hits are cs-sorted inside a contig, the later partners of a hit are a
-// contiguous run; the runs are counted, prefix-summed over the wave and expanded into a list of (earlier, later) slot
-// pairs with at least one member among the wave's hits.  The list is evaluated one pair per lane (full lanes, every
-// pair once -- a thread-per-hit walk evaluates each pair twice and runs as long as the busiest lane).  Outcomes reach
-// the loser through LDS atomics: a lose flag, the 64-bit max of the winner's score key, then the smallest winner
-// slot among those with that key ("first in array order", overlap.c:150).  Pairs across a wave or tile border are
-// evaluated by both sides, each updating only its own hit: no global atomics, no inter-wave synchronisation.
-// Hits whose partners reach beyond the window, and waves whose list overflows, go to a work list for k_sweep_slow.
+// A workgroup stages SW_TILE consecutive hits (cs order) plus SW_HALO neighbours on each side (36 B/hit, 52 when the C
+// records are needed; coalesced 16-byte loads) and after ONE barrier its waves work independently: a wave owns 64 hits
+// and looks at a window of SW_HALO more slots on each side.  Because hits are cs-sorted inside a contig, the later
+// partners of a hit are a contiguous run; the runs are counted, prefix-summed over the wave and expanded into a list
+// of (earlier, later) slot pairs with at least one member among the wave's hits.  The list is evaluated one pair per
+// lane (full lanes, every pair once -- a thread-per-hit walk evaluates each pair twice and runs as long as the busiest
+// lane).  The outcome reaches the loser as ONE 64-bit LDS atomicMax of (winner's score rank, "lost" bit, inverted
+// winner slot): the maximum is the best-scoring winner and, among equals, the first in array order (overlap.c:150).
+// Pairs across a wave or tile border are evaluated by both sides, each updating only its own hit: no global atomics,
+// no inter-wave synchronisation.  Hits whose partners reach beyond the window, and waves whose list overflows, go
+// to a work list for k_sweep_slow.
 // MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform
-constexpr int SW_TILE = 256, SW_LDS = SW_TILE + 2 * SW_HALO, SW_WCAP = 512, SW_NW = SW_TILE / 64;
-
-struct SwStage { int4 a, b, c; uint32_t f; int32_t o; };
+constexpr int SW_HALO = 32, SW_TILE = 256, SW_LDS = SW_TILE + 2 * SW_HALO, SW_WCAP = 512, SW_NW = SW_TILE / 64;
 
 #ifdef PGA_SW_PROFILE // tuning build: s_memtime stamps of lane 0 of every wave at the phase boundaries
 #define SW_STAMP(k) do { if (v.prof && (threadIdx.x & 63) == 0) v.prof[((long long)blockIdx.x * SW_NW + (threadIdx.x >> 6)) * 8 + (k)] = clock64(); } while (0)
 #else
 #define SW_STAMP(k) do { } while (0)
 #endif
-
-template <int MODE>
-__device__ __forceinline__ void sw_fetch(const SweepView &v, int g, SwStage &s)
-{
-	s.a = make_int4(-2, 0, 0, 0), s.b = s.c = make_int4(0, 0, 0, 0), s.f = PGA_F_FLT, s.o = 0;
-	if (g >= 0 && g < v.n) {
-		s.a = v.A[g], s.b = v.B[g], s.c = v.C[g], s.f = v.flags[g];
-		if (MODE == 1) s.o = v.sori[g];
-	}
-}
 
 // epilogue of a hit, overlap.c:157-175.  The hit at index 0 of a genome is never reset (loop starts at 1, overlap.c:108).
 template <int MODE>
@@ -463,158 +411,170 @@ __device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl
 	}
 }
 
-template <int MODE>
+template <int MODE, bool STAGE_C>
 __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 {
 	static_assert(2 * SW_HALO <= 64 && SW_LDS <= 1024, "halo slots are staged by the first wave; slot ids are packed in 10 bits");
-	__shared__ int4 sA[SW_LDS], sB[SW_LDS], sC[SW_LDS];
+	static_assert(MODE != 1 || STAGE_C, "score_dom needs score_ori, which lives in the C records");
+	__shared__ int4 sA[SW_LDS], sB[SW_LDS], sC[STAGE_C ? SW_LDS : 1];
 	__shared__ uint32_t sF[SW_LDS];
-	__shared__ int32_t sOri[MODE == 1 ? SW_LDS : 1]; // score_ori, for score_dom (overlap.c:170)
 	__shared__ uint32_t sPairAll[SW_NW][SW_WCAP];
-	__shared__ unsigned long long sBestAll[SW_NW][64];
-	__shared__ uint32_t sIdxAll[SW_NW][64];
-	__shared__ uint8_t sLoseAll[SW_NW][64];
+	__shared__ unsigned long long sKeyAll[SW_NW][64];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	uint32_t *sPair = sPairAll[wave];
-	unsigned long long *sBest = sBestAll[wave];
-	uint32_t *sIdx = sIdxAll[wave];
-	uint8_t *sLose = sLoseAll[wave];
-	const bool extra = tid < 2 * SW_HALO; // the first wave also stages the slots past SW_TILE
-	const int tile = blockIdx.x;
+	unsigned long long *sKey = sKeyAll[wave];
+	const int tile = blockIdx.x, base = tile * SW_TILE - SW_HALO;
 	SW_STAMP(0);
-	{
-		SwStage s0, s1;
-		const int base = tile * SW_TILE - SW_HALO;
-		sw_fetch<MODE>(v, base + tid, s0);
-		if (extra) sw_fetch<MODE>(v, base + SW_TILE + tid, s1);
-		sA[tid] = s0.a, sB[tid] = s0.b, sC[tid] = s0.c, sF[tid] = s0.f;
-		if (MODE == 1) sOri[tid] = s0.o;
-		if (extra) {
-			sA[SW_TILE + tid] = s1.a, sB[SW_TILE + tid] = s1.b, sC[SW_TILE + tid] = s1.c, sF[SW_TILE + tid] = s1.f;
-			if (MODE == 1) sOri[SW_TILE + tid] = s1.o;
+#pragma unroll
+	for (int k = 0; k < 2; ++k) {
+		if (k == 1 && tid >= 2 * SW_HALO) break; // the first wave also stages the slots past SW_TILE
+		const int l = k * SW_TILE + tid, g = base + l;
+		int4 a = make_int4(-2, 0, 0, 0), b = make_int4(0, 0, 0, 0), c = b;
+		uint32_t f = PGA_F_FLT;
+		if (g >= 0 && g < v.n) {
+			a = v.A[g], b = v.B[g], f = v.flags[g];
+			if (STAGE_C) c = v.C[g];
 		}
-		sBest[lane] = 0, sIdx[lane] = 0xffffffffu, sLose[lane] = 0;
+		sA[l] = a, sB[l] = b, sF[l] = f;
+		if (STAGE_C) sC[l] = c;
 	}
+	sKey[lane] = 0;
 	SW_STAMP(1);
 	__syncthreads();
 	SW_STAMP(2);
-	{
-		// ---- from here on every wave is on its own ----
-		const int lo = SW_HALO + wave * 64, wend = lo + 64 + SW_HALO; // own slots [lo, lo+64), window [lo-SW_HALO, wend)
-		// later partners of a slot: the run (l, l+n]; only the part that has a member among the wave's hits is listed
-		int first[2] = { 0, 0 }, cnt[2] = { 0, 0 };
+	// ---- from here on every wave is on its own ----
+	const int lo = SW_HALO + wave * 64, wend = lo + 64 + SW_HALO; // own slots [lo, lo+64), window [lo-SW_HALO, wend)
+	// later partners of a slot: the run (l, l+n]; only the part that has a member among the wave's hits is listed
+	int first[2] = { 0, 0 }, cnt[2] = { 0, 0 };
 #pragma unroll
-		for (int k = 0; k < 2; ++k) {
-			const int l = k == 0 ? lo - SW_HALO + lane : lo + lane; // k == 0: a slot of the left context (first SW_HALO lanes)
-			if (k == 0 && lane >= SW_HALO) continue;
-			const int2 a = *(const int2 *)&sA[l].x; // (seg, cs)
-			const int ce = sA[l].z;
-			if (sF[l] & PGA_F_FLT) continue;
-			// a context slot's run reaches the wave's hits iff it reaches the first of them: start there
-			int m = k == 0 ? lo : l + 1;
-			first[k] = m;
-			for (;;) { // four candidates per round trip to LDS
-				int2 q[4];
+	for (int k = 0; k < 2; ++k) {
+		const int l = k == 0 ? lo - SW_HALO + lane : lo + lane; // k == 0: a slot of the left context (first SW_HALO lanes)
+		if (k == 0 && lane >= SW_HALO) continue;
+		const int2 a = *(const int2 *)&sA[l].x; // (seg, cs)
+		const int ce = sA[l].z;
+		if (sF[l] & PGA_F_FLT) continue;
+		// a context slot's run reaches the wave's hits iff it reaches the first of them: start there
+		int m = k == 0 ? lo : l + 1;
+		first[k] = m;
+		for (;;) { // four candidates per round trip to LDS
+			int2 q[4];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) q[u] = *(const int2 *)&sA[m + u < SW_LDS ? m + u : SW_LDS - 1];
-				int nq = 0;
-				bool go = true;
+			for (int u = 0; u < 4; ++u) q[u] = *(const int2 *)&sA[m + u < SW_LDS ? m + u : SW_LDS - 1];
+			int nq = 0;
+			bool go = true;
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					go = go && m + u < wend && q[u].x == a.x && q[u].y < ce;
-					nq += go ? 1 : 0;
-				}
-				m += nq;
-				if (nq < 4) break;
+			for (int u = 0; u < 4; ++u) {
+				go = go && m + u < wend && q[u].x == a.x && q[u].y < ce;
+				nq += go ? 1 : 0;
 			}
-			cnt[k] = m - first[k];
+			m += nq;
+			if (nq < 4) break;
 		}
-		int tot;
-		int off = wave_scan_small(cnt[0] + cnt[1], &tot);
-		SW_STAMP(3);
-		const bool listed = tot <= SW_WCAP; // wave-uniform
-		if (listed) {
+		cnt[k] = m - first[k];
+	}
+	int tot;
+	int off = wave_scan_small(cnt[0] + cnt[1], &tot);
+	SW_STAMP(3);
+	const bool listed = tot <= SW_WCAP; // wave-uniform
+	if (listed) {
 #pragma nounroll
-			for (int k = 0; k < cnt[0]; ++k) sPair[off + k] = (uint32_t)(lo - SW_HALO + lane) << 10 | (uint32_t)(first[0] + k);
-			off += cnt[0];
+		for (int k = 0; k < cnt[0]; ++k) sPair[off + k] = (uint32_t)(lo - SW_HALO + lane) << 10 | (uint32_t)(first[0] + k);
+		off += cnt[0];
 #pragma nounroll
-			for (int k = 0; k < cnt[1]; ++k) sPair[off + k] = (uint32_t)(lo + lane) << 10 | (uint32_t)(first[1] + k);
-			wave_sync();
-			SW_STAMP(4);
-			for (int p = lane; p < tot; p += 64) {
-				const uint32_t w = sPair[p];
-				const int l = (int)(w >> 10), m = (int)(w & 1023u);
-				unsigned long long sp;
-				const uint32_t res = sw_pair_once<MODE>(v, sA, sB, sC, sF, l, m, &sp);
-				if (res) {
-					const int Lt = ((res & 1) ? m : l) - lo;
-					if ((unsigned)Lt < 64u) {
-						sLose[Lt] = 1;
-						if (MODE != 2 && sp > 0) atomicMax(&sBest[Lt], sp);
-					}
-				}
-				if (MODE != 2) sPair[p] = w | res << 20;
+		for (int k = 0; k < cnt[1]; ++k) sPair[off + k] = (uint32_t)(lo + lane) << 10 | (uint32_t)(first[1] + k);
+		wave_sync();
+		SW_STAMP(4);
+		// one pair per lane: slot l precedes slot m in the array (l is "j", m is "i" of overlap.c:126-154 / 76-87)
+		for (int p = lane; p < tot; p += 64) {
+			const uint32_t w = sPair[p];
+			const int l = (int)(w >> 10), m = (int)(w & 1023u);
+			const uint32_t fj = sF[l], fi = sF[m];
+			const int2 aj = *(const int2 *)&sA[l].y, ai = *(const int2 *)&sA[m].y; // (cs, ce)
+			const int4 bj = sB[l], bi = sB[m];                                       // {rk, gid, cds, pid}
+			bool ok = !((fj | fi) & PGA_F_FLT);
+			if (v.check_strand) ok = ok && !((fj ^ fi) & PGA_F_REV);
+			const bool same_gene = bj.y == bi.y;
+			if (MODE == 2) ok = ok && same_gene;
+			int x;
+			{
+				const int s0 = aj.x > ai.x ? aj.x : ai.x, e0 = aj.y < ai.y ? aj.y : ai.y;
+				x = e0 > s0 ? e0 - s0 : 0; // single-exon x single-exon: the CDS intersection is the interval intersection
 			}
-			SW_STAMP(5);
+			bool i_loses = (uint32_t)bi.x < (uint32_t)bj.x;
+			// the C records only when a pair of the wave needs them: multi-exon hits, or two hits with the same score key
+			// (the same protein with the same score) whose order the rank decides
+			const bool multi = ok && ((fj | fi) & F_MULTI), tie = ok && bi.x == bj.x;
+			if (__ballot(multi || tie)) {
+				if (multi || tie) {
+					const int4 cj = STAGE_C ? sC[l] : v.C[base + l], ci = STAGE_C ? sC[m] : v.C[base + m]; // {rank, n_exon, off_exon, score_ori}
+					if (multi) x = cds_inter(v.exon, cj.z, cj.y, aj.x, aj.y, ci.z, ci.y, ai.x, ai.y);
+					if (tie) i_loses = ci.x > cj.x; // rank_i > rank_j
+				}
+			}
+			ok = ok && x > 0; // overlap.c:132
 			if (MODE != 2) {
-				wave_sync();
-				for (int p = lane; p < tot; p += 64) {
-					const uint32_t w = sPair[p], res = w >> 20;
-					if (!res) continue;
-					const int l = (int)(w >> 10 & 1023u), m = (int)(w & 1023u);
-					const int W = (res & 1) ? l : m, Lt = ((res & 1) ? m : l) - lo;
-					if ((unsigned)Lt >= 64u) continue;
-					const int2 bw = *(const int2 *)&sB[W];
-					const unsigned long long sp = (unsigned long long)(uint32_t)bw.x | (unsigned long long)(uint32_t)bw.y << 32;
-					if (sp > 0 && sp == sBest[Lt]) {
-						const uint32_t old = atomicMin(&sIdx[Lt], (uint32_t)W); // smallest winner slot
-						if (old != 0xffffffffu) atomicAdd((unsigned long long *)&v.hz[3], 1ull); // hazard H3: two winners with the best key
-					}
-				}
+				const int mn = bi.z < bj.z ? bi.z : bj.z;
+				// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < min(cds): x/m is
+				// within 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
+				bool too_short;
+				if (v.min_ov == 0.5) too_short = 2u * (uint32_t)x < (uint32_t)mn;
+				else too_short = (double)x / (mn > 0 ? mn : 1) < v.min_ov;
+				ok = ok && (same_gene || !too_short);
+				const uint32_t wk_i = fi & PGA_F_WEAK_MASK, wk_j = fj & PGA_F_WEAK_MASK;
+				i_loses = (!same_gene && wk_i != wk_j) ? wk_i > wk_j : i_loses; // overlap.c:139-147
 			}
-			wave_sync();
+			const int L = i_loses ? m : l, W = i_loses ? l : m, Lt = L - lo;
+			if (ok && (unsigned)Lt < 64u) {
+				const uint32_t rw = (uint32_t)(i_loses ? bj.x : bi.x);
+				const unsigned long long key = (unsigned long long)rw << 32 | 0x80000000u | (uint32_t)(1023 - W);
+				const unsigned long long old = atomicMax(&sKey[Lt], key);
+				if (MODE != 2 && rw != 0 && (uint32_t)(old >> 32) == rw) atomicAdd((unsigned long long *)&v.hz[3], 1ull); // hazard H3: two winners with one key
+			}
 		}
-		SW_STAMP(6);
-		{
-			const int h = tile * SW_TILE + wave * 64 + lane, lh = lo + lane;
-			const uint32_t fl = sF[lh];
-			if (h < v.n && !(fl & PGA_F_FLT)) { // filtered hits keep stale shadow/pid_dom (overlap.c:112)
-				const int4 a = sA[lh], b = sB[lh], c2 = sC[lh];
-				// partners outside the window?  (pm = running max of ce is non-decreasing inside a contig)
-				const int4 w0 = sA[lo - SW_HALO], w1 = sA[wend - 1];
-				const bool open = (w0.x == a.x && w0.w > a.y) || (w1.x == a.x && w1.y < a.z);
-				if (!listed || open) {
-					const unsigned long long at = atomicAdd((unsigned long long *)v.slow_cnt, 1ull);
-					v.slow_list[at] = h;
-				} else {
-					const unsigned long long best = MODE == 2 ? 0 : sBest[lane];
-					const bool lose = sLose[lane] != 0;
-					int pid_w = -1, ov = 0, cds_w = 1, so_w = 0;
-					if (MODE != 2 && best > 0) {
-						const int W = (int)sIdx[lane];
-						const int4 aw = sA[W], bw = sB[W], cw = sC[W];
-						pid_w = cw.w, cds_w = bw.w;
-						if (MODE == 1) {
-							so_w = sOri[W];
-							const int s0 = aw.y > a.y ? aw.y : a.y, e0 = aw.z < a.z ? aw.z : a.z;
-							ov = e0 > s0 ? e0 - s0 : 0;
-							if ((fl | sF[W]) & F_MULTI) { // the earlier hit goes first, as in the pair evaluation
-								const bool wf = W < lh;
-								ov = cds_inter(v.exon, wf ? cw.z : c2.z, wf ? cw.y : c2.y, wf ? aw.y : a.y, wf ? aw.z : a.z,
-								               wf ? c2.z : cw.z, wf ? c2.y : cw.y, wf ? a.y : aw.y, wf ? a.z : aw.z);
-							}
+		wave_sync();
+	}
+	SW_STAMP(5);
+	SW_STAMP(6);
+	{
+		const int h = tile * SW_TILE + wave * 64 + lane, lh = lo + lane;
+		const uint32_t fl = sF[lh];
+		if (h < v.n && !(fl & PGA_F_FLT)) { // filtered hits keep stale shadow/pid_dom (overlap.c:112)
+			const int4 a = sA[lh];
+			// partners outside the window?  (pm = running max of ce is non-decreasing inside a contig)
+			const int4 w0 = sA[lo - SW_HALO], w1 = sA[wend - 1];
+			const bool open = (w0.x == a.x && w0.w > a.y) || (w1.x == a.x && w1.y < a.z);
+			if (!listed || open) {
+				const unsigned long long at = atomicAdd((unsigned long long *)v.slow_cnt, 1ull);
+				v.slow_list[at] = h;
+			} else {
+				const unsigned long long key = sKey[lane];
+				const bool lose = key != 0, has_dom = MODE != 2 && (key >> 32) != 0;
+				int pid_w = -1, ov = 0, cds_w = 1, so_w = 0, so_h = 0, cds_h = 1;
+				if (has_dom) {
+					const int W = 1023 - (int)(key & 1023u);
+					const int4 bw = sB[W];
+					pid_w = bw.w, cds_w = bw.z;
+					if (MODE == 1) {
+						const int4 aw = sA[W], cw = sC[W], c2 = sC[lh];
+						so_w = cw.w, so_h = c2.w, cds_h = sB[lh].z;
+						const int s0 = aw.y > a.y ? aw.y : a.y, e0 = aw.z < a.z ? aw.z : a.z;
+						ov = e0 > s0 ? e0 - s0 : 0;
+						if ((fl | sF[W]) & F_MULTI) { // the earlier hit goes first, as in the pair evaluation
+							const bool wf = W < lh;
+							ov = cds_inter(v.exon, wf ? cw.z : c2.z, wf ? cw.y : c2.y, wf ? aw.y : a.y, wf ? aw.z : a.z,
+							               wf ? c2.z : cw.z, wf ? c2.y : cw.y, wf ? a.y : aw.y, wf ? a.z : aw.z);
 						}
 					}
-					sw_finish<MODE>(v, h, fl, lose, MODE != 2 && best > 0, pid_w, ov, b.w, cds_w, MODE == 1 ? sOri[lh] : 0, so_w);
 				}
+				sw_finish<MODE>(v, h, fl, lose, has_dom, pid_w, ov, cds_h, cds_w, so_h, so_w);
 			}
 		}
-		SW_STAMP(7);
 	}
+	SW_STAMP(7);
 }
 
 // The rare hits k_sweep could not finish inside its LDS window: one thread per listed hit walks all its partners in
-// global memory, in both directions (the original thread-per-hit formulation of the sweep).
+// global memory, in both directions (the plain thread-per-hit formulation of the sweep).
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *next_cnt)
 {
@@ -624,11 +584,12 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *ne
 		const int h = v.slow_list[q];
 		const uint32_t fl = v.flags[h];
 		SwHit t;
+		const int4 ch = v.C[h];
 		{
-			const int4 a = v.A[h], b = v.B[h], c = v.C[h];
-			t.sg = a.x, t.cs = a.y, t.ce = a.z, t.gid = b.z, t.cds = b.w, t.rank = c.x, t.nex = c.y, t.offx = c.z;
+			const int4 a = v.A[h], b = v.B[h];
+			t.sg = a.x, t.cs = a.y, t.ce = a.z, t.gid = b.y, t.cds = b.z, t.rank = ch.x, t.nex = ch.y, t.offx = ch.z;
 			t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
-			t.sc = (uint64_t)(uint32_t)b.x | (uint64_t)(uint32_t)b.y << 32;
+			t.sc = (uint32_t)b.x;
 		}
 		SwBest r = { false, 0, -1, 0, -1, 0 };
 		// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so the
@@ -644,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *ne
 			if (a.x != t.sg || a.y >= t.ce) break;
 			sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i, true);
 		}
-		sw_finish<MODE>(v, h, fl, r.lose, r.best > 0, r.pid, r.ov, t.cds, r.cds, MODE == 1 ? v.sori[h] : 0, MODE == 1 && r.best > 0 ? v.sori[r.j] : 0);
+		sw_finish<MODE>(v, h, fl, r.lose, r.best > 0, r.pid, r.ov, t.cds, r.cds, ch.w, MODE == 1 && r.best > 0 ? v.C[r.j].w : 0);
 	}
 }
 
@@ -1358,21 +1319,20 @@ __global__ __launch_bounds__(BLOCK) void k_set_head(const int32_t *head_file, co
 	headpos[g] = np;
 }
 
-struct PermArrays { int32_t *a[16]; uint64_t *sc64; };
+struct PermArrays { int32_t *a[17]; }; // a[15] = flags, a[16] = rk
 
 __global__ __launch_bounds__(BLOCK) void k_ov_gather(PermArrays p, const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv,
-                                                       int32_t *tmp, uint64_t *tmp64, int32_t *remap)
+                                                       int32_t *tmp, int32_t *remap)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= t) return;
 	int src = inv[ov_file[i]];
 	remap[src] = ov_pos[i];
 #pragma unroll
-	for (int k = 0; k < 16; ++k) tmp[(int64_t)k * t + i] = p.a[k][src];
-	tmp64[i] = p.sc64[src];
+	for (int k = 0; k < 17; ++k) tmp[(int64_t)k * t + i] = p.a[k][src];
 }
 
-__global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_t *ov_pos, int64_t t, const int32_t *tmp, const uint64_t *tmp64,
+__global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_t *ov_pos, int64_t t, const int32_t *tmp,
                                                         const int32_t *gnm, const int32_t *goff)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1383,7 +1343,7 @@ __global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_
 	uint32_t f = (uint32_t)tmp[(int64_t)15 * t + i] & ~F_HEAD; // a[15] = flags; the head mark is positional
 	if (pos == goff[gnm[pos]]) f |= F_HEAD;
 	p.a[15][pos] = (int32_t)f;
-	p.sc64[pos] = tmp64[i];
+	p.a[16][pos] = tmp[(int64_t)16 * t + i];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_ov_remap_y(int32_t *yperm, int n, const int32_t *remap)
@@ -1408,8 +1368,8 @@ static int bits_for(uint32_t maxv) { int b = 1; while (b < 32 && (maxv >> b)) ++
 
 static int make_sweep_view(pga_ctx *c, SweepView *v)
 {
-	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->sori = c->sori, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
-	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4;
+	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
+	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4, v->stage_c = c->any_multi;
 	v->slow_cnt = nullptr, v->slow_list = (int32_t *)c->pool.get(S_SLOW, sizeof(int32_t) * (size_t)c->N);
 	if (!v->slow_list) return PGA_ERR_NOMEM;
 	return 0;
@@ -1417,8 +1377,8 @@ static int make_sweep_view(pga_ctx *c, SweepView *v)
 
 static void pack_records(pga_ctx *c)
 {
-	if (c->N) hipLaunchKernelGGL(k_pack_rec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->seg, c->cs, c->ce, c->pm, c->sc64, c->gid, c->cds, c->rank, c->nex, c->offx,
-	                             c->pid, c->N, c->recA, c->recB, c->recC);
+	if (c->N) hipLaunchKernelGGL(k_pack_rec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->seg, c->cs, c->ce, c->pm, c->rk, c->gid, c->cds, c->rank, c->nex, c->offx,
+	                             c->pid, c->sori, c->N, c->recA, c->recB, c->recC);
 }
 
 template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
@@ -1440,7 +1400,9 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 #endif
 	for (int rep = 0; rep < reps; ++rep) {
 		v.slow_cnt = c->dcnt + 12 + (c->sweep_seq & 1);
-		hipLaunchKernelGGL((k_sweep<MODE>), dim3(nt), dim3(SW_TILE), 0, c->st, v);
+		if (MODE == 1 || c->any_multi) hipLaunchKernelGGL((k_sweep<MODE, true>), dim3(nt), dim3(SW_TILE), 0, c->st, v);
+		else hipLaunchKernelGGL((k_sweep<MODE, MODE == 1>), dim3(nt), dim3(SW_TILE), 0, c->st, v);
+		if (timed_which >= 0 && reps == 1) HIPCHK(hipEventRecord(t.b, c->st)); // the events bracket k_sweep itself (what rocprofv3 reports for it)
 		hipLaunchKernelGGL((k_sweep_slow<MODE>), dim3(64), dim3(BLOCK), 0, c->st, v, (long long *)(c->dcnt + 12 + ((c->sweep_seq + 1) & 1)));
 		++c->sweep_seq;
 	}
@@ -1453,11 +1415,14 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 		double d[8] = { 0 };
 		for (size_t w = 0; w < (size_t)SW_NW * nt; ++w)
 			for (int k = 1; k < 8; ++k) d[k] += (double)(hp[w * 8 + k] - hp[w * 8 + k - 1]);
-		fprintf(stderr, "[sweep<%d> profile, cycles/wave] load+put %.0f | barrier %.0f | count+scan %.0f | list %.0f | eval %.0f | argmin %.0f | finish %.0f\n", MODE,
+		fprintf(stderr, "[sweep<%d> profile, cycles/wave] load+put %.0f | barrier %.0f | count+scan %.0f | list %.0f | eval %.0f | - %.0f | finish %.0f\n", MODE,
 		        d[1] / (SW_NW * nt), d[2] / (SW_NW * nt), d[3] / (SW_NW * nt), d[4] / (SW_NW * nt), d[5] / (SW_NW * nt), d[6] / (SW_NW * nt), d[7] / (SW_NW * nt));
 	}
 #endif
-	if (timed_which >= 0) { HIPCHK(hipEventRecord(t.b, c->st)); c->timed.push_back(t); }
+	if (timed_which >= 0) {
+		if (reps != 1) HIPCHK(hipEventRecord(t.b, c->st));
+		c->timed.push_back(t);
+	}
 	return 0;
 }
 
@@ -1518,7 +1483,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	// persistent arrays
 	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
 	TRY(dalloc(c, &c->cs, N)); TRY(dalloc(c, &c->ce, N)); TRY(dalloc(c, &c->cm, N)); TRY(dalloc(c, &c->cds, N)); TRY(dalloc(c, &c->nex, N));
-	TRY(dalloc(c, &c->offx, N)); TRY(dalloc(c, &c->sori, N)); TRY(dalloc(c, &c->sadj, N)); TRY(dalloc(c, &c->pm, N)); TRY(dalloc(c, &c->sc64, N)); TRY(dalloc(c, &c->recA, N)); TRY(dalloc(c, &c->recB, N)); TRY(dalloc(c, &c->recC, N));
+	TRY(dalloc(c, &c->offx, N)); TRY(dalloc(c, &c->sori, N)); TRY(dalloc(c, &c->sadj, N)); TRY(dalloc(c, &c->pm, N)); TRY(dalloc(c, &c->rk, N)); TRY(dalloc(c, &c->recA, N)); TRY(dalloc(c, &c->recB, N)); TRY(dalloc(c, &c->recC, N));
 	TRY(dalloc(c, &c->rank, N)); TRY(dalloc(c, &c->sdom, N)); TRY(dalloc(c, &c->pdom, N)); TRY(dalloc(c, &c->pdom0, N)); TRY(dalloc(c, &c->flags, N));
 	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->ctg_base, GL + 1)); TRY(dalloc(c, &c->inv, N)); TRY(dalloc(c, &c->headpos, GL + 1)); TRY(dalloc(c, &c->exon, E));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q));
@@ -1531,12 +1496,17 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	for (int g = 0; g < GL; ++g) ctg_base[(size_t)g + 1] = ctg_base[(size_t)g] + sh->n_ctg[g];
 	c->n_seg_ctg = ctg_base[(size_t)GL];
 	c->h_ggl.assign(sh->genome_global, sh->genome_global + GL);
-	uint32_t max_cs = 0, max_cm = 0;
+	uint32_t max_cs = 0, max_cm = 0, max_sadj = 0;
+	bool neg_sadj = false, multi = false;
 	for (int i = 0; i < N; ++i) {
 		if (sh->cs[i] < 0 || sh->ce[i] < sh->cs[i] || sh->cm[i] < 0 || sh->cid[i] < 0) return PGA_ERR_RANGE;
 		max_cs = std::max(max_cs, (uint32_t)sh->cs[i]), max_cm = std::max(max_cm, (uint32_t)sh->cm[i]);
+		if (sh->score_adj[i] < 0) neg_sadj = true; else max_sadj = std::max(max_sadj, (uint32_t)sh->score_adj[i]);
+		multi = multi || sh->n_exon_of[i] != 1;
 	}
 	c->cs_bits = bits_for(max_cs), c->cm_bits = bits_for(max_cm), c->seg_bits = bits_for((uint32_t)std::max(1, c->n_seg_ctg));
+	c->sc_bits = neg_sadj ? 64 : std::min(64, 33 + bits_for(max_sadj)); // score key = score_adj << 33 | preferred << 32 | hash(pid)
+	c->any_multi = multi;
 	std::vector<int2> hex((size_t)E);
 	for (int e = 0; e < E; ++e) hex[(size_t)e] = make_int2(sh->exon_os[e], sh->exon_oe[e]);
 
@@ -1575,18 +1545,28 @@ extern "C" int pga_begin(pga_ctx_t *c)
 		*f_offx = up + 6 * (size_t)N, *f_cs = up + 7 * (size_t)N, *f_ce = up + 8 * (size_t)N, *f_cm = up + 9 * (size_t)N,
 		*f_gnm = up + 10 * (size_t)N, *f_seg = up + 11 * (size_t)N, *f_gid = up + 12 * (size_t)N, *f_cds = up + 13 * (size_t)N;
 	uint8_t *f_rev = (uint8_t *)(up + 14 * (size_t)N);
-	uint64_t *sc64_f = (uint64_t *)c->pool.get(S_TAB_A, sizeof(uint64_t) * (size_t)N);
+	int32_t *rk_f = (int32_t *)c->pool.get(S_TAB_A, sizeof(uint64_t) * (size_t)N);
+	int32_t *head = (int32_t *)c->pool.get(S_HEAD, sizeof(int32_t) * ((size_t)N + 1)), *incl = (int32_t *)c->pool.get(S_SLOT, sizeof(int32_t) * ((size_t)N + 1));
 	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, 0);
 	uint32_t *val = (uint32_t *)c->pool.get(S_VAL_A, 0);
-	if (!up || !sc64_f || !key || !val) return PGA_ERR_NOMEM;
+	if (!up || !rk_f || !head || !incl || !key || !val) return PGA_ERR_NOMEM;
 	FileHits f = { f_pid, f_cid, f_rank, f_sori, f_sadj, f_nex, f_offx, f_cs, f_ce, f_cm, f_rev };
 	hipLaunchKernelGGL(k_prepare, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, N, c->goff, GL, c->ctg_base, c->exon, c->prot_gid, c->gene_pref,
-	                   c->cs_bits, f_gnm, f_seg, f_gid, f_cds, sc64_f, key, val);
-	// X order: pg_hit_sort(g, 0), hit.c:29-64, for every genome at once; stable => ties keep file order
+	                   f_gnm, f_seg, f_gid, f_cds, key, val);
 	uint64_t *ks; uint32_t *vs;
+	{ // dense rank of the score keys (see k_rank_scatter)
+		TRY(radix_sort_pool(c, key, val, N, c->sc_bits, &ks, &vs));
+		hipLaunchKernelGGL(k_arc_head, dim3(nblk(N)), dim3(BLOCK), 0, c->st, ks, (int64_t)N, head);
+		I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+		device_scan<I32>(InI32{head}, OutInclI32{incl}, N, tile, OpSum{}, I32{0}, c->st);
+		hipLaunchKernelGGL(k_rank_scatter, dim3(nblk(N)), dim3(BLOCK), 0, c->st, ks, vs, incl, N, rk_f);
+	}
+	// X order: pg_hit_sort(g, 0), hit.c:29-64, for every genome at once; stable => ties keep file order
+	key = (uint64_t *)c->pool.get(S_KEY_A, 0), val = (uint32_t *)c->pool.get(S_VAL_A, 0);
+	hipLaunchKernelGGL(k_xkey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f_seg, f_cs, N, c->cs_bits, key, val);
 	TRY(radix_sort_pool(c, key, val, N, c->cs_bits + c->seg_bits, &ks, &vs));
-	HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->sc64, c->flags };
-	hipLaunchKernelGGL(k_gather, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, f_gnm, f_seg, f_gid, f_cds, sc64_f, vs, N, c->goff, o);
+	HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->rk, c->flags };
+	hipLaunchKernelGGL(k_gather, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, f_gnm, f_seg, f_gid, f_cds, rk_f, vs, N, c->goff, o);
 	hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv);
 	HIPCHK(hipMemcpyAsync(c->headpos, c->goff, sizeof(int32_t) * ((size_t)GL + 1), hipMemcpyDeviceToDevice, c->st));
 	// running max of ce per contig
@@ -2046,10 +2026,9 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	}
 	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * 18 * (size_t)T + 64);
 	if (!tmp) return PGA_ERR_NOMEM;
-	uint64_t *tmp64 = (uint64_t *)(tmp + 16 * (size_t)T);
-	PermArrays p = { { c->fidx, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, (int32_t *)c->flags }, c->sc64 };
-	hipLaunchKernelGGL(k_ov_gather, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, inv, tmp, tmp64, remap);
-	hipLaunchKernelGGL(k_ov_scatter, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, T, tmp, tmp64, c->gnm, c->goff);
+	PermArrays p = { { c->fidx, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, (int32_t *)c->flags, c->rk } };
+	hipLaunchKernelGGL(k_ov_gather, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, inv, tmp, remap);
+	hipLaunchKernelGGL(k_ov_scatter, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, T, tmp, c->gnm, c->goff);
 	hipLaunchKernelGGL(k_ov_remap_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, N, remap);
 	SegMax *tile = (SegMax *)c->pool.get(S_TILE, 0);
 	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);

@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-B="python bench.py --no-cpu-baseline --steps 1 --warmup 0"
-$B --genomes-per-gpu 400 2>&1 >/dev/null | grep "profile" | sort | uniq -c | sort -rn | head -4
-$B --genomes-per-gpu 100 2>&1 >/dev/null | grep "profile" | head -3
 timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+B="python bench.py --no-cpu-baseline --steps 1 --warmup 0"
+for g in 400 100; do
+PGA_SW_REPS=20 $B --genomes-per-gpu $g 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('genomes $g', round(d['roofline']['avg_launch_ms']/20*1000,1), 'us', d['gfa_md5'])"; done
+python bench.py --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline'])"
