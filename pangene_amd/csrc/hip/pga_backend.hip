@@ -256,7 +256,8 @@ __global__ __launch_bounds__(BLOCK) void k_pseudo3(const int32_t *gnm, const int
 // the interval-dominance sweep: pg_shadow (overlap.c:101-178) and pg_flt_ov_isoform (58-93)
 // ------------------------------------------------------------------------------------------------
 // Packed per-hit records for the sweep: a partner costs 16-byte loads instead of a dozen 4-byte ones.
-//   A = {seg, cs, ce, pm}   B = {rk, gid, cds, pid}   C = {rank, n_exon, off_exon, score_ori}
+//   A = {cs, seg, ce, pm}   B = {rk, gid, cds, pid}   C = {rank, n_exon, off_exon, score_ori}
+// (A.xy read as one 64-bit word is seg << 32 | cs: the sort key of the X order, non-decreasing along the array)
 // C is only needed for multi-exon hits, for two hits with the same score key and for score_dom.
 __global__ __launch_bounds__(BLOCK) void k_pack_rec(const int32_t *seg, const int32_t *cs, const int32_t *ce, const int32_t *pm, const int32_t *rk,
                                                       const int32_t *gid, const int32_t *cds, const int32_t *rank, const int32_t *nex, const int32_t *offx,
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_rec(const int32_t *seg, const in
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
-	A[h] = make_int4(seg[h], cs[h], ce[h], pm[h]);
+	A[h] = make_int4(cs[h], seg[h], ce[h], pm[h]);
 	B[h] = make_int4(rk[h], gid[h], cds[h], pid[h]);
 	C[h] = make_int4(rank[h], nex[h], offx[h], sori[h]);
 }
@@ -312,6 +313,8 @@ struct SwBest { bool lose; uint32_t best; int j, ov, pid, cds; };
 
 // Thread-per-hit form of one pair, used by k_sweep_slow: partner p (records a/b/c, flags fp, array index pi) of hit t;
 // EARLIER: p precedes t in the array.  overlap.c:126-154 (pg_shadow) / 76-87 (pg_flt_ov_isoform).
+__device__ __forceinline__ int4 sw_scse(int4 r) { return make_int4(r.y, r.x, r.z, r.w); } // record A -> (seg, cs, ce, pm)
+
 template <int MODE, bool EARLIER>
 __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBest &r, const int4 a, const uint32_t fp, const int4 b, const int4 c, int pi, bool ok)
 {
@@ -414,9 +417,9 @@ __device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl
 template <int MODE, bool STAGE_C>
 __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 {
-	static_assert(2 * SW_HALO <= 64 && SW_LDS <= 1024, "halo slots are staged by the first wave; slot ids are packed in 10 bits");
+	static_assert(2 * SW_HALO == 64 && SW_NW == 4 && SW_LDS <= 1024, "the slots past SW_TILE are staged one array per wave; slot ids are packed in 10 bits");
 	static_assert(MODE != 1 || STAGE_C, "score_dom needs score_ori, which lives in the C records");
-	__shared__ int4 sA[SW_LDS], sB[SW_LDS], sC[STAGE_C ? SW_LDS : 1];
+	__shared__ int4 sA[SW_LDS + 4], sB[SW_LDS], sC[STAGE_C ? SW_LDS : 1]; // sA: four sentinel slots close the array
 	__shared__ uint32_t sF[SW_LDS];
 	__shared__ uint32_t sPairAll[SW_NW][SW_WCAP];
 	__shared__ unsigned long long sKeyAll[SW_NW][64];
@@ -425,79 +428,92 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 	unsigned long long *sKey = sKeyAll[wave];
 	const int tile = blockIdx.x, base = tile * SW_TILE - SW_HALO;
 	SW_STAMP(0);
-#pragma unroll
-	for (int k = 0; k < 2; ++k) {
-		if (k == 1 && tid >= 2 * SW_HALO) break; // the first wave also stages the slots past SW_TILE
-		const int l = k * SW_TILE + tid, g = base + l;
-		int4 a = make_int4(-2, 0, 0, 0), b = make_int4(0, 0, 0, 0), c = b;
+	{
+		const int g = base + tid;
+		int4 a = make_int4(0, -2, 0, 0), b = make_int4(0, 0, 0, 0), c = b; // slots outside the array: contig -2, filtered
 		uint32_t f = PGA_F_FLT;
 		if (g >= 0 && g < v.n) {
 			a = v.A[g], b = v.B[g], f = v.flags[g];
 			if (STAGE_C) c = v.C[g];
 		}
-		sA[l] = a, sB[l] = b, sF[l] = f;
-		if (STAGE_C) sC[l] = c;
+		// the 2 * SW_HALO slots past SW_TILE: one array per wave, so that no wave has more to stage than the others
+		const int l2 = SW_TILE + lane, g2 = base + l2;
+		const bool in2 = lane < 2 * SW_HALO && g2 >= 0 && g2 < v.n;
+		if (wave == 0) sA[l2] = in2 ? v.A[g2] : make_int4(0, -2, 0, 0);
+		else if (wave == 1) sB[l2] = in2 ? v.B[g2] : make_int4(0, 0, 0, 0);
+		else if (wave == 2) sF[l2] = in2 ? v.flags[g2] : PGA_F_FLT;
+		else if (STAGE_C) sC[l2] = in2 ? v.C[g2] : make_int4(0, 0, 0, 0);
+		sA[tid] = a, sB[tid] = b, sF[tid] = f;
+		if (STAGE_C) sC[tid] = c;
 	}
+	if (tid < 4) sA[SW_LDS + tid] = make_int4(0, -2, 0, 0);
 	sKey[lane] = 0;
 	SW_STAMP(1);
 	__syncthreads();
 	SW_STAMP(2);
 	// ---- from here on every wave is on its own ----
 	const int lo = SW_HALO + wave * 64, wend = lo + 64 + SW_HALO; // own slots [lo, lo+64), window [lo-SW_HALO, wend)
-	// later partners of a slot: the run (l, l+n]; only the part that has a member among the wave's hits is listed
-	int first[2] = { 0, 0 }, cnt[2] = { 0, 0 };
+	// Later partners of a slot l: the run (l, e) with e = the first slot whose sort key (contig, cs) is not below
+	// (contig_l, ce_l); the keys are non-decreasing, so four candidates are tested per round trip to LDS and the tests are
+	// independent.  Lane t looks after its own slot and, the first SW_HALO lanes, after a slot of the left context, whose
+	// run matters from the wave's first hit on.
+	const int l1 = lo + lane, l0 = lo - SW_HALO + (lane & (SW_HALO - 1));
+	int m1 = l1 + 1, m0 = lo, c1, c0;
+	{
+		const int4 a1 = sA[l1], a0 = sA[l0];
+		const unsigned long long t1 = (unsigned long long)(uint32_t)a1.y << 32 | (uint32_t)a1.z, t0 = (unsigned long long)(uint32_t)a0.y << 32 | (uint32_t)a0.z;
+		bool go1 = !(sF[l1] & PGA_F_FLT), go0 = lane < SW_HALO && !(sF[l0] & PGA_F_FLT);
+		const int f1 = m1;
+		while (go0 || go1) {
+			unsigned long long q1[4], q0[4];
 #pragma unroll
-	for (int k = 0; k < 2; ++k) {
-		const int l = k == 0 ? lo - SW_HALO + lane : lo + lane; // k == 0: a slot of the left context (first SW_HALO lanes)
-		if (k == 0 && lane >= SW_HALO) continue;
-		const int2 a = *(const int2 *)&sA[l].x; // (seg, cs)
-		const int ce = sA[l].z;
-		if (sF[l] & PGA_F_FLT) continue;
-		// a context slot's run reaches the wave's hits iff it reaches the first of them: start there
-		int m = k == 0 ? lo : l + 1;
-		first[k] = m;
-		for (;;) { // four candidates per round trip to LDS
-			int2 q[4];
+			for (int u = 0; u < 4; ++u) q1[u] = *(const unsigned long long *)&sA[m1 + u], q0[u] = *(const unsigned long long *)&sA[m0 + u];
+			int n1 = 0, n0 = 0;
 #pragma unroll
-			for (int u = 0; u < 4; ++u) q[u] = *(const int2 *)&sA[m + u < SW_LDS ? m + u : SW_LDS - 1];
-			int nq = 0;
-			bool go = true;
-#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				go = go && m + u < wend && q[u].x == a.x && q[u].y < ce;
-				nq += go ? 1 : 0;
-			}
-			m += nq;
-			if (nq < 4) break;
+			for (int u = 0; u < 4; ++u) n1 += q1[u] < t1 ? 1 : 0, n0 += q0[u] < t0 ? 1 : 0;
+			n1 = go1 ? n1 : 0, n0 = go0 ? n0 : 0;
+			m1 += n1, m0 += n0;
+			go1 = n1 == 4 && m1 < wend, go0 = n0 == 4 && m0 < wend;
 		}
-		cnt[k] = m - first[k];
+		c1 = (m1 < wend ? m1 : wend) - f1, c0 = (m0 < wend ? m0 : wend) - lo;
 	}
-	int tot;
-	int off = wave_scan_small(cnt[0] + cnt[1], &tot);
 	SW_STAMP(3);
+	// The pair list, k-th partners of all slots together: their places follow from one ballot, no prefix sum needed.
+	int tot = 0;
+#pragma nounroll
+	for (int k = 0;; ++k) {
+		const unsigned long long mk = __ballot(c0 > k);
+		if (mk == 0) break;
+		const int at = tot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+		if (c0 > k && at < SW_WCAP) sPair[at] = (uint32_t)l0 << 10 | (uint32_t)(lo + k);
+		tot += __popcll(mk);
+	}
+#pragma nounroll
+	for (int k = 0;; ++k) {
+		const unsigned long long mk = __ballot(c1 > k);
+		if (mk == 0) break;
+		const int at = tot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+		if (c1 > k && at < SW_WCAP) sPair[at] = (uint32_t)l1 << 10 | (uint32_t)(l1 + 1 + k);
+		tot += __popcll(mk);
+	}
 	const bool listed = tot <= SW_WCAP; // wave-uniform
+	wave_sync();
+	SW_STAMP(4);
 	if (listed) {
-#pragma nounroll
-		for (int k = 0; k < cnt[0]; ++k) sPair[off + k] = (uint32_t)(lo - SW_HALO + lane) << 10 | (uint32_t)(first[0] + k);
-		off += cnt[0];
-#pragma nounroll
-		for (int k = 0; k < cnt[1]; ++k) sPair[off + k] = (uint32_t)(lo + lane) << 10 | (uint32_t)(first[1] + k);
-		wave_sync();
-		SW_STAMP(4);
 		// one pair per lane: slot l precedes slot m in the array (l is "j", m is "i" of overlap.c:126-154 / 76-87)
 		for (int p = lane; p < tot; p += 64) {
 			const uint32_t w = sPair[p];
 			const int l = (int)(w >> 10), m = (int)(w & 1023u);
 			const uint32_t fj = sF[l], fi = sF[m];
-			const int2 aj = *(const int2 *)&sA[l].y, ai = *(const int2 *)&sA[m].y; // (cs, ce)
-			const int4 bj = sB[l], bi = sB[m];                                       // {rk, gid, cds, pid}
+			const int csj = sA[l].x, cej = sA[l].z, csi = sA[m].x, cei = sA[m].z;
+			const int4 bj = sB[l], bi = sB[m]; // {rk, gid, cds, pid}
 			bool ok = !((fj | fi) & PGA_F_FLT);
 			if (v.check_strand) ok = ok && !((fj ^ fi) & PGA_F_REV);
 			const bool same_gene = bj.y == bi.y;
 			if (MODE == 2) ok = ok && same_gene;
 			int x;
 			{
-				const int s0 = aj.x > ai.x ? aj.x : ai.x, e0 = aj.y < ai.y ? aj.y : ai.y;
+				const int s0 = csj > csi ? csj : csi, e0 = cej < cei ? cej : cei;
 				x = e0 > s0 ? e0 - s0 : 0; // single-exon x single-exon: the CDS intersection is the interval intersection
 			}
 			bool i_loses = (uint32_t)bi.x < (uint32_t)bj.x;
@@ -507,7 +523,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 			if (__ballot(multi || tie)) {
 				if (multi || tie) {
 					const int4 cj = STAGE_C ? sC[l] : v.C[base + l], ci = STAGE_C ? sC[m] : v.C[base + m]; // {rank, n_exon, off_exon, score_ori}
-					if (multi) x = cds_inter(v.exon, cj.z, cj.y, aj.x, aj.y, ci.z, ci.y, ai.x, ai.y);
+					if (multi) x = cds_inter(v.exon, cj.z, cj.y, csj, cej, ci.z, ci.y, csi, cei);
 					if (tie) i_loses = ci.x > cj.x; // rank_i > rank_j
 				}
 			}
@@ -539,10 +555,10 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 		const int h = tile * SW_TILE + wave * 64 + lane, lh = lo + lane;
 		const uint32_t fl = sF[lh];
 		if (h < v.n && !(fl & PGA_F_FLT)) { // filtered hits keep stale shadow/pid_dom (overlap.c:112)
-			const int4 a = sA[lh];
+			const int4 a = sA[lh]; // {cs, seg, ce, pm}
 			// partners outside the window?  (pm = running max of ce is non-decreasing inside a contig)
 			const int4 w0 = sA[lo - SW_HALO], w1 = sA[wend - 1];
-			const bool open = (w0.x == a.x && w0.w > a.y) || (w1.x == a.x && w1.y < a.z);
+			const bool open = (w0.y == a.y && w0.w > a.x) || (w1.y == a.y && w1.x < a.z);
 			if (!listed || open) {
 				const unsigned long long at = atomicAdd((unsigned long long *)v.slow_cnt, 1ull);
 				v.slow_list[at] = h;
@@ -557,12 +573,12 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 					if (MODE == 1) {
 						const int4 aw = sA[W], cw = sC[W], c2 = sC[lh];
 						so_w = cw.w, so_h = c2.w, cds_h = sB[lh].z;
-						const int s0 = aw.y > a.y ? aw.y : a.y, e0 = aw.z < a.z ? aw.z : a.z;
+						const int s0 = aw.x > a.x ? aw.x : a.x, e0 = aw.z < a.z ? aw.z : a.z;
 						ov = e0 > s0 ? e0 - s0 : 0;
 						if ((fl | sF[W]) & F_MULTI) { // the earlier hit goes first, as in the pair evaluation
 							const bool wf = W < lh;
-							ov = cds_inter(v.exon, wf ? cw.z : c2.z, wf ? cw.y : c2.y, wf ? aw.y : a.y, wf ? aw.z : a.z,
-							               wf ? c2.z : cw.z, wf ? c2.y : cw.y, wf ? a.y : aw.y, wf ? a.z : aw.z);
+							ov = cds_inter(v.exon, wf ? cw.z : c2.z, wf ? cw.y : c2.y, wf ? aw.x : a.x, wf ? aw.z : a.z,
+							               wf ? c2.z : cw.z, wf ? c2.y : cw.y, wf ? a.x : aw.x, wf ? a.z : aw.z);
 						}
 					}
 				}
@@ -586,7 +602,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *ne
 		SwHit t;
 		const int4 ch = v.C[h];
 		{
-			const int4 a = v.A[h], b = v.B[h];
+			const int4 a = sw_scse(v.A[h]), b = v.B[h];
 			t.sg = a.x, t.cs = a.y, t.ce = a.z, t.gid = b.y, t.cds = b.z, t.rank = ch.x, t.nex = ch.y, t.offx = ch.z;
 			t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
 			t.sc = (uint32_t)b.x;
@@ -595,13 +611,13 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *ne
 		// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so the
 		// walk stops at the first j whose pm is <= cs_h.
 		for (int j = h - 1; j >= 0; --j) {
-			const int4 a = v.A[j];
+			const int4 a = sw_scse(v.A[j]);
 			if (a.x != t.sg || a.w <= t.cs) break;
 			sw_pair<MODE, true>(v, t, r, a, v.flags[j], v.B[j], v.C[j], j, a.z > t.cs);
 		}
 		// partners after h: every i with cs_i < ce_h
 		for (int i = h + 1; i < v.n; ++i) {
-			const int4 a = v.A[i];
+			const int4 a = sw_scse(v.A[i]);
 			if (a.x != t.sg || a.y >= t.ce) break;
 			sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i, true);
 		}
