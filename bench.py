@@ -66,6 +66,7 @@ def main():
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     lib.pg_set_exact_mode({"off": 0, "auto": 1, "all": 2}[a.exact])
     keep = None
+    exchange_kind = "none (single process)"
     force_x = os.environ.get("PANGENE_FORCE_EXCHANGE") == "1"
     if world > 1 or force_x:
         if world == 1:
@@ -73,7 +74,12 @@ def main():
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
         from pangene_amd import exchange
-        keep = exchange.install(lib, device=dev)
+        # RCCL called by the library itself, on the kernels' stream; PANGENE_EXCHANGE=torch keeps the collectives in
+        # torch.distributed (Python callbacks) instead -- also the fallback when RCCL cannot be bound
+        exchange_kind = "rccl-native"
+        if os.environ.get("PANGENE_EXCHANGE") == "torch" or not exchange.install_native(lib):
+            keep = exchange.install(lib, device=dev)
+            exchange_kind = "torch.distributed(nccl) callbacks"
 
     # ---- synthetic input (not timed): every rank writes its own genomes, then registers the ids of the others
     G = a.genomes_per_gpu * world
@@ -196,7 +202,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic bacterial pangenome, %d genomes x %d proteins per GPU (%d genomes, %d hits in total), default options"
                                    % (a.genomes_per_gpu, a.proteins, G, tot_hits),
-                       "exact_order_mode": a.exact, "parallelism": "genomes sharded over %d GPU(s)" % world},
+                       "exact_order_mode": a.exact, "parallelism": "genomes sharded over %d GPU(s)" % world, "exchange": exchange_kind},
             "roofline": roof, "cpu_baseline": cpu,
             "gfa_md5": hashlib.md5(gfa).hexdigest() if world == 1 else None,
             "gfa_identical_to_reference": (hashlib.md5(gfa).hexdigest() == ref_md5) if ref_md5 else None,

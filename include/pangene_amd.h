@@ -190,6 +190,14 @@ typedef struct {
 } pg_exchange_t;
 void pg_set_exchange(const pg_exchange_t *x);
 
+/* Built-in exchange for the HIP backend: RCCL collectives enqueued on the kernels' own stream (no host round trip).
+ * Rank 0 obtains the 128-byte bootstrap id, the launcher hands it to every rank, every rank calls pg_rccl_init with
+ * its HIP device current; this installs the exchange (pg_set_exchange).  0 on success; pg_rccl_error() says why not. */
+int pg_rccl_unique_id(void *out128);
+int pg_rccl_init(int32_t rank, int32_t world, const void *id128);
+int pg_rccl_finalize(void);
+const char *pg_rccl_error(void);
+
 /* Wall-clock seconds spent inside the last pg_post_process + pg_graph_gen (stages A+B+C), and the
  * number of hits they processed (local shard). */
 double  pg_last_path_seconds(void);

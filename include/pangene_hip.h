@@ -241,6 +241,8 @@ const pga_backend_t *pga_backend(void);
 /* Optional: run every kernel on this hipStream_t instead of the library's own stream (lets a host
  * framework order its collectives with the kernels without extra synchronisation). */
 int pga_set_stream(pga_ctx_t *ctx, void *hip_stream);
+/* The hipStream_t the live context runs on (collectives of a sharded run are enqueued on it). */
+void *pga_active_stream(void);
 
 /* Kernel timing hooks for bench.py: HIP events bracket every launch of the named kernel class on the
  * library's stream.  which: 0 = "k1" (stage A sweep, the hit-filter+overlap kernel). */

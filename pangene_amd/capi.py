@@ -69,6 +69,14 @@ _API = {
     "pg_phase_name": (C.c_char_p, [C.c_int]),
 }
 
+# only in the HIP product library (the oracle-host test library has no RCCL exchange)
+_API_HIP_ONLY = {
+    "pg_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "pg_rccl_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p]),
+    "pg_rccl_finalize": (C.c_int, []),
+    "pg_rccl_error": (C.c_char_p, []),
+}
+
 
 def load(oracle_host: bool = False) -> C.CDLL:
     path = LIB_ORACLE_HOST if oracle_host else LIB_HIP
@@ -78,6 +86,10 @@ def load(oracle_host: bool = False) -> C.CDLL:
     for name, (res, args) in _API.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    if not oracle_host:
+        for name, (res, args) in _API_HIP_ONLY.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
     return lib
 
 

@@ -980,24 +980,46 @@ __global__ __launch_bounds__(BLOCK) void k_arc_l2(const uint64_t *key, int64_t m
 // ------------------------------------------------------------------------------------------------
 // cross-shard merge of arc tables (after the all-gather): gather valid entries, sort by x, wave-per-run sums
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_mg_keys(const pga_arc_part_t *g, const int32_t *src, int64_t tot, uint64_t *key, uint32_t *val)
+// Every rank's table arrives sorted by x with unique keys, so the merged order needs no sort: the place of an entry is
+// the number of entries before it in all the tables (binary searches; equal keys keep rank order).
+struct MergeLists { int32_t W; int64_t slot_sz; const int64_t *off; }; // off[r] = entries of ranks < r, off[W] = total
+
+__device__ __forceinline__ int64_t mg_bound(const pga_arc_part_t *a, int64_t n, uint64_t x, bool upper)
 {
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= tot) return;
-	key[i] = g[src[i]].x; // x = v<<32|w with v,w < 2^21: 53 significant bits at most
-	val[i] = (uint32_t)src[i];
+	int64_t lo = 0, hi = n;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		const uint64_t y = a[mid].x;
+		if (upper ? y <= x : y < x) lo = mid + 1; else hi = mid;
+	}
+	return lo;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_mg_head(const uint64_t *key, int64_t m, int32_t *head)
+__global__ __launch_bounds__(BLOCK) void k_mg_rank(const pga_arc_part_t *g, MergeLists L, uint64_t *key, uint32_t *val)
 {
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i < m) head[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= L.off[L.W]) return;
+	int r = 0;
+	while (L.off[r + 1] <= i) ++r; // the table entry i belongs to (W is small)
+	const int64_t k = i - L.off[r], src = r * L.slot_sz + k;
+	const uint64_t x = g[src].x;
+	int64_t pos = k;
+	for (int q = 0; q < L.W; ++q)
+		if (q != r) pos += mg_bound(g + q * L.slot_sz, L.off[q + 1] - L.off[q], x, q < r);
+	key[pos] = x, val[pos] = (uint32_t)src;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_mg_runstart(const int32_t *head, const int32_t *slot, int64_t m, int32_t *run_start)
+struct InMgHead { const uint64_t *key; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(i == 0 || key[i] != key[i - 1]) ? 1 : 0}; } };
+
+__global__ __launch_bounds__(BLOCK) void k_mg_count(const uint64_t *key, const int32_t *slot, int64_t m, int64_t *box) // number of distinct keys
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0) *box = slot[m - 1] + ((m == 1 || key[m - 1] != key[m - 2]) ? 1 : 0); // slot = exclusive count of run heads
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mg_runstart(const uint64_t *key, const int32_t *slot, int64_t m, int32_t *run_start)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i < m && head[i]) run_start[slot[i]] = (int32_t)i;
+	if (i < m && (i == 0 || key[i] != key[i - 1])) run_start[slot[i]] = (int32_t)i;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_mg_sum(const pga_arc_part_t *g, const uint32_t *val, int64_t m, int64_t n_run, const int32_t *run_start, pga_arc_part_t *out)
@@ -1467,12 +1489,17 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 	delete c;
 }
 
+static hipStream_t g_active_stream = nullptr; // stream of the live context: collectives of a sharded run are enqueued here
+
+extern "C" void *pga_active_stream(void) { return (void *)g_active_stream; }
+
 extern "C" int pga_set_stream(pga_ctx_t *c, void *hip_stream)
 {
 	if (c == nullptr) return PGA_ERR_ARG;
 	if (c->st) HIPCHK(hipStreamSynchronize(c->st));
 	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
 	c->st = (hipStream_t)hip_stream, c->own_stream = false;
+	g_active_stream = c->st;
 	return 0;
 }
 
@@ -1489,6 +1516,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 {
 	const int N = c->N, E = c->E, GL = c->n_genome;
 	HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+	g_active_stream = c->st;
 	{
 		int dev = 0, ncu = 0;
 		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) c->n_cu = ncu;
@@ -1821,39 +1849,32 @@ extern "C" int pga_arc_merge(pga_ctx_t *c, const pga_arc_part_t *gathered, const
 	for (int r = 0; r < W; ++r) tot += count[r];
 	*out = nullptr, *n_out = 0;
 	if (tot == 0) return 0;
-	std::vector<int32_t> src((size_t)tot);
-	{
-		int64_t i = 0;
-		for (int r = 0; r < W; ++r) for (int64_t k = 0; k < count[r]; ++k) src[(size_t)i++] = (int32_t)(r * slot_sz + k);
-	}
-	int32_t *d_src = (int32_t *)c->pool.get(S_MG_SRC, sizeof(int32_t) * (size_t)tot);
-	uint64_t *key = (uint64_t *)c->pool.get(S_MG_KEY, sizeof(uint64_t) * 2 * (size_t)tot + 64);
-	uint32_t *val = (uint32_t *)c->pool.get(S_MG_VAL, sizeof(uint32_t) * 2 * (size_t)tot + 64);
-	int32_t *head = (int32_t *)c->pool.get(S_MG_HEAD, sizeof(int32_t) * (size_t)tot), *slot = (int32_t *)c->pool.get(S_MG_SLOT, sizeof(int32_t) * (size_t)tot);
-	uint32_t *table = (uint32_t *)c->pool.get(S_TABLE, 0);
+	std::vector<int64_t> off((size_t)W + 1, 0);
+	for (int r = 0; r < W; ++r) off[(size_t)r + 1] = off[(size_t)r] + count[r];
+	int64_t *d_off = (int64_t *)c->pool.get(S_MG_SRC, sizeof(int64_t) * ((size_t)W + 1));
+	uint64_t *key = (uint64_t *)c->pool.get(S_MG_KEY, sizeof(uint64_t) * (size_t)tot + 64);
+	uint32_t *val = (uint32_t *)c->pool.get(S_MG_VAL, sizeof(uint32_t) * (size_t)tot + 64);
+	int32_t *slot = (int32_t *)c->pool.get(S_MG_SLOT, sizeof(int32_t) * (size_t)tot);
 	int32_t *tile = (int32_t *)c->pool.get(S_TILE, 0);
-	if (!d_src || !key || !val || !head || !slot || !table || !tile) return PGA_ERR_NOMEM;
-	if (tot > 2 * (int64_t)c->N + 2 && (rs_table_len(tot) > rs_table_len(2 * (int64_t)c->N + 2))) { // work buffers are sized for 2N items
-		table = (uint32_t *)c->pool.get(S_TABLE, sizeof(uint32_t) * (size_t)rs_table_len(tot));
+	if (!d_off || !key || !val || !slot || !tile) return PGA_ERR_NOMEM;
+	if (tot > 2 * (int64_t)c->N + 2) { // the scan buffer is sized for 2N items
 		tile = (int32_t *)c->pool.get(S_TILE, sizeof(int64_t) * (size_t)(scan_tiles(std::max<int64_t>(rs_table_len(tot), tot)) + 8));
-		if (!table || !tile) return PGA_ERR_NOMEM;
+		if (!tile) return PGA_ERR_NOMEM;
 	}
-	TRY(upload(c, d_src, src.data(), (size_t)tot));
-	hipLaunchKernelGGL(k_mg_keys, dim3(nblk(tot)), dim3(BLOCK), 0, c->st, gathered, d_src, tot, key, val);
-	RadixBufs b = { key + tot, val + tot, table, tile };
-	uint64_t *ks; uint32_t *vs;
-	const int vb = bits_for((uint32_t)(2 * std::max(1, c->n_seg)));
-	device_radix_sort(key, val, tot, 32 + vb, b, &ks, &vs, c->st);
-	hipLaunchKernelGGL(k_mg_head, dim3(nblk(tot)), dim3(BLOCK), 0, c->st, ks, tot, head);
-	device_scan<I32>(InI32{head}, OutExclI32{slot}, tot, (I32 *)tile, OpSum{}, I32{0}, c->st);
-	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, slot + (tot - 1), head + (tot - 1), c->dcnt + 10);
-	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	TRY(upload(c, d_off, off.data(), (size_t)W + 1));
+	MergeLists L = { W, slot_sz, d_off };
+	hipLaunchKernelGGL(k_mg_rank, dim3(nblk(tot)), dim3(BLOCK), 0, c->st, gathered, L, key, val);
+	device_scan<I32>(InMgHead{key}, OutExclI32{slot}, tot, (I32 *)tile, OpSum{}, I32{0}, c->st);
+	int64_t *box = nullptr;
+	HIPCHK(hipHostGetDevicePointer((void **)&box, c->h_cnt, 0)); // the count goes straight into the pinned mirror
+	hipLaunchKernelGGL(k_mg_count, dim3(1), dim3(64), 0, c->st, key, slot, tot, box + 10);
 	TRY(sync_st(c));
+	const uint64_t *ks = key; const uint32_t *vs = val;
 	const int64_t A = c->h_cnt[10];
 	int32_t *run_start = (int32_t *)c->pool.get(S_MG_RUN, sizeof(int32_t) * (size_t)A + 16);
 	pga_arc_part_t *res = (pga_arc_part_t *)c->pool.get(S_MG_OUT, sizeof(pga_arc_part_t) * (size_t)A + 16);
 	if (!run_start || !res) return PGA_ERR_NOMEM;
-	hipLaunchKernelGGL(k_mg_runstart, dim3(nblk(tot)), dim3(BLOCK), 0, c->st, head, slot, tot, run_start);
+	hipLaunchKernelGGL(k_mg_runstart, dim3(nblk(tot)), dim3(BLOCK), 0, c->st, ks, slot, tot, run_start);
 	hipLaunchKernelGGL(k_mg_sum, dim3(nblk(A, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gathered, vs, tot, A, run_start, res);
 	*out = res, *n_out = A;
 	return 0;
@@ -2176,6 +2197,27 @@ extern "C" int pga_selftest_sort(uint64_t *keys, uint32_t *vals, int64_t n, int3
 	HIPCHK(hipMemcpy(vals, vr, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
 	(void)hipFree(ka); (void)hipFree(kb); (void)hipFree(va); (void)hipFree(vb); (void)hipFree(table); (void)hipFree(tile);
 	return 0;
+}
+
+// cross-shard arc merge on host data: `gathered` holds W slots of slot_sz entries (count[r] valid, sorted by x, unique keys)
+extern "C" int pga_selftest_merge(const pga_arc_part_t *gathered, const int64_t *count, int32_t W, int64_t slot_sz, pga_arc_part_t *out, int64_t *n_out)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PGA_ERR_NO_DEVICE;
+	pga_ctx c; // a bare context: stream, counters, pool
+	HIPCHK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
+	TRY(dalloc(&c, &c.dcnt, 16));
+	HIPCHK(hipHostMalloc((void **)&c.h_cnt, 16 * sizeof(int64_t), hipHostMallocDefault));
+	pga_arc_part_t *dg = nullptr, *res = nullptr;
+	HIPCHK(hipMalloc((void **)&dg, sizeof(pga_arc_part_t) * (size_t)(W * slot_sz + 1)));
+	HIPCHK(hipMemcpy(dg, gathered, sizeof(pga_arc_part_t) * (size_t)(W * slot_sz), hipMemcpyHostToDevice));
+	int rc = pga_arc_merge(&c, dg, count, W, slot_sz, &res, n_out);
+	if (rc == 0 && *n_out) rc = hipMemcpyAsync(out, res, sizeof(pga_arc_part_t) * (size_t)*n_out, hipMemcpyDeviceToHost, c.st) == hipSuccess ? 0 : PGA_ERR_NO_DEVICE;
+	(void)hipStreamSynchronize(c.st);
+	(void)hipFree(dg); (void)hipFree(c.dcnt); (void)hipHostFree(c.h_cnt);
+	c.pool.release();
+	(void)hipStreamDestroy(c.st);
+	return rc;
 }
 
 // mode 0: exclusive sum; 1: exclusive max (identity -1); 2: segmented inclusive max with seg[]

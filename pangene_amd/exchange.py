@@ -69,5 +69,36 @@ def install(lib: C.CDLL, device=None, group=None):
     return (x, keep)
 
 
+def install_native(lib: C.CDLL, group=None) -> bool:
+    """Sharded runs of the HIP backend: let the library talk to RCCL itself (pg_rccl_init, include/pangene_amd.h) --
+    collectives are enqueued on the kernels' stream, no Python in the loop.  torch.distributed is only used to hand the
+    128-byte bootstrap id from rank 0 to the others.  Returns False (with the reason on stderr) if RCCL cannot be set up;
+    the caller then falls back to install()."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    uid = C.create_string_buffer(128)
+    ok = 1
+    if rank == 0 and lib.pg_rccl_unique_id(uid) != 0:
+        ok = 0
+    box = [uid.raw if ok else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    if box[0] is None:
+        if rank == 0:
+            print("[pangene_amd.exchange] native RCCL exchange unavailable:", lib.pg_rccl_error().decode(), flush=True)
+        return False
+    uid = C.create_string_buffer(box[0], 128)
+    rc = lib.pg_rccl_init(rank, world, uid)
+    flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32)
+    if world > 1:  # all ranks take the same path
+        if dist.get_backend(group) == "nccl":
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        print("[pangene_amd.exchange] pg_rccl_init failed on some rank:", lib.pg_rccl_error().decode(), flush=True)
+        lib.pg_rccl_finalize()
+        return False
+    return True
+
+
 def uninstall(lib: C.CDLL):
     lib.pg_set_exchange(None)

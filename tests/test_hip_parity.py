@@ -60,6 +60,43 @@ def test_device_primitives(hip):
             assert np.array_equal(out, exp), (n, mode)
 
 
+def test_cross_shard_arc_merge(hip):
+    """pga_arc_merge (what every rank runs on the all-gathered arc tables of a sharded round) against a numpy reduce-by-key"""
+    raw = C.CDLL(capi.LIB_HIP)
+    dt = np.dtype([("x", "<u8"), ("n_genome", "<i4"), ("tot_cnt", "<i4"), ("sum_dist", "<u8"), ("sum_s1", "<i8"), ("sum_s2", "<i8")])
+    assert dt.itemsize == 40
+    rng = np.random.default_rng(7)
+    for W, n_key, frac in [(1, 50, 1.0), (2, 1000, 0.7), (3, 5000, 0.5), (8, 20000, 0.6), (4, 10, 0.0), (5, 3000, 0.05)]:
+        universe = np.unique(rng.integers(0, 1 << 14, size=n_key, dtype=np.uint64) << np.uint64(32) | rng.integers(0, 1 << 14, size=n_key, dtype=np.uint64))
+        lists = []
+        for r in range(W):
+            keys = universe[rng.random(universe.size) < frac]  # sorted, unique
+            a = np.zeros(keys.size, dtype=dt)
+            a["x"] = keys
+            a["n_genome"] = rng.integers(1, 50, size=keys.size); a["tot_cnt"] = a["n_genome"] + rng.integers(0, 9, size=keys.size)
+            a["sum_dist"] = rng.integers(0, 1 << 40, size=keys.size, dtype=np.uint64)
+            a["sum_s1"] = rng.integers(0, 1 << 33, size=keys.size); a["sum_s2"] = rng.integers(0, 1 << 33, size=keys.size)
+            lists.append(a)
+        cnt = np.array([len(a) for a in lists], dtype=np.int64)
+        slot = int(max(1, cnt.max()))
+        g = np.zeros(W * slot, dtype=dt)
+        for r, a in enumerate(lists):
+            g[r * slot: r * slot + len(a)] = a
+        out = np.zeros(int(cnt.sum()) + 1, dtype=dt)
+        n_out = C.c_int64(0)
+        assert raw.pga_selftest_merge(g.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), C.c_int32(W), C.c_int64(slot),
+                                      out.ctypes.data_as(C.c_void_p), C.byref(n_out)) == 0
+        allv = np.concatenate(lists) if cnt.sum() else np.zeros(0, dtype=dt)
+        ux, inv = np.unique(allv["x"], return_inverse=True)
+        assert n_out.value == ux.size
+        got = out[: ux.size]
+        assert np.array_equal(got["x"], ux)
+        for f in ("n_genome", "tot_cnt", "sum_dist", "sum_s1", "sum_s2"):
+            exp = np.zeros(ux.size, dtype=np.int64)
+            np.add.at(exp, inv, allv[f].astype(np.int64))
+            assert np.array_equal(got[f].astype(np.int64), exp), (W, f)
+
+
 @pytest.mark.parametrize("name,variant", all_cases())
 def test_hip_equals_reference_md5(hip, expected, name, variant):
     """exact mode 'all': bytes equal to the untouched reference's, --bed line order included"""
@@ -125,6 +162,33 @@ def test_exchange_aliases_device_memory():
     t.add_(5)
     torch.cuda.synchronize()
     assert base[3].item() == 8 and t.data_ptr() == base.data_ptr()
+
+
+def test_forced_exchange_single_rank_native_rccl(built, tmp_path):
+    """one GPU, world size 1, every collective issued by the library itself through RCCL on its own stream: same GFA"""
+    import sys
+    files = synth.write_files(synth.bact(10, 300, seed=3), str(tmp_path / "x"))
+    code = r'''
+import sys, os, ctypes as C
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from pangene_amd import capi, exchange
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", WORLD_SIZE="1", PANGENE_FORCE_EXCHANGE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+lib = capi.load(); C.c_int.in_dll(lib, "pg_verbose").value = 0
+assert exchange.install_native(lib), lib.pg_rccl_error()
+out = capi.run(lib, sys.argv[2:], [])
+open(sys.argv[1], 'wb').write(out)
+lib.pg_rccl_finalize()
+dist.destroy_process_group()
+''' % ROOT
+    outp = str(tmp_path / "x.gfa")
+    r = subprocess.run([sys.executable, "-c", code, outp] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lib = capi.load()
+    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    assert open(outp, "rb").read() == capi.run(lib, files, [])
 
 
 def test_forced_exchange_single_rank_nccl(built, tmp_path):
