@@ -388,6 +388,36 @@ def fuzz(seed: int, harsh: bool = True) -> Iterator[Tuple[str, str]]:
         yield ("f%02d.paf" % j, "".join(lines))
 
 
+def dense(seed: int = 1, G: int = 4, n_small: int = 700, pile: int = 48) -> Iterator[Tuple[str, str]]:
+    """Stress shape for the interval sweep: per genome one contig with (a) a lattice of small single-exon hits that each
+    overlap a few neighbours, (b) one giant two-exon hit whose intron spans the whole lattice (every hit then has a
+    partner hundreds of array slots away), (c) pile-ups of `pile` different genes on one locus (hundreds of overlapping
+    pairs inside 64 consecutive hits) in single- and multi-exon flavour, (d) exact duplicates of one protein."""
+    for j in range(G):
+        rj = _rng(seed, 7000 + j)
+        lines = []
+
+        def add(name, plen, x, ops, span, ms, strand="+", idn=1.0):
+            mlen = int(3 * plen * idn)
+            lines.append("%s\t%d\t0\t%d\t%s\tD%d#0#c0\t%d\t%d\t%d\t%d\t%d\t0\tms:i:%d\tcg:Z:%s\n" % (
+                name, plen, plen, strand, j, 3000000, x, x + span, mlen, 3 * plen, ms, ops))
+
+        for g in range(n_small):  # (a)
+            if rj.random() < 0.1:
+                continue
+            plen = int(rj.choice([60, 100, 140]))
+            x = 5000 + g * 150 + int(rj.integers(0, 3)) * 30
+            add("s%04d" % g, plen, x, "%dM" % plen, 3 * plen, int(4.8 * plen * float(rj.choice([1.0, 0.95, 0.9]))), "+-"[int(rj.integers(0, 2))])
+        add("giant", 200, 4000, "100M%dN100M" % (n_small * 150 + 3000), 600 + n_small * 150 + 3000, 900 + j)  # (b)
+        for k in range(pile):  # (c) single exon, then three exons
+            plen = 100 + (k % 5)
+            add("p%03d" % k, plen, 400000 + (k % 4) * 30, "%dM" % plen, 3 * plen, 400 + int(rj.integers(0, 60)), "+-"[k & 1])
+            add("m%03d" % k, 90, 600000 + (k % 3) * 30, "30M200N30M300U30M", 270 + 500, 350 + int(rj.integers(0, 60)), "+-"[k & 1])
+        for k in range(3):  # (d) the same protein, same score, same place
+            add("dup", 120, 800000, "120M", 360, 500)
+        yield ("d%02d.paf" % j, "".join(lines))
+
+
 def write_files(gen: Iterator[Tuple[str, str]], out_dir: str, gz: bool = False) -> List[str]:
     os.makedirs(out_dir, exist_ok=True)
     paths = []

@@ -60,6 +60,18 @@ def test_device_primitives(hip):
             assert np.array_equal(out, exp), (n, mode)
 
 
+@pytest.mark.parametrize("args", ["", "-p0 -a1", "-S", "-f0.3"])
+def test_sweep_slow_list_and_list_overflow(hip, ora, tmp_path, args):
+    """synth.dense: hits with partners hundreds of slots away and waves with > 512 overlapping pairs leave the LDS pair
+    list for k_sweep_slow; the result must not depend on which path a hit took (HIP == oracle, which == the reference)"""
+    fs = synth.write_files(synth.dense(3), str(tmp_path / "d"))
+    for mode in (1, 2):
+        hip.pg_set_exact_mode(mode); ora.pg_set_exact_mode(mode)
+        a, b = capi.run(hip, fs, args.split()), capi.run(ora, fs, args.split())
+        assert a == b and len(a) > 1000
+    hip.pg_set_exact_mode(1); ora.pg_set_exact_mode(1)
+
+
 def test_cross_shard_arc_merge(hip):
     """pga_arc_merge (what every rank runs on the all-gathered arc tables of a sharded round) against a numpy reduce-by-key"""
     raw = C.CDLL(capi.LIB_HIP)

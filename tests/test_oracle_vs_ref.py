@@ -70,6 +70,19 @@ def test_live_against_reference_binary(ora, tmp_path, seed):
             assert mine == want
 
 
+def test_dense_shape_against_reference_binary(ora, tmp_path):
+    """giant spanning hit + pile-ups (the shape the GPU sweep sends through its slow list), host driver + oracle vs oracle/_ref"""
+    ref = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/pangene_ref not built")
+    fs = synth.write_files(synth.dense(3), str(tmp_path / "d"))
+    for mode, args in ((2, []), (2, ["-p0", "-a1"]), (1, []), (1, ["-S"])):
+        ora.pg_set_exact_mode(mode)
+        mine = capi.run(ora, fs, args)
+        want = subprocess.run([ref] + args + fs, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        assert mine == want and len(want) > 1000
+
+
 @pytest.mark.parametrize("name", ["C4", "bact20", "human8f", "fuzz3"])
 def test_batch_reader_equals_sequential_reader(built, name):
     """pg_read_paf_batch (threads + ordered commit) numbers genes/proteins exactly like per-file pg_read_paf calls."""
