@@ -52,8 +52,8 @@ struct OpSegMax { // a is to the left of b
 };
 
 // ------------------------------------------------------------------------------------------------
-// device-wide scan in three launches: tile reduce -> one-block scan of the tile sums -> tile scan
-// with carry-in.  A tile is BLOCK * IPT consecutive elements; thread t owns IPT consecutive ones.
+// device-wide scan: tile reduce -> (one-block scan of the tile sums, folded into the next step while tiles are few) ->
+// tile scan with carry-in.  A tile is BLOCK * IPT consecutive elements; thread t owns IPT consecutive ones.
 // In/Out are functors: T In::operator()(int64 i), void Out::operator()(int64 i, T incl, T excl_or_identity)
 // ------------------------------------------------------------------------------------------------
 constexpr int IPT = 4;
@@ -114,10 +114,19 @@ __global__ __launch_bounds__(BLOCK) void scan_tile_sums(T *tile_sum, int64_t n_t
 	}
 }
 
-template <class T, class Op, class In, class Out>
+// FUSED: tile_excl holds the raw tile sums and every workgroup reduces the ones before its tile itself (in order: Op need
+// not commute) -- one launch less, worth it while there are few tiles
+template <bool FUSED, class T, class Op, class In, class Out>
 __global__ __launch_bounds__(BLOCK) void scan_tile_apply(In in, Out out, int64_t n, const T *tile_excl, Op op, T identity)
 {
 	__shared__ T wave_tot[BLOCK / WAVE];
+	T carry_in;
+	if (FUSED) {
+		const int64_t nt = blockIdx.x, chunk = (nt + BLOCK - 1) / BLOCK, lo = (int64_t)threadIdx.x * chunk, hi = lo + chunk < nt ? lo + chunk : nt;
+		T a = identity;
+		for (int64_t i = lo; i < hi; ++i) a = op(a, tile_excl[i]);
+		block_scan_excl(a, op, identity, wave_tot, &carry_in);
+	} else carry_in = tile_excl[blockIdx.x];
 	const int64_t base = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * IPT;
 	T v[IPT];
 	T acc = identity;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(BLOCK) void scan_tile_apply(In in, Out out, int64_t
 		acc = op(acc, v[k]);
 	}
 	T excl = block_scan_excl(acc, op, identity, wave_tot, (T *)nullptr);
-	T run = op(tile_excl[blockIdx.x], excl);
+	T run = op(carry_in, excl);
 #pragma unroll
 	for (int k = 0; k < IPT; ++k) {
 		if (base + k < n) {
@@ -145,8 +154,12 @@ static inline void device_scan(In in, Out out, int64_t n, T *tile_buf, Op op, T 
 	if (n <= 0) return;
 	const int64_t n_tile = (n + TILE - 1) / TILE;
 	hipLaunchKernelGGL((scan_tile_reduce<T, Op, In>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, n, tile_buf, op, identity);
-	hipLaunchKernelGGL((scan_tile_sums<T, Op>), dim3(1), dim3(BLOCK), 0, st, tile_buf, n_tile, op, identity);
-	hipLaunchKernelGGL((scan_tile_apply<T, Op, In, Out>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, out, n, tile_buf, op, identity);
+	if (n_tile <= 2048) {
+		hipLaunchKernelGGL((scan_tile_apply<true, T, Op, In, Out>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, out, n, tile_buf, op, identity);
+	} else {
+		hipLaunchKernelGGL((scan_tile_sums<T, Op>), dim3(1), dim3(BLOCK), 0, st, tile_buf, n_tile, op, identity);
+		hipLaunchKernelGGL((scan_tile_apply<false, T, Op, In, Out>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, out, n, tile_buf, op, identity);
+	}
 }
 static inline int64_t scan_tiles(int64_t n) { return (n + TILE - 1) / TILE + 1; }
 

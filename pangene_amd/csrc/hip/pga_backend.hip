@@ -84,6 +84,7 @@ struct pga_ctx {
 	int32_t *max_ori = 0; int64_t *sums = 0; int32_t *vtx_cnt = 0; int32_t *g2s = 0; int32_t n_seg = 0;
 	int64_t *dcnt = 0;      // device counters: [0] triples [1] arcs-temp [2] misc [3] invariant flag, [4..7] hazards
 	int64_t *h_cnt = 0;     // pinned mirror
+	int64_t *h_box = 0;     // the same memory as the device sees it
 	DevPool pool;
 	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
 	int64_t br_n = 0, br_np = 0; int32_t br_S = 0; // arcs / pairs / segments of the last branch_pairs
@@ -137,9 +138,30 @@ __global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v)
 
 // mailbox[k] = a[0] + b[0]: totals of a scan land in the device mailbox so that one 128-byte copy brings every
 // size the host needs (one round trip instead of one per value)
-__global__ void k_mail_sum(const int32_t *a, const int32_t *b, int64_t *box)
+// dcnt[10] = a[0] + b[0] (element count after a compaction scan), then all 16 device counters go straight into the pinned
+// host mirror: the host reads them after the stream sync without a separate copy command
+__global__ void k_mail_sum(const int32_t *a, const int32_t *b, int64_t *dcnt, int64_t *host_box)
 {
-	if (threadIdx.x == 0 && blockIdx.x == 0) *box = (int64_t)a[0] + b[0];
+	if (threadIdx.x == 0) dcnt[10] = (int64_t)a[0] + b[0];
+	__syncthreads();
+	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
+}
+
+__global__ void k_mail_flush(const int64_t *dcnt, int64_t *host_box)
+{
+	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
+}
+
+struct ZeroList { void *p[4]; unsigned long long dwords[4]; };
+// several small clears in one launch (each hipMemsetAsync is a launch of its own; a round needs a dozen of them)
+__global__ __launch_bounds__(BLOCK) void k_zero_multi(ZeroList z)
+{
+	unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		if (i < z.dwords[k]) { ((uint32_t *)z.p[k])[i] = 0; return; }
+		i -= z.dwords[k];
+	}
 }
 
 __device__ __forceinline__ int genome_of(const int32_t *goff, int n_genome, int i) // last g with goff[g] <= i
@@ -1503,6 +1525,14 @@ extern "C" int pga_set_stream(pga_ctx_t *c, void *hip_stream)
 	return 0;
 }
 
+// clears up to four buffers (byte counts are rounded up to whole dwords; every pool buffer has that slack) in one launch
+static void zero_multi(pga_ctx *c, void *p0, size_t b0, void *p1 = nullptr, size_t b1 = 0, void *p2 = nullptr, size_t b2 = 0, void *p3 = nullptr, size_t b3 = 0)
+{
+	ZeroList z = { { p0, p1, p2, p3 }, { (b0 + 3) / 4, (b1 + 3) / 4, (b2 + 3) / 4, (b3 + 3) / 4 } };
+	const unsigned long long tot = z.dwords[0] + z.dwords[1] + z.dwords[2] + z.dwords[3];
+	if (tot) hipLaunchKernelGGL(k_zero_multi, dim3((unsigned)((tot + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->st, z);
+}
+
 template <class T> static int upload(pga_ctx *c, T *dst, const T *src, size_t n)
 {
 	if (n == 0) return 0;
@@ -1523,6 +1553,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	}
 	c->own_stream = true;
 	HIPCHK(hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(int64_t), hipHostMallocDefault));
+	HIPCHK(hipHostGetDevicePointer((void **)&c->h_box, c->h_cnt, 0));
 	TRY(dalloc(c, &c->dcnt, 16));
 	// persistent arrays
 	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
@@ -1684,8 +1715,7 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 
 extern "C" int pga_post_partials(pga_ctx_t *c, int32_t **max_ori, int64_t **sums)
 {
-	HIPCHK(hipMemsetAsync(c->max_ori, 0, sizeof(int32_t) * (size_t)std::max(1, c->P), c->st));
-	HIPCHK(hipMemsetAsync(c->sums, 0, sizeof(int64_t) * 6 * (size_t)std::max(1, c->P), c->st));
+	zero_multi(c, c->max_ori, sizeof(int32_t) * (size_t)std::max(1, c->P), c->sums, sizeof(int64_t) * 6 * (size_t)std::max(1, c->P));
 	if (c->N) hipLaunchKernelGGL(k_post_part, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->rank, c->sori, c->sadj, c->nex, c->N, c->P,
 	                             c->max_ori, (unsigned long long *)c->sums);
 	*max_ori = c->max_ori, *sums = c->sums;
@@ -1728,9 +1758,9 @@ extern "C" int pga_set_filter(pga_ctx_t *c, int32_t which)
 	return 0;
 }
 
-static int check_invariant(pga_ctx *c)
+static int check_invariant(pga_ctx *c, bool flushed = false) // flushed: a k_mail_sum just sent the counters to the host mirror
 {
-	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	if (!flushed) hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
 	TRY(sync_st(c));
 	return c->h_cnt[3] ? PGA_ERR_INVARIANT : 0;
 }
@@ -1741,9 +1771,7 @@ extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **triples,
 	const int64_t wpg = (Q + 31) / 32;
 	uint32_t *bits = (uint32_t *)c->pool.get(S_BITS, sizeof(uint32_t) * (size_t)(wpg * GL) + 16);
 	if (!bits) return PGA_ERR_NOMEM;
-	HIPCHK(hipMemsetAsync(bits, 0, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->st));
-	HIPCHK(hipMemsetAsync(c->vtx_cnt, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, Q), c->st));
-	HIPCHK(hipMemsetAsync(c->dcnt, 0, sizeof(int64_t), c->st));
+	zero_multi(c, bits, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->vtx_cnt, sizeof(int32_t) * 2 * (size_t)std::max(1, Q), c->dcnt, sizeof(int64_t));
 	*n_triples = 0, *triples = nullptr, *cnt = c->vtx_cnt;
 	if (N == 0) return sync_st(c);
 	hipLaunchKernelGGL(k_vtx1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt);
@@ -1788,9 +1816,11 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	const int N = c->N, S = c->n_seg, GL = c->n_genome;
 	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES);
 	if (!seg_cnt) return PGA_ERR_NOMEM;
-	HIPCHK(hipMemsetAsync(seg_cnt, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES, c->st));
 	*seg_cnt_out = seg_cnt, *arcs_out = nullptr, *n_arcs_out = 0;
-	if (N == 0) return sync_st(c);
+	if (N == 0) {
+		HIPCHK(hipMemsetAsync(seg_cnt, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES, c->st));
+		return sync_st(c);
+	}
 	TRY(launch_sweep<0>(c, 2)); // graph.c:102
 	int32_t *val, *prev;
 	TRY(walk_prev(c, &val, &prev));
@@ -1799,14 +1829,14 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	int32_t *has = (int32_t *)c->pool.get(S_I32_C, sizeof(int32_t) * (size_t)N);
 	int32_t *slot = (int32_t *)c->pool.get(S_SLOT, sizeof(int32_t) * (size_t)(2 * (int64_t)N + 2));
 	if (!seen || !has || !slot) return PGA_ERR_NOMEM;
-	HIPCHK(hipMemsetAsync(seen, 0, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->st));
+	zero_multi(c, seen, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, seg_cnt, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES);
 	hipLaunchKernelGGL(k_arc_flag, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yperm, c->seg, c->gid, c->gnm, c->cm, c->g2s, N, S, has, seg_cnt, seen, wpg, c->dcnt);
 	if (S) hipLaunchKernelGGL(k_segcnt_sum, dim3(nblk(2 * S)), dim3(BLOCK), 0, c->st, seg_cnt, 2 * S);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{has}, OutExclI32{slot}, N, tile, OpSum{}, I32{0}, c->st);
 	// number of adjacencies = slot[N-1] + has[N-1]
-	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, slot + (N - 1), has + (N - 1), c->dcnt + 10);
-	TRY(check_invariant(c));
+	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, slot + (N - 1), has + (N - 1), c->dcnt, c->h_box);
+	TRY(check_invariant(c, true));
 	const int64_t M = 2 * c->h_cnt[10];
 	if (M == 0) return sync_st(c);
 	const int vbits = bits_for((uint32_t)(2 * std::max(1, S)));
@@ -1823,8 +1853,7 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	hipLaunchKernelGGL(k_arc_head, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, M, head);
 	tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{head}, OutExclI32{slot}, M, tile, OpSum{}, I32{0}, c->st);
-	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, slot + (M - 1), head + (M - 1), c->dcnt + 10);
-	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, slot + (M - 1), head + (M - 1), c->dcnt, c->h_box);
 	TRY(sync_st(c));
 	const int64_t A = c->h_cnt[10];
 	pga_arc_part_t *arcs = (pga_arc_part_t *)c->pool.get(S_ARCS, sizeof(pga_arc_part_t) * (size_t)A);
@@ -1893,9 +1922,8 @@ extern "C" int pga_arc_set_current(pga_ctx_t *c, const pga_arc_part_t *arcs, int
 	int32_t *sg = (int32_t *)c->pool.get(S_BR_SEGGID, sizeof(int32_t) * (size_t)n_seg + 16), *dg = (int32_t *)c->pool.get(S_BR_PC, sizeof(int32_t) * (size_t)n_vtx + 16);
 	if (!ax || !aw || !s1 || !agid || !vs || !ve || !sg || !dg) return PGA_ERR_NOMEM;
 	if (n_vtx == 0) return 0;
-	HIPCHK(hipMemsetAsync(vs, 0, sizeof(int32_t) * (size_t)n_vtx, c->st)); HIPCHK(hipMemsetAsync(ve, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
+	zero_multi(c, vs, sizeof(int32_t) * (size_t)n_vtx, ve, sizeof(int32_t) * (size_t)n_vtx, aw, (size_t)n_arc);
 	if (n_arc) {
-		HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st));
 		hipLaunchKernelGGL(k_seg_gid, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, c->Q, n_seg, sg);
 		hipLaunchKernelGGL(k_cur_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, arcs, n_arc, sg, ax, s1, agid, vs, ve);
 	}
@@ -1971,8 +1999,7 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
-	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, poff + (n_vtx - 1), pc + (n_vtx - 1), c->dcnt + 10);
-	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, poff + (n_vtx - 1), pc + (n_vtx - 1), c->dcnt, c->h_box);
 	TRY(sync_st(c));
 	const int64_t np = c->h_cnt[10];
 	c->br_np = np, *n_pairs = np;
@@ -1998,7 +2025,7 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	int32_t *pc = (int32_t *)c->pool.get(S_BR_PC, 0), *poff = (int32_t *)c->pool.get(S_BR_POFF, 0), *cnt = (int32_t *)c->pool.get(S_NLCNT, 0);
 	int32_t *grp = (int32_t *)c->pool.get(S_BR_GRP, sizeof(int32_t) * (size_t)n_arc + 16), *ndl = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
 	if (!grp || !ndl) return PGA_ERR_NOMEM;
-	HIPCHK(hipMemsetAsync(grp, 0, sizeof(int32_t) * (size_t)n_arc, c->st)); HIPCHK(hipMemsetAsync(ndl, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
+	zero_multi(c, grp, sizeof(int32_t) * (size_t)n_arc, ndl, sizeof(int32_t) * (size_t)n_vtx);
 	hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, cnt,
 	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt);
 	if (arc_weak) HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
@@ -2022,8 +2049,7 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 	int32_t *wn = (int32_t *)c->pool.get(S_WEAKNEW, sizeof(int32_t) * (size_t)N);
 	if (!ax || !aw || !wn) return PGA_ERR_NOMEM;
 	if (arc_x) { TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, aw, arc_weak, (size_t)n_arc)); }
-	HIPCHK(hipMemsetAsync(wn, 0, sizeof(int32_t) * (size_t)N, c->st));
-	HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
+	zero_multi(c, wn, sizeof(int32_t) * (size_t)N, c->dcnt + 2, sizeof(int64_t));
 	int32_t *val, *prev;
 	TRY(walk_prev(c, &val, &prev));
 	const int32_t *vs = arc_x ? nullptr : (const int32_t *)c->pool.get(S_BR_VS, 0), *ve = arc_x ? nullptr : (const int32_t *)c->pool.get(S_BR_VE, 0);
