@@ -32,6 +32,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def _pmc_traffic(hits_per_launch):
+    """HBM bytes per launch of K1 from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    runs of this very command, FETCH doubled as the gfx950 guide prescribes); null when the recorded passes are for another size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")) as f:
+            t = json.load(f)
+        return int(t["bytes_per_launch"]) if t.get("hits_per_launch") == hits_per_launch else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,8 +186,9 @@ def main():
     if nl.value:
         avg_ms = ms.value / nl.value
         ach = bytes_per_hit * (units.value / nl.value) / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_sweep<1> (pg_shadow cal_dom_sc=1, stage A)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": nl.value,
+        roof = {"bound": "hbm", "kernel": "k_sweep<1, true> (pg_shadow cal_dom_sc=1, stage A)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(units.value // nl.value), "avg_launch_ms": round(avg_ms, 4), "launches": nl.value,
+                "timing": "per-dispatch HIP start/stop events (hipExtLaunchKernelGGL) on the library's stream",
                 "algorithmic_bytes_per_hit": bytes_per_hit, "hits_per_launch": units.value // nl.value}
 
     # ---- CPU baseline: the untouched reference binary on the same PAF files, 1 core (rank 0, N = 1 only)

@@ -13,6 +13,7 @@
 // Everything is integer work except three IEEE-double expressions (overlap.c:134,170) -- compile with
 // -ffp-contract=off.  No MFMA: this path is HBM/latency bound.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1447,12 +1448,13 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 	if (c->N == 0) return 0;
 	{ const int rc = make_sweep_view(c, &v); if (rc) return rc; }
 	TimedLaunch t; t.which = timed_which; t.units = c->N;
-	if (timed_which >= 0) {
+	static const int reps = [] { const char *e = getenv("PGA_SW_REPS"); return e && atoi(e) > 0 ? atoi(e) : 1; }(); // tuning aid: the sweep is idempotent
+	const bool timed = timed_which >= 0;
+	if (timed) {
 		HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
-		HIPCHK(hipEventRecord(t.a, c->st));
+		if (reps != 1) HIPCHK(hipEventRecord(t.a, c->st));
 	}
 	c->walk_valid = false;
-	static const int reps = [] { const char *e = getenv("PGA_SW_REPS"); return e && atoi(e) > 0 ? atoi(e) : 1; }(); // tuning aid: the sweep is idempotent
 	const int nt = (int)nblk(c->N, SW_TILE);
 	v.prof = nullptr;
 #ifdef PGA_SW_PROFILE
@@ -1460,9 +1462,11 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 #endif
 	for (int rep = 0; rep < reps; ++rep) {
 		v.slow_cnt = c->dcnt + 12 + (c->sweep_seq & 1);
-		if (MODE == 1 || c->any_multi) hipLaunchKernelGGL((k_sweep<MODE, true>), dim3(nt), dim3(SW_TILE), 0, c->st, v);
-		else hipLaunchKernelGGL((k_sweep<MODE, MODE == 1>), dim3(nt), dim3(SW_TILE), 0, c->st, v);
-		if (timed_which >= 0 && reps == 1) HIPCHK(hipEventRecord(t.b, c->st)); // the events bracket k_sweep itself (what rocprofv3 reports for it)
+		// a timed launch carries its own start/stop events: they take the dispatch's begin and end time stamps, i.e. the
+		// duration of k_sweep itself, the figure rocprofv3 --kernel-trace reports for it
+		hipEvent_t ea = timed && reps == 1 ? t.a : nullptr, eb = timed && reps == 1 ? t.b : nullptr;
+		if (MODE == 1 || c->any_multi) hipExtLaunchKernelGGL((k_sweep<MODE, true>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
+		else hipExtLaunchKernelGGL((k_sweep<MODE, MODE == 1>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
 		hipLaunchKernelGGL((k_sweep_slow<MODE>), dim3(64), dim3(BLOCK), 0, c->st, v, (long long *)(c->dcnt + 12 + ((c->sweep_seq + 1) & 1)));
 		++c->sweep_seq;
 	}
