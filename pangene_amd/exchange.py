@@ -36,12 +36,21 @@ def _tensor(ptr: int, nbytes: int, is_device: int, device) -> torch.Tensor:
 def install(lib: C.CDLL, device=None, group=None):
     """Registers the exchange callbacks on `lib`; returns an object that must be kept alive."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    # HBM buffers over a host-only process group (gloo): staged through host memory.  Only meant for tests that run several
+    # ranks of the HIP backend on ONE GPU, where RCCL refuses to put two ranks on a device.
+    via_host = dist.get_backend(group) == "gloo"
 
     def allreduce(user, buf, count, dtype, op, is_device):
         try:
             tdt, _, sz = _DT[dtype]
             t = _tensor(buf, count * sz, is_device, device).view(tdt)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=group)
+            rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+            if is_device and via_host:
+                h = t.cpu()
+                dist.all_reduce(h, op=rop, group=group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=rop, group=group)
             if is_device:
                 torch.cuda.current_stream(device).synchronize()
             return 0
@@ -53,7 +62,12 @@ def install(lib: C.CDLL, device=None, group=None):
         try:
             tin = _tensor(src, nbytes, is_device, device)
             tout = _tensor(dst, nbytes * world, is_device, device)
-            dist.all_gather_into_tensor(tout, tin, group=group)
+            if is_device and via_host:
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, tin.cpu(), group=group)
+                tout.copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(tout, tin, group=group)
             if is_device:
                 torch.cuda.current_stream(device).synchronize()
             return 0

@@ -5,6 +5,7 @@ import ctypes as C
 import hashlib
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -227,3 +228,47 @@ dist.destroy_process_group()
     lib = capi.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     assert open(outp, "rb").read() == capi.run(lib, files, [])
+
+
+def _rank_on_shared_gpu(rank, world, port, files, variant, cuts, q):
+    import torch, torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from pangene_amd import capi as capi2, exchange
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    lib = capi2.load()
+    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    keep = exchange.install(lib, device=torch.device("cuda", 0))
+    n = len(files)
+    out = capi2.run(lib, files, variant, scan_only=[not (cuts[rank] <= k < cuts[rank + 1]) for k in range(n)])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+    del keep
+
+
+@pytest.mark.parametrize("name,variant,cuts", [("bact20", "", [0, 10, 20]), ("human8f", "-p0 -a1", [0, 3, 8]), ("bact20", "", [0, 7, 13, 20]), ("fuzz2", "-F", [0, 2, 2, 99])])
+def test_sharded_hip_ranks_on_one_gpu(built, expected, name, variant, cuts):
+    """The whole sharded HIP path with W > 1 (id scan, partial vectors, cross-shard arc merge on the device, n_local sums):
+    several ranks share this box's one GPU and exchange through gloo with host staging (RCCL will not put two ranks on
+    one device).  Their combined output must be the reference's single-process GFA."""
+    import socket
+    import torch.multiprocessing as mp
+    files = golden_files(name)
+    cuts = [min(c, len(files)) for c in cuts]
+    world = len(cuts) - 1
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_on_shared_gpu, args=(r, world, port, files, variant.split(), cuts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sl = [b"\n".join(l for l in res[r].split(b"\n") if l[:1] in (b"S", b"L")) for r in range(world)]
+    assert all(x == sl[0] for x in sl)
+    w = b"\n".join(l for r in range(world) for l in res[r].split(b"\n") if l[:1] == b"W")
+    whole = sl[0] + b"\n" + w + b"\n"
+    assert hashlib.md5(whole).hexdigest() == expected[name][variant]["md5"]

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['gfa_md5'], d['roofline']['frac'], d['host_phases_ms_per_step'])"
+timeout 900 python -m pytest tests -m gpu -x -q -k "one_gpu or exchange" 2>&1 | tail -8
