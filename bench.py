@@ -71,6 +71,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # test hook: PANGENE_BENCH_ONE_GPU=1 lets several ranks share device 0 and exchange over gloo (RCCL refuses two ranks on
+    # one device); it exercises this script's multi-rank flow on a 1-GPU box and says nothing about performance
+    one_gpu = os.environ.get("PANGENE_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = capi.load()
@@ -83,12 +88,15 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         from pangene_amd import exchange
         # RCCL called by the library itself, on the kernels' stream; PANGENE_EXCHANGE=torch keeps the collectives in
         # torch.distributed (Python callbacks) instead -- also the fallback when RCCL cannot be bound
         exchange_kind = "rccl-native"
-        if os.environ.get("PANGENE_EXCHANGE") == "torch" or not exchange.install_native(lib):
+        if one_gpu or os.environ.get("PANGENE_EXCHANGE") == "torch" or not exchange.install_native(lib):
             keep = exchange.install(lib, device=dev)
             exchange_kind = "torch.distributed(nccl) callbacks"
 
@@ -165,10 +173,11 @@ def main():
     sync()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        xdev = torch.device("cpu") if one_gpu else dev
+        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        h = torch.tensor([n_hits], dtype=torch.int64, device=dev)
+        h = torch.tensor([n_hits], dtype=torch.int64, device=xdev)
         dist.all_reduce(h)
         tot_hits = int(h.item())
     else:
@@ -217,6 +226,8 @@ def main():
                        "exact_order_mode": a.exact, "parallelism": "genomes sharded over %d GPU(s)" % world, "exchange": exchange_kind},
             "roofline": roof, "cpu_baseline": cpu,
             "gfa_md5": hashlib.md5(gfa).hexdigest() if world == 1 else None,
+            # S and L lines are the same on every rank of a sharded run (W lines are per rank): comparable across --gpus N for equal G
+            "gfa_sl_md5": hashlib.md5(b"\n".join(l for l in gfa.split(b"\n") if l[:1] in (b"S", b"L"))).hexdigest(),
             "gfa_identical_to_reference": (hashlib.md5(gfa).hexdigest() == ref_md5) if ref_md5 else None,
             "not_timed": {"paf_generate_s": round(t_gen, 2), "paf_parse_s": round(t_parse, 2), "first_pass_incl_upload_s": round(t_first, 3),
                           "pack_and_upload_s": round(t_upload, 3), "path_only_ms_per_step": round(path_sec / a.steps * 1e3, 3)},
