@@ -136,10 +136,11 @@ typedef struct {
 	int  pfx##_shadow(pga_ctx_t *ctx, int32_t cal_dom_sc, int32_t *stats); \
 	/* PG_SET_FILTER (pgpriv.h:109-116) */ \
 	int  pfx##_set_filter(pga_ctx_t *ctx, int32_t which); \
-	/* pg_gen_vtx per-genome part (vertex.c:28-51): cnt[2Q] = n_dom[Q] then n_sub[Q]; triples = \
-	 * genome_global<<40 | sub_gene<<20 | dom_gene for every (genome, gene) that is sub-ordinate to a \
-	 * gene which is dominant in that genome (the only entries the greedy vertex.c:60-80 can observe) */ \
-	int  pfx##_vtx_partials(pga_ctx_t *ctx, int32_t **cnt, uint64_t **triples, int64_t *n_triples); \
+	/* pg_gen_vtx per-genome part (vertex.c:28-51): cnt[2Q] = n_dom[Q] then n_sub[Q]; records of \
+	 * 1 + ceil(n_genome_global / 64) words: sub_gene<<20 | dom_gene, then the set (bit = global genome index) of this \
+	 * shard's genomes in which sub_gene is sub-ordinate to dom_gene and dom_gene is dominant (the only cells the greedy \
+	 * vertex.c:60-80 can observe).  A (sub, dom) key may occur in more than one record; their sets are disjoint. */ \
+	int  pfx##_vtx_partials(pga_ctx_t *ctx, int32_t **cnt, uint64_t **records, int64_t *n_records); \
 	/* pg_graph_flag_vtx (graph.c:61-69); g2s: [n_gene] host */ \
 	int  pfx##_flag_vtx(pga_ctx_t *ctx, const int32_t *g2s, int32_t n_seg); \
 	/* per-genome part of pg_gen_arc (graph.c:97-146) + local reduce-by-key of its global part. \

@@ -42,6 +42,7 @@ struct pga_ctx {
 	/* exchange buffers */
 	int32_t *max_ori; int64_t *sums;
 	int32_t *vtx_cnt; uint64_t *triples; int64_t n_triples, m_triples;
+	uint64_t *vtx_rec; /* folded (sub, dom) records handed to the driver */
 	int32_t *g2s; int32_t n_seg;
 	int32_t *seg_cnt; pga_arc_part_t *arcs; int64_t n_arcs, m_arcs;
 	/* rep_pos: per local genome, per gene */
@@ -133,7 +134,7 @@ void pgo_destroy(pga_ctx_t *c)
 	free(c->pid); free(c->gid); free(c->cid); free(c->rank); free(c->score_ori); free(c->score_adj); free(c->score_dom);
 	free(c->n_exon_of); free(c->off_exon); free(c->cs); free(c->ce); free(c->cm); free(c->cds);
 	free(c->pid_dom); free(c->pid_dom0); free(c->flags); free(c->yo); free(c->exon_os); free(c->exon_oe);
-	free(c->prot_gid); free(c->gene_pref); free(c->max_ori); free(c->sums); free(c->vtx_cnt); free(c->triples);
+	free(c->prot_gid); free(c->gene_pref); free(c->max_ori); free(c->sums); free(c->vtx_cnt); free(c->triples); free(c->vtx_rec);
 	free(c->g2s); free(c->seg_cnt); free(c->arcs); free(c->rp_x); free(c->rp_y); free(c->nl_cnt); free(c->scratch); free(c->head);
 	free(c->br_x); free(c->br_s1); free(c->br_gid); free(c->br_pairs); free(c->br_weak);
 	free(c->r_pid); free(c->r_cid); free(c->r_rank); free(c->r_sori); free(c->r_sadj); free(c->r_nex); free(c->r_offx); free(c->r_cs); free(c->r_ce); free(c->r_cm); free(c->r_rev);
@@ -461,8 +462,10 @@ int pgo_set_filter(pga_ctx_t *c, int32_t which)
 	return PGA_OK;
 }
 
+static int cmp_u64(const void *a, const void *b) { uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : x > y; }
+
 /* per-genome part of pg_gen_vtx, vertex.c:21-51 */
-int pgo_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **triples, int64_t *n_triples)
+int pgo_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records, int64_t *n_records)
 {
 	int32_t j, Q = c->n_gene;
 	uint32_t *aux = MALLOC(uint32_t, Q);
@@ -503,7 +506,21 @@ int pgo_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **triples, int64_t *n
 		}
 	}
 	free(aux); free(flag);
-	*cnt = c->vtx_cnt, *triples = c->triples, *n_triples = c->n_triples;
+	{ /* fold the (genome, sub, dom) triples into one record per (sub, dom): key, then the bit set of global genome indices */
+		const int64_t nw = ((int64_t)c->n_genome_global + 63) / 64, stride = 1 + nw;
+		const uint64_t m40 = (1ULL << 40) - 1;
+		int64_t k, n_rec = 0;
+		for (k = 0; k < c->n_triples; ++k) c->triples[k] = (c->triples[k] & m40) << 24 | c->triples[k] >> 40; /* (sub, dom) major, genome minor */
+		qsort(c->triples, (size_t)c->n_triples, sizeof(uint64_t), cmp_u64);
+		free(c->vtx_rec);
+		c->vtx_rec = (uint64_t*)calloc((size_t)(c->n_triples * stride + 1), sizeof(uint64_t));
+		for (k = 0; k < c->n_triples; ++k) {
+			const uint64_t key = c->triples[k] >> 24, g = c->triples[k] & 0xffffff;
+			if (k == 0 || key != c->triples[k - 1] >> 24) c->vtx_rec[n_rec++ * stride] = key;
+			c->vtx_rec[(n_rec - 1) * stride + 1 + (int64_t)(g >> 6)] |= 1ULL << (g & 63);
+		}
+		*cnt = c->vtx_cnt, *records = c->vtx_rec, *n_records = n_rec;
+	}
 	return PGA_OK;
 }
 

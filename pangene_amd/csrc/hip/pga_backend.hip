@@ -812,29 +812,60 @@ __global__ __launch_bounds__(BLOCK) void k_vtx1(const uint32_t *flags, const int
 	}
 }
 
-template <bool COUNT_ONLY>
-__global__ __launch_bounds__(BLOCK) void k_vtx2(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *pdom,
-                                                  const int32_t *prot_gid, const int32_t *ggl, int n, const uint32_t *dombits, int64_t words_per_genome,
-                                                  uint64_t *triples, int64_t *dcnt)
+// Fold of the (genome, sub gene, dom gene) relation into one genome bitset per (sub, dom) pair, the form the host greedy
+// consumes (vertex.c:60-80 marks cell (genome, dom) for every genome of the pair).  A sub gene has very few distinct dom
+// genes, so each gene owns VTX_K slots: a slot is claimed for a dom gene with atomicCAS, the genome bit is an atomicOr.
+// A gene with more than VTX_K dom genes spills single-genome records into an overflow area.
+constexpr int VTX_K = 8;
+
+__global__ __launch_bounds__(BLOCK) void k_vtx_fold(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *pdom,
+                                                      const int32_t *prot_gid, const int32_t *ggl, int n, const uint32_t *dombits, int64_t words_per_genome,
+                                                      int32_t *dom_tab, unsigned long long *bits, int nw, unsigned long long *ovf, long long ovf_cap, int64_t *dcnt)
 {
-	const int h0 = blockIdx.x * BLOCK + threadIdx.x, h = h0 < n ? h0 : n - 1;
+	const int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
 	const uint32_t f = flags[h];
-	bool emit = h0 < n && !(f & PGA_F_FLT) && rank[h] == 0 && (f & PGA_F_SHADOW) && pdom[h] >= 0;
-	int j = 0, D = 0;
-	if (emit) {
-		j = gnm[h], D = prot_gid[pdom[h]];
-		emit = (dombits[(int64_t)j * words_per_genome + (D >> 5)] >> (D & 31) & 1u) != 0;
+	if ((f & PGA_F_FLT) || rank[h] != 0 || !(f & PGA_F_SHADOW) || pdom[h] < 0) return;
+	const int j = gnm[h], D = prot_gid[pdom[h]], g = gid[h];
+	if (!(dombits[(int64_t)j * words_per_genome + (D >> 5)] >> (D & 31) & 1u)) return; // dom is not dominant in this genome: the greedy never looks
+	const int jg = ggl[j];
+	int k = 0;
+	for (; k < VTX_K; ++k) {
+		int32_t *p = &dom_tab[(int64_t)g * VTX_K + k];
+		int cur = *(volatile int32_t *)p;
+		if (cur < 0) cur = atomicCAS(p, -1, D), cur = cur < 0 ? D : cur;
+		if (cur == D) break;
 	}
-	// one atomic per wave: the leader reserves a range, lanes fill it in lane order
-	const unsigned long long m = __ballot(emit);
-	if (m == 0) return;
-	const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-	unsigned long long base = 0;
-	if (lane == leader) base = atomicAdd((unsigned long long *)&dcnt[0], (unsigned long long)__popcll(m));
-	base = __shfl(base, leader, WAVE);
-	if (!COUNT_ONLY && emit) {
-		const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-		triples[base + __popcll(m & lt)] = (uint64_t)ggl[j] << 40 | (uint64_t)gid[h] << 20 | (uint64_t)D;
+	if (k < VTX_K) {
+		atomicOr(&bits[((int64_t)g * VTX_K + k) * nw + (jg >> 6)], 1ull << (jg & 63));
+	} else {
+		const long long at = (long long)atomicAdd((unsigned long long *)&dcnt[0], 1ull);
+		if (at < ovf_cap) {
+			unsigned long long *r = ovf + at * (1 + nw);
+			r[0] = (unsigned long long)g << 20 | (unsigned long long)D;
+			for (int w = 0; w < nw; ++w) r[1 + w] = w == (jg >> 6) ? 1ull << (jg & 63) : 0ull;
+		}
+	}
+}
+
+struct InDomSet { const int32_t *tab; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{tab[i] >= 0 ? 1 : 0}; } };
+
+// slot -> record: key (sub << 20 | dom), then the genome words; also mails the record count (dcnt[10]) and the counters to the host
+__global__ __launch_bounds__(BLOCK) void k_vtx_compact(const int32_t *dom_tab, const int32_t *slot, int64_t n_slot, const unsigned long long *bits, int nw,
+                                                         unsigned long long *out, int64_t *dcnt, int64_t *host_box)
+{
+	const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (s >= n_slot) return;
+	const int D = dom_tab[s];
+	if (D >= 0) {
+		unsigned long long *r = out + (int64_t)slot[s] * (1 + nw);
+		r[0] = (unsigned long long)(s / VTX_K) << 20 | (unsigned long long)D;
+		for (int w = 0; w < nw; ++w) r[1 + w] = bits[s * nw + w];
+	}
+	if (s == n_slot - 1) {
+		dcnt[10] = slot[s] + (D >= 0 ? 1 : 0);
+		__threadfence();
+		for (int t = 0; t < 16; ++t) host_box[t] = dcnt[t];
 	}
 }
 
@@ -1769,26 +1800,40 @@ static int check_invariant(pga_ctx *c, bool flushed = false) // flushed: a k_mai
 	return c->h_cnt[3] ? PGA_ERR_INVARIANT : 0;
 }
 
-extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **triples, int64_t *n_triples)
+extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records, int64_t *n_records)
 {
 	const int N = c->N, Q = c->Q, GL = c->n_genome;
-	const int64_t wpg = (Q + 31) / 32;
+	const int64_t wpg = (Q + 31) / 32, n_slot = (int64_t)std::max(1, Q) * VTX_K;
+	const int nw = (c->n_genome_global + 63) / 64;
+	const long long ovf_cap = 65536;
 	uint32_t *bits = (uint32_t *)c->pool.get(S_BITS, sizeof(uint32_t) * (size_t)(wpg * GL) + 16);
-	if (!bits) return PGA_ERR_NOMEM;
-	zero_multi(c, bits, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->vtx_cnt, sizeof(int32_t) * 2 * (size_t)std::max(1, Q), c->dcnt, sizeof(int64_t));
-	*n_triples = 0, *triples = nullptr, *cnt = c->vtx_cnt;
+	// [dom_tab: n_slot i32][slot: n_slot i32][pair bits: n_slot * nw u64][records: (n_slot + ovf_cap) * (1 + nw) u64]
+	const size_t b_tab = sizeof(int32_t) * (size_t)n_slot, b_bits = sizeof(uint64_t) * (size_t)n_slot * (size_t)nw, b_rec = sizeof(uint64_t) * (size_t)(n_slot + ovf_cap) * (size_t)(1 + nw);
+	char *blk = (char *)c->pool.get(S_TRIPLES, 2 * b_tab + b_bits + b_rec + 64);
+	if (!bits || !blk) return PGA_ERR_NOMEM;
+	int32_t *dom_tab = (int32_t *)blk, *slot = (int32_t *)(blk + b_tab);
+	unsigned long long *pbits = (unsigned long long *)(blk + 2 * b_tab), *rec = (unsigned long long *)(blk + 2 * b_tab + b_bits);
+	zero_multi(c, bits, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->vtx_cnt, sizeof(int32_t) * 2 * (size_t)std::max(1, Q), c->dcnt, sizeof(int64_t), pbits, b_bits);
+	HIPCHK(hipMemsetAsync(dom_tab, 0xff, b_tab, c->st)); // every slot empty (-1)
+	*n_records = 0, *records = (uint64_t *)rec, *cnt = c->vtx_cnt;
 	if (N == 0) return sync_st(c);
 	hipLaunchKernelGGL(k_vtx1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt);
-	hipLaunchKernelGGL((k_vtx2<true>), dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, c->prot_gid, c->ggl, N, bits, wpg,
-	                   (uint64_t *)nullptr, c->dcnt);
-	TRY(check_invariant(c));
-	const int64_t nt = c->h_cnt[0];
-	uint64_t *tri = (uint64_t *)c->pool.get(S_TRIPLES, sizeof(uint64_t) * (size_t)nt + 16);
-	if (!tri) return PGA_ERR_NOMEM;
-	HIPCHK(hipMemsetAsync(c->dcnt, 0, sizeof(int64_t), c->st));
-	hipLaunchKernelGGL((k_vtx2<false>), dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, c->prot_gid, c->ggl, N, bits, wpg, tri, c->dcnt);
-	*triples = tri, *n_triples = nt;
-	return sync_st(c);
+	hipLaunchKernelGGL(k_vtx_fold, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, c->prot_gid, c->ggl, N, bits, wpg,
+	                   dom_tab, pbits, nw, rec + n_slot * (1 + nw), ovf_cap, c->dcnt);
+	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+	if (!tile) return PGA_ERR_NOMEM;
+	device_scan<I32>(InDomSet{dom_tab}, OutExclI32{slot}, n_slot, tile, OpSum{}, I32{0}, c->st);
+	hipLaunchKernelGGL(k_vtx_compact, dim3(nblk(n_slot)), dim3(BLOCK), 0, c->st, dom_tab, slot, n_slot, pbits, nw, rec, c->dcnt, c->h_box);
+	TRY(sync_st(c));
+	if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
+	const int64_t n_rec = c->h_cnt[10], n_ovf = c->h_cnt[0];
+	if (n_ovf > ovf_cap) return PGA_ERR_RANGE; // > 65536 (genome, gene) cells beyond VTX_K dominators per gene
+	if (n_ovf) { // the spilled single-genome records follow the folded ones
+		HIPCHK(hipMemcpyAsync(rec + n_rec * (1 + nw), rec + n_slot * (1 + nw), sizeof(uint64_t) * (size_t)n_ovf * (size_t)(1 + nw), hipMemcpyDeviceToDevice, c->st));
+		TRY(sync_st(c));
+	}
+	*n_records = n_rec + n_ovf;
+	return 0;
 }
 
 extern "C" int pga_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg)

@@ -95,10 +95,11 @@ static int xgather_raw(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, 
 
 // all-gather of a variable-length array living in backend memory -> host vector (rank order)
 template <class T>
-static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int64_t n, std::vector<T> &out)
+static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int64_t n, std::vector<T> &out, bool local_on_host = false)
 {
 	if (!sharded()) {
 		out.resize((size_t)n);
+		if (local_on_host) { if (n) std::memcpy(out.data(), local, (size_t)n * sizeof(T)); return 0; }
 		return n ? be->fetch(ctx, out.data(), local, (size_t)n * sizeof(T)) : 0;
 	}
 	const int W = g_xchg.world;
@@ -114,7 +115,7 @@ static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int6
 	if (mx == 0) return 0;
 	size_t slot = (size_t)mx * sizeof(T);
 	BE_CALL(be->scratch(ctx, slot * (size_t)(W + 1), &scr), "scratch");
-	if (n) BE_CALL(be->copy(ctx, scr, local, (size_t)n * sizeof(T)), "copy");
+	if (n) BE_CALL(local_on_host ? be->put(ctx, scr, local, (size_t)n * sizeof(T)) : be->copy(ctx, scr, local, (size_t)n * sizeof(T)), "copy");
 	BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + slot, (int64_t)slot, be->is_device()), "allgather(data)");
 	std::vector<T> all((size_t)mx * (size_t)W);
 	BE_CALL(be->fetch(ctx, all.data(), (char *)scr + slot, slot * (size_t)W), "fetch");
@@ -385,25 +386,36 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	const int32_t Q = d->n_gene, G = d->n_genome;
 	Phase ph_vtx(PH_VTX);
 	int32_t *b_cnt; uint64_t *b_tri; int64_t n_tri;
+	const double tv0 = now_sec();
 	BE_CALL(be->vtx_partials(ext->ctx, &b_cnt, &b_tri, &n_tri), "vtx_partials");
+	const double tv1 = now_sec();
 	BE_CALL(xreduce(be, b_cnt, 2 * (int64_t)Q, PG_X_I32, PG_X_SUM), "allreduce(n_dom,n_sub)");
 	std::vector<int32_t> cntv((size_t)Q * 2);
 	if (Q) BE_CALL(be->fetch(ext->ctx, cntv.data(), b_cnt, sizeof(int32_t) * (size_t)Q * 2), "fetch");
-	std::vector<uint64_t> tri;
-	BE_CALL(xgather(be, ext->ctx, b_tri, n_tri, tri), "allgather(triples)");
-
-	// per sub gene: the (genome, dom gene) cells it would mark; cells are addressed genome*Q + gene
+	// What the greedy needs is, per (sub, dom) gene pair, the SET of genomes in which sub is sub-ordinate to a dominant dom: a
+	// selected sub gene marks cell (genome, dom) in each of them (vertex.c:73-77).  The backend hands over one genome
+	// bitset per pair of its shard and only those travel between ranks: the host work is O(pairs x G/64), independent of
+	// the number of hits.
 	const uint64_t m20 = (1u << 20) - 1;
+	const int64_t nw = ((int64_t)G + 63) / 64; // words of a genome bitset
+	std::vector<uint64_t> pairs((size_t)(n_tri * (1 + nw))); // records of 1 + nw words: key = sub << 20 | dom, then the genome bits
+	if (n_tri && !sharded()) BE_CALL(be->fetch(ext->ctx, pairs.data(), b_tri, sizeof(uint64_t) * pairs.size()), "fetch");
+	const double tv2 = now_sec();
+	if (sharded()) { // every rank's records, concatenated in rank order; a pair may come from several ranks (disjoint genome bits)
+		BE_CALL(xgather(be, ext->ctx, b_tri, n_tri * (1 + nw), pairs), "allgather(vertex pairs)");
+	}
+	// group the records by sub gene (counting sort on the key's sub field keeps it linear)
+	const int64_t n_rec = (int64_t)(pairs.size() / (size_t)(1 + nw));
 	std::vector<int64_t> sub_off((size_t)Q + 1, 0);
-	for (uint64_t t : tri) ++sub_off[(size_t)((t >> 20) & m20) + 1];
+	for (int64_t r = 0; r < n_rec; ++r) ++sub_off[(size_t)(pairs[(size_t)(r * (1 + nw))] >> 20) + 1];
 	for (int32_t g = 0; g < Q; ++g) sub_off[(size_t)g + 1] += sub_off[(size_t)g];
-	std::vector<int64_t> sub_cell(tri.size());
+	std::vector<int64_t> sub_rec((size_t)n_rec);
 	{
 		std::vector<int64_t> cur(sub_off.begin(), sub_off.end() - 1);
-		for (uint64_t t : tri)
-			sub_cell[(size_t)cur[(size_t)((t >> 20) & m20)]++] = (int64_t)(t >> 40) * Q + (int64_t)(t & m20);
+		for (int64_t r = 0; r < n_rec; ++r) sub_rec[(size_t)cur[(size_t)(pairs[(size_t)(r * (1 + nw))] >> 20)]++] = r;
 	}
-	std::vector<uint8_t> marked((size_t)G * (size_t)Q, 0);
+	std::vector<uint64_t> marked; // genome bitset per dom gene, allocated on first use
+	std::vector<int32_t> mark_slot((size_t)Q, -1);
 	std::vector<int32_t> ycnt((size_t)Q, 0); // #genomes where the gene is dominant and already marked
 
 	std::vector<pg128_t> cnt((size_t)Q);
@@ -438,11 +450,18 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 			p->gid = gid, p->n_dom = n_dom, p->n_sub = n_sub;
 			if (x > 0)
 				for (int64_t k = sub_off[(size_t)gid]; k < sub_off[(size_t)gid + 1]; ++k) {
-					const int64_t cell = sub_cell[(size_t)k];
-					if (!marked[(size_t)cell]) marked[(size_t)cell] = 1, ++ycnt[(size_t)(cell % Q)];
+					const uint64_t *rec = &pairs[(size_t)(sub_rec[(size_t)k] * (1 + nw))];
+					const int32_t dom = (int32_t)(rec[0] & m20);
+					if (mark_slot[(size_t)dom] < 0) mark_slot[(size_t)dom] = (int32_t)(marked.size() / (size_t)nw), marked.resize(marked.size() + (size_t)nw, 0);
+					uint64_t *mk = &marked[(size_t)mark_slot[(size_t)dom] * (size_t)nw];
+					for (int64_t w = 0; w < nw; ++w) {
+						const uint64_t fresh = rec[1 + w] & ~mk[w];
+						mk[w] |= fresh, ycnt[(size_t)dom] += __builtin_popcountll(fresh);
+					}
 				}
 		}
 	}
+	if (std::getenv("PANGENE_VTX_TIMING")) std::fprintf(stderr, "[vtx] partials %.3f ms, fetch %.3f ms (records %ld / %ld), greedy %.3f ms\n", (tv1 - tv0) * 1e3, (tv2 - tv1) * 1e3, (long)n_tri, (long)n_rec, (now_sec() - tv2) * 1e3);
 	// segments by gene id (vertex.c:85-94; keys unique, any sort gives the reference's order)
 	std::sort(q->seg, q->seg + q->n_seg, [](const pg_seg_t &a, const pg_seg_t &b) { return a.gid < b.gid; });
 	gen_g2s(q);

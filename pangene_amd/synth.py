@@ -418,6 +418,34 @@ def dense(seed: int = 1, G: int = 4, n_small: int = 700, pile: int = 48) -> Iter
         yield ("d%02d.paf" % j, "".join(lines))
 
 
+def many_doms(seed: int = 1, G: int = 24, n_x: int = 6) -> Iterator[Tuple[str, str]]:
+    """Genes x0..x{n_x-1} stand alone in the even genomes and lose, in odd genome j, to a stronger gene y{i}_{(j // 2) % 11}
+    on the same locus: each x is dominant often enough to be selected first and then marks cells of 11 distinct dominators
+    (more than the eight slots per gene the device fold of pg_gen_vtx keeps); y genes that only ever dominate an x end up
+    with all their genomes marked (vertex.c:70: y == x, not selected) unless they also occur on their own (every third).
+    A background of ordinary genes provides vertices and arcs."""
+    for j in range(G):
+        rj = _rng(seed, 9000 + j)
+        lines = []
+
+        def add(name, plen, x, ms, strand="+"):
+            lines.append("%s\t%d\t0\t%d\t%s\tM%d#0#c0\t%d\t%d\t%d\t%d\t%d\t0\tms:i:%d\tcg:Z:%dM\n" % (
+                name, plen, plen, strand, j, 1000000, x, x + 3 * plen, 3 * plen, 3 * plen, ms, plen))
+
+        for b in range(60):
+            if rj.random() < 0.9:
+                add("bg%02d" % b, 100, 2000 + b * 1000, 480, "+-"[b & 1])
+        for i in range(n_x):
+            x = 100000 + i * 5000
+            add("x%d" % i, 100, x, 300)
+            if j & 1:
+                add("y%d_%d" % (i, (j // 2) % 11), 110, x - 15, 520)
+            for k in range(0, 11, 3):  # these dominators also stand alone in every genome
+                if not ((j & 1) and k == (j // 2) % 11):
+                    add("y%d_%d" % (i, k), 110, 200000 + (i * 11 + k) * 1000, 520)
+        yield ("m%02d.paf" % j, "".join(lines))
+
+
 def write_files(gen: Iterator[Tuple[str, str]], out_dir: str, gz: bool = False) -> List[str]:
     os.makedirs(out_dir, exist_ok=True)
     paths = []

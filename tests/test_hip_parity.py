@@ -73,6 +73,14 @@ def test_sweep_slow_list_and_list_overflow(hip, ora, tmp_path, args):
     hip.pg_set_exact_mode(1); ora.pg_set_exact_mode(1)
 
 
+@pytest.mark.parametrize("args", ["", "-p0 -a1", "-G"])
+def test_vertex_fold_spills_beyond_eight_dominators(hip, ora, tmp_path, args):
+    """synth.many_doms: genes with 11 distinct dominators over the genomes overflow the per-gene slots of k_vtx_fold"""
+    fs = synth.write_files(synth.many_doms(2), str(tmp_path / "m"))
+    a, b = capi.run(hip, fs, args.split()), capi.run(ora, fs, args.split())
+    assert a == b and len(a) > 1000
+
+
 def test_cross_shard_arc_merge(hip):
     """pga_arc_merge (what every rank runs on the all-gathered arc tables of a sharded round) against a numpy reduce-by-key"""
     raw = C.CDLL(capi.LIB_HIP)

@@ -75,12 +75,12 @@ def test_dense_shape_against_reference_binary(ora, tmp_path):
     ref = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
     if not os.path.exists(ref):
         pytest.skip("oracle/_ref/pangene_ref not built")
-    fs = synth.write_files(synth.dense(3), str(tmp_path / "d"))
-    for mode, args in ((2, []), (2, ["-p0", "-a1"]), (1, []), (1, ["-S"])):
-        ora.pg_set_exact_mode(mode)
-        mine = capi.run(ora, fs, args)
-        want = subprocess.run([ref] + args + fs, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
-        assert mine == want and len(want) > 1000
+    for fs in (synth.write_files(synth.dense(3), str(tmp_path / "d")), synth.write_files(synth.many_doms(2), str(tmp_path / "m"))):
+        for mode, args in ((2, []), (2, ["-p0", "-a1"]), (1, []), (1, ["-S"]), (1, ["-G"])):
+            ora.pg_set_exact_mode(mode)
+            mine = capi.run(ora, fs, args)
+            want = subprocess.run([ref] + args + fs, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+            assert mine == want and len(want) > 1000
 
 
 @pytest.mark.parametrize("name", ["C4", "bact20", "human8f", "fuzz3"])
