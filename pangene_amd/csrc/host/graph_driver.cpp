@@ -70,29 +70,6 @@ static int xreduce(const pga_backend_t *be, void *buf, int64_t count, int32_t dt
 	return g_xchg.allreduce(g_xchg.user, buf, count, dtype, op, be->is_device());
 }
 
-// all-gather of a variable-length array living in backend memory: every rank's n entries end up in backend
-// memory as W slots of *slot_entries entries (pointer *gathered), cnt[r] of them valid
-template <class T>
-static int xgather_raw(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int64_t n, std::vector<int64_t> &cnt, int64_t *slot_entries, T **gathered)
-{
-	const int W = g_xchg.world;
-	void *scr;
-	cnt.assign((size_t)W, 0);
-	BE_CALL(be->scratch(ctx, sizeof(int64_t) * (size_t)(W + 1), &scr), "scratch");
-	BE_CALL(be->put(ctx, scr, &n, sizeof(int64_t)), "put");
-	BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + sizeof(int64_t), sizeof(int64_t), be->is_device()), "allgather(count)");
-	BE_CALL(be->fetch(ctx, cnt.data(), (char *)scr + sizeof(int64_t), sizeof(int64_t) * (size_t)W), "fetch");
-	const int64_t mx = *std::max_element(cnt.begin(), cnt.end());
-	*slot_entries = mx, *gathered = nullptr;
-	if (mx == 0) return 0;
-	const size_t slot = (size_t)mx * sizeof(T);
-	BE_CALL(be->scratch(ctx, slot * (size_t)(W + 1), &scr), "scratch");
-	if (n) BE_CALL(be->copy(ctx, scr, local, (size_t)n * sizeof(T)), "copy");
-	BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + slot, (int64_t)slot, be->is_device()), "allgather(data)");
-	*gathered = (T *)((char *)scr + slot);
-	return 0;
-}
-
 // all-gather of a variable-length array living in backend memory -> host vector (rank order)
 template <class T>
 static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int64_t n, std::vector<T> &out, bool local_on_host = false)
@@ -481,22 +458,41 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), &b_seg, &b_arc, &n_loc), "arc_round"); }
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
 	Phase ph_host(PH_ARC_HOST);
-	BE_CALL(xreduce(be, b_seg, 2 * (int64_t)S, PG_X_I32, PG_X_SUM), "allreduce(seg counts)");
 	std::vector<int32_t> sc((size_t)S * 2);
-	if (S) BE_CALL(be->fetch(ext->ctx, sc.data(), b_seg, sizeof(int32_t) * (size_t)S * 2), "fetch");
-	for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
 	// The arc table stays in backend memory (after the cross-shard merge when sharded): branch marking, hit marking and the
 	// degree filter read it there; it travels to the host once, after the last round (fetch_arcs).
 	const pga_arc_part_t *cur = b_arc;
 	int64_t n_cur = n_loc;
-	if (sharded()) { // all-gather the local tables (RCCL) and reduce by key on the backend; integer sums => order-independent
-		std::vector<int64_t> cnt;
+	if (!sharded()) {
+		if (S) BE_CALL(be->fetch(ext->ctx, sc.data(), b_seg, sizeof(int32_t) * (size_t)S * 2), "fetch");
+	} else {
+		// one all-reduce carries the segment counters and, in W extra slots, every rank's arc-table size (each rank adds its
+		// own into its slot), so the all-gather of the tables below needs no size exchange of its own
+		const int W = g_xchg.world;
+		std::vector<int32_t> mine((size_t)W, 0), all((size_t)S * 2 + (size_t)W);
+		mine[(size_t)g_xchg.rank] = (int32_t)n_loc;
+		void *scr;
+		BE_CALL(be->scratch(ext->ctx, sizeof(int32_t) * ((size_t)S * 2 + (size_t)W), &scr), "scratch");
+		if (S) BE_CALL(be->copy(ext->ctx, scr, b_seg, sizeof(int32_t) * (size_t)S * 2), "copy");
+		BE_CALL(be->put(ext->ctx, (int32_t *)scr + (size_t)S * 2, mine.data(), sizeof(int32_t) * (size_t)W), "put");
+		BE_CALL(xreduce(be, scr, 2 * (int64_t)S + W, PG_X_I32, PG_X_SUM), "allreduce(seg counts, table sizes)");
+		BE_CALL(be->fetch(ext->ctx, all.data(), scr, sizeof(int32_t) * all.size()), "fetch");
+		std::copy(all.begin(), all.begin() + (size_t)S * 2, sc.begin());
+		// all-gather the local tables (RCCL) and reduce by key on the backend; integer sums => order-independent
+		std::vector<int64_t> cnt((size_t)W);
 		int64_t slot = 0, n_mg = 0;
-		pga_arc_part_t *gathered = nullptr, *merged = nullptr;
-		BE_CALL(xgather_raw(be, ext->ctx, b_arc, n_loc, cnt, &slot, &gathered), "allgather(arcs)");
-		if (slot) BE_CALL(be->arc_merge(ext->ctx, gathered, cnt.data(), g_xchg.world, slot, &merged, &n_mg), "arc_merge");
+		for (int r = 0; r < W; ++r) cnt[(size_t)r] = all[(size_t)S * 2 + (size_t)r], slot = std::max(slot, cnt[(size_t)r]);
+		pga_arc_part_t *merged = nullptr;
+		if (slot) {
+			const size_t bytes = (size_t)slot * sizeof(pga_arc_part_t);
+			BE_CALL(be->scratch(ext->ctx, bytes * (size_t)(W + 1), &scr), "scratch");
+			if (n_loc) BE_CALL(be->copy(ext->ctx, scr, b_arc, (size_t)n_loc * sizeof(pga_arc_part_t)), "copy");
+			BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + bytes, (int64_t)bytes, be->is_device()), "allgather(arcs)");
+			BE_CALL(be->arc_merge(ext->ctx, (pga_arc_part_t *)((char *)scr + bytes), cnt.data(), W, slot, &merged, &n_mg), "arc_merge");
+		}
 		cur = merged, n_cur = n_mg;
 	}
+	for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
 	ext->deg.assign((size_t)S * 2 + 1, 0);
 	BE_CALL(be->arc_set_current(ext->ctx, cur, n_cur, S, ext->deg.data()), "arc_set_current");
 	ext->cur_arcs = cur, q->n_arc = (int32_t)n_cur;
