@@ -75,6 +75,7 @@ struct pga_ctx {
 	int32_t *rk = 0;        // dense rank of the score key (score_adj, preferred, hash(pid)) of overlap.c:137 over the shard; 0 = key 0
 	int sc_bits = 64;       // significant bits of that key
 	bool any_multi = true;  // some hit has more than one exon
+	bool rp_compact = false; // 8-byte (gene, genome) position records (see k_rep_fill)
 	int4 *recA = 0, *recB = 0, *recC = 0; // packed sweep records (derived from the arrays above, see k_pack_rec)
 	// dynamic per hit
 	int32_t *rank = 0, *sdom = 0, *pdom = 0, *pdom0 = 0; uint32_t *flags = 0;
@@ -1119,36 +1120,60 @@ __global__ __launch_bounds__(BLOCK) void k_rep_last(const int32_t *wk, const int
 	atomicMax(&rp_pos[(int64_t)gid[h] * GL + gnm[h]], h + 1);
 }
 
+// Position record of (gene, genome): {contig, rank among the walkable hits of the genome, cm}.  COMPACT (every genome has
+// < 4096 contigs and < 2^20 hits, decided once in create): 8 bytes {cm, local contig << 20 | rank}, half the L2 traffic of
+// pg_n_local, which reads two records per (pair, genome); otherwise 16 bytes {global contig, rank, cm, 0}.  Absent: -1.
+template <bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void k_rep_fill(const int32_t *rp_pos, int64_t n_ent, int GL, const int32_t *seg, const int32_t *cm, const int32_t *rx,
-                                                      const int32_t *goff, int4 *rp)
+                                                      const int32_t *goff, const int32_t *ctg_base, void *rp_out)
 {
 	int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (e >= n_ent) return;
-	int p = rp_pos[e];
-	if (p == 0) { rp[e] = make_int4(-1, 0, 0, 0); return; }
-	int h = p - 1, j = (int)(e % GL);
-	rp[e] = make_int4(seg[h], rx[h] - rx[goff[j]], cm[h], 0); // {contig, rank among the walkable hits of the genome, cm}
+	const int p = rp_pos[e];
+	if (COMPACT) {
+		int2 *rp = (int2 *)rp_out;
+		if (p == 0) { rp[e] = make_int2(0, -1); return; }
+		const int h = p - 1, j = (int)(e % GL);
+		rp[e] = make_int2(cm[h], (seg[h] - ctg_base[j]) << 20 | (rx[h] - rx[goff[j]]));
+	} else {
+		int4 *rp = (int4 *)rp_out;
+		if (p == 0) { rp[e] = make_int4(-1, 0, 0, 0); return; }
+		const int h = p - 1, j = (int)(e % GL);
+		rp[e] = make_int4(seg[h], rx[h] - rx[goff[j]], cm[h], 0);
+	}
 }
 
-// one wave per gene pair, lanes over the local genomes; one 16-byte record per (gene, genome)
-__global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const int4 *rp,
+// one wave per gene pair, lanes over the local genomes (branch.c:31-46); the count is a popcount of ballots: no
+// cross-lane reduction
+template <bool COMPACT>
+__global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const void *rp_in,
                                                      int local_dist, int local_count, int frag_mode, int32_t *cnt)
 {
 	const int64_t k = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
 	if (k >= n_pair) return;
-	const int4 *r1 = rp + (int64_t)pairs[2 * k] * GL, *r2 = rp + (int64_t)pairs[2 * k + 1] * GL;
+	const int64_t g1 = (int64_t)pairs[2 * k] * GL, g2 = (int64_t)pairs[2 * k + 1] * GL;
 	int c = 0;
-	for (int j = lane; j < GL; j += WAVE) {
-		const int4 a = r1[j], b = r2[j];
-		if (a.x < 0 || b.x < 0) continue;
-		if (!frag_mode && a.x != b.x) continue;
-		const int64_t d = (int64_t)a.z - (int64_t)b.z;
-		const int cc = a.y - b.y;
-		if ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count)) ++c;
+	for (int j0 = 0; j0 < GL; j0 += WAVE) {
+		const int j = j0 + lane;
+		bool hit = false;
+		if (j < GL) {
+			if (COMPACT) {
+				const int2 a = ((const int2 *)rp_in)[g1 + j], b = ((const int2 *)rp_in)[g2 + j];
+				const int64_t d = (int64_t)a.x - (int64_t)b.x;
+				const int cc = (a.y & 0xfffff) - (b.y & 0xfffff);
+				hit = (a.y | b.y) >= 0 && (frag_mode || ((a.y ^ b.y) >> 20) == 0) &&
+				      ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+			} else {
+				const int4 a = ((const int4 *)rp_in)[g1 + j], b = ((const int4 *)rp_in)[g2 + j];
+				const int64_t d = (int64_t)a.z - (int64_t)b.z;
+				const int cc = a.y - b.y;
+				hit = a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x) &&
+				      ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+			}
+		}
+		c += __popcll(__ballot(hit));
 	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, WAVE);
 	if (lane == 0) cnt[k] = c;
 }
 
@@ -1604,6 +1629,8 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->h_goff.resize((size_t)GL + 1);
 	for (int g = 0; g <= GL; ++g) c->h_goff[(size_t)g] = (int32_t)sh->hit_off[g];
 	for (int g = 0; g < GL; ++g) ctg_base[(size_t)g + 1] = ctg_base[(size_t)g] + sh->n_ctg[g];
+	c->rp_compact = true;
+	for (int g = 0; g < GL; ++g) if (sh->n_ctg[g] >= 4096 || sh->hit_off[g + 1] - sh->hit_off[g] >= (1 << 20)) c->rp_compact = false;
 	c->n_seg_ctg = ctg_base[(size_t)GL];
 	c->h_ggl.assign(sh->genome_global, sh->genome_global + GL);
 	uint32_t max_cs = 0, max_cm = 0, max_sadj = 0;
@@ -1998,9 +2025,10 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		device_scan<I32>(InI32{wk}, OutExclI32{rx}, N, tile, OpSum{}, I32{0}, c->st);
 		hipLaunchKernelGGL(k_rep_last, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->gnm, c->gid, N, GL, rp_pos);
 		hipLaunchKernelGGL(k_hz_cs, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->seg, c->cs, N, c->dcnt);
-		if (n_ent) hipLaunchKernelGGL(k_rep_fill, dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, rp);
+		if (n_ent && c->rp_compact) hipLaunchKernelGGL((k_rep_fill<true>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, c->ctg_base, (void *)rp);
+		else if (n_ent) hipLaunchKernelGGL((k_rep_fill<false>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, c->ctg_base, (void *)rp);
 	} else if (n_ent) {
-		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(4 * n_ent)), dim3(BLOCK), 0, c->st, (int32_t *)rp, 4 * n_ent, -1);
+		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(4 * n_ent)), dim3(BLOCK), 0, c->st, (int32_t *)rp, 4 * n_ent, -1); // "absent" in either record form
 	}
 	return 0;
 }
@@ -2011,7 +2039,8 @@ static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, int32_t lo
 	int4 *rp = (int4 *)c->pool.get(S_RP_SEG, 0);
 	if (!d_cnt || !rp) return PGA_ERR_NOMEM;
 	*cnt = d_cnt;
-	if (n) hipLaunchKernelGGL(k_n_local, dim3(nblk(n, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, rp, local_dist, local_count, frag_mode, d_cnt);
+	if (n && c->rp_compact) hipLaunchKernelGGL((k_n_local<true>), dim3(nblk(n, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt);
+	else if (n) hipLaunchKernelGGL((k_n_local<false>), dim3(nblk(n, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt);
 	return 0;
 }
 
