@@ -187,6 +187,9 @@ typedef struct {
 	int (*allreduce)(void *user, void *buf, int64_t count, int32_t dtype, int32_t op, int32_t is_device);
 	/* all-gather `nbytes` from every rank into out[world*nbytes] */
 	int (*allgather)(void *user, const void *in, void *out, int64_t nbytes, int32_t is_device);
+	/* non-zero: the callbacks enqueue on the backend's own stream (pga_active_stream), so the library need not wait for
+	 * its kernels before calling them; zero: it synchronises first */
+	int32_t stream_ordered;
 } pg_exchange_t;
 void pg_set_exchange(const pg_exchange_t *x);
 

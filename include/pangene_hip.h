@@ -193,6 +193,12 @@ typedef struct {
 	/* one reusable scratch buffer in backend memory (staging area for padded all-gathers); a second \
 	 * call invalidates the first pointer */ \
 	int  pfx##_scratch(pga_ctx_t *ctx, size_t nbytes, void **ptr); \
+	/* wait until everything issued so far has finished (only needed before handing backend memory to code that does not \
+	 * run on the backend's stream; fetch and the calls that return host values synchronise by themselves) */ \
+	int  pfx##_sync(pga_ctx_t *ctx); \
+	/* fetch without waiting: the bytes are copied to host memory owned by the backend, *host_view points at them and is \
+	 * valid from the next synchronising call (fetch, sync, arc_set_current, ...) until the next fetch_later */ \
+	int  pfx##_fetch_later(pga_ctx_t *ctx, const void *src_backend, size_t nbytes, const void **host_view); \
 	/* per-hit state in file order */ \
 	int  pfx##_download(pga_ctx_t *ctx, const pga_hit_state_t *out); \
 	int  pfx##_hazards(pga_ctx_t *ctx, pga_hazard_t *out); \
@@ -235,6 +241,8 @@ typedef struct {
 	const char *(*strerror)(int);
 	int  (*timing_reset)(pga_ctx_t *);  /* may be NULL */
 	int  (*timing_get)(pga_ctx_t *, int32_t, double *, int64_t *, int64_t *);
+	int  (*sync)(pga_ctx_t *);
+	int  (*fetch_later)(pga_ctx_t *, const void *, size_t, const void **);
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);

@@ -744,6 +744,9 @@ static int64_t branch_vertex(pga_ctx_t *c, int64_t a0, int32_t n, double branch_
 }
 
 /* the round's arc table: s1 (graph.c:171), target genes, out-degrees (graph.c:243-250) */
+int pgo_sync(pga_ctx_t *c) { (void)c; return PGA_OK; }
+int pgo_fetch_later(pga_ctx_t *c, const void *src, size_t nbytes, const void **host_view) { (void)c; (void)nbytes; *host_view = src; return PGA_OK; }
+
 int pgo_arc_set_current(pga_ctx_t *c, const pga_arc_part_t *arcs, int64_t n_arc, int32_t n_seg, int32_t *deg)
 {
 	int64_t i;
@@ -958,7 +961,7 @@ const pga_backend_t *pgo_backend(void)
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
 		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_arc_merge, pgo_arc_set_current, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
-		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0
+		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later
 	};
 	return &b;
 }

@@ -35,7 +35,7 @@ ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int6
 
 
 class pg_exchange_t(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("allreduce", ALLREDUCE_CB), ("allgather", ALLGATHER_CB)]
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("allreduce", ALLREDUCE_CB), ("allgather", ALLGATHER_CB), ("stream_ordered", C.c_int32)]
 
 
 _API = {

@@ -87,6 +87,8 @@ struct pga_ctx {
 	int64_t *dcnt = 0;      // device counters: [0] triples [1] arcs-temp [2] misc [3] invariant flag, [4..7] hazards
 	int64_t *h_cnt = 0;     // pinned mirror
 	int64_t *h_box = 0;     // the same memory as the device sees it
+	void *h_stage = nullptr; size_t h_stage_cap = 0; // pinned landing area of fetch_later
+	int32_t *h_g2s = nullptr; size_t h_g2s_cap = 0; hipEvent_t g2s_done = nullptr; // pinned staging of flag_vtx's gene -> segment map
 	DevPool pool;
 	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
 	int64_t br_n = 0, br_np = 0; int32_t br_S = 0; // arcs / pairs / segments of the last branch_pairs
@@ -1567,6 +1569,9 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 	for (void *q : c->owned) (void)hipFree(q);
 	c->pool.release();
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+	if (c->h_stage) (void)hipHostFree(c->h_stage);
+	if (c->h_g2s) (void)hipHostFree(c->h_g2s);
+	if (c->g2s_done) (void)hipEventDestroy(c->g2s_done);
 	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
 	delete c;
 }
@@ -1781,7 +1786,7 @@ extern "C" int pga_post_partials(pga_ctx_t *c, int32_t **max_ori, int64_t **sums
 	if (c->N) hipLaunchKernelGGL(k_post_part, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->rank, c->sori, c->sadj, c->nex, c->N, c->P,
 	                             c->max_ori, (unsigned long long *)c->sums);
 	*max_ori = c->max_ori, *sums = c->sums;
-	return sync_st(c); // the exchange may run on another stream
+	return 0; // no wait: a consumer that is not on this stream calls pga_sync first
 }
 
 extern "C" int pga_post_apply(pga_ctx_t *c, const uint8_t *prot_rep, const uint8_t *prot_pj, int64_t *n_pseudo)
@@ -1865,10 +1870,21 @@ extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records,
 
 extern "C" int pga_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg)
 {
-	TRY(upload(c, c->g2s, g2s, (size_t)c->Q));
+	// g2s is caller memory: it is copied into a pinned staging area so that the call need not wait for the upload
+	const size_t nb = sizeof(int32_t) * (size_t)c->Q;
+	if (c->h_g2s_cap < nb) {
+		if (c->h_g2s) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipHostFree(c->h_g2s); c->h_g2s = nullptr; }
+		HIPCHK(hipHostMalloc((void **)&c->h_g2s, nb + 64, hipHostMallocDefault));
+		c->h_g2s_cap = nb;
+	}
+	if (!c->g2s_done) HIPCHK(hipEventCreateWithFlags(&c->g2s_done, hipEventDisableTiming));
+	else HIPCHK(hipEventSynchronize(c->g2s_done)); // the previous upload out of the staging area (long finished in practice)
+	if (nb) memcpy(c->h_g2s, g2s, nb);
+	TRY(upload(c, c->g2s, (const int32_t *)c->h_g2s, (size_t)c->Q));
+	HIPCHK(hipEventRecord(c->g2s_done, c->st));
 	c->n_seg = n_seg;
 	if (c->N) hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, c->N, c->g2s);
-	return sync_st(c); // g2s is caller memory: make the copy complete before returning
+	return 0;
 }
 
 // walkable marks in cm order + predecessor; shared by arc_round and mark_hits
@@ -2086,7 +2102,7 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	if (np) hipLaunchKernelGGL((k_br_wave<1>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, pairs,
 	                           (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt);
 	TRY(n_local_dev(c, pairs, np, local_dist, local_count, frag_mode, cnt));
-	return sync_st(c); // the exchange may run on another stream
+	return 0; // no wait: a consumer that is not on this stream calls pga_sync first
 }
 
 extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch_diff_dist, double branch_diff_cut, uint8_t *arc_weak,
@@ -2189,6 +2205,20 @@ extern "C" int pga_set_head(pga_ctx_t *c, const int32_t *head_file)
 	return sync_st(c); // head_file is caller memory
 }
 
+extern "C" int pga_sync(pga_ctx_t *c) { return sync_st(c); }
+
+extern "C" int pga_fetch_later(pga_ctx_t *c, const void *src_backend, size_t nbytes, const void **host_view)
+{
+	if (c->h_stage_cap < nbytes) {
+		if (c->h_stage) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipHostFree(c->h_stage); c->h_stage = nullptr; }
+		HIPCHK(hipHostMalloc(&c->h_stage, nbytes + nbytes / 2 + 256, hipHostMallocDefault));
+		c->h_stage_cap = nbytes + nbytes / 2 + 256;
+	}
+	*host_view = c->h_stage;
+	if (nbytes) HIPCHK(hipMemcpyAsync(c->h_stage, src_backend, nbytes, hipMemcpyDeviceToHost, c->st));
+	return 0;
+}
+
 extern "C" int pga_fetch(pga_ctx_t *c, void *dst_host, const void *src_backend, size_t nbytes)
 {
 	if (nbytes == 0) return 0;
@@ -2274,7 +2304,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later
 	};
 	return &b;
 }

@@ -102,7 +102,7 @@ int pg_rccl_init(int32_t rank, int32_t world, const void *id128)
 	if (r != ncclSuccess) { g_comm = nullptr; return fail(r, "ncclCommInitRank"); }
 	g_rank = rank, g_world = world;
 	pg_exchange_t x;
-	x.rank = rank, x.world = world, x.user = nullptr, x.allreduce = x_allreduce, x.allgather = x_allgather;
+	x.rank = rank, x.world = world, x.user = nullptr, x.allreduce = x_allreduce, x.allgather = x_allgather, x.stream_ordered = 1;
 	pg_set_exchange(&x);
 	return 0;
 }

@@ -64,9 +64,14 @@ static inline bool sharded()
 
 #define BE_CALL(expr, where) do { int rc__ = (expr); if (rc__ != 0) { set_error(rc__, where); return rc__; } } while (0)
 
-static int xreduce(const pga_backend_t *be, void *buf, int64_t count, int32_t dtype, int32_t op)
+// the exchange callbacks run on the backend's stream (built-in RCCL) or somewhere else (torch.distributed, gloo): in the
+// second case the backend has to finish what it was asked to do first
+static inline int xready(const pga_backend_t *be, pga_ctx_t *ctx) { return g_xchg.stream_ordered ? 0 : be->sync(ctx); }
+
+static int xreduce(const pga_backend_t *be, pga_ctx_t *ctx, void *buf, int64_t count, int32_t dtype, int32_t op)
 {
 	if (!sharded() || count == 0) return 0;
+	BE_CALL(xready(be, ctx), "sync");
 	return g_xchg.allreduce(g_xchg.user, buf, count, dtype, op, be->is_device());
 }
 
@@ -84,6 +89,7 @@ static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int6
 	std::vector<int64_t> cnt((size_t)W);
 	BE_CALL(be->scratch(ctx, sizeof(int64_t) * (size_t)(W + 1), &scr), "scratch");
 	BE_CALL(be->put(ctx, scr, &n, sizeof(int64_t)), "put");
+	BE_CALL(xready(be, ctx), "sync");
 	BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + sizeof(int64_t), sizeof(int64_t), be->is_device()), "allgather(count)");
 	BE_CALL(be->fetch(ctx, cnt.data(), (char *)scr + sizeof(int64_t), sizeof(int64_t) * (size_t)W), "fetch");
 	int64_t mx = *std::max_element(cnt.begin(), cnt.end()), tot = 0;
@@ -93,6 +99,7 @@ static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int6
 	size_t slot = (size_t)mx * sizeof(T);
 	BE_CALL(be->scratch(ctx, slot * (size_t)(W + 1), &scr), "scratch");
 	if (n) BE_CALL(local_on_host ? be->put(ctx, scr, local, (size_t)n * sizeof(T)) : be->copy(ctx, scr, local, (size_t)n * sizeof(T)), "copy");
+	BE_CALL(xready(be, ctx), "sync");
 	BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + slot, (int64_t)slot, be->is_device()), "allgather(data)");
 	std::vector<T> all((size_t)mx * (size_t)W);
 	BE_CALL(be->fetch(ctx, all.data(), (char *)scr + slot, slot * (size_t)W), "fetch");
@@ -281,8 +288,8 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 
 	int32_t *b_max; int64_t *b_sum;
 	BE_CALL(be->post_partials(ctx, &b_max, &b_sum), "post_partials");
-	BE_CALL(xreduce(be, b_max, P, PG_X_I32, PG_X_MAX), "allreduce(max_score_ori)");
-	BE_CALL(xreduce(be, b_sum, 6 * (int64_t)P, PG_X_I64, PG_X_SUM), "allreduce(protein sums)");
+	BE_CALL(xreduce(be, ext->ctx, b_max, P, PG_X_I32, PG_X_MAX), "allreduce(max_score_ori)");
+	BE_CALL(xreduce(be, ext->ctx, b_sum, 6 * (int64_t)P, PG_X_I64, PG_X_SUM), "allreduce(protein sums)");
 	std::vector<int32_t> mx((size_t)P);
 	std::vector<int64_t> sm((size_t)P * 6);
 	if (P) {
@@ -366,7 +373,7 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	const double tv0 = now_sec();
 	BE_CALL(be->vtx_partials(ext->ctx, &b_cnt, &b_tri, &n_tri), "vtx_partials");
 	const double tv1 = now_sec();
-	BE_CALL(xreduce(be, b_cnt, 2 * (int64_t)Q, PG_X_I32, PG_X_SUM), "allreduce(n_dom,n_sub)");
+	BE_CALL(xreduce(be, ext->ctx, b_cnt, 2 * (int64_t)Q, PG_X_I32, PG_X_SUM), "allreduce(n_dom,n_sub)");
 	std::vector<int32_t> cntv((size_t)Q * 2);
 	if (Q) BE_CALL(be->fetch(ext->ctx, cntv.data(), b_cnt, sizeof(int32_t) * (size_t)Q * 2), "fetch");
 	// What the greedy needs is, per (sub, dom) gene pair, the SET of genomes in which sub is sub-ordinate to a dominant dom: a
@@ -463,8 +470,9 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	// degree filter read it there; it travels to the host once, after the last round (fetch_arcs).
 	const pga_arc_part_t *cur = b_arc;
 	int64_t n_cur = n_loc;
+	const void *sc_view = nullptr;
 	if (!sharded()) {
-		if (S) BE_CALL(be->fetch(ext->ctx, sc.data(), b_seg, sizeof(int32_t) * (size_t)S * 2), "fetch");
+		BE_CALL(be->fetch_later(ext->ctx, b_seg, sizeof(int32_t) * (size_t)S * 2, &sc_view), "fetch_later"); // lands with arc_set_current's wait below
 	} else {
 		// one all-reduce carries the segment counters and, in W extra slots, every rank's arc-table size (each rank adds its
 		// own into its slot), so the all-gather of the tables below needs no size exchange of its own
@@ -475,7 +483,7 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 		BE_CALL(be->scratch(ext->ctx, sizeof(int32_t) * ((size_t)S * 2 + (size_t)W), &scr), "scratch");
 		if (S) BE_CALL(be->copy(ext->ctx, scr, b_seg, sizeof(int32_t) * (size_t)S * 2), "copy");
 		BE_CALL(be->put(ext->ctx, (int32_t *)scr + (size_t)S * 2, mine.data(), sizeof(int32_t) * (size_t)W), "put");
-		BE_CALL(xreduce(be, scr, 2 * (int64_t)S + W, PG_X_I32, PG_X_SUM), "allreduce(seg counts, table sizes)");
+		BE_CALL(xreduce(be, ext->ctx, scr, 2 * (int64_t)S + W, PG_X_I32, PG_X_SUM), "allreduce(seg counts, table sizes)");
 		BE_CALL(be->fetch(ext->ctx, all.data(), scr, sizeof(int32_t) * all.size()), "fetch");
 		std::copy(all.begin(), all.begin() + (size_t)S * 2, sc.begin());
 		// all-gather the local tables (RCCL) and reduce by key on the backend; integer sums => order-independent
@@ -487,14 +495,16 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 			const size_t bytes = (size_t)slot * sizeof(pga_arc_part_t);
 			BE_CALL(be->scratch(ext->ctx, bytes * (size_t)(W + 1), &scr), "scratch");
 			if (n_loc) BE_CALL(be->copy(ext->ctx, scr, b_arc, (size_t)n_loc * sizeof(pga_arc_part_t)), "copy");
+			BE_CALL(xready(be, ext->ctx), "sync");
 			BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + bytes, (int64_t)bytes, be->is_device()), "allgather(arcs)");
 			BE_CALL(be->arc_merge(ext->ctx, (pga_arc_part_t *)((char *)scr + bytes), cnt.data(), W, slot, &merged, &n_mg), "arc_merge");
 		}
 		cur = merged, n_cur = n_mg;
 	}
-	for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
 	ext->deg.assign((size_t)S * 2 + 1, 0);
 	BE_CALL(be->arc_set_current(ext->ctx, cur, n_cur, S, ext->deg.data()), "arc_set_current");
+	if (sc_view && S) std::memcpy(sc.data(), sc_view, sizeof(int32_t) * (size_t)S * 2);
+	for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
 	ext->cur_arcs = cur, q->n_arc = (int32_t)n_cur;
 	return 0;
 }
@@ -565,7 +575,7 @@ static int mark_branch_flt_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 		Phase ph(PH_NLOCAL);
 		BE_CALL(be->branch_pairs(ext->ctx, nullptr, nullptr, 0, nullptr, q->n_seg, opt->branch_diff, opt->local_dist, opt->local_count,
 		                         !!(opt->flag & PG_F_FRAG_MODE), &b_cnt, &np), "branch_pairs");
-		BE_CALL(xreduce(be, b_cnt, np, PG_X_I32, PG_X_SUM), "allreduce(n_local)");
+		BE_CALL(xreduce(be, ext->ctx, b_cnt, np, PG_X_I32, PG_X_SUM), "allreduce(n_local)");
 		std::vector<uint8_t> aw(pg_verbose >= 3 ? (size_t)q->n_arc + 1 : 0); // per-arc weak_br only feeds the log line; it stays resident for mark_hits
 		BE_CALL(be->branch_decide(ext->ctx, opt->branch_diff, opt->branch_diff_dist, opt->branch_diff_cut, aw.empty() ? nullptr : aw.data(), ndl.data(), &n_flt1, &n_flt2), "branch_decide");
 		g_phase[PH_BRANCH_HOST] -= now_sec() - ph.t0; // counted under PH_NLOCAL
@@ -695,7 +705,7 @@ static int hazards_seen(DataExt *ext, bool *seen)
 		int32_t v = n > 0;
 		BE_CALL(ext->be->scratch(ext->ctx, 16, &scr), "scratch");
 		BE_CALL(ext->be->put(ext->ctx, scr, &v, sizeof(v)), "put");
-		BE_CALL(xreduce(ext->be, scr, 1, PG_X_I32, PG_X_MAX), "allreduce(hazard)");
+		BE_CALL(xreduce(ext->be, ext->ctx, scr, 1, PG_X_I32, PG_X_MAX), "allreduce(hazard)");
 		BE_CALL(ext->be->fetch(ext->ctx, &v, scr, sizeof(v)), "fetch");
 		n = v;
 	}

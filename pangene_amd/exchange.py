@@ -77,6 +77,7 @@ def install(lib: C.CDLL, device=None, group=None):
 
     x = capi.pg_exchange_t()
     x.rank, x.world, x.user = rank, world, None
+    x.stream_ordered = 0  # torch's collectives run on torch's streams: the library waits for its own first
     keep = (capi.ALLREDUCE_CB(allreduce), capi.ALLGATHER_CB(allgather))
     x.allreduce, x.allgather = keep
     lib.pg_set_exchange(C.byref(x))
