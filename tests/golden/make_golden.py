@@ -18,11 +18,14 @@ from pangene_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
 VARIANTS = [[], ["-p0", "-a1"], ["-a2"], ["-E"], ["-J"], ["-S"], ["-F"], ["--ori-sc"], ["-w"], ["-a2", "-E"], ["-D", "300", "-C", "2"], ["-G"],
             ["-c", "3", "-g", "6"], ["-T", "3"], ["-f", "0.2"], ["-e", "0.9", "-l", "0.8"], ["-m", "0.5"],
+            ["-b", "0.2", "-B", "0.1", "-y", "0.3"], ["-b", "0.01", "-r", "1"],
             ["--bed=raw"], ["--bed=flag"], ["--bed=walk"]]
 SETS = {
     "bact20": lambda: synth.bact(20, 500, seed=1),
     "human8": lambda: synth.human(8, 300, iso=3.0, seed=1, n_chr=6),
     "human8f": lambda: synth.human(8, 300, iso=3.0, seed=2, n_chr=4, frag=True),
+    "dense": lambda: synth.dense(3),          # giant spanning hit + pile-ups: the sweep's slow-list / overflow paths
+    "manydoms": lambda: synth.many_doms(2),   # > 8 dominators per gene: the spill path of the vertex fold
 }
 for s in range(6):
     SETS["fuzz%d" % s] = (lambda s=s: synth.fuzz(s, harsh=(s % 2 == 0)))
