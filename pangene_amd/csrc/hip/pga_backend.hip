@@ -91,6 +91,7 @@ struct pga_ctx {
 	int32_t *h_g2s = nullptr; size_t h_g2s_cap = 0; hipEvent_t g2s_done = nullptr; // pinned staging of flag_vtx's gene -> segment map
 	DevPool pool;
 	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
+	int4 *yrecA = 0, *yrecB = 0; bool yrec_valid = false; // Y-order static records (k_pack_yrec), rebuilt after anything that changes their sources
 	int64_t br_n = 0, br_np = 0; int32_t br_S = 0; // arcs / pairs / segments of the last branch_pairs
 	std::vector<TimedLaunch> timed;
 	std::vector<void *> owned;
@@ -904,44 +905,57 @@ __global__ __launch_bounds__(BLOCK) void k_walk_mark(const uint32_t *flags, cons
 struct InWalk { const int32_t *val; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{val[i]}; } };
 struct OutPrev { int32_t *prev; __device__ __forceinline__ void operator()(int64_t i, I32, I32 ex) const { prev[i] = ex.v; } };
 
+// Static per-hit fields in Y (cm) order, packed once per run: the arc kernels walk the hits in that order and would otherwise
+// gather every field through yperm.   YA = {seg, gid, genome, cm}   YB = {score_ori, score_dom, gene of pid_dom0's protein
+// (-1: none), X position << 1 | rev}
+__global__ __launch_bounds__(BLOCK) void k_pack_yrec(const int32_t *yperm, const int32_t *seg, const int32_t *gid, const int32_t *gnm, const int32_t *cm,
+                                                       const int32_t *sori, const int32_t *sdom, const int32_t *pdom0, const int32_t *prot_gid, const uint32_t *flags,
+                                                       int n, int4 *YA, int4 *YB)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y >= n) return;
+	const int a = yperm[y], p0 = pdom0[a];
+	YA[y] = make_int4(seg[a], gid[a], gnm[a], cm[a]);
+	YB[y] = make_int4(sori[a], sdom[a], p0 < 0 ? -1 : prot_gid[p0], a << 1 | (flags[a] & PGA_F_REV ? 1 : 0));
+}
+
 // has_arc[y] = 1 if walkable y has a walkable predecessor on the same contig; also per-segment counts
 // (graph.c:113,125-126) and hazard H2a (equal cm of two consecutive walkable hits)
-__global__ __launch_bounds__(BLOCK) void k_arc_flag(const int32_t *val, const int32_t *prev, const int32_t *yperm, const int32_t *seg, const int32_t *gid,
-                                                      const int32_t *gnm, const int32_t *cm, const int32_t *g2s, int n, int S, int32_t *has, int32_t *seg_cnt,
+__global__ __launch_bounds__(BLOCK) void k_arc_flag(const int32_t *val, const int32_t *prev, const int4 *YA, const int32_t *g2s, int n, int S, int32_t *has, int32_t *seg_cnt,
                                                       uint32_t *seen, int64_t words_per_genome, int64_t *dcnt)
 {
 	int y = blockIdx.x * BLOCK + threadIdx.x;
 	if (y >= n) return;
 	int out = 0;
 	if (val[y] >= 0) {
-		int a = yperm[y], sid = g2s[gid[a]];
+		const int4 ra = YA[y];
+		const int sid = g2s[ra.y];
 		if (sid < 0) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // graph.c:111
 		else {
 			int32_t *copy = seg_cnt + (int64_t)(blockIdx.x & (SEGCNT_COPIES - 1)) * 2 * S; // 64 copies: 64x less contention per address
 			atomicAdd(&copy[S + sid], 1);
-			uint32_t old = atomicOr(&seen[(int64_t)gnm[a] * words_per_genome + (sid >> 5)], 1u << (sid & 31));
+			uint32_t old = atomicOr(&seen[(int64_t)ra.z * words_per_genome + (sid >> 5)], 1u << (sid & 31));
 			if (!(old >> (sid & 31) & 1u)) atomicAdd(&copy[sid], 1);
 		}
-		int p = prev[y];
+		const int p = prev[y];
 		if (p >= 0) {
-			int b = yperm[p];
-			if (seg[b] == seg[a]) {
+			const int4 rb = YA[p];
+			if (rb.x == ra.x) {
 				out = 1;
-				if (cm[b] == cm[a]) atomicAdd((unsigned long long *)&dcnt[5], 1ull);
+				if (rb.w == ra.w) atomicAdd((unsigned long long *)&dcnt[5], 1ull);
 			}
 		}
 	}
 	has[y] = out;
 }
 
-__device__ __forceinline__ int arc_score(int a, int ori, const int32_t *sori, const int32_t *sdom, const int32_t *pdom0, const int32_t *prot_gid, const int32_t *g2s)
-{ // pg_get_score, graph.c:82-85
-	int so = sori[a], sd = sdom[a], p0 = pdom0[a];
-	return (ori || so > sd || p0 < 0 || g2s[prot_gid[p0]] >= 0) ? so : sd;
+__device__ __forceinline__ int arc_score(const int4 yb, int ori, const int32_t *g2s)
+{ // pg_get_score, graph.c:82-85: score_ori unless the dominator's gene is not a vertex and score_dom is at least as large
+	return (ori || yb.x > yb.y || yb.z < 0 || g2s[yb.z] >= 0) ? yb.x : yb.y;
 }
 
 struct ArcEmit {
-	const int32_t *has, *slot, *prev, *yperm, *gid, *gnm, *cm, *sori, *sdom, *pdom0, *prot_gid, *g2s; const uint32_t *flags;
+	const int32_t *has, *slot, *prev; const int4 *YA, *YB; const int32_t *g2s;
 	uint64_t *key; uint32_t *idx; int4 *pay; // payload {dist, s1, s2, genome}
 	int n, ori, vbits;
 };
@@ -950,12 +964,13 @@ __global__ __launch_bounds__(BLOCK) void k_arc_emit(ArcEmit e)
 {
 	int y = blockIdx.x * BLOCK + threadIdx.x;
 	if (y >= e.n || !e.has[y]) return;
-	int a = e.yperm[y], b = e.yperm[e.prev[y]];
-	uint32_t w = (uint32_t)e.g2s[e.gid[a]] << 1 | (e.flags[a] & PGA_F_REV ? 1u : 0u);
-	uint32_t v = (uint32_t)e.g2s[e.gid[b]] << 1 | (e.flags[b] & PGA_F_REV ? 1u : 0u);
-	int sa = arc_score(a, e.ori, e.sori, e.sdom, e.pdom0, e.prot_gid, e.g2s);
-	int sb = arc_score(b, e.ori, e.sori, e.sdom, e.pdom0, e.prot_gid, e.g2s);
-	int d = e.cm[a] - e.cm[b], g = e.gnm[a];
+	const int p = e.prev[y];
+	const int4 aA = e.YA[y], bA = e.YA[p], aB = e.YB[y], bB = e.YB[p];
+	uint32_t w = (uint32_t)e.g2s[aA.y] << 1 | (uint32_t)(aB.w & 1);
+	uint32_t v = (uint32_t)e.g2s[bA.y] << 1 | (uint32_t)(bB.w & 1);
+	int sa = arc_score(aB, e.ori, e.g2s);
+	int sb = arc_score(bB, e.ori, e.g2s);
+	int d = aA.w - bA.w, g = aA.z;
 	int64_t o = (int64_t)e.slot[y] * 2;
 	e.key[o] = (uint64_t)v << e.vbits | w;           e.idx[o] = (uint32_t)o;         // v -> w      (graph.c:117)
 	e.pay[o] = make_int4(d, sb, sa, g);
@@ -1344,22 +1359,22 @@ __device__ __forceinline__ int arc_weak_v(const uint64_t *ax, const uint8_t *aw,
 	return 0;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_mark_hits(const int32_t *val, const int32_t *prev, const int32_t *yperm, const int32_t *seg, const int32_t *gid,
-                                                       const uint32_t *flags, const int32_t *g2s, int n, const uint64_t *ax, const uint8_t *aw, int64_t n_arc,
-                                                       const int32_t *vs, const int32_t *ve, int32_t *weak_new)
+__global__ __launch_bounds__(BLOCK) void k_mark_hits(const int32_t *val, const int32_t *prev, const int4 *YA, const int4 *YB, const int32_t *g2s, int n,
+                                                       const uint64_t *ax, const uint8_t *aw, int64_t n_arc, const int32_t *vs, const int32_t *ve, int32_t *weak_new)
 {
 	int y = blockIdx.x * BLOCK + threadIdx.x;
 	if (y >= n || val[y] < 0) return;
 	int p = prev[y];
 	if (p < 0) return;
-	int a = yperm[y], b = yperm[p];
-	if (seg[a] != seg[b]) return; // branch.c:124
-	uint32_t w = (uint32_t)g2s[gid[a]] << 1 | (flags[a] & PGA_F_REV ? 1u : 0u);
-	uint32_t v = (uint32_t)g2s[gid[b]] << 1 | (flags[b] & PGA_F_REV ? 1u : 0u);
+	const int4 aA = YA[y], bA = YA[p];
+	if (aA.x != bA.x) return; // branch.c:124
+	const int aw_ = YB[y].w, bw_ = YB[p].w; // X position << 1 | rev
+	uint32_t w = (uint32_t)g2s[aA.y] << 1 | (uint32_t)(aw_ & 1);
+	uint32_t v = (uint32_t)g2s[bA.y] << 1 | (uint32_t)(bw_ & 1);
 	int e1 = vs ? arc_weak_v(ax, aw, vs, ve, v, w) : arc_weak(ax, aw, n_arc, (uint64_t)v << 32 | w);                       // branch.c:128-130: marks the earlier hit
-	if (e1) atomicMax(&weak_new[b], e1);
+	if (e1) atomicMax(&weak_new[bw_ >> 1], e1);
 	int e2 = vs ? arc_weak_v(ax, aw, vs, ve, w ^ 1, v ^ 1) : arc_weak(ax, aw, n_arc, (uint64_t)(w ^ 1) << 32 | (v ^ 1)); // branch.c:131-133: marks this hit
-	if (e2) atomicMax(&weak_new[a], e2);
+	if (e2) atomicMax(&weak_new[aw_ >> 1], e2);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_weak_merge(uint32_t *flags, const int32_t *weak_new, int n, int64_t *cnt)
@@ -1623,7 +1638,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	// persistent arrays
 	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
 	TRY(dalloc(c, &c->cs, N)); TRY(dalloc(c, &c->ce, N)); TRY(dalloc(c, &c->cm, N)); TRY(dalloc(c, &c->cds, N)); TRY(dalloc(c, &c->nex, N));
-	TRY(dalloc(c, &c->offx, N)); TRY(dalloc(c, &c->sori, N)); TRY(dalloc(c, &c->sadj, N)); TRY(dalloc(c, &c->pm, N)); TRY(dalloc(c, &c->rk, N)); TRY(dalloc(c, &c->recA, N)); TRY(dalloc(c, &c->recB, N)); TRY(dalloc(c, &c->recC, N));
+	TRY(dalloc(c, &c->offx, N)); TRY(dalloc(c, &c->sori, N)); TRY(dalloc(c, &c->sadj, N)); TRY(dalloc(c, &c->pm, N)); TRY(dalloc(c, &c->rk, N)); TRY(dalloc(c, &c->recA, N)); TRY(dalloc(c, &c->recB, N)); TRY(dalloc(c, &c->recC, N)); TRY(dalloc(c, &c->yrecA, N)); TRY(dalloc(c, &c->yrecB, N));
 	TRY(dalloc(c, &c->rank, N)); TRY(dalloc(c, &c->sdom, N)); TRY(dalloc(c, &c->pdom, N)); TRY(dalloc(c, &c->pdom0, N)); TRY(dalloc(c, &c->flags, N));
 	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->ctg_base, GL + 1)); TRY(dalloc(c, &c->inv, N)); TRY(dalloc(c, &c->headpos, GL + 1)); TRY(dalloc(c, &c->exon, E));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q));
@@ -1676,6 +1691,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 // per-hit constants in file order, X order (sort + gather), running max of ce, Y order; resets all state
 extern "C" int pga_begin(pga_ctx_t *c)
 {
+	c->yrec_valid = false;
 	const int N = c->N, GL = c->n_genome;
 	c->walk_valid = false;
 	HIPCHK(hipMemsetAsync(c->dcnt, 0, 16 * sizeof(int64_t), c->st));
@@ -1744,6 +1760,7 @@ extern "C" int pga_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_para
 // stage A (read.c:243-260) for all genomes of the shard
 extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 {
+	c->yrec_valid = false;
 	const int N = c->N, GL = c->n_genome, P = c->P, Q = c->Q;
 	int32_t *d_stats = (int32_t *)c->pool.get(S_STATS, sizeof(int32_t) * 4 * (size_t)GL + 16);
 	if (!d_stats) return PGA_ERR_NOMEM;
@@ -1791,6 +1808,7 @@ extern "C" int pga_post_partials(pga_ctx_t *c, int32_t **max_ori, int64_t **sums
 
 extern "C" int pga_post_apply(pga_ctx_t *c, const uint8_t *prot_rep, const uint8_t *prot_pj, int64_t *n_pseudo)
 {
+	c->yrec_valid = false;
 	uint8_t *d = (uint8_t *)c->pool.get(S_MISC, 2 * (size_t)c->P + 16);
 	if (!d) return PGA_ERR_NOMEM;
 	c->walk_valid = false;
@@ -1805,6 +1823,7 @@ extern "C" int pga_post_apply(pga_ctx_t *c, const uint8_t *prot_rep, const uint8
 
 extern "C" int pga_shadow(pga_ctx_t *c, int32_t cal_dom_sc, int32_t *stats)
 {
+	c->yrec_valid = false;
 	if (cal_dom_sc) TRY(launch_sweep<1>(c, -1)); else TRY(launch_sweep<0>(c, 2));
 	if (stats) {
 		int32_t *d_stats = (int32_t *)c->pool.get(S_STATS, sizeof(int32_t) * 4 * (size_t)c->n_genome + 16);
@@ -1887,6 +1906,14 @@ extern "C" int pga_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg)
 	return 0;
 }
 
+static void ensure_yrec(pga_ctx *c)
+{
+	if (c->yrec_valid || c->N == 0) return;
+	hipLaunchKernelGGL(k_pack_yrec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->yperm, c->seg, c->gid, c->gnm, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags,
+	                   c->N, c->yrecA, c->yrecB);
+	c->yrec_valid = true;
+}
+
 // walkable marks in cm order + predecessor; shared by arc_round and mark_hits
 static int walk_prev(pga_ctx *c, int32_t **val_out, int32_t **prev_out)
 {
@@ -1922,7 +1949,8 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	int32_t *slot = (int32_t *)c->pool.get(S_SLOT, sizeof(int32_t) * (size_t)(2 * (int64_t)N + 2));
 	if (!seen || !has || !slot) return PGA_ERR_NOMEM;
 	zero_multi(c, seen, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, seg_cnt, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES);
-	hipLaunchKernelGGL(k_arc_flag, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yperm, c->seg, c->gid, c->gnm, c->cm, c->g2s, N, S, has, seg_cnt, seen, wpg, c->dcnt);
+	ensure_yrec(c);
+	hipLaunchKernelGGL(k_arc_flag, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yrecA, c->g2s, N, S, has, seg_cnt, seen, wpg, c->dcnt);
 	if (S) hipLaunchKernelGGL(k_segcnt_sum, dim3(nblk(2 * S)), dim3(BLOCK), 0, c->st, seg_cnt, 2 * S);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{has}, OutExclI32{slot}, N, tile, OpSum{}, I32{0}, c->st);
@@ -1937,7 +1965,7 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	int4 *tpay = (int4 *)c->pool.get(S_TDIST, sizeof(int4) * (size_t)M), *spay = (int4 *)c->pool.get(S_SDIST, sizeof(int4) * (size_t)M);
 	int32_t *head = (int32_t *)c->pool.get(S_HEAD, sizeof(int32_t) * (size_t)M);
 	if (!key || !idx || !tpay || !spay || !head) return PGA_ERR_NOMEM;
-	ArcEmit e = { has, slot, prev, c->yperm, c->gid, c->gnm, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->g2s, c->flags, key, idx, tpay, N, use_ori, vbits };
+	ArcEmit e = { has, slot, prev, c->yrecA, c->yrecB, c->g2s, key, idx, tpay, N, use_ori, vbits };
 	hipLaunchKernelGGL(k_arc_emit, dim3(nblk(N)), dim3(BLOCK), 0, c->st, e);
 	uint64_t *ks; uint32_t *vs;
 	TRY(radix_sort_pool(c, key, idx, M, 2 * vbits, &ks, &vs)); // graph.c:127 and :151 in one stable sort
@@ -2147,7 +2175,8 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 	int32_t *val, *prev;
 	TRY(walk_prev(c, &val, &prev));
 	const int32_t *vs = arc_x ? nullptr : (const int32_t *)c->pool.get(S_BR_VS, 0), *ve = arc_x ? nullptr : (const int32_t *)c->pool.get(S_BR_VE, 0);
-	hipLaunchKernelGGL(k_mark_hits, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yperm, c->seg, c->gid, c->flags, c->g2s, N, ax, aw, n_arc, vs, ve, wn);
+	ensure_yrec(c);
+	hipLaunchKernelGGL(k_mark_hits, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yrecA, c->yrecB, c->g2s, N, ax, aw, n_arc, vs, ve, wn);
 	hipLaunchKernelGGL(k_weak_merge, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, wn, N, n_marked ? c->dcnt + 2 : (int64_t *)nullptr);
 	if (n_marked) {
 		HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
@@ -2162,7 +2191,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
                                   const int64_t *seg_off, const int32_t *file_idx)
 {
 	const int N = c->N;
-	c->walk_valid = false;
+	c->walk_valid = false, c->yrec_valid = false;
 	if (n_seg <= 0 || N == 0) return 0;
 	const int64_t T = seg_off[n_seg];
 	if (T == 0) return 0;
