@@ -113,6 +113,8 @@ typedef struct {
 	int64_t h3_dom_tie;          /* dominator arg-max tie / subopt-isoform tie at equal (contig, cs) */
 } pga_hazard_t;
 
+#define PGA_HAZARD_CAP 4096
+
 #define PGA_DECLARE(pfx) \
 	/* copy a shard (file order) into backend memory; nothing is computed yet */ \
 	int  pfx##_create(pga_ctx_t **ctx, const pga_shard_t *sh, const pga_params_t *par); \
@@ -202,6 +204,10 @@ typedef struct {
 	/* per-hit state in file order */ \
 	int  pfx##_download(pga_ctx_t *ctx, const pga_hit_state_t *out); \
 	int  pfx##_hazards(pga_ctx_t *ctx, pga_hazard_t *out); \
+	/* where the h2_cm_tie / h3_dom_tie events of the run happened: up to cap contig-segment ids (position of the contig in \
+	 * the shard's genome-major list of contigs) in segs, one per event, duplicates possible; *n_total = number of events \
+	 * (the backend keeps at most PGA_HAZARD_CAP of them: n_total larger than what was returned = list incomplete) */ \
+	int  pfx##_hazard_segs(pga_ctx_t *ctx, int32_t *segs, int32_t cap, int64_t *n_total); \
 	/* 1 if `**` pointers are device memory (exchange must use the device collective) */ \
 	int  pfx##_is_device(void); \
 	const char *pfx##_strerror(int code);
@@ -243,6 +249,7 @@ typedef struct {
 	int  (*timing_get)(pga_ctx_t *, int32_t, double *, int64_t *, int64_t *);
 	int  (*sync)(pga_ctx_t *);
 	int  (*fetch_later)(pga_ctx_t *, const void *, size_t, const void **);
+	int  (*hazard_segs)(pga_ctx_t *, int32_t *, int32_t, int64_t *);
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);

@@ -43,6 +43,7 @@ struct pga_ctx {
 	int32_t *max_ori; int64_t *sums;
 	int32_t *vtx_cnt; uint64_t *triples; int64_t n_triples, m_triples;
 	uint64_t *vtx_rec; /* folded (sub, dom) records handed to the driver */
+	int32_t *ctg_base; int32_t hz_seg[PGA_HAZARD_CAP]; int64_t hz_n; /* contig-segment ids of the h2_cm / h3 hazard events */
 	int32_t *g2s; int32_t n_seg;
 	int32_t *seg_cnt; pga_arc_part_t *arcs; int64_t n_arcs, m_arcs;
 	/* rep_pos: per local genome, per gene */
@@ -75,6 +76,8 @@ const char *pgo_strerror(int code)
 /* ---- small helpers ---- */
 
 /* pg_hash_uint32, pgpriv.h:88-97 (the score tie-breaker) */
+static void hz_note(pga_ctx_t *c, int32_t j, int32_t cid) { if (c->hz_n < PGA_HAZARD_CAP) c->hz_seg[c->hz_n] = c->ctg_base[j] + cid; c->hz_n++; }
+
 static inline uint32_t hash32(uint32_t key)
 {
 	key += ~(key << 15);
@@ -134,7 +137,7 @@ void pgo_destroy(pga_ctx_t *c)
 	free(c->pid); free(c->gid); free(c->cid); free(c->rank); free(c->score_ori); free(c->score_adj); free(c->score_dom);
 	free(c->n_exon_of); free(c->off_exon); free(c->cs); free(c->ce); free(c->cm); free(c->cds);
 	free(c->pid_dom); free(c->pid_dom0); free(c->flags); free(c->yo); free(c->exon_os); free(c->exon_oe);
-	free(c->prot_gid); free(c->gene_pref); free(c->max_ori); free(c->sums); free(c->vtx_cnt); free(c->triples); free(c->vtx_rec);
+	free(c->prot_gid); free(c->gene_pref); free(c->max_ori); free(c->sums); free(c->vtx_cnt); free(c->triples); free(c->vtx_rec); free(c->ctg_base);
 	free(c->g2s); free(c->seg_cnt); free(c->arcs); free(c->rp_x); free(c->rp_y); free(c->nl_cnt); free(c->scratch); free(c->head);
 	free(c->br_x); free(c->br_s1); free(c->br_gid); free(c->br_pairs); free(c->br_weak);
 	free(c->r_pid); free(c->r_cid); free(c->r_rank); free(c->r_sori); free(c->r_sadj); free(c->r_nex); free(c->r_offx); free(c->r_cs); free(c->r_ce); free(c->r_cm); free(c->r_rev);
@@ -155,6 +158,7 @@ int pgo_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
 	DUP(int64_t, c->off, sh->hit_off, sh->n_genome + 1);
 	DUP(int32_t, c->genome_global, sh->genome_global, sh->n_genome);
 	DUP(int32_t, c->n_ctg, sh->n_ctg, sh->n_genome);
+	{ int32_t g; c->ctg_base = CALLOC(int32_t, sh->n_genome + 1); for (g = 0; g < sh->n_genome; ++g) c->ctg_base[g + 1] = c->ctg_base[g] + sh->n_ctg[g]; }
 	DUP(int32_t, c->exon_os, sh->exon_os, sh->n_exon); DUP(int32_t, c->exon_oe, sh->exon_oe, sh->n_exon);
 	DUP(int32_t, c->prot_gid, sh->prot_gid, sh->n_prot); DUP(uint8_t, c->gene_pref, sh->gene_pref, sh->n_gene);
 	DUP(int32_t, c->r_pid, sh->pid, N); DUP(int32_t, c->r_cid, sh->cid, N); DUP(int32_t, c->r_rank, sh->rank, N);
@@ -184,6 +188,7 @@ int pgo_begin(pga_ctx_t *c)
 	int32_t j;
 	skey_t *key = MALLOC(skey_t, N);
 	memset(&c->hz, 0, sizeof(c->hz));
+	c->hz_n = 0;
 	for (j = 0; j < c->n_genome; ++j) c->head[j] = c->off[j];
 	for (i = 0; i < c->n_gene; ++i) c->g2s[i] = -1;
 	c->n_seg = 0;
@@ -280,11 +285,11 @@ static int32_t shadow_genome(pga_ctx_t *c, int32_t j, int cal_dom_sc, int32_t *n
 			else sh = 1;
 			if (sh == 0) { /* overlap.c:148-154 */
 				c->flags[i] |= PGA_F_SHADOW;
-				if (tmp[i - st].score == sj && sj > 0) c->hz.h3_dom_tie++;
+				if (tmp[i - st].score == sj && sj > 0) { c->hz.h3_dom_tie++; hz_note(c, j, c->cid[i]); }
 				if (tmp[i - st].score < sj) tmp[i - st].score = sj, tmp[i - st].aid = jj, tmp[i - st].ov_len = x;
 			} else {
 				c->flags[jj] |= PGA_F_SHADOW;
-				if (tmp[jj - st].score == si && si > 0) c->hz.h3_dom_tie++;
+				if (tmp[jj - st].score == si && si > 0) { c->hz.h3_dom_tie++; hz_note(c, j, c->cid[jj]); }
 				if (tmp[jj - st].score < si) tmp[jj - st].score = si, tmp[jj - st].aid = i, tmp[jj - st].ov_len = x;
 			}
 		}
@@ -840,7 +845,7 @@ int pgo_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_w, int
 			if (c->flags[a] & (PGA_F_FLT | PGA_F_SHADOW)) continue;
 			sid = c->g2s[c->gid[a]];
 			if (vi >= 0 && c->cid[a] != c->cid[vi]) v = (uint32_t)-1;
-			if (vi >= 0 && c->cid[a] == c->cid[vi] && c->cm[a] == c->cm[vi]) c->hz.h2_cm_tie++;
+			if (vi >= 0 && c->cid[a] == c->cid[vi] && c->cm[a] == c->cm[vi]) { c->hz.h2_cm_tie++; hz_note(c, j, c->cid[a]); }
 			w = (uint32_t)sid << 1 | (c->flags[a] & PGA_F_REV ? 1 : 0);
 			if (v != (uint32_t)-1) {
 				e = arc_weak(arc_x, arc_w, n_arc, (uint64_t)v << 32 | w);
@@ -955,13 +960,21 @@ int pgo_download(pga_ctx_t *c, const pga_hit_state_t *o)
 }
 
 int pgo_hazards(pga_ctx_t *c, pga_hazard_t *out) { *out = c->hz; return PGA_OK; }
+int pgo_hazard_segs(pga_ctx_t *c, int32_t *segs, int32_t cap, int64_t *n_total)
+{
+	int64_t n = c->hz_n < PGA_HAZARD_CAP ? c->hz_n : PGA_HAZARD_CAP;
+	if (n > cap) n = cap;
+	if (n > 0) memcpy(segs, c->hz_seg, (size_t)n * sizeof(int32_t));
+	*n_total = c->hz_n;
+	return PGA_OK;
+}
 
 const pga_backend_t *pgo_backend(void)
 {
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
 		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_arc_merge, pgo_arc_set_current, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
-		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later
+		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs
 	};
 	return &b;
 }

@@ -56,7 +56,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC, S_SLOW,
+	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST,
 	S_COUNT
 };
 
@@ -297,6 +297,13 @@ __global__ __launch_bounds__(BLOCK) void k_pack_rec(const int32_t *seg, const in
 	C[h] = make_int4(rank[h], nex[h], offx[h], sori[h]);
 }
 
+// where a tie-order hazard (h2_cm_tie / h3_dom_tie) happened: contig-segment ids, at most PGA_HAZARD_CAP of them (counter: dcnt[14])
+__device__ __forceinline__ void hz_note(int64_t *cnt14, int32_t *list, int seg)
+{
+	const unsigned long long at = atomicAdd((unsigned long long *)cnt14, 1ull);
+	if (at < (unsigned long long)PGA_HAZARD_CAP) list[at] = seg;
+}
+
 struct SweepView {
 	const int4 *A, *B, *C; const int2 *exon;
 	uint32_t *flags; int32_t *pdom, *sdom;
@@ -305,6 +312,7 @@ struct SweepView {
 	int64_t *hz;
 	int64_t *slow_cnt; int32_t *slow_list; // work list for k_sweep_slow
 	long long *prof; // PGA_SW_PROFILE builds only
+	int32_t *hz_list; // hz[10] (= dcnt[14]) counts its entries
 };
 
 // CDS intersection of hit a (exons ea[na], start ca) and hit b: pg_hit_overlap, overlap.c:6-42
@@ -375,7 +383,7 @@ __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBe
 	// dominator = best-scoring winner, first in array order on ties (overlap.c:150,153).  Earlier partners are visited in
 	// DEscending index order, so an equal score replaces; later partners in ascending order, so it does not.
 	const bool upd = t_loses && (EARLIER ? (sp > 0 && sp >= r.best) : (sp > r.best));
-	if (t_loses && sp == r.best && sp > 0) atomicAdd((unsigned long long *)&v.hz[3], 1ull); // hazard H3, rare
+	if (t_loses && sp == r.best && sp > 0) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, t.sg); } // hazard H3, rare
 	r.best = upd ? sp : r.best, r.j = upd ? pi : r.j, r.ov = upd ? x : r.ov, r.pid = upd ? b.w : r.pid, r.cds = upd ? b.z : r.cds;
 }
 
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 				const uint32_t rw = (uint32_t)(i_loses ? bj.x : bi.x);
 				const unsigned long long key = (unsigned long long)rw << 32 | 0x80000000u | (uint32_t)(1023 - W);
 				const unsigned long long old = atomicMax(&sKey[Lt], key);
-				if (MODE != 2 && rw != 0 && (uint32_t)(old >> 32) == rw) atomicAdd((unsigned long long *)&v.hz[3], 1ull); // hazard H3: two winners with one key
+				if (MODE != 2 && rw != 0 && (uint32_t)(old >> 32) == rw) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, sA[L].y); } // hazard H3: two winners with one key
 			}
 		}
 		wave_sync();
@@ -922,7 +930,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_yrec(const int32_t *yperm, const
 // has_arc[y] = 1 if walkable y has a walkable predecessor on the same contig; also per-segment counts
 // (graph.c:113,125-126) and hazard H2a (equal cm of two consecutive walkable hits)
 __global__ __launch_bounds__(BLOCK) void k_arc_flag(const int32_t *val, const int32_t *prev, const int4 *YA, const int32_t *g2s, int n, int S, int32_t *has, int32_t *seg_cnt,
-                                                      uint32_t *seen, int64_t words_per_genome, int64_t *dcnt)
+                                                      uint32_t *seen, int64_t words_per_genome, int64_t *dcnt, int32_t *hz_list)
 {
 	int y = blockIdx.x * BLOCK + threadIdx.x;
 	if (y >= n) return;
@@ -942,7 +950,7 @@ __global__ __launch_bounds__(BLOCK) void k_arc_flag(const int32_t *val, const in
 			const int4 rb = YA[p];
 			if (rb.x == ra.x) {
 				out = 1;
-				if (rb.w == ra.w) atomicAdd((unsigned long long *)&dcnt[5], 1ull);
+				if (rb.w == ra.w) { atomicAdd((unsigned long long *)&dcnt[5], 1ull); hz_note(&dcnt[14], hz_list, ra.x); }
 			}
 		}
 	}
@@ -1505,7 +1513,8 @@ static int make_sweep_view(pga_ctx *c, SweepView *v)
 	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
 	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4, v->stage_c = c->any_multi;
 	v->slow_cnt = nullptr, v->slow_list = (int32_t *)c->pool.get(S_SLOW, sizeof(int32_t) * (size_t)c->N);
-	if (!v->slow_list) return PGA_ERR_NOMEM;
+	v->hz_list = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
+	if (!v->slow_list || !v->hz_list) return PGA_ERR_NOMEM;
 	return 0;
 }
 
@@ -1950,7 +1959,7 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	if (!seen || !has || !slot) return PGA_ERR_NOMEM;
 	zero_multi(c, seen, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, seg_cnt, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES);
 	ensure_yrec(c);
-	hipLaunchKernelGGL(k_arc_flag, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yrecA, c->g2s, N, S, has, seg_cnt, seen, wpg, c->dcnt);
+	hipLaunchKernelGGL(k_arc_flag, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yrecA, c->g2s, N, S, has, seg_cnt, seen, wpg, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP));
 	if (S) hipLaunchKernelGGL(k_segcnt_sum, dim3(nblk(2 * S)), dim3(BLOCK), 0, c->st, seg_cnt, 2 * S);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 	device_scan<I32>(InI32{has}, OutExclI32{slot}, N, tile, OpSum{}, I32{0}, c->st);
@@ -2234,6 +2243,17 @@ extern "C" int pga_set_head(pga_ctx_t *c, const int32_t *head_file)
 	return sync_st(c); // head_file is caller memory
 }
 
+extern "C" int pga_hazard_segs(pga_ctx_t *c, int32_t *segs, int32_t cap, int64_t *n_total)
+{
+	hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
+	TRY(sync_st(c));
+	*n_total = c->h_cnt[14];
+	int64_t n = std::min<int64_t>(std::min<int64_t>(*n_total, PGA_HAZARD_CAP), cap);
+	const int32_t *list = (const int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
+	if (n > 0 && list) { HIPCHK(hipMemcpyAsync(segs, list, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->st)); TRY(sync_st(c)); }
+	return 0;
+}
+
 extern "C" int pga_sync(pga_ctx_t *c) { return sync_st(c); }
 
 extern "C" int pga_fetch_later(pga_ctx_t *c, const void *src_backend, size_t nbytes, const void **host_view)
@@ -2333,7 +2353,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs
 	};
 	return &b;
 }

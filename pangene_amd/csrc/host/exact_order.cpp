@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <climits>
 #include <thread>
 #include "pg_internal.hpp"
 #include "ksort_exact.hpp"
@@ -60,22 +62,36 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 			for (int32_t h = 0; h < g->n_hit; ++h) host_of_file[(size_t)ext->file_of_host[(size_t)j][(size_t)h]] = h;
 		else
 			for (int32_t h = 0; h < g->n_hit; ++h) host_of_file[(size_t)h] = h;
+		// contigs that get the full treatment although the mode is auto (tie hazards seen there in a previous attempt)
+		std::vector<int32_t> extra;
+		if (mode == 1) {
+			auto lo = std::lower_bound(ext->extra_ctgs.begin(), ext->extra_ctgs.end(), std::make_pair((int32_t)k, (int32_t)INT32_MIN));
+			for (; lo != ext->extra_ctgs.end() && lo->first == (int32_t)k; ++lo) extra.push_back(lo->second);
+		}
+		// file indices grouped by contig, file order inside a contig (one pass; a contig's hits are then contiguous)
+		const bool every = mode == 2 || !extra.empty();
+		std::vector<int32_t> by_ctg((size_t)g->n_hit), cur(cnt.begin(), cnt.end() - 1);
+		for (int32_t i = 0; i < g->n_hit; ++i) {
+			const int32_t c = g->hit[host_of_file[(size_t)i]].cid;
+			if (every || c == c0) by_ctg[(size_t)cur[(size_t)c]++] = i;
+		}
 		for (int32_t c = c0; c < g->n_ctg; ++c) {
+			const bool full = mode == 2 || std::binary_search(extra.begin(), extra.end(), c);
+			if (!full && c != c0) { if (extra.empty()) break; else continue; } // auto only ever looks at the first non-empty contig
 			const int32_t n = cnt[(size_t)c + 1] - cnt[(size_t)c];
-			if (n < 2) { if (mode == 1) break; else continue; }
+			if (n < 2) continue;
 			ExactSeg s;
-			s.k = (int32_t)k, s.start = cnt[(size_t)c];
-			s.file.reserve((size_t)n);
+			s.k = (int32_t)k, s.start = cnt[(size_t)c], s.full = full;
+			s.file.reserve((size_t)n), s.cs.reserve((size_t)n), s.cm.reserve((size_t)n);
 			int64_t min_cs = INT64_MAX; int32_t n_min = 0;
-			for (int32_t i = 0; i < g->n_hit; ++i) {
+			for (int32_t t = cnt[(size_t)c]; t < cnt[(size_t)c + 1]; ++t) {
+				const int32_t i = by_ctg[(size_t)t];
 				const pg_hit_t *a = &g->hit[host_of_file[(size_t)i]];
-				if (a->cid != c) continue;
 				s.file.push_back(i), s.cs.push_back((uint64_t)a->cs), s.cm.push_back((uint64_t)a->cm);
 				if (a->cs < min_cs) min_cs = a->cs, n_min = 1; else if (a->cs == min_cs) ++n_min;
 			}
-			if (mode == 1 && n_min < 2) break;  // auto: only the index-0 channel, i.e. a leading tie group on the first contig
+			if (!full && n_min < 2) continue;  // auto: only the index-0 channel, i.e. a leading tie group on the first contig
 			ext->xsegs.push_back(std::move(s));
-			if (mode == 1) break;
 		}
 	}
 }
@@ -151,7 +167,7 @@ void exact_begin(DataExt *ext)
 			for (;;) {
 				size_t i = ext->xnext.fetch_add(1);
 				if (i >= ext->xsegs.size()) break;
-				replay(ext->xsegs[i], all);
+				replay(ext->xsegs[i], all || ext->xsegs[i].full);
 			}
 		});
 }
@@ -162,18 +178,21 @@ int exact_sort(DataExt *ext, int by_cm)
 	if (ext->xsegs.empty()) return 0;
 	exact_wait(ext);
 	const int t = ++ext->x_sorts[by_cm];
-	if (exact_mode() != 2) { // auto: only the identity of the hit at array index 0 matters, and only for the cs order
-		if (by_cm) return 0;
+	// contigs tracked for the index-0 channel only (mode auto): the identity of the hit at array index 0, cs order only
+	if (!by_cm) {
 		bool changed = false;
 		for (ExactSeg &s : ext->xsegs) {
+			if (s.full) continue;
 			const int32_t h = s.heads[order_index(s, t, s.heads.size())];
 			if (ext->head_file[(size_t)s.k] != h) ext->head_file[(size_t)s.k] = h, changed = true;
 		}
-		return changed ? ext->be->set_head(ext->ctx, ext->head_file.data()) : 0;
+		if (changed) { const int rc = ext->be->set_head(ext->ctx, ext->head_file.data()); if (rc) return rc; }
 	}
+	// fully tracked contigs: the whole order
 	std::vector<int32_t> sg, ss, fi;
 	std::vector<int64_t> so(1, 0);
 	for (ExactSeg &s : ext->xsegs) {
+		if (!s.full) continue;
 		const std::vector<std::vector<int32_t>> &h = by_cm ? s.hy : s.hx;
 		if (h.empty()) continue;
 		const std::vector<int32_t> &ord = h[order_index(s, t, h.size())];

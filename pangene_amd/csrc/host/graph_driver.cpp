@@ -243,6 +243,15 @@ int sync_host(pg_data_t *d, bool full)
 	return 0;
 }
 
+// Fully tracked contigs need their exact S1 order from stage A on (first-wins ties); the index-0 channel alone only
+// matters from stage C on, so its hand-over (and the wait for the background replay) is deferred to pg_graph_gen then.
+static bool exact_early(const DataExt *ext)
+{
+	if (exact_mode() == 2) return true;
+	for (const ExactSeg &s : ext->xsegs) if (s.full) return true;
+	return false;
+}
+
 // ---------------------------------------------------------------------------------------------
 // stage A + B
 // ---------------------------------------------------------------------------------------------
@@ -270,7 +279,7 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 	// pg_hit_sort(g, 0), read.c:247.  Mode "all" needs the exact S1 order for stage A (first-wins ties); in mode "auto"
 	// only array index 0 matters and it is inert while every shadow flag is 0 (read.c:252, i.e. until the sweep of
 	// round 1), so the hand-over waits until pg_graph_gen and the replay overlaps stages A and B.
-	if (exact_mode() == 2) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); }
+	if (exact_early(ext)) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); }
 	const int32_t nl = (int32_t)ext->local_genomes.size(), P = d->n_prot;
 	if (pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] %d genes and %d proteins; %ld hits of %d genomes on backend '%s'\n", __func__, stamp(),
@@ -606,7 +615,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	// graph 1: initial vertices (graph.c:284-291)
 	BE_CALL(be->set_filter(ctx, PGA_FLT_PSEUDO), "set_filter");
 	BE_CALL(gen_vtx(opt, q, ext), "gen_vtx");
-	if (exact_mode() != 2) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "set_head"); } // index 0 of the S1 order, needed from the first sweep of stage C on (see post_process_impl)
+	if (!exact_early(ext)) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "set_head"); } // index 0 of the S1 order, needed from the first sweep of stage C on (see post_process_impl)
 	BE_CALL(flag_vtx(q, ext), "flag_vtx");
 	BE_CALL(be->set_filter(ctx, PGA_FLT_VTX0), "set_filter");
 	BE_CALL(gen_arc(opt, q, ext), "gen_arc");
@@ -695,21 +704,45 @@ pg_graph_t *pg_graph_init(pg_data_t *d) // graph.c:34-41
 
 // Did a tie-order channel other than array index 0 open during the run (two walkable hits sharing
 // (contig, cm); two equal-score dominators)?  Collective: every rank gets the same answer.
-static int hazards_seen(DataExt *ext, bool *seen)
+// Tie-order hazards of the run that just finished (mode auto).  *need: some event happened on a contig that does not follow
+// the reference's exact order yet (collective answer when sharded); *give_up: the event list is incomplete somewhere.  The
+// contigs concerned are added to ext->extra_ctgs.
+static int hazards_review(DataExt *ext, bool *need, bool *give_up)
 {
 	pga_hazard_t hz;
 	BE_CALL(ext->be->hazards(ext->ctx, &hz), "hazards");
-	int64_t n = hz.h2_cm_tie + hz.h3_dom_tie;
+	int32_t flags[2] = { 0, 0 }; // {need, give up}
+	if (hz.h2_cm_tie + hz.h3_dom_tie > 0) {
+		std::vector<int32_t> segs(PGA_HAZARD_CAP);
+		int64_t n_total = 0;
+		BE_CALL(ext->be->hazard_segs(ext->ctx, segs.data(), (int32_t)segs.size(), &n_total), "hazard_segs");
+		const int64_t n_got = std::min<int64_t>(n_total, (int64_t)segs.size());
+		if (n_total > n_got) flags[0] = flags[1] = 1;
+		// contig-segment id -> (local genome, contig): the shard lists the contigs genome-major
+		std::vector<int32_t> base(ext->local_genomes.size() + 1, 0);
+		for (size_t k = 0; k < ext->local_genomes.size(); ++k) base[k + 1] = base[k] + ext->q_d->genome[ext->local_genomes[k]].n_ctg;
+		std::sort(segs.begin(), segs.begin() + n_got);
+		int64_t n_new = 0;
+		for (int64_t i = 0; i < n_got; ++i) {
+			if (i && segs[(size_t)i] == segs[(size_t)i - 1]) continue;
+			const size_t k = (size_t)(std::upper_bound(base.begin(), base.end(), segs[(size_t)i]) - base.begin()) - 1;
+			const std::pair<int32_t, int32_t> gc((int32_t)k, segs[(size_t)i] - base[k]);
+			auto it = std::lower_bound(ext->extra_ctgs.begin(), ext->extra_ctgs.end(), gc);
+			if (it == ext->extra_ctgs.end() || *it != gc) ext->extra_ctgs.insert(it, gc), ++n_new;
+		}
+		if (n_new) flags[0] = 1;
+		if (pg_verbose >= 2)
+			std::fprintf(stderr, "[M::%s::%s] tie-order hazards on this rank: %ld equal-cm neighbours, %ld equal-key dominators, on %ld contig(s) not yet following the exact order\n",
+			             "pg_graph_gen", stamp(), (long)hz.h2_cm_tie, (long)hz.h3_dom_tie, (long)n_new);
+	}
 	if (sharded()) {
 		void *scr;
-		int32_t v = n > 0;
 		BE_CALL(ext->be->scratch(ext->ctx, 16, &scr), "scratch");
-		BE_CALL(ext->be->put(ext->ctx, scr, &v, sizeof(v)), "put");
-		BE_CALL(xreduce(ext->be, ext->ctx, scr, 1, PG_X_I32, PG_X_MAX), "allreduce(hazard)");
-		BE_CALL(ext->be->fetch(ext->ctx, &v, scr, sizeof(v)), "fetch");
-		n = v;
+		BE_CALL(ext->be->put(ext->ctx, scr, flags, sizeof(flags)), "put");
+		BE_CALL(xreduce(ext->be, ext->ctx, scr, 2, PG_X_I32, PG_X_MAX), "allreduce(hazard)");
+		BE_CALL(ext->be->fetch(ext->ctx, flags, scr, sizeof(flags)), "fetch");
 	}
-	*seen = n > 0;
+	*need = flags[0] != 0, *give_up = flags[1] != 0;
 	return 0;
 }
 
@@ -718,20 +751,31 @@ void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 	double t = now_sec();
 	if (g_err == 0 && graph_gen_impl(opt, q) != 0) q->n_arc = 0;
 	DataExt *ext = ext_of(q->d, false);
-	bool seen = false;
-	if (g_err == 0 && ext && exact_mode() == 1 && hazards_seen(ext, &seen) == 0 && seen) {
-		// The canonical order is only guaranteed to reproduce the reference when no such tie occurred: repeat the run on
-		// the resident shard with the reference's exact order replayed for EVERY contig (mode "all").
+	if (ext) ext->q_d = q->d;
+	// Mode auto: the canonical order provably gives the reference's result unless a tie-order hazard occurred.  Where one
+	// did, the contigs concerned get the reference's exact order (replayed on the host) and stages A-C are repeated on the
+	// resident shard; hazards that then only occur on such contigs are harmless.  After three attempts, or when the event
+	// list overflowed, every contig is tracked (mode "all").  The decision is collective when sharded.
+	for (int attempt = 0; g_err == 0 && ext && exact_mode() == 1; ++attempt) {
+		bool need = false, give_up = false;
+		if (hazards_review(ext, &need, &give_up) != 0 || !need) break;
+		const bool all = give_up || attempt >= 2;
 		if (pg_verbose >= 2)
-			std::fprintf(stderr, "[M::%s::%s] tie-order hazard seen: repeating stages A-C with the reference's exact hit order on every contig\n", __func__, stamp());
-		exact_override(2);
+			std::fprintf(stderr, "[M::%s::%s] repeating stages A-C with the reference's exact hit order on %s\n", __func__, stamp(),
+			             all ? "every contig" : "the contigs where the ties occurred");
+		if (all) exact_override(2);
+		exact_shutdown(ext);
+		exact_init(q->d, ext), ext->exact_mode_of_segs = exact_mode();
 		q->n_seg = 0, q->n_arc = 0;
 		std::memset((void *)q->seg, 0, sizeof(pg_seg_t) * (size_t)q->m_seg);
 		ext->rerun = true;
 		if (post_process_impl(opt, q->d) != 0 || graph_gen_impl(opt, q) != 0) q->n_arc = 0;
-		exact_override(-1);
+		if (all) { exact_override(-1); break; }
+	}
+	if (ext && (!ext->extra_ctgs.empty() || ext->exact_mode_of_segs != exact_mode())) { // back to the cheap tracking for a later rerun
+		ext->extra_ctgs.clear();
 		exact_shutdown(ext);
-		exact_init(q->d, ext), ext->exact_mode_of_segs = exact_mode(); // back to the cheap tracking for a later rerun
+		exact_init(q->d, ext), ext->exact_mode_of_segs = exact_mode();
 	}
 	if (ext && !ext->vtx_sel_text.empty()) {
 		std::fwrite(ext->vtx_sel_text.data(), 1, ext->vtx_sel_text.size(), out_stream());

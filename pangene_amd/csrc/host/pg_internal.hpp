@@ -48,6 +48,7 @@ struct ExactSeg {
 	std::vector<int32_t> heads;           // file index of the hit at array index 0 of X_1, X_2, ...
 	int cyc_start = -1, period = 0;       // X_t == X_{cyc_start + (t - cyc_start) % period} for t >= cyc_start (1-based)
 	std::vector<int32_t> pushed[2];       // order the backend currently holds for cs (0) and cm (1)
+	bool full = false;                    // every order of the contig is replayed and handed over (mode all, or a contig on which a tie hazard was seen)
 };
 
 // host-private companion of a pg_data_t (struct layout of pg_data_t itself must not change)
@@ -64,6 +65,8 @@ struct DataExt {
 	const pga_arc_part_t *cur_arcs = nullptr; // the round's arc table, in backend memory
 	std::string vtx_sel_text;          // -G output of the current run (printed when pg_graph_gen returns)
 	int exact_mode_of_segs = -1;       // mode xsegs was built for
+	const pg_data_t *q_d = nullptr;    // the data set the context belongs to
+	std::vector<std::pair<int32_t, int32_t>> extra_ctgs; // (local genome, contig) pairs that get the full exact order although the mode is auto (sorted)
 	std::vector<std::thread> xworkers; // background replay of the reference's sort sequence
 	std::atomic<size_t> xnext{0};
 	int x_sorts[2] = {0, 0};           // cs / cm sorts of the reference seen so far in this run

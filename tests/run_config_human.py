@@ -23,8 +23,10 @@ C.c_int.in_dll(lib, "pg_verbose").value = 1
 t0 = time.time(); out = capi.run(lib, files, opts); t_hip = time.time() - t0
 path_s, hits = lib.pg_last_path_seconds(), lib.pg_last_path_hits()
 t0 = time.time(); out2 = capi.run(lib, files, opts); t_hip2 = time.time() - t0
+ph = (C.c_double * 16)(); nph = lib.pg_phase_times(ph, 16)
+phases = {lib.pg_phase_name(i).decode(): round(ph[i] * 1e3, 2) for i in range(nph)}
 res = {"G": G, "Q": Q, "iso": iso, "opts": opts, "hits": hits, "gen_s": round(t_gen, 1), "hip_total_s": round(t_hip, 2), "hip_path_ms": round(path_s * 1e3, 1),
-       "hip_path_ms_2nd": round(lib.pg_last_path_seconds() * 1e3, 1), "hip_md5": hashlib.md5(out).hexdigest(), "rerun_identical": out == out2}
+       "hip_path_ms_2nd": round(lib.pg_last_path_seconds() * 1e3, 1), "hip_md5": hashlib.md5(out).hexdigest(), "rerun_identical": out == out2, "host_phases_ms_2nd": phases}
 ref = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
 if os.path.exists(ref):
     t0 = time.time(); r = subprocess.run([ref] + opts + files, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL); t_ref = time.time() - t0
