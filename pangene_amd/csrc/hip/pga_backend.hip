@@ -452,14 +452,14 @@ __device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl
 template <int MODE, bool STAGE_C>
 __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 {
-	static_assert(2 * SW_HALO == 64 && SW_NW == 4 && SW_LDS <= 1024, "the slots past SW_TILE are staged one array per wave; slot ids are packed in 10 bits");
+	static_assert(2 * SW_HALO == 64 && SW_NW == 4 && SW_LDS <= 1024 && 64 + 2 * SW_HALO <= 128, "the slots past SW_TILE are staged one array per wave; window-relative slot ids are packed in 7 bits, winner slots in 10");
 	static_assert(MODE != 1 || STAGE_C, "score_dom needs score_ori, which lives in the C records");
 	__shared__ int4 sA[SW_LDS + 4], sB[SW_LDS], sC[STAGE_C ? SW_LDS : 1]; // sA: four sentinel slots close the array
 	__shared__ uint32_t sF[SW_LDS];
-	__shared__ uint32_t sPairAll[SW_NW][SW_WCAP];
+	__shared__ uint16_t sPairAll[SW_NW][SW_WCAP]; // (earlier slot - window start) << 7 | (later slot - first own slot): both < 96
 	__shared__ unsigned long long sKeyAll[SW_NW][64];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	uint32_t *sPair = sPairAll[wave];
+	uint16_t *sPair = sPairAll[wave];
 	unsigned long long *sKey = sKeyAll[wave];
 	const int tile = blockIdx.x, base = tile * SW_TILE - SW_HALO;
 	SW_STAMP(0);
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 		const unsigned long long mk = __ballot(c0 > k);
 		if (mk == 0) break;
 		const int at = tot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-		if (c0 > k && at < SW_WCAP) sPair[at] = (uint32_t)l0 << 10 | (uint32_t)(lo + k);
+		if (c0 > k && at < SW_WCAP) sPair[at] = (uint16_t)((lane & (SW_HALO - 1)) << 7 | k);
 		tot += __popcll(mk);
 	}
 #pragma nounroll
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 		const unsigned long long mk = __ballot(c1 > k);
 		if (mk == 0) break;
 		const int at = tot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-		if (c1 > k && at < SW_WCAP) sPair[at] = (uint32_t)l1 << 10 | (uint32_t)(l1 + 1 + k);
+		if (c1 > k && at < SW_WCAP) sPair[at] = (uint16_t)((SW_HALO + lane) << 7 | (lane + 1 + k));
 		tot += __popcll(mk);
 	}
 	const bool listed = tot <= SW_WCAP; // wave-uniform
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 		// one pair per lane: slot l precedes slot m in the array (l is "j", m is "i" of overlap.c:126-154 / 76-87)
 		for (int p = lane; p < tot; p += 64) {
 			const uint32_t w = sPair[p];
-			const int l = (int)(w >> 10), m = (int)(w & 1023u);
+			const int l = lo - SW_HALO + (int)(w >> 7), m = lo + (int)(w & 127u);
 			const uint32_t fj = sF[l], fi = sF[m];
 			const int csj = sA[l].x, cej = sA[l].z, csi = sA[m].x, cei = sA[m].z;
 			const int4 bj = sB[l], bi = sB[m]; // {rk, gid, cds, pid}
