@@ -195,7 +195,7 @@ def main():
     if nl.value:
         avg_ms = ms.value / nl.value
         ach = bytes_per_hit * (units.value / nl.value) / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_sweep<1, true> (pg_shadow cal_dom_sc=1, stage A)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": "k_sweep<1, false> (pg_shadow cal_dom_sc=1, stage A; the flavour for shards without multi-exon hits)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(units.value // nl.value), "avg_launch_ms": round(avg_ms, 4), "launches": nl.value,
                 "timing": "per-dispatch HIP start/stop events (hipExtLaunchKernelGGL) on the library's stream",
                 "algorithmic_bytes_per_hit": bytes_per_hit, "hits_per_launch": units.value // nl.value}

@@ -305,7 +305,7 @@ __device__ __forceinline__ void hz_note(int64_t *cnt14, int32_t *list, int seg)
 }
 
 struct SweepView {
-	const int4 *A, *B, *C; const int2 *exon;
+	const int4 *A, *B, *C; const int32_t *sori; const int2 *exon;
 	uint32_t *flags; int32_t *pdom, *sdom;
 	int n; double min_ov; int check_strand;
 	int stage_c; // some hit of the shard has several exons: stage the C records with the others
@@ -453,9 +453,10 @@ template <int MODE, bool STAGE_C>
 __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 {
 	static_assert(2 * SW_HALO == 64 && SW_NW == 4 && SW_LDS <= 1024 && 64 + 2 * SW_HALO <= 128, "the slots past SW_TILE are staged one array per wave; window-relative slot ids are packed in 7 bits, winner slots in 10");
-	static_assert(MODE != 1 || STAGE_C, "score_dom needs score_ori, which lives in the C records");
+	constexpr bool STAGE_ORI = MODE == 1 && !STAGE_C; // score_dom needs score_ori: out of the C records when they are staged, else staged alone
 	__shared__ int4 sA[SW_LDS + 4], sB[SW_LDS], sC[STAGE_C ? SW_LDS : 1]; // sA: four sentinel slots close the array
 	__shared__ uint32_t sF[SW_LDS];
+	__shared__ int32_t sOri[STAGE_ORI ? SW_LDS : 1];
 	__shared__ uint16_t sPairAll[SW_NW][SW_WCAP]; // (earlier slot - window start) << 7 | (later slot - first own slot): both < 96
 	__shared__ unsigned long long sKeyAll[SW_NW][64];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -467,9 +468,11 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 		const int g = base + tid;
 		int4 a = make_int4(0, -2, 0, 0), b = make_int4(0, 0, 0, 0), c = b; // slots outside the array: contig -2, filtered
 		uint32_t f = PGA_F_FLT;
+		int32_t so = 0;
 		if (g >= 0 && g < v.n) {
 			a = v.A[g], b = v.B[g], f = v.flags[g];
 			if (STAGE_C) c = v.C[g];
+			if (STAGE_ORI) so = v.sori[g];
 		}
 		// the 2 * SW_HALO slots past SW_TILE: one array per wave, so that no wave has more to stage than the others
 		const int l2 = SW_TILE + lane, g2 = base + l2;
@@ -478,8 +481,10 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 		else if (wave == 1) sB[l2] = in2 ? v.B[g2] : make_int4(0, 0, 0, 0);
 		else if (wave == 2) sF[l2] = in2 ? v.flags[g2] : PGA_F_FLT;
 		else if (STAGE_C) sC[l2] = in2 ? v.C[g2] : make_int4(0, 0, 0, 0);
+		else if (STAGE_ORI) sOri[l2] = in2 ? v.sori[g2] : 0;
 		sA[tid] = a, sB[tid] = b, sF[tid] = f;
 		if (STAGE_C) sC[tid] = c;
+		if (STAGE_ORI) sOri[tid] = so;
 	}
 	if (tid < 4) sA[SW_LDS + tid] = make_int4(0, -2, 0, 0);
 	sKey[lane] = 0;
@@ -606,11 +611,11 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 					const int4 bw = sB[W];
 					pid_w = bw.w, cds_w = bw.z;
 					if (MODE == 1) {
-						const int4 aw = sA[W], cw = sC[W], c2 = sC[lh];
+						const int4 aw = sA[W], cw = STAGE_C ? sC[W] : make_int4(0, 1, 0, sOri[W]), c2 = STAGE_C ? sC[lh] : make_int4(0, 1, 0, sOri[lh]);
 						so_w = cw.w, so_h = c2.w, cds_h = sB[lh].z;
 						const int s0 = aw.x > a.x ? aw.x : a.x, e0 = aw.z < a.z ? aw.z : a.z;
 						ov = e0 > s0 ? e0 - s0 : 0;
-						if ((fl | sF[W]) & F_MULTI) { // the earlier hit goes first, as in the pair evaluation
+						if (STAGE_C && ((fl | sF[W]) & F_MULTI)) { // the earlier hit goes first, as in the pair evaluation
 							const bool wf = W < lh;
 							ov = cds_inter(v.exon, wf ? cw.z : c2.z, wf ? cw.y : c2.y, wf ? aw.x : a.x, wf ? aw.z : a.z,
 							               wf ? c2.z : cw.z, wf ? c2.y : cw.y, wf ? a.x : aw.x, wf ? a.z : aw.z);
@@ -1510,7 +1515,7 @@ static int bits_for(uint32_t maxv) { int b = 1; while (b < 32 && (maxv >> b)) ++
 
 static int make_sweep_view(pga_ctx *c, SweepView *v)
 {
-	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
+	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->sori = c->sori, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
 	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4, v->stage_c = c->any_multi;
 	v->slow_cnt = nullptr, v->slow_list = (int32_t *)c->pool.get(S_SLOW, sizeof(int32_t) * (size_t)c->N);
 	v->hz_list = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
@@ -1547,8 +1552,8 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 		// a timed launch carries its own start/stop events: they take the dispatch's begin and end time stamps, i.e. the
 		// duration of k_sweep itself, the figure rocprofv3 --kernel-trace reports for it
 		hipEvent_t ea = timed && reps == 1 ? t.a : nullptr, eb = timed && reps == 1 ? t.b : nullptr;
-		if (MODE == 1 || c->any_multi) hipExtLaunchKernelGGL((k_sweep<MODE, true>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
-		else hipExtLaunchKernelGGL((k_sweep<MODE, MODE == 1>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
+		if (c->any_multi) hipExtLaunchKernelGGL((k_sweep<MODE, true>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
+		else hipExtLaunchKernelGGL((k_sweep<MODE, false>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
 		hipLaunchKernelGGL((k_sweep_slow<MODE>), dim3(64), dim3(BLOCK), 0, c->st, v, (long long *)(c->dcnt + 12 + ((c->sweep_seq + 1) & 1)));
 		++c->sweep_seq;
 	}

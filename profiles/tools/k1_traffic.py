@@ -12,5 +12,5 @@ for line in open(sys.argv[1]):
 b = json.load(open(sys.argv[2]))
 hits = b["roofline"]["hits_per_launch"]
 tot = int((2 * fetch + write) * 1024)
-print(json.dumps({"kernel": "k_sweep<1, true>", "hits_per_launch": hits, "fetch_kb_raw": fetch, "write_kb": write, "bytes_per_launch": tot,
+print(json.dumps({"kernel": "k_sweep<1, *>", "hits_per_launch": hits, "fetch_kb_raw": fetch, "write_kb": write, "bytes_per_launch": tot,
                   "bytes_per_hit": round(tot / hits, 1), "note": "FETCH_SIZE x2 (gfx950 correction), separate --pmc passes of `python bench.py --no-cpu-baseline`"}))
