@@ -1,0 +1,241 @@
+// k_arcs.hpp -- pg_gen_arc: walk marks, adjacency arcs, two-level collapse, cross-shard merge.
+// Included by pga_backend.hip (one translation unit); uses the context types, BLOCK / WAVE and dev_prims.hpp from there.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// pg_gen_arc, per-genome part (graph.c:97-146)
+// ------------------------------------------------------------------------------------------------
+constexpr int SEGCNT_COPIES = 64;
+__global__ __launch_bounds__(BLOCK) void k_segcnt_sum(int32_t *seg_cnt, int n2s)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n2s) return;
+	int t = 0;
+	for (int k = 0; k < SEGCNT_COPIES; ++k) t += seg_cnt[(int64_t)k * n2s + i];
+	seg_cnt[i] = t;
+}
+
+// walkable = !flt && !shadow; val[y] = y if the y-th hit in cm order is walkable else -1
+__global__ __launch_bounds__(BLOCK) void k_walk_mark(const uint32_t *flags, const int32_t *yperm, int n, int32_t *val)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y >= n) return;
+	val[y] = (flags[yperm[y]] & (PGA_F_FLT | PGA_F_SHADOW)) ? -1 : y;
+}
+
+struct InWalk { const int32_t *val; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{val[i]}; } };
+struct OutPrev { int32_t *prev; __device__ __forceinline__ void operator()(int64_t i, I32, I32 ex) const { prev[i] = ex.v; } };
+
+// Static per-hit fields in Y (cm) order, packed once per run: the arc kernels walk the hits in that order and would otherwise
+// gather every field through yperm.   YA = {seg, gid, genome, cm}   YB = {score_ori, score_dom, gene of pid_dom0's protein
+// (-1: none), X position << 1 | rev}
+__global__ __launch_bounds__(BLOCK) void k_pack_yrec(const int32_t *yperm, const int32_t *seg, const int32_t *gid, const int32_t *gnm, const int32_t *cm,
+                                                       const int32_t *sori, const int32_t *sdom, const int32_t *pdom0, const int32_t *prot_gid, const uint32_t *flags,
+                                                       int n, int4 *YA, int4 *YB)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y >= n) return;
+	const int a = yperm[y], p0 = pdom0[a];
+	YA[y] = make_int4(seg[a], gid[a], gnm[a], cm[a]);
+	YB[y] = make_int4(sori[a], sdom[a], p0 < 0 ? -1 : prot_gid[p0], a << 1 | (flags[a] & PGA_F_REV ? 1 : 0));
+}
+
+// has_arc[y] = 1 if walkable y has a walkable predecessor on the same contig; also per-segment counts
+// (graph.c:113,125-126) and hazard H2a (equal cm of two consecutive walkable hits)
+__global__ __launch_bounds__(BLOCK) void k_arc_flag(const int32_t *val, const int32_t *prev, const int4 *YA, const int32_t *g2s, int n, int S, int32_t *has, int32_t *seg_cnt,
+                                                      uint32_t *seen, int64_t words_per_genome, int64_t *dcnt, int32_t *hz_list)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y >= n) return;
+	int out = 0;
+	if (val[y] >= 0) {
+		const int4 ra = YA[y];
+		const int sid = g2s[ra.y];
+		if (sid < 0) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // graph.c:111
+		else {
+			int32_t *copy = seg_cnt + (int64_t)(blockIdx.x & (SEGCNT_COPIES - 1)) * 2 * S; // 64 copies: 64x less contention per address
+			atomicAdd(&copy[S + sid], 1);
+			uint32_t old = atomicOr(&seen[(int64_t)ra.z * words_per_genome + (sid >> 5)], 1u << (sid & 31));
+			if (!(old >> (sid & 31) & 1u)) atomicAdd(&copy[sid], 1);
+		}
+		const int p = prev[y];
+		if (p >= 0) {
+			const int4 rb = YA[p];
+			if (rb.x == ra.x) {
+				out = 1;
+				if (rb.w == ra.w) { atomicAdd((unsigned long long *)&dcnt[5], 1ull); hz_note(&dcnt[14], hz_list, ra.x); }
+			}
+		}
+	}
+	has[y] = out;
+}
+
+__device__ __forceinline__ int arc_score(const int4 yb, int ori, const int32_t *g2s)
+{ // pg_get_score, graph.c:82-85: score_ori unless the dominator's gene is not a vertex and score_dom is at least as large
+	return (ori || yb.x > yb.y || yb.z < 0 || g2s[yb.z] >= 0) ? yb.x : yb.y;
+}
+
+struct ArcEmit {
+	const int32_t *has, *slot, *prev; const int4 *YA, *YB; const int32_t *g2s;
+	uint64_t *key; uint32_t *idx; int4 *pay; // payload {dist, s1, s2, genome}
+	int n, ori, vbits;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_arc_emit(ArcEmit e)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y >= e.n || !e.has[y]) return;
+	const int p = e.prev[y];
+	const int4 aA = e.YA[y], bA = e.YA[p], aB = e.YB[y], bB = e.YB[p];
+	uint32_t w = (uint32_t)e.g2s[aA.y] << 1 | (uint32_t)(aB.w & 1);
+	uint32_t v = (uint32_t)e.g2s[bA.y] << 1 | (uint32_t)(bB.w & 1);
+	int sa = arc_score(aB, e.ori, e.g2s);
+	int sb = arc_score(bB, e.ori, e.g2s);
+	int d = aA.w - bA.w, g = aA.z;
+	int64_t o = (int64_t)e.slot[y] * 2;
+	e.key[o] = (uint64_t)v << e.vbits | w;           e.idx[o] = (uint32_t)o;         // v -> w      (graph.c:117)
+	e.pay[o] = make_int4(d, sb, sa, g);
+	e.key[o + 1] = (uint64_t)(w ^ 1) << e.vbits | (v ^ 1); e.idx[o + 1] = (uint32_t)(o + 1); // w^1 -> v^1 (graph.c:119)
+	e.pay[o + 1] = make_int4(d, sa, sb, g);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_arc_gather(const uint32_t *idx, int64_t m, const int4 *pay, int4 *opay)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i < m) opay[i] = pay[idx[i]]; // one random 16-byte read per temp arc
+}
+
+__global__ __launch_bounds__(BLOCK) void k_arc_head(const uint64_t *key, int64_t m, int32_t *head)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= m) return;
+	head[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+}
+
+// Two-level collapse of the sorted temp arcs (graph.c:128-175).  Equal keys are adjacent and, inside one key,
+// grouped by genome (stable sort of a genome-major emission).
+// level 1: the first element of every (key, genome) run collapses its run -- almost always a single element --
+//          into (n, rounded mean dist * n, max s1, max s2) stored at its own position; other positions hold zeros;
+// level 2: one wave per distinct key sums those records over the key's run with coalesced strided reads.
+__global__ __launch_bounds__(BLOCK) void k_arc_l1(const uint64_t *key, int64_t m, const int4 *pay, const int32_t *head, const int32_t *slot, int32_t *run_start,
+                                                    int32_t *o_n, uint64_t *o_dn, int32_t *o_s1, int32_t *o_s2)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= m) return;
+	const uint64_t k = key[i];
+	const int4 p = pay[i];
+	const int g = p.w;
+	if (head[i]) run_start[slot[i]] = (int32_t)i;
+	if (i > 0 && key[i - 1] == k && pay[i - 1].w == g) { o_n[i] = 0, o_dn[i] = 0, o_s1[i] = 0, o_s2[i] = 0; return; }
+	int n = 1, m1 = p.y, m2 = p.z;
+	uint64_t sd = (uint64_t)(int64_t)p.x;
+	for (int64_t j = i + 1; j < m && key[j] == k; ++j) { // almost always empty: one adjacency per (arc, genome)
+		const int4 q = pay[j];
+		if (q.w != g) break;
+		sd += (uint64_t)(int64_t)q.x;
+		m1 = m1 > q.y ? m1 : q.y;
+		m2 = m2 > q.z ? m2 : q.z;
+		++n;
+	}
+	const int dg = (int32_t)((double)sd / n + .499); // graph.c:141
+	o_n[i] = n, o_dn[i] = (uint64_t)(int64_t)dg * (uint64_t)n, o_s1[i] = m1, o_s2[i] = m2;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_arc_l2(const uint64_t *key, int64_t m, int64_t n_run, const int32_t *run_start, const int32_t *c_n, const uint64_t *c_dn,
+                                                    const int32_t *c_s1, const int32_t *c_s2, int vbits, pga_arc_part_t *out)
+{
+	const int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (w >= n_run) return;
+	const int64_t st = run_start[w], en = w + 1 < n_run ? run_start[w + 1] : m;
+	int ng = 0, tot = 0;
+	uint64_t sd = 0;
+	int64_t a1 = 0, a2 = 0;
+	for (int64_t j = st + lane; j < en; j += WAVE) {
+		const int n = c_n[j];
+		ng += n > 0, tot += n, sd += c_dn[j], a1 += c_s1[j], a2 += c_s2[j];
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		ng += __shfl_xor(ng, o, WAVE), tot += __shfl_xor(tot, o, WAVE);
+		sd += (uint64_t)__shfl_xor((long long)sd, o, WAVE), a1 += __shfl_xor((long long)a1, o, WAVE), a2 += __shfl_xor((long long)a2, o, WAVE);
+	}
+	if (lane == 0) {
+		const uint64_t k = key[st];
+		pga_arc_part_t r;
+		r.x = (k >> vbits) << 32 | (k & ((1ull << vbits) - 1));
+		r.n_genome = ng, r.tot_cnt = tot, r.sum_dist = sd, r.sum_s1 = a1, r.sum_s2 = a2;
+		out[w] = r;
+	}
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// cross-shard merge of arc tables (after the all-gather): gather valid entries, sort by x, wave-per-run sums
+// ------------------------------------------------------------------------------------------------
+// Every rank's table arrives sorted by x with unique keys, so the merged order needs no sort: the place of an entry is
+// the number of entries before it in all the tables (binary searches; equal keys keep rank order).
+struct MergeLists { int32_t W; int64_t slot_sz; const int64_t *off; }; // off[r] = entries of ranks < r, off[W] = total
+
+__device__ __forceinline__ int64_t mg_bound(const pga_arc_part_t *a, int64_t n, uint64_t x, bool upper)
+{
+	int64_t lo = 0, hi = n;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		const uint64_t y = a[mid].x;
+		if (upper ? y <= x : y < x) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mg_rank(const pga_arc_part_t *g, MergeLists L, uint64_t *key, uint32_t *val)
+{
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= L.off[L.W]) return;
+	int r = 0;
+	while (L.off[r + 1] <= i) ++r; // the table entry i belongs to (W is small)
+	const int64_t k = i - L.off[r], src = r * L.slot_sz + k;
+	const uint64_t x = g[src].x;
+	int64_t pos = k;
+	for (int q = 0; q < L.W; ++q)
+		if (q != r) pos += mg_bound(g + q * L.slot_sz, L.off[q + 1] - L.off[q], x, q < r);
+	key[pos] = x, val[pos] = (uint32_t)src;
+}
+
+struct InMgHead { const uint64_t *key; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(i == 0 || key[i] != key[i - 1]) ? 1 : 0}; } };
+
+__global__ __launch_bounds__(BLOCK) void k_mg_count(const uint64_t *key, const int32_t *slot, int64_t m, int64_t *box) // number of distinct keys
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0) *box = slot[m - 1] + ((m == 1 || key[m - 1] != key[m - 2]) ? 1 : 0); // slot = exclusive count of run heads
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mg_runstart(const uint64_t *key, const int32_t *slot, int64_t m, int32_t *run_start)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i < m && (i == 0 || key[i] != key[i - 1])) run_start[slot[i]] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mg_sum(const pga_arc_part_t *g, const uint32_t *val, int64_t m, int64_t n_run, const int32_t *run_start, pga_arc_part_t *out)
+{
+	const int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (w >= n_run) return;
+	const int64_t st = run_start[w], en = w + 1 < n_run ? run_start[w + 1] : m;
+	int ng = 0, tot = 0;
+	uint64_t sd = 0, x = 0;
+	int64_t a1 = 0, a2 = 0;
+	for (int64_t j = st + lane; j < en; j += WAVE) {
+		const pga_arc_part_t p = g[val[j]];
+		x = p.x, ng += p.n_genome, tot += p.tot_cnt, sd += p.sum_dist, a1 += p.sum_s1, a2 += p.sum_s2;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		ng += __shfl_xor(ng, o, WAVE), tot += __shfl_xor(tot, o, WAVE);
+		sd += (uint64_t)__shfl_xor((long long)sd, o, WAVE), a1 += __shfl_xor((long long)a1, o, WAVE), a2 += __shfl_xor((long long)a2, o, WAVE);
+	}
+	if (lane == 0) { // lane 0 always owns element st
+		pga_arc_part_t r;
+		r.x = x, r.n_genome = ng, r.tot_cnt = tot, r.sum_dist = sd, r.sum_s1 = a1, r.sum_s2 = a2;
+		out[w] = r;
+	}
+}

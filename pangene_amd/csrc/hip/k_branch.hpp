@@ -1,0 +1,284 @@
+// k_branch.hpp -- branch.c on the device.
+// Included by pga_backend.hip (one translation unit); uses the context types, BLOCK / WAVE and dev_prims.hpp from there.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// branch.c on device: pg_gen_rep_pos (6-29), pg_n_local (31-46), pg_mark_branch_flt_hit (108-145)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_walk_x(const uint32_t *flags, int n, int32_t *wk)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	wk[h] = (flags[h] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1;
+}
+
+// the last walkable hit of a gene in array order wins (branch.c:22-23 overwrite)
+__global__ __launch_bounds__(BLOCK) void k_rep_last(const int32_t *wk, const int32_t *gnm, const int32_t *gid, int n, int GL, int32_t *rp_pos)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n || !wk[h]) return;
+	atomicMax(&rp_pos[(int64_t)gid[h] * GL + gnm[h]], h + 1);
+}
+
+// Position record of (gene, genome): {contig, rank among the walkable hits of the genome, cm}.  COMPACT (every genome has
+// < 4096 contigs and < 2^20 hits, decided once in create): 8 bytes {cm, local contig << 20 | rank}, half the L2 traffic of
+// pg_n_local, which reads two records per (pair, genome); otherwise 16 bytes {global contig, rank, cm, 0}.  Absent: -1.
+template <bool COMPACT>
+__global__ __launch_bounds__(BLOCK) void k_rep_fill(const int32_t *rp_pos, int64_t n_ent, int GL, const int32_t *seg, const int32_t *cm, const int32_t *rx,
+                                                      const int32_t *goff, const int32_t *ctg_base, void *rp_out)
+{
+	int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (e >= n_ent) return;
+	const int p = rp_pos[e];
+	if (COMPACT) {
+		int2 *rp = (int2 *)rp_out;
+		if (p == 0) { rp[e] = make_int2(0, -1); return; }
+		const int h = p - 1, j = (int)(e % GL);
+		rp[e] = make_int2(cm[h], (seg[h] - ctg_base[j]) << 20 | (rx[h] - rx[goff[j]]));
+	} else {
+		int4 *rp = (int4 *)rp_out;
+		if (p == 0) { rp[e] = make_int4(-1, 0, 0, 0); return; }
+		const int h = p - 1, j = (int)(e % GL);
+		rp[e] = make_int4(seg[h], rx[h] - rx[goff[j]], cm[h], 0);
+	}
+}
+
+// one wave per gene pair, lanes over the local genomes (branch.c:31-46); the count is a popcount of ballots: no
+// cross-lane reduction
+template <bool COMPACT>
+__global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const void *rp_in,
+                                                     int local_dist, int local_count, int frag_mode, int32_t *cnt)
+{
+	const int64_t k = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (k >= n_pair) return;
+	const int64_t g1 = (int64_t)pairs[2 * k] * GL, g2 = (int64_t)pairs[2 * k + 1] * GL;
+	int c = 0;
+	for (int j0 = 0; j0 < GL; j0 += WAVE) {
+		const int j = j0 + lane;
+		bool hit = false;
+		if (j < GL) {
+			if (COMPACT) {
+				const int2 a = ((const int2 *)rp_in)[g1 + j], b = ((const int2 *)rp_in)[g2 + j];
+				const int64_t d = (int64_t)a.x - (int64_t)b.x;
+				const int cc = (a.y & 0xfffff) - (b.y & 0xfffff);
+				hit = (a.y | b.y) >= 0 && (frag_mode || ((a.y ^ b.y) >> 20) == 0) &&
+				      ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+			} else {
+				const int4 a = ((const int4 *)rp_in)[g1 + j], b = ((const int4 *)rp_in)[g2 + j];
+				const int64_t d = (int64_t)a.z - (int64_t)b.z;
+				const int cc = a.y - b.y;
+				hit = a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x) &&
+				      ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+			}
+		}
+		c += __popcll(__ballot(hit));
+	}
+	if (lane == 0) cnt[k] = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pg_mark_branch_flt_arc (branch.c:48-106) on the arc table: one thread per oriented vertex
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_br_prep(const uint64_t *ax, int64_t n_arc, const int32_t *seg_gid, int32_t *agid, int32_t *vs, int32_t *ve)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n_arc) return;
+	const uint64_t x = ax[i];
+	const uint32_t v = (uint32_t)(x >> 32);
+	agid[i] = seg_gid[(uint32_t)x >> 1];
+	if (i == 0 || (uint32_t)(ax[i - 1] >> 32) != v) vs[v] = (int32_t)i;
+	if (i == n_arc - 1 || (uint32_t)(ax[i + 1] >> 32) != v) ve[v] = (int32_t)i + 1;
+}
+
+// the round's arc table -> what branch marking reads (see pga_arc_set_current)
+__global__ __launch_bounds__(BLOCK) void k_seg_gid(const int32_t *g2s, int Q, int n_seg, int32_t *seg_gid)
+{
+	int g = blockIdx.x * BLOCK + threadIdx.x;
+	if (g < Q) { int s = g2s[g]; if (s >= 0 && s < n_seg) seg_gid[s] = g; }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cur_prep(const pga_arc_part_t *arcs, int64_t n_arc, const int32_t *seg_gid, uint64_t *ax, int32_t *s1, int32_t *agid,
+                                                      int32_t *vs, int32_t *ve)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n_arc) return;
+	const pga_arc_part_t a = arcs[i];
+	const uint32_t v = (uint32_t)(a.x >> 32);
+	ax[i] = a.x;
+	s1[i] = (int32_t)((double)a.sum_s1 / a.n_genome + .499); // graph.c:171
+	agid[i] = seg_gid[(uint32_t)a.x >> 1];
+	if (i == 0 || (uint32_t)(arcs[i - 1].x >> 32) != v) vs[v] = (int32_t)i;
+	if (i == n_arc - 1 || (uint32_t)(arcs[i + 1].x >> 32) != v) ve[v] = (int32_t)i + 1;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_deg(const int32_t *vs, const int32_t *ve, int n_vtx, int32_t *deg)
+{
+	int v = blockIdx.x * BLOCK + threadIdx.x;
+	if (v < n_vtx) deg[v] = ve[v] - vs[v];
+}
+
+// number of pg_n_local calls of vertex v: n_max * n_weak (branch.c:70-75) + n(n-1)/2 (branch.c:83-88)
+__global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1, double bd, int32_t *pc)
+{
+	const int v = blockIdx.x * BLOCK + threadIdx.x;
+	if (v >= n_vtx) return;
+	const int a0 = vs[v], n = ve[v] - a0;
+	if (n < 2) { pc[v] = 0; return; }
+	int max_s1 = 0, n_max = 0, n_weak = 0;
+	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[a0 + i] ? max_s1 : s1[a0 + i];
+	for (int i = 0; i < n; ++i) {
+		n_max += s1[a0 + i] == max_s1;
+		n_weak += (1.0 - (double)s1[a0 + i] / max_s1) > bd; // branch.c:71-72
+	}
+	pc[v] = n_max * n_weak + n * (n - 1) / 2;
+}
+
+// sequential form (one lane), used for vertices with more than 64 arcs.  MODE 1: write pairs; 2: decide.
+template <int MODE>
+__device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *agid, double bd, int64_t k, int32_t *pairs, const int32_t *cnt,
+                              double bdist, double bcut, uint8_t *weak, int32_t *grp, int32_t *ndl_out, int64_t *dcnt)
+{
+	int max_s1 = 0;
+	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[a0 + i] ? max_s1 : s1[a0 + i];
+	for (int i = 0; i < n; ++i) {
+		const double r = 1.0 - (double)s1[a0 + i] / max_s1;
+		if (!(r > bd)) continue;
+		int n_local = 0;
+		for (int j = 0; j < n; ++j) {
+			if (s1[a0 + j] != max_s1) continue;
+			if (MODE == 1) pairs[2 * k] = agid[a0 + j], pairs[2 * k + 1] = agid[a0 + i];
+			if (MODE == 2) n_local += cnt[k];
+			++k;
+		}
+		if (MODE == 2) {
+			weak[a0 + i] = ((n_local == 0 && r > bdist) || r > bcut) ? 2 : 1;
+		}
+	}
+	int n_group = 0;
+	for (int i = 0; i < n; ++i) {
+		if (MODE == 2 && grp[a0 + i] == 0) grp[a0 + i] = ++n_group;
+		for (int j = i + 1; j < n; ++j) {
+			if (MODE == 1) pairs[2 * k] = agid[a0 + i], pairs[2 * k + 1] = agid[a0 + j];
+			if (MODE == 2 && cnt[k] > 0 && grp[a0 + j] == 0) grp[a0 + j] = grp[a0 + i];
+			++k;
+		}
+	}
+	if (MODE == 2) *ndl_out = n_group;
+}
+
+// One WAVE per oriented vertex; lane j holds arc j (score, target gene, group mark) in registers and arcs are
+// broadcast with shuffles, so the O(n^2) pair loops of branch.c:70-90 touch memory only for the pair list
+// (coalesced stores, MODE 1) or the all-reduced counts (coalesced loads, MODE 2).
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
+                                                     const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
+                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt)
+{
+	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (v >= n_vtx) return;
+	const int a0 = vs[v], n = ve[v] - a0;
+	if (n < 2) return;
+	const int64_t k0 = poff[v];
+	if (n > WAVE) {
+		if (lane == 0) { int32_t g = 0; br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt); if (MODE == 2) ndl[v] = g; }
+		return;
+	}
+	const bool in = lane < n;
+	const int my_s1 = in ? s1g[a0 + lane] : 0, my_gid = in ? agidg[a0 + lane] : 0;
+	int max_s1 = my_s1;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(max_s1, o, WAVE); max_s1 = max_s1 > t ? max_s1 : t; }
+	const double r = in ? 1.0 - (double)my_s1 / max_s1 : 0.0; // branch.c:71
+	const bool is_weak = in && r > bd, is_max = in && my_s1 == max_s1;
+	const unsigned long long m_weak = __ballot(is_weak), m_max = __ballot(is_max);
+	const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	const int n_max = __popcll(m_max), mrank = __popcll(m_max & lt);
+	// part 1 (branch.c:70-77): for every weak arc i (ascending), one pair per best-scoring arc j (ascending)
+	int wb = 0;
+	for (unsigned long long m = m_weak; m; m &= m - 1, ++wb) {
+		const int i = __ffsll((long long)m) - 1;
+		const int gid_i = __shfl(my_gid, i, WAVE);
+		const int64_t k = k0 + (int64_t)wb * n_max + mrank;
+		if (MODE == 1) { if (is_max) pairs[2 * k] = my_gid, pairs[2 * k + 1] = gid_i; }
+		else {
+			int c = is_max ? cnt[k] : 0;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
+			if (lane == i) {
+				weak[a0 + i] = ((c == 0 && r > bdist) || r > bcut) ? 2 : 1;
+			}
+		}
+	}
+	// part 2 (branch.c:82-90): all i<j pairs, row i starts after i*n - i(i+1)/2 earlier pairs
+	const int64_t k2 = k0 + (int64_t)n_max * __popcll(m_weak);
+	int grp = 0, n_group = 0;
+	for (int i = 0; i < n; ++i) {
+		const int64_t k = k2 + (int64_t)i * n - (int64_t)i * (i + 1) / 2 + (lane - i - 1);
+		if (MODE == 1) {
+			const int gid_i = __shfl(my_gid, i, WAVE);
+			if (lane > i && in) pairs[2 * k] = gid_i, pairs[2 * k + 1] = my_gid;
+		} else {
+			int gi = __shfl(grp, i, WAVE);
+			if (gi == 0) { gi = ++n_group; if (lane == i) grp = gi; } // uniform: every lane sees the same gi
+			if (lane > i && in && grp == 0 && cnt[k] > 0) grp = gi;
+		}
+	}
+	if (MODE == 2 && lane == 0) ndl[v] = n_group;
+}
+
+__device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107
+{
+	int64_t lo = 0, hi = n;
+	while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ax[mid] < x) lo = mid + 1; else hi = mid; }
+	return (lo < n && ax[lo] == x) ? aw[lo] : 0;
+}
+
+// pg_get_arc as in the reference (pgpriv.h:99-107): scan the few arcs leaving v; vs/ve = arc range of each vertex
+__device__ __forceinline__ int arc_weak_v(const uint64_t *ax, const uint8_t *aw, const int32_t *vs, const int32_t *ve, uint32_t v, uint32_t w)
+{
+	for (int i = vs[v], e = ve[v]; i < e; ++i)
+		if ((uint32_t)ax[i] == w) return aw[i];
+	return 0;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mark_hits(const int32_t *val, const int32_t *prev, const int4 *YA, const int4 *YB, const int32_t *g2s, int n,
+                                                       const uint64_t *ax, const uint8_t *aw, int64_t n_arc, const int32_t *vs, const int32_t *ve, int32_t *weak_new)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y >= n || val[y] < 0) return;
+	int p = prev[y];
+	if (p < 0) return;
+	const int4 aA = YA[y], bA = YA[p];
+	if (aA.x != bA.x) return; // branch.c:124
+	const int aw_ = YB[y].w, bw_ = YB[p].w; // X position << 1 | rev
+	uint32_t w = (uint32_t)g2s[aA.y] << 1 | (uint32_t)(aw_ & 1);
+	uint32_t v = (uint32_t)g2s[bA.y] << 1 | (uint32_t)(bw_ & 1);
+	int e1 = vs ? arc_weak_v(ax, aw, vs, ve, v, w) : arc_weak(ax, aw, n_arc, (uint64_t)v << 32 | w);                       // branch.c:128-130: marks the earlier hit
+	if (e1) atomicMax(&weak_new[bw_ >> 1], e1);
+	int e2 = vs ? arc_weak_v(ax, aw, vs, ve, w ^ 1, v ^ 1) : arc_weak(ax, aw, n_arc, (uint64_t)(w ^ 1) << 32 | (v ^ 1)); // branch.c:131-133: marks this hit
+	if (e2) atomicMax(&weak_new[aw_ >> 1], e2);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_weak_merge(uint32_t *flags, const int32_t *weak_new, int n, int64_t *cnt)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	const bool in = h < n;
+	if (!in) h = n - 1;
+	uint32_t f = flags[h];
+	int cur = in ? (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT) : 0, nw = in ? weak_new[h] : 0;
+	if (nw > cur) { cur = nw; flags[h] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT; }
+	if (cnt) { // log-only counter (branch.c:137-139): one atomic per wave, and only when somebody asks
+		const unsigned long long m = __ballot(cur != 0);
+		if (m && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd((unsigned long long *)cnt, (unsigned long long)__popcll(m));
+	}
+}
+
+// hazard H2b: two consecutive walkable hits (cs order) share (contig, cs)
+__global__ __launch_bounds__(BLOCK) void k_hz_cs(const int32_t *wk, const int32_t *seg, const int32_t *cs, int n, int64_t *dcnt)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n || h == 0 || !wk[h]) return;
+	for (int j = h - 1; j >= 0 && seg[j] == seg[h] && cs[j] == cs[h]; --j)
+		if (wk[j]) { atomicAdd((unsigned long long *)&dcnt[6], 1ull); break; }
+}

@@ -1,0 +1,205 @@
+// k_ingest.hpp -- stage A kernels except the sweep: per-hit constants and sort keys, pg_flag_pseudo (hit.c:66-105), and the filters that consume the sweep's flags (pg_flt_ov_isoform's apply step, pg_flt_chain_shadow, pg_flt_subopt_isoform, hit.c:107-146).
+// Included by pga_backend.hip (one translation unit); uses the context types, BLOCK / WAVE and dev_prims.hpp from there.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// create: derive per-hit constants in file order, sort into X order, gather, pm, Y order
+// ------------------------------------------------------------------------------------------------
+struct FileHits { const int32_t *pid, *cid, *rank, *sori, *sadj, *nex, *offx, *cs, *ce, *cm; const uint8_t *rev; };
+
+__global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int32_t *goff, int n_genome, const int32_t *ctg_base,
+                                                     const int2 *exon, const int32_t *prot_gid, const uint8_t *gene_pref,
+                                                     int32_t *gnm_f, int32_t *seg_f, int32_t *gid_f, int32_t *cds_f, uint64_t *key, uint32_t *val)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	int g = genome_of(goff, n_genome, i);
+	// skip empty genomes that share the same offset: genome_of returns the LAST g with goff[g] <= i, which is the owner
+	int sg = ctg_base[g] + f.cid[i];
+	int gid = prot_gid[f.pid[i]];
+	int len = 0, ne = f.nex[i], ox = f.offx[i];
+	for (int e = 0; e < ne; ++e) { int2 x = exon[ox + e]; len += x.y - x.x; } // pg_cds_len, overlap.c:45-51
+	gnm_f[i] = g, seg_f[i] = sg, gid_f[i] = gid, cds_f[i] = len;
+	key[i] = (uint64_t)(int64_t)f.sadj[i] << 33 | (uint64_t)gene_pref[gid] << 32 | hash_u32((uint32_t)f.pid[i]); // the score key of overlap.c:137
+	val[i] = (uint32_t)i;
+}
+
+// The sweep only ever COMPARES score keys, so every hit gets the dense rank of its key over the shard (one sort per
+// run): 32-bit compares instead of 64-bit ones, and rank and partner slot fit one 64-bit word for a single LDS
+// atomicMax ("best winner, first in array order").  Key 0 keeps rank 0: such a hit never becomes a dominator.
+__global__ __launch_bounds__(BLOCK) void k_rank_scatter(const uint64_t *ks, const uint32_t *vs, const int32_t *incl, int n, int32_t *rk_f)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n) rk_f[vs[i]] = ks[i] == 0 ? 0 : incl[i]; // incl >= 1; when key 0 exists it owns rank value 1, which then stays unused
+}
+
+__global__ __launch_bounds__(BLOCK) void k_xkey(const int32_t *seg_f, const int32_t *cs_f, int n, int cs_bits, uint64_t *key, uint32_t *val)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n) key[i] = (uint64_t)seg_f[i] << cs_bits | (uint32_t)cs_f[i], val[i] = (uint32_t)i;
+}
+
+struct HitArrays {
+	int32_t *fidx, *gnm, *seg, *pid, *gid, *cs, *ce, *cm, *cds, *nex, *offx, *sori, *sadj, *rank, *sdom, *pdom, *pdom0;
+	int32_t *rk; uint32_t *flags;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_gather(FileHits f, const int32_t *gnm_f, const int32_t *seg_f, const int32_t *gid_f, const int32_t *cds_f,
+                                                    const int32_t *rk_f, const uint32_t *perm, int n, const int32_t *goff, HitArrays o)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int s = (int)perm[h];
+	int g = gnm_f[s];
+	o.fidx[h] = s - goff[g], o.gnm[h] = g, o.seg[h] = seg_f[s], o.pid[h] = f.pid[s], o.gid[h] = gid_f[s];
+	o.cs[h] = f.cs[s], o.ce[h] = f.ce[s], o.cm[h] = f.cm[s], o.cds[h] = cds_f[s], o.nex[h] = f.nex[s], o.offx[h] = f.offx[s];
+	o.sori[h] = f.sori[s], o.sadj[h] = f.sadj[s], o.rank[h] = f.rank[s], o.rk[h] = rk_f[s];
+	o.sdom[h] = 0, o.pdom[h] = -1, o.pdom0[h] = 0; // read.c:133-134
+	o.flags[h] = (f.rev[s] ? PGA_F_REV : 0u) | (h == goff[g] ? F_HEAD : 0u) | (f.nex[s] != 1 ? F_MULTI : 0u);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_ykey(const int32_t *seg, const int32_t *cm, int n, int cm_bits, uint64_t *key, uint32_t *val)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	key[h] = (uint64_t)seg[h] << cm_bits | (uint32_t)cm[h];
+	val[h] = (uint32_t)h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pg_flag_pseudo (hit.c:66-105) with a (genome, protein) table instead of a sort by pid<<32|rank
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_pseudo1(const int32_t *gnm, const int32_t *pid, const int32_t *nex, int n, int P, int32_t *tmax, int32_t *tmin)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int64_t t = (int64_t)gnm[h] * P + pid[h];
+	atomicMax(&tmax[t], nex[h]);
+	atomicMin(&tmin[t], nex[h]);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pseudo2(const int32_t *gnm, const int32_t *pid, const int32_t *nex, const int32_t *rank, uint32_t *flags,
+                                                     int n, int P, const int32_t *tmax, const int32_t *tmin, int32_t *tr1, int32_t *stats)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int64_t t = (int64_t)gnm[h] * P + pid[h];
+	int mx = tmax[t], mn = tmin[t], ne = nex[h];
+	if (!(mx > 1 && (mn == 1 || mn * 2 <= mx))) return; // hit.c:84
+	if (ne == 1 || ne * 2 <= mx) {
+		flags[h] |= PGA_F_PSEUDO | PGA_F_FLT; // hit.c:89 + PG_SET_FILTER(pseudo), read.c:246
+		atomicAdd(&stats[gnm[h] * 4 + 0], 1);
+	} else atomicMin(&tr1[t], rank[h]);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pseudo3(const int32_t *gnm, const int32_t *pid, int32_t *rank, int n, int P,
+                                                     const int32_t *tmax, const int32_t *tmin, const int32_t *tr1)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int64_t t = (int64_t)gnm[h] * P + pid[h];
+	int mx = tmax[t], mn = tmin[t], r1 = tr1[t];
+	if (!(mx > 1 && (mn == 1 || mn * 2 <= mx)) || r1 == INT32_MAX || r1 == 0) return;
+	int r = rank[h];
+	if (r < r1) rank[h] = r + 1; // hit.c:95-97
+	else if (r == r1) rank[h] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// after the sweeps of stage A: counters for the log, isoform / chain / sub-optimal filters
+// ------------------------------------------------------------------------------------------------
+// log-only counters (graph.c:23-27).  Hits are genome-major, so a workgroup mostly sees one genome: count
+// that genome in LDS and add once; stragglers of the next genome go to global memory directly.
+__global__ __launch_bounds__(BLOCK) void k_count_shadow(const uint32_t *flags, const int32_t *gnm, int n, int32_t *stats)
+{
+	__shared__ int s_cnt[2];
+	__shared__ int s_g;
+	const int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (threadIdx.x == 0) s_cnt[0] = s_cnt[1] = 0, s_g = gnm[blockIdx.x * BLOCK];
+	__syncthreads();
+	if (h < n) {
+		const uint32_t f = flags[h];
+		if (!(f & PGA_F_FLT)) {
+			const int g = gnm[h];
+			if (g == s_g) { atomicAdd(&s_cnt[0], 1); if (f & PGA_F_SHADOW) atomicAdd(&s_cnt[1], 1); }
+			else { atomicAdd(&stats[g * 2], 1); if (f & PGA_F_SHADOW) atomicAdd(&stats[g * 2 + 1], 1); }
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (s_cnt[0]) atomicAdd(&stats[s_g * 2], s_cnt[0]);
+		if (s_cnt[1]) atomicAdd(&stats[s_g * 2 + 1], s_cnt[1]);
+	}
+}
+
+// read.c:249-253
+__global__ __launch_bounds__(BLOCK) void k_ingest_reset(uint32_t *flags, int32_t *pdom, int32_t *pdom0, int n)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	pdom0[h] = pdom[h];
+	pdom[h] = -1;
+	flags[h] &= ~PGA_F_SHADOW;
+}
+
+// tail of pg_flt_ov_isoform (overlap.c:89-91) + first loop of pg_flt_chain_shadow (hit.c:136-138)
+__global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int32_t *gnm, const int32_t *pid, int n, int P, int32_t *tiso, int32_t *stats)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h];
+	if (f & PGA_F_ISO_OV) {
+		flags[h] = f | PGA_F_FLT;
+		atomicAdd(&stats[gnm[h] * 4 + 1], 1);
+	} else tiso[(int64_t)gnm[h] * P + pid[h]] = 0;
+}
+
+// second loop of pg_flt_chain_shadow (hit.c:139-143)
+__global__ __launch_bounds__(BLOCK) void k_chain(uint32_t *flags, const int32_t *gnm, const int32_t *pdom0, int n, int P, const int32_t *tiso, int32_t *stats)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int p0 = pdom0[h];
+	if (p0 >= 0 && tiso[(int64_t)gnm[h] * P + p0]) {
+		flags[h] |= PGA_F_FLT | PGA_F_CHAIN;
+		atomicAdd(&stats[gnm[h] * 4 + 2], 1);
+	}
+}
+
+// pg_flt_subopt_isoform (hit.c:107-128).  best[gene] of one genome = first maximum of score_adj in
+// array order; the (int32 > uint64) comparison of hit.c:116 lets a negative score_adj always win, the
+// last one in array order staying.
+__global__ __launch_bounds__(BLOCK) void k_subopt1(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *sadj,
+                                                     const int32_t *goff, int n, int Q, unsigned long long *tbest)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	if ((flags[h] & PGA_F_FLT) || rank[h] > 0) return;
+	int s = sadj[h], g = gnm[h];
+	uint32_t pos = (uint32_t)(h - goff[g]);
+	unsigned long long k;
+	if (s > 0) k = (unsigned long long)(uint32_t)s << 32 | (0xffffffffu - pos);
+	else if (s < 0) k = 1ull << 63 | pos;
+	else return;
+	atomicMax(&tbest[(int64_t)g * Q + gid[h]], k);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_subopt2(uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *pid, const int32_t *goff, int n, int Q,
+                                                     const unsigned long long *tbest, int32_t *stats)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h];
+	if (f & PGA_F_FLT) return;
+	int g = gnm[h];
+	unsigned long long k = tbest[(int64_t)g * Q + gid[h]];
+	int best_pid = 0; // hit.c:111: calloc'ed best => pid 0 when the gene has no candidate
+	if (k) {
+		uint32_t pos = (k >> 63) ? (uint32_t)k : 0xffffffffu - (uint32_t)k;
+		best_pid = pid[goff[g] + (int)pos];
+	}
+	if (pid[h] != best_pid) {
+		flags[h] = f | PGA_F_FLT | PGA_F_ISO_SUB;
+		atomicAdd(&stats[g * 4 + 3], 1);
+	}
+}

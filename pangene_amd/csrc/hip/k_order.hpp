@@ -1,0 +1,96 @@
+// k_order.hpp -- per-hit state download and the exact-order overrides.
+// Included by pga_backend.hip (one translation unit); uses the context types, BLOCK / WAVE and dev_prims.hpp from there.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// download: per-hit state back to file order
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_to_file(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, const uint32_t *flags, const int32_t *rank,
+                                                     const int32_t *sdom, const int32_t *pdom, const int32_t *pdom0, const int32_t *yperm, int n,
+                                                     uint32_t *oflags, int32_t *orank, int32_t *osdom, int32_t *opdom, int32_t *opdom0, int32_t *opx, int32_t *opy)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	int g = gnm[h], f = goff[g] + fidx[h];
+	oflags[f] = flags[h] & F_PUBLIC, orank[f] = rank[h], osdom[f] = sdom[h], opdom[f] = pdom[h], opdom0[f] = pdom0[h];
+	opx[f] = h - goff[g];
+	int x = yperm[h]; // h doubles as a Y position here
+	opy[goff[gnm[x]] + fidx[x]] = h - goff[gnm[x]];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// exact-order overrides (pangene_hip.h): re-permute contig segments of the physical (X) order, or
+// rewrite slices of the Y permutation.  Rare (a few calls per run), not tuned.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_ov_inv(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, int n, int32_t *inv, int32_t *remap)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	inv[goff[gnm[h]] + fidx[h]] = h;
+	remap[h] = h;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_ov_sety(const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv, int32_t *yperm)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i < t) yperm[ov_pos[i]] = inv[ov_file[i]];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_inv_only(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, int n, int32_t *inv)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h < n) inv[goff[gnm[h]] + fidx[h]] = h;
+}
+
+// move the "index 0" mark of each genome to the hit the reference has there (overlap.c:108)
+__global__ __launch_bounds__(BLOCK) void k_set_head(const int32_t *head_file, const int32_t *goff, const int32_t *inv, int n_genome, int32_t *headpos, uint32_t *flags)
+{
+	int g = blockIdx.x * BLOCK + threadIdx.x;
+	if (g >= n_genome || goff[g] == goff[g + 1]) return;
+	int np = head_file[g] < 0 ? goff[g] : inv[goff[g] + head_file[g]], op = headpos[g];
+	if (np == op) return;
+	flags[op] &= ~F_HEAD;
+	flags[np] |= F_HEAD;
+	headpos[g] = np;
+}
+
+struct PermArrays { int32_t *a[17]; }; // a[15] = flags, a[16] = rk
+
+__global__ __launch_bounds__(BLOCK) void k_ov_gather(PermArrays p, const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv,
+                                                       int32_t *tmp, int32_t *remap)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= t) return;
+	int src = inv[ov_file[i]];
+	remap[src] = ov_pos[i];
+#pragma unroll
+	for (int k = 0; k < 17; ++k) tmp[(int64_t)k * t + i] = p.a[k][src];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_t *ov_pos, int64_t t, const int32_t *tmp,
+                                                        const int32_t *gnm, const int32_t *goff)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= t) return;
+	int pos = ov_pos[i];
+#pragma unroll
+	for (int k = 0; k < 15; ++k) p.a[k][pos] = tmp[(int64_t)k * t + i];
+	uint32_t f = (uint32_t)tmp[(int64_t)15 * t + i] & ~F_HEAD; // a[15] = flags; the head mark is positional
+	if (pos == goff[gnm[pos]]) f |= F_HEAD;
+	p.a[15][pos] = (int32_t)f;
+	p.a[16][pos] = tmp[(int64_t)16 * t + i];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_ov_remap_y(int32_t *yperm, int n, const int32_t *remap)
+{
+	int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y < n) yperm[y] = remap[yperm[y]];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_flt_bits(const uint32_t *flags, int n, unsigned long long *bits)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	const unsigned long long m = __ballot(h < n && (flags[h < n ? h : n - 1] & PGA_F_FLT));
+	if ((threadIdx.x & 63) == 0 && h < n) bits[h >> 6] = m;
+}

@@ -1,0 +1,389 @@
+// k_sweep.hpp -- the interval-dominance sweep (K1): pg_shadow, pg_flt_ov_isoform, pg_hit_overlap.
+// Included by pga_backend.hip (one translation unit); uses the context types, BLOCK / WAVE and dev_prims.hpp from there.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// the interval-dominance sweep: pg_shadow (overlap.c:101-178) and pg_flt_ov_isoform (58-93)
+// ------------------------------------------------------------------------------------------------
+// Packed per-hit records for the sweep: a partner costs 16-byte loads instead of a dozen 4-byte ones.
+//   A = {cs, seg, ce, pm}   B = {rk, gid, cds, pid}   C = {rank, n_exon, off_exon, score_ori}
+// (A.xy read as one 64-bit word is seg << 32 | cs: the sort key of the X order, non-decreasing along the array)
+// C is only needed for multi-exon hits, for two hits with the same score key and for score_dom.
+__global__ __launch_bounds__(BLOCK) void k_pack_rec(const int32_t *seg, const int32_t *cs, const int32_t *ce, const int32_t *pm, const int32_t *rk,
+                                                      const int32_t *gid, const int32_t *cds, const int32_t *rank, const int32_t *nex, const int32_t *offx,
+                                                      const int32_t *pid, const int32_t *sori, int n, int4 *A, int4 *B, int4 *C)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	A[h] = make_int4(cs[h], seg[h], ce[h], pm[h]);
+	B[h] = make_int4(rk[h], gid[h], cds[h], pid[h]);
+	C[h] = make_int4(rank[h], nex[h], offx[h], sori[h]);
+}
+
+// where a tie-order hazard (h2_cm_tie / h3_dom_tie) happened: contig-segment ids, at most PGA_HAZARD_CAP of them (counter: dcnt[14])
+__device__ __forceinline__ void hz_note(int64_t *cnt14, int32_t *list, int seg)
+{
+	const unsigned long long at = atomicAdd((unsigned long long *)cnt14, 1ull);
+	if (at < (unsigned long long)PGA_HAZARD_CAP) list[at] = seg;
+}
+
+struct SweepView {
+	const int4 *A, *B, *C; const int32_t *sori; const int2 *exon;
+	uint32_t *flags; int32_t *pdom, *sdom;
+	int n; double min_ov; int check_strand;
+	int stage_c; // some hit of the shard has several exons: stage the C records with the others
+	int64_t *hz;
+	int64_t *slow_cnt; int32_t *slow_list; // work list for k_sweep_slow
+	long long *prof; // PGA_SW_PROFILE builds only
+	int32_t *hz_list; // hz[10] (= dcnt[14]) counts its entries
+};
+
+// CDS intersection of hit a (exons ea[na], start ca) and hit b: pg_hit_overlap, overlap.c:6-42
+__device__ __forceinline__ int cds_inter(const int2 *__restrict__ ex, int oa, int na, int ca, int ea_end, int ob, int nb, int cb, int eb_end)
+{
+	if (!(ca < eb_end && ea_end > cb)) return 0;
+	if (na == 1 && nb == 1) { // single-exon x single-exon: plain interval intersection
+		int s = ca > cb ? ca : cb, e = ea_end < eb_end ? ea_end : eb_end;
+		return e > s ? e - s : 0;
+	}
+	int ia = 0, ib = 0, inter = 0;
+	int2 xa = ex[oa], xb = ex[ob];
+	while (true) {
+		int s0 = ca + xa.x, e0 = ca + xa.y, s1 = cb + xb.x, e1 = cb + xb.y;
+		bool adv_a;
+		if (s0 < s1) {
+			if (e0 < e1) { int o = e0 - s1; inter += o > 0 ? o : 0; adv_a = true; }
+			else { inter += e1 - s1; adv_a = false; }
+		} else {
+			if (e1 < e0) { int o = e1 - s0; inter += o > 0 ? o : 0; adv_a = false; }
+			else { inter += e0 - s0; adv_a = true; }
+		}
+		if (adv_a) { if (++ia >= na) break; xa = ex[oa + ia]; }
+		else { if (++ib >= nb) break; xb = ex[ob + ib]; }
+	}
+	return inter;
+}
+
+struct SwHit { // the hit a thread works for
+	int sg, cs, ce, gid, cds, rank, nex, offx, weak; uint32_t fl; uint32_t sc;
+};
+struct SwBest { bool lose; uint32_t best; int j, ov, pid, cds; };
+
+// Thread-per-hit form of one pair, used by k_sweep_slow: partner p (records a/b/c, flags fp, array index pi) of hit t;
+// EARLIER: p precedes t in the array.  overlap.c:126-154 (pg_shadow) / 76-87 (pg_flt_ov_isoform).
+__device__ __forceinline__ int4 sw_scse(int4 r) { return make_int4(r.y, r.x, r.z, r.w); } // record A -> (seg, cs, ce, pm)
+
+template <int MODE, bool EARLIER>
+__device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBest &r, const int4 a, const uint32_t fp, const int4 b, const int4 c, int pi, bool ok)
+{
+	ok = ok && !(fp & PGA_F_FLT);
+	if (v.check_strand) ok = ok && !((fp ^ t.fl) & PGA_F_REV);
+	const bool same_gene = b.y == t.gid;
+	if (MODE == 2) ok = ok && same_gene;
+	const int x = !ok ? 0 : EARLIER ? cds_inter(v.exon, c.z, c.y, a.y, a.z, t.offx, t.nex, t.cs, t.ce)
+	                                : cds_inter(v.exon, t.offx, t.nex, t.cs, t.ce, c.z, c.y, a.y, a.z);
+	ok = ok && x > 0; // overlap.c:132
+	const uint32_t sp = (uint32_t)b.x;
+	// "i" of the reference is the later hit of the pair: i loses if (si < sj || (si == sj && rank_i > rank_j))
+	const uint32_t s_i = EARLIER ? t.sc : sp, s_j = EARLIER ? sp : t.sc;
+	const int rk_i = EARLIER ? t.rank : c.x, rk_j = EARLIER ? c.x : t.rank;
+	bool i_loses = s_i < s_j || (s_i == s_j && rk_i > rk_j);
+	if (MODE != 2) {
+		const int m = t.cds < b.z ? t.cds : b.z;
+		// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < m: x/m is within
+		// 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
+		bool too_short;
+		if (v.min_ov == 0.5) too_short = 2u * (uint32_t)x < (uint32_t)m;
+		else too_short = (double)x / (m > 0 ? m : 1) < v.min_ov;
+		ok = ok && (same_gene || !too_short);
+		const int wk_p = (int)((fp & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
+		const int wk_i = EARLIER ? t.weak : wk_p, wk_j = EARLIER ? wk_p : t.weak;
+		i_loses = (!same_gene && wk_i != wk_j) ? wk_i > wk_j : i_loses; // overlap.c:139-147
+	}
+	const bool t_loses = ok && (EARLIER ? i_loses : !i_loses);
+	r.lose = r.lose || t_loses;
+	if (MODE == 2) return;
+	// dominator = best-scoring winner, first in array order on ties (overlap.c:150,153).  Earlier partners are visited in
+	// DEscending index order, so an equal score replaces; later partners in ascending order, so it does not.
+	const bool upd = t_loses && (EARLIER ? (sp > 0 && sp >= r.best) : (sp > r.best));
+	if (t_loses && sp == r.best && sp > 0) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, t.sg); } // hazard H3, rare
+	r.best = upd ? sp : r.best, r.j = upd ? pi : r.j, r.ov = upd ? x : r.ov, r.pid = upd ? b.w : r.pid, r.cds = upd ? b.z : r.cds;
+}
+
+__device__ __forceinline__ void wave_sync() // LDS hand-over between lanes of ONE wave (the LDS queue of a wave is in order)
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exclusive prefix sum over the wave of a small count (c < 256), one ballot per bit: no LDS traffic, no cross-lane moves
+__device__ __forceinline__ int wave_scan_small(int c, int *total)
+{
+	int off = 0, tot = 0;
+#pragma unroll
+	for (int b = 0; b < 8; ++b) {
+		const unsigned long long mk = __ballot((c >> b) & 1);
+		off += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u)) << b;
+		tot += __popcll(mk) << b;
+	}
+	*total = tot;
+	return off;
+}
+
+// The interval-dominance sweep as an LDS pair list.
+//
+// A workgroup stages SW_TILE consecutive hits (cs order) plus SW_HALO neighbours on each side (36 B/hit, 52 when the C
+// records are needed; coalesced 16-byte loads) and after ONE barrier its waves work independently: a wave owns 64 hits
+// and looks at a window of SW_HALO more slots on each side.  Because hits are cs-sorted inside a contig, the later
+// partners of a hit are a contiguous run; the runs are counted, prefix-summed over the wave and expanded into a list
+// of (earlier, later) slot pairs with at least one member among the wave's hits.  The list is evaluated one pair per
+// lane (full lanes, every pair once -- a thread-per-hit walk evaluates each pair twice and runs as long as the busiest
+// lane).  The outcome reaches the loser as ONE 64-bit LDS atomicMax of (winner's score rank, "lost" bit, inverted
+// winner slot): the maximum is the best-scoring winner and, among equals, the first in array order (overlap.c:150).
+// Pairs across a wave or tile border are evaluated by both sides, each updating only its own hit: no global atomics,
+// no inter-wave synchronisation.  Hits whose partners reach beyond the window, and waves whose list overflows, go
+// to a work list for k_sweep_slow.
+// MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform
+constexpr int SW_HALO = 32, SW_TILE = 256, SW_LDS = SW_TILE + 2 * SW_HALO, SW_WCAP = 512, SW_NW = SW_TILE / 64;
+
+#ifdef PGA_SW_PROFILE // tuning build: s_memtime stamps of lane 0 of every wave at the phase boundaries
+#define SW_STAMP(k) do { if (v.prof && (threadIdx.x & 63) == 0) v.prof[((long long)blockIdx.x * SW_NW + (threadIdx.x >> 6)) * 8 + (k)] = clock64(); } while (0)
+#else
+#define SW_STAMP(k) do { } while (0)
+#endif
+
+// epilogue of a hit, overlap.c:157-175.  The hit at index 0 of a genome is never reset (loop starts at 1, overlap.c:108).
+template <int MODE>
+__device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl, bool lose, bool has_dom, int pid_w, int ov, int cds_h, int cds_w, int sori_h, int sori_w)
+{
+	if (MODE == 2) {
+		if (lose) v.flags[h] = fl | PGA_F_ISO_OV;
+		return;
+	}
+	uint32_t nf = (fl & F_HEAD) ? fl : (fl & ~PGA_F_SHADOW);
+	if (lose) nf |= PGA_F_SHADOW;
+	if (nf != fl) v.flags[h] = nf;
+	v.pdom[h] = has_dom ? pid_w : -1;
+	if (MODE == 1) {
+		int sd = -1;
+		if (has_dom) sd = (int32_t)(sori_h * (1.0 - (double)ov / cds_h) + sori_w * ((double)ov / cds_w) + .499); // overlap.c:170
+		v.sdom[h] = sd;
+	}
+}
+
+template <int MODE, bool STAGE_C>
+__global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
+{
+	static_assert(2 * SW_HALO == 64 && SW_NW == 4 && SW_LDS <= 1024 && 64 + 2 * SW_HALO <= 128, "the slots past SW_TILE are staged one array per wave; window-relative slot ids are packed in 7 bits, winner slots in 10");
+	constexpr bool STAGE_ORI = MODE == 1 && !STAGE_C; // score_dom needs score_ori: out of the C records when they are staged, else staged alone
+	__shared__ int4 sA[SW_LDS + 4], sB[SW_LDS], sC[STAGE_C ? SW_LDS : 1]; // sA: four sentinel slots close the array
+	__shared__ uint32_t sF[SW_LDS];
+	__shared__ int32_t sOri[STAGE_ORI ? SW_LDS : 1];
+	__shared__ uint16_t sPairAll[SW_NW][SW_WCAP]; // (earlier slot - window start) << 7 | (later slot - first own slot): both < 96
+	__shared__ unsigned long long sKeyAll[SW_NW][64];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	uint16_t *sPair = sPairAll[wave];
+	unsigned long long *sKey = sKeyAll[wave];
+	const int tile = blockIdx.x, base = tile * SW_TILE - SW_HALO;
+	SW_STAMP(0);
+	{
+		const int g = base + tid;
+		int4 a = make_int4(0, -2, 0, 0), b = make_int4(0, 0, 0, 0), c = b; // slots outside the array: contig -2, filtered
+		uint32_t f = PGA_F_FLT;
+		int32_t so = 0;
+		if (g >= 0 && g < v.n) {
+			a = v.A[g], b = v.B[g], f = v.flags[g];
+			if (STAGE_C) c = v.C[g];
+			if (STAGE_ORI) so = v.sori[g];
+		}
+		// the 2 * SW_HALO slots past SW_TILE: one array per wave, so that no wave has more to stage than the others
+		const int l2 = SW_TILE + lane, g2 = base + l2;
+		const bool in2 = lane < 2 * SW_HALO && g2 >= 0 && g2 < v.n;
+		if (wave == 0) sA[l2] = in2 ? v.A[g2] : make_int4(0, -2, 0, 0);
+		else if (wave == 1) sB[l2] = in2 ? v.B[g2] : make_int4(0, 0, 0, 0);
+		else if (wave == 2) sF[l2] = in2 ? v.flags[g2] : PGA_F_FLT;
+		else if (STAGE_C) sC[l2] = in2 ? v.C[g2] : make_int4(0, 0, 0, 0);
+		else if (STAGE_ORI) sOri[l2] = in2 ? v.sori[g2] : 0;
+		sA[tid] = a, sB[tid] = b, sF[tid] = f;
+		if (STAGE_C) sC[tid] = c;
+		if (STAGE_ORI) sOri[tid] = so;
+	}
+	if (tid < 4) sA[SW_LDS + tid] = make_int4(0, -2, 0, 0);
+	sKey[lane] = 0;
+	SW_STAMP(1);
+	__syncthreads();
+	SW_STAMP(2);
+	// ---- from here on every wave is on its own ----
+	const int lo = SW_HALO + wave * 64, wend = lo + 64 + SW_HALO; // own slots [lo, lo+64), window [lo-SW_HALO, wend)
+	// Later partners of a slot l: the run (l, e) with e = the first slot whose sort key (contig, cs) is not below
+	// (contig_l, ce_l); the keys are non-decreasing, so four candidates are tested per round trip to LDS and the tests are
+	// independent.  Lane t looks after its own slot and, the first SW_HALO lanes, after a slot of the left context, whose
+	// run matters from the wave's first hit on.
+	const int l1 = lo + lane, l0 = lo - SW_HALO + (lane & (SW_HALO - 1));
+	int m1 = l1 + 1, m0 = lo, c1, c0;
+	{
+		const int4 a1 = sA[l1], a0 = sA[l0];
+		const unsigned long long t1 = (unsigned long long)(uint32_t)a1.y << 32 | (uint32_t)a1.z, t0 = (unsigned long long)(uint32_t)a0.y << 32 | (uint32_t)a0.z;
+		bool go1 = !(sF[l1] & PGA_F_FLT), go0 = lane < SW_HALO && !(sF[l0] & PGA_F_FLT);
+		const int f1 = m1;
+		while (go0 || go1) {
+			unsigned long long q1[4], q0[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) q1[u] = *(const unsigned long long *)&sA[m1 + u], q0[u] = *(const unsigned long long *)&sA[m0 + u];
+			int n1 = 0, n0 = 0;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) n1 += q1[u] < t1 ? 1 : 0, n0 += q0[u] < t0 ? 1 : 0;
+			n1 = go1 ? n1 : 0, n0 = go0 ? n0 : 0;
+			m1 += n1, m0 += n0;
+			go1 = n1 == 4 && m1 < wend, go0 = n0 == 4 && m0 < wend;
+		}
+		c1 = (m1 < wend ? m1 : wend) - f1, c0 = (m0 < wend ? m0 : wend) - lo;
+	}
+	SW_STAMP(3);
+	// The pair list, k-th partners of all slots together: their places follow from one ballot, no prefix sum needed.
+	int tot = 0;
+#pragma nounroll
+	for (int k = 0;; ++k) {
+		const unsigned long long mk = __ballot(c0 > k);
+		if (mk == 0) break;
+		const int at = tot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+		if (c0 > k && at < SW_WCAP) sPair[at] = (uint16_t)((lane & (SW_HALO - 1)) << 7 | k);
+		tot += __popcll(mk);
+	}
+#pragma nounroll
+	for (int k = 0;; ++k) {
+		const unsigned long long mk = __ballot(c1 > k);
+		if (mk == 0) break;
+		const int at = tot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+		if (c1 > k && at < SW_WCAP) sPair[at] = (uint16_t)((SW_HALO + lane) << 7 | (lane + 1 + k));
+		tot += __popcll(mk);
+	}
+	const bool listed = tot <= SW_WCAP; // wave-uniform
+	wave_sync();
+	SW_STAMP(4);
+	if (listed) {
+		// one pair per lane: slot l precedes slot m in the array (l is "j", m is "i" of overlap.c:126-154 / 76-87)
+		for (int p = lane; p < tot; p += 64) {
+			const uint32_t w = sPair[p];
+			const int l = lo - SW_HALO + (int)(w >> 7), m = lo + (int)(w & 127u);
+			const uint32_t fj = sF[l], fi = sF[m];
+			const int csj = sA[l].x, cej = sA[l].z, csi = sA[m].x, cei = sA[m].z;
+			const int4 bj = sB[l], bi = sB[m]; // {rk, gid, cds, pid}
+			bool ok = !((fj | fi) & PGA_F_FLT);
+			if (v.check_strand) ok = ok && !((fj ^ fi) & PGA_F_REV);
+			const bool same_gene = bj.y == bi.y;
+			if (MODE == 2) ok = ok && same_gene;
+			int x;
+			{
+				const int s0 = csj > csi ? csj : csi, e0 = cej < cei ? cej : cei;
+				x = e0 > s0 ? e0 - s0 : 0; // single-exon x single-exon: the CDS intersection is the interval intersection
+			}
+			bool i_loses = (uint32_t)bi.x < (uint32_t)bj.x;
+			// the C records only when a pair of the wave needs them: multi-exon hits, or two hits with the same score key
+			// (the same protein with the same score) whose order the rank decides
+			const bool multi = ok && ((fj | fi) & F_MULTI), tie = ok && bi.x == bj.x;
+			if (__ballot(multi || tie)) {
+				if (multi || tie) {
+					const int4 cj = STAGE_C ? sC[l] : v.C[base + l], ci = STAGE_C ? sC[m] : v.C[base + m]; // {rank, n_exon, off_exon, score_ori}
+					if (multi) x = cds_inter(v.exon, cj.z, cj.y, csj, cej, ci.z, ci.y, csi, cei);
+					if (tie) i_loses = ci.x > cj.x; // rank_i > rank_j
+				}
+			}
+			ok = ok && x > 0; // overlap.c:132
+			if (MODE != 2) {
+				const int mn = bi.z < bj.z ? bi.z : bj.z;
+				// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < min(cds): x/m is
+				// within 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
+				bool too_short;
+				if (v.min_ov == 0.5) too_short = 2u * (uint32_t)x < (uint32_t)mn;
+				else too_short = (double)x / (mn > 0 ? mn : 1) < v.min_ov;
+				ok = ok && (same_gene || !too_short);
+				const uint32_t wk_i = fi & PGA_F_WEAK_MASK, wk_j = fj & PGA_F_WEAK_MASK;
+				i_loses = (!same_gene && wk_i != wk_j) ? wk_i > wk_j : i_loses; // overlap.c:139-147
+			}
+			const int L = i_loses ? m : l, W = i_loses ? l : m, Lt = L - lo;
+			if (ok && (unsigned)Lt < 64u) {
+				const uint32_t rw = (uint32_t)(i_loses ? bj.x : bi.x);
+				const unsigned long long key = (unsigned long long)rw << 32 | 0x80000000u | (uint32_t)(1023 - W);
+				const unsigned long long old = atomicMax(&sKey[Lt], key);
+				if (MODE != 2 && rw != 0 && (uint32_t)(old >> 32) == rw) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, sA[L].y); } // hazard H3: two winners with one key
+			}
+		}
+		wave_sync();
+	}
+	SW_STAMP(5);
+	SW_STAMP(6);
+	{
+		const int h = tile * SW_TILE + wave * 64 + lane, lh = lo + lane;
+		const uint32_t fl = sF[lh];
+		if (h < v.n && !(fl & PGA_F_FLT)) { // filtered hits keep stale shadow/pid_dom (overlap.c:112)
+			const int4 a = sA[lh]; // {cs, seg, ce, pm}
+			// partners outside the window?  (pm = running max of ce is non-decreasing inside a contig)
+			const int4 w0 = sA[lo - SW_HALO], w1 = sA[wend - 1];
+			const bool open = (w0.y == a.y && w0.w > a.x) || (w1.y == a.y && w1.x < a.z);
+			if (!listed || open) {
+				const unsigned long long at = atomicAdd((unsigned long long *)v.slow_cnt, 1ull);
+				v.slow_list[at] = h;
+			} else {
+				const unsigned long long key = sKey[lane];
+				const bool lose = key != 0, has_dom = MODE != 2 && (key >> 32) != 0;
+				int pid_w = -1, ov = 0, cds_w = 1, so_w = 0, so_h = 0, cds_h = 1;
+				if (has_dom) {
+					const int W = 1023 - (int)(key & 1023u);
+					const int4 bw = sB[W];
+					pid_w = bw.w, cds_w = bw.z;
+					if (MODE == 1) {
+						const int4 aw = sA[W], cw = STAGE_C ? sC[W] : make_int4(0, 1, 0, sOri[W]), c2 = STAGE_C ? sC[lh] : make_int4(0, 1, 0, sOri[lh]);
+						so_w = cw.w, so_h = c2.w, cds_h = sB[lh].z;
+						const int s0 = aw.x > a.x ? aw.x : a.x, e0 = aw.z < a.z ? aw.z : a.z;
+						ov = e0 > s0 ? e0 - s0 : 0;
+						if (STAGE_C && ((fl | sF[W]) & F_MULTI)) { // the earlier hit goes first, as in the pair evaluation
+							const bool wf = W < lh;
+							ov = cds_inter(v.exon, wf ? cw.z : c2.z, wf ? cw.y : c2.y, wf ? aw.x : a.x, wf ? aw.z : a.z,
+							               wf ? c2.z : cw.z, wf ? c2.y : cw.y, wf ? a.x : aw.x, wf ? a.z : aw.z);
+						}
+					}
+				}
+				sw_finish<MODE>(v, h, fl, lose, has_dom, pid_w, ov, cds_h, cds_w, so_h, so_w);
+			}
+		}
+	}
+	SW_STAMP(7);
+}
+
+// The rare hits k_sweep could not finish inside its LDS window: one thread per listed hit walks all its partners in
+// global memory, in both directions (the plain thread-per-hit formulation of the sweep).
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *next_cnt)
+{
+	const long long n_slow = *v.slow_cnt;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *next_cnt = 0; // the counter the NEXT sweep will use (ping-pong; nobody reads it now)
+	for (long long q = blockIdx.x * (long long)BLOCK + threadIdx.x; q < n_slow; q += (long long)gridDim.x * BLOCK) {
+		const int h = v.slow_list[q];
+		const uint32_t fl = v.flags[h];
+		SwHit t;
+		const int4 ch = v.C[h];
+		{
+			const int4 a = sw_scse(v.A[h]), b = v.B[h];
+			t.sg = a.x, t.cs = a.y, t.ce = a.z, t.gid = b.y, t.cds = b.z, t.rank = ch.x, t.nex = ch.y, t.offx = ch.z;
+			t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
+			t.sc = (uint32_t)b.x;
+		}
+		SwBest r = { false, 0, -1, 0, -1, 0 };
+		// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so the
+		// walk stops at the first j whose pm is <= cs_h.
+		for (int j = h - 1; j >= 0; --j) {
+			const int4 a = sw_scse(v.A[j]);
+			if (a.x != t.sg || a.w <= t.cs) break;
+			sw_pair<MODE, true>(v, t, r, a, v.flags[j], v.B[j], v.C[j], j, a.z > t.cs);
+		}
+		// partners after h: every i with cs_i < ce_h
+		for (int i = h + 1; i < v.n; ++i) {
+			const int4 a = sw_scse(v.A[i]);
+			if (a.x != t.sg || a.y >= t.ce) break;
+			sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i, true);
+		}
+		sw_finish<MODE>(v, h, fl, r.lose, r.best > 0, r.pid, r.ov, t.cds, r.cds, ch.w, MODE == 1 && r.best > 0 ? v.C[r.j].w : 0);
+	}
+}

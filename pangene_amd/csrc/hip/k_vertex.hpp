@@ -1,0 +1,89 @@
+// k_vertex.hpp -- pg_gen_vtx per-genome part and pg_graph_flag_vtx.
+// Included by pga_backend.hip (one translation unit); uses the context types, BLOCK / WAVE and dev_prims.hpp from there.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// pg_gen_vtx, per-genome part (vertex.c:28-51)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_vtx1(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *pdom,
+                                                  int n, int Q, int32_t *cnt, uint32_t *dombits, int64_t words_per_genome, int64_t *dcnt)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h];
+	if ((f & PGA_F_FLT) || rank[h] != 0) return;
+	int g = gid[h];
+	if (f & PGA_F_SHADOW) {
+		if (pdom[h] < 0) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // vertex.c:38
+		atomicAdd(&cnt[Q + g], 1);
+	} else {
+		atomicAdd(&cnt[g], 1);
+		uint32_t old = atomicOr(&dombits[(int64_t)gnm[h] * words_per_genome + (g >> 5)], 1u << (g & 31));
+		if (old & (1u << (g & 31))) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // two rank-0 hits of one gene: cannot happen after hit.c:107-128
+	}
+}
+
+// Fold of the (genome, sub gene, dom gene) relation into one genome bitset per (sub, dom) pair, the form the host greedy
+// consumes (vertex.c:60-80 marks cell (genome, dom) for every genome of the pair).  A sub gene has very few distinct dom
+// genes, so each gene owns VTX_K slots: a slot is claimed for a dom gene with atomicCAS, the genome bit is an atomicOr.
+// A gene with more than VTX_K dom genes spills single-genome records into an overflow area.
+constexpr int VTX_K = 8;
+
+__global__ __launch_bounds__(BLOCK) void k_vtx_fold(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *pdom,
+                                                      const int32_t *prot_gid, const int32_t *ggl, int n, const uint32_t *dombits, int64_t words_per_genome,
+                                                      int32_t *dom_tab, unsigned long long *bits, int nw, unsigned long long *ovf, long long ovf_cap, int64_t *dcnt)
+{
+	const int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	const uint32_t f = flags[h];
+	if ((f & PGA_F_FLT) || rank[h] != 0 || !(f & PGA_F_SHADOW) || pdom[h] < 0) return;
+	const int j = gnm[h], D = prot_gid[pdom[h]], g = gid[h];
+	if (!(dombits[(int64_t)j * words_per_genome + (D >> 5)] >> (D & 31) & 1u)) return; // dom is not dominant in this genome: the greedy never looks
+	const int jg = ggl[j];
+	int k = 0;
+	for (; k < VTX_K; ++k) {
+		int32_t *p = &dom_tab[(int64_t)g * VTX_K + k];
+		int cur = *(volatile int32_t *)p;
+		if (cur < 0) cur = atomicCAS(p, -1, D), cur = cur < 0 ? D : cur;
+		if (cur == D) break;
+	}
+	if (k < VTX_K) {
+		atomicOr(&bits[((int64_t)g * VTX_K + k) * nw + (jg >> 6)], 1ull << (jg & 63));
+	} else {
+		const long long at = (long long)atomicAdd((unsigned long long *)&dcnt[0], 1ull);
+		if (at < ovf_cap) {
+			unsigned long long *r = ovf + at * (1 + nw);
+			r[0] = (unsigned long long)g << 20 | (unsigned long long)D;
+			for (int w = 0; w < nw; ++w) r[1 + w] = w == (jg >> 6) ? 1ull << (jg & 63) : 0ull;
+		}
+	}
+}
+
+struct InDomSet { const int32_t *tab; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{tab[i] >= 0 ? 1 : 0}; } };
+
+// slot -> record: key (sub << 20 | dom), then the genome words; also mails the record count (dcnt[10]) and the counters to the host
+__global__ __launch_bounds__(BLOCK) void k_vtx_compact(const int32_t *dom_tab, const int32_t *slot, int64_t n_slot, const unsigned long long *bits, int nw,
+                                                         unsigned long long *out, int64_t *dcnt, int64_t *host_box)
+{
+	const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (s >= n_slot) return;
+	const int D = dom_tab[s];
+	if (D >= 0) {
+		unsigned long long *r = out + (int64_t)slot[s] * (1 + nw);
+		r[0] = (unsigned long long)(s / VTX_K) << 20 | (unsigned long long)D;
+		for (int w = 0; w < nw; ++w) r[1 + w] = bits[s * nw + w];
+	}
+	if (s == n_slot - 1) {
+		dcnt[10] = slot[s] + (D >= 0 ? 1 : 0);
+		__threadfence();
+		for (int t = 0; t < 16; ++t) host_box[t] = dcnt[t];
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32_t *gid, int n, const int32_t *g2s) // graph.c:61-69
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	uint32_t f = flags[h], nf = g2s[gid[h]] >= 0 ? (f | PGA_F_VTX) : (f & ~PGA_F_VTX);
+	if (nf != f) flags[h] = nf;
+}

@@ -121,1390 +121,15 @@ extern "C" const char *pga_strerror(int code)
 	return "unknown";
 }
 
-// ------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t hash_u32(uint32_t key) // pg_hash_uint32, pgpriv.h:88-97
-{
-	key += ~(key << 15);
-	key ^=  (key >> 10);
-	key +=  (key << 3);
-	key ^=  (key >> 6);
-	key += ~(key << 11);
-	key ^=  (key >> 16);
-	return key;
-}
-
-__global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v)
-{
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i < n) p[i] = v;
-}
-
-// mailbox[k] = a[0] + b[0]: totals of a scan land in the device mailbox so that one 128-byte copy brings every
-// size the host needs (one round trip instead of one per value)
-// dcnt[10] = a[0] + b[0] (element count after a compaction scan), then all 16 device counters go straight into the pinned
-// host mirror: the host reads them after the stream sync without a separate copy command
-__global__ void k_mail_sum(const int32_t *a, const int32_t *b, int64_t *dcnt, int64_t *host_box)
-{
-	if (threadIdx.x == 0) dcnt[10] = (int64_t)a[0] + b[0];
-	__syncthreads();
-	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
-}
-
-__global__ void k_mail_flush(const int64_t *dcnt, int64_t *host_box)
-{
-	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
-}
-
-struct ZeroList { void *p[4]; unsigned long long dwords[4]; };
-// several small clears in one launch (each hipMemsetAsync is a launch of its own; a round needs a dozen of them)
-__global__ __launch_bounds__(BLOCK) void k_zero_multi(ZeroList z)
-{
-	unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		if (i < z.dwords[k]) { ((uint32_t *)z.p[k])[i] = 0; return; }
-		i -= z.dwords[k];
-	}
-}
-
-__device__ __forceinline__ int genome_of(const int32_t *goff, int n_genome, int i) // last g with goff[g] <= i
-{
-	int lo = 0, hi = n_genome;
-	while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (goff[mid] <= i) lo = mid; else hi = mid; }
-	return lo;
-}
-
-// ------------------------------------------------------------------------------------------------
-// create: derive per-hit constants in file order, sort into X order, gather, pm, Y order
-// ------------------------------------------------------------------------------------------------
-struct FileHits { const int32_t *pid, *cid, *rank, *sori, *sadj, *nex, *offx, *cs, *ce, *cm; const uint8_t *rev; };
-
-__global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int32_t *goff, int n_genome, const int32_t *ctg_base,
-                                                     const int2 *exon, const int32_t *prot_gid, const uint8_t *gene_pref,
-                                                     int32_t *gnm_f, int32_t *seg_f, int32_t *gid_f, int32_t *cds_f, uint64_t *key, uint32_t *val)
-{
-	int i = blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= n) return;
-	int g = genome_of(goff, n_genome, i);
-	// skip empty genomes that share the same offset: genome_of returns the LAST g with goff[g] <= i, which is the owner
-	int sg = ctg_base[g] + f.cid[i];
-	int gid = prot_gid[f.pid[i]];
-	int len = 0, ne = f.nex[i], ox = f.offx[i];
-	for (int e = 0; e < ne; ++e) { int2 x = exon[ox + e]; len += x.y - x.x; } // pg_cds_len, overlap.c:45-51
-	gnm_f[i] = g, seg_f[i] = sg, gid_f[i] = gid, cds_f[i] = len;
-	key[i] = (uint64_t)(int64_t)f.sadj[i] << 33 | (uint64_t)gene_pref[gid] << 32 | hash_u32((uint32_t)f.pid[i]); // the score key of overlap.c:137
-	val[i] = (uint32_t)i;
-}
-
-// The sweep only ever COMPARES score keys, so every hit gets the dense rank of its key over the shard (one sort per
-// run): 32-bit compares instead of 64-bit ones, and rank and partner slot fit one 64-bit word for a single LDS
-// atomicMax ("best winner, first in array order").  Key 0 keeps rank 0: such a hit never becomes a dominator.
-__global__ __launch_bounds__(BLOCK) void k_rank_scatter(const uint64_t *ks, const uint32_t *vs, const int32_t *incl, int n, int32_t *rk_f)
-{
-	int i = blockIdx.x * BLOCK + threadIdx.x;
-	if (i < n) rk_f[vs[i]] = ks[i] == 0 ? 0 : incl[i]; // incl >= 1; when key 0 exists it owns rank value 1, which then stays unused
-}
-
-__global__ __launch_bounds__(BLOCK) void k_xkey(const int32_t *seg_f, const int32_t *cs_f, int n, int cs_bits, uint64_t *key, uint32_t *val)
-{
-	int i = blockIdx.x * BLOCK + threadIdx.x;
-	if (i < n) key[i] = (uint64_t)seg_f[i] << cs_bits | (uint32_t)cs_f[i], val[i] = (uint32_t)i;
-}
-
-struct HitArrays {
-	int32_t *fidx, *gnm, *seg, *pid, *gid, *cs, *ce, *cm, *cds, *nex, *offx, *sori, *sadj, *rank, *sdom, *pdom, *pdom0;
-	int32_t *rk; uint32_t *flags;
-};
-
-__global__ __launch_bounds__(BLOCK) void k_gather(FileHits f, const int32_t *gnm_f, const int32_t *seg_f, const int32_t *gid_f, const int32_t *cds_f,
-                                                    const int32_t *rk_f, const uint32_t *perm, int n, const int32_t *goff, HitArrays o)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	int s = (int)perm[h];
-	int g = gnm_f[s];
-	o.fidx[h] = s - goff[g], o.gnm[h] = g, o.seg[h] = seg_f[s], o.pid[h] = f.pid[s], o.gid[h] = gid_f[s];
-	o.cs[h] = f.cs[s], o.ce[h] = f.ce[s], o.cm[h] = f.cm[s], o.cds[h] = cds_f[s], o.nex[h] = f.nex[s], o.offx[h] = f.offx[s];
-	o.sori[h] = f.sori[s], o.sadj[h] = f.sadj[s], o.rank[h] = f.rank[s], o.rk[h] = rk_f[s];
-	o.sdom[h] = 0, o.pdom[h] = -1, o.pdom0[h] = 0; // read.c:133-134
-	o.flags[h] = (f.rev[s] ? PGA_F_REV : 0u) | (h == goff[g] ? F_HEAD : 0u) | (f.nex[s] != 1 ? F_MULTI : 0u);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_ykey(const int32_t *seg, const int32_t *cm, int n, int cm_bits, uint64_t *key, uint32_t *val)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	key[h] = (uint64_t)seg[h] << cm_bits | (uint32_t)cm[h];
-	val[h] = (uint32_t)h;
-}
-
-// ------------------------------------------------------------------------------------------------
-// pg_flag_pseudo (hit.c:66-105) with a (genome, protein) table instead of a sort by pid<<32|rank
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_pseudo1(const int32_t *gnm, const int32_t *pid, const int32_t *nex, int n, int P, int32_t *tmax, int32_t *tmin)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	int64_t t = (int64_t)gnm[h] * P + pid[h];
-	atomicMax(&tmax[t], nex[h]);
-	atomicMin(&tmin[t], nex[h]);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_pseudo2(const int32_t *gnm, const int32_t *pid, const int32_t *nex, const int32_t *rank, uint32_t *flags,
-                                                     int n, int P, const int32_t *tmax, const int32_t *tmin, int32_t *tr1, int32_t *stats)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	int64_t t = (int64_t)gnm[h] * P + pid[h];
-	int mx = tmax[t], mn = tmin[t], ne = nex[h];
-	if (!(mx > 1 && (mn == 1 || mn * 2 <= mx))) return; // hit.c:84
-	if (ne == 1 || ne * 2 <= mx) {
-		flags[h] |= PGA_F_PSEUDO | PGA_F_FLT; // hit.c:89 + PG_SET_FILTER(pseudo), read.c:246
-		atomicAdd(&stats[gnm[h] * 4 + 0], 1);
-	} else atomicMin(&tr1[t], rank[h]);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_pseudo3(const int32_t *gnm, const int32_t *pid, int32_t *rank, int n, int P,
-                                                     const int32_t *tmax, const int32_t *tmin, const int32_t *tr1)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	int64_t t = (int64_t)gnm[h] * P + pid[h];
-	int mx = tmax[t], mn = tmin[t], r1 = tr1[t];
-	if (!(mx > 1 && (mn == 1 || mn * 2 <= mx)) || r1 == INT32_MAX || r1 == 0) return;
-	int r = rank[h];
-	if (r < r1) rank[h] = r + 1; // hit.c:95-97
-	else if (r == r1) rank[h] = 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// the interval-dominance sweep: pg_shadow (overlap.c:101-178) and pg_flt_ov_isoform (58-93)
-// ------------------------------------------------------------------------------------------------
-// Packed per-hit records for the sweep: a partner costs 16-byte loads instead of a dozen 4-byte ones.
-//   A = {cs, seg, ce, pm}   B = {rk, gid, cds, pid}   C = {rank, n_exon, off_exon, score_ori}
-// (A.xy read as one 64-bit word is seg << 32 | cs: the sort key of the X order, non-decreasing along the array)
-// C is only needed for multi-exon hits, for two hits with the same score key and for score_dom.
-__global__ __launch_bounds__(BLOCK) void k_pack_rec(const int32_t *seg, const int32_t *cs, const int32_t *ce, const int32_t *pm, const int32_t *rk,
-                                                      const int32_t *gid, const int32_t *cds, const int32_t *rank, const int32_t *nex, const int32_t *offx,
-                                                      const int32_t *pid, const int32_t *sori, int n, int4 *A, int4 *B, int4 *C)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	A[h] = make_int4(cs[h], seg[h], ce[h], pm[h]);
-	B[h] = make_int4(rk[h], gid[h], cds[h], pid[h]);
-	C[h] = make_int4(rank[h], nex[h], offx[h], sori[h]);
-}
-
-// where a tie-order hazard (h2_cm_tie / h3_dom_tie) happened: contig-segment ids, at most PGA_HAZARD_CAP of them (counter: dcnt[14])
-__device__ __forceinline__ void hz_note(int64_t *cnt14, int32_t *list, int seg)
-{
-	const unsigned long long at = atomicAdd((unsigned long long *)cnt14, 1ull);
-	if (at < (unsigned long long)PGA_HAZARD_CAP) list[at] = seg;
-}
-
-struct SweepView {
-	const int4 *A, *B, *C; const int32_t *sori; const int2 *exon;
-	uint32_t *flags; int32_t *pdom, *sdom;
-	int n; double min_ov; int check_strand;
-	int stage_c; // some hit of the shard has several exons: stage the C records with the others
-	int64_t *hz;
-	int64_t *slow_cnt; int32_t *slow_list; // work list for k_sweep_slow
-	long long *prof; // PGA_SW_PROFILE builds only
-	int32_t *hz_list; // hz[10] (= dcnt[14]) counts its entries
-};
-
-// CDS intersection of hit a (exons ea[na], start ca) and hit b: pg_hit_overlap, overlap.c:6-42
-__device__ __forceinline__ int cds_inter(const int2 *__restrict__ ex, int oa, int na, int ca, int ea_end, int ob, int nb, int cb, int eb_end)
-{
-	if (!(ca < eb_end && ea_end > cb)) return 0;
-	if (na == 1 && nb == 1) { // single-exon x single-exon: plain interval intersection
-		int s = ca > cb ? ca : cb, e = ea_end < eb_end ? ea_end : eb_end;
-		return e > s ? e - s : 0;
-	}
-	int ia = 0, ib = 0, inter = 0;
-	int2 xa = ex[oa], xb = ex[ob];
-	while (true) {
-		int s0 = ca + xa.x, e0 = ca + xa.y, s1 = cb + xb.x, e1 = cb + xb.y;
-		bool adv_a;
-		if (s0 < s1) {
-			if (e0 < e1) { int o = e0 - s1; inter += o > 0 ? o : 0; adv_a = true; }
-			else { inter += e1 - s1; adv_a = false; }
-		} else {
-			if (e1 < e0) { int o = e1 - s0; inter += o > 0 ? o : 0; adv_a = false; }
-			else { inter += e0 - s0; adv_a = true; }
-		}
-		if (adv_a) { if (++ia >= na) break; xa = ex[oa + ia]; }
-		else { if (++ib >= nb) break; xb = ex[ob + ib]; }
-	}
-	return inter;
-}
-
-struct SwHit { // the hit a thread works for
-	int sg, cs, ce, gid, cds, rank, nex, offx, weak; uint32_t fl; uint32_t sc;
-};
-struct SwBest { bool lose; uint32_t best; int j, ov, pid, cds; };
-
-// Thread-per-hit form of one pair, used by k_sweep_slow: partner p (records a/b/c, flags fp, array index pi) of hit t;
-// EARLIER: p precedes t in the array.  overlap.c:126-154 (pg_shadow) / 76-87 (pg_flt_ov_isoform).
-__device__ __forceinline__ int4 sw_scse(int4 r) { return make_int4(r.y, r.x, r.z, r.w); } // record A -> (seg, cs, ce, pm)
-
-template <int MODE, bool EARLIER>
-__device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBest &r, const int4 a, const uint32_t fp, const int4 b, const int4 c, int pi, bool ok)
-{
-	ok = ok && !(fp & PGA_F_FLT);
-	if (v.check_strand) ok = ok && !((fp ^ t.fl) & PGA_F_REV);
-	const bool same_gene = b.y == t.gid;
-	if (MODE == 2) ok = ok && same_gene;
-	const int x = !ok ? 0 : EARLIER ? cds_inter(v.exon, c.z, c.y, a.y, a.z, t.offx, t.nex, t.cs, t.ce)
-	                                : cds_inter(v.exon, t.offx, t.nex, t.cs, t.ce, c.z, c.y, a.y, a.z);
-	ok = ok && x > 0; // overlap.c:132
-	const uint32_t sp = (uint32_t)b.x;
-	// "i" of the reference is the later hit of the pair: i loses if (si < sj || (si == sj && rank_i > rank_j))
-	const uint32_t s_i = EARLIER ? t.sc : sp, s_j = EARLIER ? sp : t.sc;
-	const int rk_i = EARLIER ? t.rank : c.x, rk_j = EARLIER ? c.x : t.rank;
-	bool i_loses = s_i < s_j || (s_i == s_j && rk_i > rk_j);
-	if (MODE != 2) {
-		const int m = t.cds < b.z ? t.cds : b.z;
-		// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < m: x/m is within
-		// 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
-		bool too_short;
-		if (v.min_ov == 0.5) too_short = 2u * (uint32_t)x < (uint32_t)m;
-		else too_short = (double)x / (m > 0 ? m : 1) < v.min_ov;
-		ok = ok && (same_gene || !too_short);
-		const int wk_p = (int)((fp & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
-		const int wk_i = EARLIER ? t.weak : wk_p, wk_j = EARLIER ? wk_p : t.weak;
-		i_loses = (!same_gene && wk_i != wk_j) ? wk_i > wk_j : i_loses; // overlap.c:139-147
-	}
-	const bool t_loses = ok && (EARLIER ? i_loses : !i_loses);
-	r.lose = r.lose || t_loses;
-	if (MODE == 2) return;
-	// dominator = best-scoring winner, first in array order on ties (overlap.c:150,153).  Earlier partners are visited in
-	// DEscending index order, so an equal score replaces; later partners in ascending order, so it does not.
-	const bool upd = t_loses && (EARLIER ? (sp > 0 && sp >= r.best) : (sp > r.best));
-	if (t_loses && sp == r.best && sp > 0) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, t.sg); } // hazard H3, rare
-	r.best = upd ? sp : r.best, r.j = upd ? pi : r.j, r.ov = upd ? x : r.ov, r.pid = upd ? b.w : r.pid, r.cds = upd ? b.z : r.cds;
-}
-
-__device__ __forceinline__ void wave_sync() // LDS hand-over between lanes of ONE wave (the LDS queue of a wave is in order)
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// exclusive prefix sum over the wave of a small count (c < 256), one ballot per bit: no LDS traffic, no cross-lane moves
-__device__ __forceinline__ int wave_scan_small(int c, int *total)
-{
-	int off = 0, tot = 0;
-#pragma unroll
-	for (int b = 0; b < 8; ++b) {
-		const unsigned long long mk = __ballot((c >> b) & 1);
-		off += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u)) << b;
-		tot += __popcll(mk) << b;
-	}
-	*total = tot;
-	return off;
-}
-
-// The interval-dominance sweep as an LDS pair list.
-//
-// A workgroup stages SW_TILE consecutive hits (cs order) plus SW_HALO neighbours on each side (36 B/hit, 52 when the C
-// records are needed; coalesced 16-byte loads) and after ONE barrier its waves work independently: a wave owns 64 hits
-// and looks at a window of SW_HALO more slots on each side.  Because hits are cs-sorted inside a contig, the later
-// partners of a hit are a contiguous run; the runs are counted, prefix-summed over the wave and expanded into a list
-// of (earlier, later) slot pairs with at least one member among the wave's hits.  The list is evaluated one pair per
-// lane (full lanes, every pair once -- a thread-per-hit walk evaluates each pair twice and runs as long as the busiest
-// lane).  The outcome reaches the loser as ONE 64-bit LDS atomicMax of (winner's score rank, "lost" bit, inverted
-// winner slot): the maximum is the best-scoring winner and, among equals, the first in array order (overlap.c:150).
-// Pairs across a wave or tile border are evaluated by both sides, each updating only its own hit: no global atomics,
-// no inter-wave synchronisation.  Hits whose partners reach beyond the window, and waves whose list overflows, go
-// to a work list for k_sweep_slow.
-// MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform
-constexpr int SW_HALO = 32, SW_TILE = 256, SW_LDS = SW_TILE + 2 * SW_HALO, SW_WCAP = 512, SW_NW = SW_TILE / 64;
-
-#ifdef PGA_SW_PROFILE // tuning build: s_memtime stamps of lane 0 of every wave at the phase boundaries
-#define SW_STAMP(k) do { if (v.prof && (threadIdx.x & 63) == 0) v.prof[((long long)blockIdx.x * SW_NW + (threadIdx.x >> 6)) * 8 + (k)] = clock64(); } while (0)
-#else
-#define SW_STAMP(k) do { } while (0)
-#endif
-
-// epilogue of a hit, overlap.c:157-175.  The hit at index 0 of a genome is never reset (loop starts at 1, overlap.c:108).
-template <int MODE>
-__device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl, bool lose, bool has_dom, int pid_w, int ov, int cds_h, int cds_w, int sori_h, int sori_w)
-{
-	if (MODE == 2) {
-		if (lose) v.flags[h] = fl | PGA_F_ISO_OV;
-		return;
-	}
-	uint32_t nf = (fl & F_HEAD) ? fl : (fl & ~PGA_F_SHADOW);
-	if (lose) nf |= PGA_F_SHADOW;
-	if (nf != fl) v.flags[h] = nf;
-	v.pdom[h] = has_dom ? pid_w : -1;
-	if (MODE == 1) {
-		int sd = -1;
-		if (has_dom) sd = (int32_t)(sori_h * (1.0 - (double)ov / cds_h) + sori_w * ((double)ov / cds_w) + .499); // overlap.c:170
-		v.sdom[h] = sd;
-	}
-}
-
-template <int MODE, bool STAGE_C>
-__global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
-{
-	static_assert(2 * SW_HALO == 64 && SW_NW == 4 && SW_LDS <= 1024 && 64 + 2 * SW_HALO <= 128, "the slots past SW_TILE are staged one array per wave; window-relative slot ids are packed in 7 bits, winner slots in 10");
-	constexpr bool STAGE_ORI = MODE == 1 && !STAGE_C; // score_dom needs score_ori: out of the C records when they are staged, else staged alone
-	__shared__ int4 sA[SW_LDS + 4], sB[SW_LDS], sC[STAGE_C ? SW_LDS : 1]; // sA: four sentinel slots close the array
-	__shared__ uint32_t sF[SW_LDS];
-	__shared__ int32_t sOri[STAGE_ORI ? SW_LDS : 1];
-	__shared__ uint16_t sPairAll[SW_NW][SW_WCAP]; // (earlier slot - window start) << 7 | (later slot - first own slot): both < 96
-	__shared__ unsigned long long sKeyAll[SW_NW][64];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	uint16_t *sPair = sPairAll[wave];
-	unsigned long long *sKey = sKeyAll[wave];
-	const int tile = blockIdx.x, base = tile * SW_TILE - SW_HALO;
-	SW_STAMP(0);
-	{
-		const int g = base + tid;
-		int4 a = make_int4(0, -2, 0, 0), b = make_int4(0, 0, 0, 0), c = b; // slots outside the array: contig -2, filtered
-		uint32_t f = PGA_F_FLT;
-		int32_t so = 0;
-		if (g >= 0 && g < v.n) {
-			a = v.A[g], b = v.B[g], f = v.flags[g];
-			if (STAGE_C) c = v.C[g];
-			if (STAGE_ORI) so = v.sori[g];
-		}
-		// the 2 * SW_HALO slots past SW_TILE: one array per wave, so that no wave has more to stage than the others
-		const int l2 = SW_TILE + lane, g2 = base + l2;
-		const bool in2 = lane < 2 * SW_HALO && g2 >= 0 && g2 < v.n;
-		if (wave == 0) sA[l2] = in2 ? v.A[g2] : make_int4(0, -2, 0, 0);
-		else if (wave == 1) sB[l2] = in2 ? v.B[g2] : make_int4(0, 0, 0, 0);
-		else if (wave == 2) sF[l2] = in2 ? v.flags[g2] : PGA_F_FLT;
-		else if (STAGE_C) sC[l2] = in2 ? v.C[g2] : make_int4(0, 0, 0, 0);
-		else if (STAGE_ORI) sOri[l2] = in2 ? v.sori[g2] : 0;
-		sA[tid] = a, sB[tid] = b, sF[tid] = f;
-		if (STAGE_C) sC[tid] = c;
-		if (STAGE_ORI) sOri[tid] = so;
-	}
-	if (tid < 4) sA[SW_LDS + tid] = make_int4(0, -2, 0, 0);
-	sKey[lane] = 0;
-	SW_STAMP(1);
-	__syncthreads();
-	SW_STAMP(2);
-	// ---- from here on every wave is on its own ----
-	const int lo = SW_HALO + wave * 64, wend = lo + 64 + SW_HALO; // own slots [lo, lo+64), window [lo-SW_HALO, wend)
-	// Later partners of a slot l: the run (l, e) with e = the first slot whose sort key (contig, cs) is not below
-	// (contig_l, ce_l); the keys are non-decreasing, so four candidates are tested per round trip to LDS and the tests are
-	// independent.  Lane t looks after its own slot and, the first SW_HALO lanes, after a slot of the left context, whose
-	// run matters from the wave's first hit on.
-	const int l1 = lo + lane, l0 = lo - SW_HALO + (lane & (SW_HALO - 1));
-	int m1 = l1 + 1, m0 = lo, c1, c0;
-	{
-		const int4 a1 = sA[l1], a0 = sA[l0];
-		const unsigned long long t1 = (unsigned long long)(uint32_t)a1.y << 32 | (uint32_t)a1.z, t0 = (unsigned long long)(uint32_t)a0.y << 32 | (uint32_t)a0.z;
-		bool go1 = !(sF[l1] & PGA_F_FLT), go0 = lane < SW_HALO && !(sF[l0] & PGA_F_FLT);
-		const int f1 = m1;
-		while (go0 || go1) {
-			unsigned long long q1[4], q0[4];
-#pragma unroll
-			for (int u = 0; u < 4; ++u) q1[u] = *(const unsigned long long *)&sA[m1 + u], q0[u] = *(const unsigned long long *)&sA[m0 + u];
-			int n1 = 0, n0 = 0;
-#pragma unroll
-			for (int u = 0; u < 4; ++u) n1 += q1[u] < t1 ? 1 : 0, n0 += q0[u] < t0 ? 1 : 0;
-			n1 = go1 ? n1 : 0, n0 = go0 ? n0 : 0;
-			m1 += n1, m0 += n0;
-			go1 = n1 == 4 && m1 < wend, go0 = n0 == 4 && m0 < wend;
-		}
-		c1 = (m1 < wend ? m1 : wend) - f1, c0 = (m0 < wend ? m0 : wend) - lo;
-	}
-	SW_STAMP(3);
-	// The pair list, k-th partners of all slots together: their places follow from one ballot, no prefix sum needed.
-	int tot = 0;
-#pragma nounroll
-	for (int k = 0;; ++k) {
-		const unsigned long long mk = __ballot(c0 > k);
-		if (mk == 0) break;
-		const int at = tot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-		if (c0 > k && at < SW_WCAP) sPair[at] = (uint16_t)((lane & (SW_HALO - 1)) << 7 | k);
-		tot += __popcll(mk);
-	}
-#pragma nounroll
-	for (int k = 0;; ++k) {
-		const unsigned long long mk = __ballot(c1 > k);
-		if (mk == 0) break;
-		const int at = tot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-		if (c1 > k && at < SW_WCAP) sPair[at] = (uint16_t)((SW_HALO + lane) << 7 | (lane + 1 + k));
-		tot += __popcll(mk);
-	}
-	const bool listed = tot <= SW_WCAP; // wave-uniform
-	wave_sync();
-	SW_STAMP(4);
-	if (listed) {
-		// one pair per lane: slot l precedes slot m in the array (l is "j", m is "i" of overlap.c:126-154 / 76-87)
-		for (int p = lane; p < tot; p += 64) {
-			const uint32_t w = sPair[p];
-			const int l = lo - SW_HALO + (int)(w >> 7), m = lo + (int)(w & 127u);
-			const uint32_t fj = sF[l], fi = sF[m];
-			const int csj = sA[l].x, cej = sA[l].z, csi = sA[m].x, cei = sA[m].z;
-			const int4 bj = sB[l], bi = sB[m]; // {rk, gid, cds, pid}
-			bool ok = !((fj | fi) & PGA_F_FLT);
-			if (v.check_strand) ok = ok && !((fj ^ fi) & PGA_F_REV);
-			const bool same_gene = bj.y == bi.y;
-			if (MODE == 2) ok = ok && same_gene;
-			int x;
-			{
-				const int s0 = csj > csi ? csj : csi, e0 = cej < cei ? cej : cei;
-				x = e0 > s0 ? e0 - s0 : 0; // single-exon x single-exon: the CDS intersection is the interval intersection
-			}
-			bool i_loses = (uint32_t)bi.x < (uint32_t)bj.x;
-			// the C records only when a pair of the wave needs them: multi-exon hits, or two hits with the same score key
-			// (the same protein with the same score) whose order the rank decides
-			const bool multi = ok && ((fj | fi) & F_MULTI), tie = ok && bi.x == bj.x;
-			if (__ballot(multi || tie)) {
-				if (multi || tie) {
-					const int4 cj = STAGE_C ? sC[l] : v.C[base + l], ci = STAGE_C ? sC[m] : v.C[base + m]; // {rank, n_exon, off_exon, score_ori}
-					if (multi) x = cds_inter(v.exon, cj.z, cj.y, csj, cej, ci.z, ci.y, csi, cei);
-					if (tie) i_loses = ci.x > cj.x; // rank_i > rank_j
-				}
-			}
-			ok = ok && x > 0; // overlap.c:132
-			if (MODE != 2) {
-				const int mn = bi.z < bj.z ? bi.z : bj.z;
-				// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < min(cds): x/m is
-				// within 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
-				bool too_short;
-				if (v.min_ov == 0.5) too_short = 2u * (uint32_t)x < (uint32_t)mn;
-				else too_short = (double)x / (mn > 0 ? mn : 1) < v.min_ov;
-				ok = ok && (same_gene || !too_short);
-				const uint32_t wk_i = fi & PGA_F_WEAK_MASK, wk_j = fj & PGA_F_WEAK_MASK;
-				i_loses = (!same_gene && wk_i != wk_j) ? wk_i > wk_j : i_loses; // overlap.c:139-147
-			}
-			const int L = i_loses ? m : l, W = i_loses ? l : m, Lt = L - lo;
-			if (ok && (unsigned)Lt < 64u) {
-				const uint32_t rw = (uint32_t)(i_loses ? bj.x : bi.x);
-				const unsigned long long key = (unsigned long long)rw << 32 | 0x80000000u | (uint32_t)(1023 - W);
-				const unsigned long long old = atomicMax(&sKey[Lt], key);
-				if (MODE != 2 && rw != 0 && (uint32_t)(old >> 32) == rw) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, sA[L].y); } // hazard H3: two winners with one key
-			}
-		}
-		wave_sync();
-	}
-	SW_STAMP(5);
-	SW_STAMP(6);
-	{
-		const int h = tile * SW_TILE + wave * 64 + lane, lh = lo + lane;
-		const uint32_t fl = sF[lh];
-		if (h < v.n && !(fl & PGA_F_FLT)) { // filtered hits keep stale shadow/pid_dom (overlap.c:112)
-			const int4 a = sA[lh]; // {cs, seg, ce, pm}
-			// partners outside the window?  (pm = running max of ce is non-decreasing inside a contig)
-			const int4 w0 = sA[lo - SW_HALO], w1 = sA[wend - 1];
-			const bool open = (w0.y == a.y && w0.w > a.x) || (w1.y == a.y && w1.x < a.z);
-			if (!listed || open) {
-				const unsigned long long at = atomicAdd((unsigned long long *)v.slow_cnt, 1ull);
-				v.slow_list[at] = h;
-			} else {
-				const unsigned long long key = sKey[lane];
-				const bool lose = key != 0, has_dom = MODE != 2 && (key >> 32) != 0;
-				int pid_w = -1, ov = 0, cds_w = 1, so_w = 0, so_h = 0, cds_h = 1;
-				if (has_dom) {
-					const int W = 1023 - (int)(key & 1023u);
-					const int4 bw = sB[W];
-					pid_w = bw.w, cds_w = bw.z;
-					if (MODE == 1) {
-						const int4 aw = sA[W], cw = STAGE_C ? sC[W] : make_int4(0, 1, 0, sOri[W]), c2 = STAGE_C ? sC[lh] : make_int4(0, 1, 0, sOri[lh]);
-						so_w = cw.w, so_h = c2.w, cds_h = sB[lh].z;
-						const int s0 = aw.x > a.x ? aw.x : a.x, e0 = aw.z < a.z ? aw.z : a.z;
-						ov = e0 > s0 ? e0 - s0 : 0;
-						if (STAGE_C && ((fl | sF[W]) & F_MULTI)) { // the earlier hit goes first, as in the pair evaluation
-							const bool wf = W < lh;
-							ov = cds_inter(v.exon, wf ? cw.z : c2.z, wf ? cw.y : c2.y, wf ? aw.x : a.x, wf ? aw.z : a.z,
-							               wf ? c2.z : cw.z, wf ? c2.y : cw.y, wf ? a.x : aw.x, wf ? a.z : aw.z);
-						}
-					}
-				}
-				sw_finish<MODE>(v, h, fl, lose, has_dom, pid_w, ov, cds_h, cds_w, so_h, so_w);
-			}
-		}
-	}
-	SW_STAMP(7);
-}
-
-// The rare hits k_sweep could not finish inside its LDS window: one thread per listed hit walks all its partners in
-// global memory, in both directions (the plain thread-per-hit formulation of the sweep).
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *next_cnt)
-{
-	const long long n_slow = *v.slow_cnt;
-	if (blockIdx.x == 0 && threadIdx.x == 0) *next_cnt = 0; // the counter the NEXT sweep will use (ping-pong; nobody reads it now)
-	for (long long q = blockIdx.x * (long long)BLOCK + threadIdx.x; q < n_slow; q += (long long)gridDim.x * BLOCK) {
-		const int h = v.slow_list[q];
-		const uint32_t fl = v.flags[h];
-		SwHit t;
-		const int4 ch = v.C[h];
-		{
-			const int4 a = sw_scse(v.A[h]), b = v.B[h];
-			t.sg = a.x, t.cs = a.y, t.ce = a.z, t.gid = b.y, t.cds = b.z, t.rank = ch.x, t.nex = ch.y, t.offx = ch.z;
-			t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
-			t.sc = (uint32_t)b.x;
-		}
-		SwBest r = { false, 0, -1, 0, -1, 0 };
-		// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so the
-		// walk stops at the first j whose pm is <= cs_h.
-		for (int j = h - 1; j >= 0; --j) {
-			const int4 a = sw_scse(v.A[j]);
-			if (a.x != t.sg || a.w <= t.cs) break;
-			sw_pair<MODE, true>(v, t, r, a, v.flags[j], v.B[j], v.C[j], j, a.z > t.cs);
-		}
-		// partners after h: every i with cs_i < ce_h
-		for (int i = h + 1; i < v.n; ++i) {
-			const int4 a = sw_scse(v.A[i]);
-			if (a.x != t.sg || a.y >= t.ce) break;
-			sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i, true);
-		}
-		sw_finish<MODE>(v, h, fl, r.lose, r.best > 0, r.pid, r.ov, t.cds, r.cds, ch.w, MODE == 1 && r.best > 0 ? v.C[r.j].w : 0);
-	}
-}
-
-// log-only counters (graph.c:23-27).  Hits are genome-major, so a workgroup mostly sees one genome: count
-// that genome in LDS and add once; stragglers of the next genome go to global memory directly.
-__global__ __launch_bounds__(BLOCK) void k_count_shadow(const uint32_t *flags, const int32_t *gnm, int n, int32_t *stats)
-{
-	__shared__ int s_cnt[2];
-	__shared__ int s_g;
-	const int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (threadIdx.x == 0) s_cnt[0] = s_cnt[1] = 0, s_g = gnm[blockIdx.x * BLOCK];
-	__syncthreads();
-	if (h < n) {
-		const uint32_t f = flags[h];
-		if (!(f & PGA_F_FLT)) {
-			const int g = gnm[h];
-			if (g == s_g) { atomicAdd(&s_cnt[0], 1); if (f & PGA_F_SHADOW) atomicAdd(&s_cnt[1], 1); }
-			else { atomicAdd(&stats[g * 2], 1); if (f & PGA_F_SHADOW) atomicAdd(&stats[g * 2 + 1], 1); }
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		if (s_cnt[0]) atomicAdd(&stats[s_g * 2], s_cnt[0]);
-		if (s_cnt[1]) atomicAdd(&stats[s_g * 2 + 1], s_cnt[1]);
-	}
-}
-
-// read.c:249-253
-__global__ __launch_bounds__(BLOCK) void k_ingest_reset(uint32_t *flags, int32_t *pdom, int32_t *pdom0, int n)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	pdom0[h] = pdom[h];
-	pdom[h] = -1;
-	flags[h] &= ~PGA_F_SHADOW;
-}
-
-// tail of pg_flt_ov_isoform (overlap.c:89-91) + first loop of pg_flt_chain_shadow (hit.c:136-138)
-__global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int32_t *gnm, const int32_t *pid, int n, int P, int32_t *tiso, int32_t *stats)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	uint32_t f = flags[h];
-	if (f & PGA_F_ISO_OV) {
-		flags[h] = f | PGA_F_FLT;
-		atomicAdd(&stats[gnm[h] * 4 + 1], 1);
-	} else tiso[(int64_t)gnm[h] * P + pid[h]] = 0;
-}
-
-// second loop of pg_flt_chain_shadow (hit.c:139-143)
-__global__ __launch_bounds__(BLOCK) void k_chain(uint32_t *flags, const int32_t *gnm, const int32_t *pdom0, int n, int P, const int32_t *tiso, int32_t *stats)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	int p0 = pdom0[h];
-	if (p0 >= 0 && tiso[(int64_t)gnm[h] * P + p0]) {
-		flags[h] |= PGA_F_FLT | PGA_F_CHAIN;
-		atomicAdd(&stats[gnm[h] * 4 + 2], 1);
-	}
-}
-
-// pg_flt_subopt_isoform (hit.c:107-128).  best[gene] of one genome = first maximum of score_adj in
-// array order; the (int32 > uint64) comparison of hit.c:116 lets a negative score_adj always win, the
-// last one in array order staying.
-__global__ __launch_bounds__(BLOCK) void k_subopt1(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *sadj,
-                                                     const int32_t *goff, int n, int Q, unsigned long long *tbest)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	if ((flags[h] & PGA_F_FLT) || rank[h] > 0) return;
-	int s = sadj[h], g = gnm[h];
-	uint32_t pos = (uint32_t)(h - goff[g]);
-	unsigned long long k;
-	if (s > 0) k = (unsigned long long)(uint32_t)s << 32 | (0xffffffffu - pos);
-	else if (s < 0) k = 1ull << 63 | pos;
-	else return;
-	atomicMax(&tbest[(int64_t)g * Q + gid[h]], k);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_subopt2(uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *pid, const int32_t *goff, int n, int Q,
-                                                     const unsigned long long *tbest, int32_t *stats)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	uint32_t f = flags[h];
-	if (f & PGA_F_FLT) return;
-	int g = gnm[h];
-	unsigned long long k = tbest[(int64_t)g * Q + gid[h]];
-	int best_pid = 0; // hit.c:111: calloc'ed best => pid 0 when the gene has no candidate
-	if (k) {
-		uint32_t pos = (k >> 63) ? (uint32_t)k : 0xffffffffu - (uint32_t)k;
-		best_pid = pid[goff[g] + (int)pos];
-	}
-	if (pid[h] != best_pid) {
-		flags[h] = f | PGA_F_FLT | PGA_F_ISO_SUB;
-		atomicAdd(&stats[g * 4 + 3], 1);
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// stage B (hit.c:153-247)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_post_part(const uint32_t *flags, const int32_t *pid, const int32_t *rank, const int32_t *sori, const int32_t *sadj,
-                                                       const int32_t *nex, int n, int P, int32_t *max_ori, unsigned long long *sums)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	int p = pid[h];
-	atomicMax(&max_ori[p], sori[h]);
-	if (rank[h] == 0 && !(flags[h] & PGA_F_FLT)) {
-		int w = nex[h] == 1 ? 0 : 1;
-		atomicAdd(&sums[p], (unsigned long long)(long long)sadj[h]);
-		atomicAdd(&sums[(int64_t)P + p], 1ull);
-		atomicAdd(&sums[(int64_t)(2 + w) * P + p], 1ull);
-		atomicAdd(&sums[(int64_t)(4 + w) * P + p], (unsigned long long)(long long)sori[h]);
-	}
-}
-
-__global__ __launch_bounds__(BLOCK) void k_post_apply(uint32_t *flags, const int32_t *pid, const int32_t *nex, int32_t *sdom, int n,
-                                                        const int32_t *max_ori, const uint8_t *rep, const uint8_t *pj, int64_t *cnt)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	int p = pid[h];
-	int mo = max_ori[p];
-	if (sdom[h] > mo) sdom[h] = mo; // hit.c:243-244
-	uint32_t f = flags[h], nf = rep[p] ? (f | PGA_F_REP) : (f & ~PGA_F_REP);
-	if (!(f & (PGA_F_FLT | PGA_F_PSEUDO)) && nex[h] == 1 && pj[p]) { // hit.c:175-182
-		nf |= PGA_F_PSEUDO;
-		atomicAdd((unsigned long long *)cnt, 1ull);
-	}
-	if (nf != f) flags[h] = nf;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_set_filter(uint32_t *flags, int n, int which) // pgpriv.h:109-116
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	uint32_t f = flags[h];
-	bool hit = which == PGA_FLT_PSEUDO ? (f & PGA_F_PSEUDO) != 0
-	         : which == PGA_FLT_VTX0 ? (f & PGA_F_VTX) == 0
-	         : which == PGA_FLT_WEAK2 ? ((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT) == 2
-	         : (f & PGA_F_SHADOW) != 0;
-	if (hit && !(f & PGA_F_FLT)) flags[h] = f | PGA_F_FLT;
-}
-
-// ------------------------------------------------------------------------------------------------
-// pg_gen_vtx, per-genome part (vertex.c:28-51)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_vtx1(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *pdom,
-                                                  int n, int Q, int32_t *cnt, uint32_t *dombits, int64_t words_per_genome, int64_t *dcnt)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	uint32_t f = flags[h];
-	if ((f & PGA_F_FLT) || rank[h] != 0) return;
-	int g = gid[h];
-	if (f & PGA_F_SHADOW) {
-		if (pdom[h] < 0) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // vertex.c:38
-		atomicAdd(&cnt[Q + g], 1);
-	} else {
-		atomicAdd(&cnt[g], 1);
-		uint32_t old = atomicOr(&dombits[(int64_t)gnm[h] * words_per_genome + (g >> 5)], 1u << (g & 31));
-		if (old & (1u << (g & 31))) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // two rank-0 hits of one gene: cannot happen after hit.c:107-128
-	}
-}
-
-// Fold of the (genome, sub gene, dom gene) relation into one genome bitset per (sub, dom) pair, the form the host greedy
-// consumes (vertex.c:60-80 marks cell (genome, dom) for every genome of the pair).  A sub gene has very few distinct dom
-// genes, so each gene owns VTX_K slots: a slot is claimed for a dom gene with atomicCAS, the genome bit is an atomicOr.
-// A gene with more than VTX_K dom genes spills single-genome records into an overflow area.
-constexpr int VTX_K = 8;
-
-__global__ __launch_bounds__(BLOCK) void k_vtx_fold(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *pdom,
-                                                      const int32_t *prot_gid, const int32_t *ggl, int n, const uint32_t *dombits, int64_t words_per_genome,
-                                                      int32_t *dom_tab, unsigned long long *bits, int nw, unsigned long long *ovf, long long ovf_cap, int64_t *dcnt)
-{
-	const int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	const uint32_t f = flags[h];
-	if ((f & PGA_F_FLT) || rank[h] != 0 || !(f & PGA_F_SHADOW) || pdom[h] < 0) return;
-	const int j = gnm[h], D = prot_gid[pdom[h]], g = gid[h];
-	if (!(dombits[(int64_t)j * words_per_genome + (D >> 5)] >> (D & 31) & 1u)) return; // dom is not dominant in this genome: the greedy never looks
-	const int jg = ggl[j];
-	int k = 0;
-	for (; k < VTX_K; ++k) {
-		int32_t *p = &dom_tab[(int64_t)g * VTX_K + k];
-		int cur = *(volatile int32_t *)p;
-		if (cur < 0) cur = atomicCAS(p, -1, D), cur = cur < 0 ? D : cur;
-		if (cur == D) break;
-	}
-	if (k < VTX_K) {
-		atomicOr(&bits[((int64_t)g * VTX_K + k) * nw + (jg >> 6)], 1ull << (jg & 63));
-	} else {
-		const long long at = (long long)atomicAdd((unsigned long long *)&dcnt[0], 1ull);
-		if (at < ovf_cap) {
-			unsigned long long *r = ovf + at * (1 + nw);
-			r[0] = (unsigned long long)g << 20 | (unsigned long long)D;
-			for (int w = 0; w < nw; ++w) r[1 + w] = w == (jg >> 6) ? 1ull << (jg & 63) : 0ull;
-		}
-	}
-}
-
-struct InDomSet { const int32_t *tab; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{tab[i] >= 0 ? 1 : 0}; } };
-
-// slot -> record: key (sub << 20 | dom), then the genome words; also mails the record count (dcnt[10]) and the counters to the host
-__global__ __launch_bounds__(BLOCK) void k_vtx_compact(const int32_t *dom_tab, const int32_t *slot, int64_t n_slot, const unsigned long long *bits, int nw,
-                                                         unsigned long long *out, int64_t *dcnt, int64_t *host_box)
-{
-	const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (s >= n_slot) return;
-	const int D = dom_tab[s];
-	if (D >= 0) {
-		unsigned long long *r = out + (int64_t)slot[s] * (1 + nw);
-		r[0] = (unsigned long long)(s / VTX_K) << 20 | (unsigned long long)D;
-		for (int w = 0; w < nw; ++w) r[1 + w] = bits[s * nw + w];
-	}
-	if (s == n_slot - 1) {
-		dcnt[10] = slot[s] + (D >= 0 ? 1 : 0);
-		__threadfence();
-		for (int t = 0; t < 16; ++t) host_box[t] = dcnt[t];
-	}
-}
-
-__global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32_t *gid, int n, const int32_t *g2s) // graph.c:61-69
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	uint32_t f = flags[h], nf = g2s[gid[h]] >= 0 ? (f | PGA_F_VTX) : (f & ~PGA_F_VTX);
-	if (nf != f) flags[h] = nf;
-}
-
-// ------------------------------------------------------------------------------------------------
-// pg_gen_arc, per-genome part (graph.c:97-146)
-// ------------------------------------------------------------------------------------------------
-constexpr int SEGCNT_COPIES = 64;
-__global__ __launch_bounds__(BLOCK) void k_segcnt_sum(int32_t *seg_cnt, int n2s)
-{
-	int i = blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= n2s) return;
-	int t = 0;
-	for (int k = 0; k < SEGCNT_COPIES; ++k) t += seg_cnt[(int64_t)k * n2s + i];
-	seg_cnt[i] = t;
-}
-
-// walkable = !flt && !shadow; val[y] = y if the y-th hit in cm order is walkable else -1
-__global__ __launch_bounds__(BLOCK) void k_walk_mark(const uint32_t *flags, const int32_t *yperm, int n, int32_t *val)
-{
-	int y = blockIdx.x * BLOCK + threadIdx.x;
-	if (y >= n) return;
-	val[y] = (flags[yperm[y]] & (PGA_F_FLT | PGA_F_SHADOW)) ? -1 : y;
-}
-
-struct InWalk { const int32_t *val; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{val[i]}; } };
-struct OutPrev { int32_t *prev; __device__ __forceinline__ void operator()(int64_t i, I32, I32 ex) const { prev[i] = ex.v; } };
-
-// Static per-hit fields in Y (cm) order, packed once per run: the arc kernels walk the hits in that order and would otherwise
-// gather every field through yperm.   YA = {seg, gid, genome, cm}   YB = {score_ori, score_dom, gene of pid_dom0's protein
-// (-1: none), X position << 1 | rev}
-__global__ __launch_bounds__(BLOCK) void k_pack_yrec(const int32_t *yperm, const int32_t *seg, const int32_t *gid, const int32_t *gnm, const int32_t *cm,
-                                                       const int32_t *sori, const int32_t *sdom, const int32_t *pdom0, const int32_t *prot_gid, const uint32_t *flags,
-                                                       int n, int4 *YA, int4 *YB)
-{
-	int y = blockIdx.x * BLOCK + threadIdx.x;
-	if (y >= n) return;
-	const int a = yperm[y], p0 = pdom0[a];
-	YA[y] = make_int4(seg[a], gid[a], gnm[a], cm[a]);
-	YB[y] = make_int4(sori[a], sdom[a], p0 < 0 ? -1 : prot_gid[p0], a << 1 | (flags[a] & PGA_F_REV ? 1 : 0));
-}
-
-// has_arc[y] = 1 if walkable y has a walkable predecessor on the same contig; also per-segment counts
-// (graph.c:113,125-126) and hazard H2a (equal cm of two consecutive walkable hits)
-__global__ __launch_bounds__(BLOCK) void k_arc_flag(const int32_t *val, const int32_t *prev, const int4 *YA, const int32_t *g2s, int n, int S, int32_t *has, int32_t *seg_cnt,
-                                                      uint32_t *seen, int64_t words_per_genome, int64_t *dcnt, int32_t *hz_list)
-{
-	int y = blockIdx.x * BLOCK + threadIdx.x;
-	if (y >= n) return;
-	int out = 0;
-	if (val[y] >= 0) {
-		const int4 ra = YA[y];
-		const int sid = g2s[ra.y];
-		if (sid < 0) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // graph.c:111
-		else {
-			int32_t *copy = seg_cnt + (int64_t)(blockIdx.x & (SEGCNT_COPIES - 1)) * 2 * S; // 64 copies: 64x less contention per address
-			atomicAdd(&copy[S + sid], 1);
-			uint32_t old = atomicOr(&seen[(int64_t)ra.z * words_per_genome + (sid >> 5)], 1u << (sid & 31));
-			if (!(old >> (sid & 31) & 1u)) atomicAdd(&copy[sid], 1);
-		}
-		const int p = prev[y];
-		if (p >= 0) {
-			const int4 rb = YA[p];
-			if (rb.x == ra.x) {
-				out = 1;
-				if (rb.w == ra.w) { atomicAdd((unsigned long long *)&dcnt[5], 1ull); hz_note(&dcnt[14], hz_list, ra.x); }
-			}
-		}
-	}
-	has[y] = out;
-}
-
-__device__ __forceinline__ int arc_score(const int4 yb, int ori, const int32_t *g2s)
-{ // pg_get_score, graph.c:82-85: score_ori unless the dominator's gene is not a vertex and score_dom is at least as large
-	return (ori || yb.x > yb.y || yb.z < 0 || g2s[yb.z] >= 0) ? yb.x : yb.y;
-}
-
-struct ArcEmit {
-	const int32_t *has, *slot, *prev; const int4 *YA, *YB; const int32_t *g2s;
-	uint64_t *key; uint32_t *idx; int4 *pay; // payload {dist, s1, s2, genome}
-	int n, ori, vbits;
-};
-
-__global__ __launch_bounds__(BLOCK) void k_arc_emit(ArcEmit e)
-{
-	int y = blockIdx.x * BLOCK + threadIdx.x;
-	if (y >= e.n || !e.has[y]) return;
-	const int p = e.prev[y];
-	const int4 aA = e.YA[y], bA = e.YA[p], aB = e.YB[y], bB = e.YB[p];
-	uint32_t w = (uint32_t)e.g2s[aA.y] << 1 | (uint32_t)(aB.w & 1);
-	uint32_t v = (uint32_t)e.g2s[bA.y] << 1 | (uint32_t)(bB.w & 1);
-	int sa = arc_score(aB, e.ori, e.g2s);
-	int sb = arc_score(bB, e.ori, e.g2s);
-	int d = aA.w - bA.w, g = aA.z;
-	int64_t o = (int64_t)e.slot[y] * 2;
-	e.key[o] = (uint64_t)v << e.vbits | w;           e.idx[o] = (uint32_t)o;         // v -> w      (graph.c:117)
-	e.pay[o] = make_int4(d, sb, sa, g);
-	e.key[o + 1] = (uint64_t)(w ^ 1) << e.vbits | (v ^ 1); e.idx[o + 1] = (uint32_t)(o + 1); // w^1 -> v^1 (graph.c:119)
-	e.pay[o + 1] = make_int4(d, sa, sb, g);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_arc_gather(const uint32_t *idx, int64_t m, const int4 *pay, int4 *opay)
-{
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i < m) opay[i] = pay[idx[i]]; // one random 16-byte read per temp arc
-}
-
-__global__ __launch_bounds__(BLOCK) void k_arc_head(const uint64_t *key, int64_t m, int32_t *head)
-{
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= m) return;
-	head[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
-}
-
-// Two-level collapse of the sorted temp arcs (graph.c:128-175).  Equal keys are adjacent and, inside one key,
-// grouped by genome (stable sort of a genome-major emission).
-// level 1: the first element of every (key, genome) run collapses its run -- almost always a single element --
-//          into (n, rounded mean dist * n, max s1, max s2) stored at its own position; other positions hold zeros;
-// level 2: one wave per distinct key sums those records over the key's run with coalesced strided reads.
-__global__ __launch_bounds__(BLOCK) void k_arc_l1(const uint64_t *key, int64_t m, const int4 *pay, const int32_t *head, const int32_t *slot, int32_t *run_start,
-                                                    int32_t *o_n, uint64_t *o_dn, int32_t *o_s1, int32_t *o_s2)
-{
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= m) return;
-	const uint64_t k = key[i];
-	const int4 p = pay[i];
-	const int g = p.w;
-	if (head[i]) run_start[slot[i]] = (int32_t)i;
-	if (i > 0 && key[i - 1] == k && pay[i - 1].w == g) { o_n[i] = 0, o_dn[i] = 0, o_s1[i] = 0, o_s2[i] = 0; return; }
-	int n = 1, m1 = p.y, m2 = p.z;
-	uint64_t sd = (uint64_t)(int64_t)p.x;
-	for (int64_t j = i + 1; j < m && key[j] == k; ++j) { // almost always empty: one adjacency per (arc, genome)
-		const int4 q = pay[j];
-		if (q.w != g) break;
-		sd += (uint64_t)(int64_t)q.x;
-		m1 = m1 > q.y ? m1 : q.y;
-		m2 = m2 > q.z ? m2 : q.z;
-		++n;
-	}
-	const int dg = (int32_t)((double)sd / n + .499); // graph.c:141
-	o_n[i] = n, o_dn[i] = (uint64_t)(int64_t)dg * (uint64_t)n, o_s1[i] = m1, o_s2[i] = m2;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_arc_l2(const uint64_t *key, int64_t m, int64_t n_run, const int32_t *run_start, const int32_t *c_n, const uint64_t *c_dn,
-                                                    const int32_t *c_s1, const int32_t *c_s2, int vbits, pga_arc_part_t *out)
-{
-	const int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	if (w >= n_run) return;
-	const int64_t st = run_start[w], en = w + 1 < n_run ? run_start[w + 1] : m;
-	int ng = 0, tot = 0;
-	uint64_t sd = 0;
-	int64_t a1 = 0, a2 = 0;
-	for (int64_t j = st + lane; j < en; j += WAVE) {
-		const int n = c_n[j];
-		ng += n > 0, tot += n, sd += c_dn[j], a1 += c_s1[j], a2 += c_s2[j];
-	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		ng += __shfl_xor(ng, o, WAVE), tot += __shfl_xor(tot, o, WAVE);
-		sd += (uint64_t)__shfl_xor((long long)sd, o, WAVE), a1 += __shfl_xor((long long)a1, o, WAVE), a2 += __shfl_xor((long long)a2, o, WAVE);
-	}
-	if (lane == 0) {
-		const uint64_t k = key[st];
-		pga_arc_part_t r;
-		r.x = (k >> vbits) << 32 | (k & ((1ull << vbits) - 1));
-		r.n_genome = ng, r.tot_cnt = tot, r.sum_dist = sd, r.sum_s1 = a1, r.sum_s2 = a2;
-		out[w] = r;
-	}
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// cross-shard merge of arc tables (after the all-gather): gather valid entries, sort by x, wave-per-run sums
-// ------------------------------------------------------------------------------------------------
-// Every rank's table arrives sorted by x with unique keys, so the merged order needs no sort: the place of an entry is
-// the number of entries before it in all the tables (binary searches; equal keys keep rank order).
-struct MergeLists { int32_t W; int64_t slot_sz; const int64_t *off; }; // off[r] = entries of ranks < r, off[W] = total
-
-__device__ __forceinline__ int64_t mg_bound(const pga_arc_part_t *a, int64_t n, uint64_t x, bool upper)
-{
-	int64_t lo = 0, hi = n;
-	while (lo < hi) {
-		const int64_t mid = (lo + hi) >> 1;
-		const uint64_t y = a[mid].x;
-		if (upper ? y <= x : y < x) lo = mid + 1; else hi = mid;
-	}
-	return lo;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_mg_rank(const pga_arc_part_t *g, MergeLists L, uint64_t *key, uint32_t *val)
-{
-	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= L.off[L.W]) return;
-	int r = 0;
-	while (L.off[r + 1] <= i) ++r; // the table entry i belongs to (W is small)
-	const int64_t k = i - L.off[r], src = r * L.slot_sz + k;
-	const uint64_t x = g[src].x;
-	int64_t pos = k;
-	for (int q = 0; q < L.W; ++q)
-		if (q != r) pos += mg_bound(g + q * L.slot_sz, L.off[q + 1] - L.off[q], x, q < r);
-	key[pos] = x, val[pos] = (uint32_t)src;
-}
-
-struct InMgHead { const uint64_t *key; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(i == 0 || key[i] != key[i - 1]) ? 1 : 0}; } };
-
-__global__ __launch_bounds__(BLOCK) void k_mg_count(const uint64_t *key, const int32_t *slot, int64_t m, int64_t *box) // number of distinct keys
-{
-	if (blockIdx.x == 0 && threadIdx.x == 0) *box = slot[m - 1] + ((m == 1 || key[m - 1] != key[m - 2]) ? 1 : 0); // slot = exclusive count of run heads
-}
-
-__global__ __launch_bounds__(BLOCK) void k_mg_runstart(const uint64_t *key, const int32_t *slot, int64_t m, int32_t *run_start)
-{
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i < m && (i == 0 || key[i] != key[i - 1])) run_start[slot[i]] = (int32_t)i;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_mg_sum(const pga_arc_part_t *g, const uint32_t *val, int64_t m, int64_t n_run, const int32_t *run_start, pga_arc_part_t *out)
-{
-	const int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	if (w >= n_run) return;
-	const int64_t st = run_start[w], en = w + 1 < n_run ? run_start[w + 1] : m;
-	int ng = 0, tot = 0;
-	uint64_t sd = 0, x = 0;
-	int64_t a1 = 0, a2 = 0;
-	for (int64_t j = st + lane; j < en; j += WAVE) {
-		const pga_arc_part_t p = g[val[j]];
-		x = p.x, ng += p.n_genome, tot += p.tot_cnt, sd += p.sum_dist, a1 += p.sum_s1, a2 += p.sum_s2;
-	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		ng += __shfl_xor(ng, o, WAVE), tot += __shfl_xor(tot, o, WAVE);
-		sd += (uint64_t)__shfl_xor((long long)sd, o, WAVE), a1 += __shfl_xor((long long)a1, o, WAVE), a2 += __shfl_xor((long long)a2, o, WAVE);
-	}
-	if (lane == 0) { // lane 0 always owns element st
-		pga_arc_part_t r;
-		r.x = x, r.n_genome = ng, r.tot_cnt = tot, r.sum_dist = sd, r.sum_s1 = a1, r.sum_s2 = a2;
-		out[w] = r;
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// branch.c on device: pg_gen_rep_pos (6-29), pg_n_local (31-46), pg_mark_branch_flt_hit (108-145)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_walk_x(const uint32_t *flags, int n, int32_t *wk)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	wk[h] = (flags[h] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1;
-}
-
-// the last walkable hit of a gene in array order wins (branch.c:22-23 overwrite)
-__global__ __launch_bounds__(BLOCK) void k_rep_last(const int32_t *wk, const int32_t *gnm, const int32_t *gid, int n, int GL, int32_t *rp_pos)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n || !wk[h]) return;
-	atomicMax(&rp_pos[(int64_t)gid[h] * GL + gnm[h]], h + 1);
-}
-
-// Position record of (gene, genome): {contig, rank among the walkable hits of the genome, cm}.  COMPACT (every genome has
-// < 4096 contigs and < 2^20 hits, decided once in create): 8 bytes {cm, local contig << 20 | rank}, half the L2 traffic of
-// pg_n_local, which reads two records per (pair, genome); otherwise 16 bytes {global contig, rank, cm, 0}.  Absent: -1.
-template <bool COMPACT>
-__global__ __launch_bounds__(BLOCK) void k_rep_fill(const int32_t *rp_pos, int64_t n_ent, int GL, const int32_t *seg, const int32_t *cm, const int32_t *rx,
-                                                      const int32_t *goff, const int32_t *ctg_base, void *rp_out)
-{
-	int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (e >= n_ent) return;
-	const int p = rp_pos[e];
-	if (COMPACT) {
-		int2 *rp = (int2 *)rp_out;
-		if (p == 0) { rp[e] = make_int2(0, -1); return; }
-		const int h = p - 1, j = (int)(e % GL);
-		rp[e] = make_int2(cm[h], (seg[h] - ctg_base[j]) << 20 | (rx[h] - rx[goff[j]]));
-	} else {
-		int4 *rp = (int4 *)rp_out;
-		if (p == 0) { rp[e] = make_int4(-1, 0, 0, 0); return; }
-		const int h = p - 1, j = (int)(e % GL);
-		rp[e] = make_int4(seg[h], rx[h] - rx[goff[j]], cm[h], 0);
-	}
-}
-
-// one wave per gene pair, lanes over the local genomes (branch.c:31-46); the count is a popcount of ballots: no
-// cross-lane reduction
-template <bool COMPACT>
-__global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const void *rp_in,
-                                                     int local_dist, int local_count, int frag_mode, int32_t *cnt)
-{
-	const int64_t k = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	if (k >= n_pair) return;
-	const int64_t g1 = (int64_t)pairs[2 * k] * GL, g2 = (int64_t)pairs[2 * k + 1] * GL;
-	int c = 0;
-	for (int j0 = 0; j0 < GL; j0 += WAVE) {
-		const int j = j0 + lane;
-		bool hit = false;
-		if (j < GL) {
-			if (COMPACT) {
-				const int2 a = ((const int2 *)rp_in)[g1 + j], b = ((const int2 *)rp_in)[g2 + j];
-				const int64_t d = (int64_t)a.x - (int64_t)b.x;
-				const int cc = (a.y & 0xfffff) - (b.y & 0xfffff);
-				hit = (a.y | b.y) >= 0 && (frag_mode || ((a.y ^ b.y) >> 20) == 0) &&
-				      ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
-			} else {
-				const int4 a = ((const int4 *)rp_in)[g1 + j], b = ((const int4 *)rp_in)[g2 + j];
-				const int64_t d = (int64_t)a.z - (int64_t)b.z;
-				const int cc = a.y - b.y;
-				hit = a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x) &&
-				      ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
-			}
-		}
-		c += __popcll(__ballot(hit));
-	}
-	if (lane == 0) cnt[k] = c;
-}
-
-// ------------------------------------------------------------------------------------------------
-// pg_mark_branch_flt_arc (branch.c:48-106) on the arc table: one thread per oriented vertex
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_br_prep(const uint64_t *ax, int64_t n_arc, const int32_t *seg_gid, int32_t *agid, int32_t *vs, int32_t *ve)
-{
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= n_arc) return;
-	const uint64_t x = ax[i];
-	const uint32_t v = (uint32_t)(x >> 32);
-	agid[i] = seg_gid[(uint32_t)x >> 1];
-	if (i == 0 || (uint32_t)(ax[i - 1] >> 32) != v) vs[v] = (int32_t)i;
-	if (i == n_arc - 1 || (uint32_t)(ax[i + 1] >> 32) != v) ve[v] = (int32_t)i + 1;
-}
-
-// the round's arc table -> what branch marking reads (see pga_arc_set_current)
-__global__ __launch_bounds__(BLOCK) void k_seg_gid(const int32_t *g2s, int Q, int n_seg, int32_t *seg_gid)
-{
-	int g = blockIdx.x * BLOCK + threadIdx.x;
-	if (g < Q) { int s = g2s[g]; if (s >= 0 && s < n_seg) seg_gid[s] = g; }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_cur_prep(const pga_arc_part_t *arcs, int64_t n_arc, const int32_t *seg_gid, uint64_t *ax, int32_t *s1, int32_t *agid,
-                                                      int32_t *vs, int32_t *ve)
-{
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= n_arc) return;
-	const pga_arc_part_t a = arcs[i];
-	const uint32_t v = (uint32_t)(a.x >> 32);
-	ax[i] = a.x;
-	s1[i] = (int32_t)((double)a.sum_s1 / a.n_genome + .499); // graph.c:171
-	agid[i] = seg_gid[(uint32_t)a.x >> 1];
-	if (i == 0 || (uint32_t)(arcs[i - 1].x >> 32) != v) vs[v] = (int32_t)i;
-	if (i == n_arc - 1 || (uint32_t)(arcs[i + 1].x >> 32) != v) ve[v] = (int32_t)i + 1;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_deg(const int32_t *vs, const int32_t *ve, int n_vtx, int32_t *deg)
-{
-	int v = blockIdx.x * BLOCK + threadIdx.x;
-	if (v < n_vtx) deg[v] = ve[v] - vs[v];
-}
-
-// number of pg_n_local calls of vertex v: n_max * n_weak (branch.c:70-75) + n(n-1)/2 (branch.c:83-88)
-__global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1, double bd, int32_t *pc)
-{
-	const int v = blockIdx.x * BLOCK + threadIdx.x;
-	if (v >= n_vtx) return;
-	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2) { pc[v] = 0; return; }
-	int max_s1 = 0, n_max = 0, n_weak = 0;
-	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[a0 + i] ? max_s1 : s1[a0 + i];
-	for (int i = 0; i < n; ++i) {
-		n_max += s1[a0 + i] == max_s1;
-		n_weak += (1.0 - (double)s1[a0 + i] / max_s1) > bd; // branch.c:71-72
-	}
-	pc[v] = n_max * n_weak + n * (n - 1) / 2;
-}
-
-// sequential form (one lane), used for vertices with more than 64 arcs.  MODE 1: write pairs; 2: decide.
-template <int MODE>
-__device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *agid, double bd, int64_t k, int32_t *pairs, const int32_t *cnt,
-                              double bdist, double bcut, uint8_t *weak, int32_t *grp, int32_t *ndl_out, int64_t *dcnt)
-{
-	int max_s1 = 0;
-	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[a0 + i] ? max_s1 : s1[a0 + i];
-	for (int i = 0; i < n; ++i) {
-		const double r = 1.0 - (double)s1[a0 + i] / max_s1;
-		if (!(r > bd)) continue;
-		int n_local = 0;
-		for (int j = 0; j < n; ++j) {
-			if (s1[a0 + j] != max_s1) continue;
-			if (MODE == 1) pairs[2 * k] = agid[a0 + j], pairs[2 * k + 1] = agid[a0 + i];
-			if (MODE == 2) n_local += cnt[k];
-			++k;
-		}
-		if (MODE == 2) {
-			weak[a0 + i] = ((n_local == 0 && r > bdist) || r > bcut) ? 2 : 1;
-		}
-	}
-	int n_group = 0;
-	for (int i = 0; i < n; ++i) {
-		if (MODE == 2 && grp[a0 + i] == 0) grp[a0 + i] = ++n_group;
-		for (int j = i + 1; j < n; ++j) {
-			if (MODE == 1) pairs[2 * k] = agid[a0 + i], pairs[2 * k + 1] = agid[a0 + j];
-			if (MODE == 2 && cnt[k] > 0 && grp[a0 + j] == 0) grp[a0 + j] = grp[a0 + i];
-			++k;
-		}
-	}
-	if (MODE == 2) *ndl_out = n_group;
-}
-
-// One WAVE per oriented vertex; lane j holds arc j (score, target gene, group mark) in registers and arcs are
-// broadcast with shuffles, so the O(n^2) pair loops of branch.c:70-90 touch memory only for the pair list
-// (coalesced stores, MODE 1) or the all-reduced counts (coalesced loads, MODE 2).
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
-                                                     const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
-                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt)
-{
-	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-	if (v >= n_vtx) return;
-	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2) return;
-	const int64_t k0 = poff[v];
-	if (n > WAVE) {
-		if (lane == 0) { int32_t g = 0; br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt); if (MODE == 2) ndl[v] = g; }
-		return;
-	}
-	const bool in = lane < n;
-	const int my_s1 = in ? s1g[a0 + lane] : 0, my_gid = in ? agidg[a0 + lane] : 0;
-	int max_s1 = my_s1;
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(max_s1, o, WAVE); max_s1 = max_s1 > t ? max_s1 : t; }
-	const double r = in ? 1.0 - (double)my_s1 / max_s1 : 0.0; // branch.c:71
-	const bool is_weak = in && r > bd, is_max = in && my_s1 == max_s1;
-	const unsigned long long m_weak = __ballot(is_weak), m_max = __ballot(is_max);
-	const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-	const int n_max = __popcll(m_max), mrank = __popcll(m_max & lt);
-	// part 1 (branch.c:70-77): for every weak arc i (ascending), one pair per best-scoring arc j (ascending)
-	int wb = 0;
-	for (unsigned long long m = m_weak; m; m &= m - 1, ++wb) {
-		const int i = __ffsll((long long)m) - 1;
-		const int gid_i = __shfl(my_gid, i, WAVE);
-		const int64_t k = k0 + (int64_t)wb * n_max + mrank;
-		if (MODE == 1) { if (is_max) pairs[2 * k] = my_gid, pairs[2 * k + 1] = gid_i; }
-		else {
-			int c = is_max ? cnt[k] : 0;
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
-			if (lane == i) {
-				weak[a0 + i] = ((c == 0 && r > bdist) || r > bcut) ? 2 : 1;
-			}
-		}
-	}
-	// part 2 (branch.c:82-90): all i<j pairs, row i starts after i*n - i(i+1)/2 earlier pairs
-	const int64_t k2 = k0 + (int64_t)n_max * __popcll(m_weak);
-	int grp = 0, n_group = 0;
-	for (int i = 0; i < n; ++i) {
-		const int64_t k = k2 + (int64_t)i * n - (int64_t)i * (i + 1) / 2 + (lane - i - 1);
-		if (MODE == 1) {
-			const int gid_i = __shfl(my_gid, i, WAVE);
-			if (lane > i && in) pairs[2 * k] = gid_i, pairs[2 * k + 1] = my_gid;
-		} else {
-			int gi = __shfl(grp, i, WAVE);
-			if (gi == 0) { gi = ++n_group; if (lane == i) grp = gi; } // uniform: every lane sees the same gi
-			if (lane > i && in && grp == 0 && cnt[k] > 0) grp = gi;
-		}
-	}
-	if (MODE == 2 && lane == 0) ndl[v] = n_group;
-}
-
-__device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107
-{
-	int64_t lo = 0, hi = n;
-	while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ax[mid] < x) lo = mid + 1; else hi = mid; }
-	return (lo < n && ax[lo] == x) ? aw[lo] : 0;
-}
-
-// pg_get_arc as in the reference (pgpriv.h:99-107): scan the few arcs leaving v; vs/ve = arc range of each vertex
-__device__ __forceinline__ int arc_weak_v(const uint64_t *ax, const uint8_t *aw, const int32_t *vs, const int32_t *ve, uint32_t v, uint32_t w)
-{
-	for (int i = vs[v], e = ve[v]; i < e; ++i)
-		if ((uint32_t)ax[i] == w) return aw[i];
-	return 0;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_mark_hits(const int32_t *val, const int32_t *prev, const int4 *YA, const int4 *YB, const int32_t *g2s, int n,
-                                                       const uint64_t *ax, const uint8_t *aw, int64_t n_arc, const int32_t *vs, const int32_t *ve, int32_t *weak_new)
-{
-	int y = blockIdx.x * BLOCK + threadIdx.x;
-	if (y >= n || val[y] < 0) return;
-	int p = prev[y];
-	if (p < 0) return;
-	const int4 aA = YA[y], bA = YA[p];
-	if (aA.x != bA.x) return; // branch.c:124
-	const int aw_ = YB[y].w, bw_ = YB[p].w; // X position << 1 | rev
-	uint32_t w = (uint32_t)g2s[aA.y] << 1 | (uint32_t)(aw_ & 1);
-	uint32_t v = (uint32_t)g2s[bA.y] << 1 | (uint32_t)(bw_ & 1);
-	int e1 = vs ? arc_weak_v(ax, aw, vs, ve, v, w) : arc_weak(ax, aw, n_arc, (uint64_t)v << 32 | w);                       // branch.c:128-130: marks the earlier hit
-	if (e1) atomicMax(&weak_new[bw_ >> 1], e1);
-	int e2 = vs ? arc_weak_v(ax, aw, vs, ve, w ^ 1, v ^ 1) : arc_weak(ax, aw, n_arc, (uint64_t)(w ^ 1) << 32 | (v ^ 1)); // branch.c:131-133: marks this hit
-	if (e2) atomicMax(&weak_new[aw_ >> 1], e2);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_weak_merge(uint32_t *flags, const int32_t *weak_new, int n, int64_t *cnt)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	const bool in = h < n;
-	if (!in) h = n - 1;
-	uint32_t f = flags[h];
-	int cur = in ? (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT) : 0, nw = in ? weak_new[h] : 0;
-	if (nw > cur) { cur = nw; flags[h] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT; }
-	if (cnt) { // log-only counter (branch.c:137-139): one atomic per wave, and only when somebody asks
-		const unsigned long long m = __ballot(cur != 0);
-		if (m && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd((unsigned long long *)cnt, (unsigned long long)__popcll(m));
-	}
-}
-
-// hazard H2b: two consecutive walkable hits (cs order) share (contig, cs)
-__global__ __launch_bounds__(BLOCK) void k_hz_cs(const int32_t *wk, const int32_t *seg, const int32_t *cs, int n, int64_t *dcnt)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n || h == 0 || !wk[h]) return;
-	for (int j = h - 1; j >= 0 && seg[j] == seg[h] && cs[j] == cs[h]; --j)
-		if (wk[j]) { atomicAdd((unsigned long long *)&dcnt[6], 1ull); break; }
-}
-
-// ------------------------------------------------------------------------------------------------
-// download: per-hit state back to file order
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_to_file(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, const uint32_t *flags, const int32_t *rank,
-                                                     const int32_t *sdom, const int32_t *pdom, const int32_t *pdom0, const int32_t *yperm, int n,
-                                                     uint32_t *oflags, int32_t *orank, int32_t *osdom, int32_t *opdom, int32_t *opdom0, int32_t *opx, int32_t *opy)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	int g = gnm[h], f = goff[g] + fidx[h];
-	oflags[f] = flags[h] & F_PUBLIC, orank[f] = rank[h], osdom[f] = sdom[h], opdom[f] = pdom[h], opdom0[f] = pdom0[h];
-	opx[f] = h - goff[g];
-	int x = yperm[h]; // h doubles as a Y position here
-	opy[goff[gnm[x]] + fidx[x]] = h - goff[gnm[x]];
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// exact-order overrides (pangene_hip.h): re-permute contig segments of the physical (X) order, or
-// rewrite slices of the Y permutation.  Rare (a few calls per run), not tuned.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_ov_inv(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, int n, int32_t *inv, int32_t *remap)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	inv[goff[gnm[h]] + fidx[h]] = h;
-	remap[h] = h;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_ov_sety(const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv, int32_t *yperm)
-{
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i < t) yperm[ov_pos[i]] = inv[ov_file[i]];
-}
-
-__global__ __launch_bounds__(BLOCK) void k_inv_only(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, int n, int32_t *inv)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h < n) inv[goff[gnm[h]] + fidx[h]] = h;
-}
-
-// move the "index 0" mark of each genome to the hit the reference has there (overlap.c:108)
-__global__ __launch_bounds__(BLOCK) void k_set_head(const int32_t *head_file, const int32_t *goff, const int32_t *inv, int n_genome, int32_t *headpos, uint32_t *flags)
-{
-	int g = blockIdx.x * BLOCK + threadIdx.x;
-	if (g >= n_genome || goff[g] == goff[g + 1]) return;
-	int np = head_file[g] < 0 ? goff[g] : inv[goff[g] + head_file[g]], op = headpos[g];
-	if (np == op) return;
-	flags[op] &= ~F_HEAD;
-	flags[np] |= F_HEAD;
-	headpos[g] = np;
-}
-
-struct PermArrays { int32_t *a[17]; }; // a[15] = flags, a[16] = rk
-
-__global__ __launch_bounds__(BLOCK) void k_ov_gather(PermArrays p, const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv,
-                                                       int32_t *tmp, int32_t *remap)
-{
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= t) return;
-	int src = inv[ov_file[i]];
-	remap[src] = ov_pos[i];
-#pragma unroll
-	for (int k = 0; k < 17; ++k) tmp[(int64_t)k * t + i] = p.a[k][src];
-}
-
-__global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_t *ov_pos, int64_t t, const int32_t *tmp,
-                                                        const int32_t *gnm, const int32_t *goff)
-{
-	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= t) return;
-	int pos = ov_pos[i];
-#pragma unroll
-	for (int k = 0; k < 15; ++k) p.a[k][pos] = tmp[(int64_t)k * t + i];
-	uint32_t f = (uint32_t)tmp[(int64_t)15 * t + i] & ~F_HEAD; // a[15] = flags; the head mark is positional
-	if (pos == goff[gnm[pos]]) f |= F_HEAD;
-	p.a[15][pos] = (int32_t)f;
-	p.a[16][pos] = tmp[(int64_t)16 * t + i];
-}
-
-__global__ __launch_bounds__(BLOCK) void k_ov_remap_y(int32_t *yperm, int n, const int32_t *remap)
-{
-	int y = blockIdx.x * BLOCK + threadIdx.x;
-	if (y < n) yperm[y] = remap[yperm[y]];
-}
-
-__global__ __launch_bounds__(BLOCK) void k_flt_bits(const uint32_t *flags, int n, unsigned long long *bits)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	const unsigned long long m = __ballot(h < n && (flags[h < n ? h : n - 1] & PGA_F_FLT));
-	if ((threadIdx.x & 63) == 0 && h < n) bits[h >> 6] = m;
-}
+// The kernels live in one header per part of the path; this file holds the context and the host side of the C ABI.
+#include "k_common.hpp"
+#include "k_ingest.hpp"
+#include "k_sweep.hpp"
+#include "k_stage_b.hpp"
+#include "k_vertex.hpp"
+#include "k_arcs.hpp"
+#include "k_branch.hpp"
+#include "k_order.hpp"
 
 // ================================================================================================
 // host side of the ABI
