@@ -43,38 +43,59 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(const int32_t *rp_pos, int64
 	}
 }
 
-// one wave per gene pair, lanes over the local genomes (branch.c:31-46); the count is a popcount of ballots: no
-// cross-lane reduction
+// pg_n_local (branch.c:31-46): one wave per NL_PAIRS gene pairs, lanes over the local genomes.  The pair indices are made
+// wave-uniform (scalar loads) and all record loads of the wave's pairs are issued before the first is used, so a wave pays
+// the memory latency twice for four pairs instead of three times per pair; the count is a popcount of ballots (no
+// cross-lane reduction).
+constexpr int NL_PAIRS = 4;
+
 template <bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const void *rp_in,
                                                      int local_dist, int local_count, int frag_mode, int32_t *cnt)
 {
-	const int64_t k = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
-	if (k >= n_pair) return;
-	const int64_t g1 = (int64_t)pairs[2 * k] * GL, g2 = (int64_t)pairs[2 * k + 1] * GL;
-	int c = 0;
+	const int64_t k0 = (int64_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * NL_PAIRS));
+	if (k0 >= n_pair) return;
+	int64_t g1[NL_PAIRS], g2[NL_PAIRS];
+#pragma unroll
+	for (int u = 0; u < NL_PAIRS; ++u) {
+		const int64_t k = k0 + u < n_pair ? k0 + u : n_pair - 1; // the last wave repeats the last pair, nothing is stored for the repeats
+		g1[u] = (int64_t)pairs[2 * k] * GL, g2[u] = (int64_t)pairs[2 * k + 1] * GL;
+	}
+	int c[NL_PAIRS] = { 0, 0, 0, 0 };
 	for (int j0 = 0; j0 < GL; j0 += WAVE) {
 		const int j = j0 + lane;
-		bool hit = false;
-		if (j < GL) {
-			if (COMPACT) {
-				const int2 a = ((const int2 *)rp_in)[g1 + j], b = ((const int2 *)rp_in)[g2 + j];
-				const int64_t d = (int64_t)a.x - (int64_t)b.x;
-				const int cc = (a.y & 0xfffff) - (b.y & 0xfffff);
-				hit = (a.y | b.y) >= 0 && (frag_mode || ((a.y ^ b.y) >> 20) == 0) &&
-				      ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
-			} else {
-				const int4 a = ((const int4 *)rp_in)[g1 + j], b = ((const int4 *)rp_in)[g2 + j];
-				const int64_t d = (int64_t)a.z - (int64_t)b.z;
-				const int cc = a.y - b.y;
-				hit = a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x) &&
-				      ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+		const bool in = j < GL;
+		const int jj = in ? j : 0;
+		if (COMPACT) {
+			int2 a[NL_PAIRS], b[NL_PAIRS];
+#pragma unroll
+			for (int u = 0; u < NL_PAIRS; ++u) a[u] = ((const int2 *)rp_in)[g1[u] + jj], b[u] = ((const int2 *)rp_in)[g2[u] + jj];
+#pragma unroll
+			for (int u = 0; u < NL_PAIRS; ++u) {
+				const int64_t d = (int64_t)a[u].x - (int64_t)b[u].x;
+				const int cc = (a[u].y & 0xfffff) - (b[u].y & 0xfffff);
+				const bool hit = in && (a[u].y | b[u].y) >= 0 && (frag_mode || ((a[u].y ^ b[u].y) >> 20) == 0) &&
+				                 ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+				c[u] += __popcll(__ballot(hit));
+			}
+		} else {
+			int4 a[NL_PAIRS], b[NL_PAIRS];
+#pragma unroll
+			for (int u = 0; u < NL_PAIRS; ++u) a[u] = ((const int4 *)rp_in)[g1[u] + jj], b[u] = ((const int4 *)rp_in)[g2[u] + jj];
+#pragma unroll
+			for (int u = 0; u < NL_PAIRS; ++u) {
+				const int64_t d = (int64_t)a[u].z - (int64_t)b[u].z;
+				const int cc = a[u].y - b[u].y;
+				const bool hit = in && a[u].x >= 0 && b[u].x >= 0 && (frag_mode || a[u].x == b[u].x) &&
+				                 ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+				c[u] += __popcll(__ballot(hit));
 			}
 		}
-		c += __popcll(__ballot(hit));
 	}
-	if (lane == 0) cnt[k] = c;
+#pragma unroll
+	for (int u = 0; u < NL_PAIRS; ++u)
+		if (lane == u && k0 + u < n_pair) cnt[k0 + u] = c[u];
 }
 
 // ------------------------------------------------------------------------------------------------

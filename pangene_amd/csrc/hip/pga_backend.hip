@@ -722,8 +722,8 @@ static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, int32_t lo
 	int4 *rp = (int4 *)c->pool.get(S_RP_SEG, 0);
 	if (!d_cnt || !rp) return PGA_ERR_NOMEM;
 	*cnt = d_cnt;
-	if (n && c->rp_compact) hipLaunchKernelGGL((k_n_local<true>), dim3(nblk(n, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt);
-	else if (n) hipLaunchKernelGGL((k_n_local<false>), dim3(nblk(n, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt);
+	if (n && c->rp_compact) hipLaunchKernelGGL((k_n_local<true>), dim3(nblk(n, BLOCK / WAVE * NL_PAIRS)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt);
+	else if (n) hipLaunchKernelGGL((k_n_local<false>), dim3(nblk(n, BLOCK / WAVE * NL_PAIRS)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt);
 	return 0;
 }
 
