@@ -155,11 +155,8 @@ __global__ __launch_bounds__(BLOCK) void k_arc_l2(const uint64_t *key, int64_t m
 		const int n = c_n[j];
 		ng += n > 0, tot += n, sd += c_dn[j], a1 += c_s1[j], a2 += c_s2[j];
 	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		ng += __shfl_xor(ng, o, WAVE), tot += __shfl_xor(tot, o, WAVE);
-		sd += (uint64_t)__shfl_xor((long long)sd, o, WAVE), a1 += __shfl_xor((long long)a1, o, WAVE), a2 += __shfl_xor((long long)a2, o, WAVE);
-	}
+	ng = wave_sum(ng), tot = wave_sum(tot);
+	sd = wave_sum64(sd), a1 = (int64_t)wave_sum64((unsigned long long)a1), a2 = (int64_t)wave_sum64((unsigned long long)a2);
 	if (lane == 0) {
 		const uint64_t k = key[st];
 		pga_arc_part_t r;
@@ -228,11 +225,8 @@ __global__ __launch_bounds__(BLOCK) void k_mg_sum(const pga_arc_part_t *g, const
 		const pga_arc_part_t p = g[val[j]];
 		x = p.x, ng += p.n_genome, tot += p.tot_cnt, sd += p.sum_dist, a1 += p.sum_s1, a2 += p.sum_s2;
 	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		ng += __shfl_xor(ng, o, WAVE), tot += __shfl_xor(tot, o, WAVE);
-		sd += (uint64_t)__shfl_xor((long long)sd, o, WAVE), a1 += __shfl_xor((long long)a1, o, WAVE), a2 += __shfl_xor((long long)a2, o, WAVE);
-	}
+	ng = wave_sum(ng), tot = wave_sum(tot);
+	sd = wave_sum64(sd), a1 = (int64_t)wave_sum64((unsigned long long)a1), a2 = (int64_t)wave_sum64((unsigned long long)a2);
 	if (lane == 0) { // lane 0 always owns element st
 		pga_arc_part_t r;
 		r.x = x, r.n_genome = ng, r.tot_cnt = tot, r.sum_dist = sd, r.sum_s1 = a1, r.sum_s2 = a2;

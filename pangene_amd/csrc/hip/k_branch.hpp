@@ -207,9 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 	}
 	const bool in = lane < n;
 	const int my_s1 = in ? s1g[a0 + lane] : 0, my_gid = in ? agidg[a0 + lane] : 0;
-	int max_s1 = my_s1;
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(max_s1, o, WAVE); max_s1 = max_s1 > t ? max_s1 : t; }
+	const int max_s1 = wave_max(my_s1);
 	const double r = in ? 1.0 - (double)my_s1 / max_s1 : 0.0; // branch.c:71
 	const bool is_weak = in && r > bd, is_max = in && my_s1 == max_s1;
 	const unsigned long long m_weak = __ballot(is_weak), m_max = __ballot(is_max);
@@ -219,15 +217,13 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 	int wb = 0;
 	for (unsigned long long m = m_weak; m; m &= m - 1, ++wb) {
 		const int i = __ffsll((long long)m) - 1;
-		const int gid_i = __shfl(my_gid, i, WAVE);
+		const int gid_i = __builtin_amdgcn_readlane(my_gid, i); // i is wave-uniform
 		const int64_t k = k0 + (int64_t)wb * n_max + mrank;
 		if (MODE == 1) { if (is_max) pairs[2 * k] = my_gid, pairs[2 * k + 1] = gid_i; }
 		else {
-			int c = is_max ? cnt[k] : 0;
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
+			const bool none_local = __ballot(is_max && cnt[k] != 0) == 0; // the counts are >= 0: their sum is 0 iff all are
 			if (lane == i) {
-				weak[a0 + i] = ((c == 0 && r > bdist) || r > bcut) ? 2 : 1;
+				weak[a0 + i] = ((none_local && r > bdist) || r > bcut) ? 2 : 1;
 			}
 		}
 	}
@@ -237,10 +233,10 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 	for (int i = 0; i < n; ++i) {
 		const int64_t k = k2 + (int64_t)i * n - (int64_t)i * (i + 1) / 2 + (lane - i - 1);
 		if (MODE == 1) {
-			const int gid_i = __shfl(my_gid, i, WAVE);
+			const int gid_i = __builtin_amdgcn_readlane(my_gid, i);
 			if (lane > i && in) pairs[2 * k] = gid_i, pairs[2 * k + 1] = my_gid;
 		} else {
-			int gi = __shfl(grp, i, WAVE);
+			int gi = __builtin_amdgcn_readlane(grp, i);
 			if (gi == 0) { gi = ++n_group; if (lane == i) grp = gi; } // uniform: every lane sees the same gi
 			if (lane > i && in && grp == 0 && cnt[k] > 0) grp = gi;
 		}

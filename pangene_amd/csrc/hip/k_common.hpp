@@ -56,3 +56,38 @@ __device__ __forceinline__ int genome_of(const int32_t *goff, int n_genome, int 
 	while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (goff[mid] <= i) lo = mid; else hi = mid; }
 	return lo;
 }
+
+// Wave-wide reductions without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32): four DPP row shifts leave every row's
+// total in its last lane, four v_readlane collect them.  The result is wave-uniform.  All 64 lanes must be active.
+#define PGA_DPP_SHR(x, n) __builtin_amdgcn_update_dpp(0, (x), 0x110 | (n), 0xf, 0xf, false) /* row_shr:n, 0 where the row ends */
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+	v += PGA_DPP_SHR(v, 1); v += PGA_DPP_SHR(v, 2); v += PGA_DPP_SHR(v, 4); v += PGA_DPP_SHR(v, 8);
+	return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63);
+}
+
+#define PGA_DPP_SHR64(v, n) do { \
+	const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v), 0x110 | (n), 0xf, 0xf, false); \
+	const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((v) >> 32), 0x110 | (n), 0xf, 0xf, false); \
+	(v) += (unsigned long long)hi_ << 32 | lo_; } while (0)
+
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
+{
+	PGA_DPP_SHR64(v, 1); PGA_DPP_SHR64(v, 2); PGA_DPP_SHR64(v, 4); PGA_DPP_SHR64(v, 8);
+	unsigned long long s = 0;
+#pragma unroll
+	for (int l = 15; l < 64; l += 16)
+		s += (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l) << 32 | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+	return s;
+}
+
+#define PGA_DPP_MAX(v, n) do { const int t_ = __builtin_amdgcn_update_dpp((v), (v), 0x110 | (n), 0xf, 0xf, false); (v) = (v) > t_ ? (v) : t_; } while (0) /* own value where the row ends */
+
+__device__ __forceinline__ int wave_max(int v)
+{
+	PGA_DPP_MAX(v, 1); PGA_DPP_MAX(v, 2); PGA_DPP_MAX(v, 4); PGA_DPP_MAX(v, 8);
+	const int a = __builtin_amdgcn_readlane(v, 15), b = __builtin_amdgcn_readlane(v, 31), c = __builtin_amdgcn_readlane(v, 47), e = __builtin_amdgcn_readlane(v, 63);
+	const int ab = a > b ? a : b, ce = c > e ? c : e;
+	return ab > ce ? ab : ce;
+}
