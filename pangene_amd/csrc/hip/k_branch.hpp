@@ -194,7 +194,7 @@ __device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *a
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
                                                      const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
-                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt)
+                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, uint8_t *vwk /* MODE 2: vertex has a weak arc */)
 {
 	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (v >= n_vtx) return;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 	if (n < 2) return;
 	const int64_t k0 = poff[v];
 	if (n > WAVE) {
-		if (lane == 0) { int32_t g = 0; br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt); if (MODE == 2) ndl[v] = g; }
+		if (lane == 0) { int32_t g = 0; br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt); if (MODE == 2) ndl[v] = g, vwk[v] = 1; }
 		return;
 	}
 	const bool in = lane < n;
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 	const double r = in ? 1.0 - (double)my_s1 / max_s1 : 0.0; // branch.c:71
 	const bool is_weak = in && r > bd, is_max = in && my_s1 == max_s1;
 	const unsigned long long m_weak = __ballot(is_weak), m_max = __ballot(is_max);
+	if (MODE == 2 && lane == 0 && m_weak) vwk[v] = 1;
 	const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 	const int n_max = __popcll(m_max), mrank = __popcll(m_max & lt);
 	// part 1 (branch.c:70-77): for every weak arc i (ascending), one pair per best-scoring arc j (ascending)
@@ -260,7 +261,7 @@ __device__ __forceinline__ int arc_weak_v(const uint64_t *ax, const uint8_t *aw,
 }
 
 __global__ __launch_bounds__(BLOCK) void k_mark_hits(const int32_t *val, const int32_t *prev, const int4 *YA, const int4 *YB, const int32_t *g2s, int n,
-                                                       const uint64_t *ax, const uint8_t *aw, int64_t n_arc, const int32_t *vs, const int32_t *ve, int32_t *weak_new)
+                                                       const uint64_t *ax, const uint8_t *aw, int64_t n_arc, const int32_t *vs, const int32_t *ve, const uint8_t *vwk, int32_t *weak_new)
 {
 	int y = blockIdx.x * BLOCK + threadIdx.x;
 	if (y >= n || val[y] < 0) return;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(BLOCK) void k_mark_hits(const int32_t *val, const i
 	const int aw_ = YB[y].w, bw_ = YB[p].w; // X position << 1 | rev
 	uint32_t w = (uint32_t)g2s[aA.y] << 1 | (uint32_t)(aw_ & 1);
 	uint32_t v = (uint32_t)g2s[bA.y] << 1 | (uint32_t)(bw_ & 1);
+	if (vwk && !vwk[v] && !vwk[w ^ 1]) return; // neither vertex has a weak out-arc (the common case): nothing to look up
 	int e1 = vs ? arc_weak_v(ax, aw, vs, ve, v, w) : arc_weak(ax, aw, n_arc, (uint64_t)v << 32 | w);                       // branch.c:128-130: marks the earlier hit
 	if (e1) atomicMax(&weak_new[bw_ >> 1], e1);
 	int e2 = vs ? arc_weak_v(ax, aw, vs, ve, w ^ 1, v ^ 1) : arc_weak(ax, aw, n_arc, (uint64_t)(w ^ 1) << 32 | (v ^ 1)); // branch.c:131-133: marks this hit
