@@ -785,7 +785,7 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	if (n_arc == 0 || n_vtx == 0) return 0;
 	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, 0);
 	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, 0), *agid = (int32_t *)c->pool.get(S_BR_GID, 0), *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0);
-	int32_t *pc = (int32_t *)c->pool.get(S_BR_PC, 0), *poff = (int32_t *)c->pool.get(S_BR_POFF, 0), *cnt = (int32_t *)c->pool.get(S_NLCNT, 0);
+	int32_t *poff = (int32_t *)c->pool.get(S_BR_POFF, 0), *cnt = (int32_t *)c->pool.get(S_NLCNT, 0);
 	int32_t *grp = (int32_t *)c->pool.get(S_BR_GRP, sizeof(int32_t) * (size_t)n_arc + 16), *ndl = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
 	if (!grp || !ndl) return PGA_ERR_NOMEM;
 	zero_multi(c, grp, sizeof(int32_t) * (size_t)n_arc, ndl, sizeof(int32_t) * (size_t)n_vtx);
