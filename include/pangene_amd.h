@@ -18,6 +18,7 @@
  *   pg_graph_init/gen/destroy graph.c:34-47, 280-322 -> HIP kernels + host round driver
  *   pg_write_bed/graph/walk format.c:113-225
  *   pg_read_list_dict, pg_dict_destroy  read.c:305-318, dict.c:38-49 (main.c:73-75,140-142 need them)
+ *   pg_realtime/cputime/peakrss sys.c:117-140   (main.c:117,149 need them)
  *
  * Additions (not in the reference) are at the end: the exchange hook used to shard genomes across
  * GPUs/processes, id-only scanning of PAFs owned by another shard, and error reporting.
@@ -153,6 +154,10 @@ void       pg_write_graph(const pg_graph_t *g);
 void       pg_write_walk(pg_graph_t *g);
 void      *pg_read_list_dict(const char *o);
 void       pg_dict_destroy(void *h);
+/* private in the reference too (pgpriv.h, sys.c:117-140) but called by main.c:117,149 */
+double     pg_realtime(void);   /* seconds since the first call */
+double     pg_cputime(void);    /* user + system CPU seconds */
+long       pg_peakrss(void);    /* bytes */
 
 /* ---------------------------------------------------------------------------------------------
  * Additions

@@ -834,6 +834,29 @@ int pg_kernel_timing_reset(pg_data_t *d)
 }
 int64_t pg_last_path_hits(void) { return g_path_hits; }
 
+// the reference's timers (sys.c:117-140; pgpriv.h): main.c:117,149 calls them, so a main.c built on top of this library links
+double pg_realtime(void)
+{
+	static double t0 = -1.0;
+	const double t = now_sec();
+	if (t0 < 0) t0 = t;
+	return t - t0;
+}
+
+double pg_cputime(void)
+{
+	struct rusage r;
+	getrusage(RUSAGE_SELF, &r);
+	return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+}
+
+long pg_peakrss(void)
+{
+	struct rusage r;
+	getrusage(RUSAGE_SELF, &r);
+	return r.ru_maxrss * 1024L; // Linux reports kilobytes
+}
+
 void pg_set_exchange(const pg_exchange_t *x)
 {
 	if (x) g_xchg = *x, g_has_xchg = true;

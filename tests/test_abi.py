@@ -6,7 +6,9 @@ import re
 import subprocess
 import tempfile
 
-from conftest import ROOT
+import pytest
+
+from conftest import ROOT, golden_files
 
 SIZES = {"pg_opt_t": 128, "pg_hit_t": 88, "pg_exon_t": 8, "pg_prot_t": 32, "pg_gene_t": 16, "pg_ctg_t": 16, "pg_genome_t": 56,
          "pg_data_t": 72, "pg_seg_t": 32, "pg_arc_t": 32, "pg_graph_t": 56, "pg128_t": 16, "pga_arc_part_t": 40}
@@ -68,3 +70,25 @@ def test_product_fails_loudly_without_gpu(built):
         assert "backend status" in str(e)
     else:
         raise AssertionError("the product path produced output without a GPU")
+
+
+def test_reference_main_c_builds_and_runs_on_this_library(built, expected, tmp_path):
+    """Drop-in at source level: the reference's own, unmodified main.c (compiled where it lies) links against this library's
+    pangene.h-compatible surface and, on top of the host driver + oracle backend, prints the reference's GFA for test/C4."""
+    import hashlib, subprocess
+    ref_dir = "/root/reference"
+    if not os.path.exists(os.path.join(ref_dir, "main.c")):
+        pytest.skip("reference sources not present (GPU box)")
+    shim = tmp_path / "shim"
+    shim.mkdir()
+    (shim / "pgpriv.h").write_text('#include "pangene_amd.h"\n')
+    exe = str(tmp_path / "pangene_main_c")
+    lib_dir = os.path.join(ROOT, "tests", "_build")
+    r = subprocess.run(["gcc", "-std=c99", "-O2", "-I", str(shim), "-I", os.path.join(ROOT, "include"), "-I", ref_dir, os.path.join(ref_dir, "main.c"),
+                        "-o", exe, "-L", lib_dir, "-lpangene_oraclehost", "-Wl,-rpath," + lib_dir, "-lm"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    env = dict(os.environ, PANGENE_EXACT="all")
+    out = subprocess.run([exe] + golden_files("C4"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, check=True).stdout
+    assert hashlib.md5(out).hexdigest() == expected["C4"][""]["md5"]
+    out = subprocess.run([exe, "-p0", "-a1"] + golden_files("C4"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, check=True).stdout
+    assert hashlib.md5(out).hexdigest() == expected["C4"]["-p0 -a1"]["md5"]

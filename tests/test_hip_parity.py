@@ -81,6 +81,19 @@ def test_vertex_fold_spills_beyond_eight_dominators(hip, ora, tmp_path, args):
     assert a == b and len(a) > 1000
 
 
+@pytest.mark.parametrize("name,variant", [("C4", ""), ("C4", "-p0 -a1"), ("bact20", ""), ("human8f", "-S")])
+def test_reference_main_c_on_the_product_library(built, expected, name, variant):
+    """oracle/_ref/pangene_main_on_amd = the reference's unmodified main.c linked against libpangene_amd.so (built in the build
+    container, oracle/Makefile): the drop-in claim as an executable, on the GPU"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "pangene_main_on_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/pangene_main_on_amd was not built")
+    env = dict(os.environ, PANGENE_EXACT="all")
+    r = subprocess.run([exe] + variant.split() + golden_files(name), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert hashlib.md5(r.stdout).hexdigest() == expected[name][variant]["md5"]
+
+
 def test_cross_shard_arc_merge(hip):
     """pga_arc_merge (what every rank runs on the all-gathered arc tables of a sharded round) against a numpy reduce-by-key"""
     raw = C.CDLL(capi.LIB_HIP)
