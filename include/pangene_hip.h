@@ -80,7 +80,8 @@ typedef struct {
 	double  min_ov_ratio;        /* pg_opt_t::min_ov_ratio (overlap.c:136) */
 	int32_t check_strand;        /* PG_F_CHECK_STRAND */
 	int32_t drop_sgl_exon;       /* PG_F_DROP_SGL_EXON (hit.c:180) -- evaluated on the host, kept for reference */
-	int32_t reserved[4];
+	int32_t count_cs_ties;       /* also count hazard h2_cs_tie (only feeds a warning when the exact-order replay is switched off) */
+	int32_t reserved[3];
 } pga_params_t;
 
 /* per-hit state, FILE order, host memory (any pointer may be NULL = not wanted) */

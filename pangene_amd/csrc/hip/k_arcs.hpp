@@ -16,15 +16,18 @@ __global__ __launch_bounds__(BLOCK) void k_segcnt_sum(int32_t *seg_cnt, int n2s)
 }
 
 // walkable = !flt && !shadow; val[y] = y if the y-th hit in cm order is walkable else -1
-__global__ __launch_bounds__(BLOCK) void k_walk_mark(const uint32_t *flags, const int32_t *yperm, int n, int32_t *val)
-{
-	int y = blockIdx.x * BLOCK + threadIdx.x;
-	if (y >= n) return;
-	val[y] = (flags[yperm[y]] & (PGA_F_FLT | PGA_F_SHADOW)) ? -1 : y;
-}
-
-struct InWalk { const int32_t *val; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{val[i]}; } };
-struct OutPrev { int32_t *prev; __device__ __forceinline__ void operator()(int64_t i, I32, I32 ex) const { prev[i] = ex.v; } };
+// walkable mark of Y position y: y itself if the hit there is neither filtered nor shadowed, else -1 (graph.c:108).  The exclusive
+// running maximum of the marks is the previous walkable hit; a mark is recovered from the scan itself (the marks grow with y, so
+// the inclusive maximum differs from the exclusive one exactly at walkable positions): no separate marking pass.
+struct InWalk {
+	const uint32_t *flags; const int32_t *yperm;
+	__device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(flags[yperm[i]] & (PGA_F_FLT | PGA_F_SHADOW)) ? -1 : (int32_t)i}; }
+};
+struct OutPrev {
+	int32_t *val, *prev;
+	__device__ __forceinline__ void operator()(int64_t i, I32 incl, I32 ex) const { val[i] = incl.v != ex.v ? incl.v : -1, prev[i] = ex.v; }
+};
+struct InKeyHead { const uint64_t *key; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(i == 0 || key[i] != key[i - 1]) ? 1 : 0}; } };
 
 // Static per-hit fields in Y (cm) order, packed once per run: the arc kernels walk the hits in that order and would otherwise
 // gather every field through yperm.   YA = {seg, gid, genome, cm}   YB = {score_ori, score_dom, gene of pid_dom0's protein
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void k_arc_head(const uint64_t *key, int64_t
 // level 1: the first element of every (key, genome) run collapses its run -- almost always a single element --
 //          into (n, rounded mean dist * n, max s1, max s2) stored at its own position; other positions hold zeros;
 // level 2: one wave per distinct key sums those records over the key's run with coalesced strided reads.
-__global__ __launch_bounds__(BLOCK) void k_arc_l1(const uint64_t *key, int64_t m, const int4 *pay, const int32_t *head, const int32_t *slot, int32_t *run_start,
+__global__ __launch_bounds__(BLOCK) void k_arc_l1(const uint64_t *key, int64_t m, const int4 *pay, const int32_t *slot, int32_t *run_start,
                                                     int32_t *o_n, uint64_t *o_dn, int32_t *o_s1, int32_t *o_s2)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(BLOCK) void k_arc_l1(const uint64_t *key, int64_t m
 	const uint64_t k = key[i];
 	const int4 p = pay[i];
 	const int g = p.w;
-	if (head[i]) run_start[slot[i]] = (int32_t)i;
+	if (i == 0 || key[i - 1] != k) run_start[slot[i]] = (int32_t)i; // head of the key's run
 	if (i > 0 && key[i - 1] == k && pay[i - 1].w == g) { o_n[i] = 0, o_dn[i] = 0, o_s1[i] = 0, o_s2[i] = 0; return; }
 	int n = 1, m1 = p.y, m2 = p.z;
 	uint64_t sd = (uint64_t)(int64_t)p.x;

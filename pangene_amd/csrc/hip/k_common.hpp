@@ -33,6 +33,15 @@ __global__ void k_mail_sum(const int32_t *a, const int32_t *b, int64_t *dcnt, in
 	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
 }
 
+// the same for a run count: dcnt[10] = number of distinct keys of a sorted array, from the exclusive count of run heads before
+// its last element
+__global__ void k_mail_runs(const uint64_t *key, const int32_t *slot, int64_t m, int64_t *dcnt, int64_t *host_box)
+{
+	if (threadIdx.x == 0) dcnt[10] = (int64_t)slot[m - 1] + ((m == 1 || key[m - 1] != key[m - 2]) ? 1 : 0);
+	__syncthreads();
+	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
+}
+
 __global__ void k_mail_flush(const int64_t *dcnt, int64_t *host_box)
 {
 	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];

@@ -563,8 +563,7 @@ static int walk_prev(pga_ctx *c, int32_t **val_out, int32_t **prev_out)
 	if (!val || !prev || !tile) return PGA_ERR_NOMEM;
 	*val_out = val, *prev_out = prev;
 	if (c->walk_valid) return 0; // pg_mark_branch_flt_hit walks exactly what the pg_gen_arc before it walked: nothing changed in between
-	hipLaunchKernelGGL(k_walk_mark, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->yperm, N, val);
-	device_scan<I32>(InWalk{val}, OutPrev{prev}, N, tile, OpMax{}, I32{-1}, c->st); // exclusive running max = previous walkable
+	device_scan<I32>(InWalk{c->flags, c->yperm}, OutPrev{val, prev}, N, tile, OpMax{}, I32{-1}, c->st); // marks + exclusive running max = previous walkable
 	c->walk_valid = true;
 	return 0;
 }
@@ -602,17 +601,15 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, sizeof(uint64_t) * (size_t)M);
 	uint32_t *idx = (uint32_t *)c->pool.get(S_VAL_A, sizeof(uint32_t) * (size_t)M);
 	int4 *tpay = (int4 *)c->pool.get(S_TDIST, sizeof(int4) * (size_t)M), *spay = (int4 *)c->pool.get(S_SDIST, sizeof(int4) * (size_t)M);
-	int32_t *head = (int32_t *)c->pool.get(S_HEAD, sizeof(int32_t) * (size_t)M);
-	if (!key || !idx || !tpay || !spay || !head) return PGA_ERR_NOMEM;
+	if (!key || !idx || !tpay || !spay) return PGA_ERR_NOMEM;
 	ArcEmit e = { has, slot, prev, c->yrecA, c->yrecB, c->g2s, key, idx, tpay, N, use_ori, vbits };
 	hipLaunchKernelGGL(k_arc_emit, dim3(nblk(N)), dim3(BLOCK), 0, c->st, e);
 	uint64_t *ks; uint32_t *vs;
 	TRY(radix_sort_pool(c, key, idx, M, 2 * vbits, &ks, &vs)); // graph.c:127 and :151 in one stable sort
 	hipLaunchKernelGGL(k_arc_gather, dim3(nblk(M)), dim3(BLOCK), 0, c->st, vs, M, tpay, spay);
-	hipLaunchKernelGGL(k_arc_head, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, M, head);
 	tile = (I32 *)c->pool.get(S_TILE, 0);
-	device_scan<I32>(InI32{head}, OutExclI32{slot}, M, tile, OpSum{}, I32{0}, c->st);
-	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, slot + (M - 1), head + (M - 1), c->dcnt, c->h_box);
+	device_scan<I32>(InKeyHead{ks}, OutExclI32{slot}, M, tile, OpSum{}, I32{0}, c->st); // run heads straight from the sorted keys
+	hipLaunchKernelGGL(k_mail_runs, dim3(1), dim3(64), 0, c->st, ks, slot, M, c->dcnt, c->h_box);
 	TRY(sync_st(c));
 	const int64_t A = c->h_cnt[10];
 	pga_arc_part_t *arcs = (pga_arc_part_t *)c->pool.get(S_ARCS, sizeof(pga_arc_part_t) * (size_t)A);
@@ -622,7 +619,7 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 		int32_t *c_n = (int32_t *)tpay, *c_s1 = c_n + (size_t)M, *c_s2 = c_n + 2 * (size_t)M; // the unsorted payload is free again: reuse it
 		uint64_t *c_dn = (uint64_t *)c->pool.get(S_CDN, sizeof(uint64_t) * (size_t)M);
 		if (!run_start || !c_dn) return PGA_ERR_NOMEM;
-		hipLaunchKernelGGL(k_arc_l1, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, M, spay, head, slot, run_start, c_n, c_dn, c_s1, c_s2);
+		hipLaunchKernelGGL(k_arc_l1, dim3(nblk(M)), dim3(BLOCK), 0, c->st, ks, M, spay, slot, run_start, c_n, c_dn, c_s1, c_s2);
 		hipLaunchKernelGGL(k_arc_l2, dim3(nblk(A, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, ks, M, A, run_start, c_n, c_dn, c_s1, c_s2, vbits, arcs);
 	}
 	*arcs_out = arcs, *n_arcs_out = A;
@@ -709,7 +706,7 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		hipLaunchKernelGGL(k_walk_x, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, N, wk);
 		device_scan<I32>(InI32{wk}, OutExclI32{rx}, N, tile, OpSum{}, I32{0}, c->st);
 		hipLaunchKernelGGL(k_rep_last, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->gnm, c->gid, N, GL, rp_pos);
-		hipLaunchKernelGGL(k_hz_cs, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->seg, c->cs, N, c->dcnt);
+		if (c->par.count_cs_ties) hipLaunchKernelGGL(k_hz_cs, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->seg, c->cs, N, c->dcnt);
 		if (n_ent && c->rp_compact) hipLaunchKernelGGL((k_rep_fill<true>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, c->ctg_base, (void *)rp);
 		else if (n_ent) hipLaunchKernelGGL((k_rep_fill<false>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, c->ctg_base, (void *)rp);
 	} else if (n_ent) {

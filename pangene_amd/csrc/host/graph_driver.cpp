@@ -162,6 +162,7 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	par.min_ov_ratio = opt->min_ov_ratio;
 	par.check_strand = !!(opt->flag & PG_F_CHECK_STRAND);
 	par.drop_sgl_exon = !!(opt->flag & PG_F_DROP_SGL_EXON);
+	par.count_cs_ties = exact_mode() == 0; // only the warning of mode "off" reads that counter
 	if (ext->ctx) ext->be->destroy(ext->ctx), ext->ctx = nullptr;
 	ext->n_hit_local = N;
 	return ext->be->create(&ext->ctx, &sh, &par);
