@@ -12,13 +12,18 @@ __global__ __launch_bounds__(BLOCK) void k_walk_x(const uint32_t *flags, int n, 
 	wk[h] = (flags[h] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1;
 }
 
-// the last walkable hit of a gene in array order wins (branch.c:22-23 overwrite)
-__global__ __launch_bounds__(BLOCK) void k_rep_last(const int32_t *wk, const int32_t *gnm, const int32_t *gid, int n, int GL, int32_t *rp_pos)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n || !wk[h]) return;
-	atomicMax(&rp_pos[(int64_t)gid[h] * GL + gnm[h]], h + 1);
-}
+// pg_gen_rep_pos (branch.c:6-29) as ONE scan over the X order: the input is the walkable mark of a hit (computed on the fly), the
+// exclusive sum is its rank among the walkable hits (rx), and the output step also records the hit as its gene's representative in
+// its genome -- the last walkable hit of a gene in array order wins (branch.c:22-23 overwrite), hence the atomicMax of h + 1.
+struct InWalkX { const uint32_t *flags; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(flags[i] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1}; } };
+struct OutRankRep {
+	int32_t *rx; const int32_t *gnm, *gid; int GL; int32_t *rp_pos;
+	__device__ __forceinline__ void operator()(int64_t i, I32 incl, I32 ex) const
+	{
+		rx[i] = ex.v;
+		if (incl.v != ex.v) atomicMax(&rp_pos[(int64_t)gid[i] * GL + gnm[i]], (int32_t)i + 1);
+	}
+};
 
 // Position record of (gene, genome): {contig, rank among the walkable hits of the genome, cm}.  COMPACT (every genome has
 // < 4096 contigs and < 2^20 hits, decided once in create): 8 bytes {cm, local contig << 20 | rank}, half the L2 traffic of
