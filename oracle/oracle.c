@@ -583,6 +583,7 @@ int pgo_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_
 			if (c->cid[a] != vcid) v = (uint32_t)-1, vpos = -1;
 			sc = get_score(c, a, use_ori);
 			if (v != (uint32_t)-1) {
+				if (c->cm[a] == vpos) { c->hz.h2_cm_tie++; hz_note(c, j, c->cid[a]); } /* hazard H2a: the order of the two decides the arc */
 				if (n1 + 2 > m1) { m1 = m1 ? m1 * 2 : 1024; arc1 = (tmparc_t*)realloc(arc1, m1 * sizeof(tmparc_t)); }
 				arc1[n1].x = (uint64_t)v << 32 | w, arc1[n1].dist = c->cm[a] - vpos, arc1[n1].s1 = si, arc1[n1].s2 = sc, arc1[n1].n = 0, ++n1;
 				arc1[n1].x = (uint64_t)(w^1) << 32 | (v^1), arc1[n1].dist = c->cm[a] - vpos, arc1[n1].s1 = sc, arc1[n1].s2 = si, arc1[n1].n = 0, ++n1;
