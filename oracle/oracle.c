@@ -516,7 +516,7 @@ int pgo_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records, int64_t *n
 		const uint64_t m40 = (1ULL << 40) - 1;
 		int64_t k, n_rec = 0;
 		for (k = 0; k < c->n_triples; ++k) c->triples[k] = (c->triples[k] & m40) << 24 | c->triples[k] >> 40; /* (sub, dom) major, genome minor */
-		qsort(c->triples, (size_t)c->n_triples, sizeof(uint64_t), cmp_u64);
+		if (c->n_triples) qsort(c->triples, (size_t)c->n_triples, sizeof(uint64_t), cmp_u64);
 		free(c->vtx_rec);
 		c->vtx_rec = (uint64_t*)calloc((size_t)(c->n_triples * stride + 1), sizeof(uint64_t));
 		for (k = 0; k < c->n_triples; ++k) {
@@ -592,7 +592,7 @@ int pgo_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_
 		}
 		for (i = 0; i < S; ++i) /* graph.c:125-126 */
 			c->seg_cnt[i] += cnt[i] > 0, c->seg_cnt[S + i] += cnt[i];
-		qsort(arc1, (size_t)n1, sizeof(tmparc_t), tmparc_cmp);
+		if (n1) qsort(arc1, (size_t)n1, sizeof(tmparc_t), tmparc_cmp);
 		for (i = 1, i0 = 0; i <= n1; ++i) { /* per-genome collapse, graph.c:128-145 */
 			if (i == n1 || arc1[i0].x != arc1[i].x) {
 				int32_t max_s1 = 0, max_s2 = 0;
@@ -611,7 +611,7 @@ int pgo_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_
 		}
 	}
 	free(arc1); free(cnt);
-	qsort(arc, (size_t)n_arc, sizeof(tmparc_t), tmparc_cmp); /* graph.c:151 */
+	if (n_arc) qsort(arc, (size_t)n_arc, sizeof(tmparc_t), tmparc_cmp); /* graph.c:151 */
 	c->n_arcs = 0;
 	for (i0 = 0, i = 1; i <= n_arc; ++i) { /* integer part of graph.c:153-169 */
 		if (i == n_arc || arc[i].x != arc[i0].x) {
@@ -648,7 +648,7 @@ int pgo_arc_merge(pga_ctx_t *c, const pga_arc_part_t *gathered, const int64_t *c
 	for (r = 0; r < W; ++r) tot += count[r];
 	t = MALLOC(pga_arc_part_t, tot);
 	for (r = 0, i = 0; r < W; ++r) { memcpy(t + i, gathered + (int64_t)r * slot, count[r] * sizeof(pga_arc_part_t)); i += count[r]; }
-	qsort(t, (size_t)tot, sizeof(pga_arc_part_t), arcpart_cmp);
+	if (tot) qsort(t, (size_t)tot, sizeof(pga_arc_part_t), arcpart_cmp);
 	for (i = 0; i < tot; ++i) {
 		if (k > 0 && t[k-1].x == t[i].x) {
 			t[k-1].n_genome += t[i].n_genome, t[k-1].tot_cnt += t[i].tot_cnt;
