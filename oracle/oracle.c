@@ -675,7 +675,7 @@ int pgo_rep_pos(pga_ctx_t *c)
 			if (i > c->off[j]) { /* hazard H2b bookkeeping: previous walkable hit with the same (cid, cs) */
 				int64_t p = i - 1;
 				while (p >= c->off[j] && (c->flags[p] & (PGA_F_FLT | PGA_F_SHADOW))) --p;
-				if (p >= c->off[j] && c->cid[p] == c->cid[i] && c->cs[p] == c->cs[i]) c->hz.h2_cs_tie++;
+				if (p >= c->off[j] && c->cid[p] == c->cid[i] && c->cs[p] == c->cs[i]) { c->hz.h2_cs_tie++; if (getenv("PGO_EXPERIMENT_NOTE_CS_TIES")) hz_note(c, j, c->cid[i]); }
 			}
 			c->rp_x[j * Q + c->gid[i]] = (int64_t)c->cid[i] << 32 | r;
 			c->rp_y[j * Q + c->gid[i]] = c->cm[i];

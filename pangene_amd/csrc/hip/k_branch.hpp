@@ -299,10 +299,15 @@ __global__ __launch_bounds__(BLOCK) void k_weak_merge(uint32_t *flags, const int
 }
 
 // hazard H2b: two consecutive walkable hits (cs order) share (contig, cs)
-__global__ __launch_bounds__(BLOCK) void k_hz_cs(const int32_t *wk, const int32_t *seg, const int32_t *cs, int n, int64_t *dcnt)
+// (hz_list != NULL: experimental -- the contig also goes to the hazard event list, see pg_graph_gen)
+__global__ __launch_bounds__(BLOCK) void k_hz_cs(const int32_t *wk, const int32_t *seg, const int32_t *cs, int n, int64_t *dcnt, int32_t *hz_list)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n || h == 0 || !wk[h]) return;
 	for (int j = h - 1; j >= 0 && seg[j] == seg[h] && cs[j] == cs[h]; --j)
-		if (wk[j]) { atomicAdd((unsigned long long *)&dcnt[6], 1ull); break; }
+		if (wk[j]) {
+			atomicAdd((unsigned long long *)&dcnt[6], 1ull);
+			if (hz_list) hz_note(&dcnt[14], hz_list, seg[h]);
+			break;
+		}
 }

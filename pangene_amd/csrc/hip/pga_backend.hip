@@ -704,9 +704,11 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 		if (!wk || !rx || !tile) return PGA_ERR_NOMEM;
 		device_scan<I32>(InWalkX{c->flags}, OutRankRep{rx, c->gnm, c->gid, GL, rp_pos}, N, tile, OpSum{}, I32{0}, c->st);
-		if (c->par.count_cs_ties) { // hazard h2_cs_tie, only read by the warning of mode "off"
+		static const bool note_cs = getenv("PANGENE_EXPERIMENT_SELECTIVE") != nullptr; // experimental per-contig escalation: cs-tie contigs join the event list
+		if (c->par.count_cs_ties || note_cs) { // hazard h2_cs_tie, otherwise only read by the warning of mode "off"
 			hipLaunchKernelGGL(k_walk_x, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, N, wk);
-			hipLaunchKernelGGL(k_hz_cs, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->seg, c->cs, N, c->dcnt);
+			hipLaunchKernelGGL(k_hz_cs, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->seg, c->cs, N, c->dcnt,
+			                   note_cs ? (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP) : (int32_t *)nullptr);
 		}
 		if (n_ent && c->rp_compact) hipLaunchKernelGGL((k_rep_fill<true>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, c->ctg_base, (void *)rp);
 		else if (n_ent) hipLaunchKernelGGL((k_rep_fill<false>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, c->ctg_base, (void *)rp);

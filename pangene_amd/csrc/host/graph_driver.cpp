@@ -764,7 +764,7 @@ void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 		// (they perturb pg_gen_rep_pos's running counter and so pg_n_local's local_count test) are not part of
 		// the trigger but do matter once some other tie has changed the walkable set (fuzz seeds 1035 and 3013 with -S differ
 		// from the reference that way).  Until the hazard list also carries those contigs, every contig is tracked.
-		constexpr bool k_selective = false;
+		const bool k_selective = std::getenv("PANGENE_EXPERIMENT_SELECTIVE") != nullptr; // off: see above
 		const bool all = !k_selective || give_up || attempt >= 2;
 		if (pg_verbose >= 2)
 			std::fprintf(stderr, "[M::%s::%s] repeating stages A-C with the reference's exact hit order on %s\n", __func__, stamp(),
