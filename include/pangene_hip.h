@@ -80,8 +80,7 @@ typedef struct {
 	double  min_ov_ratio;        /* pg_opt_t::min_ov_ratio (overlap.c:136) */
 	int32_t check_strand;        /* PG_F_CHECK_STRAND */
 	int32_t drop_sgl_exon;       /* PG_F_DROP_SGL_EXON (hit.c:180) -- evaluated on the host, kept for reference */
-	int32_t count_cs_ties;       /* also count hazard h2_cs_tie (only feeds a warning when the exact-order replay is switched off) */
-	int32_t reserved[3];
+	int32_t reserved[4];
 } pga_params_t;
 
 /* per-hit state, FILE order, host memory (any pointer may be NULL = not wanted) */
@@ -110,7 +109,9 @@ typedef struct pga_ctx pga_ctx_t;
 typedef struct {
 	int64_t h1_head_tie;         /* index-0 quirk outcome depends on who sits at index 0 */
 	int64_t h2_cm_tie;           /* two walkable hits share (contig, cm) */
-	int64_t h2_cs_tie;           /* two walkable hits share (contig, cs) (perturbs pg_gen_rep_pos's r) */
+	int64_t h2_cs_tie;           /* walkable hits sharing (contig, cs) get pg_gen_rep_pos's counter r in tie order (branch.c:14,22-24): counts the
+	                              * pg_n_local evaluations (branch.c:31-46) whose |r1 - r2| <= local_count test is not the same for every order of
+	                              * the tie group(s) (interval form), and tie groups holding two walkable hits of one gene */
 	int64_t h3_dom_tie;          /* dominator arg-max tie / subopt-isoform tie at equal (contig, cs) */
 } pga_hazard_t;
 
@@ -205,7 +206,7 @@ typedef struct {
 	/* per-hit state in file order */ \
 	int  pfx##_download(pga_ctx_t *ctx, const pga_hit_state_t *out); \
 	int  pfx##_hazards(pga_ctx_t *ctx, pga_hazard_t *out); \
-	/* where the h2_cm_tie / h3_dom_tie events of the run happened: up to cap contig-segment ids (position of the contig in \
+	/* where the h2_cm_tie / h2_cs_tie / h3_dom_tie events of the run happened: up to cap contig-segment ids (position of the contig in \
 	 * the shard's genome-major list of contigs) in segs, one per event, duplicates possible; *n_total = number of events \
 	 * (the backend keeps at most PGA_HAZARD_CAP of them: n_total larger than what was returned = list incomplete) */ \
 	int  pfx##_hazard_segs(pga_ctx_t *ctx, int32_t *segs, int32_t cap, int64_t *n_total); \

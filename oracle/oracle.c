@@ -48,6 +48,7 @@ struct pga_ctx {
 	int32_t *seg_cnt; pga_arc_part_t *arcs; int64_t n_arcs, m_arcs;
 	/* rep_pos: per local genome, per gene */
 	int64_t *rp_x; int32_t *rp_y;  /* rp_x = cid<<32|r or -1 */
+	int32_t *rp_iv;           /* H2b: (#walkable hits of the representative's (contig, cs) tie group before it) << 16 | (#after it) */
 	int32_t *nl_cnt;
 	pga_hazard_t hz;
 	void *scratch; size_t m_scratch;
@@ -138,7 +139,7 @@ void pgo_destroy(pga_ctx_t *c)
 	free(c->n_exon_of); free(c->off_exon); free(c->cs); free(c->ce); free(c->cm); free(c->cds);
 	free(c->pid_dom); free(c->pid_dom0); free(c->flags); free(c->yo); free(c->exon_os); free(c->exon_oe);
 	free(c->prot_gid); free(c->gene_pref); free(c->max_ori); free(c->sums); free(c->vtx_cnt); free(c->triples); free(c->vtx_rec); free(c->ctg_base);
-	free(c->g2s); free(c->seg_cnt); free(c->arcs); free(c->rp_x); free(c->rp_y); free(c->nl_cnt); free(c->scratch); free(c->head);
+	free(c->g2s); free(c->seg_cnt); free(c->arcs); free(c->rp_x); free(c->rp_y); free(c->rp_iv); free(c->nl_cnt); free(c->scratch); free(c->head);
 	free(c->br_x); free(c->br_s1); free(c->br_gid); free(c->br_pairs); free(c->br_weak);
 	free(c->r_pid); free(c->r_cid); free(c->r_rank); free(c->r_sori); free(c->r_sadj); free(c->r_nex); free(c->r_offx); free(c->r_cs); free(c->r_ce); free(c->r_cm); free(c->r_rev);
 	free(c);
@@ -355,18 +356,28 @@ static int32_t flt_chain_shadow(pga_ctx_t *c, int32_t j, int8_t *flag)
 	return n_flt;
 }
 
-/* pg_flt_subopt_isoform, hit.c:107-128, one genome; best[] has n_gene zeroed entries on entry and exit */
-static int32_t flt_subopt_isoform(pga_ctx_t *c, int32_t j, uint64_t *best)
+/* pg_flt_subopt_isoform, hit.c:107-128, one genome; best[] / bidx[] have n_gene zeroed entries on entry and exit.
+ * Tie order: the winner of a gene is the FIRST candidate with the maximal score_adj in array order (the last
+ * one among negative scores); a candidate of another protein with the winner's score and the winner's (contig, cs) could sit
+ * before it in the reference's unstable order: hazard. */
+static int32_t flt_subopt_isoform(pga_ctx_t *c, int32_t j, uint64_t *best, int64_t *bidx)
 {
 	int64_t st = c->off[j], en = c->off[j + 1], i;
 	int32_t n_flt = 0;
 	for (i = st; i < en; ++i) {
 		if (is_flt(c, i) || c->rank[i] > 0) continue;
 		if (c->score_adj[i] > 0 && (uint64_t)c->score_adj[i] > best[c->gid[i]] >> 32) { /* hit.c:116; the cast there makes negatives huge */
-			best[c->gid[i]] = (uint64_t)c->score_adj[i] << 32 | (uint32_t)c->pid[i];
+			best[c->gid[i]] = (uint64_t)c->score_adj[i] << 32 | (uint32_t)c->pid[i], bidx[c->gid[i]] = i;
 		} else if (c->score_adj[i] < 0) { /* (int32 > uint64) promotes to unsigned: a negative score_adj always wins */
-			best[c->gid[i]] = (uint64_t)c->score_adj[i] << 32 | (uint32_t)c->pid[i];
+			best[c->gid[i]] = (uint64_t)c->score_adj[i] << 32 | (uint32_t)c->pid[i], bidx[c->gid[i]] = i;
 		}
+	}
+	for (i = st; i < en; ++i) {
+		int64_t w;
+		if (is_flt(c, i) || c->rank[i] > 0 || best[c->gid[i]] == 0) continue;
+		w = bidx[c->gid[i]];
+		if (c->pid[i] != c->pid[w] && c->cid[i] == c->cid[w] && c->cs[i] == c->cs[w] &&
+		    (c->score_adj[w] < 0 ? c->score_adj[i] < 0 : c->score_adj[i] == c->score_adj[w])) { c->hz.h3_dom_tie++; hz_note(c, j, c->cid[i]); }
 	}
 	for (i = st; i < en; ++i) {
 		if (is_flt(c, i)) continue;
@@ -382,12 +393,12 @@ int pgo_ingest(pga_ctx_t *c, int32_t *stats)
 {
 	int32_t j, *maxn, *minn, *r1;
 	int8_t *flag;
-	uint64_t *best;
+	uint64_t *best; int64_t *bidx;
 	int64_t i;
 	maxn = CALLOC(int32_t, c->n_prot), minn = CALLOC(int32_t, c->n_prot), r1 = CALLOC(int32_t, c->n_prot);
 	flag = MALLOC(int8_t, c->n_prot);
 	for (i = 0; i < c->n_prot; ++i) flag[i] = 1;
-	best = CALLOC(uint64_t, c->n_gene);
+	best = CALLOC(uint64_t, c->n_gene); bidx = CALLOC(int64_t, c->n_gene);
 	for (j = 0; j < c->n_genome; ++j) {
 		int32_t n_pseudo, n_ov, n_chain, n_sub;
 		n_pseudo = flag_pseudo(c, j, maxn, minn, r1);
@@ -400,10 +411,10 @@ int pgo_ingest(pga_ctx_t *c, int32_t *stats)
 		}
 		n_ov = flt_ov_isoform(c, j);
 		n_chain = flt_chain_shadow(c, j, flag);
-		n_sub = flt_subopt_isoform(c, j, best);
+		n_sub = flt_subopt_isoform(c, j, best, bidx);
 		if (stats) stats[j*4] = n_pseudo, stats[j*4+1] = n_ov, stats[j*4+2] = n_chain, stats[j*4+3] = n_sub;
 	}
-	free(maxn); free(minn); free(r1); free(flag); free(best);
+	free(maxn); free(minn); free(r1); free(flag); free(best); free(bidx);
 	return PGA_OK;
 }
 
@@ -661,24 +672,32 @@ int pgo_arc_merge(pga_ctx_t *c, const pga_arc_part_t *gathered, const int64_t *c
 	return PGA_OK;
 }
 
-/* pg_gen_rep_pos, branch.c:6-29 */
+/* pg_gen_rep_pos, branch.c:6-29.
+ * Tie order (hazard H2b): the reference's unstable sort may permute the hits that share (contig, cs).  The walkable
+ * ones among them receive consecutive values of the running counter r in whatever order they end up, so the r of a representative
+ * is only known up to the interval [r - nb, r + na] (nb / na = walkable members of its tie group before / after it in the canonical
+ * order); pgo_n_local raises the hazard when that matters.  Two walkable hits of ONE gene inside a tie group (possible with -S:
+ * opposite strands) make the representative itself order-dependent (branch.c:22-23: the last one wins): hazard at once. */
 int pgo_rep_pos(pga_ctx_t *c)
 {
 	int64_t Q = c->n_gene, i, n = Q * c->n_genome;
 	int32_t j;
-	if (c->rp_x == 0) c->rp_x = MALLOC(int64_t, n), c->rp_y = MALLOC(int32_t, n);
-	for (i = 0; i < n; ++i) c->rp_x[i] = -1, c->rp_y[i] = 0;
+	if (c->rp_x == 0) c->rp_x = MALLOC(int64_t, n), c->rp_y = MALLOC(int32_t, n), c->rp_iv = MALLOC(int32_t, n);
+	for (i = 0; i < n; ++i) c->rp_x[i] = -1, c->rp_y[i] = 0, c->rp_iv[i] = 0;
 	for (j = 0; j < c->n_genome; ++j) {
 		int32_t r = 0;
 		for (i = c->off[j]; i < c->off[j + 1]; ++i) {
+			int64_t p;
+			int32_t nb = 0, na = 0, same_gene = 0;
 			if (c->flags[i] & (PGA_F_FLT | PGA_F_SHADOW)) continue;
-			if (i > c->off[j]) { /* hazard H2b bookkeeping: previous walkable hit with the same (cid, cs) */
-				int64_t p = i - 1;
-				while (p >= c->off[j] && (c->flags[p] & (PGA_F_FLT | PGA_F_SHADOW))) --p;
-				if (p >= c->off[j] && c->cid[p] == c->cid[i] && c->cs[p] == c->cs[i]) { c->hz.h2_cs_tie++; if (getenv("PGO_EXPERIMENT_NOTE_CS_TIES")) hz_note(c, j, c->cid[i]); }
-			}
+			for (p = i - 1; p >= c->off[j] && c->cid[p] == c->cid[i] && c->cs[p] == c->cs[i]; --p)
+				if (!(c->flags[p] & (PGA_F_FLT | PGA_F_SHADOW))) ++nb, same_gene |= c->gid[p] == c->gid[i];
+			for (p = i + 1; p < c->off[j + 1] && c->cid[p] == c->cid[i] && c->cs[p] == c->cs[i]; ++p)
+				if (!(c->flags[p] & (PGA_F_FLT | PGA_F_SHADOW))) ++na, same_gene |= c->gid[p] == c->gid[i];
+			if (same_gene || nb > 0xffff || na > 0xffff) c->hz.h2_cs_tie++, hz_note(c, j, c->cid[i]), nb = na = 0;
 			c->rp_x[j * Q + c->gid[i]] = (int64_t)c->cid[i] << 32 | r;
 			c->rp_y[j * Q + c->gid[i]] = c->cm[i];
+			c->rp_iv[j * Q + c->gid[i]] = nb << 16 | na;
 			++r;
 		}
 	}
@@ -697,12 +716,21 @@ int pgo_n_local(pga_ctx_t *c, const int32_t *pairs, int64_t n, int32_t local_dis
 		int32_t g1 = pairs[2*k], g2 = pairs[2*k+1], n_local = 0;
 		for (j = 0; j < c->n_genome; ++j) {
 			int64_t x1 = c->rp_x[j * Q + g1], x2 = c->rp_x[j * Q + g2], d;
-			int32_t cc;
+			int32_t cc, iv1 = c->rp_iv[j * Q + g1], iv2 = c->rp_iv[j * Q + g2];
 			if (x1 == -1 || x2 == -1) continue;
 			if (!frag_mode && x1 >> 32 != x2 >> 32) continue;
 			d = (int64_t)c->rp_y[j * Q + g1] - (int64_t)c->rp_y[j * Q + g2];
 			cc = (int32_t)x1 - (int32_t)x2;
 			if ((d >= -local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count)) ++n_local;
+			if ((iv1 | iv2) && !(d >= -local_dist && d <= local_dist)) { /* H2b: is |r1 - r2| <= local_count the same for every tie order? */
+				const int32_t lo = cc - (iv1 >> 16) - (iv2 & 0xffff), hi = cc + (iv1 & 0xffff) + (iv2 >> 16);
+				const int all_in = lo >= -local_count && hi <= local_count, all_out = hi < -local_count || lo > local_count;
+				if (!all_in && !all_out) {
+					c->hz.h2_cs_tie++;
+					if (iv1) hz_note(c, j, (int32_t)(x1 >> 32));
+					if (iv2) hz_note(c, j, (int32_t)(x2 >> 32));
+				}
+			}
 		}
 		c->nl_cnt[k] = n_local;
 	}

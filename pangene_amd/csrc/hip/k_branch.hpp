@@ -5,47 +5,85 @@
 // ------------------------------------------------------------------------------------------------
 // branch.c on device: pg_gen_rep_pos (6-29), pg_n_local (31-46), pg_mark_branch_flt_hit (108-145)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_walk_x(const uint32_t *flags, int n, int32_t *wk)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	wk[h] = (flags[h] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1;
-}
-
 // pg_gen_rep_pos (branch.c:6-29) as ONE scan over the X order: the input is the walkable mark of a hit (computed on the fly), the
 // exclusive sum is its rank among the walkable hits (rx), and the output step also records the hit as its gene's representative in
 // its genome -- the last walkable hit of a gene in array order wins (branch.c:22-23 overwrite), hence the atomicMax of h + 1.
 struct InWalkX { const uint32_t *flags; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(flags[i] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1}; } };
 struct OutRankRep {
-	int32_t *rx; const int32_t *gnm, *gid; int GL; int32_t *rp_pos;
+	int32_t *rx; const int32_t *gnm, *gid; int GL; int32_t *rp_pos; const uint32_t *flags;
 	__device__ __forceinline__ void operator()(int64_t i, I32 incl, I32 ex) const
 	{
-		rx[i] = ex.v;
+		rx[i] = ex.v | ((flags[i] & F_CSTIE) ? (int32_t)0x80000000 : 0); // bit 31: member of a cs tie group (k_rep_fill looks closer)
 		if (incl.v != ex.v) atomicMax(&rp_pos[(int64_t)gid[i] * GL + gnm[i]], (int32_t)i + 1);
 	}
 };
 
 // Position record of (gene, genome): {contig, rank among the walkable hits of the genome, cm}.  COMPACT (every genome has
 // < 4096 contigs and < 2^20 hits, decided once in create): 8 bytes {cm, local contig << 20 | rank}, half the L2 traffic of
-// pg_n_local, which reads two records per (pair, genome); otherwise 16 bytes {global contig, rank, cm, 0}.  Absent: -1.
+// pg_n_local, which reads two records per (pair, genome); otherwise 16 bytes {global contig, rank, cm, interval}.  Absent: -1.
+//
+// Tie order (hazard H2b).  The reference's unstable sort may permute the hits sharing (contig, cs); the walkable
+// ones among them receive consecutive values of the counter r (branch.c:14,22-24) in whatever order they end up, so the r of
+// a representative inside such a group is only known up to [r - nb, r + na] (nb / na = walkable members before / after it in
+// the canonical order).  Representatives with nb + na > 0 carry bit 31 of their cm word and the interval nb << 16 | na (side
+// table iv[] in the compact form); k_n_local raises the hazard where it matters.  Two walkable hits of ONE gene in a group
+// (-S: opposite strands) make the choice of the representative itself order-dependent (branch.c:22-23): hazard at once.
+struct RepFill {
+	const int32_t *rp_pos; int64_t n_ent; int GL; const int4 *A; const int32_t *gid; const uint32_t *flags; const int32_t *rx, *goff, *ctg_base;
+	void *rp_out; int32_t *iv; int64_t *dcnt; int32_t *hz_list;
+};
+
 template <bool COMPACT>
-__global__ __launch_bounds__(BLOCK) void k_rep_fill(const int32_t *rp_pos, int64_t n_ent, int GL, const int32_t *seg, const int32_t *cm, const int32_t *rx,
-                                                      const int32_t *goff, const int32_t *ctg_base, void *rp_out)
+__global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a, const int32_t *cm)
 {
 	int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (e >= n_ent) return;
-	const int p = rp_pos[e];
-	if (COMPACT) {
-		int2 *rp = (int2 *)rp_out;
-		if (p == 0) { rp[e] = make_int2(0, -1); return; }
-		const int h = p - 1, j = (int)(e % GL);
-		rp[e] = make_int2(cm[h], (seg[h] - ctg_base[j]) << 20 | (rx[h] - rx[goff[j]]));
-	} else {
-		int4 *rp = (int4 *)rp_out;
-		if (p == 0) { rp[e] = make_int4(-1, 0, 0, 0); return; }
-		const int h = p - 1, j = (int)(e % GL);
-		rp[e] = make_int4(seg[h], rx[h] - rx[goff[j]], cm[h], 0);
+	if (e >= a.n_ent) return;
+	const int p = a.rp_pos[e];
+	if (p == 0) {
+		if (COMPACT) ((int2 *)a.rp_out)[e] = make_int2(0, -1); else ((int4 *)a.rp_out)[e] = make_int4(-1, 0, 0, 0);
+		return;
 	}
+	const int h = p - 1, j = (int)(e % a.GL);
+	const int rxh = a.rx[h], r = (rxh & 0x7fffffff) - (a.rx[a.goff[j]] & 0x7fffffff);
+	const int4 ah = a.A[h]; // {cs, seg, ce, pm}
+	int ivl = 0;
+	if (rxh < 0) { // member of a static tie group: count its walkable members on either side
+		const int lo = a.goff[j], hi = a.goff[j + 1], g = a.gid[h];
+		int nb = 0, na = 0; bool same_gene = false;
+		for (int q = h - 1; q >= lo; --q) {
+			const int4 aq = a.A[q];
+			if (aq.y != ah.y || aq.x != ah.x) break;
+			if (!(a.flags[q] & (PGA_F_FLT | PGA_F_SHADOW))) ++nb, same_gene = same_gene || a.gid[q] == g;
+		}
+		for (int q = h + 1; q < hi; ++q) {
+			const int4 aq = a.A[q];
+			if (aq.y != ah.y || aq.x != ah.x) break;
+			if (!(a.flags[q] & (PGA_F_FLT | PGA_F_SHADOW))) ++na, same_gene = same_gene || a.gid[q] == g;
+		}
+		if (same_gene || nb > 0xffff || na > 0xffff) {
+			atomicAdd((unsigned long long *)&a.dcnt[6], 1ull);
+			hz_note(&a.dcnt[14], a.hz_list, ah.y);
+		} else ivl = nb << 16 | na;
+	}
+	const int cmw = cm[h] | (ivl ? (int)0x80000000 : 0);
+	if (COMPACT) {
+		((int2 *)a.rp_out)[e] = make_int2(cmw, (ah.y - a.ctg_base[j]) << 20 | r);
+		if (ivl) a.iv[e] = ivl;
+	} else ((int4 *)a.rp_out)[e] = make_int4(ah.y, r, cmw, ivl);
+}
+
+// hazard H2b inside pg_n_local: the pair's distance test failed, so the count test |r1 - r2| <= local_count decides, and at
+// least one r is only known up to an interval: is the answer the same over the whole interval?  (rare path)
+struct NLocalHz { const int32_t *iv; const int32_t *ctg_base; int64_t *dcnt; int32_t *list; };
+
+__device__ __noinline__ void nl_hazard(const NLocalHz &z, int cc, int iv1, int iv2, int seg1, int seg2, int local_count)
+{
+	const int lo = cc - (iv1 >> 16) - (iv2 & 0xffff), hi = cc + (iv1 & 0xffff) + (iv2 >> 16);
+	const bool all_in = lo >= -local_count && hi <= local_count, all_out = hi < -local_count || lo > local_count;
+	if (all_in || all_out) return;
+	atomicAdd((unsigned long long *)&z.dcnt[6], 1ull);
+	if (iv1) hz_note(&z.dcnt[14], z.list, seg1);
+	if (iv2) hz_note(&z.dcnt[14], z.list, seg2);
 }
 
 // pg_n_local (branch.c:31-46): one wave per NL_PAIRS gene pairs, lanes over the local genomes.  The pair indices are made
@@ -56,7 +94,7 @@ constexpr int NL_PAIRS = 4;
 
 template <bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const void *rp_in,
-                                                     int local_dist, int local_count, int frag_mode, int32_t *cnt)
+                                                     int local_dist, int local_count, int frag_mode, int32_t *cnt, NLocalHz hz)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t k0 = (int64_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * NL_PAIRS));
@@ -78,11 +116,15 @@ __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t
 			for (int u = 0; u < NL_PAIRS; ++u) a[u] = ((const int2 *)rp_in)[g1[u] + jj], b[u] = ((const int2 *)rp_in)[g2[u] + jj];
 #pragma unroll
 			for (int u = 0; u < NL_PAIRS; ++u) {
-				const int64_t d = (int64_t)a[u].x - (int64_t)b[u].x;
+				const int d = (a[u].x & 0x7fffffff) - (b[u].x & 0x7fffffff); // cm < 2^31: the difference fits
 				const int cc = (a[u].y & 0xfffff) - (b[u].y & 0xfffff);
-				const bool hit = in && (a[u].y | b[u].y) >= 0 && (frag_mode || ((a[u].y ^ b[u].y) >> 20) == 0) &&
-				                 ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+				const bool cmp = in && (a[u].y | b[u].y) >= 0 && (frag_mode || ((a[u].y ^ b[u].y) >> 20) == 0);
+				const bool near = d >= -local_dist && d <= local_dist;
+				const bool hit = cmp && (near || (cc >= -local_count && cc <= local_count));
 				c[u] += __popcll(__ballot(hit));
+				if (cmp && !near && (a[u].x | b[u].x) < 0 && k0 + u < n_pair) // rare: an r of the pair depends on the tie order (H2b)
+					nl_hazard(hz, cc, a[u].x < 0 ? hz.iv[g1[u] + jj] : 0, b[u].x < 0 ? hz.iv[g2[u] + jj] : 0,
+					          hz.ctg_base[jj] + (a[u].y >> 20), hz.ctg_base[jj] + (b[u].y >> 20), local_count);
 			}
 		} else {
 			int4 a[NL_PAIRS], b[NL_PAIRS];
@@ -90,11 +132,14 @@ __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t
 			for (int u = 0; u < NL_PAIRS; ++u) a[u] = ((const int4 *)rp_in)[g1[u] + jj], b[u] = ((const int4 *)rp_in)[g2[u] + jj];
 #pragma unroll
 			for (int u = 0; u < NL_PAIRS; ++u) {
-				const int64_t d = (int64_t)a[u].z - (int64_t)b[u].z;
+				const int d = (a[u].z & 0x7fffffff) - (b[u].z & 0x7fffffff);
 				const int cc = a[u].y - b[u].y;
-				const bool hit = in && a[u].x >= 0 && b[u].x >= 0 && (frag_mode || a[u].x == b[u].x) &&
-				                 ((d >= -(int64_t)local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count));
+				const bool cmp = in && a[u].x >= 0 && b[u].x >= 0 && (frag_mode || a[u].x == b[u].x);
+				const bool near = d >= -local_dist && d <= local_dist;
+				const bool hit = cmp && (near || (cc >= -local_count && cc <= local_count));
 				c[u] += __popcll(__ballot(hit));
+				if (cmp && !near && (a[u].z | b[u].z) < 0 && k0 + u < n_pair)
+					nl_hazard(hz, cc, a[u].w, b[u].w, a[u].x, b[u].x, local_count);
 			}
 		}
 	}
@@ -296,18 +341,4 @@ __global__ __launch_bounds__(BLOCK) void k_weak_merge(uint32_t *flags, const int
 		const unsigned long long m = __ballot(cur != 0);
 		if (m && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd((unsigned long long *)cnt, (unsigned long long)__popcll(m));
 	}
-}
-
-// hazard H2b: two consecutive walkable hits (cs order) share (contig, cs)
-// (hz_list != NULL: experimental -- the contig also goes to the hazard event list, see pg_graph_gen)
-__global__ __launch_bounds__(BLOCK) void k_hz_cs(const int32_t *wk, const int32_t *seg, const int32_t *cs, int n, int64_t *dcnt, int32_t *hz_list)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n || h == 0 || !wk[h]) return;
-	for (int j = h - 1; j >= 0 && seg[j] == seg[h] && cs[j] == cs[h]; --j)
-		if (wk[j]) {
-			atomicAdd((unsigned long long *)&dcnt[6], 1ull);
-			if (hz_list) hz_note(&dcnt[14], hz_list, seg[h]);
-			break;
-		}
 }

@@ -100,3 +100,10 @@ __device__ __forceinline__ int wave_max(int v)
 	const int ab = a > b ? a : b, ce = c > e ? c : e;
 	return ab > ce ? ab : ce;
 }
+
+// where a tie-order hazard (h2_cm_tie / h2_cs_tie / h3_dom_tie) happened: contig-segment ids, at most PGA_HAZARD_CAP of them (counter: dcnt[14])
+__device__ __forceinline__ void hz_note(int64_t *cnt14, int32_t *list, int seg)
+{
+	const unsigned long long at = atomicAdd((unsigned long long *)cnt14, 1ull);
+	if (at < (unsigned long long)PGA_HAZARD_CAP) list[at] = seg;
+}

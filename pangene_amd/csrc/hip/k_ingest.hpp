@@ -184,8 +184,12 @@ __global__ __launch_bounds__(BLOCK) void k_subopt1(const uint32_t *flags, const 
 	atomicMax(&tbest[(int64_t)g * Q + gid[h]], k);
 }
 
+// Tie order: the winner is the FIRST candidate with the maximal score_adj in array order (the last one among
+// negative scores); a candidate of another protein with the winner's score and the winner's (contig, cs) could sit before it
+// in the reference's unstable order: hazard.
 __global__ __launch_bounds__(BLOCK) void k_subopt2(uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *pid, const int32_t *goff, int n, int Q,
-                                                     const unsigned long long *tbest, int32_t *stats)
+                                                     const unsigned long long *tbest, int32_t *stats, const int32_t *rank, const int32_t *sadj, const int4 *A,
+                                                     int64_t *dcnt, int32_t *hz_list)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
@@ -196,7 +200,15 @@ __global__ __launch_bounds__(BLOCK) void k_subopt2(uint32_t *flags, const int32_
 	int best_pid = 0; // hit.c:111: calloc'ed best => pid 0 when the gene has no candidate
 	if (k) {
 		uint32_t pos = (k >> 63) ? (uint32_t)k : 0xffffffffu - (uint32_t)k;
-		best_pid = pid[goff[g] + (int)pos];
+		const int w = goff[g] + (int)pos;
+		best_pid = pid[w];
+		if (pid[h] != best_pid && rank[h] == 0) { // a losing candidate: could it have been first?
+			const int s = sadj[h];
+			if ((k >> 63) ? s < 0 : (s > 0 && (uint32_t)s == (uint32_t)(k >> 32))) {
+				const int4 ah = A[h], aw = A[w];
+				if (ah.x == aw.x && ah.y == aw.y) { atomicAdd((unsigned long long *)&dcnt[7], 1ull); hz_note(&dcnt[14], hz_list, ah.y); }
+			}
+		}
 	}
 	if (pid[h] != best_pid) {
 		flags[h] = f | PGA_F_FLT | PGA_F_ISO_SUB;

@@ -11,20 +11,19 @@
 // C is only needed for multi-exon hits, for two hits with the same score key and for score_dom.
 __global__ __launch_bounds__(BLOCK) void k_pack_rec(const int32_t *seg, const int32_t *cs, const int32_t *ce, const int32_t *pm, const int32_t *rk,
                                                       const int32_t *gid, const int32_t *cds, const int32_t *rank, const int32_t *nex, const int32_t *offx,
-                                                      const int32_t *pid, const int32_t *sori, int n, int4 *A, int4 *B, int4 *C)
+                                                      const int32_t *pid, const int32_t *sori, int n, int4 *A, int4 *B, int4 *C, uint32_t *flags)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
-	A[h] = make_int4(cs[h], seg[h], ce[h], pm[h]);
+	const int sg = seg[h], c0 = cs[h];
+	A[h] = make_int4(c0, sg, ce[h], pm[h]);
+	// static mark of the cs sort's tie groups (an X neighbour with the same contig and start): only their members can have
+	// their place in pg_gen_rep_pos's count depend on the reference's unstable sort (hazard H2b, k_rep_fill)
+	const bool tie = (h > 0 && seg[h - 1] == sg && cs[h - 1] == c0) || (h + 1 < n && seg[h + 1] == sg && cs[h + 1] == c0);
+	const uint32_t f = flags[h], nf = tie ? f | F_CSTIE : f & ~F_CSTIE;
+	if (nf != f) flags[h] = nf;
 	B[h] = make_int4(rk[h], gid[h], cds[h], pid[h]);
 	C[h] = make_int4(rank[h], nex[h], offx[h], sori[h]);
-}
-
-// where a tie-order hazard (h2_cm_tie / h3_dom_tie) happened: contig-segment ids, at most PGA_HAZARD_CAP of them (counter: dcnt[14])
-__device__ __forceinline__ void hz_note(int64_t *cnt14, int32_t *list, int seg)
-{
-	const unsigned long long at = atomicAdd((unsigned long long *)cnt14, 1ull);
-	if (at < (unsigned long long)PGA_HAZARD_CAP) list[at] = seg;
 }
 
 struct SweepView {

@@ -29,6 +29,7 @@ using namespace pgd;
 
 #define F_HEAD 0x80000000u   // static: first hit of its genome in X order (index-0 quirk, overlap.c:108)
 #define F_MULTI 0x40000000u  // static: the hit has more than one exon (lets the sweep skip the exon records)
+#define F_CSTIE 0x20000000u  // static: an X-order neighbour shares (contig, cs) -- member of a tie group of the cs sort (hazard H2b; set by k_pack_rec)
 #define F_PUBLIC 0x7ffu
 
 static inline unsigned nblk(int64_t n, int per = BLOCK) { return (unsigned)((n + per - 1) / per); }
@@ -56,7 +57,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK,
+	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK,
 	S_COUNT
 };
 
@@ -151,7 +152,7 @@ static int make_sweep_view(pga_ctx *c, SweepView *v)
 static void pack_records(pga_ctx *c)
 {
 	if (c->N) hipLaunchKernelGGL(k_pack_rec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->seg, c->cs, c->ce, c->pm, c->rk, c->gid, c->cds, c->rank, c->nex, c->offx,
-	                             c->pid, c->sori, c->N, c->recA, c->recB, c->recC);
+	                             c->pid, c->sori, c->N, c->recA, c->recB, c->recC, c->flags);
 }
 
 template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
@@ -427,7 +428,8 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 		hipLaunchKernelGGL(k_chain, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pdom0, N, P, tiso, d_stats);
 		HIPCHK(hipMemsetAsync(tbest, 0, sizeof(uint64_t) * (size_t)TQ, c->st));
 		hipLaunchKernelGGL(k_subopt1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->sadj, c->goff, N, Q, tbest);
-		hipLaunchKernelGGL(k_subopt2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->pid, c->goff, N, Q, tbest, d_stats);
+		hipLaunchKernelGGL(k_subopt2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->pid, c->goff, N, Q, tbest, d_stats, c->rank, c->sadj, c->recA, c->dcnt,
+		                   (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP));
 	}
 	if (stats) {
 		HIPCHK(hipMemcpyAsync(stats, d_stats, sizeof(int32_t) * 4 * (size_t)GL, hipMemcpyDeviceToHost, c->st));
@@ -703,15 +705,13 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		int32_t *rx = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
 		I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
 		if (!wk || !rx || !tile) return PGA_ERR_NOMEM;
-		device_scan<I32>(InWalkX{c->flags}, OutRankRep{rx, c->gnm, c->gid, GL, rp_pos}, N, tile, OpSum{}, I32{0}, c->st);
-		static const bool note_cs = getenv("PANGENE_EXPERIMENT_SELECTIVE") != nullptr; // experimental per-contig escalation: cs-tie contigs join the event list
-		if (c->par.count_cs_ties || note_cs) { // hazard h2_cs_tie, otherwise only read by the warning of mode "off"
-			hipLaunchKernelGGL(k_walk_x, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, N, wk);
-			hipLaunchKernelGGL(k_hz_cs, dim3(nblk(N)), dim3(BLOCK), 0, c->st, wk, c->seg, c->cs, N, c->dcnt,
-			                   note_cs ? (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP) : (int32_t *)nullptr);
-		}
-		if (n_ent && c->rp_compact) hipLaunchKernelGGL((k_rep_fill<true>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, c->ctg_base, (void *)rp);
-		else if (n_ent) hipLaunchKernelGGL((k_rep_fill<false>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rp_pos, n_ent, GL, c->seg, c->cm, rx, c->goff, c->ctg_base, (void *)rp);
+		device_scan<I32>(InWalkX{c->flags}, OutRankRep{rx, c->gnm, c->gid, GL, rp_pos, c->flags}, N, tile, OpSum{}, I32{0}, c->st);
+		int32_t *iv = (int32_t *)c->pool.get(S_RP_IV, sizeof(int32_t) * (size_t)n_ent);
+		int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
+		if (!iv || !hzl) return PGA_ERR_NOMEM;
+		RepFill rf = { rp_pos, n_ent, GL, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl };
+		if (n_ent && c->rp_compact) hipLaunchKernelGGL((k_rep_fill<true>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rf, c->cm);
+		else if (n_ent) hipLaunchKernelGGL((k_rep_fill<false>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rf, c->cm);
 	} else if (n_ent) {
 		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(4 * n_ent)), dim3(BLOCK), 0, c->st, (int32_t *)rp, 4 * n_ent, -1); // "absent" in either record form
 	}
@@ -724,8 +724,10 @@ static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, int32_t lo
 	int4 *rp = (int4 *)c->pool.get(S_RP_SEG, 0);
 	if (!d_cnt || !rp) return PGA_ERR_NOMEM;
 	*cnt = d_cnt;
-	if (n && c->rp_compact) hipLaunchKernelGGL((k_n_local<true>), dim3(nblk(n, BLOCK / WAVE * NL_PAIRS)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt);
-	else if (n) hipLaunchKernelGGL((k_n_local<false>), dim3(nblk(n, BLOCK / WAVE * NL_PAIRS)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt);
+	NLocalHz hz = { (const int32_t *)c->pool.get(S_RP_IV, 0), c->ctg_base, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP) };
+	if (!hz.iv || !hz.list) return PGA_ERR_NOMEM;
+	if (n && c->rp_compact) hipLaunchKernelGGL((k_n_local<true>), dim3(nblk(n, BLOCK / WAVE * NL_PAIRS)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
+	else if (n) hipLaunchKernelGGL((k_n_local<false>), dim3(nblk(n, BLOCK / WAVE * NL_PAIRS)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
 	return 0;
 }
 

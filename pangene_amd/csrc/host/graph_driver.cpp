@@ -162,7 +162,6 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	par.min_ov_ratio = opt->min_ov_ratio;
 	par.check_strand = !!(opt->flag & PG_F_CHECK_STRAND);
 	par.drop_sgl_exon = !!(opt->flag & PG_F_DROP_SGL_EXON);
-	par.count_cs_ties = exact_mode() == 0; // only the warning of mode "off" reads that counter
 	if (ext->ctx) ext->be->destroy(ext->ctx), ext->ctx = nullptr;
 	ext->n_hit_local = N;
 	return ext->be->create(&ext->ctx, &sh, &par);
@@ -657,9 +656,9 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	BE_CALL(exact_sort(ext, 1), "override_order"); // the cm order pg_write_walk will see (format.c:190)
 	ext->host_stale = true;
 	pga_hazard_t hz;
-	if (exact_mode() == 0 && be->hazards(ctx, &hz) == 0 && (hz.h1_head_tie | hz.h2_cm_tie | hz.h3_dom_tie) && pg_verbose >= 2)
-		std::fprintf(stderr, "[W::%s] tie-order hazards seen (head-tie %ld, cm-tie %ld, dominator-tie %ld): output may differ from the reference's unstable sort order\n",
-		             "pg_graph_gen", (long)hz.h1_head_tie, (long)hz.h2_cm_tie, (long)hz.h3_dom_tie);
+	if (exact_mode() == 0 && be->hazards(ctx, &hz) == 0 && (hz.h1_head_tie | hz.h2_cm_tie | hz.h3_dom_tie | hz.h2_cs_tie) && pg_verbose >= 2)
+		std::fprintf(stderr, "[W::%s] tie-order hazards seen (head-tie %ld, cm-tie %ld, dominator-tie %ld, cs-tie at the local_count boundary %ld): output may differ from the reference's unstable sort order\n",
+		             "pg_graph_gen", (long)hz.h1_head_tie, (long)hz.h2_cm_tie, (long)hz.h3_dom_tie, (long)hz.h2_cs_tie);
 	return sync_host(q->d, false);
 }
 
@@ -713,7 +712,7 @@ static int hazards_review(DataExt *ext, bool *need, bool *give_up)
 	pga_hazard_t hz;
 	BE_CALL(ext->be->hazards(ext->ctx, &hz), "hazards");
 	int32_t flags[2] = { 0, 0 }; // {need, give up}
-	if (hz.h2_cm_tie + hz.h3_dom_tie > 0) {
+	if (hz.h2_cm_tie + hz.h3_dom_tie + hz.h2_cs_tie > 0) {
 		std::vector<int32_t> segs(PGA_HAZARD_CAP);
 		int64_t n_total = 0;
 		BE_CALL(ext->be->hazard_segs(ext->ctx, segs.data(), (int32_t)segs.size(), &n_total), "hazard_segs");
@@ -733,8 +732,8 @@ static int hazards_review(DataExt *ext, bool *need, bool *give_up)
 		}
 		if (n_new) flags[0] = 1;
 		if (pg_verbose >= 2)
-			std::fprintf(stderr, "[M::%s::%s] tie-order hazards on this rank: %ld equal-cm neighbours, %ld equal-key dominators, on %ld contig(s) not yet following the exact order\n",
-			             "pg_graph_gen", stamp(), (long)hz.h2_cm_tie, (long)hz.h3_dom_tie, (long)n_new);
+			std::fprintf(stderr, "[M::%s::%s] tie-order hazards on this rank: %ld equal-cm neighbours, %ld equal-key dominators, %ld order-dependent local_count tests, on %ld contig(s) not yet following the exact order\n",
+			             "pg_graph_gen", stamp(), (long)hz.h2_cm_tie, (long)hz.h3_dom_tie, (long)hz.h2_cs_tie, (long)n_new);
 	}
 	if (sharded()) {
 		void *scr;

@@ -12,7 +12,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 hip, ora = capi.load(), capi.load(oracle_host=True)
 for lib in (hip, ora):
     C.c_int.in_dll(lib, "pg_verbose").value = 0
-VARIANTS = [[], ["-p0", "-a1"], ["-S"], ["-F"], ["-E"], ["-b", "0.2", "-B", "0.1", "-y", "0.3"], ["--bed=flag"], ["-f", "0.2"]]
+VARIANTS = [[], ["-p0", "-a1"], ["-S"], ["-F"], ["-E"], ["-b", "0.2", "-B", "0.1", "-y", "0.3"], ["--bed=flag"], ["-f", "0.2"],
+            ["-D", "300", "-C", "2"], ["-D", "1000", "-C", "1", "-p0", "-a1"], ["-D", "600", "-C", "3", "-F"], ["-S", "-D", "600", "-C", "3"]]
 bad = tot = 0
 base = tempfile.mkdtemp(prefix="pg_fuzz_")
 for s in range(first, first + n):

@@ -19,6 +19,8 @@ REF = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
 VARIANTS = [[], ["-p0", "-a1"], ["-a2"], ["-E"], ["-J"], ["-S"], ["-F"], ["--ori-sc"], ["-w"], ["-a2", "-E"], ["-D", "300", "-C", "2"], ["-G"],
             ["-c", "3", "-g", "6"], ["-T", "3"], ["-f", "0.2"], ["-e", "0.9", "-l", "0.8"], ["-m", "0.5"],
             ["-b", "0.2", "-B", "0.1", "-y", "0.3"], ["-b", "0.01", "-r", "1"],
+            # pg_n_local's local_dist / local_count boundary inside the fixture shapes (cs ties among walkable hits)
+            ["-D", "1000", "-C", "1", "-p0", "-a1"], ["-D", "600", "-C", "3", "-F"], ["-S", "-D", "600", "-C", "3"],
             ["--bed=raw"], ["--bed=flag"], ["--bed=walk"]]
 SETS = {
     "bact20": lambda: synth.bact(20, 500, seed=1),
@@ -29,6 +31,10 @@ SETS = {
 }
 for s in range(6):
     SETS["fuzz%d" % s] = (lambda s=s: synth.fuzz(s, harsh=(s % 2 == 0)))
+# seeds on which the default tie-order mode differed from the reference before H2b became a trigger
+SETS["fuzz7115"] = lambda: synth.fuzz(7115, harsh=False)
+SETS["fuzz7115h"] = lambda: synth.fuzz(7115, harsh=True)
+SETS["fuzz7126"] = lambda: synth.fuzz(7126, harsh=False)
 
 
 def files_of(name):
@@ -56,8 +62,8 @@ def main():
                 ent["md5_sorted"] = hashlib.md5(b"\n".join(sorted(r.stdout.split(b"\n")))).hexdigest()
             exp[name][key] = ent
             if not v:
-                with gzip.open(os.path.join(HERE, name + ".gfa.gz"), "wb") as f:
-                    f.write(r.stdout)
+                with open(os.path.join(HERE, name + ".gfa.gz"), "wb") as f:
+                    f.write(gzip.compress(r.stdout, mtime=0))  # mtime 0: regenerating does not change the bytes
     with open(os.path.join(HERE, "expected.json"), "w") as f:
         json.dump(exp, f, indent=1, sort_keys=True)
     print("wrote expected.json for", len(exp), "sets")

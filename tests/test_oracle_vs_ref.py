@@ -70,6 +70,21 @@ def test_live_against_reference_binary(ora, tmp_path, seed):
             assert mine == want
 
 
+@pytest.mark.parametrize("first,n,shapes,variants", [
+    (7000, 150, (False, True), "dc"),   # the seeds and -D/-C variants of the round-1 review: 147 of these 1200 default-mode runs differed then
+    (9000, 160, (False,), "all"), (9160, 160, (True,), "all"),  # fresh seeds, every variant of the sweep
+])
+def test_fuzz_sweep_default_mode_against_reference_binary(built, first, n, shapes, variants):
+    """tests/fuzz_oracle_vs_ref.py as a test: the DEFAULT tie-order mode (auto) must print the reference's bytes on > 300 fresh fuzz
+    seeds, including the variants that put pg_n_local's local_dist / local_count boundary inside the fuzz shapes (H2b)."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "pangene_ref")):
+        pytest.skip("oracle/_ref/pangene_ref not built")
+    import fuzz_oracle_vs_ref as fz
+    vs = [v for v in fz.VARIANTS if "-D" in v] if variants == "dc" else fz.VARIANTS
+    tot, bad = fz.sweep(first, n, modes=(1,), variants=vs, shapes=shapes, verbose=False)
+    assert tot == n * len(shapes) * len(vs) and not bad, bad[:10]
+
+
 def test_dense_shape_against_reference_binary(ora, tmp_path):
     """giant spanning hit + pile-ups (the shape the GPU sweep sends through its slow list), host driver + oracle vs oracle/_ref"""
     ref = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
