@@ -210,7 +210,10 @@ const char *pg_rccl_error(void);
  * number of hits they processed (local shard). */
 double  pg_last_path_seconds(void);
 int64_t pg_last_path_hits(void);
-double  pg_last_upload_seconds(void);   /* host pack + H2D copy of the last pg_post_process (not part of the path time) */
+double  pg_last_upload_seconds(void);   /* allocation + H2D copy + order-replay set-up of the last pg_post_process (0 for a resident rerun) */
+double  pg_last_pack_seconds(void);     /* wall seconds the reader spent packing the genomes of the last upload into their blocks */
+/* hits and exons of the local shard of d (what the last pg_post_process uploaded) */
+int     pg_shard_counts(const pg_data_t *d, int64_t *n_hit, int64_t *n_exon);
 
 /* pg_post_process / pg_graph_gen leave the per-hit FLAG fields of the host records (flt, shadow, rank, ...) on the
  * device until a writer needs them: pg_write_graph/pg_write_walk only fetch one flt bit per hit, pg_write_bed
@@ -226,8 +229,9 @@ void pg_set_exact_mode(int mode);
  * already resident in HBM (no re-pack, no PCIe upload).  The host hit arrays are left as they are. */
 int pg_rerun_resident(pg_data_t *d);
 
-/* HIP-event timing of kernel classes of the last run(s): which 0 = stage-A sweep pg_shadow(cal_dom_sc=1)
- * ("K1", the hit-filter+overlap kernel), 1 = pg_flt_ov_isoform sweep, 2 = the other pg_shadow sweeps. */
+/* HIP-event timing of kernel classes of the runs since the last pg_kernel_timing_reset (which also switches the
+ * timing on): which 0 = stage-A sweep pg_shadow(cal_dom_sc=1) ("K1", the hit-filter+overlap kernel), 1 = pg_flt_ov_isoform
+ * sweep, 2 = the other pg_shadow sweeps, 3 = all of stage A (sorts, per-hit constants, pg_flag_pseudo, sweeps, filters). */
 int pg_kernel_timing(pg_data_t *d, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
 int pg_kernel_timing_reset(pg_data_t *d);
 

@@ -58,20 +58,32 @@ enum {
 	PGA_ERR_INVARIANT = -5    /* an invariant the reference asserts (e.g. vertex.c:38) was violated */
 };
 
-/* One shard = a set of genomes with all their hits, structure-of-arrays, FILE order inside a genome.
- * (pg_hit_t pangene.h:61-72, pg_exon_t 44-46, pg_genome_t 79-87) */
+/* One genome of a shard, packed by the host right after its PAF has been parsed (pg_read_paf / pg_read_paf_batch), in FILE
+ * order: what read.c:128-236 leaves in pg_genome_t::hit / ::exon (pangene.h:44-46,61-72,79-87), structure-of-arrays.
+ * `data` is ONE buffer (pinned host memory when it came from host_alloc(), so the upload is a plain DMA):
+ *   10 planes of n_hit int32:  pid, cid, rank, score_ori, score_adj, n_exon, off_exon (into THIS genome's exon list), cs, ce, cm
+ *   n_hit bytes rev, padded to a multiple of 4
+ *   n_exon pairs of int32 (os, oe), relative to cs, ascending (pangene.h:44-46)
+ * The maxima let the backend size its sort keys without looking at the data on the host. */
+#define PGA_BLOCK_PLANES 10
+typedef struct {
+	int32_t n_hit, n_exon, n_ctg;
+	int32_t max_cs, max_cm, max_score_adj;   /* over the hits of the genome; 0 when it has none */
+	int32_t any_neg_score_adj, any_multi_exon;
+	const int32_t *data;
+	size_t n_words;                          /* 10 * n_hit + (n_hit + 3) / 4 + 2 * n_exon */
+} pga_genome_block_t;
+
+/* One shard = a set of genomes with all their hits (pg_hit_t pangene.h:61-72, pg_exon_t 44-46, pg_genome_t 79-87).
+ * Device layout limits (PGA_ERR_RANGE otherwise): contig coordinates < 2^31 (pangene.h:71 has int64), < 2^31 hits and
+ * exons per shard, < 2^20 genes, < 2^24 genomes. */
 typedef struct {
 	int32_t n_genome;            /* genomes in this shard (may include genomes with 0 hits) */
 	int32_t n_genome_global;     /* G of the whole run (all shards) */
 	const int32_t *genome_global;/* [n_genome] global genome index of each local genome */
 	int32_t n_prot, n_gene;      /* global table sizes (ids are assigned on the host before upload) */
-	int64_t n_hit, n_exon;
-	const int64_t *hit_off;      /* [n_genome+1] */
-	const int32_t *n_ctg;        /* [n_genome] contigs per genome */
-	const int32_t *pid, *cid, *rank, *score_ori, *score_adj, *n_exon_of, *off_exon; /* [n_hit] */
-	const int32_t *cs, *ce, *cm; /* [n_hit] contig coordinates; must be < 2^31 */
-	const uint8_t *rev;          /* [n_hit] */
-	const int32_t *exon_os, *exon_oe; /* [n_exon] relative to cs, ascending (pangene.h:44-46) */
+	int64_t n_hit, n_exon;       /* sums over the blocks */
+	const pga_genome_block_t *block; /* [n_genome] */
 	const int32_t *prot_gid;     /* [n_prot] */
 	const uint8_t *gene_pref;    /* [n_gene] pg_gene_t::preferred */
 } pga_shard_t;
@@ -161,6 +173,10 @@ typedef struct {
 	 * travel to the host once, after the last round: branch_pairs(arc_x = NULL), mark_hits(arc_x = NULL) use it. \
 	 * deg (host, [2*n_seg]) receives the out-degree of every oriented vertex (pg_flt_high_occ, graph.c:243-250). */ \
 	int  pfx##_arc_set_current(pga_ctx_t *ctx, const pga_arc_part_t *arcs, int64_t n_arc, int32_t n_seg, int32_t *deg); \
+	/* pg_gen_arc (graph.c:87-177) of a run that is NOT sharded, in one call: the round's table becomes the graph's table at once \
+	 * (as after arc_set_current), the host receives seg_cnt[2 * n_seg] (n_genome[S] then tot_cnt[S]), the out-degree of every \
+	 * oriented vertex deg[2 * n_seg], the table size and where the table lives in backend memory (sorted by x) after a single wait */ \
+	int  pfx##_arc_round_local(pga_ctx_t *ctx, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt, int32_t *deg, const pga_arc_part_t **arcs, int64_t *n_arc); \
 	/* pg_gen_rep_pos (branch.c:6-29) kept in backend memory */ \
 	int  pfx##_rep_pos(pga_ctx_t *ctx); \
 	/* pg_n_local (branch.c:31-46) for n gene pairs (pairs[2i], pairs[2i+1]) summed over local genomes */ \
@@ -212,6 +228,10 @@ typedef struct {
 	int  pfx##_hazard_segs(pga_ctx_t *ctx, int32_t *segs, int32_t cap, int64_t *n_total); \
 	/* 1 if `**` pointers are device memory (exchange must use the device collective) */ \
 	int  pfx##_is_device(void); \
+	/* host memory the backend can upload from without staging (hipHostMalloc for pga_*, malloc for pgo_*); usable before \
+	 * any context exists: the PAF reader packs every genome into such a buffer as soon as it has been parsed */ \
+	int  pfx##_host_alloc(size_t nbytes, void **ptr); \
+	void pfx##_host_free(void *ptr); \
 	const char *pfx##_strerror(int code);
 
 PGA_DECLARE(pga)
@@ -252,6 +272,9 @@ typedef struct {
 	int  (*sync)(pga_ctx_t *);
 	int  (*fetch_later)(pga_ctx_t *, const void *, size_t, const void **);
 	int  (*hazard_segs)(pga_ctx_t *, int32_t *, int32_t, int64_t *);
+	int  (*host_alloc)(size_t, void **);
+	void (*host_free)(void *);
+	int  (*arc_round_local)(pga_ctx_t *, int32_t, int32_t, int32_t *, int32_t *, const pga_arc_part_t **, int64_t *);
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);
@@ -263,7 +286,8 @@ int pga_set_stream(pga_ctx_t *ctx, void *hip_stream);
 void *pga_active_stream(void);
 
 /* Kernel timing hooks for bench.py: HIP events bracket every launch of the named kernel class on the
- * library's stream.  which: 0 = "k1" (stage A sweep, the hit-filter+overlap kernel). */
+ * library's stream, from the first pga_timing_reset on.  which: 0 = "k1" (stage A sweep, the hit-filter+overlap kernel),
+ * 1 = the pg_flt_ov_isoform sweep, 2 = the other pg_shadow sweeps, 3 = the whole of stage A (pga_begin + pga_ingest). */
 int pga_timing_reset(pga_ctx_t *ctx);
 int pga_timing_get(pga_ctx_t *ctx, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
 

@@ -60,6 +60,8 @@ struct pga_ctx {
 };
 
 int pgo_is_device(void) { return 0; }
+int pgo_host_alloc(size_t nbytes, void **ptr) { *ptr = malloc(nbytes ? nbytes : 1); return *ptr ? PGA_OK : PGA_ERR_NOMEM; }
+void pgo_host_free(void *ptr) { free(ptr); }
 
 const char *pgo_strerror(int code)
 {
@@ -156,16 +158,34 @@ int pgo_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
 	c = CALLOC(pga_ctx_t, 1);
 	c->n_genome = sh->n_genome, c->n_genome_global = sh->n_genome_global, c->n_prot = sh->n_prot, c->n_gene = sh->n_gene;
 	c->n_hit = N, c->n_exon = sh->n_exon, c->par = *par;
-	DUP(int64_t, c->off, sh->hit_off, sh->n_genome + 1);
+	c->off = CALLOC(int64_t, sh->n_genome + 1);
 	DUP(int32_t, c->genome_global, sh->genome_global, sh->n_genome);
-	DUP(int32_t, c->n_ctg, sh->n_ctg, sh->n_genome);
-	{ int32_t g; c->ctg_base = CALLOC(int32_t, sh->n_genome + 1); for (g = 0; g < sh->n_genome; ++g) c->ctg_base[g + 1] = c->ctg_base[g] + sh->n_ctg[g]; }
-	DUP(int32_t, c->exon_os, sh->exon_os, sh->n_exon); DUP(int32_t, c->exon_oe, sh->exon_oe, sh->n_exon);
+	c->n_ctg = CALLOC(int32_t, sh->n_genome);
+	{ int32_t g; c->ctg_base = CALLOC(int32_t, sh->n_genome + 1); for (g = 0; g < sh->n_genome; ++g) c->ctg_base[g + 1] = c->ctg_base[g] + sh->block[g].n_ctg; }
+	c->exon_os = MALLOC(int32_t, sh->n_exon); c->exon_oe = MALLOC(int32_t, sh->n_exon);
 	DUP(int32_t, c->prot_gid, sh->prot_gid, sh->n_prot); DUP(uint8_t, c->gene_pref, sh->gene_pref, sh->n_gene);
-	DUP(int32_t, c->r_pid, sh->pid, N); DUP(int32_t, c->r_cid, sh->cid, N); DUP(int32_t, c->r_rank, sh->rank, N);
-	DUP(int32_t, c->r_sori, sh->score_ori, N); DUP(int32_t, c->r_sadj, sh->score_adj, N); DUP(int32_t, c->r_nex, sh->n_exon_of, N);
-	DUP(int32_t, c->r_offx, sh->off_exon, N); DUP(int32_t, c->r_cs, sh->cs, N); DUP(int32_t, c->r_ce, sh->ce, N); DUP(int32_t, c->r_cm, sh->cm, N);
-	DUP(uint8_t, c->r_rev, sh->rev, N);
+	c->r_pid = MALLOC(int32_t, N); c->r_cid = MALLOC(int32_t, N); c->r_rank = MALLOC(int32_t, N); c->r_sori = MALLOC(int32_t, N); c->r_sadj = MALLOC(int32_t, N);
+	c->r_nex = MALLOC(int32_t, N); c->r_offx = MALLOC(int32_t, N); c->r_cs = MALLOC(int32_t, N); c->r_ce = MALLOC(int32_t, N); c->r_cm = MALLOC(int32_t, N);
+	c->r_rev = MALLOC(uint8_t, N);
+	{ /* unpack the per-genome blocks (pga_genome_block_t) into flat file-order arrays; exon offsets become shard-wide */
+		int32_t g; int64_t hb = 0, eb = 0;
+		for (g = 0; g < sh->n_genome; ++g) {
+			const pga_genome_block_t *b = &sh->block[g];
+			const int64_t n = b->n_hit;
+			const int32_t *w = b->data, *ex = w + PGA_BLOCK_PLANES * n + (n + 3) / 4;
+			const uint8_t *rev = (const uint8_t *)(w + PGA_BLOCK_PLANES * n);
+			for (i = 0; i < n; ++i) {
+				c->r_pid[hb + i] = w[i], c->r_cid[hb + i] = w[n + i], c->r_rank[hb + i] = w[2 * n + i], c->r_sori[hb + i] = w[3 * n + i];
+				c->r_sadj[hb + i] = w[4 * n + i], c->r_nex[hb + i] = w[5 * n + i], c->r_offx[hb + i] = (int32_t)(eb + w[6 * n + i]);
+				c->r_cs[hb + i] = w[7 * n + i], c->r_ce[hb + i] = w[8 * n + i], c->r_cm[hb + i] = w[9 * n + i], c->r_rev[hb + i] = rev[i];
+			}
+			for (i = 0; i < b->n_exon; ++i) c->exon_os[eb + i] = ex[2 * i], c->exon_oe[eb + i] = ex[2 * i + 1];
+			c->off[g] = hb, c->n_ctg[g] = b->n_ctg;
+			hb += n, eb += b->n_exon;
+		}
+		c->off[sh->n_genome] = hb;
+		if (hb != N || eb != sh->n_exon) { pgo_destroy(c); return PGA_ERR_ARG; }
+	}
 	c->fidx = MALLOC(int32_t, N); c->pid = MALLOC(int32_t, N); c->gid = MALLOC(int32_t, N); c->cid = MALLOC(int32_t, N);
 	c->rank = MALLOC(int32_t, N); c->score_ori = MALLOC(int32_t, N); c->score_adj = MALLOC(int32_t, N);
 	c->score_dom = CALLOC(int32_t, N); c->n_exon_of = MALLOC(int32_t, N); c->off_exon = MALLOC(int32_t, N);
@@ -800,6 +820,17 @@ int pgo_arc_set_current(pga_ctx_t *c, const pga_arc_part_t *arcs, int64_t n_arc,
 	return PGA_OK;
 }
 
+int pgo_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt, int32_t *deg, const pga_arc_part_t **arcs_out, int64_t *n_arc)
+{
+	int32_t *sc; pga_arc_part_t *arcs;
+	int rc = pgo_arc_round(c, use_ori, &sc, &arcs, n_arc);
+	*arcs_out = arcs;
+	if (rc != PGA_OK) return rc;
+	if (n_seg != c->n_seg) return PGA_ERR_ARG;
+	memcpy(seg_cnt, sc, 2 * (size_t)n_seg * sizeof(int32_t));
+	return pgo_arc_set_current(c, arcs, *n_arc, n_seg, deg);
+}
+
 int pgo_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg,
                      double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs)
 {
@@ -925,7 +956,7 @@ int pgo_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, const int32_t
 #undef PERM_ARR
 			for (i = st; i < en; ++i) c->yo[i] = remap[c->yo[i] - st];
 			free(remap);
-			c->head[j] = st;
+			if (p0 == st) c->head[j] = st; /* the genome's first contig now follows the exact order: array index 0 is its first hit */
 		}
 		free(inv);
 	}
@@ -1003,7 +1034,7 @@ const pga_backend_t *pgo_backend(void)
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
 		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_arc_merge, pgo_arc_set_current, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
-		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs
+		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs, pgo_host_alloc, pgo_host_free, pgo_arc_round_local
 	};
 	return &b;
 }

@@ -5,6 +5,33 @@
 // ------------------------------------------------------------------------------------------------
 // create: derive per-hit constants in file order, sort into X order, gather, pm, Y order
 // ------------------------------------------------------------------------------------------------
+// The shard arrives as one block per genome (pga_genome_block_t: 10 planes of n_hit int32, rev bytes, exon pairs), copied as
+// it is into `raw`.  One pass spreads the blocks into flat file-order arrays (plane f of the shard at up + f * N; rev bytes at
+// plane 14) and makes the exon offsets shard-wide.
+__global__ __launch_bounds__(BLOCK) void k_unblock(const int32_t *raw, const int64_t *woff, const int32_t *goff, const int32_t *eoff, int n_genome, int n, int32_t *up)
+{
+	const int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const int g = genome_of(goff, n_genome, i), li = i - goff[g], ng = goff[g + 1] - goff[g];
+	const int32_t *b = raw + woff[g];
+#pragma unroll
+	for (int f = 0; f < PGA_BLOCK_PLANES; ++f) {
+		int32_t v = b[(int64_t)f * ng + li];
+		if (f == 6) v += eoff[g]; // off_exon
+		up[(int64_t)f * n + i] = v;
+	}
+	((uint8_t *)(up + 14 * (int64_t)n))[i] = ((const uint8_t *)(b + (int64_t)PGA_BLOCK_PLANES * ng))[li];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_unblock_exons(const int32_t *raw, const int64_t *woff, const int32_t *goff, const int32_t *eoff, int n_genome, int n_exon, int2 *exon)
+{
+	const int e = blockIdx.x * BLOCK + threadIdx.x;
+	if (e >= n_exon) return;
+	const int g = genome_of(eoff, n_genome, e), ng = goff[g + 1] - goff[g];
+	const int32_t *x = raw + woff[g] + (int64_t)PGA_BLOCK_PLANES * ng + (ng + 3) / 4 + 2 * (int64_t)(e - eoff[g]);
+	exon[e] = make_int2(x[0], x[1]);
+}
+
 struct FileHits { const int32_t *pid, *cid, *rank, *sori, *sadj, *nex, *offx, *cs, *ce, *cm; const uint8_t *rev; };
 
 __global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int32_t *goff, int n_genome, const int32_t *ctg_base,

@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 #include <algorithm>
 #include "pangene_hip.h"
@@ -32,32 +33,45 @@ using namespace pgd;
 #define F_CSTIE 0x20000000u  // static: an X-order neighbour shares (contig, cs) -- member of a tie group of the cs sort (hazard H2b; set by k_pack_rec)
 #define F_PUBLIC 0x7ffu
 
+// the shared scan / sort work buffer: tile sums of a scan over n items (8 bytes each) or the 256 digit totals of a radix pass
+static inline size_t tile_buf_bytes(int64_t n) { return std::max<size_t>(sizeof(int64_t) * (size_t)(scan_tiles(std::max<int64_t>(rs_table_len(n), n)) + 8), 256 * sizeof(uint32_t) + 64); }
+
 static inline unsigned nblk(int64_t n, int per = BLOCK) { return (unsigned)((n + per - 1) / per); }
 
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
 struct DevPool { // persistent, grow-only device temporaries keyed by slot
-	std::vector<void *> p; std::vector<size_t> cap;
+	std::vector<void *> p; std::vector<size_t> cap; std::vector<char> own; // own: the slot has a hipMalloc of its own
+	// One big allocation made in create() from which the slots are carved (a bump allocator: a slot that outgrows its piece
+	// takes a new one): the first pass of a run then needs two hipMalloc calls instead of ~70.
+	char *arena = nullptr; size_t arena_cap = 0, arena_off = 0;
 	void *get(int slot, size_t bytes)
 	{
-		if ((int)p.size() <= slot) p.resize(slot + 1, nullptr), cap.resize(slot + 1, 0);
+		if ((int)p.size() <= slot) p.resize(slot + 1, nullptr), cap.resize(slot + 1, 0), own.resize(slot + 1, 0);
 		if (bytes == 0) bytes = 16;
 		if (cap[slot] < bytes) {
-			if (p[slot]) (void)hipFree(p[slot]);
-			size_t want = bytes + bytes / 4 + 256;
-			if (hipMalloc(&p[slot], want) != hipSuccess) { p[slot] = nullptr; cap[slot] = 0; return nullptr; }
+			if (p[slot] && own[slot]) (void)hipFree(p[slot]);
+			size_t want = (bytes + bytes / 4 + 256 + 255) & ~(size_t)255;
+			if (arena && arena_off + want <= arena_cap) { p[slot] = arena + arena_off, arena_off += want, own[slot] = 0; }
+			else if (hipMalloc(&p[slot], want) == hipSuccess) own[slot] = 1;
+			else { p[slot] = nullptr; cap[slot] = 0; own[slot] = 0; return nullptr; }
 			cap[slot] = want;
 		}
 		return p[slot];
 	}
-	void release() { for (void *q : p) if (q) (void)hipFree(q); p.clear(); cap.clear(); }
+	void release()
+	{
+		for (size_t i = 0; i < p.size(); ++i) if (p[i] && own[i]) (void)hipFree(p[i]);
+		if (arena) (void)hipFree(arena);
+		p.clear(); cap.clear(); own.clear(); arena = nullptr; arena_cap = arena_off = 0;
+	}
 };
 
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK,
+	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK,
 	S_COUNT
 };
 
@@ -80,7 +94,7 @@ struct pga_ctx {
 	int4 *recA = 0, *recB = 0, *recC = 0; // packed sweep records (derived from the arrays above, see k_pack_rec)
 	// dynamic per hit
 	int32_t *rank = 0, *sdom = 0, *pdom = 0, *pdom0 = 0; uint32_t *flags = 0;
-	int32_t *yperm = 0, *goff = 0, *ggl = 0, *ctg_base = 0, *inv = 0, *headpos = 0;
+	int32_t *yperm = 0, *goff = 0, *ggl = 0, *ctg_base = 0, *inv = 0, *headpos = 0, *eoff = 0; int64_t *woff = 0;
 	int cs_bits = 1, cm_bits = 1, seg_bits = 1;
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors
@@ -92,22 +106,52 @@ struct pga_ctx {
 	int32_t *h_g2s = nullptr; size_t h_g2s_cap = 0; hipEvent_t g2s_done = nullptr; // pinned staging of flag_vtx's gene -> segment map
 	DevPool pool;
 	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
+	// gene-major index (k_genes.hpp): hits by (gene, genome, X position); half-arc records of the current walk
+	int2 *zrec = 0; int32_t *zpos = 0, *zposy = 0, *zoff = 0; int4 *hf = 0, *hb = 0;
+	bool z_valid = false, ha_valid = false; uint32_t round_tag = 0; int ha_ori = -1;
+	int32_t *h_round = nullptr; size_t h_round_cap = 0; // pinned: segment counters + degrees of a round
 	int4 *yrecA = 0, *yrecB = 0; bool yrec_valid = false; // Y-order static records (k_pack_yrec), rebuilt after anything that changes their sources
 	int64_t br_n = 0, br_np = 0; int32_t br_S = 0; // arcs / pairs / segments of the last branch_pairs
-	std::vector<TimedLaunch> timed;
+	std::vector<TimedLaunch> timed; bool timing_on = false; // HIP-event timing of kernel classes, switched on by pga_timing_reset (bench.py)
+	hipEvent_t span_a = nullptr; // start of stage A (pga_begin), paired with an event at the end of pga_ingest
 	std::vector<void *> owned;
+	std::vector<std::pair<void **, size_t>> plan; // persistent arrays waiting for the arena (create)
 };
 
+// persistent arrays are carved from ONE allocation: dalloc() only records the request, dalloc_commit() allocates and hands out
 template <class T> static int dalloc(pga_ctx *c, T **p, size_t n)
 {
-	void *q = nullptr;
-	if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return PGA_ERR_NOMEM;
-	*p = (T *)q;
-	c->owned.push_back(q);
+	c->plan.emplace_back((void **)p, (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t)255);
+	return 0;
+}
+
+static int dalloc_commit(pga_ctx *c)
+{
+	size_t tot = 0;
+	if (getenv("PANGENE_NO_ARENA")) { // debugging aid: one allocation per array (out-of-bounds accesses then land in padding)
+		for (auto &e : c->plan) { void *q = nullptr; if (hipMalloc(&q, e.second) != hipSuccess) return PGA_ERR_NOMEM; *e.first = q; c->owned.push_back(q); }
+		c->plan.clear();
+		return 0;
+	}
+	for (auto &e : c->plan) tot += e.second;
+	void *base = nullptr;
+	if (hipMalloc(&base, tot ? tot : 256) != hipSuccess) return PGA_ERR_NOMEM;
+	c->owned.push_back(base);
+	size_t off = 0;
+	for (auto &e : c->plan) *e.first = (char *)base + off, off += e.second;
+	c->plan.clear();
 	return 0;
 }
 
 extern "C" int pga_is_device(void) { return 1; }
+
+// pinned host memory: what the reader packs the genomes into, so that the upload is plain DMA
+extern "C" int pga_host_alloc(size_t nbytes, void **ptr)
+{
+	*ptr = nullptr;
+	return hipHostMalloc(ptr, nbytes ? nbytes : 1, hipHostMallocDefault) == hipSuccess ? 0 : PGA_ERR_NOMEM;
+}
+extern "C" void pga_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
 
 extern "C" const char *pga_strerror(int code)
 {
@@ -130,6 +174,7 @@ extern "C" const char *pga_strerror(int code)
 #include "k_vertex.hpp"
 #include "k_arcs.hpp"
 #include "k_branch.hpp"
+#include "k_genes.hpp"
 #include "k_order.hpp"
 
 // ================================================================================================
@@ -162,12 +207,12 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 	{ const int rc = make_sweep_view(c, &v); if (rc) return rc; }
 	TimedLaunch t; t.which = timed_which; t.units = c->N;
 	static const int reps = [] { const char *e = getenv("PGA_SW_REPS"); return e && atoi(e) > 0 ? atoi(e) : 1; }(); // tuning aid: the sweep is idempotent
-	const bool timed = timed_which >= 0;
+	const bool timed = timed_which >= 0 && c->timing_on;
 	if (timed) {
 		HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
 		if (reps != 1) HIPCHK(hipEventRecord(t.a, c->st));
 	}
-	c->walk_valid = false;
+	c->walk_valid = false, c->ha_valid = false;
 	const int nt = (int)nblk(c->N, SW_TILE);
 	v.prof = nullptr;
 #ifdef PGA_SW_PROFILE
@@ -196,7 +241,7 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 		        d[1] / (SW_NW * nt), d[2] / (SW_NW * nt), d[3] / (SW_NW * nt), d[4] / (SW_NW * nt), d[5] / (SW_NW * nt), d[6] / (SW_NW * nt), d[7] / (SW_NW * nt));
 	}
 #endif
-	if (timed_which >= 0) {
+	if (timed) {
 		if (reps != 1) HIPCHK(hipEventRecord(t.b, c->st));
 		c->timed.push_back(t);
 	}
@@ -210,7 +255,7 @@ static int radix_sort_pool(pga_ctx *c, uint64_t *keys, uint32_t *vals, int64_t n
 	b.k_alt = (uint64_t *)c->pool.get(S_KEY_B, 0);
 	b.v_alt = (uint32_t *)c->pool.get(S_VAL_B, 0);
 	b.table = (uint32_t *)c->pool.get(S_TABLE, 0);
-	b.tile_buf = (int32_t *)c->pool.get(S_TILE, 0);
+	b.tile_buf = (int32_t *)c->pool.get(S_TILE, tile_buf_bytes(n));
 	if (!b.k_alt || !b.v_alt || !b.table || !b.tile_buf) return PGA_ERR_NOMEM;
 	device_radix_sort(keys, vals, n, n_bits, b, kres, vres, c->st);
 	return 0;
@@ -221,11 +266,13 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 	if (c == nullptr) return;
 	if (c->st) (void)hipStreamSynchronize(c->st);
 	for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+	if (c->span_a) (void)hipEventDestroy(c->span_a);
 	for (void *q : c->owned) (void)hipFree(q);
 	c->pool.release();
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	if (c->h_stage) (void)hipHostFree(c->h_stage);
 	if (c->h_g2s) (void)hipHostFree(c->h_g2s);
+	if (c->h_round) (void)hipHostFree(c->h_round);
 	if (c->g2s_done) (void)hipEventDestroy(c->g2s_done);
 	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
 	delete c;
@@ -265,6 +312,9 @@ template <class T> static int upload(pga_ctx *c, T *dst, const T *src, size_t n)
 static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 {
 	const int N = c->N, E = c->E, GL = c->n_genome;
+	static const bool timing = getenv("PANGENE_TIMING") != nullptr;
+	auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+	const double t0 = now();
 	HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
 	g_active_stream = c->st;
 	{
@@ -281,59 +331,77 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(dalloc(c, &c->offx, N)); TRY(dalloc(c, &c->sori, N)); TRY(dalloc(c, &c->sadj, N)); TRY(dalloc(c, &c->pm, N)); TRY(dalloc(c, &c->rk, N)); TRY(dalloc(c, &c->recA, N)); TRY(dalloc(c, &c->recB, N)); TRY(dalloc(c, &c->recC, N)); TRY(dalloc(c, &c->yrecA, N)); TRY(dalloc(c, &c->yrecB, N));
 	TRY(dalloc(c, &c->rank, N)); TRY(dalloc(c, &c->sdom, N)); TRY(dalloc(c, &c->pdom, N)); TRY(dalloc(c, &c->pdom0, N)); TRY(dalloc(c, &c->flags, N));
 	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->ctg_base, GL + 1)); TRY(dalloc(c, &c->inv, N)); TRY(dalloc(c, &c->headpos, GL + 1)); TRY(dalloc(c, &c->exon, E));
+	TRY(dalloc(c, &c->eoff, GL + 1)); TRY(dalloc(c, &c->woff, GL + 1));
+	TRY(dalloc(c, &c->zrec, N)); TRY(dalloc(c, &c->zpos, N)); TRY(dalloc(c, &c->zposy, N)); TRY(dalloc(c, &c->zoff, (size_t)c->Q + 2)); TRY(dalloc(c, &c->hf, N)); TRY(dalloc(c, &c->hb, N));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q));
 	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
+	TRY(dalloc_commit(c));
 
-	// host-side small tables
-	std::vector<int32_t> ctg_base((size_t)GL + 1, 0);
-	c->h_goff.resize((size_t)GL + 1);
-	for (int g = 0; g <= GL; ++g) c->h_goff[(size_t)g] = (int32_t)sh->hit_off[g];
-	for (int g = 0; g < GL; ++g) ctg_base[(size_t)g + 1] = ctg_base[(size_t)g] + sh->n_ctg[g];
+	// host-side small tables (genome-sized)
+	std::vector<int32_t> ctg_base((size_t)GL + 1, 0), eoff((size_t)GL + 1, 0);
+	std::vector<int64_t> woff((size_t)GL + 1, 0);
+	c->h_goff.assign((size_t)GL + 1, 0);
 	c->rp_compact = true;
-	for (int g = 0; g < GL; ++g) if (sh->n_ctg[g] >= 4096 || sh->hit_off[g + 1] - sh->hit_off[g] >= (1 << 20)) c->rp_compact = false;
-	c->n_seg_ctg = ctg_base[(size_t)GL];
-	c->h_ggl.assign(sh->genome_global, sh->genome_global + GL);
 	uint32_t max_cs = 0, max_cm = 0, max_sadj = 0;
 	bool neg_sadj = false, multi = false;
-	for (int i = 0; i < N; ++i) {
-		if (sh->cs[i] < 0 || sh->ce[i] < sh->cs[i] || sh->cm[i] < 0 || sh->cid[i] < 0) return PGA_ERR_RANGE;
-		max_cs = std::max(max_cs, (uint32_t)sh->cs[i]), max_cm = std::max(max_cm, (uint32_t)sh->cm[i]);
-		if (sh->score_adj[i] < 0) neg_sadj = true; else max_sadj = std::max(max_sadj, (uint32_t)sh->score_adj[i]);
-		multi = multi || sh->n_exon_of[i] != 1;
+	for (int g = 0; g < GL; ++g) {
+		const pga_genome_block_t &b = sh->block[g];
+		if (b.n_hit < 0 || b.n_exon < 0 || b.n_ctg < 0 || b.n_words != (size_t)PGA_BLOCK_PLANES * b.n_hit + ((size_t)b.n_hit + 3) / 4 + 2 * (size_t)b.n_exon) return PGA_ERR_ARG;
+		c->h_goff[(size_t)g + 1] = c->h_goff[(size_t)g] + b.n_hit, eoff[(size_t)g + 1] = eoff[(size_t)g] + b.n_exon;
+		ctg_base[(size_t)g + 1] = ctg_base[(size_t)g] + b.n_ctg, woff[(size_t)g + 1] = woff[(size_t)g] + (int64_t)b.n_words;
+		if (b.n_ctg >= 4096 || b.n_hit >= (1 << 20)) c->rp_compact = false;
+		max_cs = std::max(max_cs, (uint32_t)b.max_cs), max_cm = std::max(max_cm, (uint32_t)b.max_cm), max_sadj = std::max(max_sadj, (uint32_t)b.max_score_adj);
+		neg_sadj = neg_sadj || b.any_neg_score_adj, multi = multi || b.any_multi_exon;
 	}
+	if (c->h_goff[(size_t)GL] != N || eoff[(size_t)GL] != E) return PGA_ERR_ARG;
+	c->n_seg_ctg = ctg_base[(size_t)GL];
+	c->h_ggl.assign(sh->genome_global, sh->genome_global + GL);
 	c->cs_bits = bits_for(max_cs), c->cm_bits = bits_for(max_cm), c->seg_bits = bits_for((uint32_t)std::max(1, c->n_seg_ctg));
 	c->sc_bits = neg_sadj ? 64 : std::min(64, 33 + bits_for(max_sadj)); // score key = score_adj << 33 | preferred << 32 | hash(pid)
 	c->any_multi = multi;
-	std::vector<int2> hex((size_t)E);
-	for (int e = 0; e < E; ++e) hex[(size_t)e] = make_int2(sh->exon_os[e], sh->exon_oe[e]);
 
-	// the shard in file order stays resident (S_UPLOAD) so that begin() can restart a run without PCIe traffic
-	int32_t *up = (int32_t *)c->pool.get(S_UPLOAD, sizeof(int32_t) * (size_t)N * 16 + 64);
-	if (!up) return PGA_ERR_NOMEM;
-	TRY(upload(c, up, sh->pid, N)); TRY(upload(c, up + (size_t)N, sh->cid, N)); TRY(upload(c, up + 2 * (size_t)N, sh->rank, N));
-	TRY(upload(c, up + 3 * (size_t)N, sh->score_ori, N)); TRY(upload(c, up + 4 * (size_t)N, sh->score_adj, N));
-	TRY(upload(c, up + 5 * (size_t)N, sh->n_exon_of, N)); TRY(upload(c, up + 6 * (size_t)N, sh->off_exon, N));
-	TRY(upload(c, up + 7 * (size_t)N, sh->cs, N)); TRY(upload(c, up + 8 * (size_t)N, sh->ce, N)); TRY(upload(c, up + 9 * (size_t)N, sh->cm, N));
-	TRY(upload(c, (uint8_t *)(up + 14 * (size_t)N), sh->rev, N));
+	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
+		const size_t per_hit = 420, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
+		const size_t want = ((size_t)N * per_hit + tables + (64u << 20) + (size_t)woff[(size_t)GL] * 4 + 255) & ~(size_t)255;
+		void *a = nullptr;
+		if (getenv("PANGENE_NO_POOL_ARENA") == nullptr && hipMalloc(&a, want) == hipSuccess) c->pool.arena = (char *)a, c->pool.arena_cap = want, c->pool.arena_off = 0; // else: slot by slot
+		else (void)hipGetLastError();
+	}
+	const double t1 = now();
+	// the blocks as they are (one DMA per genome out of pinned memory), then one kernel spreads them into flat file-order arrays
+	int32_t *raw = (int32_t *)c->pool.get(S_RAW, sizeof(int32_t) * (size_t)woff[(size_t)GL] + 64);
+	int32_t *up = (int32_t *)c->pool.get(S_UPLOAD, sizeof(int32_t) * (size_t)N * 16 + 64); // stays resident: begin() restarts a run without PCIe traffic
+	if (!raw || !up) return PGA_ERR_NOMEM;
+	for (int g = 0; g < GL; ++g)
+		if (sh->block[g].n_words) HIPCHK(hipMemcpyAsync(raw + woff[(size_t)g], sh->block[g].data, sizeof(int32_t) * sh->block[g].n_words, hipMemcpyHostToDevice, c->st));
 	TRY(upload(c, c->goff, c->h_goff.data(), (size_t)GL + 1)); TRY(upload(c, c->ggl, c->h_ggl.data(), GL));
-	TRY(upload(c, c->ctg_base, ctg_base.data(), (size_t)GL + 1));
-	TRY(upload(c, c->exon, hex.data(), E)); TRY(upload(c, c->prot_gid, sh->prot_gid, c->P)); TRY(upload(c, c->gene_pref, sh->gene_pref, c->Q));
+	TRY(upload(c, c->ctg_base, ctg_base.data(), (size_t)GL + 1)); TRY(upload(c, c->eoff, eoff.data(), (size_t)GL + 1)); TRY(upload(c, c->woff, woff.data(), (size_t)GL + 1));
+	TRY(upload(c, c->prot_gid, sh->prot_gid, c->P)); TRY(upload(c, c->gene_pref, sh->gene_pref, c->Q));
+	if (N) hipLaunchKernelGGL(k_unblock, dim3(nblk(N)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, N, up);
+	if (E) hipLaunchKernelGGL(k_unblock_exons, dim3(nblk(E)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, E, c->exon);
 	{ // work buffers shared by every sort / scan of the run: sized for the largest input (2N temp arcs)
 		const int64_t W = 2 * (int64_t)N + 2;
 		if (!c->pool.get(S_KEY_A, sizeof(uint64_t) * (size_t)W) || !c->pool.get(S_VAL_A, sizeof(uint32_t) * (size_t)W) ||
 		    !c->pool.get(S_KEY_B, sizeof(uint64_t) * (size_t)W) || !c->pool.get(S_VAL_B, sizeof(uint32_t) * (size_t)W) ||
 		    !c->pool.get(S_TABLE, sizeof(uint32_t) * (size_t)rs_table_len(W)) ||
-		    !c->pool.get(S_TILE, sizeof(int64_t) * (size_t)(scan_tiles(std::max<int64_t>(rs_table_len(W), W)) + 8))) return PGA_ERR_NOMEM;
+		    !c->pool.get(S_TILE, tile_buf_bytes(W))) return PGA_ERR_NOMEM;
 	}
-	return sync_st(c);
+	const int rc = sync_st(c); // the caller's blocks and tables have been read
+	if (timing) fprintf(stderr, "[pga_create] allocations %.3f ms, upload of %.1f MB + unpack %.3f ms\n", (t1 - t0) * 1e3, woff[(size_t)GL] * 4e-6, (now() - t1) * 1e3);
+	return rc;
 }
 
 // per-hit constants in file order, X order (sort + gather), running max of ce, Y order; resets all state
 extern "C" int pga_begin(pga_ctx_t *c)
 {
-	c->yrec_valid = false;
+	c->yrec_valid = false, c->z_valid = false;
 	const int N = c->N, GL = c->n_genome;
-	c->walk_valid = false;
+	c->walk_valid = false, c->ha_valid = false;
+	if (c->timing_on) { // class 3: the whole of stage A (sorts, per-hit constants, pg_flag_pseudo, sweeps, filters) = pga_begin + pga_ingest
+		if (c->span_a) (void)hipEventDestroy(c->span_a);
+		HIPCHK(hipEventCreate(&c->span_a));
+		HIPCHK(hipEventRecord(c->span_a, c->st));
+	}
 	HIPCHK(hipMemsetAsync(c->dcnt, 0, 16 * sizeof(int64_t), c->st));
 	if (c->Q) hipLaunchKernelGGL(k_fill_i32, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, (int64_t)c->Q, -1);
 	c->n_seg = 0;
@@ -355,7 +423,7 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	{ // dense rank of the score keys (see k_rank_scatter)
 		TRY(radix_sort_pool(c, key, val, N, c->sc_bits, &ks, &vs));
 		hipLaunchKernelGGL(k_arc_head, dim3(nblk(N)), dim3(BLOCK), 0, c->st, ks, (int64_t)N, head);
-		I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
 		device_scan<I32>(InI32{head}, OutInclI32{incl}, N, tile, OpSum{}, I32{0}, c->st);
 		hipLaunchKernelGGL(k_rank_scatter, dim3(nblk(N)), dim3(BLOCK), 0, c->st, ks, vs, incl, N, rk_f);
 	}
@@ -368,7 +436,7 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv);
 	HIPCHK(hipMemcpyAsync(c->headpos, c->goff, sizeof(int32_t) * ((size_t)GL + 1), hipMemcpyDeviceToDevice, c->st));
 	// running max of ce per contig
-	SegMax *tile = (SegMax *)c->pool.get(S_TILE, 0);
+	SegMax *tile = (SegMax *)c->pool.get(S_TILE, tile_buf_bytes(N));
 	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
 	pack_records(c);
 	// Y order: pg_hit_sort(g, 1); ties keep X order
@@ -391,6 +459,7 @@ extern "C" int pga_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_para
 	pga_ctx *c = new pga_ctx();
 	c->n_genome = sh->n_genome, c->n_genome_global = sh->n_genome_global, c->P = sh->n_prot, c->Q = sh->n_gene;
 	c->N = (int32_t)sh->n_hit, c->E = (int32_t)sh->n_exon, c->par = *par;
+	if (sh->n_genome > 0 && sh->block == nullptr) { delete c; return PGA_ERR_ARG; }
 	int rc = create_impl(c, sh);
 	if (rc) { pga_destroy(c); return rc; }
 	*out = c;
@@ -431,6 +500,12 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 		hipLaunchKernelGGL(k_subopt2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->pid, c->goff, N, Q, tbest, d_stats, c->rank, c->sadj, c->recA, c->dcnt,
 		                   (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP));
 	}
+	if (c->timing_on && c->span_a) {
+		TimedLaunch t; t.which = 3, t.units = N, t.a = c->span_a, c->span_a = nullptr;
+		HIPCHK(hipEventCreate(&t.b));
+		HIPCHK(hipEventRecord(t.b, c->st));
+		c->timed.push_back(t);
+	}
 	if (stats) {
 		HIPCHK(hipMemcpyAsync(stats, d_stats, sizeof(int32_t) * 4 * (size_t)GL, hipMemcpyDeviceToHost, c->st));
 		return sync_st(c);
@@ -452,7 +527,7 @@ extern "C" int pga_post_apply(pga_ctx_t *c, const uint8_t *prot_rep, const uint8
 	c->yrec_valid = false;
 	uint8_t *d = (uint8_t *)c->pool.get(S_MISC, 2 * (size_t)c->P + 16);
 	if (!d) return PGA_ERR_NOMEM;
-	c->walk_valid = false;
+	c->walk_valid = false, c->ha_valid = false;
 	TRY(upload(c, d, prot_rep, (size_t)c->P)); TRY(upload(c, d + c->P, prot_pj, (size_t)c->P));
 	HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
 	if (c->N) hipLaunchKernelGGL(k_post_apply, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->nex, c->sdom, c->N, c->max_ori, d, d + c->P, c->dcnt + 2);
@@ -480,7 +555,7 @@ extern "C" int pga_shadow(pga_ctx_t *c, int32_t cal_dom_sc, int32_t *stats)
 extern "C" int pga_set_filter(pga_ctx_t *c, int32_t which)
 {
 	if (which < 0 || which > 3) return PGA_ERR_ARG;
-	c->walk_valid = false;
+	c->walk_valid = false, c->ha_valid = false;
 	if (c->N) hipLaunchKernelGGL(k_set_filter, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->N, which);
 	return 0;
 }
@@ -512,7 +587,7 @@ extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records,
 	hipLaunchKernelGGL(k_vtx1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt);
 	hipLaunchKernelGGL(k_vtx_fold, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, c->prot_gid, c->ggl, N, bits, wpg,
 	                   dom_tab, pbits, nw, rec + n_slot * (1 + nw), ovf_cap, c->dcnt);
-	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_slot));
 	if (!tile) return PGA_ERR_NOMEM;
 	device_scan<I32>(InDomSet{dom_tab}, OutExclI32{slot}, n_slot, tile, OpSum{}, I32{0}, c->st);
 	hipLaunchKernelGGL(k_vtx_compact, dim3(nblk(n_slot)), dim3(BLOCK), 0, c->st, dom_tab, slot, n_slot, pbits, nw, rec, c->dcnt, c->h_box);
@@ -561,7 +636,7 @@ static int walk_prev(pga_ctx *c, int32_t **val_out, int32_t **prev_out)
 	const int N = c->N;
 	int32_t *val = (int32_t *)c->pool.get(S_WALK_VAL, sizeof(int32_t) * (size_t)N);
 	int32_t *prev = (int32_t *)c->pool.get(S_WALK_PREV, sizeof(int32_t) * (size_t)N);
-	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
 	if (!val || !prev || !tile) return PGA_ERR_NOMEM;
 	*val_out = val, *prev_out = prev;
 	if (c->walk_valid) return 0; // pg_mark_branch_flt_hit walks exactly what the pg_gen_arc before it walked: nothing changed in between
@@ -570,7 +645,90 @@ static int walk_prev(pga_ctx *c, int32_t **val_out, int32_t **prev_out)
 	return 0;
 }
 
-extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int64_t *n_arcs_out)
+// gene-major index: hits sorted by (gene, X position) -- X order is genome-major, so a gene's hits are grouped by genome
+static int ensure_z(pga_ctx *c)
+{
+	if (c->z_valid || c->N == 0) return 0;
+	const int N = c->N;
+	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, 0);
+	uint32_t *val = (uint32_t *)c->pool.get(S_VAL_A, 0);
+	if (!key || !val) return PGA_ERR_NOMEM;
+	hipLaunchKernelGGL(k_zkey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gid, N, key, val);
+	uint64_t *ks; uint32_t *vs;
+	TRY(radix_sort_pool(c, key, val, N, bits_for((uint32_t)std::max(1, c->Q)), &ks, &vs));
+	hipLaunchKernelGGL(k_zrec, dim3(nblk(N)), dim3(BLOCK), 0, c->st, vs, c->gnm, c->flags, N, c->zrec, c->zpos);
+	hipLaunchKernelGGL(k_zoff, dim3(nblk(c->Q + 1)), dim3(BLOCK), 0, c->st, ks, N, c->Q, c->zoff);
+	hipLaunchKernelGGL(k_zpos_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, c->zpos, N, c->zposy);
+	c->z_valid = true, c->ha_valid = false;
+	return 0;
+}
+
+// (A) of k_genes.hpp: walk the cm order once, leave every walkable hit's two half-arc records
+static int ensure_half_arcs(pga_ctx *c, int use_ori)
+{
+	if (c->N == 0) return 0;
+	TRY(ensure_z(c));
+	ensure_yrec(c);
+	if (c->ha_valid && c->ha_ori == use_ori) return 0;
+	if (++c->round_tag > HA_TAG_MAX) { // tags wrap: forget every old record
+		HIPCHK(hipMemsetAsync(c->hf, 0xff, sizeof(int4) * (size_t)c->N, c->st));
+		HIPCHK(hipMemsetAsync(c->hb, 0xff, sizeof(int4) * (size_t)c->N, c->st));
+		c->round_tag = 1;
+	}
+	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(c->N));
+	int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
+	if (!tile || !hzl) return PGA_ERR_NOMEM;
+	device_scan<I32>(InWalk{c->flags, c->yperm}, OutHalfArcs{c->yrecA, c->yrecB, c->zposy, c->g2s, c->hf, c->hb, c->round_tag, use_ori, c->dcnt, hzl}, c->N, tile, OpMax{}, I32{-1}, c->st);
+	c->ha_valid = true, c->ha_ori = use_ori;
+	return 0;
+}
+
+struct CurTable { uint64_t *ax; uint8_t *aw, *vwk; int32_t *s1, *agid, *vs, *ve, *sg, *dg; };
+static int cur_table(pga_ctx *c, int64_t n_arc, int n_seg, CurTable *t)
+{
+	const int n_vtx = 2 * n_seg;
+	t->ax = (uint64_t *)c->pool.get(S_ARCX, sizeof(uint64_t) * (size_t)n_arc + 16);
+	t->aw = (uint8_t *)c->pool.get(S_ARCW, (size_t)n_arc + 16);
+	t->s1 = (int32_t *)c->pool.get(S_BR_S1, sizeof(int32_t) * (size_t)n_arc + 16), t->agid = (int32_t *)c->pool.get(S_BR_GID, sizeof(int32_t) * (size_t)n_arc + 16);
+	t->vs = (int32_t *)c->pool.get(S_BR_VS, sizeof(int32_t) * (size_t)n_vtx + 16), t->ve = (int32_t *)c->pool.get(S_BR_VE, sizeof(int32_t) * (size_t)n_vtx + 16);
+	t->sg = (int32_t *)c->pool.get(S_BR_SEGGID, sizeof(int32_t) * (size_t)n_seg + 16), t->dg = (int32_t *)c->pool.get(S_DEG, sizeof(int32_t) * (size_t)n_vtx + 16);
+	t->vwk = (uint8_t *)c->pool.get(S_VWK, (size_t)n_vtx + 16);
+	return (t->ax && t->aw && t->s1 && t->agid && t->vs && t->ve && t->sg && t->dg && t->vwk) ? 0 : PGA_ERR_NOMEM;
+}
+
+// pg_gen_arc on the gene-major index (k_genes.hpp).  Leaves the round's arc table (sorted by x) in S_ARCS and everything derived
+// from it (what pga_arc_set_current would compute) in place; seg_cnt[2S] and the degrees stay on the device.  The table size and
+// the overflow mark travel to the pinned mirror with the last kernel; nothing waits here.
+static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int32_t **deg_out)
+{
+	const int N = c->N, S = c->n_seg;
+	const int64_t cap = 2 * (int64_t)N + 2; // distinct arcs <= half-arcs <= 2 (N - 1)
+	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES);
+	pga_arc_part_t *stage = (pga_arc_part_t *)c->pool.get(S_ARC_STAGE, sizeof(pga_arc_part_t) * (size_t)cap);
+	pga_arc_part_t *arcs = (pga_arc_part_t *)c->pool.get(S_ARCS, sizeof(pga_arc_part_t) * (size_t)cap);
+	int4 *gmeta = (int4 *)c->pool.get(S_GMETA, sizeof(int4) * (size_t)std::max(1, S));
+	int32_t *off = (int32_t *)c->pool.get(S_GOFF, sizeof(int32_t) * (size_t)std::max(1, S));
+	CurTable t;
+	if (!seg_cnt || !stage || !arcs || !gmeta || !off) return PGA_ERR_NOMEM;
+	TRY(cur_table(c, cap, S, &t));
+	*seg_cnt_out = seg_cnt, *arcs_out = arcs, *deg_out = t.dg;
+	TRY(launch_sweep<0>(c, 2)); // graph.c:102
+	TRY(ensure_half_arcs(c, use_ori));
+	HIPCHK(hipMemsetAsync(c->dcnt + 8, 0, 3 * sizeof(int64_t), c->st)); // staged arcs, overflowed genes, table size
+	if (S == 0) { hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box); return 0; }
+	GeneArcs ga = { c->zrec, c->zoff, c->flags, c->hf, c->hb, c->g2s, c->Q, S, c->round_tag, seg_cnt, t.sg, stage, gmeta, c->dcnt };
+	hipLaunchKernelGGL(k_gene_arcs, dim3((unsigned)c->Q), dim3(BLOCK), 0, c->st, ga);
+	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(S));
+	if (!tile) return PGA_ERR_NOMEM;
+	device_scan<I32>(InGmeta{gmeta}, OutExclI32{off}, S, tile, OpSum{}, I32{0}, c->st);
+	ArcFinal f = { gmeta, off, S, stage, t.sg, arcs, t.ax, t.s1, t.agid, t.vs, t.ve, t.dg, t.aw, t.vwk, c->dcnt, c->h_box };
+	hipLaunchKernelGGL(k_arc_final, dim3(nblk(S)), dim3(BLOCK), 0, c->st, f);
+	return 0;
+}
+
+// The reference's formulation -- every temp arc through one global sort (graph.c:127,151): kept as the path of rounds in which a
+// hub gene overflows the LDS table of k_gene_arcs, and (PANGENE_ARC_SORT_PATH=1) as an independent check of the gene path.
+static int arc_round_sorted(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int64_t *n_arcs_out)
 {
 	const int N = c->N, S = c->n_seg, GL = c->n_genome;
 	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES);
@@ -592,7 +750,7 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	ensure_yrec(c);
 	hipLaunchKernelGGL(k_arc_flag, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yrecA, c->g2s, N, S, has, seg_cnt, seen, wpg, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP));
 	if (S) hipLaunchKernelGGL(k_segcnt_sum, dim3(nblk(2 * S)), dim3(BLOCK), 0, c->st, seg_cnt, 2 * S);
-	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
 	device_scan<I32>(InI32{has}, OutExclI32{slot}, N, tile, OpSum{}, I32{0}, c->st);
 	// number of adjacencies = slot[N-1] + has[N-1]
 	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, slot + (N - 1), has + (N - 1), c->dcnt, c->h_box);
@@ -609,7 +767,7 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	uint64_t *ks; uint32_t *vs;
 	TRY(radix_sort_pool(c, key, idx, M, 2 * vbits, &ks, &vs)); // graph.c:127 and :151 in one stable sort
 	hipLaunchKernelGGL(k_arc_gather, dim3(nblk(M)), dim3(BLOCK), 0, c->st, vs, M, tpay, spay);
-	tile = (I32 *)c->pool.get(S_TILE, 0);
+	tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(M));
 	device_scan<I32>(InKeyHead{ks}, OutExclI32{slot}, M, tile, OpSum{}, I32{0}, c->st); // run heads straight from the sorted keys
 	hipLaunchKernelGGL(k_mail_runs, dim3(1), dim3(64), 0, c->st, ks, slot, M, c->dcnt, c->h_box);
 	TRY(sync_st(c));
@@ -626,6 +784,59 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	}
 	*arcs_out = arcs, *n_arcs_out = A;
 	return sync_st(c);
+}
+
+static bool arc_sort_path_forced() { static const bool f = getenv("PANGENE_ARC_SORT_PATH") != nullptr; return f; }
+
+extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int64_t *n_arcs_out)
+{
+	if (c->N && !arc_sort_path_forced()) {
+		int32_t *deg;
+		*n_arcs_out = 0;
+		TRY(arc_round_genes(c, use_ori, seg_cnt_out, arcs_out, &deg));
+		TRY(sync_st(c));
+		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
+		if (c->h_cnt[9] == 0) { *n_arcs_out = c->h_cnt[10]; return 0; }
+	}
+	return arc_round_sorted(c, use_ori, seg_cnt_out, arcs_out, n_arcs_out);
+}
+
+// pg_gen_arc for a run that is not sharded: the round's table is the graph's table at once (what pga_arc_set_current would
+// derive is produced by the same kernels), and the only things the host needs -- segment counters, out-degrees, table size --
+// arrive with ONE wait at the end.
+extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt_host, int32_t *deg_host, const pga_arc_part_t **arcs_out, int64_t *n_arc)
+{
+	const int S = n_seg, n_vtx = 2 * S;
+	*n_arc = 0, *arcs_out = nullptr;
+	if (S != c->n_seg) return PGA_ERR_ARG;
+	if (c->N && !arc_sort_path_forced()) {
+		int32_t *seg_cnt, *deg; pga_arc_part_t *arcs;
+		const size_t need = sizeof(int32_t) * 2 * (size_t)n_vtx + 64;
+		if (c->h_round_cap < need) {
+			if (c->h_round) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipHostFree(c->h_round); c->h_round = nullptr; }
+			HIPCHK(hipHostMalloc((void **)&c->h_round, need + need / 2, hipHostMallocDefault));
+			c->h_round_cap = need + need / 2;
+		}
+		TRY(arc_round_genes(c, use_ori, &seg_cnt, &arcs, &deg));
+		if (n_vtx) {
+			HIPCHK(hipMemcpyAsync(c->h_round, seg_cnt, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
+			HIPCHK(hipMemcpyAsync(c->h_round + n_vtx, deg, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
+		}
+		TRY(sync_st(c));
+		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
+		if (c->h_cnt[9] == 0) {
+			if (n_vtx) memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
+			*n_arc = c->h_cnt[10], *arcs_out = arcs;
+			c->br_n = *n_arc, c->br_S = S, c->br_np = 0;
+			return 0;
+		}
+	}
+	int32_t *seg_cnt; pga_arc_part_t *arcs; int64_t n = 0;
+	TRY(arc_round_sorted(c, use_ori, &seg_cnt, &arcs, &n));
+	TRY(pga_arc_set_current(c, arcs, n, S, deg_host));
+	if (n_vtx) TRY(pga_fetch(c, seg_cnt_host, seg_cnt, sizeof(int32_t) * (size_t)n_vtx));
+	*n_arc = n, *arcs_out = arcs;
+	return 0;
 }
 
 
@@ -645,7 +856,7 @@ extern "C" int pga_arc_merge(pga_ctx_t *c, const pga_arc_part_t *gathered, const
 	int32_t *tile = (int32_t *)c->pool.get(S_TILE, 0);
 	if (!d_off || !key || !val || !slot || !tile) return PGA_ERR_NOMEM;
 	if (tot > 2 * (int64_t)c->N + 2) { // the scan buffer is sized for 2N items
-		tile = (int32_t *)c->pool.get(S_TILE, sizeof(int64_t) * (size_t)(scan_tiles(std::max<int64_t>(rs_table_len(tot), tot)) + 8));
+		tile = (int32_t *)c->pool.get(S_TILE, tile_buf_bytes(tot));
 		if (!tile) return PGA_ERR_NOMEM;
 	}
 	TRY(upload(c, d_off, off.data(), (size_t)W + 1));
@@ -673,22 +884,16 @@ extern "C" int pga_arc_set_current(pga_ctx_t *c, const pga_arc_part_t *arcs, int
 	const int n_vtx = 2 * n_seg;
 	c->br_n = n_arc, c->br_S = n_seg, c->br_np = 0;
 	if (n_vtx) memset(deg, 0, sizeof(int32_t) * (size_t)n_vtx);
-	uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, sizeof(uint64_t) * (size_t)n_arc + 16);
-	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, (size_t)n_arc + 16);
-	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, sizeof(int32_t) * (size_t)n_arc + 16), *agid = (int32_t *)c->pool.get(S_BR_GID, sizeof(int32_t) * (size_t)n_arc + 16);
-	int32_t *vs = (int32_t *)c->pool.get(S_BR_VS, sizeof(int32_t) * (size_t)n_vtx + 16), *ve = (int32_t *)c->pool.get(S_BR_VE, sizeof(int32_t) * (size_t)n_vtx + 16);
-	int32_t *sg = (int32_t *)c->pool.get(S_BR_SEGGID, sizeof(int32_t) * (size_t)n_seg + 16), *dg = (int32_t *)c->pool.get(S_BR_PC, sizeof(int32_t) * (size_t)n_vtx + 16);
-	if (!ax || !aw || !s1 || !agid || !vs || !ve || !sg || !dg) return PGA_ERR_NOMEM;
+	CurTable t;
+	TRY(cur_table(c, n_arc, n_seg, &t));
 	if (n_vtx == 0) return 0;
-	uint8_t *vwk = (uint8_t *)c->pool.get(S_VWK, (size_t)n_vtx + 16);
-	if (!vwk) return PGA_ERR_NOMEM;
-	zero_multi(c, vs, sizeof(int32_t) * (size_t)n_vtx, ve, sizeof(int32_t) * (size_t)n_vtx, aw, (size_t)n_arc, vwk, (size_t)n_vtx);
+	zero_multi(c, t.vs, sizeof(int32_t) * (size_t)n_vtx, t.ve, sizeof(int32_t) * (size_t)n_vtx, t.aw, (size_t)n_arc, t.vwk, (size_t)n_vtx);
 	if (n_arc) {
-		hipLaunchKernelGGL(k_seg_gid, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, c->Q, n_seg, sg);
-		hipLaunchKernelGGL(k_cur_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, arcs, n_arc, sg, ax, s1, agid, vs, ve);
+		hipLaunchKernelGGL(k_seg_gid, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, c->Q, n_seg, t.sg);
+		hipLaunchKernelGGL(k_cur_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, arcs, n_arc, t.sg, t.ax, t.s1, t.agid, t.vs, t.ve);
 	}
-	hipLaunchKernelGGL(k_deg, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, vs, ve, n_vtx, dg);
-	HIPCHK(hipMemcpyAsync(deg, dg, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
+	hipLaunchKernelGGL(k_deg, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, t.vs, t.ve, n_vtx, t.dg);
+	HIPCHK(hipMemcpyAsync(deg, t.dg, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
 	return sync_st(c);
 }
 
@@ -703,7 +908,7 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 	if (N) {
 		int32_t *wk = (int32_t *)c->pool.get(S_I32_A, sizeof(int32_t) * (size_t)N);
 		int32_t *rx = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
-		I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
 		if (!wk || !rx || !tile) return PGA_ERR_NOMEM;
 		device_scan<I32>(InWalkX{c->flags}, OutRankRep{rx, c->gnm, c->gid, GL, rp_pos, c->flags}, N, tile, OpSum{}, I32{0}, c->st);
 		int32_t *iv = (int32_t *)c->pool.get(S_RP_IV, sizeof(int32_t) * (size_t)n_ent);
@@ -762,7 +967,7 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	}
 	HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st));
 	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
-	I32 *tile = (I32 *)c->pool.get(S_TILE, 0);
+	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_vtx));
 	device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
 	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, poff + (n_vtx - 1), pc + (n_vtx - 1), c->dcnt, c->h_box);
 	TRY(sync_st(c));
@@ -808,19 +1013,29 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 	const int N = c->N;
 	if (n_marked) *n_marked = 0;
 	if (N == 0) return 0;
-	if (arc_x == nullptr) n_arc = c->br_n; // the arcs (and weak_br) left resident by branch_pairs / branch_decide
-	uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, arc_x ? sizeof(uint64_t) * (size_t)n_arc + 16 : 0);
-	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, arc_x ? (size_t)n_arc + 16 : 0);
-	int32_t *wn = (int32_t *)c->pool.get(S_WEAKNEW, sizeof(int32_t) * (size_t)N);
-	if (!ax || !aw || !wn) return PGA_ERR_NOMEM;
-	if (arc_x) { TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, aw, arc_weak, (size_t)n_arc)); }
-	zero_multi(c, wn, sizeof(int32_t) * (size_t)N, c->dcnt + 2, sizeof(int64_t));
-	int32_t *val, *prev;
-	TRY(walk_prev(c, &val, &prev));
-	const int32_t *vs = arc_x ? nullptr : (const int32_t *)c->pool.get(S_BR_VS, 0), *ve = arc_x ? nullptr : (const int32_t *)c->pool.get(S_BR_VE, 0);
-	ensure_yrec(c);
-	hipLaunchKernelGGL(k_mark_hits, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yrecA, c->yrecB, c->g2s, N, ax, aw, n_arc, vs, ve, arc_x ? (const uint8_t *)nullptr : (const uint8_t *)c->pool.get(S_VWK, 0), wn);
-	hipLaunchKernelGGL(k_weak_merge, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, wn, N, n_marked ? c->dcnt + 2 : (int64_t *)nullptr);
+	if (arc_x == nullptr) { // the arcs (and their weak_br) left resident by the round: every hit looks at its own two half-arcs (k_genes.hpp)
+		TRY(ensure_half_arcs(c, c->ha_ori < 0 ? 0 : c->ha_ori));
+		const uint64_t *ax = (const uint64_t *)c->pool.get(S_ARCX, 0); const uint8_t *aw = (const uint8_t *)c->pool.get(S_ARCW, 0);
+		const int32_t *vs = (const int32_t *)c->pool.get(S_BR_VS, 0), *ve = (const int32_t *)c->pool.get(S_BR_VE, 0);
+		const uint8_t *vwk = (const uint8_t *)c->pool.get(S_VWK, 0);
+		if (!ax || !aw || !vs || !ve || !vwk) return PGA_ERR_NOMEM;
+		if (n_marked) HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
+		hipLaunchKernelGGL(k_mark_hits_z, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->zrec, c->hf, c->hb, c->round_tag, N, c->g2s, c->gid, ax, aw, vs, ve, vwk, c->flags,
+		                   n_marked ? c->dcnt + 2 : (int64_t *)nullptr);
+		// weak_br does not enter the walkable test: the half-arcs stay valid
+	} else {
+		uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, sizeof(uint64_t) * (size_t)n_arc + 16);
+		uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, (size_t)n_arc + 16);
+		int32_t *wn = (int32_t *)c->pool.get(S_WEAKNEW, sizeof(int32_t) * (size_t)N);
+		if (!ax || !aw || !wn) return PGA_ERR_NOMEM;
+		TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, aw, arc_weak, (size_t)n_arc));
+		zero_multi(c, wn, sizeof(int32_t) * (size_t)N, c->dcnt + 2, sizeof(int64_t));
+		int32_t *val, *prev;
+		TRY(walk_prev(c, &val, &prev));
+		ensure_yrec(c);
+		hipLaunchKernelGGL(k_mark_hits, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yrecA, c->yrecB, c->g2s, N, ax, aw, n_arc, (const int32_t *)nullptr, (const int32_t *)nullptr, (const uint8_t *)nullptr, wn);
+		hipLaunchKernelGGL(k_weak_merge, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, wn, N, n_marked ? c->dcnt + 2 : (int64_t *)nullptr);
+	}
 	if (n_marked) {
 		HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
 		TRY(sync_st(c));
@@ -859,7 +1074,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	hipLaunchKernelGGL(k_ov_gather, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, inv, tmp, remap);
 	hipLaunchKernelGGL(k_ov_scatter, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, T, tmp, c->gnm, c->goff);
 	hipLaunchKernelGGL(k_ov_remap_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, N, remap);
-	SegMax *tile = (SegMax *)c->pool.get(S_TILE, 0);
+	SegMax *tile = (SegMax *)c->pool.get(S_TILE, tile_buf_bytes(N));
 	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
 	hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv);
 	pack_records(c);
@@ -963,6 +1178,7 @@ extern "C" int pga_timing_reset(pga_ctx_t *c)
 	TRY(sync_st(c));
 	for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	c->timed.clear();
+	c->timing_on = true;
 	return 0;
 }
 
@@ -987,7 +1203,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local
 	};
 	return &b;
 }
@@ -1003,7 +1219,7 @@ extern "C" int pga_selftest_sort(uint64_t *keys, uint32_t *vals, int64_t n, int3
 	HIPCHK(hipMalloc((void **)&ka, sizeof(uint64_t) * (size_t)(n + 1))); HIPCHK(hipMalloc((void **)&kb, sizeof(uint64_t) * (size_t)(n + 1)));
 	HIPCHK(hipMalloc((void **)&va, sizeof(uint32_t) * (size_t)(n + 1))); HIPCHK(hipMalloc((void **)&vb, sizeof(uint32_t) * (size_t)(n + 1)));
 	HIPCHK(hipMalloc((void **)&table, sizeof(uint32_t) * (size_t)(rs_table_len(n) + 1)));
-	HIPCHK(hipMalloc((void **)&tile, sizeof(int64_t) * (size_t)(scan_tiles(std::max<int64_t>(rs_table_len(n), n)) + 8)));
+	HIPCHK(hipMalloc((void **)&tile, tile_buf_bytes(n)));
 	HIPCHK(hipMemcpy(ka, keys, sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(va, vals, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
 	RadixBufs b = { kb, vb, table, tile };
@@ -1023,7 +1239,7 @@ extern "C" int pga_selftest_merge(const pga_arc_part_t *gathered, const int64_t 
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PGA_ERR_NO_DEVICE;
 	pga_ctx c; // a bare context: stream, counters, pool
 	HIPCHK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
-	TRY(dalloc(&c, &c.dcnt, 16));
+	TRY(dalloc(&c, &c.dcnt, 16)); TRY(dalloc_commit(&c));
 	HIPCHK(hipHostMalloc((void **)&c.h_cnt, 16 * sizeof(int64_t), hipHostMallocDefault));
 	pga_arc_part_t *dg = nullptr, *res = nullptr;
 	HIPCHK(hipMalloc((void **)&dg, sizeof(pga_arc_part_t) * (size_t)(W * slot_sz + 1)));

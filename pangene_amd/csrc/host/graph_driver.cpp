@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <climits>
 #include <thread>
 #include "pg_internal.hpp"
 #include "ksort_exact.hpp"
@@ -24,7 +26,7 @@ namespace pgx {
 pg_exchange_t g_xchg; bool g_has_xchg = false;
 double g_phase[PH_COUNT];
 static int g_err = 0; static char g_errstr[256] = "";
-static double g_path_sec = 0.0, g_upload_sec = 0.0, g_t_path0 = 0.0; static int64_t g_path_hits = 0;
+static double g_path_sec = 0.0, g_upload_sec = 0.0, g_pack_sec = 0.0, g_t_path0 = 0.0; static int64_t g_path_hits = 0;
 
 void set_error(int code, const char *where)
 {
@@ -110,53 +112,108 @@ static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int6
 }
 
 // ---------------------------------------------------------------------------------------------
-// shard packing: host AoS (pg_hit_t, 88 B) -> SoA for the local genomes, file order
+// shard packing: host AoS (pg_hit_t, 88 B) -> one structure-of-arrays block per genome (pga_genome_block_t), FILE order.
+// Done by the reader as soon as a genome has been parsed (host threads, pinned memory), so that pg_post_process only has
+// to hand the blocks to the backend: the upload is then plain DMA out of pinned memory.
 // ---------------------------------------------------------------------------------------------
+static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
+{
+	GenomePack &pk = ext->packs[(size_t)j];
+	const pg_genome_t *g = &d->genome[j];
+	const pga_backend_t *be = backend_default();
+	const int64_t n = g->n_hit, ne = g->n_exon;
+	const size_t nw = (size_t)(PGA_BLOCK_PLANES * n + (n + 3) / 4 + 2 * ne);
+	pk = GenomePack();
+	if (be->host_alloc && be->host_alloc((nw ? nw : 1) * sizeof(int32_t), &pk.buf) == 0) pk.pinned = true;
+	else pk.buf = std::malloc((nw ? nw : 1) * sizeof(int32_t)), pk.pinned = false;
+	int32_t *w = (int32_t *)pk.buf;
+	uint8_t *rev = (uint8_t *)(w + PGA_BLOCK_PLANES * n);
+	int32_t *ex = w + PGA_BLOCK_PLANES * n + (n + 3) / 4;
+	// the host array is in file order until the first sync_host and in cs order afterwards (file_of_host: host index -> file index)
+	const bool sorted = (size_t)j < ext->hits_sorted.size() && ext->hits_sorted[(size_t)j] && (size_t)j < ext->file_of_host.size();
+	const int32_t *fof = sorted ? ext->file_of_host[(size_t)j].data() : nullptr;
+	int32_t max_cs = 0, max_cm = 0, max_sadj = 0, neg = 0, multi = 0;
+	for (int64_t h = 0; h < n; ++h) {
+		const pg_hit_t *a = &g->hit[h];
+		const int64_t f = fof ? fof[h] : h;
+		if (a->cs < 0 || a->ce >= INT32_MAX || a->cm < 0 || a->cm >= INT32_MAX || a->ce < a->cs || a->cid < 0) { pk.err = PGA_ERR_RANGE; continue; }
+		w[f] = a->pid, w[n + f] = a->cid, w[2 * n + f] = a->rank, w[3 * n + f] = a->score_ori, w[4 * n + f] = a->score_adj;
+		w[5 * n + f] = a->n_exon, w[6 * n + f] = a->off_exon, w[7 * n + f] = (int32_t)a->cs, w[8 * n + f] = (int32_t)a->ce, w[9 * n + f] = (int32_t)a->cm;
+		rev[f] = a->rev;
+		max_cs = std::max(max_cs, (int32_t)a->cs), max_cm = std::max(max_cm, (int32_t)a->cm);
+		if (a->score_adj < 0) neg = 1; else max_sadj = std::max(max_sadj, a->score_adj);
+		multi |= a->n_exon != 1;
+	}
+	for (int64_t e = 0; e < ne; ++e) ex[2 * e] = g->exon[e].os, ex[2 * e + 1] = g->exon[e].oe;
+	pga_genome_block_t &b = pk.blk;
+	b.n_hit = (int32_t)n, b.n_exon = (int32_t)ne, b.n_ctg = g->n_ctg;
+	b.max_cs = max_cs, b.max_cm = max_cm, b.max_score_adj = max_sadj, b.any_neg_score_adj = neg, b.any_multi_exon = multi;
+	b.data = w, b.n_words = nw;
+}
+
+void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1)
+{
+	const double t0 = now_sec();
+	ext->packs.resize((size_t)d->n_genome);
+	std::vector<int32_t> todo;
+	int64_t hits = 0;
+	for (int32_t j = j0; j < j1; ++j)
+		if (ext->packs[(size_t)j].buf == nullptr && ((size_t)j >= ext->is_local.size() || ext->is_local[(size_t)j])) todo.push_back(j), hits += d->genome[j].n_hit;
+	unsigned nt = hits > 100000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+	if (nt > todo.size()) nt = (unsigned)todo.size();
+	if (nt <= 1) { for (int32_t j : todo) pack_one(d, ext, j); }
+	else {
+		std::atomic<size_t> next{0};
+		std::vector<std::thread> th;
+		for (unsigned t = 0; t < nt; ++t)
+			th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= todo.size()) break; pack_one(d, ext, todo[i]); } });
+		for (auto &x : th) x.join();
+	}
+	ext->pack_sec += now_sec() - t0;
+}
+
+void free_packs(DataExt *ext)
+{
+	const pga_backend_t *be = backend_default();
+	for (GenomePack &pk : ext->packs) {
+		if (pk.buf == nullptr) continue;
+		if (pk.pinned) be->host_free(pk.buf); else std::free(pk.buf);
+		pk = GenomePack();
+	}
+}
+
 static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 {
+	const double t_bb0 = now_sec();
 	ext->be = backend_default();
 	ext->local_genomes.clear();
 	ext->is_local.resize((size_t)d->n_genome, 1);
-	ext->hits_sorted.assign((size_t)d->n_genome, 0);
+	ext->hits_sorted.resize((size_t)d->n_genome, 0); // genomes a previous sync_host put into cs order stay marked: their file order is in file_of_host
 	ext->pos_valid = false, ext->host_full = false;
 	for (int32_t j = 0; j < d->n_genome; ++j)
 		if (ext->is_local[(size_t)j]) ext->local_genomes.push_back(j);
 	const int32_t nl = (int32_t)ext->local_genomes.size();
+	pack_genomes(d, ext, 0, d->n_genome); // only those the reader has not packed already (or whose pack was released after an earlier upload)
 	int64_t N = 0, E = 0;
 	ext->hit_off.assign((size_t)nl + 1, 0);
+	std::vector<pga_genome_block_t> blk((size_t)nl);
 	for (int32_t k = 0; k < nl; ++k) {
-		const pg_genome_t *g = &d->genome[ext->local_genomes[(size_t)k]];
-		N += g->n_hit, E += g->n_exon;
+		const GenomePack &pk = ext->packs[(size_t)ext->local_genomes[(size_t)k]];
+		if (pk.err) return pk.err;
+		blk[(size_t)k] = pk.blk;
+		N += pk.blk.n_hit, E += pk.blk.n_exon;
 		ext->hit_off[(size_t)k + 1] = N;
 	}
 	if (d->n_gene >= (1 << 20) || d->n_genome >= (1 << 24) || E >= INT32_MAX || N >= INT32_MAX) return PGA_ERR_RANGE;
-	std::vector<int32_t> pid((size_t)N), cid((size_t)N), rank((size_t)N), sori((size_t)N), sadj((size_t)N), nex((size_t)N), offx((size_t)N),
-		cs((size_t)N), ce((size_t)N), cm((size_t)N), eos((size_t)E), eoe((size_t)E), nctg((size_t)nl), pgid((size_t)d->n_prot);
-	std::vector<uint8_t> rev((size_t)N), gpref((size_t)d->n_gene);
-	int64_t i = 0, ebase = 0;
-	for (int32_t k = 0; k < nl; ++k) {
-		const pg_genome_t *g = &d->genome[ext->local_genomes[(size_t)k]];
-		nctg[(size_t)k] = g->n_ctg;
-		for (int32_t h = 0; h < g->n_hit; ++h, ++i) {
-			const pg_hit_t *a = &g->hit[h];
-			if (a->cs < 0 || a->ce >= INT32_MAX || a->cm < 0 || a->cm >= INT32_MAX || a->ce < a->cs) return PGA_ERR_RANGE;
-			pid[(size_t)i] = a->pid, cid[(size_t)i] = a->cid, rank[(size_t)i] = a->rank, sori[(size_t)i] = a->score_ori, sadj[(size_t)i] = a->score_adj;
-			nex[(size_t)i] = a->n_exon, offx[(size_t)i] = (int32_t)(ebase + a->off_exon);
-			cs[(size_t)i] = (int32_t)a->cs, ce[(size_t)i] = (int32_t)a->ce, cm[(size_t)i] = (int32_t)a->cm, rev[(size_t)i] = a->rev;
-		}
-		for (int32_t e = 0; e < g->n_exon; ++e) eos[(size_t)(ebase + e)] = g->exon[e].os, eoe[(size_t)(ebase + e)] = g->exon[e].oe;
-		ebase += g->n_exon;
-	}
+	std::vector<int32_t> pgid((size_t)d->n_prot);
+	std::vector<uint8_t> gpref((size_t)d->n_gene);
 	for (int32_t p = 0; p < d->n_prot; ++p) pgid[(size_t)p] = d->prot[p].gid;
 	for (int32_t q = 0; q < d->n_gene; ++q) gpref[(size_t)q] = d->gene[q].preferred;
 	pga_shard_t sh;
 	std::memset(&sh, 0, sizeof(sh));
 	sh.n_genome = nl, sh.n_genome_global = d->n_genome, sh.genome_global = ext->local_genomes.data();
 	sh.n_prot = d->n_prot, sh.n_gene = d->n_gene, sh.n_hit = N, sh.n_exon = E;
-	sh.hit_off = ext->hit_off.data(), sh.n_ctg = nctg.data();
-	sh.pid = pid.data(), sh.cid = cid.data(), sh.rank = rank.data(), sh.score_ori = sori.data(), sh.score_adj = sadj.data();
-	sh.n_exon_of = nex.data(), sh.off_exon = offx.data(), sh.cs = cs.data(), sh.ce = ce.data(), sh.cm = cm.data(), sh.rev = rev.data();
-	sh.exon_os = eos.data(), sh.exon_oe = eoe.data(), sh.prot_gid = pgid.data(), sh.gene_pref = gpref.data();
+	sh.block = blk.data(), sh.prot_gid = pgid.data(), sh.gene_pref = gpref.data();
 	pga_params_t par;
 	std::memset(&par, 0, sizeof(par));
 	par.min_ov_ratio = opt->min_ov_ratio;
@@ -164,7 +221,13 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	par.drop_sgl_exon = !!(opt->flag & PG_F_DROP_SGL_EXON);
 	if (ext->ctx) ext->be->destroy(ext->ctx), ext->ctx = nullptr;
 	ext->n_hit_local = N;
-	return ext->be->create(&ext->ctx, &sh, &par);
+	static const bool timing = std::getenv("PANGENE_TIMING") != nullptr;
+	const double t1 = now_sec();
+	const int rc = ext->be->create(&ext->ctx, &sh, &par); // returns when the blocks have been read
+	const double t2 = now_sec();
+	free_packs(ext);
+	if (timing) std::fprintf(stderr, "[build_backend] tables %.3f ms, create %.3f ms, release of the host blocks %.3f ms\n", (t1 - t_bb0) * 1e3, (t2 - t1) * 1e3, (now_sec() - t2) * 1e3);
+	return rc;
 }
 
 // Pull per-hit state back and (first time) put the host arrays into cs order, which is how the reference
@@ -260,8 +323,12 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 	DataExt *ext = ext_of(d, true);
 	double t0 = now_sec();
 	if (!(ext->rerun && ext->ctx)) {
-		BE_CALL(build_backend(opt, d, ext), "create"); // pack + H2D, outside the timed path
+		g_pack_sec = ext->pack_sec, ext->pack_sec = 0.0; // what the reader spent on the blocks of this upload
+		BE_CALL(build_backend(opt, d, ext), "create"); // (rest of the) pack + allocation + H2D
+		g_pack_sec += ext->pack_sec, ext->pack_sec = 0.0;
+		const double tx0 = now_sec();
 		exact_init(d, ext);
+		if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[post_process] exact_init %.3f ms\n", (now_sec() - tx0) * 1e3);
 		ext->exact_mode_of_segs = exact_mode();
 	} else if (ext->exact_mode_of_segs != exact_mode()) {
 		exact_shutdown(ext);
@@ -471,18 +538,25 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	const int32_t S = q->n_seg;
 	int32_t *b_seg; pga_arc_part_t *b_arc; int64_t n_loc;
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 1), "override_order"); } // graph.c:103
+	std::vector<int32_t> sc((size_t)S * 2 + 1);
+	ext->deg.assign((size_t)S * 2 + 1, 0);
+	if (!sharded()) {
+		// one call, one wait: the backend keeps the table (and what branch marking, hit marking and the degree filter read from
+		// it) resident; it travels to the host once, after the last round (fetch_arcs)
+		int64_t n_arc = 0;
+		const pga_arc_part_t *tab = nullptr;
+		{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, sc.data(), ext->deg.data(), &tab, &n_arc), "arc_round"); }
+		{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
+		for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
+		ext->cur_arcs = tab, q->n_arc = (int32_t)n_arc;
+		return 0;
+	}
 	{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), &b_seg, &b_arc, &n_loc), "arc_round"); }
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
 	Phase ph_host(PH_ARC_HOST);
-	std::vector<int32_t> sc((size_t)S * 2);
-	// The arc table stays in backend memory (after the cross-shard merge when sharded): branch marking, hit marking and the
-	// degree filter read it there; it travels to the host once, after the last round (fetch_arcs).
 	const pga_arc_part_t *cur = b_arc;
 	int64_t n_cur = n_loc;
-	const void *sc_view = nullptr;
-	if (!sharded()) {
-		BE_CALL(be->fetch_later(ext->ctx, b_seg, sizeof(int32_t) * (size_t)S * 2, &sc_view), "fetch_later"); // lands with arc_set_current's wait below
-	} else {
+	{
 		// one all-reduce carries the segment counters and, in W extra slots, every rank's arc-table size (each rank adds its
 		// own into its slot), so the all-gather of the tables below needs no size exchange of its own
 		const int W = g_xchg.world;
@@ -510,9 +584,7 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 		}
 		cur = merged, n_cur = n_mg;
 	}
-	ext->deg.assign((size_t)S * 2 + 1, 0);
 	BE_CALL(be->arc_set_current(ext->ctx, cur, n_cur, S, ext->deg.data()), "arc_set_current");
-	if (sc_view && S) std::memcpy(sc.data(), sc_view, sizeof(int32_t) * (size_t)S * 2);
 	for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
 	ext->cur_arcs = cur, q->n_arc = (int32_t)n_cur;
 	return 0;
@@ -729,6 +801,7 @@ static int hazards_review(DataExt *ext, bool *need, bool *give_up)
 			const std::pair<int32_t, int32_t> gc((int32_t)k, segs[(size_t)i] - base[k]);
 			auto it = std::lower_bound(ext->extra_ctgs.begin(), ext->extra_ctgs.end(), gc);
 			if (it == ext->extra_ctgs.end() || *it != gc) ext->extra_ctgs.insert(it, gc), ++n_new;
+			if (std::getenv("PANGENE_DEBUG_HAZARDS")) std::fprintf(stderr, "[hazard] local genome %d contig %d\n", gc.first, gc.second);
 		}
 		if (n_new) flags[0] = 1;
 		if (pg_verbose >= 2)
@@ -759,11 +832,11 @@ void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 	for (int attempt = 0; g_err == 0 && ext && exact_mode() == 1; ++attempt) {
 		bool need = false, give_up = false;
 		if (hazards_review(ext, &need, &give_up) != 0 || !need) break;
-		// Tracking only the contigs on which the ties occurred (k_selective) is NOT enough in general: cs ties among walkable hits
-		// (they perturb pg_gen_rep_pos's running counter and so pg_n_local's local_count test) are not part of
-		// the trigger but do matter once some other tie has changed the walkable set (fuzz seeds 1035 and 3013 with -S differ
-		// from the reference that way).  Until the hazard list also carries those contigs, every contig is tracked.
-		const bool k_selective = std::getenv("PANGENE_EXPERIMENT_SELECTIVE") != nullptr; // off: see above
+		// Only the contigs on which the ties occurred get the reference's exact order (the event list covers every channel of
+		// equal cm of walkable neighbours, equal-key dominators / sub-optimal isoforms, cs ties that decide a
+		// local_count test); the repeated run is reviewed again, and ties that then only occur on tracked contigs are harmless.
+		// PANGENE_ESCALATE_ALL=1 tracks every contig at once instead (the round-1 behaviour).
+		const bool k_selective = std::getenv("PANGENE_ESCALATE_ALL") == nullptr;
 		const bool all = !k_selective || give_up || attempt >= 2;
 		if (pg_verbose >= 2)
 			std::fprintf(stderr, "[M::%s::%s] repeating stages A-C with the reference's exact hit order on %s\n", __func__, stamp(),
@@ -787,6 +860,11 @@ void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 		ext->vtx_sel_text.clear();
 	}
 	g_path_sec += now_sec() - t;
+	if (std::getenv("PANGENE_TIMING")) {
+		std::fprintf(stderr, "[phases]");
+		for (int i = 0; i < PH_COUNT; ++i) std::fprintf(stderr, " %s %.2f", pg_phase_name(i), g_phase[i] * 1e3);
+		std::fprintf(stderr, " | path %.2f ms\n", g_path_sec * 1e3);
+	}
 }
 
 void pg_graph_destroy(pg_graph_t *q) // graph.c:43-47
@@ -800,6 +878,18 @@ int pg_last_error(void) { return g_err; }
 const char *pg_last_error_str(void) { return g_errstr; }
 double pg_last_path_seconds(void) { return g_path_sec; }
 double pg_last_upload_seconds(void) { return g_upload_sec; }
+double pg_last_pack_seconds(void) { return g_pack_sec; }
+
+int pg_shard_counts(const pg_data_t *d, int64_t *n_hit, int64_t *n_exon)
+{
+	DataExt *ext = ext_of(d, false);
+	if (ext == nullptr) return PGA_ERR_ARG;
+	int64_t h = 0, e = 0;
+	for (int32_t j : ext->local_genomes) h += d->genome[j].n_hit, e += d->genome[j].n_exon;
+	if (n_hit) *n_hit = h;
+	if (n_exon) *n_exon = e;
+	return 0;
+}
 
 int pg_sync_host(pg_data_t *d) { return sync_host(d, true); } // refresh every per-hit field of the host records
 

@@ -37,6 +37,7 @@ void ext_drop(const pg_data_t *d)
 	DataExt *e = it->second;
 	exact_shutdown(e);
 	if (e->ctx && e->be) e->be->destroy(e->ctx);
+	free_packs(e);
 	delete e;
 	g_ext.erase(it);
 }
@@ -338,6 +339,7 @@ static int32_t read_paf_impl(const pg_opt_t *opt, pg_data_t *d, const char *fn, 
 	parse_file(opt, fn, ids_only, fp);
 	int32_t rc = commit_file(d, fp);
 	std::free(fp.label);
+	if (rc == 0 && !ids_only) pack_genomes(d, ext_of(d, true), d->n_genome - 1, d->n_genome); // SoA block for the backend, while the next file is read
 	return rc;
 }
 
@@ -385,7 +387,9 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 	work();
 	for (auto &x : th) x.join();
 	int32_t n_fail = 0;
+	const int32_t j0 = d->n_genome;
 	for (int32_t i = 0; i < n; ++i) { if (commit_file(d, fp[(size_t)i]) != 0) ++n_fail; std::free(fp[(size_t)i].label); }
+	pack_genomes(d, ext_of(d, true), j0, d->n_genome); // global ids are final now: SoA blocks for the backend, on host threads
 	return -n_fail;
 }
 

@@ -51,6 +51,13 @@ struct ExactSeg {
 	bool full = false;                    // every order of the contig is replayed and handed over (mode all, or a contig on which a tie hazard was seen)
 };
 
+// one genome packed for the backend (pga_genome_block_t) as soon as its PAF has been parsed; freed after the upload
+struct GenomePack {
+	pga_genome_block_t blk{};
+	void *buf = nullptr; bool pinned = false; // pinned: from the backend's host_alloc, else malloc
+	int err = 0;                              // PGA_ERR_RANGE: a coordinate does not fit the device layout
+};
+
 // host-private companion of a pg_data_t (struct layout of pg_data_t itself must not change)
 struct DataExt {
 	std::vector<uint8_t> is_local;     // per genome: hits live in this process
@@ -78,10 +85,15 @@ struct DataExt {
 	std::vector<int32_t> pos_x;        // per local hit (file order): position inside its genome in cs order
 	std::vector<std::vector<int32_t>> file_of_host; // per genome: host array index -> file index
 	bool host_stale = false;           // per-hit flags on the host are older than the backend's
+	std::vector<GenomePack> packs;     // per genome (global index); empty buf = not packed (any more)
+	double pack_sec = 0.0;             // wall seconds spent packing (reader threads) since the last upload
 	int64_t n_hit_local = 0;
 };
 
 DataExt *ext_of(const pg_data_t *d, bool create);
+// pack the genomes [j0, j1) that have no pack yet (host threads); called by the reader after the commit and by the driver as a fallback
+void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1);
+void free_packs(DataExt *ext);
 void ext_drop(const pg_data_t *d);
 
 const pga_backend_t *backend_default();   // link-time selected (HIP in the product)
