@@ -179,7 +179,9 @@ typedef struct {
 	int  pfx##_arc_round_local(pga_ctx_t *ctx, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt, int32_t *deg, const pga_arc_part_t **arcs, int64_t *n_arc); \
 	/* pg_gen_rep_pos (branch.c:6-29) kept in backend memory */ \
 	int  pfx##_rep_pos(pga_ctx_t *ctx); \
-	/* pg_n_local (branch.c:31-46) for n gene pairs (pairs[2i], pairs[2i+1]) summed over local genomes */ \
+	/* pg_n_local (branch.c:31-46) for n gene pairs (pairs[2i], pairs[2i+1]) over the local genomes.  The reference only tests the \
+	 * result against zero (branch.c:76,86): cnt[i] > 0 iff the pair is local in some local genome; a backend may stop counting \
+	 * at the first such genome (the HIP one does), so the exact value is unspecified beyond that */ \
 	int  pfx##_n_local(pga_ctx_t *ctx, const int32_t *pairs, int64_t n, int32_t local_dist, int32_t local_count, \
 	                   int32_t frag_mode, int32_t **cnt); \
 	/* pg_mark_branch_flt_arc (branch.c:48-106), split in two so that the counts can be all-reduced in between. \

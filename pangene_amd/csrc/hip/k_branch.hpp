@@ -76,76 +76,67 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a, const int32_t *cm
 // least one r is only known up to an interval: is the answer the same over the whole interval?  (rare path)
 struct NLocalHz { const int32_t *iv; const int32_t *ctg_base; int64_t *dcnt; int32_t *list; };
 
-__device__ __noinline__ void nl_hazard(const NLocalHz &z, int cc, int iv1, int iv2, int seg1, int seg2, int local_count)
+__device__ __noinline__ bool nl_hazard(const NLocalHz &z, int cc, int iv1, int iv2, int seg1, int seg2, int local_count) // true: the same for every tie order
 {
 	const int lo = cc - (iv1 >> 16) - (iv2 & 0xffff), hi = cc + (iv1 & 0xffff) + (iv2 >> 16);
 	const bool all_in = lo >= -local_count && hi <= local_count, all_out = hi < -local_count || lo > local_count;
-	if (all_in || all_out) return;
+	if (all_in || all_out) return true;
 	atomicAdd((unsigned long long *)&z.dcnt[6], 1ull);
 	if (iv1) hz_note(&z.dcnt[14], z.list, seg1);
 	if (iv2) hz_note(&z.dcnt[14], z.list, seg2);
+	return false;
 }
 
-// pg_n_local (branch.c:31-46): one wave per NL_PAIRS gene pairs, lanes over the local genomes.  The pair indices are made
-// wave-uniform (scalar loads) and all record loads of the wave's pairs are issued before the first is used, so a wave pays
-// the memory latency twice for four pairs instead of three times per pair; the count is a popcount of ballots (no
-// cross-lane reduction).
-constexpr int NL_PAIRS = 4;
+// pg_n_local (branch.c:31-46).  Its callers only ever ask whether the count is zero (branch.c:76 and 86), so the search over
+// the genomes stops at the first genome in which the pair is local FOR CERTAIN (a hit whose local_count test depends on the tie
+// order -- hazard H2b -- does not stop it); cnt[k] = the hits seen until then: > 0 iff pg_n_local > 0, and sums over shards keep
+// that property.  Sixteen lanes work on one pair (sixteen genomes per step, one coalesced 128-byte read per record table), four
+// pairs per wave; as a rule the first step settles a pair, so the cost no longer grows with the number of genomes.
+constexpr int NL_PAIRS = 4, NL_LANES = 16;
 
 template <bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const void *rp_in,
                                                      int local_dist, int local_count, int frag_mode, int32_t *cnt, NLocalHz hz)
 {
-	const int lane = threadIdx.x & 63;
-	const int64_t k0 = (int64_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * NL_PAIRS));
-	if (k0 >= n_pair) return;
-	int64_t g1[NL_PAIRS], g2[NL_PAIRS];
-#pragma unroll
-	for (int u = 0; u < NL_PAIRS; ++u) {
-		const int64_t k = k0 + u < n_pair ? k0 + u : n_pair - 1; // the last wave repeats the last pair, nothing is stored for the repeats
-		g1[u] = (int64_t)pairs[2 * k] * GL, g2[u] = (int64_t)pairs[2 * k + 1] * GL;
-	}
-	int c[NL_PAIRS] = { 0, 0, 0, 0 };
-	for (int j0 = 0; j0 < GL; j0 += WAVE) {
-		const int j = j0 + lane;
-		const bool in = j < GL;
-		const int jj = in ? j : 0;
+	const int lane = threadIdx.x & 63, grp = lane >> 4, sub = lane & (NL_LANES - 1);
+	const int64_t k = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * NL_PAIRS + grp;
+	const bool have = k < n_pair;
+	const int64_t kk = have ? k : n_pair - 1;
+	if (n_pair <= 0) return;
+	const int64_t g1 = (int64_t)pairs[2 * kk] * GL, g2 = (int64_t)pairs[2 * kk + 1] * GL;
+	int c = 0;
+	bool open = have; // still searching (uniform over the sixteen lanes of the pair)
+	for (int j0 = 0; j0 < GL; j0 += NL_LANES) {
+		if (__ballot(open) == 0) break;
+		const int j = j0 + sub;
+		const bool in = open && j < GL;
+		const int jj = j < GL ? j : 0;
+		bool hit = false, sure = false;
 		if (COMPACT) {
-			int2 a[NL_PAIRS], b[NL_PAIRS];
-#pragma unroll
-			for (int u = 0; u < NL_PAIRS; ++u) a[u] = ((const int2 *)rp_in)[g1[u] + jj], b[u] = ((const int2 *)rp_in)[g2[u] + jj];
-#pragma unroll
-			for (int u = 0; u < NL_PAIRS; ++u) {
-				const int d = (a[u].x & 0x7fffffff) - (b[u].x & 0x7fffffff); // cm < 2^31: the difference fits
-				const int cc = (a[u].y & 0xfffff) - (b[u].y & 0xfffff);
-				const bool cmp = in && (a[u].y | b[u].y) >= 0 && (frag_mode || ((a[u].y ^ b[u].y) >> 20) == 0);
-				const bool near = d >= -local_dist && d <= local_dist;
-				const bool hit = cmp && (near || (cc >= -local_count && cc <= local_count));
-				c[u] += __popcll(__ballot(hit));
-				if (cmp && !near && (a[u].x | b[u].x) < 0 && k0 + u < n_pair) // rare: an r of the pair depends on the tie order (H2b)
-					nl_hazard(hz, cc, a[u].x < 0 ? hz.iv[g1[u] + jj] : 0, b[u].x < 0 ? hz.iv[g2[u] + jj] : 0,
-					          hz.ctg_base[jj] + (a[u].y >> 20), hz.ctg_base[jj] + (b[u].y >> 20), local_count);
-			}
+			const int2 a = ((const int2 *)rp_in)[g1 + jj], b = ((const int2 *)rp_in)[g2 + jj];
+			const int d = (a.x & 0x7fffffff) - (b.x & 0x7fffffff); // cm < 2^31: the difference fits
+			const int cc = (a.y & 0xfffff) - (b.y & 0xfffff);
+			const bool cmp = in && (a.y | b.y) >= 0 && (frag_mode || ((a.y ^ b.y) >> 20) == 0);
+			const bool near = d >= -local_dist && d <= local_dist;
+			hit = cmp && (near || (cc >= -local_count && cc <= local_count));
+			sure = hit;
+			if (cmp && !near && (a.x | b.x) < 0) // rare: an r of the pair depends on the tie order (H2b)
+				sure = nl_hazard(hz, cc, a.x < 0 ? hz.iv[g1 + jj] : 0, b.x < 0 ? hz.iv[g2 + jj] : 0, hz.ctg_base[jj] + (a.y >> 20), hz.ctg_base[jj] + (b.y >> 20), local_count) && hit;
 		} else {
-			int4 a[NL_PAIRS], b[NL_PAIRS];
-#pragma unroll
-			for (int u = 0; u < NL_PAIRS; ++u) a[u] = ((const int4 *)rp_in)[g1[u] + jj], b[u] = ((const int4 *)rp_in)[g2[u] + jj];
-#pragma unroll
-			for (int u = 0; u < NL_PAIRS; ++u) {
-				const int d = (a[u].z & 0x7fffffff) - (b[u].z & 0x7fffffff);
-				const int cc = a[u].y - b[u].y;
-				const bool cmp = in && a[u].x >= 0 && b[u].x >= 0 && (frag_mode || a[u].x == b[u].x);
-				const bool near = d >= -local_dist && d <= local_dist;
-				const bool hit = cmp && (near || (cc >= -local_count && cc <= local_count));
-				c[u] += __popcll(__ballot(hit));
-				if (cmp && !near && (a[u].z | b[u].z) < 0 && k0 + u < n_pair)
-					nl_hazard(hz, cc, a[u].w, b[u].w, a[u].x, b[u].x, local_count);
-			}
+			const int4 a = ((const int4 *)rp_in)[g1 + jj], b = ((const int4 *)rp_in)[g2 + jj];
+			const int d = (a.z & 0x7fffffff) - (b.z & 0x7fffffff);
+			const int cc = a.y - b.y;
+			const bool cmp = in && a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x);
+			const bool near = d >= -local_dist && d <= local_dist;
+			hit = cmp && (near || (cc >= -local_count && cc <= local_count));
+			sure = hit;
+			if (cmp && !near && (a.z | b.z) < 0) sure = nl_hazard(hz, cc, a.w, b.w, a.x, b.x, local_count) && hit;
 		}
+		const unsigned long long mh = __ballot(hit), ms = __ballot(sure);
+		c += __popcll((mh >> (grp * NL_LANES)) & 0xffffull);
+		if ((ms >> (grp * NL_LANES)) & 0xffffull) open = false;
 	}
-#pragma unroll
-	for (int u = 0; u < NL_PAIRS; ++u)
-		if (lane == u && k0 + u < n_pair) cnt[k0 + u] = c[u];
+	if (have && sub == 0) cnt[k] = c;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -89,7 +89,7 @@ constexpr int GA_CAP = 512; // distinct (orientation, target) pairs of one gene 
 
 struct GeneArcs {
 	const int2 *zrec; const int32_t *zoff; const uint32_t *flags; const int4 *hf, *hb; const int32_t *g2s;
-	int Q, S; uint32_t tag;
+	int Q, S; uint32_t tag; int cap_log2; // table size actually used (<= GA_CAP; tests shrink it to reach the overflow path)
 	int32_t *seg_cnt, *seg_gid;       // [2S] n_genome then tot_cnt (graph.c:125-126); [S] gene of each segment
 	pga_arc_part_t *stage; int4 *gmeta; // arcs of a gene at stage[gmeta.x ...): gmeta = {base, #arcs leaving (sid, +), #arcs leaving (sid, -), 0}
 	int64_t *dcnt;                      // [3] invariant, [8] staged arcs, [9] genes that overflowed the table
@@ -150,13 +150,14 @@ __global__ __launch_bounds__(BLOCK) void k_gene_arcs(GeneArcs a)
 			m1 = m1 > 0 ? m1 : 0, m2 = m2 > 0 ? m2 : 0; // the reference's running maxima start at 0 (graph.c:133)
 			const int dg = (int32_t)((double)(long long)sd / n + .499); // graph.c:141
 			// level 2 (graph.c:153-169): sums over the genomes, LDS table keyed by (orientation, target)
-			uint32_t slot = (key * 2654435761u) >> (32 - 9);
+			const int cap = 1 << a.cap_log2;
+			uint32_t slot = (key * 2654435761u) >> (32 - a.cap_log2);
 			int probes = 0;
-			for (; probes < GA_CAP; ++probes, slot = (slot + 1) & (GA_CAP - 1)) {
+			for (; probes < cap; ++probes, slot = (slot + 1) & (cap - 1)) {
 				const uint32_t old = atomicCAS(&t_key[slot], 0xffffffffu, key);
 				if (old == 0xffffffffu || old == key) break;
 			}
-			if (probes == GA_CAP) { s_over = 1; continue; }
+			if (probes == cap) { s_over = 1; continue; }
 			atomicAdd(&t_ng[slot], 1); atomicAdd(&t_tot[slot], n);
 			atomicAdd(&t_sd[slot], (unsigned long long)(long long)dg * (unsigned long long)n);
 			atomicAdd(&t_s1[slot], (unsigned long long)(long long)m1); atomicAdd(&t_s2[slot], (unsigned long long)(long long)m2);

@@ -377,6 +377,8 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(upload(c, c->goff, c->h_goff.data(), (size_t)GL + 1)); TRY(upload(c, c->ggl, c->h_ggl.data(), GL));
 	TRY(upload(c, c->ctg_base, ctg_base.data(), (size_t)GL + 1)); TRY(upload(c, c->eoff, eoff.data(), (size_t)GL + 1)); TRY(upload(c, c->woff, woff.data(), (size_t)GL + 1));
 	TRY(upload(c, c->prot_gid, sh->prot_gid, c->P)); TRY(upload(c, c->gene_pref, sh->gene_pref, c->Q));
+	// half-arc records are validated by a round tag: none may survive from an earlier context whose memory this one inherited
+	if (N) { HIPCHK(hipMemsetAsync(c->hf, 0xff, sizeof(int4) * (size_t)N, c->st)); HIPCHK(hipMemsetAsync(c->hb, 0xff, sizeof(int4) * (size_t)N, c->st)); }
 	if (N) hipLaunchKernelGGL(k_unblock, dim3(nblk(N)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, N, up);
 	if (E) hipLaunchKernelGGL(k_unblock_exons, dim3(nblk(E)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, E, c->exon);
 	{ // work buffers shared by every sort / scan of the run: sized for the largest input (2N temp arcs)
@@ -716,7 +718,8 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, pga_a
 	TRY(ensure_half_arcs(c, use_ori));
 	HIPCHK(hipMemsetAsync(c->dcnt + 8, 0, 3 * sizeof(int64_t), c->st)); // staged arcs, overflowed genes, table size
 	if (S == 0) { hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box); return 0; }
-	GeneArcs ga = { c->zrec, c->zoff, c->flags, c->hf, c->hb, c->g2s, c->Q, S, c->round_tag, seg_cnt, t.sg, stage, gmeta, c->dcnt };
+	static const int cap_log2 = [] { const char *e = getenv("PANGENE_GENE_TABLE_LOG2"); const int v = e ? atoi(e) : 9; return v < 1 ? 1 : v > 9 ? 9 : v; }();
+	GeneArcs ga = { c->zrec, c->zoff, c->flags, c->hf, c->hb, c->g2s, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta, c->dcnt };
 	hipLaunchKernelGGL(k_gene_arcs, dim3((unsigned)c->Q), dim3(BLOCK), 0, c->st, ga);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(S));
 	if (!tile) return PGA_ERR_NOMEM;
@@ -823,6 +826,21 @@ extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg,
 			HIPCHK(hipMemcpyAsync(c->h_round + n_vtx, deg, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
 		}
 		TRY(sync_st(c));
+		if (c->h_cnt[3] && getenv("PANGENE_DEBUG_INVARIANT")) { // which hit?
+			const int N = c->N, Q = c->Q;
+			std::vector<int2> zr((size_t)N); std::vector<int32_t> zo((size_t)Q + 1), g2((size_t)Q), gd((size_t)N); std::vector<uint32_t> fl((size_t)N);
+			(void)hipMemcpy(zr.data(), c->zrec, sizeof(int2) * (size_t)N, hipMemcpyDeviceToHost); (void)hipMemcpy(zo.data(), c->zoff, sizeof(int32_t) * ((size_t)Q + 1), hipMemcpyDeviceToHost);
+			(void)hipMemcpy(g2.data(), c->g2s, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost); (void)hipMemcpy(fl.data(), c->flags, sizeof(uint32_t) * (size_t)N, hipMemcpyDeviceToHost);
+			(void)hipMemcpy(gd.data(), c->gid, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost);
+			fprintf(stderr, "[debug] invariant count %ld; N %d Q %d S %d zoff[0] %d zoff[Q] %d\n", (long)c->h_cnt[3], N, Q, S, zo[0], zo[(size_t)Q]);
+			int shown = 0;
+			for (int g = 0; g < Q && shown < 8; ++g)
+				for (int z = zo[(size_t)g]; z < zo[(size_t)g + 1] && shown < 8; ++z) {
+					const int x = zr[(size_t)z].x;
+					if (gd[(size_t)x] != g) { fprintf(stderr, "[debug] z %d: gene %d but gid[x=%d] = %d\n", z, g, x, gd[(size_t)x]); ++shown; }
+					else if (g2[(size_t)g] < 0 && !(fl[(size_t)x] & (PGA_F_FLT | PGA_F_SHADOW))) { fprintf(stderr, "[debug] gene %d (no vertex) has walkable hit x %d flags %x\n", g, x, fl[(size_t)x]); ++shown; }
+				}
+		}
 		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
 		if (c->h_cnt[9] == 0) {
 			if (n_vtx) memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
@@ -1049,7 +1067,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
                                   const int64_t *seg_off, const int32_t *file_idx)
 {
 	const int N = c->N;
-	c->walk_valid = false, c->yrec_valid = false;
+	c->walk_valid = false, c->ha_valid = false, c->yrec_valid = false, c->z_valid = false;
 	if (n_seg <= 0 || N == 0) return 0;
 	const int64_t T = seg_off[n_seg];
 	if (T == 0) return 0;

@@ -47,9 +47,13 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 	ext->xsegs.clear();
 	const int mode = exact_mode();
 	if (mode == 0) return;
-	for (size_t k = 0; k < ext->local_genomes.size(); ++k) {
+	// genomes are independent: host threads collect their segments, which are then appended in genome order
+	const size_t ng = ext->local_genomes.size();
+	std::vector<std::vector<ExactSeg>> per((size_t)ng);
+	auto do_genome = [&](size_t k) {
+		std::vector<ExactSeg> &out = per[k];
 		const pg_genome_t *g = &d->genome[ext->local_genomes[k]];
-		if (g->n_hit < 2) continue;
+		if (g->n_hit < 2) return;
 		std::vector<int32_t> cnt((size_t)g->n_ctg + 1, 0);
 		for (int32_t i = 0; i < g->n_hit; ++i) ++cnt[(size_t)g->hit[i].cid + 1];
 		for (int32_t c = 0; c < g->n_ctg; ++c) cnt[(size_t)c + 1] += cnt[(size_t)c];
@@ -91,9 +95,22 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 				if (a->cs < min_cs) min_cs = a->cs, n_min = 1; else if (a->cs == min_cs) ++n_min;
 			}
 			if (!full && n_min < 2) continue;  // auto: only the index-0 channel, i.e. a leading tie group on the first contig
-			ext->xsegs.push_back(std::move(s));
+			out.push_back(std::move(s));
 		}
+	};
+	int64_t tot = 0;
+	for (size_t k = 0; k < ng; ++k) tot += d->genome[ext->local_genomes[k]].n_hit;
+	unsigned nt = tot > 200000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+	if (nt > ng) nt = (unsigned)ng;
+	if (nt <= 1) { for (size_t k = 0; k < ng; ++k) do_genome(k); }
+	else {
+		std::atomic<size_t> next{0};
+		std::vector<std::thread> th;
+		for (unsigned t = 0; t < nt; ++t) th.emplace_back([&]() { for (;;) { const size_t k = next.fetch_add(1); if (k >= ng) break; do_genome(k); } });
+		for (auto &x : th) x.join();
 	}
+	for (size_t k = 0; k < ng; ++k)
+		for (ExactSeg &s : per[k]) ext->xsegs.push_back(std::move(s));
 }
 
 static void emulate(ExactSeg &s, std::vector<int32_t> &curv, int by_cm) // one pg_hit_sort of this contig segment

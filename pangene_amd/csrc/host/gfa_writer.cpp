@@ -121,28 +121,33 @@ void pg_write_graph(const pg_graph_t *q) // format.c:120-157
 	std::fflush(fp);
 }
 
-// W-lines (format.c:183-225): per genome, contigs in id order, surviving hits in cm order.  The host
-// array stays in cs order; the cm order comes from the backend's Y permutation (DataExt::y_order).
+// W-lines (format.c:183-225): per genome, contigs in id order, surviving hits in cm order.  The host records stay where they
+// are (file order, or cs order after a full sync); the cm order comes from the backend's Y permutation as file indices
+// (DataExt::y_file) and flt from the bit vector of the last sync (indexed by X position).
 void pg_write_walk(pg_graph_t *q)
 {
 	pg_data_t *d = q->d;
 	if (sync_host(d, false) != 0) return;
-	DataExt *ext = ext_of(d, true);
+	DataExt *ext = ext_of(d, false);
+	if (ext == nullptr || ext->ctx == nullptr) { set_error(PGA_ERR_ARG, "pg_write_walk: pg_graph_gen has not run on this data set"); return; }
 	FILE *fp = out_stream();
 	std::string o, sample;
+	std::vector<int64_t> goff_of((size_t)d->n_genome, -1);
+	for (size_t k = 0; k < ext->local_genomes.size(); ++k) goff_of[(size_t)ext->local_genomes[k]] = ext->hit_off[k];
 	for (int32_t j = 0; j < d->n_genome; ++j) {
 		const pg_genome_t *g = &d->genome[j];
 		if (g->n_hit == 0) continue;
-		const int32_t *yo = ext->y_order[j].data();
-		// flt comes from the bit vector of the last sync (the flag fields of the host records are only refreshed by a
-		// full sync); the shard offset of genome j is found through its position among the local genomes
-		int64_t goff = -1;
-		for (size_t k = 0; k < ext->local_genomes.size(); ++k) if (ext->local_genomes[k] == j) { goff = ext->hit_off[k]; break; }
+		const int64_t goff = goff_of[(size_t)j];
+		if (goff < 0 || (size_t)j >= ext->y_file.size() || ext->y_file[(size_t)j].size() != (size_t)g->n_hit) { set_error(PGA_ERR_ARG, "pg_write_walk: genome without backend state"); return; }
+		const int32_t *yf = ext->y_file[(size_t)j].data();
+		const int32_t *hof = ext->hits_sorted[(size_t)j] ? ext->host_of_file[(size_t)j].data() : nullptr;
+		const int32_t *px = ext->pos_x.data() + goff;
 		const uint64_t *fb = ext->flt_bits.data();
-		auto is_flt = [&](int32_t host_idx) { const int64_t b = goff + host_idx; return (fb[b >> 6] >> (b & 63) & 1) != 0; };
+		auto hit_of = [&](int32_t k) -> const pg_hit_t * { const int32_t f = yf[k]; return &g->hit[hof ? hof[f] : f]; };
+		auto is_flt = [&](int32_t k) { const int64_t b = goff + px[yf[k]]; return (fb[b >> 6] >> (b & 63) & 1) != 0; };
 		for (int32_t i0 = 0, i = 1; i <= g->n_hit; ++i) {
-			if (i != g->n_hit && g->hit[yo[i]].cid == g->hit[yo[i0]].cid) continue;
-			int32_t cid = g->hit[yo[i0]].cid, n = 0;
+			if (i != g->n_hit && hit_of(i)->cid == hit_of(i0)->cid) continue;
+			int32_t cid = hit_of(i0)->cid, n = 0;
 			int32_t hap = parse_sample(sample, g->ctg[cid].name);
 			o.clear();
 			if (hap >= 0) { o += "W\t"; o += sample; o += '\t'; put_i32(o, hap); }
@@ -150,17 +155,16 @@ void pg_write_walk(pg_graph_t *q)
 			else { o += "W\t"; put_i32(o, j); o += "\t0"; }
 			o += '\t'; o += g->ctg[cid].name; o += "\t*\t*\t";
 			for (int32_t k = i0; k < i; ++k) {
-				const pg_hit_t *a = &g->hit[yo[k]];
-				if (is_flt(yo[k])) continue;
+				if (is_flt(k)) continue;
+				const pg_hit_t *a = hit_of(k);
 				o += "><"[a->rev]; o += d->gene[d->prot[a->pid].gid].name;
 				++n;
 			}
 			if (n > 0) {
 				o += "\tlf:B:i";
 				for (int32_t k = i0; k < i; ++k) {
-					const pg_hit_t *a = &g->hit[yo[k]];
-					if (is_flt(yo[k])) continue;
-					o += ','; put_i32(o, a->lof);
+					if (is_flt(k)) continue;
+					o += ','; put_i32(o, hit_of(k)->lof);
 				}
 				o += '\n';
 				std::fwrite(o.data(), 1, o.size(), fp);

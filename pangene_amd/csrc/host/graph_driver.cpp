@@ -15,6 +15,7 @@
 #include <cstring>
 #include <atomic>
 #include <climits>
+#include <mutex>
 #include <thread>
 #include "pg_internal.hpp"
 #include "ksort_exact.hpp"
@@ -116,16 +117,16 @@ static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int6
 // Done by the reader as soon as a genome has been parsed (host threads, pinned memory), so that pg_post_process only has
 // to hand the blocks to the backend: the upload is then plain DMA out of pinned memory.
 // ---------------------------------------------------------------------------------------------
+static void *block_alloc(DataExt *ext, size_t bytes);
+
 static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 {
 	GenomePack &pk = ext->packs[(size_t)j];
 	const pg_genome_t *g = &d->genome[j];
-	const pga_backend_t *be = backend_default();
 	const int64_t n = g->n_hit, ne = g->n_exon;
 	const size_t nw = (size_t)(PGA_BLOCK_PLANES * n + (n + 3) / 4 + 2 * ne);
 	pk = GenomePack();
-	if (be->host_alloc && be->host_alloc((nw ? nw : 1) * sizeof(int32_t), &pk.buf) == 0) pk.pinned = true;
-	else pk.buf = std::malloc((nw ? nw : 1) * sizeof(int32_t)), pk.pinned = false;
+	pk.buf = block_alloc(ext, (nw ? nw : 1) * sizeof(int32_t));
 	int32_t *w = (int32_t *)pk.buf;
 	uint8_t *rev = (uint8_t *)(w + PGA_BLOCK_PLANES * n);
 	int32_t *ex = w + PGA_BLOCK_PLANES * n + (n + 3) / 4;
@@ -172,14 +173,60 @@ void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1)
 	ext->pack_sec += now_sec() - t0;
 }
 
-void free_packs(DataExt *ext)
+// Pinned host memory is expensive to get and to give back (every hipHostMalloc / hipHostFree maps or unmaps pages and takes the
+// runtime's lock: 0.1-0.3 ms a call): the blocks are carved out of a few large slabs, and the slabs of a finished upload go into
+// a process-wide cache for the next data set instead of back to the driver (bounded: what exceeds the bound is released).
+static std::mutex g_slab_mu;
+static std::vector<HostSlab> g_slab_cache;
+static size_t g_slab_cached = 0;
+static const size_t SLAB_BYTES = (size_t)32 << 20, SLAB_CACHE_MAX = (size_t)4 << 30;
+
+static HostSlab slab_get(size_t min_bytes)
 {
-	const pga_backend_t *be = backend_default();
-	for (GenomePack &pk : ext->packs) {
-		if (pk.buf == nullptr) continue;
-		if (pk.pinned) be->host_free(pk.buf); else std::free(pk.buf);
-		pk = GenomePack();
+	{
+		std::lock_guard<std::mutex> lk(g_slab_mu);
+		for (size_t i = 0; i < g_slab_cache.size(); ++i)
+			if (g_slab_cache[i].cap >= min_bytes) {
+				HostSlab s = g_slab_cache[i];
+				g_slab_cache.erase(g_slab_cache.begin() + (long)i);
+				g_slab_cached -= s.cap, s.off = 0;
+				return s;
+			}
 	}
+	HostSlab s;
+	s.cap = std::max(min_bytes, SLAB_BYTES);
+	const pga_backend_t *be = backend_default();
+	void *q = nullptr;
+	if (be->host_alloc && be->host_alloc(s.cap, &q) == 0) s.pinned = true;
+	else q = std::malloc(s.cap), s.pinned = false; // no device: plain memory (the upload will fail loudly later)
+	s.p = (char *)q;
+	return s;
+}
+
+static void *block_alloc(DataExt *ext, size_t bytes)
+{
+	bytes = (bytes + 255) & ~(size_t)255;
+	std::lock_guard<std::mutex> lk(ext->slab_mu);
+	if (ext->slabs.empty() || ext->slabs.back().off + bytes > ext->slabs.back().cap) ext->slabs.push_back(slab_get(bytes));
+	HostSlab &s = ext->slabs.back();
+	void *r = s.p + s.off;
+	s.off += bytes;
+	return r;
+}
+
+void free_packs(DataExt *ext, bool wait)
+{
+	(void)wait;
+	for (GenomePack &pk : ext->packs) pk = GenomePack();
+	std::lock_guard<std::mutex> lk(g_slab_mu);
+	const pga_backend_t *be = backend_default();
+	for (HostSlab &s : ext->slabs) {
+		if (s.p == nullptr) continue;
+		if (s.pinned && g_slab_cached + s.cap <= SLAB_CACHE_MAX) g_slab_cache.push_back(s), g_slab_cached += s.cap;
+		else if (s.pinned) be->host_free(s.p);
+		else std::free(s.p);
+	}
+	ext->slabs.clear();
 }
 
 static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
@@ -225,16 +272,17 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	const double t1 = now_sec();
 	const int rc = ext->be->create(&ext->ctx, &sh, &par); // returns when the blocks have been read
 	const double t2 = now_sec();
-	free_packs(ext);
+	free_packs(ext, false);
 	if (timing) std::fprintf(stderr, "[build_backend] tables %.3f ms, create %.3f ms, release of the host blocks %.3f ms\n", (t1 - t_bb0) * 1e3, (t2 - t1) * 1e3, (now_sec() - t2) * 1e3);
 	return rc;
 }
 
-// Pull per-hit state back and (first time) put the host arrays into cs order, which is how the reference
-// leaves them (hit.c:57-63 replaces g->hit on every sort).
-//   full = false: what the GFA writers need -- one flt bit per hit (DataExt::flt_bits) and, once per order epoch,
-//                 the two orders; the flag fields of the host records are NOT refreshed;
-//   full = true : every per-hit field of the host records (BED writers, pg_sync_host()).
+// Pull per-hit state back.
+//   full = false: what the GFA writers need -- one flt bit per hit (DataExt::flt_bits, indexed by X position) and, once per order
+//                 epoch, the two orders (pos_x: file index -> X position; y_file: k-th hit in cm order -> file index).  The host
+//                 records are neither moved nor refreshed: pg_write_walk reaches them through the file index.
+//   full = true : every per-hit field of the host records, and the records themselves put into cs order, which is how the
+//                 reference leaves them (hit.c:57-63 replaces g->hit on every sort; the BED writers print in array order).
 int sync_host(pg_data_t *d, bool full)
 {
 	DataExt *ext = ext_of(d, false);
@@ -252,14 +300,20 @@ int sync_host(pg_data_t *d, bool full)
 	                       full ? pdom0.data() : nullptr, need_pos ? ext->pos_x.data() : nullptr, need_pos ? py.data() : nullptr, ext->flt_bits.data() };
 	BE_CALL(ext->be->download(ext->ctx, &st), "download");
 	const int32_t *px = ext->pos_x.data();
-	ext->y_order.resize((size_t)d->n_genome);
+	ext->y_file.resize((size_t)d->n_genome);
 	ext->file_of_host.resize((size_t)d->n_genome);
+	ext->host_of_file.resize((size_t)d->n_genome);
+	if (need_pos) ext->host_order_valid = false; // the records (if they were ever moved) follow an older cs order
+	const bool move = full && !ext->host_order_valid;
 	auto do_genome = [&](size_t k) {
 		int32_t j = ext->local_genomes[k];
 		pg_genome_t *g = &d->genome[j];
 		const int64_t off = ext->hit_off[k];
 		if (need_pos) {
-			// the host array is in file order before the first sync and in the PREVIOUS cs order afterwards
+			ext->y_file[(size_t)j].assign((size_t)g->n_hit, 0);
+			for (int32_t f = 0; f < g->n_hit; ++f) ext->y_file[(size_t)j][(size_t)py[(size_t)(off + f)]] = f;
+		}
+		if (move) { // the host array is in file order until the first move and in the PREVIOUS cs order afterwards
 			pg_hit_t *a = (pg_hit_t *)std::malloc(sizeof(pg_hit_t) * (size_t)(g->n_hit > 0 ? g->n_hit : 1));
 			if (!ext->hits_sorted[(size_t)j]) {
 				for (int32_t f = 0; f < g->n_hit; ++f) a[px[(size_t)(off + f)]] = g->hit[f];
@@ -271,10 +325,10 @@ int sync_host(pg_data_t *d, bool full)
 			g->hit = a, g->m_hit = g->n_hit;
 			ext->hits_sorted[(size_t)j] = 1;
 			ext->file_of_host[(size_t)j].assign((size_t)g->n_hit, 0);
-			ext->y_order[(size_t)j].assign((size_t)g->n_hit, 0);
+			ext->host_of_file[(size_t)j].assign((size_t)g->n_hit, 0);
 			for (int32_t f = 0; f < g->n_hit; ++f) {
 				ext->file_of_host[(size_t)j][(size_t)px[(size_t)(off + f)]] = f;
-				ext->y_order[(size_t)j][(size_t)py[(size_t)(off + f)]] = px[(size_t)(off + f)];
+				ext->host_of_file[(size_t)j][(size_t)f] = px[(size_t)(off + f)];
 			}
 		}
 		if (!full) return;
@@ -300,6 +354,7 @@ int sync_host(pg_data_t *d, bool full)
 			for (auto &x : th) x.join();
 		}
 	}
+	if (move) ext->host_order_valid = true;
 	ext->pos_valid = true;
 	ext->host_stale = false;
 	ext->host_full = full;

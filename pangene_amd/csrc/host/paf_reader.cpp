@@ -37,7 +37,7 @@ void ext_drop(const pg_data_t *d)
 	DataExt *e = it->second;
 	exact_shutdown(e);
 	if (e->ctx && e->be) e->be->destroy(e->ctx);
-	free_packs(e);
+	free_packs(e, true);
 	delete e;
 	g_ext.erase(it);
 }

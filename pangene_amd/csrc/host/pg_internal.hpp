@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <atomic>
 #include <string_view>
@@ -51,12 +52,14 @@ struct ExactSeg {
 	bool full = false;                    // every order of the contig is replayed and handed over (mode all, or a contig on which a tie hazard was seen)
 };
 
-// one genome packed for the backend (pga_genome_block_t) as soon as its PAF has been parsed; freed after the upload
+// one genome packed for the backend (pga_genome_block_t) as soon as its PAF has been parsed.  The block is carved out of a
+// slab of pinned host memory (DataExt::slabs); slabs go back to a process-wide cache after the upload.
 struct GenomePack {
 	pga_genome_block_t blk{};
-	void *buf = nullptr; bool pinned = false; // pinned: from the backend's host_alloc, else malloc
+	void *buf = nullptr;
 	int err = 0;                              // PGA_ERR_RANGE: a coordinate does not fit the device layout
 };
+struct HostSlab { char *p = nullptr; size_t cap = 0, off = 0; bool pinned = false; };
 
 // host-private companion of a pg_data_t (struct layout of pg_data_t itself must not change)
 struct DataExt {
@@ -66,7 +69,7 @@ struct DataExt {
 	pga_ctx_t *ctx = nullptr;          // backend context (owns the HBM-resident shard)
 	std::vector<int32_t> local_genomes; // global index of each genome in the shard
 	std::vector<int64_t> hit_off;      // shard hit offsets
-	std::vector<std::vector<int32_t>> y_order; // per genome: host index of the k-th hit in cm order
+	std::vector<std::vector<int32_t>> y_file;  // per genome: FILE index of the k-th hit in cm order
 	std::vector<ExactSeg> xsegs;
 	std::vector<int32_t> deg;          // out-degree of every oriented vertex of the round's arc table
 	const pga_arc_part_t *cur_arcs = nullptr; // the round's arc table, in backend memory
@@ -83,17 +86,20 @@ struct DataExt {
 	bool pos_valid = false;            // pos_x / y_order on the host match the backend's current orders
 	std::vector<uint64_t> flt_bits;    // bit (shard hit offset of the genome + host index) = flt, refreshed by every sync
 	std::vector<int32_t> pos_x;        // per local hit (file order): position inside its genome in cs order
-	std::vector<std::vector<int32_t>> file_of_host; // per genome: host array index -> file index
+	std::vector<std::vector<int32_t>> file_of_host, host_of_file; // per genome whose records were moved into cs order (hits_sorted): host array index <-> file index
+	bool host_order_valid = false;     // the moved records follow the backend's CURRENT cs order
 	bool host_stale = false;           // per-hit flags on the host are older than the backend's
 	std::vector<GenomePack> packs;     // per genome (global index); empty buf = not packed (any more)
 	double pack_sec = 0.0;             // wall seconds spent packing (reader threads) since the last upload
+	std::vector<HostSlab> slabs;       // pinned memory the blocks live in (guarded by slab_mu while reader threads pack)
+	std::mutex slab_mu;
 	int64_t n_hit_local = 0;
 };
 
 DataExt *ext_of(const pg_data_t *d, bool create);
 // pack the genomes [j0, j1) that have no pack yet (host threads); called by the reader after the commit and by the driver as a fallback
 void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1);
-void free_packs(DataExt *ext);
+void free_packs(DataExt *ext, bool wait);
 void ext_drop(const pg_data_t *d);
 
 const pga_backend_t *backend_default();   // link-time selected (HIP in the product)

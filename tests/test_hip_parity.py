@@ -94,6 +94,33 @@ def test_reference_main_c_on_the_product_library(built, expected, name, variant)
     assert hashlib.md5(r.stdout).hexdigest() == expected[name][variant]["md5"]
 
 
+_ENV_RUN = r'''
+import sys, ctypes as C
+sys.path.insert(0, %r)
+from pangene_amd import capi
+lib = capi.load(); C.c_int.in_dll(lib, "pg_verbose").value = 0
+lib.pg_set_exact_mode(int(sys.argv[2]))
+open(sys.argv[1], "wb").write(capi.run(lib, sys.argv[4:], sys.argv[3].split()))
+''' % ROOT
+
+
+def _run_with_env(tmp_path, env, mode, variant, files):
+    outp = str(tmp_path / "o.bin")
+    r = subprocess.run([sys.executable, "-c", _ENV_RUN, outp, str(mode), variant] + files, env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return open(outp, "rb").read()
+
+
+@pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
+@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1"}, {"PANGENE_GENE_TABLE_LOG2": "2"}])
+def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
+    """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
+    (the path of rounds in which a hub gene overflows the per-gene LDS table).  Forcing the sort path, and shrinking the table to 4
+    entries so that most rounds overflow, must both reproduce the reference's bytes (mode all)."""
+    out = _run_with_env(tmp_path, env, 2, variant, golden_files(name))
+    assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
+
+
 def test_cross_shard_arc_merge(hip):
     """pga_arc_merge (what every rank runs on the all-gathered arc tables of a sharded round) against a numpy reduce-by-key"""
     raw = C.CDLL(capi.LIB_HIP)
