@@ -163,6 +163,13 @@ long       pg_peakrss(void);    /* bytes */
  * Additions
  * ------------------------------------------------------------------------------------------- */
 
+/* pangene.js `gfa2matrix` (pangene.js:1168-1247), the gene x assembly presence / copy-number matrix:
+ * pg_write_matrix prints it for the graph in memory (after pg_graph_gen; the per-hit reduction runs on the GPU),
+ * pg_gfa2matrix_file for any GFA file, plain or gzipped, exactly as the script does (clstr_fn: optional CD-HIT cluster
+ * file, option -d there; print_cd: its -p).  Output: "Gene<TAB>asm..." then one row per segment. */
+void pg_write_matrix(pg_graph_t *g, int32_t copy_number);
+int  pg_gfa2matrix_file(const char *gfa_fn, int32_t copy_number, const char *clstr_fn, int32_t print_cd);
+
 /* Last error of the path (0 = none).  The reference aborts on invariant violations; this library
  * records a status instead, prints one line to stderr, and leaves the graph empty. */
 int         pg_last_error(void);

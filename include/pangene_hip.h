@@ -221,6 +221,13 @@ typedef struct {
 	/* fetch without waiting: the bytes are copied to host memory owned by the backend, *host_view points at them and is \
 	 * valid from the next synchronising call (fetch, sync, arc_set_current, ...) until the next fetch_later */ \
 	int  pfx##_fetch_later(pga_ctx_t *ctx, const void *src_backend, size_t nbytes, const void **host_view); \
+	/* pangene.js gfa2matrix (pangene.js:1168-1247) as a reduction over what the W-lines would contain.  ctg_counts: the number \
+	 * of hits that survive (flt == 0) on every contig of the shard (genome-major list of contigs, host array of that length): \
+	 * a contig prints a W-line iff it has one (format.c:209).  gene_matrix: asm_of_ctg[contig] = column of the contig's \
+	 * sample#haplotype (-1: none); mat[n_seg * n_asm] (host) receives, per segment and column, the number of surviving hits of \
+	 * the segment's gene on the column's contigs, i.e. the occurrences of the segment in that assembly's walks */ \
+	int  pfx##_ctg_counts(pga_ctx_t *ctx, int32_t *cnt); \
+	int  pfx##_gene_matrix(pga_ctx_t *ctx, const int32_t *asm_of_ctg, int32_t n_asm, int32_t n_seg, int32_t *mat); \
 	/* per-hit state in file order */ \
 	int  pfx##_download(pga_ctx_t *ctx, const pga_hit_state_t *out); \
 	int  pfx##_hazards(pga_ctx_t *ctx, pga_hazard_t *out); \
@@ -277,6 +284,8 @@ typedef struct {
 	int  (*host_alloc)(size_t, void **);
 	void (*host_free)(void *);
 	int  (*arc_round_local)(pga_ctx_t *, int32_t, int32_t, int32_t *, int32_t *, const pga_arc_part_t **, int64_t *);
+	int  (*ctg_counts)(pga_ctx_t *, int32_t *);
+	int  (*gene_matrix)(pga_ctx_t *, const int32_t *, int32_t, int32_t, int32_t *);
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);

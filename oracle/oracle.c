@@ -1019,6 +1019,30 @@ int pgo_download(pga_ctx_t *c, const pga_hit_state_t *o)
 	return PGA_OK;
 }
 
+/* pangene.js gfa2matrix (pangene.js:1168-1247) over what the W-lines contain (format.c:183-225: the hits with flt == 0) */
+int pgo_ctg_counts(pga_ctx_t *c, int32_t *cnt)
+{
+	int32_t j; int64_t i;
+	memset(cnt, 0, (size_t)c->ctg_base[c->n_genome] * sizeof(int32_t));
+	for (j = 0; j < c->n_genome; ++j)
+		for (i = c->off[j]; i < c->off[j + 1]; ++i)
+			if (!(c->flags[i] & PGA_F_FLT)) ++cnt[c->ctg_base[j] + c->cid[i]];
+	return PGA_OK;
+}
+
+int pgo_gene_matrix(pga_ctx_t *c, const int32_t *asm_of_ctg, int32_t n_asm, int32_t n_seg, int32_t *mat)
+{
+	int32_t j; int64_t i;
+	if (n_seg != c->n_seg) return PGA_ERR_ARG;
+	memset(mat, 0, (size_t)n_seg * (size_t)n_asm * sizeof(int32_t));
+	for (j = 0; j < c->n_genome; ++j)
+		for (i = c->off[j]; i < c->off[j + 1]; ++i) {
+			int32_t sid = c->g2s[c->gid[i]], col = asm_of_ctg[c->ctg_base[j] + c->cid[i]];
+			if (!(c->flags[i] & PGA_F_FLT) && sid >= 0 && col >= 0) ++mat[(int64_t)sid * n_asm + col];
+		}
+	return PGA_OK;
+}
+
 int pgo_hazards(pga_ctx_t *c, pga_hazard_t *out) { *out = c->hz; return PGA_OK; }
 int pgo_hazard_segs(pga_ctx_t *c, int32_t *segs, int32_t cap, int64_t *n_total)
 {
@@ -1034,7 +1058,7 @@ const pga_backend_t *pgo_backend(void)
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
 		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_arc_merge, pgo_arc_set_current, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
-		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs, pgo_host_alloc, pgo_host_free, pgo_arc_round_local
+		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs, pgo_host_alloc, pgo_host_free, pgo_arc_round_local, pgo_ctg_counts, pgo_gene_matrix
 	};
 	return &b;
 }

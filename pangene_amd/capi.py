@@ -52,6 +52,8 @@ _API = {
     "pg_write_bed": (None, [C.c_void_p, C.c_int32]),
     "pg_write_graph": (None, [C.c_void_p]),
     "pg_write_walk": (None, [C.c_void_p]),
+    "pg_write_matrix": (None, [C.c_void_p, C.c_int32]),
+    "pg_gfa2matrix_file": (C.c_int, [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]),
     "pg_read_list_dict": (C.c_void_p, [C.c_char_p]),
     "pg_dict_destroy": (None, [C.c_void_p]),
     "pg_last_error": (C.c_int, []),
@@ -111,6 +113,7 @@ def parse_args(lib: C.CDLL, argv: Sequence[str]) -> pg_opt_t:
         elif a in ("--bed", "--bed=walk"): opt.flag |= PG_F_WRITE_BED_WALK
         elif a == "--bed=raw": opt.flag |= PG_F_WRITE_BED_RAW
         elif a == "--bed=flag": opt.flag |= PG_F_WRITE_BED_FLAG
+        elif a in ("--matrix", "--matrix=presence", "--matrix=count"): pass  # handled by run()
         elif a[:2] in ("-p", "-a", "-f", "-c", "-g", "-r", "-b", "-B", "-y", "-T", "-D", "-C", "-e", "-l", "-m", "-d", "-X", "-I", "-P"):
             v = a[2:] if len(a) > 2 else next(it)
             k = a[1]
@@ -171,7 +174,8 @@ def run(lib: C.CDLL, files: Sequence[str], argv: Sequence[str] = (), scan_only: 
             lib.pg_graph_gen(C.byref(opt), g)
             if lib.pg_last_error():
                 raise RuntimeError("pangene_amd: " + lib.pg_last_error_str().decode())
-            if opt.flag & PG_F_WRITE_BED_WALK: lib.pg_write_bed(d, 1)
+            if any(x.startswith("--matrix") for x in argv): lib.pg_write_matrix(g, 1 if "--matrix=count" in argv else 0)
+            elif opt.flag & PG_F_WRITE_BED_WALK: lib.pg_write_bed(d, 1)
             elif opt.flag & PG_F_WRITE_BED_FLAG: lib.pg_write_bed(d, 0)
             else:
                 lib.pg_write_graph(g)

@@ -36,7 +36,9 @@ static int usage(FILE *fp, const pg_opt_t *opt)
 	std::fprintf(fp, "  Output:\n");
 	std::fprintf(fp, "    -w            Suppress walk lines (W-lines)\n");
 	std::fprintf(fp, "    --bed[=STR]   output 12-column BED where STR is walk, raw or flag [walk]\n");
+	std::fprintf(fp, "    --matrix[=STR] output the gene x assembly matrix of pangene.js gfa2matrix, STR presence or count [presence]\n");
 	std::fprintf(fp, "    --version     print version number\n");
+	std::fprintf(fp, "  Also: pangene gfa2matrix [-c] [-d FILE] [-p] <in.gfa>   (pangene.js gfa2matrix on a GFA file)\n");
 	return fp == stdout ? 0 : 1;
 }
 
@@ -50,10 +52,28 @@ static int64_t parse_num(const char *s) // "2m", "500k", ... (main.c:45-55)
 	return (int64_t)(x + .499);
 }
 
+static int main_gfa2matrix(int argc, char *argv[]) // pangene.js:1168-1183
+{
+	int c, copy_number = 0, print_cd = 0;
+	const char *clstr = nullptr;
+	while ((c = getopt(argc, argv, "cd:p")) >= 0) {
+		if (c == 'c') copy_number = 1;
+		else if (c == 'd') clstr = optarg;
+		else if (c == 'p') print_cd = 1;
+	}
+	if (argc - optind < 1) {
+		std::puts("Usage: pangene gfa2matrix [options] <in.gfa>\nOptions:\n  -c        output counts\n  -d FILE   CD-HIT cluster file to merge paralogs []");
+		return 0;
+	}
+	return pg_gfa2matrix_file(argv[optind], copy_number, clstr, print_cd) == 0 ? 0 : 1;
+}
+
 int main(int argc, char *argv[])
 {
+	if (argc >= 2 && std::strcmp(argv[1], "gfa2matrix") == 0) return main_gfa2matrix(argc - 1, argv + 1);
+	int matrix = 0; // 1 presence, 2 counts
 	static const struct option lopts[] = {
-		{ "bed", optional_argument, nullptr, 301 }, { "ori-sc", no_argument, nullptr, 302 },
+		{ "bed", optional_argument, nullptr, 301 }, { "ori-sc", no_argument, nullptr, 302 }, { "matrix", optional_argument, nullptr, 303 },
 		{ "version", no_argument, nullptr, 401 }, { nullptr, 0, nullptr, 0 } };
 	pg_opt_t opt;
 	pg_opt_init(&opt);
@@ -94,6 +114,7 @@ int main(int argc, char *argv[])
 			else { std::fprintf(stderr, "ERROR: unrecognized --bed argument. Should be 'raw' or 'walk'.\n"); return 1; }
 			break;
 		case 302: opt.flag |= PG_F_ORI_FOR_BRANCH; break;
+		case 303: matrix = (optarg && std::strcmp(optarg, "count") == 0) ? 2 : 1; break;
 		case 401: std::puts(PG_VERSION); return 0;
 		default: break;
 		}
@@ -109,6 +130,7 @@ int main(int argc, char *argv[])
 		pg_graph_t *g = pg_graph_init(d);
 		pg_graph_gen(&opt, g);
 		if (pg_last_error()) rc = 2;
+		else if (matrix) pg_write_matrix(g, matrix == 2);
 		else if (opt.flag & PG_F_WRITE_BED_WALK) pg_write_bed(d, 1);
 		else if (opt.flag & PG_F_WRITE_BED_FLAG) pg_write_bed(d, 0);
 		else {

@@ -9,18 +9,22 @@
 // exclusive sum is its rank among the walkable hits (rx), and the output step also records the hit as its gene's representative in
 // its genome -- the last walkable hit of a gene in array order wins (branch.c:22-23 overwrite), hence the atomicMax of h + 1.
 struct InWalkX { const uint32_t *flags; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(flags[i] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1}; } };
-struct OutRankRep {
-	int32_t *rx; const int32_t *gnm, *gid; int GL; int32_t *rp_pos; const uint32_t *flags;
-	__device__ __forceinline__ void operator()(int64_t i, I32 incl, I32 ex) const
+struct OutRank {
+	int32_t *rx; const uint32_t *flags;
+	__device__ __forceinline__ void operator()(int64_t i, I32, I32 ex) const
 	{
 		rx[i] = ex.v | ((flags[i] & F_CSTIE) ? (int32_t)0x80000000 : 0); // bit 31: member of a cs tie group (k_rep_fill looks closer)
-		if (incl.v != ex.v) atomicMax(&rp_pos[(int64_t)gid[i] * GL + gnm[i]], (int32_t)i + 1);
 	}
 };
 
-// Position record of (gene, genome): {contig, rank among the walkable hits of the genome, cm}.  COMPACT (every genome has
-// < 4096 contigs and < 2^20 hits, decided once in create): 8 bytes {cm, local contig << 20 | rank}, half the L2 traffic of
-// pg_n_local, which reads two records per (pair, genome); otherwise 16 bytes {global contig, rank, cm, interval}.  Absent: -1.
+// Position record of (gene, genome): {contig, rank among the walkable hits of the genome, cm} of the gene's LAST walkable hit in
+// the genome's array order (branch.c:22-23 overwrite).  COMPACT (every genome has < 4096 contigs and < 2^20 hits, decided once in
+// create): 8 bytes {cm, local contig << 20 | rank}, half the L2 traffic of pg_n_local, which reads two records per (pair, genome);
+// otherwise 16 bytes {global contig, rank, cm, interval}.  Absent: -1.
+//
+// Filled from the gene-major index: the hits of (gene, genome) are adjacent there, in array order, so the last hit of each
+// group finds the group's last walkable hit (walkable = its half-arc record carries the round's tag) and also writes the "absent"
+// records of the genomes up to the next group -- every record is written exactly once, nothing is cleared, nothing is atomic.
 //
 // Tie order (hazard H2b).  The reference's unstable sort may permute the hits sharing (contig, cs); the walkable
 // ones among them receive consecutive values of the counter r (branch.c:14,22-24) in whatever order they end up, so the r of
@@ -29,41 +33,58 @@ struct OutRankRep {
 // table iv[] in the compact form); k_n_local raises the hazard where it matters.  Two walkable hits of ONE gene in a group
 // (-S: opposite strands) make the choice of the representative itself order-dependent (branch.c:22-23): hazard at once.
 struct RepFill {
-	const int32_t *rp_pos; int64_t n_ent; int GL; const int4 *A; const int32_t *gid; const uint32_t *flags; const int32_t *rx, *goff, *ctg_base;
+	int64_t n_ent; int GL, Q, N; const int4 *zrec; const int32_t *zoff; const int4 *hb; uint32_t tag;
+	const int4 *A; const int32_t *gid; const uint32_t *flags; const int32_t *rx, *goff, *ctg_base;
 	void *rp_out; int32_t *iv; int64_t *dcnt; int32_t *hz_list;
 };
 
 template <bool COMPACT>
+__device__ __forceinline__ void rep_absent(const RepFill &a, int64_t e0, int n)
+{
+	for (int k = 0; k < n; ++k) {
+		if (COMPACT) ((int2 *)a.rp_out)[e0 + k] = make_int2(0, -1); else ((int4 *)a.rp_out)[e0 + k] = make_int4(-1, 0, 0, 0);
+	}
+}
+
+template <bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a, const int32_t *cm)
 {
-	int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (e >= a.n_ent) return;
-	const int p = a.rp_pos[e];
-	if (p == 0) {
-		if (COMPACT) ((int2 *)a.rp_out)[e] = make_int2(0, -1); else ((int4 *)a.rp_out)[e] = make_int4(-1, 0, 0, 0);
-		return;
-	}
-	const int h = p - 1, j = (int)(e % a.GL);
+	const int t = blockIdx.x * BLOCK + threadIdx.x;
+	if (t < a.Q && a.zoff[t] == a.zoff[t + 1]) rep_absent<COMPACT>(a, (int64_t)t * a.GL, a.GL); // a gene without hits in this shard
+	if (t >= a.N) return;
+	const int z = t;
+	const int4 zr = a.zrec[z];
+	const int g = zr.z, j = zr.y >> 1, z0 = a.zoff[g], z1 = a.zoff[g + 1];
+	if (z + 1 < z1 && (a.zrec[z + 1].y >> 1) == j) return; // not the last hit of its (gene, genome) group
+	const int64_t e = (int64_t)g * a.GL + j;
+	// the genomes without a hit of this gene: before the first group, and between this group and the next
+	int gs = z;
+	while (gs > z0 && (a.zrec[gs - 1].y >> 1) == j) --gs;
+	if (gs == z0 && j > 0) rep_absent<COMPACT>(a, (int64_t)g * a.GL, j);
+	const int jn = z + 1 < z1 ? (a.zrec[z + 1].y >> 1) : a.GL;
+	if (jn > j + 1) rep_absent<COMPACT>(a, e + 1, jn - j - 1);
+	int q = z;
+	while (q >= gs && !ha_walk(a.hb[q], a.tag)) --q; // the group's last walkable hit
+	if (q < gs) { rep_absent<COMPACT>(a, e, 1); return; }
+	const int h = a.zrec[q].x;
 	const int rxh = a.rx[h], r = (rxh & 0x7fffffff) - (a.rx[a.goff[j]] & 0x7fffffff);
 	const int4 ah = a.A[h]; // {cs, seg, ce, pm}
 	int ivl = 0;
-	if (rxh < 0) { // member of a static tie group: count its walkable members on either side
-		const int lo = a.goff[j], hi = a.goff[j + 1], g = a.gid[h];
-		int nb = 0, na = 0; bool same_gene = false;
-		for (int q = h - 1; q >= lo; --q) {
-			const int4 aq = a.A[q];
-			if (aq.y != ah.y || aq.x != ah.x) break;
-			if (!(a.flags[q] & (PGA_F_FLT | PGA_F_SHADOW))) ++nb, same_gene = same_gene || a.gid[q] == g;
+	if (rxh < 0) { // member of a static tie group [ta, tb): its walkable members on either side, from the walkable ranks at the group's ends
+		const int lo = a.goff[j], hi = a.goff[j + 1];
+		int ta = h, tb = h + 1;
+		while (ta > lo) { const int4 ap = a.A[ta - 1]; if (ap.y != ah.y || ap.x != ah.x) break; --ta; }
+		while (tb < hi) { const int4 ap = a.A[tb]; if (ap.y != ah.y || ap.x != ah.x) break; ++tb; }
+		const int re = tb < a.N ? (a.rx[tb] & 0x7fffffff) : (a.rx[tb - 1] & 0x7fffffff) + ((a.flags[tb - 1] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1);
+		const int nb = (rxh & 0x7fffffff) - (a.rx[ta] & 0x7fffffff), na = re - (rxh & 0x7fffffff) - 1;
+		if (nb + na > 0) { // rare: walkable hits do share this start
+			bool same_gene = false; // two walkable hits of ONE gene in the group: the representative itself depends on the tie order
+			for (int p = ta; p < tb; ++p) same_gene = same_gene || (p != h && a.gid[p] == g && !(a.flags[p] & (PGA_F_FLT | PGA_F_SHADOW)));
+			if (same_gene || nb > 0xffff || na > 0xffff) {
+				atomicAdd((unsigned long long *)&a.dcnt[6], 1ull);
+				hz_note(&a.dcnt[14], a.hz_list, ah.y);
+			} else ivl = nb << 16 | na;
 		}
-		for (int q = h + 1; q < hi; ++q) {
-			const int4 aq = a.A[q];
-			if (aq.y != ah.y || aq.x != ah.x) break;
-			if (!(a.flags[q] & (PGA_F_FLT | PGA_F_SHADOW))) ++na, same_gene = same_gene || a.gid[q] == g;
-		}
-		if (same_gene || nb > 0xffff || na > 0xffff) {
-			atomicAdd((unsigned long long *)&a.dcnt[6], 1ull);
-			hz_note(&a.dcnt[14], a.hz_list, ah.y);
-		} else ivl = nb << 16 | na;
 	}
 	const int cmw = cm[h] | (ivl ? (int)0x80000000 : 0);
 	if (COMPACT) {

@@ -107,3 +107,12 @@ __device__ __forceinline__ void hz_note(int64_t *cnt14, int32_t *list, int seg)
 	const unsigned long long at = atomicAdd((unsigned long long *)cnt14, 1ull);
 	if (at < (unsigned long long)PGA_HAZARD_CAP) list[at] = seg;
 }
+
+// Half-arc records (k_genes.hpp): per hit, in gene-major order, its successor (hf) and predecessor (hb) adjacency of the current
+// walk: {round tag << 21 | target vertex (gene << 1 | rev), distance, score of this hit, score of the other hit}.
+constexpr uint32_t HA_NONE = 0x1fffffu;  // "no adjacency" target (gene ids stay below 2^20 - 1)
+constexpr int HA_TAG_SHIFT = 21;
+constexpr uint32_t HA_TAG_MAX = 0x7ffu;
+__device__ __forceinline__ bool ha_valid(const int4 h, uint32_t tag) { return ((uint32_t)h.x >> HA_TAG_SHIFT) == tag && ((uint32_t)h.x & HA_NONE) != HA_NONE; }
+// a hit is walkable in this round exactly when the walk wrote its predecessor record in this round
+__device__ __forceinline__ bool ha_walk(const int4 hb, uint32_t tag) { return ((uint32_t)hb.x >> HA_TAG_SHIFT) == tag; }

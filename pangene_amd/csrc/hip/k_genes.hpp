@@ -18,9 +18,7 @@
 // gene's vertices and raises its own weak_br.
 #pragma once
 
-constexpr uint32_t HA_NONE = 0x1fffffu;  // "no adjacency" target (gene ids stay below 2^20 - 1)
-constexpr int HA_TAG_SHIFT = 21;         // half-arc word 0 = round tag << 21 | target vertex (gene << 1 | rev)
-constexpr uint32_t HA_TAG_MAX = 0x7ffu;
+// (the half-arc record format -- HA_NONE, HA_TAG_SHIFT, ha_valid, ha_walk -- lives in k_common.hpp: k_branch.hpp reads the records too)
 
 // ------------------------------------------------------------------------------------------------
 // the gene-major index (static per run: rebuilt only when an order override moves hits)
@@ -31,13 +29,13 @@ __global__ __launch_bounds__(BLOCK) void k_zkey(const int32_t *gid, int n, uint6
 	if (h < n) key[h] = (uint64_t)(uint32_t)gid[h], val[h] = (uint32_t)h;
 }
 
-// zrec[z] = {X position, local genome << 1 | rev}; zpos[x] = z
-__global__ __launch_bounds__(BLOCK) void k_zrec(const uint32_t *perm, const int32_t *gnm, const uint32_t *flags, int n, int2 *zrec, int32_t *zpos)
+// zrec[z] = {X position, local genome << 1 | rev, gene, 0}; zpos[x] = z
+__global__ __launch_bounds__(BLOCK) void k_zrec(const uint32_t *perm, const uint64_t *ks, const int32_t *gnm, const uint32_t *flags, int n, int4 *zrec, int32_t *zpos)
 {
 	int z = blockIdx.x * BLOCK + threadIdx.x;
 	if (z >= n) return;
 	const int x = (int)perm[z];
-	zrec[z] = make_int2(x, gnm[x] << 1 | ((flags[x] & PGA_F_REV) ? 1 : 0));
+	zrec[z] = make_int4(x, gnm[x] << 1 | ((flags[x] & PGA_F_REV) ? 1 : 0), (int)ks[z], 0);
 	zpos[x] = z;
 }
 
@@ -83,111 +81,169 @@ struct OutHalfArcs {
 };
 
 // ------------------------------------------------------------------------------------------------
-// (B) one workgroup per gene
+// (B) one wave per gene (one workgroup for a gene with many hits or many neighbours)
 // ------------------------------------------------------------------------------------------------
-constexpr int GA_CAP = 512; // distinct (orientation, target) pairs of one gene the LDS table holds; more = the round takes the sort path
+constexpr int GA_CAP_WAVE = 128, GA_CAP = 512; // distinct (orientation, target) pairs of one gene the LDS tables hold; more than GA_CAP = the round takes the sort path
+constexpr int GA_WAVE_HITS = 256;              // genes with more hits go to the workgroup kernel straight away
+constexpr int GA_BIG_STAGE = 2048;             // hits the workgroup kernel stages at a time
 
 struct GeneArcs {
-	const int2 *zrec; const int32_t *zoff; const uint32_t *flags; const int4 *hf, *hb; const int32_t *g2s;
-	int Q, S; uint32_t tag; int cap_log2; // table size actually used (<= GA_CAP; tests shrink it to reach the overflow path)
+	const int4 *zrec; const int32_t *zoff; const int4 *hf, *hb; const int32_t *g2s;
+	int Q, S; uint32_t tag; int cap_log2; // table size actually used (<= GA_CAP; tests shrink it to reach the overflow paths)
 	int32_t *seg_cnt, *seg_gid;       // [2S] n_genome then tot_cnt (graph.c:125-126); [S] gene of each segment
-	pga_arc_part_t *stage; int4 *gmeta; // arcs of a gene at stage[gmeta.x ...): gmeta = {base, #arcs leaving (sid, +), #arcs leaving (sid, -), 0}
-	int64_t *dcnt;                      // [3] invariant, [8] staged arcs, [9] genes that overflowed the table
+	pga_arc_part_t *stage; int32_t *stage_sid; int4 *gmeta; // (stage_sid: segment of every staged arc)  arcs of a gene at stage[gmeta.x ...): gmeta = {base, #arcs leaving (sid, +), #arcs leaving (sid, -), 0}
+	int32_t *big_list;                  // genes left to the workgroup kernel (dcnt[11] counts them)
+	int64_t *dcnt;                      // [3] invariant, [8] staged arcs, [9] genes that overflowed GA_CAP, [11] big_list entries
 };
 
-__device__ __forceinline__ bool ha_valid(const int4 h, uint32_t tag) { return ((uint32_t)h.x >> HA_TAG_SHIFT) == tag && ((uint32_t)h.x & HA_NONE) != HA_NONE; }
 
-__global__ __launch_bounds__(BLOCK) void k_gene_arcs(GeneArcs a)
+template <int CAP, int STAGE> struct GeneTable {
+	uint32_t key[CAP]; int32_t ng[CAP], tot[CAP]; unsigned long long sd[CAP], s1[CAP], s2[CAP]; uint16_t dense[CAP];
+	int32_t zy[STAGE]; uint32_t fx[STAGE], bx[STAGE]; // staged window of the gene's hits: genome << 1 | rev, word 0 of the two half-arcs
+	int n_tot, n_gen, over, m, m0, base;
+};
+
+// The group logic (which hits of the gene lie in the same genome, which of their half-arcs share a key) only needs three words
+// per hit; they are staged in LDS a window at a time, so that looking at a neighbour costs no trip to memory.  Outside the
+// window (groups that straddle a window border: rare) the same words come from global memory.
+template <int CAP, int STAGE> struct GeneWin {
+	const GeneArcs &a; const GeneTable<CAP, STAGE> &T; int lo, hi;
+	__device__ __forceinline__ int zy(int z) const { return (z >= lo && z < hi) ? T.zy[z - lo] : a.zrec[z].y; }
+	__device__ __forceinline__ uint32_t fx(int z) const { return (z >= lo && z < hi) ? T.fx[z - lo] : (uint32_t)a.hf[z].x; }
+	__device__ __forceinline__ uint32_t bx(int z) const { return (z >= lo && z < hi) ? T.bx[z - lo] : (uint32_t)a.hb[z].x; }
+};
+__device__ __forceinline__ bool hx_valid(uint32_t x, uint32_t tag) { return (x >> HA_TAG_SHIFT) == tag && (x & HA_NONE) != HA_NONE; }
+__device__ __forceinline__ bool hx_walk(uint32_t x, uint32_t tag) { return (x >> HA_TAG_SHIFT) == tag; }
+
+// NT cooperating threads (one wave: 64, one workgroup: 256), tid in [0, NT).  Returns false when the table overflowed.
+template <int NT, int CAP, int STAGE>
+__device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, STAGE> &T, const int g, const int sid, const int tid, const int cap_log2)
 {
-	__shared__ uint32_t t_key[GA_CAP];
-	__shared__ int32_t t_ng[GA_CAP], t_tot[GA_CAP];
-	__shared__ unsigned long long t_sd[GA_CAP], t_s1[GA_CAP], t_s2[GA_CAP];
-	__shared__ uint16_t t_dense[GA_CAP];
-	__shared__ int s_tot, s_ngen, s_over, s_m, s_m0, s_base;
-	const int g = blockIdx.x, tid = threadIdx.x;
-	const int sid = a.g2s[g], z0 = a.zoff[g], z1 = a.zoff[g + 1];
-	if (sid < 0) { // not a vertex: none of its hits may be walkable (graph.c:111)
-		for (int z = z0 + tid; z < z1; z += BLOCK)
-			if (!(a.flags[a.zrec[z].x] & (PGA_F_FLT | PGA_F_SHADOW))) atomicAdd((unsigned long long *)&a.dcnt[3], 1ull);
-		return;
-	}
-	for (int k = tid; k < GA_CAP; k += BLOCK) t_key[k] = 0xffffffffu, t_ng[k] = 0, t_tot[k] = 0, t_sd[k] = 0, t_s1[k] = 0, t_s2[k] = 0;
-	if (tid == 0) s_tot = 0, s_ngen = 0, s_over = 0, s_m = 0, s_m0 = 0;
-	__syncthreads();
-	for (int z = z0 + tid; z < z1; z += BLOCK) {
-		const int2 zr = a.zrec[z];
-		if (a.flags[zr.x] & (PGA_F_FLT | PGA_F_SHADOW)) continue;
-		const int genome = zr.y >> 1, rev = zr.y & 1;
-		// the hits of this gene in this genome: [gs, ge) around z (one or two as a rule)
-		int gs = z, ge = z + 1;
-		while (gs > z0 && (a.zrec[gs - 1].y >> 1) == genome) --gs;
-		while (ge < z1 && (a.zrec[ge].y >> 1) == genome) ++ge;
-		bool first = true; // first walkable hit of the group: it counts the genome (graph.c:125)
-		for (int q = gs; q < z; ++q) first = first && (a.flags[a.zrec[q].x] & (PGA_F_FLT | PGA_F_SHADOW)) != 0;
-		atomicAdd(&s_tot, 1);
-		if (first) atomicAdd(&s_ngen, 1);
+	constexpr int HALO = STAGE >= 1024 ? 32 : 0; // the wave kernel stages a whole gene at once
+	const int z0 = a.zoff[g], z1 = a.zoff[g + 1], cap = 1 << cap_log2;
+	for (int k = tid; k < cap; k += NT) T.key[k] = 0xffffffffu, T.ng[k] = 0, T.tot[k] = 0, T.sd[k] = 0, T.s1[k] = 0, T.s2[k] = 0;
+	if (tid == 0) T.n_tot = 0, T.n_gen = 0, T.over = 0, T.m = 0, T.m0 = 0;
+	for (int c0 = z0; c0 < z1; c0 += STAGE - 2 * HALO) {
+		const int c1 = c0 + (STAGE - 2 * HALO) < z1 ? c0 + (STAGE - 2 * HALO) : z1;
+		GeneWin<CAP, STAGE> W = { a, T, c0 - HALO > z0 ? c0 - HALO : z0, c1 + HALO < z1 ? c1 + HALO : z1 };
+		if (NT == 64) wave_sync(); else __syncthreads(); // the previous window is done with (and the table is clear)
+		for (int z = W.lo + tid; z < W.hi; z += NT) T.zy[z - W.lo] = a.zrec[z].y, T.fx[z - W.lo] = (uint32_t)a.hf[z].x, T.bx[z - W.lo] = (uint32_t)a.hb[z].x;
+		if (NT == 64) wave_sync(); else __syncthreads();
+		for (int z = c0 + tid; z < c1; z += NT) {
+			if (!hx_walk(T.bx[z - W.lo], a.tag)) continue;
+			const int zy = T.zy[z - W.lo], genome = zy >> 1, rev = zy & 1;
+			// the hits of this gene in this genome: [gs, ge) around z (one or two as a rule)
+			int gs = z, ge = z + 1;
+			while (gs > z0 && (W.zy(gs - 1) >> 1) == genome) --gs;
+			while (ge < z1 && (W.zy(ge) >> 1) == genome) ++ge;
+			bool first = true; // first walkable hit of the group: it counts the genome (graph.c:125)
+			for (int q = gs; q < z; ++q) first = first && !hx_walk(W.bx(q), a.tag);
+			atomicAdd(&T.n_tot, 1);
+			if (first) atomicAdd(&T.n_gen, 1);
 #pragma unroll
-		for (int dir = 0; dir < 2; ++dir) {
-			const int4 h = dir ? a.hb[z] : a.hf[z];
-			if (!ha_valid(h, a.tag)) continue;
-			const uint32_t key = (uint32_t)(dir ? !rev : rev) << HA_TAG_SHIFT | ((uint32_t)h.x & HA_NONE);
-			// level 1 (graph.c:128-145): the first item of the group with this key collapses the group's items with the same key
-			bool leader = true;
-			int n = 1, m1 = h.z, m2 = h.w;
-			unsigned long long sd = (unsigned long long)(long long)h.y;
-			for (int q = gs; q < ge && leader; ++q) {
-				const int rq = a.zrec[q].y & 1;
+			for (int dir = 0; dir < 2; ++dir) {
+				const uint32_t hx = dir ? T.bx[z - W.lo] : T.fx[z - W.lo];
+				if (!hx_valid(hx, a.tag)) continue;
+				const uint32_t key = (uint32_t)(dir ? !rev : rev) << HA_TAG_SHIFT | (hx & HA_NONE);
+				// level 1 (graph.c:128-145): the first item of the group with this key collapses the group's items with the same key
+				// (the two half-arcs of one hit never share a key: their orientation bits differ)
+				bool leader = true;
+				int n = 1;
+				for (int q = gs; q < ge && leader && ge - gs > 1; ++q) {
+					if (q == z) continue;
+					const int rq = W.zy(q) & 1;
 #pragma unroll
-				for (int d2 = 0; d2 < 2; ++d2) {
-					if (q == z && d2 == dir) continue;
-					const int4 o = d2 ? a.hb[q] : a.hf[q];
-					if (!ha_valid(o, a.tag) || ((uint32_t)(d2 ? !rq : rq) << HA_TAG_SHIFT | ((uint32_t)o.x & HA_NONE)) != key) continue;
-					if (q < z || (q == z && d2 < dir)) { leader = false; break; }
-					++n, sd += (unsigned long long)(long long)o.y, m1 = m1 > o.z ? m1 : o.z, m2 = m2 > o.w ? m2 : o.w;
+					for (int d2 = 0; d2 < 2; ++d2) {
+						const uint32_t ox = d2 ? W.bx(q) : W.fx(q);
+						if (!hx_valid(ox, a.tag) || ((uint32_t)(d2 ? !rq : rq) << HA_TAG_SHIFT | (ox & HA_NONE)) != key) continue;
+						if (q < z) { leader = false; break; }
+						++n;
+					}
 				}
+				if (!leader) continue;
+				const int4 h = dir ? a.hb[z] : a.hf[z]; // the payload: distance and the two scores
+				int m1 = h.z, m2 = h.w;
+				unsigned long long sd = (unsigned long long)(long long)h.y;
+				if (n > 1) // rare: the same adjacency twice in one genome
+					for (int q = z + 1; q < ge; ++q) {
+						const int rq = W.zy(q) & 1;
+#pragma unroll
+						for (int d2 = 0; d2 < 2; ++d2) {
+							const uint32_t ox = d2 ? W.bx(q) : W.fx(q);
+							if (!hx_valid(ox, a.tag) || ((uint32_t)(d2 ? !rq : rq) << HA_TAG_SHIFT | (ox & HA_NONE)) != key) continue;
+							const int4 o = d2 ? a.hb[q] : a.hf[q];
+							sd += (unsigned long long)(long long)o.y, m1 = m1 > o.z ? m1 : o.z, m2 = m2 > o.w ? m2 : o.w;
+						}
+					}
+				m1 = m1 > 0 ? m1 : 0, m2 = m2 > 0 ? m2 : 0; // the reference's running maxima start at 0 (graph.c:133)
+				const int dg = (int32_t)((double)(long long)sd / n + .499); // graph.c:141
+				// level 2 (graph.c:153-169): sums over the genomes, LDS table keyed by (orientation, target)
+				uint32_t slot = (key * 2654435761u) >> (32 - cap_log2);
+				int probes = 0;
+				for (; probes < cap; ++probes, slot = (slot + 1) & (cap - 1)) {
+					const uint32_t old = atomicCAS(&T.key[slot], 0xffffffffu, key);
+					if (old == 0xffffffffu || old == key) break;
+				}
+				if (probes == cap) { T.over = 1; continue; }
+				atomicAdd(&T.ng[slot], 1); atomicAdd(&T.tot[slot], n);
+				atomicAdd(&T.sd[slot], (unsigned long long)(long long)dg * (unsigned long long)n);
+				atomicAdd(&T.s1[slot], (unsigned long long)(long long)m1); atomicAdd(&T.s2[slot], (unsigned long long)(long long)m2);
 			}
-			if (!leader) continue;
-			m1 = m1 > 0 ? m1 : 0, m2 = m2 > 0 ? m2 : 0; // the reference's running maxima start at 0 (graph.c:133)
-			const int dg = (int32_t)((double)(long long)sd / n + .499); // graph.c:141
-			// level 2 (graph.c:153-169): sums over the genomes, LDS table keyed by (orientation, target)
-			const int cap = 1 << a.cap_log2;
-			uint32_t slot = (key * 2654435761u) >> (32 - a.cap_log2);
-			int probes = 0;
-			for (; probes < cap; ++probes, slot = (slot + 1) & (cap - 1)) {
-				const uint32_t old = atomicCAS(&t_key[slot], 0xffffffffu, key);
-				if (old == 0xffffffffu || old == key) break;
-			}
-			if (probes == cap) { s_over = 1; continue; }
-			atomicAdd(&t_ng[slot], 1); atomicAdd(&t_tot[slot], n);
-			atomicAdd(&t_sd[slot], (unsigned long long)(long long)dg * (unsigned long long)n);
-			atomicAdd(&t_s1[slot], (unsigned long long)(long long)m1); atomicAdd(&t_s2[slot], (unsigned long long)(long long)m2);
 		}
 	}
-	__syncthreads();
-	if (s_over) { // too many distinct neighbours for the table (a hub gene): this round is redone on the sort path
-		if (tid == 0) atomicAdd((unsigned long long *)&a.dcnt[9], 1ull), a.gmeta[sid] = make_int4(0, 0, 0, 0);
-		return;
-	}
-	for (int k = tid; k < GA_CAP; k += BLOCK)
-		if (t_key[k] != 0xffffffffu) { const int at = atomicAdd(&s_m, 1); t_dense[at] = (uint16_t)k; if (!(t_key[k] >> HA_TAG_SHIFT)) atomicAdd(&s_m0, 1); }
-	__syncthreads();
-	const int m = s_m;
+	if (NT == 64) wave_sync(); else __syncthreads();
+	if (T.over) return false;
+	for (int k = tid; k < cap; k += NT)
+		if (T.key[k] != 0xffffffffu) { const int at = atomicAdd(&T.m, 1); T.dense[at] = (uint16_t)k; if (!(T.key[k] >> HA_TAG_SHIFT)) atomicAdd(&T.m0, 1); }
+	if (NT == 64) wave_sync(); else __syncthreads();
+	const int m = T.m;
 	if (tid == 0) {
-		s_base = m ? (int)atomicAdd((unsigned long long *)&a.dcnt[8], (unsigned long long)m) : 0;
-		a.seg_cnt[sid] = s_ngen, a.seg_cnt[a.S + sid] = s_tot, a.seg_gid[sid] = g;
+		T.base = m ? (int)atomicAdd((unsigned long long *)&a.dcnt[8], (unsigned long long)m) : 0;
+		a.seg_cnt[sid] = T.n_gen, a.seg_cnt[a.S + sid] = T.n_tot, a.seg_gid[sid] = g;
+		a.gmeta[sid] = make_int4(T.base, T.m0, m - T.m0, 0);
 	}
-	__syncthreads();
-	if (tid == 0) a.gmeta[sid] = make_int4(s_base, s_m0, m - s_m0, 0);
-	for (int e = tid; e < m; e += BLOCK) { // rank among the gene's entries = place in the table (keys are distinct)
-		const int k = t_dense[e];
-		const uint32_t key = t_key[k];
+	if (NT == 64) wave_sync(); else __syncthreads();
+	for (int e = tid; e < m; e += NT) { // rank among the gene's entries = place in the table (keys are distinct)
+		const int k = T.dense[e];
+		const uint32_t key = T.key[k];
 		int r = 0;
-		for (int j = 0; j < m; ++j) r += t_key[t_dense[j]] < key;
+		for (int j = 0; j < m; ++j) r += T.key[T.dense[j]] < key;
 		pga_arc_part_t o;
 		const uint32_t t = key & HA_NONE;
 		o.x = (uint64_t)((uint32_t)sid << 1 | (key >> HA_TAG_SHIFT)) << 32 | (uint32_t)((uint32_t)a.g2s[t >> 1] << 1 | (t & 1u));
-		o.n_genome = t_ng[k], o.tot_cnt = t_tot[k], o.sum_dist = t_sd[k], o.sum_s1 = (int64_t)t_s1[k], o.sum_s2 = (int64_t)t_s2[k];
-		a.stage[s_base + r] = o;
+		o.n_genome = T.ng[k], o.tot_cnt = T.tot[k], o.sum_dist = T.sd[k], o.sum_s1 = (int64_t)T.s1[k], o.sum_s2 = (int64_t)T.s2[k];
+		a.stage[T.base + r] = o;
+		a.stage_sid[T.base + r] = sid;
+	}
+	return true;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gene_arcs_wave(GeneArcs a)
+{
+	__shared__ GeneTable<GA_CAP_WAVE, GA_WAVE_HITS> T[BLOCK / WAVE];
+	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int g = blockIdx.x * (BLOCK / WAVE) + w;
+	if (g >= a.Q) return;
+	const int sid = a.g2s[g], z0 = a.zoff[g], z1 = a.zoff[g + 1];
+	if (sid < 0) { // not a vertex: none of its hits may be walkable (graph.c:111)
+		for (int z = z0 + lane; z < z1; z += WAVE)
+			if (ha_walk(a.hb[z], a.tag)) atomicAdd((unsigned long long *)&a.dcnt[3], 1ull);
+		return;
+	}
+	const int cl = a.cap_log2 < 7 ? a.cap_log2 : 7;
+	if (z1 - z0 <= GA_WAVE_HITS && gene_arcs_one<WAVE, GA_CAP_WAVE, GA_WAVE_HITS>(a, T[w], g, sid, lane, cl)) return;
+	if (lane == 0) a.big_list[atomicAdd((unsigned long long *)&a.dcnt[11], 1ull)] = g; // many hits, or many neighbours: the workgroup kernel takes it
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gene_arcs_big(GeneArcs a)
+{
+	__shared__ GeneTable<GA_CAP, GA_BIG_STAGE> T;
+	const int n_big = (int)a.dcnt[11];
+	for (int i = blockIdx.x; i < n_big; i += gridDim.x) {
+		const int g = a.big_list[i], sid = a.g2s[g];
+		if (!gene_arcs_one<BLOCK, GA_CAP, GA_BIG_STAGE>(a, T, g, sid, threadIdx.x, a.cap_log2) && threadIdx.x == 0) // a hub gene: this round is redone on the sort path
+			atomicAdd((unsigned long long *)&a.dcnt[9], 1ull), a.gmeta[sid] = make_int4(0, 0, 0, 0);
+		__syncthreads();
 	}
 }
 
@@ -197,53 +253,63 @@ __global__ __launch_bounds__(BLOCK) void k_gene_arcs(GeneArcs a)
 struct InGmeta { const int4 *gm; __device__ __forceinline__ I32 operator()(int64_t i) const { const int4 m = gm[i]; return I32{m.y + m.z}; } };
 
 struct ArcFinal {
-	const int4 *gmeta; const int32_t *off; int S; const pga_arc_part_t *stage; const int32_t *seg_gid;
+	const int4 *gmeta; const int32_t *off; int S; const pga_arc_part_t *stage; const int32_t *stage_sid, *seg_gid, *seg_cnt;
 	pga_arc_part_t *arcs; uint64_t *ax; int32_t *s1, *agid, *vs, *ve, *deg; uint8_t *aw, *vwk; int64_t *dcnt, *host_box;
+	int32_t *h_round; // pinned host memory (or NULL): seg_cnt[2S] then deg[2S] for the host, written straight from here
 };
 
 __global__ __launch_bounds__(BLOCK) void k_arc_final(ArcFinal f)
 {
-	const int sid = blockIdx.x * BLOCK + threadIdx.x;
-	if (sid >= f.S) return;
-	const int4 m = f.gmeta[sid];
-	const int o = f.off[sid], n = m.y + m.z;
-	for (int i = 0; i < n; ++i) {
-		const pga_arc_part_t a = f.stage[m.x + i];
-		f.arcs[o + i] = a;
-		f.ax[o + i] = a.x;
-		f.s1[o + i] = (int32_t)((double)a.sum_s1 / a.n_genome + .499); // graph.c:171
-		f.agid[o + i] = f.seg_gid[(uint32_t)a.x >> 1];
-		f.aw[o + i] = 0;
+	const int64_t T = (int64_t)gridDim.x * BLOCK, tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const int4 ml = f.gmeta[f.S - 1];
+	const int n_arc = f.off[f.S - 1] + ml.y + ml.z;
+	for (int64_t j = tid; j < n_arc; j += T) { // one staged arc per thread: its place = offset of its segment + its rank inside the gene
+		const int sid = f.stage_sid[j];
+		const int64_t i = f.off[sid] + (j - f.gmeta[sid].x);
+		const pga_arc_part_t a = f.stage[j];
+		f.arcs[i] = a;
+		f.ax[i] = a.x;
+		f.s1[i] = (int32_t)((double)a.sum_s1 / a.n_genome + .499); // graph.c:171
+		f.agid[i] = f.seg_gid[(uint32_t)a.x >> 1];
+		f.aw[i] = 0;
 	}
-	f.vs[2 * sid] = o, f.ve[2 * sid] = o + m.y, f.vs[2 * sid + 1] = o + m.y, f.ve[2 * sid + 1] = o + n;
-	f.deg[2 * sid] = m.y, f.deg[2 * sid + 1] = m.z;
-	f.vwk[2 * sid] = 0, f.vwk[2 * sid + 1] = 0;
-	if (sid == f.S - 1) { // table size and the device counters for the host (read after its next wait)
-		f.dcnt[10] = o + n;
-		__threadfence();
+	for (int64_t sid = tid; sid < f.S; sid += T) {
+		const int4 m = f.gmeta[sid];
+		const int o = f.off[sid], n = m.y + m.z;
+		f.vs[2 * sid] = o, f.ve[2 * sid] = o + m.y, f.vs[2 * sid + 1] = o + m.y, f.ve[2 * sid + 1] = o + n;
+		f.deg[2 * sid] = m.y, f.deg[2 * sid + 1] = m.z;
+		f.vwk[2 * sid] = 0, f.vwk[2 * sid + 1] = 0;
+		if (f.h_round) {
+			f.h_round[sid] = f.seg_cnt[sid], f.h_round[f.S + sid] = f.seg_cnt[f.S + sid];
+			f.h_round[2 * f.S + 2 * sid] = m.y, f.h_round[2 * f.S + 2 * sid + 1] = m.z;
+		}
+	}
+	if (tid == 0) { // table size and the device counters for the host (read after its next wait); the round's counters start again
+		f.dcnt[10] = n_arc;
 		for (int t = 0; t < 16; ++t) f.host_box[t] = f.dcnt[t];
+		f.dcnt[8] = 0, f.dcnt[9] = 0, f.dcnt[11] = 0;
 	}
 }
 
 // ------------------------------------------------------------------------------------------------
 // pg_mark_branch_flt_hit (branch.c:108-145): a hit is marked by the weak arcs among its own two half-arcs
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_mark_hits_z(const int2 *zrec, const int4 *hf, const int4 *hb, uint32_t tag, int n, const int32_t *g2s, const int32_t *gid,
+__global__ __launch_bounds__(BLOCK) void k_mark_hits_z(const int4 *zrec, const int4 *hf, const int4 *hb, uint32_t tag, int n, const int32_t *g2s,
                                                         const uint64_t *ax, const uint8_t *aw, const int32_t *vs, const int32_t *ve, const uint8_t *vwk,
                                                         uint32_t *flags, int64_t *cnt)
 {
 	int z = blockIdx.x * BLOCK + threadIdx.x;
-	int cur = 0;
+	bool marked = false;
 	if (z < n) {
-		const int2 zr = zrec[z];
-		const uint32_t f = flags[zr.x];
-		cur = (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT);
-		if (!(f & (PGA_F_FLT | PGA_F_SHADOW))) {
-			const int sid = g2s[gid[zr.x]], rev = zr.y & 1;
+		const int4 hbz = hb[z];
+		const bool walk = ha_walk(hbz, tag);
+		const int4 zr = walk || cnt ? zrec[z] : make_int4(0, 0, 0, 0);
+		if (walk) {
+			const int sid = g2s[zr.z], rev = zr.y & 1;
 			int nw = 0;
 #pragma unroll
 			for (int dir = 0; dir < 2; ++dir) {
-				const int4 h = dir ? hb[z] : hf[z];
+				const int4 h = dir ? hbz : hf[z];
 				if (!ha_valid(h, tag) || sid < 0) continue;
 				const uint32_t u = (uint32_t)sid << 1 | (uint32_t)(dir ? !rev : rev), t = (uint32_t)h.x & HA_NONE;
 				if (!vwk[u]) continue; // the vertex has no weak out-arc (the common case)
@@ -251,11 +317,16 @@ __global__ __launch_bounds__(BLOCK) void k_mark_hits_z(const int2 *zrec, const i
 				const int e = arc_weak_v(ax, aw, vs, ve, u, w); // dir 0: arc v -> w marks the earlier hit (branch.c:128-130); dir 1: w^1 -> v^1 marks the later one (131-133)
 				nw = nw > e ? nw : e;
 			}
-			if (nw > cur) { cur = nw; flags[zr.x] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT; }
+			if (nw) { // rare: only now is the hit's flag word touched
+				const uint32_t f = flags[zr.x];
+				if (nw > (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT)) flags[zr.x] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT;
+				marked = true;
+			}
 		}
+		if (cnt && !marked) marked = (flags[zr.x] & PGA_F_WEAK_MASK) != 0; // log-only counter (branch.c:137-139): every hit with weak_br != 0
 	}
-	if (cnt) { // log-only counter (branch.c:137-139)
-		const unsigned long long mk = __ballot(z < n && cur != 0);
+	if (cnt) {
+		const unsigned long long mk = __ballot(marked);
 		if (mk && (threadIdx.x & 63) == (unsigned)__ffsll((long long)mk) - 1) atomicAdd((unsigned long long *)cnt, (unsigned long long)__popcll(mk));
 	}
 }

@@ -36,7 +36,8 @@ struct FileHits { const int32_t *pid, *cid, *rank, *sori, *sadj, *nex, *offx, *c
 
 __global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int32_t *goff, int n_genome, const int32_t *ctg_base,
                                                      const int2 *exon, const int32_t *prot_gid, const uint8_t *gene_pref,
-                                                     int32_t *gnm_f, int32_t *seg_f, int32_t *gid_f, int32_t *cds_f, uint64_t *key, uint32_t *val)
+                                                     int32_t *gnm_f, int32_t *seg_f, int32_t *gid_f, int32_t *cds_f, uint64_t *key, uint32_t *val,
+                                                     int rk_shift, const int32_t *hrank, int32_t *rk_f)
 {
 	int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
@@ -47,8 +48,24 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int3
 	int len = 0, ne = f.nex[i], ox = f.offx[i];
 	for (int e = 0; e < ne; ++e) { int2 x = exon[ox + e]; len += x.y - x.x; } // pg_cds_len, overlap.c:45-51
 	gnm_f[i] = g, seg_f[i] = sg, gid_f[i] = gid, cds_f[i] = len;
+	if (rk_shift >= 0) { // the same order in 32 bits (see pga_ctx::rk_shift): 0 exactly when the 64-bit key is 0
+		rk_f[i] = (int32_t)((uint32_t)f.sadj[i] << rk_shift | (uint32_t)gene_pref[gid] << (rk_shift - 1) | (uint32_t)hrank[f.pid[i]]);
+		return;
+	}
 	key[i] = (uint64_t)(int64_t)f.sadj[i] << 33 | (uint64_t)gene_pref[gid] << 32 | hash_u32((uint32_t)f.pid[i]); // the score key of overlap.c:137
 	val[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_hkey(int P, uint64_t *key, uint32_t *val)
+{
+	int p = blockIdx.x * BLOCK + threadIdx.x;
+	if (p < P) key[p] = hash_u32((uint32_t)p), val[p] = (uint32_t)p;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_hrank(const uint64_t *ks, const uint32_t *vs, int P, int32_t *hrank)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < P) hrank[vs[i]] = ks[i] == 0 ? 0 : i + 1; // distinct proteins have distinct hashes; rank + 1 keeps 0 for a hash of 0
 }
 
 // The sweep only ever COMPARES score keys, so every hit gets the dense rank of its key over the shard (one sort per

@@ -94,3 +94,21 @@ __global__ __launch_bounds__(BLOCK) void k_flt_bits(const uint32_t *flags, int n
 	const unsigned long long m = __ballot(h < n && (flags[h < n ? h : n - 1] & PGA_F_FLT));
 	if ((threadIdx.x & 63) == 0 && h < n) bits[h >> 6] = m;
 }
+
+// ------------------------------------------------------------------------------------------------
+// gfa2matrix (pangene.js:1168-1247): the gene x assembly occurrence matrix as a reduction over the walks
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_ctg_counts(const uint32_t *flags, const int32_t *seg, int n, int32_t *cnt)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h < n && !(flags[h] & PGA_F_FLT)) atomicAdd(&cnt[seg[h]], 1);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gene_matrix(const uint32_t *flags, const int32_t *seg, const int32_t *gid, const int32_t *g2s, int n,
+                                                         const int32_t *asm_of_ctg, int n_asm, int32_t *mat)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n || (flags[h] & PGA_F_FLT)) return;
+	const int sid = g2s[gid[h]], col = asm_of_ctg[seg[h]];
+	if (sid >= 0 && col >= 0) atomicAdd(&mat[(int64_t)sid * n_asm + col], 1); // a walk step whose gene is not a segment is ignored (pangene.js:178)
+}

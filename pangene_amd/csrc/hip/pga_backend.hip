@@ -71,7 +71,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK,
+	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_BIGLIST, S_STAGE_SID, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK,
 	S_COUNT
 };
 
@@ -89,6 +89,8 @@ struct pga_ctx {
 	int32_t *fidx = 0, *gnm = 0, *seg = 0, *pid = 0, *gid = 0, *cs = 0, *ce = 0, *cm = 0, *cds = 0, *nex = 0, *offx = 0, *sori = 0, *sadj = 0, *pm = 0;
 	int32_t *rk = 0;        // dense rank of the score key (score_adj, preferred, hash(pid)) of overlap.c:137 over the shard; 0 = key 0
 	int sc_bits = 64;       // significant bits of that key
+	int rk_shift = -1;      // >= 0: the key fits 32 bits as score_adj << rk_shift | preferred << (rk_shift - 1) | (rank of hash(pid) among the proteins): no sort
+	int32_t *hrank = 0;     // [P] rank of hash(pid) + 1 (0 for a hash of 0)
 	bool any_multi = true;  // some hit has more than one exon
 	bool rp_compact = false; // 8-byte (gene, genome) position records (see k_rep_fill)
 	int4 *recA = 0, *recB = 0, *recC = 0; // packed sweep records (derived from the arrays above, see k_pack_rec)
@@ -107,7 +109,7 @@ struct pga_ctx {
 	DevPool pool;
 	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
 	// gene-major index (k_genes.hpp): hits by (gene, genome, X position); half-arc records of the current walk
-	int2 *zrec = 0; int32_t *zpos = 0, *zposy = 0, *zoff = 0; int4 *hf = 0, *hb = 0;
+	int4 *zrec = 0; int32_t *zpos = 0, *zposy = 0, *zoff = 0; int4 *hf = 0, *hb = 0;
 	bool z_valid = false, ha_valid = false; uint32_t round_tag = 0; int ha_ori = -1;
 	int32_t *h_round = nullptr; size_t h_round_cap = 0; // pinned: segment counters + degrees of a round
 	int4 *yrecA = 0, *yrecB = 0; bool yrec_valid = false; // Y-order static records (k_pack_yrec), rebuilt after anything that changes their sources
@@ -251,7 +253,7 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 static int radix_sort_pool(pga_ctx *c, uint64_t *keys, uint32_t *vals, int64_t n, int n_bits, uint64_t **kres, uint32_t **vres)
 {
 	RadixBufs b;
-	if (n > 2 * (int64_t)c->N) return PGA_ERR_ARG; // work buffers are sized once, in create, for 2N items
+	if (n > std::max<int64_t>(2 * (int64_t)c->N + 2, (int64_t)c->P + 2)) return PGA_ERR_ARG; // work buffers are sized once, in create
 	b.k_alt = (uint64_t *)c->pool.get(S_KEY_B, 0);
 	b.v_alt = (uint32_t *)c->pool.get(S_VAL_B, 0);
 	b.table = (uint32_t *)c->pool.get(S_TABLE, 0);
@@ -333,7 +335,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->ctg_base, GL + 1)); TRY(dalloc(c, &c->inv, N)); TRY(dalloc(c, &c->headpos, GL + 1)); TRY(dalloc(c, &c->exon, E));
 	TRY(dalloc(c, &c->eoff, GL + 1)); TRY(dalloc(c, &c->woff, GL + 1));
 	TRY(dalloc(c, &c->zrec, N)); TRY(dalloc(c, &c->zpos, N)); TRY(dalloc(c, &c->zposy, N)); TRY(dalloc(c, &c->zoff, (size_t)c->Q + 2)); TRY(dalloc(c, &c->hf, N)); TRY(dalloc(c, &c->hb, N));
-	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q));
+	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q)); TRY(dalloc(c, &c->hrank, c->P));
 	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
 	TRY(dalloc_commit(c));
 
@@ -358,6 +360,12 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->h_ggl.assign(sh->genome_global, sh->genome_global + GL);
 	c->cs_bits = bits_for(max_cs), c->cm_bits = bits_for(max_cm), c->seg_bits = bits_for((uint32_t)std::max(1, c->n_seg_ctg));
 	c->sc_bits = neg_sadj ? 64 : std::min(64, 33 + bits_for(max_sadj)); // score key = score_adj << 33 | preferred << 32 | hash(pid)
+	// pg_hash_uint32 is a bijection, so its rank among the P proteins orders them as the hash does: when score_adj, the preferred bit
+	// and that rank fit 32 bits together, the hits' comparison keys need no sort of their own (a P-sized sort instead of an N-sized one)
+	{
+		const int pb = bits_for((uint32_t)std::max(1, c->P)), sb = bits_for(max_sadj);
+		c->rk_shift = (!neg_sadj && sb + 1 + pb <= 32 && getenv("PANGENE_RANK_BY_SORT") == nullptr) ? pb + 1 : -1;
+	}
 	c->any_multi = multi;
 
 	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
@@ -382,11 +390,19 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	if (N) hipLaunchKernelGGL(k_unblock, dim3(nblk(N)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, N, up);
 	if (E) hipLaunchKernelGGL(k_unblock_exons, dim3(nblk(E)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, E, c->exon);
 	{ // work buffers shared by every sort / scan of the run: sized for the largest input (2N temp arcs)
-		const int64_t W = 2 * (int64_t)N + 2;
+		const int64_t W = std::max<int64_t>(2 * (int64_t)N + 2, (int64_t)c->P + 2);
 		if (!c->pool.get(S_KEY_A, sizeof(uint64_t) * (size_t)W) || !c->pool.get(S_VAL_A, sizeof(uint32_t) * (size_t)W) ||
 		    !c->pool.get(S_KEY_B, sizeof(uint64_t) * (size_t)W) || !c->pool.get(S_VAL_B, sizeof(uint32_t) * (size_t)W) ||
 		    !c->pool.get(S_TABLE, sizeof(uint32_t) * (size_t)rs_table_len(W)) ||
 		    !c->pool.get(S_TILE, tile_buf_bytes(W))) return PGA_ERR_NOMEM;
+	}
+	if (c->P && c->rk_shift >= 0) { // rank of hash(pid) over the proteins
+		uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, 0); uint32_t *val = (uint32_t *)c->pool.get(S_VAL_A, 0);
+		hipLaunchKernelGGL(k_hkey, dim3(nblk(c->P)), dim3(BLOCK), 0, c->st, c->P, key, val);
+		RadixBufs b = { (uint64_t *)c->pool.get(S_KEY_B, 0), (uint32_t *)c->pool.get(S_VAL_B, 0), (uint32_t *)c->pool.get(S_TABLE, 0), (int32_t *)c->pool.get(S_TILE, 0) };
+		uint64_t *ks; uint32_t *vs;
+		device_radix_sort(key, val, c->P, 32, b, &ks, &vs, c->st);
+		hipLaunchKernelGGL(k_hrank, dim3(nblk(c->P)), dim3(BLOCK), 0, c->st, ks, vs, c->P, c->hrank);
 	}
 	const int rc = sync_st(c); // the caller's blocks and tables have been read
 	if (timing) fprintf(stderr, "[pga_create] allocations %.3f ms, upload of %.1f MB + unpack %.3f ms\n", (t1 - t0) * 1e3, woff[(size_t)GL] * 4e-6, (now() - t1) * 1e3);
@@ -420,9 +436,9 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	if (!up || !rk_f || !head || !incl || !key || !val) return PGA_ERR_NOMEM;
 	FileHits f = { f_pid, f_cid, f_rank, f_sori, f_sadj, f_nex, f_offx, f_cs, f_ce, f_cm, f_rev };
 	hipLaunchKernelGGL(k_prepare, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, N, c->goff, GL, c->ctg_base, c->exon, c->prot_gid, c->gene_pref,
-	                   f_gnm, f_seg, f_gid, f_cds, key, val);
+	                   f_gnm, f_seg, f_gid, f_cds, key, val, c->rk_shift, c->hrank, rk_f);
 	uint64_t *ks; uint32_t *vs;
-	{ // dense rank of the score keys (see k_rank_scatter)
+	if (c->rk_shift < 0) { // dense rank of the 64-bit score keys (see k_rank_scatter)
 		TRY(radix_sort_pool(c, key, val, N, c->sc_bits, &ks, &vs));
 		hipLaunchKernelGGL(k_arc_head, dim3(nblk(N)), dim3(BLOCK), 0, c->st, ks, (int64_t)N, head);
 		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
@@ -658,7 +674,7 @@ static int ensure_z(pga_ctx *c)
 	hipLaunchKernelGGL(k_zkey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gid, N, key, val);
 	uint64_t *ks; uint32_t *vs;
 	TRY(radix_sort_pool(c, key, val, N, bits_for((uint32_t)std::max(1, c->Q)), &ks, &vs));
-	hipLaunchKernelGGL(k_zrec, dim3(nblk(N)), dim3(BLOCK), 0, c->st, vs, c->gnm, c->flags, N, c->zrec, c->zpos);
+	hipLaunchKernelGGL(k_zrec, dim3(nblk(N)), dim3(BLOCK), 0, c->st, vs, ks, c->gnm, c->flags, N, c->zrec, c->zpos);
 	hipLaunchKernelGGL(k_zoff, dim3(nblk(c->Q + 1)), dim3(BLOCK), 0, c->st, ks, N, c->Q, c->zoff);
 	hipLaunchKernelGGL(k_zpos_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, c->zpos, N, c->zposy);
 	c->z_valid = true, c->ha_valid = false;
@@ -701,7 +717,7 @@ static int cur_table(pga_ctx *c, int64_t n_arc, int n_seg, CurTable *t)
 // pg_gen_arc on the gene-major index (k_genes.hpp).  Leaves the round's arc table (sorted by x) in S_ARCS and everything derived
 // from it (what pga_arc_set_current would compute) in place; seg_cnt[2S] and the degrees stay on the device.  The table size and
 // the overflow mark travel to the pinned mirror with the last kernel; nothing waits here.
-static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int32_t **deg_out)
+static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int32_t **deg_out, int32_t *h_round_dev)
 {
 	const int N = c->N, S = c->n_seg;
 	const int64_t cap = 2 * (int64_t)N + 2; // distinct arcs <= half-arcs <= 2 (N - 1)
@@ -716,16 +732,20 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, pga_a
 	*seg_cnt_out = seg_cnt, *arcs_out = arcs, *deg_out = t.dg;
 	TRY(launch_sweep<0>(c, 2)); // graph.c:102
 	TRY(ensure_half_arcs(c, use_ori));
-	HIPCHK(hipMemsetAsync(c->dcnt + 8, 0, 3 * sizeof(int64_t), c->st)); // staged arcs, overflowed genes, table size
 	if (S == 0) { hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box); return 0; }
+	int32_t *big = (int32_t *)c->pool.get(S_BIGLIST, sizeof(int32_t) * (size_t)std::max(1, c->Q));
+	if (!big) return PGA_ERR_NOMEM;
 	static const int cap_log2 = [] { const char *e = getenv("PANGENE_GENE_TABLE_LOG2"); const int v = e ? atoi(e) : 9; return v < 1 ? 1 : v > 9 ? 9 : v; }();
-	GeneArcs ga = { c->zrec, c->zoff, c->flags, c->hf, c->hb, c->g2s, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta, c->dcnt };
-	hipLaunchKernelGGL(k_gene_arcs, dim3((unsigned)c->Q), dim3(BLOCK), 0, c->st, ga);
+	int32_t *stage_sid = (int32_t *)c->pool.get(S_STAGE_SID, sizeof(int32_t) * (size_t)cap);
+	if (!stage_sid) return PGA_ERR_NOMEM;
+	GeneArcs ga = { c->zrec, c->zoff, c->hf, c->hb, c->g2s, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, stage_sid, gmeta, big, c->dcnt };
+	hipLaunchKernelGGL(k_gene_arcs_wave, dim3(nblk(c->Q, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, ga);
+	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 4 * c->n_cu)), dim3(BLOCK), 0, c->st, ga);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(S));
 	if (!tile) return PGA_ERR_NOMEM;
 	device_scan<I32>(InGmeta{gmeta}, OutExclI32{off}, S, tile, OpSum{}, I32{0}, c->st);
-	ArcFinal f = { gmeta, off, S, stage, t.sg, arcs, t.ax, t.s1, t.agid, t.vs, t.ve, t.dg, t.aw, t.vwk, c->dcnt, c->h_box };
-	hipLaunchKernelGGL(k_arc_final, dim3(nblk(S)), dim3(BLOCK), 0, c->st, f);
+	ArcFinal f = { gmeta, off, S, stage, stage_sid, t.sg, seg_cnt, arcs, t.ax, t.s1, t.agid, t.vs, t.ve, t.dg, t.aw, t.vwk, c->dcnt, c->h_box, h_round_dev };
+	hipLaunchKernelGGL(k_arc_final, dim3((unsigned)std::max(1, 2 * c->n_cu)), dim3(BLOCK), 0, c->st, f);
 	return 0;
 }
 
@@ -796,7 +816,7 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	if (c->N && !arc_sort_path_forced()) {
 		int32_t *deg;
 		*n_arcs_out = 0;
-		TRY(arc_round_genes(c, use_ori, seg_cnt_out, arcs_out, &deg));
+		TRY(arc_round_genes(c, use_ori, seg_cnt_out, arcs_out, &deg, nullptr));
 		TRY(sync_st(c));
 		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
 		if (c->h_cnt[9] == 0) { *n_arcs_out = c->h_cnt[10]; return 0; }
@@ -820,27 +840,10 @@ extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg,
 			HIPCHK(hipHostMalloc((void **)&c->h_round, need + need / 2, hipHostMallocDefault));
 			c->h_round_cap = need + need / 2;
 		}
-		TRY(arc_round_genes(c, use_ori, &seg_cnt, &arcs, &deg));
-		if (n_vtx) {
-			HIPCHK(hipMemcpyAsync(c->h_round, seg_cnt, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
-			HIPCHK(hipMemcpyAsync(c->h_round + n_vtx, deg, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
-		}
+		int32_t *h_dev = nullptr;
+		HIPCHK(hipHostGetDevicePointer((void **)&h_dev, c->h_round, 0));
+		TRY(arc_round_genes(c, use_ori, &seg_cnt, &arcs, &deg, h_dev)); // the last kernel writes the counters and degrees into the pinned buffer
 		TRY(sync_st(c));
-		if (c->h_cnt[3] && getenv("PANGENE_DEBUG_INVARIANT")) { // which hit?
-			const int N = c->N, Q = c->Q;
-			std::vector<int2> zr((size_t)N); std::vector<int32_t> zo((size_t)Q + 1), g2((size_t)Q), gd((size_t)N); std::vector<uint32_t> fl((size_t)N);
-			(void)hipMemcpy(zr.data(), c->zrec, sizeof(int2) * (size_t)N, hipMemcpyDeviceToHost); (void)hipMemcpy(zo.data(), c->zoff, sizeof(int32_t) * ((size_t)Q + 1), hipMemcpyDeviceToHost);
-			(void)hipMemcpy(g2.data(), c->g2s, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost); (void)hipMemcpy(fl.data(), c->flags, sizeof(uint32_t) * (size_t)N, hipMemcpyDeviceToHost);
-			(void)hipMemcpy(gd.data(), c->gid, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost);
-			fprintf(stderr, "[debug] invariant count %ld; N %d Q %d S %d zoff[0] %d zoff[Q] %d\n", (long)c->h_cnt[3], N, Q, S, zo[0], zo[(size_t)Q]);
-			int shown = 0;
-			for (int g = 0; g < Q && shown < 8; ++g)
-				for (int z = zo[(size_t)g]; z < zo[(size_t)g + 1] && shown < 8; ++z) {
-					const int x = zr[(size_t)z].x;
-					if (gd[(size_t)x] != g) { fprintf(stderr, "[debug] z %d: gene %d but gid[x=%d] = %d\n", z, g, x, gd[(size_t)x]); ++shown; }
-					else if (g2[(size_t)g] < 0 && !(fl[(size_t)x] & (PGA_F_FLT | PGA_F_SHADOW))) { fprintf(stderr, "[debug] gene %d (no vertex) has walkable hit x %d flags %x\n", g, x, fl[(size_t)x]); ++shown; }
-				}
-		}
 		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
 		if (c->h_cnt[9] == 0) {
 			if (n_vtx) memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
@@ -919,22 +922,20 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 {
 	const int N = c->N, GL = c->n_genome, Q = c->Q;
 	const int64_t n_ent = (int64_t)Q * GL;
-	int32_t *rp_pos = (int32_t *)c->pool.get(S_RP_POS, sizeof(int32_t) * (size_t)n_ent);
 	int4 *rp = (int4 *)c->pool.get(S_RP_SEG, sizeof(int4) * (size_t)n_ent);
-	if (!rp_pos || !rp) return PGA_ERR_NOMEM;
-	HIPCHK(hipMemsetAsync(rp_pos, 0, sizeof(int32_t) * (size_t)n_ent, c->st));
+	int32_t *iv = (int32_t *)c->pool.get(S_RP_IV, sizeof(int32_t) * (size_t)n_ent);
+	int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
+	if (!rp || !iv || !hzl) return PGA_ERR_NOMEM;
 	if (N) {
-		int32_t *wk = (int32_t *)c->pool.get(S_I32_A, sizeof(int32_t) * (size_t)N);
 		int32_t *rx = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
 		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
-		if (!wk || !rx || !tile) return PGA_ERR_NOMEM;
-		device_scan<I32>(InWalkX{c->flags}, OutRankRep{rx, c->gnm, c->gid, GL, rp_pos, c->flags}, N, tile, OpSum{}, I32{0}, c->st);
-		int32_t *iv = (int32_t *)c->pool.get(S_RP_IV, sizeof(int32_t) * (size_t)n_ent);
-		int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
-		if (!iv || !hzl) return PGA_ERR_NOMEM;
-		RepFill rf = { rp_pos, n_ent, GL, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl };
-		if (n_ent && c->rp_compact) hipLaunchKernelGGL((k_rep_fill<true>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rf, c->cm);
-		else if (n_ent) hipLaunchKernelGGL((k_rep_fill<false>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, rf, c->cm);
+		if (!rx || !tile) return PGA_ERR_NOMEM;
+		TRY(ensure_half_arcs(c, c->ha_ori < 0 ? 0 : c->ha_ori)); // which hits are walkable, gene-major (normally left by the arc round just before)
+		device_scan<I32>(InWalkX{c->flags}, OutRank{rx, c->flags}, N, tile, OpSum{}, I32{0}, c->st); // rank among the walkable hits, cs order
+		RepFill rf = { n_ent, GL, Q, N, c->zrec, c->zoff, c->hb, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl };
+		const unsigned nb = nblk(std::max(N, Q));
+		if (c->rp_compact) hipLaunchKernelGGL((k_rep_fill<true>), dim3(nb), dim3(BLOCK), 0, c->st, rf, c->cm);
+		else hipLaunchKernelGGL((k_rep_fill<false>), dim3(nb), dim3(BLOCK), 0, c->st, rf, c->cm);
 	} else if (n_ent) {
 		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(4 * n_ent)), dim3(BLOCK), 0, c->st, (int32_t *)rp, 4 * n_ent, -1); // "absent" in either record form
 	}
@@ -1038,7 +1039,7 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 		const uint8_t *vwk = (const uint8_t *)c->pool.get(S_VWK, 0);
 		if (!ax || !aw || !vs || !ve || !vwk) return PGA_ERR_NOMEM;
 		if (n_marked) HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
-		hipLaunchKernelGGL(k_mark_hits_z, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->zrec, c->hf, c->hb, c->round_tag, N, c->g2s, c->gid, ax, aw, vs, ve, vwk, c->flags,
+		hipLaunchKernelGGL(k_mark_hits_z, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->zrec, c->hf, c->hb, c->round_tag, N, c->g2s, ax, aw, vs, ve, vwk, c->flags,
 		                   n_marked ? c->dcnt + 2 : (int64_t *)nullptr);
 		// weak_br does not enter the walkable test: the half-arcs stay valid
 	} else {
@@ -1183,6 +1184,29 @@ extern "C" int pga_download(pga_ctx_t *c, const pga_hit_state_t *o)
 	return sync_st(c);
 }
 
+extern "C" int pga_ctg_counts(pga_ctx_t *c, int32_t *cnt)
+{
+	const size_t nb = sizeof(int32_t) * (size_t)std::max(1, c->n_seg_ctg);
+	int32_t *d = (int32_t *)c->pool.get(S_MISC, nb + 16);
+	if (!d) return PGA_ERR_NOMEM;
+	HIPCHK(hipMemsetAsync(d, 0, nb, c->st));
+	if (c->N) hipLaunchKernelGGL(k_ctg_counts, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->seg, c->N, d);
+	return c->n_seg_ctg ? pga_fetch(c, cnt, d, sizeof(int32_t) * (size_t)c->n_seg_ctg) : sync_st(c);
+}
+
+extern "C" int pga_gene_matrix(pga_ctx_t *c, const int32_t *asm_of_ctg, int32_t n_asm, int32_t n_seg, int32_t *mat)
+{
+	if (n_seg != c->n_seg || n_asm < 0) return PGA_ERR_ARG;
+	const size_t nm = (size_t)n_seg * (size_t)n_asm, nc = (size_t)std::max(1, c->n_seg_ctg);
+	int32_t *d = (int32_t *)c->pool.get(S_MISC, sizeof(int32_t) * (nm + nc) + 64);
+	if (!d) return PGA_ERR_NOMEM;
+	if (nm == 0) return 0;
+	HIPCHK(hipMemsetAsync(d, 0, sizeof(int32_t) * nm, c->st));
+	TRY(upload(c, d + nm, asm_of_ctg, (size_t)c->n_seg_ctg));
+	if (c->N) hipLaunchKernelGGL(k_gene_matrix, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->seg, c->gid, c->g2s, c->N, d + nm, n_asm, d);
+	return pga_fetch(c, mat, d, sizeof(int32_t) * nm);
+}
+
 extern "C" int pga_hazards(pga_ctx_t *c, pga_hazard_t *out)
 {
 	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
@@ -1221,7 +1245,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix
 	};
 	return &b;
 }

@@ -1,9 +1,12 @@
 // gfa_writer.cpp -- BED / GFA S-,L-,W-line emission (the reference's format.c:78-225).  Host-side;
 // bytes must equal the reference's, so integer formatting follows its pg_sprintf_lite (format.c:24-76:
 // "%ld" arguments are narrowed to int before printing) and the id:f tag its "%.4f".
+#include <zlib.h>
+#include <cctype>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include "pg_internal.hpp"
 
 namespace pgx {
@@ -59,6 +62,24 @@ static int32_t parse_sample(std::string &sample, const char *name)
 	char *r;
 	long hap = std::strtol(q, &r, 10);
 	return (r == p && hap >= 0) ? (int32_t)hap : -1;
+}
+
+// every line of a plain or gzipped text file (without the line terminators)
+static int read_lines(const char *fn, std::vector<std::string> &out)
+{
+	gzFile fp = (fn && std::strcmp(fn, "-") != 0) ? gzopen(fn, "r") : gzdopen(0, "r");
+	if (fp == nullptr) return -1;
+	std::string cur;
+	char buf[1 << 16];
+	int n;
+	while ((n = gzread(fp, buf, sizeof(buf))) > 0)
+		for (int i = 0; i < n; ++i) {
+			if (buf[i] == '\n') { if (!cur.empty() && cur.back() == '\r') cur.pop_back(); out.push_back(cur); cur.clear(); }
+			else cur.push_back(buf[i]);
+		}
+	if (!cur.empty()) out.push_back(cur);
+	gzclose(fp);
+	return 0;
 }
 
 } // namespace pgx
@@ -173,6 +194,169 @@ void pg_write_walk(pg_graph_t *q)
 		}
 	}
 	std::fflush(fp);
+}
+
+// pangene.js gfa2matrix (pangene.js:1168-1247) straight from the graph in memory: rows = segments in S-line order, columns =
+// sample#haplotype in the order the W-lines would introduce them, entry = presence (or, copy_number != 0, the number of
+// occurrences) of the segment in the walks of that assembly.  The per-hit reduction runs on the backend (pga_gene_matrix).
+void pg_write_matrix(pg_graph_t *q, int32_t copy_number)
+{
+	pg_data_t *d = q->d;
+	DataExt *ext = ext_of(d, false);
+	if (ext == nullptr || ext->ctx == nullptr) { set_error(PGA_ERR_ARG, "pg_write_matrix: pg_graph_gen has not run on this data set"); return; }
+	size_t n_ctg = 0;
+	for (int32_t j : ext->local_genomes) n_ctg += (size_t)d->genome[j].n_ctg;
+	std::vector<int32_t> cnt(n_ctg + 1, 0), col(n_ctg + 1, -1);
+	int rc = ext->be->ctg_counts(ext->ctx, cnt.data());
+	if (rc != 0) { set_error(rc, "ctg_counts"); return; }
+	std::vector<std::string> names;
+	std::unordered_map<std::string, int32_t> idx;
+	std::string sample, key;
+	size_t k = 0;
+	for (int32_t j : ext->local_genomes) { // W-lines: genomes in input order, contigs in id order, only contigs with a surviving hit (format.c:183-225)
+		const pg_genome_t *g = &d->genome[j];
+		for (int32_t c = 0; c < g->n_ctg; ++c, ++k) {
+			if (cnt[k] == 0) continue;
+			const int32_t hap = parse_sample(sample, g->ctg[c].name);
+			char num[16];
+			if (hap >= 0) std::snprintf(num, sizeof(num), "%d", hap), key = sample + "#" + num;
+			else if (g->label) key = std::string(g->label) + "#0";
+			else std::snprintf(num, sizeof(num), "%d", j), key = std::string(num) + "#0";
+			auto it = idx.find(key);
+			if (it == idx.end()) it = idx.emplace(key, (int32_t)names.size()).first, names.push_back(key);
+			col[k] = it->second;
+		}
+	}
+	const int32_t n_asm = (int32_t)names.size();
+	std::vector<int32_t> mat((size_t)q->n_seg * (size_t)n_asm + 1, 0);
+	rc = ext->be->gene_matrix(ext->ctx, col.data(), n_asm, q->n_seg, mat.data());
+	if (rc != 0) { set_error(rc, "gene_matrix"); return; }
+	FILE *fp = out_stream();
+	std::string o = "Gene\t";
+	for (int32_t a = 0; a < n_asm; ++a) { if (a) o += '\t'; o += names[(size_t)a]; }
+	o += '\n';
+	std::fwrite(o.data(), 1, o.size(), fp);
+	for (int32_t i = 0; i < q->n_seg; ++i) {
+		o.assign(d->gene[q->seg[i].gid].name); o += '\t';
+		for (int32_t a = 0; a < n_asm; ++a) {
+			int32_t v = mat[(size_t)i * (size_t)n_asm + (size_t)a];
+			if (!copy_number && v > 1) v = 1;
+			if (a) o += '\t';
+			put_i32(o, v);
+		}
+		o += '\n';
+		std::fwrite(o.data(), 1, o.size(), fp);
+	}
+	std::fflush(fp);
+}
+
+// The same command on a GFA file, as pangene.js runs it (pangene.js:1168-1247 with the parser at 131-197): segments in the order
+// S- and L-lines introduce them, walk steps whose name is not a segment yet are ignored, assemblies = "sample#hap" of the W-lines
+// in first-seen order.  clstr_fn (may be NULL): CD-HIT cluster file; the members of a cluster are added to its representative
+// ("*") and not printed themselves; print_cd prints the (member, representative) pairs instead of the matrix.  Plain or gzipped
+// input.  Returns 0, or -1 when a file cannot be opened.
+int pg_gfa2matrix_file(const char *gfa_fn, int32_t copy_number, const char *clstr_fn, int32_t print_cd)
+{
+	std::vector<std::string> lines;
+	if (read_lines(gfa_fn, lines) != 0) return -1;
+	std::vector<std::string> seg, asm_a;
+	std::unordered_map<std::string, int32_t> seg_h, asm_h;
+	std::vector<std::pair<int32_t, int32_t>> walk; // (assembly, segment) of every walk step
+	auto seg_add = [&](const std::string &n) { auto it = seg_h.find(n); if (it == seg_h.end()) it = seg_h.emplace(n, (int32_t)seg.size()).first, seg.push_back(n); return it->second; };
+	auto split = [](const std::string &l, std::vector<std::string> &t) { t.clear(); size_t b = 0; for (;;) { size_t e = l.find('\t', b); t.push_back(l.substr(b, e == std::string::npos ? e : e - b)); if (e == std::string::npos) break; b = e + 1; } };
+	std::vector<std::string> t;
+	for (const std::string &l : lines) {
+		if (l.empty()) continue;
+		if (l[0] == 'S') { split(l, t); if (t.size() >= 3) seg_add(t[1]); }
+		else if (l[0] == 'L') { split(l, t); if (t.size() >= 5 && (t[2] == "+" || t[2] == "-") && (t[4] == "+" || t[4] == "-")) seg_add(t[1]), seg_add(t[3]); }
+		else if (l[0] == 'W') {
+			split(l, t);
+			if (t.size() < 7) continue;
+			const std::string a = t[1] + "#" + t[2];
+			auto it = asm_h.find(a);
+			if (it == asm_h.end()) it = asm_h.emplace(a, (int32_t)asm_a.size()).first, asm_a.push_back(a);
+			const std::string &w = t[6];
+			for (size_t i = 0; i < w.size();) { // ([><])([^\s><]+)
+				if (w[i] != '>' && w[i] != '<') { ++i; continue; }
+				size_t e = i + 1;
+				while (e < w.size() && w[e] != '>' && w[e] != '<' && !std::isspace((unsigned char)w[e])) ++e;
+				if (e > i + 1) { auto sit = seg_h.find(w.substr(i + 1, e - i - 1)); if (sit != seg_h.end()) walk.emplace_back(it->second, sit->second); }
+				i = e;
+			}
+		}
+	}
+	const size_t n_asm = asm_a.size();
+	std::vector<int32_t> mat(seg.size() * n_asm + 1, 0);
+	for (const auto &st : walk) ++mat[(size_t)st.second * n_asm + (size_t)st.first];
+	std::unordered_map<std::string, std::string> paralog;
+	std::vector<std::string> paralog_order;
+	FILE *fp = out_stream();
+	if (clstr_fn) {
+		std::vector<std::string> cl;
+		if (read_lines(clstr_fn, cl) != 0) return -1;
+		std::vector<std::pair<std::string, bool>> b;
+		auto gene_of = [](const std::string &x) { return x.substr(0, x.find(':')); };
+		auto process = [&]() {
+			int sel = -1;
+			for (size_t i = 0; i < b.size(); ++i) if (b[i].second) sel = (int)i;
+			if (sel >= 0)
+				for (size_t i = 0; i < b.size(); ++i) {
+					if ((int)i == sel) continue;
+					const std::string g = gene_of(b[i].first), p = gene_of(b[(size_t)sel].first);
+					if (paralog.find(g) == paralog.end()) paralog_order.push_back(g);
+					paralog[g] = p;
+					if (print_cd) { const std::string o = g + "\t" + p + "\n"; std::fwrite(o.data(), 1, o.size(), fp); }
+				}
+			b.clear();
+		};
+		for (const std::string &l : cl) {
+			if (!l.empty() && l[0] == '>') { process(); continue; }
+			// ^\d+\s+\S+,\s+>(\S+)\.\.\.\s+(\S+)
+			size_t i = 0;
+			while (i < l.size() && std::isdigit((unsigned char)l[i])) ++i;
+			if (i == 0) continue;
+			size_t j2 = i;
+			while (j2 < l.size() && std::isspace((unsigned char)l[j2])) ++j2;
+			if (j2 == i) continue;
+			const size_t gt = l.find(", >", j2);
+			size_t gt2 = l.find(">", j2);
+			if (gt == std::string::npos && gt2 == std::string::npos) continue;
+			const size_t nm0 = l.find('>', j2) + 1, dots = l.find("...", nm0);
+			if (nm0 == 0 || dots == std::string::npos) continue;
+			size_t r = dots + 3;
+			while (r < l.size() && std::isspace((unsigned char)l[r])) ++r;
+			if (r >= l.size()) continue;
+			size_t re = r;
+			while (re < l.size() && !std::isspace((unsigned char)l[re])) ++re;
+			b.emplace_back(l.substr(nm0, dots - nm0), l.substr(r, re - r) == "*");
+		}
+		process();
+		for (const std::string &g : paralog_order) { // (the reference iterates its hash in insertion order)
+			const std::string &pp = paralog[g];
+			auto gi = seg_h.find(g), pi = seg_h.find(pp);
+			if (gi == seg_h.end() || pi == seg_h.end()) continue;
+			for (size_t a = 0; a < n_asm; ++a) mat[(size_t)pi->second * n_asm + a] += mat[(size_t)gi->second * n_asm + a];
+		}
+	}
+	if (print_cd) { std::fflush(fp); return 0; }
+	std::string o = "Gene\t";
+	for (size_t a = 0; a < n_asm; ++a) { if (a) o += '\t'; o += asm_a[a]; }
+	o += '\n';
+	std::fwrite(o.data(), 1, o.size(), fp);
+	for (size_t i = 0; i < seg.size(); ++i) {
+		if (paralog.find(seg[i]) != paralog.end()) continue;
+		o = seg[i]; o += '\t';
+		for (size_t a = 0; a < n_asm; ++a) {
+			int32_t v = mat[i * n_asm + a];
+			if (!copy_number && v > 1) v = 1;
+			if (a) o += '\t';
+			put_i32(o, v);
+		}
+		o += '\n';
+		std::fwrite(o.data(), 1, o.size(), fp);
+	}
+	std::fflush(fp);
+	return 0;
 }
 
 } // extern "C"
