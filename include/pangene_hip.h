@@ -157,8 +157,9 @@ typedef struct {
 	 * shard's genomes in which sub_gene is sub-ordinate to dom_gene and dom_gene is dominant (the only cells the greedy \
 	 * vertex.c:60-80 can observe).  A (sub, dom) key may occur in more than one record; their sets are disjoint. */ \
 	int  pfx##_vtx_partials(pga_ctx_t *ctx, int32_t **cnt, uint64_t **records, int64_t *n_records); \
-	/* pg_graph_flag_vtx (graph.c:61-69); g2s: [n_gene] host */ \
-	int  pfx##_flag_vtx(pga_ctx_t *ctx, const int32_t *g2s, int32_t n_seg); \
+	/* pg_graph_flag_vtx (graph.c:61-69); g2s: [n_gene] host.  then_filter != 0: followed at once by PG_SET_FILTER(vtx == 0), \
+	 * as everywhere in pg_graph_gen (graph.c:287-288,295,312), in the same pass over the hits */ \
+	int  pfx##_flag_vtx(pga_ctx_t *ctx, const int32_t *g2s, int32_t n_seg, int32_t then_filter); \
 	/* per-genome part of pg_gen_arc (graph.c:97-146) + local reduce-by-key of its global part. \
 	 * seg_cnt[2S] = n_genome[S] then tot_cnt[S] (graph.c:125-126); arcs sorted by x */ \
 	int  pfx##_arc_round(pga_ctx_t *ctx, int32_t use_ori, int32_t **seg_cnt, pga_arc_part_t **arcs, int64_t *n_arcs); \
@@ -175,8 +176,10 @@ typedef struct {
 	int  pfx##_arc_set_current(pga_ctx_t *ctx, const pga_arc_part_t *arcs, int64_t n_arc, int32_t n_seg, int32_t *deg); \
 	/* pg_gen_arc (graph.c:87-177) of a run that is NOT sharded, in one call: the round's table becomes the graph's table at once \
 	 * (as after arc_set_current), the host receives seg_cnt[2 * n_seg] (n_genome[S] then tot_cnt[S]), the out-degree of every \
-	 * oriented vertex deg[2 * n_seg], the table size and where the table lives in backend memory (sorted by x) after a single wait */ \
-	int  pfx##_arc_round_local(pga_ctx_t *ctx, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt, int32_t *deg, const pga_arc_part_t **arcs, int64_t *n_arc); \
+	 * oriented vertex deg[2 * n_seg] after a single wait.  The table itself stays where the backend likes it (arc_table) */ \
+	int  pfx##_arc_round_local(pga_ctx_t *ctx, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt, int32_t *deg); \
+	/* the graph's current arc table (of arc_round_local or arc_set_current) as ONE array sorted by x, in backend memory */ \
+	int  pfx##_arc_table(pga_ctx_t *ctx, const pga_arc_part_t **arcs, int64_t *n_arc); \
 	/* pg_gen_rep_pos (branch.c:6-29) kept in backend memory */ \
 	int  pfx##_rep_pos(pga_ctx_t *ctx); \
 	/* pg_n_local (branch.c:31-46) for n gene pairs (pairs[2i], pairs[2i+1]) over the local genomes.  The reference only tests the \
@@ -189,14 +192,17 @@ typedef struct {
 	 * with >= 2 arcs it lists the gene pairs the reference hands to pg_n_local -- the (best-scoring target, weaker \
 	 * target) pairs of branch.c:70-75, then every i<j pair of 83-88 -- and counts each over the local genomes \
 	 * (needs rep_pos): cnt[n_pairs] in backend memory.  arc_x = NULL: the table of arc_set_current.  branch_decide (after the all-reduce of cnt): branch.c:76-77 \
-	 * and 82-90 -> weak_br per arc (host, n_arc bytes) and n_dist_loci (host, 2S).  The arcs and their weak_br stay \
-	 * resident: mark_hits(NULL, NULL, n_arc) uses them. */ \
+	 * and 82-90 -> weak_br per arc (arc_weak: host, n_arc bytes of the table of arc_set_current / branch_pairs(arc_x), or NULL), \
+	 * n_dist_loci (host, 2S) and, when asked for (non-NULL), the numbers of arcs marked 1 and 2.  The arcs and their weak_br stay \
+	 * resident: mark_hits(NULL, NULL, n_arc) uses them.  n_pairs may be NULL when nobody outside the backend needs the count \
+	 * (a run that is not sharded): the backend then does not wait for it either. */ \
 	int  pfx##_branch_pairs(pga_ctx_t *ctx, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg, \
 	                        double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs); \
 	int  pfx##_branch_decide(pga_ctx_t *ctx, double branch_diff, double branch_diff_dist, double branch_diff_cut, uint8_t *arc_weak, \
 	                         int32_t *n_dist_loci, int64_t *n_flt1, int64_t *n_flt2); \
-	/* pg_mark_branch_flt_hit (branch.c:108-145); arcs sorted by x with their weak_br (0 allowed) */ \
-	int  pfx##_mark_hits(pga_ctx_t *ctx, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked); \
+	/* pg_mark_branch_flt_hit (branch.c:108-145); arcs sorted by x with their weak_br (0 allowed).  then_filter != 0: followed at \
+	 * once by PG_SET_FILTER(weak_br == 2) (graph.c:309), in the same pass over the hits */ \
+	int  pfx##_mark_hits(pga_ctx_t *ctx, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked, int32_t then_filter); \
 	/* Replace the order inside contig segments by the exact order the reference's unstable radix sort \
 	 * (ksort.h:52-87) leaves there (computed by the host).  which 0 = cs order (the \
 	 * physical array order: index 0 of a genome, first-wins ties), 1 = cm order.  Segment s covers the \
@@ -257,7 +263,7 @@ typedef struct {
 	int  (*shadow)(pga_ctx_t *, int32_t, int32_t *);
 	int  (*set_filter)(pga_ctx_t *, int32_t);
 	int  (*vtx_partials)(pga_ctx_t *, int32_t **, uint64_t **, int64_t *);
-	int  (*flag_vtx)(pga_ctx_t *, const int32_t *, int32_t);
+	int  (*flag_vtx)(pga_ctx_t *, const int32_t *, int32_t, int32_t);
 	int  (*arc_round)(pga_ctx_t *, int32_t, int32_t **, pga_arc_part_t **, int64_t *);
 	int  (*arc_merge)(pga_ctx_t *, const pga_arc_part_t *, const int64_t *, int32_t, int64_t, pga_arc_part_t **, int64_t *);
 	int  (*arc_set_current)(pga_ctx_t *, const pga_arc_part_t *, int64_t, int32_t, int32_t *);
@@ -265,7 +271,7 @@ typedef struct {
 	int  (*n_local)(pga_ctx_t *, const int32_t *, int64_t, int32_t, int32_t, int32_t, int32_t **);
 	int  (*branch_pairs)(pga_ctx_t *, const uint64_t *, const int32_t *, int64_t, const int32_t *, int32_t, double, int32_t, int32_t, int32_t, int32_t **, int64_t *);
 	int  (*branch_decide)(pga_ctx_t *, double, double, double, uint8_t *, int32_t *, int64_t *, int64_t *);
-	int  (*mark_hits)(pga_ctx_t *, const uint64_t *, const uint8_t *, int64_t, int64_t *);
+	int  (*mark_hits)(pga_ctx_t *, const uint64_t *, const uint8_t *, int64_t, int64_t *, int32_t);
 	int  (*override_order)(pga_ctx_t *, int32_t, int32_t, const int32_t *, const int32_t *, const int64_t *, const int32_t *);
 	int  (*set_head)(pga_ctx_t *, const int32_t *);
 	int  (*fetch)(pga_ctx_t *, void *, const void *, size_t);
@@ -283,9 +289,10 @@ typedef struct {
 	int  (*hazard_segs)(pga_ctx_t *, int32_t *, int32_t, int64_t *);
 	int  (*host_alloc)(size_t, void **);
 	void (*host_free)(void *);
-	int  (*arc_round_local)(pga_ctx_t *, int32_t, int32_t, int32_t *, int32_t *, const pga_arc_part_t **, int64_t *);
+	int  (*arc_round_local)(pga_ctx_t *, int32_t, int32_t, int32_t *, int32_t *);
 	int  (*ctg_counts)(pga_ctx_t *, int32_t *);
 	int  (*gene_matrix)(pga_ctx_t *, const int32_t *, int32_t, int32_t, int32_t *);
+	int  (*arc_table)(pga_ctx_t *, const pga_arc_part_t **, int64_t *);
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);

@@ -54,6 +54,7 @@ struct pga_ctx {
 	void *scratch; size_t m_scratch;
 	/* branch state kept between branch_pairs and branch_decide / mark_hits */
 	uint64_t *br_x; int32_t *br_s1, *br_gid, *br_pairs; uint8_t *br_weak; int64_t br_n, br_np; int32_t br_S;
+	const pga_arc_part_t *cur_tab; int64_t cur_tab_n; /* the table of arc_set_current */
 	int64_t *head;            /* [n_genome] X position of the hit that plays "index 0" (never reset by pg_shadow) */
 	/* raw shard, file order (kept so that begin() can restart the run) */
 	int32_t *r_pid, *r_cid, *r_rank, *r_sori, *r_sadj, *r_nex, *r_offx, *r_cs, *r_ce, *r_cm; uint8_t *r_rev;
@@ -561,7 +562,7 @@ int pgo_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records, int64_t *n
 }
 
 /* pg_graph_flag_vtx, graph.c:61-69 */
-int pgo_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg)
+int pgo_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg, int32_t then_filter)
 {
 	int64_t i;
 	memcpy(c->g2s, g2s, c->n_gene * sizeof(int32_t));
@@ -570,7 +571,7 @@ int pgo_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg)
 		if (g2s[c->gid[i]] >= 0) c->flags[i] |= PGA_F_VTX;
 		else c->flags[i] &= ~PGA_F_VTX;
 	}
-	return PGA_OK;
+	return then_filter ? pgo_set_filter(c, PGA_FLT_VTX0) : PGA_OK;
 }
 
 typedef struct { uint64_t x; int32_t n, dist, s1, s2; } tmparc_t;
@@ -816,15 +817,17 @@ int pgo_arc_set_current(pga_ctx_t *c, const pga_arc_part_t *arcs, int64_t n_arc,
 		deg[arcs[i].x >> 32]++;
 	}
 	c->br_n = n_arc, c->br_S = n_seg;
+	c->cur_tab = arcs, c->cur_tab_n = n_arc;
 	free(seg_gid);
 	return PGA_OK;
 }
 
-int pgo_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt, int32_t *deg, const pga_arc_part_t **arcs_out, int64_t *n_arc)
+int pgo_arc_table(pga_ctx_t *c, const pga_arc_part_t **arcs, int64_t *n_arc) { *arcs = c->cur_tab, *n_arc = c->cur_tab_n; return PGA_OK; }
+
+int pgo_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt, int32_t *deg)
 {
-	int32_t *sc; pga_arc_part_t *arcs;
+	int32_t *sc; pga_arc_part_t *arcs; int64_t n = 0, *n_arc = &n;
 	int rc = pgo_arc_round(c, use_ori, &sc, &arcs, n_arc);
-	*arcs_out = arcs;
 	if (rc != PGA_OK) return rc;
 	if (n_seg != c->n_seg) return PGA_ERR_ARG;
 	memcpy(seg_cnt, sc, 2 * (size_t)n_seg * sizeof(int32_t));
@@ -859,7 +862,7 @@ int pgo_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32_t *arc_s1,
 	}
 	c->br_np = np;
 	rc = pgo_n_local(c, c->br_pairs, np, local_dist, local_count, frag_mode, cnt);
-	*n_pairs = np;
+	if (n_pairs) *n_pairs = np;
 	return rc;
 }
 
@@ -891,7 +894,7 @@ static int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x
 }
 
 /* pg_mark_branch_flt_hit, branch.c:108-145 */
-int pgo_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_w, int64_t n_arc, int64_t *n_marked)
+int pgo_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_w, int64_t n_arc, int64_t *n_marked, int32_t then_filter)
 {
 	int32_t j;
 	int64_t k, n = 0;
@@ -921,7 +924,7 @@ int pgo_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_w, int
 			if (c->flags[k] & PGA_F_WEAK_MASK) ++n;
 	}
 	if (n_marked) *n_marked = n;
-	return PGA_OK;
+	return then_filter ? pgo_set_filter(c, PGA_FLT_WEAK2) : PGA_OK;
 }
 
 /* exact-order override (see pangene_hip.h): re-permute one contig segment of the X-ordered arrays, or
@@ -1058,7 +1061,7 @@ const pga_backend_t *pgo_backend(void)
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
 		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_arc_merge, pgo_arc_set_current, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
-		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs, pgo_host_alloc, pgo_host_free, pgo_arc_round_local, pgo_ctg_counts, pgo_gene_matrix
+		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs, pgo_host_alloc, pgo_host_free, pgo_arc_round_local, pgo_ctg_counts, pgo_gene_matrix, pgo_arc_table
 	};
 	return &b;
 }

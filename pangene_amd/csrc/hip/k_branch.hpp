@@ -53,25 +53,32 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a, const int32_t *cm
 	if (t < a.Q && a.zoff[t] == a.zoff[t + 1]) rep_absent<COMPACT>(a, (int64_t)t * a.GL, a.GL); // a gene without hits in this shard
 	if (t >= a.N) return;
 	const int z = t;
-	const int4 zr = a.zrec[z];
-	const int g = zr.z, j = zr.y >> 1, z0 = a.zoff[g], z1 = a.zoff[g + 1];
-	if (z + 1 < z1 && (a.zrec[z + 1].y >> 1) == j) return; // not the last hit of its (gene, genome) group
+	// the loads are issued in as few dependent rounds as possible (the kernel is latency bound): round 1 = the three records around z
+	const int4 zr = a.zrec[z], zn = z + 1 < a.N ? a.zrec[z + 1] : make_int4(0, -2, -1, 0), zp = z > 0 ? a.zrec[z - 1] : make_int4(0, -2, -1, 0);
+	const int4 hbz = a.hb[z];
+	const int g = zr.z, j = zr.y >> 1;
+	if (zn.z == g && (zn.y >> 1) == j) return; // not the last hit of its (gene, genome) group
+	// round 2: everything that hangs on the gene, the genome or the hit itself
+	const int z0 = a.zoff[g], gj = a.goff[j], rx0 = a.rx[gj], cb = a.ctg_base[j];
+	const int rx_z = a.rx[zr.x], cm_z = cm[zr.x];
+	const int4 a_z = a.A[zr.x];
 	const int64_t e = (int64_t)g * a.GL + j;
 	// the genomes without a hit of this gene: before the first group, and between this group and the next
 	int gs = z;
-	while (gs > z0 && (a.zrec[gs - 1].y >> 1) == j) --gs;
+	if (zp.z == g && (zp.y >> 1) == j) { gs = z - 1; while (gs > z0 && (a.zrec[gs - 1].y >> 1) == j) --gs; }
 	if (gs == z0 && j > 0) rep_absent<COMPACT>(a, (int64_t)g * a.GL, j);
-	const int jn = z + 1 < z1 ? (a.zrec[z + 1].y >> 1) : a.GL;
+	const int jn = zn.z == g ? (zn.y >> 1) : a.GL;
 	if (jn > j + 1) rep_absent<COMPACT>(a, e + 1, jn - j - 1);
 	int q = z;
-	while (q >= gs && !ha_walk(a.hb[q], a.tag)) --q; // the group's last walkable hit
+	if (!ha_walk(hbz, a.tag)) { q = z - 1; while (q >= gs && !ha_walk(a.hb[q], a.tag)) --q; } // the group's last walkable hit
 	if (q < gs) { rep_absent<COMPACT>(a, e, 1); return; }
-	const int h = a.zrec[q].x;
-	const int rxh = a.rx[h], r = (rxh & 0x7fffffff) - (a.rx[a.goff[j]] & 0x7fffffff);
-	const int4 ah = a.A[h]; // {cs, seg, ce, pm}
+	const int h = q == z ? zr.x : a.zrec[q].x;
+	const int rxh = q == z ? rx_z : a.rx[h], r = (rxh & 0x7fffffff) - (rx0 & 0x7fffffff);
+	const int4 ah = q == z ? a_z : a.A[h]; // {cs, seg, ce, pm}
+	const int cmh = q == z ? cm_z : cm[h];
 	int ivl = 0;
 	if (rxh < 0) { // member of a static tie group [ta, tb): its walkable members on either side, from the walkable ranks at the group's ends
-		const int lo = a.goff[j], hi = a.goff[j + 1];
+		const int lo = gj, hi = a.goff[j + 1];
 		int ta = h, tb = h + 1;
 		while (ta > lo) { const int4 ap = a.A[ta - 1]; if (ap.y != ah.y || ap.x != ah.x) break; --ta; }
 		while (tb < hi) { const int4 ap = a.A[tb]; if (ap.y != ah.y || ap.x != ah.x) break; ++tb; }
@@ -86,9 +93,9 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a, const int32_t *cm
 			} else ivl = nb << 16 | na;
 		}
 	}
-	const int cmw = cm[h] | (ivl ? (int)0x80000000 : 0);
+	const int cmw = cmh | (ivl ? (int)0x80000000 : 0);
 	if (COMPACT) {
-		((int2 *)a.rp_out)[e] = make_int2(cmw, (ah.y - a.ctg_base[j]) << 20 | r);
+		((int2 *)a.rp_out)[e] = make_int2(cmw, (ah.y - cb) << 20 | r);
 		if (ivl) a.iv[e] = ivl;
 	} else ((int4 *)a.rp_out)[e] = make_int4(ah.y, r, cmw, ivl);
 }
@@ -116,48 +123,52 @@ __device__ __noinline__ bool nl_hazard(const NLocalHz &z, int cc, int iv1, int i
 constexpr int NL_PAIRS = 4, NL_LANES = 16;
 
 template <bool COMPACT>
-__global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_pair, int GL, const void *rp_in,
+__global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_cap, const int64_t *np_dev, int GL, const void *rp_in,
                                                      int local_dist, int local_count, int frag_mode, int32_t *cnt, NLocalHz hz)
 {
 	const int lane = threadIdx.x & 63, grp = lane >> 4, sub = lane & (NL_LANES - 1);
-	const int64_t k = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * NL_PAIRS + grp;
-	const bool have = k < n_pair;
-	const int64_t kk = have ? k : n_pair - 1;
-	if (n_pair <= 0) return;
-	const int64_t g1 = (int64_t)pairs[2 * kk] * GL, g2 = (int64_t)pairs[2 * kk + 1] * GL;
-	int c = 0;
-	bool open = have; // still searching (uniform over the sixteen lanes of the pair)
-	for (int j0 = 0; j0 < GL; j0 += NL_LANES) {
-		if (__ballot(open) == 0) break;
-		const int j = j0 + sub;
-		const bool in = open && j < GL;
-		const int jj = j < GL ? j : 0;
-		bool hit = false, sure = false;
-		if (COMPACT) {
-			const int2 a = ((const int2 *)rp_in)[g1 + jj], b = ((const int2 *)rp_in)[g2 + jj];
-			const int d = (a.x & 0x7fffffff) - (b.x & 0x7fffffff); // cm < 2^31: the difference fits
-			const int cc = (a.y & 0xfffff) - (b.y & 0xfffff);
-			const bool cmp = in && (a.y | b.y) >= 0 && (frag_mode || ((a.y ^ b.y) >> 20) == 0);
-			const bool near = d >= -local_dist && d <= local_dist;
-			hit = cmp && (near || (cc >= -local_count && cc <= local_count));
-			sure = hit;
-			if (cmp && !near && (a.x | b.x) < 0) // rare: an r of the pair depends on the tie order (H2b)
-				sure = nl_hazard(hz, cc, a.x < 0 ? hz.iv[g1 + jj] : 0, b.x < 0 ? hz.iv[g2 + jj] : 0, hz.ctg_base[jj] + (a.y >> 20), hz.ctg_base[jj] + (b.y >> 20), local_count) && hit;
-		} else {
-			const int4 a = ((const int4 *)rp_in)[g1 + jj], b = ((const int4 *)rp_in)[g2 + jj];
-			const int d = (a.z & 0x7fffffff) - (b.z & 0x7fffffff);
-			const int cc = a.y - b.y;
-			const bool cmp = in && a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x);
-			const bool near = d >= -local_dist && d <= local_dist;
-			hit = cmp && (near || (cc >= -local_count && cc <= local_count));
-			sure = hit;
-			if (cmp && !near && (a.z | b.z) < 0) sure = nl_hazard(hz, cc, a.w, b.w, a.x, b.x, local_count) && hit;
+	int64_t n_pair = np_dev ? *np_dev : n_cap; // the count may still be on its way to the host: it is read here
+	if (n_pair > n_cap) n_pair = n_cap;        // (pairs beyond the capacity were not listed; the host repeats the round with room)
+	const int64_t stride = (int64_t)gridDim.x * (BLOCK / WAVE) * NL_PAIRS;
+	for (int64_t k0 = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * NL_PAIRS; k0 < n_pair; k0 += stride) {
+		const int64_t k = k0 + grp;
+		const bool have = k < n_pair;
+		const int64_t kk = have ? k : n_pair - 1;
+		const int64_t g1 = (int64_t)pairs[2 * kk] * GL, g2 = (int64_t)pairs[2 * kk + 1] * GL;
+		int c = 0;
+		bool open = have; // still searching (uniform over the sixteen lanes of the pair)
+		for (int j0 = 0; j0 < GL; j0 += NL_LANES) {
+			if (__ballot(open) == 0) break;
+			const int j = j0 + sub;
+			const bool in = open && j < GL;
+			const int jj = j < GL ? j : 0;
+			bool hit = false, sure = false;
+			if (COMPACT) {
+				const int2 a = ((const int2 *)rp_in)[g1 + jj], b = ((const int2 *)rp_in)[g2 + jj];
+				const int d = (a.x & 0x7fffffff) - (b.x & 0x7fffffff); // cm < 2^31: the difference fits
+				const int cc = (a.y & 0xfffff) - (b.y & 0xfffff);
+				const bool cmp = in && (a.y | b.y) >= 0 && (frag_mode || ((a.y ^ b.y) >> 20) == 0);
+				const bool near = d >= -local_dist && d <= local_dist;
+				hit = cmp && (near || (cc >= -local_count && cc <= local_count));
+				sure = hit;
+				if (cmp && !near && (a.x | b.x) < 0) // rare: an r of the pair depends on the tie order (H2b)
+					sure = nl_hazard(hz, cc, a.x < 0 ? hz.iv[g1 + jj] : 0, b.x < 0 ? hz.iv[g2 + jj] : 0, hz.ctg_base[jj] + (a.y >> 20), hz.ctg_base[jj] + (b.y >> 20), local_count) && hit;
+			} else {
+				const int4 a = ((const int4 *)rp_in)[g1 + jj], b = ((const int4 *)rp_in)[g2 + jj];
+				const int d = (a.z & 0x7fffffff) - (b.z & 0x7fffffff);
+				const int cc = a.y - b.y;
+				const bool cmp = in && a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x);
+				const bool near = d >= -local_dist && d <= local_dist;
+				hit = cmp && (near || (cc >= -local_count && cc <= local_count));
+				sure = hit;
+				if (cmp && !near && (a.z | b.z) < 0) sure = nl_hazard(hz, cc, a.w, b.w, a.x, b.x, local_count) && hit;
+			}
+			const unsigned long long mh = __ballot(hit), ms = __ballot(sure);
+			c += __popcll((mh >> (grp * NL_LANES)) & 0xffffull);
+			if ((ms >> (grp * NL_LANES)) & 0xffffull) open = false;
 		}
-		const unsigned long long mh = __ballot(hit), ms = __ballot(sure);
-		c += __popcll((mh >> (grp * NL_LANES)) & 0xffffull);
-		if ((ms >> (grp * NL_LANES)) & 0xffffull) open = false;
+		if (have && sub == 0) cnt[k] = c;
 	}
-	if (have && sub == 0) cnt[k] = c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,6 +247,7 @@ __device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *a
 		}
 		if (MODE == 2) {
 			weak[a0 + i] = ((n_local == 0 && r > bdist) || r > bcut) ? 2 : 1;
+			if (dcnt) atomicAdd((unsigned long long *)&dcnt[weak[a0 + i] - 1], 1ull);
 		}
 	}
 	int n_group = 0;
@@ -255,16 +267,22 @@ __device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *a
 // (coalesced stores, MODE 1) or the all-reduced counts (coalesced loads, MODE 2).
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
-                                                     const int32_t *poff, int32_t *pairs, const int32_t *cnt, double bdist, double bcut,
+                                                     const int32_t *poff, int32_t *pairs, int64_t pair_cap /* MODE 1: room in pairs[] */, const int32_t *pcnt /* MODE 1: pairs of each vertex */, const int32_t *cnt, double bdist, double bcut,
                                                      uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, uint8_t *vwk /* MODE 2: vertex has a weak arc */)
 {
 	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (v >= n_vtx) return;
 	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2) return;
+	if (n < 2) { if (MODE == 2 && lane == 0) ndl[v] = 0; return; } // (every n_dist_loci entry is written: nothing to clear beforehand)
 	const int64_t k0 = poff[v];
+	if (MODE == 1 && k0 + pcnt[v] > pair_cap) return; // would run past the list: left out -- the total then exceeds the capacity too, the host sees that and repeats the round with room
 	if (n > WAVE) {
-		if (lane == 0) { int32_t g = 0; br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt); if (MODE == 2) ndl[v] = g, vwk[v] = 1; }
+		if (lane == 0) {
+			int32_t g = 0;
+			if (MODE == 2) for (int i = 0; i < n; ++i) grpg[a0 + i] = 0;
+			br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt);
+			if (MODE == 2) ndl[v] = g, vwk[v] = 1;
+		}
 		return;
 	}
 	const bool in = lane < n;
@@ -286,7 +304,9 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 		else {
 			const bool none_local = __ballot(is_max && cnt[k] != 0) == 0; // the counts are >= 0: their sum is 0 iff all are
 			if (lane == i) {
-				weak[a0 + i] = ((none_local && r > bdist) || r > bcut) ? 2 : 1;
+				const int wk = ((none_local && r > bdist) || r > bcut) ? 2 : 1;
+				weak[a0 + i] = (uint8_t)wk;
+				if (dcnt) atomicAdd((unsigned long long *)&dcnt[wk - 1], 1ull); // log only
 			}
 		}
 	}

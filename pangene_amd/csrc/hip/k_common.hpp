@@ -42,6 +42,22 @@ __global__ void k_mail_runs(const uint64_t *key, const int32_t *slot, int64_t m,
 	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
 }
 
+// the number of gene pairs of a branch round (dcnt[15] = a[0] + b[0]) for kernels and host alike
+__global__ void k_mail_pairs(const int32_t *a, const int32_t *b, int64_t *dcnt, int64_t *host_box)
+{
+	if (threadIdx.x == 0) dcnt[15] = (int64_t)a[0] + b[0];
+	__syncthreads();
+	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
+}
+
+// end of an arc round on the gene-major index: the counters for the host, then the round's overflow counter starts again
+__global__ void k_mail_round(int64_t *dcnt, int64_t *host_box)
+{
+	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
+	__syncthreads();
+	if (threadIdx.x == 0) dcnt[9] = 0;
+}
+
 __global__ void k_mail_flush(const int64_t *dcnt, int64_t *host_box)
 {
 	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];

@@ -12,8 +12,11 @@
 //       (graph.c:128-145; genomes are contiguous inside a gene), sums over the genomes in an LDS hash table keyed by
 //       (orientation, target) (graph.c:153-169: integer sums, order-free), sorts the few entries and writes the gene's arcs;
 //       it also counts the gene's walkable hits and genomes (graph.c:125-126) -- no global atomics except one per gene;
-//   (C) a scan over the segments places every gene's arcs: the table comes out sorted by x = v << 32 | w because
-//       segments are numbered in gene order (vertex.c:85-94).
+//   (C) the arcs of gene g stay where the workgroup put them -- its own stretch [2 zoff[g], ...) of the table arrays, sorted by
+//       target -- and the per-vertex ranges vs[] / ve[] point there: the steps that read the table (branch marking, hit marking,
+//       the degree filter) go through those ranges, so the table need not be contiguous.  Only when somebody wants it as ONE
+//       array sorted by x = v << 32 | w (the exchange of a sharded run, the host after the last round) do a scan over the segments
+//       and a copy compact it: segments are numbered in gene order (vertex.c:85-94), so the stretches are already in x order.
 // pg_mark_branch_flt_hit then needs no walk at all: every hit looks its own two half-arcs up in the arc lists of its own
 // gene's vertices and raises its own weak_br.
 #pragma once
@@ -35,7 +38,10 @@ __global__ __launch_bounds__(BLOCK) void k_zrec(const uint32_t *perm, const uint
 	int z = blockIdx.x * BLOCK + threadIdx.x;
 	if (z >= n) return;
 	const int x = (int)perm[z];
-	zrec[z] = make_int4(x, gnm[x] << 1 | ((flags[x] & PGA_F_REV) ? 1 : 0), (int)ks[z], 0);
+	// w: 1 = the only hit of its gene in its genome (nearly all are): the group logic of k_gene_arcs has nothing to do for it
+	const int gn = gnm[x];
+	const bool grp_prev = z > 0 && ks[z - 1] == ks[z] && gnm[(int)perm[z - 1]] == gn, grp_next = z + 1 < n && ks[z + 1] == ks[z] && gnm[(int)perm[z + 1]] == gn;
+	zrec[z] = make_int4(x, gn << 1 | ((flags[x] & PGA_F_REV) ? 1 : 0), (int)ks[z], (grp_prev || grp_next) ? 0 : 1);
 	zpos[x] = z;
 }
 
@@ -58,25 +64,24 @@ __global__ __launch_bounds__(BLOCK) void k_zpos_y(const int32_t *yperm, const in
 // (A) output step of the walk scan (cm order): previous walkable hit -> half-arc records
 // ------------------------------------------------------------------------------------------------
 struct OutHalfArcs {
-	const int4 *YA, *YB; const int32_t *zposy, *g2s; int4 *hf, *hb; uint32_t tag; int ori; int64_t *dcnt; int32_t *hz_list;
+	const int4 *__restrict__ YA, *__restrict__ YB; const int32_t *__restrict__ zposy, *__restrict__ g2s; int4 *__restrict__ hf, *__restrict__ hb; uint32_t tag; int ori; int64_t *dcnt; int32_t *hz_list;
 	__device__ __forceinline__ void operator()(int64_t i, I32 incl, I32 ex) const
 	{
 		if (incl.v == ex.v) return; // not walkable (graph.c:108)
-		const int p = ex.v;
-		const int4 aA = YA[i]; // {seg, gid, genome, cm}
+		const int p = ex.v, pp = p >= 0 ? p : (int)i;
+		const int4 aA = YA[i], aB = YB[i], bA = YA[pp], bB = YB[pp]; // {seg, gid, genome, cm}, {score_ori, score_dom, gene of pid_dom0, X position << 1 | rev}: one round of loads
+		const int zi = zposy[i], zp = zposy[pp];
 		int4 rec = make_int4((int)(tag << HA_TAG_SHIFT | HA_NONE), 0, 0, 0);
 		if (p >= 0) {
-			const int4 bA = YA[p];
 			if (bA.x == aA.x) { // same contig: adjacency p -> i (graph.c:113-121)
-				const int4 aB = YB[i], bB = YB[p];
 				const uint32_t w = (uint32_t)aA.y << 1 | (uint32_t)(aB.w & 1), v = (uint32_t)bA.y << 1 | (uint32_t)(bB.w & 1);
 				const int sa = arc_score(aB, ori, g2s), sb = arc_score(bB, ori, g2s), d = aA.w - bA.w;
 				if (aA.w == bA.w) { atomicAdd((unsigned long long *)&dcnt[5], 1ull); hz_note(&dcnt[14], hz_list, aA.x); } // hazard H2a: equal cm
-				hf[zposy[p]] = make_int4((int)(tag << HA_TAG_SHIFT | w), d, sb, sa);       // v -> w,       s1 = score(v), s2 = score(w) (graph.c:117)
+				hf[zp] = make_int4((int)(tag << HA_TAG_SHIFT | w), d, sb, sa);       // v -> w,       s1 = score(v), s2 = score(w) (graph.c:117)
 				rec = make_int4((int)(tag << HA_TAG_SHIFT | (v ^ 1u)), d, sa, sb);          // w^1 -> v^1,   s1 = score(w), s2 = score(v) (graph.c:119)
 			}
 		}
-		hb[zposy[i]] = rec;
+		hb[zi] = rec;
 	}
 };
 
@@ -89,11 +94,15 @@ constexpr int GA_BIG_STAGE = 2048;             // hits the workgroup kernel stag
 
 struct GeneArcs {
 	const int4 *zrec; const int32_t *zoff; const int4 *hf, *hb; const int32_t *g2s;
+	int dbg; // tuning aid (PGA_GENE_DEBUG): 1 skip the table insertion, 2 skip the payload loads, 4 skip the output, 8 skip the group logic
 	int Q, S; uint32_t tag; int cap_log2; // table size actually used (<= GA_CAP; tests shrink it to reach the overflow paths)
 	int32_t *seg_cnt, *seg_gid;       // [2S] n_genome then tot_cnt (graph.c:125-126); [S] gene of each segment
-	pga_arc_part_t *stage; int32_t *stage_sid; int4 *gmeta; // (stage_sid: segment of every staged arc)  arcs of a gene at stage[gmeta.x ...): gmeta = {base, #arcs leaving (sid, +), #arcs leaving (sid, -), 0}
-	int32_t *big_list;                  // genes left to the workgroup kernel (dcnt[11] counts them)
-	int64_t *dcnt;                      // [3] invariant, [8] staged arcs, [9] genes that overflowed GA_CAP, [11] big_list entries
+	pga_arc_part_t *stage; int4 *gmeta; // arcs of a gene at stage[gmeta.x ...): gmeta = {base, #arcs leaving (sid, +), #arcs leaving (sid, -), 0}
+	// what the branch steps read, at the same (sparse) positions: x, rounded s1 (graph.c:171), target gene, weak_br = 0; per oriented vertex its range, degree, "has a weak arc" = 0
+	uint64_t *ax; int32_t *s1, *agid; uint8_t *aw; int32_t *vs, *ve, *deg; uint8_t *vwk;
+	int32_t *h_round;                   // pinned host memory (or NULL): seg_cnt[2S] then deg[2S] for the host, written straight from here
+	int32_t *big_list;                  // [Q] 1 = the gene is left to the workgroup kernel
+	int64_t *dcnt;                      // [3] invariant, [9] genes that overflowed GA_CAP
 };
 
 
@@ -108,7 +117,7 @@ template <int CAP, int STAGE> struct GeneTable {
 // window (groups that straddle a window border: rare) the same words come from global memory.
 template <int CAP, int STAGE> struct GeneWin {
 	const GeneArcs &a; const GeneTable<CAP, STAGE> &T; int lo, hi;
-	__device__ __forceinline__ int zy(int z) const { return (z >= lo && z < hi) ? T.zy[z - lo] : a.zrec[z].y; }
+	__device__ __forceinline__ int zy(int z) const { return (z >= lo && z < hi) ? (T.zy[z - lo] & 0x7fffffff) : a.zrec[z].y; }
 	__device__ __forceinline__ uint32_t fx(int z) const { return (z >= lo && z < hi) ? T.fx[z - lo] : (uint32_t)a.hf[z].x; }
 	__device__ __forceinline__ uint32_t bx(int z) const { return (z >= lo && z < hi) ? T.bx[z - lo] : (uint32_t)a.hb[z].x; }
 };
@@ -123,23 +132,25 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 	const int z0 = a.zoff[g], z1 = a.zoff[g + 1], cap = 1 << cap_log2;
 	for (int k = tid; k < cap; k += NT) T.key[k] = 0xffffffffu, T.ng[k] = 0, T.tot[k] = 0, T.sd[k] = 0, T.s1[k] = 0, T.s2[k] = 0;
 	if (tid == 0) T.n_tot = 0, T.n_gen = 0, T.over = 0, T.m = 0, T.m0 = 0;
+	int n_tot = 0, n_gen = 0; // this thread's walkable hits / genomes it counted (graph.c:125-126)
 	for (int c0 = z0; c0 < z1; c0 += STAGE - 2 * HALO) {
 		const int c1 = c0 + (STAGE - 2 * HALO) < z1 ? c0 + (STAGE - 2 * HALO) : z1;
 		GeneWin<CAP, STAGE> W = { a, T, c0 - HALO > z0 ? c0 - HALO : z0, c1 + HALO < z1 ? c1 + HALO : z1 };
 		if (NT == 64) wave_sync(); else __syncthreads(); // the previous window is done with (and the table is clear)
-		for (int z = W.lo + tid; z < W.hi; z += NT) T.zy[z - W.lo] = a.zrec[z].y, T.fx[z - W.lo] = (uint32_t)a.hf[z].x, T.bx[z - W.lo] = (uint32_t)a.hb[z].x;
+		for (int z = W.lo + tid; z < W.hi; z += NT) { const int4 zr = a.zrec[z]; T.zy[z - W.lo] = zr.y | (zr.w ? (int)0x80000000 : 0), T.fx[z - W.lo] = (uint32_t)a.hf[z].x, T.bx[z - W.lo] = (uint32_t)a.hb[z].x; } // bit 31: singleton group
 		if (NT == 64) wave_sync(); else __syncthreads();
 		for (int z = c0 + tid; z < c1; z += NT) {
 			if (!hx_walk(T.bx[z - W.lo], a.tag)) continue;
-			const int zy = T.zy[z - W.lo], genome = zy >> 1, rev = zy & 1;
-			// the hits of this gene in this genome: [gs, ge) around z (one or two as a rule)
+			const int zyw = T.zy[z - W.lo], zy = zyw & 0x7fffffff, genome = zy >> 1, rev = zy & 1;
+			// the hits of this gene in this genome: [gs, ge) around z -- z alone as a rule (static mark), then nothing to look at
 			int gs = z, ge = z + 1;
-			while (gs > z0 && (W.zy(gs - 1) >> 1) == genome) --gs;
-			while (ge < z1 && (W.zy(ge) >> 1) == genome) ++ge;
 			bool first = true; // first walkable hit of the group: it counts the genome (graph.c:125)
-			for (int q = gs; q < z; ++q) first = first && !hx_walk(W.bx(q), a.tag);
-			atomicAdd(&T.n_tot, 1);
-			if (first) atomicAdd(&T.n_gen, 1);
+			if (zyw >= 0) {
+				while (gs > z0 && (W.zy(gs - 1) >> 1) == genome) --gs;
+				while (ge < z1 && (W.zy(ge) >> 1) == genome) ++ge;
+				for (int q = gs; q < z; ++q) first = first && !hx_walk(W.bx(q), a.tag);
+			}
+			n_tot += 1, n_gen += first ? 1 : 0;
 #pragma unroll
 			for (int dir = 0; dir < 2; ++dir) {
 				const uint32_t hx = dir ? T.bx[z - W.lo] : T.fx[z - W.lo];
@@ -149,7 +160,7 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 				// (the two half-arcs of one hit never share a key: their orientation bits differ)
 				bool leader = true;
 				int n = 1;
-				for (int q = gs; q < ge && leader && ge - gs > 1; ++q) {
+				for (int q = gs; q < ge && leader && ge - gs > 1 && !(a.dbg & 8); ++q) {
 					if (q == z) continue;
 					const int rq = W.zy(q) & 1;
 #pragma unroll
@@ -161,7 +172,7 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 					}
 				}
 				if (!leader) continue;
-				const int4 h = dir ? a.hb[z] : a.hf[z]; // the payload: distance and the two scores
+				const int4 h = (a.dbg & 2) ? make_int4(0, 5, 6, 7) : dir ? a.hb[z] : a.hf[z]; // the payload: distance and the two scores
 				int m1 = h.z, m2 = h.w;
 				unsigned long long sd = (unsigned long long)(long long)h.y;
 				if (n > 1) // rare: the same adjacency twice in one genome
@@ -177,6 +188,7 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 					}
 				m1 = m1 > 0 ? m1 : 0, m2 = m2 > 0 ? m2 : 0; // the reference's running maxima start at 0 (graph.c:133)
 				const int dg = (int32_t)((double)(long long)sd / n + .499); // graph.c:141
+				if (a.dbg & 1) continue;
 				// level 2 (graph.c:153-169): sums over the genomes, LDS table keyed by (orientation, target)
 				uint32_t slot = (key * 2654435761u) >> (32 - cap_log2);
 				int probes = 0;
@@ -191,6 +203,10 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 			}
 		}
 	}
+	{ // one LDS atomic per wave, not per hit
+		const int wt = wave_sum(n_tot), wg = wave_sum(n_gen);
+		if ((tid & 63) == 0) { if (NT == 64) T.n_tot = wt, T.n_gen = wg; else atomicAdd(&T.n_tot, wt), atomicAdd(&T.n_gen, wg); }
+	}
 	if (NT == 64) wave_sync(); else __syncthreads();
 	if (T.over) return false;
 	for (int k = tid; k < cap; k += NT)
@@ -198,12 +214,20 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 	if (NT == 64) wave_sync(); else __syncthreads();
 	const int m = T.m;
 	if (tid == 0) {
-		T.base = m ? (int)atomicAdd((unsigned long long *)&a.dcnt[8], (unsigned long long)m) : 0;
+		const int b = 2 * z0, m0 = T.m0; // the gene's own stretch of the table: it has at most two half-arcs per hit (no allocation, no atomic)
+		T.base = b;
 		a.seg_cnt[sid] = T.n_gen, a.seg_cnt[a.S + sid] = T.n_tot, a.seg_gid[sid] = g;
-		a.gmeta[sid] = make_int4(T.base, T.m0, m - T.m0, 0);
+		a.gmeta[sid] = make_int4(b, m0, m - m0, 0);
+		a.vs[2 * sid] = b, a.ve[2 * sid] = b + m0, a.vs[2 * sid + 1] = b + m0, a.ve[2 * sid + 1] = b + m;
+		a.deg[2 * sid] = m0, a.deg[2 * sid + 1] = m - m0;
+		a.vwk[2 * sid] = 0, a.vwk[2 * sid + 1] = 0;
+		if (a.h_round) {
+			a.h_round[sid] = T.n_gen, a.h_round[a.S + sid] = T.n_tot;
+			a.h_round[2 * a.S + 2 * sid] = m0, a.h_round[2 * a.S + 2 * sid + 1] = m - m0;
+		}
 	}
 	if (NT == 64) wave_sync(); else __syncthreads();
-	for (int e = tid; e < m; e += NT) { // rank among the gene's entries = place in the table (keys are distinct)
+	for (int e = tid; e < m && !(a.dbg & 4); e += NT) { // rank among the gene's entries = place in its stretch (keys are distinct)
 		const int k = T.dense[e];
 		const uint32_t key = T.key[k];
 		int r = 0;
@@ -212,8 +236,12 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 		const uint32_t t = key & HA_NONE;
 		o.x = (uint64_t)((uint32_t)sid << 1 | (key >> HA_TAG_SHIFT)) << 32 | (uint32_t)((uint32_t)a.g2s[t >> 1] << 1 | (t & 1u));
 		o.n_genome = T.ng[k], o.tot_cnt = T.tot[k], o.sum_dist = T.sd[k], o.sum_s1 = (int64_t)T.s1[k], o.sum_s2 = (int64_t)T.s2[k];
-		a.stage[T.base + r] = o;
-		a.stage_sid[T.base + r] = sid;
+		const int at = T.base + r;
+		a.stage[at] = o;
+		a.ax[at] = o.x;
+		a.s1[at] = (int32_t)((double)o.sum_s1 / o.n_genome + .499); // graph.c:171
+		a.agid[at] = (int32_t)(t >> 1);
+		a.aw[at] = 0;
 	}
 	return true;
 }
@@ -228,21 +256,22 @@ __global__ __launch_bounds__(BLOCK) void k_gene_arcs_wave(GeneArcs a)
 	if (sid < 0) { // not a vertex: none of its hits may be walkable (graph.c:111)
 		for (int z = z0 + lane; z < z1; z += WAVE)
 			if (ha_walk(a.hb[z], a.tag)) atomicAdd((unsigned long long *)&a.dcnt[3], 1ull);
+		if (lane == 0) a.big_list[g] = 0;
 		return;
 	}
 	const int cl = a.cap_log2 < 7 ? a.cap_log2 : 7;
-	if (z1 - z0 <= GA_WAVE_HITS && gene_arcs_one<WAVE, GA_CAP_WAVE, GA_WAVE_HITS>(a, T[w], g, sid, lane, cl)) return;
-	if (lane == 0) a.big_list[atomicAdd((unsigned long long *)&a.dcnt[11], 1ull)] = g; // many hits, or many neighbours: the workgroup kernel takes it
+	if (z1 - z0 <= GA_WAVE_HITS && gene_arcs_one<WAVE, GA_CAP_WAVE, GA_WAVE_HITS>(a, T[w], g, sid, lane, cl)) { if (lane == 0) a.big_list[g] = 0; return; }
+	if (lane == 0) a.big_list[g] = 1; // many hits, or many neighbours: the workgroup kernel takes it
 }
 
 __global__ __launch_bounds__(BLOCK) void k_gene_arcs_big(GeneArcs a)
 {
 	__shared__ GeneTable<GA_CAP, GA_BIG_STAGE> T;
-	const int n_big = (int)a.dcnt[11];
-	for (int i = blockIdx.x; i < n_big; i += gridDim.x) {
-		const int g = a.big_list[i], sid = a.g2s[g];
+	for (int g = blockIdx.x; g < a.Q; g += gridDim.x) { // the genes the wave kernel left (a flag per gene: no list, no counter)
+		if (!a.big_list[g]) continue;
+		const int sid = a.g2s[g];
 		if (!gene_arcs_one<BLOCK, GA_CAP, GA_BIG_STAGE>(a, T, g, sid, threadIdx.x, a.cap_log2) && threadIdx.x == 0) // a hub gene: this round is redone on the sort path
-			atomicAdd((unsigned long long *)&a.dcnt[9], 1ull), a.gmeta[sid] = make_int4(0, 0, 0, 0);
+			atomicAdd((unsigned long long *)&a.dcnt[9], 1ull), a.gmeta[sid] = make_int4(0, 0, 0, 0); // (the whole round is repeated: nothing else to leave behind)
 		__syncthreads();
 	}
 }
@@ -252,42 +281,19 @@ __global__ __launch_bounds__(BLOCK) void k_gene_arcs_big(GeneArcs a)
 // ------------------------------------------------------------------------------------------------
 struct InGmeta { const int4 *gm; __device__ __forceinline__ I32 operator()(int64_t i) const { const int4 m = gm[i]; return I32{m.y + m.z}; } };
 
-struct ArcFinal {
-	const int4 *gmeta; const int32_t *off; int S; const pga_arc_part_t *stage; const int32_t *stage_sid, *seg_gid, *seg_cnt;
-	pga_arc_part_t *arcs; uint64_t *ax; int32_t *s1, *agid, *vs, *ve, *deg; uint8_t *aw, *vwk; int64_t *dcnt, *host_box;
-	int32_t *h_round; // pinned host memory (or NULL): seg_cnt[2S] then deg[2S] for the host, written straight from here
-};
-
-__global__ __launch_bounds__(BLOCK) void k_arc_final(ArcFinal f)
+// the table as ONE array sorted by x: one wave per segment copies the gene's stretch to its place (off[] = exclusive scan of the
+// segments' arc counts); the last segment also leaves the table size in dcnt[10] and mails the counters
+__global__ __launch_bounds__(BLOCK) void k_arc_compact(const int4 *gmeta, const int32_t *off, int S, const pga_arc_part_t *stage, pga_arc_part_t *arcs, int64_t *dcnt, int64_t *host_box)
 {
-	const int64_t T = (int64_t)gridDim.x * BLOCK, tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	const int4 ml = f.gmeta[f.S - 1];
-	const int n_arc = f.off[f.S - 1] + ml.y + ml.z;
-	for (int64_t j = tid; j < n_arc; j += T) { // one staged arc per thread: its place = offset of its segment + its rank inside the gene
-		const int sid = f.stage_sid[j];
-		const int64_t i = f.off[sid] + (j - f.gmeta[sid].x);
-		const pga_arc_part_t a = f.stage[j];
-		f.arcs[i] = a;
-		f.ax[i] = a.x;
-		f.s1[i] = (int32_t)((double)a.sum_s1 / a.n_genome + .499); // graph.c:171
-		f.agid[i] = f.seg_gid[(uint32_t)a.x >> 1];
-		f.aw[i] = 0;
-	}
-	for (int64_t sid = tid; sid < f.S; sid += T) {
-		const int4 m = f.gmeta[sid];
-		const int o = f.off[sid], n = m.y + m.z;
-		f.vs[2 * sid] = o, f.ve[2 * sid] = o + m.y, f.vs[2 * sid + 1] = o + m.y, f.ve[2 * sid + 1] = o + n;
-		f.deg[2 * sid] = m.y, f.deg[2 * sid + 1] = m.z;
-		f.vwk[2 * sid] = 0, f.vwk[2 * sid + 1] = 0;
-		if (f.h_round) {
-			f.h_round[sid] = f.seg_cnt[sid], f.h_round[f.S + sid] = f.seg_cnt[f.S + sid];
-			f.h_round[2 * f.S + 2 * sid] = m.y, f.h_round[2 * f.S + 2 * sid + 1] = m.z;
+	const int lane = threadIdx.x & 63;
+	for (int sid = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); sid < S; sid += gridDim.x * (BLOCK / WAVE)) {
+		const int4 m = gmeta[sid];
+		const int o = off[sid], n = m.y + m.z;
+		for (int i = lane; i < n; i += WAVE) arcs[o + i] = stage[m.x + i];
+		if (lane == 0 && sid == S - 1) {
+			dcnt[10] = o + n;
+			for (int t = 0; t < 16; ++t) host_box[t] = dcnt[t];
 		}
-	}
-	if (tid == 0) { // table size and the device counters for the host (read after its next wait); the round's counters start again
-		f.dcnt[10] = n_arc;
-		for (int t = 0; t < 16; ++t) f.host_box[t] = f.dcnt[t];
-		f.dcnt[8] = 0, f.dcnt[9] = 0, f.dcnt[11] = 0;
 	}
 }
 
@@ -296,20 +302,19 @@ __global__ __launch_bounds__(BLOCK) void k_arc_final(ArcFinal f)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_mark_hits_z(const int4 *zrec, const int4 *hf, const int4 *hb, uint32_t tag, int n, const int32_t *g2s,
                                                         const uint64_t *ax, const uint8_t *aw, const int32_t *vs, const int32_t *ve, const uint8_t *vwk,
-                                                        uint32_t *flags, int64_t *cnt)
+                                                        uint32_t *flags, int64_t *cnt, int then_filter)
 {
 	int z = blockIdx.x * BLOCK + threadIdx.x;
 	bool marked = false;
 	if (z < n) {
-		const int4 hbz = hb[z];
+		const int4 hbz = hb[z], hfz = hf[z], zr = zrec[z]; // three independent loads up front: the chain below is then two levels deep
 		const bool walk = ha_walk(hbz, tag);
-		const int4 zr = walk || cnt ? zrec[z] : make_int4(0, 0, 0, 0);
 		if (walk) {
 			const int sid = g2s[zr.z], rev = zr.y & 1;
 			int nw = 0;
 #pragma unroll
 			for (int dir = 0; dir < 2; ++dir) {
-				const int4 h = dir ? hbz : hf[z];
+				const int4 h = dir ? hbz : hfz;
 				if (!ha_valid(h, tag) || sid < 0) continue;
 				const uint32_t u = (uint32_t)sid << 1 | (uint32_t)(dir ? !rev : rev), t = (uint32_t)h.x & HA_NONE;
 				if (!vwk[u]) continue; // the vertex has no weak out-arc (the common case)
@@ -319,7 +324,8 @@ __global__ __launch_bounds__(BLOCK) void k_mark_hits_z(const int4 *zrec, const i
 			}
 			if (nw) { // rare: only now is the hit's flag word touched
 				const uint32_t f = flags[zr.x];
-				if (nw > (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT)) flags[zr.x] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT;
+				// (then_filter: PG_SET_FILTER(weak_br == 2), graph.c:309 -- only a hit marked here can newly have weak_br == 2)
+				if (nw > (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT)) flags[zr.x] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT | ((then_filter && nw == 2) ? PGA_F_FLT : 0u);
 				marked = true;
 			}
 		}

@@ -80,10 +80,11 @@ __global__ __launch_bounds__(BLOCK) void k_vtx_compact(const int32_t *dom_tab, c
 	}
 }
 
-__global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32_t *gid, int n, const int32_t *g2s) // graph.c:61-69
+__global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32_t *gid, int n, const int32_t *g2s, int then_filter) // graph.c:61-69 (+ PG_SET_FILTER(vtx == 0))
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
 	uint32_t f = flags[h], nf = g2s[gid[h]] >= 0 ? (f | PGA_F_VTX) : (f & ~PGA_F_VTX);
+	if (then_filter && !(nf & PGA_F_VTX)) nf |= PGA_F_FLT;
 	if (nf != f) flags[h] = nf;
 }

@@ -111,9 +111,14 @@ struct pga_ctx {
 	// gene-major index (k_genes.hpp): hits by (gene, genome, X position); half-arc records of the current walk
 	int4 *zrec = 0; int32_t *zpos = 0, *zposy = 0, *zoff = 0; int4 *hf = 0, *hb = 0;
 	bool z_valid = false, ha_valid = false; uint32_t round_tag = 0; int ha_ori = -1;
+	const pga_arc_part_t *cur_tab = nullptr; int64_t cur_tab_n = 0; // the table of pga_arc_set_current
+	bool table_sparse = false; // the current arc table lives in the genes' stretches (arc_round_genes) and has not been compacted
 	int32_t *h_round = nullptr; size_t h_round_cap = 0; // pinned: segment counters + degrees of a round
 	int4 *yrecA = 0, *yrecB = 0; bool yrec_valid = false; // Y-order static records (k_pack_yrec), rebuilt after anything that changes their sources
-	int64_t br_n = 0, br_np = 0; int32_t br_S = 0; // arcs / pairs / segments of the last branch_pairs
+	int64_t br_np_seen = 0; // the last pair count the host got to know (sizes the next grid)
+	int64_t br_n = 0, br_np = 0, br_cap = 0; int32_t br_S = 0; // arcs / pairs (-1: not known on the host yet) / pair capacity / segments of the last branch_pairs
+	struct { double diff; int32_t local_dist, local_count, frag_mode; } br_par = { 0, 0, 0, 0 };
+	int32_t *h_ndl = nullptr; size_t h_ndl_cap = 0; // pinned: n_dist_loci of a round
 	std::vector<TimedLaunch> timed; bool timing_on = false; // HIP-event timing of kernel classes, switched on by pga_timing_reset (bench.py)
 	hipEvent_t span_a = nullptr; // start of stage A (pga_begin), paired with an event at the end of pga_ingest
 	std::vector<void *> owned;
@@ -275,6 +280,7 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 	if (c->h_stage) (void)hipHostFree(c->h_stage);
 	if (c->h_g2s) (void)hipHostFree(c->h_g2s);
 	if (c->h_round) (void)hipHostFree(c->h_round);
+	if (c->h_ndl) (void)hipHostFree(c->h_ndl);
 	if (c->g2s_done) (void)hipEventDestroy(c->g2s_done);
 	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
 	delete c;
@@ -590,38 +596,47 @@ extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records,
 	const int N = c->N, Q = c->Q, GL = c->n_genome;
 	const int64_t wpg = (Q + 31) / 32, n_slot = (int64_t)std::max(1, Q) * VTX_K;
 	const int nw = (c->n_genome_global + 63) / 64;
-	const long long ovf_cap = 65536;
+	static const long long first_cap = [] { const char *e = getenv("PANGENE_VTX_SPILL_CAP"); return e && atoll(e) > 0 ? atoll(e) : 65536ll; }(); // (tests shrink it to reach the second attempt)
+	long long ovf_cap = first_cap;
 	uint32_t *bits = (uint32_t *)c->pool.get(S_BITS, sizeof(uint32_t) * (size_t)(wpg * GL) + 16);
-	// [dom_tab: n_slot i32][slot: n_slot i32][pair bits: n_slot * nw u64][records: (n_slot + ovf_cap) * (1 + nw) u64]
-	const size_t b_tab = sizeof(int32_t) * (size_t)n_slot, b_bits = sizeof(uint64_t) * (size_t)n_slot * (size_t)nw, b_rec = sizeof(uint64_t) * (size_t)(n_slot + ovf_cap) * (size_t)(1 + nw);
-	char *blk = (char *)c->pool.get(S_TRIPLES, 2 * b_tab + b_bits + b_rec + 64);
-	if (!bits || !blk) return PGA_ERR_NOMEM;
-	int32_t *dom_tab = (int32_t *)blk, *slot = (int32_t *)(blk + b_tab);
-	unsigned long long *pbits = (unsigned long long *)(blk + 2 * b_tab), *rec = (unsigned long long *)(blk + 2 * b_tab + b_bits);
-	zero_multi(c, bits, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->vtx_cnt, sizeof(int32_t) * 2 * (size_t)std::max(1, Q), c->dcnt, sizeof(int64_t), pbits, b_bits);
-	HIPCHK(hipMemsetAsync(dom_tab, 0xff, b_tab, c->st)); // every slot empty (-1)
-	*n_records = 0, *records = (uint64_t *)rec, *cnt = c->vtx_cnt;
-	if (N == 0) return sync_st(c);
-	hipLaunchKernelGGL(k_vtx1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt);
-	hipLaunchKernelGGL(k_vtx_fold, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, c->prot_gid, c->ggl, N, bits, wpg,
-	                   dom_tab, pbits, nw, rec + n_slot * (1 + nw), ovf_cap, c->dcnt);
-	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_slot));
-	if (!tile) return PGA_ERR_NOMEM;
-	device_scan<I32>(InDomSet{dom_tab}, OutExclI32{slot}, n_slot, tile, OpSum{}, I32{0}, c->st);
-	hipLaunchKernelGGL(k_vtx_compact, dim3(nblk(n_slot)), dim3(BLOCK), 0, c->st, dom_tab, slot, n_slot, pbits, nw, rec, c->dcnt, c->h_box);
-	TRY(sync_st(c));
-	if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
-	const int64_t n_rec = c->h_cnt[10], n_ovf = c->h_cnt[0];
-	if (n_ovf > ovf_cap) return PGA_ERR_RANGE; // > 65536 (genome, gene) cells beyond VTX_K dominators per gene
-	if (n_ovf) { // the spilled single-genome records follow the folded ones
-		HIPCHK(hipMemcpyAsync(rec + n_rec * (1 + nw), rec + n_slot * (1 + nw), sizeof(uint64_t) * (size_t)n_ovf * (size_t)(1 + nw), hipMemcpyDeviceToDevice, c->st));
+	if (!bits) return PGA_ERR_NOMEM;
+	*n_records = 0, *cnt = c->vtx_cnt;
+	for (int attempt = 0;; ++attempt) { // the spill area beyond the VTX_K dominator slots per gene grows to what the first attempt counted
+		// [dom_tab: n_slot i32][slot: n_slot i32][pair bits: n_slot * nw u64][records: (n_slot + ovf_cap) * (1 + nw) u64]
+		const size_t b_tab = sizeof(int32_t) * (size_t)n_slot, b_bits = sizeof(uint64_t) * (size_t)n_slot * (size_t)nw, b_rec = sizeof(uint64_t) * (size_t)(n_slot + ovf_cap) * (size_t)(1 + nw);
+		char *blk = (char *)c->pool.get(S_TRIPLES, 2 * b_tab + b_bits + b_rec + 64);
+		if (!blk) return PGA_ERR_NOMEM;
+		int32_t *dom_tab = (int32_t *)blk, *slot = (int32_t *)(blk + b_tab);
+		unsigned long long *pbits = (unsigned long long *)(blk + 2 * b_tab), *rec = (unsigned long long *)(blk + 2 * b_tab + b_bits);
+		zero_multi(c, bits, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->vtx_cnt, sizeof(int32_t) * 2 * (size_t)std::max(1, Q), c->dcnt, sizeof(int64_t), pbits, b_bits);
+		HIPCHK(hipMemsetAsync(dom_tab, 0xff, b_tab, c->st)); // every slot empty (-1)
+		*records = (uint64_t *)rec;
+		if (N == 0) return sync_st(c);
+		hipLaunchKernelGGL(k_vtx1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt);
+		hipLaunchKernelGGL(k_vtx_fold, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, c->prot_gid, c->ggl, N, bits, wpg,
+		                   dom_tab, pbits, nw, rec + n_slot * (1 + nw), ovf_cap, c->dcnt);
+		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_slot));
+		if (!tile) return PGA_ERR_NOMEM;
+		device_scan<I32>(InDomSet{dom_tab}, OutExclI32{slot}, n_slot, tile, OpSum{}, I32{0}, c->st);
+		hipLaunchKernelGGL(k_vtx_compact, dim3(nblk(n_slot)), dim3(BLOCK), 0, c->st, dom_tab, slot, n_slot, pbits, nw, rec, c->dcnt, c->h_box);
 		TRY(sync_st(c));
+		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
+		const int64_t n_rec = c->h_cnt[10], n_ovf = c->h_cnt[0];
+		if (n_ovf > ovf_cap) { // more spilled (genome, gene) cells than there was room for: once more, with room (the reference has no such limit)
+			if (attempt) return PGA_ERR_RANGE;
+			ovf_cap = n_ovf;
+			continue;
+		}
+		if (n_ovf) { // the spilled single-genome records follow the folded ones
+			HIPCHK(hipMemcpyAsync(rec + n_rec * (1 + nw), rec + n_slot * (1 + nw), sizeof(uint64_t) * (size_t)n_ovf * (size_t)(1 + nw), hipMemcpyDeviceToDevice, c->st));
+			TRY(sync_st(c));
+		}
+		*n_records = n_rec + n_ovf;
+		return 0;
 	}
-	*n_records = n_rec + n_ovf;
-	return 0;
 }
 
-extern "C" int pga_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg)
+extern "C" int pga_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg, int32_t then_filter)
 {
 	// g2s is caller memory: it is copied into a pinned staging area so that the call need not wait for the upload
 	const size_t nb = sizeof(int32_t) * (size_t)c->Q;
@@ -636,7 +651,8 @@ extern "C" int pga_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg)
 	TRY(upload(c, c->g2s, (const int32_t *)c->h_g2s, (size_t)c->Q));
 	HIPCHK(hipEventRecord(c->g2s_done, c->st));
 	c->n_seg = n_seg;
-	if (c->N) hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, c->N, c->g2s);
+	if (then_filter) c->walk_valid = false, c->ha_valid = false;
+	if (c->N) hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, c->N, c->g2s, then_filter);
 	return 0;
 }
 
@@ -714,38 +730,52 @@ static int cur_table(pga_ctx *c, int64_t n_arc, int n_seg, CurTable *t)
 	return (t->ax && t->aw && t->s1 && t->agid && t->vs && t->ve && t->sg && t->dg && t->vwk) ? 0 : PGA_ERR_NOMEM;
 }
 
-// pg_gen_arc on the gene-major index (k_genes.hpp).  Leaves the round's arc table (sorted by x) in S_ARCS and everything derived
-// from it (what pga_arc_set_current would compute) in place; seg_cnt[2S] and the degrees stay on the device.  The table size and
-// the overflow mark travel to the pinned mirror with the last kernel; nothing waits here.
-static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int32_t **deg_out, int32_t *h_round_dev)
+// pg_gen_arc on the gene-major index (k_genes.hpp).  Leaves the round's arcs, every gene's in its own stretch of the table arrays,
+// and everything the branch steps read (what pga_arc_set_current would derive) in place; seg_cnt[2S] and the degrees go to the
+// pinned buffer h_round_dev when one is given.  The counters travel to the pinned mirror with the last kernel; nothing waits here.
+static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32_t **deg_out, int32_t *h_round_dev)
 {
 	const int N = c->N, S = c->n_seg;
 	const int64_t cap = 2 * (int64_t)N + 2; // distinct arcs <= half-arcs <= 2 (N - 1)
 	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES);
 	pga_arc_part_t *stage = (pga_arc_part_t *)c->pool.get(S_ARC_STAGE, sizeof(pga_arc_part_t) * (size_t)cap);
-	pga_arc_part_t *arcs = (pga_arc_part_t *)c->pool.get(S_ARCS, sizeof(pga_arc_part_t) * (size_t)cap);
 	int4 *gmeta = (int4 *)c->pool.get(S_GMETA, sizeof(int4) * (size_t)std::max(1, S));
-	int32_t *off = (int32_t *)c->pool.get(S_GOFF, sizeof(int32_t) * (size_t)std::max(1, S));
 	CurTable t;
-	if (!seg_cnt || !stage || !arcs || !gmeta || !off) return PGA_ERR_NOMEM;
+	if (!seg_cnt || !stage || !gmeta) return PGA_ERR_NOMEM;
 	TRY(cur_table(c, cap, S, &t));
-	*seg_cnt_out = seg_cnt, *arcs_out = arcs, *deg_out = t.dg;
+	*seg_cnt_out = seg_cnt, *deg_out = t.dg;
+	c->table_sparse = true;
 	TRY(launch_sweep<0>(c, 2)); // graph.c:102
 	TRY(ensure_half_arcs(c, use_ori));
 	if (S == 0) { hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box); return 0; }
 	int32_t *big = (int32_t *)c->pool.get(S_BIGLIST, sizeof(int32_t) * (size_t)std::max(1, c->Q));
 	if (!big) return PGA_ERR_NOMEM;
 	static const int cap_log2 = [] { const char *e = getenv("PANGENE_GENE_TABLE_LOG2"); const int v = e ? atoi(e) : 9; return v < 1 ? 1 : v > 9 ? 9 : v; }();
-	int32_t *stage_sid = (int32_t *)c->pool.get(S_STAGE_SID, sizeof(int32_t) * (size_t)cap);
-	if (!stage_sid) return PGA_ERR_NOMEM;
-	GeneArcs ga = { c->zrec, c->zoff, c->hf, c->hb, c->g2s, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, stage_sid, gmeta, big, c->dcnt };
+	static const int gdbg = [] { const char *e = getenv("PGA_GENE_DEBUG"); return e ? atoi(e) : 0; }();
+	GeneArcs ga = { c->zrec, c->zoff, c->hf, c->hb, c->g2s, gdbg, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta,
+	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt };
 	hipLaunchKernelGGL(k_gene_arcs_wave, dim3(nblk(c->Q, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, ga);
-	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 4 * c->n_cu)), dim3(BLOCK), 0, c->st, ga);
+	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 8 * c->n_cu)), dim3(BLOCK), 0, c->st, ga);
+	hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box); // invariant / overflow counters for the host; the overflow counter starts again
+	return 0;
+}
+
+// the round's table as one array sorted by x (see k_genes.hpp (C)); waits, returns the size
+static int arc_table_compact(pga_ctx *c, pga_arc_part_t **arcs_out, int64_t *n_out)
+{
+	const int S = c->n_seg;
+	*n_out = 0, *arcs_out = nullptr;
+	if (S == 0 || c->N == 0) return 0;
+	const int64_t cap = 2 * (int64_t)c->N + 2;
+	pga_arc_part_t *stage = (pga_arc_part_t *)c->pool.get(S_ARC_STAGE, 0), *arcs = (pga_arc_part_t *)c->pool.get(S_ARCS, sizeof(pga_arc_part_t) * (size_t)cap);
+	int4 *gmeta = (int4 *)c->pool.get(S_GMETA, 0);
+	int32_t *off = (int32_t *)c->pool.get(S_GOFF, sizeof(int32_t) * (size_t)S);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(S));
-	if (!tile) return PGA_ERR_NOMEM;
+	if (!stage || !arcs || !gmeta || !off || !tile) return PGA_ERR_NOMEM;
 	device_scan<I32>(InGmeta{gmeta}, OutExclI32{off}, S, tile, OpSum{}, I32{0}, c->st);
-	ArcFinal f = { gmeta, off, S, stage, stage_sid, t.sg, seg_cnt, arcs, t.ax, t.s1, t.agid, t.vs, t.ve, t.dg, t.aw, t.vwk, c->dcnt, c->h_box, h_round_dev };
-	hipLaunchKernelGGL(k_arc_final, dim3((unsigned)std::max(1, 2 * c->n_cu)), dim3(BLOCK), 0, c->st, f);
+	hipLaunchKernelGGL(k_arc_compact, dim3(nblk(S, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gmeta, off, S, stage, arcs, c->dcnt, c->h_box);
+	TRY(sync_st(c));
+	*arcs_out = arcs, *n_out = c->h_cnt[10];
 	return 0;
 }
 
@@ -816,24 +846,24 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 	if (c->N && !arc_sort_path_forced()) {
 		int32_t *deg;
 		*n_arcs_out = 0;
-		TRY(arc_round_genes(c, use_ori, seg_cnt_out, arcs_out, &deg, nullptr));
+		TRY(arc_round_genes(c, use_ori, seg_cnt_out, &deg, nullptr));
 		TRY(sync_st(c));
 		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
-		if (c->h_cnt[9] == 0) { *n_arcs_out = c->h_cnt[10]; return 0; }
+		if (c->h_cnt[9] == 0) return arc_table_compact(c, arcs_out, n_arcs_out); // the exchange wants one sorted array
 	}
+	c->table_sparse = false;
 	return arc_round_sorted(c, use_ori, seg_cnt_out, arcs_out, n_arcs_out);
 }
 
 // pg_gen_arc for a run that is not sharded: the round's table is the graph's table at once (what pga_arc_set_current would
 // derive is produced by the same kernels), and the only things the host needs -- segment counters, out-degrees, table size --
 // arrive with ONE wait at the end.
-extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt_host, int32_t *deg_host, const pga_arc_part_t **arcs_out, int64_t *n_arc)
+extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt_host, int32_t *deg_host)
 {
 	const int S = n_seg, n_vtx = 2 * S;
-	*n_arc = 0, *arcs_out = nullptr;
 	if (S != c->n_seg) return PGA_ERR_ARG;
 	if (c->N && !arc_sort_path_forced()) {
-		int32_t *seg_cnt, *deg; pga_arc_part_t *arcs;
+		int32_t *seg_cnt, *deg;
 		const size_t need = sizeof(int32_t) * 2 * (size_t)n_vtx + 64;
 		if (c->h_round_cap < need) {
 			if (c->h_round) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipHostFree(c->h_round); c->h_round = nullptr; }
@@ -842,24 +872,34 @@ extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg,
 		}
 		int32_t *h_dev = nullptr;
 		HIPCHK(hipHostGetDevicePointer((void **)&h_dev, c->h_round, 0));
-		TRY(arc_round_genes(c, use_ori, &seg_cnt, &arcs, &deg, h_dev)); // the last kernel writes the counters and degrees into the pinned buffer
+		TRY(arc_round_genes(c, use_ori, &seg_cnt, &deg, h_dev)); // the gene kernels write the counters and degrees into the pinned buffer
 		TRY(sync_st(c));
 		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
 		if (c->h_cnt[9] == 0) {
 			if (n_vtx) memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
-			*n_arc = c->h_cnt[10], *arcs_out = arcs;
-			c->br_n = *n_arc, c->br_S = S, c->br_np = 0;
+			c->br_n = 2 * (int64_t)c->N + 2, c->br_S = S, c->br_np = 0; // (br_n: extent of the table arrays; the arcs are counted when somebody asks, pga_arc_table)
 			return 0;
 		}
 	}
 	int32_t *seg_cnt; pga_arc_part_t *arcs; int64_t n = 0;
+	c->table_sparse = false;
 	TRY(arc_round_sorted(c, use_ori, &seg_cnt, &arcs, &n));
 	TRY(pga_arc_set_current(c, arcs, n, S, deg_host));
 	if (n_vtx) TRY(pga_fetch(c, seg_cnt_host, seg_cnt, sizeof(int32_t) * (size_t)n_vtx));
-	*n_arc = n, *arcs_out = arcs;
 	return 0;
 }
 
+extern "C" int pga_arc_table(pga_ctx_t *c, const pga_arc_part_t **arcs, int64_t *n_arc)
+{
+	if (c->table_sparse) {
+		pga_arc_part_t *a;
+		TRY(arc_table_compact(c, &a, n_arc));
+		*arcs = a;
+		return 0;
+	}
+	*arcs = c->cur_tab, *n_arc = c->cur_tab_n;
+	return 0;
+}
 
 extern "C" int pga_arc_merge(pga_ctx_t *c, const pga_arc_part_t *gathered, const int64_t *count, int32_t W, int64_t slot_sz,
                              pga_arc_part_t **out, int64_t *n_out)
@@ -904,6 +944,7 @@ extern "C" int pga_arc_set_current(pga_ctx_t *c, const pga_arc_part_t *arcs, int
 {
 	const int n_vtx = 2 * n_seg;
 	c->br_n = n_arc, c->br_S = n_seg, c->br_np = 0;
+	c->cur_tab = arcs, c->cur_tab_n = n_arc, c->table_sparse = false;
 	if (n_vtx) memset(deg, 0, sizeof(int32_t) * (size_t)n_vtx);
 	CurTable t;
 	TRY(cur_table(c, n_arc, n_seg, &t));
@@ -942,7 +983,8 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 	return 0;
 }
 
-static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt)
+// n = number of pairs, or (np_dev != NULL) the capacity of d_pairs with the actual number in device memory
+static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, const int64_t *np_dev, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt)
 {
 	int32_t *d_cnt = (int32_t *)c->pool.get(S_NLCNT, sizeof(int32_t) * (size_t)n + 16);
 	int4 *rp = (int4 *)c->pool.get(S_RP_SEG, 0);
@@ -950,8 +992,11 @@ static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, int32_t lo
 	*cnt = d_cnt;
 	NLocalHz hz = { (const int32_t *)c->pool.get(S_RP_IV, 0), c->ctg_base, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP) };
 	if (!hz.iv || !hz.list) return PGA_ERR_NOMEM;
-	if (n && c->rp_compact) hipLaunchKernelGGL((k_n_local<true>), dim3(nblk(n, BLOCK / WAVE * NL_PAIRS)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
-	else if (n) hipLaunchKernelGGL((k_n_local<false>), dim3(nblk(n, BLOCK / WAVE * NL_PAIRS)), dim3(BLOCK), 0, c->st, d_pairs, n, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
+	// the grid follows the last known number of pairs (the kernel strides over whatever there is)
+	const int64_t est = np_dev ? (c->br_np_seen > 0 ? c->br_np_seen : std::min<int64_t>(n, 1 << 18)) : n;
+	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nblk(est, BLOCK / WAVE * NL_PAIRS), 1 << 20));
+	if (n && c->rp_compact) hipLaunchKernelGGL((k_n_local<true>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
+	else if (n) hipLaunchKernelGGL((k_n_local<false>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
 	return 0;
 }
 
@@ -960,8 +1005,21 @@ extern "C" int pga_n_local(pga_ctx_t *c, const int32_t *pairs, int64_t n, int32_
 	int32_t *d_pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)n + 16);
 	if (!d_pairs) return PGA_ERR_NOMEM;
 	if (n) TRY(upload(c, d_pairs, pairs, 2 * (size_t)n));
-	TRY(n_local_dev(c, d_pairs, n, local_dist, local_count, frag_mode, cnt));
+	TRY(n_local_dev(c, d_pairs, n, nullptr, local_dist, local_count, frag_mode, cnt));
 	return sync_st(c); // pairs is caller memory; the exchange may run on another stream
+}
+
+// enumerate the pairs and count them (k_br_wave<1>, k_n_local) for the pair count in dcnt[15] (capacity c->br_cap)
+static int branch_enumerate(pga_ctx *c, int32_t **cnt)
+{
+	const int n_vtx = 2 * c->br_S;
+	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, 0), *agid = (int32_t *)c->pool.get(S_BR_GID, 0), *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0);
+	int32_t *poff = (int32_t *)c->pool.get(S_BR_POFF, 0);
+	int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)c->br_cap + 16);
+	if (!pairs || !s1 || !agid || !vs || !ve || !poff) return PGA_ERR_NOMEM;
+	hipLaunchKernelGGL((k_br_wave<1>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, c->br_par.diff, poff, pairs, c->br_cap, (const int32_t *)c->pool.get(S_BR_PC, 0),
+	                   (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt, (uint8_t *)nullptr);
+	return n_local_dev(c, pairs, c->br_cap, c->dcnt + 15, c->br_par.local_dist, c->br_par.local_count, c->br_par.frag_mode, cnt);
 }
 
 extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg,
@@ -976,28 +1034,31 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	int32_t *pc = (int32_t *)c->pool.get(S_BR_PC, sizeof(int32_t) * (size_t)n_vtx + 16), *poff = (int32_t *)c->pool.get(S_BR_POFF, sizeof(int32_t) * (size_t)n_vtx + 16);
 	int32_t *sg = (int32_t *)c->pool.get(S_BR_SEGGID, sizeof(int32_t) * (size_t)n_seg + 16);
 	if (!ax || !aw || !s1 || !agid || !vs || !ve || !pc || !poff || !sg) return PGA_ERR_NOMEM;
-	c->br_n = n_arc, c->br_S = n_seg, c->br_np = 0;
-	*n_pairs = 0, *cnt = (int32_t *)c->pool.get(S_NLCNT, 16);
-	if (n_arc == 0 || n_vtx == 0) return sync_st(c);
+	c->br_n = n_arc, c->br_S = n_seg, c->br_np = -1;
+	c->br_par.diff = branch_diff, c->br_par.local_dist = local_dist, c->br_par.local_count = local_count, c->br_par.frag_mode = frag_mode;
+	if (n_pairs) *n_pairs = 0;
+	*cnt = (int32_t *)c->pool.get(S_NLCNT, 16);
+	if (n_arc == 0 || n_vtx == 0) { c->br_np = 0; return sync_st(c); }
 	if (arc_x) {
 		TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, s1, arc_s1, (size_t)n_arc)); TRY(upload(c, sg, seg_gid, (size_t)n_seg));
 		HIPCHK(hipMemsetAsync(vs, 0, sizeof(int32_t) * (size_t)n_vtx, c->st)); HIPCHK(hipMemsetAsync(ve, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
 		hipLaunchKernelGGL(k_br_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, ax, n_arc, sg, agid, vs, ve);
+		HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st)); // (the tables of arc_round_local / arc_set_current arrive with weak_br = 0)
 	}
-	HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st));
 	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_vtx));
 	device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
-	hipLaunchKernelGGL(k_mail_sum, dim3(1), dim3(64), 0, c->st, poff + (n_vtx - 1), pc + (n_vtx - 1), c->dcnt, c->h_box);
-	TRY(sync_st(c));
-	const int64_t np = c->h_cnt[10];
-	c->br_np = np, *n_pairs = np;
-	int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)np + 16);
-	if (!pairs) return PGA_ERR_NOMEM;
-	if (np) hipLaunchKernelGGL((k_br_wave<1>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, pairs,
-	                           (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt, (uint8_t *)nullptr);
-	TRY(n_local_dev(c, pairs, np, local_dist, local_count, frag_mode, cnt));
-	return 0; // no wait: a consumer that is not on this stream calls pga_sync first
+	hipLaunchKernelGGL(k_mail_pairs, dim3(1), dim3(64), 0, c->st, poff + (n_vtx - 1), pc + (n_vtx - 1), c->dcnt, c->h_box); // dcnt[15] = number of pairs
+	if (n_pairs) { // somebody outside needs the count (the all-reduce of a sharded run): wait for it and size the buffers exactly
+		TRY(sync_st(c));
+		c->br_np = c->h_cnt[15], *n_pairs = c->br_np;
+		c->br_cap = std::max<int64_t>(c->br_np, 16);
+		return c->br_np ? branch_enumerate(c, cnt) : 0;
+	}
+	// otherwise nothing waits: the buffers keep the capacity that was enough so far, pga_branch_decide checks the count when
+	// it has to wait for its own results anyway and repeats the enumeration in the (first-round) case that it was not
+	if (c->br_cap < 4 * (int64_t)n_vtx) c->br_cap = 4 * (int64_t)n_vtx;
+	return branch_enumerate(c, cnt);
 }
 
 extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch_diff_dist, double branch_diff_cut, uint8_t *arc_weak,
@@ -1011,23 +1072,40 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	if (n_arc == 0 || n_vtx == 0) return 0;
 	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, 0);
 	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, 0), *agid = (int32_t *)c->pool.get(S_BR_GID, 0), *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0);
-	int32_t *poff = (int32_t *)c->pool.get(S_BR_POFF, 0), *cnt = (int32_t *)c->pool.get(S_NLCNT, 0);
-	int32_t *grp = (int32_t *)c->pool.get(S_BR_GRP, sizeof(int32_t) * (size_t)n_arc + 16), *ndl = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
-	if (!grp || !ndl) return PGA_ERR_NOMEM;
-	zero_multi(c, grp, sizeof(int32_t) * (size_t)n_arc, ndl, sizeof(int32_t) * (size_t)n_vtx);
-	hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, cnt,
-	                   branch_diff_dist, branch_diff_cut, aw, grp, ndl, c->dcnt, (uint8_t *)c->pool.get(S_VWK, (size_t)n_vtx + 16));
-	if (arc_weak) HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(n_dist_loci, ndl, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
-	TRY(sync_st(c));
-	int64_t f1 = 0, f2 = 0;
-	if (arc_weak) for (int64_t i = 0; i < n_arc; ++i) f1 += arc_weak[i] == 1, f2 += arc_weak[i] == 2;
-	if (n_flt1) *n_flt1 = f1;
-	if (n_flt2) *n_flt2 = f2;
+	int32_t *poff = (int32_t *)c->pool.get(S_BR_POFF, 0);
+	int32_t *grp = (int32_t *)c->pool.get(S_BR_GRP, sizeof(int32_t) * (size_t)n_arc + 16);
+	uint8_t *vwk = (uint8_t *)c->pool.get(S_VWK, (size_t)n_vtx + 16);
+	const size_t need = sizeof(int32_t) * (size_t)n_vtx + 64;
+	if (c->h_ndl_cap < need) {
+		if (c->h_ndl) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipHostFree(c->h_ndl); c->h_ndl = nullptr; }
+		HIPCHK(hipHostMalloc((void **)&c->h_ndl, need + need / 2, hipHostMallocDefault));
+		c->h_ndl_cap = need + need / 2;
+	}
+	int32_t *ndl_dev = nullptr;
+	HIPCHK(hipHostGetDevicePointer((void **)&ndl_dev, c->h_ndl, 0)); // n_dist_loci goes straight into pinned host memory
+	if (!grp || !vwk) return PGA_ERR_NOMEM;
+	for (int attempt = 0;; ++attempt) {
+		int32_t *cnt = (int32_t *)c->pool.get(S_NLCNT, 0);
+		if (n_flt1 || n_flt2) HIPCHK(hipMemsetAsync(c->dcnt, 0, 2 * sizeof(int64_t), c->st)); // [0], [1]: arcs marked 1 / 2 (log only)
+		hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, (int64_t)0, (const int32_t *)nullptr, cnt,
+		                   branch_diff_dist, branch_diff_cut, aw, grp, ndl_dev, (n_flt1 || n_flt2) ? c->dcnt : (int64_t *)nullptr, vwk);
+		if (arc_weak && !c->table_sparse) HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
+		if (n_flt1 || n_flt2) hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
+		TRY(sync_st(c));
+		if (c->br_np >= 0 || c->h_cnt[15] <= c->br_cap || attempt) { if (c->br_np < 0) c->br_np = c->h_cnt[15]; c->br_np_seen = c->br_np; break; }
+		// more pairs than the buffers held (pairs beyond the capacity were neither listed nor counted): enumerate again, with room
+		c->br_cap = c->h_cnt[15] + c->h_cnt[15] / 2;
+		HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st)); HIPCHK(hipMemsetAsync(vwk, 0, (size_t)n_vtx, c->st));
+		int32_t *dummy;
+		TRY(branch_enumerate(c, &dummy));
+	}
+	memcpy(n_dist_loci, c->h_ndl, sizeof(int32_t) * (size_t)n_vtx);
+	if (n_flt1) *n_flt1 = c->h_cnt[0];
+	if (n_flt2) *n_flt2 = c->h_cnt[1];
 	return 0;
 }
 
-extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked)
+extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked, int32_t then_filter)
 {
 	const int N = c->N;
 	if (n_marked) *n_marked = 0;
@@ -1040,8 +1118,8 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 		if (!ax || !aw || !vs || !ve || !vwk) return PGA_ERR_NOMEM;
 		if (n_marked) HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
 		hipLaunchKernelGGL(k_mark_hits_z, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->zrec, c->hf, c->hb, c->round_tag, N, c->g2s, ax, aw, vs, ve, vwk, c->flags,
-		                   n_marked ? c->dcnt + 2 : (int64_t *)nullptr);
-		// weak_br does not enter the walkable test: the half-arcs stay valid
+		                   n_marked ? c->dcnt + 2 : (int64_t *)nullptr, then_filter);
+		if (then_filter) c->walk_valid = false, c->ha_valid = false; // else: weak_br does not enter the walkable test, the half-arcs stay valid
 	} else {
 		uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, sizeof(uint64_t) * (size_t)n_arc + 16);
 		uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, (size_t)n_arc + 16);
@@ -1054,6 +1132,7 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 		ensure_yrec(c);
 		hipLaunchKernelGGL(k_mark_hits, dim3(nblk(N)), dim3(BLOCK), 0, c->st, val, prev, c->yrecA, c->yrecB, c->g2s, N, ax, aw, n_arc, (const int32_t *)nullptr, (const int32_t *)nullptr, (const uint8_t *)nullptr, wn);
 		hipLaunchKernelGGL(k_weak_merge, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, wn, N, n_marked ? c->dcnt + 2 : (int64_t *)nullptr);
+		if (then_filter) TRY(pga_set_filter(c, PGA_FLT_WEAK2));
 	}
 	if (n_marked) {
 		HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
@@ -1245,7 +1324,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table
 	};
 	return &b;
 }

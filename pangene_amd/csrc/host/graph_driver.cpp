@@ -600,7 +600,8 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 		// it) resident; it travels to the host once, after the last round (fetch_arcs)
 		int64_t n_arc = 0;
 		const pga_arc_part_t *tab = nullptr;
-		{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, sc.data(), ext->deg.data(), &tab, &n_arc), "arc_round"); }
+		{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, sc.data(), ext->deg.data()), "arc_round"); }
+		if (pg_verbose >= 3) BE_CALL(be->arc_table(ext->ctx, &tab, &n_arc), "arc_table"); // only the log lines want the number of arcs of every round
 		{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
 		for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
 		ext->cur_arcs = tab, q->n_arc = (int32_t)n_arc;
@@ -649,6 +650,11 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 static int fetch_arcs(pg_graph_t *q, DataExt *ext)
 {
 	Phase ph_host(PH_ARC_HOST);
+	{ // the table as one array sorted by x, wherever the last round left it
+		int64_t n = 0;
+		BE_CALL(ext->be->arc_table(ext->ctx, &ext->cur_arcs, &n), "arc_table");
+		q->n_arc = (int32_t)n;
+	}
 	std::vector<pga_arc_part_t> part((size_t)q->n_arc);
 	if (q->n_arc) BE_CALL(ext->be->fetch(ext->ctx, part.data(), ext->cur_arcs, sizeof(pga_arc_part_t) * part.size()), "fetch");
 	if ((int64_t)part.size() > q->m_arc) {
@@ -666,7 +672,8 @@ static int fetch_arcs(pg_graph_t *q, DataExt *ext)
 	return 0;
 }
 
-static int flag_vtx(pg_graph_t *q, DataExt *ext) { return ext->be->flag_vtx(ext->ctx, q->g2s, q->n_seg); }
+// pg_graph_flag_vtx + PG_SET_FILTER(vtx == 0): they always come as a pair (graph.c:287-288,295,312)
+static int flag_vtx(pg_graph_t *q, DataExt *ext) { return ext->be->flag_vtx(ext->ctx, q->g2s, q->n_seg, 1); }
 
 // pg_flt_high_occ + pg_hard_delete (graph.c:219-263)
 static int flt_high_occ(int32_t max_avg_occ, int32_t max_degree, int32_t max_dist_loci, pg_graph_t *q, DataExt *ext)
@@ -710,10 +717,10 @@ static int mark_branch_flt_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	{
 		Phase ph(PH_NLOCAL);
 		BE_CALL(be->branch_pairs(ext->ctx, nullptr, nullptr, 0, nullptr, q->n_seg, opt->branch_diff, opt->local_dist, opt->local_count,
-		                         !!(opt->flag & PG_F_FRAG_MODE), &b_cnt, &np), "branch_pairs");
+		                         !!(opt->flag & PG_F_FRAG_MODE), &b_cnt, sharded() ? &np : nullptr), "branch_pairs"); // the pair count only matters to the all-reduce
 		BE_CALL(xreduce(be, ext->ctx, b_cnt, np, PG_X_I32, PG_X_SUM), "allreduce(n_local)");
-		std::vector<uint8_t> aw(pg_verbose >= 3 ? (size_t)q->n_arc + 1 : 0); // per-arc weak_br only feeds the log line; it stays resident for mark_hits
-		BE_CALL(be->branch_decide(ext->ctx, opt->branch_diff, opt->branch_diff_dist, opt->branch_diff_cut, aw.empty() ? nullptr : aw.data(), ndl.data(), &n_flt1, &n_flt2), "branch_decide");
+		// per-arc weak_br stays resident for mark_hits; the two totals only feed the log line
+		BE_CALL(be->branch_decide(ext->ctx, opt->branch_diff, opt->branch_diff_dist, opt->branch_diff_cut, nullptr, ndl.data(), pg_verbose >= 3 ? &n_flt1 : nullptr, pg_verbose >= 3 ? &n_flt2 : nullptr), "branch_decide");
 		g_phase[PH_BRANCH_HOST] -= now_sec() - ph.t0; // counted under PH_NLOCAL
 	}
 	for (int32_t j = 0; j < q->n_seg; ++j) q->seg[j].n_dist_loci[0] = ndl[(size_t)j * 2], q->seg[j].n_dist_loci[1] = ndl[(size_t)j * 2 + 1];
@@ -726,7 +733,7 @@ static int mark_branch_flt_hit(pg_graph_t *q, DataExt *ext) // branch.c:108-145;
 {
 	int64_t n = 0;
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 1), "override_order"); } // branch.c:116
-	{ Phase ph(PH_MARK_HITS); BE_CALL(ext->be->mark_hits(ext->ctx, nullptr, nullptr, q->n_arc, pg_verbose >= 3 ? &n : nullptr), "mark_hits"); }
+	{ Phase ph(PH_MARK_HITS); BE_CALL(ext->be->mark_hits(ext->ctx, nullptr, nullptr, q->n_arc, pg_verbose >= 3 ? &n : nullptr, 1), "mark_hits"); }
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // branch.c:140
 	if (pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] marked %ld diverged hits\n", "pg_mark_branch_flt_hit", stamp(), (long)n);
@@ -744,12 +751,10 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	BE_CALL(gen_vtx(opt, q, ext), "gen_vtx");
 	if (!exact_early(ext)) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "set_head"); } // index 0 of the S1 order, needed from the first sweep of stage C on (see post_process_impl)
 	BE_CALL(flag_vtx(q, ext), "flag_vtx");
-	BE_CALL(be->set_filter(ctx, PGA_FLT_VTX0), "set_filter");
 	BE_CALL(gen_arc(opt, q, ext), "gen_arc");
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-1 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
 	// graph 2: after removing high-occurrence vertices (graph.c:293-298)
 	BE_CALL(flt_high_occ(opt->max_avg_occ * 2, opt->max_degree * 2, opt->max_dist_loci, q, ext), "flt_high_occ");
-	BE_CALL(be->set_filter(ctx, PGA_FLT_VTX0), "set_filter");
 	BE_CALL(gen_arc(opt, q, ext), "gen_arc");
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-2 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
 	// graph 3: branch filtering (graph.c:300-315)
@@ -759,12 +764,8 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 		int32_t max_degree = (int32_t)(opt->max_degree * r + .499);
 		int32_t max_dist_loci = (int32_t)(opt->max_dist_loci * r + .499);
 		BE_CALL(mark_branch_flt_arc(opt, q, ext), "mark_branch_flt_arc");
-		BE_CALL(mark_branch_flt_hit(q, ext), "mark_branch_flt_hit");
-		BE_CALL(be->set_filter(ctx, PGA_FLT_WEAK2), "set_filter");
-		if (i > 0) {
-			BE_CALL(flt_high_occ(max_avg_occ, max_degree, max_dist_loci, q, ext), "flt_high_occ");
-			BE_CALL(be->set_filter(ctx, PGA_FLT_VTX0), "set_filter");
-		}
+		BE_CALL(mark_branch_flt_hit(q, ext), "mark_branch_flt_hit"); // with PG_SET_FILTER(weak_br == 2), graph.c:309
+		if (i > 0) BE_CALL(flt_high_occ(max_avg_occ, max_degree, max_dist_loci, q, ext), "flt_high_occ"); // with PG_SET_FILTER(vtx == 0), graph.c:312
 		BE_CALL(gen_arc(opt, q, ext), "gen_arc");
 	}
 	BE_CALL(be->set_filter(ctx, PGA_FLT_SHADOW), "set_filter"); // graph.c:316
