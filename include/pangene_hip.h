@@ -176,8 +176,13 @@ typedef struct {
 	int  pfx##_arc_set_current(pga_ctx_t *ctx, const pga_arc_part_t *arcs, int64_t n_arc, int32_t n_seg, int32_t *deg); \
 	/* pg_gen_arc (graph.c:87-177) of a run that is NOT sharded, in one call: the round's table becomes the graph's table at once \
 	 * (as after arc_set_current), the host receives seg_cnt[2 * n_seg] (n_genome[S] then tot_cnt[S]), the out-degree of every \
-	 * oriented vertex deg[2 * n_seg] after a single wait.  The table itself stays where the backend likes it (arc_table) */ \
+	 * oriented vertex deg[2 * n_seg] after a single wait.  The table itself stays where the backend likes it (arc_table). \
+	 * seg_cnt == NULL: nothing waits; the steps that read the table on the backend (rep_pos, branch_pairs, branch_decide) may be \
+	 * queued behind it, and arc_round_finish -- to be called before anything that changes the hits (mark_hits, filters) -- \
+	 * delivers the two arrays.  It returns 1 when the round has to be repeated (a plain arc_round_local call; whatever was \
+	 * queued behind the first one has to be repeated after it as well). */ \
 	int  pfx##_arc_round_local(pga_ctx_t *ctx, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt, int32_t *deg); \
+	int  pfx##_arc_round_finish(pga_ctx_t *ctx, int32_t n_seg, int32_t *seg_cnt, int32_t *deg); \
 	/* the graph's current arc table (of arc_round_local or arc_set_current) as ONE array sorted by x, in backend memory */ \
 	int  pfx##_arc_table(pga_ctx_t *ctx, const pga_arc_part_t **arcs, int64_t *n_arc); \
 	/* pg_gen_rep_pos (branch.c:6-29) kept in backend memory */ \
@@ -293,6 +298,7 @@ typedef struct {
 	int  (*ctg_counts)(pga_ctx_t *, int32_t *);
 	int  (*gene_matrix)(pga_ctx_t *, const int32_t *, int32_t, int32_t, int32_t *);
 	int  (*arc_table)(pga_ctx_t *, const pga_arc_part_t **, int64_t *);
+	int  (*arc_round_finish)(pga_ctx_t *, int32_t, int32_t *, int32_t *);
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);

@@ -55,6 +55,7 @@ struct pga_ctx {
 	/* branch state kept between branch_pairs and branch_decide / mark_hits */
 	uint64_t *br_x; int32_t *br_s1, *br_gid, *br_pairs; uint8_t *br_weak; int64_t br_n, br_np; int32_t br_S;
 	const pga_arc_part_t *cur_tab; int64_t cur_tab_n; /* the table of arc_set_current */
+	int32_t *def_sc, *def_deg; /* results of a deferred arc_round_local */
 	int64_t *head;            /* [n_genome] X position of the hit that plays "index 0" (never reset by pg_shadow) */
 	/* raw shard, file order (kept so that begin() can restart the run) */
 	int32_t *r_pid, *r_cid, *r_rank, *r_sori, *r_sadj, *r_nex, *r_offx, *r_cs, *r_ce, *r_cm; uint8_t *r_rev;
@@ -143,7 +144,7 @@ void pgo_destroy(pga_ctx_t *c)
 	free(c->pid_dom); free(c->pid_dom0); free(c->flags); free(c->yo); free(c->exon_os); free(c->exon_oe);
 	free(c->prot_gid); free(c->gene_pref); free(c->max_ori); free(c->sums); free(c->vtx_cnt); free(c->triples); free(c->vtx_rec); free(c->ctg_base);
 	free(c->g2s); free(c->seg_cnt); free(c->arcs); free(c->rp_x); free(c->rp_y); free(c->rp_iv); free(c->nl_cnt); free(c->scratch); free(c->head);
-	free(c->br_x); free(c->br_s1); free(c->br_gid); free(c->br_pairs); free(c->br_weak);
+	free(c->br_x); free(c->br_s1); free(c->br_gid); free(c->br_pairs); free(c->br_weak); free(c->def_sc); free(c->def_deg);
 	free(c->r_pid); free(c->r_cid); free(c->r_rank); free(c->r_sori); free(c->r_sadj); free(c->r_nex); free(c->r_offx); free(c->r_cs); free(c->r_ce); free(c->r_cm); free(c->r_rev);
 	free(c);
 }
@@ -824,8 +825,22 @@ int pgo_arc_set_current(pga_ctx_t *c, const pga_arc_part_t *arcs, int64_t n_arc,
 
 int pgo_arc_table(pga_ctx_t *c, const pga_arc_part_t **arcs, int64_t *n_arc) { *arcs = c->cur_tab, *n_arc = c->cur_tab_n; return PGA_OK; }
 
+/* the deferred form (seg_cnt == NULL): the work is done at once, the results are handed over by arc_round_finish */
+int pgo_arc_round_finish(pga_ctx_t *c, int32_t n_seg, int32_t *seg_cnt, int32_t *deg)
+{
+	if (c->def_sc == 0) return PGA_ERR_ARG;
+	memcpy(seg_cnt, c->def_sc, 2 * (size_t)n_seg * sizeof(int32_t)); memcpy(deg, c->def_deg, 2 * (size_t)n_seg * sizeof(int32_t));
+	free(c->def_sc); free(c->def_deg); c->def_sc = c->def_deg = 0;
+	return PGA_OK;
+}
+
 int pgo_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt, int32_t *deg)
 {
+	if (seg_cnt == 0) {
+		free(c->def_sc); free(c->def_deg);
+		c->def_sc = CALLOC(int32_t, 2 * (int64_t)n_seg), c->def_deg = CALLOC(int32_t, 2 * (int64_t)n_seg);
+		return pgo_arc_round_local(c, use_ori, n_seg, c->def_sc, c->def_deg);
+	}
 	int32_t *sc; pga_arc_part_t *arcs; int64_t n = 0, *n_arc = &n;
 	int rc = pgo_arc_round(c, use_ori, &sc, &arcs, n_arc);
 	if (rc != PGA_OK) return rc;
@@ -1061,7 +1076,7 @@ const pga_backend_t *pgo_backend(void)
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
 		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_arc_merge, pgo_arc_set_current, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
-		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs, pgo_host_alloc, pgo_host_free, pgo_arc_round_local, pgo_ctg_counts, pgo_gene_matrix, pgo_arc_table
+		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs, pgo_host_alloc, pgo_host_free, pgo_arc_round_local, pgo_ctg_counts, pgo_gene_matrix, pgo_arc_table, pgo_arc_round_finish
 	};
 	return &b;
 }

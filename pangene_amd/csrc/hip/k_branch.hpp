@@ -33,7 +33,7 @@ struct OutRank {
 // table iv[] in the compact form); k_n_local raises the hazard where it matters.  Two walkable hits of ONE gene in a group
 // (-S: opposite strands) make the choice of the representative itself order-dependent (branch.c:22-23): hazard at once.
 struct RepFill {
-	int64_t n_ent; int GL, Q, N; const int4 *zrec; const int32_t *zoff; const int4 *hb; uint32_t tag;
+	int64_t n_ent; int GL, Q, N; const int32_t *zx, *zy, *zg; const int2 *zst; const int32_t *zoff; const uint32_t *hbk; uint32_t tag;
 	const int4 *A; const int32_t *gid; const uint32_t *flags; const int32_t *rx, *goff, *ctg_base;
 	void *rp_out; int32_t *iv; int64_t *dcnt; int32_t *hz_list;
 };
@@ -47,38 +47,40 @@ __device__ __forceinline__ void rep_absent(const RepFill &a, int64_t e0, int n)
 }
 
 template <bool COMPACT>
-__global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a, const int32_t *cm)
+__global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 {
 	const int t = blockIdx.x * BLOCK + threadIdx.x;
 	if (t < a.Q && a.zoff[t] == a.zoff[t + 1]) rep_absent<COMPACT>(a, (int64_t)t * a.GL, a.GL); // a gene without hits in this shard
 	if (t >= a.N) return;
 	const int z = t;
-	// the loads are issued in as few dependent rounds as possible (the kernel is latency bound): round 1 = the three records around z
-	const int4 zr = a.zrec[z], zn = z + 1 < a.N ? a.zrec[z + 1] : make_int4(0, -2, -1, 0), zp = z > 0 ? a.zrec[z - 1] : make_int4(0, -2, -1, 0);
-	const int4 hbz = a.hb[z];
-	const int g = zr.z, j = zr.y >> 1;
-	if (zn.z == g && (zn.y >> 1) == j) return; // not the last hit of its (gene, genome) group
+	// the loads are issued in as few dependent rounds as possible, from 4-byte planes in gene-major order (the kernel is bound by
+	// latency and sectors, not by arithmetic): round 1 = genome / gene of z and of its two neighbours, z's walkable mark
+	const int g = a.zg[z], y = a.zy[z] & 0x7fffffff, j = y >> 1;
+	const bool has_n = z + 1 < a.N, has_p = z > 0;
+	const int gn = has_n ? a.zg[z + 1] : -1, yn = has_n ? (a.zy[z + 1] & 0x7fffffff) : 0, gp = has_p ? a.zg[z - 1] : -1, yp = has_p ? (a.zy[z - 1] & 0x7fffffff) : 0;
+	const uint32_t kb = a.hbk[z];
+	if (gn == g && (yn >> 1) == j) return; // not the last hit of its (gene, genome) group
 	// round 2: everything that hangs on the gene, the genome or the hit itself
-	const int z0 = a.zoff[g], gj = a.goff[j], rx0 = a.rx[gj], cb = a.ctg_base[j];
-	const int rx_z = a.rx[zr.x], cm_z = cm[zr.x];
-	const int4 a_z = a.A[zr.x];
+	const int z0 = a.zoff[g], gj = a.goff[j], cb = a.ctg_base[j], xz = a.zx[z];
+	const int2 st_z = a.zst[z]; // {cm, contig segment}
 	const int64_t e = (int64_t)g * a.GL + j;
 	// the genomes without a hit of this gene: before the first group, and between this group and the next
 	int gs = z;
-	if (zp.z == g && (zp.y >> 1) == j) { gs = z - 1; while (gs > z0 && (a.zrec[gs - 1].y >> 1) == j) --gs; }
+	if (gp == g && (yp >> 1) == j) { gs = z - 1; while (gs > z0 && ((a.zy[gs - 1] & 0x7fffffff) >> 1) == j) --gs; }
 	if (gs == z0 && j > 0) rep_absent<COMPACT>(a, (int64_t)g * a.GL, j);
-	const int jn = zn.z == g ? (zn.y >> 1) : a.GL;
+	const int jn = gn == g ? (yn >> 1) : a.GL;
 	if (jn > j + 1) rep_absent<COMPACT>(a, e + 1, jn - j - 1);
 	int q = z;
-	if (!ha_walk(hbz, a.tag)) { q = z - 1; while (q >= gs && !ha_walk(a.hb[q], a.tag)) --q; } // the group's last walkable hit
+	if (!hx_walk(kb, a.tag)) { q = z - 1; while (q >= gs && !hx_walk(a.hbk[q], a.tag)) --q; } // the group's last walkable hit
 	if (q < gs) { rep_absent<COMPACT>(a, e, 1); return; }
-	const int h = q == z ? zr.x : a.zrec[q].x;
-	const int rxh = q == z ? rx_z : a.rx[h], r = (rxh & 0x7fffffff) - (rx0 & 0x7fffffff);
-	const int4 ah = q == z ? a_z : a.A[h]; // {cs, seg, ce, pm}
-	const int cmh = q == z ? cm_z : cm[h];
+	const int h = q == z ? xz : a.zx[q];
+	const int2 st = q == z ? st_z : a.zst[q];
+	// round 3: the one gather into cs order -- the hit's rank among the walkable hits (and the rank at the genome's start)
+	const int rxh = a.rx[h], r = (rxh & 0x7fffffff) - (a.rx[gj] & 0x7fffffff);
 	int ivl = 0;
 	if (rxh < 0) { // member of a static tie group [ta, tb): its walkable members on either side, from the walkable ranks at the group's ends
 		const int lo = gj, hi = a.goff[j + 1];
+		const int4 ah = a.A[h]; // {cs, seg, ce, pm}
 		int ta = h, tb = h + 1;
 		while (ta > lo) { const int4 ap = a.A[ta - 1]; if (ap.y != ah.y || ap.x != ah.x) break; --ta; }
 		while (tb < hi) { const int4 ap = a.A[tb]; if (ap.y != ah.y || ap.x != ah.x) break; ++tb; }
@@ -89,15 +91,15 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a, const int32_t *cm
 			for (int p = ta; p < tb; ++p) same_gene = same_gene || (p != h && a.gid[p] == g && !(a.flags[p] & (PGA_F_FLT | PGA_F_SHADOW)));
 			if (same_gene || nb > 0xffff || na > 0xffff) {
 				atomicAdd((unsigned long long *)&a.dcnt[6], 1ull);
-				hz_note(&a.dcnt[14], a.hz_list, ah.y);
+				hz_note(&a.dcnt[14], a.hz_list, st.y);
 			} else ivl = nb << 16 | na;
 		}
 	}
-	const int cmw = cmh | (ivl ? (int)0x80000000 : 0);
+	const int cmw = st.x | (ivl ? (int)0x80000000 : 0);
 	if (COMPACT) {
-		((int2 *)a.rp_out)[e] = make_int2(cmw, (ah.y - cb) << 20 | r);
+		((int2 *)a.rp_out)[e] = make_int2(cmw, (st.y - cb) << 20 | r);
 		if (ivl) a.iv[e] = ivl;
-	} else ((int4 *)a.rp_out)[e] = make_int4(ah.y, r, cmw, ivl);
+	} else ((int4 *)a.rp_out)[e] = make_int4(st.y, r, cmw, ivl);
 }
 
 // hazard H2b inside pg_n_local: the pair's distance test failed, so the count test |r1 - r2| <= local_count decides, and at
@@ -337,8 +339,12 @@ __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, i
 // pg_get_arc as in the reference (pgpriv.h:99-107): scan the few arcs leaving v; vs/ve = arc range of each vertex
 __device__ __forceinline__ int arc_weak_v(const uint64_t *ax, const uint8_t *aw, const int32_t *vs, const int32_t *ve, uint32_t v, uint32_t w)
 {
-	for (int i = vs[v], e = ve[v]; i < e; ++i)
-		if ((uint32_t)ax[i] == w) return aw[i];
+	const int e = ve[v];
+	for (int i = vs[v]; i < e; i += 4) { // four targets per round trip (the list is a handful of arcs)
+		const uint32_t t0 = (uint32_t)ax[i], t1 = i + 1 < e ? (uint32_t)ax[i + 1] : ~0u, t2 = i + 2 < e ? (uint32_t)ax[i + 2] : ~0u, t3 = i + 3 < e ? (uint32_t)ax[i + 3] : ~0u;
+		const int k = t0 == w ? 0 : t1 == w ? 1 : t2 == w ? 2 : t3 == w ? 3 : -1;
+		if (k >= 0) return aw[i + k];
+	}
 	return 0;
 }
 

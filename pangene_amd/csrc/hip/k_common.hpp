@@ -51,12 +51,16 @@ __global__ void k_mail_pairs(const int32_t *a, const int32_t *b, int64_t *dcnt, 
 }
 
 // end of an arc round on the gene-major index: the counters for the host, then the round's overflow counter starts again
-__global__ void k_mail_round(int64_t *dcnt, int64_t *host_box)
+__global__ void k_mail_round(int64_t *dcnt, int64_t *host_box, int32_t *tail /* pinned, or NULL: {overflowed genes, invariant violations} of this round */)
 {
 	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
+	if (threadIdx.x == 0 && tail) tail[0] = (int32_t)dcnt[9], tail[1] = (int32_t)dcnt[3];
 	__syncthreads();
 	if (threadIdx.x == 0) dcnt[9] = 0;
 }
+
+// the doorbell of sync_st (pga_backend.hip): the host spins on this pinned word
+__global__ void k_ring(unsigned long long *door, unsigned long long seq) { __threadfence_system(); *door = seq; }
 
 __global__ void k_mail_flush(const int64_t *dcnt, int64_t *host_box)
 {
@@ -124,11 +128,12 @@ __device__ __forceinline__ void hz_note(int64_t *cnt14, int32_t *list, int seg)
 	if (at < (unsigned long long)PGA_HAZARD_CAP) list[at] = seg;
 }
 
-// Half-arc records (k_genes.hpp): per hit, in gene-major order, its successor (hf) and predecessor (hb) adjacency of the current
-// walk: {round tag << 21 | target vertex (gene << 1 | rev), distance, score of this hit, score of the other hit}.
+// Half-arc records (k_genes.hpp): per hit, in gene-major order, its successor (hf*) and predecessor (hb*) adjacency of the current
+// walk: key word = round tag << 21 | target vertex (gene << 1 | rev) in hfk / hbk, payload {distance, score of this hit, score
+// of the other hit, 0} in hfp / hbp.
 constexpr uint32_t HA_NONE = 0x1fffffu;  // "no adjacency" target (gene ids stay below 2^20 - 1)
 constexpr int HA_TAG_SHIFT = 21;
 constexpr uint32_t HA_TAG_MAX = 0x7ffu;
-__device__ __forceinline__ bool ha_valid(const int4 h, uint32_t tag) { return ((uint32_t)h.x >> HA_TAG_SHIFT) == tag && ((uint32_t)h.x & HA_NONE) != HA_NONE; }
-// a hit is walkable in this round exactly when the walk wrote its predecessor record in this round
-__device__ __forceinline__ bool ha_walk(const int4 hb, uint32_t tag) { return ((uint32_t)hb.x >> HA_TAG_SHIFT) == tag; }
+__device__ __forceinline__ bool hx_valid(uint32_t x, uint32_t tag) { return (x >> HA_TAG_SHIFT) == tag && (x & HA_NONE) != HA_NONE; }
+// a hit is walkable in this round exactly when the walk wrote its predecessor key in this round
+__device__ __forceinline__ bool hx_walk(uint32_t x, uint32_t tag) { return (x >> HA_TAG_SHIFT) == tag; }

@@ -32,17 +32,21 @@ __global__ __launch_bounds__(BLOCK) void k_zkey(const int32_t *gid, int n, uint6
 	if (h < n) key[h] = (uint64_t)(uint32_t)gid[h], val[h] = (uint32_t)h;
 }
 
-// zrec[z] = {X position, local genome << 1 | rev, gene, 0}; zpos[x] = z
-__global__ __launch_bounds__(BLOCK) void k_zrec(const uint32_t *perm, const uint64_t *ks, const int32_t *gnm, const uint32_t *flags, int n, int4 *zrec, int32_t *zpos)
+// The gene-major index as separate 4-byte planes (each kernel reads only the planes it needs):
+//   zx[z] = X position; zy[z] = local genome << 1 | rev, bit 31 = the only hit of its gene in its genome (nearly all are: the
+//   group logic of the gene kernels has nothing to do for it); zg[z] = gene; zst[z] = {cm, contig segment} (static);  zpos[x] = z
+struct ZIndex { int32_t *zx, *zy, *zg; int2 *zst; int32_t *zpos; };
+__global__ __launch_bounds__(BLOCK) void k_zrec(const uint32_t *perm, const uint64_t *ks, const int32_t *gnm, const uint32_t *flags, const int32_t *cm, const int32_t *seg, int n, ZIndex o)
 {
 	int z = blockIdx.x * BLOCK + threadIdx.x;
 	if (z >= n) return;
 	const int x = (int)perm[z];
-	// w: 1 = the only hit of its gene in its genome (nearly all are): the group logic of k_gene_arcs has nothing to do for it
 	const int gn = gnm[x];
 	const bool grp_prev = z > 0 && ks[z - 1] == ks[z] && gnm[(int)perm[z - 1]] == gn, grp_next = z + 1 < n && ks[z + 1] == ks[z] && gnm[(int)perm[z + 1]] == gn;
-	zrec[z] = make_int4(x, gn << 1 | ((flags[x] & PGA_F_REV) ? 1 : 0), (int)ks[z], (grp_prev || grp_next) ? 0 : 1);
-	zpos[x] = z;
+	o.zx[z] = x, o.zg[z] = (int)ks[z];
+	o.zy[z] = gn << 1 | ((flags[x] & PGA_F_REV) ? 1 : 0) | ((grp_prev || grp_next) ? 0 : (int)0x80000000);
+	o.zst[z] = make_int2(cm[x], seg[x]);
+	o.zpos[x] = z;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_zoff(const uint64_t *ks, int n, int Q, int32_t *zoff) // zoff[g] = first z with gene >= g
@@ -64,24 +68,24 @@ __global__ __launch_bounds__(BLOCK) void k_zpos_y(const int32_t *yperm, const in
 // (A) output step of the walk scan (cm order): previous walkable hit -> half-arc records
 // ------------------------------------------------------------------------------------------------
 struct OutHalfArcs {
-	const int4 *__restrict__ YA, *__restrict__ YB; const int32_t *__restrict__ zposy, *__restrict__ g2s; int4 *__restrict__ hf, *__restrict__ hb; uint32_t tag; int ori; int64_t *dcnt; int32_t *hz_list;
+	const int4 *__restrict__ YA, *__restrict__ YB; const int32_t *__restrict__ zposy, *__restrict__ g2s;
+	uint32_t *__restrict__ hfk, *__restrict__ hbk; int4 *__restrict__ hfp, *__restrict__ hbp; // key word / payload {distance, score of this hit, score of the other, 0} of the two half-arcs
+	uint32_t tag; int ori; int64_t *dcnt; int32_t *hz_list;
 	__device__ __forceinline__ void operator()(int64_t i, I32 incl, I32 ex) const
 	{
 		if (incl.v == ex.v) return; // not walkable (graph.c:108)
 		const int p = ex.v, pp = p >= 0 ? p : (int)i;
 		const int4 aA = YA[i], aB = YB[i], bA = YA[pp], bB = YB[pp]; // {seg, gid, genome, cm}, {score_ori, score_dom, gene of pid_dom0, X position << 1 | rev}: one round of loads
 		const int zi = zposy[i], zp = zposy[pp];
-		int4 rec = make_int4((int)(tag << HA_TAG_SHIFT | HA_NONE), 0, 0, 0);
-		if (p >= 0) {
-			if (bA.x == aA.x) { // same contig: adjacency p -> i (graph.c:113-121)
-				const uint32_t w = (uint32_t)aA.y << 1 | (uint32_t)(aB.w & 1), v = (uint32_t)bA.y << 1 | (uint32_t)(bB.w & 1);
-				const int sa = arc_score(aB, ori, g2s), sb = arc_score(bB, ori, g2s), d = aA.w - bA.w;
-				if (aA.w == bA.w) { atomicAdd((unsigned long long *)&dcnt[5], 1ull); hz_note(&dcnt[14], hz_list, aA.x); } // hazard H2a: equal cm
-				hf[zp] = make_int4((int)(tag << HA_TAG_SHIFT | w), d, sb, sa);       // v -> w,       s1 = score(v), s2 = score(w) (graph.c:117)
-				rec = make_int4((int)(tag << HA_TAG_SHIFT | (v ^ 1u)), d, sa, sb);          // w^1 -> v^1,   s1 = score(w), s2 = score(v) (graph.c:119)
-			}
+		uint32_t key = tag << HA_TAG_SHIFT | HA_NONE;
+		if (p >= 0 && bA.x == aA.x) { // same contig: adjacency p -> i (graph.c:113-121)
+			const uint32_t w = (uint32_t)aA.y << 1 | (uint32_t)(aB.w & 1), v = (uint32_t)bA.y << 1 | (uint32_t)(bB.w & 1);
+			const int sa = arc_score(aB, ori, g2s), sb = arc_score(bB, ori, g2s), d = aA.w - bA.w;
+			if (aA.w == bA.w) { atomicAdd((unsigned long long *)&dcnt[5], 1ull); hz_note(&dcnt[14], hz_list, aA.x); } // hazard H2a: equal cm
+			hfk[zp] = tag << HA_TAG_SHIFT | w, hfp[zp] = make_int4(d, sb, sa, 0); // v -> w,     s1 = score(v), s2 = score(w) (graph.c:117)
+			key = tag << HA_TAG_SHIFT | (v ^ 1u), hbp[zi] = make_int4(d, sa, sb, 0); // w^1 -> v^1, s1 = score(w), s2 = score(v) (graph.c:119)
 		}
-		hb[zi] = rec;
+		hbk[zi] = key; // written for EVERY walkable hit: "carries the round's tag" = "is walkable in this round"
 	}
 };
 
@@ -89,11 +93,11 @@ struct OutHalfArcs {
 // (B) one wave per gene (one workgroup for a gene with many hits or many neighbours)
 // ------------------------------------------------------------------------------------------------
 constexpr int GA_CAP_WAVE = 128, GA_CAP = 512; // distinct (orientation, target) pairs of one gene the LDS tables hold; more than GA_CAP = the round takes the sort path
-constexpr int GA_WAVE_HITS = 256;              // genes with more hits go to the workgroup kernel straight away
+constexpr int GA_WAVE_HITS = 512;              // genes with more hits go to the second kernel straight away
 constexpr int GA_BIG_STAGE = 2048;             // hits the workgroup kernel stages at a time
 
 struct GeneArcs {
-	const int4 *zrec; const int32_t *zoff; const int4 *hf, *hb; const int32_t *g2s;
+	const int32_t *zy; const int32_t *zoff; const uint32_t *hfk, *hbk; const int4 *hfp, *hbp; const int32_t *g2s;
 	int dbg; // tuning aid (PGA_GENE_DEBUG): 1 skip the table insertion, 2 skip the payload loads, 4 skip the output, 8 skip the group logic
 	int Q, S; uint32_t tag; int cap_log2; // table size actually used (<= GA_CAP; tests shrink it to reach the overflow paths)
 	int32_t *seg_cnt, *seg_gid;       // [2S] n_genome then tot_cnt (graph.c:125-126); [S] gene of each segment
@@ -117,18 +121,16 @@ template <int CAP, int STAGE> struct GeneTable {
 // window (groups that straddle a window border: rare) the same words come from global memory.
 template <int CAP, int STAGE> struct GeneWin {
 	const GeneArcs &a; const GeneTable<CAP, STAGE> &T; int lo, hi;
-	__device__ __forceinline__ int zy(int z) const { return (z >= lo && z < hi) ? (T.zy[z - lo] & 0x7fffffff) : a.zrec[z].y; }
-	__device__ __forceinline__ uint32_t fx(int z) const { return (z >= lo && z < hi) ? T.fx[z - lo] : (uint32_t)a.hf[z].x; }
-	__device__ __forceinline__ uint32_t bx(int z) const { return (z >= lo && z < hi) ? T.bx[z - lo] : (uint32_t)a.hb[z].x; }
+	__device__ __forceinline__ int zy(int z) const { return ((z >= lo && z < hi) ? T.zy[z - lo] : a.zy[z]) & 0x7fffffff; }
+	__device__ __forceinline__ uint32_t fx(int z) const { return (z >= lo && z < hi) ? T.fx[z - lo] : a.hfk[z]; }
+	__device__ __forceinline__ uint32_t bx(int z) const { return (z >= lo && z < hi) ? T.bx[z - lo] : a.hbk[z]; }
 };
-__device__ __forceinline__ bool hx_valid(uint32_t x, uint32_t tag) { return (x >> HA_TAG_SHIFT) == tag && (x & HA_NONE) != HA_NONE; }
-__device__ __forceinline__ bool hx_walk(uint32_t x, uint32_t tag) { return (x >> HA_TAG_SHIFT) == tag; }
 
 // NT cooperating threads (one wave: 64, one workgroup: 256), tid in [0, NT).  Returns false when the table overflowed.
 template <int NT, int CAP, int STAGE>
 __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, STAGE> &T, const int g, const int sid, const int tid, const int cap_log2)
 {
-	constexpr int HALO = STAGE >= 1024 ? 32 : 0; // the wave kernel stages a whole gene at once
+	constexpr int HALO = STAGE >= 1024 ? 32 : 0; // the first kernel stages a whole gene at once
 	const int z0 = a.zoff[g], z1 = a.zoff[g + 1], cap = 1 << cap_log2;
 	for (int k = tid; k < cap; k += NT) T.key[k] = 0xffffffffu, T.ng[k] = 0, T.tot[k] = 0, T.sd[k] = 0, T.s1[k] = 0, T.s2[k] = 0;
 	if (tid == 0) T.n_tot = 0, T.n_gen = 0, T.over = 0, T.m = 0, T.m0 = 0;
@@ -137,7 +139,7 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 		const int c1 = c0 + (STAGE - 2 * HALO) < z1 ? c0 + (STAGE - 2 * HALO) : z1;
 		GeneWin<CAP, STAGE> W = { a, T, c0 - HALO > z0 ? c0 - HALO : z0, c1 + HALO < z1 ? c1 + HALO : z1 };
 		if (NT == 64) wave_sync(); else __syncthreads(); // the previous window is done with (and the table is clear)
-		for (int z = W.lo + tid; z < W.hi; z += NT) { const int4 zr = a.zrec[z]; T.zy[z - W.lo] = zr.y | (zr.w ? (int)0x80000000 : 0), T.fx[z - W.lo] = (uint32_t)a.hf[z].x, T.bx[z - W.lo] = (uint32_t)a.hb[z].x; } // bit 31: singleton group
+		for (int z = W.lo + tid; z < W.hi; z += NT) T.zy[z - W.lo] = a.zy[z], T.fx[z - W.lo] = a.hfk[z], T.bx[z - W.lo] = a.hbk[z]; // 12 bytes a hit (zy bit 31: singleton group)
 		if (NT == 64) wave_sync(); else __syncthreads();
 		for (int z = c0 + tid; z < c1; z += NT) {
 			if (!hx_walk(T.bx[z - W.lo], a.tag)) continue;
@@ -172,9 +174,9 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 					}
 				}
 				if (!leader) continue;
-				const int4 h = (a.dbg & 2) ? make_int4(0, 5, 6, 7) : dir ? a.hb[z] : a.hf[z]; // the payload: distance and the two scores
-				int m1 = h.z, m2 = h.w;
-				unsigned long long sd = (unsigned long long)(long long)h.y;
+				const int4 h = (a.dbg & 2) ? make_int4(5, 6, 7, 0) : dir ? a.hbp[z] : a.hfp[z]; // the payload: distance and the two scores
+				int m1 = h.y, m2 = h.z;
+				unsigned long long sd = (unsigned long long)(long long)h.x;
 				if (n > 1) // rare: the same adjacency twice in one genome
 					for (int q = z + 1; q < ge; ++q) {
 						const int rq = W.zy(q) & 1;
@@ -182,8 +184,8 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 						for (int d2 = 0; d2 < 2; ++d2) {
 							const uint32_t ox = d2 ? W.bx(q) : W.fx(q);
 							if (!hx_valid(ox, a.tag) || ((uint32_t)(d2 ? !rq : rq) << HA_TAG_SHIFT | (ox & HA_NONE)) != key) continue;
-							const int4 o = d2 ? a.hb[q] : a.hf[q];
-							sd += (unsigned long long)(long long)o.y, m1 = m1 > o.z ? m1 : o.z, m2 = m2 > o.w ? m2 : o.w;
+							const int4 o = d2 ? a.hbp[q] : a.hfp[q];
+							sd += (unsigned long long)(long long)o.x, m1 = m1 > o.y ? m1 : o.y, m2 = m2 > o.z ? m2 : o.z;
 						}
 					}
 				m1 = m1 > 0 ? m1 : 0, m2 = m2 > 0 ? m2 : 0; // the reference's running maxima start at 0 (graph.c:133)
@@ -246,22 +248,21 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 	return true;
 }
 
+// one workgroup per gene: at the usual sizes (a few hundred hits of a gene in the shard) its 256 threads see every hit in one go
 __global__ __launch_bounds__(BLOCK) void k_gene_arcs_wave(GeneArcs a)
 {
-	__shared__ GeneTable<GA_CAP_WAVE, GA_WAVE_HITS> T[BLOCK / WAVE];
-	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int g = blockIdx.x * (BLOCK / WAVE) + w;
-	if (g >= a.Q) return;
+	__shared__ GeneTable<GA_CAP_WAVE, GA_WAVE_HITS> T;
+	const int g = blockIdx.x, tid = threadIdx.x;
 	const int sid = a.g2s[g], z0 = a.zoff[g], z1 = a.zoff[g + 1];
 	if (sid < 0) { // not a vertex: none of its hits may be walkable (graph.c:111)
-		for (int z = z0 + lane; z < z1; z += WAVE)
-			if (ha_walk(a.hb[z], a.tag)) atomicAdd((unsigned long long *)&a.dcnt[3], 1ull);
-		if (lane == 0) a.big_list[g] = 0;
+		for (int z = z0 + tid; z < z1; z += BLOCK)
+			if (hx_walk(a.hbk[z], a.tag)) atomicAdd((unsigned long long *)&a.dcnt[3], 1ull);
+		if (tid == 0) a.big_list[g] = 0;
 		return;
 	}
 	const int cl = a.cap_log2 < 7 ? a.cap_log2 : 7;
-	if (z1 - z0 <= GA_WAVE_HITS && gene_arcs_one<WAVE, GA_CAP_WAVE, GA_WAVE_HITS>(a, T[w], g, sid, lane, cl)) { if (lane == 0) a.big_list[g] = 0; return; }
-	if (lane == 0) a.big_list[g] = 1; // many hits, or many neighbours: the workgroup kernel takes it
+	const bool done = z1 - z0 <= GA_WAVE_HITS && gene_arcs_one<BLOCK, GA_CAP_WAVE, GA_WAVE_HITS>(a, T, g, sid, tid, cl);
+	if (tid == 0) a.big_list[g] = done ? 0 : 1; // many hits, or many neighbours: the second kernel takes it
 }
 
 __global__ __launch_bounds__(BLOCK) void k_gene_arcs_big(GeneArcs a)
@@ -300,36 +301,37 @@ __global__ __launch_bounds__(BLOCK) void k_arc_compact(const int4 *gmeta, const 
 // ------------------------------------------------------------------------------------------------
 // pg_mark_branch_flt_hit (branch.c:108-145): a hit is marked by the weak arcs among its own two half-arcs
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_mark_hits_z(const int4 *zrec, const int4 *hf, const int4 *hb, uint32_t tag, int n, const int32_t *g2s,
+__global__ __launch_bounds__(BLOCK) void k_mark_hits_z(const int32_t *zx, const int32_t *zy, const int32_t *zg, const uint32_t *hfk, const uint32_t *hbk, uint32_t tag, int n, const int32_t *g2s,
                                                         const uint64_t *ax, const uint8_t *aw, const int32_t *vs, const int32_t *ve, const uint8_t *vwk,
                                                         uint32_t *flags, int64_t *cnt, int then_filter)
 {
 	int z = blockIdx.x * BLOCK + threadIdx.x;
 	bool marked = false;
 	if (z < n) {
-		const int4 hbz = hb[z], hfz = hf[z], zr = zrec[z]; // three independent loads up front: the chain below is then two levels deep
-		const bool walk = ha_walk(hbz, tag);
-		if (walk) {
-			const int sid = g2s[zr.z], rev = zr.y & 1;
+		const uint32_t kb = hbk[z], kf = hfk[z]; // 16 bytes a hit, all independent loads
+		const int y = zy[z], g = zg[z];
+		if (hx_walk(kb, tag)) {
+			const int sid = g2s[g], rev = y & 1;
 			int nw = 0;
 #pragma unroll
 			for (int dir = 0; dir < 2; ++dir) {
-				const int4 h = dir ? hbz : hfz;
-				if (!ha_valid(h, tag) || sid < 0) continue;
-				const uint32_t u = (uint32_t)sid << 1 | (uint32_t)(dir ? !rev : rev), t = (uint32_t)h.x & HA_NONE;
-				if (!vwk[u]) continue; // the vertex has no weak out-arc (the common case)
+				const uint32_t h = dir ? kb : kf;
+				if (!hx_valid(h, tag) || sid < 0) continue;
+				const uint32_t u = (uint32_t)sid << 1 | (uint32_t)(dir ? !rev : rev), t = h & HA_NONE;
+				if (!vwk[u]) continue; // the vertex has no weak out-arc
 				const uint32_t w = (uint32_t)g2s[t >> 1] << 1 | (t & 1u);
 				const int e = arc_weak_v(ax, aw, vs, ve, u, w); // dir 0: arc v -> w marks the earlier hit (branch.c:128-130); dir 1: w^1 -> v^1 marks the later one (131-133)
 				nw = nw > e ? nw : e;
 			}
 			if (nw) { // rare: only now is the hit's flag word touched
-				const uint32_t f = flags[zr.x];
+				const int x = zx[z];
+				const uint32_t f = flags[x];
 				// (then_filter: PG_SET_FILTER(weak_br == 2), graph.c:309 -- only a hit marked here can newly have weak_br == 2)
-				if (nw > (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT)) flags[zr.x] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT | ((then_filter && nw == 2) ? PGA_F_FLT : 0u);
+				if (nw > (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT)) flags[x] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT | ((then_filter && nw == 2) ? PGA_F_FLT : 0u);
 				marked = true;
 			}
 		}
-		if (cnt && !marked) marked = (flags[zr.x] & PGA_F_WEAK_MASK) != 0; // log-only counter (branch.c:137-139): every hit with weak_br != 0
+		if (cnt && !marked) marked = (flags[zx[z]] & PGA_F_WEAK_MASK) != 0; // log-only counter (branch.c:137-139): every hit with weak_br != 0
 	}
 	if (cnt) {
 		const unsigned long long mk = __ballot(marked);

@@ -109,11 +109,14 @@ struct pga_ctx {
 	DevPool pool;
 	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
 	// gene-major index (k_genes.hpp): hits by (gene, genome, X position); half-arc records of the current walk
-	int4 *zrec = 0; int32_t *zpos = 0, *zposy = 0, *zoff = 0; int4 *hf = 0, *hb = 0;
+	int32_t *zx = 0, *zy = 0, *zg = 0; int2 *zst = 0; int32_t *zpos = 0, *zposy = 0, *zoff = 0; // gene-major planes (k_genes.hpp)
+	uint32_t *hfk = 0, *hbk = 0; int4 *hfp = 0, *hbp = 0; // half-arc key words and payloads
 	bool z_valid = false, ha_valid = false; uint32_t round_tag = 0; int ha_ori = -1;
 	const pga_arc_part_t *cur_tab = nullptr; int64_t cur_tab_n = 0; // the table of pga_arc_set_current
 	bool table_sparse = false; // the current arc table lives in the genes' stretches (arc_round_genes) and has not been compacted
 	int32_t *h_round = nullptr; size_t h_round_cap = 0; // pinned: segment counters + degrees of a round
+	unsigned long long *door = nullptr, *door_dev = nullptr, door_seq = 0; // pinned doorbell of sync_st
+	unsigned long long sync_epoch = 0, arc_epoch = 0; bool arc_deferred = false, arc_done = false, force_sort_once = false; std::vector<int32_t> def_host; // a round whose results nobody has waited for yet (pga_arc_round_finish)
 	int4 *yrecA = 0, *yrecB = 0; bool yrec_valid = false; // Y-order static records (k_pack_yrec), rebuilt after anything that changes their sources
 	int64_t br_np_seen = 0; // the last pair count the host got to know (sizes the next grid)
 	int64_t br_n = 0, br_np = 0, br_cap = 0; int32_t br_S = 0; // arcs / pairs (-1: not known on the host yet) / pair capacity / segments of the last branch_pairs
@@ -187,7 +190,30 @@ extern "C" const char *pga_strerror(int code)
 // ================================================================================================
 // host side of the ABI
 // ================================================================================================
-static int sync_st(pga_ctx *c) { HIPCHK(hipStreamSynchronize(c->st)); return 0; }
+// Wait until everything issued so far has finished.  A run waits ~45 times for results of a few hundred bytes, and
+// hipStreamSynchronize costs tens of microseconds each time (the host thread is put to sleep and woken up).  So: one more
+// kernel at the end of the queue writes a sequence number into a pinned word (the "doorbell") and the host thread spins on it;
+// the stream is in order, so everything before the ring -- kernels and copies -- is done when it rings.  If it has not rung after
+// a generous while (a kernel fault, a hung device) the ordinary call takes over and reports what happened.
+static int sync_st(pga_ctx *c)
+{
+	static const bool spin = getenv("PANGENE_NO_SPIN_WAIT") == nullptr;
+	if (!spin || c->door == nullptr) { ++c->sync_epoch; HIPCHK(hipStreamSynchronize(c->st)); return 0; }
+	++c->sync_epoch;
+	const unsigned long long seq = ++c->door_seq;
+	hipLaunchKernelGGL(k_ring, dim3(1), dim3(1), 0, c->st, c->door_dev, seq);
+	const volatile unsigned long long *d = c->door;
+	timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (unsigned long long it = 1; *d != seq; ++it) {
+		__builtin_ia32_pause();
+		if ((it & 0xffff) == 0) {
+			timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+			if ((t.tv_sec - t0.tv_sec) + (t.tv_nsec - t0.tv_nsec) * 1e-9 > 2.0) break; // something is wrong or very slow: let the runtime wait and tell
+		}
+	}
+	if (*d != seq) HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
 
 static int bits_for(uint32_t maxv) { int b = 1; while (b < 32 && (maxv >> b)) ++b; return b; }
 
@@ -280,6 +306,7 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 	if (c->h_stage) (void)hipHostFree(c->h_stage);
 	if (c->h_g2s) (void)hipHostFree(c->h_g2s);
 	if (c->h_round) (void)hipHostFree(c->h_round);
+	if (c->door) (void)hipHostFree(c->door);
 	if (c->h_ndl) (void)hipHostFree(c->h_ndl);
 	if (c->g2s_done) (void)hipEventDestroy(c->g2s_done);
 	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
@@ -332,6 +359,9 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->own_stream = true;
 	HIPCHK(hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(int64_t), hipHostMallocDefault));
 	HIPCHK(hipHostGetDevicePointer((void **)&c->h_box, c->h_cnt, 0));
+	HIPCHK(hipHostMalloc((void **)&c->door, 64, hipHostMallocDefault));
+	*c->door = 0;
+	HIPCHK(hipHostGetDevicePointer((void **)&c->door_dev, c->door, 0));
 	TRY(dalloc(c, &c->dcnt, 16));
 	// persistent arrays
 	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
@@ -340,7 +370,8 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(dalloc(c, &c->rank, N)); TRY(dalloc(c, &c->sdom, N)); TRY(dalloc(c, &c->pdom, N)); TRY(dalloc(c, &c->pdom0, N)); TRY(dalloc(c, &c->flags, N));
 	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->ctg_base, GL + 1)); TRY(dalloc(c, &c->inv, N)); TRY(dalloc(c, &c->headpos, GL + 1)); TRY(dalloc(c, &c->exon, E));
 	TRY(dalloc(c, &c->eoff, GL + 1)); TRY(dalloc(c, &c->woff, GL + 1));
-	TRY(dalloc(c, &c->zrec, N)); TRY(dalloc(c, &c->zpos, N)); TRY(dalloc(c, &c->zposy, N)); TRY(dalloc(c, &c->zoff, (size_t)c->Q + 2)); TRY(dalloc(c, &c->hf, N)); TRY(dalloc(c, &c->hb, N));
+	TRY(dalloc(c, &c->zx, N)); TRY(dalloc(c, &c->zy, N)); TRY(dalloc(c, &c->zg, N)); TRY(dalloc(c, &c->zst, N)); TRY(dalloc(c, &c->zpos, N)); TRY(dalloc(c, &c->zposy, N)); TRY(dalloc(c, &c->zoff, (size_t)c->Q + 2));
+	TRY(dalloc(c, &c->hfk, N)); TRY(dalloc(c, &c->hbk, N)); TRY(dalloc(c, &c->hfp, N)); TRY(dalloc(c, &c->hbp, N));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q)); TRY(dalloc(c, &c->hrank, c->P));
 	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
 	TRY(dalloc_commit(c));
@@ -392,7 +423,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(upload(c, c->ctg_base, ctg_base.data(), (size_t)GL + 1)); TRY(upload(c, c->eoff, eoff.data(), (size_t)GL + 1)); TRY(upload(c, c->woff, woff.data(), (size_t)GL + 1));
 	TRY(upload(c, c->prot_gid, sh->prot_gid, c->P)); TRY(upload(c, c->gene_pref, sh->gene_pref, c->Q));
 	// half-arc records are validated by a round tag: none may survive from an earlier context whose memory this one inherited
-	if (N) { HIPCHK(hipMemsetAsync(c->hf, 0xff, sizeof(int4) * (size_t)N, c->st)); HIPCHK(hipMemsetAsync(c->hb, 0xff, sizeof(int4) * (size_t)N, c->st)); }
+	if (N) { HIPCHK(hipMemsetAsync(c->hfk, 0xff, sizeof(uint32_t) * (size_t)N, c->st)); HIPCHK(hipMemsetAsync(c->hbk, 0xff, sizeof(uint32_t) * (size_t)N, c->st)); }
 	if (N) hipLaunchKernelGGL(k_unblock, dim3(nblk(N)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, N, up);
 	if (E) hipLaunchKernelGGL(k_unblock_exons, dim3(nblk(E)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, E, c->exon);
 	{ // work buffers shared by every sort / scan of the run: sized for the largest input (2N temp arcs)
@@ -690,7 +721,7 @@ static int ensure_z(pga_ctx *c)
 	hipLaunchKernelGGL(k_zkey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gid, N, key, val);
 	uint64_t *ks; uint32_t *vs;
 	TRY(radix_sort_pool(c, key, val, N, bits_for((uint32_t)std::max(1, c->Q)), &ks, &vs));
-	hipLaunchKernelGGL(k_zrec, dim3(nblk(N)), dim3(BLOCK), 0, c->st, vs, ks, c->gnm, c->flags, N, c->zrec, c->zpos);
+	hipLaunchKernelGGL(k_zrec, dim3(nblk(N)), dim3(BLOCK), 0, c->st, vs, ks, c->gnm, c->flags, c->cm, c->seg, N, ZIndex{c->zx, c->zy, c->zg, c->zst, c->zpos});
 	hipLaunchKernelGGL(k_zoff, dim3(nblk(c->Q + 1)), dim3(BLOCK), 0, c->st, ks, N, c->Q, c->zoff);
 	hipLaunchKernelGGL(k_zpos_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, c->zpos, N, c->zposy);
 	c->z_valid = true, c->ha_valid = false;
@@ -705,14 +736,14 @@ static int ensure_half_arcs(pga_ctx *c, int use_ori)
 	ensure_yrec(c);
 	if (c->ha_valid && c->ha_ori == use_ori) return 0;
 	if (++c->round_tag > HA_TAG_MAX) { // tags wrap: forget every old record
-		HIPCHK(hipMemsetAsync(c->hf, 0xff, sizeof(int4) * (size_t)c->N, c->st));
-		HIPCHK(hipMemsetAsync(c->hb, 0xff, sizeof(int4) * (size_t)c->N, c->st));
+		HIPCHK(hipMemsetAsync(c->hfk, 0xff, sizeof(uint32_t) * (size_t)c->N, c->st));
+		HIPCHK(hipMemsetAsync(c->hbk, 0xff, sizeof(uint32_t) * (size_t)c->N, c->st));
 		c->round_tag = 1;
 	}
 	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(c->N));
 	int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
 	if (!tile || !hzl) return PGA_ERR_NOMEM;
-	device_scan<I32>(InWalk{c->flags, c->yperm}, OutHalfArcs{c->yrecA, c->yrecB, c->zposy, c->g2s, c->hf, c->hb, c->round_tag, use_ori, c->dcnt, hzl}, c->N, tile, OpMax{}, I32{-1}, c->st);
+	device_scan<I32>(InWalk{c->flags, c->yperm}, OutHalfArcs{c->yrecA, c->yrecB, c->zposy, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->dcnt, hzl}, c->N, tile, OpMax{}, I32{-1}, c->st);
 	c->ha_valid = true, c->ha_ori = use_ori;
 	return 0;
 }
@@ -752,11 +783,11 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	if (!big) return PGA_ERR_NOMEM;
 	static const int cap_log2 = [] { const char *e = getenv("PANGENE_GENE_TABLE_LOG2"); const int v = e ? atoi(e) : 9; return v < 1 ? 1 : v > 9 ? 9 : v; }();
 	static const int gdbg = [] { const char *e = getenv("PGA_GENE_DEBUG"); return e ? atoi(e) : 0; }();
-	GeneArcs ga = { c->zrec, c->zoff, c->hf, c->hb, c->g2s, gdbg, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta,
+	GeneArcs ga = { c->zy, c->zoff, c->hfk, c->hbk, c->hfp, c->hbp, c->g2s, gdbg, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta,
 	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt };
-	hipLaunchKernelGGL(k_gene_arcs_wave, dim3(nblk(c->Q, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, ga);
+	hipLaunchKernelGGL(k_gene_arcs_wave, dim3((unsigned)c->Q), dim3(BLOCK), 0, c->st, ga);
 	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 8 * c->n_cu)), dim3(BLOCK), 0, c->st, ga);
-	hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box); // invariant / overflow counters for the host; the overflow counter starts again
+	hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box, h_round_dev ? h_round_dev + 4 * (size_t)S : (int32_t *)nullptr); // invariant / overflow counters for the host; the overflow counter starts again
 	return 0;
 }
 
@@ -858,13 +889,24 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 // pg_gen_arc for a run that is not sharded: the round's table is the graph's table at once (what pga_arc_set_current would
 // derive is produced by the same kernels), and the only things the host needs -- segment counters, out-degrees, table size --
 // arrive with ONE wait at the end.
+static int arc_round_check(pga_ctx *c, int S, int32_t *seg_cnt_host, int32_t *deg_host) // after a wait: 0 ok, 1 = a gene overflowed its table, < 0 error
+{
+	const int n_vtx = 2 * S;
+	const int32_t *tail = c->h_round + 2 * (size_t)n_vtx; // {overflowed genes, invariant violations} of THIS round (the mailbox may have moved on)
+	if (tail[1]) return PGA_ERR_INVARIANT;
+	if (tail[0]) return 1;
+	if (n_vtx) memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
+	return 0;
+}
+
 extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt_host, int32_t *deg_host)
 {
 	const int S = n_seg, n_vtx = 2 * S;
 	if (S != c->n_seg) return PGA_ERR_ARG;
-	if (c->N && !arc_sort_path_forced()) {
+	c->arc_deferred = false, c->arc_done = false;
+	if (c->N && !arc_sort_path_forced() && !c->force_sort_once) {
 		int32_t *seg_cnt, *deg;
-		const size_t need = sizeof(int32_t) * 2 * (size_t)n_vtx + 64;
+		const size_t need = sizeof(int32_t) * (2 * (size_t)n_vtx + 2) + 64;
 		if (c->h_round_cap < need) {
 			if (c->h_round) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipHostFree(c->h_round); c->h_round = nullptr; }
 			HIPCHK(hipHostMalloc((void **)&c->h_round, need + need / 2, hipHostMallocDefault));
@@ -873,20 +915,40 @@ extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg,
 		int32_t *h_dev = nullptr;
 		HIPCHK(hipHostGetDevicePointer((void **)&h_dev, c->h_round, 0));
 		TRY(arc_round_genes(c, use_ori, &seg_cnt, &deg, h_dev)); // the gene kernels write the counters and degrees into the pinned buffer
+		c->br_n = 2 * (int64_t)c->N + 2, c->br_S = S, c->br_np = 0; // (br_n: extent of the table arrays; the arcs are counted when somebody asks, pga_arc_table)
+		if (seg_cnt_host == nullptr) { c->arc_deferred = true, c->arc_epoch = c->sync_epoch; return 0; } // the caller collects the results later (pga_arc_round_finish)
 		TRY(sync_st(c));
-		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
-		if (c->h_cnt[9] == 0) {
-			if (n_vtx) memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
-			c->br_n = 2 * (int64_t)c->N + 2, c->br_S = S, c->br_np = 0; // (br_n: extent of the table arrays; the arcs are counted when somebody asks, pga_arc_table)
-			return 0;
-		}
+		const int rc = arc_round_check(c, S, seg_cnt_host, deg_host);
+		if (rc <= 0) return rc;
+	}
+	if (seg_cnt_host == nullptr) { // deferred call on the sort path: done at once, the results wait in host memory for pga_arc_round_finish
+		c->def_host.assign(2 * (size_t)n_vtx + 1, 0);
+		TRY(pga_arc_round_local(c, use_ori, n_seg, c->def_host.data(), c->def_host.data() + n_vtx));
+		c->arc_deferred = true, c->arc_done = true;
+		return 0;
 	}
 	int32_t *seg_cnt; pga_arc_part_t *arcs; int64_t n = 0;
-	c->table_sparse = false;
+	c->table_sparse = false, c->force_sort_once = false;
 	TRY(arc_round_sorted(c, use_ori, &seg_cnt, &arcs, &n));
 	TRY(pga_arc_set_current(c, arcs, n, S, deg_host));
 	if (n_vtx) TRY(pga_fetch(c, seg_cnt_host, seg_cnt, sizeof(int32_t) * (size_t)n_vtx));
 	return 0;
+}
+
+extern "C" int pga_arc_round_finish(pga_ctx_t *c, int32_t n_seg, int32_t *seg_cnt_host, int32_t *deg_host)
+{
+	if (!c->arc_deferred) return PGA_ERR_ARG;
+	c->arc_deferred = false;
+	if (c->arc_done) { // the round took the sort path and is complete
+		const size_t n_vtx = 2 * (size_t)n_seg;
+		c->arc_done = false;
+		if (n_vtx) memcpy(seg_cnt_host, c->def_host.data(), sizeof(int32_t) * n_vtx), memcpy(deg_host, c->def_host.data() + n_vtx, sizeof(int32_t) * n_vtx);
+		return 0;
+	}
+	if (c->sync_epoch == c->arc_epoch) TRY(sync_st(c)); // nobody has waited since the round was queued
+	const int rc = arc_round_check(c, n_seg, seg_cnt_host, deg_host);
+	if (rc == 1) c->force_sort_once = true; // the caller repeats the round (without deferring): it takes the sort path
+	return rc;
 }
 
 extern "C" int pga_arc_table(pga_ctx_t *c, const pga_arc_part_t **arcs, int64_t *n_arc)
@@ -973,10 +1035,10 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		if (!rx || !tile) return PGA_ERR_NOMEM;
 		TRY(ensure_half_arcs(c, c->ha_ori < 0 ? 0 : c->ha_ori)); // which hits are walkable, gene-major (normally left by the arc round just before)
 		device_scan<I32>(InWalkX{c->flags}, OutRank{rx, c->flags}, N, tile, OpSum{}, I32{0}, c->st); // rank among the walkable hits, cs order
-		RepFill rf = { n_ent, GL, Q, N, c->zrec, c->zoff, c->hb, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl };
+		RepFill rf = { n_ent, GL, Q, N, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl };
 		const unsigned nb = nblk(std::max(N, Q));
-		if (c->rp_compact) hipLaunchKernelGGL((k_rep_fill<true>), dim3(nb), dim3(BLOCK), 0, c->st, rf, c->cm);
-		else hipLaunchKernelGGL((k_rep_fill<false>), dim3(nb), dim3(BLOCK), 0, c->st, rf, c->cm);
+		if (c->rp_compact) hipLaunchKernelGGL((k_rep_fill<true>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+		else hipLaunchKernelGGL((k_rep_fill<false>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
 	} else if (n_ent) {
 		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(4 * n_ent)), dim3(BLOCK), 0, c->st, (int32_t *)rp, 4 * n_ent, -1); // "absent" in either record form
 	}
@@ -1117,7 +1179,7 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 		const uint8_t *vwk = (const uint8_t *)c->pool.get(S_VWK, 0);
 		if (!ax || !aw || !vs || !ve || !vwk) return PGA_ERR_NOMEM;
 		if (n_marked) HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
-		hipLaunchKernelGGL(k_mark_hits_z, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->zrec, c->hf, c->hb, c->round_tag, N, c->g2s, ax, aw, vs, ve, vwk, c->flags,
+		hipLaunchKernelGGL(k_mark_hits_z, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->zx, c->zy, c->zg, c->hfk, c->hbk, c->round_tag, N, c->g2s, ax, aw, vs, ve, vwk, c->flags,
 		                   n_marked ? c->dcnt + 2 : (int64_t *)nullptr, then_filter);
 		if (then_filter) c->walk_valid = false, c->ha_valid = false; // else: weak_br does not enter the walkable test, the half-arcs stay valid
 	} else {
@@ -1324,7 +1386,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish
 	};
 	return &b;
 }

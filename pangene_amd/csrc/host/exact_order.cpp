@@ -44,7 +44,9 @@ void set_exact_mode(int m) { g_exact_mode = m; }
 // build the tracked segments from the host arrays, which must still be in FILE order
 void exact_init(const pg_data_t *d, DataExt *ext)
 {
+	exact_shutdown(ext); // nobody may still be replaying the segments that go away
 	ext->xsegs.clear();
+	ext->xreplayed = false, ext->xsegs_n_genome = d->n_genome;
 	const int mode = exact_mode();
 	if (mode == 0) return;
 	// genomes are independent: host threads collect their segments, which are then appended in genome order
@@ -166,12 +168,10 @@ static void exact_wait(DataExt *ext)
 
 // start of a run: the arrays are in file order (read.c:232-234).  The replay depends on the keys only, so it runs
 // on background threads while the GPU does stage A and B; the first consumer joins them.
-void exact_begin(DataExt *ext)
+static void spawn_replay(DataExt *ext)
 {
-	exact_wait(ext);
-	ext->head_file.assign(ext->local_genomes.size(), -1);
-	ext->x_sorts[0] = ext->x_sorts[1] = 0;
-	for (ExactSeg &s : ext->xsegs) s.pushed[0].clear(), s.pushed[1].clear();
+	if (ext->xreplayed) return;
+	ext->xreplayed = true; // (valid once the workers have been joined: exact_wait)
 	if (ext->xsegs.empty()) return;
 	const bool all = exact_mode() == 2;
 	size_t tot = 0;
@@ -187,6 +187,33 @@ void exact_begin(DataExt *ext)
 				replay(ext->xsegs[i], all || ext->xsegs[i].full);
 			}
 		});
+}
+
+// start of a run: the arrays are in file order (read.c:232-234).  The replay depends on the keys only: it runs on background
+// threads, started as early as the reader (exact_prefetch) or here, while the GPU does stages A and B; the first consumer joins
+// them.  A repeated run on the same shard (pg_rerun_resident) finds the replay done.
+void exact_begin(DataExt *ext)
+{
+	exact_wait(ext);
+	ext->head_file.assign(ext->local_genomes.size(), -1);
+	ext->x_sorts[0] = ext->x_sorts[1] = 0;
+	for (ExactSeg &s : ext->xsegs) s.pushed[0].clear(), s.pushed[1].clear();
+	spawn_replay(ext);
+}
+
+// called by the reader when a batch of files has been committed: the tracked segments and their replay need nothing but the
+// parsed keys, so they are out of the way before pg_post_process even starts
+void exact_prefetch(const pg_data_t *d, DataExt *ext)
+{
+	ext->local_genomes.clear();
+	ext->is_local.resize((size_t)d->n_genome, 1);
+	for (int32_t j = 0; j < d->n_genome; ++j)
+		if (ext->is_local[(size_t)j]) ext->local_genomes.push_back(j);
+	for (int32_t j : ext->local_genomes) if ((size_t)j < ext->hits_sorted.size() && ext->hits_sorted[(size_t)j]) return; // records already moved: pg_post_process sorts it out
+	ext->extra_ctgs.clear();
+	exact_init(d, ext);
+	ext->exact_mode_of_segs = exact_mode();
+	spawn_replay(ext);
 }
 
 // One pg_hit_sort(g, by_cm) of the reference happened: hand the orders that changed to the backend.

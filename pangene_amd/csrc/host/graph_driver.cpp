@@ -382,9 +382,11 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 		BE_CALL(build_backend(opt, d, ext), "create"); // (rest of the) pack + allocation + H2D
 		g_pack_sec += ext->pack_sec, ext->pack_sec = 0.0;
 		const double tx0 = now_sec();
-		exact_init(d, ext);
+		if (!(ext->xsegs_n_genome == d->n_genome && ext->exact_mode_of_segs == exact_mode() && ext->extra_ctgs.empty() && ext->xreplayed)) { // else: the reader did it
+			exact_init(d, ext);
+			ext->exact_mode_of_segs = exact_mode();
+		}
 		if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[post_process] exact_init %.3f ms\n", (now_sec() - tx0) * 1e3);
-		ext->exact_mode_of_segs = exact_mode();
 	} else if (ext->exact_mode_of_segs != exact_mode()) {
 		exact_shutdown(ext);
 		exact_init(d, ext);
@@ -587,7 +589,9 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 
 // pg_gen_arc (graph.c:87-177): per-genome work + local reduce on the backend, cross-shard merge and
 // the three double roundings of graph.c:170-172 here
-static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
+// defer: the next thing is a branch step, which reads the table on the backend and waits for its own results anyway: the round's
+// host results (segment counters, degrees) are collected there (arc_collect) instead of being waited for here
+static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer = false)
 {
 	const pga_backend_t *be = ext->be;
 	const int32_t S = q->n_seg;
@@ -600,6 +604,12 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 		// it) resident; it travels to the host once, after the last round (fetch_arcs)
 		int64_t n_arc = 0;
 		const pga_arc_part_t *tab = nullptr;
+		if (defer && pg_verbose < 3 && be->arc_round_finish) {
+			{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, nullptr, nullptr), "arc_round"); }
+			{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
+			ext->arc_pending = true, ext->cur_arcs = nullptr, q->n_arc = 0;
+			return 0;
+		}
 		{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, sc.data(), ext->deg.data()), "arc_round"); }
 		if (pg_verbose >= 3) BE_CALL(be->arc_table(ext->ctx, &tab, &n_arc), "arc_table"); // only the log lines want the number of arcs of every round
 		{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
@@ -644,6 +654,22 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
 	ext->cur_arcs = cur, q->n_arc = (int32_t)n_cur;
 	return 0;
+}
+
+// collect the host results of a deferred round.  1: the round had to be repeated (a hub gene overflowed the per-gene table), so
+// whatever was computed from its table on the backend in the meantime has to be repeated as well
+static int arc_collect(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
+{
+	if (!ext->arc_pending) return 0;
+	ext->arc_pending = false;
+	const int32_t S = q->n_seg;
+	std::vector<int32_t> sc((size_t)S * 2 + 1);
+	ext->deg.assign((size_t)S * 2 + 1, 0);
+	int rc = ext->be->arc_round_finish(ext->ctx, S, sc.data(), ext->deg.data());
+	if (rc < 0) { set_error(rc, "arc_round_finish"); return rc; }
+	if (rc == 1) BE_CALL(ext->be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, sc.data(), ext->deg.data()), "arc_round");
+	for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
+	return rc;
 }
 
 // bring the round's arc table to the host and apply the three double roundings of graph.c:170-172
@@ -711,10 +737,11 @@ static int mark_branch_flt_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 {
 	const pga_backend_t *be = ext->be;
 	Phase ph_all(PH_BRANCH_HOST);
-	BE_CALL(be->rep_pos(ext->ctx), "rep_pos");
 	std::vector<int32_t> ndl((size_t)q->n_seg * 2 + 1);
-	int32_t *b_cnt; int64_t np = 0, n_flt1 = 0, n_flt2 = 0;
-	{
+	int64_t n_flt1 = 0, n_flt2 = 0;
+	for (int attempt = 0;; ++attempt) {
+		BE_CALL(be->rep_pos(ext->ctx), "rep_pos");
+		int32_t *b_cnt; int64_t np = 0;
 		Phase ph(PH_NLOCAL);
 		BE_CALL(be->branch_pairs(ext->ctx, nullptr, nullptr, 0, nullptr, q->n_seg, opt->branch_diff, opt->local_dist, opt->local_count,
 		                         !!(opt->flag & PG_F_FRAG_MODE), &b_cnt, sharded() ? &np : nullptr), "branch_pairs"); // the pair count only matters to the all-reduce
@@ -722,6 +749,11 @@ static int mark_branch_flt_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 		// per-arc weak_br stays resident for mark_hits; the two totals only feed the log line
 		BE_CALL(be->branch_decide(ext->ctx, opt->branch_diff, opt->branch_diff_dist, opt->branch_diff_cut, nullptr, ndl.data(), pg_verbose >= 3 ? &n_flt1 : nullptr, pg_verbose >= 3 ? &n_flt2 : nullptr), "branch_decide");
 		g_phase[PH_BRANCH_HOST] -= now_sec() - ph.t0; // counted under PH_NLOCAL
+		// branch_decide has waited: a round that was left running behind this step is over too -- its results are collected now,
+		// before anything touches the hits.  Had it to be repeated, so has this step (it read the discarded table).
+		const int rc = arc_collect(opt, q, ext);
+		if (rc < 0) return rc;
+		if (rc == 0 || attempt) break;
 	}
 	for (int32_t j = 0; j < q->n_seg; ++j) q->seg[j].n_dist_loci[0] = ndl[(size_t)j * 2], q->seg[j].n_dist_loci[1] = ndl[(size_t)j * 2 + 1];
 	if (pg_verbose >= 3)
@@ -746,6 +778,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	if (ext == nullptr || ext->ctx == nullptr) { set_error(PGA_ERR_ARG, "pg_graph_gen: pg_post_process has not run"); return PGA_ERR_ARG; }
 	const pga_backend_t *be = ext->be;
 	pga_ctx_t *ctx = ext->ctx;
+	ext->arc_pending = false;
 	// graph 1: initial vertices (graph.c:284-291)
 	BE_CALL(be->set_filter(ctx, PGA_FLT_PSEUDO), "set_filter");
 	BE_CALL(gen_vtx(opt, q, ext), "gen_vtx");
@@ -755,7 +788,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-1 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
 	// graph 2: after removing high-occurrence vertices (graph.c:293-298)
 	BE_CALL(flt_high_occ(opt->max_avg_occ * 2, opt->max_degree * 2, opt->max_dist_loci, q, ext), "flt_high_occ");
-	BE_CALL(gen_arc(opt, q, ext), "gen_arc");
+	BE_CALL(gen_arc(opt, q, ext, opt->n_branch_flt > 0), "gen_arc");
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-2 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
 	// graph 3: branch filtering (graph.c:300-315)
 	for (int32_t i = 0; i < opt->n_branch_flt; ++i) {
@@ -766,7 +799,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 		BE_CALL(mark_branch_flt_arc(opt, q, ext), "mark_branch_flt_arc");
 		BE_CALL(mark_branch_flt_hit(q, ext), "mark_branch_flt_hit"); // with PG_SET_FILTER(weak_br == 2), graph.c:309
 		if (i > 0) BE_CALL(flt_high_occ(max_avg_occ, max_degree, max_dist_loci, q, ext), "flt_high_occ"); // with PG_SET_FILTER(vtx == 0), graph.c:312
-		BE_CALL(gen_arc(opt, q, ext), "gen_arc");
+		BE_CALL(gen_arc(opt, q, ext, i + 1 < opt->n_branch_flt), "gen_arc");
 	}
 	BE_CALL(be->set_filter(ctx, PGA_FLT_SHADOW), "set_filter"); // graph.c:316
 	BE_CALL(fetch_arcs(q, ext), "fetch_arcs");

@@ -390,6 +390,7 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 	const int32_t j0 = d->n_genome;
 	for (int32_t i = 0; i < n; ++i) { if (commit_file(d, fp[(size_t)i]) != 0) ++n_fail; std::free(fp[(size_t)i].label); }
 	pack_genomes(d, ext_of(d, true), j0, d->n_genome); // global ids are final now: SoA blocks for the backend, on host threads
+	exact_prefetch(d, ext_of(d, true));                // and the replay of the reference's tie order starts in the background
 	return -n_fail;
 }
 

@@ -79,8 +79,11 @@ struct DataExt {
 	std::vector<std::pair<int32_t, int32_t>> extra_ctgs; // (local genome, contig) pairs that get the full exact order although the mode is auto (sorted)
 	std::vector<std::thread> xworkers; // background replay of the reference's sort sequence
 	std::atomic<size_t> xnext{0};
+	bool xreplayed = false;            // the segments' sort sequences have been (or are being) replayed
+	int32_t xsegs_n_genome = -1;       // number of genomes the segments were built for
 	int x_sorts[2] = {0, 0};           // cs / cm sorts of the reference seen so far in this run
 	std::vector<int32_t> head_file;    // per local genome: file index of the hit at array index 0 (-1 canonical)
+	bool arc_pending = false;          // a deferred arc round whose host results have not been collected (arc_collect)
 	bool rerun = false;                // pg_rerun_resident(): keep the backend context, skip pack + upload
 	bool host_full = false;            // the last sync also fetched rank / score_dom / dominators
 	bool pos_valid = false;            // pos_x / y_order on the host match the backend's current orders
@@ -119,6 +122,7 @@ int exact_mode();
 void exact_override(int m);
 void exact_init(const pg_data_t *d, DataExt *ext);
 void exact_begin(DataExt *ext);
+void exact_prefetch(const pg_data_t *d, DataExt *ext);
 int exact_sort(DataExt *ext, int by_cm);
 void exact_shutdown(DataExt *ext);
 

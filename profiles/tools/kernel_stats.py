@@ -10,3 +10,21 @@ print("# total kernel time %.3f ms in %d launches" % (tot / 1e6, sum(r[1] for r 
 print("# %-88s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
 for r in rows:
     print("%-90s %7d %12.1f %10.2f %10.2f %10.2f %6.2f" % (r[0][:90], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot))
+
+# GPU timeline: how much of the span between the first and the last kernel of the timed steps is spent inside kernels, and how the
+# idle time is distributed (launch gaps vs host waits); the last `--steps` passes are delimited by the k_prepare launches
+try:
+    ev = cur.execute("SELECT name, start, end FROM kernels ORDER BY start").fetchall()
+    starts = [i for i, e in enumerate(ev) if e[0].startswith("k_prepare")]
+    if len(starts) >= 3:
+        a, b = starts[-2], starts[-1]  # one whole pass: from one k_prepare to the next
+        seg = ev[a:b]
+        span = seg[-1][2] - seg[0][1]
+        busy = sum(e[2] - e[1] for e in seg)
+        gaps = [seg[i + 1][1] - seg[i][2] for i in range(len(seg) - 1)]
+        big = [g for g in gaps if g > 15000]
+        print("# one pass (k_prepare to k_prepare): %d launches, span %.3f ms, inside kernels %.3f ms (%.0f %%), idle %.3f ms: %d gaps > 15 us (host waits) = %.3f ms, the other %d gaps = %.3f ms (mean %.2f us)"
+              % (len(seg), span / 1e6, busy / 1e6, 100.0 * busy / span, (span - busy) / 1e6, len(big), sum(big) / 1e6, len(gaps) - len(big), (sum(gaps) - sum(big)) / 1e6,
+                 (sum(gaps) - sum(big)) / 1e3 / max(1, len(gaps) - len(big))))
+except Exception as ex:  # older databases
+    print("# (no timeline: %s)" % ex)
