@@ -130,7 +130,7 @@ __global__ __launch_bounds__(BLOCK) void k_arc_l1(const uint64_t *key, int64_t m
 	const int g = p.w;
 	if (i == 0 || key[i - 1] != k) run_start[slot[i]] = (int32_t)i; // head of the key's run
 	if (i > 0 && key[i - 1] == k && pay[i - 1].w == g) { o_n[i] = 0, o_dn[i] = 0, o_s1[i] = 0, o_s2[i] = 0; return; }
-	int n = 1, m1 = p.y, m2 = p.z;
+	int n = 1, m1 = p.y > 0 ? p.y : 0, m2 = p.z > 0 ? p.z : 0; // the reference's running maxima start at 0 (graph.c:133): non-positive scores count as 0
 	uint64_t sd = (uint64_t)(int64_t)p.x;
 	for (int64_t j = i + 1; j < m && key[j] == k; ++j) { // almost always empty: one adjacency per (arc, genome)
 		const int4 q = pay[j];

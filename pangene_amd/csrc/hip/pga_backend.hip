@@ -116,7 +116,7 @@ struct pga_ctx {
 	bool table_sparse = false; // the current arc table lives in the genes' stretches (arc_round_genes) and has not been compacted
 	int32_t *h_round = nullptr; size_t h_round_cap = 0; // pinned: segment counters + degrees of a round
 	unsigned long long *door = nullptr, *door_dev = nullptr, door_seq = 0; // pinned doorbell of sync_st
-	unsigned long long sync_epoch = 0, arc_epoch = 0; bool arc_deferred = false, arc_done = false, force_sort_once = false; std::vector<int32_t> def_host; // a round whose results nobody has waited for yet (pga_arc_round_finish)
+	unsigned long long sync_epoch = 0, arc_epoch = 0; bool arc_deferred = false, arc_done = false, force_sort_once = false, sweep_done = false; std::vector<int32_t> def_host; // a round whose results nobody has waited for yet (pga_arc_round_finish)
 	int4 *yrecA = 0, *yrecB = 0; bool yrec_valid = false; // Y-order static records (k_pack_yrec), rebuilt after anything that changes their sources
 	int64_t br_np_seen = 0; // the last pair count the host got to know (sizes the next grid)
 	int64_t br_n = 0, br_np = 0, br_cap = 0; int32_t br_S = 0; // arcs / pairs (-1: not known on the host yet) / pair capacity / segments of the last branch_pairs
@@ -812,7 +812,9 @@ static int arc_table_compact(pga_ctx *c, pga_arc_part_t **arcs_out, int64_t *n_o
 
 // The reference's formulation -- every temp arc through one global sort (graph.c:127,151): kept as the path of rounds in which a
 // hub gene overflows the LDS table of k_gene_arcs, and (PANGENE_ARC_SORT_PATH=1) as an independent check of the gene path.
-static int arc_round_sorted(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int64_t *n_arcs_out)
+// sweep_done: the round's pg_shadow (graph.c:102) has run already (a gene-path attempt that overflowed): it must not run again --
+// by the time a deferred round is repeated the hits may follow the NEXT cs order (graph.c:123), and ties would fall differently.
+static int arc_round_sorted(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int64_t *n_arcs_out, bool sweep_done)
 {
 	const int N = c->N, S = c->n_seg, GL = c->n_genome;
 	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES);
@@ -822,7 +824,7 @@ static int arc_round_sorted(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out
 		HIPCHK(hipMemsetAsync(seg_cnt, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES, c->st));
 		return sync_st(c);
 	}
-	TRY(launch_sweep<0>(c, 2)); // graph.c:102
+	if (!sweep_done) TRY(launch_sweep<0>(c, 2)); // graph.c:102
 	int32_t *val, *prev;
 	TRY(walk_prev(c, &val, &prev));
 	const int64_t wpg = (S + 31) / 32;
@@ -881,9 +883,11 @@ extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_ou
 		TRY(sync_st(c));
 		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
 		if (c->h_cnt[9] == 0) return arc_table_compact(c, arcs_out, n_arcs_out); // the exchange wants one sorted array
+		c->table_sparse = false;
+		return arc_round_sorted(c, use_ori, seg_cnt_out, arcs_out, n_arcs_out, true);
 	}
 	c->table_sparse = false;
-	return arc_round_sorted(c, use_ori, seg_cnt_out, arcs_out, n_arcs_out);
+	return arc_round_sorted(c, use_ori, seg_cnt_out, arcs_out, n_arcs_out, false);
 }
 
 // pg_gen_arc for a run that is not sharded: the round's table is the graph's table at once (what pga_arc_set_current would
@@ -920,6 +924,7 @@ extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg,
 		TRY(sync_st(c));
 		const int rc = arc_round_check(c, S, seg_cnt_host, deg_host);
 		if (rc <= 0) return rc;
+		c->sweep_done = true;
 	}
 	if (seg_cnt_host == nullptr) { // deferred call on the sort path: done at once, the results wait in host memory for pga_arc_round_finish
 		c->def_host.assign(2 * (size_t)n_vtx + 1, 0);
@@ -928,8 +933,9 @@ extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg,
 		return 0;
 	}
 	int32_t *seg_cnt; pga_arc_part_t *arcs; int64_t n = 0;
-	c->table_sparse = false, c->force_sort_once = false;
-	TRY(arc_round_sorted(c, use_ori, &seg_cnt, &arcs, &n));
+	const bool sweep_done = c->sweep_done; // set by a gene-path attempt of this very round (just above, or the deferred one being repeated)
+	c->table_sparse = false, c->force_sort_once = false, c->sweep_done = false;
+	TRY(arc_round_sorted(c, use_ori, &seg_cnt, &arcs, &n, sweep_done));
 	TRY(pga_arc_set_current(c, arcs, n, S, deg_host));
 	if (n_vtx) TRY(pga_fetch(c, seg_cnt_host, seg_cnt, sizeof(int32_t) * (size_t)n_vtx));
 	return 0;
@@ -947,7 +953,7 @@ extern "C" int pga_arc_round_finish(pga_ctx_t *c, int32_t n_seg, int32_t *seg_cn
 	}
 	if (c->sync_epoch == c->arc_epoch) TRY(sync_st(c)); // nobody has waited since the round was queued
 	const int rc = arc_round_check(c, n_seg, seg_cnt_host, deg_host);
-	if (rc == 1) c->force_sort_once = true; // the caller repeats the round (without deferring): it takes the sort path
+	if (rc == 1) c->force_sort_once = true, c->sweep_done = true; // the caller repeats the round (without deferring): it takes the sort path, without a second sweep
 	return rc;
 }
 

@@ -92,3 +92,23 @@ def test_reference_main_c_builds_and_runs_on_this_library(built, expected, tmp_p
     assert hashlib.md5(out).hexdigest() == expected["C4"][""]["md5"]
     out = subprocess.run([exe, "-p0", "-a1"] + golden_files("C4"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, check=True).stdout
     assert hashlib.md5(out).hexdigest() == expected["C4"]["-p0 -a1"]["md5"]
+
+
+def test_device_layout_limits_are_reported_not_asserted(tmp_path):
+    """include/pangene_hip.h documents the device layout limits (contig coordinates < 2^31: pangene.h:71 has int64).  A PAF beyond
+    them must come back as PGA_ERR_RANGE from the packing step -- on any backend, before a device is touched -- and as
+    pg_last_error() != 0 with an empty graph, never as an abort or a silent truncation."""
+    import ctypes as C
+    from pangene_amd import capi
+    lib = capi.load(oracle_host=True)
+    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    big = 3_000_000_000
+    p = tmp_path / "big.paf"
+    p.write_text("g1\t100\t0\t100\t+\tc1\t%d\t%d\t%d\t300\t300\t0\tms:i:400\tcg:Z:100M\n" % (big + 1000, big, big + 300)
+                 + "g2\t100\t0\t100\t+\tc1\t%d\t10\t310\t300\t300\t0\tms:i:410\tcg:Z:100M\n" % (big + 1000))
+    with pytest.raises(RuntimeError, match="status -2"):
+        capi.run(lib, [str(p)], [])
+    assert lib.pg_last_error() == -2
+    q = tmp_path / "ok.paf"  # and the library is usable afterwards
+    q.write_text("g1\t100\t0\t100\t+\tc1\t1000\t10\t310\t300\t300\t0\tms:i:400\tcg:Z:100M\n")
+    assert capi.run(lib, [str(q)], []).startswith(b"S\tg1")
