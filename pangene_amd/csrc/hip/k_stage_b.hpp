@@ -32,7 +32,7 @@ __global__ __launch_bounds__(BLOCK) void k_post_apply(uint32_t *flags, const int
 	uint32_t f = flags[h], nf = rep[p] ? (f | PGA_F_REP) : (f & ~PGA_F_REP);
 	if (!(f & (PGA_F_FLT | PGA_F_PSEUDO)) && nex[h] == 1 && pj[p]) { // hit.c:175-182
 		nf |= PGA_F_PSEUDO;
-		atomicAdd((unsigned long long *)cnt, 1ull);
+		if (cnt) atomicAdd((unsigned long long *)cnt, 1ull); // log only
 	}
 	if (nf != f) flags[h] = nf;
 }

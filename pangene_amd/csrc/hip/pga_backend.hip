@@ -19,6 +19,7 @@
 #include <string.h>
 #include <time.h>
 #include <vector>
+#include <mutex>
 #include <algorithm>
 #include "pangene_hip.h"
 #include "dev_prims.hpp"
@@ -68,6 +69,42 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 	}
 };
 
+// Small pinned host buffers (mailboxes, staging areas, per-round results): carved out of a few pinned blocks that outlive the
+// context in a process-wide cache -- hipHostMalloc costs milliseconds and would otherwise be paid several times in the first pass
+// over every data set.
+struct PinBlock { char *p; size_t cap; };
+static std::mutex g_pin_mu;
+static std::vector<PinBlock> g_pin_cache;
+struct PinArena {
+	std::vector<PinBlock> blocks; size_t off = 0;
+	void *get(size_t bytes)
+	{
+		bytes = (bytes + 255) & ~(size_t)255;
+		if (blocks.empty() || off + bytes > blocks.back().cap) {
+			PinBlock b = { nullptr, 0 };
+			{
+				std::lock_guard<std::mutex> lk(g_pin_mu);
+				for (size_t i = 0; i < g_pin_cache.size(); ++i)
+					if (g_pin_cache[i].cap >= bytes) { b = g_pin_cache[i]; g_pin_cache.erase(g_pin_cache.begin() + (long)i); break; }
+			}
+			if (b.p == nullptr) {
+				b.cap = std::max<size_t>(bytes, (size_t)8 << 20);
+				if (hipHostMalloc((void **)&b.p, b.cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+			}
+			blocks.push_back(b), off = 0;
+		}
+		void *r = blocks.back().p + off;
+		off += bytes;
+		return r;
+	}
+	void release() // back to the cache (a handful of blocks per process)
+	{
+		std::lock_guard<std::mutex> lk(g_pin_mu);
+		for (PinBlock &b : blocks) { if (g_pin_cache.size() < 16) g_pin_cache.push_back(b); else (void)hipHostFree(b.p); }
+		blocks.clear(), off = 0;
+	}
+};
+
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
@@ -106,7 +143,7 @@ struct pga_ctx {
 	int64_t *h_box = 0;     // the same memory as the device sees it
 	void *h_stage = nullptr; size_t h_stage_cap = 0; // pinned landing area of fetch_later
 	int32_t *h_g2s = nullptr; size_t h_g2s_cap = 0; hipEvent_t g2s_done = nullptr; // pinned staging of flag_vtx's gene -> segment map
-	DevPool pool;
+	DevPool pool; PinArena pin;
 	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
 	// gene-major index (k_genes.hpp): hits by (gene, genome, X position); half-arc records of the current walk
 	int32_t *zx = 0, *zy = 0, *zg = 0; int2 *zst = 0; int32_t *zpos = 0, *zposy = 0, *zoff = 0; // gene-major planes (k_genes.hpp)
@@ -302,12 +339,7 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 	if (c->span_a) (void)hipEventDestroy(c->span_a);
 	for (void *q : c->owned) (void)hipFree(q);
 	c->pool.release();
-	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
-	if (c->h_stage) (void)hipHostFree(c->h_stage);
-	if (c->h_g2s) (void)hipHostFree(c->h_g2s);
-	if (c->h_round) (void)hipHostFree(c->h_round);
-	if (c->door) (void)hipHostFree(c->door);
-	if (c->h_ndl) (void)hipHostFree(c->h_ndl);
+	c->pin.release(); // h_cnt, h_stage, h_g2s, h_round, door, h_ndl live there
 	if (c->g2s_done) (void)hipEventDestroy(c->g2s_done);
 	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
 	delete c;
@@ -344,6 +376,8 @@ template <class T> static int upload(pga_ctx *c, T *dst, const T *src, size_t n)
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+static int stage_upload(pga_ctx *c, void *d0, const void *s0, size_t n0, void *d1 = nullptr, const void *s1 = nullptr, size_t n1 = 0);
+
 static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 {
 	const int N = c->N, E = c->E, GL = c->n_genome;
@@ -357,9 +391,12 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) c->n_cu = ncu;
 	}
 	c->own_stream = true;
-	HIPCHK(hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(int64_t), hipHostMallocDefault));
+	c->h_cnt = (int64_t *)c->pin.get(16 * sizeof(int64_t));
+	if (!c->h_cnt) return PGA_ERR_NOMEM;
+	memset(c->h_cnt, 0, 16 * sizeof(int64_t));
 	HIPCHK(hipHostGetDevicePointer((void **)&c->h_box, c->h_cnt, 0));
-	HIPCHK(hipHostMalloc((void **)&c->door, 64, hipHostMallocDefault));
+	c->door = (unsigned long long *)c->pin.get(64);
+	if (!c->door) return PGA_ERR_NOMEM;
 	*c->door = 0;
 	HIPCHK(hipHostGetDevicePointer((void **)&c->door_dev, c->door, 0));
 	TRY(dalloc(c, &c->dcnt, 16));
@@ -583,12 +620,14 @@ extern "C" int pga_post_apply(pga_ctx_t *c, const uint8_t *prot_rep, const uint8
 	uint8_t *d = (uint8_t *)c->pool.get(S_MISC, 2 * (size_t)c->P + 16);
 	if (!d) return PGA_ERR_NOMEM;
 	c->walk_valid = false, c->ha_valid = false;
-	TRY(upload(c, d, prot_rep, (size_t)c->P)); TRY(upload(c, d + c->P, prot_pj, (size_t)c->P));
-	HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
-	if (c->N) hipLaunchKernelGGL(k_post_apply, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->nex, c->sdom, c->N, c->max_ori, d, d + c->P, c->dcnt + 2);
-	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
-	TRY(sync_st(c));
-	if (n_pseudo) *n_pseudo = c->h_cnt[2];
+	TRY(stage_upload(c, d, prot_rep, (size_t)c->P, d + c->P, prot_pj, (size_t)c->P)); // caller memory
+	if (n_pseudo) HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
+	if (c->N) hipLaunchKernelGGL(k_post_apply, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->nex, c->sdom, c->N, c->max_ori, d, d + c->P, n_pseudo ? c->dcnt + 2 : (int64_t *)nullptr);
+	if (n_pseudo) { // the count only feeds a log line: nobody waits for it otherwise
+		HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+		TRY(sync_st(c));
+		*n_pseudo = c->h_cnt[2];
+	}
 	return 0;
 }
 
@@ -667,20 +706,30 @@ extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records,
 	}
 }
 
-extern "C" int pga_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg, int32_t then_filter)
+// Upload out of CALLER memory without waiting for it: the bytes (up to three pieces) are copied into a pinned staging area first,
+// so the caller's buffers are free when the call returns and the DMA runs in stream order.
+static int stage_upload(pga_ctx *c, void *d0, const void *s0, size_t n0, void *d1, const void *s1, size_t n1)
 {
-	// g2s is caller memory: it is copied into a pinned staging area so that the call need not wait for the upload
-	const size_t nb = sizeof(int32_t) * (size_t)c->Q;
+	const size_t a0 = (n0 + 15) & ~(size_t)15, nb = a0 + n1;
+	if (nb == 0) return 0;
 	if (c->h_g2s_cap < nb) {
-		if (c->h_g2s) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipHostFree(c->h_g2s); c->h_g2s = nullptr; }
-		HIPCHK(hipHostMalloc((void **)&c->h_g2s, nb + 64, hipHostMallocDefault));
-		c->h_g2s_cap = nb;
+		if (c->h_g2s) HIPCHK(hipStreamSynchronize(c->st)); // (the old piece stays in the arena)
+		c->h_g2s = (int32_t *)c->pin.get(nb + nb / 2 + 64);
+		if (!c->h_g2s) return PGA_ERR_NOMEM;
+		c->h_g2s_cap = nb + nb / 2;
 	}
 	if (!c->g2s_done) HIPCHK(hipEventCreateWithFlags(&c->g2s_done, hipEventDisableTiming));
 	else HIPCHK(hipEventSynchronize(c->g2s_done)); // the previous upload out of the staging area (long finished in practice)
-	if (nb) memcpy(c->h_g2s, g2s, nb);
-	TRY(upload(c, c->g2s, (const int32_t *)c->h_g2s, (size_t)c->Q));
+	char *h = (char *)c->h_g2s;
+	if (n0) { memcpy(h, s0, n0); HIPCHK(hipMemcpyAsync(d0, h, n0, hipMemcpyHostToDevice, c->st)); }
+	if (n1) { memcpy(h + a0, s1, n1); HIPCHK(hipMemcpyAsync(d1, h + a0, n1, hipMemcpyHostToDevice, c->st)); }
 	HIPCHK(hipEventRecord(c->g2s_done, c->st));
+	return 0;
+}
+
+extern "C" int pga_flag_vtx(pga_ctx_t *c, const int32_t *g2s, int32_t n_seg, int32_t then_filter)
+{
+	TRY(stage_upload(c, c->g2s, g2s, sizeof(int32_t) * (size_t)c->Q)); // g2s is caller memory
 	c->n_seg = n_seg;
 	if (then_filter) c->walk_valid = false, c->ha_valid = false;
 	if (c->N) hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, c->N, c->g2s, then_filter);
@@ -912,8 +961,9 @@ extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg,
 		int32_t *seg_cnt, *deg;
 		const size_t need = sizeof(int32_t) * (2 * (size_t)n_vtx + 2) + 64;
 		if (c->h_round_cap < need) {
-			if (c->h_round) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipHostFree(c->h_round); c->h_round = nullptr; }
-			HIPCHK(hipHostMalloc((void **)&c->h_round, need + need / 2, hipHostMallocDefault));
+			if (c->h_round) HIPCHK(hipStreamSynchronize(c->st));
+			c->h_round = (int32_t *)c->pin.get(need + need / 2);
+			if (!c->h_round) return PGA_ERR_NOMEM;
 			c->h_round_cap = need + need / 2;
 		}
 		int32_t *h_dev = nullptr;
@@ -1145,8 +1195,9 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	uint8_t *vwk = (uint8_t *)c->pool.get(S_VWK, (size_t)n_vtx + 16);
 	const size_t need = sizeof(int32_t) * (size_t)n_vtx + 64;
 	if (c->h_ndl_cap < need) {
-		if (c->h_ndl) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipHostFree(c->h_ndl); c->h_ndl = nullptr; }
-		HIPCHK(hipHostMalloc((void **)&c->h_ndl, need + need / 2, hipHostMallocDefault));
+		if (c->h_ndl) HIPCHK(hipStreamSynchronize(c->st));
+		c->h_ndl = (int32_t *)c->pin.get(need + need / 2);
+		if (!c->h_ndl) return PGA_ERR_NOMEM;
 		c->h_ndl_cap = need + need / 2;
 	}
 	int32_t *ndl_dev = nullptr;
@@ -1253,9 +1304,9 @@ extern "C" int pga_set_head(pga_ctx_t *c, const int32_t *head_file)
 	if (GL == 0 || c->N == 0) return 0;
 	int32_t *d = (int32_t *)c->pool.get(S_OVFILE, sizeof(int32_t) * (size_t)GL);
 	if (!d) return PGA_ERR_NOMEM;
-	TRY(upload(c, d, head_file, (size_t)GL));
+	TRY(stage_upload(c, d, head_file, sizeof(int32_t) * (size_t)GL)); // head_file is caller memory
 	hipLaunchKernelGGL(k_set_head, dim3(nblk(GL)), dim3(BLOCK), 0, c->st, d, c->goff, c->inv, GL, c->headpos, c->flags);
-	return sync_st(c); // head_file is caller memory
+	return 0;
 }
 
 extern "C" int pga_hazard_segs(pga_ctx_t *c, int32_t *segs, int32_t cap, int64_t *n_total)
@@ -1274,8 +1325,9 @@ extern "C" int pga_sync(pga_ctx_t *c) { return sync_st(c); }
 extern "C" int pga_fetch_later(pga_ctx_t *c, const void *src_backend, size_t nbytes, const void **host_view)
 {
 	if (c->h_stage_cap < nbytes) {
-		if (c->h_stage) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipHostFree(c->h_stage); c->h_stage = nullptr; }
-		HIPCHK(hipHostMalloc(&c->h_stage, nbytes + nbytes / 2 + 256, hipHostMallocDefault));
+		if (c->h_stage) HIPCHK(hipStreamSynchronize(c->st));
+		c->h_stage = c->pin.get(nbytes + nbytes / 2 + 256);
+		if (!c->h_stage) return PGA_ERR_NOMEM;
 		c->h_stage_cap = nbytes + nbytes / 2 + 256;
 	}
 	*host_view = c->h_stage;

@@ -425,9 +425,11 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 	BE_CALL(xreduce(be, ext->ctx, b_sum, 6 * (int64_t)P, PG_X_I64, PG_X_SUM), "allreduce(protein sums)");
 	std::vector<int32_t> mx((size_t)P);
 	std::vector<int64_t> sm((size_t)P * 6);
-	if (P) {
-		BE_CALL(be->fetch(ctx, mx.data(), b_max, sizeof(int32_t) * (size_t)P), "fetch");
+	if (P) { // one wait for both vectors: the first copy rides with the second one's
+		const void *mx_view = nullptr;
+		BE_CALL(be->fetch_later(ctx, b_max, sizeof(int32_t) * (size_t)P, &mx_view), "fetch_later");
 		BE_CALL(be->fetch(ctx, sm.data(), b_sum, sizeof(int64_t) * (size_t)P * 6), "fetch");
+		std::memcpy(mx.data(), mx_view, sizeof(int32_t) * (size_t)P);
 	}
 	// pg_cap_score_dom's table (hit.c:230-238) and pg_flag_representative's protein part (hit.c:205-217)
 	std::vector<pg128_t> z((size_t)P);
@@ -458,7 +460,7 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 		}
 	}
 	int64_t n_pj = 0;
-	BE_CALL(be->post_apply(ctx, rep.data(), pj.data(), &n_pj), "post_apply");
+	BE_CALL(be->post_apply(ctx, rep.data(), pj.data(), (!(opt->flag & PG_F_NO_JOINT_PSEUDO) && pg_verbose >= 3) ? &n_pj : nullptr), "post_apply");
 	if (!(opt->flag & PG_F_NO_JOINT_PSEUDO) && pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] %ld pseudogene hits identified jointly\n", __func__, stamp(), (long)n_pj);
 	std::vector<int32_t> st2((size_t)nl * 2);
@@ -508,7 +510,8 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	const double tv1 = now_sec();
 	BE_CALL(xreduce(be, ext->ctx, b_cnt, 2 * (int64_t)Q, PG_X_I32, PG_X_SUM), "allreduce(n_dom,n_sub)");
 	std::vector<int32_t> cntv((size_t)Q * 2);
-	if (Q) BE_CALL(be->fetch(ext->ctx, cntv.data(), b_cnt, sizeof(int32_t) * (size_t)Q * 2), "fetch");
+	const void *cntv_view = nullptr; // copied out behind the next wait (the fetch of the pair records, or the explicit one below)
+	if (Q) BE_CALL(be->fetch_later(ext->ctx, b_cnt, sizeof(int32_t) * (size_t)Q * 2, &cntv_view), "fetch_later");
 	// What the greedy needs is, per (sub, dom) gene pair, the SET of genomes in which sub is sub-ordinate to a dominant dom: a
 	// selected sub gene marks cell (genome, dom) in each of them (vertex.c:73-77).  The backend hands over one genome
 	// bitset per pair of its shard and only those travel between ranks: the host work is O(pairs x G/64), independent of
@@ -520,6 +523,10 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	const double tv2 = now_sec();
 	if (sharded()) { // every rank's records, concatenated in rank order; a pair may come from several ranks (disjoint genome bits)
 		BE_CALL(xgather(be, ext->ctx, b_tri, n_tri * (1 + nw), pairs), "allgather(vertex pairs)");
+	}
+	if (Q) {
+		if (n_tri == 0 || sharded()) BE_CALL(be->sync(ext->ctx), "sync"); // (no fetch above waited)
+		std::memcpy(cntv.data(), cntv_view, sizeof(int32_t) * (size_t)Q * 2);
 	}
 	// group the records by sub gene (counting sort on the key's sub field keeps it linear)
 	const int64_t n_rec = (int64_t)(pairs.size() / (size_t)(1 + nw));

@@ -1,16 +1,50 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch of K1 (k_sweep<1, true>) from the two PMC passes.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB
-(1 unit = 1024 B); on gfx950 FETCH_SIZE tallies 64 B per request where a wide coalesced read moves 128 B, so it is doubled
-(MI355X_MICROARCH.md, HBM section).  usage: k1_traffic.py <pmc_summary.txt> <bench.json>"""
-import json, sys
-fetch = write = None
-for line in open(sys.argv[1]):
-    f = line.rstrip("\n").split("\t")
-    if len(f) >= 5 and f[0] == "pmc" and "k_sweep<1" in f[1]:
-        if f[2] == "FETCH_SIZE": fetch = float(f[4])
-        if f[2] == "WRITE_SIZE": write = float(f[4])
-b = json.load(open(sys.argv[2]))
-hits = b["roofline"]["hits_per_launch"]
-tot = int((2 * fetch + write) * 1024)
-print(json.dumps({"kernel": "k_sweep<1, *>", "hits_per_launch": hits, "fetch_kb_raw": fetch, "write_kb": write, "bytes_per_launch": tot,
-                  "bytes_per_hit": round(tot / hits, 1), "note": "FETCH_SIZE x2 (gfx950 correction), separate --pmc passes of `python bench.py --no-cpu-baseline`"}))
+"""HBM bytes per launch of K1 (k_sweep<1, *>) from the two PMC passes of `python bench.py --no-cpu-baseline`, per shard size.
+rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB (1 unit = 1024 B); on gfx950 FETCH_SIZE tallies 64 B per request where a wide
+coalesced read moves 128 B, so it is doubled (MI355X_MICROARCH.md, HBM section).  The bench launches K1 on three shard sizes (the
+tiny warm-up set, the bench workload, the past-L3 shard of the roofline leg): the dispatches are told apart by their counter
+values (each size is > 5x the previous one).
+usage: k1_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <bench.json>"""
+import glob, json, os, sqlite3, sys
+
+
+def per_dispatch(root, counter):
+    db = sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True))[0]
+    cur = sqlite3.connect(db).cursor()
+    cur.execute("SELECT * FROM pmc_events LIMIT 1")
+    c = [d[0] for d in cur.description]
+    kn = ([x for x in c if x in ("name", "kernel_name")] or [x for x in c if "name" in x and "counter" not in x])[0]
+    cn = ([x for x in c if x in ("counter_name", "pmc_name")] or [x for x in c if "counter" in x and "name" in x])[0]
+    vn = ([x for x in c if x in ("counter_value", "value")] or [x for x in c if "value" in x])[0]
+    dn = ([x for x in c if x in ("dispatch_id", "event_id")] or [x for x in c if "dispatch" in x])[0]
+    acc = {}
+    for name, ctr, val, did in cur.execute("SELECT %s, %s, %s, %s FROM pmc_events" % (kn, cn, vn, dn)):
+        if "k_sweep<1" in name and ctr == counter:
+            acc[did] = acc.get(did, 0.0) + (val or 0.0)
+    return sorted(acc.values())
+
+
+def groups(vals):  # consecutive values within a factor 3 form one shard size
+    out = []
+    for v in vals:
+        if out and v <= 3 * out[-1][0]:
+            out[-1].append(v)
+        else:
+            out.append([v])
+    return [sum(g) / len(g) for g in out], [len(g) for g in out]
+
+
+f, nf = groups(per_dispatch(sys.argv[1], "FETCH_SIZE"))
+w, nw = groups(per_dispatch(sys.argv[2], "WRITE_SIZE"))
+b = json.load(open(sys.argv[3]))
+sizes = [b["roofline"]["hits_per_launch"]]
+if "also_at_bench_size" in b["roofline"]:
+    sizes.insert(0, b["roofline"]["also_at_bench_size"]["hits_per_launch"])
+out = []
+for k, hits in enumerate(reversed(sizes)):  # largest group = largest shard
+    fk, wk = f[-1 - k], w[-1 - k]
+    tot = int((2 * fk + wk) * 1024)
+    out.append({"kernel": "k_sweep<1, *>", "hits_per_launch": hits, "fetch_kb_raw": round(fk, 1), "write_kb": round(wk, 1), "bytes_per_launch": tot,
+                "bytes_per_hit": round(tot / hits, 1), "dispatches": [nf[-1 - k], nw[-1 - k]],
+                "note": "FETCH_SIZE x2 (gfx950 correction), separate --pmc passes of `python bench.py --no-cpu-baseline --steps 2 --warmup 0`"})
+print(json.dumps(out[::-1], indent=1))
