@@ -827,7 +827,10 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	c->table_sparse = true;
 	TRY(launch_sweep<0>(c, 2)); // graph.c:102
 	TRY(ensure_half_arcs(c, use_ori));
-	if (S == 0) { hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box); return 0; }
+	if (S == 0) { // nothing to build; the round's tail still has to be written (the pinned buffer is recycled memory)
+		hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box, h_round_dev);
+		return 0;
+	}
 	int32_t *big = (int32_t *)c->pool.get(S_BIGLIST, sizeof(int32_t) * (size_t)std::max(1, c->Q));
 	if (!big) return PGA_ERR_NOMEM;
 	static const int cap_log2 = [] { const char *e = getenv("PANGENE_GENE_TABLE_LOG2"); const int v = e ? atoi(e) : 9; return v < 1 ? 1 : v > 9 ? 9 : v; }();
