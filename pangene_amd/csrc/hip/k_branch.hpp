@@ -130,7 +130,7 @@ __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t
 {
 	const int lane = threadIdx.x & 63, grp = lane >> 4, sub = lane & (NL_LANES - 1);
 	int64_t n_pair = np_dev ? *np_dev : n_cap; // the count may still be on its way to the host: it is read here
-	if (n_pair > n_cap) n_pair = n_cap;        // (pairs beyond the capacity were not listed; the host repeats the round with room)
+	if (n_pair > n_cap) return; // more pairs than the list holds: some stretches of it were never written, and the host repeats the step with room
 	const int64_t stride = (int64_t)gridDim.x * (BLOCK / WAVE) * NL_PAIRS;
 	for (int64_t k0 = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * NL_PAIRS; k0 < n_pair; k0 += stride) {
 		const int64_t k = k0 + grp;

@@ -59,9 +59,6 @@ __global__ void k_mail_round(int64_t *dcnt, int64_t *host_box, int32_t *tail /* 
 	if (threadIdx.x == 0) dcnt[9] = 0;
 }
 
-// the doorbell of sync_st (pga_backend.hip): the host spins on this pinned word
-__global__ void k_ring(unsigned long long *door, unsigned long long seq) { __threadfence_system(); *door = seq; }
-
 __global__ void k_mail_flush(const int64_t *dcnt, int64_t *host_box)
 {
 	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];

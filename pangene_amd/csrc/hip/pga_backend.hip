@@ -29,6 +29,10 @@ using namespace pgd;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
 	fprintf(stderr, "[E::pga] %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return PGA_ERR_NO_DEVICE; } } while (0)
 
+// debugging aid: PANGENE_POISON=1 fills every fresh device / pinned allocation with a pattern, so that a read of memory nobody
+// wrote shows up the same way in every run (recycled memory otherwise holds whatever the previous context left there)
+static bool poison_on() { static const bool f = getenv("PANGENE_POISON") != nullptr; return f; }
+
 #define F_HEAD 0x80000000u   // static: first hit of its genome in X order (index-0 quirk, overlap.c:108)
 #define F_MULTI 0x40000000u  // static: the hit has more than one exon (lets the sweep skip the exon records)
 #define F_CSTIE 0x20000000u  // static: an X-order neighbour shares (contig, cs) -- member of a tie group of the cs sort (hazard H2b; set by k_pack_rec)
@@ -55,7 +59,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 			if (p[slot] && own[slot]) (void)hipFree(p[slot]);
 			size_t want = (bytes + bytes / 4 + 256 + 255) & ~(size_t)255;
 			if (arena && arena_off + want <= arena_cap) { p[slot] = arena + arena_off, arena_off += want, own[slot] = 0; }
-			else if (hipMalloc(&p[slot], want) == hipSuccess) own[slot] = 1;
+			else if (hipMalloc(&p[slot], want) == hipSuccess) { own[slot] = 1; if (poison_on()) (void)hipMemset(p[slot], 0x5a, want); }
 			else { p[slot] = nullptr; cap[slot] = 0; own[slot] = 0; return nullptr; }
 			cap[slot] = want;
 		}
@@ -95,6 +99,7 @@ struct PinArena {
 		}
 		void *r = blocks.back().p + off;
 		off += bytes;
+		if (poison_on()) memset(r, 0x5a, bytes);
 		return r;
 	}
 	void release() // back to the cache (a handful of blocks per process)
@@ -152,7 +157,6 @@ struct pga_ctx {
 	const pga_arc_part_t *cur_tab = nullptr; int64_t cur_tab_n = 0; // the table of pga_arc_set_current
 	bool table_sparse = false; // the current arc table lives in the genes' stretches (arc_round_genes) and has not been compacted
 	int32_t *h_round = nullptr; size_t h_round_cap = 0; // pinned: segment counters + degrees of a round
-	unsigned long long *door = nullptr, *door_dev = nullptr, door_seq = 0; // pinned doorbell of sync_st
 	unsigned long long sync_epoch = 0, arc_epoch = 0; bool arc_deferred = false, arc_done = false, force_sort_once = false, sweep_done = false; std::vector<int32_t> def_host; // a round whose results nobody has waited for yet (pga_arc_round_finish)
 	int4 *yrecA = 0, *yrecB = 0; bool yrec_valid = false; // Y-order static records (k_pack_yrec), rebuilt after anything that changes their sources
 	int64_t br_np_seen = 0; // the last pair count the host got to know (sizes the next grid)
@@ -176,7 +180,7 @@ static int dalloc_commit(pga_ctx *c)
 {
 	size_t tot = 0;
 	if (getenv("PANGENE_NO_ARENA")) { // debugging aid: one allocation per array (out-of-bounds accesses then land in padding)
-		for (auto &e : c->plan) { void *q = nullptr; if (hipMalloc(&q, e.second) != hipSuccess) return PGA_ERR_NOMEM; *e.first = q; c->owned.push_back(q); }
+		for (auto &e : c->plan) { void *q = nullptr; if (hipMalloc(&q, e.second) != hipSuccess) return PGA_ERR_NOMEM; *e.first = q; c->owned.push_back(q); if (poison_on()) (void)hipMemset(q, 0x5a, e.second); }
 		c->plan.clear();
 		return 0;
 	}
@@ -184,6 +188,7 @@ static int dalloc_commit(pga_ctx *c)
 	void *base = nullptr;
 	if (hipMalloc(&base, tot ? tot : 256) != hipSuccess) return PGA_ERR_NOMEM;
 	c->owned.push_back(base);
+	if (poison_on()) (void)hipMemset(base, 0x5a, tot ? tot : 256);
 	size_t off = 0;
 	for (auto &e : c->plan) *e.first = (char *)base + off, off += e.second;
 	c->plan.clear();
@@ -227,28 +232,31 @@ extern "C" const char *pga_strerror(int code)
 // ================================================================================================
 // host side of the ABI
 // ================================================================================================
-// Wait until everything issued so far has finished.  A run waits ~45 times for results of a few hundred bytes, and
-// hipStreamSynchronize costs tens of microseconds each time (the host thread is put to sleep and woken up).  So: one more
-// kernel at the end of the queue writes a sequence number into a pinned word (the "doorbell") and the host thread spins on it;
-// the stream is in order, so everything before the ring -- kernels and copies -- is done when it rings.  If it has not rung after
-// a generous while (a kernel fault, a hung device) the ordinary call takes over and reports what happened.
+// Waiting for the stream.  hipStreamSynchronize parks the thread (tens of microseconds to come back); the waits of a pass are
+// short and many, so the thread polls hipStreamQuery instead.  The runtime's own completion tracking is what makes the results
+// visible: kernels in the middle of a stream release their writes at agent scope only, and it is the runtime's end-of-stream
+// marker that releases them at system scope -- data a kernel (or a copy kernel) stored into pinned host memory may otherwise
+// still sit in the L2 of the XCD that wrote it.  (A doorbell written by a last tiny kernel and polled by the host was faster
+// still and WRONG for exactly that reason: its fence covers the L2 of one XCD; one run in a few hundred read stale counters.)
+// PANGENE_WAIT=sync selects the plain blocking call.
 static int sync_st(pga_ctx *c)
 {
-	static const bool spin = getenv("PANGENE_NO_SPIN_WAIT") == nullptr;
-	if (!spin || c->door == nullptr) { ++c->sync_epoch; HIPCHK(hipStreamSynchronize(c->st)); return 0; }
+	static const bool poll = [] { const char *e = getenv("PANGENE_WAIT"); return !(e && strcmp(e, "sync") == 0); }();
 	++c->sync_epoch;
-	const unsigned long long seq = ++c->door_seq;
-	hipLaunchKernelGGL(k_ring, dim3(1), dim3(1), 0, c->st, c->door_dev, seq);
-	const volatile unsigned long long *d = c->door;
-	timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
-	for (unsigned long long it = 1; *d != seq; ++it) {
-		__builtin_ia32_pause();
-		if ((it & 0xffff) == 0) {
-			timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
-			if ((t.tv_sec - t0.tv_sec) + (t.tv_nsec - t0.tv_nsec) * 1e-9 > 2.0) break; // something is wrong or very slow: let the runtime wait and tell
+	if (poll) {
+		timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+		for (unsigned long long it = 1;; ++it) {
+			const hipError_t e = hipStreamQuery(c->st);
+			if (e == hipSuccess) return 0;
+			if (e != hipErrorNotReady) HIPCHK(e);
+			__builtin_ia32_pause();
+			if ((it & 0x3ff) == 0) {
+				timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+				if ((t.tv_sec - t0.tv_sec) + (t.tv_nsec - t0.tv_nsec) * 1e-9 > 2.0) break; // something is wrong or very slow: let the runtime wait and tell
+			}
 		}
 	}
-	if (*d != seq) HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
 	return 0;
 }
 
@@ -339,7 +347,7 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 	if (c->span_a) (void)hipEventDestroy(c->span_a);
 	for (void *q : c->owned) (void)hipFree(q);
 	c->pool.release();
-	c->pin.release(); // h_cnt, h_stage, h_g2s, h_round, door, h_ndl live there
+	c->pin.release(); // h_cnt, h_stage, h_g2s, h_round, h_ndl live there
 	if (c->g2s_done) (void)hipEventDestroy(c->g2s_done);
 	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
 	delete c;
@@ -395,10 +403,6 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	if (!c->h_cnt) return PGA_ERR_NOMEM;
 	memset(c->h_cnt, 0, 16 * sizeof(int64_t));
 	HIPCHK(hipHostGetDevicePointer((void **)&c->h_box, c->h_cnt, 0));
-	c->door = (unsigned long long *)c->pin.get(64);
-	if (!c->door) return PGA_ERR_NOMEM;
-	*c->door = 0;
-	HIPCHK(hipHostGetDevicePointer((void **)&c->door_dev, c->door, 0));
 	TRY(dalloc(c, &c->dcnt, 16));
 	// persistent arrays
 	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
@@ -446,7 +450,10 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		const size_t per_hit = 420, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
 		const size_t want = ((size_t)N * per_hit + tables + (64u << 20) + (size_t)woff[(size_t)GL] * 4 + 255) & ~(size_t)255;
 		void *a = nullptr;
-		if (getenv("PANGENE_NO_POOL_ARENA") == nullptr && hipMalloc(&a, want) == hipSuccess) c->pool.arena = (char *)a, c->pool.arena_cap = want, c->pool.arena_off = 0; // else: slot by slot
+		if (getenv("PANGENE_NO_POOL_ARENA") == nullptr && hipMalloc(&a, want) == hipSuccess) { // else: slot by slot
+			c->pool.arena = (char *)a, c->pool.arena_cap = want, c->pool.arena_off = 0;
+			if (poison_on()) (void)hipMemset(a, 0x5a, want);
+		}
 		else (void)hipGetLastError();
 	}
 	const double t1 = now();

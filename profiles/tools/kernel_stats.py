@@ -26,5 +26,14 @@ try:
         print("# one pass (k_prepare to k_prepare): %d launches, span %.3f ms, inside kernels %.3f ms (%.0f %%), idle %.3f ms: %d gaps > 15 us (host waits) = %.3f ms, the other %d gaps = %.3f ms (mean %.2f us)"
               % (len(seg), span / 1e6, busy / 1e6, 100.0 * busy / span, (span - busy) / 1e6, len(big), sum(big) / 1e6, len(gaps) - len(big), (sum(gaps) - sum(big)) / 1e6,
                  (sum(gaps) - sum(big)) / 1e3 / max(1, len(gaps) - len(big))))
+        # where the host waits are: (kernel before the gap -> kernel after it), count, mean gap
+        kinds = {}
+        for i in range(len(seg) - 1):
+            g = seg[i + 1][1] - seg[i][2]
+            if g > 15000:
+                k = (seg[i][0].split("(")[0][:40], seg[i + 1][0].split("(")[0][:40])
+                kinds.setdefault(k, []).append(g)
+        for k, v in sorted(kinds.items(), key=lambda kv: -sum(kv[1])):
+            print("#   wait  %-40s -> %-40s  x%-3d mean %.1f us" % (k[0], k[1], len(v), sum(v) / len(v) / 1e3))
 except Exception as ex:  # older databases
     print("# (no timeline: %s)" % ex)

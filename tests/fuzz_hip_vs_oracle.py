@@ -2,7 +2,7 @@
 """One-off wide parity sweep on a GPU box: HIP path vs the oracle backend (same host driver) on many fresh fuzz / bacterial /
 human-shaped seeds and option variants, both tie-order modes.  Prints one line per mismatch and a summary; exit code 1 on any.
     python tests/fuzz_hip_vs_oracle.py [first_seed] [n_seeds]"""
-import ctypes as C, os, sys, tempfile
+import ctypes as C, hashlib, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pangene_amd import capi, synth
@@ -31,6 +31,16 @@ for s in range(first, first + n):
                 tot += 1
                 if a != b:
                     bad += 1
-                    print("MISMATCH seed %d set %s variant %r mode %d (%d vs %d bytes)" % (s, name, v, mode, len(a), len(b)), flush=True)
+                    a2, b2 = capi.run(hip, fs, v), capi.run(ora, fs, v)  # which side moved?
+                    if "--bed=flag" in v and mode == 1:
+                        a2, b2 = b"\n".join(sorted(a2.split(b"\n"))), b"\n".join(sorted(b2.split(b"\n")))
+                    dump = os.environ.get("PG_FUZZ_DUMP")
+                    if dump:
+                        os.makedirs(dump, exist_ok=True)
+                        tag = "%s%d_v%d_m%d" % (name, s, VARIANTS.index(v), mode)
+                        open(os.path.join(dump, tag + ".hip"), "wb").write(a); open(os.path.join(dump, tag + ".ora"), "wb").write(b)
+                        open(os.path.join(dump, tag + ".hip2"), "wb").write(a2)
+                    print("  again: hip %s its first answer, hip %s the oracle; oracle %s its first answer" % ("==" if a2 == a else "!=", "==" if a2 == b else "!=", "==" if b2 == b else "!="), flush=True)
+                    print("MISMATCH seed %d set %s variant %r mode %d (%d vs %d bytes, md5 %s)" % (s, name, v, mode, len(a), len(b), hashlib.md5(a).hexdigest()[:8]), flush=True)
 print("fuzz sweep: %d comparisons, %d mismatches" % (tot, bad))
 sys.exit(1 if bad else 0)
