@@ -230,6 +230,31 @@ __global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs
 	pc[v] = n_max * n_weak + n * (n - 1) / 2;
 }
 
+// Exclusive prefix sums of the vertices' pair counts in ONE workgroup: a graph has thousands of vertices, not millions, and the
+// general scan costs two launches plus one more for the total.  The total goes to dcnt[15] and, with the other counters, to the
+// host's mailbox.  (Graphs beyond PO_THREADS * PO_MAX_ITEMS vertices take the general scan.)
+constexpr int PO_THREADS = 1024, PO_MAX_ITEMS = 64;
+__global__ __launch_bounds__(PO_THREADS) void k_pair_offsets(const int32_t *pc, int n, int32_t *poff, int64_t *dcnt, int64_t *host_box)
+{
+	__shared__ int32_t part[PO_THREADS];
+	const int t = threadIdx.x, per = (n + PO_THREADS - 1) / PO_THREADS, i0 = t * per, i1 = i0 + per < n ? i0 + per : n;
+	int32_t s = 0;
+	for (int i = i0; i < i1; ++i) s += pc[i];
+	part[t] = s;
+	__syncthreads();
+	for (int d = 1; d < PO_THREADS; d <<= 1) { // inclusive scan of the partial sums
+		const int32_t v = t >= d ? part[t - d] : 0;
+		__syncthreads();
+		part[t] += v;
+		__syncthreads();
+	}
+	int32_t run = part[t] - s;
+	for (int i = i0; i < i1; ++i) { poff[i] = run; run += pc[i]; }
+	if (t == PO_THREADS - 1) dcnt[15] = part[t];
+	__syncthreads();
+	if (t < 16) sys_store(&host_box[t], dcnt[t]);
+}
+
 // sequential form (one lane), used for vertices with more than 64 arcs.  MODE 1: write pairs; 2: decide.
 template <int MODE>
 __device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *agid, double bd, int64_t k, int32_t *pairs, const int32_t *cnt,
@@ -270,12 +295,14 @@ __device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *a
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
                                                      const int32_t *poff, int32_t *pairs, int64_t pair_cap /* MODE 1: room in pairs[] */, const int32_t *pcnt /* MODE 1: pairs of each vertex */, const int32_t *cnt, double bdist, double bcut,
-                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, uint8_t *vwk /* MODE 2: vertex has a weak arc */)
+                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, uint8_t *vwk /* MODE 2: vertex has a weak arc */,
+                                                     const int64_t *np_dev = nullptr /* MODE 2: the number of pairs, when the list has a capacity (pair_cap) */)
 {
 	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (v >= n_vtx) return;
+	if (MODE == 2 && np_dev && *np_dev > pair_cap) return; // the list overflowed: there are no counts to read, the host repeats the step with room
 	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2) { if (MODE == 2 && lane == 0) ndl[v] = 0; return; } // (every n_dist_loci entry is written: nothing to clear beforehand)
+	if (n < 2) { if (MODE == 2 && lane == 0) sys_store(&ndl[v], 0); return; } // (every n_dist_loci entry is written: nothing to clear beforehand)
 	const int64_t k0 = poff[v];
 	if (MODE == 1 && k0 + pcnt[v] > pair_cap) return; // would run past the list: left out -- the total then exceeds the capacity too, the host sees that and repeats the round with room
 	if (n > WAVE) {
@@ -283,7 +310,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 			int32_t g = 0;
 			if (MODE == 2) for (int i = 0; i < n; ++i) grpg[a0 + i] = 0;
 			br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt);
-			if (MODE == 2) ndl[v] = g, vwk[v] = 1;
+			if (MODE == 2) sys_store(&ndl[v], g), vwk[v] = 1;
 		}
 		return;
 	}
@@ -326,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 			if (lane > i && in && grp == 0 && cnt[k] > 0) grp = gi;
 		}
 	}
-	if (MODE == 2 && lane == 0) ndl[v] = n_group;
+	if (MODE == 2 && lane == 0) sys_store(&ndl[v], n_group); // (ndl is pinned host memory in the unsharded path)
 }
 
 __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107

@@ -16,6 +16,35 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t key) // pg_hash_uint32, pg
 	return key;
 }
 
+// Pinned host memory seen from a kernel.  The caches between a CU and the host are not part of the in-stream ordering the kernels
+// rely on among themselves (a store may rest in the L2 of the XCD that issued it until a system-scope release, a load may be
+// served from a line fetched for an earlier upload out of the same staging area): what crosses that boundary is accessed at
+// system scope, explicitly.
+__device__ __forceinline__ void sys_store(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sys_store(int64_t *p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ uint32_t sys_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// small uploads (a g2s table, per-protein marks, head indices) straight out of the pinned staging area: one short kernel in
+// stream order instead of a DMA command, whose set-up latency sits between two dependent kernels.  src is 4-byte aligned and
+// padded to whole words (stage_upload); dst may be any byte address.
+struct CopyIn { void *dst[2]; const uint32_t *src[2]; unsigned long long n[2]; };
+__global__ __launch_bounds__(BLOCK) void k_copy_in(CopyIn l)
+{
+	const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x, step = (size_t)gridDim.x * BLOCK;
+#pragma unroll
+	for (int k = 0; k < 2; ++k) {
+		const size_t n = l.n[k];
+		if (n == 0) continue;
+		if (((size_t)l.dst[k] & 3) == 0) {
+			uint32_t *d = (uint32_t *)l.dst[k];
+			for (size_t i = t; i < (n >> 2); i += step) d[i] = sys_load(l.src[k] + i);
+			for (size_t i = (n & ~(size_t)3) + t; i < n; i += step) ((uint8_t *)l.dst[k])[i] = (uint8_t)(sys_load(l.src[k] + (i >> 2)) >> (8 * (i & 3)));
+		} else {
+			for (size_t i = t; i < n; i += step) ((uint8_t *)l.dst[k])[i] = (uint8_t)(sys_load(l.src[k] + (i >> 2)) >> (8 * (i & 3)));
+		}
+	}
+}
+
 __global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -30,7 +59,7 @@ __global__ void k_mail_sum(const int32_t *a, const int32_t *b, int64_t *dcnt, in
 {
 	if (threadIdx.x == 0) dcnt[10] = (int64_t)a[0] + b[0];
 	__syncthreads();
-	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
+	if (threadIdx.x < 16) sys_store(&host_box[threadIdx.x], dcnt[threadIdx.x]);
 }
 
 // the same for a run count: dcnt[10] = number of distinct keys of a sorted array, from the exclusive count of run heads before
@@ -39,7 +68,7 @@ __global__ void k_mail_runs(const uint64_t *key, const int32_t *slot, int64_t m,
 {
 	if (threadIdx.x == 0) dcnt[10] = (int64_t)slot[m - 1] + ((m == 1 || key[m - 1] != key[m - 2]) ? 1 : 0);
 	__syncthreads();
-	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
+	if (threadIdx.x < 16) sys_store(&host_box[threadIdx.x], dcnt[threadIdx.x]);
 }
 
 // the number of gene pairs of a branch round (dcnt[15] = a[0] + b[0]) for kernels and host alike
@@ -47,21 +76,21 @@ __global__ void k_mail_pairs(const int32_t *a, const int32_t *b, int64_t *dcnt, 
 {
 	if (threadIdx.x == 0) dcnt[15] = (int64_t)a[0] + b[0];
 	__syncthreads();
-	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
+	if (threadIdx.x < 16) sys_store(&host_box[threadIdx.x], dcnt[threadIdx.x]);
 }
 
 // end of an arc round on the gene-major index: the counters for the host, then the round's overflow counter starts again
 __global__ void k_mail_round(int64_t *dcnt, int64_t *host_box, int32_t *tail /* pinned, or NULL: {overflowed genes, invariant violations} of this round */)
 {
-	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
-	if (threadIdx.x == 0 && tail) tail[0] = (int32_t)dcnt[9], tail[1] = (int32_t)dcnt[3];
+	if (threadIdx.x < 16) sys_store(&host_box[threadIdx.x], dcnt[threadIdx.x]);
+	if (threadIdx.x == 0 && tail) sys_store(&tail[0], (int32_t)dcnt[9]), sys_store(&tail[1], (int32_t)dcnt[3]);
 	__syncthreads();
 	if (threadIdx.x == 0) dcnt[9] = 0;
 }
 
 __global__ void k_mail_flush(const int64_t *dcnt, int64_t *host_box)
 {
-	if (threadIdx.x < 16) host_box[threadIdx.x] = dcnt[threadIdx.x];
+	if (threadIdx.x < 16) sys_store(&host_box[threadIdx.x], dcnt[threadIdx.x]);
 }
 
 struct ZeroList { void *p[4]; unsigned long long dwords[4]; };

@@ -224,8 +224,8 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 		a.deg[2 * sid] = m0, a.deg[2 * sid + 1] = m - m0;
 		a.vwk[2 * sid] = 0, a.vwk[2 * sid + 1] = 0;
 		if (a.h_round) {
-			a.h_round[sid] = T.n_gen, a.h_round[a.S + sid] = T.n_tot;
-			a.h_round[2 * a.S + 2 * sid] = m0, a.h_round[2 * a.S + 2 * sid + 1] = m - m0;
+			sys_store(&a.h_round[sid], T.n_gen), sys_store(&a.h_round[a.S + sid], T.n_tot); // pinned host memory
+			sys_store(&a.h_round[2 * a.S + 2 * sid], m0), sys_store(&a.h_round[2 * a.S + 2 * sid + 1], m - m0);
 		}
 	}
 	if (NT == 64) wave_sync(); else __syncthreads();
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(BLOCK) void k_arc_compact(const int4 *gmeta, const 
 		for (int i = lane; i < n; i += WAVE) arcs[o + i] = stage[m.x + i];
 		if (lane == 0 && sid == S - 1) {
 			dcnt[10] = o + n;
-			for (int t = 0; t < 16; ++t) host_box[t] = dcnt[t];
+			for (int t = 0; t < 16; ++t) sys_store(&host_box[t], dcnt[t]);
 		}
 	}
 }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(BLOCK) void k_vtx_compact(const int32_t *dom_tab, c
 	if (s == n_slot - 1) {
 		dcnt[10] = slot[s] + (D >= 0 ? 1 : 0);
 		__threadfence();
-		for (int t = 0; t < 16; ++t) host_box[t] = dcnt[t];
+		for (int t = 0; t < 16; ++t) sys_store(&host_box[t], dcnt[t]);
 	}
 }
 

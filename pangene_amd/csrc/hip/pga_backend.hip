@@ -700,8 +700,10 @@ extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records,
 		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
 		const int64_t n_rec = c->h_cnt[10], n_ovf = c->h_cnt[0];
 		if (n_ovf > ovf_cap) { // more spilled (genome, gene) cells than there was room for: once more, with room (the reference has no such limit)
-			if (attempt) return PGA_ERR_RANGE;
-			ovf_cap = n_ovf;
+			// which dominators win a gene's slots is a race, so the number of spilled cells may differ a little between attempts:
+			// the second attempt gets a margin, a third one the upper bound (a spilled cell is at least one hit)
+			if (ovf_cap >= (long long)N) return PGA_ERR_RANGE;
+			ovf_cap = attempt == 0 ? std::min<long long>(N, 2 * n_ovf + 64) : (long long)N;
 			continue;
 		}
 		if (n_ovf) { // the spilled single-genome records follow the folded ones
@@ -728,8 +730,17 @@ static int stage_upload(pga_ctx *c, void *d0, const void *s0, size_t n0, void *d
 	if (!c->g2s_done) HIPCHK(hipEventCreateWithFlags(&c->g2s_done, hipEventDisableTiming));
 	else HIPCHK(hipEventSynchronize(c->g2s_done)); // the previous upload out of the staging area (long finished in practice)
 	char *h = (char *)c->h_g2s;
-	if (n0) { memcpy(h, s0, n0); HIPCHK(hipMemcpyAsync(d0, h, n0, hipMemcpyHostToDevice, c->st)); }
-	if (n1) { memcpy(h + a0, s1, n1); HIPCHK(hipMemcpyAsync(d1, h + a0, n1, hipMemcpyHostToDevice, c->st)); }
+	if (n0) memcpy(h, s0, n0);
+	if (n1) memcpy(h + a0, s1, n1);
+	if (nb <= ((size_t)1 << 20)) { // small: a copy kernel reads the staging area itself (see k_copy_in)
+		char *hd = nullptr;
+		HIPCHK(hipHostGetDevicePointer((void **)&hd, h, 0));
+		CopyIn l = { { d0, d1 }, { (const uint32_t *)hd, (const uint32_t *)(hd + a0) }, { n0, n1 } };
+		hipLaunchKernelGGL(k_copy_in, dim3(nblk((std::max(n0, n1) + 3) / 4)), dim3(BLOCK), 0, c->st, l);
+	} else {
+		if (n0) HIPCHK(hipMemcpyAsync(d0, h, n0, hipMemcpyHostToDevice, c->st));
+		if (n1) HIPCHK(hipMemcpyAsync(d1, h + a0, n1, hipMemcpyHostToDevice, c->st));
+	}
 	HIPCHK(hipEventRecord(c->g2s_done, c->st));
 	return 0;
 }
@@ -1174,9 +1185,13 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 		HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st)); // (the tables of arc_round_local / arc_set_current arrive with weak_br = 0)
 	}
 	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
-	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_vtx));
-	device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
-	hipLaunchKernelGGL(k_mail_pairs, dim3(1), dim3(64), 0, c->st, poff + (n_vtx - 1), pc + (n_vtx - 1), c->dcnt, c->h_box); // dcnt[15] = number of pairs
+	static const bool general_scan = getenv("PANGENE_PAIR_SCAN_GENERAL") != nullptr; // (tests: the path of graphs with more than 65536 vertices)
+	if (n_vtx <= PO_THREADS * PO_MAX_ITEMS && !general_scan) hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(PO_THREADS), 0, c->st, pc, n_vtx, poff, c->dcnt, c->h_box); // offsets, and dcnt[15] = number of pairs
+	else {
+		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_vtx));
+		device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
+		hipLaunchKernelGGL(k_mail_pairs, dim3(1), dim3(64), 0, c->st, poff + (n_vtx - 1), pc + (n_vtx - 1), c->dcnt, c->h_box);
+	}
 	if (n_pairs) { // somebody outside needs the count (the all-reduce of a sharded run): wait for it and size the buffers exactly
 		TRY(sync_st(c));
 		c->br_np = c->h_cnt[15], *n_pairs = c->br_np;
@@ -1216,8 +1231,8 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	for (int attempt = 0;; ++attempt) {
 		int32_t *cnt = (int32_t *)c->pool.get(S_NLCNT, 0);
 		if (n_flt1 || n_flt2) HIPCHK(hipMemsetAsync(c->dcnt, 0, 2 * sizeof(int64_t), c->st)); // [0], [1]: arcs marked 1 / 2 (log only)
-		hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, (int64_t)0, (const int32_t *)nullptr, cnt,
-		                   branch_diff_dist, branch_diff_cut, aw, grp, ndl_dev, (n_flt1 || n_flt2) ? c->dcnt : (int64_t *)nullptr, vwk);
+		hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, (int64_t)c->br_cap, (const int32_t *)nullptr, cnt,
+		                   branch_diff_dist, branch_diff_cut, aw, grp, ndl_dev, (n_flt1 || n_flt2) ? c->dcnt : (int64_t *)nullptr, vwk, c->br_np < 0 ? c->dcnt + 15 : (const int64_t *)nullptr);
 		if (arc_weak && !c->table_sparse) HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
 		if (n_flt1 || n_flt2) hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
 		TRY(sync_st(c));

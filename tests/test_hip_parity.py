@@ -112,13 +112,14 @@ def _run_with_env(tmp_path, env, mode, variant, files):
 
 
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
-@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1"}, {"PANGENE_GENE_TABLE_LOG2": "2"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1"}])
+@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1"}, {"PANGENE_GENE_TABLE_LOG2": "2"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1"}])
 def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
     (the path of rounds in which a hub gene overflows the per-gene LDS table).  Forcing the sort path, and shrinking the table to 4
     entries so that most rounds overflow, must both reproduce the reference's bytes (mode all).  Third setting: a vertex spill area of
     three records (manydoms then needs the second, grown attempt of pga_vtx_partials) and the 64-bit comparison keys ranked by a sort
-    (the path of shards whose score, preferred bit and protein rank do not fit 32 bits)."""
+    (the path of shards whose score, preferred bit and protein rank do not fit 32 bits), and the general scan for the pair offsets
+    (the path of graphs with more than 65536 oriented vertices)."""
     out = _run_with_env(tmp_path, env, 2, variant, golden_files(name))
     assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
 
@@ -158,6 +159,29 @@ def test_cross_shard_arc_merge(hip):
             exp = np.zeros(ux.size, dtype=np.int64)
             np.add.at(exp, inv, allv[f].astype(np.int64))
             assert np.array_equal(got[f].astype(np.int64), exp), (W, f)
+
+
+@pytest.mark.parametrize("name,variant,mode", [("bact20", "", 1), ("bact20", "-D 600 -C 3 -F", 2), ("human8f", "-p0 -a1", 1), ("fuzz7115", "-D 1000 -C 1 -p0 -a1", 2), ("manydoms", "-G", 1)])
+def test_repeated_runs_give_the_same_bytes(hip, expected, name, variant, mode):
+    """Forty runs in one process, one answer.  This is the detector for host/device ordering mistakes: the host reads counters,
+    degrees and n_dist_loci out of pinned memory after a wait, and a wait that does not release the device's writes at system scope
+    (the doorbell kernel this library once used) shows up as a different GFA once in a few hundred runs, on some boxes only."""
+    hip.pg_set_exact_mode(mode)
+    files, args = golden_files(name), variant.split()
+    first = capi.run(hip, files, args)
+    if variant in expected[name] and "md5" in expected[name][variant]:
+        assert hashlib.md5(first).hexdigest() == expected[name][variant]["md5"]
+    for _ in range(39):
+        assert capi.run(hip, files, args) == first
+
+
+@pytest.mark.parametrize("name,variant", [("C4", ""), ("bact20", "-S"), ("human8f", "-p0 -a1"), ("fuzz7126", "-D 300 -C 2"), ("manydoms", "-G"), ("dense", "")])
+def test_poisoned_allocations_change_nothing(hip, expected, tmp_path, name, variant):
+    """PANGENE_POISON=1 fills every fresh device and pinned allocation with a pattern: a kernel or the host reading memory that
+    nobody wrote then faults or changes the output instead of passing on whatever an earlier context left there."""
+    for mode in (2, 1):
+        out = _run_with_env(tmp_path, {"PANGENE_POISON": "1"}, mode, variant, golden_files(name))
+        assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
 
 
 @pytest.mark.parametrize("name,variant", all_cases())
