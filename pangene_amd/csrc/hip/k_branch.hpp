@@ -302,7 +302,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 	if (v >= n_vtx) return;
 	if (MODE == 2 && np_dev && *np_dev > pair_cap) return; // the list overflowed: there are no counts to read, the host repeats the step with room
 	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2) { if (MODE == 2 && lane == 0) sys_store(&ndl[v], 0); return; } // (every n_dist_loci entry is written: nothing to clear beforehand)
+	if (n < 2) { if (MODE == 2 && lane == 0) ndl[v] = 0; return; } // (every n_dist_loci entry is written: nothing to clear beforehand)
 	const int64_t k0 = poff[v];
 	if (MODE == 1 && k0 + pcnt[v] > pair_cap) return; // would run past the list: left out -- the total then exceeds the capacity too, the host sees that and repeats the round with room
 	if (n > WAVE) {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 			int32_t g = 0;
 			if (MODE == 2) for (int i = 0; i < n; ++i) grpg[a0 + i] = 0;
 			br_vertex_seq<MODE>(a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, grpg, &g, dcnt);
-			if (MODE == 2) sys_store(&ndl[v], g), vwk[v] = 1;
+			if (MODE == 2) ndl[v] = g, vwk[v] = 1;
 		}
 		return;
 	}
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 			if (lane > i && in && grp == 0 && cnt[k] > 0) grp = gi;
 		}
 	}
-	if (MODE == 2 && lane == 0) sys_store(&ndl[v], n_group); // (ndl is pinned host memory in the unsharded path)
+	if (MODE == 2 && lane == 0) ndl[v] = n_group; // (pinned host memory in the unsharded path: plain stores, released when the host asks the runtime about the stream)
 }
 
 __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107

@@ -17,9 +17,11 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t key) // pg_hash_uint32, pg
 }
 
 // Pinned host memory seen from a kernel.  The caches between a CU and the host are not part of the in-stream ordering the kernels
-// rely on among themselves (a store may rest in the L2 of the XCD that issued it until a system-scope release, a load may be
-// served from a line fetched for an earlier upload out of the same staging area): what crosses that boundary is accessed at
-// system scope, explicitly.
+// rely on among themselves: a plain store may rest in the L2 of the XCD that issued it until a system-scope release -- the one the
+// runtime issues when the host asks about the stream (sync_st), which is why the bulk results (segment counters, degrees,
+// n_dist_loci: thousands of words a round) can be plain stores.  The few words of the mailboxes and the staging-area reads of
+// k_copy_in are accessed at system scope explicitly (a system-scope store per word is slow: doing it for the bulk results made
+// the gene kernels 30 us slower).
 __device__ __forceinline__ void sys_store(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void sys_store(int64_t *p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ uint32_t sys_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }

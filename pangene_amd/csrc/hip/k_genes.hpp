@@ -224,8 +224,8 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 		a.deg[2 * sid] = m0, a.deg[2 * sid + 1] = m - m0;
 		a.vwk[2 * sid] = 0, a.vwk[2 * sid + 1] = 0;
 		if (a.h_round) {
-			sys_store(&a.h_round[sid], T.n_gen), sys_store(&a.h_round[a.S + sid], T.n_tot); // pinned host memory
-			sys_store(&a.h_round[2 * a.S + 2 * sid], m0), sys_store(&a.h_round[2 * a.S + 2 * sid + 1], m - m0);
+			a.h_round[sid] = T.n_gen, a.h_round[a.S + sid] = T.n_tot; // pinned host memory, plain stores (see sys_store in k_common.hpp)
+			a.h_round[2 * a.S + 2 * sid] = m0, a.h_round[2 * a.S + 2 * sid + 1] = m - m0;
 		}
 	}
 	if (NT == 64) wave_sync(); else __syncthreads();
