@@ -363,6 +363,38 @@ int sync_host(pg_data_t *d, bool full)
 
 // Fully tracked contigs need their exact S1 order from stage A on (first-wins ties); the index-0 channel alone only
 // matters from stage C on, so its hand-over (and the wait for the background replay) is deferred to pg_graph_gen then.
+// PANGENE_TRACE=<file>: after every step of the path, one line with a hash of each per-hit state array as the backend holds it
+// (file order, so independent of the backend's internal orders).  Two backends driven over the same input write the same
+// lines; the first line that differs names the step -- and so the group of kernels -- that went wrong (tests/test_trace.py).
+static const char *trace_path() { static const char *p = std::getenv("PANGENE_TRACE"); return (p && *p) ? p : nullptr; }
+static uint64_t fnv1a(const void *data, size_t n, uint32_t mask)
+{
+	uint64_t h = 1469598103934665603ull;
+	const uint32_t *w = (const uint32_t *)data;
+	for (size_t i = 0; i < n; ++i) {
+		uint32_t v = w[i] & mask;
+		for (int b = 0; b < 4; ++b) h = (h ^ (v & 0xffu)) * 1099511628211ull, v >>= 8;
+	}
+	return h;
+}
+static int trace_state(DataExt *ext, const char *step, int round, bool first = false)
+{
+	if (trace_path() == nullptr || ext == nullptr || ext->ctx == nullptr) return 0;
+	const size_t N = (size_t)ext->n_hit_local;
+	std::vector<uint32_t> flags(N + 1);
+	std::vector<int32_t> rank(N + 1), sdom(N + 1), pdom(N + 1), pdom0(N + 1), px(N + 1), py(N + 1);
+	pga_hit_state_t st = { flags.data(), rank.data(), sdom.data(), pdom.data(), pdom0.data(), px.data(), py.data(), nullptr };
+	BE_CALL(ext->be->download(ext->ctx, &st), "download(trace)");
+	std::FILE *fp = std::fopen(trace_path(), first ? "w" : "a");
+	if (fp == nullptr) return 0;
+	std::fprintf(fp, "%s\t%d\tflags=%016llx\trank=%016llx\tscore_dom=%016llx\tpid_dom=%016llx\tpid_dom0=%016llx\tpos_x=%016llx\tpos_y=%016llx\n", step, round,
+	             (unsigned long long)fnv1a(flags.data(), N, 0x7ffu), (unsigned long long)fnv1a(rank.data(), N, ~0u), (unsigned long long)fnv1a(sdom.data(), N, ~0u),
+	             (unsigned long long)fnv1a(pdom.data(), N, ~0u), (unsigned long long)fnv1a(pdom0.data(), N, ~0u), (unsigned long long)fnv1a(px.data(), N, ~0u),
+	             (unsigned long long)fnv1a(py.data(), N, ~0u));
+	std::fclose(fp);
+	return 0;
+}
+
 static bool exact_early(const DataExt *ext)
 {
 	if (exact_mode() == 2) return true;
@@ -411,6 +443,7 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 
 	std::vector<int32_t> st4((size_t)nl * 4);
 	{ Phase ph(PH_INGEST); BE_CALL(be->ingest(ctx, pg_verbose >= 3 ? st4.data() : nullptr), "ingest"); } // read.c:243-260 for every local genome
+	BE_CALL(trace_state(ext, "ingest", 0, true), "trace");
 	Phase ph_post(PH_POST);
 	if (pg_verbose >= 3)
 		for (int32_t k = 0; k < nl; ++k) {
@@ -472,6 +505,7 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 			             ext->local_genomes[(size_t)k], g->label ? g->label : "-", st2[(size_t)k*2], st2[(size_t)k*2+1]);
 		}
 	ext->host_stale = true;
+	BE_CALL(trace_state(ext, "post_process", 0), "trace");
 	return 0;
 }
 
@@ -791,11 +825,15 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	BE_CALL(gen_vtx(opt, q, ext), "gen_vtx");
 	if (!exact_early(ext)) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "set_head"); } // index 0 of the S1 order, needed from the first sweep of stage C on (see post_process_impl)
 	BE_CALL(flag_vtx(q, ext), "flag_vtx");
+	BE_CALL(trace_state(ext, "gen_vtx+flag_vtx", 0), "trace");
 	BE_CALL(gen_arc(opt, q, ext), "gen_arc");
+	BE_CALL(trace_state(ext, "gen_arc", 1), "trace");
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-1 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
 	// graph 2: after removing high-occurrence vertices (graph.c:293-298)
 	BE_CALL(flt_high_occ(opt->max_avg_occ * 2, opt->max_degree * 2, opt->max_dist_loci, q, ext), "flt_high_occ");
+	BE_CALL(trace_state(ext, "flt_high_occ", 1), "trace");
 	BE_CALL(gen_arc(opt, q, ext, opt->n_branch_flt > 0), "gen_arc");
+	BE_CALL(trace_state(ext, "gen_arc", 2), "trace");
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-2 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
 	// graph 3: branch filtering (graph.c:300-315)
 	for (int32_t i = 0; i < opt->n_branch_flt; ++i) {
@@ -805,8 +843,11 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 		int32_t max_dist_loci = (int32_t)(opt->max_dist_loci * r + .499);
 		BE_CALL(mark_branch_flt_arc(opt, q, ext), "mark_branch_flt_arc");
 		BE_CALL(mark_branch_flt_hit(q, ext), "mark_branch_flt_hit"); // with PG_SET_FILTER(weak_br == 2), graph.c:309
+		BE_CALL(trace_state(ext, "mark_branch", i + 3), "trace");
 		if (i > 0) BE_CALL(flt_high_occ(max_avg_occ, max_degree, max_dist_loci, q, ext), "flt_high_occ"); // with PG_SET_FILTER(vtx == 0), graph.c:312
+		if (i > 0) BE_CALL(trace_state(ext, "flt_high_occ", i + 3), "trace");
 		BE_CALL(gen_arc(opt, q, ext, i + 1 < opt->n_branch_flt), "gen_arc");
+		BE_CALL(trace_state(ext, "gen_arc", i + 3), "trace");
 	}
 	BE_CALL(be->set_filter(ctx, PGA_FLT_SHADOW), "set_filter"); // graph.c:316
 	BE_CALL(fetch_arcs(q, ext), "fetch_arcs");
