@@ -93,24 +93,22 @@ __global__ __launch_bounds__(BLOCK) void scan_tile_reduce(In in, int64_t n, T *t
 	if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
 }
 
-// exclusive scan of the tile sums, one workgroup, in place
+// exclusive scan of the tile sums, one workgroup, in place.  Every thread takes a contiguous chunk (its loads are independent of each
+// other, unlike a loop of 256-wide steps with a carried sum: 36 us -> a few us for the 6000 tiles of a 12 M-hit shard); chunks are
+// in order, so Op need not commute.
 template <class T, class Op>
 __global__ __launch_bounds__(BLOCK) void scan_tile_sums(T *tile_sum, int64_t n_tile, Op op, T identity)
 {
 	__shared__ T wave_tot[BLOCK / WAVE];
-	__shared__ T carry_s;
-	if (threadIdx.x == 0) carry_s = identity;
-	__syncthreads();
-	for (int64_t base = 0; base < n_tile; base += BLOCK) {
-		const int64_t i = base + threadIdx.x;
-		T v = i < n_tile ? tile_sum[i] : identity;
-		T tot;
-		T excl = block_scan_excl(v, op, identity, wave_tot, &tot);
-		T carry = carry_s;
-		if (i < n_tile) tile_sum[i] = op(carry, excl);
-		__syncthreads();
-		if (threadIdx.x == 0) carry_s = op(carry, tot);
-		__syncthreads();
+	const int64_t chunk = (n_tile + BLOCK - 1) / BLOCK, lo = (int64_t)threadIdx.x * chunk, hi = lo + chunk < n_tile ? lo + chunk : n_tile;
+	T a = identity;
+	for (int64_t i = lo; i < hi; ++i) a = op(a, tile_sum[i]);
+	T tot;
+	T excl = block_scan_excl(a, op, identity, wave_tot, &tot);
+	for (int64_t i = lo; i < hi; ++i) {
+		const T v = tile_sum[i];
+		tile_sum[i] = excl;
+		excl = op(excl, v);
 	}
 }
 

@@ -98,7 +98,6 @@ constexpr int GA_BIG_STAGE = 2048;             // hits the workgroup kernel stag
 
 struct GeneArcs {
 	const int32_t *zy; const int32_t *zoff; const uint32_t *hfk, *hbk; const int4 *hfp, *hbp; const int32_t *g2s;
-	int dbg; // tuning aid (PGA_GENE_DEBUG): 1 skip the table insertion, 2 skip the payload loads, 4 skip the output, 8 skip the group logic
 	int Q, S; uint32_t tag; int cap_log2; // table size actually used (<= GA_CAP; tests shrink it to reach the overflow paths)
 	int32_t *seg_cnt, *seg_gid;       // [2S] n_genome then tot_cnt (graph.c:125-126); [S] gene of each segment
 	pga_arc_part_t *stage; int4 *gmeta; // arcs of a gene at stage[gmeta.x ...): gmeta = {base, #arcs leaving (sid, +), #arcs leaving (sid, -), 0}
@@ -162,7 +161,7 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 				// (the two half-arcs of one hit never share a key: their orientation bits differ)
 				bool leader = true;
 				int n = 1;
-				for (int q = gs; q < ge && leader && ge - gs > 1 && !(a.dbg & 8); ++q) {
+				for (int q = gs; q < ge && leader && ge - gs > 1; ++q) {
 					if (q == z) continue;
 					const int rq = W.zy(q) & 1;
 #pragma unroll
@@ -174,7 +173,7 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 					}
 				}
 				if (!leader) continue;
-				const int4 h = (a.dbg & 2) ? make_int4(5, 6, 7, 0) : dir ? a.hbp[z] : a.hfp[z]; // the payload: distance and the two scores
+				const int4 h = dir ? a.hbp[z] : a.hfp[z]; // the payload: distance and the two scores
 				int m1 = h.y, m2 = h.z;
 				unsigned long long sd = (unsigned long long)(long long)h.x;
 				if (n > 1) // rare: the same adjacency twice in one genome
@@ -190,7 +189,6 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 					}
 				m1 = m1 > 0 ? m1 : 0, m2 = m2 > 0 ? m2 : 0; // the reference's running maxima start at 0 (graph.c:133)
 				const int dg = (int32_t)((double)(long long)sd / n + .499); // graph.c:141
-				if (a.dbg & 1) continue;
 				// level 2 (graph.c:153-169): sums over the genomes, LDS table keyed by (orientation, target)
 				uint32_t slot = (key * 2654435761u) >> (32 - cap_log2);
 				int probes = 0;
@@ -229,7 +227,7 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 		}
 	}
 	if (NT == 64) wave_sync(); else __syncthreads();
-	for (int e = tid; e < m && !(a.dbg & 4); e += NT) { // rank among the gene's entries = place in its stretch (keys are distinct)
+	for (int e = tid; e < m; e += NT) { // rank among the gene's entries = place in its stretch (keys are distinct)
 		const int k = T.dense[e];
 		const uint32_t key = T.key[k];
 		int r = 0;

@@ -852,8 +852,7 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	int32_t *big = (int32_t *)c->pool.get(S_BIGLIST, sizeof(int32_t) * (size_t)std::max(1, c->Q));
 	if (!big) return PGA_ERR_NOMEM;
 	static const int cap_log2 = [] { const char *e = getenv("PANGENE_GENE_TABLE_LOG2"); const int v = e ? atoi(e) : 9; return v < 1 ? 1 : v > 9 ? 9 : v; }();
-	static const int gdbg = [] { const char *e = getenv("PGA_GENE_DEBUG"); return e ? atoi(e) : 0; }();
-	GeneArcs ga = { c->zy, c->zoff, c->hfk, c->hbk, c->hfp, c->hbp, c->g2s, gdbg, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta,
+	GeneArcs ga = { c->zy, c->zoff, c->hfk, c->hbk, c->hfp, c->hbp, c->g2s, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta,
 	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt };
 	hipLaunchKernelGGL(k_gene_arcs_wave, dim3((unsigned)c->Q), dim3(BLOCK), 0, c->st, ga);
 	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 8 * c->n_cu)), dim3(BLOCK), 0, c->st, ga);

@@ -41,7 +41,7 @@ def test_device_primitives(hip):
         assert raw.pga_selftest_sort(k2.ctypes.data_as(C.c_void_p), v2.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int32(nb)) == 0
         o = np.argsort(k, kind="stable")
         assert np.array_equal(k2, k[o]) and np.array_equal(v2, v[o])
-    for n in [1, 100, 1024, 1025, 300000, 2_000_001]:
+    for n in [1, 100, 1024, 1025, 300000, 2_000_001, 5_000_011]:  # the last one has more than 2048 tiles: the three-launch form of the scan
         a = rng.integers(-5, 50, size=n).astype(np.int32)
         seg = np.sort(rng.integers(0, max(1, n // 7), size=n)).astype(np.int32)
         out = np.zeros(n, dtype=np.int32)
@@ -53,11 +53,8 @@ def test_device_primitives(hip):
             elif mode == 1:
                 exp = np.concatenate(([-1], np.maximum.accumulate(np.maximum(a, -1))[:-1])).astype(np.int32)
             else:
-                exp = a.copy()
-                start = np.concatenate(([True], seg[1:] != seg[:-1]))
-                for i in range(1, n):
-                    if not start[i] and exp[i - 1] > exp[i]:
-                        exp[i] = exp[i - 1]
+                # running maximum inside the segments: seg is sorted and a in [-5, 50), so a + 100 seg restarts above every earlier value
+                exp = (np.maximum.accumulate(a.astype(np.int64) + 100 * seg.astype(np.int64)) - 100 * seg.astype(np.int64)).astype(np.int32)
             assert np.array_equal(out, exp), (n, mode)
 
 
@@ -112,7 +109,7 @@ def _run_with_env(tmp_path, env, mode, variant, files):
 
 
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
-@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1"}, {"PANGENE_GENE_TABLE_LOG2": "2"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1"}])
+@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1"}])
 def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
     (the path of rounds in which a hub gene overflows the per-gene LDS table).  Forcing the sort path, and shrinking the table to 4
