@@ -343,6 +343,12 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 {
 	if (c == nullptr) return;
 	if (c->st) (void)hipStreamSynchronize(c->st);
+	if (getenv("PANGENE_TIMING")) { // how well the one-allocation plan of create_impl fitted the run
+		size_t n_own = 0, b_own = 0;
+		for (size_t i = 0; i < c->pool.p.size(); ++i) if (c->pool.p[i] && c->pool.own[i]) ++n_own, b_own += c->pool.cap[i];
+		fprintf(stderr, "[pga_destroy] %d hits: temporaries used %.1f of %.1f MB of their arena, %zu slots (%.1f MB) had to be allocated on their own\n",
+		        c->N, c->pool.arena_off / 1048576.0, c->pool.arena_cap / 1048576.0, n_own, b_own / 1048576.0);
+	}
 	for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	if (c->span_a) (void)hipEventDestroy(c->span_a);
 	for (void *q : c->owned) (void)hipFree(q);
@@ -447,7 +453,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->any_multi = multi;
 
 	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
-		const size_t per_hit = 420, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
+		const size_t per_hit = 560 /* measured: 530-540 B/hit at 1 M and 12 M hits (PANGENE_TIMING reports the fit at destroy) */, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
 		const size_t want = ((size_t)N * per_hit + tables + (64u << 20) + (size_t)woff[(size_t)GL] * 4 + 255) & ~(size_t)255;
 		void *a = nullptr;
 		if (getenv("PANGENE_NO_POOL_ARENA") == nullptr && hipMalloc(&a, want) == hipSuccess) { // else: slot by slot

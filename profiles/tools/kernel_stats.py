@@ -15,7 +15,7 @@ for r in rows:
 try:
     k1 = [r[0] for r in cur.execute("SELECT duration FROM kernels WHERE name LIKE '%k_sweep<1,%'").fetchall()]
     if k1:
-        full = [d for d in k1 if d > 0.25 * max(k1)]
+        full = [d for d in k1 if d > 0.6 * max(k1)]
         print("# K1 k_sweep<1, *>: %d launches on the shard (of %d), mean %.2f us" % (len(full), len(k1), sum(full) / len(full) / 1e3))
 except Exception as ex:
     print("# (no K1 line: %s)" % ex)
