@@ -586,6 +586,13 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	}
 	ksort_exact(cnt.data(), cnt.size(), [](const pg128_t &a) { return a.x; }); // vertex.c:59, tie order matters
 	q->n_seg = 0;
+	if (q->m_seg < Q) { // room for every gene at once (the loop below would otherwise grow the array a dozen times)
+		const int32_t old_m = q->m_seg;
+		q->m_seg = Q + 16;
+		q->seg = (pg_seg_t *)std::realloc(q->seg, sizeof(pg_seg_t) * (size_t)q->m_seg);
+		std::memset((void *)(q->seg + old_m), 0, sizeof(pg_seg_t) * (size_t)(q->m_seg - old_m));
+	}
+	marked.reserve((size_t)nw * 1024);
 	ext->vtx_sel_text.clear();
 	for (int32_t i = Q - 1; i >= 0; --i) { // vertex.c:60-80
 		const int32_t n_dom = (int32_t)(cnt[(size_t)i].x << 1 >> 33), n_sub = (int32_t)(cnt[(size_t)i].y >> 32);
@@ -621,7 +628,13 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	}
 	if (std::getenv("PANGENE_VTX_TIMING")) std::fprintf(stderr, "[vtx] partials %.3f ms, fetch %.3f ms (records %ld / %ld), greedy %.3f ms\n", (tv1 - tv0) * 1e3, (tv2 - tv1) * 1e3, (long)n_tri, (long)n_rec, (now_sec() - tv2) * 1e3);
 	// segments by gene id (vertex.c:85-94; keys unique, any sort gives the reference's order)
-	std::sort(q->seg, q->seg + q->n_seg, [](const pg_seg_t &a, const pg_seg_t &b) { return a.gid < b.gid; });
+	{ // (gene ids are unique and < Q: one placement pass instead of a comparison sort)
+		std::vector<int32_t> at((size_t)Q, -1);
+		for (int32_t i = 0; i < q->n_seg; ++i) at[(size_t)q->seg[i].gid] = i;
+		std::vector<pg_seg_t> tmp(q->seg, q->seg + q->n_seg);
+		int32_t k = 0;
+		for (int32_t g = 0; g < Q; ++g) if (at[(size_t)g] >= 0) q->seg[k++] = tmp[(size_t)at[(size_t)g]];
+	}
 	gen_g2s(q);
 	if (pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] selected %d vertices out of %d genes\n", "pg_gen_vtx", stamp(), q->n_seg, Q);
@@ -638,6 +651,12 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer 
 	const int32_t S = q->n_seg;
 	int32_t *b_seg; pga_arc_part_t *b_arc; int64_t n_loc;
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 1), "override_order"); } // graph.c:103
+	if (!sharded() && defer && pg_verbose < 3 && be->arc_round_finish) { // the host results are collected later (arc_collect): nothing to prepare here
+		{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, nullptr, nullptr), "arc_round"); }
+		{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
+		ext->arc_pending = true, ext->cur_arcs = nullptr, q->n_arc = 0;
+		return 0;
+	}
 	std::vector<int32_t> sc((size_t)S * 2 + 1);
 	ext->deg.assign((size_t)S * 2 + 1, 0);
 	if (!sharded()) {
@@ -645,12 +664,6 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer 
 		// it) resident; it travels to the host once, after the last round (fetch_arcs)
 		int64_t n_arc = 0;
 		const pga_arc_part_t *tab = nullptr;
-		if (defer && pg_verbose < 3 && be->arc_round_finish) {
-			{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, nullptr, nullptr), "arc_round"); }
-			{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
-			ext->arc_pending = true, ext->cur_arcs = nullptr, q->n_arc = 0;
-			return 0;
-		}
 		{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, sc.data(), ext->deg.data()), "arc_round"); }
 		if (pg_verbose >= 3) BE_CALL(be->arc_table(ext->ctx, &tab, &n_arc), "arc_table"); // only the log lines want the number of arcs of every round
 		{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
