@@ -75,7 +75,7 @@ typedef struct {
 } pga_genome_block_t;
 
 /* One shard = a set of genomes with all their hits (pg_hit_t pangene.h:61-72, pg_exon_t 44-46, pg_genome_t 79-87).
- * Device layout limits (PGA_ERR_RANGE otherwise): contig coordinates < 2^31 (pangene.h:71 has int64), < 2^31 hits and
+ * Device layout limits (PGA_ERR_RANGE otherwise): contig coordinates < 2^31 (pangene.h:71 has int64), < 2^30 hits and < 2^31
  * exons per shard, < 2^20 genes, < 2^24 genomes. */
 typedef struct {
 	int32_t n_genome;            /* genomes in this shard (may include genomes with 0 hits) */

@@ -560,7 +560,7 @@ extern "C" int pga_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_para
 		fprintf(stderr, "[E::pga_create] no HIP device is visible; libpangene_amd has no CPU fallback\n");
 		return PGA_ERR_NO_DEVICE;
 	}
-	if (sh->n_hit >= INT32_MAX || sh->n_exon >= INT32_MAX || sh->n_gene >= (1 << 20) || sh->n_genome_global >= (1 << 24)) return PGA_ERR_RANGE;
+	if (sh->n_hit >= (1 << 30) /* arc table positions are 2 * (gene-major index) in 32 bits */ || sh->n_exon >= INT32_MAX || sh->n_gene >= (1 << 20) || sh->n_genome_global >= (1 << 24)) return PGA_ERR_RANGE;
 	pga_ctx *c = new pga_ctx();
 	c->n_genome = sh->n_genome, c->n_genome_global = sh->n_genome_global, c->P = sh->n_prot, c->Q = sh->n_gene;
 	c->N = (int32_t)sh->n_hit, c->E = (int32_t)sh->n_exon, c->par = *par;
