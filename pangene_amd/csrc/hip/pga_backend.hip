@@ -147,6 +147,7 @@ struct pga_ctx {
 	int64_t *h_cnt = 0;     // pinned mirror
 	int64_t *h_box = 0;     // the same memory as the device sees it
 	void *h_stage = nullptr; size_t h_stage_cap = 0; // pinned landing area of fetch_later
+	void *h_fetch = nullptr; size_t h_fetch_cap = 0; // pinned landing area of pga_fetch
 	int32_t *h_g2s = nullptr; size_t h_g2s_cap = 0; hipEvent_t g2s_done = nullptr; // pinned staging of flag_vtx's gene -> segment map
 	DevPool pool; PinArena pin;
 	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
@@ -1368,6 +1369,20 @@ extern "C" int pga_fetch_later(pga_ctx_t *c, const void *src_backend, size_t nby
 extern "C" int pga_fetch(pga_ctx_t *c, void *dst_host, const void *src_backend, size_t nbytes)
 {
 	if (nbytes == 0) return 0;
+	// dst_host is caller memory, as a rule pageable: a copy straight into it makes the runtime stage it, or pin and unpin the
+	// pages (megabytes: milliseconds, part of them charged to whatever runtime call comes next).  Up to a few megabytes the data
+	// lands in a pinned buffer of the context first.
+	if (nbytes <= ((size_t)2 << 20)) {
+		if (c->h_fetch_cap < nbytes) {
+			c->h_fetch = c->pin.get(nbytes + nbytes / 2 + 256);
+			if (!c->h_fetch) return PGA_ERR_NOMEM;
+			c->h_fetch_cap = nbytes + nbytes / 2 + 256;
+		}
+		HIPCHK(hipMemcpyAsync(c->h_fetch, src_backend, nbytes, hipMemcpyDeviceToHost, c->st));
+		TRY(sync_st(c));
+		memcpy(dst_host, c->h_fetch, nbytes);
+		return 0;
+	}
 	HIPCHK(hipMemcpyAsync(dst_host, src_backend, nbytes, hipMemcpyDeviceToHost, c->st));
 	return sync_st(c);
 }

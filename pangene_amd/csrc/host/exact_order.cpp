@@ -194,7 +194,9 @@ static void spawn_replay(DataExt *ext)
 // them.  A repeated run on the same shard (pg_rerun_resident) finds the replay done.
 void exact_begin(DataExt *ext)
 {
+	const double t0 = now_sec();
 	exact_wait(ext);
+	if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[exact_begin] waited %.3f ms for the order replay the reader started\n", (now_sec() - t0) * 1e3);
 	ext->head_file.assign(ext->local_genomes.size(), -1);
 	ext->x_sorts[0] = ext->x_sorts[1] = 0;
 	for (ExactSeg &s : ext->xsegs) s.pushed[0].clear(), s.pushed[1].clear();

@@ -214,6 +214,16 @@ static void *block_alloc(DataExt *ext, size_t bytes)
 	return r;
 }
 
+static void slab_put(HostSlab &s) // back into the process-wide cache (or to the system)
+{
+	if (s.p == nullptr) return;
+	std::lock_guard<std::mutex> lk(g_slab_mu);
+	if (s.pinned && g_slab_cached + s.cap <= SLAB_CACHE_MAX) g_slab_cache.push_back(s), g_slab_cached += s.cap;
+	else if (s.pinned) backend_default()->host_free(s.p);
+	else std::free(s.p);
+	s.p = nullptr;
+}
+
 void free_packs(DataExt *ext, bool wait)
 {
 	(void)wait;
@@ -291,14 +301,26 @@ int sync_host(pg_data_t *d, bool full)
 	Phase ph(PH_SYNC_HOST);
 	const int64_t N = ext->n_hit_local;
 	const bool need_pos = !ext->pos_valid;
-	std::vector<uint32_t> flags;
-	std::vector<int32_t> rank, sdom, pdom, pdom0, py;
-	if (full) flags.resize((size_t)N), rank.resize((size_t)N), sdom.resize((size_t)N), pdom.resize((size_t)N), pdom0.resize((size_t)N);
-	if (need_pos) ext->pos_x.resize((size_t)N), py.resize((size_t)N);
-	ext->flt_bits.resize((size_t)((N + 63) / 64) + 1);
-	pga_hit_state_t st = { full ? flags.data() : nullptr, full ? rank.data() : nullptr, full ? sdom.data() : nullptr, full ? pdom.data() : nullptr,
-	                       full ? pdom0.data() : nullptr, need_pos ? ext->pos_x.data() : nullptr, need_pos ? py.data() : nullptr, ext->flt_bits.data() };
-	BE_CALL(ext->be->download(ext->ctx, &st), "download");
+	// The arrays land in one of the pinned slabs the genome blocks were uploaded from (idle by now, kept in the process-wide
+	// cache): megabytes copied into pageable memory make the runtime pin and unpin the destination, which costs milliseconds and
+	// was seen to stall the NEXT runtime call of a process's first big run by 10-25 ms.
+	const size_t nbits = (size_t)((N + 63) / 64) + 1, n_arr = (full ? 5 : 0) + (need_pos ? 2 : 0);
+	HostSlab land = slab_get(sizeof(int32_t) * (size_t)N * n_arr + sizeof(uint64_t) * nbits + 64);
+	if (land.p == nullptr) { set_error(PGA_ERR_NOMEM, "sync_host"); return g_err; }
+	int32_t *w = (int32_t *)land.p;
+	uint32_t *flags = nullptr;
+	int32_t *rank = nullptr, *sdom = nullptr, *pdom = nullptr, *pdom0 = nullptr, *pxl = nullptr, *py = nullptr;
+	if (full) flags = (uint32_t *)w, rank = w + (size_t)N, sdom = w + 2 * (size_t)N, pdom = w + 3 * (size_t)N, pdom0 = w + 4 * (size_t)N, w += 5 * (size_t)N;
+	if (need_pos) pxl = w, py = w + (size_t)N, w += 2 * (size_t)N;
+	uint64_t *bits = (uint64_t *)(land.p + ((((char *)w - land.p) + 7) & ~(size_t)7));
+	pga_hit_state_t st = { flags, rank, sdom, pdom, pdom0, pxl, py, bits };
+	{
+		const int rc = ext->be->download(ext->ctx, &st);
+		if (rc) { slab_put(land); set_error(rc, "download"); return rc; }
+	}
+	ext->flt_bits.assign(bits, bits + nbits);
+	if (need_pos) ext->pos_x.assign(pxl, pxl + (size_t)N);
+	struct Land { HostSlab &s; ~Land() { slab_put(s); } } land_guard{land}; // released when the records have been updated
 	const int32_t *px = ext->pos_x.data();
 	ext->y_file.resize((size_t)d->n_genome);
 	ext->file_of_host.resize((size_t)d->n_genome);
@@ -932,12 +954,17 @@ pg_graph_t *pg_graph_init(pg_data_t *d) // graph.c:34-41
 static int hazards_review(DataExt *ext, bool *need, bool *give_up)
 {
 	pga_hazard_t hz;
+	const double th0 = now_sec();
 	BE_CALL(ext->be->hazards(ext->ctx, &hz), "hazards");
+	const double th1 = now_sec();
+	double th2 = th1, th3 = th1;
 	int32_t flags[2] = { 0, 0 }; // {need, give up}
 	if (hz.h2_cm_tie + hz.h3_dom_tie + hz.h2_cs_tie > 0) {
 		std::vector<int32_t> segs(PGA_HAZARD_CAP);
 		int64_t n_total = 0;
+		th2 = now_sec();
 		BE_CALL(ext->be->hazard_segs(ext->ctx, segs.data(), (int32_t)segs.size(), &n_total), "hazard_segs");
+		th3 = now_sec();
 		const int64_t n_got = std::min<int64_t>(n_total, (int64_t)segs.size());
 		if (n_total > n_got) flags[0] = flags[1] = 1;
 		// contig-segment id -> (local genome, contig): the shard lists the contigs genome-major
@@ -966,6 +993,8 @@ static int hazards_review(DataExt *ext, bool *need, bool *give_up)
 		BE_CALL(ext->be->fetch(ext->ctx, flags, scr, sizeof(flags)), "fetch");
 	}
 	*need = flags[0] != 0, *give_up = flags[1] != 0;
+	if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[hazards_review] counters %.3f ms, list set-up %.3f ms, list fetch %.3f ms, rest %.3f ms (cm %ld dom %ld cs %ld)\n",
+	                                               (th1 - th0) * 1e3, (th2 - th1) * 1e3, (th3 - th2) * 1e3, (now_sec() - th3) * 1e3, (long)hz.h2_cm_tie, (long)hz.h3_dom_tie, (long)hz.h2_cs_tie);
 	return 0;
 }
 
@@ -973,15 +1002,22 @@ void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 {
 	double t = now_sec();
 	if (g_err == 0 && graph_gen_impl(opt, q) != 0) q->n_arc = 0;
+	const double t_first = now_sec() - t;
+	int n_attempt = 1;
 	DataExt *ext = ext_of(q->d, false);
 	if (ext) ext->q_d = q->d;
 	// Mode auto: the canonical order provably gives the reference's result unless a tie-order hazard occurred.  Where one
 	// did, the contigs concerned get the reference's exact order (replayed on the host) and stages A-C are repeated on the
 	// resident shard; hazards that then only occur on such contigs are harmless.  After three attempts, or when the event
 	// list overflowed, every contig is tracked (mode "all").  The decision is collective when sharded.
+	double t_review = 0.0;
+	const double path_before = g_path_sec; // what pg_post_process measured
 	for (int attempt = 0; g_err == 0 && ext && exact_mode() == 1; ++attempt) {
 		bool need = false, give_up = false;
-		if (hazards_review(ext, &need, &give_up) != 0 || !need) break;
+		const double tr0 = now_sec();
+		const int rc_review = hazards_review(ext, &need, &give_up);
+		t_review += now_sec() - tr0;
+		if (rc_review != 0 || !need) break;
 		// Only the contigs on which the ties occurred get the reference's exact order (the event list covers every channel of
 		// equal cm of walkable neighbours, equal-key dominators / sub-optimal isoforms, cs ties that decide a
 		// local_count test); the repeated run is reviewed again, and ties that then only occur on tracked contigs are harmless.
@@ -997,6 +1033,7 @@ void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 		q->n_seg = 0, q->n_arc = 0;
 		std::memset((void *)q->seg, 0, sizeof(pg_seg_t) * (size_t)q->m_seg);
 		ext->rerun = true;
+		++n_attempt;
 		if (post_process_impl(opt, q->d) != 0 || graph_gen_impl(opt, q) != 0) q->n_arc = 0;
 		if (all) { exact_override(-1); break; }
 	}
@@ -1013,7 +1050,7 @@ void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 	if (std::getenv("PANGENE_TIMING")) {
 		std::fprintf(stderr, "[phases]");
 		for (int i = 0; i < PH_COUNT; ++i) std::fprintf(stderr, " %s %.2f", pg_phase_name(i), g_phase[i] * 1e3);
-		std::fprintf(stderr, " | path %.2f ms\n", g_path_sec * 1e3);
+		std::fprintf(stderr, " | path %.2f ms (%d attempt%s; pg_post_process %.2f, pg_graph_gen's first attempt %.2f, hazard review %.2f ms)\n", g_path_sec * 1e3, n_attempt, n_attempt > 1 ? "s: tie-order hazards" : "", path_before * 1e3, t_first * 1e3, t_review * 1e3);
 	}
 }
 
