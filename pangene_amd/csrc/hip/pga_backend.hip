@@ -1217,8 +1217,7 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 	const int64_t n_arc = c->br_n;
 	if (n_flt1) *n_flt1 = 0;
 	if (n_flt2) *n_flt2 = 0;
-	if (n_vtx) memset(n_dist_loci, 0, sizeof(int32_t) * (size_t)n_vtx);
-	if (n_arc == 0 || n_vtx == 0) return 0;
+	if (n_arc == 0 || n_vtx == 0) { if (n_vtx) memset(n_dist_loci, 0, sizeof(int32_t) * (size_t)n_vtx); return 0; }
 	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, 0);
 	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, 0), *agid = (int32_t *)c->pool.get(S_BR_GID, 0), *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0);
 	int32_t *poff = (int32_t *)c->pool.get(S_BR_POFF, 0);

@@ -739,8 +739,9 @@ static int arc_collect(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	if (!ext->arc_pending) return 0;
 	ext->arc_pending = false;
 	const int32_t S = q->n_seg;
-	std::vector<int32_t> sc((size_t)S * 2 + 1);
-	ext->deg.assign((size_t)S * 2 + 1, 0);
+	std::vector<int32_t> &sc = ext->sc_buf; // (both buffers are overwritten in full: no clearing, no allocation per round)
+	if (sc.size() < (size_t)S * 2 + 1) sc.resize((size_t)S * 2 + 1);
+	if (ext->deg.size() < (size_t)S * 2 + 1) ext->deg.resize((size_t)S * 2 + 1);
 	int rc = ext->be->arc_round_finish(ext->ctx, S, sc.data(), ext->deg.data());
 	if (rc < 0) { set_error(rc, "arc_round_finish"); return rc; }
 	if (rc == 1) BE_CALL(ext->be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, sc.data(), ext->deg.data()), "arc_round");

@@ -72,6 +72,7 @@ struct DataExt {
 	std::vector<std::vector<int32_t>> y_file;  // per genome: FILE index of the k-th hit in cm order
 	std::vector<ExactSeg> xsegs;
 	std::vector<int32_t> deg;          // out-degree of every oriented vertex of the round's arc table
+	std::vector<int32_t> sc_buf;       // landing area of a round's segment counters (arc_collect)
 	const pga_arc_part_t *cur_arcs = nullptr; // the round's arc table, in backend memory
 	std::string vtx_sel_text;          // -G output of the current run (printed when pg_graph_gen returns)
 	int exact_mode_of_segs = -1;       // mode xsegs was built for
