@@ -182,7 +182,7 @@ typedef struct {
 	 * delivers the two arrays.  It returns 1 when the round has to be repeated (a plain arc_round_local call; whatever was \
 	 * queued behind the first one has to be repeated after it as well). */ \
 	int  pfx##_arc_round_local(pga_ctx_t *ctx, int32_t use_ori, int32_t n_seg, int32_t *seg_cnt, int32_t *deg); \
-	int  pfx##_arc_round_finish(pga_ctx_t *ctx, int32_t n_seg, int32_t *seg_cnt, int32_t *deg); \
+	int  pfx##_arc_round_finish(pga_ctx_t *ctx, int32_t n_seg, int32_t *seg_cnt, int32_t *deg); /* seg_cnt = deg = NULL: the status only */ \
 	/* the graph's current arc table (of arc_round_local or arc_set_current) as ONE array sorted by x, in backend memory */ \
 	int  pfx##_arc_table(pga_ctx_t *ctx, const pga_arc_part_t **arcs, int64_t *n_arc); \
 	/* pg_gen_rep_pos (branch.c:6-29) kept in backend memory */ \
@@ -205,6 +205,15 @@ typedef struct {
 	                        double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs); \
 	int  pfx##_branch_decide(pga_ctx_t *ctx, double branch_diff, double branch_diff_dist, double branch_diff_cut, uint8_t *arc_weak, \
 	                         int32_t *n_dist_loci, int64_t *n_flt1, int64_t *n_flt2); \
+	/* branch_decide for a run that is not sharded, behind an arc round whose host results have not been collected yet \
+	 * (arc_round_local(seg_cnt = NULL)): n_dist_loci stays on the backend, and with do_filter != 0 the three tests of \
+	 * pg_flt_high_occ (graph.c:226-258) are made there too -- del[s] = 1 (host, n_seg bytes) when segment s has \
+	 * tot_cnt > max_tot_cnt, an oriented vertex with more than max_degree out-arcs, or more than max_dist_loci distant loci \
+	 * on a side -- so that the round's counters, degrees and n_dist_loci (12 n_seg words) need not travel; the caller \
+	 * then asks arc_round_finish(NULL, NULL) whether the round stands.  Waits.  Returns 2 when the preconditions do not \
+	 * hold (the round took the sort path): the caller uses branch_decide + arc_round_finish + its own tests instead. */ \
+	int  pfx##_branch_decide_filter(pga_ctx_t *ctx, double branch_diff, double branch_diff_dist, double branch_diff_cut, int32_t do_filter, \
+	                                int32_t max_tot_cnt, int32_t max_degree, int32_t max_dist_loci, uint8_t *del); \
 	/* pg_mark_branch_flt_hit (branch.c:108-145); arcs sorted by x with their weak_br (0 allowed).  then_filter != 0: followed at \
 	 * once by PG_SET_FILTER(weak_br == 2) (graph.c:309), in the same pass over the hits */ \
 	int  pfx##_mark_hits(pga_ctx_t *ctx, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked, int32_t then_filter); \
@@ -299,6 +308,7 @@ typedef struct {
 	int  (*gene_matrix)(pga_ctx_t *, const int32_t *, int32_t, int32_t, int32_t *);
 	int  (*arc_table)(pga_ctx_t *, const pga_arc_part_t **, int64_t *);
 	int  (*arc_round_finish)(pga_ctx_t *, int32_t, int32_t *, int32_t *);
+	int  (*branch_decide_filter)(pga_ctx_t *, double, double, double, int32_t, int32_t, int32_t, int32_t, uint8_t *); /* may be NULL */
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);

@@ -829,7 +829,7 @@ int pgo_arc_table(pga_ctx_t *c, const pga_arc_part_t **arcs, int64_t *n_arc) { *
 int pgo_arc_round_finish(pga_ctx_t *c, int32_t n_seg, int32_t *seg_cnt, int32_t *deg)
 {
 	if (c->def_sc == 0) return PGA_ERR_ARG;
-	memcpy(seg_cnt, c->def_sc, 2 * (size_t)n_seg * sizeof(int32_t)); memcpy(deg, c->def_deg, 2 * (size_t)n_seg * sizeof(int32_t));
+	if (seg_cnt) { memcpy(seg_cnt, c->def_sc, 2 * (size_t)n_seg * sizeof(int32_t)); memcpy(deg, c->def_deg, 2 * (size_t)n_seg * sizeof(int32_t)); } /* NULL: status only */
 	free(c->def_sc); free(c->def_deg); c->def_sc = c->def_deg = 0;
 	return PGA_OK;
 }
@@ -899,6 +899,24 @@ int pgo_branch_decide(pga_ctx_t *c, double branch_diff, double branch_diff_dist,
 	if (n_flt1) *n_flt1 = f1;
 	if (n_flt2) *n_flt2 = f2;
 	return PGA_OK;
+}
+
+/* branch_decide + the three tests of pg_flt_high_occ (graph.c:226-258) behind a deferred arc round */
+int pgo_branch_decide_filter(pga_ctx_t *c, double branch_diff, double branch_diff_dist, double branch_diff_cut, int32_t do_filter,
+                             int32_t max_tot_cnt, int32_t max_degree, int32_t max_dist_loci, uint8_t *del)
+{
+	int32_t s, S = c->br_S, *ndl;
+	int rc;
+	if (c->def_sc == 0 || (do_filter && del == 0)) return 2; /* no deferred round pending: the caller takes the classic calls */
+	ndl = CALLOC(int32_t, 2 * (int64_t)S + 1);
+	rc = pgo_branch_decide(c, branch_diff, branch_diff_dist, branch_diff_cut, 0, ndl, 0, 0);
+	if (rc == PGA_OK && do_filter)
+		for (s = 0; s < S; ++s) {
+			int32_t m = ndl[2 * s] > ndl[2 * s + 1] ? ndl[2 * s] : ndl[2 * s + 1];
+			del[s] = c->def_sc[S + s] > max_tot_cnt || c->def_deg[2 * s] > max_degree || c->def_deg[2 * s + 1] > max_degree || m > max_dist_loci;
+		}
+	free(ndl);
+	return rc;
 }
 
 static int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) /* pg_get_arc, pgpriv.h:99-107 */
@@ -1076,7 +1094,7 @@ const pga_backend_t *pgo_backend(void)
 	static const pga_backend_t b = {
 		"oracle", pgo_create, pgo_destroy, pgo_begin, pgo_ingest, pgo_post_partials, pgo_post_apply, pgo_shadow, pgo_set_filter,
 		pgo_vtx_partials, pgo_flag_vtx, pgo_arc_round, pgo_arc_merge, pgo_arc_set_current, pgo_rep_pos, pgo_n_local, pgo_branch_pairs, pgo_branch_decide, pgo_mark_hits, pgo_override_order, pgo_set_head, pgo_fetch, pgo_put, pgo_copy, pgo_scratch, pgo_download,
-		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs, pgo_host_alloc, pgo_host_free, pgo_arc_round_local, pgo_ctg_counts, pgo_gene_matrix, pgo_arc_table, pgo_arc_round_finish
+		pgo_hazards, pgo_is_device, pgo_strerror, 0, 0, pgo_sync, pgo_fetch_later, pgo_hazard_segs, pgo_host_alloc, pgo_host_free, pgo_arc_round_local, pgo_ctg_counts, pgo_gene_matrix, pgo_arc_table, pgo_arc_round_finish, pgo_branch_decide_filter
 	};
 	return &b;
 }

@@ -356,6 +356,16 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 	if (MODE == 2 && lane == 0) ndl[v] = n_group; // (pinned host memory in the unsharded path: plain stores, released when the host asks the runtime about the stream)
 }
 
+// pg_flt_high_occ's three tests (graph.c:226-258) for every segment of the round, from what the round left on the device:
+// seg_cnt[S + s] = tot_cnt (graph.c:126), deg[] = out-degree of each oriented vertex, ndl[] = n_dist_loci of the branch step
+__global__ __launch_bounds__(BLOCK) void k_round_filter(int S, const int32_t *seg_cnt, const int32_t *deg, const int32_t *ndl, int max_tot_cnt, int max_degree, int max_dist_loci, uint8_t *del)
+{
+	const int s = blockIdx.x * BLOCK + threadIdx.x;
+	if (s >= S) return;
+	const int l0 = ndl[2 * s], l1 = ndl[2 * s + 1];
+	del[s] = (seg_cnt[S + s] > max_tot_cnt || deg[2 * s] > max_degree || deg[2 * s + 1] > max_degree || (l0 > l1 ? l0 : l1) > max_dist_loci) ? 1 : 0;
+}
+
 __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107
 {
 	int64_t lo = 0, hi = n;

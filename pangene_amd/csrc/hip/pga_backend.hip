@@ -975,7 +975,7 @@ static int arc_round_check(pga_ctx *c, int S, int32_t *seg_cnt_host, int32_t *de
 	const int32_t *tail = c->h_round + 2 * (size_t)n_vtx; // {overflowed genes, invariant violations} of THIS round (the mailbox may have moved on)
 	if (tail[1]) return PGA_ERR_INVARIANT;
 	if (tail[0]) return 1;
-	if (n_vtx) memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
+	if (n_vtx && seg_cnt_host) memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
 	return 0;
 }
 
@@ -1025,7 +1025,7 @@ extern "C" int pga_arc_round_finish(pga_ctx_t *c, int32_t n_seg, int32_t *seg_cn
 	if (c->arc_done) { // the round took the sort path and is complete
 		const size_t n_vtx = 2 * (size_t)n_seg;
 		c->arc_done = false;
-		if (n_vtx) memcpy(seg_cnt_host, c->def_host.data(), sizeof(int32_t) * n_vtx), memcpy(deg_host, c->def_host.data() + n_vtx, sizeof(int32_t) * n_vtx);
+		if (n_vtx && seg_cnt_host) memcpy(seg_cnt_host, c->def_host.data(), sizeof(int32_t) * n_vtx), memcpy(deg_host, c->def_host.data() + n_vtx, sizeof(int32_t) * n_vtx);
 		return 0;
 	}
 	if (c->sync_epoch == c->arc_epoch) TRY(sync_st(c)); // nobody has waited since the round was queued
@@ -1210,14 +1210,21 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	return branch_enumerate(c, cnt);
 }
 
-extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch_diff_dist, double branch_diff_cut, uint8_t *arc_weak,
-                                 int32_t *n_dist_loci, int64_t *n_flt1, int64_t *n_flt2)
+// pg_flt_high_occ's three tests (graph.c:226-258) on the device, so that a branch round's bulk results need not travel
+struct RoundFilter { int on; int32_t max_tot_cnt, max_degree, max_dist_loci; uint8_t *del_host; };
+
+static int decide_impl(pga_ctx *c, double branch_diff, double branch_diff_dist, double branch_diff_cut, uint8_t *arc_weak,
+                       int32_t *n_dist_loci, int64_t *n_flt1, int64_t *n_flt2, const RoundFilter *rf)
 {
-	const int n_vtx = 2 * c->br_S;
+	const int n_vtx = 2 * c->br_S, S = c->br_S;
 	const int64_t n_arc = c->br_n;
 	if (n_flt1) *n_flt1 = 0;
 	if (n_flt2) *n_flt2 = 0;
-	if (n_arc == 0 || n_vtx == 0) { if (n_vtx) memset(n_dist_loci, 0, sizeof(int32_t) * (size_t)n_vtx); return 0; }
+	if (n_arc == 0 || n_vtx == 0) {
+		if (n_vtx && n_dist_loci) memset(n_dist_loci, 0, sizeof(int32_t) * (size_t)n_vtx);
+		if (rf && rf->on && S) memset(rf->del_host, 0, (size_t)S);
+		return rf ? sync_st(c) : 0;
+	}
 	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, 0);
 	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, 0), *agid = (int32_t *)c->pool.get(S_BR_GID, 0), *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0);
 	int32_t *poff = (int32_t *)c->pool.get(S_BR_POFF, 0);
@@ -1231,13 +1238,21 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 		c->h_ndl_cap = need + need / 2;
 	}
 	int32_t *ndl_dev = nullptr;
-	HIPCHK(hipHostGetDevicePointer((void **)&ndl_dev, c->h_ndl, 0)); // n_dist_loci goes straight into pinned host memory
+	HIPCHK(hipHostGetDevicePointer((void **)&ndl_dev, c->h_ndl, 0)); // n_dist_loci goes straight into pinned host memory ...
+	int32_t *ndl_out = ndl_dev;
+	if (rf) { // ... unless only the device looks at it: then the pinned buffer carries the per-segment verdicts instead
+		ndl_out = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
+		if (!ndl_out) return PGA_ERR_NOMEM;
+	}
 	if (!grp || !vwk) return PGA_ERR_NOMEM;
 	for (int attempt = 0;; ++attempt) {
 		int32_t *cnt = (int32_t *)c->pool.get(S_NLCNT, 0);
 		if (n_flt1 || n_flt2) HIPCHK(hipMemsetAsync(c->dcnt, 0, 2 * sizeof(int64_t), c->st)); // [0], [1]: arcs marked 1 / 2 (log only)
 		hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, branch_diff, poff, (int32_t *)nullptr, (int64_t)c->br_cap, (const int32_t *)nullptr, cnt,
-		                   branch_diff_dist, branch_diff_cut, aw, grp, ndl_dev, (n_flt1 || n_flt2) ? c->dcnt : (int64_t *)nullptr, vwk, c->br_np < 0 ? c->dcnt + 15 : (const int64_t *)nullptr);
+		                   branch_diff_dist, branch_diff_cut, aw, grp, ndl_out, (n_flt1 || n_flt2) ? c->dcnt : (int64_t *)nullptr, vwk, c->br_np < 0 ? c->dcnt + 15 : (const int64_t *)nullptr);
+		if (rf && rf->on)
+			hipLaunchKernelGGL(k_round_filter, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)c->pool.get(S_SEGCNT, 0), (const int32_t *)c->pool.get(S_DEG, 0), (const int32_t *)ndl_out,
+			                   rf->max_tot_cnt, rf->max_degree, rf->max_dist_loci, (uint8_t *)ndl_dev);
 		if (arc_weak && !c->table_sparse) HIPCHK(hipMemcpyAsync(arc_weak, aw, (size_t)n_arc, hipMemcpyDeviceToHost, c->st));
 		if (n_flt1 || n_flt2) hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
 		TRY(sync_st(c));
@@ -1248,10 +1263,27 @@ extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch
 		int32_t *dummy;
 		TRY(branch_enumerate(c, &dummy));
 	}
-	memcpy(n_dist_loci, c->h_ndl, sizeof(int32_t) * (size_t)n_vtx);
+	if (n_dist_loci && !rf) memcpy(n_dist_loci, c->h_ndl, sizeof(int32_t) * (size_t)n_vtx);
+	if (rf && rf->on) memcpy(rf->del_host, c->h_ndl, (size_t)S);
 	if (n_flt1) *n_flt1 = c->h_cnt[0];
 	if (n_flt2) *n_flt2 = c->h_cnt[1];
 	return 0;
+}
+
+extern "C" int pga_branch_decide(pga_ctx_t *c, double branch_diff, double branch_diff_dist, double branch_diff_cut, uint8_t *arc_weak,
+                                 int32_t *n_dist_loci, int64_t *n_flt1, int64_t *n_flt2)
+{
+	if (n_dist_loci == nullptr) return PGA_ERR_ARG;
+	return decide_impl(c, branch_diff, branch_diff_dist, branch_diff_cut, arc_weak, n_dist_loci, n_flt1, n_flt2, nullptr);
+}
+
+extern "C" int pga_branch_decide_filter(pga_ctx_t *c, double branch_diff, double branch_diff_dist, double branch_diff_cut, int32_t do_filter,
+                                        int32_t max_tot_cnt, int32_t max_degree, int32_t max_dist_loci, uint8_t *del)
+{
+	// only behind a deferred round on the gene-major path: its segment counters and degrees are then where k_round_filter looks
+	if (!(c->arc_deferred && !c->arc_done && c->table_sparse) || c->br_S != c->n_seg || (do_filter && del == nullptr)) return 2;
+	RoundFilter rf = { do_filter, max_tot_cnt, max_degree, max_dist_loci, del };
+	return decide_impl(c, branch_diff, branch_diff_dist, branch_diff_cut, nullptr, nullptr, nullptr, nullptr, &rf);
 }
 
 extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked, int32_t then_filter)
@@ -1488,7 +1520,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter
 	};
 	return &b;
 }

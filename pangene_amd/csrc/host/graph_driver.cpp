@@ -838,6 +838,55 @@ static int mark_branch_flt_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	return 0;
 }
 
+// The same step for the common case -- not sharded, no log lines, the round's arc table still waiting to be collected -- with
+// pg_flt_high_occ's tests made on the backend as well (branch_decide_filter): what comes back is one byte per segment instead
+// of the round's counters, degrees and n_dist_loci.  *done = false: the preconditions did not hold, or the arc round had to be
+// repeated -- the caller takes the general route (mark_branch_flt_arc + flt_high_occ) for this round.
+static int mark_branch_flt_arc_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool do_filter, int32_t max_tot_cnt, int32_t max_degree, int32_t max_dist_loci,
+                                    std::vector<uint8_t> &del, bool *done)
+{
+	const pga_backend_t *be = ext->be;
+	*done = false;
+	static const bool host_only = std::getenv("PANGENE_ROUND_FILTER_HOST") != nullptr; // (tests: keep the general route exercised)
+	if (host_only || sharded() || pg_verbose >= 3 || be->branch_decide_filter == nullptr || !ext->arc_pending) return 0;
+	const int32_t S = q->n_seg;
+	{
+		Phase ph(PH_NLOCAL);
+		BE_CALL(be->rep_pos(ext->ctx), "rep_pos");
+		int32_t *b_cnt;
+		BE_CALL(be->branch_pairs(ext->ctx, nullptr, nullptr, 0, nullptr, S, opt->branch_diff, opt->local_dist, opt->local_count, !!(opt->flag & PG_F_FRAG_MODE), &b_cnt, nullptr), "branch_pairs");
+		del.resize((size_t)S + 1);
+		const int rc = be->branch_decide_filter(ext->ctx, opt->branch_diff, opt->branch_diff_dist, opt->branch_diff_cut, do_filter ? 1 : 0, max_tot_cnt, max_degree, max_dist_loci, del.data());
+		if (rc == 2) return 0; // not behind a deferred round of the gene-major path
+		if (rc != 0) { set_error(rc, "branch_decide_filter"); return rc; }
+	}
+	Phase ph(PH_BRANCH_HOST);
+	ext->arc_pending = false;
+	const int rc = be->arc_round_finish(ext->ctx, S, nullptr, nullptr); // the wait is over: does the round stand?
+	if (rc < 0) { set_error(rc, "arc_round_finish"); return rc; }
+	if (rc == 1) { // a hub gene overflowed the per-gene table: the round is repeated on the sort path, the branch step on the general route
+		std::vector<int32_t> sc((size_t)S * 2 + 1);
+		ext->deg.assign((size_t)S * 2 + 1, 0);
+		BE_CALL(be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, sc.data(), ext->deg.data()), "arc_round");
+		for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
+		return 0;
+	}
+	*done = true;
+	return 0;
+}
+
+// pg_flt_high_occ + pg_hard_delete with the verdicts of branch_decide_filter
+static int apply_round_filter(pg_graph_t *q, DataExt *ext, const std::vector<uint8_t> &del)
+{
+	Phase ph(PH_FLT);
+	int32_t k = 0;
+	for (int32_t i = 0; i < q->n_seg; ++i)
+		if (!del[(size_t)i]) q->seg[k++] = q->seg[i];
+	q->n_seg = k;
+	gen_g2s(q);
+	return flag_vtx(q, ext);
+}
+
 static int mark_branch_flt_hit(pg_graph_t *q, DataExt *ext) // branch.c:108-145; the arcs and their weak_br are already resident
 {
 	int64_t n = 0;
@@ -877,10 +926,16 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 		int32_t max_avg_occ = (int32_t)(opt->max_avg_occ * r + .499);
 		int32_t max_degree = (int32_t)(opt->max_degree * r + .499);
 		int32_t max_dist_loci = (int32_t)(opt->max_dist_loci * r + .499);
-		BE_CALL(mark_branch_flt_arc(opt, q, ext), "mark_branch_flt_arc");
+		// every round but the last one leaves its bulk results on the backend when it can (the last one fills the public fields of
+		// pg_seg_t: n_genome, tot_cnt, n_dist_loci)
+		bool on_backend = false;
+		if (i + 1 < opt->n_branch_flt)
+			BE_CALL(mark_branch_flt_arc_fast(opt, q, ext, i > 0, max_avg_occ * q->d->n_genome, max_degree, max_dist_loci, ext->del_buf, &on_backend), "mark_branch_flt_arc");
+		if (!on_backend) BE_CALL(mark_branch_flt_arc(opt, q, ext), "mark_branch_flt_arc");
 		BE_CALL(mark_branch_flt_hit(q, ext), "mark_branch_flt_hit"); // with PG_SET_FILTER(weak_br == 2), graph.c:309
 		BE_CALL(trace_state(ext, "mark_branch", i + 3), "trace");
-		if (i > 0) BE_CALL(flt_high_occ(max_avg_occ, max_degree, max_dist_loci, q, ext), "flt_high_occ"); // with PG_SET_FILTER(vtx == 0), graph.c:312
+		if (i > 0 && on_backend) BE_CALL(apply_round_filter(q, ext, ext->del_buf), "flt_high_occ");
+		else if (i > 0) BE_CALL(flt_high_occ(max_avg_occ, max_degree, max_dist_loci, q, ext), "flt_high_occ"); // with PG_SET_FILTER(vtx == 0), graph.c:312
 		if (i > 0) BE_CALL(trace_state(ext, "flt_high_occ", i + 3), "trace");
 		BE_CALL(gen_arc(opt, q, ext, i + 1 < opt->n_branch_flt), "gen_arc");
 		BE_CALL(trace_state(ext, "gen_arc", i + 3), "trace");

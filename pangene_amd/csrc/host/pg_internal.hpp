@@ -73,6 +73,7 @@ struct DataExt {
 	std::vector<ExactSeg> xsegs;
 	std::vector<int32_t> deg;          // out-degree of every oriented vertex of the round's arc table
 	std::vector<int32_t> sc_buf;       // landing area of a round's segment counters (arc_collect)
+	std::vector<uint8_t> del_buf;      // per-segment verdicts of branch_decide_filter
 	const pga_arc_part_t *cur_arcs = nullptr; // the round's arc table, in backend memory
 	std::string vtx_sel_text;          // -G output of the current run (printed when pg_graph_gen returns)
 	int exact_mode_of_segs = -1;       // mode xsegs was built for

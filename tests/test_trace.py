@@ -43,6 +43,22 @@ def test_trace_of_the_oracle_backend_has_every_step(built, tmp_path):
     assert rows == _trace(tmp_path, "oracle", 1, "", golden_files("C4"))  # and it is a function of the input
 
 
+@pytest.mark.parametrize("name,variant", [("C4", ""), ("fuzz7126", "-D 300 -C 2"), ("human8f", "-p0 -a1")])
+def test_round_filter_on_the_host_and_on_the_backend_agree(built, tmp_path, name, variant):
+    """A branch round either leaves pg_flt_high_occ's tests to the backend (branch_decide_filter: one byte per segment comes back) or
+    makes them on the host from the round's counters, degrees and n_dist_loci (PANGENE_ROUND_FILTER_HOST=1, also the route of sharded
+    runs and of runs with log lines): same states after every step, with the oracle backend here and with the HIP backend in
+    test_arc_round_paths_agree."""
+    files = golden_files(name)
+    a = _trace(tmp_path, "oracle", 1, variant, files)
+    os.environ["PANGENE_ROUND_FILTER_HOST"] = "1"
+    try:
+        b = _trace(tmp_path, "oracle", 1, variant, files)
+    finally:
+        del os.environ["PANGENE_ROUND_FILTER_HOST"]
+    assert a == b and len(a) > 40
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,variant,mode", [("C4", "", 1), ("bact20", "", 1), ("human8f", "-p0 -a1", 1), ("human8", "-S", 2), ("fuzz7126", "-D 300 -C 2", 1),
                                                ("fuzz3", "-F", 0), ("dense", "", 1), ("manydoms", "", 1)])
