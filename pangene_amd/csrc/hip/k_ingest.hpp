@@ -176,35 +176,36 @@ __global__ __launch_bounds__(BLOCK) void k_count_shadow(const uint32_t *flags, c
 	}
 }
 
-// read.c:249-253
-__global__ __launch_bounds__(BLOCK) void k_ingest_reset(uint32_t *flags, int32_t *pdom, int32_t *pdom0, int n)
+// read.c:249-253 (pid_dom0 = pid_dom, pid_dom = -1, shadow = 0) + tail of pg_flt_ov_isoform (overlap.c:89-91) + first loop of
+// pg_flt_chain_shadow (hit.c:136-138).  noiso: one bit per (genome, protein), set when the protein has a hit in the genome that
+// does not carry flt_iso_ov (the complement of hit.c:134-138's flag[], for the proteins that occur at all -- pid_dom0 always does).
+__global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int32_t *gnm, const int32_t *pid, int32_t *pdom, int32_t *pdom0, int n, int P, uint32_t *noiso, int32_t *stats)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
 	pdom0[h] = pdom[h];
 	pdom[h] = -1;
-	flags[h] &= ~PGA_F_SHADOW;
-}
-
-// tail of pg_flt_ov_isoform (overlap.c:89-91) + first loop of pg_flt_chain_shadow (hit.c:136-138)
-__global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int32_t *gnm, const int32_t *pid, int n, int P, int32_t *tiso, int32_t *stats)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	uint32_t f = flags[h];
+	const uint32_t f = flags[h];
+	uint32_t nf = f & ~PGA_F_SHADOW;
 	if (f & PGA_F_ISO_OV) {
-		flags[h] = f | PGA_F_FLT;
+		nf |= PGA_F_FLT;
 		atomicAdd(&stats[gnm[h] * 4 + 1], 1);
-	} else tiso[(int64_t)gnm[h] * P + pid[h]] = 0;
+	} else {
+		const int64_t t = (int64_t)gnm[h] * P + pid[h];
+		atomicOr(&noiso[t >> 5], 1u << (t & 31));
+	}
+	if (nf != f) flags[h] = nf;
 }
 
 // second loop of pg_flt_chain_shadow (hit.c:139-143)
-__global__ __launch_bounds__(BLOCK) void k_chain(uint32_t *flags, const int32_t *gnm, const int32_t *pdom0, int n, int P, const int32_t *tiso, int32_t *stats)
+__global__ __launch_bounds__(BLOCK) void k_chain(uint32_t *flags, const int32_t *gnm, const int32_t *pdom0, int n, int P, const uint32_t *noiso, int32_t *stats)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
 	int p0 = pdom0[h];
-	if (p0 >= 0 && tiso[(int64_t)gnm[h] * P + p0]) {
+	if (p0 < 0) return;
+	const int64_t t = (int64_t)gnm[h] * P + p0;
+	if (!((noiso[t >> 5] >> (t & 31)) & 1u)) {
 		flags[h] |= PGA_F_FLT | PGA_F_CHAIN;
 		atomicAdd(&stats[gnm[h] * 4 + 2], 1);
 	}

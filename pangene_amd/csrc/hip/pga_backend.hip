@@ -139,7 +139,8 @@ struct pga_ctx {
 	// dynamic per hit
 	int32_t *rank = 0, *sdom = 0, *pdom = 0, *pdom0 = 0; uint32_t *flags = 0;
 	int32_t *yperm = 0, *goff = 0, *ggl = 0, *ctg_base = 0, *inv = 0, *headpos = 0, *eoff = 0; int64_t *woff = 0;
-	int cs_bits = 1, cm_bits = 1, seg_bits = 1;
+	int cs_bits = 1, cm_bits = 1, seg_bits = 1, ctg_bits = 1;
+	bool gs_ok = false; int gs_np = 64; // stage A's orders by k_genome_sort (one workgroup per genome, keys in LDS): every genome fits
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors
 	int32_t *max_ori = 0; int64_t *sums = 0; int32_t *vtx_cnt = 0; int32_t *g2s = 0; int32_t n_seg = 0;
@@ -223,6 +224,7 @@ extern "C" const char *pga_strerror(int code)
 #include "k_common.hpp"
 #include "k_ingest.hpp"
 #include "k_sweep.hpp"
+#include "k_segsort.hpp"
 #include "k_stage_b.hpp"
 #include "k_vertex.hpp"
 #include "k_arcs.hpp"
@@ -430,6 +432,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->h_goff.assign((size_t)GL + 1, 0);
 	c->rp_compact = true;
 	uint32_t max_cs = 0, max_cm = 0, max_sadj = 0;
+	int32_t max_hit = 0, max_ctg = 1;
 	bool neg_sadj = false, multi = false;
 	for (int g = 0; g < GL; ++g) {
 		const pga_genome_block_t &b = sh->block[g];
@@ -439,6 +442,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		if (b.n_ctg >= 4096 || b.n_hit >= (1 << 20)) c->rp_compact = false;
 		max_cs = std::max(max_cs, (uint32_t)b.max_cs), max_cm = std::max(max_cm, (uint32_t)b.max_cm), max_sadj = std::max(max_sadj, (uint32_t)b.max_score_adj);
 		neg_sadj = neg_sadj || b.any_neg_score_adj, multi = multi || b.any_multi_exon;
+		max_hit = std::max(max_hit, b.n_hit), max_ctg = std::max(max_ctg, b.n_ctg);
 	}
 	if (c->h_goff[(size_t)GL] != N || eoff[(size_t)GL] != E) return PGA_ERR_ARG;
 	c->n_seg_ctg = ctg_base[(size_t)GL];
@@ -452,6 +456,13 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		c->rk_shift = (!neg_sadj && sb + 1 + pb <= 32 && getenv("PANGENE_RANK_BY_SORT") == nullptr) ? pb + 1 : -1;
 	}
 	c->any_multi = multi;
+	c->ctg_bits = bits_for((uint32_t)(max_ctg - 1));
+	c->gs_np = std::max(64, (max_hit + 63) & ~63);
+	c->gs_ok = c->gs_np <= GS_NP_MAX && c->rk_shift >= 0 && getenv("PANGENE_GLOBAL_SORT") == nullptr;
+	if (c->gs_ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_genome_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes(c->gs_np)) != hipSuccess) {
+		(void)hipGetLastError();
+		c->gs_ok = false;
+	}
 
 	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
 		const size_t per_hit = 560 /* measured: 530-540 B/hit at 1 M and 12 M hits (PANGENE_TIMING reports the fit at destroy) */, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
@@ -517,6 +528,14 @@ extern "C" int pga_begin(pga_ctx_t *c)
 		*f_offx = up + 6 * (size_t)N, *f_cs = up + 7 * (size_t)N, *f_ce = up + 8 * (size_t)N, *f_cm = up + 9 * (size_t)N,
 		*f_gnm = up + 10 * (size_t)N, *f_seg = up + 11 * (size_t)N, *f_gid = up + 12 * (size_t)N, *f_cds = up + 13 * (size_t)N;
 	uint8_t *f_rev = (uint8_t *)(up + 14 * (size_t)N);
+	if (!up) return PGA_ERR_NOMEM;
+	if (c->gs_ok) { // one launch: both orders, every per-hit constant, the packed records (k_segsort.hpp)
+		HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->rk, c->flags };
+		GenomeSort gs = { up, (int64_t)N, c->goff, c->ctg_base, c->exon, c->prot_gid, c->gene_pref, c->hrank, c->rk_shift, c->cs_bits, c->cm_bits, c->ctg_bits, c->gs_np, GL,
+		                  o, c->pm, c->inv, c->yperm, c->headpos, c->recA, c->recB, c->recC };
+		hipLaunchKernelGGL(k_genome_sort, dim3((unsigned)GL), dim3(GS_T), gs_lds_bytes(c->gs_np), c->st, gs);
+		return 0;
+	}
 	int32_t *rk_f = (int32_t *)c->pool.get(S_TAB_A, sizeof(uint64_t) * (size_t)N);
 	int32_t *head = (int32_t *)c->pool.get(S_HEAD, sizeof(int32_t) * ((size_t)N + 1)), *incl = (int32_t *)c->pool.get(S_SLOT, sizeof(int32_t) * ((size_t)N + 1));
 	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, 0);
@@ -582,25 +601,27 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 	HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(int32_t) * 4 * (size_t)GL + 16, c->st));
 	if (N) {
 		const int64_t TP = (int64_t)GL * P, TQ = (int64_t)GL * Q;
-		int32_t *tmax = (int32_t *)c->pool.get(S_TAB_A, sizeof(int32_t) * (size_t)TP);
-		int32_t *tmin = (int32_t *)c->pool.get(S_TAB_B, sizeof(int32_t) * (size_t)TP);
-		int32_t *tr1 = (int32_t *)c->pool.get(S_TAB_C, sizeof(int32_t) * (size_t)TP);
+		if (c->any_multi) { // pg_flag_pseudo (hit.c:66-105) only ever marks a protein that has a multi-exon hit (max_n > 1, hit.c:84)
+			int32_t *tmax = (int32_t *)c->pool.get(S_TAB_A, sizeof(int32_t) * (size_t)TP);
+			int32_t *tmin = (int32_t *)c->pool.get(S_TAB_B, sizeof(int32_t) * (size_t)TP);
+			int32_t *tr1 = (int32_t *)c->pool.get(S_TAB_C, sizeof(int32_t) * (size_t)TP);
+			if (!tmax || !tmin || !tr1) return PGA_ERR_NOMEM;
+			HIPCHK(hipMemsetAsync(tmax, 0, sizeof(int32_t) * (size_t)TP, c->st));
+			hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tmin, TP, INT32_MAX);
+			hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tr1, TP, INT32_MAX);
+			hipLaunchKernelGGL(k_pseudo1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, N, P, tmax, tmin);
+			hipLaunchKernelGGL(k_pseudo2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, c->rank, c->flags, N, P, tmax, tmin, tr1, d_stats);
+			hipLaunchKernelGGL(k_pseudo3, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->rank, N, P, tmax, tmin, tr1);
+			pack_records(c); // rank changed
+		}
 		unsigned long long *tbest = (unsigned long long *)c->pool.get(S_TAB_D, sizeof(uint64_t) * (size_t)TQ);
-		if (!tmax || !tmin || !tr1 || !tbest) return PGA_ERR_NOMEM;
-		HIPCHK(hipMemsetAsync(tmax, 0, sizeof(int32_t) * (size_t)TP, c->st));
-		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tmin, TP, INT32_MAX);
-		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tr1, TP, INT32_MAX);
-		hipLaunchKernelGGL(k_pseudo1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, N, P, tmax, tmin);
-		hipLaunchKernelGGL(k_pseudo2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, c->rank, c->flags, N, P, tmax, tmin, tr1, d_stats);
-		hipLaunchKernelGGL(k_pseudo3, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->rank, N, P, tmax, tmin, tr1);
-		pack_records(c); // rank changed
+		uint32_t *noiso = (uint32_t *)c->pool.get(S_TAB_A, sizeof(uint32_t) * (size_t)((TP + 31) / 32) + 16); // bit (genome, protein): the protein has a hit there without flt_iso_ov
+		if (!tbest || !noiso) return PGA_ERR_NOMEM;
 		TRY(launch_sweep<1>(c, 0)); // pg_shadow(cal_dom_sc=1), read.c:248 -- "K1", the hit-filter+overlap kernel
-		hipLaunchKernelGGL(k_ingest_reset, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->pdom, c->pdom0, N);
-		TRY(launch_sweep<2>(c, 1)); // pg_flt_ov_isoform, read.c:254
-		int32_t *tiso = tmax; // reuse: 1 = every hit of (genome, protein) carries flt_iso_ov
-		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tiso, TP, 1);
-		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, N, P, tiso, d_stats);
-		hipLaunchKernelGGL(k_chain, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pdom0, N, P, tiso, d_stats);
+		TRY(launch_sweep<2>(c, 1)); // pg_flt_ov_isoform, read.c:254 (reads neither the shadow flags nor pid_dom: read.c:249-253 follows, in k_iso_apply)
+		HIPCHK(hipMemsetAsync(noiso, 0, sizeof(uint32_t) * (size_t)((TP + 31) / 32), c->st));
+		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, c->pdom, c->pdom0, N, P, noiso, d_stats);
+		hipLaunchKernelGGL(k_chain, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pdom0, N, P, noiso, d_stats);
 		HIPCHK(hipMemsetAsync(tbest, 0, sizeof(uint64_t) * (size_t)TQ, c->st));
 		hipLaunchKernelGGL(k_subopt1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->sadj, c->goff, N, Q, tbest);
 		hipLaunchKernelGGL(k_subopt2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->pid, c->goff, N, Q, tbest, d_stats, c->rank, c->sadj, c->recA, c->dcnt,
