@@ -37,7 +37,7 @@ struct FileHits { const int32_t *pid, *cid, *rank, *sori, *sadj, *nex, *offx, *c
 __global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int32_t *goff, int n_genome, const int32_t *ctg_base,
                                                      const int2 *exon, const int32_t *prot_gid, const uint8_t *gene_pref,
                                                      int32_t *gnm_f, int32_t *seg_f, int32_t *gid_f, int32_t *cds_f, uint64_t *key, uint32_t *val,
-                                                     int rk_shift, const int32_t *hrank, int32_t *rk_f)
+                                                     int rk_shift, const int32_t *hrank, int32_t *rk_f, int32_t *fl_f)
 {
 	int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int3
 	int len = 0, ne = f.nex[i], ox = f.offx[i];
 	for (int e = 0; e < ne; ++e) { int2 x = exon[ox + e]; len += x.y - x.x; } // pg_cds_len, overlap.c:45-51
 	gnm_f[i] = g, seg_f[i] = sg, gid_f[i] = gid, cds_f[i] = len;
+	fl_f[i] = (int32_t)((f.rev[i] ? PGA_F_REV : 0u) | (ne != 1 ? F_MULTI : 0u)); // the static bits of the flag word
 	if (rk_shift >= 0) { // the same order in 32 bits (see pga_ctx::rk_shift): 0 exactly when the 64-bit key is 0
 		rk_f[i] = (int32_t)((uint32_t)f.sadj[i] << rk_shift | (uint32_t)gene_pref[gid] << (rk_shift - 1) | (uint32_t)hrank[f.pid[i]]);
 		return;
@@ -177,9 +178,9 @@ __global__ __launch_bounds__(BLOCK) void k_count_shadow(const uint32_t *flags, c
 }
 
 // read.c:249-253 (pid_dom0 = pid_dom, pid_dom = -1, shadow = 0) + tail of pg_flt_ov_isoform (overlap.c:89-91) + first loop of
-// pg_flt_chain_shadow (hit.c:136-138).  noiso: one bit per (genome, protein), set when the protein has a hit in the genome that
+// pg_flt_chain_shadow (hit.c:136-138).  noiso: one byte per (genome, protein), set when the protein has a hit in the genome that
 // does not carry flt_iso_ov (the complement of hit.c:134-138's flag[], for the proteins that occur at all -- pid_dom0 always does).
-__global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int32_t *gnm, const int32_t *pid, int32_t *pdom, int32_t *pdom0, int n, int P, uint32_t *noiso, int32_t *stats)
+__global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int32_t *gnm, const int32_t *pid, int32_t *pdom, int32_t *pdom0, int n, int P, uint8_t *noiso, int32_t *stats)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
@@ -191,21 +192,19 @@ __global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int3
 		nf |= PGA_F_FLT;
 		atomicAdd(&stats[gnm[h] * 4 + 1], 1);
 	} else {
-		const int64_t t = (int64_t)gnm[h] * P + pid[h];
-		atomicOr(&noiso[t >> 5], 1u << (t & 31));
+		noiso[(int64_t)gnm[h] * P + pid[h]] = 1; // (plain byte stores of the same value: no atomics needed)
 	}
 	if (nf != f) flags[h] = nf;
 }
 
 // second loop of pg_flt_chain_shadow (hit.c:139-143)
-__global__ __launch_bounds__(BLOCK) void k_chain(uint32_t *flags, const int32_t *gnm, const int32_t *pdom0, int n, int P, const uint32_t *noiso, int32_t *stats)
+__global__ __launch_bounds__(BLOCK) void k_chain(uint32_t *flags, const int32_t *gnm, const int32_t *pdom0, int n, int P, const uint8_t *noiso, int32_t *stats)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
 	int p0 = pdom0[h];
 	if (p0 < 0) return;
-	const int64_t t = (int64_t)gnm[h] * P + p0;
-	if (!((noiso[t >> 5] >> (t & 31)) & 1u)) {
+	if (!noiso[(int64_t)gnm[h] * P + p0]) {
 		flags[h] |= PGA_F_FLT | PGA_F_CHAIN;
 		atomicAdd(&stats[gnm[h] * 4 + 2], 1);
 	}

@@ -55,7 +55,9 @@ __global__ __launch_bounds__(BLOCK) void k_set_head(const int32_t *head_file, co
 	headpos[g] = np;
 }
 
-struct PermArrays { int32_t *a[17]; }; // a[15] = flags, a[16] = rk
+// what moves with a hit: the 4-byte planes (OV_FLAGS = the flag word, whose head mark is positional) and the three packed records
+constexpr int OV_PLANES = 12, OV_FLAGS = 10;
+struct PermArrays { int32_t *a[OV_PLANES]; int4 *r[3]; };
 
 __global__ __launch_bounds__(BLOCK) void k_ov_gather(PermArrays p, const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv,
                                                        int32_t *tmp, int32_t *remap)
@@ -65,7 +67,10 @@ __global__ __launch_bounds__(BLOCK) void k_ov_gather(PermArrays p, const int32_t
 	int src = inv[ov_file[i]];
 	remap[src] = ov_pos[i];
 #pragma unroll
-	for (int k = 0; k < 17; ++k) tmp[(int64_t)k * t + i] = p.a[k][src];
+	for (int k = 0; k < OV_PLANES; ++k) tmp[(int64_t)k * t + i] = p.a[k][src];
+	int4 *tr = (int4 *)(tmp + (int64_t)OV_PLANES * t);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) tr[(int64_t)k * t + i] = p.r[k][src];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_t *ov_pos, int64_t t, const int32_t *tmp,
@@ -75,11 +80,18 @@ __global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_
 	if (i >= t) return;
 	int pos = ov_pos[i];
 #pragma unroll
-	for (int k = 0; k < 15; ++k) p.a[k][pos] = tmp[(int64_t)k * t + i];
-	uint32_t f = (uint32_t)tmp[(int64_t)15 * t + i] & ~F_HEAD; // a[15] = flags; the head mark is positional
-	if (pos == goff[gnm[pos]]) f |= F_HEAD;
-	p.a[15][pos] = (int32_t)f;
-	p.a[16][pos] = tmp[(int64_t)16 * t + i];
+	for (int k = 0; k < OV_PLANES; ++k) {
+		int32_t v = tmp[(int64_t)k * t + i];
+		if (k == OV_FLAGS) { // the head mark is positional
+			uint32_t f = (uint32_t)v & ~F_HEAD;
+			if (pos == goff[gnm[pos]]) f |= F_HEAD;
+			v = (int32_t)f;
+		}
+		p.a[k][pos] = v;
+	}
+	const int4 *tr = (const int4 *)(tmp + (int64_t)OV_PLANES * t);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) p.r[k][pos] = tr[(int64_t)k * t + i];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_ov_remap_y(int32_t *yperm, int n, const int32_t *remap)

@@ -26,6 +26,30 @@ __global__ __launch_bounds__(BLOCK) void k_pack_rec(const int32_t *seg, const in
 	C[h] = make_int4(rank[h], nex[h], offx[h], sori[h]);
 }
 
+// record C carries a copy of the rank (pg_flag_pseudo / pg_post_process change it)
+__global__ __launch_bounds__(BLOCK) void k_pack_rank(const int32_t *rank, int n, int4 *C)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h < n) ((int32_t *)&C[h])[0] = rank[h];
+}
+
+// the static tie marks of the cs order from the records alone (after an order override moved hits)
+__global__ __launch_bounds__(BLOCK) void k_cstie(const int4 *A, int n, uint32_t *flags)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n) return;
+	const int4 a = A[h];
+	bool tie = false;
+	if (h > 0) { const int4 p = A[h - 1]; tie = p.y == a.y && p.x == a.x; }
+	if (!tie && h + 1 < n) { const int4 q = A[h + 1]; tie = q.y == a.y && q.x == a.x; }
+	const uint32_t f = flags[h], nf = tie ? f | F_CSTIE : f & ~F_CSTIE;
+	if (nf != f) flags[h] = nf;
+}
+
+// pm (record A, word 3) = running maximum of ce inside a contig, as a segmented scan over the records
+struct InSegMaxA { const int4 *A; __device__ __forceinline__ SegMax operator()(int64_t i) const { const int4 a = A[i]; return SegMax{a.y, a.z}; } };
+struct OutSegMaxA { int4 *A; __device__ __forceinline__ void operator()(int64_t i, SegMax in, SegMax) const { ((int32_t *)&A[i])[3] = in.v; } };
+
 struct SweepView {
 	const int4 *A, *B, *C; const int32_t *sori; const int2 *exon;
 	uint32_t *flags; int32_t *pdom, *sdom;
@@ -35,6 +59,7 @@ struct SweepView {
 	int64_t *slow_cnt; int32_t *slow_list; // work list for k_sweep_slow
 	long long *prof; // PGA_SW_PROFILE builds only
 	int32_t *hz_list; // hz[10] (= dcnt[14]) counts its entries
+	int init_dom; // MODE 1, first sweep of a run: filtered hits get pid_dom = -1, score_dom = 0 (read.c:133-134) here, nobody wrote them before
 };
 
 // CDS intersection of hit a (exons ea[na], start ca) and hit b: pg_hit_overlap, overlap.c:6-42
@@ -346,7 +371,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 				}
 				sw_finish<MODE>(v, h, fl, lose, has_dom, pid_w, ov, cds_h, cds_w, so_h, so_w);
 			}
-		}
+		} else if (MODE == 1 && v.init_dom && h < v.n) v.pdom[h] = -1, v.sdom[h] = 0;
 	}
 	SW_STAMP(7);
 }

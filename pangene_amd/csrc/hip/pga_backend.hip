@@ -140,6 +140,8 @@ struct pga_ctx {
 	int32_t *rank = 0, *sdom = 0, *pdom = 0, *pdom0 = 0; uint32_t *flags = 0;
 	int32_t *yperm = 0, *goff = 0, *ggl = 0, *ctg_base = 0, *inv = 0, *headpos = 0, *eoff = 0; int64_t *woff = 0;
 	int cs_bits = 1, cm_bits = 1, seg_bits = 1, ctg_bits = 1;
+	bool inv_valid = false;  // inv[] (file index -> X position) matches the current order: built on demand (pga_set_head)
+	bool sweep_init = false; // the next pg_shadow(cal_dom_sc=1) also initialises pid_dom / score_dom of the filtered hits (pga_ingest)
 	bool gs_ok = false; int gs_np = 64; // stage A's orders by k_genome_sort (one workgroup per genome, keys in LDS): every genome fits
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors
@@ -269,6 +271,7 @@ static int make_sweep_view(pga_ctx *c, SweepView *v)
 {
 	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->sori = c->sori, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
 	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4, v->stage_c = c->any_multi;
+	v->init_dom = c->sweep_init ? 1 : 0;
 	v->slow_cnt = nullptr, v->slow_list = (int32_t *)c->pool.get(S_SLOW, sizeof(int32_t) * (size_t)c->N);
 	v->hz_list = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
 	if (!v->slow_list || !v->hz_list) return PGA_ERR_NOMEM;
@@ -459,13 +462,13 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->ctg_bits = bits_for((uint32_t)(max_ctg - 1));
 	c->gs_np = std::max(64, (max_hit + 63) & ~63);
 	c->gs_ok = c->gs_np <= GS_NP_MAX && c->rk_shift >= 0 && getenv("PANGENE_GLOBAL_SORT") == nullptr;
-	if (c->gs_ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_genome_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes(c->gs_np)) != hipSuccess) {
-		(void)hipGetLastError();
-		c->gs_ok = false;
+	if (c->gs_ok) {
+		const void *kf = c->gs_np <= GS_K_SMALL * GS_T ? reinterpret_cast<const void *>(k_genome_sort) : reinterpret_cast<const void *>(k_genome_sort_big);
+		if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes(c->gs_np)) != hipSuccess) { (void)hipGetLastError(); c->gs_ok = false; }
 	}
 
 	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
-		const size_t per_hit = 560 /* measured: 530-540 B/hit at 1 M and 12 M hits (PANGENE_TIMING reports the fit at destroy) */, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
+		const size_t per_hit = 568 /* measured: 530-540 B/hit at 1 M and 12 M hits (PANGENE_TIMING reports the fit at destroy) */, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
 		const size_t want = ((size_t)N * per_hit + tables + (64u << 20) + (size_t)woff[(size_t)GL] * 4 + 255) & ~(size_t)255;
 		void *a = nullptr;
 		if (getenv("PANGENE_NO_POOL_ARENA") == nullptr && hipMalloc(&a, want) == hipSuccess) { // else: slot by slot
@@ -477,7 +480,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	const double t1 = now();
 	// the blocks as they are (one DMA per genome out of pinned memory), then one kernel spreads them into flat file-order arrays
 	int32_t *raw = (int32_t *)c->pool.get(S_RAW, sizeof(int32_t) * (size_t)woff[(size_t)GL] + 64);
-	int32_t *up = (int32_t *)c->pool.get(S_UPLOAD, sizeof(int32_t) * (size_t)N * 16 + 64); // stays resident: begin() restarts a run without PCIe traffic
+	int32_t *up = (int32_t *)c->pool.get(S_UPLOAD, sizeof(int32_t) * (size_t)N * 18 + 64); // stays resident: begin() restarts a run without PCIe traffic
 	if (!raw || !up) return PGA_ERR_NOMEM;
 	for (int g = 0; g < GL; ++g)
 		if (sh->block[g].n_words) HIPCHK(hipMemcpyAsync(raw + woff[(size_t)g], sh->block[g].data, sizeof(int32_t) * sh->block[g].n_words, hipMemcpyHostToDevice, c->st));
@@ -502,6 +505,13 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		uint64_t *ks; uint32_t *vs;
 		device_radix_sort(key, val, c->P, 32, b, &ks, &vs, c->st);
 		hipLaunchKernelGGL(k_hrank, dim3(nblk(c->P)), dim3(BLOCK), 0, c->st, ks, vs, c->P, c->hrank);
+	}
+	if (N) { // per-hit constants that depend on the input alone (gene, CDS length, score key, static flag bits): once per upload, file order
+		FileHits f = { up, up + (size_t)N, up + 2 * (size_t)N, up + 3 * (size_t)N, up + 4 * (size_t)N, up + 5 * (size_t)N, up + 6 * (size_t)N, up + 7 * (size_t)N, up + 8 * (size_t)N,
+		               up + 9 * (size_t)N, (const uint8_t *)(up + 14 * (size_t)N) };
+		hipLaunchKernelGGL(k_prepare, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, N, c->goff, GL, c->ctg_base, c->exon, c->prot_gid, c->gene_pref,
+		                   up + 10 * (size_t)N, up + 11 * (size_t)N, up + 12 * (size_t)N, up + 13 * (size_t)N, (uint64_t *)c->pool.get(S_KEY_A, 0), (uint32_t *)c->pool.get(S_VAL_A, 0),
+		                   c->rk_shift, c->hrank, up + 15 * (size_t)N, up + 16 * (size_t)N);
 	}
 	const int rc = sync_st(c); // the caller's blocks and tables have been read
 	if (timing) fprintf(stderr, "[pga_create] allocations %.3f ms, upload of %.1f MB + unpack %.3f ms\n", (t1 - t0) * 1e3, woff[(size_t)GL] * 4e-6, (now() - t1) * 1e3);
@@ -531,9 +541,24 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	if (!up) return PGA_ERR_NOMEM;
 	if (c->gs_ok) { // one launch: both orders, every per-hit constant, the packed records (k_segsort.hpp)
 		HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->rk, c->flags };
-		GenomeSort gs = { up, (int64_t)N, c->goff, c->ctg_base, c->exon, c->prot_gid, c->gene_pref, c->hrank, c->rk_shift, c->cs_bits, c->cm_bits, c->ctg_bits, c->gs_np, GL,
-		                  o, c->pm, c->inv, c->yperm, c->headpos, c->recA, c->recB, c->recC };
-		hipLaunchKernelGGL(k_genome_sort, dim3((unsigned)GL), dim3(GS_T), gs_lds_bytes(c->gs_np), c->st, gs);
+		GenomeSort gs = { up, (int64_t)N, c->goff, c->ctg_base, c->cs_bits, c->cm_bits, c->ctg_bits, c->gs_np, GL,
+		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr };
+		static const bool gs_prof = getenv("PANGENE_GS_PROF") != nullptr;
+		if (gs_prof) { gs.prof = (long long *)c->pool.get(S_SCRATCH, sizeof(long long) * 32 * (size_t)GL); if (gs.prof) HIPCHK(hipMemsetAsync(gs.prof, 0, sizeof(long long) * 32 * (size_t)GL, c->st)); }
+		if (c->gs_np <= GS_K_SMALL * GS_T) hipLaunchKernelGGL(k_genome_sort, dim3((unsigned)GL), dim3(GS_T), gs_lds_bytes(c->gs_np), c->st, gs);
+		else hipLaunchKernelGGL(k_genome_sort_big, dim3((unsigned)GL), dim3(GS_T), gs_lds_bytes(c->gs_np), c->st, gs);
+		c->inv_valid = false;
+		if (gs.prof) { // mean cycles per phase over the workgroups (100 MHz constant counter: 10 ns per tick)
+			std::vector<long long> hp((size_t)32 * GL);
+			HIPCHK(hipStreamSynchronize(c->st));
+			HIPCHK(hipMemcpy(hp.data(), gs.prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+			double d[20] = { 0 }; long long t_min = INT64_MAX, t_max = 0;
+			for (int g2 = 0; g2 < GL; ++g2) { for (int k = 1; k <= 12; ++k) d[k] += (double)(hp[(size_t)g2 * 32 + k] - hp[(size_t)g2 * 32 + k - 1]); for (int k = 17; k <= 21; ++k) d[k - 4] += (double)(hp[(size_t)g2 * 32 + k] - hp[(size_t)g2 * 32 + k - 1]); d[0] += (double)(hp[(size_t)g2 * 32 + 16] - hp[(size_t)g2 * 32]); t_min = std::min(t_min, hp[(size_t)g2 * 32]), t_max = std::max(t_max, hp[(size_t)g2 * 32 + 12]); }
+			fprintf(stderr, "[k_genome_sort profile, np %d, ticks/workgroup]", c->gs_np);
+			for (int k = 1; k <= 12; ++k) fprintf(stderr, " %d:%.0f", k, d[k] / GL);
+			fprintf(stderr, " | first radix pass: until the byte plane is staged %.0f, histogram %.0f (wave 0) + %.0f (barrier), scan %.0f, scatter %.0f (wave 0) + %.0f (barrier)", d[0] / GL, d[13] / GL, d[14] / GL, d[15] / GL, d[16] / GL, d[17] / GL);
+			fprintf(stderr, " | kernel span %lld ticks\n", t_max - t_min);
+		}
 		return 0;
 	}
 	int32_t *rk_f = (int32_t *)c->pool.get(S_TAB_A, sizeof(uint64_t) * (size_t)N);
@@ -543,7 +568,7 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	if (!up || !rk_f || !head || !incl || !key || !val) return PGA_ERR_NOMEM;
 	FileHits f = { f_pid, f_cid, f_rank, f_sori, f_sadj, f_nex, f_offx, f_cs, f_ce, f_cm, f_rev };
 	hipLaunchKernelGGL(k_prepare, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, N, c->goff, GL, c->ctg_base, c->exon, c->prot_gid, c->gene_pref,
-	                   f_gnm, f_seg, f_gid, f_cds, key, val, c->rk_shift, c->hrank, rk_f);
+	                   f_gnm, f_seg, f_gid, f_cds, key, val, c->rk_shift, c->hrank, rk_f, up + 16 * (size_t)N);
 	uint64_t *ks; uint32_t *vs;
 	if (c->rk_shift < 0) { // dense rank of the 64-bit score keys (see k_rank_scatter)
 		TRY(radix_sort_pool(c, key, val, N, c->sc_bits, &ks, &vs));
@@ -559,6 +584,7 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->rk, c->flags };
 	hipLaunchKernelGGL(k_gather, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, f_gnm, f_seg, f_gid, f_cds, rk_f, vs, N, c->goff, o);
 	hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv);
+	c->inv_valid = true;
 	HIPCHK(hipMemcpyAsync(c->headpos, c->goff, sizeof(int32_t) * ((size_t)GL + 1), hipMemcpyDeviceToDevice, c->st));
 	// running max of ce per contig
 	SegMax *tile = (SegMax *)c->pool.get(S_TILE, tile_buf_bytes(N));
@@ -612,14 +638,17 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 			hipLaunchKernelGGL(k_pseudo1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, N, P, tmax, tmin);
 			hipLaunchKernelGGL(k_pseudo2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, c->rank, c->flags, N, P, tmax, tmin, tr1, d_stats);
 			hipLaunchKernelGGL(k_pseudo3, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->rank, N, P, tmax, tmin, tr1);
-			pack_records(c); // rank changed
+			hipLaunchKernelGGL(k_pack_rank, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->rank, N, c->recC); // rank changed
 		}
 		unsigned long long *tbest = (unsigned long long *)c->pool.get(S_TAB_D, sizeof(uint64_t) * (size_t)TQ);
-		uint32_t *noiso = (uint32_t *)c->pool.get(S_TAB_A, sizeof(uint32_t) * (size_t)((TP + 31) / 32) + 16); // bit (genome, protein): the protein has a hit there without flt_iso_ov
+		uint8_t *noiso = (uint8_t *)c->pool.get(S_TAB_A, (size_t)TP + 16); // byte (genome, protein): the protein has a hit there without flt_iso_ov
 		if (!tbest || !noiso) return PGA_ERR_NOMEM;
-		TRY(launch_sweep<1>(c, 0)); // pg_shadow(cal_dom_sc=1), read.c:248 -- "K1", the hit-filter+overlap kernel
+		c->sweep_init = true;
+		const int rc_sw = launch_sweep<1>(c, 0); // pg_shadow(cal_dom_sc=1), read.c:248 -- "K1", the hit-filter+overlap kernel
+		c->sweep_init = false;
+		TRY(rc_sw);
 		TRY(launch_sweep<2>(c, 1)); // pg_flt_ov_isoform, read.c:254 (reads neither the shadow flags nor pid_dom: read.c:249-253 follows, in k_iso_apply)
-		HIPCHK(hipMemsetAsync(noiso, 0, sizeof(uint32_t) * (size_t)((TP + 31) / 32), c->st));
+		HIPCHK(hipMemsetAsync(noiso, 0, (size_t)TP, c->st));
 		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, c->pdom, c->pdom0, N, P, noiso, d_stats);
 		hipLaunchKernelGGL(k_chain, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pdom0, N, P, noiso, d_stats);
 		HIPCHK(hipMemsetAsync(tbest, 0, sizeof(uint64_t) * (size_t)TQ, c->st));
@@ -1368,16 +1397,18 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 		hipLaunchKernelGGL(k_ov_sety, dim3(nblk(T)), dim3(BLOCK), 0, c->st, d_pos, d_fil, T, inv, c->yperm);
 		return sync_st(c);
 	}
-	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * 18 * (size_t)T + 64);
+	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * (OV_PLANES + 12) * (size_t)T + 64);
 	if (!tmp) return PGA_ERR_NOMEM;
-	PermArrays p = { { c->fidx, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, (int32_t *)c->flags, c->rk } };
+	PermArrays p = { { c->fidx, c->pid, c->gid, c->cm, c->nex, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, (int32_t *)c->flags, c->sori }, { c->recA, c->recB, c->recC } };
+	static_assert(OV_FLAGS == 10, "the flag word's place in PermArrays");
 	hipLaunchKernelGGL(k_ov_gather, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, inv, tmp, remap);
 	hipLaunchKernelGGL(k_ov_scatter, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, T, tmp, c->gnm, c->goff);
 	hipLaunchKernelGGL(k_ov_remap_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, N, remap);
 	SegMax *tile = (SegMax *)c->pool.get(S_TILE, tile_buf_bytes(N));
-	device_scan<SegMax>(InSegMax{c->seg, c->ce}, OutSegMax{c->pm}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
+	device_scan<SegMax>(InSegMaxA{c->recA}, OutSegMaxA{c->recA}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st); // pm follows the new order
 	hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv);
-	pack_records(c);
+	c->inv_valid = true;
+	hipLaunchKernelGGL(k_cstie, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->recA, N, c->flags);
 	return sync_st(c);
 }
 
@@ -1388,6 +1419,7 @@ extern "C" int pga_set_head(pga_ctx_t *c, const int32_t *head_file)
 	int32_t *d = (int32_t *)c->pool.get(S_OVFILE, sizeof(int32_t) * (size_t)GL);
 	if (!d) return PGA_ERR_NOMEM;
 	TRY(stage_upload(c, d, head_file, sizeof(int32_t) * (size_t)GL)); // head_file is caller memory
+	if (!c->inv_valid) { hipLaunchKernelGGL(k_inv_only, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, c->N, c->inv); c->inv_valid = true; }
 	hipLaunchKernelGGL(k_set_head, dim3(nblk(GL)), dim3(BLOCK), 0, c->st, d, c->goff, c->inv, GL, c->headpos, c->flags);
 	return 0;
 }
