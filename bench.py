@@ -263,6 +263,8 @@ def main():
         return r
 
     roof = roofline_of(d, nh.value, ne.value, "the bench workload itself (fits the 256 MiB Infinity Cache: an L3 figure)")
+    lib.pg_data_destroy(d)  # one context (and one HIP stream) at a time: the legs below bring their own
+    d = None
     big = None
     if rank == 0 and world == 1 and a.roofline_genomes > 0 and kind == "bact":
         RG = a.roofline_genomes
@@ -341,7 +343,8 @@ def main():
             "host_phases_ms_per_step": {lib.pg_phase_name(i).decode(): round(v / a.steps * 1e3, 3) for i, v in enumerate(phases or [])},
         }
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
-    lib.pg_data_destroy(d)
+    if d is not None:
+        lib.pg_data_destroy(d)
     if world > 1 or force_x:
         dist.barrier()
         dist.destroy_process_group()

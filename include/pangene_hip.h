@@ -266,6 +266,7 @@ typedef struct {
 PGA_DECLARE(pga)
 
 /* the same ABI as a table, so the host driver is written once */
+struct pga_branch_par_s;
 typedef struct {
 	const char *name;
 	int  (*create)(pga_ctx_t **, const pga_shard_t *, const pga_params_t *);
@@ -309,9 +310,26 @@ typedef struct {
 	int  (*arc_table)(pga_ctx_t *, const pga_arc_part_t **, int64_t *);
 	int  (*arc_round_finish)(pga_ctx_t *, int32_t, int32_t *, int32_t *);
 	int  (*branch_decide_filter)(pga_ctx_t *, double, double, double, int32_t, int32_t, int32_t, int32_t, uint8_t *); /* may be NULL */
+	int  (*branch_loop)(pga_ctx_t *, int32_t, const struct pga_branch_par_s *, const int32_t *, const int32_t *, const int32_t *, uint8_t *); /* may be NULL */
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);
+
+/* The branch-filter rounds of pg_graph_gen (graph.c:300-314) without the host in between.  Behind a deferred arc round of a run
+ * that is not sharded (arc_round_local(seg_cnt = NULL)), rounds r = 0 .. n_round-1 are queued back to back:
+ *   pg_mark_branch_flt_arc (rep_pos, branch_pairs, branch_decide), pg_mark_branch_flt_hit + PG_SET_FILTER(weak_br == 2),
+ *   for r > 0 pg_flt_high_occ's three tests with max_tot_cnt[r] / max_degree[r] / max_dist_loci[r] (graph.c:226-258) and
+ *   PG_SET_FILTER(vtx == 0), and -- except after the last round -- the next pg_gen_arc.
+ * A deleted segment is not renumbered away: its gene loses its vertex (g2s = -1), its two vertices keep their numbers and
+ * simply have no arcs from then on (renumbering is monotone, so the order of every arc list, pair list and group number --
+ * all the rounds look at -- is the same with the holes as without).  seg_alive[n_seg] (host) tells the caller which
+ * segments are left; it renumbers them, hands the new g2s over (flag_vtx) and runs the arc round the loop left out.
+ * ONE wait, at the end.  Returns 0; 1 = something the queued rounds could not handle happened on the way (a hub gene
+ * overflowed its LDS table, the pair list its capacity): the shard's state is then undefined and the caller repeats the
+ * run with host-driven rounds; 2 = not applicable here (nothing was queued). */
+typedef struct pga_branch_par_s { double branch_diff, branch_diff_dist, branch_diff_cut; int32_t local_dist, local_count, frag_mode, use_ori; } pga_branch_par_t;
+int pga_branch_loop(pga_ctx_t *ctx, int32_t n_round, const pga_branch_par_t *par, const int32_t *max_tot_cnt, const int32_t *max_degree,
+                    const int32_t *max_dist_loci, uint8_t *seg_alive);
 
 /* Optional: run every kernel on this hipStream_t instead of the library's own stream (lets a host
  * framework order its collectives with the kernels without extra synchronisation). */

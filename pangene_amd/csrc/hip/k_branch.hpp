@@ -234,7 +234,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs
 // general scan costs two launches plus one more for the total.  The total goes to dcnt[15] and, with the other counters, to the
 // host's mailbox.  (Graphs beyond PO_THREADS * PO_MAX_ITEMS vertices take the general scan.)
 constexpr int PO_THREADS = 1024, PO_MAX_ITEMS = 64;
-__global__ __launch_bounds__(PO_THREADS) void k_pair_offsets(const int32_t *pc, int n, int32_t *poff, int64_t *dcnt, int64_t *host_box)
+__global__ __launch_bounds__(PO_THREADS) void k_pair_offsets(const int32_t *pc, int n, int32_t *poff, int64_t *dcnt, int64_t *host_box, long long cap /* room in the pair list, or < 0 */)
 {
 	__shared__ int32_t part[PO_THREADS];
 	const int t = threadIdx.x, per = (n + PO_THREADS - 1) / PO_THREADS, i0 = t * per, i1 = i0 + per < n ? i0 + per : n;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pair_offsets(const int32_t *pc, 
 	}
 	int32_t run = part[t] - s;
 	for (int i = i0; i < i1; ++i) { poff[i] = run; run += pc[i]; }
-	if (t == PO_THREADS - 1) dcnt[15] = part[t];
+	if (t == PO_THREADS - 1) { dcnt[15] = part[t]; if (cap >= 0 && part[t] > cap) dcnt[11] = 1; } // [11]: sticky "a queued round could not be completed" (pga_branch_loop)
 	__syncthreads();
 	if (t < 16) sys_store(&host_box[t], dcnt[t]);
 }
@@ -364,6 +364,20 @@ __global__ __launch_bounds__(BLOCK) void k_round_filter(int S, const int32_t *se
 	if (s >= S) return;
 	const int l0 = ndl[2 * s], l1 = ndl[2 * s + 1];
 	del[s] = (seg_cnt[S + s] > max_tot_cnt || deg[2 * s] > max_degree || deg[2 * s + 1] > max_degree || (l0 > l1 ? l0 : l1) > max_dist_loci) ? 1 : 0;
+}
+
+// pga_branch_loop: the verdicts of k_round_filter applied on the device.  A deleted segment keeps its number: its gene loses its
+// vertex, its two vertices their arcs and counters (nothing refers to them from then on: hits of the gene are filtered next).
+__global__ __launch_bounds__(BLOCK) void k_apply_del(int S, const uint8_t *del, const int32_t *seg_gid, int32_t *g2s, int32_t *vs, int32_t *ve, int32_t *deg, int32_t *seg_cnt, uint8_t *vwk, uint8_t *alive)
+{
+	const int s = blockIdx.x * BLOCK + threadIdx.x;
+	if (s >= S || !del[s] || !alive[s]) return;
+	alive[s] = 0;
+	g2s[seg_gid[s]] = -1;
+	vs[2 * s] = ve[2 * s] = vs[2 * s + 1] = ve[2 * s + 1] = 0;
+	deg[2 * s] = deg[2 * s + 1] = 0;
+	seg_cnt[s] = seg_cnt[S + s] = 0;
+	vwk[2 * s] = vwk[2 * s + 1] = 0;
 }
 
 __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107

@@ -87,7 +87,7 @@ __global__ void k_mail_round(int64_t *dcnt, int64_t *host_box, int32_t *tail /* 
 	if (threadIdx.x < 16) sys_store(&host_box[threadIdx.x], dcnt[threadIdx.x]);
 	if (threadIdx.x == 0 && tail) sys_store(&tail[0], (int32_t)dcnt[9]), sys_store(&tail[1], (int32_t)dcnt[3]);
 	__syncthreads();
-	if (threadIdx.x == 0) dcnt[9] = 0;
+	if (threadIdx.x == 0) { if (dcnt[9] || dcnt[3]) dcnt[11] = 1; dcnt[9] = 0; } // [11]: sticky, for rounds nobody looks at one by one (pga_branch_loop)
 }
 
 __global__ void k_mail_flush(const int64_t *dcnt, int64_t *host_box)

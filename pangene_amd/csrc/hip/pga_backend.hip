@@ -1045,6 +1045,7 @@ extern "C" int pga_arc_round_local(pga_ctx_t *c, int32_t use_ori, int32_t n_seg,
 		}
 		int32_t *h_dev = nullptr;
 		HIPCHK(hipHostGetDevicePointer((void **)&h_dev, c->h_round, 0));
+		if (seg_cnt_host == nullptr) HIPCHK(hipMemsetAsync(c->dcnt + 11, 0, sizeof(int64_t), c->st)); // the sticky flag of pga_branch_loop covers this round and what follows it
 		TRY(arc_round_genes(c, use_ori, &seg_cnt, &deg, h_dev)); // the gene kernels write the counters and degrees into the pinned buffer
 		c->br_n = 2 * (int64_t)c->N + 2, c->br_S = S, c->br_np = 0; // (br_n: extent of the table arrays; the arcs are counted when somebody asks, pga_arc_table)
 		if (seg_cnt_host == nullptr) { c->arc_deferred = true, c->arc_epoch = c->sync_epoch; return 0; } // the caller collects the results later (pga_arc_round_finish)
@@ -1242,7 +1243,7 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	}
 	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
 	static const bool general_scan = getenv("PANGENE_PAIR_SCAN_GENERAL") != nullptr; // (tests: the path of graphs with more than 65536 vertices)
-	if (n_vtx <= PO_THREADS * PO_MAX_ITEMS && !general_scan) hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(PO_THREADS), 0, c->st, pc, n_vtx, poff, c->dcnt, c->h_box); // offsets, and dcnt[15] = number of pairs
+	if (n_vtx <= PO_THREADS * PO_MAX_ITEMS && !general_scan) hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(PO_THREADS), 0, c->st, pc, n_vtx, poff, c->dcnt, c->h_box, n_pairs ? -1ll : (long long)std::max<int64_t>(c->br_cap, 4 * (int64_t)n_vtx)); // offsets, and dcnt[15] = number of pairs
 	else {
 		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_vtx));
 		device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
@@ -1334,6 +1335,61 @@ extern "C" int pga_branch_decide_filter(pga_ctx_t *c, double branch_diff, double
 	if (!(c->arc_deferred && !c->arc_done && c->table_sparse) || c->br_S != c->n_seg || (do_filter && del == nullptr)) return 2;
 	RoundFilter rf = { do_filter, max_tot_cnt, max_degree, max_dist_loci, del };
 	return decide_impl(c, branch_diff, branch_diff_dist, branch_diff_cut, nullptr, nullptr, nullptr, nullptr, &rf);
+}
+
+extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_par_t *par, const int32_t *max_tot_cnt, const int32_t *max_degree,
+                               const int32_t *max_dist_loci, uint8_t *seg_alive)
+{
+	static const bool off = getenv("PANGENE_BRANCH_LOOP_HOST") != nullptr; // (tests: keep the host-driven rounds exercised)
+	const int S = c->n_seg, n_vtx = 2 * S, N = c->N;
+	if (off || n_round <= 0 || par == nullptr || seg_alive == nullptr || N == 0 || S == 0 || !(c->arc_deferred && !c->arc_done && c->table_sparse) || c->br_S != S || n_vtx > PO_THREADS * PO_MAX_ITEMS) return 2;
+	uint8_t *del = (uint8_t *)c->pool.get(S_MISC, 2 * (size_t)S + 64), *alive = del ? del + S : nullptr;
+	int32_t *ndl = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
+	if (!del || !ndl) return PGA_ERR_NOMEM;
+	HIPCHK(hipMemsetAsync(alive, 1, (size_t)S, c->st));
+	c->br_cap = std::max<int64_t>(c->br_cap, std::max<int64_t>(32 * (int64_t)n_vtx, 2 * c->br_np_seen)); // generous: a list that overflows costs a repeated run
+	for (int r = 0; r < n_round; ++r) {
+		// pg_mark_branch_flt_arc (branch.c:48-106)
+		TRY(pga_rep_pos(c));
+		int32_t *cnt;
+		TRY(pga_branch_pairs(c, nullptr, nullptr, 0, nullptr, S, par->branch_diff, par->local_dist, par->local_count, par->frag_mode, &cnt, nullptr));
+		{
+			const int64_t n_arc = c->br_n;
+			uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, 0), *vwk = (uint8_t *)c->pool.get(S_VWK, (size_t)n_vtx + 16);
+			int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, 0), *agid = (int32_t *)c->pool.get(S_BR_GID, 0), *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0);
+			int32_t *poff = (int32_t *)c->pool.get(S_BR_POFF, 0), *grp = (int32_t *)c->pool.get(S_BR_GRP, sizeof(int32_t) * (size_t)n_arc + 16);
+			int32_t *sg = (int32_t *)c->pool.get(S_BR_SEGGID, 0), *dg = (int32_t *)c->pool.get(S_DEG, 0), *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, 0);
+			if (!aw || !vwk || !s1 || !agid || !vs || !ve || !poff || !grp || !sg || !dg || !seg_cnt) return PGA_ERR_NOMEM;
+			hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, par->branch_diff, poff, (int32_t *)nullptr, (int64_t)c->br_cap, (const int32_t *)nullptr, (const int32_t *)c->pool.get(S_NLCNT, 0),
+			                   par->branch_diff_dist, par->branch_diff_cut, aw, grp, ndl, (int64_t *)nullptr, vwk, c->dcnt + 15);
+			if (r > 0) hipLaunchKernelGGL(k_round_filter, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)seg_cnt, (const int32_t *)dg, (const int32_t *)ndl, max_tot_cnt[r], max_degree[r], max_dist_loci[r], del);
+			// pg_mark_branch_flt_hit + PG_SET_FILTER(weak_br == 2) (branch.c:108-145, graph.c:309): with the numbering the arcs were made with
+			TRY(pga_mark_hits(c, nullptr, nullptr, 0, nullptr, 1));
+			if (r > 0) { // pg_flt_high_occ + pg_hard_delete + PG_SET_FILTER(vtx == 0) (graph.c:219-263, 312)
+				hipLaunchKernelGGL(k_apply_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const uint8_t *)del, (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive);
+				hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1);
+				c->walk_valid = false, c->ha_valid = false;
+			}
+		}
+		if (r + 1 < n_round) { // pg_gen_arc (graph.c:313)
+			int32_t *seg_cnt, *deg;
+			TRY(arc_round_genes(c, par->use_ori, &seg_cnt, &deg, nullptr));
+			c->br_n = 2 * (int64_t)N + 2, c->br_S = S, c->br_np = 0;
+		}
+	}
+	c->arc_deferred = false, c->arc_done = false;
+	if (c->h_fetch_cap < (size_t)S) {
+		c->h_fetch = c->pin.get((size_t)S + S / 2 + 256);
+		if (!c->h_fetch) return PGA_ERR_NOMEM;
+		c->h_fetch_cap = (size_t)S + S / 2 + 256;
+	}
+	HIPCHK(hipMemcpyAsync(c->h_fetch, alive, (size_t)S, hipMemcpyDeviceToHost, c->st));
+	hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
+	TRY(sync_st(c));
+	c->br_np_seen = std::max<int64_t>(c->br_np_seen, c->h_cnt[15]);
+	if (c->h_cnt[11]) return c->h_cnt[3] ? PGA_ERR_INVARIANT : 1;
+	memcpy(seg_alive, c->h_fetch, (size_t)S);
+	return 0;
 }
 
 extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t *arc_weak, int64_t n_arc, int64_t *n_marked, int32_t then_filter)
@@ -1573,7 +1629,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop
 	};
 	return &b;
 }

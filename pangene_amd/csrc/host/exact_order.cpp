@@ -255,6 +255,23 @@ int exact_sort(DataExt *ext, int by_cm)
 
 void exact_shutdown(DataExt *ext) { exact_wait(ext); }
 
+// Would the next n sorts of each kind (hit.c:29-64) need nothing from the host?  True when no contig is tracked in full and the
+// hit at array index 0 of every genome stays the one the backend holds through the next n cs sorts.
+bool exact_quiet(DataExt *ext, int n)
+{
+	if (ext->xsegs.empty()) return true;
+	exact_wait(ext);
+	for (const ExactSeg &s : ext->xsegs) {
+		if (s.full) return false;
+		for (int t = ext->x_sorts[0] + 1; t <= ext->x_sorts[0] + n; ++t)
+			if (s.heads[order_index(s, t, s.heads.size())] != ext->head_file[(size_t)s.k]) return false;
+	}
+	return true;
+}
+
+// the backend made n sorts of each kind on its own (after exact_quiet said it could)
+void exact_skip(DataExt *ext, int n) { if (!ext->xsegs.empty()) ext->x_sorts[0] += n, ext->x_sorts[1] += n; }
+
 } // namespace pgx
 
 extern "C" void pg_set_exact_mode(int mode) { pgx::set_exact_mode(mode); }

@@ -887,6 +887,49 @@ static int apply_round_filter(pg_graph_t *q, DataExt *ext, const std::vector<uin
 	return flag_vtx(q, ext);
 }
 
+// Rounds 0 .. R-1 of the branch filter (graph.c:300-314) queued on the backend in one go, one wait at the end (pga_branch_loop):
+// the common case -- not sharded, no log lines, no contig whose order is replayed in full.  *done = false: not applicable
+// (nothing happened).  Returns RC_REDO when the queued rounds met something only the host-driven rounds can handle: the
+// shard's state is undefined then and pg_graph_gen repeats the run.
+enum { RC_REDO = 1000 };
+static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, int32_t R, bool *done)
+{
+	*done = false;
+	const pga_backend_t *be = ext->be;
+	if (be->branch_loop == nullptr || sharded() || pg_verbose >= 3 || trace_path() != nullptr || !ext->arc_pending || R < 1 || ext->no_branch_loop) return 0;
+	const int n_sorts = 2 * R - 1; // of each kind: one pair per pg_mark_branch_flt_hit (branch.c:116,140), one per pg_gen_arc (graph.c:103,123)
+	{ Phase ph(PH_EXACT); if (!exact_quiet(ext, n_sorts)) return 0; }
+	const int32_t S = q->n_seg, n = opt->n_branch_flt;
+	std::vector<int32_t> m_tot((size_t)R), m_deg((size_t)R), m_loci((size_t)R);
+	for (int32_t i = 0; i < R; ++i) { // graph.c:303-306
+		const double r = 1.0 + (double)(n - 1 - i) / n;
+		m_tot[(size_t)i] = (int32_t)(opt->max_avg_occ * r + .499) * q->d->n_genome;
+		m_deg[(size_t)i] = (int32_t)(opt->max_degree * r + .499);
+		m_loci[(size_t)i] = (int32_t)(opt->max_dist_loci * r + .499);
+	}
+	pga_branch_par_t par;
+	par.branch_diff = opt->branch_diff, par.branch_diff_dist = opt->branch_diff_dist, par.branch_diff_cut = opt->branch_diff_cut;
+	par.local_dist = opt->local_dist, par.local_count = opt->local_count, par.frag_mode = !!(opt->flag & PG_F_FRAG_MODE), par.use_ori = !!(opt->flag & PG_F_ORI_FOR_BRANCH);
+	std::vector<uint8_t> &alive = ext->del_buf;
+	alive.assign((size_t)S + 1, 1);
+	int rc;
+	{ Phase ph(PH_NLOCAL); rc = be->branch_loop(ext->ctx, R, &par, m_tot.data(), m_deg.data(), m_loci.data(), alive.data()); }
+	if (rc == 2) return 0;
+	if (rc == 1) { ext->no_branch_loop = true; return RC_REDO; }
+	if (rc != 0) { set_error(rc, "branch_loop"); return rc; }
+	ext->arc_pending = false;
+	exact_skip(ext, n_sorts);
+	Phase ph(PH_FLT);
+	int32_t k = 0;
+	for (int32_t i = 0; i < S; ++i)
+		if (alive[(size_t)i]) q->seg[k++] = q->seg[i];
+	q->n_seg = k;
+	gen_g2s(q);
+	BE_CALL(flag_vtx(q, ext), "flag_vtx"); // the renumbered g2s (the hits' flags do not change: the loop filtered them already)
+	*done = true;
+	return 0;
+}
+
 static int mark_branch_flt_hit(pg_graph_t *q, DataExt *ext) // branch.c:108-145; the arcs and their weak_br are already resident
 {
 	int64_t n = 0;
@@ -921,7 +964,17 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	BE_CALL(trace_state(ext, "gen_arc", 2), "trace");
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-2 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
 	// graph 3: branch filtering (graph.c:300-315)
-	for (int32_t i = 0; i < opt->n_branch_flt; ++i) {
+	int32_t i_first = 0;
+	if (opt->n_branch_flt >= 2) { // all rounds but the last one in one go, when the backend can (the last one fills the public fields of pg_seg_t)
+		bool done = false;
+		const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt - 1, &done);
+		if (rc) return rc;
+		if (done) {
+			i_first = opt->n_branch_flt - 1;
+			BE_CALL(gen_arc(opt, q, ext, true), "gen_arc"); // the arc round of round n-2, with the renumbered segments
+		}
+	}
+	for (int32_t i = i_first; i < opt->n_branch_flt; ++i) {
 		double r = 1.0 + (double)(opt->n_branch_flt - 1 - i) / opt->n_branch_flt;
 		int32_t max_avg_occ = (int32_t)(opt->max_avg_occ * r + .499);
 		int32_t max_degree = (int32_t)(opt->max_degree * r + .499);
@@ -1057,11 +1110,23 @@ static int hazards_review(DataExt *ext, bool *need, bool *give_up)
 void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 {
 	double t = now_sec();
-	if (g_err == 0 && graph_gen_impl(opt, q) != 0) q->n_arc = 0;
-	const double t_first = now_sec() - t;
-	int n_attempt = 1;
 	DataExt *ext = ext_of(q->d, false);
 	if (ext) ext->q_d = q->d;
+	auto run_graph = [&]() { // graph_gen_impl; when the queued branch rounds gave up, once more from stage A with host-driven rounds
+		int rc = graph_gen_impl(opt, q);
+		if (rc == RC_REDO && ext) {
+			if (pg_verbose >= 2) std::fprintf(stderr, "[M::%s::%s] the queued branch rounds met a case they leave to the host: repeating stages A-C with host-driven rounds\n", "pg_graph_gen", stamp());
+			q->n_seg = 0, q->n_arc = 0;
+			std::memset((void *)q->seg, 0, sizeof(pg_seg_t) * (size_t)q->m_seg);
+			ext->rerun = true;
+			rc = post_process_impl(opt, q->d);
+			if (rc == 0) rc = graph_gen_impl(opt, q);
+		}
+		return rc;
+	};
+	if (g_err == 0 && run_graph() != 0) q->n_arc = 0;
+	const double t_first = now_sec() - t;
+	int n_attempt = 1;
 	// Mode auto: the canonical order provably gives the reference's result unless a tie-order hazard occurred.  Where one
 	// did, the contigs concerned get the reference's exact order (replayed on the host) and stages A-C are repeated on the
 	// resident shard; hazards that then only occur on such contigs are harmless.  After three attempts, or when the event
@@ -1090,7 +1155,7 @@ void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 		std::memset((void *)q->seg, 0, sizeof(pg_seg_t) * (size_t)q->m_seg);
 		ext->rerun = true;
 		++n_attempt;
-		if (post_process_impl(opt, q->d) != 0 || graph_gen_impl(opt, q) != 0) q->n_arc = 0;
+		if (post_process_impl(opt, q->d) != 0 || run_graph() != 0) q->n_arc = 0;
 		if (all) { exact_override(-1); break; }
 	}
 	if (ext && (!ext->extra_ctgs.empty() || ext->exact_mode_of_segs != exact_mode())) { // back to the cheap tracking for a later rerun

@@ -85,6 +85,7 @@ struct DataExt {
 	int32_t xsegs_n_genome = -1;       // number of genomes the segments were built for
 	int x_sorts[2] = {0, 0};           // cs / cm sorts of the reference seen so far in this run
 	std::vector<int32_t> head_file;    // per local genome: file index of the hit at array index 0 (-1 canonical)
+	bool no_branch_loop = false;       // the queued branch rounds (pga_branch_loop) met something they cannot handle on this data set: host-driven rounds from now on
 	bool arc_pending = false;          // a deferred arc round whose host results have not been collected (arc_collect)
 	bool rerun = false;                // pg_rerun_resident(): keep the backend context, skip pack + upload
 	bool host_full = false;            // the last sync also fetched rank / score_dom / dominators
@@ -127,6 +128,8 @@ void exact_begin(DataExt *ext);
 void exact_prefetch(const pg_data_t *d, DataExt *ext);
 int exact_sort(DataExt *ext, int by_cm);
 void exact_shutdown(DataExt *ext);
+bool exact_quiet(DataExt *ext, int n);
+void exact_skip(DataExt *ext, int n);
 
 // phase accounting of the host driver (seconds, accumulated over the last run)
 enum { PH_BEGIN, PH_EXACT, PH_INGEST, PH_POST, PH_VTX, PH_ARC_DEV, PH_ARC_HOST, PH_BRANCH_HOST, PH_NLOCAL, PH_MARK_HITS, PH_FLT, PH_SYNC_HOST, PH_COUNT };

@@ -24,7 +24,7 @@ except Exception as ex:
 # idle time is distributed (launch gaps vs host waits); the last `--steps` passes are delimited by the k_prepare launches
 try:
     ev = cur.execute("SELECT name, start, end FROM kernels ORDER BY start").fetchall()
-    starts = [i for i, e in enumerate(ev) if e[0].startswith("k_prepare")]
+    starts = [i for i, e in enumerate(ev) if e[0].startswith("k_genome_sort")] or [i for i, e in enumerate(ev) if e[0].startswith("k_prepare")]  # first big kernel of pga_begin
     if len(starts) >= 3:
         a, b = starts[-2], starts[-1]  # one whole pass: from one k_prepare to the next
         seg = ev[a:b]
@@ -32,7 +32,7 @@ try:
         busy = sum(e[2] - e[1] for e in seg)
         gaps = [seg[i + 1][1] - seg[i][2] for i in range(len(seg) - 1)]
         big = [g for g in gaps if g > 15000]
-        print("# one pass (k_prepare to k_prepare): %d launches, span %.3f ms, inside kernels %.3f ms (%.0f %%), idle %.3f ms: %d gaps > 15 us (host waits) = %.3f ms, the other %d gaps = %.3f ms (mean %.2f us)"
+        print("# one pass (from the first kernel of pga_begin to the next one): %d launches, span %.3f ms, inside kernels %.3f ms (%.0f %%), idle %.3f ms: %d gaps > 15 us (host waits) = %.3f ms, the other %d gaps = %.3f ms (mean %.2f us)"
               % (len(seg), span / 1e6, busy / 1e6, 100.0 * busy / span, (span - busy) / 1e6, len(big), sum(big) / 1e6, len(gaps) - len(big), (sum(gaps) - sum(big)) / 1e6,
                  (sum(gaps) - sum(big)) / 1e3 / max(1, len(gaps) - len(big))))
         # where the host waits are: (kernel before the gap -> kernel after it), count, mean gap
@@ -46,3 +46,15 @@ try:
             print("#   wait  %-40s -> %-40s  x%-3d mean %.1f us" % (k[0], k[1], len(v), sum(v) / len(v) / 1e3))
 except Exception as ex:  # older databases
     print("# (no timeline: %s)" % ex)
+
+# stage A of the last whole pass, launch by launch (start relative to the pass's first kernel, duration)
+try:
+    if len(starts) >= 3:
+        seg = ev[starts[-2]:starts[-1]]
+        t0 = seg[0][1]
+        last = max(i for i, e in enumerate(seg) if e[0].startswith("k_subopt2") or e[0].startswith("k_chain"))
+        print("# stage A of that pass (pga_begin + pga_ingest), launch by launch: start us, duration us, kernel")
+        for e in seg[:last + 1]:
+            print("#   %9.1f %9.1f  %s" % ((e[1] - t0) / 1e3, (e[2] - e[1]) / 1e3, e[0][:70]))
+except Exception as ex:
+    print("# (no stage-A timeline: %s)" % ex)
