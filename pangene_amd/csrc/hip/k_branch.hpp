@@ -366,12 +366,14 @@ __global__ __launch_bounds__(BLOCK) void k_round_filter(int S, const int32_t *se
 	del[s] = (seg_cnt[S + s] > max_tot_cnt || deg[2 * s] > max_degree || deg[2 * s + 1] > max_degree || (l0 > l1 ? l0 : l1) > max_dist_loci) ? 1 : 0;
 }
 
-// pga_branch_loop: the verdicts of k_round_filter applied on the device.  A deleted segment keeps its number: its gene loses its
+// pga_branch_loop: k_round_filter's tests and their consequences in one launch.  A deleted segment keeps its number: its gene loses its
 // vertex, its two vertices their arcs and counters (nothing refers to them from then on: hits of the gene are filtered next).
-__global__ __launch_bounds__(BLOCK) void k_apply_del(int S, const uint8_t *del, const int32_t *seg_gid, int32_t *g2s, int32_t *vs, int32_t *ve, int32_t *deg, int32_t *seg_cnt, uint8_t *vwk, uint8_t *alive)
+__global__ __launch_bounds__(BLOCK) void k_round_del(int S, const int32_t *ndl, int max_tot_cnt, int max_degree, int max_dist_loci, const int32_t *seg_gid, int32_t *g2s, int32_t *vs, int32_t *ve, int32_t *deg, int32_t *seg_cnt, uint8_t *vwk, uint8_t *alive)
 {
 	const int s = blockIdx.x * BLOCK + threadIdx.x;
-	if (s >= S || !del[s] || !alive[s]) return;
+	if (s >= S || !alive[s]) return;
+	const int l0 = ndl[2 * s], l1 = ndl[2 * s + 1];
+	if (!(seg_cnt[S + s] > max_tot_cnt || deg[2 * s] > max_degree || deg[2 * s + 1] > max_degree || (l0 > l1 ? l0 : l1) > max_dist_loci)) return; // k_round_filter's tests
 	alive[s] = 0;
 	g2s[seg_gid[s]] = -1;
 	vs[2 * s] = ve[2 * s] = vs[2 * s + 1] = ve[2 * s + 1] = 0;

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) void k_gene_arcs_wave(GeneArcs a)
 	const int sid = a.g2s[g], z0 = a.zoff[g], z1 = a.zoff[g + 1];
 	if (sid < 0) { // not a vertex: none of its hits may be walkable (graph.c:111)
 		for (int z = z0 + tid; z < z1; z += BLOCK)
-			if (hx_walk(a.hbk[z], a.tag)) atomicAdd((unsigned long long *)&a.dcnt[3], 1ull);
+			if (hx_walk(a.hbk[z], a.tag)) atomicAdd((unsigned long long *)&a.dcnt[3], 1ull), a.dcnt[11] = 1; // ([11]: sticky, for rounds nobody looks at one by one: pga_branch_loop)
 		if (tid == 0) a.big_list[g] = 0;
 		return;
 	}
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void k_gene_arcs_big(GeneArcs a)
 		if (!a.big_list[g]) continue;
 		const int sid = a.g2s[g];
 		if (!gene_arcs_one<BLOCK, GA_CAP, GA_BIG_STAGE>(a, T, g, sid, threadIdx.x, a.cap_log2) && threadIdx.x == 0) // a hub gene: this round is redone on the sort path
-			atomicAdd((unsigned long long *)&a.dcnt[9], 1ull), a.gmeta[sid] = make_int4(0, 0, 0, 0); // (the whole round is repeated: nothing else to leave behind)
+			atomicAdd((unsigned long long *)&a.dcnt[9], 1ull), a.dcnt[11] = 1, a.gmeta[sid] = make_int4(0, 0, 0, 0); // (the whole round is repeated: nothing else to leave behind)
 		__syncthreads();
 	}
 }

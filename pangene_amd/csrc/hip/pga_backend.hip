@@ -291,7 +291,7 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 	{ const int rc = make_sweep_view(c, &v); if (rc) return rc; }
 	TimedLaunch t; t.which = timed_which; t.units = c->N;
 	static const int reps = [] { const char *e = getenv("PGA_SW_REPS"); return e && atoi(e) > 0 ? atoi(e) : 1; }(); // tuning aid: the sweep is idempotent
-	const bool timed = timed_which >= 0 && c->timing_on;
+	const bool timed = (timed_which == 0 || timed_which == 1) && c->timing_on; // (the stage-C sweeps are not timed one by one: two events per launch cost ~10 us of queue time)
 	if (timed) {
 		HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
 		if (reps != 1) HIPCHK(hipEventRecord(t.a, c->st));
@@ -888,7 +888,7 @@ static int cur_table(pga_ctx *c, int64_t n_arc, int n_seg, CurTable *t)
 // pg_gen_arc on the gene-major index (k_genes.hpp).  Leaves the round's arcs, every gene's in its own stretch of the table arrays,
 // and everything the branch steps read (what pga_arc_set_current would derive) in place; seg_cnt[2S] and the degrees go to the
 // pinned buffer h_round_dev when one is given.  The counters travel to the pinned mirror with the last kernel; nothing waits here.
-static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32_t **deg_out, int32_t *h_round_dev)
+static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32_t **deg_out, int32_t *h_round_dev, bool mail = true)
 {
 	const int N = c->N, S = c->n_seg;
 	const int64_t cap = 2 * (int64_t)N + 2; // distinct arcs <= half-arcs <= 2 (N - 1)
@@ -913,7 +913,7 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt };
 	hipLaunchKernelGGL(k_gene_arcs_wave, dim3((unsigned)c->Q), dim3(BLOCK), 0, c->st, ga);
 	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 8 * c->n_cu)), dim3(BLOCK), 0, c->st, ga);
-	hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box, h_round_dev ? h_round_dev + 4 * (size_t)S : (int32_t *)nullptr); // invariant / overflow counters for the host; the overflow counter starts again
+	if (mail) hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box, h_round_dev ? h_round_dev + 4 * (size_t)S : (int32_t *)nullptr); // invariant / overflow counters for the host; the overflow counter starts again
 	return 0;
 }
 
@@ -1241,9 +1241,10 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 		hipLaunchKernelGGL(k_br_prep, dim3(nblk(n_arc)), dim3(BLOCK), 0, c->st, ax, n_arc, sg, agid, vs, ve);
 		HIPCHK(hipMemsetAsync(aw, 0, (size_t)n_arc, c->st)); // (the tables of arc_round_local / arc_set_current arrive with weak_br = 0)
 	}
-	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
 	static const bool general_scan = getenv("PANGENE_PAIR_SCAN_GENERAL") != nullptr; // (tests: the path of graphs with more than 65536 vertices)
-	if (n_vtx <= PO_THREADS * PO_MAX_ITEMS && !general_scan) hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(PO_THREADS), 0, c->st, pc, n_vtx, poff, c->dcnt, c->h_box, n_pairs ? -1ll : (long long)std::max<int64_t>(c->br_cap, 4 * (int64_t)n_vtx)); // offsets, and dcnt[15] = number of pairs
+	const bool one_wg = n_vtx <= PO_THREADS * PO_MAX_ITEMS && !general_scan;
+	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
+	if (one_wg) hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(PO_THREADS), 0, c->st, (const int32_t *)pc, n_vtx, poff, c->dcnt, c->h_box, n_pairs ? -1ll : (long long)std::max<int64_t>(c->br_cap, 4 * (int64_t)n_vtx)); // offsets, and dcnt[15] = number of pairs
 	else {
 		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_vtx));
 		device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
@@ -1252,7 +1253,7 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	if (n_pairs) { // somebody outside needs the count (the all-reduce of a sharded run): wait for it and size the buffers exactly
 		TRY(sync_st(c));
 		c->br_np = c->h_cnt[15], *n_pairs = c->br_np;
-		c->br_cap = std::max<int64_t>(c->br_np, 16);
+		c->br_cap = std::max<int64_t>(c->br_cap, std::max<int64_t>(c->br_np, 16)); // (never shrinks: lists queued earlier may still be in use)
 		return c->br_np ? branch_enumerate(c, cnt) : 0;
 	}
 	// otherwise nothing waits: the buffers keep the capacity that was enough so far, pga_branch_decide checks the count when
@@ -1343,11 +1344,17 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	static const bool off = getenv("PANGENE_BRANCH_LOOP_HOST") != nullptr; // (tests: keep the host-driven rounds exercised)
 	const int S = c->n_seg, n_vtx = 2 * S, N = c->N;
 	if (off || n_round <= 0 || par == nullptr || seg_alive == nullptr || N == 0 || S == 0 || !(c->arc_deferred && !c->arc_done && c->table_sparse) || c->br_S != S || n_vtx > PO_THREADS * PO_MAX_ITEMS) return 2;
-	uint8_t *del = (uint8_t *)c->pool.get(S_MISC, 2 * (size_t)S + 64), *alive = del ? del + S : nullptr;
+	uint8_t *alive = (uint8_t *)c->pool.get(S_MISC, (size_t)S + 64);
 	int32_t *ndl = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
-	if (!del || !ndl) return PGA_ERR_NOMEM;
+	if (!alive || !ndl) return PGA_ERR_NOMEM;
 	HIPCHK(hipMemsetAsync(alive, 1, (size_t)S, c->st));
-	c->br_cap = std::max<int64_t>(c->br_cap, std::max<int64_t>(32 * (int64_t)n_vtx, 2 * c->br_np_seen)); // generous: a list that overflows costs a repeated run
+	{ // Room for the pair lists of every round (nobody can ask for more on the way): a vertex with n out-arcs lists at most n^2
+	  // pairs (branch.c:70-88), and pg_flt_high_occ keeps n near max_degree (graph.c:243-250) -- the lists grow over the rounds,
+	  // so the first round's length says little.  A list that still overflows costs a repeated run (sticky flag), not a wrong one.
+		int64_t dmax = 8;
+		for (int r = 1; r < n_round; ++r) dmax = std::max<int64_t>(dmax, max_degree[r]);
+		c->br_cap = std::max<int64_t>(c->br_cap, std::min<int64_t>((int64_t)n_vtx * dmax * dmax, (int64_t)1 << 26));
+	}
 	for (int r = 0; r < n_round; ++r) {
 		// pg_mark_branch_flt_arc (branch.c:48-106)
 		TRY(pga_rep_pos(c));
@@ -1362,18 +1369,17 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 			if (!aw || !vwk || !s1 || !agid || !vs || !ve || !poff || !grp || !sg || !dg || !seg_cnt) return PGA_ERR_NOMEM;
 			hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, par->branch_diff, poff, (int32_t *)nullptr, (int64_t)c->br_cap, (const int32_t *)nullptr, (const int32_t *)c->pool.get(S_NLCNT, 0),
 			                   par->branch_diff_dist, par->branch_diff_cut, aw, grp, ndl, (int64_t *)nullptr, vwk, c->dcnt + 15);
-			if (r > 0) hipLaunchKernelGGL(k_round_filter, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)seg_cnt, (const int32_t *)dg, (const int32_t *)ndl, max_tot_cnt[r], max_degree[r], max_dist_loci[r], del);
 			// pg_mark_branch_flt_hit + PG_SET_FILTER(weak_br == 2) (branch.c:108-145, graph.c:309): with the numbering the arcs were made with
 			TRY(pga_mark_hits(c, nullptr, nullptr, 0, nullptr, 1));
 			if (r > 0) { // pg_flt_high_occ + pg_hard_delete + PG_SET_FILTER(vtx == 0) (graph.c:219-263, 312)
-				hipLaunchKernelGGL(k_apply_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const uint8_t *)del, (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive);
+				hipLaunchKernelGGL(k_round_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)ndl, max_tot_cnt[r], max_degree[r], max_dist_loci[r], (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive);
 				hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1);
 				c->walk_valid = false, c->ha_valid = false;
 			}
 		}
 		if (r + 1 < n_round) { // pg_gen_arc (graph.c:313)
 			int32_t *seg_cnt, *deg;
-			TRY(arc_round_genes(c, par->use_ori, &seg_cnt, &deg, nullptr));
+			TRY(arc_round_genes(c, par->use_ori, &seg_cnt, &deg, nullptr, false)); // (no mail: the kernels raise the sticky flag themselves)
 			c->br_n = 2 * (int64_t)N + 2, c->br_S = S, c->br_np = 0;
 		}
 	}
@@ -1387,6 +1393,7 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
 	TRY(sync_st(c));
 	c->br_np_seen = std::max<int64_t>(c->br_np_seen, c->h_cnt[15]);
+	if (getenv("PANGENE_DEBUG_LOOP")) fprintf(stderr, "[pga_branch_loop] counters after %d rounds: invariant %lld, table overflows (last round) %lld, sticky %lld, pairs (last round) %lld of capacity %lld\n", n_round, (long long)c->h_cnt[3], (long long)c->h_cnt[9], (long long)c->h_cnt[11], (long long)c->h_cnt[15], (long long)c->br_cap);
 	if (c->h_cnt[11]) return c->h_cnt[3] ? PGA_ERR_INVARIANT : 1;
 	memcpy(seg_alive, c->h_fetch, (size_t)S);
 	return 0;

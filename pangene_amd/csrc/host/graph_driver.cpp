@@ -898,7 +898,8 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	const pga_backend_t *be = ext->be;
 	if (be->branch_loop == nullptr || sharded() || pg_verbose >= 3 || trace_path() != nullptr || !ext->arc_pending || R < 1 || ext->no_branch_loop) return 0;
 	const int n_sorts = 2 * R - 1; // of each kind: one pair per pg_mark_branch_flt_hit (branch.c:116,140), one per pg_gen_arc (graph.c:103,123)
-	{ Phase ph(PH_EXACT); if (!exact_quiet(ext, n_sorts)) return 0; }
+	static const bool dbg = std::getenv("PANGENE_DEBUG_LOOP") != nullptr;
+	{ Phase ph(PH_EXACT); if (!exact_quiet(ext, n_sorts)) { if (dbg) std::fprintf(stderr, "[branch_loop] not quiet: the hit at array index 0 of some genome changes within the next %d sorts\n", n_sorts); return 0; } }
 	const int32_t S = q->n_seg, n = opt->n_branch_flt;
 	std::vector<int32_t> m_tot((size_t)R), m_deg((size_t)R), m_loci((size_t)R);
 	for (int32_t i = 0; i < R; ++i) { // graph.c:303-306
@@ -914,6 +915,7 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	alive.assign((size_t)S + 1, 1);
 	int rc;
 	{ Phase ph(PH_NLOCAL); rc = be->branch_loop(ext->ctx, R, &par, m_tot.data(), m_deg.data(), m_loci.data(), alive.data()); }
+	if (dbg) std::fprintf(stderr, "[branch_loop] %d rounds queued: backend status %d\n", R, rc);
 	if (rc == 2) return 0;
 	if (rc == 1) { ext->no_branch_loop = true; return RC_REDO; }
 	if (rc != 0) { set_error(rc, "branch_loop"); return rc; }

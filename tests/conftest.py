@@ -13,6 +13,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_first():
+    """On a GPU box torch's HIP runtime is brought up before the product library's first HIP call (the order bench.py and the
+    sharded launcher use): a `-k` selection that reaches a torch test only after the library has run otherwise finds torch
+    without a device ("No HIP GPUs are available"), whatever the library did before."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    return True
+
+
 @pytest.fixture(scope="session")
 def built():
     """Everything compiled (product for gfx950, oracle, CPU checker binary)."""
