@@ -446,6 +446,32 @@ def many_doms(seed: int = 1, G: int = 24, n_x: int = 6) -> Iterator[Tuple[str, s
         yield ("m%02d.paf" % j, "".join(lines))
 
 
+def mutate(gen: Iterator[Tuple[str, str]], seed: int, p_score: float = 0.06, p_dup: float = 0.03, p_flip: float = 0.03, p_tag: float = 0.03,
+           p_drop: float = 0.02, p_shuffle: float = 0.3) -> Iterator[Tuple[str, str]]:
+    """Inputs the generators above never produce but the format allows: non-positive `ms:i:` scores (graph.c:133 running maxima
+    start at 0; a negative score_adj takes the 64-bit score-key route), exact duplicates of an alignment, flipped strands, `fs:i:` /
+    `st:i:` tags (read.c:217-220), missing lines, and -- in about a third of the files -- lines that are not grouped by protein."""
+    for j, (name, text) in enumerate(gen):
+        r = _rng(seed, 5000 + j)
+        out = []
+        for line in text.splitlines():
+            if r.random() < p_drop:
+                continue
+            f = line.split("\t")
+            if r.random() < p_score:
+                f = [("ms:i:%d" % int(r.choice([0, 1, -5, -100]))) if x.startswith("ms:i:") else x for x in f]
+            if r.random() < p_flip:
+                f[4] = "-" if f[4] == "+" else "+"
+            if r.random() < p_tag:
+                f.insert(12, "fs:i:%d" % int(r.integers(1, 3)) if r.random() < 0.5 else "st:i:1")
+            out.append("\t".join(f))
+            if r.random() < p_dup:
+                out.append(out[-1])
+        if r.random() < p_shuffle:
+            out = [out[i] for i in r.permutation(len(out))]
+        yield (name, "".join(x + "\n" for x in out))
+
+
 def write_files(gen: Iterator[Tuple[str, str]], out_dir: str, gz: bool = False) -> List[str]:
     os.makedirs(out_dir, exist_ok=True)
     paths = []

@@ -35,6 +35,11 @@ for s in range(6):
 SETS["fuzz7115"] = lambda: synth.fuzz(7115, harsh=False)
 SETS["fuzz7115h"] = lambda: synth.fuzz(7115, harsh=True)
 SETS["fuzz7126"] = lambda: synth.fuzz(7126, harsh=False)
+# what the generators never emit on their own: non-positive scores, duplicated alignments, strand flips, fs / st
+# tags, dropped lines, lines not grouped by protein
+SETS["mut0"] = lambda: synth.mutate(synth.fuzz(100, harsh=False), 1)
+SETS["mut1"] = lambda: synth.mutate(synth.bact(12, 200, seed=5), 2)
+SETS["mut2"] = lambda: synth.mutate(synth.human(6, 150, iso=2.0, seed=3, n_chr=3, frag=True), 3)
 
 
 def files_of(name):

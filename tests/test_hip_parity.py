@@ -109,7 +109,8 @@ def _run_with_env(tmp_path, env, mode, variant, files):
 
 
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
-@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1"}])
+@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1"},
+                                 {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1"}])
 def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
     (the path of rounds in which a hub gene overflows the per-gene LDS table).  Forcing the sort path, and shrinking the table to 4
@@ -117,7 +118,11 @@ def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     three records (manydoms then needs the second, grown attempt of pga_vtx_partials) and the 64-bit comparison keys ranked by a sort
     (the path of shards whose score, preferred bit and protein rank do not fit 32 bits), and the general scan for the pair offsets
     (the path of graphs with more than 65536 oriented vertices).  The second setting also keeps pg_flt_high_occ's tests on the host
-    (the general route of a branch round: sharded runs, log lines, rounds repeated on the sort path)."""
+    (the general route of a branch round: sharded runs, log lines, rounds repeated on the sort path) -- and with a four-entry table
+    the queued branch rounds (pga_branch_loop, the default) give up on their sticky flag, so the run is repeated with host-driven
+    rounds (RC_REDO).  Fourth setting: host-driven rounds from the start (one wait per round, verdicts of pg_flt_high_occ fetched as
+    bytes: the default of round 2) and stage A's orders by the multi-workgroup radix sort instead of k_genome_sort (the path of
+    genomes with more than 25 600 hits)."""
     out = _run_with_env(tmp_path, env, 2, variant, golden_files(name))
     assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
 
@@ -274,6 +279,22 @@ def test_empty_and_degenerate_inputs(hip, ora, tmp_path):
     files = [str(p / x) for x in ("a.paf", "b.paf", "c.paf")]
     for args in ([], ["-p0"], ["--bed=raw"]):
         assert capi.run(hip, files, args) == capi.run(ora, files, args)
+
+
+def test_fresh_seed_fuzz_hip_vs_oracle(hip, ora, tmp_path):
+    """HIP == oracle on seeds no fixture holds (tests/fuzz_hip_vs_oracle.py, a bounded slice: ~300 comparisons): fuzz, bacterial
+    and mutated shapes (non-positive scores, duplicated alignments, strand flips, ungrouped lines) x 7 option variants x both
+    tie-order modes.  The seed base follows the calendar hour, so every run of the suite covers other inputs; PG_FUZZ_SEED pins it
+    (the base is in the assertion message: a failure can be replayed)."""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fuzz_hip_vs_oracle as fz
+    first = int(os.environ.get("PG_FUZZ_SEED", 20000 + (int(time.time()) // 3600) % 50000 * 7))
+    variants = [[], ["-p0", "-a1"], ["-S"], ["-F"], ["-b", "0.2", "-B", "0.1", "-y", "0.3"], ["-D", "300", "-C", "2"], ["-S", "-D", "600", "-C", "3"]]
+    msgs = []
+    tot, bad = fz.sweep(hip, ora, first, 7, str(tmp_path), variants=variants, human=False, log=msgs.append)
+    assert tot >= 280
+    assert not bad, "first seed %d: %s" % (first, "; ".join(bad[:5]))
 
 
 def test_exchange_aliases_device_memory():
