@@ -14,7 +14,11 @@
  *                                            deferred to pg_post_process and run on the GPU -- exact,
  *                                            SURVEY.md 9.5; nothing can observe the difference because
  *                                            main.c calls pg_post_process next)
- *   pg_post_process        graph.c:7-32     (+ the deferred read.c:243-260) -> HIP kernels
+ *   pg_post_process        graph.c:7-32     (+ the deferred read.c:243-260) -> HIP kernels.  The hits are taken as pg_read_paf
+ *                                            left them (each genome is packed for the device while the next file is parsed);
+ *                                            a genome edited in between is packed again when its hit / exon count changed or a
+ *                                            sample of its records (every 257th, the first, the last) did -- other in-place
+ *                                            edits of g->hit between the two calls are not seen
  *   pg_graph_init/gen/destroy graph.c:34-47, 280-322 -> HIP kernels + host round driver
  *   pg_write_bed/graph/walk format.c:113-225
  *   pg_read_list_dict, pg_dict_destroy  read.c:305-318, dict.c:38-49 (main.c:73-75,140-142 need them)
@@ -238,9 +242,13 @@ int pg_rerun_resident(pg_data_t *d);
 
 /* HIP-event timing of kernel classes of the runs since the last pg_kernel_timing_reset (which also switches the
  * timing on): which 0 = stage-A sweep pg_shadow(cal_dom_sc=1) ("K1", the hit-filter+overlap kernel), 1 = pg_flt_ov_isoform
- * sweep, 2 = the other pg_shadow sweeps, 3 = all of stage A (sorts, per-hit constants, pg_flag_pseudo, sweeps, filters). */
+ * sweep, 2 = (not timed any more: the stage-C sweeps), 3 = all of stage A (sorts, per-hit constants, pg_flag_pseudo, sweeps, filters). */
 int pg_kernel_timing(pg_data_t *d, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
 int pg_kernel_timing_reset(pg_data_t *d);
+
+/* Page-locked host memory: the library keeps the pinned slabs of an upload for the next one (up to 4 GiB while a data set is
+ * alive; 256 MiB after the last pg_data_destroy).  A long-lived host calls this to give back what exceeds keep_bytes (0 = all). */
+void pg_trim_host_cache(size_t keep_bytes);
 
 /* wall seconds the host driver spent per phase of the last run (names via pg_phase_name) */
 int pg_phase_times(double *out, int n);

@@ -209,6 +209,15 @@ extern "C" int pga_host_alloc(size_t nbytes, void **ptr)
 }
 extern "C" void pga_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
 
+extern "C" void pga_host_trim(size_t keep_bytes)
+{
+	std::lock_guard<std::mutex> lk(g_pin_mu);
+	size_t kept = 0, n_keep = 0;
+	for (; n_keep < g_pin_cache.size() && kept + g_pin_cache[n_keep].cap <= keep_bytes; ++n_keep) kept += g_pin_cache[n_keep].cap;
+	for (size_t i = n_keep; i < g_pin_cache.size(); ++i) (void)hipHostFree(g_pin_cache[i].p);
+	g_pin_cache.resize(n_keep);
+}
+
 extern "C" const char *pga_strerror(int code)
 {
 	switch (code) {
@@ -1636,7 +1645,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim
 	};
 	return &b;
 }

@@ -118,6 +118,7 @@ static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int6
 // to hand the blocks to the backend: the upload is then plain DMA out of pinned memory.
 // ---------------------------------------------------------------------------------------------
 static void *block_alloc(DataExt *ext, size_t bytes);
+static uint64_t genome_signature(const pg_genome_t *g);
 
 static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 {
@@ -150,17 +151,39 @@ static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 	b.n_hit = (int32_t)n, b.n_exon = (int32_t)ne, b.n_ctg = g->n_ctg;
 	b.max_cs = max_cs, b.max_cm = max_cm, b.max_score_adj = max_sadj, b.any_neg_score_adj = neg, b.any_multi_exon = multi;
 	b.data = w, b.n_words = nw;
+	pk.sig = sorted ? 0 : genome_signature(g);
 }
 
-void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1)
+// A pack made when the genome was read is only good while the genome still is what it was then.  The public pg_data_t may be
+// edited between pg_read_paf and pg_post_process (the reference reads g->hit at post-process time): a changed hit or exon count,
+// or a change in a sample of the records, makes the block stale and it is packed again.  (Edits that keep the counts and miss
+// the sample -- every 257th record, the first and the last -- are not seen: see include/pangene_amd.h, pg_post_process.)
+static uint64_t genome_signature(const pg_genome_t *g)
+{
+	uint64_t h = 1469598103934665603ull ^ (uint64_t)(uint32_t)g->n_hit ^ (uint64_t)(uint32_t)g->n_exon << 32;
+	auto mix = [&h](const pg_hit_t &a) {
+		const uint64_t w[4] = { (uint64_t)(uint32_t)a.pid << 32 | (uint32_t)a.cid, (uint64_t)a.cs, (uint64_t)a.ce ^ (uint64_t)a.cm << 1, (uint64_t)(uint32_t)a.score_adj << 32 | (uint32_t)a.n_exon << 1 | (uint32_t)a.rev };
+		for (uint64_t x : w) h = (h ^ x) * 1099511628211ull;
+	};
+	for (int32_t i = 0; i < g->n_hit; i += 257) mix(g->hit[i]);
+	if (g->n_hit > 0) mix(g->hit[g->n_hit - 1]);
+	return h;
+}
+
+void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, double time_share)
 {
 	const double t0 = now_sec();
-	ext->packs.resize((size_t)d->n_genome);
+	if (ext->packs.size() < (size_t)d->n_genome) ext->packs.resize((size_t)d->n_genome); // (batch reads reserve the entries before their threads start)
 	std::vector<int32_t> todo;
 	int64_t hits = 0;
-	for (int32_t j = j0; j < j1; ++j)
-		if (ext->packs[(size_t)j].buf == nullptr && ((size_t)j >= ext->is_local.size() || ext->is_local[(size_t)j])) todo.push_back(j), hits += d->genome[j].n_hit;
-	unsigned nt = hits > 100000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+	for (int32_t j = j0; j < j1; ++j) {
+		if ((size_t)j < ext->is_local.size() && !ext->is_local[(size_t)j]) continue;
+		GenomePack &pk = ext->packs[(size_t)j];
+		const bool sorted = (size_t)j < ext->hits_sorted.size() && ext->hits_sorted[(size_t)j]; // (records moved into cs order by a sync_host: the signature was taken in file order)
+		if (pk.buf != nullptr && (pk.blk.n_hit != d->genome[j].n_hit || pk.blk.n_exon != d->genome[j].n_exon || (!sorted && pk.sig != genome_signature(&d->genome[j])))) pk = GenomePack(); // stale: the slab keeps the old bytes until the upload is over
+		if (pk.buf == nullptr) todo.push_back(j), hits += d->genome[j].n_hit;
+	}
+	unsigned nt = hits > 100000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u) : 1u;
 	if (nt > todo.size()) nt = (unsigned)todo.size();
 	if (nt <= 1) { for (int32_t j : todo) pack_one(d, ext, j); }
 	else {
@@ -170,7 +193,8 @@ void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1)
 			th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= todo.size()) break; pack_one(d, ext, todo[i]); } });
 		for (auto &x : th) x.join();
 	}
-	ext->pack_sec += now_sec() - t0;
+	std::lock_guard<std::mutex> lk(ext->slab_mu);
+	ext->pack_sec += (now_sec() - t0) * time_share;
 }
 
 // Pinned host memory is expensive to get and to give back (every hipHostMalloc / hipHostFree maps or unmaps pages and takes the
@@ -179,7 +203,9 @@ void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1)
 static std::mutex g_slab_mu;
 static std::vector<HostSlab> g_slab_cache;
 static size_t g_slab_cached = 0;
-static const size_t SLAB_BYTES = (size_t)32 << 20, SLAB_CACHE_MAX = (size_t)4 << 30;
+static const size_t SLAB_BYTES = (size_t)32 << 20;
+static const size_t SLAB_CACHE_MAX = (size_t)4 << 30;   // while a data set is alive (its upload and its downloads reuse the slabs)
+static const size_t SLAB_CACHE_IDLE = (size_t)256 << 20; // what a process keeps page-locked when no data set is left (pg_trim_host_cache(0) releases that too)
 
 static HostSlab slab_get(size_t min_bytes)
 {
@@ -224,6 +250,24 @@ static void slab_put(HostSlab &s) // back into the process-wide cache (or to the
 	s.p = nullptr;
 }
 
+// release cached pinned memory beyond `keep` bytes (largest slabs first stay: they are the ones the next upload asks for)
+void trim_host_caches(size_t keep)
+{
+	const pga_backend_t *be = backend_default();
+	{
+		std::lock_guard<std::mutex> lk(g_slab_mu);
+		std::sort(g_slab_cache.begin(), g_slab_cache.end(), [](const HostSlab &a, const HostSlab &b) { return a.cap > b.cap; });
+		size_t kept = 0, n_keep = 0;
+		for (; n_keep < g_slab_cache.size() && kept + g_slab_cache[n_keep].cap <= keep; ++n_keep) kept += g_slab_cache[n_keep].cap;
+		for (size_t i = n_keep; i < g_slab_cache.size(); ++i) {
+			if (g_slab_cache[i].pinned) be->host_free(g_slab_cache[i].p); else std::free(g_slab_cache[i].p);
+		}
+		g_slab_cache.resize(n_keep);
+		g_slab_cached = kept;
+	}
+	if (be->host_trim) be->host_trim(keep / 4);
+}
+
 void free_packs(DataExt *ext, bool wait)
 {
 	(void)wait;
@@ -256,7 +300,7 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	std::vector<pga_genome_block_t> blk((size_t)nl);
 	for (int32_t k = 0; k < nl; ++k) {
 		const GenomePack &pk = ext->packs[(size_t)ext->local_genomes[(size_t)k]];
-		if (pk.err) return pk.err;
+		if (pk.err) { const int e = pk.err; free_packs(ext, false); return e; }
 		blk[(size_t)k] = pk.blk;
 		N += pk.blk.n_hit, E += pk.blk.n_exon;
 		ext->hit_off[(size_t)k + 1] = N;
@@ -1189,6 +1233,8 @@ const char *pg_last_error_str(void) { return g_errstr; }
 double pg_last_path_seconds(void) { return g_path_sec; }
 double pg_last_upload_seconds(void) { return g_upload_sec; }
 double pg_last_pack_seconds(void) { return g_pack_sec; }
+
+void pg_trim_host_cache(size_t keep_bytes) { trim_host_caches(keep_bytes); } // page-locked memory the library keeps for its next upload
 
 int pg_shard_counts(const pg_data_t *d, int64_t *n_hit, int64_t *n_exon)
 {

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include "pg_internal.hpp"
 
@@ -40,6 +41,7 @@ void ext_drop(const pg_data_t *d)
 	free_packs(e, true);
 	delete e;
 	g_ext.erase(it);
+	if (g_ext.empty()) trim_host_caches((size_t)256 << 20); // no data set left: most of the page-locked memory goes back
 }
 
 // gz-or-plain line source (zlib reads plain files transparently, as the reference's gzopen does)
@@ -177,9 +179,19 @@ struct FileParse {
 	std::vector<uint8_t> g_pref, g_incl;      // per local gene (read.c:147-150,158-159)
 	std::vector<int32_t> g_len, p_gene, p_len; // gene.len = max protein len (read.c:177); prot.gid, prot.len of the last line
 	std::vector<int64_t> ctg_len;
-	std::vector<pg_hit_t> hits;               // pid / cid are LOCAL ids
-	std::vector<pg_exon_t> exons;
+	// pid / cid are LOCAL ids.  Plain malloc'ed arrays: they become the genome's own g->hit / g->exon (freed by pg_data_destroy)
+	pg_hit_t *hits = nullptr; int32_t n_hit = 0, m_hit = 0;
+	pg_exon_t *exons = nullptr; int32_t n_exon = 0, m_exon = 0;
+	std::vector<int32_t> gmap, pmap;          // local -> global ids, -1 = not known yet (resolved at commit time)
+	int32_t genome = -1;                      // index of the genome the commit appended
+	~FileParse() { std::free(hits); std::free(exons); std::free(label); }
 };
+
+template <class T> static inline void push_raw(T *&a, int32_t &n, int32_t &m, const T &v)
+{
+	if (n == m) { m = m ? m + (m >> 1) : 4096; a = (T *)std::realloc((void *)a, sizeof(T) * (size_t)m); }
+	a[n++] = v;
+}
 
 static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileParse &fp)
 {
@@ -259,8 +271,8 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 				else if (std::strncmp(q, "st:i:", 5) == 0) n_stop = (int32_t)std::strtol(q + 5, nullptr, 10);
 				else if (std::strncmp(q, "cg:Z:", 5) == 0) {
 					if (cigar_to_exons(q + 5, hit.rev, hit.ce - hit.cs, ex, &cig_fs)) {
-						hit.n_exon = (int32_t)ex.size(), hit.off_exon = (int32_t)fp.exons.size(), hit.lof = cig_fs;
-						fp.exons.insert(fp.exons.end(), ex.begin(), ex.end());
+						hit.n_exon = (int32_t)ex.size(), hit.off_exon = fp.n_exon, hit.lof = cig_fs;
+						for (const pg_exon_t &e : ex) push_raw(fp.exons, fp.n_exon, fp.m_exon, e);
 						have_exons = true;
 					} else if (pg_verbose >= 1) {
 						std::fprintf(stderr, "[W::%s] CIGAR of line %d in '%s' does not span the alignment; hit dropped\n", __func__, fp.n_tot, fn ? fn : "-");
@@ -273,44 +285,66 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 		if (dropped || !have_exons || hit.n_exon < 1) continue;
 		int32_t lof = (n_fs > 0 ? n_fs : 0) + (n_stop > 0 ? n_stop : 0); // read.c:230-231
 		if (hit.lof < lof) hit.lof = lof;
-		hit.cm = middle_cds(hit.cs, fp.exons.data() + hit.off_exon, hit.n_exon);
+		hit.cm = middle_cds(hit.cs, fp.exons + hit.off_exon, hit.n_exon);
 		if (hit.cm < 0) continue;
-		fp.hits.push_back(hit);
+		push_raw(fp.hits, fp.n_hit, fp.m_hit, hit);
 	}
 }
 
-// sequential part: global ids in first-seen order, genome appended to `d`
-static int32_t commit_file(pg_data_t *d, FileParse &fp)
+// Names that are in the global dictionaries already get their ids before the commit (read-only look-ups, any thread, under
+// the reader side of g_dict_mu): a pangenome's files share nearly all their names, so the sequential part of a batch read
+// shrinks from "every name of every file" to the names a file is the first to bring.
+static std::shared_mutex g_dict_mu;
+static void preresolve(const pg_data_t *d, FileParse &fp)
+{
+	const NameDict *dg = (const NameDict *)d->d_gene, *dp = (const NameDict *)d->d_prot;
+	fp.gmap.assign((size_t)fp.genes.size(), -1), fp.pmap.assign((size_t)fp.prots.size(), -1);
+	std::shared_lock<std::shared_mutex> lk(g_dict_mu);
+	for (int32_t i = 0; i < fp.genes.size(); ++i) fp.gmap[(size_t)i] = dg->get(fp.genes.name(i));
+	for (int32_t i = 0; i < fp.prots.size(); ++i) fp.pmap[(size_t)i] = dp->get(fp.prots.name(i));
+}
+
+// sequential part: global ids in first-seen order (the numbering of per-line dict_put calls, read.c:151-168), genome appended to `d`
+static int32_t commit_ids(pg_data_t *d, FileParse &fp)
 {
 	if (!fp.opened) return -1;
 	NameDict *dg = (NameDict *)d->d_gene, *dp = (NameDict *)d->d_prot, *dc = (NameDict *)d->d_ctg;
 	DataExt *ext = ext_of(d, true);
+	std::unique_lock<std::shared_mutex> lk(g_dict_mu);
 	grow0(d->genome, d->n_genome, d->m_genome);
+	fp.genome = d->n_genome;
 	pg_genome_t *g = &d->genome[d->n_genome++];
 	std::memset(g, 0, sizeof(*g));
 	g->label = fp.label, fp.label = nullptr;
-	ext->is_local.resize((size_t)d->n_genome, 0);
-	ext->hits_sorted.resize((size_t)d->n_genome, 0);
+	if (ext->is_local.size() < (size_t)d->n_genome) ext->is_local.resize((size_t)d->n_genome, 0);
+	if (ext->hits_sorted.size() < (size_t)d->n_genome) ext->hits_sorted.resize((size_t)d->n_genome, 0);
 	ext->is_local[(size_t)d->n_genome - 1] = fp.ids_only ? 0 : 1;
-	// genes then proteins, each in the order this file saw them first: the same numbering as per-line dict_put calls
-	std::vector<int32_t> gmap((size_t)fp.genes.size()), pmap((size_t)fp.prots.size());
+	if (fp.gmap.size() != (size_t)fp.genes.size()) fp.gmap.assign((size_t)fp.genes.size(), -1);
+	if (fp.pmap.size() != (size_t)fp.prots.size()) fp.pmap.assign((size_t)fp.prots.size(), -1);
+	// genes then proteins, each in the order this file saw them first
 	for (int32_t i = 0; i < fp.genes.size(); ++i) {
-		bool absent;
-		const int32_t gid = dg->put(fp.genes.name(i), &absent);
-		if (absent) { d->n_gene++; grow0(d->gene, gid, d->m_gene); }
-		d->gene[gid].name = dg->name(gid);
+		int32_t gid = fp.gmap[(size_t)i];
+		if (gid < 0) {
+			bool absent;
+			gid = dg->put(fp.genes.name(i), &absent);
+			if (absent) { d->n_gene++; grow0(d->gene, gid, d->m_gene); }
+			d->gene[gid].name = dg->name(gid);
+			fp.gmap[(size_t)i] = gid;
+		}
 		d->gene[gid].preferred = fp.g_pref[(size_t)i], d->gene[gid].included = fp.g_incl[(size_t)i];
 		if ((int32_t)d->gene[gid].len < fp.g_len[(size_t)i]) d->gene[gid].len = (uint32_t)fp.g_len[(size_t)i];
-		gmap[(size_t)i] = gid;
 	}
 	for (int32_t i = 0; i < fp.prots.size(); ++i) {
-		bool absent;
-		const int32_t pid = dp->put(fp.prots.name(i), &absent);
-		if (absent) { d->n_prot++; grow0(d->prot, pid, d->m_prot); }
-		d->prot[pid].name = dp->name(pid);
-		d->prot[pid].gid = gmap[(size_t)fp.p_gene[(size_t)i]];
+		int32_t pid = fp.pmap[(size_t)i];
+		if (pid < 0) {
+			bool absent;
+			pid = dp->put(fp.prots.name(i), &absent);
+			if (absent) { d->n_prot++; grow0(d->prot, pid, d->m_prot); }
+			d->prot[pid].name = dp->name(pid);
+			fp.pmap[(size_t)i] = pid;
+		}
+		d->prot[pid].gid = fp.gmap[(size_t)fp.p_gene[(size_t)i]];
 		d->prot[pid].len = fp.p_len[(size_t)i];
-		pmap[(size_t)i] = pid;
 	}
 	if (!fp.ids_only) {
 		g->n_ctg = g->m_ctg = fp.ctgs.size();
@@ -320,25 +354,33 @@ static int32_t commit_file(pg_data_t *d, FileParse &fp)
 			g->ctg[c].name = dc->name(dc->put(fp.ctgs.name(c), &a2));
 			g->ctg[c].len = fp.ctg_len[(size_t)c];
 		}
-		g->n_hit = g->m_hit = (int32_t)fp.hits.size();
-		g->hit = (pg_hit_t *)std::malloc(sizeof(pg_hit_t) * (size_t)(g->n_hit > 0 ? g->n_hit : 1));
-		for (int32_t i = 0; i < g->n_hit; ++i) { g->hit[i] = fp.hits[(size_t)i]; g->hit[i].pid = pmap[(size_t)fp.hits[(size_t)i].pid]; }
-		g->n_exon = g->m_exon = (int32_t)fp.exons.size();
-		g->exon = (pg_exon_t *)std::malloc(sizeof(pg_exon_t) * (size_t)(g->n_exon > 0 ? g->n_exon : 1));
-		if (g->n_exon) std::memcpy(g->exon, fp.exons.data(), sizeof(pg_exon_t) * (size_t)g->n_exon);
 	}
 	if (pg_verbose >= 3)
 		std::fprintf(stderr, "[M::%s::%s] [%d] %s: %d lines parsed, %d hits kept%s\n", "pg_read_paf", stamp(), d->n_genome - 1,
-		             g->label ? g->label : "-", fp.n_tot, g->n_hit, fp.ids_only ? " (ids only; hits owned by another shard)" : "");
+		             g->label ? g->label : "-", fp.n_tot, fp.ids_only ? 0 : fp.n_hit, fp.ids_only ? " (ids only; hits owned by another shard)" : "");
 	return 0;
+}
+
+// per-genome part, any thread (the genome's slot in d->genome exists and does not move: batch reads reserve the array first): the
+// parsed arrays become the genome's own, the local protein ids are replaced by the global ones in place
+static void finalize_genome(pg_data_t *d, FileParse &fp)
+{
+	if (!fp.opened || fp.ids_only || fp.genome < 0) return;
+	pg_genome_t *g = &d->genome[fp.genome];
+	for (int32_t i = 0; i < fp.n_hit; ++i) fp.hits[i].pid = fp.pmap[(size_t)fp.hits[i].pid];
+	g->n_hit = fp.n_hit, g->m_hit = fp.m_hit > 0 ? fp.m_hit : 1;
+	g->hit = fp.hits ? fp.hits : (pg_hit_t *)std::malloc(sizeof(pg_hit_t));
+	g->n_exon = fp.n_exon, g->m_exon = fp.m_exon > 0 ? fp.m_exon : 1;
+	g->exon = fp.exons ? fp.exons : (pg_exon_t *)std::malloc(sizeof(pg_exon_t));
+	fp.hits = nullptr, fp.exons = nullptr, fp.n_hit = fp.m_hit = fp.n_exon = fp.m_exon = 0;
 }
 
 static int32_t read_paf_impl(const pg_opt_t *opt, pg_data_t *d, const char *fn, bool ids_only)
 {
 	FileParse fp;
 	parse_file(opt, fn, ids_only, fp);
-	int32_t rc = commit_file(d, fp);
-	std::free(fp.label);
+	int32_t rc = commit_ids(d, fp);
+	if (rc == 0) finalize_genome(d, fp);
 	if (rc == 0 && !ids_only) pack_genomes(d, ext_of(d, true), d->n_genome - 1, d->n_genome); // SoA block for the backend, while the next file is read
 	return rc;
 }
@@ -374,24 +416,85 @@ int32_t pg_scan_paf_ids(const pg_opt_t *opt, pg_data_t *d, const char *fn) { ret
 
 // parse many PAFs on host threads, commit them in command-line order (ids identical to n sequential
 // pg_read_paf / pg_scan_paf_ids calls).  ids_only[i] != 0: register names only (the hits belong to another shard).
+// A pipeline, not three barriers: every thread parses files (and looks the names it can up in the global dictionaries); whoever
+// finds the next file of the command line parsed commits its ids (sequential, but short: only new names are inserted); a
+// committed file's hits are then finished -- global protein ids, the SoA block in pinned memory for the backend -- by any
+// thread.  Memory holds the files that are parsed but not finished yet, not the whole batch twice.
 int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const char *const *fns, const uint8_t *ids_only, int32_t n_threads)
 {
 	if (n <= 0) return 0;
-	if (n_threads <= 0) n_threads = (int32_t)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+	if (n_threads <= 0) {
+		const char *e = std::getenv("PANGENE_READ_THREADS");
+		n_threads = e && std::atoi(e) > 0 ? std::atoi(e) : (int32_t)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 128u);
+	}
 	if (n_threads > n) n_threads = n;
+	DataExt *ext = ext_of(d, true);
+	const int32_t j0 = d->n_genome;
+	{ // the arrays the per-genome part indexes must not move while it runs
+		std::unique_lock<std::shared_mutex> lk(g_dict_mu);
+		if (d->m_genome < j0 + n) {
+			const int32_t old = d->m_genome;
+			d->m_genome = j0 + n + 16;
+			d->genome = (pg_genome_t *)std::realloc((void *)d->genome, sizeof(pg_genome_t) * (size_t)d->m_genome);
+			std::memset((void *)(d->genome + old), 0, sizeof(pg_genome_t) * (size_t)(d->m_genome - old));
+		}
+		ext->is_local.resize((size_t)(j0 + n), 0), ext->hits_sorted.resize((size_t)(j0 + n), 0);
+		ext->packs.resize((size_t)(j0 + n));
+	}
 	std::vector<FileParse> fp((size_t)n);
-	std::atomic<int32_t> next{0};
-	auto work = [&]() { for (;;) { int32_t i = next.fetch_add(1); if (i >= n) break; parse_file(opt, fns[i], ids_only && ids_only[i], fp[(size_t)i]); } };
+	std::vector<std::atomic<uint8_t>> state((size_t)n); // 0 new, 1 parsed, 2 committed (ids final), 3 being / has been finished
+	for (auto &x : state) x.store(0);
+	std::atomic<int32_t> next_parse{0}, n_commit{0}, next_final{0}, n_fail{0};
+	std::mutex commit_mu;
+	auto try_commit = [&]() {
+		std::unique_lock<std::mutex> lk(commit_mu, std::try_to_lock);
+		if (!lk.owns_lock()) return; // somebody else is at it (and will see what this thread just parsed: it re-checks before it leaves)
+		for (;;) {
+			const int32_t k = n_commit.load();
+			if (k >= n || state[(size_t)k].load() != 1) break;
+			if (commit_ids(d, fp[(size_t)k]) != 0) n_fail.fetch_add(1);
+			state[(size_t)k].store(2);
+			n_commit.store(k + 1);
+		}
+	};
+	auto try_final = [&]() -> bool { // finish one committed file, if there is one
+		for (;;) {
+			int32_t k = next_final.load();
+			if (k >= n || state[(size_t)k].load() < 2) return false;
+			if (!next_final.compare_exchange_weak(k, k + 1)) continue;
+			FileParse &f = fp[(size_t)k];
+			finalize_genome(d, f);
+			if (f.opened && !f.ids_only && f.genome >= 0) pack_genomes(d, ext, f.genome, f.genome + 1, 1.0 / n_threads); // (one genome: on this thread)
+			{ FileParse done; std::swap(done.genes, f.genes), std::swap(done.prots, f.prots), std::swap(done.ctgs, f.ctgs); } // the names are not needed any more
+			state[(size_t)k].store(3);
+			return true;
+		}
+	};
+	auto work = [&]() {
+		for (;;) {
+			const int32_t i = next_parse.fetch_add(1);
+			if (i < n) {
+				parse_file(opt, fns[i], ids_only && ids_only[i], fp[(size_t)i]);
+				if (fp[(size_t)i].opened) preresolve(d, fp[(size_t)i]);
+				state[(size_t)i].store(1);
+				try_commit();
+				// (a commit that was skipped because another thread held the lock: that thread may have left just before this
+				// file's state changed -- look again once)
+				if (n_commit.load() < n && state[(size_t)n_commit.load()].load() == 1) try_commit();
+				while (try_final()) { }
+				continue;
+			}
+			if (next_final.load() >= n) break;
+			try_commit();
+			if (!try_final()) std::this_thread::yield();
+		}
+	};
 	std::vector<std::thread> th;
 	for (int32_t t = 1; t < n_threads; ++t) th.emplace_back(work);
 	work();
 	for (auto &x : th) x.join();
-	int32_t n_fail = 0;
-	const int32_t j0 = d->n_genome;
-	for (int32_t i = 0; i < n; ++i) { if (commit_file(d, fp[(size_t)i]) != 0) ++n_fail; std::free(fp[(size_t)i].label); }
-	pack_genomes(d, ext_of(d, true), j0, d->n_genome); // global ids are final now: SoA blocks for the backend, on host threads
-	exact_prefetch(d, ext_of(d, true));                // and the replay of the reference's tie order starts in the background
-	return -n_fail;
+	exact_prefetch(d, ext); // the replay of the reference's tie order starts in the background
+	return -n_fail.load();
 }
 
 // "-X a,b,c" or "-X @file" (first token of each line) -> name set (read.c:265-318)

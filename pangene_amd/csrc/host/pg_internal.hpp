@@ -58,6 +58,7 @@ struct GenomePack {
 	pga_genome_block_t blk{};
 	void *buf = nullptr;
 	int err = 0;                              // PGA_ERR_RANGE: a coordinate does not fit the device layout
+	uint64_t sig = 0;                         // what the genome looked like when it was packed (graph_driver.cpp: genome_signature)
 };
 struct HostSlab { char *p = nullptr; size_t cap = 0, off = 0; bool pinned = false; };
 
@@ -104,7 +105,8 @@ struct DataExt {
 
 DataExt *ext_of(const pg_data_t *d, bool create);
 // pack the genomes [j0, j1) that have no pack yet (host threads); called by the reader after the commit and by the driver as a fallback
-void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1);
+void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, double time_share = 1.0); // time_share: fraction of the call's wall time booked as packing time (calls that run side by side on n threads: 1 / n)
+void trim_host_caches(size_t keep_bytes);
 void free_packs(DataExt *ext, bool wait);
 void ext_drop(const pg_data_t *d);
 
