@@ -11,15 +11,22 @@ embarrassingly, ids are global, every round exchanges a few small integer vector
 configs[2] stand-in (47 human-shaped haplotypes x 20 k multi-exon genes; real HPRC PAFs are not available offline).
 
 A step = one full pass of the hot path over the shard that is already resident in HBM:
-pg_post_process (device sort, stage A filters + interval sweeps, stage B) + pg_graph_gen (vertex selection,
-17 arc rounds, 15 branch rounds) + the final per-hit state download.  `value` is that resident rate.
-`cold_pass` (upload included) is the one pass a `pangene *.paf` invocation makes on a data set the
+pg_post_process (stage A: both orders and the per-hit records per genome in LDS, filters + interval sweeps; stage B) +
+pg_graph_gen (vertex selection, 17 arc rounds, 15 branch rounds) + the final per-hit state download.  `value` is that
+resident rate.  `cold_pass` (upload included) is the one pass a `pangene *.paf` invocation makes on a data set the
 process has not seen: block packing (reader threads) + allocation + H2D + stages A+B+C; PAF text parsing and GFA
 printing are reported separately.  A tiny data set is run first so that kernel code objects are loaded.
 
-The roofline leg (N = 1 only) times K1 = the stage-A interval-dominance sweep on a shard that does not fit the 256 MiB
-Infinity Cache (default 1250 x 5 k = the per-GPU shard of configs[3], ~12 M hits; SURVEY 8d asks for >= 10 M hits), and all
-of stage A next to it.  Rank 0 prints ONE JSON line.
+Legs of the default run (N = 1 only; each brings its own data set and context, one context at a time):
+  roofline / big_shard  K1 = the stage-A interval-dominance sweep, and all of stage A, on a shard past the 256 MiB Infinity
+                        Cache (1250 x 5 k = the per-GPU shard of configs[3], ~12 M hits; SURVEY 8d asks for >= 10 M hits)
+  human_shard           the same on a human-shaped shard (multi-exon hits, fragmented contigs: the k_sweep<1, true> flavour)
+  exchange_overhead     the timed steps once more in a fresh process with every collective of the sharded route issued
+                        (world size 1, native RCCL on the kernels' stream): what the exchange plumbing costs by itself
+  cli                   `pangene_amd/bin/pangene files > /dev/null` in a fresh process (process start, HIP initialisation,
+                        code-object load, parsing, path, GFA text) next to the reference binary's wall time
+  cpu_baseline          the untouched reference binary on the same files, 1 core
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -40,32 +47,63 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def _pmc_traffic(hits_per_launch):
+def _sweep_src_sha():
+    with open(os.path.join(ROOT, "pangene_amd", "csrc", "hip", "k_sweep.hpp"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def _pmc_traffic(hits_per_launch, flavour):
     """HBM bytes per launch of K1 from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    runs of this very command, FETCH doubled as the gfx950 guide prescribes); null when the recorded passes are for another size."""
+    runs of this very command, FETCH doubled as the gfx950 guide prescribes).  An entry counts only for the shard size, the kernel
+    flavour and the very source of the sweep (sha256 of k_sweep.hpp) it was measured with; null otherwise."""
     try:
         with open(os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")) as f:
             t = json.load(f)
+        sha = _sweep_src_sha()
         for ent in (t if isinstance(t, list) else [t]):
-            if ent.get("hits_per_launch") == hits_per_launch:
+            if ent.get("hits_per_launch") == hits_per_launch and ent.get("flavour", "false") == flavour and ent.get("k_sweep_sha16") == sha:
                 return int(ent["bytes_per_launch"])
     except Exception:
         pass
     return None
 
 
-def _gen(synth, kind, base, lo, hi, G, proteins, seed):
-    """PAF files of genomes [lo, hi) of the seeded set (cached under the temp dir between runs on one box)"""
-    os.makedirs(base, exist_ok=True)
-    mine = [os.path.join(base, "g%05d.paf" % j) for j in range(lo, hi)]
-    if all(os.path.exists(p + ".done") for p in mine):
-        return
-    gen = synth.bact(G, proteins, seed=seed, first=lo, last=hi) if kind == "bact" else synth.human(G, proteins, iso=1.0, seed=seed, first=lo, last=hi, frag=True)
+def _gen_range(args):
+    kind, base, a, b, G, proteins, seed = args
+    from pangene_amd import synth
+    gen = synth.bact(G, proteins, seed=seed, first=a, last=b) if kind == "bact" else synth.human(G, proteins, iso=1.0, seed=seed, first=a, last=b, frag=True)
     for k, (name, text) in enumerate(gen):
-        p = mine[k]
+        p = os.path.join(base, "g%05d.paf" % (a + k))
         with open(p, "w") as f:
             f.write(text)
         open(p + ".done", "w").close()
+    return b - a
+
+
+def _gen(kind, base, lo, hi, G, proteins, seed):
+    """PAF files of genomes [lo, hi) of the seeded set (cached under the temp dir between runs on one box).  Every genome is
+    seeded on its own, so the files are written by a pool of processes -- forked BEFORE this process touches the GPU."""
+    os.makedirs(base, exist_ok=True)
+    todo = [j for j in range(lo, hi) if not os.path.exists(os.path.join(base, "g%05d.paf.done" % j))]
+    if not todo:
+        return
+    nproc = max(1, min(len(todo), min(os.cpu_count() or 1, 96)))
+    per = max(1, (len(todo) + 4 * nproc - 1) // (4 * nproc))
+    jobs = []
+    i = 0
+    while i < len(todo):  # runs of consecutive genomes
+        k = i
+        while k + 1 < len(todo) and todo[k + 1] == todo[k] + 1 and k + 1 - i < per:
+            k += 1
+        jobs.append((kind, base, todo[i], todo[k] + 1, G, proteins, seed))
+        i = k + 1
+    if nproc == 1:
+        for jb in jobs:
+            _gen_range(jb)
+        return
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(nproc) as pool:
+        list(pool.imap_unordered(_gen_range, jobs))
 
 
 def main():
@@ -80,14 +118,50 @@ def main():
     ap.add_argument("--proteins", type=int, default=0, help="default 5000 (bact) / 20000 genes (human47)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--exact", default="auto", choices=["auto", "all", "off"])
-    ap.add_argument("--roofline-genomes", type=int, default=1250, help="size of the past-L3 shard of the roofline leg (0 = use the main workload)")
+    ap.add_argument("--roofline-genomes", type=int, default=1250, help="size of the past-L3 bacterial shard of the roofline leg (0 = no such leg)")
+    ap.add_argument("--human-genomes", type=int, default=500, help="size of the human-shaped shard (x 20 k genes) of the human leg (0 = no such leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the exchange-overhead and command-line legs")
+    ap.add_argument("--leg", default="", help=argparse.SUPPRESS)  # internal: "steps-only" prints {"ms_per_step": ...} for the exchange-overhead leg
     a = ap.parse_args()
     kind = "bact" if a.workload == "bact" else "human"
     if a.proteins == 0:
         a.proteins = 5000 if kind == "bact" else 20000
     if a.genomes_per_gpu == 0:
         a.genomes_per_gpu = 100 if kind == "bact" else 47
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    force_x = os.environ.get("PANGENE_FORCE_EXCHANGE") == "1"
+    solo = rank == 0 and world == 1 and not force_x and a.leg == ""
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+
+    # ---- synthetic inputs first (not timed): a pool of forked processes writes them, before this process touches the GPU
+    if a.scaling == "strong":
+        G = a.genomes or a.genomes_per_gpu * 8
+        lo, hi = G * rank // world, G * (rank + 1) // world
+    else:
+        G = a.genomes_per_gpu * world
+        lo, hi = rank * a.genomes_per_gpu, (rank + 1) * a.genomes_per_gpu
+    tmp = tempfile.gettempdir()
+    base = os.path.join(tmp, "pangene_bench_%s%dx%d_s%d" % (kind[0], G, a.proteins, a.seed))
+    t0 = time.time()
+    _gen(kind, base, lo, hi, G, a.proteins, a.seed)
+    t_gen = time.time() - t0
+    files = [os.path.join(base, "g%05d.paf" % j) for j in range(G)]
+    legs = {}
+    if solo and kind == "bact" and a.roofline_genomes > 0:
+        b2 = os.path.join(tmp, "pangene_bench_b%dx%d_s%d" % (a.roofline_genomes, a.proteins, a.seed))
+        t0 = time.time()
+        _gen("bact", b2, 0, a.roofline_genomes, a.roofline_genomes, a.proteins, a.seed)
+        legs["big"] = (b2, a.roofline_genomes, time.time() - t0)
+    if solo and kind == "bact" and a.human_genomes > 0:
+        b3 = os.path.join(tmp, "pangene_bench_h%dx%d_s%d" % (a.human_genomes, 20000, a.seed))
+        t0 = time.time()
+        _gen("human", b3, 0, a.human_genomes, a.human_genomes, 20000, a.seed)
+        legs["human"] = (b3, a.human_genomes, time.time() - t0)
 
     # RCCL / HIP print banners on fd 1; the contract is ONE JSON line on stdout: park fd 1 on stderr until the end
     real_stdout = os.dup(1)
@@ -97,11 +171,6 @@ def main():
     import torch.distributed as dist
     from pangene_amd import capi, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # test hook: PANGENE_BENCH_ONE_GPU=1 lets several ranks share device 0 and exchange over gloo (RCCL refuses two ranks on
@@ -116,7 +185,6 @@ def main():
     lib.pg_set_exact_mode({"off": 0, "auto": 1, "all": 2}[a.exact])
     keep = None
     exchange_kind = "none (single process)"
-    force_x = os.environ.get("PANGENE_FORCE_EXCHANGE") == "1"
     if world > 1 or force_x:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
@@ -132,6 +200,7 @@ def main():
         if one_gpu or os.environ.get("PANGENE_EXCHANGE") == "torch" or not exchange.install_native(lib):
             keep = exchange.install(lib, device=dev)
             exchange_kind = "torch.distributed(nccl) callbacks"
+        dist.barrier()  # (every rank's files are written)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -151,12 +220,15 @@ def main():
             raise RuntimeError(lib.pg_last_error_str().decode())
         return g
 
-    def gfa_of(g):
+    def gfa_of(g, timing=None):
         out = tempfile.mktemp(prefix="pangene_bench_", suffix=".gfa")
+        t0 = time.time()
         lib.pg_set_output(out.encode())
         lib.pg_write_graph(g)
         lib.pg_write_walk(g)
         lib.pg_set_output(None)
+        if timing is not None:
+            timing.append(time.time() - t0)
         b = open(out, "rb").read()
         os.unlink(out)
         return b
@@ -177,21 +249,6 @@ def main():
         lib.pg_graph_destroy(one_pass(dw, True))
         lib.pg_data_destroy(dw)
 
-    # ---- synthetic input (not timed): every rank writes its own genomes, then registers the ids of the others
-    if a.scaling == "strong":
-        G = a.genomes or a.genomes_per_gpu * 8
-        lo, hi = G * rank // world, G * (rank + 1) // world
-    else:
-        G = a.genomes_per_gpu * world
-        lo, hi = rank * a.genomes_per_gpu, (rank + 1) * a.genomes_per_gpu
-    base = os.path.join(tempfile.gettempdir(), "pangene_bench_%s%dx%d_s%d" % (kind[0], G, a.proteins, a.seed))
-    t0 = time.time()
-    _gen(synth, kind, base, lo, hi, G, a.proteins, a.seed)
-    if world > 1:
-        dist.barrier()
-    files = [os.path.join(base, "g%05d.paf" % j) for j in range(G)]
-    t_gen = time.time() - t0
-
     d = lib.pg_data_init()
     t0 = time.time()
     capi.read_files(lib, opt, d, files, [not (lo <= j < hi) for j in range(G)])  # host threads; ids as in sequential reads; packs the blocks
@@ -207,7 +264,8 @@ def main():
     n_hits = lib.pg_last_path_hits()
     nh, ne = C.c_int64(), C.c_int64()
     lib.pg_shard_counts(d, C.byref(nh), C.byref(ne))
-    gfa = gfa_of(g)
+    t_write = []
+    gfa = gfa_of(g, t_write)
     lib.pg_graph_destroy(g)
     for _ in range(max(0, a.warmup)):
         lib.pg_graph_destroy(one_pass(d, False))
@@ -225,6 +283,13 @@ def main():
         phases = cur if phases is None else [x + y for x, y in zip(phases, cur)]
     sync()
     dt = time.time() - t0
+    if a.leg == "steps-only":  # the exchange-overhead leg of another bench.py: its own line, nothing else
+        os.write(real_stdout, (json.dumps({"ms_per_step": round(dt / a.steps * 1e3, 3), "exchange": exchange_kind, "gfa_sl_md5": sl_md5(gfa)}) + "\n").encode())
+        lib.pg_data_destroy(d)
+        if world > 1 or force_x:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if world > 1:
         xdev = torch.device("cpu") if one_gpu else dev
         t = torch.tensor([dt, t_cold + t_pack], dtype=torch.float64, device=xdev)
@@ -240,7 +305,7 @@ def main():
     # Algorithmic bytes of THIS kernel: SURVEY 8(d) gives 56 + 8E B/hit for a pg_shadow sweep (reads cs ce cid pid gid score_adj rank
     # flags n/off_exon + exons, writes flags pid_dom); the cal_dom_sc=1 flavour also reads score_ori and writes score_dom => 64 + 8E.
     # Stage A as a whole (SURVEY 8d "K1 = ingest stage A"): 72 + 8E B/hit, timed from the first kernel of pga_begin to the last of
-    # pga_ingest (sorts, per-hit constants, pg_flag_pseudo, both sweeps, isoform / chain / sub-optimal filters).
+    # pga_ingest (both orders + per-hit records, pg_flag_pseudo, both sweeps, isoform / chain / sub-optimal filters).
     def roofline_of(dd, hits, exons, note):
         E = exons / max(1, hits)
         ms, nl, units = k_timing(dd, 0)
@@ -251,28 +316,24 @@ def main():
         avg_ms = ms / nl
         ach = bph * (units / nl) / (avg_ms * 1e-3) / 1e9
         r = {"bound": "hbm", "kernel": "k_sweep<1, %s> (pg_shadow cal_dom_sc=1, stage A)" % ("true" if multi else "false"), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(units // nl), "avg_launch_ms": round(avg_ms, 4), "launches": nl,
+             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(units // nl, "true" if multi else "false"), "avg_launch_ms": round(avg_ms, 4), "launches": nl,
              "timing": "per-dispatch HIP start/stop events (hipExtLaunchKernelGGL) on the library's stream",
              "algorithmic_bytes_per_hit": round(bph, 1), "hits_per_launch": units // nl, "shard": note}
         ms3, nl3, u3 = k_timing(dd, 3)
         if nl3:
             b3 = 72 + 8 * E
             a3 = b3 * (u3 / nl3) / (ms3 / nl3 * 1e-3) / 1e9
-            r["stage_a"] = {"what": "all of stage A (pga_begin + pga_ingest: sorts, constants, pg_flag_pseudo, sweeps, filters), SURVEY 8(d) K1 as defined there",
+            r["stage_a"] = {"what": "all of stage A (pga_begin + pga_ingest: both orders and the per-hit records, pg_flag_pseudo, sweeps, filters), SURVEY 8(d) K1 as defined there",
                             "ms": round(ms3 / nl3, 4), "algorithmic_bytes_per_hit": round(b3, 1), "achieved": round(a3, 1), "frac": round(a3 / HBM_PEAK_GBS, 4)}
         return r
 
     roof = roofline_of(d, nh.value, ne.value, "the bench workload itself (fits the 256 MiB Infinity Cache: an L3 figure)")
     lib.pg_data_destroy(d)  # one context (and one HIP stream) at a time: the legs below bring their own
     d = None
-    big = None
-    if rank == 0 and world == 1 and a.roofline_genomes > 0 and kind == "bact":
-        RG = a.roofline_genomes
-        bbase = os.path.join(tempfile.gettempdir(), "pangene_bench_b%dx%d_s%d" % (RG, a.proteins, a.seed))
-        t0 = time.time()
-        _gen(synth, "bact", bbase, 0, RG, RG, a.proteins, a.seed)
-        bfiles = [os.path.join(bbase, "g%05d.paf" % j) for j in range(RG)]
-        tb_gen = time.time() - t0
+
+    def shard_leg(dirname, n_genomes, what, n_pass=3):
+        """a leg on a data set of its own: parse, cold pass, one warm pass, n_pass timed passes; the K1 / stage-A roofline of that shard"""
+        bfiles = [os.path.join(dirname, "g%05d.paf" % j) for j in range(n_genomes)]
         db = lib.pg_data_init()
         t0 = time.time()
         capi.read_files(lib, opt, db, bfiles)
@@ -285,33 +346,78 @@ def main():
         tb_pack, tb_up = lib.pg_last_pack_seconds(), lib.pg_last_upload_seconds()
         bh, be_ = C.c_int64(), C.c_int64()
         lib.pg_shard_counts(db, C.byref(bh), C.byref(be_))
-        bgfa = gfa_of(gb)
+        tw = []
+        bgfa = gfa_of(gb, tw)
         lib.pg_graph_destroy(gb)
         lib.pg_graph_destroy(one_pass(db, False))
         lib.pg_kernel_timing_reset(db)
         torch.cuda.synchronize(dev)
         t0 = time.time()
-        nb = 3
-        for _ in range(nb):
+        for _ in range(n_pass):
             lib.pg_graph_destroy(one_pass(db, False))
         torch.cuda.synchronize(dev)
-        tb = (time.time() - t0) / nb
-        note = "%d genomes x %d proteins, %d hits (configs[3] per-GPU shard): past the Infinity Cache" % (RG, a.proteins, bh.value)
+        tb = (time.time() - t0) / n_pass
+        note = "%s, %d hits, %.2f exons per hit: past the Infinity Cache" % (what, bh.value, be_.value / max(1, bh.value))
         r2 = roofline_of(db, bh.value, be_.value, note)
+        info = {"workload": note, "ms_per_step": round(tb * 1e3, 2), "M_hits_per_s": round(bh.value / tb / 1e6, 2),
+                "cold_pass_ms": round((tb_cold + tb_pack) * 1e3, 1), "cold_M_hits_per_s": round(bh.value / (tb_cold + tb_pack) / 1e6, 2),
+                "pack_ms": round(tb_pack * 1e3, 1), "alloc_upload_ms": round(tb_up * 1e3, 1), "paf_parse_s": round(tb_parse, 3),
+                "paf_parse_M_hits_per_s": round(bh.value / tb_parse / 1e6, 1), "gfa_write_s": round(tw[0], 3),
+                "gfa_md5": hashlib.md5(bgfa).hexdigest(), "gfa_sl_md5": sl_md5(bgfa)}
+        lib.pg_data_destroy(db)
+        return r2, info
+
+    big = human = None
+    if "big" in legs:
+        r2, big = shard_leg(legs["big"][0], legs["big"][1], "%d genomes x %d proteins (configs[3] per-GPU shard)" % (legs["big"][1], a.proteins))
+        big["paf_generate_s"] = round(legs["big"][2], 1)
         if r2:
             r2["also_at_bench_size"] = {k: roof[k] for k in ("achieved", "frac", "avg_launch_ms", "hits_per_launch", "traffic", "stage_a") if roof and k in roof}
             roof = r2
-        big = {"workload": note, "ms_per_step": round(tb * 1e3, 2), "M_hits_per_s": round(bh.value / tb / 1e6, 2),
-               "cold_pass_ms": round((tb_cold + tb_pack) * 1e3, 1), "cold_M_hits_per_s": round(bh.value / (tb_cold + tb_pack) / 1e6, 2),
-               "pack_ms": round(tb_pack * 1e3, 1), "alloc_upload_ms": round(tb_up * 1e3, 1), "paf_generate_s": round(tb_gen, 1), "paf_parse_s": round(tb_parse, 2),
-               "gfa_md5": hashlib.md5(bgfa).hexdigest(), "gfa_sl_md5": sl_md5(bgfa)}
-        lib.pg_data_destroy(db)
+    if "human" in legs:
+        r3, human = shard_leg(legs["human"][0], legs["human"][1], "%d human-shaped haplotypes x 20000 multi-exon genes, fragmented contigs (configs[2] / [4] shape)" % legs["human"][1])
+        human["paf_generate_s"] = round(legs["human"][2], 1)
+        human["roofline"] = r3
+
+    # ---- the exchange plumbing by itself: the same steps in a fresh process, world size 1, every collective of the sharded route issued
+    xo = None
+    if solo and not a.no_extra_legs:
+        try:
+            env = dict(os.environ, PANGENE_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            cmd = [sys.executable, os.path.abspath(__file__), "--leg", "steps-only", "--steps", str(a.steps), "--warmup", str(a.warmup), "--workload", a.workload,
+                   "--genomes-per-gpu", str(a.genomes_per_gpu), "--proteins", str(a.proteins), "--seed", str(a.seed), "--exact", a.exact]
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+            if r.returncode == 0 and line:
+                x = json.loads(line[-1])
+                plain = dt / a.steps * 1e3
+                xo = {"ms_per_step": x["ms_per_step"], "plain_ms_per_step": round(plain, 3), "overhead": round(x["ms_per_step"] / plain - 1.0, 4), "exchange": x["exchange"],
+                      "same_graph": x["gfa_sl_md5"] == sl_md5(gfa),
+                      "what": "PANGENE_FORCE_EXCHANGE=1, world size 1: the sharded route with every collective issued (identities), in a fresh process"}
+            else:
+                xo = {"error": (r.stderr.decode()[-300:] or "no output")}
+        except Exception as ex:  # the leg is informative: never fail the bench for it
+            xo = {"error": str(ex)[:300]}
+
+    # ---- the whole command in a fresh process, next to the reference's
+    cli = None
+    exe = os.path.join(ROOT, "pangene_amd", "bin", "pangene")
+    if solo and not a.no_extra_legs and os.path.exists(exe):
+        try:
+            t0 = time.time()
+            r = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            t_cli = time.time() - t0
+            cli = {"wall_s": round(t_cli, 3), "M_hits_per_s": round(n_hits / t_cli / 1e6, 2), "rc": r.returncode, "gfa_md5": hashlib.md5(r.stdout).hexdigest(),
+                   "same_bytes_as_the_library_run": hashlib.md5(r.stdout).hexdigest() == hashlib.md5(gfa).hexdigest(),
+                   "what": "pangene_amd/bin/pangene <%d files> > pipe: process start + HIP initialisation + code-object load + parsing + path + GFA text" % len(files)}
+        except Exception as ex:
+            cli = {"error": str(ex)[:300]}
 
     # ---- CPU baseline: the untouched reference binary on the same PAF files, 1 core (rank 0, N = 1 only)
     cpu = None
     ref = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
     ref_md5 = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and os.path.exists(ref):
+    if solo and not a.no_cpu_baseline and os.path.exists(ref):
         t0 = time.time()
         r = subprocess.run([ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         t_ref = time.time() - t0
@@ -322,6 +428,8 @@ def main():
                "sample": "whole workload (%d genomes, %d hits kept): reference binary wall until 'round-3 graph' %.2f s incl. its PAF parsing (stage A is interleaved with parsing there); host has %d cores, the reference is single-threaded"
                          % (G, n_hits, t_path, os.cpu_count() or 0),
                "total_wall_s": round(t_ref, 2)}
+        if cli and "wall_s" in cli:
+            cli["reference_wall_s"] = round(t_ref, 2)
     if rank == 0:
         cfg = "BASELINE configs[1]: synthetic bacterial pangenome" if kind == "bact" else "BASELINE configs[2] stand-in: synthetic human-shaped haplotypes (multi-exon, fragmented contigs)"
         res = {
@@ -335,16 +443,14 @@ def main():
             "cold_pass": {"value": round(tot_hits / t_cold_all / 1e6, 3), "unit": "M hits/s", "ms": round(t_cold_all * 1e3, 2),
                           "includes": "block packing in the reader threads (%.1f ms) + allocation, H2D and order-replay set-up (%.1f ms) + stages A+B+C; excludes PAF text parsing and GFA printing; kernels were loaded by a tiny warm-up data set"
                                       % (t_pack * 1e3, t_upload * 1e3)},
-            "roofline": roof, "cpu_baseline": cpu, "big_shard": big,
+            "roofline": roof, "cpu_baseline": cpu, "big_shard": big, "human_shard": human, "exchange_overhead": xo, "cli": cli,
             "gfa_md5": hashlib.md5(gfa).hexdigest() if world == 1 else None,
             "gfa_sl_md5": sl_md5(gfa),
             "gfa_identical_to_reference": (hashlib.md5(gfa).hexdigest() == ref_md5) if ref_md5 else None,
-            "not_timed": {"paf_generate_s": round(t_gen, 2), "paf_parse_and_pack_s": round(t_parse, 2), "path_only_ms_per_step": round(path_sec / a.steps * 1e3, 3)},
+            "not_timed": {"paf_generate_s": round(t_gen, 2), "paf_parse_and_pack_s": round(t_parse, 3), "gfa_write_s": round(t_write[0], 4), "path_only_ms_per_step": round(path_sec / a.steps * 1e3, 3)},
             "host_phases_ms_per_step": {lib.pg_phase_name(i).decode(): round(v / a.steps * 1e3, 3) for i, v in enumerate(phases or [])},
         }
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
-    if d is not None:
-        lib.pg_data_destroy(d)
     if world > 1 or force_x:
         dist.barrier()
         dist.destroy_process_group()

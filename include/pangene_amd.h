@@ -217,6 +217,15 @@ int pg_rccl_init(int32_t rank, int32_t world, const void *id128);
 int pg_rccl_finalize(void);
 const char *pg_rccl_error(void);
 
+/* The exchange between the processes one command forks, for backends whose vectors live in host memory (the HIP backend uses
+ * RCCL): the launcher maps a shared region before the fork (pg_shm_create), every rank installs it after (pg_shm_init). */
+void *pg_shm_create(int32_t world, int64_t slot_bytes);
+int pg_shm_init(void *region, int32_t rank);
+/* 1 when the linked backend keeps its vectors in device memory (HIP), 0 otherwise; the HIP device a process is to use */
+int pg_backend_is_device(void);
+int pg_set_device(int32_t device);
+int pg_device_count(void);
+
 /* Wall-clock seconds spent inside the last pg_post_process + pg_graph_gen (stages A+B+C), and the
  * number of hits they processed (local shard). */
 double  pg_last_path_seconds(void);

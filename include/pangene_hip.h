@@ -312,6 +312,8 @@ typedef struct {
 	int  (*branch_decide_filter)(pga_ctx_t *, double, double, double, int32_t, int32_t, int32_t, int32_t, uint8_t *); /* may be NULL */
 	int  (*branch_loop)(pga_ctx_t *, int32_t, const struct pga_branch_par_s *, const int32_t *, const int32_t *, const int32_t *, uint8_t *); /* may be NULL */
 	void (*host_trim)(size_t); /* may be NULL */
+	int  (*set_device)(int32_t); /* may be NULL */
+	int  (*device_count)(void);  /* may be NULL */
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);
@@ -330,6 +332,9 @@ const pga_backend_t *pga_backend(void);
  * run with host-driven rounds; 2 = not applicable here (nothing was queued). */
 /* Page-locked host memory the backend keeps between contexts (mailboxes, staging areas): give back what exceeds keep_bytes. */
 void pga_host_trim(size_t keep_bytes);
+/* the HIP device of this process (before the first context); the number of visible devices */
+int pga_set_device(int32_t device);
+int pga_device_count(void);
 
 typedef struct pga_branch_par_s { double branch_diff, branch_diff_dist, branch_diff_cut; int32_t local_dist, local_count, frag_mode, use_ori; } pga_branch_par_t;
 int pga_branch_loop(pga_ctx_t *ctx, int32_t n_round, const pga_branch_par_t *par, const int32_t *max_tot_cnt, const int32_t *max_degree,

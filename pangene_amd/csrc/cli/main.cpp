@@ -1,10 +1,16 @@
 // pangene command line: `pangene [options] <in.paf> [...] > graph.gfa` with the reference's option
 // letters, defaults and usage text (main.c:12-152, option.c:9-25), on top of libpangene_amd.
+#include <dlfcn.h>
 #include <getopt.h>
+#include <signal.h>
 #include <sys/resource.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 #include "pangene_amd.h"
 
 static int usage(FILE *fp, const pg_opt_t *opt)
@@ -37,6 +43,7 @@ static int usage(FILE *fp, const pg_opt_t *opt)
 	std::fprintf(fp, "    -w            Suppress walk lines (W-lines)\n");
 	std::fprintf(fp, "    --bed[=STR]   output 12-column BED where STR is walk, raw or flag [walk]\n");
 	std::fprintf(fp, "    --matrix[=STR] output the gene x assembly matrix of pangene.js gfa2matrix, STR presence or count [presence]\n");
+	std::fprintf(fp, "    --gpus=INT    shard the genomes over INT GPUs of this node: one process per device, RCCL over xGMI [1]\n");
 	std::fprintf(fp, "    --version     print version number\n");
 	std::fprintf(fp, "  Also: pangene gfa2matrix [-c] [-d FILE] [-p] <in.gfa>   (pangene.js gfa2matrix on a GFA file)\n");
 	return fp == stdout ? 0 : 1;
@@ -68,12 +75,135 @@ static int main_gfa2matrix(int argc, char *argv[]) // pangene.js:1168-1183
 	return pg_gfa2matrix_file(argv[optind], copy_number, clstr, print_cd) == 0 ? 0 : 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// `pangene --gpus N`: main.c:117-142 for N devices of one node.  The command forks N - 1 workers BEFORE anything touches the GPU;
+// rank r takes device r and the r-th contiguous block of the PAF files (so that the ranks' W / BED lines, concatenated in rank
+// order, are in command-line order) and registers the names of the other files (ids as in a sequential read).  The exchange is
+// RCCL on the kernels' stream (the 128-byte id travels through a pipe); on a backend without a device (the oracle host of the
+// tests) it is a shared-memory region mapped before the fork.  Rank 0 prints the graph; every rank writes the lines of its own
+// genomes to a temporary file that rank 0 copies to stdout in rank order.
+// ---------------------------------------------------------------------------------------------------------------
+struct Output { int matrix = 0; };
+
+static int run_path(pg_opt_t &opt, int n_files, char **files, const uint8_t *ids_only, const Output &o, bool graph_lines, bool own_lines)
+{
+	pg_data_t *d = pg_data_init();
+	pg_read_paf_batch(&opt, d, n_files, files, ids_only, 0); // parallel parse, ids as in sequential pg_read_paf calls
+	pg_post_process(&opt, d);
+	int rc = 0;
+	if (pg_last_error()) rc = 2;
+	else if (opt.flag & PG_F_WRITE_BED_RAW) { if (own_lines) pg_write_bed(d, 0); }
+	else {
+		pg_graph_t *g = pg_graph_init(d);
+		pg_graph_gen(&opt, g);
+		if (pg_last_error()) rc = 2;
+		else if (o.matrix) pg_write_matrix(g, o.matrix == 2);
+		else if (opt.flag & PG_F_WRITE_BED_WALK) { if (own_lines) pg_write_bed(d, 1); }
+		else if (opt.flag & PG_F_WRITE_BED_FLAG) { if (own_lines) pg_write_bed(d, 0); }
+		else {
+			if (graph_lines) { pg_write_graph(g); std::fflush(stdout); }
+			if (own_lines && !(opt.flag & PG_F_WRITE_NO_WALK)) pg_write_walk(g);
+		}
+		pg_graph_destroy(g);
+	}
+	pg_data_destroy(d);
+	return rc;
+}
+
+static bool read_all(int fd, void *buf, size_t n) { char *p = (char *)buf; while (n) { ssize_t k = read(fd, p, n); if (k <= 0) return false; p += k, n -= (size_t)k; } return true; }
+static bool write_all(int fd, const void *buf, size_t n) { const char *p = (const char *)buf; while (n) { ssize_t k = write(fd, p, n); if (k <= 0) return false; p += k, n -= (size_t)k; } return true; }
+
+static int run_sharded(pg_opt_t &opt, int W, int n_files, char **files, const Output &o)
+{
+	if (o.matrix) { std::fprintf(stderr, "ERROR: --matrix needs every genome in one process; run it without --gpus\n"); return 1; }
+	const bool dev = pg_backend_is_device() != 0;
+	typedef int (*uid_fn)(void *); typedef int (*init_fn)(int32_t, int32_t, const void *); typedef int (*fin_fn)(void);
+	uid_fn rccl_uid = nullptr; init_fn rccl_init = nullptr; fin_fn rccl_fin = nullptr;
+	void *region = nullptr;
+	if (dev) { // bound at run time: only the HIP build of the library has them
+		rccl_uid = (uid_fn)dlsym(RTLD_DEFAULT, "pg_rccl_unique_id"), rccl_init = (init_fn)dlsym(RTLD_DEFAULT, "pg_rccl_init"), rccl_fin = (fin_fn)dlsym(RTLD_DEFAULT, "pg_rccl_finalize");
+		if (!rccl_uid || !rccl_init) { std::fprintf(stderr, "ERROR: this build of the library has no RCCL exchange\n"); return 1; }
+	} else if ((region = pg_shm_create(W, (int64_t)16 << 20)) == nullptr) { std::fprintf(stderr, "ERROR: cannot map the exchange region\n"); return 1; }
+	// files of rank r: [n r / W, n (r + 1) / W)
+	std::vector<std::string> tmp((size_t)W);
+	std::vector<int> id_pipe((size_t)W * 2, -1), st_pipe((size_t)W * 2, -1);
+	std::vector<pid_t> kid((size_t)W, 0);
+	const char *td = std::getenv("TMPDIR");
+	for (int r = 0; r < W; ++r) {
+		std::string t = std::string(td && *td ? td : "/tmp") + "/pangene_rank" + std::to_string(r) + "_XXXXXX";
+		const int fd = mkstemp(&t[0]);
+		if (fd < 0) { std::fprintf(stderr, "ERROR: cannot create a temporary file for rank %d\n", r); return 1; }
+		close(fd);
+		tmp[(size_t)r] = t;
+		if (r && (pipe(&id_pipe[(size_t)r * 2]) != 0 || pipe(&st_pipe[(size_t)r * 2]) != 0)) { std::fprintf(stderr, "ERROR: pipe()\n"); return 1; }
+	}
+	std::fflush(stdout); std::fflush(stderr);
+	int rank = 0;
+	for (int r = 1; r < W; ++r) {
+		const pid_t p = fork();
+		if (p < 0) { std::fprintf(stderr, "ERROR: fork()\n"); for (int k = 1; k < r; ++k) kill(kid[(size_t)k], SIGTERM); return 1; }
+		if (p == 0) { rank = r; break; }
+		kid[(size_t)r] = p;
+	}
+	auto cleanup = [&]() { for (int r = 0; r < W; ++r) unlink(tmp[(size_t)r].c_str()); };
+	std::vector<uint8_t> ids_only((size_t)n_files, 1);
+	for (int i = (int)((int64_t)n_files * rank / W); i < (int)((int64_t)n_files * (rank + 1) / W); ++i) ids_only[(size_t)i] = 0;
+	int rc = 0;
+	if (dev && pg_set_device(rank) != 0) { std::fprintf(stderr, "[E::pangene] rank %d: no HIP device %d\n", rank, rank); rc = 3; }
+	// bootstrap: rank 0 hands the id out and hears from every worker before anybody enters the communicator
+	unsigned char id[128] = { 0 };
+	if (rank == 0) {
+		if (dev && rc == 0 && rccl_uid(id) != 0) rc = 3;
+		unsigned char ok = rc == 0 ? 1 : 0;
+		for (int r = 1; r < W; ++r) {
+			close(id_pipe[(size_t)r * 2]), close(st_pipe[(size_t)r * 2 + 1]);
+			if (!write_all(id_pipe[(size_t)r * 2 + 1], &ok, 1) || !write_all(id_pipe[(size_t)r * 2 + 1], id, sizeof(id))) ok = 0;
+		}
+		for (int r = 1; r < W; ++r) { unsigned char s = 0; if (!read_all(st_pipe[(size_t)r * 2], &s, 1) || !s) ok = 0; }
+		for (int r = 1; r < W; ++r) write_all(id_pipe[(size_t)r * 2 + 1], &ok, 1); // go / no go
+		if (!ok) { for (int r = 1; r < W; ++r) { int st; waitpid(kid[(size_t)r], &st, 0); } cleanup(); return 3; }
+	} else {
+		close(id_pipe[(size_t)rank * 2 + 1]), close(st_pipe[(size_t)rank * 2]);
+		unsigned char ok = 0, go = 0, mine = rc == 0 ? 1 : 0;
+		if (!read_all(id_pipe[(size_t)rank * 2], &ok, 1) || !read_all(id_pipe[(size_t)rank * 2], id, sizeof(id))) ok = 0;
+		if (!ok) mine = 0;
+		write_all(st_pipe[(size_t)rank * 2 + 1], &mine, 1);
+		if (!read_all(id_pipe[(size_t)rank * 2], &go, 1) || !go) _exit(3);
+		opt.flag &= ~PG_F_WRITE_VTX_SEL; // (-G lines come from rank 0 only)
+		if (pg_verbose > 1) pg_verbose = 1; // one log, rank 0's
+	}
+	if ((dev ? rccl_init(rank, W, id) : pg_shm_init(region, rank)) != 0) { std::fprintf(stderr, "[E::pangene] rank %d: cannot join the exchange\n", rank); rc = 3; }
+	if (rc == 0) {
+		if (rank) { if (pg_set_output(tmp[(size_t)rank].c_str()) != 0) rc = 3; }
+		if (rc == 0) rc = run_path(opt, n_files, files, ids_only.data(), o, rank == 0, true);
+		if (rank) pg_set_output(nullptr);
+	}
+	if (dev && rccl_fin) rccl_fin();
+	if (rank) _exit(rc);
+	std::fflush(stdout);
+	for (int r = 1; r < W; ++r) {
+		int st = 0;
+		if (waitpid(kid[(size_t)r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { std::fprintf(stderr, "[E::pangene] rank %d failed\n", r); rc = rc ? rc : 2; }
+	}
+	for (int r = 1; r < W && rc == 0; ++r) { // the other ranks' lines, in rank (= command-line) order
+		FILE *fp = std::fopen(tmp[(size_t)r].c_str(), "rb");
+		if (!fp) { rc = 2; break; }
+		char buf[1 << 16];
+		size_t k;
+		while ((k = std::fread(buf, 1, sizeof(buf), fp)) > 0) std::fwrite(buf, 1, k, stdout);
+		std::fclose(fp);
+	}
+	cleanup();
+	return rc;
+}
+
 int main(int argc, char *argv[])
 {
 	if (argc >= 2 && std::strcmp(argv[1], "gfa2matrix") == 0) return main_gfa2matrix(argc - 1, argv + 1);
-	int matrix = 0; // 1 presence, 2 counts
+	int matrix = 0, n_gpus = 1; // matrix: 1 presence, 2 counts
 	static const struct option lopts[] = {
 		{ "bed", optional_argument, nullptr, 301 }, { "ori-sc", no_argument, nullptr, 302 }, { "matrix", optional_argument, nullptr, 303 },
+		{ "gpus", required_argument, nullptr, 304 }, { "procs", required_argument, nullptr, 304 },
 		{ "version", no_argument, nullptr, 401 }, { nullptr, 0, nullptr, 0 } };
 	pg_opt_t opt;
 	pg_opt_init(&opt);
@@ -115,31 +245,18 @@ int main(int argc, char *argv[])
 			break;
 		case 302: opt.flag |= PG_F_ORI_FOR_BRANCH; break;
 		case 303: matrix = (optarg && std::strcmp(optarg, "count") == 0) ? 2 : 1; break;
+		case 304: n_gpus = std::atoi(optarg); break;
 		case 401: std::puts(PG_VERSION); return 0;
 		default: break;
 		}
 	}
 	if (argc - optind < 1) return usage(stderr, &opt);
-	pg_data_t *d = pg_data_init();
-	pg_read_paf_batch(&opt, d, argc - optind, argv + optind, nullptr, 0); // parallel parse, ids as in sequential pg_read_paf calls
-	pg_post_process(&opt, d);
-	int rc = 0;
-	if (pg_last_error()) rc = 2;
-	else if (opt.flag & PG_F_WRITE_BED_RAW) pg_write_bed(d, 0);
-	else {
-		pg_graph_t *g = pg_graph_init(d);
-		pg_graph_gen(&opt, g);
-		if (pg_last_error()) rc = 2;
-		else if (matrix) pg_write_matrix(g, matrix == 2);
-		else if (opt.flag & PG_F_WRITE_BED_WALK) pg_write_bed(d, 1);
-		else if (opt.flag & PG_F_WRITE_BED_FLAG) pg_write_bed(d, 0);
-		else {
-			pg_write_graph(g);
-			if (!(opt.flag & PG_F_WRITE_NO_WALK)) pg_write_walk(g);
-		}
-		pg_graph_destroy(g);
-	}
-	pg_data_destroy(d);
+	Output o;
+	o.matrix = matrix;
+	int rc;
+	if (n_gpus > 1) {
+		rc = run_sharded(opt, n_gpus, argc - optind, argv + optind, o);
+	} else rc = run_path(opt, argc - optind, argv + optind, nullptr, o, true, true);
 	if (opt.excl) pg_dict_destroy(opt.excl);
 	if (opt.incl) pg_dict_destroy(opt.incl);
 	if (opt.preferred) pg_dict_destroy(opt.preferred);

@@ -209,6 +209,9 @@ extern "C" int pga_host_alloc(size_t nbytes, void **ptr)
 }
 extern "C" void pga_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
 
+extern "C" int pga_set_device(int32_t device) { return hipSetDevice(device) == hipSuccess ? 0 : PGA_ERR_NO_DEVICE; }
+extern "C" int pga_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
 extern "C" void pga_host_trim(size_t keep_bytes)
 {
 	std::lock_guard<std::mutex> lk(g_pin_mu);
@@ -1645,7 +1648,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count
 	};
 	return &b;
 }

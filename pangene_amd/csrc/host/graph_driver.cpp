@@ -1234,6 +1234,10 @@ double pg_last_path_seconds(void) { return g_path_sec; }
 double pg_last_upload_seconds(void) { return g_upload_sec; }
 double pg_last_pack_seconds(void) { return g_pack_sec; }
 
+int pg_backend_is_device(void) { return backend_default()->is_device(); }
+int pg_set_device(int32_t device) { const pga_backend_t *be = backend_default(); return be->set_device ? be->set_device(device) : 0; }
+int pg_device_count(void) { const pga_backend_t *be = backend_default(); return be->device_count ? be->device_count() : 0; }
+
 void pg_trim_host_cache(size_t keep_bytes) { trim_host_caches(keep_bytes); } // page-locked memory the library keeps for its next upload
 
 int pg_shard_counts(const pg_data_t *d, int64_t *n_hit, int64_t *n_exon)

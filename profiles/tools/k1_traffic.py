@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch of K1 (k_sweep<1, *>) from the two PMC passes of `python bench.py --no-cpu-baseline`, per shard size.
-rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB (1 unit = 1024 B); on gfx950 FETCH_SIZE tallies 64 B per request where a wide
-coalesced read moves 128 B, so it is doubled (MI355X_MICROARCH.md, HBM section).  The bench launches K1 on three shard sizes (the
-tiny warm-up set, the bench workload, the past-L3 shard of the roofline leg): the dispatches are told apart by their counter
-values (each size is > 5x the previous one).
+"""HBM bytes per launch of K1 (k_sweep<1, *>) from the two PMC passes of `python bench.py --no-cpu-baseline --no-extra-legs`, per
+kernel flavour and shard size.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB (1 unit = 1024 B); on gfx950 FETCH_SIZE tallies
+64 B per request where a wide coalesced read moves 128 B, so it is doubled (MI355X_MICROARCH.md, HBM section).  The bench launches
+k_sweep<1, false> on three shard sizes (the tiny warm-up set, the bench workload, the past-L3 shard of the roofline leg) and
+k_sweep<1, true> on the human-shaped shard: the dispatches are told apart by their counter values (each size is > 5x the previous
+one).  Every entry carries the sha256 of k_sweep.hpp it was measured with: bench.py only reports it as `traffic` while the source
+is the same.
 usage: k1_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <bench.json>"""
-import glob, json, os, sqlite3, sys
+import glob, hashlib, json, os, sqlite3, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def per_dispatch(root, counter):
+def per_dispatch(root, counter, pat):
     db = sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True))[0]
     cur = sqlite3.connect(db).cursor()
     cur.execute("SELECT * FROM pmc_events LIMIT 1")
@@ -19,7 +23,7 @@ def per_dispatch(root, counter):
     dn = ([x for x in c if x in ("dispatch_id", "event_id")] or [x for x in c if "dispatch" in x])[0]
     acc = {}
     for name, ctr, val, did in cur.execute("SELECT %s, %s, %s, %s FROM pmc_events" % (kn, cn, vn, dn)):
-        if "k_sweep<1" in name and ctr == counter:
+        if pat in name and ctr == counter:
             acc[did] = acc.get(did, 0.0) + (val or 0.0)
     return sorted(acc.values())
 
@@ -34,17 +38,27 @@ def groups(vals):  # consecutive values within a factor 3 form one shard size
     return [sum(g) / len(g) for g in out], [len(g) for g in out]
 
 
-f, nf = groups(per_dispatch(sys.argv[1], "FETCH_SIZE"))
-w, nw = groups(per_dispatch(sys.argv[2], "WRITE_SIZE"))
 b = json.load(open(sys.argv[3]))
-sizes = [b["roofline"]["hits_per_launch"]]
+sha = hashlib.sha256(open(os.path.join(ROOT, "pangene_amd", "csrc", "hip", "k_sweep.hpp"), "rb").read()).hexdigest()[:16]
+want = {"false": [b["roofline"]["hits_per_launch"]], "true": []}
 if "also_at_bench_size" in b["roofline"]:
-    sizes.insert(0, b["roofline"]["also_at_bench_size"]["hits_per_launch"])
+    want["false"].insert(0, b["roofline"]["also_at_bench_size"]["hits_per_launch"])
+if b.get("human_shard") and b["human_shard"].get("roofline"):
+    want["true"].append(b["human_shard"]["roofline"]["hits_per_launch"])
 out = []
-for k, hits in enumerate(reversed(sizes)):  # largest group = largest shard
-    fk, wk = f[-1 - k], w[-1 - k]
-    tot = int((2 * fk + wk) * 1024)
-    out.append({"kernel": "k_sweep<1, *>", "hits_per_launch": hits, "fetch_kb_raw": round(fk, 1), "write_kb": round(wk, 1), "bytes_per_launch": tot,
-                "bytes_per_hit": round(tot / hits, 1), "dispatches": [nf[-1 - k], nw[-1 - k]],
-                "note": "FETCH_SIZE x2 (gfx950 correction), separate --pmc passes of `python bench.py --no-cpu-baseline --steps 2 --warmup 0`"})
-print(json.dumps(out[::-1], indent=1))
+for flavour, sizes in want.items():
+    if not sizes:
+        continue
+    f, nf = groups(per_dispatch(sys.argv[1], "FETCH_SIZE", "k_sweep<1, %s>" % flavour))
+    w, nw = groups(per_dispatch(sys.argv[2], "WRITE_SIZE", "k_sweep<1, %s>" % flavour))
+    ent = []
+    for k, hits in enumerate(reversed(sizes)):  # largest group = largest shard
+        if k >= len(f) or k >= len(w):
+            break
+        fk, wk = f[-1 - k], w[-1 - k]
+        tot = int((2 * fk + wk) * 1024)
+        ent.append({"kernel": "k_sweep<1, %s>" % flavour, "flavour": flavour, "k_sweep_sha16": sha, "hits_per_launch": hits, "fetch_kb_raw": round(fk, 1), "write_kb": round(wk, 1),
+                    "bytes_per_launch": tot, "bytes_per_hit": round(tot / hits, 1), "dispatches": [nf[-1 - k], nw[-1 - k]],
+                    "note": "FETCH_SIZE x2 (gfx950 correction), separate --pmc passes of `python bench.py --no-cpu-baseline --no-extra-legs --steps 2 --warmup 0`"})
+    out += ent[::-1]
+print(json.dumps(out, indent=1))

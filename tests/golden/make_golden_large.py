@@ -4,6 +4,7 @@ the inputs are too large to commit, so the tests regenerate them from the seeded
 box and compare md5s.  Writes tests/golden/expected_large.json:
   human47x20k   BASELINE configs[2] stand-in  synth.human(47, 20000, iso=1.0, seed=1, frag=True)   (multi-exon K1 flavour)
   bact1250x5k   configs[3] per-GPU shard      synth.bact(1250, 5000, seed=1)                        (~12 M hits)
+  human25x20k_iso5.5  configs[4] per-GPU shard  synth.human(25, 20000, iso=5.5, seed=1, frag=True), -p0 -a1 (~2.8 M hits, ~110 k proteins)
 """
 import hashlib, json, os, subprocess, sys, tempfile, time
 
@@ -16,6 +17,8 @@ REF = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
 SETS = {
     "human47x20k": (lambda: synth.human(47, 20000, iso=1.0, seed=1, frag=True), [[], ["-p0", "-a1"]]),
     "bact1250x5k": (lambda: synth.bact(1250, 5000, seed=1), [[]]),
+    # the per-GPU shard of BASELINE configs[4] (200 assemblies x ~110 k all-isoform proteins over 8 GPUs, -p0 -a1): 25 x 20 k genes x 5.5 isoforms
+    "human25x20k_iso5.5": (lambda: synth.human(25, 20000, iso=5.5, seed=1, frag=True), [["-p0", "-a1"]]),
 }
 
 
