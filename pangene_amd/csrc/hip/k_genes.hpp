@@ -125,6 +125,22 @@ template <int CAP, int STAGE> struct GeneWin {
 	__device__ __forceinline__ uint32_t bx(int z) const { return (z >= lo && z < hi) ? T.bx[z - lo] : a.hbk[z]; }
 };
 
+// a thread's sums for one key -> the gene's table (false: no room)
+template <int CAP, class Table>
+__device__ __forceinline__ bool ga_flush(Table &T, int cap, int cap_log2, uint32_t key, int ng, int tot, unsigned long long sd, unsigned long long s1, unsigned long long s2)
+{
+	uint32_t slot = (key * 2654435761u) >> (32 - cap_log2);
+	int probes = 0;
+	for (; probes < cap; ++probes, slot = (slot + 1) & (cap - 1)) {
+		const uint32_t old = atomicCAS(&T.key[slot], 0xffffffffu, key);
+		if (old == 0xffffffffu || old == key) break;
+	}
+	if (probes == cap) return false;
+	atomicAdd(&T.ng[slot], ng); atomicAdd(&T.tot[slot], tot);
+	atomicAdd(&T.sd[slot], sd); atomicAdd(&T.s1[slot], s1); atomicAdd(&T.s2[slot], s2);
+	return true;
+}
+
 // NT cooperating threads (one wave: 64, one workgroup: 256), tid in [0, NT).  Returns false when the table overflowed.
 template <int NT, int CAP, int STAGE>
 __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, STAGE> &T, const int g, const int sid, const int tid, const int cap_log2)
@@ -134,6 +150,9 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 	for (int k = tid; k < cap; k += NT) T.key[k] = 0xffffffffu, T.ng[k] = 0, T.tot[k] = 0, T.sd[k] = 0, T.s1[k] = 0, T.s2[k] = 0;
 	if (tid == 0) T.n_tot = 0, T.n_gen = 0, T.over = 0, T.m = 0, T.m0 = 0;
 	int n_tot = 0, n_gen = 0; // this thread's walkable hits / genomes it counted (graph.c:125-126)
+	uint32_t pk[2] = { 0xffffffffu, 0xffffffffu }; // per direction: the key whose run this thread is summing, and the sums
+	int png[2] = { 0, 0 }, ptot[2] = { 0, 0 };
+	unsigned long long psd[2] = { 0, 0 }, ps1[2] = { 0, 0 }, ps2[2] = { 0, 0 };
 	for (int c0 = z0; c0 < z1; c0 += STAGE - 2 * HALO) {
 		const int c1 = c0 + (STAGE - 2 * HALO) < z1 ? c0 + (STAGE - 2 * HALO) : z1;
 		GeneWin<CAP, STAGE> W = { a, T, c0 - HALO > z0 ? c0 - HALO : z0, c1 + HALO < z1 ? c1 + HALO : z1 };
@@ -189,20 +208,22 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 					}
 				m1 = m1 > 0 ? m1 : 0, m2 = m2 > 0 ? m2 : 0; // the reference's running maxima start at 0 (graph.c:133)
 				const int dg = (int32_t)((double)(long long)sd / n + .499); // graph.c:141
-				// level 2 (graph.c:153-169): sums over the genomes, LDS table keyed by (orientation, target)
-				uint32_t slot = (key * 2654435761u) >> (32 - cap_log2);
-				int probes = 0;
-				for (; probes < cap; ++probes, slot = (slot + 1) & (cap - 1)) {
-					const uint32_t old = atomicCAS(&T.key[slot], 0xffffffffu, key);
-					if (old == 0xffffffffu || old == key) break;
+				// level 2 (graph.c:153-169): sums over the genomes, LDS table keyed by (orientation, target).  A lane's hits lie in
+				// different genomes and mostly have the same neighbour: runs of one key are summed in registers and reach the table
+				// as ONE set of atomics (a gene with 2 400 hits and ten neighbours would otherwise send 24 000 atomics to ten slots).
+				if (key != pk[dir]) {
+					if (pk[dir] != 0xffffffffu && !ga_flush<CAP>(T, cap, cap_log2, pk[dir], png[dir], ptot[dir], psd[dir], ps1[dir], ps2[dir])) T.over = 1;
+					pk[dir] = key, png[dir] = 0, ptot[dir] = 0, psd[dir] = 0, ps1[dir] = 0, ps2[dir] = 0;
 				}
-				if (probes == cap) { T.over = 1; continue; }
-				atomicAdd(&T.ng[slot], 1); atomicAdd(&T.tot[slot], n);
-				atomicAdd(&T.sd[slot], (unsigned long long)(long long)dg * (unsigned long long)n);
-				atomicAdd(&T.s1[slot], (unsigned long long)(long long)m1); atomicAdd(&T.s2[slot], (unsigned long long)(long long)m2);
+				png[dir] += 1, ptot[dir] += n;
+				psd[dir] += (unsigned long long)(long long)dg * (unsigned long long)n;
+				ps1[dir] += (unsigned long long)(long long)m1, ps2[dir] += (unsigned long long)(long long)m2;
 			}
 		}
 	}
+#pragma unroll
+	for (int dir = 0; dir < 2; ++dir)
+		if (pk[dir] != 0xffffffffu && !ga_flush<CAP>(T, cap, cap_log2, pk[dir], png[dir], ptot[dir], psd[dir], ps1[dir], ps2[dir])) T.over = 1;
 	{ // one LDS atomic per wave, not per hit
 		const int wt = wave_sum(n_tot), wg = wave_sum(n_gen);
 		if ((tid & 63) == 0) { if (NT == 64) T.n_tot = wt, T.n_gen = wg; else atomicAdd(&T.n_tot, wt), atomicAdd(&T.n_gen, wg); }

@@ -155,21 +155,22 @@ __device__ __forceinline__ void gs_body(const GenomeSort &a, unsigned char *gs_m
 	// 4 score_adj, 5 n_exon, 6 off_exon, 7 cs, 8 ce, 9 cm; static per-hit constants derived once in pga_create: 12 gene, 13 CDS
 	// length, 15 score key, 16 rev / multi-exon flag bits)
 	constexpr int NPL = 15;
-	const int32_t *const pl[NPL] = { a.up + N + gb, a.up + 7 * N + gb, a.up + 8 * N + gb, a.up + gb, a.up + 12 * N + gb, a.up + 15 * N + gb, a.up + 2 * N + gb, a.up + 3 * N + gb,
-	                                 a.up + 4 * N + gb, a.up + 5 * N + gb, a.up + 6 * N + gb, a.up + 13 * N + gb, a.up + 16 * N + gb, a.up + 9 * N + gb, a.up + N + gb };
+	const int32_t *const pl[NPL] = { a.up + N + gb, a.up + 7 * N + gb, a.up + 8 * N + gb, a.up + gb, a.up + 12 * N + gb, a.up + 15 * N + gb, a.up + 13 * N + gb, a.up + 2 * N + gb,
+	                                 a.up + 3 * N + gb, a.up + 4 * N + gb, a.up + 5 * N + gb, a.up + 6 * N + gb, a.up + 16 * N + gb, a.up + 9 * N + gb, a.up + N + gb };
 	const int cb = a.ctg_base[g];
 	uint32_t R[D][K]; // D planes in registers (loaded D planes ahead of their use): element u belongs to item tid + u * GS_T
 	GS_STAMP(0);
 
 #define GS_LOADP(q) do { if ((q) < NPL) { _Pragma("unroll") for (int u = 0; u < K; ++u) { const int i = tid + u * GS_T; R[(q) % D][u] = i < n ? (uint32_t)pl[(q) < NPL ? (q) : 0][i] : 0u; } } } while (0)
 	// ---- X order: pg_hit_sort(g, 0) = by (contig, cs), ties in file order (the reference's own tie order is replayed later where it matters) ----
-	GS_LOADP(0); GS_LOADP(1);
+	if (D >= 2) { GS_LOADP(0); GS_LOADP(1); } else GS_LOADP(1); // (one register set: cs first, the contig plane after its passes)
 	if (D > 2) GS_LOADP(2);
 #pragma unroll
 	for (int u = 0; u < K; ++u) { const int i = tid + u * GS_T; if (i < n) L.cur[i] = (uint16_t)i; }
 	gs_bar();
 	gs_sort_bits<K>(L, n, R[1 % D], a.cs_bits, a.prof ? a.prof + (long long)blockIdx.x * 32 : nullptr);
 	GS_STAMP(1);
+	if (D < 2) GS_LOADP(0);
 	gs_sort_bits<K>(L, n, R[0], a.ctg_bits);
 	GS_STAMP(2);
 	if (L.cur != idx0) { // the permutation phase wants the order in the first array (S becomes the staging area)
@@ -278,26 +279,23 @@ __device__ __forceinline__ void gs_body(const GenomeSort &a, unsigned char *gs_m
 	GS_BEGIN(5); GS_GET(); gs_bar(); // score key: only in record B
 #pragma unroll
 	for (int u = 0; u < K; ++u) CSX[u] = V[u];
-	GS_PLANE(6, a.o.rank);
-	GS_PLANE(7, a.o.sori); // (also a plane: the single-exon flavour of the sweep stages it alone)
-	uint32_t SOX[K];
+	GS_BEGIN(6); GS_GET(); gs_bar(); // CDS length: only in record B
 #pragma unroll
-	for (int u = 0; u < K; ++u) SOX[u] = V[u];
-	GS_PLANE(8, a.o.sadj);
-	GS_PLANE(9, a.o.nex);
-	GS_BEGIN(10); GS_GET(); gs_bar(); // off_exon: only in record C
-#pragma unroll
-	for (int u = 0; u < K; ++u) { // record C = {rank, n_exon, off_exon, score_ori}: the two planes just written come back out of L2
-		const int x = tid + u * GS_T;
-		if (x < n) a.C[gb + x] = make_int4(0, 0, (int)V[u], (int)SOX[u]);
-	}
-	GS_STAMP(6);
-	GS_BEGIN(11); GS_GET(); gs_bar(); // CDS length: only in record B
-#pragma unroll
-	for (int u = 0; u < K; ++u) { // record B = {rk, gid, cds, pid}
+	for (int u = 0; u < K; ++u) { // record B = {rk, gid, cds, pid}: gid and pid come back out of their planes at the end
 		const int x = tid + u * GS_T;
 		if (x < n) a.B[gb + x] = make_int4((int)CSX[u], 0, (int)V[u], 0);
 	}
+	GS_PLANE(7, a.o.rank);
+	GS_PLANE(8, a.o.sori); // (also a plane: the single-exon flavour of the sweep stages it alone)
+	GS_PLANE(9, a.o.sadj);
+	GS_PLANE(10, a.o.nex);
+	GS_BEGIN(11); GS_GET(); gs_bar(); // off_exon: only in record C = {rank, n_exon, off_exon, score_ori}; the other three come back out of their planes
+#pragma unroll
+	for (int u = 0; u < K; ++u) {
+		const int x = tid + u * GS_T;
+		if (x < n) ((int32_t *)&a.C[gb + x])[2] = (int32_t)V[u];
+	}
+	GS_STAMP(6);
 	GS_BEGIN(12);
 	GS_GET();
 #pragma unroll
@@ -332,33 +330,33 @@ __device__ __forceinline__ void gs_body(const GenomeSort &a, unsigned char *gs_m
 	for (int u = 0; u < K; ++u) { const int y = tid + u * GS_T; if (y < n) a.yperm[gb + y] = gb + (int32_t)L.cur[y]; }
 	__syncthreads(); // everything this workgroup wrote is in L2 now (this barrier waits for the stores)
 	GS_STAMP(11);
-	// the words of records B and C that also exist as planes (gid, pid; rank, n_exon) are filled in from there
+	// the words of records B and C that also exist as planes (gid, pid; rank, n_exon, score_ori) are filled in from there
 	for (int x0 = tid; x0 < n; x0 += 4 * GS_T) {
-		int32_t q[4][4];
+		int32_t q[4][5];
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
 			const int h = gb + (x0 + u * GS_T < n ? x0 + u * GS_T : x0);
-			q[u][0] = a.o.gid[h], q[u][1] = a.o.pid[h], q[u][2] = a.o.rank[h], q[u][3] = a.o.nex[h];
+			q[u][0] = a.o.gid[h], q[u][1] = a.o.pid[h], q[u][2] = a.o.rank[h], q[u][3] = a.o.nex[h], q[u][4] = a.o.sori[h];
 		}
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
 			if (x0 + u * GS_T >= n) break;
 			const int h = gb + x0 + u * GS_T;
 			((int32_t *)&a.B[h])[1] = q[u][0], ((int32_t *)&a.B[h])[3] = q[u][1];
-			((int32_t *)&a.C[h])[0] = q[u][2], ((int32_t *)&a.C[h])[1] = q[u][3];
+			((int32_t *)&a.C[h])[0] = q[u][2], ((int32_t *)&a.C[h])[1] = q[u][3], ((int32_t *)&a.C[h])[3] = q[u][4];
 		}
 	}
 	GS_STAMP(12);
 }
 
-// two instantiations: up to 14 items per thread with the loads three planes ahead, up to 25 with the loads two planes ahead
+// two instantiations: up to 14 items per thread with the loads two planes ahead, up to 25 with the loads one plane ahead (registers)
 __global__ __launch_bounds__(GS_T, 4) void k_genome_sort(GenomeSort a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char gs_mem[];
-	gs_body<GS_K_SMALL, 3>(a, gs_mem);
+	gs_body<GS_K_SMALL, 2>(a, gs_mem);
 }
 __global__ __launch_bounds__(GS_T, 4) void k_genome_sort_big(GenomeSort a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char gs_mem_big[];
-	gs_body<GS_K_BIG, 2>(a, gs_mem_big);
+	gs_body<GS_K_BIG, 1>(a, gs_mem_big);
 }

@@ -3,12 +3,14 @@
 // "must be rebuilt on host"); what matters here is that ids, ranks, exon lists, cm and score_adj come
 // out exactly as the reference's reader produces them (read.c:107-236, hit.c:14-27), because
 // pg_hash_uint32(pid) and the first-seen numbering are score-relevant downstream.
+#include <sys/stat.h>
 #include <zlib.h>
 #include <cctype>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <thread>
@@ -49,7 +51,7 @@ class LineSource {
 public:
 	explicit LineSource(const char *fn) {
 		fp_ = (fn && std::strcmp(fn, "-") != 0) ? gzopen(fn, "r") : gzdopen(0, "r");
-		if (fp_) gzbuffer(fp_, 1 << 18);
+		if (fp_) gzbuffer(fp_, 1 << 16); // (below the allocator's mmap threshold: a buffer that is mapped and unmapped per file costs every thread of the process a TLB shoot-down)
 		buf_.resize(1 << 16);
 	}
 	~LineSource() { if (fp_) gzclose(fp_); }
@@ -84,6 +86,17 @@ private:
 	int beg_ = 0, end_ = 0;
 	bool eof_ = false;
 };
+
+// strtol(q, 0, 10) for the digit strings of a PAF line: optional blanks and sign, then digits (anything else ends the number)
+static inline int64_t parse_i64(const char *q)
+{
+	while (*q == ' ') ++q;
+	bool neg = false;
+	if (*q == '-') neg = true, ++q; else if (*q == '+') ++q;
+	int64_t v = 0;
+	while ((unsigned)(*q - '0') < 10u) v = v * 10 + (*q - '0'), ++q;
+	return neg ? -v : v;
+}
 
 // grow helpers keeping the reference's malloc/realloc ownership (pg_data_destroy frees with free())
 template <class T> static void grow0(T *&ptr, int32_t idx, int32_t &cap)
@@ -200,10 +213,20 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 	if (!src.ok()) return;
 	fp.opened = true;
 	fp.label = file_label(fn);
+	if (!ids_only && fn && std::strcmp(fn, "-") != 0) { // room for the whole file at once (~150 bytes of text a line; a .gz holds 4-5 times its size)
+		struct stat sb;
+		if (stat(fn, &sb) == 0 && sb.st_size > 0) {
+			const size_t len = std::strlen(fn);
+			const size_t text = (size_t)sb.st_size * (len > 3 && std::strcmp(fn + len - 3, ".gz") == 0 ? 5 : 1);
+			fp.m_hit = (int32_t)std::min<size_t>(text / 120 + 64, (size_t)1 << 30), fp.hits = (pg_hit_t *)std::malloc(sizeof(pg_hit_t) * (size_t)fp.m_hit);
+			fp.m_exon = (int32_t)std::min<size_t>(text / 100 + 64, (size_t)1 << 30), fp.exons = (pg_exon_t *)std::malloc(sizeof(pg_exon_t) * (size_t)fp.m_exon);
+		}
+	}
 	const NameDict *excl = (const NameDict *)opt->excl, *incl = (const NameDict *)opt->incl, *pref = (const NameDict *)opt->preferred;
 	std::vector<int32_t> rank_of; // per local protein: lines seen in this file (read.c:170)
 	std::vector<pg_exon_t> ex;
-	std::string line;
+	std::string line, last_name;
+	int32_t last_pid = -1, last_gid = -1;
 	while (src.next(line)) {
 		++fp.n_tot;
 		pg_hit_t hit;
@@ -215,11 +238,20 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 		char *q = s;
 		int32_t col = 0;
 		bool dropped = false;
+		char *const line_end = s + line.size();
 		for (char *p = s;; ++p) {
-			if (*p != '\t' && *p != 0) continue;
+			p = (char *)std::memchr(p, '\t', (size_t)(line_end - p));
+			if (p == nullptr) p = line_end;
 			char term = *p;
 			*p = 0;
-			if (col == 0) { // query name: gene<delim>protein (read.c:139-171)
+			if (col == 0 && last_pid >= 0 && (size_t)(p - q) == last_name.size() && std::memcmp(q, last_name.data(), last_name.size()) == 0) {
+				// the same protein as the line before (PAF files are grouped by protein as a rule): the ids are known, and what the
+				// dictionary calls would do again -- preferred / included marks, prot.gid, prot.len = 0 -- has the same outcome
+				pid = last_pid, gid = last_gid;
+				fp.p_len[(size_t)pid] = 0; // read.c:168
+				hit.pid = pid;
+				hit.rank = ++rank_of[(size_t)pid];
+			} else if (col == 0) { // query name: gene<delim>protein (read.c:139-171)
 				char *r = q;
 				while (r < p && *r != opt->gene_delim) ++r;
 				if (excl && excl->get(q) >= 0) { dropped = true; break; }
@@ -238,14 +270,15 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 				fp.p_len[(size_t)pid] = 0; // read.c:168
 				hit.pid = pid;
 				hit.rank = ++rank_of[(size_t)pid];
+				last_pid = pid, last_gid = gid, last_name.assign(q, (size_t)(p - q));
 			} else if (col == 1) {
-				int32_t len = (int32_t)std::strtol(q, nullptr, 10);
+				int32_t len = (int32_t)parse_i64(q);
 				fp.p_len[(size_t)pid] = len;
 				if (fp.g_len[(size_t)gid] < len) fp.g_len[(size_t)gid] = len;
 				if (ids_only) { dropped = true; break; }
-			} else if (col == 2) hit.qs = (int32_t)std::strtol(q, nullptr, 10);
+			} else if (col == 2) hit.qs = (int32_t)parse_i64(q);
 			else if (col == 3) {
-				hit.qe = (int32_t)std::strtol(q, nullptr, 10);
+				hit.qe = (int32_t)parse_i64(q);
 				if (hit.qe - hit.qs < fp.p_len[(size_t)pid] * opt->min_prot_ratio) { dropped = true; break; }
 			} else if (col == 4) {
 				if (*q != '+' && *q != '-') { dropped = true; break; }
@@ -254,21 +287,21 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 				bool a2;
 				hit.cid = fp.ctgs.put(q, &a2);
 				if (a2) fp.ctg_len.push_back(0);
-			} else if (col == 6) fp.ctg_len[(size_t)hit.cid] = std::strtol(q, nullptr, 10);
-			else if (col == 7) hit.cs = std::strtol(q, nullptr, 10);
-			else if (col == 8) hit.ce = std::strtol(q, nullptr, 10);
-			else if (col == 9) hit.mlen = (int32_t)std::strtol(q, nullptr, 10);
+			} else if (col == 6) fp.ctg_len[(size_t)hit.cid] = parse_i64(q);
+			else if (col == 7) hit.cs = parse_i64(q);
+			else if (col == 8) hit.ce = parse_i64(q);
+			else if (col == 9) hit.mlen = (int32_t)parse_i64(q);
 			else if (col == 10) {
-				hit.blen = (int32_t)std::strtol(q, nullptr, 10);
+				hit.blen = (int32_t)parse_i64(q);
 				if (hit.mlen < hit.blen * opt->min_prot_iden) { dropped = true; break; }
 			} else if (col >= 12) {
 				if (std::strncmp(q, "ms:i:", 5) == 0) { // read.c:212-216: long double exp, then truncation
 					double div = 1.0 - (double)hit.mlen / hit.blen;
 					double uncov = 1.0 - (double)(hit.qe - hit.qs) / fp.p_len[(size_t)pid];
-					hit.score_ori = (int32_t)std::strtol(q + 5, nullptr, 10);
+					hit.score_ori = (int32_t)parse_i64(q + 5);
 					hit.score_adj = (int32_t)(hit.score_ori * expl(-opt->score_adj_coef * (div + uncov)) + .499);
-				} else if (std::strncmp(q, "fs:i:", 5) == 0) n_fs = (int32_t)std::strtol(q + 5, nullptr, 10);
-				else if (std::strncmp(q, "st:i:", 5) == 0) n_stop = (int32_t)std::strtol(q + 5, nullptr, 10);
+				} else if (std::strncmp(q, "fs:i:", 5) == 0) n_fs = (int32_t)parse_i64(q + 5);
+				else if (std::strncmp(q, "st:i:", 5) == 0) n_stop = (int32_t)parse_i64(q + 5);
 				else if (std::strncmp(q, "cg:Z:", 5) == 0) {
 					if (cigar_to_exons(q + 5, hit.rev, hit.ce - hit.cs, ex, &cig_fs)) {
 						hit.n_exon = (int32_t)ex.size(), hit.off_exon = fp.n_exon, hit.lof = cig_fs;
@@ -291,17 +324,31 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 	}
 }
 
-// Names that are in the global dictionaries already get their ids before the commit (read-only look-ups, any thread, under
-// the reader side of g_dict_mu): a pangenome's files share nearly all their names, so the sequential part of a batch read
-// shrinks from "every name of every file" to the names a file is the first to bring.
-static std::shared_mutex g_dict_mu;
-static void preresolve(const pg_data_t *d, FileParse &fp)
+// Names that are in the global dictionaries already get their ids before the commit, from a frozen SNAPSHOT of the dictionaries
+// (an immutable map published by the committing thread after the first file and whenever a thousand names have come since):
+// look-ups need no lock and never wait for a commit, the commit never waits for a reader.  A pangenome's files share nearly all
+// their names, so the sequential part of a batch read shrinks from "every name of every file" to the names a file is the first
+// to bring (names missing from the snapshot are resolved by the commit itself).
+struct DictSnap { std::unordered_map<std::string_view, int32_t> genes, prots; };
+static std::shared_mutex g_dict_mu; // writers of pg_data_t's growing arrays (batch and single-file reads)
+
+static void snap_refresh(const pg_data_t *d, std::shared_ptr<const DictSnap> &slot)
 {
 	const NameDict *dg = (const NameDict *)d->d_gene, *dp = (const NameDict *)d->d_prot;
+	auto s = std::make_shared<DictSnap>();
+	s->genes.reserve((size_t)dg->size() * 2), s->prots.reserve((size_t)dp->size() * 2);
+	for (int32_t i = 0; i < dg->size(); ++i) s->genes.emplace(std::string_view(dg->name(i)), i);
+	for (int32_t i = 0; i < dp->size(); ++i) s->prots.emplace(std::string_view(dp->name(i)), i);
+	std::atomic_store(&slot, std::shared_ptr<const DictSnap>(s));
+}
+
+static void preresolve(const std::shared_ptr<const DictSnap> &slot, FileParse &fp)
+{
 	fp.gmap.assign((size_t)fp.genes.size(), -1), fp.pmap.assign((size_t)fp.prots.size(), -1);
-	std::shared_lock<std::shared_mutex> lk(g_dict_mu);
-	for (int32_t i = 0; i < fp.genes.size(); ++i) fp.gmap[(size_t)i] = dg->get(fp.genes.name(i));
-	for (int32_t i = 0; i < fp.prots.size(); ++i) fp.pmap[(size_t)i] = dp->get(fp.prots.name(i));
+	const std::shared_ptr<const DictSnap> s = std::atomic_load(&slot);
+	if (!s) return;
+	for (int32_t i = 0; i < fp.genes.size(); ++i) { auto it = s->genes.find(std::string_view(fp.genes.name(i))); if (it != s->genes.end()) fp.gmap[(size_t)i] = it->second; }
+	for (int32_t i = 0; i < fp.prots.size(); ++i) { auto it = s->prots.find(std::string_view(fp.prots.name(i))); if (it != s->prots.end()) fp.pmap[(size_t)i] = it->second; }
 }
 
 // sequential part: global ids in first-seen order (the numbering of per-line dict_put calls, read.c:151-168), genome appended to `d`
@@ -425,7 +472,7 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 	if (n <= 0) return 0;
 	if (n_threads <= 0) {
 		const char *e = std::getenv("PANGENE_READ_THREADS");
-		n_threads = e && std::atoi(e) > 0 ? std::atoi(e) : (int32_t)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 128u);
+		n_threads = e && std::atoi(e) > 0 ? std::atoi(e) : (int32_t)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u); // (beyond that the threads of one address space get in each other's way: page faults, allocator)
 	}
 	if (n_threads > n) n_threads = n;
 	DataExt *ext = ext_of(d, true);
@@ -441,18 +488,35 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 		ext->is_local.resize((size_t)(j0 + n), 0), ext->hits_sorted.resize((size_t)(j0 + n), 0);
 		ext->packs.resize((size_t)(j0 + n));
 	}
+	std::thread slab_helper;
+	{ // the blocks of the local files take about 0.4 bytes per byte of PAF text (44 B a hit + 8 B an exon against ~150 B a line)
+		size_t text = 0;
+		for (int32_t i = 0; i < n; ++i) {
+			struct stat sb;
+			if (!(ids_only && ids_only[i]) && fns[i] && stat(fns[i], &sb) == 0) text += (size_t)sb.st_size;
+		}
+		if (text > ((size_t)64 << 20)) slab_prefetch(std::min<size_t>(text / 5 * 2, (size_t)192 << 20), &slab_helper); // (up to the budget of freshly locked memory: block_alloc)
+	}
 	std::vector<FileParse> fp((size_t)n);
 	std::vector<std::atomic<uint8_t>> state((size_t)n); // 0 new, 1 parsed, 2 committed (ids final), 3 being / has been finished
 	for (auto &x : state) x.store(0);
 	std::atomic<int32_t> next_parse{0}, n_commit{0}, next_final{0}, n_fail{0};
+	static const bool timing = std::getenv("PANGENE_TIMING") != nullptr;
+	std::atomic<int64_t> us_parse{0}, us_resolve{0}, us_commit{0}, us_final{0};
+	const double t_batch0 = now_sec();
 	std::mutex commit_mu;
+	std::shared_ptr<const DictSnap> snap; // published with atomic_store by whoever commits
+	int32_t snap_names = 0;
 	auto try_commit = [&]() {
 		std::unique_lock<std::mutex> lk(commit_mu, std::try_to_lock);
 		if (!lk.owns_lock()) return; // somebody else is at it (and will see what this thread just parsed: it re-checks before it leaves)
 		for (;;) {
 			const int32_t k = n_commit.load();
 			if (k >= n || state[(size_t)k].load() != 1) break;
+			const double tc0 = timing ? now_sec() : 0.0;
 			if (commit_ids(d, fp[(size_t)k]) != 0) n_fail.fetch_add(1);
+			if (d->n_gene + d->n_prot >= snap_names + 1000 || (k == 0 && d->n_gene + d->n_prot > 0)) snap_refresh(d, snap), snap_names = d->n_gene + d->n_prot;
+			if (timing) us_commit.fetch_add((int64_t)((now_sec() - tc0) * 1e6));
 			state[(size_t)k].store(2);
 			n_commit.store(k + 1);
 		}
@@ -463,9 +527,11 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 			if (k >= n || state[(size_t)k].load() < 2) return false;
 			if (!next_final.compare_exchange_weak(k, k + 1)) continue;
 			FileParse &f = fp[(size_t)k];
+			const double tf0 = timing ? now_sec() : 0.0;
 			finalize_genome(d, f);
 			if (f.opened && !f.ids_only && f.genome >= 0) pack_genomes(d, ext, f.genome, f.genome + 1, 1.0 / n_threads); // (one genome: on this thread)
 			{ FileParse done; std::swap(done.genes, f.genes), std::swap(done.prots, f.prots), std::swap(done.ctgs, f.ctgs); } // the names are not needed any more
+			if (timing) us_final.fetch_add((int64_t)((now_sec() - tf0) * 1e6));
 			state[(size_t)k].store(3);
 			return true;
 		}
@@ -474,8 +540,11 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 		for (;;) {
 			const int32_t i = next_parse.fetch_add(1);
 			if (i < n) {
+				const double tp0 = timing ? now_sec() : 0.0;
 				parse_file(opt, fns[i], ids_only && ids_only[i], fp[(size_t)i]);
-				if (fp[(size_t)i].opened) preresolve(d, fp[(size_t)i]);
+				const double tp1 = timing ? now_sec() : 0.0;
+				if (fp[(size_t)i].opened) preresolve(snap, fp[(size_t)i]);
+				if (timing) us_parse.fetch_add((int64_t)((tp1 - tp0) * 1e6)), us_resolve.fetch_add((int64_t)((now_sec() - tp1) * 1e6));
 				state[(size_t)i].store(1);
 				try_commit();
 				// (a commit that was skipped because another thread held the lock: that thread may have left just before this
@@ -493,6 +562,10 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 	for (int32_t t = 1; t < n_threads; ++t) th.emplace_back(work);
 	work();
 	for (auto &x : th) x.join();
+	const double t_joined = now_sec();
+	if (slab_helper.joinable()) slab_helper.join();
+	if (timing) std::fprintf(stderr, "[pg_read_paf_batch] %d files on %d threads: %.1f ms wall (+ %.1f ms for the slab helper); summed over the threads: parsing %.1f ms, name look-ups %.1f ms, finishing (ids in place + SoA block) %.1f ms; the sequential commits %.1f ms\n",
+	                         n, n_threads, (t_joined - t_batch0) * 1e3, (now_sec() - t_joined) * 1e3, us_parse.load() * 1e-3, us_resolve.load() * 1e-3, us_final.load() * 1e-3, us_commit.load() * 1e-3);
 	exact_prefetch(d, ext); // the replay of the reference's tie order starts in the background
 	return -n_fail.load();
 }

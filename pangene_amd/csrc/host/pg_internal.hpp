@@ -60,7 +60,7 @@ struct GenomePack {
 	int err = 0;                              // PGA_ERR_RANGE: a coordinate does not fit the device layout
 	uint64_t sig = 0;                         // what the genome looked like when it was packed (graph_driver.cpp: genome_signature)
 };
-struct HostSlab { char *p = nullptr; size_t cap = 0, off = 0; bool pinned = false; };
+struct HostSlab { char *p = nullptr; size_t cap = 0, off = 0; bool pinned = false, fresh = false; }; // fresh: page-locked for this very read (not taken from the cache)
 
 // host-private companion of a pg_data_t (struct layout of pg_data_t itself must not change)
 struct DataExt {
@@ -107,6 +107,7 @@ DataExt *ext_of(const pg_data_t *d, bool create);
 // pack the genomes [j0, j1) that have no pack yet (host threads); called by the reader after the commit and by the driver as a fallback
 void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, double time_share = 1.0); // time_share: fraction of the call's wall time booked as packing time (calls that run side by side on n threads: 1 / n)
 void trim_host_caches(size_t keep_bytes);
+void slab_prefetch(size_t bytes, std::thread *helper); // page-lock about `bytes` of block memory ahead, on a helper thread the caller joins
 void free_packs(DataExt *ext, bool wait);
 void ext_drop(const pg_data_t *d);
 

@@ -485,3 +485,26 @@ def write_files(gen: Iterator[Tuple[str, str]], out_dir: str, gz: bool = False) 
                 f.write(text)
         paths.append(p)
     return paths
+
+
+def write_files_parallel(kind: str, out_dir: str, n_proc: int = 0, **kw) -> List[str]:
+    """write_files for the big sets, by a few fresh interpreters side by side (every genome is seeded on its own, so any split of
+    [0, G) gives the same files; fresh processes -- not forks -- because the caller may hold a GPU context).
+    kind: "bact" (G, P, seed) or "human" (G, Q, iso, seed, frag)."""
+    import subprocess, sys
+    G = int(kw["G"])
+    n_proc = n_proc or max(1, min(G, min(os.cpu_count() or 1, 64)))
+    os.makedirs(out_dir, exist_ok=True)
+    procs = []
+    for k in range(n_proc):
+        a, b = G * k // n_proc, G * (k + 1) // n_proc
+        if a == b:
+            continue
+        arg = dict(kw, first=a, last=b)
+        code = "import sys; sys.path.insert(0, %r); from pangene_amd import synth; synth.write_files(synth.%s(**%r), %r)" % (
+            os.path.dirname(os.path.dirname(os.path.abspath(__file__))), kind, arg, out_dir)
+        procs.append(subprocess.Popen([sys.executable, "-c", code]))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("a generator process failed")
+    return sorted(os.path.join(out_dir, f) for f in os.listdir(out_dir))

@@ -237,7 +237,7 @@ def _expected_large(name, variant):
 def test_config1_full_size_against_reference(hip, tmp_path):
     """BASELINE configs[1]: bact(100, 5000), ~1 M hits: GFA bit-identical to the reference binary (run here when it was shipped,
     explicit skip of that half otherwise); rerun on the HBM-resident shard is idempotent."""
-    files = synth.write_files(synth.bact(100, 5000, seed=1), str(tmp_path / "c2"))
+    files = synth.write_files_parallel("bact", str(tmp_path / "c2"), G=100, P=5000, seed=1)
     hip.pg_set_exact_mode(1)
     a = capi.run(hip, files, [])
     b = capi.run(hip, files, [])
@@ -260,7 +260,7 @@ def test_config2_human47_full_size_md5(hip, tmp_path_factory, variant):
     e = _expected_large("human47x20k", variant)
     d = tmp_path_factory.getbasetemp() / "human47"
     if not d.exists():
-        synth.write_files(synth.human(47, 20000, iso=1.0, seed=1, frag=True), str(d))
+        synth.write_files_parallel("human", str(d), G=47, Q=20000, iso=1.0, seed=1, frag=True)
     files = sorted(str(d / f) for f in os.listdir(d))
     hip.pg_set_exact_mode(1)
     out = capi.run(hip, files, variant.split())
@@ -271,9 +271,20 @@ def test_config3_per_gpu_shard_full_size_md5(hip, tmp_path):
     """the per-GPU shard of BASELINE configs[3] (1250 x 5 k bacterial genomes, ~12 M hits, past the Infinity Cache): md5 of the GFA
     equal to the untouched reference's (recorded in the build container)"""
     e = _expected_large("bact1250x5k", "")
-    files = synth.write_files(synth.bact(1250, 5000, seed=1), str(tmp_path / "c3"))
+    files = synth.write_files_parallel("bact", str(tmp_path / "c3"), G=1250, P=5000, seed=1)
     hip.pg_set_exact_mode(1)
     out = capi.run(hip, files, [])
+    assert len(out) == e["bytes"] and hashlib.md5(out).hexdigest() == e["md5"]
+
+
+def test_config4_per_gpu_shard_full_size_md5(hip, tmp_path):
+    """the per-GPU shard of BASELINE configs[4] (200 assemblies x ~110 k all-isoform proteins over 8 GPUs, -p0 -a1): 25 human-shaped
+    haplotypes x 20 k genes x 5.5 isoforms (~110 k proteins, ~2.8 M hits, genomes of ~110 k hits: beyond k_genome_sort's LDS budget,
+    so stage A's orders take the multi-workgroup radix sort): md5 of the GFA equal to the untouched reference's"""
+    e = _expected_large("human25x20k_iso5.5", "-p0 -a1")
+    files = synth.write_files_parallel("human", str(tmp_path / "c4"), G=25, Q=20000, iso=5.5, seed=1, frag=True)
+    hip.pg_set_exact_mode(1)
+    out = capi.run(hip, files, ["-p0", "-a1"])
     assert len(out) == e["bytes"] and hashlib.md5(out).hexdigest() == e["md5"]
 
 
