@@ -75,9 +75,14 @@ typedef struct {
 } pga_genome_block_t;
 
 /* One shard = a set of genomes with all their hits (pg_hit_t pangene.h:61-72, pg_exon_t 44-46, pg_genome_t 79-87).
+ * Every hit is checked on the device against what its block declares (contig id < n_ctg, 0 <= cs <= ce, cs <= max_cs, cm <= max_cm,
+ * score_adj <= max_score_adj or any_neg_score_adj, exon range inside the block's exon list, n_exon > 1 only with any_multi_exon):
+ * pga_create answers PGA_ERR_RANGE for a block that breaks its own declaration instead of indexing out of bounds later.
  * Device layout limits (PGA_ERR_RANGE otherwise): contig coordinates < 2^31 (pangene.h:71 has int64), < 2^30 hits and < 2^31
  * exons per shard, < 2^20 genes, < 2^24 genomes. */
+#define PGA_ABI_VERSION 3u  /* bumped whenever a struct of this header or the order of pga_backend_t changes; pga_create refuses another */
 typedef struct {
+	uint32_t abi_version;        /* = PGA_ABI_VERSION of the header the caller was compiled against (PGA_ERR_ARG otherwise) */
 	int32_t n_genome;            /* genomes in this shard (may include genomes with 0 hits) */
 	int32_t n_genome_global;     /* G of the whole run (all shards) */
 	const int32_t *genome_global;/* [n_genome] global genome index of each local genome */

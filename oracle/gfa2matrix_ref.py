@@ -76,7 +76,12 @@ def gfa2matrix(gfa_lines, copy_number=False, clstr_lines=None, print_cd=False):
                 if m:
                     b.append((m.group(1), m.group(2) == "*"))
         process(b)
-        for g, p in paralog.items():
+        def js_key_order(keys):  # `for (const g in paralog)`: integer-like keys first, ascending; then the others in insertion order
+            ints = sorted((int(k), k) for k in keys if re.fullmatch(r"0|[1-9][0-9]{0,9}", k) and int(k) < 4294967295)
+            isint = {k for _, k in ints}
+            return [k for _, k in ints] + [k for k in keys if k not in isint]
+        for g in js_key_order(list(paralog)):
+            p = paralog[g]
             if g in segname and p in segname:
                 for i in range(len(asm_a)):
                     mat[segname[p]][i] += mat[segname[g]][i]

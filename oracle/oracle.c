@@ -156,7 +156,7 @@ int pgo_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
 {
 	pga_ctx_t *c;
 	int64_t N = sh->n_hit, i;
-	if (out == 0 || sh == 0 || par == 0) return PGA_ERR_ARG;
+	if (out == 0 || sh == 0 || par == 0 || sh->abi_version != PGA_ABI_VERSION) return PGA_ERR_ARG;
 	c = CALLOC(pga_ctx_t, 1);
 	c->n_genome = sh->n_genome, c->n_genome_global = sh->n_genome_global, c->n_prot = sh->n_prot, c->n_gene = sh->n_gene;
 	c->n_hit = N, c->n_exon = sh->n_exon, c->par = *par;

@@ -8,17 +8,29 @@
 // The shard arrives as one block per genome (pga_genome_block_t: 10 planes of n_hit int32, rev bytes, exon pairs), copied as
 // it is into `raw`.  One pass spreads the blocks into flat file-order arrays (plane f of the shard at up + f * N; rev bytes at
 // plane 14) and makes the exon offsets shard-wide.
-__global__ __launch_bounds__(BLOCK) void k_unblock(const int32_t *raw, const int64_t *woff, const int32_t *goff, const int32_t *eoff, int n_genome, int n, int32_t *up)
+// The blocks are also CHECKED here (once per upload): a hit whose contig id, coordinates or exon range lie outside what its genome
+// block declares (n_ctg, n_exon, max_cs, max_cm, max_score_adj, the two any_* marks) would index out of bounds or lose key bits
+// later on -- dcnt[8] counts them and pga_create answers PGA_ERR_RANGE.
+__global__ __launch_bounds__(BLOCK) void k_unblock(const int32_t *raw, const int64_t *woff, const int32_t *goff, const int32_t *eoff, int n_genome, int n, int32_t *up,
+                                                     const int32_t *ctg_base, int32_t max_cs, int32_t max_cm, int32_t max_sadj, int neg_sadj, int multi, int n_prot, int64_t *dcnt)
 {
 	const int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
 	const int g = genome_of(goff, n_genome, i), li = i - goff[g], ng = goff[g + 1] - goff[g];
 	const int32_t *b = raw + woff[g];
+	int32_t w[PGA_BLOCK_PLANES];
 #pragma unroll
 	for (int f = 0; f < PGA_BLOCK_PLANES; ++f) {
 		int32_t v = b[(int64_t)f * ng + li];
+		w[f] = v;
 		if (f == 6) v += eoff[g]; // off_exon
 		up[(int64_t)f * n + i] = v;
+	}
+	{ // planes: 0 pid, 1 contig, 2 rank, 3 score_ori, 4 score_adj, 5 n_exon, 6 off_exon, 7 cs, 8 ce, 9 cm
+		const int n_ctg = ctg_base[g + 1] - ctg_base[g], n_ex = eoff[g + 1] - eoff[g];
+		const bool bad = w[1] < 0 || w[1] >= n_ctg || w[7] < 0 || w[8] < w[7] || w[9] < 0 || w[7] > max_cs || w[9] > max_cm || w[5] < 0 || w[6] < 0 || w[6] + w[5] > n_ex ||
+		                 (w[4] < 0 ? !neg_sadj : w[4] > max_sadj) || (w[5] != 1 && !multi) || w[0] < 0 || w[0] >= n_prot;
+		if (bad) atomicAdd((unsigned long long *)&dcnt[8], 1ull);
 	}
 	((uint8_t *)(up + 14 * (int64_t)n))[i] = ((const uint8_t *)(b + (int64_t)PGA_BLOCK_PLANES * ng))[li];
 }

@@ -260,16 +260,17 @@ static int sync_st(pga_ctx *c)
 {
 	static const bool poll = [] { const char *e = getenv("PANGENE_WAIT"); return !(e && strcmp(e, "sync") == 0); }();
 	++c->sync_epoch;
-	if (poll) {
+	if (poll) { // poll for up to ~200 us (the waits of a pass are 20-30 us as a rule), then let the runtime park the thread:
+		// a rank must not burn a core through a wait of milliseconds (the queued branch rounds; several ranks share a node)
 		timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
 		for (unsigned long long it = 1;; ++it) {
 			const hipError_t e = hipStreamQuery(c->st);
 			if (e == hipSuccess) return 0;
 			if (e != hipErrorNotReady) HIPCHK(e);
 			__builtin_ia32_pause();
-			if ((it & 0x3ff) == 0) {
+			if ((it & 0x3f) == 0) {
 				timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
-				if ((t.tv_sec - t0.tv_sec) + (t.tv_nsec - t0.tv_nsec) * 1e-9 > 2.0) break; // something is wrong or very slow: let the runtime wait and tell
+				if ((t.tv_sec - t0.tv_sec) + (t.tv_nsec - t0.tv_nsec) * 1e-9 > 200e-6) break;
 			}
 		}
 	}
@@ -501,7 +502,8 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(upload(c, c->prot_gid, sh->prot_gid, c->P)); TRY(upload(c, c->gene_pref, sh->gene_pref, c->Q));
 	// half-arc records are validated by a round tag: none may survive from an earlier context whose memory this one inherited
 	if (N) { HIPCHK(hipMemsetAsync(c->hfk, 0xff, sizeof(uint32_t) * (size_t)N, c->st)); HIPCHK(hipMemsetAsync(c->hbk, 0xff, sizeof(uint32_t) * (size_t)N, c->st)); }
-	if (N) hipLaunchKernelGGL(k_unblock, dim3(nblk(N)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, N, up);
+	HIPCHK(hipMemsetAsync(c->dcnt, 0, 16 * sizeof(int64_t), c->st));
+	if (N) hipLaunchKernelGGL(k_unblock, dim3(nblk(N)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, N, up, c->ctg_base, (int32_t)max_cs, (int32_t)max_cm, (int32_t)max_sadj, neg_sadj ? 1 : 0, multi ? 1 : 0, c->P, c->dcnt);
 	if (E) hipLaunchKernelGGL(k_unblock_exons, dim3(nblk(E)), dim3(BLOCK), 0, c->st, raw, c->woff, c->goff, c->eoff, GL, E, c->exon);
 	{ // work buffers shared by every sort / scan of the run: sized for the largest input (2N temp arcs)
 		const int64_t W = std::max<int64_t>(2 * (int64_t)N + 2, (int64_t)c->P + 2);
@@ -525,7 +527,12 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		                   up + 10 * (size_t)N, up + 11 * (size_t)N, up + 12 * (size_t)N, up + 13 * (size_t)N, (uint64_t *)c->pool.get(S_KEY_A, 0), (uint32_t *)c->pool.get(S_VAL_A, 0),
 		                   c->rk_shift, c->hrank, up + 15 * (size_t)N, up + 16 * (size_t)N);
 	}
-	const int rc = sync_st(c); // the caller's blocks and tables have been read
+	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	int rc = sync_st(c); // the caller's blocks and tables have been read
+	if (rc == 0 && c->h_cnt[8]) { // k_unblock: a hit outside the device layout, or beyond what its block declared (direct users of this ABI: the host driver checks while it packs)
+		fprintf(stderr, "[E::pga_create] %lld hit(s) with coordinates, contig ids or scores outside what their genome block declares\n", (long long)c->h_cnt[8]);
+		rc = PGA_ERR_RANGE;
+	}
 	if (timing) fprintf(stderr, "[pga_create] allocations %.3f ms, upload of %.1f MB + unpack %.3f ms\n", (t1 - t0) * 1e3, woff[(size_t)GL] * 4e-6, (now() - t1) * 1e3);
 	return rc;
 }
@@ -618,6 +625,7 @@ extern "C" int pga_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_para
 		fprintf(stderr, "[E::pga_create] no HIP device is visible; libpangene_amd has no CPU fallback\n");
 		return PGA_ERR_NO_DEVICE;
 	}
+	if (sh->abi_version != PGA_ABI_VERSION) { fprintf(stderr, "[E::pga_create] the caller was built against ABI version %u of pangene_hip.h, this library implements %u\n", sh->abi_version, (unsigned)PGA_ABI_VERSION); return PGA_ERR_ARG; }
 	if (sh->n_hit >= (1 << 30) /* arc table positions are 2 * (gene-major index) in 32 bits */ || sh->n_exon >= INT32_MAX || sh->n_gene >= (1 << 20) || sh->n_genome_global >= (1 << 24)) return PGA_ERR_RANGE;
 	pga_ctx *c = new pga_ctx();
 	c->n_genome = sh->n_genome, c->n_genome_global = sh->n_genome_global, c->P = sh->n_prot, c->Q = sh->n_gene;

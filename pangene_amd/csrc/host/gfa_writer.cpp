@@ -5,6 +5,7 @@
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
+#include <regex>
 #include <string>
 #include <unordered_map>
 #include "pg_internal.hpp"
@@ -309,29 +310,30 @@ int pg_gfa2matrix_file(const char *gfa_fn, int32_t copy_number, const char *clst
 				}
 			b.clear();
 		};
+		static const std::regex re_member("^\\d+\\s+\\S+,\\s+>(\\S+)\\.\\.\\.\\s+(\\S+)"); // the script's own pattern (pangene.js:1223), ECMAScript semantics
 		for (const std::string &l : cl) {
 			if (!l.empty() && l[0] == '>') { process(); continue; }
-			// ^\d+\s+\S+,\s+>(\S+)\.\.\.\s+(\S+)
-			size_t i = 0;
-			while (i < l.size() && std::isdigit((unsigned char)l[i])) ++i;
-			if (i == 0) continue;
-			size_t j2 = i;
-			while (j2 < l.size() && std::isspace((unsigned char)l[j2])) ++j2;
-			if (j2 == i) continue;
-			const size_t gt = l.find(", >", j2);
-			size_t gt2 = l.find(">", j2);
-			if (gt == std::string::npos && gt2 == std::string::npos) continue;
-			const size_t nm0 = l.find('>', j2) + 1, dots = l.find("...", nm0);
-			if (nm0 == 0 || dots == std::string::npos) continue;
-			size_t r = dots + 3;
-			while (r < l.size() && std::isspace((unsigned char)l[r])) ++r;
-			if (r >= l.size()) continue;
-			size_t re = r;
-			while (re < l.size() && !std::isspace((unsigned char)l[re])) ++re;
-			b.emplace_back(l.substr(nm0, dots - nm0), l.substr(r, re - r) == "*");
+			std::smatch m;
+			if (std::regex_search(l, m, re_member)) b.emplace_back(m[1].str(), m[2].str() == "*");
 		}
 		process();
-		for (const std::string &g : paralog_order) { // (the reference iterates its hash in insertion order)
+		// `for (const g in paralog)`: JavaScript visits integer-like keys first, in ascending numeric order, then the others in
+		// insertion order -- and the order matters when a paralog's target is itself a paralog
+		std::vector<std::string> order;
+		{
+			std::vector<std::pair<uint64_t, std::string>> ints;
+			for (const std::string &g : paralog_order) {
+				bool idx = !g.empty() && g.size() <= 10 && (g.size() == 1 || g[0] != '0');
+				uint64_t v = 0;
+				for (char ch : g) { if (ch < '0' || ch > '9') { idx = false; break; } v = v * 10 + (uint64_t)(ch - '0'); }
+				if (idx && v < 4294967295ull) ints.emplace_back(v, g);
+			}
+			std::sort(ints.begin(), ints.end());
+			std::unordered_map<std::string, bool> is_int;
+			for (auto &x : ints) order.push_back(x.second), is_int[x.second] = true;
+			for (const std::string &g : paralog_order) if (!is_int.count(g)) order.push_back(g);
+		}
+		for (const std::string &g : order) {
 			const std::string &pp = paralog[g];
 			auto gi = seg_h.find(g), pi = seg_h.find(pp);
 			if (gi == seg_h.end() || pi == seg_h.end()) continue;

@@ -364,6 +364,7 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	for (int32_t q = 0; q < d->n_gene; ++q) gpref[(size_t)q] = d->gene[q].preferred;
 	pga_shard_t sh;
 	std::memset(&sh, 0, sizeof(sh));
+	sh.abi_version = PGA_ABI_VERSION;
 	sh.n_genome = nl, sh.n_genome_global = d->n_genome, sh.genome_global = ext->local_genomes.data();
 	sh.n_prot = d->n_prot, sh.n_gene = d->n_gene, sh.n_hit = N, sh.n_exon = E;
 	sh.block = blk.data(), sh.prot_gid = pgid.data(), sh.gene_pref = gpref.data();

@@ -468,3 +468,46 @@ def test_ranks_over_native_rccl(built, expected, name, variant, world):
     assert all(x == sl[0] for x in sl)
     w = b"\n".join(l for r in range(world) for l in res[r].split(b"\n") if l[:1] == b"W")
     assert hashlib.md5(sl[0] + b"\n" + w + b"\n").hexdigest() == expected[name][variant]["md5"]
+
+
+@pytest.mark.gpu
+def test_pga_create_checks_abi_version_and_block_contents(hip):
+    """A direct user of include/pangene_hip.h (not the host driver, which checks while it packs): pga_create refuses a shard built
+    against another PGA_ABI_VERSION (PGA_ERR_ARG) and a block whose hits break the block's own declaration -- contig id >= n_ctg,
+    cs beyond max_cs, exon range outside the exon list -- with PGA_ERR_RANGE, instead of indexing out of bounds later."""
+    hdr = open(os.path.join(ROOT, "include", "pangene_hip.h")).read()
+    import re
+    abi = int(re.search(r"#define PGA_ABI_VERSION (\d+)u", hdr).group(1))
+
+    class Block(C.Structure):
+        _fields_ = [(k, C.c_int32) for k in ("n_hit", "n_exon", "n_ctg", "max_cs", "max_cm", "max_score_adj", "any_neg", "any_multi")] + [("data", C.c_void_p), ("n_words", C.c_size_t)]
+
+    class Shard(C.Structure):
+        _fields_ = [("abi_version", C.c_uint32), ("n_genome", C.c_int32), ("n_genome_global", C.c_int32), ("genome_global", C.c_void_p), ("n_prot", C.c_int32),
+                    ("n_gene", C.c_int32), ("n_hit", C.c_int64), ("n_exon", C.c_int64), ("block", C.c_void_p), ("prot_gid", C.c_void_p), ("gene_pref", C.c_void_p)]
+
+    class Par(C.Structure):
+        _fields_ = [("min_ov_ratio", C.c_double), ("check_strand", C.c_int32), ("drop_sgl_exon", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+    def attempt(version=abi, cid=0, cs=100, offx=0):
+        n, ne = 2, 2
+        planes = np.zeros((10, n), np.int32)  # pid, contig, rank, score_ori, score_adj, n_exon, off_exon, cs, ce, cm
+        planes[0] = [0, 1]; planes[1] = [0, cid]; planes[3] = planes[4] = 50; planes[5] = 1; planes[6] = [0, offx]
+        planes[7] = [10, cs]; planes[8] = planes[7] + 90; planes[9] = planes[7] + 45
+        words = np.concatenate([planes.ravel(), np.zeros(1, np.int32), np.array([0, 90, 0, 90], np.int32)])
+        blk = Block(n, ne, 1, 100, 145, 50, 0, 0, words.ctypes.data, words.size)
+        gg, pg, pref = np.zeros(1, np.int32), np.array([0, 1], np.int32), np.zeros(2, np.uint8)
+        sh = Shard(version, 1, 1, gg.ctypes.data, 2, 2, n, ne, C.addressof(blk), pg.ctypes.data, pref.ctypes.data)
+        par, ctx = Par(0.5, 0, 0), C.c_void_p()
+        hip.pga_create.restype = C.c_int
+        rc = hip.pga_create(C.byref(ctx), C.byref(sh), C.byref(par))
+        if ctx.value:
+            hip.pga_destroy.restype = None
+            hip.pga_destroy(ctx)
+        return rc
+
+    assert attempt() == 0
+    assert attempt(version=abi + 1) == -3  # PGA_ERR_ARG
+    assert attempt(cid=1) == -2            # PGA_ERR_RANGE: contig 1 of a genome with one contig
+    assert attempt(cs=101) == -2           # beyond the declared max_cs: the sort key would lose its top bit
+    assert attempt(offx=2) == -2           # exon range outside the genome's exon list
