@@ -271,7 +271,7 @@ typedef struct {
 PGA_DECLARE(pga)
 
 /* the same ABI as a table, so the host driver is written once */
-struct pga_branch_par_s;
+struct pga_branch_par_s; struct pga_loop_xchg_s;
 typedef struct {
 	const char *name;
 	int  (*create)(pga_ctx_t **, const pga_shard_t *, const pga_params_t *);
@@ -315,7 +315,7 @@ typedef struct {
 	int  (*arc_table)(pga_ctx_t *, const pga_arc_part_t **, int64_t *);
 	int  (*arc_round_finish)(pga_ctx_t *, int32_t, int32_t *, int32_t *);
 	int  (*branch_decide_filter)(pga_ctx_t *, double, double, double, int32_t, int32_t, int32_t, int32_t, uint8_t *); /* may be NULL */
-	int  (*branch_loop)(pga_ctx_t *, int32_t, const struct pga_branch_par_s *, const int32_t *, const int32_t *, const int32_t *, uint8_t *); /* may be NULL */
+	int  (*branch_loop)(pga_ctx_t *, int32_t, const struct pga_branch_par_s *, const int32_t *, const int32_t *, const int32_t *, uint8_t *, const struct pga_loop_xchg_s *); /* may be NULL */
 	void (*host_trim)(size_t); /* may be NULL */
 	int  (*set_device)(int32_t); /* may be NULL */
 	int  (*device_count)(void);  /* may be NULL */
@@ -334,7 +334,24 @@ const pga_backend_t *pga_backend(void);
  * segments are left; it renumbers them, hands the new g2s over (flag_vtx) and runs the arc round the loop left out.
  * ONE wait, at the end.  Returns 0; 1 = something the queued rounds could not handle happened on the way (a hub gene
  * overflowed its LDS table, the pair list its capacity): the shard's state is then undefined and the caller repeats the
- * run with host-driven rounds; 2 = not applicable here (nothing was queued). */
+ * run with host-driven rounds; 2 = not applicable here (nothing was queued); 3 (sharded form only) = an exchange buffer
+ * was too small: state undefined as with 1, but the capacities have been raised and a later run can queue its rounds again.
+ *
+ * Sharded form (x != NULL): behind pga_arc_set_current (the merged table of a host-driven round), every rank queues the same
+ * rounds; where the host-driven route exchanges (graph_driver.cpp gen_arc / mark_branch_flt_arc) the backend calls x's two
+ * collectives between its kernels -- per round ONE all-gather (every rank's slot: arc count, segment counters, arc table; the
+ * tables are merged by key on the device, counts never leave it) and ONE all-reduce (the n_local counts of the round's pair
+ * list, at a capacity all ranks share), plus one small all-reduce at the end that makes the return value collective.  A
+ * callback returns when its collective is ORDERED with the context's stream: enqueued on it (RCCL on pga_active_stream), or
+ * completed after the callee waited for the stream itself.  Every rank must call with the same n_round, capacities follow
+ * from values all ranks share (arc_cap_hint: the largest local arc table of the last host-driven round, over all ranks). */
+typedef struct pga_loop_xchg_s {
+	void *user;
+	int32_t rank, world;
+	int64_t arc_cap_hint;
+	int (*allreduce_i32_sum)(void *user, void *buf, int64_t count);                  /* in place, device memory */
+	int (*allgather)(void *user, const void *in, void *out, int64_t bytes_per_rank); /* out: world slots, rank order */
+} pga_loop_xchg_t;
 /* Page-locked host memory the backend keeps between contexts (mailboxes, staging areas): give back what exceeds keep_bytes. */
 void pga_host_trim(size_t keep_bytes);
 /* the HIP device of this process (before the first context); the number of visible devices */
@@ -343,7 +360,7 @@ int pga_device_count(void);
 
 typedef struct pga_branch_par_s { double branch_diff, branch_diff_dist, branch_diff_cut; int32_t local_dist, local_count, frag_mode, use_ori; } pga_branch_par_t;
 int pga_branch_loop(pga_ctx_t *ctx, int32_t n_round, const pga_branch_par_t *par, const int32_t *max_tot_cnt, const int32_t *max_degree,
-                    const int32_t *max_dist_loci, uint8_t *seg_alive);
+                    const int32_t *max_dist_loci, uint8_t *seg_alive, const pga_loop_xchg_t *x);
 
 /* Optional: run every kernel on this hipStream_t instead of the library's own stream (lets a host
  * framework order its collectives with the kernels without extra synchronisation). */

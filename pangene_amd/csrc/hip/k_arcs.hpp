@@ -236,3 +236,102 @@ __global__ __launch_bounds__(BLOCK) void k_mg_sum(const pga_arc_part_t *g, const
 		out[w] = r;
 	}
 }
+
+// ------------------------------------------------------------------------------------------------
+// the same merge inside the sharded form of pga_branch_loop: every count stays in device memory
+// ------------------------------------------------------------------------------------------------
+// A rank's slot of the round's all-gather, in 32-bit words: [0] arcs in its table (the true number, also when it is beyond
+// the slot's capacity), [1..15] 0; [16, 16 + 2S) its segment counters (graph.c:125-126); then, 8-byte aligned, arc_cap table
+// entries sorted by x.  Grids are sized by capacities the host knows; what is really there is read from the slots.
+constexpr int XS_HDR = 16;
+__host__ __device__ inline int64_t xs_seg_words(int S) { return ((int64_t)2 * S + 1) & ~(int64_t)1; }
+__host__ __device__ inline int64_t xs_slot_words(int S, int64_t arc_cap) { return XS_HDR + xs_seg_words(S) + arc_cap * (int64_t)(sizeof(pga_arc_part_t) / sizeof(int32_t)); }
+struct XSlots {
+	const int32_t *all; int64_t slot_words, arc_cap; int W, S;
+	__device__ __forceinline__ const pga_arc_part_t *arcs(int r) const { return (const pga_arc_part_t *)(all + r * slot_words + XS_HDR + xs_seg_words(S)); }
+};
+
+// global segment counters = sum over the slots; off[r] = entries of ranks < r (a table beyond the capacity raises the sticky flag:
+// the round, and with it the run, is void); the largest table and the longest pair list seen, for the next run's capacities
+__global__ __launch_bounds__(BLOCK) void k_xs_sum(XSlots X, int32_t *seg_cnt, int64_t *off, int64_t *dcnt, int64_t *xstat)
+{
+	const int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < 2 * X.S) {
+		int32_t t = 0;
+		for (int r = 0; r < X.W; ++r) t += X.all[r * X.slot_words + XS_HDR + i];
+		seg_cnt[i] = t;
+	}
+	if (i == 0) {
+		int64_t run = 0, mx = 0;
+		off[0] = 0;
+		for (int r = 0; r < X.W; ++r) {
+			int64_t n = X.all[r * X.slot_words];
+			mx = mx > n ? mx : n;
+			if (n > X.arc_cap) dcnt[11] = 1, xstat[2] = 1, n = X.arc_cap;
+			run += n, off[r + 1] = run;
+		}
+		if (mx > xstat[1]) xstat[1] = mx;
+		if (dcnt[15] > xstat[0]) xstat[0] = dcnt[15];
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mgx_rank(XSlots X, const int64_t *off, uint64_t *key, uint32_t *val)
+{
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= off[X.W]) return;
+	int r = 0;
+	while (off[r + 1] <= i) ++r;
+	const int64_t k = i - off[r];
+	const uint64_t x = X.arcs(r)[k].x;
+	int64_t pos = k;
+	for (int q = 0; q < X.W; ++q)
+		if (q != r) pos += mg_bound(X.arcs(q), off[q + 1] - off[q], x, q < r);
+	key[pos] = x, val[pos] = (uint32_t)(r * X.arc_cap + k);
+}
+
+struct InMgHeadN { const uint64_t *key; const int64_t *n; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(i < *n && (i == 0 || key[i] != key[i - 1])) ? 1 : 0}; } };
+
+__global__ __launch_bounds__(BLOCK) void k_mgx_count(const uint64_t *key, const int32_t *slot, const int64_t *n, int64_t *n_run)
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0) { const int64_t m = *n; *n_run = m ? slot[m - 1] + ((m == 1 || key[m - 1] != key[m - 2]) ? 1 : 0) : 0; }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mgx_runstart(const uint64_t *key, const int32_t *slot, const int64_t *n, int32_t *run_start)
+{
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i < *n && (i == 0 || key[i] != key[i - 1])) run_start[slot[i]] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mgx_sum(XSlots X, const uint32_t *val, const int64_t *m_dev, const int64_t *n_run_dev, const int32_t *run_start, pga_arc_part_t *out)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t m = *m_dev, n_run = *n_run_dev;
+	for (int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); w < n_run; w += (int64_t)gridDim.x * (BLOCK / WAVE)) {
+		const int64_t st = run_start[w], en = w + 1 < n_run ? run_start[w + 1] : m;
+		int ng = 0, tot = 0;
+		uint64_t sd = 0, x = 0;
+		int64_t a1 = 0, a2 = 0;
+		for (int64_t j = st + lane; j < en; j += WAVE) {
+			const uint32_t v = val[j];
+			const pga_arc_part_t p = X.arcs((int)(v / X.arc_cap))[v % X.arc_cap];
+			x = p.x, ng += p.n_genome, tot += p.tot_cnt, sd += p.sum_dist, a1 += p.sum_s1, a2 += p.sum_s2;
+		}
+		ng = wave_sum(ng), tot = wave_sum(tot);
+		sd = wave_sum64(sd), a1 = (int64_t)wave_sum64((unsigned long long)a1), a2 = (int64_t)wave_sum64((unsigned long long)a2);
+		if (lane == 0) { // lane 0 always owns element st
+			pga_arc_part_t r;
+			r.x = x, r.n_genome = ng, r.tot_cnt = tot, r.sum_dist = sd, r.sum_s1 = a1, r.sum_s2 = a2;
+			out[w] = r;
+		}
+	}
+}
+
+// what the caller is told at the end (summed over the ranks): [0] some queued round is void, [1] an invariant was violated, [2] an
+// exchange buffer was too small (learnable: the capacities follow xstat), [3] a hub gene overflowed its LDS table
+__global__ void k_xs_flags(int64_t *dcnt, int64_t *xstat, long long pair_cap, int32_t *out4)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		if (dcnt[15] > xstat[0]) xstat[0] = dcnt[15];
+		out4[0] = dcnt[11] != 0, out4[1] = dcnt[3] != 0, out4[2] = (xstat[2] != 0 || xstat[0] > pair_cap), out4[3] = dcnt[9] != 0;
+	}
+}

@@ -208,6 +208,19 @@ __global__ __launch_bounds__(BLOCK) void k_cur_prep(const pga_arc_part_t *arcs, 
 	if (i == n_arc - 1 || (uint32_t)(arcs[i + 1].x >> 32) != v) ve[v] = (int32_t)i + 1;
 }
 
+__global__ __launch_bounds__(BLOCK) void k_curx_prep(const pga_arc_part_t *arcs, const int64_t *n_dev, const int32_t *seg_gid, uint64_t *ax, int32_t *s1, int32_t *agid, int32_t *vs, int32_t *ve)
+{ // k_cur_prep with the table's size in device memory (sharded pga_branch_loop)
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x, n_arc = *n_dev;
+	if (i >= n_arc) return;
+	const pga_arc_part_t a = arcs[i];
+	const uint32_t v = (uint32_t)(a.x >> 32);
+	ax[i] = a.x;
+	s1[i] = (int32_t)((double)a.sum_s1 / a.n_genome + .499); // graph.c:171
+	agid[i] = seg_gid[(uint32_t)a.x >> 1];
+	if (i == 0 || (uint32_t)(arcs[i - 1].x >> 32) != v) vs[v] = (int32_t)i;
+	if (i == n_arc - 1 || (uint32_t)(arcs[i + 1].x >> 32) != v) ve[v] = (int32_t)i + 1;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_deg(const int32_t *vs, const int32_t *ve, int n_vtx, int32_t *deg)
 {
 	int v = blockIdx.x * BLOCK + threadIdx.x;
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(BLOCK) void k_round_filter(int S, const int32_t *se
 
 // pga_branch_loop: k_round_filter's tests and their consequences in one launch.  A deleted segment keeps its number: its gene loses its
 // vertex, its two vertices their arcs and counters (nothing refers to them from then on: hits of the gene are filtered next).
-__global__ __launch_bounds__(BLOCK) void k_round_del(int S, const int32_t *ndl, int max_tot_cnt, int max_degree, int max_dist_loci, const int32_t *seg_gid, int32_t *g2s, int32_t *vs, int32_t *ve, int32_t *deg, int32_t *seg_cnt, uint8_t *vwk, uint8_t *alive)
+__global__ __launch_bounds__(BLOCK) void k_round_del(int S, const int32_t *ndl, int max_tot_cnt, int max_degree, int max_dist_loci, const int32_t *seg_gid, int32_t *g2s, int32_t *vs, int32_t *ve, int32_t *deg, int32_t *seg_cnt, uint8_t *vwk, uint8_t *alive, int4 *gmeta /* or NULL */)
 {
 	const int s = blockIdx.x * BLOCK + threadIdx.x;
 	if (s >= S || !alive[s]) return;
@@ -380,6 +393,7 @@ __global__ __launch_bounds__(BLOCK) void k_round_del(int S, const int32_t *ndl, 
 	deg[2 * s] = deg[2 * s + 1] = 0;
 	seg_cnt[s] = seg_cnt[S + s] = 0;
 	vwk[2 * s] = vwk[2 * s + 1] = 0;
+	if (gmeta) gmeta[s] = make_int4(0, 0, 0, 0); // (sharded rounds compact the genes' stretches: this one has none from now on)
 }
 
 __device__ __forceinline__ int arc_weak(const uint64_t *ax, const uint8_t *aw, int64_t n, uint64_t x) // pg_get_arc, pgpriv.h:99-107

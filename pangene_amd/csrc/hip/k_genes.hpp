@@ -317,6 +317,24 @@ __global__ __launch_bounds__(BLOCK) void k_arc_compact(const int4 *gmeta, const 
 	}
 }
 
+// the same into the rank's slot of a sharded round's all-gather (k_arcs.hpp, XS_HDR): the table, the segment counters and the table's size
+__global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const int32_t *off, int S, const pga_arc_part_t *stage, const int32_t *seg_cnt, int32_t *slot, int64_t arc_cap)
+{
+	const int lane = threadIdx.x & 63;
+	int32_t *segc = slot + XS_HDR;
+	pga_arc_part_t *arcs = (pga_arc_part_t *)(slot + XS_HDR + xs_seg_words(S));
+	for (int sid = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); sid < S; sid += gridDim.x * (BLOCK / WAVE)) {
+		const int4 m = gmeta[sid];
+		const int o = off[sid], n = m.y + m.z;
+		if ((int64_t)o + n <= arc_cap)
+			for (int i = lane; i < n; i += WAVE) arcs[o + i] = stage[m.x + i];
+		if (lane == 0) {
+			segc[sid] = seg_cnt[sid], segc[S + sid] = seg_cnt[S + sid];
+			if (sid == S - 1) { slot[0] = o + n; for (int t = 1; t < XS_HDR; ++t) slot[t] = 0; }
+		}
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // pg_mark_branch_flt_hit (branch.c:108-145): a hit is marked by the weak arcs among its own two half-arcs
 // ------------------------------------------------------------------------------------------------

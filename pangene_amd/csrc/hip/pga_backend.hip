@@ -113,7 +113,7 @@ struct PinArena {
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_BIGLIST, S_STAGE_SID, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK,
+	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_BIGLIST, S_STAGE_SID, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK, S_XG_BUF, S_XG_OUT, S_XSTAT,
 	S_COUNT
 };
 
@@ -146,6 +146,7 @@ struct pga_ctx {
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors
 	int32_t *max_ori = 0; int64_t *sums = 0; int32_t *vtx_cnt = 0; int32_t *g2s = 0; int32_t n_seg = 0;
+	int64_t x_pairs_seen = 0, x_arcs_seen = 0; // sharded pga_branch_loop: the longest pair list / the largest local arc table of any rank in the last run of this context
 	int64_t *dcnt = 0;      // device counters: [0] triples [1] arcs-temp [2] misc [3] invariant flag, [4..7] hazards
 	int64_t *h_cnt = 0;     // pinned mirror
 	int64_t *h_box = 0;     // the same memory as the device sees it
@@ -1358,28 +1359,109 @@ extern "C" int pga_branch_decide_filter(pga_ctx_t *c, double branch_diff, double
 	return decide_impl(c, branch_diff, branch_diff_dist, branch_diff_cut, nullptr, nullptr, nullptr, nullptr, &rf);
 }
 
+// (sharded form) the round's local table -> every rank's slot -> the merged table as the current one: pga_arc_round's compaction, the
+// all-gather, pga_arc_merge and pga_arc_set_current with every count left in device memory
+struct LoopX { const pga_loop_xchg_t *x; int64_t arc_cap, pair_cap, ecap; int32_t *gbuf; int64_t slot_words; pga_arc_part_t *merged; int64_t *xstat, *d_off; };
+
+static int loop_exchange_table(pga_ctx *c, const LoopX &L)
+{
+	const int S = c->n_seg, n_vtx = 2 * S, W = L.x->world;
+	const int64_t mcap = (int64_t)W * L.arc_cap;
+	pga_arc_part_t *stage = (pga_arc_part_t *)c->pool.get(S_ARC_STAGE, 0);
+	int4 *gmeta = (int4 *)c->pool.get(S_GMETA, 0);
+	int32_t *goff = (int32_t *)c->pool.get(S_GOFF, sizeof(int32_t) * (size_t)S);
+	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, 0);
+	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(std::max<int64_t>(std::max<int64_t>(S, mcap), 2 * (int64_t)c->N + 2)));
+	uint64_t *key = (uint64_t *)c->pool.get(S_MG_KEY, sizeof(uint64_t) * (size_t)mcap + 64);
+	uint32_t *val = (uint32_t *)c->pool.get(S_MG_VAL, sizeof(uint32_t) * (size_t)mcap + 64);
+	int32_t *slot = (int32_t *)c->pool.get(S_MG_SLOT, sizeof(int32_t) * (size_t)mcap + 64);
+	int32_t *run_start = (int32_t *)c->pool.get(S_MG_RUN, sizeof(int32_t) * (size_t)mcap + 64);
+	if (!stage || !gmeta || !goff || !seg_cnt || !tile || !key || !val || !slot || !run_start) return PGA_ERR_NOMEM;
+	device_scan<I32>(InGmeta{gmeta}, OutExclI32{goff}, S, tile, OpSum{}, I32{0}, c->st);
+	hipLaunchKernelGGL(k_xs_compact, dim3(nblk(S, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gmeta, goff, S, stage, seg_cnt, L.gbuf, L.arc_cap);
+	{ const int rc = L.x->allgather(L.x->user, L.gbuf, L.gbuf + L.slot_words, L.slot_words * (int64_t)sizeof(int32_t)); if (rc) return rc; }
+	XSlots X = { L.gbuf + L.slot_words, L.slot_words, L.arc_cap, W, S };
+	hipLaunchKernelGGL(k_xs_sum, dim3(nblk(std::max(n_vtx, 1))), dim3(BLOCK), 0, c->st, X, seg_cnt, L.d_off, c->dcnt, L.xstat);
+	hipLaunchKernelGGL(k_mgx_rank, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, X, (const int64_t *)L.d_off, key, val);
+	device_scan<I32>(InMgHeadN{key, L.d_off + W}, OutExclI32{slot}, mcap, tile, OpSum{}, I32{0}, c->st);
+	hipLaunchKernelGGL(k_mgx_count, dim3(1), dim3(64), 0, c->st, key, slot, (const int64_t *)(L.d_off + W), c->dcnt + 10);
+	hipLaunchKernelGGL(k_mgx_runstart, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, key, slot, (const int64_t *)(L.d_off + W), run_start);
+	hipLaunchKernelGGL(k_mgx_sum, dim3((unsigned)std::min<int64_t>(nblk(mcap, BLOCK / WAVE), 8 * c->n_cu)), dim3(BLOCK), 0, c->st, X, val, (const int64_t *)(L.d_off + W), (const int64_t *)(c->dcnt + 10), run_start, L.merged);
+	CurTable t;
+	TRY(cur_table(c, L.ecap, S, &t));
+	zero_multi(c, t.vs, sizeof(int32_t) * (size_t)n_vtx, t.ve, sizeof(int32_t) * (size_t)n_vtx, t.aw, (size_t)mcap, t.vwk, (size_t)n_vtx);
+	hipLaunchKernelGGL(k_seg_gid, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, c->Q, S, t.sg);
+	hipLaunchKernelGGL(k_curx_prep, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, L.merged, (const int64_t *)(c->dcnt + 10), t.sg, t.ax, t.s1, t.agid, t.vs, t.ve);
+	hipLaunchKernelGGL(k_deg, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, t.vs, t.ve, n_vtx, t.dg);
+	c->table_sparse = false, c->cur_tab = L.merged, c->cur_tab_n = 0; // (the size stays on the device: nobody may ask for this table -- the loop's caller runs a round of its own next)
+	return 0;
+}
+
 extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_par_t *par, const int32_t *max_tot_cnt, const int32_t *max_degree,
-                               const int32_t *max_dist_loci, uint8_t *seg_alive)
+                               const int32_t *max_dist_loci, uint8_t *seg_alive, const pga_loop_xchg_t *x)
 {
 	static const bool off = getenv("PANGENE_BRANCH_LOOP_HOST") != nullptr; // (tests: keep the host-driven rounds exercised)
 	const int S = c->n_seg, n_vtx = 2 * S, N = c->N;
-	if (off || n_round <= 0 || par == nullptr || seg_alive == nullptr || N == 0 || S == 0 || !(c->arc_deferred && !c->arc_done && c->table_sparse) || c->br_S != S || n_vtx > PO_THREADS * PO_MAX_ITEMS) return 2;
+	if (off || n_round <= 0 || par == nullptr || seg_alive == nullptr || N == 0 || S == 0 || c->br_S != S || n_vtx > PO_THREADS * PO_MAX_ITEMS) return 2;
+	if (x == nullptr ? !(c->arc_deferred && !c->arc_done && c->table_sparse) : (c->table_sparse || c->arc_deferred || x->world < 1 || x->allgather == nullptr || x->allreduce_i32_sum == nullptr)) return 2;
 	uint8_t *alive = (uint8_t *)c->pool.get(S_MISC, (size_t)S + 64);
 	int32_t *ndl = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
 	if (!alive || !ndl) return PGA_ERR_NOMEM;
 	HIPCHK(hipMemsetAsync(alive, 1, (size_t)S, c->st));
-	{ // Room for the pair lists of every round (nobody can ask for more on the way): a vertex with n out-arcs lists at most n^2
+	const int64_t br_cap_before = c->br_cap;
+	LoopX L = { x, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr };
+	if (x == nullptr) { // Room for the pair lists of every round (nobody can ask for more on the way): a vertex with n out-arcs lists at most n^2
 	  // pairs (branch.c:70-88), and pg_flt_high_occ keeps n near max_degree (graph.c:243-250) -- the lists grow over the rounds,
 	  // so the first round's length says little.  A list that still overflows costs a repeated run (sticky flag), not a wrong one.
 		int64_t dmax = 8;
 		for (int r = 1; r < n_round; ++r) dmax = std::max<int64_t>(dmax, max_degree[r]);
 		c->br_cap = std::max<int64_t>(c->br_cap, std::min<int64_t>((int64_t)n_vtx * dmax * dmax, (int64_t)1 << 26));
+	} else {
+		// Capacities all ranks share: they follow from the merged tables (identical everywhere) and from the slots of earlier all-gathers.
+		// The pair list's worst case (above) is too much to all-reduce every round: what earlier runs over this shard saw, with a
+		// margin, or a million pairs on the first run -- a list beyond that costs a repeated run (status 3), and the next one knows.
+		int64_t dmax = 8;
+		for (int r = 1; r < n_round; ++r) dmax = std::max<int64_t>(dmax, max_degree[r]);
+		const int64_t worst = std::min<int64_t>((int64_t)n_vtx * dmax * dmax, (int64_t)1 << 26);
+		L.pair_cap = std::min<int64_t>(worst, c->x_pairs_seen > 0 ? c->x_pairs_seen + c->x_pairs_seen / 4 + 4096 : std::max<int64_t>((int64_t)1 << 20, 4 * (int64_t)n_vtx));
+		L.pair_cap = std::max<int64_t>(L.pair_cap, 4 * (int64_t)n_vtx); // (pga_branch_pairs never works with less)
+		L.arc_cap = std::max<int64_t>(x->arc_cap_hint, c->x_arcs_seen) * 3 / 2 + 1024;
+		if (c->x_pairs_seen == 0) { // (tests: start with buffers that are too small, to reach status 3 and the learned capacities)
+			const char *ep = getenv("PANGENE_XLOOP_PAIR_CAP"), *ea = getenv("PANGENE_XLOOP_ARC_CAP");
+			if (ep) L.pair_cap = std::max<int64_t>(atoll(ep), 4 * (int64_t)n_vtx);
+			if (ea && c->x_arcs_seen == 0) L.arc_cap = std::max<int64_t>(atoll(ea), 1);
+		}
+		c->br_cap = L.pair_cap; // what k_pair_offsets tests and k_br_wave / k_n_local stride over
+		L.ecap = std::max<int64_t>(2 * (int64_t)N + 2, (int64_t)x->world * L.arc_cap);
+		L.slot_words = xs_slot_words(S, L.arc_cap);
+		L.gbuf = (int32_t *)c->pool.get(S_XG_BUF, sizeof(int32_t) * (size_t)L.slot_words * ((size_t)x->world + 1) + 64);
+		L.merged = (pga_arc_part_t *)c->pool.get(S_XG_OUT, sizeof(pga_arc_part_t) * (size_t)x->world * (size_t)L.arc_cap + 64);
+		L.xstat = (int64_t *)c->pool.get(S_XSTAT, sizeof(int64_t) * 8);
+		L.d_off = (int64_t *)c->pool.get(S_MG_SRC, sizeof(int64_t) * ((size_t)x->world + 2));
+		if (!L.gbuf || !L.merged || !L.xstat || !L.d_off) return PGA_ERR_NOMEM;
+		HIPCHK(hipMemsetAsync(L.xstat, 0, sizeof(int64_t) * 8, c->st));
+		HIPCHK(hipMemsetAsync(c->dcnt + 11, 0, sizeof(int64_t), c->st)); // the sticky flag covers the queued rounds
+		HIPCHK(hipMemsetAsync(c->dcnt + 9, 0, sizeof(int64_t), c->st));
+		// the table the caller made current (pga_arc_set_current), once more into arrays that also hold every later round's
+		CurTable t;
+		const pga_arc_part_t *tab = c->cur_tab; const int64_t n0 = c->cur_tab_n;
+		if (n0 > L.ecap) return 2;
+		TRY(cur_table(c, L.ecap, S, &t));
+		if (!c->pool.get(S_BR_GRP, sizeof(int32_t) * (size_t)L.ecap + 16)) return PGA_ERR_NOMEM;
+		zero_multi(c, t.vs, sizeof(int32_t) * (size_t)n_vtx, t.ve, sizeof(int32_t) * (size_t)n_vtx, t.aw, (size_t)L.ecap, t.vwk, (size_t)n_vtx);
+		if (n0) {
+			hipLaunchKernelGGL(k_seg_gid, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, c->Q, S, t.sg);
+			hipLaunchKernelGGL(k_cur_prep, dim3(nblk(n0)), dim3(BLOCK), 0, c->st, tab, n0, t.sg, t.ax, t.s1, t.agid, t.vs, t.ve);
+		}
+		hipLaunchKernelGGL(k_deg, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, t.vs, t.ve, n_vtx, t.dg);
+		c->br_n = L.ecap;
 	}
 	for (int r = 0; r < n_round; ++r) {
 		// pg_mark_branch_flt_arc (branch.c:48-106)
 		TRY(pga_rep_pos(c));
 		int32_t *cnt;
 		TRY(pga_branch_pairs(c, nullptr, nullptr, 0, nullptr, S, par->branch_diff, par->local_dist, par->local_count, par->frag_mode, &cnt, nullptr));
+		if (x) { const int rc = x->allreduce_i32_sum(x->user, cnt, L.pair_cap); if (rc) return rc; } // n_local over every rank's genomes (entries beyond the list's end: whatever they were)
 		{
 			const int64_t n_arc = c->br_n;
 			uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, 0), *vwk = (uint8_t *)c->pool.get(S_VWK, (size_t)n_vtx + 16);
@@ -1392,7 +1474,8 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 			// pg_mark_branch_flt_hit + PG_SET_FILTER(weak_br == 2) (branch.c:108-145, graph.c:309): with the numbering the arcs were made with
 			TRY(pga_mark_hits(c, nullptr, nullptr, 0, nullptr, 1));
 			if (r > 0) { // pg_flt_high_occ + pg_hard_delete + PG_SET_FILTER(vtx == 0) (graph.c:219-263, 312)
-				hipLaunchKernelGGL(k_round_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)ndl, max_tot_cnt[r], max_degree[r], max_dist_loci[r], (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive);
+				hipLaunchKernelGGL(k_round_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)ndl, max_tot_cnt[r], max_degree[r], max_dist_loci[r], (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive,
+				                   x ? (int4 *)c->pool.get(S_GMETA, 0) : (int4 *)nullptr);
 				hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1);
 				c->walk_valid = false, c->ha_valid = false;
 			}
@@ -1401,20 +1484,40 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 			int32_t *seg_cnt, *deg;
 			TRY(arc_round_genes(c, par->use_ori, &seg_cnt, &deg, nullptr, false)); // (no mail: the kernels raise the sticky flag themselves)
 			c->br_n = 2 * (int64_t)N + 2, c->br_S = S, c->br_np = 0;
+			if (x) { TRY(loop_exchange_table(c, L)); c->br_n = L.ecap; }
 		}
 	}
 	c->arc_deferred = false, c->arc_done = false;
-	if (c->h_fetch_cap < (size_t)S) {
-		c->h_fetch = c->pin.get((size_t)S + S / 2 + 256);
+	if (c->h_fetch_cap < (size_t)S + 128) {
+		c->h_fetch = c->pin.get((size_t)S + S / 2 + 512);
 		if (!c->h_fetch) return PGA_ERR_NOMEM;
-		c->h_fetch_cap = (size_t)S + S / 2 + 256;
+		c->h_fetch_cap = (size_t)S + S / 2 + 512;
 	}
 	HIPCHK(hipMemcpyAsync(c->h_fetch, alive, (size_t)S, hipMemcpyDeviceToHost, c->st));
+	int64_t *h_x = nullptr; // (sharded) behind the bytes, 8-byte aligned: the 4 collective flags (as int32) and the run's statistics
+	if (x) {
+		int32_t *flags4 = L.gbuf; // (the gather buffer is free again)
+		hipLaunchKernelGGL(k_xs_flags, dim3(1), dim3(64), 0, c->st, c->dcnt, L.xstat, (long long)L.pair_cap, flags4);
+		{ const int rc = x->allreduce_i32_sum(x->user, flags4, 4); if (rc) return rc; }
+		h_x = (int64_t *)((char *)c->h_fetch + (((size_t)S + 7) & ~(size_t)7));
+		HIPCHK(hipMemcpyAsync(h_x, flags4, 16, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipMemcpyAsync(h_x + 2, L.xstat, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	}
 	hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
 	TRY(sync_st(c));
 	c->br_np_seen = std::max<int64_t>(c->br_np_seen, c->h_cnt[15]);
 	if (getenv("PANGENE_DEBUG_LOOP")) fprintf(stderr, "[pga_branch_loop] counters after %d rounds: invariant %lld, table overflows (last round) %lld, sticky %lld, pairs (last round) %lld of capacity %lld\n", n_round, (long long)c->h_cnt[3], (long long)c->h_cnt[9], (long long)c->h_cnt[11], (long long)c->h_cnt[15], (long long)c->br_cap);
-	if (c->h_cnt[11]) return c->h_cnt[3] ? PGA_ERR_INVARIANT : 1;
+	if (x) {
+		const int32_t *f = (const int32_t *)h_x;
+		c->x_pairs_seen = h_x[2], c->x_arcs_seen = h_x[3]; // what the LAST run over this shard needed (every round's list is all-reduced at the capacity: not more than a margin above that)
+		c->br_np_seen = std::max<int64_t>(c->br_np_seen, h_x[2]);
+		c->br_cap = std::max<int64_t>(br_cap_before, c->br_cap);
+		if (getenv("PANGENE_DEBUG_LOOP")) fprintf(stderr, "[pga_branch_loop] sharded over %d ranks: flags (summed) void %d invariant %d capacity %d hub %d; longest pair list %lld of %lld, largest local table %lld of %lld\n", x->world, f[0], f[1], f[2], f[3],
+		                                          (long long)h_x[2], (long long)L.pair_cap, (long long)h_x[3], (long long)L.arc_cap);
+		if (f[1]) return PGA_ERR_INVARIANT;
+		if (f[0]) return (f[2] && !f[3]) ? 3 : 1;
+	}
+	else if (c->h_cnt[11]) return c->h_cnt[3] ? PGA_ERR_INVARIANT : 1;
 	memcpy(seg_alive, c->h_fetch, (size_t)S);
 	return 0;
 }

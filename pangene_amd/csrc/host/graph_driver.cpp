@@ -812,6 +812,7 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer 
 		std::vector<int64_t> cnt((size_t)W);
 		int64_t slot = 0, n_mg = 0;
 		for (int r = 0; r < W; ++r) cnt[(size_t)r] = all[(size_t)S * 2 + (size_t)r], slot = std::max(slot, cnt[(size_t)r]);
+		ext->x_arc_slot = slot; // the largest local table of this round, over all ranks (every rank has the same number)
 		pga_arc_part_t *merged = nullptr;
 		if (slot) {
 			const size_t bytes = (size_t)slot * sizeof(pga_arc_part_t);
@@ -989,14 +990,44 @@ static int apply_round_filter(pg_graph_t *q, DataExt *ext, const std::vector<uin
 // (nothing happened).  Returns RC_REDO when the queued rounds met something only the host-driven rounds can handle: the
 // shard's state is undefined then and pg_graph_gen repeats the run.
 enum { RC_REDO = 1000 };
+// the two collectives of the sharded form: ordered with the backend's stream when they return (see pga_loop_xchg_t)
+static int loop_allreduce(void *user, void *buf, int64_t count)
+{
+	DataExt *ext = (DataExt *)user;
+	if (count == 0) return 0;
+	const int rc = xready(ext->be, ext->ctx);
+	return rc ? rc : g_xchg.allreduce(g_xchg.user, buf, count, PG_X_I32, PG_X_SUM, ext->be->is_device());
+}
+static int loop_allgather(void *user, const void *in, void *out, int64_t bytes)
+{
+	DataExt *ext = (DataExt *)user;
+	const int rc = xready(ext->be, ext->ctx);
+	return rc ? rc : g_xchg.allgather(g_xchg.user, in, out, bytes, ext->be->is_device());
+}
+
 static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, int32_t R, bool *done)
 {
 	*done = false;
 	const pga_backend_t *be = ext->be;
-	if (be->branch_loop == nullptr || sharded() || pg_verbose >= 3 || trace_path() != nullptr || !ext->arc_pending || R < 1 || ext->no_branch_loop) return 0;
+	const bool shd = sharded();
+	if (be->branch_loop == nullptr || pg_verbose >= 3 || trace_path() != nullptr || (!shd && !ext->arc_pending) || R < 1 || ext->no_branch_loop) return 0;
+	static const bool no_x = std::getenv("PANGENE_SHARDED_LOOP_HOST") != nullptr; // (tests: the host-driven rounds of a sharded run)
+	if (shd && (no_x || !be->is_device())) return 0;
+	if (shd && ext->skip_loop_once) { ext->skip_loop_once = false; return 0; } // the repeated run after status 3
 	const int n_sorts = 2 * R - 1; // of each kind: one pair per pg_mark_branch_flt_hit (branch.c:116,140), one per pg_gen_arc (graph.c:103,123)
 	static const bool dbg = std::getenv("PANGENE_DEBUG_LOOP") != nullptr;
-	{ Phase ph(PH_EXACT); if (!exact_quiet(ext, n_sorts)) { if (dbg) std::fprintf(stderr, "[branch_loop] not quiet: the hit at array index 0 of some genome changes within the next %d sorts\n", n_sorts); return 0; } }
+	bool quiet;
+	{ Phase ph(PH_EXACT); quiet = exact_quiet(ext, n_sorts); }
+	if (shd) { // every rank queues the rounds, or none does: the ranks vote (a rank without hits or segments cannot; one whose hit order needs the host neither)
+		int32_t ok = (quiet && ext->n_hit_local > 0 && q->n_seg > 0) ? 1 : 0;
+		void *scr;
+		BE_CALL(be->scratch(ext->ctx, 16, &scr), "scratch");
+		BE_CALL(be->put(ext->ctx, scr, &ok, sizeof(ok)), "put");
+		BE_CALL(xreduce(be, ext->ctx, scr, 1, PG_X_I32, PG_X_SUM), "allreduce(vote)");
+		BE_CALL(be->fetch(ext->ctx, &ok, scr, sizeof(ok)), "fetch");
+		if (ok != g_xchg.world) { if (dbg) std::fprintf(stderr, "[branch_loop] %d of %d ranks can queue their rounds: host-driven rounds\n", ok, g_xchg.world); return 0; }
+	}
+	else if (!quiet) { if (dbg) std::fprintf(stderr, "[branch_loop] not quiet: the hit at array index 0 of some genome changes within the next %d sorts\n", n_sorts); return 0; }
 	const int32_t S = q->n_seg, n = opt->n_branch_flt;
 	std::vector<int32_t> m_tot((size_t)R), m_deg((size_t)R), m_loci((size_t)R);
 	for (int32_t i = 0; i < R; ++i) { // graph.c:303-306
@@ -1010,11 +1041,14 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	par.local_dist = opt->local_dist, par.local_count = opt->local_count, par.frag_mode = !!(opt->flag & PG_F_FRAG_MODE), par.use_ori = !!(opt->flag & PG_F_ORI_FOR_BRANCH);
 	std::vector<uint8_t> &alive = ext->del_buf;
 	alive.assign((size_t)S + 1, 1);
+	pga_loop_xchg_t lx;
+	lx.user = ext, lx.rank = g_xchg.rank, lx.world = g_xchg.world, lx.arc_cap_hint = ext->x_arc_slot, lx.allreduce_i32_sum = loop_allreduce, lx.allgather = loop_allgather;
 	int rc;
-	{ Phase ph(PH_NLOCAL); rc = be->branch_loop(ext->ctx, R, &par, m_tot.data(), m_deg.data(), m_loci.data(), alive.data()); }
-	if (dbg) std::fprintf(stderr, "[branch_loop] %d rounds queued: backend status %d\n", R, rc);
+	{ Phase ph(PH_NLOCAL); rc = be->branch_loop(ext->ctx, R, &par, m_tot.data(), m_deg.data(), m_loci.data(), alive.data(), shd ? &lx : nullptr); }
+	if (dbg) std::fprintf(stderr, "[branch_loop] %d rounds queued%s: backend status %d\n", R, shd ? " (sharded)" : "", rc);
 	if (rc == 2) return 0;
 	if (rc == 1) { ext->no_branch_loop = true; return RC_REDO; }
+	if (rc == 3) { ext->skip_loop_once = true; return RC_REDO; }
 	if (rc != 0) { set_error(rc, "branch_loop"); return rc; }
 	ext->arc_pending = false;
 	exact_skip(ext, n_sorts);

@@ -397,13 +397,18 @@ def _rank_on_shared_gpu(rank, world, port, files, variant, cuts, q):
     del keep
 
 
-@pytest.mark.parametrize("name,variant,cuts", [("bact20", "", [0, 10, 20]), ("human8f", "-p0 -a1", [0, 3, 8]), ("bact20", "", [0, 7, 13, 20]), ("fuzz2", "-F", [0, 2, 2, 99])])
-def test_sharded_hip_ranks_on_one_gpu(built, expected, name, variant, cuts):
-    """The whole sharded HIP path with W > 1 (id scan, partial vectors, cross-shard arc merge on the device, n_local sums):
+@pytest.mark.parametrize("name,variant,cuts", [("bact20", "", [0, 10, 20]), ("human8f", "-p0 -a1", [0, 3, 8]), ("bact20", "", [0, 7, 13, 20]), ("fuzz2", "-F", [0, 2, 2, 99]),
+                                               ("bact20", "host-driven", [0, 10, 20]), ("human8", "", [0, 2, 5, 8]), ("C4", "", [0, 16, 99])])
+def test_sharded_hip_ranks_on_one_gpu(built, expected, name, variant, cuts, monkeypatch):
+    """The whole sharded HIP path with W > 1 (id scan, partial vectors, cross-shard arc merge on the device, n_local sums; the branch
+    rounds queued on every rank with their two collectives per round in between -- each waits for the stream first here):
     several ranks share this box's one GPU and exchange through gloo with host staging (RCCL will not put two ranks on
     one device).  Their combined output must be the reference's single-process GFA."""
     import socket
     import torch.multiprocessing as mp
+    if variant == "host-driven":  # the branch rounds of the sharded run driven by the host, not queued (sharded pga_branch_loop)
+        monkeypatch.setenv("PANGENE_SHARDED_LOOP_HOST", "1")
+        variant = ""
     files = golden_files(name)
     cuts = [min(c, len(files)) for c in cuts]
     world = len(cuts) - 1
@@ -511,3 +516,84 @@ def test_pga_create_checks_abi_version_and_block_contents(hip):
     assert attempt(cid=1) == -2            # PGA_ERR_RANGE: contig 1 of a genome with one contig
     assert attempt(cs=101) == -2           # beyond the declared max_cs: the sort key would lose its top bit
     assert attempt(offx=2) == -2           # exon range outside the genome's exon list
+
+
+_XLOOP_CODE = r'''
+import sys, os, ctypes as C, hashlib, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from pangene_amd import capi, exchange
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], RANK="0", WORLD_SIZE="1", PANGENE_FORCE_EXCHANGE="1", PANGENE_DEBUG_LOOP="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+lib = capi.load(); C.c_int.in_dll(lib, "pg_verbose").value = 0
+if sys.argv[2] == "native":
+    assert exchange.install_native(lib), lib.pg_rccl_error()
+else:
+    keep = exchange.install(lib, device=torch.device("cuda", 0))
+jobs = json.load(open(sys.argv[3]))
+res = []
+import tempfile
+for files, variant, repeat in jobs:  # `repeat` passes over ONE resident shard (what bench.py's steps are): the context lives on
+    sys.stderr.write("JOB %%s %%r\n" %% (os.path.basename(os.path.dirname(files[0])), variant)); sys.stderr.flush()
+    opt = capi.parse_args(lib, variant)
+    d = lib.pg_data_init()
+    capi.read_files(lib, opt, d, files)
+    for k in range(repeat):
+        if k and lib.pg_rerun_resident(d) != 0:
+            raise RuntimeError("pg_rerun_resident failed")
+        lib.pg_post_process(C.byref(opt), d)
+        g = lib.pg_graph_init(d)
+        lib.pg_graph_gen(C.byref(opt), g)
+        if lib.pg_last_error():
+            raise RuntimeError(lib.pg_last_error_str().decode())
+        out = tempfile.mktemp(prefix="pangene_xloop_", suffix=".gfa")
+        lib.pg_set_output(out.encode()); lib.pg_write_graph(g); lib.pg_write_walk(g); lib.pg_set_output(None)
+        res.append(hashlib.md5(open(out, "rb").read()).hexdigest()); os.unlink(out)
+        lib.pg_graph_destroy(g)
+    lib.pg_data_destroy(d)
+json.dump(res, open(sys.argv[4], "w"))
+if sys.argv[2] == "native":
+    lib.pg_rccl_finalize()
+dist.destroy_process_group()
+''' % ROOT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["native", "torch"])
+def test_sharded_branch_loop_forced_exchange(built, expected, tmp_path, kind):
+    """The sharded form of pga_branch_loop (per round one all-gather of the ranks' slots + the merge on the device, one all-reduce of
+    the n_local counts; no wait until the end) with world size 1 and every collective issued -- by the library itself through RCCL on
+    the kernels' stream ("native": nothing waits), or through torch.distributed callbacks ("torch": each collective waits for the
+    stream first).  The GFA is the reference's, and the log shows that the rounds really were queued (status 0), not host-driven."""
+    import json
+    import socket
+    cases = [("bact20", ""), ("bact20", "-S"), ("C4", ""), ("human8", ""), ("human8f", "-p0 -a1"), ("mut1", ""), ("fuzz0", "-F")]
+    cases = [(n, v) for n, v in cases if n in expected and v in expected[n]]
+    jobs = [[golden_files(n), v.split(), 1] for n, v in cases]
+    (tmp_path / "jobs.json").write_text(json.dumps(jobs))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-c", _XLOOP_CODE, str(port), kind, str(tmp_path / "jobs.json"), str(tmp_path / "res.json")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-3000:]
+    res = json.load(open(tmp_path / "res.json"))
+    assert res == [expected[n][v]["md5"] for n, v in cases]
+    assert err.count("rounds queued (sharded): backend status 0") >= len(cases) - 2, err[-3000:]  # (a data set may leave its rounds to the host: exact-order replay, a hub gene)
+
+
+@pytest.mark.gpu
+def test_sharded_branch_loop_learns_its_capacities(built, expected, tmp_path):
+    """Exchange buffers that are too small (forced here) void the queued rounds: status 3, the run is repeated host-driven with the
+    reference's result, and the next run over the same shard queues its rounds again with the capacities the failed one measured."""
+    import json
+    import socket
+    jobs = [[golden_files("bact20"), [], 3]]
+    (tmp_path / "jobs.json").write_text(json.dumps(jobs))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    for envx in ({"PANGENE_XLOOP_PAIR_CAP": "64"}, {"PANGENE_XLOOP_ARC_CAP": "100"}):
+        r = subprocess.run([sys.executable, "-c", _XLOOP_CODE, str(port), "native", str(tmp_path / "jobs.json"), str(tmp_path / "res.json")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                           env=dict(os.environ, **envx))
+        err = r.stderr.decode()
+        assert r.returncode == 0, err[-3000:]
+        assert json.load(open(tmp_path / "res.json")) == [expected["bact20"][""]["md5"]] * 3
+        assert "rounds queued (sharded): backend status 3" in err and "rounds queued (sharded): backend status 0" in err, err[-3000:]
