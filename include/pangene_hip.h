@@ -319,6 +319,7 @@ typedef struct {
 	void (*host_trim)(size_t); /* may be NULL */
 	int  (*set_device)(int32_t); /* may be NULL */
 	int  (*device_count)(void);  /* may be NULL */
+	int  (*arc_round_x)(pga_ctx_t *, int32_t, int32_t, const struct pga_loop_xchg_s *, int32_t *, int32_t *, int64_t *); /* may be NULL */
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);
@@ -359,6 +360,13 @@ int pga_set_device(int32_t device);
 int pga_device_count(void);
 
 typedef struct pga_branch_par_s { double branch_diff, branch_diff_dist, branch_diff_cut; int32_t local_dist, local_count, frag_mode, use_ori; } pga_branch_par_t;
+/* pg_gen_arc (graph.c:87-177) of a sharded run with ONE wait: arc_round + the exchange + arc_merge + arc_set_current, every table
+ * size left on the device; the ranks' tables travel in slots of a capacity all ranks share (the largest local table the shard has
+ * seen, with a margin; x->arc_cap_hint before the backend has seen one).  seg_cnt[2 n_seg], deg[2 n_seg] (host) and *n_arc are the
+ * global results; the merged table is the current one (arc_table).  Returns 1 on EVERY rank when the round is void on some rank (a
+ * hub gene beyond its LDS table, a table beyond its slot): the caller repeats the round through arc_round (which then takes the sort
+ * path, without a second sweep) and the host-driven exchange; 2 = not applicable (no capacity known, n_seg = 0): nothing happened. */
+int pga_arc_round_x(pga_ctx_t *ctx, int32_t use_ori, int32_t n_seg, const pga_loop_xchg_t *x, int32_t *seg_cnt, int32_t *deg, int64_t *n_arc);
 int pga_branch_loop(pga_ctx_t *ctx, int32_t n_round, const pga_branch_par_t *par, const int32_t *max_tot_cnt, const int32_t *max_degree,
                     const int32_t *max_dist_loci, uint8_t *seg_alive, const pga_loop_xchg_t *x);
 

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) void k_mg_sum(const pga_arc_part_t *g, const
 // the same merge inside the sharded form of pga_branch_loop: every count stays in device memory
 // ------------------------------------------------------------------------------------------------
 // A rank's slot of the round's all-gather, in 32-bit words: [0] arcs in its table (the true number, also when it is beyond
-// the slot's capacity), [1..15] 0; [16, 16 + 2S) its segment counters (graph.c:125-126); then, 8-byte aligned, arc_cap table
+// the slot's capacity), [1] / [2] the rank's round is void (hub gene / invariant), [3..15] 0; [16, 16 + 2S) its segment counters (graph.c:125-126); then, 8-byte aligned, arc_cap table
 // entries sorted by x.  Grids are sized by capacities the host knows; what is really there is read from the slots.
 constexpr int XS_HDR = 16;
 __host__ __device__ inline int64_t xs_seg_words(int S) { return ((int64_t)2 * S + 1) & ~(int64_t)1; }
@@ -267,6 +267,8 @@ __global__ __launch_bounds__(BLOCK) void k_xs_sum(XSlots X, int32_t *seg_cnt, in
 		for (int r = 0; r < X.W; ++r) {
 			int64_t n = X.all[r * X.slot_words];
 			mx = mx > n ? mx : n;
+			if (X.all[r * X.slot_words + 1]) xstat[3] = 1;
+			if (X.all[r * X.slot_words + 2]) xstat[4] = 1;
 			if (n > X.arc_cap) dcnt[11] = 1, xstat[2] = 1, n = X.arc_cap;
 			run += n, off[r + 1] = run;
 		}
@@ -291,38 +293,31 @@ __global__ __launch_bounds__(BLOCK) void k_mgx_rank(XSlots X, const int64_t *off
 
 struct InMgHeadN { const uint64_t *key; const int64_t *n; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(i < *n && (i == 0 || key[i] != key[i - 1])) ? 1 : 0}; } };
 
-__global__ __launch_bounds__(BLOCK) void k_mgx_count(const uint64_t *key, const int32_t *slot, const int64_t *n, int64_t *n_run)
+// run starts, and (the thread of the last entry) the number of runs = the merged table's size
+__global__ __launch_bounds__(BLOCK) void k_mgx_runstart(const uint64_t *key, const int32_t *slot, const int64_t *n, int32_t *run_start, int64_t *n_run)
 {
-	if (blockIdx.x == 0 && threadIdx.x == 0) { const int64_t m = *n; *n_run = m ? slot[m - 1] + ((m == 1 || key[m - 1] != key[m - 2]) ? 1 : 0) : 0; }
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x, m = *n;
+	if (i == 0 && m == 0) *n_run = 0;
+	if (i >= m) return;
+	const bool head = i == 0 || key[i] != key[i - 1];
+	if (head) run_start[slot[i]] = (int32_t)i;
+	if (i == m - 1) *n_run = slot[i] + (head ? 1 : 0);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_mgx_runstart(const uint64_t *key, const int32_t *slot, const int64_t *n, int32_t *run_start)
-{
-	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i < *n && (i == 0 || key[i] != key[i - 1])) run_start[slot[i]] = (int32_t)i;
-}
-
+// every rank's keys are distinct, so a run has at most W entries: one thread per run
 __global__ __launch_bounds__(BLOCK) void k_mgx_sum(XSlots X, const uint32_t *val, const int64_t *m_dev, const int64_t *n_run_dev, const int32_t *run_start, pga_arc_part_t *out)
 {
-	const int lane = threadIdx.x & 63;
 	const int64_t m = *m_dev, n_run = *n_run_dev;
-	for (int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); w < n_run; w += (int64_t)gridDim.x * (BLOCK / WAVE)) {
+	for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_run; w += (int64_t)gridDim.x * BLOCK) {
 		const int64_t st = run_start[w], en = w + 1 < n_run ? run_start[w + 1] : m;
-		int ng = 0, tot = 0;
-		uint64_t sd = 0, x = 0;
-		int64_t a1 = 0, a2 = 0;
-		for (int64_t j = st + lane; j < en; j += WAVE) {
+		pga_arc_part_t r;
+		{ const uint32_t v = val[st]; r = X.arcs((int)(v / X.arc_cap))[v % X.arc_cap]; }
+		for (int64_t j = st + 1; j < en; ++j) {
 			const uint32_t v = val[j];
 			const pga_arc_part_t p = X.arcs((int)(v / X.arc_cap))[v % X.arc_cap];
-			x = p.x, ng += p.n_genome, tot += p.tot_cnt, sd += p.sum_dist, a1 += p.sum_s1, a2 += p.sum_s2;
+			r.n_genome += p.n_genome, r.tot_cnt += p.tot_cnt, r.sum_dist += p.sum_dist, r.sum_s1 += p.sum_s1, r.sum_s2 += p.sum_s2;
 		}
-		ng = wave_sum(ng), tot = wave_sum(tot);
-		sd = wave_sum64(sd), a1 = (int64_t)wave_sum64((unsigned long long)a1), a2 = (int64_t)wave_sum64((unsigned long long)a2);
-		if (lane == 0) { // lane 0 always owns element st
-			pga_arc_part_t r;
-			r.x = x, r.n_genome = ng, r.tot_cnt = tot, r.sum_dist = sd, r.sum_s1 = a1, r.sum_s2 = a2;
-			out[w] = r;
-		}
+		out[w] = r;
 	}
 }
 

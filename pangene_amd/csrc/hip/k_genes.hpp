@@ -318,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) void k_arc_compact(const int4 *gmeta, const 
 }
 
 // the same into the rank's slot of a sharded round's all-gather (k_arcs.hpp, XS_HDR): the table, the segment counters and the table's size
-__global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const int32_t *off, int S, const pga_arc_part_t *stage, const int32_t *seg_cnt, int32_t *slot, int64_t arc_cap)
+__global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const int32_t *off, int S, const pga_arc_part_t *stage, const int32_t *seg_cnt, int32_t *slot, int64_t arc_cap, const int64_t *dcnt)
 {
 	const int lane = threadIdx.x & 63;
 	int32_t *segc = slot + XS_HDR;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const i
 			for (int i = lane; i < n; i += WAVE) arcs[o + i] = stage[m.x + i];
 		if (lane == 0) {
 			segc[sid] = seg_cnt[sid], segc[S + sid] = seg_cnt[S + sid];
-			if (sid == S - 1) { slot[0] = o + n; for (int t = 1; t < XS_HDR; ++t) slot[t] = 0; }
+			if (sid == S - 1) { slot[0] = o + n, slot[1] = dcnt[9] != 0, slot[2] = dcnt[3] != 0; for (int t = 3; t < XS_HDR; ++t) slot[t] = 0; } // [1] a hub gene overflowed its LDS table, [2] an invariant was violated
 		}
 	}
 }

@@ -113,7 +113,7 @@ struct PinArena {
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_BIGLIST, S_STAGE_SID, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK, S_XG_BUF, S_XG_OUT, S_XSTAT,
+	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_BIGLIST, S_STAGE_SID, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK, S_XG_BUF, S_XG_OUT, S_XG_OUT2, S_XSTAT,
 	S_COUNT
 };
 
@@ -146,7 +146,9 @@ struct pga_ctx {
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors
 	int32_t *max_ori = 0; int64_t *sums = 0; int32_t *vtx_cnt = 0; int32_t *g2s = 0; int32_t n_seg = 0;
-	int64_t x_pairs_seen = 0, x_arcs_seen = 0; // sharded pga_branch_loop: the longest pair list / the largest local arc table of any rank in the last run of this context
+	bool x_redo = false; // pga_arc_round_x gave the round up: the next pga_arc_round repeats it on the sort path
+	int64_t x_pairs_seen = 0, x_arcs_seen = 0; // sharded rounds: the longest pair list / the largest local arc table of any rank in the PREVIOUS run over this context (pga_begin shifts)
+	int64_t x_pairs_run = 0, x_arcs_run = 0;   // ... and in the run under way
 	int64_t *dcnt = 0;      // device counters: [0] triples [1] arcs-temp [2] misc [3] invariant flag, [4..7] hazards
 	int64_t *h_cnt = 0;     // pinned mirror
 	int64_t *h_box = 0;     // the same memory as the device sees it
@@ -544,6 +546,9 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	c->yrec_valid = false, c->z_valid = false;
 	const int N = c->N, GL = c->n_genome;
 	c->walk_valid = false, c->ha_valid = false;
+	if (c->x_arcs_run > 0) c->x_arcs_seen = c->x_arcs_run; // sharded rounds: what the run that just ended needed is what this one's exchange buffers hold
+	if (c->x_pairs_run > 0) c->x_pairs_seen = c->x_pairs_run;
+	c->x_arcs_run = 0, c->x_pairs_run = 0, c->x_redo = false;
 	if (c->timing_on) { // class 3: the whole of stage A (sorts, per-hit constants, pg_flag_pseudo, sweeps, filters) = pga_begin + pga_ingest
 		if (c->span_a) (void)hipEventDestroy(c->span_a);
 		HIPCHK(hipEventCreate(&c->span_a));
@@ -1023,6 +1028,10 @@ static bool arc_sort_path_forced() { static const bool f = getenv("PANGENE_ARC_S
 
 extern "C" int pga_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_part_t **arcs_out, int64_t *n_arcs_out)
 {
+	if (c->x_redo) { // the round pga_arc_round_x gave up (its sweep has run)
+		c->x_redo = false, c->table_sparse = false;
+		return arc_round_sorted(c, use_ori, seg_cnt_out, arcs_out, n_arcs_out, c->N != 0);
+	}
 	if (c->N && !arc_sort_path_forced()) {
 		int32_t *deg;
 		*n_arcs_out = 0;
@@ -1359,6 +1368,14 @@ extern "C" int pga_branch_decide_filter(pga_ctx_t *c, double branch_diff, double
 	return decide_impl(c, branch_diff, branch_diff_dist, branch_diff_cut, nullptr, nullptr, nullptr, nullptr, &rf);
 }
 
+// entries of a rank's slot: what the previous run over the shard needed (the largest local table of any rank in any round) with a margin,
+// never less than the largest table the host-driven rounds have seen; before there is a previous run, that with a wide margin
+static int64_t x_arc_cap(const pga_ctx *c, const pga_loop_xchg_t *x)
+{
+	const int64_t m = std::max<int64_t>(c->x_arcs_seen, x->arc_cap_hint);
+	return c->x_arcs_seen > 0 ? m + m / 8 + 1024 : m * 3 / 2 + 1024;
+}
+
 // (sharded form) the round's local table -> every rank's slot -> the merged table as the current one: pga_arc_round's compaction, the
 // all-gather, pga_arc_merge and pga_arc_set_current with every count left in device memory
 struct LoopX { const pga_loop_xchg_t *x; int64_t arc_cap, pair_cap, ecap; int32_t *gbuf; int64_t slot_words; pga_arc_part_t *merged; int64_t *xstat, *d_off; };
@@ -1370,30 +1387,86 @@ static int loop_exchange_table(pga_ctx *c, const LoopX &L)
 	pga_arc_part_t *stage = (pga_arc_part_t *)c->pool.get(S_ARC_STAGE, 0);
 	int4 *gmeta = (int4 *)c->pool.get(S_GMETA, 0);
 	int32_t *goff = (int32_t *)c->pool.get(S_GOFF, sizeof(int32_t) * (size_t)S);
-	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, 0);
+	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, sizeof(int32_t) * 2 * (size_t)std::max(1, S) * SEGCNT_COPIES);
 	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(std::max<int64_t>(std::max<int64_t>(S, mcap), 2 * (int64_t)c->N + 2)));
 	uint64_t *key = (uint64_t *)c->pool.get(S_MG_KEY, sizeof(uint64_t) * (size_t)mcap + 64);
 	uint32_t *val = (uint32_t *)c->pool.get(S_MG_VAL, sizeof(uint32_t) * (size_t)mcap + 64);
 	int32_t *slot = (int32_t *)c->pool.get(S_MG_SLOT, sizeof(int32_t) * (size_t)mcap + 64);
 	int32_t *run_start = (int32_t *)c->pool.get(S_MG_RUN, sizeof(int32_t) * (size_t)mcap + 64);
-	if (!stage || !gmeta || !goff || !seg_cnt || !tile || !key || !val || !slot || !run_start) return PGA_ERR_NOMEM;
-	device_scan<I32>(InGmeta{gmeta}, OutExclI32{goff}, S, tile, OpSum{}, I32{0}, c->st);
-	hipLaunchKernelGGL(k_xs_compact, dim3(nblk(S, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gmeta, goff, S, stage, seg_cnt, L.gbuf, L.arc_cap);
+	if (!goff || !tile || !key || !val || !slot || !run_start || (c->N && (!stage || !gmeta || !seg_cnt))) return PGA_ERR_NOMEM;
+	if (c->N) {
+		device_scan<I32>(InGmeta{gmeta}, OutExclI32{goff}, S, tile, OpSum{}, I32{0}, c->st);
+		hipLaunchKernelGGL(k_xs_compact, dim3(nblk(S, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gmeta, goff, S, stage, seg_cnt, L.gbuf, L.arc_cap, (const int64_t *)c->dcnt);
+	}
+	else HIPCHK(hipMemsetAsync(L.gbuf, 0, sizeof(int32_t) * (size_t)(XS_HDR + xs_seg_words(S)), c->st)); // a rank without hits: an empty table, no counts
 	{ const int rc = L.x->allgather(L.x->user, L.gbuf, L.gbuf + L.slot_words, L.slot_words * (int64_t)sizeof(int32_t)); if (rc) return rc; }
 	XSlots X = { L.gbuf + L.slot_words, L.slot_words, L.arc_cap, W, S };
 	hipLaunchKernelGGL(k_xs_sum, dim3(nblk(std::max(n_vtx, 1))), dim3(BLOCK), 0, c->st, X, seg_cnt, L.d_off, c->dcnt, L.xstat);
 	hipLaunchKernelGGL(k_mgx_rank, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, X, (const int64_t *)L.d_off, key, val);
 	device_scan<I32>(InMgHeadN{key, L.d_off + W}, OutExclI32{slot}, mcap, tile, OpSum{}, I32{0}, c->st);
-	hipLaunchKernelGGL(k_mgx_count, dim3(1), dim3(64), 0, c->st, key, slot, (const int64_t *)(L.d_off + W), c->dcnt + 10);
-	hipLaunchKernelGGL(k_mgx_runstart, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, key, slot, (const int64_t *)(L.d_off + W), run_start);
-	hipLaunchKernelGGL(k_mgx_sum, dim3((unsigned)std::min<int64_t>(nblk(mcap, BLOCK / WAVE), 8 * c->n_cu)), dim3(BLOCK), 0, c->st, X, val, (const int64_t *)(L.d_off + W), (const int64_t *)(c->dcnt + 10), run_start, L.merged);
+	hipLaunchKernelGGL(k_mgx_runstart, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, key, slot, (const int64_t *)(L.d_off + W), run_start, c->dcnt + 10);
+	hipLaunchKernelGGL(k_mgx_sum, dim3((unsigned)std::min<int64_t>(nblk(mcap), 8 * c->n_cu)), dim3(BLOCK), 0, c->st, X, val, (const int64_t *)(L.d_off + W), (const int64_t *)(c->dcnt + 10), run_start, L.merged);
 	CurTable t;
 	TRY(cur_table(c, L.ecap, S, &t));
 	zero_multi(c, t.vs, sizeof(int32_t) * (size_t)n_vtx, t.ve, sizeof(int32_t) * (size_t)n_vtx, t.aw, (size_t)mcap, t.vwk, (size_t)n_vtx);
-	hipLaunchKernelGGL(k_seg_gid, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, c->Q, S, t.sg);
+	// (t.sg, the gene of every segment, stands: the gene kernels write it for every live segment, and a deleted one keeps its number)
 	hipLaunchKernelGGL(k_curx_prep, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, L.merged, (const int64_t *)(c->dcnt + 10), t.sg, t.ax, t.s1, t.agid, t.vs, t.ve);
 	hipLaunchKernelGGL(k_deg, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, t.vs, t.ve, n_vtx, t.dg);
 	c->table_sparse = false, c->cur_tab = L.merged, c->cur_tab_n = 0; // (the size stays on the device: nobody may ask for this table -- the loop's caller runs a round of its own next)
+	return 0;
+}
+
+// pg_gen_arc of a sharded run with ONE wait: pga_arc_round + the exchange + pga_arc_merge + pga_arc_set_current, the table sizes left
+// in device memory (the ranks' tables travel in slots of a capacity all ranks share, see pga_loop_xchg_t).  seg_cnt_host[2S], deg_host[2S]
+// and *n_arc are the global results.  1 = the round is void on some rank (a hub gene beyond its LDS table, a table beyond the slot):
+// every rank gets 1 and repeats the round through pga_arc_round (which then takes the sort path, without a second sweep);
+// 2 = not applicable (no capacity known yet: the first round of a shard is host-driven).
+extern "C" int pga_arc_round_x(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, const pga_loop_xchg_t *x, int32_t *seg_cnt_host, int32_t *deg_host, int64_t *n_arc)
+{
+	const int S = n_seg, n_vtx = 2 * S, N = c->N;
+	if (x == nullptr || x->world < 1 || x->allgather == nullptr || S != c->n_seg || S == 0 || arc_sort_path_forced()) return 2;
+	if (c->x_arcs_seen <= 0 && x->arc_cap_hint <= 0) return 2;
+	LoopX L = { x, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr };
+	L.arc_cap = x_arc_cap(c, x);
+	{ const char *ea = getenv("PANGENE_XLOOP_ARC_CAP"); if (ea && c->x_arcs_seen == 0) L.arc_cap = std::max<int64_t>(atoll(ea), 1); }
+	L.ecap = std::max<int64_t>(2 * (int64_t)N + 2, (int64_t)x->world * L.arc_cap);
+	L.slot_words = xs_slot_words(S, L.arc_cap);
+	L.gbuf = (int32_t *)c->pool.get(S_XG_BUF, sizeof(int32_t) * (size_t)L.slot_words * ((size_t)x->world + 1) + 64);
+	L.merged = (pga_arc_part_t *)c->pool.get(S_XG_OUT, sizeof(pga_arc_part_t) * (size_t)x->world * (size_t)L.arc_cap + 64);
+	L.xstat = (int64_t *)c->pool.get(S_XSTAT, sizeof(int64_t) * 8);
+	L.d_off = (int64_t *)c->pool.get(S_MG_SRC, sizeof(int64_t) * ((size_t)x->world + 2));
+	if (!L.gbuf || !L.merged || !L.xstat || !L.d_off) return PGA_ERR_NOMEM;
+	const size_t need = sizeof(int32_t) * (2 * (size_t)n_vtx) + 8 * sizeof(int64_t) + 64;
+	if (c->h_round_cap < need) {
+		if (c->h_round) HIPCHK(hipStreamSynchronize(c->st));
+		c->h_round = (int32_t *)c->pin.get(need + need / 2);
+		if (!c->h_round) return PGA_ERR_NOMEM;
+		c->h_round_cap = need + need / 2;
+	}
+	c->arc_deferred = false, c->arc_done = false;
+	HIPCHK(hipMemsetAsync(L.xstat, 0, sizeof(int64_t) * 8, c->st));
+	HIPCHK(hipMemsetAsync(c->dcnt + 9, 0, sizeof(int64_t), c->st));
+	HIPCHK(hipMemsetAsync(c->dcnt + 11, 0, sizeof(int64_t), c->st));
+	CurTable t;
+	TRY(cur_table(c, L.ecap, S, &t));
+	if (N) { int32_t *seg_cnt, *deg; TRY(arc_round_genes(c, use_ori, &seg_cnt, &deg, nullptr, false)); }
+	hipLaunchKernelGGL(k_seg_gid, dim3(nblk(c->Q)), dim3(BLOCK), 0, c->st, c->g2s, c->Q, S, t.sg); // (a rank without hits ran no gene kernel)
+	TRY(loop_exchange_table(c, L));
+	int32_t *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, 0);
+	int64_t *tail = (int64_t *)(c->h_round + 2 * (size_t)n_vtx + ((2 * (size_t)n_vtx) & 1)); // 8-byte aligned, behind the two vectors
+	HIPCHK(hipMemcpyAsync(c->h_round, seg_cnt, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(c->h_round + n_vtx, t.dg, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(tail, L.xstat, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
+	TRY(sync_st(c));
+	c->br_n = L.ecap, c->br_S = S, c->br_np = 0;
+	if (tail[4] || c->h_cnt[3]) return PGA_ERR_INVARIANT;
+	c->x_arcs_run = std::max<int64_t>(c->x_arcs_run, tail[1]);
+	if (tail[2]) c->x_arcs_seen = std::max<int64_t>(c->x_arcs_seen, tail[1]); // a table beyond its slot: the next round of this run already knows
+	if (tail[2] || tail[3] || c->h_cnt[11]) { c->x_redo = true; return 1; } // (every rank sees the same slots: the same verdict everywhere)
+	memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
+	c->cur_tab = L.merged, c->cur_tab_n = c->h_cnt[10], c->table_sparse = false;
+	*n_arc = c->h_cnt[10];
 	return 0;
 }
 
@@ -1423,9 +1496,9 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		int64_t dmax = 8;
 		for (int r = 1; r < n_round; ++r) dmax = std::max<int64_t>(dmax, max_degree[r]);
 		const int64_t worst = std::min<int64_t>((int64_t)n_vtx * dmax * dmax, (int64_t)1 << 26);
-		L.pair_cap = std::min<int64_t>(worst, c->x_pairs_seen > 0 ? c->x_pairs_seen + c->x_pairs_seen / 4 + 4096 : std::max<int64_t>((int64_t)1 << 20, 4 * (int64_t)n_vtx));
+		L.pair_cap = std::min<int64_t>(worst, c->x_pairs_seen > 0 ? c->x_pairs_seen + c->x_pairs_seen / 8 + 4096 : std::max<int64_t>((int64_t)1 << 20, 4 * (int64_t)n_vtx));
 		L.pair_cap = std::max<int64_t>(L.pair_cap, 4 * (int64_t)n_vtx); // (pga_branch_pairs never works with less)
-		L.arc_cap = std::max<int64_t>(x->arc_cap_hint, c->x_arcs_seen) * 3 / 2 + 1024;
+		L.arc_cap = x_arc_cap(c, x); // (every slot travels at its capacity)
 		if (c->x_pairs_seen == 0) { // (tests: start with buffers that are too small, to reach status 3 and the learned capacities)
 			const char *ep = getenv("PANGENE_XLOOP_PAIR_CAP"), *ea = getenv("PANGENE_XLOOP_ARC_CAP");
 			if (ep) L.pair_cap = std::max<int64_t>(atoll(ep), 4 * (int64_t)n_vtx);
@@ -1435,7 +1508,7 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		L.ecap = std::max<int64_t>(2 * (int64_t)N + 2, (int64_t)x->world * L.arc_cap);
 		L.slot_words = xs_slot_words(S, L.arc_cap);
 		L.gbuf = (int32_t *)c->pool.get(S_XG_BUF, sizeof(int32_t) * (size_t)L.slot_words * ((size_t)x->world + 1) + 64);
-		L.merged = (pga_arc_part_t *)c->pool.get(S_XG_OUT, sizeof(pga_arc_part_t) * (size_t)x->world * (size_t)L.arc_cap + 64);
+		L.merged = (pga_arc_part_t *)c->pool.get(S_XG_OUT2, sizeof(pga_arc_part_t) * (size_t)x->world * (size_t)L.arc_cap + 64); // (not the slot the current table may live in: it is read below)
 		L.xstat = (int64_t *)c->pool.get(S_XSTAT, sizeof(int64_t) * 8);
 		L.d_off = (int64_t *)c->pool.get(S_MG_SRC, sizeof(int64_t) * ((size_t)x->world + 2));
 		if (!L.gbuf || !L.merged || !L.xstat || !L.d_off) return PGA_ERR_NOMEM;
@@ -1509,7 +1582,8 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	if (getenv("PANGENE_DEBUG_LOOP")) fprintf(stderr, "[pga_branch_loop] counters after %d rounds: invariant %lld, table overflows (last round) %lld, sticky %lld, pairs (last round) %lld of capacity %lld\n", n_round, (long long)c->h_cnt[3], (long long)c->h_cnt[9], (long long)c->h_cnt[11], (long long)c->h_cnt[15], (long long)c->br_cap);
 	if (x) {
 		const int32_t *f = (const int32_t *)h_x;
-		c->x_pairs_seen = h_x[2], c->x_arcs_seen = h_x[3]; // what the LAST run over this shard needed (every round's list is all-reduced at the capacity: not more than a margin above that)
+		c->x_pairs_run = std::max<int64_t>(c->x_pairs_run, h_x[2]), c->x_arcs_run = std::max<int64_t>(c->x_arcs_run, h_x[3]); // the next run's capacities (every round's list travels at its capacity: a margin above what was needed, not more)
+		if (f[0] && f[2]) c->x_pairs_seen = std::max<int64_t>(c->x_pairs_seen, c->x_pairs_run), c->x_arcs_seen = std::max<int64_t>(c->x_arcs_seen, c->x_arcs_run); // (status 3: the repeated run's host-driven rounds use them too)
 		c->br_np_seen = std::max<int64_t>(c->br_np_seen, h_x[2]);
 		c->br_cap = std::max<int64_t>(br_cap_before, c->br_cap);
 		if (getenv("PANGENE_DEBUG_LOOP")) fprintf(stderr, "[pga_branch_loop] sharded over %d ranks: flags (summed) void %d invariant %d capacity %d hub %d; longest pair list %lld of %lld, largest local table %lld of %lld\n", x->world, f[0], f[1], f[2], f[3],
@@ -1759,7 +1833,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count, pga_arc_round_x
 	};
 	return &b;
 }

@@ -760,6 +760,9 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	return 0;
 }
 
+static int loop_allreduce(void *user, void *buf, int64_t count);
+static int loop_allgather(void *user, const void *in, void *out, int64_t bytes);
+
 // pg_gen_arc (graph.c:87-177): per-genome work + local reduce on the backend, cross-shard merge and
 // the three double roundings of graph.c:170-172 here
 // defer: the next thing is a branch step, which reads the table on the backend and waits for its own results anyway: the round's
@@ -778,6 +781,23 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer 
 	}
 	std::vector<int32_t> sc((size_t)S * 2 + 1);
 	ext->deg.assign((size_t)S * 2 + 1, 0);
+	static const bool no_x = std::getenv("PANGENE_SHARDED_LOOP_HOST") != nullptr; // (tests: the host-driven exchange of a sharded run)
+	if (sharded() && !no_x && be->arc_round_x && be->is_device() && ext->x_arc_slot > 0 && S > 0 && pg_verbose < 3) {
+		// every rank's table in a slot of a capacity all ranks share (no size exchange), merged on the backend, ONE wait
+		pga_loop_xchg_t lx;
+		lx.user = ext, lx.rank = g_xchg.rank, lx.world = g_xchg.world, lx.arc_cap_hint = ext->x_arc_slot, lx.allreduce_i32_sum = loop_allreduce, lx.allgather = loop_allgather;
+		int64_t n_arc = 0;
+		int rc;
+		{ Phase ph(PH_ARC_DEV); rc = be->arc_round_x(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, &lx, sc.data(), ext->deg.data(), &n_arc); }
+		if (rc < 0) { set_error(rc, "arc_round_x"); return rc; }
+		if (rc == 0) {
+			{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
+			for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
+			ext->cur_arcs = nullptr, q->n_arc = (int32_t)n_arc; // (fetch_arcs asks the backend for the table)
+			return 0;
+		}
+		// 1: void on some rank (all ranks were told), 2: not applicable -- the host-driven exchange below
+	}
 	if (!sharded()) {
 		// one call, one wait: the backend keeps the table (and what branch marking, hit marking and the degree filter read from
 		// it) resident; it travels to the host once, after the last round (fetch_arcs)
