@@ -271,6 +271,7 @@ def main():
         lib.pg_graph_destroy(one_pass(d, False))
     lib.pg_kernel_timing_reset(d)
     sync()
+    n_coll0 = lib.pg_collective_count()
     t0 = time.time()
     path_sec = 0.0
     phases = None
@@ -283,8 +284,10 @@ def main():
         phases = cur if phases is None else [x + y for x, y in zip(phases, cur)]
     sync()
     dt = time.time() - t0
+    coll_per_step = (lib.pg_collective_count() - n_coll0) / a.steps
+    waits_per_step = k_timing(d, 4)[1] / a.steps  # times the host waited for the stream
     if a.leg == "steps-only":  # the exchange-overhead leg of another bench.py: its own line, nothing else
-        os.write(real_stdout, (json.dumps({"ms_per_step": round(dt / a.steps * 1e3, 3), "exchange": exchange_kind, "gfa_sl_md5": sl_md5(gfa)}) + "\n").encode())
+        os.write(real_stdout, (json.dumps({"ms_per_step": round(dt / a.steps * 1e3, 3), "exchange": exchange_kind, "gfa_sl_md5": sl_md5(gfa), "collectives_per_step": coll_per_step, "host_waits_per_step": waits_per_step}) + "\n").encode())
         lib.pg_data_destroy(d)
         if world > 1 or force_x:
             dist.barrier()
@@ -392,7 +395,7 @@ def main():
                 x = json.loads(line[-1])
                 plain = dt / a.steps * 1e3
                 xo = {"ms_per_step": x["ms_per_step"], "plain_ms_per_step": round(plain, 3), "overhead": round(x["ms_per_step"] / plain - 1.0, 4), "exchange": x["exchange"],
-                      "same_graph": x["gfa_sl_md5"] == sl_md5(gfa),
+                      "same_graph": x["gfa_sl_md5"] == sl_md5(gfa), "collectives_per_step": x.get("collectives_per_step"), "host_waits_per_step": x.get("host_waits_per_step"),
                       "what": "PANGENE_FORCE_EXCHANGE=1, world size 1: the sharded route with every collective issued (identities), in a fresh process"}
             else:
                 xo = {"error": (r.stderr.decode()[-300:] or "no output")}
@@ -448,6 +451,7 @@ def main():
             "gfa_sl_md5": sl_md5(gfa),
             "gfa_identical_to_reference": (hashlib.md5(gfa).hexdigest() == ref_md5) if ref_md5 else None,
             "not_timed": {"paf_generate_s": round(t_gen, 2), "paf_parse_and_pack_s": round(t_parse, 3), "gfa_write_s": round(t_write[0], 4), "path_only_ms_per_step": round(path_sec / a.steps * 1e3, 3)},
+            "host_waits_per_step": waits_per_step, "collectives_per_step": coll_per_step,
             "host_phases_ms_per_step": {lib.pg_phase_name(i).decode(): round(v / a.steps * 1e3, 3) for i, v in enumerate(phases or [])},
         }
         os.write(real_stdout, (json.dumps(res) + "\n").encode())

@@ -251,9 +251,12 @@ int pg_rerun_resident(pg_data_t *d);
 
 /* HIP-event timing of kernel classes of the runs since the last pg_kernel_timing_reset (which also switches the
  * timing on): which 0 = stage-A sweep pg_shadow(cal_dom_sc=1) ("K1", the hit-filter+overlap kernel), 1 = pg_flt_ov_isoform
- * sweep, 2 = (not timed any more: the stage-C sweeps), 3 = all of stage A (sorts, per-hit constants, pg_flag_pseudo, sweeps, filters). */
+ * sweep, 2 = (not timed any more: the stage-C sweeps), 3 = all of stage A (sorts, per-hit constants, pg_flag_pseudo, sweeps, filters),
+ * 4 = no kernel class: n_launch = the number of times the host waited for the backend's stream since the reset. */
 int pg_kernel_timing(pg_data_t *d, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
 int pg_kernel_timing_reset(pg_data_t *d);
+/* collectives the driver has issued through the exchange callbacks so far, in this process (bench.py: per pass of a sharded run) */
+int64_t pg_collective_count(void);
 
 /* Page-locked host memory: the library keeps the pinned slabs of an upload for the next one (up to 4 GiB while a data set is
  * alive; 256 MiB after the last pg_data_destroy).  A long-lived host calls this to give back what exceeds keep_bytes (0 = all). */

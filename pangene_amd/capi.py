@@ -68,6 +68,7 @@ _API = {
     "pg_rerun_resident": (C.c_int, [C.c_void_p]),
     "pg_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pg_kernel_timing_reset": (C.c_int, [C.c_void_p]),
+    "pg_collective_count": (C.c_int64, []),
     "pg_set_exact_mode": (None, [C.c_int]),
     "pg_phase_times": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "pg_phase_name": (C.c_char_p, [C.c_int]),

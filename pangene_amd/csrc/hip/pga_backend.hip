@@ -146,6 +146,7 @@ struct pga_ctx {
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors
 	int32_t *max_ori = 0; int64_t *sums = 0; int32_t *vtx_cnt = 0; int32_t *g2s = 0; int32_t n_seg = 0;
+	uint64_t sync_epoch_reset = 0;
 	bool x_redo = false; // pga_arc_round_x gave the round up: the next pga_arc_round repeats it on the sort path
 	int64_t x_pairs_seen = 0, x_arcs_seen = 0; // sharded rounds: the longest pair list / the largest local arc table of any rank in the PREVIOUS run over this context (pga_begin shifts)
 	int64_t x_pairs_run = 0, x_arcs_run = 0;   // ... and in the run under way
@@ -1806,6 +1807,7 @@ extern "C" int pga_hazards(pga_ctx_t *c, pga_hazard_t *out)
 extern "C" int pga_timing_reset(pga_ctx_t *c)
 {
 	TRY(sync_st(c));
+	c->sync_epoch_reset = c->sync_epoch;
 	for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	c->timed.clear();
 	c->timing_on = true;
@@ -1814,6 +1816,12 @@ extern "C" int pga_timing_reset(pga_ctx_t *c)
 
 extern "C" int pga_timing_get(pga_ctx_t *c, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units)
 {
+	if (which == 4) { // host waits on the stream since pga_timing_reset (not a kernel class: nothing to wait for)
+		if (total_ms) *total_ms = 0;
+		if (n_launch) *n_launch = (int64_t)(c->sync_epoch - c->sync_epoch_reset);
+		if (units) *units = 0;
+		return 0;
+	}
 	TRY(sync_st(c));
 	double ms = 0; int64_t n = 0, u = 0;
 	for (auto &t : c->timed) {

@@ -26,6 +26,7 @@ int pg_verbose = 3;
 namespace pgx {
 
 pg_exchange_t g_xchg; bool g_has_xchg = false;
+static int64_t g_n_coll = 0; // collectives issued so far (pg_collective_count)
 double g_phase[PH_COUNT];
 static int g_err = 0; static char g_errstr[256] = "";
 static double g_path_sec = 0.0, g_upload_sec = 0.0, g_pack_sec = 0.0, g_t_path0 = 0.0; static int64_t g_path_hits = 0;
@@ -76,6 +77,7 @@ static int xreduce(const pga_backend_t *be, pga_ctx_t *ctx, void *buf, int64_t c
 {
 	if (!sharded() || count == 0) return 0;
 	BE_CALL(xready(be, ctx), "sync");
+	++g_n_coll;
 	return g_xchg.allreduce(g_xchg.user, buf, count, dtype, op, be->is_device());
 }
 
@@ -94,6 +96,7 @@ static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int6
 	BE_CALL(be->scratch(ctx, sizeof(int64_t) * (size_t)(W + 1), &scr), "scratch");
 	BE_CALL(be->put(ctx, scr, &n, sizeof(int64_t)), "put");
 	BE_CALL(xready(be, ctx), "sync");
+	g_n_coll += 2;
 	BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + sizeof(int64_t), sizeof(int64_t), be->is_device()), "allgather(count)");
 	BE_CALL(be->fetch(ctx, cnt.data(), (char *)scr + sizeof(int64_t), sizeof(int64_t) * (size_t)W), "fetch");
 	int64_t mx = *std::max_element(cnt.begin(), cnt.end()), tot = 0;
@@ -839,6 +842,7 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer 
 			BE_CALL(be->scratch(ext->ctx, bytes * (size_t)(W + 1), &scr), "scratch");
 			if (n_loc) BE_CALL(be->copy(ext->ctx, scr, b_arc, (size_t)n_loc * sizeof(pga_arc_part_t)), "copy");
 			BE_CALL(xready(be, ext->ctx), "sync");
+			++g_n_coll;
 			BE_CALL(g_xchg.allgather(g_xchg.user, scr, (char *)scr + bytes, (int64_t)bytes, be->is_device()), "allgather(arcs)");
 			BE_CALL(be->arc_merge(ext->ctx, (pga_arc_part_t *)((char *)scr + bytes), cnt.data(), W, slot, &merged, &n_mg), "arc_merge");
 		}
@@ -1016,12 +1020,14 @@ static int loop_allreduce(void *user, void *buf, int64_t count)
 	DataExt *ext = (DataExt *)user;
 	if (count == 0) return 0;
 	const int rc = xready(ext->be, ext->ctx);
+	++g_n_coll;
 	return rc ? rc : g_xchg.allreduce(g_xchg.user, buf, count, PG_X_I32, PG_X_SUM, ext->be->is_device());
 }
 static int loop_allgather(void *user, const void *in, void *out, int64_t bytes)
 {
 	DataExt *ext = (DataExt *)user;
 	const int rc = xready(ext->be, ext->ctx);
+	++g_n_coll;
 	return rc ? rc : g_xchg.allgather(g_xchg.user, in, out, bytes, ext->be->is_device());
 }
 
@@ -1387,6 +1393,8 @@ int pg_kernel_timing(pg_data_t *d, int32_t which, double *total_ms, int64_t *n_l
 	if (ext == nullptr || ext->ctx == nullptr || ext->be->timing_get == nullptr) return PGA_ERR_ARG;
 	return ext->be->timing_get(ext->ctx, which, total_ms, n_launch, units);
 }
+
+int64_t pg_collective_count(void) { return g_n_coll; }
 
 int pg_kernel_timing_reset(pg_data_t *d)
 {
