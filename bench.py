@@ -249,6 +249,19 @@ def main():
         lib.pg_graph_destroy(one_pass(dw, True))
         lib.pg_data_destroy(dw)
 
+    # the box's host link, as this process sees it (the pool's boxes differ by 10x here, and the cold pass carries one upload of the shard)
+    link_gbps = None
+    try:
+        hb = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+        db_ = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        db_.copy_(hb, non_blocking=True); torch.cuda.synchronize(dev)
+        t0 = time.time()
+        db_.copy_(hb, non_blocking=True); torch.cuda.synchronize(dev)
+        link_gbps = round((64 << 20) / (time.time() - t0) / 1e9, 1)
+        del hb, db_
+    except Exception:
+        pass
+
     d = lib.pg_data_init()
     t0 = time.time()
     capi.read_files(lib, opt, d, files, [not (lo <= j < hi) for j in range(G)])  # host threads; ids as in sequential reads; packs the blocks
@@ -445,7 +458,8 @@ def main():
             # SURVEY 8(d)'s metric as defined there (upload included): ONE pass over a data set the process has not seen
             "cold_pass": {"value": round(tot_hits / t_cold_all / 1e6, 3), "unit": "M hits/s", "ms": round(t_cold_all * 1e3, 2),
                           "includes": "block packing in the reader threads (%.1f ms) + allocation, H2D and order-replay set-up (%.1f ms) + stages A+B+C; excludes PAF text parsing and GFA printing; kernels were loaded by a tiny warm-up data set"
-                                      % (t_pack * 1e3, t_upload * 1e3)},
+                                      % (t_pack * 1e3, t_upload * 1e3),
+                          "upload_MB": round((44 * nh.value + 8 * ne.value) / 1e6, 1), "host_to_device_GBps_of_this_box": link_gbps},
             "roofline": roof, "cpu_baseline": cpu, "big_shard": big, "human_shard": human, "exchange_overhead": xo, "cli": cli,
             "gfa_md5": hashlib.md5(gfa).hexdigest() if world == 1 else None,
             "gfa_sl_md5": sl_md5(gfa),

@@ -382,8 +382,12 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	const double t1 = now_sec();
 	const int rc = ext->be->create(&ext->ctx, &sh, &par); // returns when the blocks have been read
 	const double t2 = now_sec();
+	size_t n_pin = 0, n_plain = 0, n_fresh = 0;
+	for (const HostSlab &x : ext->slabs) { if (x.pinned) ++n_pin; else ++n_plain; if (x.fresh) ++n_fresh; }
 	free_packs(ext, false);
-	if (timing) std::fprintf(stderr, "[build_backend] tables %.3f ms, create %.3f ms, release of the host blocks %.3f ms\n", (t1 - t_bb0) * 1e3, (t2 - t1) * 1e3, (now_sec() - t2) * 1e3);
+	if (timing) {
+		std::fprintf(stderr, "[build_backend] tables %.3f ms, create %.3f ms, release of the host blocks %.3f ms; block slabs: %zu page-locked, %zu plain, %zu new in this read\n", (t1 - t_bb0) * 1e3, (t2 - t1) * 1e3, (now_sec() - t2) * 1e3, n_pin, n_plain, n_fresh);
+	}
 	return rc;
 }
 
