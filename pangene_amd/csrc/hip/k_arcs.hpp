@@ -251,74 +251,75 @@ struct XSlots {
 	__device__ __forceinline__ const pga_arc_part_t *arcs(int r) const { return (const pga_arc_part_t *)(all + r * slot_words + XS_HDR + xs_seg_words(S)); }
 };
 
-// global segment counters = sum over the slots; off[r] = entries of ranks < r (a table beyond the capacity raises the sticky flag:
-// the round, and with it the run, is void); the largest table and the longest pair list seen, for the next run's capacities
-__global__ __launch_bounds__(BLOCK) void k_xs_sum(XSlots X, int32_t *seg_cnt, int64_t *off, int64_t *dcnt, int64_t *xstat)
+// One launch after the all-gather: the global segment counters (sum over the slots), the place of every table entry in the merged
+// order (every rank's table arrives sorted by x with distinct keys: binary searches in the other tables, equal keys keep rank order)
+// and, by thread 0, off[r] = entries of ranks < r for the kernels that follow (a table beyond its slot raises the sticky flag: the
+// round, and with it the run, is void), the largest table and the longest pair list seen (the next run's capacities), the ranks' flags.
+__global__ __launch_bounds__(BLOCK) void k_xs_sum_rank(XSlots X, int32_t *seg_cnt, int64_t *off, int64_t *dcnt, int64_t *xstat, uint64_t *key, uint32_t *val)
 {
-	const int i = blockIdx.x * BLOCK + threadIdx.x;
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (i < 2 * X.S) {
 		int32_t t = 0;
 		for (int r = 0; r < X.W; ++r) t += X.all[r * X.slot_words + XS_HDR + i];
 		seg_cnt[i] = t;
 	}
+	// A table beyond its slot was not copied in full: what its slot holds is no table.  The round is void then (sticky flag) -- and
+	// EMPTY, so that whatever still runs on it before the host gets to know runs on nothing instead of on leftovers.
+	bool void_round = false;
+	for (int q = 0; q < X.W; ++q) void_round = void_round || X.all[q * X.slot_words] > X.arc_cap;
 	if (i == 0) {
 		int64_t run = 0, mx = 0;
 		off[0] = 0;
 		for (int r = 0; r < X.W; ++r) {
-			int64_t n = X.all[r * X.slot_words];
+			const int64_t n = X.all[r * X.slot_words];
 			mx = mx > n ? mx : n;
 			if (X.all[r * X.slot_words + 1]) xstat[3] = 1;
 			if (X.all[r * X.slot_words + 2]) xstat[4] = 1;
-			if (n > X.arc_cap) dcnt[11] = 1, xstat[2] = 1, n = X.arc_cap;
-			run += n, off[r + 1] = run;
+			run += void_round ? 0 : n, off[r + 1] = run;
 		}
+		if (void_round) dcnt[11] = 1, xstat[2] = 1;
 		if (mx > xstat[1]) xstat[1] = mx;
 		if (dcnt[15] > xstat[0]) xstat[0] = dcnt[15];
 	}
-}
-
-__global__ __launch_bounds__(BLOCK) void k_mgx_rank(XSlots X, const int64_t *off, uint64_t *key, uint32_t *val)
-{
-	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= off[X.W]) return;
-	int r = 0;
-	while (off[r + 1] <= i) ++r;
-	const int64_t k = i - off[r];
+	if (void_round) return;
+	// (every thread derives the tables' sizes from the W headers itself: off[] is only written here)
+	int r = -1;
+	int64_t base = 0;
+	for (int q = 0; q < X.W; ++q) {
+		const int64_t n = X.all[q * X.slot_words];
+		if (i < base + n) { r = q; break; }
+		base += n;
+	}
+	if (r < 0) return;
+	const int64_t k = i - base;
 	const uint64_t x = X.arcs(r)[k].x;
 	int64_t pos = k;
 	for (int q = 0; q < X.W; ++q)
-		if (q != r) pos += mg_bound(X.arcs(q), off[q + 1] - off[q], x, q < r);
+		if (q != r) pos += mg_bound(X.arcs(q), (int64_t)X.all[q * X.slot_words], x, q < r);
 	key[pos] = x, val[pos] = (uint32_t)(r * X.arc_cap + k);
 }
 
 struct InMgHeadN { const uint64_t *key; const int64_t *n; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(i < *n && (i == 0 || key[i] != key[i - 1])) ? 1 : 0}; } };
 
-// run starts, and (the thread of the last entry) the number of runs = the merged table's size
-__global__ __launch_bounds__(BLOCK) void k_mgx_runstart(const uint64_t *key, const int32_t *slot, const int64_t *n, int32_t *run_start, int64_t *n_run)
+// The merged table: the first entry of a run of equal keys sums the run (at most W entries: a rank's keys are distinct) into its place
+// slot[i] = number of runs before it; the last entry leaves the number of runs = the table's size.
+__global__ __launch_bounds__(BLOCK) void k_mgx_heads_sum(XSlots X, const uint64_t *key, const uint32_t *val, const int32_t *slot, const int64_t *m_dev, pga_arc_part_t *out, int64_t *n_run)
 {
-	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x, m = *n;
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x, m = *m_dev;
 	if (i == 0 && m == 0) *n_run = 0;
 	if (i >= m) return;
-	const bool head = i == 0 || key[i] != key[i - 1];
-	if (head) run_start[slot[i]] = (int32_t)i;
+	const uint64_t x = key[i];
+	const bool head = i == 0 || key[i - 1] != x;
 	if (i == m - 1) *n_run = slot[i] + (head ? 1 : 0);
-}
-
-// every rank's keys are distinct, so a run has at most W entries: one thread per run
-__global__ __launch_bounds__(BLOCK) void k_mgx_sum(XSlots X, const uint32_t *val, const int64_t *m_dev, const int64_t *n_run_dev, const int32_t *run_start, pga_arc_part_t *out)
-{
-	const int64_t m = *m_dev, n_run = *n_run_dev;
-	for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_run; w += (int64_t)gridDim.x * BLOCK) {
-		const int64_t st = run_start[w], en = w + 1 < n_run ? run_start[w + 1] : m;
-		pga_arc_part_t r;
-		{ const uint32_t v = val[st]; r = X.arcs((int)(v / X.arc_cap))[v % X.arc_cap]; }
-		for (int64_t j = st + 1; j < en; ++j) {
-			const uint32_t v = val[j];
-			const pga_arc_part_t p = X.arcs((int)(v / X.arc_cap))[v % X.arc_cap];
-			r.n_genome += p.n_genome, r.tot_cnt += p.tot_cnt, r.sum_dist += p.sum_dist, r.sum_s1 += p.sum_s1, r.sum_s2 += p.sum_s2;
-		}
-		out[w] = r;
+	if (!head) return;
+	pga_arc_part_t r;
+	{ const uint32_t v = val[i]; r = X.arcs((int)(v / X.arc_cap))[v % X.arc_cap]; }
+	for (int64_t j = i + 1; j < m && key[j] == x; ++j) {
+		const uint32_t v = val[j];
+		const pga_arc_part_t p = X.arcs((int)(v / X.arc_cap))[v % X.arc_cap];
+		r.n_genome += p.n_genome, r.tot_cnt += p.tot_cnt, r.sum_dist += p.sum_dist, r.sum_s1 += p.sum_s1, r.sum_s2 += p.sum_s2;
 	}
+	out[slot[i]] = r;
 }
 
 // what the caller is told at the end (summed over the ranks): [0] some queued round is void, [1] an invariant was violated, [2] an

@@ -208,17 +208,31 @@ __global__ __launch_bounds__(BLOCK) void k_cur_prep(const pga_arc_part_t *arcs, 
 	if (i == n_arc - 1 || (uint32_t)(arcs[i + 1].x >> 32) != v) ve[v] = (int32_t)i + 1;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_curx_prep(const pga_arc_part_t *arcs, const int64_t *n_dev, const int32_t *seg_gid, uint64_t *ax, int32_t *s1, int32_t *agid, int32_t *vs, int32_t *ve)
-{ // k_cur_prep with the table's size in device memory (sharded pga_branch_loop)
+// pga_arc_set_current in one launch, the table's size in device memory (sharded rounds): per arc x / rounded s1 / target gene / weak_br = 0;
+// the first arc of a vertex finds the end of the vertex's run and writes its range, degree and "no weak arc", and the same (empty) for the
+// vertices without arcs before it; the vertices behind the last arc are left to the threads beyond the table (the grid has n_vtx of them).
+__global__ __launch_bounds__(BLOCK) void k_curx_table(const pga_arc_part_t *arcs, const int64_t *n_dev, int64_t cap, const int32_t *seg_gid, int n_vtx, uint64_t *ax, int32_t *s1, int32_t *agid, uint8_t *aw,
+                                                        int32_t *vs, int32_t *ve, int32_t *deg, uint8_t *vwk)
+{
 	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x, n_arc = *n_dev;
-	if (i >= n_arc) return;
+	if (i >= n_arc) { // a spare thread: one vertex behind the last one that has arcs
+		if (i < cap) return;
+		const int64_t u = (n_arc ? (int64_t)(uint32_t)(arcs[n_arc - 1].x >> 32) + 1 : 0) + (i - cap);
+		if (u < n_vtx) vs[u] = 0, ve[u] = 0, deg[u] = 0, vwk[u] = 0;
+		return;
+	}
 	const pga_arc_part_t a = arcs[i];
 	const uint32_t v = (uint32_t)(a.x >> 32);
 	ax[i] = a.x;
 	s1[i] = (int32_t)((double)a.sum_s1 / a.n_genome + .499); // graph.c:171
 	agid[i] = seg_gid[(uint32_t)a.x >> 1];
-	if (i == 0 || (uint32_t)(arcs[i - 1].x >> 32) != v) vs[v] = (int32_t)i;
-	if (i == n_arc - 1 || (uint32_t)(arcs[i + 1].x >> 32) != v) ve[v] = (int32_t)i + 1;
+	aw[i] = 0;
+	const int64_t pv = i ? (int64_t)(uint32_t)(arcs[i - 1].x >> 32) : -1;
+	if (pv == (int64_t)v) return;
+	int64_t e = i + 1;
+	while (e < n_arc && (uint32_t)(arcs[e].x >> 32) == v) ++e;
+	vs[v] = (int32_t)i, ve[v] = (int32_t)e, deg[v] = (int32_t)(e - i), vwk[v] = 0;
+	for (int64_t u = pv + 1; u < (int64_t)v; ++u) vs[u] = 0, ve[u] = 0, deg[u] = 0, vwk[u] = 0;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_deg(const int32_t *vs, const int32_t *ve, int n_vtx, int32_t *deg)

@@ -150,6 +150,7 @@ struct pga_ctx {
 	bool x_redo = false; // pga_arc_round_x gave the round up: the next pga_arc_round repeats it on the sort path
 	int64_t x_pairs_seen = 0, x_arcs_seen = 0; // sharded rounds: the longest pair list / the largest local arc table of any rank in the PREVIOUS run over this context (pga_begin shifts)
 	int64_t x_pairs_run = 0, x_arcs_run = 0;   // ... and in the run under way
+	int64_t x_pair_floor = 0, x_arc_floor = 0; // after a run that was void for want of room (its statistics are worth little): capacities not to go below
 	int64_t *dcnt = 0;      // device counters: [0] triples [1] arcs-temp [2] misc [3] invariant flag, [4..7] hazards
 	int64_t *h_cnt = 0;     // pinned mirror
 	int64_t *h_box = 0;     // the same memory as the device sees it
@@ -1374,7 +1375,8 @@ extern "C" int pga_branch_decide_filter(pga_ctx_t *c, double branch_diff, double
 static int64_t x_arc_cap(const pga_ctx *c, const pga_loop_xchg_t *x)
 {
 	const int64_t m = std::max<int64_t>(c->x_arcs_seen, x->arc_cap_hint);
-	return c->x_arcs_seen > 0 ? m + m / 8 + 1024 : m * 3 / 2 + 1024;
+	// (before there is a previous run: the tables of the branch rounds grow to a multiple of the first graphs' -- 3.5x at configs[1])
+	return std::max<int64_t>(c->x_arc_floor, c->x_arcs_seen > 0 ? m + m / 8 + 1024 : 5 * m + 4096);
 }
 
 // (sharded form) the round's local table -> every rank's slot -> the merged table as the current one: pga_arc_round's compaction, the
@@ -1393,8 +1395,7 @@ static int loop_exchange_table(pga_ctx *c, const LoopX &L)
 	uint64_t *key = (uint64_t *)c->pool.get(S_MG_KEY, sizeof(uint64_t) * (size_t)mcap + 64);
 	uint32_t *val = (uint32_t *)c->pool.get(S_MG_VAL, sizeof(uint32_t) * (size_t)mcap + 64);
 	int32_t *slot = (int32_t *)c->pool.get(S_MG_SLOT, sizeof(int32_t) * (size_t)mcap + 64);
-	int32_t *run_start = (int32_t *)c->pool.get(S_MG_RUN, sizeof(int32_t) * (size_t)mcap + 64);
-	if (!goff || !tile || !key || !val || !slot || !run_start || (c->N && (!stage || !gmeta || !seg_cnt))) return PGA_ERR_NOMEM;
+	if (!goff || !tile || !key || !val || !slot || (c->N && (!stage || !gmeta || !seg_cnt))) return PGA_ERR_NOMEM;
 	if (c->N) {
 		device_scan<I32>(InGmeta{gmeta}, OutExclI32{goff}, S, tile, OpSum{}, I32{0}, c->st);
 		hipLaunchKernelGGL(k_xs_compact, dim3(nblk(S, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gmeta, goff, S, stage, seg_cnt, L.gbuf, L.arc_cap, (const int64_t *)c->dcnt);
@@ -1402,17 +1403,13 @@ static int loop_exchange_table(pga_ctx *c, const LoopX &L)
 	else HIPCHK(hipMemsetAsync(L.gbuf, 0, sizeof(int32_t) * (size_t)(XS_HDR + xs_seg_words(S)), c->st)); // a rank without hits: an empty table, no counts
 	{ const int rc = L.x->allgather(L.x->user, L.gbuf, L.gbuf + L.slot_words, L.slot_words * (int64_t)sizeof(int32_t)); if (rc) return rc; }
 	XSlots X = { L.gbuf + L.slot_words, L.slot_words, L.arc_cap, W, S };
-	hipLaunchKernelGGL(k_xs_sum, dim3(nblk(std::max(n_vtx, 1))), dim3(BLOCK), 0, c->st, X, seg_cnt, L.d_off, c->dcnt, L.xstat);
-	hipLaunchKernelGGL(k_mgx_rank, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, X, (const int64_t *)L.d_off, key, val);
+	hipLaunchKernelGGL(k_xs_sum_rank, dim3(nblk(std::max<int64_t>(mcap, n_vtx))), dim3(BLOCK), 0, c->st, X, seg_cnt, L.d_off, c->dcnt, L.xstat, key, val);
 	device_scan<I32>(InMgHeadN{key, L.d_off + W}, OutExclI32{slot}, mcap, tile, OpSum{}, I32{0}, c->st);
-	hipLaunchKernelGGL(k_mgx_runstart, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, key, slot, (const int64_t *)(L.d_off + W), run_start, c->dcnt + 10);
-	hipLaunchKernelGGL(k_mgx_sum, dim3((unsigned)std::min<int64_t>(nblk(mcap), 8 * c->n_cu)), dim3(BLOCK), 0, c->st, X, val, (const int64_t *)(L.d_off + W), (const int64_t *)(c->dcnt + 10), run_start, L.merged);
+	hipLaunchKernelGGL(k_mgx_heads_sum, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, X, (const uint64_t *)key, (const uint32_t *)val, (const int32_t *)slot, (const int64_t *)(L.d_off + W), L.merged, c->dcnt + 10);
 	CurTable t;
 	TRY(cur_table(c, L.ecap, S, &t));
-	zero_multi(c, t.vs, sizeof(int32_t) * (size_t)n_vtx, t.ve, sizeof(int32_t) * (size_t)n_vtx, t.aw, (size_t)mcap, t.vwk, (size_t)n_vtx);
 	// (t.sg, the gene of every segment, stands: the gene kernels write it for every live segment, and a deleted one keeps its number)
-	hipLaunchKernelGGL(k_curx_prep, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, L.merged, (const int64_t *)(c->dcnt + 10), t.sg, t.ax, t.s1, t.agid, t.vs, t.ve);
-	hipLaunchKernelGGL(k_deg, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, t.vs, t.ve, n_vtx, t.dg);
+	hipLaunchKernelGGL(k_curx_table, dim3(nblk(mcap + n_vtx)), dim3(BLOCK), 0, c->st, (const pga_arc_part_t *)L.merged, (const int64_t *)(c->dcnt + 10), mcap, (const int32_t *)t.sg, n_vtx, t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk);
 	c->table_sparse = false, c->cur_tab = L.merged, c->cur_tab_n = 0; // (the size stays on the device: nobody may ask for this table -- the loop's caller runs a round of its own next)
 	return 0;
 }
@@ -1430,6 +1427,7 @@ extern "C" int pga_arc_round_x(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, con
 	LoopX L = { x, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr };
 	L.arc_cap = x_arc_cap(c, x);
 	{ const char *ea = getenv("PANGENE_XLOOP_ARC_CAP"); if (ea && c->x_arcs_seen == 0) L.arc_cap = std::max<int64_t>(atoll(ea), 1); }
+	if ((int64_t)x->world * L.arc_cap >= ((int64_t)1 << 31)) return 2; // (entries of the gathered tables are numbered in 32 bits)
 	L.ecap = std::max<int64_t>(2 * (int64_t)N + 2, (int64_t)x->world * L.arc_cap);
 	L.slot_words = xs_slot_words(S, L.arc_cap);
 	L.gbuf = (int32_t *)c->pool.get(S_XG_BUF, sizeof(int32_t) * (size_t)L.slot_words * ((size_t)x->world + 1) + 64);
@@ -1463,7 +1461,7 @@ extern "C" int pga_arc_round_x(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, con
 	c->br_n = L.ecap, c->br_S = S, c->br_np = 0;
 	if (tail[4] || c->h_cnt[3]) return PGA_ERR_INVARIANT;
 	c->x_arcs_run = std::max<int64_t>(c->x_arcs_run, tail[1]);
-	if (tail[2]) c->x_arcs_seen = std::max<int64_t>(c->x_arcs_seen, tail[1]); // a table beyond its slot: the next round of this run already knows
+	if (tail[2]) c->x_arcs_seen = std::max<int64_t>(c->x_arcs_seen, tail[1]), c->x_arc_floor = std::max<int64_t>(c->x_arc_floor, tail[1] + tail[1] / 4 + 1024); // a table beyond its slot: the next round of this run already knows
 	if (tail[2] || tail[3] || c->h_cnt[11]) { c->x_redo = true; return 1; } // (every rank sees the same slots: the same verdict everywhere)
 	memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
 	c->cur_tab = L.merged, c->cur_tab_n = c->h_cnt[10], c->table_sparse = false;
@@ -1498,7 +1496,7 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		for (int r = 1; r < n_round; ++r) dmax = std::max<int64_t>(dmax, max_degree[r]);
 		const int64_t worst = std::min<int64_t>((int64_t)n_vtx * dmax * dmax, (int64_t)1 << 26);
 		L.pair_cap = std::min<int64_t>(worst, c->x_pairs_seen > 0 ? c->x_pairs_seen + c->x_pairs_seen / 8 + 4096 : std::max<int64_t>((int64_t)1 << 20, 4 * (int64_t)n_vtx));
-		L.pair_cap = std::max<int64_t>(L.pair_cap, 4 * (int64_t)n_vtx); // (pga_branch_pairs never works with less)
+		L.pair_cap = std::max<int64_t>(std::max<int64_t>(L.pair_cap, std::min<int64_t>(worst, c->x_pair_floor)), 4 * (int64_t)n_vtx); // (pga_branch_pairs never works with less)
 		L.arc_cap = x_arc_cap(c, x); // (every slot travels at its capacity)
 		if (c->x_pairs_seen == 0) { // (tests: start with buffers that are too small, to reach status 3 and the learned capacities)
 			const char *ep = getenv("PANGENE_XLOOP_PAIR_CAP"), *ea = getenv("PANGENE_XLOOP_ARC_CAP");
@@ -1506,6 +1504,7 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 			if (ea && c->x_arcs_seen == 0) L.arc_cap = std::max<int64_t>(atoll(ea), 1);
 		}
 		c->br_cap = L.pair_cap; // what k_pair_offsets tests and k_br_wave / k_n_local stride over
+		if ((int64_t)x->world * L.arc_cap >= ((int64_t)1 << 31)) return 2; // (entries of the gathered tables are numbered in 32 bits)
 		L.ecap = std::max<int64_t>(2 * (int64_t)N + 2, (int64_t)x->world * L.arc_cap);
 		L.slot_words = xs_slot_words(S, L.arc_cap);
 		L.gbuf = (int32_t *)c->pool.get(S_XG_BUF, sizeof(int32_t) * (size_t)L.slot_words * ((size_t)x->world + 1) + 64);
@@ -1584,7 +1583,12 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	if (x) {
 		const int32_t *f = (const int32_t *)h_x;
 		c->x_pairs_run = std::max<int64_t>(c->x_pairs_run, h_x[2]), c->x_arcs_run = std::max<int64_t>(c->x_arcs_run, h_x[3]); // the next run's capacities (every round's list travels at its capacity: a margin above what was needed, not more)
-		if (f[0] && f[2]) c->x_pairs_seen = std::max<int64_t>(c->x_pairs_seen, c->x_pairs_run), c->x_arcs_seen = std::max<int64_t>(c->x_arcs_seen, c->x_arcs_run); // (status 3: the repeated run's host-driven rounds use them too)
+		if (f[0] && f[2]) { // status 3: what the void run counted is worth little (it ran on empty tables from the overflow on) -- double what was too small, keep what was not
+			c->x_pairs_seen = std::max<int64_t>(c->x_pairs_seen, c->x_pairs_run), c->x_arcs_seen = std::max<int64_t>(c->x_arcs_seen, c->x_arcs_run);
+			c->x_pair_floor = std::max<int64_t>(c->x_pair_floor, h_x[2] > L.pair_cap ? std::max<int64_t>(2 * L.pair_cap, h_x[2] + h_x[2] / 4) : L.pair_cap);
+			c->x_arc_floor = std::max<int64_t>(c->x_arc_floor, h_x[3] > L.arc_cap ? std::max<int64_t>(2 * L.arc_cap, h_x[3] + h_x[3] / 4) : L.arc_cap);
+		}
+		else if (!f[0]) c->x_pair_floor = 0, c->x_arc_floor = 0; // a run that went through: its statistics are the next run's capacities
 		c->br_np_seen = std::max<int64_t>(c->br_np_seen, h_x[2]);
 		c->br_cap = std::max<int64_t>(br_cap_before, c->br_cap);
 		if (getenv("PANGENE_DEBUG_LOOP")) fprintf(stderr, "[pga_branch_loop] sharded over %d ranks: flags (summed) void %d invariant %d capacity %d hub %d; longest pair list %lld of %lld, largest local table %lld of %lld\n", x->world, f[0], f[1], f[2], f[3],

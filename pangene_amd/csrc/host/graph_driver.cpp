@@ -839,7 +839,7 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer 
 		std::vector<int64_t> cnt((size_t)W);
 		int64_t slot = 0, n_mg = 0;
 		for (int r = 0; r < W; ++r) cnt[(size_t)r] = all[(size_t)S * 2 + (size_t)r], slot = std::max(slot, cnt[(size_t)r]);
-		ext->x_arc_slot = slot; // the largest local table of this round, over all ranks (every rank has the same number)
+		ext->x_arc_slot = std::max(ext->x_arc_slot, slot); // the largest local table of any host-driven round of this data set, over all ranks (every rank has the same number)
 		pga_arc_part_t *merged = nullptr;
 		if (slot) {
 			const size_t bytes = (size_t)slot * sizeof(pga_arc_part_t);

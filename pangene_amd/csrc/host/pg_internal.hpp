@@ -87,7 +87,7 @@ struct DataExt {
 	int x_sorts[2] = {0, 0};           // cs / cm sorts of the reference seen so far in this run
 	std::vector<int32_t> head_file;    // per local genome: file index of the hit at array index 0 (-1 canonical)
 	bool skip_loop_once = false;       // sharded pga_branch_loop asked for a repeated run because an exchange buffer was too small (status 3): that run is host-driven, later ones queue again
-	int64_t x_arc_slot = 0;            // sharded runs: the largest local arc table of the last host-driven round, over all ranks
+	int64_t x_arc_slot = 0;            // sharded runs: the largest local arc table of any host-driven round so far, over all ranks
 	bool no_branch_loop = false;       // the queued branch rounds (pga_branch_loop) met something they cannot handle on this data set: host-driven rounds from now on
 	bool arc_pending = false;          // a deferred arc round whose host results have not been collected (arc_collect)
 	bool rerun = false;                // pg_rerun_resident(): keep the backend context, skip pack + upload
