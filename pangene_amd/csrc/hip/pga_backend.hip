@@ -1462,7 +1462,7 @@ extern "C" int pga_arc_round_x(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, con
 	if (tail[4] || c->h_cnt[3]) return PGA_ERR_INVARIANT;
 	c->x_arcs_run = std::max<int64_t>(c->x_arcs_run, tail[1]);
 	if (tail[2]) c->x_arcs_seen = std::max<int64_t>(c->x_arcs_seen, tail[1]), c->x_arc_floor = std::max<int64_t>(c->x_arc_floor, tail[1] + tail[1] / 4 + 1024); // a table beyond its slot: the next round of this run already knows
-	if (tail[2] || tail[3] || c->h_cnt[11]) { c->x_redo = true; return 1; } // (every rank sees the same slots: the same verdict everywhere)
+	if (tail[2] || tail[3]) { c->x_redo = true; return 1; } // (from the gathered slots alone -- every local cause is in the rank's header: the same verdict on every rank)
 	memcpy(seg_cnt_host, c->h_round, sizeof(int32_t) * (size_t)n_vtx), memcpy(deg_host, c->h_round + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
 	c->cur_tab = L.merged, c->cur_tab_n = c->h_cnt[10], c->table_sparse = false;
 	*n_arc = c->h_cnt[10];
