@@ -23,12 +23,14 @@ stats)
 	MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 PANGENE_FORCE_EXCHANGE=1 rocprofv3 --kernel-trace --stats -d $out/prof_x -o s -- python bench.py --leg steps-only --steps 5 --warmup 2 > $out/${tag}_bench_forced_exchange_under_rocprof.json 2>/dev/null
 	python profiles/tools/kernel_stats.py $out/prof_x > $out/${tag}_kernel_stats_forced_exchange.txt; rm -rf $out/prof_x
 	head -n 14 $out/${tag}_kernel_stats_bench_default.txt; tail -n 3 $out/${tag}_kernel_stats_bench_default.txt; head -n 12 $out/${tag}_kernel_stats_big_shard_1250x5k.txt; tail -n 3 $out/${tag}_kernel_stats_forced_exchange.txt;;
-pmc)
+pmc1|pmc)
 	B="python bench.py --no-cpu-baseline --no-extra-legs --steps 1 --warmup 0"
 	rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/prof_fetch -o f -- $B > /dev/null 2>&1
 	rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/prof_write -o w -- $B > /dev/null 2>&1
-	python profiles/tools/k1_traffic.py $out/prof_fetch $out/prof_write $out/${tag}_bench_default.json > $out/k1_pmc_traffic.json
-	rm -rf $out/prof_fetch $out/prof_write
+	J=$out/${tag}_bench_default.json; [ -f $J ] || J=profiles/${tag}_bench_default.json  # (a fresh box only has what the repository holds)
+	python profiles/tools/k1_traffic.py $out/prof_fetch $out/prof_write $J > $out/k1_pmc_traffic.json
+	rm -rf $out/prof_fetch $out/prof_write; cat $out/k1_pmc_traffic.json
+	[ $stage = pmc1 ] && continue
 	B="python bench.py $Q --genomes-per-gpu 1250 --steps 1 --warmup 0"
 	rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/prof_fetch -o f -- $B > /dev/null 2>&1
 	rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/prof_write -o w -- $B > /dev/null 2>&1
