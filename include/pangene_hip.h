@@ -359,7 +359,13 @@ void pga_host_trim(size_t keep_bytes);
 int pga_set_device(int32_t device);
 int pga_device_count(void);
 
-typedef struct pga_branch_par_s { double branch_diff, branch_diff_dist, branch_diff_cut; int32_t local_dist, local_count, frag_mode, use_ori; } pga_branch_par_t;
+typedef struct pga_branch_par_s {
+	double branch_diff, branch_diff_dist, branch_diff_cut; int32_t local_dist, local_count, frag_mode, use_ori;
+	/* pre_on != 0 (unsharded form only): the deferred arc round behind which the loop is called is graph 1's (graph.c:291), and the loop
+	 * starts with graph 2's pg_flt_high_occ (graph.c:294-295: its tests with these three limits, n_dist_loci still 0) + the next
+	 * pg_gen_arc (graph.c:296) before round 0 -- deletions as holes, like those of the rounds */
+	int32_t pre_on, pre_max_tot_cnt, pre_max_degree, pre_max_dist_loci;
+} pga_branch_par_t;
 /* pg_gen_arc (graph.c:87-177) of a sharded run with ONE wait: arc_round + the exchange + arc_merge + arc_set_current, every table
  * size left on the device; the ranks' tables travel in slots of a capacity all ranks share (the largest local table the shard has
  * seen, with a margin; x->arc_cap_hint before the backend has seen one).  seg_cnt[2 n_seg], deg[2 n_seg] (host) and *n_arc are the

@@ -1529,6 +1529,19 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		hipLaunchKernelGGL(k_deg, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, t.vs, t.ve, n_vtx, t.dg);
 		c->br_n = L.ecap;
 	}
+	if (par->pre_on) { // graph 2 (graph.c:293-296): pg_flt_high_occ on graph 1's table (no branch step has run: n_dist_loci = 0), PG_SET_FILTER(vtx == 0), pg_gen_arc
+		if (x) return 2;
+		HIPCHK(hipMemsetAsync(ndl, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
+		int32_t *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0), *sg = (int32_t *)c->pool.get(S_BR_SEGGID, 0), *dg = (int32_t *)c->pool.get(S_DEG, 0), *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, 0);
+		uint8_t *vwk = (uint8_t *)c->pool.get(S_VWK, (size_t)n_vtx + 16);
+		if (!vs || !ve || !sg || !dg || !seg_cnt || !vwk) return PGA_ERR_NOMEM;
+		hipLaunchKernelGGL(k_round_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)ndl, par->pre_max_tot_cnt, par->pre_max_degree, par->pre_max_dist_loci, (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive, (int4 *)nullptr);
+		hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1);
+		c->walk_valid = false, c->ha_valid = false;
+		int32_t *sc2, *deg2;
+		TRY(arc_round_genes(c, par->use_ori, &sc2, &deg2, nullptr, false));
+		c->br_n = 2 * (int64_t)N + 2, c->br_S = S, c->br_np = 0;
+	}
 	for (int r = 0; r < n_round; ++r) {
 		// pg_mark_branch_flt_arc (branch.c:48-106)
 		TRY(pga_rep_pos(c));

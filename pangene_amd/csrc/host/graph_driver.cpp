@@ -1035,7 +1035,7 @@ static int loop_allgather(void *user, const void *in, void *out, int64_t bytes)
 	return rc ? rc : g_xchg.allgather(g_xchg.user, in, out, bytes, ext->be->is_device());
 }
 
-static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, int32_t R, bool *done)
+static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, int32_t R, bool *done, bool pre = false) // pre: behind graph 1's deferred arc round, graph 2 included (pga_branch_par_t::pre_on)
 {
 	*done = false;
 	const pga_backend_t *be = ext->be;
@@ -1044,7 +1044,8 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	static const bool no_x = std::getenv("PANGENE_SHARDED_LOOP_HOST") != nullptr; // (tests: the host-driven rounds of a sharded run)
 	if (shd && (no_x || !be->is_device())) return 0;
 	if (shd && ext->skip_loop_once) { ext->skip_loop_once = false; return 0; } // the repeated run after status 3
-	const int n_sorts = 2 * R - 1; // of each kind: one pair per pg_mark_branch_flt_hit (branch.c:116,140), one per pg_gen_arc (graph.c:103,123)
+	if (pre && shd) return 0;
+	const int n_sorts = 2 * R - 1 + (pre ? 1 : 0); // of each kind: one pair per pg_mark_branch_flt_hit (branch.c:116,140), one per pg_gen_arc (graph.c:103,123)
 	static const bool dbg = std::getenv("PANGENE_DEBUG_LOOP") != nullptr;
 	bool quiet;
 	{ Phase ph(PH_EXACT); quiet = exact_quiet(ext, n_sorts); }
@@ -1069,6 +1070,8 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	pga_branch_par_t par;
 	par.branch_diff = opt->branch_diff, par.branch_diff_dist = opt->branch_diff_dist, par.branch_diff_cut = opt->branch_diff_cut;
 	par.local_dist = opt->local_dist, par.local_count = opt->local_count, par.frag_mode = !!(opt->flag & PG_F_FRAG_MODE), par.use_ori = !!(opt->flag & PG_F_ORI_FOR_BRANCH);
+	par.pre_on = pre ? 1 : 0; // graph.c:294: pg_flt_high_occ(q, max_avg_occ * 2, max_degree * 2, max_dist_loci)
+	par.pre_max_tot_cnt = opt->max_avg_occ * 2 * q->d->n_genome, par.pre_max_degree = opt->max_degree * 2, par.pre_max_dist_loci = opt->max_dist_loci;
 	std::vector<uint8_t> &alive = ext->del_buf;
 	alive.assign((size_t)S + 1, 1);
 	pga_loop_xchg_t lx;
@@ -1117,25 +1120,39 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	if (!exact_early(ext)) { Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "set_head"); } // index 0 of the S1 order, needed from the first sweep of stage C on (see post_process_impl)
 	BE_CALL(flag_vtx(q, ext), "flag_vtx");
 	BE_CALL(trace_state(ext, "gen_vtx+flag_vtx", 0), "trace");
-	BE_CALL(gen_arc(opt, q, ext), "gen_arc");
+	// Graphs 2 and 3 as ONE queue when the backend can (pga_branch_loop with its pre-step): graph 1's arc round is left running, the
+	// loop starts with graph 2's pg_flt_high_occ + pg_gen_arc and goes on with the branch rounds -- no wait between graph 1 and round n-2.
+	static const bool no_pre = std::getenv("PANGENE_LOOP_NO_PRE") != nullptr; // (tests: graph 2 host-driven in front of the queued rounds)
+	const bool try_pre = !no_pre && opt->n_branch_flt >= 2 && ext->be->branch_loop != nullptr && !sharded() && pg_verbose < 3 && trace_path() == nullptr && !ext->no_branch_loop;
+	BE_CALL(gen_arc(opt, q, ext, try_pre), "gen_arc");
 	BE_CALL(trace_state(ext, "gen_arc", 1), "trace");
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-1 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
-	// graph 2: after removing high-occurrence vertices (graph.c:293-298)
-	BE_CALL(flt_high_occ(opt->max_avg_occ * 2, opt->max_degree * 2, opt->max_dist_loci, q, ext), "flt_high_occ");
-	BE_CALL(trace_state(ext, "flt_high_occ", 1), "trace");
-	BE_CALL(gen_arc(opt, q, ext, opt->n_branch_flt > 0), "gen_arc");
-	BE_CALL(trace_state(ext, "gen_arc", 2), "trace");
-	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-2 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
-	// graph 3: branch filtering (graph.c:300-315)
 	int32_t i_first = 0;
-	if (opt->n_branch_flt >= 2) { // all rounds but the last one in one go, when the backend can (the last one fills the public fields of pg_seg_t)
-		bool done = false;
-		const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt - 1, &done);
+	bool queued = false;
+	if (try_pre) {
+		const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt - 1, &queued, true);
 		if (rc) return rc;
-		if (done) {
-			i_first = opt->n_branch_flt - 1;
-			BE_CALL(gen_arc(opt, q, ext, true), "gen_arc"); // the arc round of round n-2, with the renumbered segments
+		if (!queued) { // not applicable after all (the order replay needs the host, ...): graph 1's results the usual way
+			const int rc2 = arc_collect(opt, q, ext);
+			if (rc2 < 0) return rc2;
 		}
+	}
+	if (!queued) {
+		// graph 2: after removing high-occurrence vertices (graph.c:293-298)
+		BE_CALL(flt_high_occ(opt->max_avg_occ * 2, opt->max_degree * 2, opt->max_dist_loci, q, ext), "flt_high_occ");
+		BE_CALL(trace_state(ext, "flt_high_occ", 1), "trace");
+		BE_CALL(gen_arc(opt, q, ext, opt->n_branch_flt > 0), "gen_arc");
+		BE_CALL(trace_state(ext, "gen_arc", 2), "trace");
+		if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-2 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
+		// graph 3: branch filtering (graph.c:300-315)
+		if (opt->n_branch_flt >= 2) { // all rounds but the last one in one go, when the backend can (the last one fills the public fields of pg_seg_t)
+			const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt - 1, &queued);
+			if (rc) return rc;
+		}
+	}
+	if (queued) {
+		i_first = opt->n_branch_flt - 1;
+		BE_CALL(gen_arc(opt, q, ext, true), "gen_arc"); // the arc round of round n-2, with the renumbered segments
 	}
 	for (int32_t i = i_first; i < opt->n_branch_flt; ++i) {
 		double r = 1.0 + (double)(opt->n_branch_flt - 1 - i) / opt->n_branch_flt;

@@ -109,7 +109,7 @@ def _run_with_env(tmp_path, env, mode, variant, files):
 
 
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
-@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1"},
+@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1", "PANGENE_LOOP_NO_PRE": "1"},
                                  {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1"}])
 def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
@@ -117,7 +117,8 @@ def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     entries so that most rounds overflow, must both reproduce the reference's bytes (mode all).  Third setting: a vertex spill area of
     three records (manydoms then needs the second, grown attempt of pga_vtx_partials) and the 64-bit comparison keys ranked by a sort
     (the path of shards whose score, preferred bit and protein rank do not fit 32 bits), and the general scan for the pair offsets
-    (the path of graphs with more than 65536 oriented vertices).  The second setting also keeps pg_flt_high_occ's tests on the host
+    (the path of graphs with more than 65536 oriented vertices), and graph 2 (graph.c:293-298) host-driven in front of the queued branch
+    rounds instead of as their pre-step.  The second setting also keeps pg_flt_high_occ's tests on the host
     (the general route of a branch round: sharded runs, log lines, rounds repeated on the sort path) -- and with a four-entry table
     the queued branch rounds (pga_branch_loop, the default) give up on their sticky flag, so the run is repeated with host-driven
     rounds (RC_REDO).  Fourth setting: host-driven rounds from the start (one wait per round, verdicts of pg_flt_high_occ fetched as
