@@ -315,7 +315,7 @@ typedef struct {
 	int  (*arc_table)(pga_ctx_t *, const pga_arc_part_t **, int64_t *);
 	int  (*arc_round_finish)(pga_ctx_t *, int32_t, int32_t *, int32_t *);
 	int  (*branch_decide_filter)(pga_ctx_t *, double, double, double, int32_t, int32_t, int32_t, int32_t, uint8_t *); /* may be NULL */
-	int  (*branch_loop)(pga_ctx_t *, int32_t, const struct pga_branch_par_s *, const int32_t *, const int32_t *, const int32_t *, uint8_t *, const struct pga_loop_xchg_s *); /* may be NULL */
+	int  (*branch_loop)(pga_ctx_t *, int32_t, const struct pga_branch_par_s *, const int32_t *, const int32_t *, const int32_t *, uint8_t *, const struct pga_loop_xchg_s *, int32_t *, int32_t *); /* may be NULL */
 	void (*host_trim)(size_t); /* may be NULL */
 	int  (*set_device)(int32_t); /* may be NULL */
 	int  (*device_count)(void);  /* may be NULL */
@@ -365,6 +365,11 @@ typedef struct pga_branch_par_s {
 	 * starts with graph 2's pg_flt_high_occ (graph.c:294-295: its tests with these three limits, n_dist_loci still 0) + the next
 	 * pg_gen_arc (graph.c:296) before round 0 -- deletions as holes, like those of the rounds */
 	int32_t pre_on, pre_max_tot_cnt, pre_max_degree, pre_max_dist_loci;
+	/* final_on != 0 (unsharded form only): n_round = ALL the rounds, and the arc round behind the last one (graph.c:313 of round
+	 * n-1, the graph that is written) is queued as well.  seg_cnt[2 n_seg] (graph.c:125-126 of that round) and n_dist_loci[2 n_seg]
+	 * (branch.c:90 of the last branch step) come back with seg_alive, all in the numbering the loop was entered with; the table
+	 * (arc_table) is in that numbering too: the caller renumbers segments and arcs (monotone, so every order stands). */
+	int32_t final_on;
 } pga_branch_par_t;
 /* pg_gen_arc (graph.c:87-177) of a sharded run with ONE wait: arc_round + the exchange + arc_merge + arc_set_current, every table
  * size left on the device; the ranks' tables travel in slots of a capacity all ranks share (the largest local table the shard has
@@ -374,7 +379,7 @@ typedef struct pga_branch_par_s {
  * path, without a second sweep) and the host-driven exchange; 2 = not applicable (no capacity known, n_seg = 0): nothing happened. */
 int pga_arc_round_x(pga_ctx_t *ctx, int32_t use_ori, int32_t n_seg, const pga_loop_xchg_t *x, int32_t *seg_cnt, int32_t *deg, int64_t *n_arc);
 int pga_branch_loop(pga_ctx_t *ctx, int32_t n_round, const pga_branch_par_t *par, const int32_t *max_tot_cnt, const int32_t *max_degree,
-                    const int32_t *max_dist_loci, uint8_t *seg_alive, const pga_loop_xchg_t *x);
+                    const int32_t *max_dist_loci, uint8_t *seg_alive, const pga_loop_xchg_t *x, int32_t *seg_cnt /* final_on: [2 n_seg], else NULL */, int32_t *n_dist_loci /* likewise */);
 
 /* Optional: run every kernel on this hipStream_t instead of the library's own stream (lets a host
  * framework order its collectives with the kernels without extra synchronisation). */

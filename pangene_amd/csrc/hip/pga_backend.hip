@@ -1470,11 +1470,12 @@ extern "C" int pga_arc_round_x(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, con
 }
 
 extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_par_t *par, const int32_t *max_tot_cnt, const int32_t *max_degree,
-                               const int32_t *max_dist_loci, uint8_t *seg_alive, const pga_loop_xchg_t *x)
+                               const int32_t *max_dist_loci, uint8_t *seg_alive, const pga_loop_xchg_t *x, int32_t *seg_cnt_host, int32_t *ndl_host)
 {
 	static const bool off = getenv("PANGENE_BRANCH_LOOP_HOST") != nullptr; // (tests: keep the host-driven rounds exercised)
 	const int S = c->n_seg, n_vtx = 2 * S, N = c->N;
 	if (off || n_round <= 0 || par == nullptr || seg_alive == nullptr || N == 0 || S == 0 || c->br_S != S || n_vtx > PO_THREADS * PO_MAX_ITEMS) return 2;
+	if (par->final_on && (x != nullptr || seg_cnt_host == nullptr || ndl_host == nullptr)) return 2;
 	if (x == nullptr ? !(c->arc_deferred && !c->arc_done && c->table_sparse) : (c->table_sparse || c->arc_deferred || x->world < 1 || x->allgather == nullptr || x->allreduce_i32_sum == nullptr)) return 2;
 	uint8_t *alive = (uint8_t *)c->pool.get(S_MISC, (size_t)S + 64);
 	int32_t *ndl = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
@@ -1535,7 +1536,8 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		int32_t *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0), *sg = (int32_t *)c->pool.get(S_BR_SEGGID, 0), *dg = (int32_t *)c->pool.get(S_DEG, 0), *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, 0);
 		uint8_t *vwk = (uint8_t *)c->pool.get(S_VWK, (size_t)n_vtx + 16);
 		if (!vs || !ve || !sg || !dg || !seg_cnt || !vwk) return PGA_ERR_NOMEM;
-		hipLaunchKernelGGL(k_round_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)ndl, par->pre_max_tot_cnt, par->pre_max_degree, par->pre_max_dist_loci, (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive, (int4 *)nullptr);
+		hipLaunchKernelGGL(k_round_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)ndl, par->pre_max_tot_cnt, par->pre_max_degree, par->pre_max_dist_loci, (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive,
+		                   par->final_on ? (int4 *)c->pool.get(S_GMETA, 0) : (int4 *)nullptr);
 		hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1);
 		c->walk_valid = false, c->ha_valid = false;
 		int32_t *sc2, *deg2;
@@ -1561,12 +1563,12 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 			TRY(pga_mark_hits(c, nullptr, nullptr, 0, nullptr, 1));
 			if (r > 0) { // pg_flt_high_occ + pg_hard_delete + PG_SET_FILTER(vtx == 0) (graph.c:219-263, 312)
 				hipLaunchKernelGGL(k_round_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)ndl, max_tot_cnt[r], max_degree[r], max_dist_loci[r], (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive,
-				                   x ? (int4 *)c->pool.get(S_GMETA, 0) : (int4 *)nullptr);
+				                   (x || par->final_on) ? (int4 *)c->pool.get(S_GMETA, 0) : (int4 *)nullptr); // (whoever compacts the genes' stretches afterwards must find a deleted one empty)
 				hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1);
 				c->walk_valid = false, c->ha_valid = false;
 			}
 		}
-		if (r + 1 < n_round) { // pg_gen_arc (graph.c:313)
+		if (r + 1 < n_round || par->final_on) { // pg_gen_arc (graph.c:313)
 			int32_t *seg_cnt, *deg;
 			TRY(arc_round_genes(c, par->use_ori, &seg_cnt, &deg, nullptr, false)); // (no mail: the kernels raise the sticky flag themselves)
 			c->br_n = 2 * (int64_t)N + 2, c->br_S = S, c->br_np = 0;
@@ -1574,12 +1576,18 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		}
 	}
 	c->arc_deferred = false, c->arc_done = false;
-	if (c->h_fetch_cap < (size_t)S + 128) {
-		c->h_fetch = c->pin.get((size_t)S + S / 2 + 512);
+	const size_t fetch_need = (size_t)S + 128 + (par->final_on ? 4 * sizeof(int32_t) * (size_t)S + 64 : 0);
+	if (c->h_fetch_cap < fetch_need) {
+		c->h_fetch = c->pin.get(fetch_need + fetch_need / 2 + 512);
 		if (!c->h_fetch) return PGA_ERR_NOMEM;
-		c->h_fetch_cap = (size_t)S + S / 2 + 512;
+		c->h_fetch_cap = fetch_need + fetch_need / 2 + 512;
 	}
 	HIPCHK(hipMemcpyAsync(c->h_fetch, alive, (size_t)S, hipMemcpyDeviceToHost, c->st));
+	int32_t *h_fin = (int32_t *)((char *)c->h_fetch + (((size_t)S + 127) & ~(size_t)63)); // (final_on) the last arc round's segment counters, the last branch step's n_dist_loci
+	if (par->final_on) {
+		HIPCHK(hipMemcpyAsync(h_fin, (const int32_t *)c->pool.get(S_SEGCNT, 0), sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipMemcpyAsync(h_fin + n_vtx, ndl, sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
+	}
 	int64_t *h_x = nullptr; // (sharded) behind the bytes, 8-byte aligned: the 4 collective flags (as int32) and the run's statistics
 	if (x) {
 		int32_t *flags4 = L.gbuf; // (the gather buffer is free again)
@@ -1611,6 +1619,7 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	}
 	else if (c->h_cnt[11]) return c->h_cnt[3] ? PGA_ERR_INVARIANT : 1;
 	memcpy(seg_alive, c->h_fetch, (size_t)S);
+	if (par->final_on) memcpy(seg_cnt_host, h_fin, sizeof(int32_t) * (size_t)n_vtx), memcpy(ndl_host, h_fin + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
 	return 0;
 }
 

@@ -894,6 +894,10 @@ static int fetch_arcs(pg_graph_t *q, DataExt *ext)
 		pg_arc_t *p = &q->arc[i];
 		std::memset(p, 0, sizeof(*p));
 		p->x = part[i].x, p->n_genome = part[i].n_genome, p->tot_cnt = part[i].tot_cnt;
+		if (!ext->seg_renumber.empty()) { // the table of rounds that were queued to the end: segment numbers of before the deletions (monotone map: the order stands)
+			const uint32_t v = (uint32_t)(p->x >> 32), w = (uint32_t)p->x;
+			p->x = (uint64_t)((uint32_t)ext->seg_renumber[v >> 1] << 1 | (v & 1u)) << 32 | ((uint32_t)ext->seg_renumber[w >> 1] << 1 | (w & 1u));
+		}
 		p->avg_dist = (int32_t)(int64_t)((double)(int64_t)part[i].sum_dist / part[i].tot_cnt + .499);
 		p->s1 = (int32_t)((double)part[i].sum_s1 / part[i].n_genome + .499);
 		p->s2 = (int32_t)((double)part[i].sum_s2 / part[i].n_genome + .499);
@@ -1035,7 +1039,9 @@ static int loop_allgather(void *user, const void *in, void *out, int64_t bytes)
 	return rc ? rc : g_xchg.allgather(g_xchg.user, in, out, bytes, ext->be->is_device());
 }
 
-static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, int32_t R, bool *done, bool pre = false) // pre: behind graph 1's deferred arc round, graph 2 included (pga_branch_par_t::pre_on)
+// pre: behind graph 1's deferred arc round, graph 2 included (pga_branch_par_t::pre_on); fin: R = all the rounds, and the arc round of the
+// graph that is written is queued too (final_on) -- the segments' public fields and the renumbering map for fetch_arcs are left here
+static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, int32_t R, bool *done, bool pre = false, bool fin = false)
 {
 	*done = false;
 	const pga_backend_t *be = ext->be;
@@ -1044,8 +1050,8 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	static const bool no_x = std::getenv("PANGENE_SHARDED_LOOP_HOST") != nullptr; // (tests: the host-driven rounds of a sharded run)
 	if (shd && (no_x || !be->is_device())) return 0;
 	if (shd && ext->skip_loop_once) { ext->skip_loop_once = false; return 0; } // the repeated run after status 3
-	if (pre && shd) return 0;
-	const int n_sorts = 2 * R - 1 + (pre ? 1 : 0); // of each kind: one pair per pg_mark_branch_flt_hit (branch.c:116,140), one per pg_gen_arc (graph.c:103,123)
+	if ((pre || fin) && shd) return 0;
+	const int n_sorts = 2 * R - 1 + (pre ? 1 : 0) + (fin ? 1 : 0); // of each kind: one pair per pg_mark_branch_flt_hit (branch.c:116,140), one per pg_gen_arc (graph.c:103,123)
 	static const bool dbg = std::getenv("PANGENE_DEBUG_LOOP") != nullptr;
 	bool quiet;
 	{ Phase ph(PH_EXACT); quiet = exact_quiet(ext, n_sorts); }
@@ -1072,12 +1078,15 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	par.local_dist = opt->local_dist, par.local_count = opt->local_count, par.frag_mode = !!(opt->flag & PG_F_FRAG_MODE), par.use_ori = !!(opt->flag & PG_F_ORI_FOR_BRANCH);
 	par.pre_on = pre ? 1 : 0; // graph.c:294: pg_flt_high_occ(q, max_avg_occ * 2, max_degree * 2, max_dist_loci)
 	par.pre_max_tot_cnt = opt->max_avg_occ * 2 * q->d->n_genome, par.pre_max_degree = opt->max_degree * 2, par.pre_max_dist_loci = opt->max_dist_loci;
+	par.final_on = fin ? 1 : 0;
 	std::vector<uint8_t> &alive = ext->del_buf;
 	alive.assign((size_t)S + 1, 1);
+	std::vector<int32_t> fin_sc, fin_ndl;
+	if (fin) fin_sc.assign((size_t)S * 2 + 1, 0), fin_ndl.assign((size_t)S * 2 + 1, 0);
 	pga_loop_xchg_t lx;
 	lx.user = ext, lx.rank = g_xchg.rank, lx.world = g_xchg.world, lx.arc_cap_hint = ext->x_arc_slot, lx.allreduce_i32_sum = loop_allreduce, lx.allgather = loop_allgather;
 	int rc;
-	{ Phase ph(PH_NLOCAL); rc = be->branch_loop(ext->ctx, R, &par, m_tot.data(), m_deg.data(), m_loci.data(), alive.data(), shd ? &lx : nullptr); }
+	{ Phase ph(PH_NLOCAL); rc = be->branch_loop(ext->ctx, R, &par, m_tot.data(), m_deg.data(), m_loci.data(), alive.data(), shd ? &lx : nullptr, fin ? fin_sc.data() : nullptr, fin ? fin_ndl.data() : nullptr); }
 	if (dbg) std::fprintf(stderr, "[branch_loop] %d rounds queued%s: backend status %d\n", R, shd ? " (sharded)" : "", rc);
 	if (rc == 2) return 0;
 	if (rc == 1) { ext->no_branch_loop = true; return RC_REDO; }
@@ -1087,11 +1096,21 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	exact_skip(ext, n_sorts);
 	Phase ph(PH_FLT);
 	int32_t k = 0;
+	if (fin) ext->seg_renumber.assign((size_t)S, -1);
 	for (int32_t i = 0; i < S; ++i)
-		if (alive[(size_t)i]) q->seg[k++] = q->seg[i];
+		if (alive[(size_t)i]) {
+			if (fin) { // the public fields of the graph that is written (graph.c:125-126 of its arc round, branch.c:90 of the last branch step)
+				pg_seg_t *sg = &q->seg[i];
+				sg->n_genome = fin_sc[(size_t)i], sg->tot_cnt = fin_sc[(size_t)S + (size_t)i];
+				sg->n_dist_loci[0] = fin_ndl[(size_t)i * 2], sg->n_dist_loci[1] = fin_ndl[(size_t)i * 2 + 1];
+				ext->seg_renumber[(size_t)i] = k;
+			}
+			q->seg[k++] = q->seg[i];
+		}
 	q->n_seg = k;
 	gen_g2s(q);
-	BE_CALL(flag_vtx(q, ext), "flag_vtx"); // the renumbered g2s (the hits' flags do not change: the loop filtered them already)
+	if (!fin) BE_CALL(flag_vtx(q, ext), "flag_vtx"); // the renumbered g2s (the hits' flags do not change: the loop filtered them already)
+	// (fin: the backend's table is in the old numbering -- it gets the new g2s when the table has been fetched: graph_gen_impl)
 	*done = true;
 	return 0;
 }
@@ -1129,8 +1148,16 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-1 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
 	int32_t i_first = 0;
 	bool queued = false;
+	bool queued_all = false;
+	ext->seg_renumber.clear();
 	if (try_pre) {
-		const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt - 1, &queued, true);
+		static const bool no_fin = std::getenv("PANGENE_LOOP_NO_FINAL") != nullptr; // (tests: the last round host-driven behind the queued ones)
+		if (!no_fin) { // every round and the arc round of the graph that is written
+			const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt, &queued_all, true, true);
+			if (rc) return rc;
+			queued = queued_all;
+		}
+		const int rc = queued ? 0 : branch_loop_fast(opt, q, ext, opt->n_branch_flt - 1, &queued, true);
 		if (rc) return rc;
 		if (!queued) { // not applicable after all (the order replay needs the host, ...): graph 1's results the usual way
 			const int rc2 = arc_collect(opt, q, ext);
@@ -1150,7 +1177,8 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 			if (rc) return rc;
 		}
 	}
-	if (queued) {
+	if (queued_all) i_first = opt->n_branch_flt; // nothing left to drive
+	else if (queued) {
 		i_first = opt->n_branch_flt - 1;
 		BE_CALL(gen_arc(opt, q, ext, true), "gen_arc"); // the arc round of round n-2, with the renumbered segments
 	}
@@ -1175,6 +1203,10 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	}
 	BE_CALL(be->set_filter(ctx, PGA_FLT_SHADOW), "set_filter"); // graph.c:316
 	BE_CALL(fetch_arcs(q, ext), "fetch_arcs");
+	if (queued_all) { // the table is on the host: now the backend may learn the new numbering (gene matrix, a later run)
+		ext->seg_renumber.clear();
+		BE_CALL(flag_vtx(q, ext), "flag_vtx");
+	}
 	if (opt->min_arc_cnt > 1) { // graph.c:191-200
 		int32_t k = 0, n_aflt = 0;
 		for (int32_t i = 0; i < q->n_arc; ++i) {

@@ -86,6 +86,7 @@ struct DataExt {
 	int32_t xsegs_n_genome = -1;       // number of genomes the segments were built for
 	int x_sorts[2] = {0, 0};           // cs / cm sorts of the reference seen so far in this run
 	std::vector<int32_t> head_file;    // per local genome: file index of the hit at array index 0 (-1 canonical)
+	std::vector<int32_t> seg_renumber; // branch rounds queued to the end: old segment number -> number in the graph that is written (-1: deleted); empty otherwise
 	bool skip_loop_once = false;       // sharded pga_branch_loop asked for a repeated run because an exchange buffer was too small (status 3): that run is host-driven, later ones queue again
 	int64_t x_arc_slot = 0;            // sharded runs: the largest local arc table of any host-driven round so far, over all ranks
 	bool no_branch_loop = false;       // the queued branch rounds (pga_branch_loop) met something they cannot handle on this data set: host-driven rounds from now on
