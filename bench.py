@@ -314,8 +314,14 @@ def main():
         h = torch.tensor([n_hits], dtype=torch.int64, device=xdev)
         dist.all_reduce(h)
         tot_hits = int(h.item())
+        # every rank must have built the same graph: the S/L lines' md5 of all ranks against rank 0's
+        m = torch.tensor(list(bytes.fromhex(sl_md5(gfa))), dtype=torch.int64, device=xdev)
+        lo_, hi_ = m.clone(), m.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN); dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        ranks_agree = bool(torch.equal(lo_, hi_))
     else:
         tot_hits, t_cold_all = n_hits, t_cold + t_pack
+        ranks_agree = None
 
     # ---- roofline of K1 = the stage-A interval-dominance sweep pg_shadow(cal_dom_sc=1), read.c:248 / overlap.c:101-178.
     # Algorithmic bytes of THIS kernel: SURVEY 8(d) gives 56 + 8E B/hit for a pg_shadow sweep (reads cs ce cid pid gid score_adj rank
@@ -462,7 +468,7 @@ def main():
                           "upload_MB": round((44 * nh.value + 8 * ne.value) / 1e6, 1), "host_to_device_GBps_of_this_box": link_gbps},
             "roofline": roof, "cpu_baseline": cpu, "big_shard": big, "human_shard": human, "exchange_overhead": xo, "cli": cli,
             "gfa_md5": hashlib.md5(gfa).hexdigest() if world == 1 else None,
-            "gfa_sl_md5": sl_md5(gfa),
+            "gfa_sl_md5": sl_md5(gfa), "gfa_sl_lines_same_on_all_ranks": ranks_agree,
             "gfa_identical_to_reference": (hashlib.md5(gfa).hexdigest() == ref_md5) if ref_md5 else None,
             "not_timed": {"paf_generate_s": round(t_gen, 2), "paf_parse_and_pack_s": round(t_parse, 3), "gfa_write_s": round(t_write[0], 4), "path_only_ms_per_step": round(path_sec / a.steps * 1e3, 3)},
             "host_waits_per_step": waits_per_step, "collectives_per_step": coll_per_step,
