@@ -249,19 +249,6 @@ def main():
         lib.pg_graph_destroy(one_pass(dw, True))
         lib.pg_data_destroy(dw)
 
-    # the box's host link, as this process sees it (the pool's boxes differ by 10x here, and the cold pass carries one upload of the shard)
-    link_gbps = None
-    try:
-        hb = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
-        db_ = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
-        db_.copy_(hb, non_blocking=True); torch.cuda.synchronize(dev)
-        t0 = time.time()
-        db_.copy_(hb, non_blocking=True); torch.cuda.synchronize(dev)
-        link_gbps = round((64 << 20) / (time.time() - t0) / 1e9, 1)
-        del hb, db_
-    except Exception:
-        pass
-
     d = lib.pg_data_init()
     t0 = time.time()
     capi.read_files(lib, opt, d, files, [not (lo <= j < hi) for j in range(G)])  # host threads; ids as in sequential reads; packs the blocks
@@ -352,6 +339,20 @@ def main():
     roof = roofline_of(d, nh.value, ne.value, "the bench workload itself (fits the 256 MiB Infinity Cache: an L3 figure)")
     lib.pg_data_destroy(d)  # one context (and one HIP stream) at a time: the legs below bring their own
     d = None
+
+    # the box's host link, as this process sees it (measured AFTER the timed passes: torch's allocations must not sit between the warm-up set and the cold pass)
+    link_gbps = None
+    try:
+        hb = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+        db_ = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        db_.copy_(hb, non_blocking=True); torch.cuda.synchronize(dev)
+        t0 = time.time()
+        db_.copy_(hb, non_blocking=True); torch.cuda.synchronize(dev)
+        link_gbps = round((64 << 20) / (time.time() - t0) / 1e9, 1)
+        del hb, db_
+    except Exception:
+        pass
+
 
     def shard_leg(dirname, n_genomes, what, n_pass=3):
         """a leg on a data set of its own: parse, cold pass, one warm pass, n_pass timed passes; the K1 / stage-A roofline of that shard"""

@@ -13,7 +13,7 @@ tests)
 	t0=$(date +%s)
 	timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -n 6 > $out/${tag}_pytest_gpu.log
 	echo "# wall time of the suite: $(( $(date +%s) - t0 )) s" >> $out/${tag}_pytest_gpu.log
-	python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.stderr
+	PANGENE_TIMING=1 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.stderr  # (stderr: the parts of every pass, the allocation / upload split of every context)
 	cat $out/${tag}_pytest_gpu.log; cat $out/${tag}_bench_default.json;;
 stats)
 	rocprofv3 --kernel-trace --stats -d $out/prof_stats -o s -- python bench.py $Q > $out/${tag}_bench_under_rocprof.json 2>/dev/null
