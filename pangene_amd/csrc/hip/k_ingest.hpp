@@ -189,6 +189,77 @@ __global__ __launch_bounds__(BLOCK) void k_count_shadow(const uint32_t *flags, c
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// read.c:249-256 with ONE workgroup per genome and the per-genome tables in LDS: the reset after pg_shadow (read.c:249-253), the
+// consequence of pg_flt_ov_isoform (overlap.c:89-91), pg_flt_chain_shadow (hit.c:130-146) and pg_flt_subopt_isoform (hit.c:107-128).
+// A genome's hits are one contiguous block of the cs order; what the four kernels below keep in (genome x protein) bytes and
+// (genome x gene) 64-bit words of HBM -- cleared and re-read every pass -- is P bytes + Q words of LDS here, and the hits are read
+// once per step by the same thread (36 B/hit of traffic instead of ~140).  Used when P + 8 Q fits the LDS (k_iso_apply .. k_subopt2
+// otherwise, and under PANGENE_FILTERS_GLOBAL=1).
+// ------------------------------------------------------------------------------------------------
+constexpr int GF_T = 1024;
+struct GenomeFilters { uint32_t *flags; const int32_t *pid, *gid, *rank, *sadj; int32_t *pdom, *pdom0; const int32_t *goff; const int4 *A; int P, Q; int32_t *stats; int64_t *dcnt; int32_t *hz_list; };
+static inline size_t gf_lds_bytes(int P, int Q) { return 8 * (size_t)Q + (((size_t)P + 7) & ~(size_t)7) + 64; }
+
+__global__ __launch_bounds__(GF_T) void k_genome_filters(GenomeFilters a)
+{
+	extern __shared__ unsigned long long gf_lds[];
+	unsigned long long *best = gf_lds;                                  // [Q] hit.c:111 `best`: score_adj << 32 | (first position wins)
+	uint8_t *noiso = (uint8_t *)(best + a.Q);                            // [P] the protein has a hit here without flt_iso_ov (= !flag[] of hit.c:134-138)
+	int32_t *cnt = (int32_t *)(noiso + (((size_t)a.P + 7) & ~(size_t)7)); // [4] the genome's counts for the log line (read.c:257)
+	const int g = blockIdx.x, tid = threadIdx.x, h0 = a.goff[g], h1 = a.goff[g + 1];
+	for (int k = tid; k < a.Q; k += GF_T) best[k] = 0;
+	for (int k = tid; k < (a.P + 7) / 8 * 2; k += GF_T) ((uint32_t *)noiso)[k] = 0;
+	if (tid < 4) cnt[tid] = 0;
+	__syncthreads();
+	int n_iso = 0, n_chain = 0, n_sub = 0;
+	for (int h = h0 + tid; h < h1; h += GF_T) { // read.c:249-253 + overlap.c:89-91
+		a.pdom0[h] = a.pdom[h];
+		a.pdom[h] = -1;
+		const uint32_t f = a.flags[h];
+		uint32_t nf = f & ~PGA_F_SHADOW;
+		if (f & PGA_F_ISO_OV) nf |= PGA_F_FLT, ++n_iso;
+		else noiso[a.pid[h]] = 1; // (plain byte stores of the same value)
+		if (nf != f) a.flags[h] = nf;
+	}
+	__syncthreads();
+	for (int h = h0 + tid; h < h1; h += GF_T) { // hit.c:139-144, then the first loop of hit.c:112-118 (it skips what the chain filter just removed)
+		const int p0 = a.pdom0[h];
+		uint32_t f = a.flags[h];
+		if (p0 >= 0 && !noiso[p0]) f |= PGA_F_FLT | PGA_F_CHAIN, a.flags[h] = f, ++n_chain;
+		if ((f & PGA_F_FLT) || a.rank[h] > 0) continue;
+		const int s = a.sadj[h];
+		const uint32_t pos = (uint32_t)(h - h0);
+		if (s > 0) atomicMax(&best[a.gid[h]], (unsigned long long)(uint32_t)s << 32 | (0xffffffffu - pos));
+		else if (s < 0) atomicMax(&best[a.gid[h]], 1ull << 63 | pos);
+	}
+	__syncthreads();
+	for (int h = h0 + tid; h < h1; h += GF_T) { // the second loop of hit.c:119-125 (+ the tie hazard of k_subopt2)
+		const uint32_t f = a.flags[h];
+		if (f & PGA_F_FLT) continue;
+		const unsigned long long k = best[a.gid[h]];
+		const int my_pid = a.pid[h];
+		int best_pid = 0; // hit.c:111: calloc'ed best => pid 0 when the gene has no candidate
+		if (k) {
+			const uint32_t pos = (k >> 63) ? (uint32_t)k : 0xffffffffu - (uint32_t)k;
+			const int w = h0 + (int)pos;
+			best_pid = a.pid[w];
+			if (my_pid != best_pid && a.rank[h] == 0) { // a losing candidate: could it have been first?
+				const int s = a.sadj[h];
+				if ((k >> 63) ? s < 0 : (s > 0 && (uint32_t)s == (uint32_t)(k >> 32))) {
+					const int4 ah = a.A[h], aw = a.A[w];
+					if (ah.x == aw.x && ah.y == aw.y) { atomicAdd((unsigned long long *)&a.dcnt[7], 1ull); hz_note(&a.dcnt[14], a.hz_list, ah.y); }
+				}
+			}
+		}
+		if (my_pid != best_pid) a.flags[h] = f | PGA_F_FLT | PGA_F_ISO_SUB, ++n_sub;
+	}
+	n_iso = wave_sum(n_iso), n_chain = wave_sum(n_chain), n_sub = wave_sum(n_sub);
+	if ((tid & 63) == 0) { atomicAdd(&cnt[1], n_iso); atomicAdd(&cnt[2], n_chain); atomicAdd(&cnt[3], n_sub); }
+	__syncthreads();
+	if (tid >= 1 && tid < 4) a.stats[g * 4 + tid] = cnt[tid];
+}
+
 // read.c:249-253 (pid_dom0 = pid_dom, pid_dom = -1, shadow = 0) + tail of pg_flt_ov_isoform (overlap.c:89-91) + first loop of
 // pg_flt_chain_shadow (hit.c:136-138).  noiso: one byte per (genome, protein), set when the protein has a hit in the genome that
 // does not carry flt_iso_ov (the complement of hit.c:134-138's flag[], for the proteins that occur at all -- pid_dom0 always does).

@@ -147,6 +147,7 @@ struct pga_ctx {
 	// exchange vectors
 	int32_t *max_ori = 0; int64_t *sums = 0; int32_t *vtx_cnt = 0; int32_t *g2s = 0; int32_t n_seg = 0;
 	uint64_t sync_epoch_reset = 0;
+	bool gf_ok = false; // k_genome_filters: the per-genome tables of read.c:254-256 fit the LDS
 	bool x_redo = false; // pga_arc_round_x gave the round up: the next pga_arc_round repeats it on the sort path
 	int64_t x_pairs_seen = 0, x_arcs_seen = 0; // sharded rounds: the longest pair list / the largest local arc table of any rank in the PREVIOUS run over this context (pga_begin shifts)
 	int64_t x_pairs_run = 0, x_arcs_run = 0;   // ... and in the run under way
@@ -485,6 +486,9 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes(c->gs_np)) != hipSuccess) { (void)hipGetLastError(); c->gs_ok = false; }
 	}
 
+	c->gf_ok = gf_lds_bytes(c->P, c->Q) <= (size_t)150 << 10 && getenv("PANGENE_FILTERS_GLOBAL") == nullptr;
+	if (c->gf_ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_genome_filters), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gf_lds_bytes(c->P, c->Q)) != hipSuccess) { (void)hipGetLastError(); c->gf_ok = false; }
+
 	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
 		const size_t per_hit = 568 /* measured: 530-540 B/hit at 1 M and 12 M hits (PANGENE_TIMING reports the fit at destroy) */, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
 		const size_t want = ((size_t)N * per_hit + tables + (64u << 20) + (size_t)woff[(size_t)GL] * 4 + 255) & ~(size_t)255;
@@ -668,14 +672,19 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 			hipLaunchKernelGGL(k_pseudo3, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->rank, N, P, tmax, tmin, tr1);
 			hipLaunchKernelGGL(k_pack_rank, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->rank, N, c->recC); // rank changed
 		}
-		unsigned long long *tbest = (unsigned long long *)c->pool.get(S_TAB_D, sizeof(uint64_t) * (size_t)TQ);
-		uint8_t *noiso = (uint8_t *)c->pool.get(S_TAB_A, (size_t)TP + 16); // byte (genome, protein): the protein has a hit there without flt_iso_ov
-		if (!tbest || !noiso) return PGA_ERR_NOMEM;
+		unsigned long long *tbest = c->gf_ok ? nullptr : (unsigned long long *)c->pool.get(S_TAB_D, sizeof(uint64_t) * (size_t)TQ);
+		uint8_t *noiso = c->gf_ok ? nullptr : (uint8_t *)c->pool.get(S_TAB_A, (size_t)TP + 16); // byte (genome, protein): the protein has a hit there without flt_iso_ov
+		if (!c->gf_ok && (!tbest || !noiso)) return PGA_ERR_NOMEM;
 		c->sweep_init = true;
 		const int rc_sw = launch_sweep<1>(c, 0); // pg_shadow(cal_dom_sc=1), read.c:248 -- "K1", the hit-filter+overlap kernel
 		c->sweep_init = false;
 		TRY(rc_sw);
 		TRY(launch_sweep<2>(c, 1)); // pg_flt_ov_isoform, read.c:254 (reads neither the shadow flags nor pid_dom: read.c:249-253 follows, in k_iso_apply)
+		if (c->gf_ok) { // read.c:249-256 per genome, the tables in LDS
+			GenomeFilters gf = { c->flags, c->pid, c->gid, c->rank, c->sadj, c->pdom, c->pdom0, c->goff, c->recA, P, Q, d_stats, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP) };
+			if (!gf.hz_list) return PGA_ERR_NOMEM;
+			hipLaunchKernelGGL(k_genome_filters, dim3((unsigned)GL), dim3(GF_T), gf_lds_bytes(P, Q), c->st, gf);
+		} else {
 		HIPCHK(hipMemsetAsync(noiso, 0, (size_t)TP, c->st));
 		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, c->pdom, c->pdom0, N, P, noiso, d_stats);
 		hipLaunchKernelGGL(k_chain, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pdom0, N, P, noiso, d_stats);
@@ -683,6 +692,7 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 		hipLaunchKernelGGL(k_subopt1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->sadj, c->goff, N, Q, tbest);
 		hipLaunchKernelGGL(k_subopt2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->pid, c->goff, N, Q, tbest, d_stats, c->rank, c->sadj, c->recA, c->dcnt,
 		                   (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP));
+		}
 	}
 	if (c->timing_on && c->span_a) {
 		TimedLaunch t; t.which = 3, t.units = N, t.a = c->span_a, c->span_a = nullptr;

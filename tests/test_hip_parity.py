@@ -110,7 +110,7 @@ def _run_with_env(tmp_path, env, mode, variant, files):
 
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
 @pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1", "PANGENE_LOOP_NO_PRE": "1"},
-                                 {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1"}, {"PANGENE_LOOP_NO_FINAL": "1"}])
+                                 {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1", "PANGENE_FILTERS_GLOBAL": "1"}, {"PANGENE_LOOP_NO_FINAL": "1"}])
 def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
     (the path of rounds in which a hub gene overflows the per-gene LDS table).  Forcing the sort path, and shrinking the table to 4
@@ -123,7 +123,8 @@ def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     the queued branch rounds (pga_branch_loop, the default) give up on their sticky flag, so the run is repeated with host-driven
     rounds (RC_REDO).  Fourth setting: host-driven rounds from the start (one wait per round, verdicts of pg_flt_high_occ fetched as
     bytes: the default of round 2) and stage A's orders by the multi-workgroup radix sort instead of k_genome_sort (the path of
-    genomes with more than 25 600 hits).  Fifth setting: the last branch round and the arc round of the graph that is written driven by the
+    genomes with more than 25 600 hits), and read.c:249-256 by the four kernels with their tables in HBM instead of k_genome_filters (the
+    path of shards whose P + 8 Q bytes do not fit the LDS).  Fifth setting: the last branch round and the arc round of the graph that is written driven by the
     host behind the queued rounds (the default queues them too and renumbers segments and arcs on the host at the end)."""
     out = _run_with_env(tmp_path, env, 2, variant, golden_files(name))
     assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
