@@ -52,7 +52,7 @@ try:
     if len(starts) >= 3:
         seg = ev[starts[-2]:starts[-1]]
         t0 = seg[0][1]
-        last = max(i for i, e in enumerate(seg) if e[0].startswith("k_subopt2") or e[0].startswith("k_chain"))
+        last = max(i for i, e in enumerate(seg) if e[0].startswith("k_subopt2") or e[0].startswith("k_chain") or e[0].startswith("k_genome_filters"))
         print("# stage A of that pass (pga_begin + pga_ingest), launch by launch: start us, duration us, kernel")
         for e in seg[:last + 1]:
             print("#   %9.1f %9.1f  %s" % ((e[1] - t0) / 1e3, (e[2] - e[1]) / 1e3, e[0][:70]))
