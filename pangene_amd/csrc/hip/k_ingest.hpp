@@ -213,46 +213,70 @@ __global__ __launch_bounds__(GF_T) void k_genome_filters(GenomeFilters a)
 	if (tid < 4) cnt[tid] = 0;
 	__syncthreads();
 	int n_iso = 0, n_chain = 0, n_sub = 0;
-	for (int h = h0 + tid; h < h1; h += GF_T) { // read.c:249-253 + overlap.c:89-91
-		a.pdom0[h] = a.pdom[h];
-		a.pdom[h] = -1;
-		const uint32_t f = a.flags[h];
-		uint32_t nf = f & ~PGA_F_SHADOW;
-		if (f & PGA_F_ISO_OV) nf |= PGA_F_FLT, ++n_iso;
-		else noiso[a.pid[h]] = 1; // (plain byte stores of the same value)
-		if (nf != f) a.flags[h] = nf;
+	constexpr int U = 4; // hits a thread has in flight per step: the loads of a step are issued together (the phases are latency-bound otherwise)
+	for (int hb = h0 + tid; hb < h1; hb += U * GF_T) { // read.c:249-253 + overlap.c:89-91
+		int32_t pd[U], pi[U]; uint32_t fl[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) { const int h = hb + u * GF_T; if (h < h1) pd[u] = a.pdom[h], fl[u] = a.flags[h], pi[u] = a.pid[h]; }
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int h = hb + u * GF_T;
+			if (h >= h1) break;
+			a.pdom0[h] = pd[u];
+			a.pdom[h] = -1;
+			uint32_t nf = fl[u] & ~PGA_F_SHADOW;
+			if (fl[u] & PGA_F_ISO_OV) nf |= PGA_F_FLT, ++n_iso;
+			else noiso[pi[u]] = 1; // (plain byte stores of the same value)
+			if (nf != fl[u]) a.flags[h] = nf;
+		}
 	}
 	__syncthreads();
-	for (int h = h0 + tid; h < h1; h += GF_T) { // hit.c:139-144, then the first loop of hit.c:112-118 (it skips what the chain filter just removed)
-		const int p0 = a.pdom0[h];
-		uint32_t f = a.flags[h];
-		if (p0 >= 0 && !noiso[p0]) f |= PGA_F_FLT | PGA_F_CHAIN, a.flags[h] = f, ++n_chain;
-		if ((f & PGA_F_FLT) || a.rank[h] > 0) continue;
-		const int s = a.sadj[h];
-		const uint32_t pos = (uint32_t)(h - h0);
-		if (s > 0) atomicMax(&best[a.gid[h]], (unsigned long long)(uint32_t)s << 32 | (0xffffffffu - pos));
-		else if (s < 0) atomicMax(&best[a.gid[h]], 1ull << 63 | pos);
+	for (int hb = h0 + tid; hb < h1; hb += U * GF_T) { // hit.c:139-144, then the first loop of hit.c:112-118 (it skips what the chain filter just removed)
+		int32_t p0[U], rk[U], sa[U], gi[U]; uint32_t fl[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) { const int h = hb + u * GF_T; if (h < h1) p0[u] = a.pdom0[h], fl[u] = a.flags[h], rk[u] = a.rank[h], sa[u] = a.sadj[h], gi[u] = a.gid[h]; }
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int h = hb + u * GF_T;
+			if (h >= h1) break;
+			uint32_t f = fl[u];
+			if (p0[u] >= 0 && !noiso[p0[u]]) f |= PGA_F_FLT | PGA_F_CHAIN, a.flags[h] = f, ++n_chain;
+			if ((f & PGA_F_FLT) || rk[u] > 0) continue;
+			const uint32_t pos = (uint32_t)(h - h0);
+			if (sa[u] > 0) atomicMax(&best[gi[u]], (unsigned long long)(uint32_t)sa[u] << 32 | (0xffffffffu - pos));
+			else if (sa[u] < 0) atomicMax(&best[gi[u]], 1ull << 63 | pos);
+		}
 	}
 	__syncthreads();
-	for (int h = h0 + tid; h < h1; h += GF_T) { // the second loop of hit.c:119-125 (+ the tie hazard of k_subopt2)
-		const uint32_t f = a.flags[h];
-		if (f & PGA_F_FLT) continue;
-		const unsigned long long k = best[a.gid[h]];
-		const int my_pid = a.pid[h];
-		int best_pid = 0; // hit.c:111: calloc'ed best => pid 0 when the gene has no candidate
-		if (k) {
-			const uint32_t pos = (k >> 63) ? (uint32_t)k : 0xffffffffu - (uint32_t)k;
-			const int w = h0 + (int)pos;
-			best_pid = a.pid[w];
-			if (my_pid != best_pid && a.rank[h] == 0) { // a losing candidate: could it have been first?
+	for (int hb = h0 + tid; hb < h1; hb += U * GF_T) { // the second loop of hit.c:119-125 (+ the tie hazard of k_subopt2)
+		int32_t pi[U], gi[U], bp[U]; uint32_t fl[U]; unsigned long long kk[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) { const int h = hb + u * GF_T; if (h < h1) fl[u] = a.flags[h], pi[u] = a.pid[h], gi[u] = a.gid[h]; }
+#pragma unroll
+		for (int u = 0; u < U; ++u) { // the winner's protein: one more (dependent) load, again all of the step's together
+			const int h = hb + u * GF_T;
+			kk[u] = 0, bp[u] = 0; // hit.c:111: calloc'ed best => pid 0 when the gene has no candidate
+			if (h < h1 && !(fl[u] & PGA_F_FLT)) {
+				kk[u] = best[gi[u]];
+				if (kk[u]) bp[u] = a.pid[h0 + (int)((kk[u] >> 63) ? (uint32_t)kk[u] : 0xffffffffu - (uint32_t)kk[u])];
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int h = hb + u * GF_T;
+			if (h >= h1) break;
+			if (fl[u] & PGA_F_FLT) continue;
+			const unsigned long long k = kk[u];
+			if (k && pi[u] != bp[u] && a.rank[h] == 0) { // a losing candidate: could it have been first?
 				const int s = a.sadj[h];
 				if ((k >> 63) ? s < 0 : (s > 0 && (uint32_t)s == (uint32_t)(k >> 32))) {
+					const int w = h0 + (int)((k >> 63) ? (uint32_t)k : 0xffffffffu - (uint32_t)k);
 					const int4 ah = a.A[h], aw = a.A[w];
 					if (ah.x == aw.x && ah.y == aw.y) { atomicAdd((unsigned long long *)&a.dcnt[7], 1ull); hz_note(&a.dcnt[14], a.hz_list, ah.y); }
 				}
 			}
+			if (pi[u] != bp[u]) a.flags[h] = fl[u] | PGA_F_FLT | PGA_F_ISO_SUB, ++n_sub;
 		}
-		if (my_pid != best_pid) a.flags[h] = f | PGA_F_FLT | PGA_F_ISO_SUB, ++n_sub;
 	}
 	n_iso = wave_sum(n_iso), n_chain = wave_sum(n_chain), n_sub = wave_sum(n_sub);
 	if ((tid & 63) == 0) { atomicAdd(&cnt[1], n_iso); atomicAdd(&cnt[2], n_chain); atomicAdd(&cnt[3], n_sub); }
