@@ -461,7 +461,8 @@ def main():
             "scaling": a.scaling, "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%s, %d genomes x %d proteins %s (%d genomes, %d hits in total), default options"
                                    % (cfg, hi - lo if a.scaling == "weak" else G, a.proteins, "per GPU" if a.scaling == "weak" else "in total", G, tot_hits),
-                       "exact_order_mode": a.exact, "parallelism": "genomes sharded over %d GPU(s)" % world, "exchange": exchange_kind},
+                       "exact_order_mode": a.exact, "parallelism": "genomes sharded over %d GPU(s)" % world, "exchange": exchange_kind,
+                       "host_wait": "hipStreamSynchronize" if os.environ.get("PANGENE_WAIT") == "sync" else "hipStreamQuery polled for up to 200 us, then hipStreamSynchronize"},
             # SURVEY 8(d)'s metric as defined there (upload included): ONE pass over a data set the process has not seen
             "cold_pass": {"value": round(tot_hits / t_cold_all / 1e6, 3), "unit": "M hits/s", "ms": round(t_cold_all * 1e3, 2),
                           "includes": "block packing in the reader threads (%.1f ms) + allocation, H2D and order-replay set-up (%.1f ms) + stages A+B+C; excludes PAF text parsing and GFA printing; kernels were loaded by a tiny warm-up data set"
