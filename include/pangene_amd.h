@@ -230,6 +230,9 @@ int pg_device_count(void);
  * number of hits they processed (local shard). */
 double  pg_last_path_seconds(void);
 int64_t pg_last_path_hits(void);
+/* how many times the last pg_graph_gen ran stages A-C: 1, plus one for every repeat after a tie-order hazard on a contig that did
+ * not follow the reference's exact order yet (mode auto; DESIGN.md "bit-identity") */
+int     pg_last_attempts(void);
 double  pg_last_upload_seconds(void);   /* allocation + H2D copy + order-replay set-up of the last pg_post_process (0 for a resident rerun) */
 double  pg_last_pack_seconds(void);     /* wall seconds the reader spent packing the genomes of the last upload into their blocks */
 /* hits and exons of the local shard of d (what the last pg_post_process uploaded) */

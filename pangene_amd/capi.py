@@ -62,6 +62,7 @@ _API = {
     "pg_set_exchange": (None, [C.POINTER(pg_exchange_t)]),
     "pg_last_path_seconds": (C.c_double, []),
     "pg_last_path_hits": (C.c_int64, []),
+    "pg_last_attempts": (C.c_int, []),
     "pg_last_upload_seconds": (C.c_double, []),
     "pg_last_pack_seconds": (C.c_double, []),
     "pg_shard_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

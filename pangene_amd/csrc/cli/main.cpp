@@ -3,13 +3,17 @@
 #include <dlfcn.h>
 #include <getopt.h>
 #include <signal.h>
+#include <sys/prctl.h>
 #include <sys/resource.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "pangene_amd.h"
 
@@ -113,6 +117,42 @@ static int run_path(pg_opt_t &opt, int n_files, char **files, const uint8_t *ids
 static bool read_all(int fd, void *buf, size_t n) { char *p = (char *)buf; while (n) { ssize_t k = read(fd, p, n); if (k <= 0) return false; p += k, n -= (size_t)k; } return true; }
 static bool write_all(int fd, const void *buf, size_t n) { const char *p = (const char *)buf; while (n) { ssize_t k = write(fd, p, n); if (k <= 0) return false; p += k, n -= (size_t)k; } return true; }
 
+// what a signal handler / the watchdog needs to take the whole command down: the workers' pids and the temporary files
+static std::vector<pid_t> g_kids;
+static std::vector<std::string> g_tmp;
+static std::atomic<int> g_kid_failed{0}; // a worker ended with an error while rank 0 was still at work
+
+static void take_down(bool unlink_tmp)
+{
+	for (pid_t p : g_kids) if (p > 0) kill(p, SIGKILL);
+	if (unlink_tmp) for (const std::string &t : g_tmp) unlink(t.c_str());
+}
+static void on_signal(int sig) { take_down(true); _exit(128 + sig); }
+
+// Files of rank r = a contiguous block of the command line (the ranks' W / BED lines, concatenated in rank order, are then in
+// command-line order), cut so that the blocks carry about the same number of HITS.  The hits of a file are not
+// known before it is parsed; its size is (one PAF line is one alignment; a .gz counts five times its size, as in the reader).
+static std::vector<int> partition_files(int W, int n_files, char **files)
+{
+	std::vector<double> w((size_t)n_files, 1.0);
+	double tot = 0;
+	for (int i = 0; i < n_files; ++i) {
+		struct stat sb;
+		const size_t len = std::strlen(files[i]);
+		if (stat(files[i], &sb) == 0 && sb.st_size > 0) w[(size_t)i] = (double)sb.st_size * (len > 3 && std::strcmp(files[i] + len - 3, ".gz") == 0 ? 5.0 : 1.0);
+		tot += w[(size_t)i];
+	}
+	std::vector<int> cut((size_t)W + 1, n_files);
+	cut[0] = 0;
+	double acc = 0;
+	int r = 1;
+	for (int i = 0; i < n_files && r < W; ++i) { // rank r starts at the first file at which the weight before it reaches r / W of the total
+		while (r < W && acc >= tot * r / W) cut[(size_t)r++] = i;
+		acc += w[(size_t)i];
+	}
+	return cut;
+}
+
 static int run_sharded(pg_opt_t &opt, int W, int n_files, char **files, const Output &o)
 {
 	if (o.matrix) { std::fprintf(stderr, "ERROR: --matrix needs every genome in one process; run it without --gpus\n"); return 1; }
@@ -124,30 +164,43 @@ static int run_sharded(pg_opt_t &opt, int W, int n_files, char **files, const Ou
 		rccl_uid = (uid_fn)dlsym(RTLD_DEFAULT, "pg_rccl_unique_id"), rccl_init = (init_fn)dlsym(RTLD_DEFAULT, "pg_rccl_init"), rccl_fin = (fin_fn)dlsym(RTLD_DEFAULT, "pg_rccl_finalize");
 		if (!rccl_uid || !rccl_init) { std::fprintf(stderr, "ERROR: this build of the library has no RCCL exchange\n"); return 1; }
 	} else if ((region = pg_shm_create(W, (int64_t)16 << 20)) == nullptr) { std::fprintf(stderr, "ERROR: cannot map the exchange region\n"); return 1; }
-	// files of rank r: [n r / W, n (r + 1) / W)
-	std::vector<std::string> tmp((size_t)W);
+	const std::vector<int> cut = partition_files(W, n_files, files);
+	std::vector<std::string> &tmp = g_tmp;
+	tmp.assign((size_t)W, std::string());
 	std::vector<int> id_pipe((size_t)W * 2, -1), st_pipe((size_t)W * 2, -1);
-	std::vector<pid_t> kid((size_t)W, 0);
+	std::vector<pid_t> &kid = g_kids;
+	kid.assign((size_t)W, 0);
 	const char *td = std::getenv("TMPDIR");
 	for (int r = 0; r < W; ++r) {
 		std::string t = std::string(td && *td ? td : "/tmp") + "/pangene_rank" + std::to_string(r) + "_XXXXXX";
 		const int fd = mkstemp(&t[0]);
-		if (fd < 0) { std::fprintf(stderr, "ERROR: cannot create a temporary file for rank %d\n", r); return 1; }
+		if (fd < 0) { std::fprintf(stderr, "ERROR: cannot create a temporary file for rank %d\n", r); take_down(true); return 1; }
 		close(fd);
 		tmp[(size_t)r] = t;
-		if (r && (pipe(&id_pipe[(size_t)r * 2]) != 0 || pipe(&st_pipe[(size_t)r * 2]) != 0)) { std::fprintf(stderr, "ERROR: pipe()\n"); return 1; }
+		if (r && (pipe(&id_pipe[(size_t)r * 2]) != 0 || pipe(&st_pipe[(size_t)r * 2]) != 0)) { std::fprintf(stderr, "ERROR: pipe()\n"); take_down(true); return 1; }
 	}
 	std::fflush(stdout); std::fflush(stderr);
+	const pid_t parent = getpid();
 	int rank = 0;
 	for (int r = 1; r < W; ++r) {
 		const pid_t p = fork();
-		if (p < 0) { std::fprintf(stderr, "ERROR: fork()\n"); for (int k = 1; k < r; ++k) kill(kid[(size_t)k], SIGTERM); return 1; }
-		if (p == 0) { rank = r; break; }
+		if (p < 0) { std::fprintf(stderr, "ERROR: fork()\n"); take_down(true); return 1; }
+		if (p == 0) {
+			rank = r;
+			prctl(PR_SET_PDEATHSIG, SIGKILL); // a worker never outlives rank 0 (it would wait in a collective for ever)
+			if (getppid() != parent) _exit(3);
+			for (int k = 1; k < W; ++k) { // the other workers' pipes are none of this one's business (an inherited write end would keep a dead rank 0's pipe open)
+				if (k == r) continue;
+				for (int e = 0; e < 2; ++e) { if (id_pipe[(size_t)k * 2 + e] >= 0) close(id_pipe[(size_t)k * 2 + e]); if (st_pipe[(size_t)k * 2 + e] >= 0) close(st_pipe[(size_t)k * 2 + e]); }
+			}
+			std::fill(kid.begin(), kid.end(), 0);
+			break;
+		}
 		kid[(size_t)r] = p;
 	}
-	auto cleanup = [&]() { for (int r = 0; r < W; ++r) unlink(tmp[(size_t)r].c_str()); };
+	if (rank == 0) { signal(SIGINT, on_signal); signal(SIGTERM, on_signal); signal(SIGHUP, on_signal); }
 	std::vector<uint8_t> ids_only((size_t)n_files, 1);
-	for (int i = (int)((int64_t)n_files * rank / W); i < (int)((int64_t)n_files * (rank + 1) / W); ++i) ids_only[(size_t)i] = 0;
+	for (int i = cut[(size_t)rank]; i < cut[(size_t)rank + 1]; ++i) ids_only[(size_t)i] = 0;
 	int rc = 0;
 	if (dev && pg_set_device(rank) != 0) { std::fprintf(stderr, "[E::pangene] rank %d: no HIP device %d\n", rank, rank); rc = 3; }
 	// bootstrap: rank 0 hands the id out and hears from every worker before anybody enters the communicator
@@ -161,7 +214,7 @@ static int run_sharded(pg_opt_t &opt, int W, int n_files, char **files, const Ou
 		}
 		for (int r = 1; r < W; ++r) { unsigned char s = 0; if (!read_all(st_pipe[(size_t)r * 2], &s, 1) || !s) ok = 0; }
 		for (int r = 1; r < W; ++r) write_all(id_pipe[(size_t)r * 2 + 1], &ok, 1); // go / no go
-		if (!ok) { for (int r = 1; r < W; ++r) { int st; waitpid(kid[(size_t)r], &st, 0); } cleanup(); return 3; }
+		if (!ok) { for (int r = 1; r < W; ++r) { int st; waitpid(kid[(size_t)r], &st, 0); } take_down(true); return 3; }
 	} else {
 		close(id_pipe[(size_t)rank * 2 + 1]), close(st_pipe[(size_t)rank * 2]);
 		unsigned char ok = 0, go = 0, mine = rc == 0 ? 1 : 0;
@@ -170,20 +223,63 @@ static int run_sharded(pg_opt_t &opt, int W, int n_files, char **files, const Ou
 		write_all(st_pipe[(size_t)rank * 2 + 1], &mine, 1);
 		if (!read_all(id_pipe[(size_t)rank * 2], &go, 1) || !go) _exit(3);
 		opt.flag &= ~PG_F_WRITE_VTX_SEL; // (-G lines come from rank 0 only)
-		if (pg_verbose > 1) pg_verbose = 1; // one log, rank 0's
+		if (pg_verbose > 1) pg_verbose = 1; // one log, rank 0's (the ROUTES of a sharded run follow a level all ranks agree on: graph_driver.cpp route_v)
 	}
+	// From here on a rank that fails alone would leave the others waiting in a collective for ever.  Rank 0 watches its workers: the
+	// first one that ends with an error (or by a signal) takes the command down -- workers and temporary files -- with status 2.
+	std::atomic<bool> watch_on{rank == 0};
+	std::vector<int> kid_status((size_t)W, -1); // exit status of the workers the watchdog has reaped
+	std::thread watchdog;
+	if (rank == 0 && W > 1) watchdog = std::thread([&]() {
+		int left = W - 1;
+		while (watch_on.load() && left > 0) {
+			bool any = false;
+			for (int r = 1; r < W; ++r) {
+				if (kid[(size_t)r] <= 0 || kid_status[(size_t)r] >= 0) continue;
+				int st = 0;
+				const pid_t p = waitpid(kid[(size_t)r], &st, WNOHANG);
+				if (p != kid[(size_t)r]) continue;
+				any = true, --left;
+				kid_status[(size_t)r] = (WIFEXITED(st) && WEXITSTATUS(st) == 0) ? 0 : 1;
+				if (kid_status[(size_t)r] == 0) kid[(size_t)r] = 0; // (reaped: the pid is nobody's any more)
+				else {
+					std::fprintf(stderr, "[E::pangene] rank %d failed; stopping the other ranks\n", r);
+					g_kid_failed.store(1);
+					kid[(size_t)r] = 0;
+					take_down(true);
+					_exit(2);
+				}
+			}
+			if (!any) usleep(20000);
+		}
+	});
 	if ((dev ? rccl_init(rank, W, id) : pg_shm_init(region, rank)) != 0) { std::fprintf(stderr, "[E::pangene] rank %d: cannot join the exchange\n", rank); rc = 3; }
+	if (const char *fr = std::getenv("PANGENE_FAULT_RANK")) if (std::atoi(fr) == rank) { std::fprintf(stderr, "[E::pangene] rank %d: injected fault (PANGENE_FAULT_RANK)\n", rank); rc = 7; } // (tests: a rank that fails alone)
 	if (rc == 0) {
 		if (rank) { if (pg_set_output(tmp[(size_t)rank].c_str()) != 0) rc = 3; }
 		if (rc == 0) rc = run_path(opt, n_files, files, ids_only.data(), o, rank == 0, true);
 		if (rank) pg_set_output(nullptr);
 	}
+	if (rank) { // (no RCCL teardown on a failed rank: the others may be inside a collective -- rank 0's watchdog ends them)
+		if (rc == 0 && dev && rccl_fin) rccl_fin();
+		std::fflush(stderr);
+		_exit(rc);
+	}
+	if (rc != 0) { // rank 0 failed: the workers may be waiting for it
+		watch_on.store(false);
+		if (watchdog.joinable()) watchdog.join();
+		take_down(true);
+		return rc;
+	}
 	if (dev && rccl_fin) rccl_fin();
-	if (rank) _exit(rc);
 	std::fflush(stdout);
+	watch_on.store(false);
+	if (watchdog.joinable()) watchdog.join();
 	for (int r = 1; r < W; ++r) {
+		if (kid_status[(size_t)r] == 0) continue; // (reaped by the watchdog, ended well)
 		int st = 0;
-		if (waitpid(kid[(size_t)r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { std::fprintf(stderr, "[E::pangene] rank %d failed\n", r); rc = rc ? rc : 2; }
+		if (kid[(size_t)r] <= 0 || waitpid(kid[(size_t)r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { std::fprintf(stderr, "[E::pangene] rank %d failed\n", r); rc = rc ? rc : 2; }
+		kid[(size_t)r] = 0;
 	}
 	for (int r = 1; r < W && rc == 0; ++r) { // the other ranks' lines, in rank (= command-line) order
 		FILE *fp = std::fopen(tmp[(size_t)r].c_str(), "rb");
@@ -193,7 +289,7 @@ static int run_sharded(pg_opt_t &opt, int W, int n_files, char **files, const Ou
 		while ((k = std::fread(buf, 1, sizeof(buf), fp)) > 0) std::fwrite(buf, 1, k, stdout);
 		std::fclose(fp);
 	}
-	cleanup();
+	take_down(true);
 	return rc;
 }
 

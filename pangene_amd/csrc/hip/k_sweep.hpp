@@ -91,7 +91,7 @@ __device__ __forceinline__ int cds_inter(const int2 *__restrict__ ex, int oa, in
 struct SwHit { // the hit a thread works for
 	int sg, cs, ce, gid, cds, rank, nex, offx, weak; uint32_t fl; uint32_t sc;
 };
-struct SwBest { bool lose; uint32_t best; int j, ov, pid, cds; };
+struct SwBest { bool lose; uint32_t best; int j, ov, pid, cds, cs; };
 
 // Thread-per-hit form of one pair, used by k_sweep_slow: partner p (records a/b/c, flags fp, array index pi) of hit t;
 // EARLIER: p precedes t in the array.  overlap.c:126-154 (pg_shadow) / 76-87 (pg_flt_ov_isoform).
@@ -130,8 +130,8 @@ __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBe
 	// dominator = best-scoring winner, first in array order on ties (overlap.c:150,153).  Earlier partners are visited in
 	// DEscending index order, so an equal score replaces; later partners in ascending order, so it does not.
 	const bool upd = t_loses && (EARLIER ? (sp > 0 && sp >= r.best) : (sp > r.best));
-	if (t_loses && sp == r.best && sp > 0) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, t.sg); } // hazard H3, rare
-	r.best = upd ? sp : r.best, r.j = upd ? pi : r.j, r.ov = upd ? x : r.ov, r.pid = upd ? b.w : r.pid, r.cds = upd ? b.z : r.cds;
+	if (t_loses && sp == r.best && sp > 0 && a.y == r.cs) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, t.sg); } // hazard H3 (both winners in one (contig, cs) tie group), rare
+	r.best = upd ? sp : r.best, r.j = upd ? pi : r.j, r.ov = upd ? x : r.ov, r.pid = upd ? b.w : r.pid, r.cds = upd ? b.z : r.cds, r.cs = upd ? a.y : r.cs;
 }
 
 __device__ __forceinline__ void wave_sync() // LDS hand-over between lanes of ONE wave (the LDS queue of a wave is in order)
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 				const uint32_t rw = (uint32_t)(i_loses ? bj.x : bi.x);
 				const unsigned long long key = (unsigned long long)rw << 32 | 0x80000000u | (uint32_t)(1023 - W);
 				const unsigned long long old = atomicMax(&sKey[Lt], key);
-				if (MODE != 2 && rw != 0 && (uint32_t)(old >> 32) == rw) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, sA[L].y); } // hazard H3: two winners with one key
+				if (MODE != 2 && rw != 0 && (uint32_t)(old >> 32) == rw && sA[1023 - (int)((uint32_t)old & 1023u)].x == sA[W].x) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, sA[L].y); } // hazard H3: two winners with one key; array order only decides between members of one (contig, cs) tie group
 			}
 		}
 		wave_sync();
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *ne
 			t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
 			t.sc = (uint32_t)b.x;
 		}
-		SwBest r = { false, 0, -1, 0, -1, 0 };
+		SwBest r = { false, 0, -1, 0, -1, 0, -1 };
 		// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so the
 		// walk stops at the first j whose pm is <= cs_h.
 		for (int j = h - 1; j >= 0; --j) {

@@ -41,6 +41,106 @@ int exact_mode()
 }
 void set_exact_mode(int m) { g_exact_mode = m; }
 
+// ---------------------------------------------------------------------------------------------
+// Static tie prediction (mode auto).  Apart from array index 0 (always tracked) the reference's unstable sort can reach the
+// output through three channels, and for each the PARSED KEYS already name the contigs on which it can open:
+//   H2a  two walkable hits with one (contig, cm): the order of the cm sort decides the arc and the W-line.  Two hits that
+//        share cm share a CDS base, so a pair of ONE gene (on one strand under -S) never stays walkable -- pg_flt_ov_isoform
+//        (overlap.c:58-93) filters one of them in stage A, unless something filtered it before.  Superset: a (contig, cm)
+//        group with two hits of different genes (or, under -S, of different strands).
+//   H3   first-wins ties: the dominator arg-max (overlap.c:150,153: equal 64-bit scores = one protein, one score_adj) and
+//        pg_flt_subopt_isoform (hit.c:116: equal score_adj of two proteins of one gene); array order only decides between hits
+//        of one (contig, cs) tie group.  Superset: two hits with one (contig, cs, gene, score_adj).
+// Such contigs follow the reference's exact order from stage A on (ExactSeg::full), so a run needs ONE attempt where the
+// round-3 design ran stages A-C, collected the hazard events and ran them again.  The dynamic detection on the backend stays:
+// it covers H2b (the local_count boundary, not predictable from the keys) and anything this prediction would miss; an event
+// on a contig that is tracked in full is harmless.  PANGENE_STATIC_TIES=0 switches the prediction off (tests: the repeated run).
+// ---------------------------------------------------------------------------------------------
+static bool static_predict() { static const bool on = [] { const char *e = std::getenv("PANGENE_STATIC_TIES"); return !(e && *e == '0'); }(); return on; }
+
+// CDS intersection of two hits of one contig (what pg_hit_overlap, overlap.c:6-42, returns in its upper word): the exon lists are
+// ascending and disjoint, so a merge of the two lists meets every intersecting pair once
+static int64_t cds_intersection(const pg_genome_t *g, const pg_hit_t *a, const pg_hit_t *b)
+{
+	if (!(a->cs < b->ce && a->ce > b->cs)) return 0;
+	const pg_exon_t *ea = g->exon + a->off_exon, *eb = g->exon + b->off_exon;
+	int32_t ia = 0, ib = 0;
+	int64_t inter = 0;
+	while (ia < a->n_exon && ib < b->n_exon) {
+		const int64_t s0 = a->cs + ea[ia].os, e0 = a->cs + ea[ia].oe, s1 = b->cs + eb[ib].os, e1 = b->cs + eb[ib].oe;
+		const int64_t lo = s0 > s1 ? s0 : s1, hi = e0 < e1 ? e0 : e1;
+		if (hi > lo) inter += hi - lo;
+		if (e0 < e1) ++ia; else ++ib;
+	}
+	return inter;
+}
+
+static int64_t cds_length(const pg_genome_t *g, const pg_hit_t *a)
+{
+	int64_t len = 0;
+	for (int32_t i = 0; i < a->n_exon; ++i) len += g->exon[a->off_exon + i].oe - g->exon[a->off_exon + i].os;
+	return len;
+}
+
+static void static_tie_contigs(const pg_data_t *d, const pg_genome_t *g, bool check_strand, double min_ov_ratio, std::vector<int32_t> &out)
+{
+	out.clear();
+	const int32_t n = g->n_hit;
+	if (n < 2) return;
+	size_t cap = 64;
+	while (cap < (size_t)n * 2) cap <<= 1;
+	// open addressing, one table for both kinds of key: slot = index of the group's first hit + 1; the members of a group are chained
+	static thread_local std::vector<int32_t> tab, nxt;
+	std::vector<uint8_t> marked((size_t)g->n_ctg, 0);
+	static const bool dbg = std::getenv("PANGENE_DEBUG_STATIC") != nullptr;
+	auto mix = [](uint64_t a, uint64_t b) { uint64_t h = (a + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull; h ^= h >> 29; h = (h + b) * 0x94d049bb133111ebull; h ^= h >> 32; return h; };
+	for (int kind = 0; kind < 2; ++kind) {
+		tab.assign(cap, 0);
+		if (kind == 0) nxt.assign((size_t)n, -1);
+		for (int32_t i = 0; i < n; ++i) {
+			const pg_hit_t *a = &g->hit[i];
+			if (a->cid < 0 || a->cid >= g->n_ctg || marked[(size_t)a->cid]) continue;
+			const int32_t ga = d->prot[a->pid].gid;
+			const uint64_t k0 = (uint64_t)(uint32_t)a->cid << 32 | (kind == 0 ? 0u : (uint32_t)ga), k1 = kind == 0 ? (uint64_t)a->cm : ((uint64_t)a->cs << 1 ^ (uint64_t)(uint32_t)a->score_adj << 40);
+			for (size_t p = (size_t)mix(k0, k1) & (cap - 1);; p = (p + 1) & (cap - 1)) {
+				if (tab[p] == 0) { tab[p] = i + 1; break; }
+				const int32_t first = tab[p] - 1;
+				const pg_hit_t *b = &g->hit[first];
+				if (b->cid != a->cid) continue;
+				if (kind == 0) {
+					if (b->cm != a->cm) continue;
+					// H2a: could a and a member of its (contig, cm) group both be walkable (!flt && !shadow)?  They share a CDS base.  One gene
+					// (one strand under -S): pg_flt_ov_isoform filters one.  Different genes: pg_shadow marks one of every pair it compares
+					// (overlap.c:126-154) -- it skips the pair when the strands differ under -S, or when the shorter CDS is covered by less
+					// than min_ov_ratio (overlap.c:134-136): only then can both stay walkable
+					int32_t last = first;
+					for (int32_t m = first; m >= 0 && !marked[(size_t)a->cid]; last = m, m = nxt[(size_t)m]) {
+						const pg_hit_t *c = &g->hit[m];
+						bool hazard = check_strand && c->rev != a->rev;
+						if (!hazard && d->prot[c->pid].gid != ga) {
+							const int64_t la = cds_length(g, a), lc = cds_length(g, c), mn = la < lc ? la : lc;
+							hazard = (double)cds_intersection(g, a, c) / (double)(mn > 0 ? mn : 1) < min_ov_ratio;
+						}
+						if (hazard) {
+							marked[(size_t)a->cid] = 1;
+							if (dbg) std::fprintf(stderr, "[static] cm tie: contig %d cm %ld: proteins %d and %d\n", a->cid, (long)a->cm, a->pid, c->pid);
+						}
+					}
+					nxt[(size_t)last] = i; // (i joins the chain; nxt[i] is -1)
+					break;
+				}
+				// H3: first-wins ties between two hits of one (contig, cs) group -- equal 64-bit scores (one protein, one score_adj: the
+				// dominator arg-max, overlap.c:150,153) or equal score_adj of two proteins of one gene (hit.c:116)
+				if (b->cs != a->cs || b->score_adj != a->score_adj || d->prot[b->pid].gid != ga) continue;
+				marked[(size_t)a->cid] = 1;
+				if (dbg) std::fprintf(stderr, "[static] cs tie: contig %d cs %ld gene %d: proteins %d and %d, score_adj %d\n", a->cid, (long)a->cs, ga, a->pid, b->pid, a->score_adj);
+				break;
+			}
+		}
+	}
+	for (int32_t c = 0; c < g->n_ctg; ++c) if (marked[(size_t)c]) out.push_back(c);
+}
+
 // build the tracked segments from the host arrays, which must still be in FILE order
 void exact_init(const pg_data_t *d, DataExt *ext)
 {
@@ -52,6 +152,8 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 	// genomes are independent: host threads collect their segments, which are then appended in genome order
 	const size_t ng = ext->local_genomes.size();
 	std::vector<std::vector<ExactSeg>> per((size_t)ng);
+	std::vector<std::vector<int32_t>> per_static((size_t)ng);
+	ext->static_ctgs.clear();
 	auto do_genome = [&](size_t k) {
 		std::vector<ExactSeg> &out = per[k];
 		const pg_genome_t *g = &d->genome[ext->local_genomes[k]];
@@ -68,11 +170,18 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 			for (int32_t h = 0; h < g->n_hit; ++h) host_of_file[(size_t)ext->file_of_host[(size_t)j][(size_t)h]] = h;
 		else
 			for (int32_t h = 0; h < g->n_hit; ++h) host_of_file[(size_t)h] = h;
-		// contigs that get the full treatment although the mode is auto (tie hazards seen there in a previous attempt)
+		// contigs that get the full treatment although the mode is auto: tie hazards seen there in a previous attempt, and the
+		// contigs on which the STATIC keys already say that a tie channel other than array index 0 can open (static_tie_contigs)
 		std::vector<int32_t> extra;
 		if (mode == 1) {
 			auto lo = std::lower_bound(ext->extra_ctgs.begin(), ext->extra_ctgs.end(), std::make_pair((int32_t)k, (int32_t)INT32_MIN));
 			for (; lo != ext->extra_ctgs.end() && lo->first == (int32_t)k; ++lo) extra.push_back(lo->second);
+			if (static_predict()) {
+				static_tie_contigs(d, g, ext->check_strand, ext->min_ov_ratio, per_static[k]);
+				for (int32_t c : per_static[k]) extra.push_back(c);
+				std::sort(extra.begin(), extra.end());
+				extra.erase(std::unique(extra.begin(), extra.end()), extra.end());
+			}
 		}
 		// file indices grouped by contig, file order inside a contig (one pass; a contig's hits are then contiguous)
 		const bool every = mode == 2 || !extra.empty();
@@ -111,8 +220,15 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 		for (unsigned t = 0; t < nt; ++t) th.emplace_back([&]() { for (;;) { const size_t k = next.fetch_add(1); if (k >= ng) break; do_genome(k); } });
 		for (auto &x : th) x.join();
 	}
-	for (size_t k = 0; k < ng; ++k)
+	for (size_t k = 0; k < ng; ++k) {
 		for (ExactSeg &s : per[k]) ext->xsegs.push_back(std::move(s));
+		for (int32_t c : per_static[k]) ext->static_ctgs.emplace_back((int32_t)k, c); // (sorted: genomes ascending, contigs ascending inside)
+	}
+	if (std::getenv("PANGENE_DEBUG_HAZARDS")) {
+		size_t n_full = 0, n_full_hits = 0;
+		for (const ExactSeg &s : ext->xsegs) if (s.full) ++n_full, n_full_hits += s.file.size();
+		std::fprintf(stderr, "[exact_init] mode %d: %zu tracked contig(s), %zu of them in full (%zu hits); %zu by the static tie prediction\n", mode, ext->xsegs.size(), n_full, n_full_hits, ext->static_ctgs.size());
+	}
 }
 
 static void emulate(ExactSeg &s, std::vector<int32_t> &curv, int by_cm) // one pg_hit_sort of this contig segment
@@ -255,14 +371,29 @@ int exact_sort(DataExt *ext, int by_cm)
 
 void exact_shutdown(DataExt *ext) { exact_wait(ext); }
 
-// Would the next n sorts of each kind (hit.c:29-64) need nothing from the host?  True when no contig is tracked in full and the
-// hit at array index 0 of every genome stays the one the backend holds through the next n cs sorts.
+// Would the next n sorts of each kind (hit.c:29-64) need nothing from the host?  True when the hit at array index 0 of every
+// genome stays the one the backend holds through the next n cs sorts, and every contig tracked in full keeps the two orders the
+// backend holds (the sort sequence of a contig is periodic -- as a rule it has reached its fixed point after two sorts, and a
+// sequence of stable sorts (<= 64 hits, ksort.h:79-80) always has: X_2 = X_3 = ..., Y_1 = Y_2 = ...).
 bool exact_quiet(DataExt *ext, int n)
 {
 	if (ext->xsegs.empty()) return true;
 	exact_wait(ext);
 	for (const ExactSeg &s : ext->xsegs) {
-		if (s.full) return false;
+		if (s.full) {
+			for (int by_cm = 0; by_cm < 2; ++by_cm) {
+				const std::vector<std::vector<int32_t>> &h = by_cm ? s.hy : s.hx;
+				if (h.empty()) continue;
+				size_t last = (size_t)-1;
+				for (int t = ext->x_sorts[by_cm] + 1; t <= ext->x_sorts[by_cm] + n; ++t) {
+					const size_t i = order_index(s, t, h.size());
+					if (i == last) continue; // (compared already)
+					if (h[i] != s.pushed[by_cm]) return false;
+					last = i;
+				}
+			}
+			continue;
+		}
 		for (int t = ext->x_sorts[0] + 1; t <= ext->x_sorts[0] + n; ++t)
 			if (s.heads[order_index(s, t, s.heads.size())] != ext->head_file[(size_t)s.k]) return false;
 	}

@@ -29,7 +29,7 @@ pg_exchange_t g_xchg; bool g_has_xchg = false;
 static int64_t g_n_coll = 0; // collectives issued so far (pg_collective_count)
 double g_phase[PH_COUNT];
 static int g_err = 0; static char g_errstr[256] = "";
-static double g_path_sec = 0.0, g_upload_sec = 0.0, g_pack_sec = 0.0, g_t_path0 = 0.0; static int64_t g_path_hits = 0;
+static double g_path_sec = 0.0, g_upload_sec = 0.0, g_pack_sec = 0.0, g_t_path0 = 0.0; static int64_t g_path_hits = 0; static int g_attempts = 0;
 
 void set_error(int code, const char *where)
 {
@@ -66,6 +66,12 @@ static inline bool sharded()
 	if (force < 0) { const char *e = std::getenv("PANGENE_FORCE_EXCHANGE"); force = e && *e == '1'; }
 	return g_has_xchg && (g_xchg.world > 1 || force);
 }
+
+// Which ROUTE a step takes (queued rounds or host-driven ones, one slot all-gather or the three-step exchange, ...) must never
+// depend on a per-rank setting: the collectives of the ranks would not match.  The log level picks routes (the verbose ones fetch
+// counts for their log lines), so a sharded run agrees on ONE level -- the maximum over the ranks, all-reduced once per upload --
+// and every routing decision reads that; what a rank PRINTS still follows its own pg_verbose.
+static inline int route_v(const DataExt *ext) { return (sharded() && ext && ext->route_verbose >= 0) ? ext->route_verbose : pg_verbose; }
 
 #define BE_CALL(expr, where) do { int rc__ = (expr); if (rc__ != 0) { set_error(rc__, where); return rc__; } } while (0)
 
@@ -539,14 +545,27 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 		g_pack_sec = ext->pack_sec, ext->pack_sec = 0.0; // what the reader spent on the blocks of this upload
 		BE_CALL(build_backend(opt, d, ext), "create"); // (rest of the) pack + allocation + H2D
 		g_pack_sec += ext->pack_sec, ext->pack_sec = 0.0;
+		ext->route_verbose = -1;
+		if (sharded()) { // the level the routes of this data set follow on EVERY rank (route_v): the most verbose rank's
+			int32_t v = pg_verbose;
+			void *scr;
+			BE_CALL(ext->be->scratch(ext->ctx, 16, &scr), "scratch");
+			BE_CALL(ext->be->put(ext->ctx, scr, &v, sizeof(v)), "put");
+			BE_CALL(xreduce(ext->be, ext->ctx, scr, 1, PG_X_I32, PG_X_MAX), "allreduce(log level)");
+			BE_CALL(ext->be->fetch(ext->ctx, &v, scr, sizeof(v)), "fetch");
+			ext->route_verbose = v;
+		}
 		const double tx0 = now_sec();
-		if (!(ext->xsegs_n_genome == d->n_genome && ext->exact_mode_of_segs == exact_mode() && ext->extra_ctgs.empty() && ext->xreplayed)) { // else: the reader did it
+		const bool cs_opt = !!(opt->flag & PG_F_CHECK_STRAND); // (enters the static tie prediction of exact_init)
+		if (!(ext->xsegs_n_genome == d->n_genome && ext->exact_mode_of_segs == exact_mode() && ext->extra_ctgs.empty() && ext->xreplayed && ext->check_strand == cs_opt && ext->min_ov_ratio == opt->min_ov_ratio)) { // else: the reader did it
+			ext->check_strand = cs_opt, ext->min_ov_ratio = opt->min_ov_ratio;
 			exact_init(d, ext);
 			ext->exact_mode_of_segs = exact_mode();
 		}
 		if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[post_process] exact_init %.3f ms\n", (now_sec() - tx0) * 1e3);
-	} else if (ext->exact_mode_of_segs != exact_mode()) {
+	} else if (ext->exact_mode_of_segs != exact_mode() || ext->check_strand != !!(opt->flag & PG_F_CHECK_STRAND) || ext->min_ov_ratio != opt->min_ov_ratio) {
 		exact_shutdown(ext);
+		ext->check_strand = !!(opt->flag & PG_F_CHECK_STRAND), ext->min_ov_ratio = opt->min_ov_ratio;
 		exact_init(d, ext);
 		ext->exact_mode_of_segs = exact_mode();
 	}
@@ -780,7 +799,7 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer 
 	const int32_t S = q->n_seg;
 	int32_t *b_seg; pga_arc_part_t *b_arc; int64_t n_loc;
 	{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 1), "override_order"); } // graph.c:103
-	if (!sharded() && defer && pg_verbose < 3 && be->arc_round_finish) { // the host results are collected later (arc_collect): nothing to prepare here
+	if (!sharded() && defer && route_v(ext) < 3 && be->arc_round_finish) { // the host results are collected later (arc_collect): nothing to prepare here
 		{ Phase ph(PH_ARC_DEV); BE_CALL(be->arc_round_local(ext->ctx, !!(opt->flag & PG_F_ORI_FOR_BRANCH), S, nullptr, nullptr), "arc_round"); }
 		{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
 		ext->arc_pending = true, ext->cur_arcs = nullptr, q->n_arc = 0;
@@ -789,7 +808,7 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer 
 	std::vector<int32_t> sc((size_t)S * 2 + 1);
 	ext->deg.assign((size_t)S * 2 + 1, 0);
 	static const bool no_x = std::getenv("PANGENE_SHARDED_LOOP_HOST") != nullptr; // (tests: the host-driven exchange of a sharded run)
-	if (sharded() && !no_x && be->arc_round_x && be->is_device() && ext->x_arc_slot > 0 && S > 0 && pg_verbose < 3) {
+	if (sharded() && !no_x && be->arc_round_x && be->is_device() && ext->x_arc_slot > 0 && S > 0 && route_v(ext) < 3) {
 		// every rank's table in a slot of a capacity all ranks share (no size exchange), merged on the backend, ONE wait
 		pga_loop_xchg_t lx;
 		lx.user = ext, lx.rank = g_xchg.rank, lx.world = g_xchg.world, lx.arc_cap_hint = ext->x_arc_slot, lx.allreduce_i32_sum = loop_allreduce, lx.allgather = loop_allgather;
@@ -978,7 +997,7 @@ static int mark_branch_flt_arc_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt 
 	const pga_backend_t *be = ext->be;
 	*done = false;
 	static const bool host_only = std::getenv("PANGENE_ROUND_FILTER_HOST") != nullptr; // (tests: keep the general route exercised)
-	if (host_only || sharded() || pg_verbose >= 3 || be->branch_decide_filter == nullptr || !ext->arc_pending) return 0;
+	if (host_only || sharded() || route_v(ext) >= 3 || be->branch_decide_filter == nullptr || !ext->arc_pending) return 0;
 	const int32_t S = q->n_seg;
 	{
 		Phase ph(PH_NLOCAL);
@@ -1046,7 +1065,7 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	*done = false;
 	const pga_backend_t *be = ext->be;
 	const bool shd = sharded();
-	if (be->branch_loop == nullptr || pg_verbose >= 3 || trace_path() != nullptr || (!shd && !ext->arc_pending) || R < 1 || ext->no_branch_loop) return 0;
+	if (be->branch_loop == nullptr || route_v(ext) >= 3 || trace_path() != nullptr || (!shd && !ext->arc_pending) || R < 1 || ext->no_branch_loop) return 0;
 	static const bool no_x = std::getenv("PANGENE_SHARDED_LOOP_HOST") != nullptr; // (tests: the host-driven rounds of a sharded run)
 	if (shd && (no_x || !be->is_device())) return 0;
 	if (shd && ext->skip_loop_once) { ext->skip_loop_once = false; return 0; } // the repeated run after status 3
@@ -1142,7 +1161,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	// Graphs 2 and 3 as ONE queue when the backend can (pga_branch_loop with its pre-step): graph 1's arc round is left running, the
 	// loop starts with graph 2's pg_flt_high_occ + pg_gen_arc and goes on with the branch rounds -- no wait between graph 1 and round n-2.
 	static const bool no_pre = std::getenv("PANGENE_LOOP_NO_PRE") != nullptr; // (tests: graph 2 host-driven in front of the queued rounds)
-	const bool try_pre = !no_pre && opt->n_branch_flt >= 2 && ext->be->branch_loop != nullptr && !sharded() && pg_verbose < 3 && trace_path() == nullptr && !ext->no_branch_loop;
+	const bool try_pre = !no_pre && opt->n_branch_flt >= 2 && ext->be->branch_loop != nullptr && !sharded() && route_v(ext) < 3 && trace_path() == nullptr && !ext->no_branch_loop;
 	BE_CALL(gen_arc(opt, q, ext, try_pre), "gen_arc");
 	BE_CALL(trace_state(ext, "gen_arc", 1), "trace");
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-1 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
@@ -1297,6 +1316,7 @@ static int hazards_review(DataExt *ext, bool *need, bool *give_up)
 			if (i && segs[(size_t)i] == segs[(size_t)i - 1]) continue;
 			const size_t k = (size_t)(std::upper_bound(base.begin(), base.end(), segs[(size_t)i]) - base.begin()) - 1;
 			const std::pair<int32_t, int32_t> gc((int32_t)k, segs[(size_t)i] - base[k]);
+			if (std::binary_search(ext->static_ctgs.begin(), ext->static_ctgs.end(), gc)) continue; // follows the exact order already (static prediction)
 			auto it = std::lower_bound(ext->extra_ctgs.begin(), ext->extra_ctgs.end(), gc);
 			if (it == ext->extra_ctgs.end() || *it != gc) ext->extra_ctgs.insert(it, gc), ++n_new;
 			if (std::getenv("PANGENE_DEBUG_HAZARDS")) std::fprintf(stderr, "[hazard] local genome %d contig %d\n", gc.first, gc.second);
@@ -1380,6 +1400,7 @@ void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 		ext->vtx_sel_text.clear();
 	}
 	g_path_sec += now_sec() - t;
+	g_attempts = n_attempt;
 	if (std::getenv("PANGENE_TIMING")) {
 		std::fprintf(stderr, "[phases]");
 		for (int i = 0; i < PH_COUNT; ++i) std::fprintf(stderr, " %s %.2f", pg_phase_name(i), g_phase[i] * 1e3);
@@ -1456,6 +1477,7 @@ int pg_kernel_timing_reset(pg_data_t *d)
 	return ext->be->timing_reset(ext->ctx);
 }
 int64_t pg_last_path_hits(void) { return g_path_hits; }
+int pg_last_attempts(void) { return g_attempts; }
 
 // the reference's timers (sys.c:117-140; pgpriv.h): main.c:117,149 calls them, so a main.c built on top of this library links
 double pg_realtime(void)

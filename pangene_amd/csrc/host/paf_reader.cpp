@@ -566,6 +566,7 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 	if (slab_helper.joinable()) slab_helper.join();
 	if (timing) std::fprintf(stderr, "[pg_read_paf_batch] %d files on %d threads: %.1f ms wall (+ %.1f ms for the slab helper); summed over the threads: parsing %.1f ms, name look-ups %.1f ms, finishing (ids in place + SoA block) %.1f ms; the sequential commits %.1f ms\n",
 	                         n, n_threads, (t_joined - t_batch0) * 1e3, (now_sec() - t_joined) * 1e3, us_parse.load() * 1e-3, us_resolve.load() * 1e-3, us_final.load() * 1e-3, us_commit.load() * 1e-3);
+	ext->check_strand = !!(opt->flag & PG_F_CHECK_STRAND), ext->min_ov_ratio = opt->min_ov_ratio;
 	exact_prefetch(d, ext); // the replay of the reference's tie order starts in the background
 	return -n_fail.load();
 }

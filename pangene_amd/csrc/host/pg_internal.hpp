@@ -80,6 +80,9 @@ struct DataExt {
 	int exact_mode_of_segs = -1;       // mode xsegs was built for
 	const pg_data_t *q_d = nullptr;    // the data set the context belongs to
 	std::vector<std::pair<int32_t, int32_t>> extra_ctgs; // (local genome, contig) pairs that get the full exact order although the mode is auto (sorted)
+	std::vector<std::pair<int32_t, int32_t>> static_ctgs; // (local genome, contig) pairs tracked in full because the static keys predict a tie channel there (exact_order.cpp: static_tie_contigs); sorted
+	bool check_strand = false;         // PG_F_CHECK_STRAND and min_ov_ratio of the options the tracked contigs were chosen with (they enter the static prediction)
+	double min_ov_ratio = 0.5;
 	std::vector<std::thread> xworkers; // background replay of the reference's sort sequence
 	std::atomic<size_t> xnext{0};
 	bool xreplayed = false;            // the segments' sort sequences have been (or are being) replayed
@@ -87,6 +90,7 @@ struct DataExt {
 	int x_sorts[2] = {0, 0};           // cs / cm sorts of the reference seen so far in this run
 	std::vector<int32_t> head_file;    // per local genome: file index of the hit at array index 0 (-1 canonical)
 	std::vector<int32_t> seg_renumber; // branch rounds queued to the end: old segment number -> number in the graph that is written (-1: deleted); empty otherwise
+	int route_verbose = -1;            // sharded runs: the log level every rank's ROUTING decisions follow (max over the ranks, agreed at upload time); -1 = pg_verbose
 	bool skip_loop_once = false;       // sharded pga_branch_loop asked for a repeated run because an exchange buffer was too small (status 3): that run is host-driven, later ones queue again
 	int64_t x_arc_slot = 0;            // sharded runs: the largest local arc table of any host-driven round so far, over all ranks
 	bool no_branch_loop = false;       // the queued branch rounds (pga_branch_loop) met something they cannot handle on this data set: host-driven rounds from now on

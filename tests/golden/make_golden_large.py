@@ -19,7 +19,12 @@ SETS = {
     "bact1250x5k": (lambda: synth.bact(1250, 5000, seed=1), [[]]),
     # the per-GPU shard of BASELINE configs[4] (200 assemblies x ~110 k all-isoform proteins over 8 GPUs, -p0 -a1): 25 x 20 k genes x 5.5 isoforms
     "human25x20k_iso5.5": (lambda: synth.human(25, 20000, iso=5.5, seed=1, frag=True), [["-p0", "-a1"]]),
+    # BASELINE configs[3] and configs[4] at their FULL stated size (one MI355X holds either): hours of reference CPU time, the files
+    # are written by parallel generator processes (a dict instead of a generator = arguments of synth.write_files_parallel)
+    "bact10000x5k": (dict(kind="bact", G=10000, P=5000, seed=1), [[]]),
+    "human200x20k_iso5.5": (dict(kind="human", G=200, Q=20000, iso=5.5, seed=1, frag=True), [["-p0", "-a1"]]),
 }
+DEFAULT = ["human47x20k", "bact1250x5k", "human25x20k_iso5.5"]
 
 
 def sl(b):
@@ -28,14 +33,14 @@ def sl(b):
 
 def main():
     out = {}
-    only = sys.argv[1:] or list(SETS)
+    only = sys.argv[1:] or DEFAULT
     p = os.path.join(HERE, "expected_large.json")
     if os.path.exists(p):
         out = json.load(open(p))
     for name in only:
         gen, variants = SETS[name]
         with tempfile.TemporaryDirectory(prefix="pg_large_") as td:
-            fs = synth.write_files(gen(), td)
+            fs = synth.write_files_parallel(out_dir=td, **gen) if isinstance(gen, dict) else synth.write_files(gen(), td)
             out[name] = {}
             for v in variants:
                 t0 = time.time()
@@ -43,8 +48,10 @@ def main():
                 out[name][" ".join(v)] = {"md5": hashlib.md5(r.stdout).hexdigest(), "sl_md5": sl(r.stdout), "bytes": len(r.stdout),
                                            "n_S": sum(1 for l in r.stdout.split(b"\n") if l[:1] == b"S"), "reference_wall_s": round(time.time() - t0, 1)}
                 print(name, v, out[name][" ".join(v)], flush=True)
+        cur = json.load(open(p)) if os.path.exists(p) else {}          # two of these may run side by side
+        cur[name] = out[name]
         with open(p, "w") as f:
-            json.dump(out, f, indent=1, sort_keys=True)
+            json.dump(cur, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -43,6 +43,39 @@ def test_sharded_command_refuses_what_it_cannot_do(built):
     assert r.returncode != 0 and b"--matrix" in r.stderr
 
 
+@pytest.mark.parametrize("bad", [0, 1, 2])
+def test_a_rank_that_fails_alone_takes_the_command_down(built, tmp_path, bad):
+    """A rank that ends with an error after the go/no-go handshake used to leave the others waiting in a collective for ever (and the
+    temporary files behind).  Rank 0 watches its workers, workers die with rank 0: the command ends, with an error, and cleans up."""
+    e = dict(os.environ, PANGENE_FAULT_RANK=str(bad), TMPDIR=str(tmp_path))
+    r = subprocess.run([ORA, "--gpus", "3"] + golden_files("bact20"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=60)
+    assert r.returncode != 0
+    assert b"injected fault" in r.stderr
+    assert os.listdir(str(tmp_path)) == []
+
+
+def test_ranks_with_different_log_levels_take_the_same_routes(built, expected):
+    """-v3 on the command line: rank 0 logs at level 3, the workers are silenced to 1 -- the ROUTES (which pick the collectives) follow
+    one level all ranks agree on, so the run ends and prints the reference's bytes"""
+    out = _run(ORA, 3, golden_files("human8f"), "-v3", {"PANGENE_EXACT": "all"})
+    assert hashlib.md5(out).hexdigest() == expected["human8f"][""]["md5"]
+
+
+def test_files_are_cut_by_size_not_by_count(built, tmp_path):
+    """contiguous blocks of genomes balanced by hit count -- one big file and many small ones"""
+    files = golden_files("bact20")
+    big = str(tmp_path / "big.paf")
+    with open(big, "wb") as f:
+        for fn in files[:10]:
+            import gzip
+            f.write(gzip.open(fn).read() if fn.endswith(".gz") else open(fn, "rb").read())
+    one = subprocess.run([ORA, big] + files[10:], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    r = subprocess.run([ORA, "--gpus", "2", "-v3", big] + files[10:], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    assert r.stdout == one
+    kept = [l for l in r.stderr.decode().split("\n") if "lines parsed" in l and "ids only" not in l]
+    assert len(kept) == 1 and "big" in kept[0]  # rank 0's log: its shard is the big file alone
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [2, 4])
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz7126", "-D 300 -C 2"), ("human8", "--bed=walk")])

@@ -13,14 +13,14 @@ import torch.multiprocessing as mp
 from conftest import ROOT, golden_files
 
 
-def _worker(rank, world, port, files, variant, q, cuts=None):
+def _worker(rank, world, port, files, variant, q, cuts=None, verbose=None):
     import ctypes as C
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from pangene_amd import capi, exchange
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     lib = capi.load(oracle_host=True)
-    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    C.c_int.in_dll(lib, "pg_verbose").value = verbose[rank] if verbose else 0
     keep = exchange.install(lib)
     n = len(files)
     lo, hi = (cuts[rank], cuts[rank + 1]) if cuts else (n * rank // world, n * (rank + 1) // world)
@@ -39,11 +39,11 @@ def _free_port():
     return p
 
 
-def _sharded(files, variant, world, cuts=None):
+def _sharded(files, variant, world, cuts=None, verbose=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, files, variant.split(), q, cuts)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, files, variant.split(), q, cuts, verbose)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)
@@ -68,3 +68,15 @@ def test_ranks_equal_single_process(built, expected, name, variant, world, cuts)
     w = b"\n".join(l for r in range(world) for l in res[r].split(b"\n") if l[:1] == b"W")
     whole = sl[0] + b"\n" + w + b"\n"
     assert hashlib.md5(whole).hexdigest() == gold["md5"], "sharded output differs from the reference's single-process GFA"
+
+
+def test_ranks_with_different_log_levels(built, expected, capfd):
+    """A per-rank log level must not select the route (and with it the collectives) of a sharded run: the level the routes follow
+    is agreed once per upload (graph_driver.cpp route_v)."""
+    files = golden_files("human8f")
+    res = _sharded(files, "", 3, None, verbose=[3, 0, 1])
+    capfd.readouterr()
+    sl = [b"\n".join(l for l in res[r].split(b"\n") if l[:1] in (b"S", b"L")) for r in range(3)]
+    assert all(x == sl[0] for x in sl)
+    w = b"\n".join(l for r in range(3) for l in res[r].split(b"\n") if l[:1] == b"W")
+    assert hashlib.md5(sl[0] + b"\n" + w + b"\n").hexdigest() == expected["human8f"][""]["md5"]
