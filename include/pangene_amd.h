@@ -265,6 +265,10 @@ int64_t pg_collective_count(void);
  * alive; 256 MiB after the last pg_data_destroy).  A long-lived host calls this to give back what exceeds keep_bytes (0 = all). */
 void pg_trim_host_cache(size_t keep_bytes);
 
+/* HBM bandwidth a plain copy kernel reaches on the current device, GB/s of read + write (measurement support: the calibration
+ * SURVEY.md 8d asks for beside the spec peak); negative without a device */
+double pg_device_copy_gbps(size_t bytes, int32_t reps);
+
 /* wall seconds the host driver spent per phase of the last run (names via pg_phase_name) */
 int pg_phase_times(double *out, int n);
 const char *pg_phase_name(int i);

@@ -80,7 +80,7 @@ typedef struct {
  * pga_create answers PGA_ERR_RANGE for a block that breaks its own declaration instead of indexing out of bounds later.
  * Device layout limits (PGA_ERR_RANGE otherwise): contig coordinates < 2^31 (pangene.h:71 has int64), < 2^30 hits and < 2^31
  * exons per shard, < 2^20 genes, < 2^24 genomes. */
-#define PGA_ABI_VERSION 3u  /* bumped whenever a struct of this header or the order of pga_backend_t changes; pga_create refuses another */
+#define PGA_ABI_VERSION 4u  /* bumped whenever a struct of this header or the order of pga_backend_t changes; pga_create refuses another */
 typedef struct {
 	uint32_t abi_version;        /* = PGA_ABI_VERSION of the header the caller was compiled against (PGA_ERR_ARG otherwise) */
 	int32_t n_genome;            /* genomes in this shard (may include genomes with 0 hits) */
@@ -320,6 +320,7 @@ typedef struct {
 	int  (*set_device)(int32_t); /* may be NULL */
 	int  (*device_count)(void);  /* may be NULL */
 	int  (*arc_round_x)(pga_ctx_t *, int32_t, int32_t, const struct pga_loop_xchg_s *, int32_t *, int32_t *, int64_t *); /* may be NULL */
+	int  (*copy_gbps)(size_t, int32_t, double *); /* may be NULL */
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);
@@ -358,6 +359,9 @@ void pga_host_trim(size_t keep_bytes);
 /* the HIP device of this process (before the first context); the number of visible devices */
 int pga_set_device(int32_t device);
 int pga_device_count(void);
+/* Measurement support (SURVEY.md 8d asks for a copy kernel beside the spec figure): the bandwidth, GB/s of read + write, that a
+ * 16-byte-per-lane copy of `bytes` reaches on the current device; best of `reps`. */
+int pga_copy_gbps(size_t bytes, int32_t reps, double *gbps);
 
 typedef struct pga_branch_par_s {
 	double branch_diff, branch_diff_dist, branch_diff_cut; int32_t local_dist, local_count, frag_mode, use_ori;

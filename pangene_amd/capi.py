@@ -63,6 +63,8 @@ _API = {
     "pg_last_path_seconds": (C.c_double, []),
     "pg_last_path_hits": (C.c_int64, []),
     "pg_last_attempts": (C.c_int, []),
+    "pg_device_copy_gbps": (C.c_double, [C.c_size_t, C.c_int32]),
+    "pg_trim_host_cache": (None, [C.c_size_t]),
     "pg_last_upload_seconds": (C.c_double, []),
     "pg_last_pack_seconds": (C.c_double, []),
     "pg_shard_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

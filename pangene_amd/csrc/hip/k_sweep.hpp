@@ -53,6 +53,7 @@ struct OutSegMaxA { int4 *A; __device__ __forceinline__ void operator()(int64_t 
 struct SweepView {
 	const int4 *A, *B, *C; const int32_t *sori; const int2 *exon;
 	uint32_t *flags; int32_t *pdom, *sdom;
+	int32_t *pdom0; // MODE 3 only
 	int n; double min_ov; int check_strand;
 	int stage_c; // some hit of the shard has several exons: stage the C records with the others
 	int64_t *hz;
@@ -91,7 +92,7 @@ __device__ __forceinline__ int cds_inter(const int2 *__restrict__ ex, int oa, in
 struct SwHit { // the hit a thread works for
 	int sg, cs, ce, gid, cds, rank, nex, offx, weak; uint32_t fl; uint32_t sc;
 };
-struct SwBest { bool lose; uint32_t best; int j, ov, pid, cds, cs; };
+struct SwBest { bool lose, iso; uint32_t best; int j, ov, pid, cds, cs; };
 
 // Thread-per-hit form of one pair, used by k_sweep_slow: partner p (records a/b/c, flags fp, array index pi) of hit t;
 // EARLIER: p precedes t in the array.  overlap.c:126-154 (pg_shadow) / 76-87 (pg_flt_ov_isoform).
@@ -126,6 +127,7 @@ __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBe
 	}
 	const bool t_loses = ok && (EARLIER ? i_loses : !i_loses);
 	r.lose = r.lose || t_loses;
+	if (MODE == 3) r.iso = r.iso || (t_loses && same_gene); // pg_flt_ov_isoform's pairs are pg_shadow's same-gene pairs, with the same loser (overlap.c:76-87 vs 126-147)
 	if (MODE == 2) return;
 	// dominator = best-scoring winner, first in array order on ties (overlap.c:150,153).  Earlier partners are visited in
 	// DEscending index order, so an equal score replaces; later partners in ascending order, so it does not.
@@ -168,7 +170,13 @@ __device__ __forceinline__ int wave_scan_small(int c, int *total)
 // Pairs across a wave or tile border are evaluated by both sides, each updating only its own hit: no global atomics,
 // no inter-wave synchronisation.  Hits whose partners reach beyond the window, and waves whose list overflows, go
 // to a work list for k_sweep_slow.
-// MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform
+// MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform;
+// 3: stage A's two sweeps in ONE (read.c:248-254): pg_shadow(cal_dom_sc=1), the reset of read.c:249-253 and pg_flt_ov_isoform.  Both
+//    enumerate the same overlapping pairs over the same flt flags (nothing between them sets flt); a same-gene pair has the same
+//    loser in both (overlap.c:139 ignores weak_br and min_ov_ratio for one gene, and both compare score then rank), so the isoform
+//    outcome is one more bit per hit: "lost a same-gene pair".  Written here: pid_dom0 (= the dominator's protein), pid_dom = -1,
+//    score_dom, flt_iso_ov; the shadow flag ends 0 for every hit (read.c:252).  flt itself is NOT set here -- other workgroups
+//    still read the flags of their halo hits -- but by the per-genome filter kernel that follows (overlap.c:89-91).
 constexpr int SW_HALO = 32, SW_TILE = 256, SW_LDS = SW_TILE + 2 * SW_HALO, SW_WCAP = 512, SW_NW = SW_TILE / 64;
 
 #ifdef PGA_SW_PROFILE // tuning build: s_memtime stamps of lane 0 of every wave at the phase boundaries
@@ -179,10 +187,17 @@ constexpr int SW_HALO = 32, SW_TILE = 256, SW_LDS = SW_TILE + 2 * SW_HALO, SW_WC
 
 // epilogue of a hit, overlap.c:157-175.  The hit at index 0 of a genome is never reset (loop starts at 1, overlap.c:108).
 template <int MODE>
-__device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl, bool lose, bool has_dom, int pid_w, int ov, int cds_h, int cds_w, int sori_h, int sori_w)
+__device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl, bool lose, bool has_dom, int pid_w, int ov, int cds_h, int cds_w, int sori_h, int sori_w, bool iso = false)
 {
 	if (MODE == 2) {
 		if (lose) v.flags[h] = fl | PGA_F_ISO_OV;
+		return;
+	}
+	if (MODE == 3) {
+		const uint32_t nf = (fl & ~PGA_F_SHADOW) | (iso ? PGA_F_ISO_OV : 0u); // read.c:252; overlap.c:83,85
+		if (nf != fl) v.flags[h] = nf;
+		v.pdom0[h] = has_dom ? pid_w : -1, v.pdom[h] = -1; // read.c:251-252
+		v.sdom[h] = has_dom ? (int32_t)(sori_h * (1.0 - (double)ov / cds_h) + sori_w * ((double)ov / cds_w) + .499) : -1; // overlap.c:161,170
 		return;
 	}
 	uint32_t nf = (fl & F_HEAD) ? fl : (fl & ~PGA_F_SHADOW);
@@ -200,15 +215,17 @@ template <int MODE, bool STAGE_C>
 __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 {
 	static_assert(2 * SW_HALO == 64 && SW_NW == 4 && SW_LDS <= 1024 && 64 + 2 * SW_HALO <= 128, "the slots past SW_TILE are staged one array per wave; window-relative slot ids are packed in 7 bits, winner slots in 10");
-	constexpr bool STAGE_ORI = MODE == 1 && !STAGE_C; // score_dom needs score_ori: out of the C records when they are staged, else staged alone
+	constexpr bool STAGE_ORI = (MODE == 1 || MODE == 3) && !STAGE_C; // score_dom needs score_ori: out of the C records when they are staged, else staged alone
 	__shared__ int4 sA[SW_LDS + 4], sB[SW_LDS], sC[STAGE_C ? SW_LDS : 1]; // sA: four sentinel slots close the array
 	__shared__ uint32_t sF[SW_LDS];
 	__shared__ int32_t sOri[STAGE_ORI ? SW_LDS : 1];
 	__shared__ uint16_t sPairAll[SW_NW][SW_WCAP]; // (earlier slot - window start) << 7 | (later slot - first own slot): both < 96
 	__shared__ unsigned long long sKeyAll[SW_NW][64];
+	__shared__ uint32_t sIsoAll[MODE == 3 ? SW_NW : 1][64]; // MODE 3: the hit lost a same-gene pair (pg_flt_ov_isoform's mark)
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	uint16_t *sPair = sPairAll[wave];
 	unsigned long long *sKey = sKeyAll[wave];
+	uint32_t *sIso = sIsoAll[MODE == 3 ? wave : 0];
 	const int tile = blockIdx.x, base = tile * SW_TILE - SW_HALO;
 	SW_STAMP(0);
 	{
@@ -235,6 +252,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 	}
 	if (tid < 4) sA[SW_LDS + tid] = make_int4(0, -2, 0, 0);
 	sKey[lane] = 0;
+	if (MODE == 3) sIso[lane] = 0;
 	SW_STAMP(1);
 	__syncthreads();
 	SW_STAMP(2);
@@ -331,6 +349,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 				const uint32_t rw = (uint32_t)(i_loses ? bj.x : bi.x);
 				const unsigned long long key = (unsigned long long)rw << 32 | 0x80000000u | (uint32_t)(1023 - W);
 				const unsigned long long old = atomicMax(&sKey[Lt], key);
+				if (MODE == 3 && same_gene) sIso[Lt] = 1u; // (plain stores of one value)
 				if (MODE != 2 && rw != 0 && (uint32_t)(old >> 32) == rw && sA[1023 - (int)((uint32_t)old & 1023u)].x == sA[W].x) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, sA[L].y); } // hazard H3: two winners with one key; array order only decides between members of one (contig, cs) tie group
 			}
 		}
@@ -357,7 +376,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 					const int W = 1023 - (int)(key & 1023u);
 					const int4 bw = sB[W];
 					pid_w = bw.w, cds_w = bw.z;
-					if (MODE == 1) {
+					if (MODE == 1 || MODE == 3) {
 						const int4 aw = sA[W], cw = STAGE_C ? sC[W] : make_int4(0, 1, 0, sOri[W]), c2 = STAGE_C ? sC[lh] : make_int4(0, 1, 0, sOri[lh]);
 						so_w = cw.w, so_h = c2.w, cds_h = sB[lh].z;
 						const int s0 = aw.x > a.x ? aw.x : a.x, e0 = aw.z < a.z ? aw.z : a.z;
@@ -369,9 +388,10 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 						}
 					}
 				}
-				sw_finish<MODE>(v, h, fl, lose, has_dom, pid_w, ov, cds_h, cds_w, so_h, so_w);
+				sw_finish<MODE>(v, h, fl, lose, has_dom, pid_w, ov, cds_h, cds_w, so_h, so_w, MODE == 3 && sIso[lane] != 0u);
 			}
 		} else if (MODE == 1 && v.init_dom && h < v.n) v.pdom[h] = -1, v.sdom[h] = 0;
+		else if (MODE == 3 && h < v.n) v.pdom0[h] = -1, v.pdom[h] = -1, v.sdom[h] = 0; // a hit filtered before the sweeps keeps what read.c:133-134 gave it
 	}
 	SW_STAMP(7);
 }
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *ne
 			t.weak = (int)((fl & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT), t.fl = fl;
 			t.sc = (uint32_t)b.x;
 		}
-		SwBest r = { false, 0, -1, 0, -1, 0, -1 };
+		SwBest r = { false, false, 0, -1, 0, -1, 0, -1 };
 		// partners before h: every j with ce_j > cs_h.  pm (running max of ce) is non-decreasing inside a contig, so the
 		// walk stops at the first j whose pm is <= cs_h.
 		for (int j = h - 1; j >= 0; --j) {
@@ -408,6 +428,6 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *ne
 			if (a.x != t.sg || a.y >= t.ce) break;
 			sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i, true);
 		}
-		sw_finish<MODE>(v, h, fl, r.lose, r.best > 0, r.pid, r.ov, t.cds, r.cds, ch.w, MODE == 1 && r.best > 0 ? v.C[r.j].w : 0);
+		sw_finish<MODE>(v, h, fl, r.lose, r.best > 0, r.pid, r.ov, t.cds, r.cds, ch.w, (MODE == 1 || MODE == 3) && r.best > 0 ? v.C[r.j].w : 0, r.iso);
 	}
 }

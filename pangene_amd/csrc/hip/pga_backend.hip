@@ -44,6 +44,64 @@ static inline size_t tile_buf_bytes(int64_t n) { return std::max<size_t>(sizeof(
 static inline unsigned nblk(int64_t n, int per = BLOCK) { return (unsigned)((n + per - 1) / per); }
 
 // ------------------------------------------------------------------------------------------------
+// The two big device allocations of a context (the arena of the persistent arrays, the arena of the temporaries) outlive it in a
+// small process-wide cache: hipMalloc / hipFree of gigabytes take anything from 0.4 to 350 ms on this pool's boxes, which made the
+// upload-inclusive pass of the SAME shard range from 10 to 47 ms.  A process that runs one data set after another (a service, the
+// bench's cold passes) pays for the memory once.  Bounded: two blocks are kept (one context's worth); a block is reused for a
+// request it fits without wasting more than half of it.  pga_host_trim(0) (pg_trim_host_cache) gives them back.
+// ------------------------------------------------------------------------------------------------
+struct DevBlock { void *p; size_t cap; };
+static std::mutex g_dev_mu;
+static std::vector<DevBlock> g_dev_cache;
+static bool dev_cache_on() { static const bool on = [] { const char *e = getenv("PANGENE_DEV_CACHE"); return !(e && *e == '0'); }(); return on; }
+
+static void *dev_big_alloc(size_t want, size_t *got)
+{
+	{
+		std::lock_guard<std::mutex> lk(g_dev_mu);
+		size_t best = (size_t)-1;
+		for (size_t i = 0; i < g_dev_cache.size(); ++i)
+			if (g_dev_cache[i].cap >= want && g_dev_cache[i].cap <= 2 * want + ((size_t)64 << 20) && (best == (size_t)-1 || g_dev_cache[i].cap < g_dev_cache[best].cap)) best = i;
+		if (best != (size_t)-1) {
+			DevBlock b = g_dev_cache[best];
+			g_dev_cache.erase(g_dev_cache.begin() + (long)best);
+			*got = b.cap;
+			return b.p;
+		}
+	}
+	void *q = nullptr;
+	if (hipMalloc(&q, want) != hipSuccess) {
+		(void)hipGetLastError();
+		{ // the cache may be what stands in the way
+			std::lock_guard<std::mutex> lk(g_dev_mu);
+			for (DevBlock &b : g_dev_cache) (void)hipFree(b.p);
+			g_dev_cache.clear();
+		}
+		if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	}
+	*got = want;
+	return q;
+}
+
+static void dev_big_free(void *p, size_t cap)
+{
+	if (p == nullptr) return;
+	if (dev_cache_on() && cap >= ((size_t)1 << 20)) {
+		std::lock_guard<std::mutex> lk(g_dev_mu);
+		if (g_dev_cache.size() >= 2) { // keep the two largest
+			size_t small = 0;
+			for (size_t i = 1; i < g_dev_cache.size(); ++i) if (g_dev_cache[i].cap < g_dev_cache[small].cap) small = i;
+			if (g_dev_cache[small].cap >= cap) { (void)hipFree(p); return; }
+			(void)hipFree(g_dev_cache[small].p);
+			g_dev_cache.erase(g_dev_cache.begin() + (long)small);
+		}
+		g_dev_cache.push_back(DevBlock{p, cap});
+		return;
+	}
+	(void)hipFree(p);
+}
+
+// ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
 struct DevPool { // persistent, grow-only device temporaries keyed by slot
@@ -68,7 +126,7 @@ struct DevPool { // persistent, grow-only device temporaries keyed by slot
 	void release()
 	{
 		for (size_t i = 0; i < p.size(); ++i) if (p[i] && own[i]) (void)hipFree(p[i]);
-		if (arena) (void)hipFree(arena);
+		dev_big_free(arena, arena_cap);
 		p.clear(); cap.clear(); own.clear(); arena = nullptr; arena_cap = arena_off = 0;
 	}
 };
@@ -142,6 +200,7 @@ struct pga_ctx {
 	int cs_bits = 1, cm_bits = 1, seg_bits = 1, ctg_bits = 1;
 	bool inv_valid = false;  // inv[] (file index -> X position) matches the current order: built on demand (pga_set_head)
 	bool sweep_init = false; // the next pg_shadow(cal_dom_sc=1) also initialises pid_dom / score_dom of the filtered hits (pga_ingest)
+	int gs2 = 0; // 1 / 2: stage A's orders by k_genome_sort2 / k_genome_sort2b (k_segsort2.hpp: genomes of up to 10 240 hits, two workgroups per CU)
 	bool gs_ok = false; int gs_np = 64; // stage A's orders by k_genome_sort (one workgroup per genome, keys in LDS): every genome fits
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors
@@ -175,7 +234,7 @@ struct pga_ctx {
 	int32_t *h_ndl = nullptr; size_t h_ndl_cap = 0; // pinned: n_dist_loci of a round
 	std::vector<TimedLaunch> timed; bool timing_on = false; // HIP-event timing of kernel classes, switched on by pga_timing_reset (bench.py)
 	hipEvent_t span_a = nullptr; // start of stage A (pga_begin), paired with an event at the end of pga_ingest
-	std::vector<void *> owned;
+	std::vector<void *> owned; void *arena = nullptr; size_t arena_cap = 0; // owned: allocations of their own (PANGENE_NO_ARENA); arena: the one block the persistent arrays are carved from
 	std::vector<std::pair<void **, size_t>> plan; // persistent arrays waiting for the arena (create)
 };
 
@@ -195,9 +254,10 @@ static int dalloc_commit(pga_ctx *c)
 		return 0;
 	}
 	for (auto &e : c->plan) tot += e.second;
-	void *base = nullptr;
-	if (hipMalloc(&base, tot ? tot : 256) != hipSuccess) return PGA_ERR_NOMEM;
-	c->owned.push_back(base);
+	size_t got = 0;
+	void *base = dev_big_alloc(tot ? tot : 256, &got);
+	if (base == nullptr) return PGA_ERR_NOMEM;
+	c->arena = base, c->arena_cap = got;
 	if (poison_on()) (void)hipMemset(base, 0x5a, tot ? tot : 256);
 	size_t off = 0;
 	for (auto &e : c->plan) *e.first = (char *)base + off, off += e.second;
@@ -220,6 +280,11 @@ extern "C" int pga_device_count(void) { int n = 0; return hipGetDeviceCount(&n) 
 
 extern "C" void pga_host_trim(size_t keep_bytes)
 {
+	if (keep_bytes == 0) { // "give everything back": the cached device blocks too
+		std::lock_guard<std::mutex> lk(g_dev_mu);
+		for (DevBlock &b : g_dev_cache) (void)hipFree(b.p);
+		g_dev_cache.clear();
+	}
 	std::lock_guard<std::mutex> lk(g_pin_mu);
 	size_t kept = 0, n_keep = 0;
 	for (; n_keep < g_pin_cache.size() && kept + g_pin_cache[n_keep].cap <= keep_bytes; ++n_keep) kept += g_pin_cache[n_keep].cap;
@@ -245,6 +310,7 @@ extern "C" const char *pga_strerror(int code)
 #include "k_ingest.hpp"
 #include "k_sweep.hpp"
 #include "k_segsort.hpp"
+#include "k_segsort2.hpp"
 #include "k_stage_b.hpp"
 #include "k_vertex.hpp"
 #include "k_arcs.hpp"
@@ -288,7 +354,7 @@ static int bits_for(uint32_t maxv) { int b = 1; while (b < 32 && (maxv >> b)) ++
 
 static int make_sweep_view(pga_ctx *c, SweepView *v)
 {
-	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->sori = c->sori, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom;
+	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->sori = c->sori, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom, v->pdom0 = c->pdom0;
 	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4, v->stage_c = c->any_multi;
 	v->init_dom = c->sweep_init ? 1 : 0;
 	v->slow_cnt = nullptr, v->slow_list = (int32_t *)c->pool.get(S_SLOW, sizeof(int32_t) * (size_t)c->N);
@@ -310,6 +376,7 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 	{ const int rc = make_sweep_view(c, &v); if (rc) return rc; }
 	TimedLaunch t; t.which = timed_which; t.units = c->N;
 	static const int reps = [] { const char *e = getenv("PGA_SW_REPS"); return e && atoi(e) > 0 ? atoi(e) : 1; }(); // tuning aid: the sweep is idempotent
+	static_assert(MODE >= 0 && MODE <= 3, "sweep modes");
 	const bool timed = (timed_which == 0 || timed_which == 1) && c->timing_on; // (the stage-C sweeps are not timed one by one: two events per launch cost ~10 us of queue time)
 	if (timed) {
 		HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
@@ -377,6 +444,7 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 	for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	if (c->span_a) (void)hipEventDestroy(c->span_a);
 	for (void *q : c->owned) (void)hipFree(q);
+	dev_big_free(c->arena, c->arena_cap), c->arena = nullptr;
 	c->pool.release();
 	c->pin.release(); // h_cnt, h_stage, h_g2s, h_round, h_ndl live there
 	if (c->g2s_done) (void)hipEventDestroy(c->g2s_done);
@@ -481,6 +549,15 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->ctg_bits = bits_for((uint32_t)(max_ctg - 1));
 	c->gs_np = std::max(64, (max_hit + 63) & ~63);
 	c->gs_ok = c->gs_np <= GS_NP_MAX && c->rk_shift >= 0 && getenv("PANGENE_GLOBAL_SORT") == nullptr;
+	c->gs2 = 0;
+	if (c->gs_ok && c->gs_np <= GS2_NP_MAX) {
+		static const int want = [] { const char *e = getenv("PANGENE_GS2"); return e ? (*e == '0' ? 0 : *e == 'b' ? 2 : 1) : 1; }(); // (tests / tuning: 0 = the round-3 kernel, b = the 512-thread form)
+		c->gs2 = want;
+		if (c->gs2) {
+			const void *kf2 = c->gs2 == 2 ? reinterpret_cast<const void *>(k_genome_sort2b) : reinterpret_cast<const void *>(k_genome_sort2);
+			if (hipFuncSetAttribute(kf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs2_lds_bytes(c->gs_np, c->gs2 == 2 ? 512 : GS2_T)) != hipSuccess) { (void)hipGetLastError(); c->gs2 = 0; }
+		}
+	}
 	if (c->gs_ok) {
 		const void *kf = c->gs_np <= GS_K_SMALL * GS_T ? reinterpret_cast<const void *>(k_genome_sort) : reinterpret_cast<const void *>(k_genome_sort_big);
 		if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes(c->gs_np)) != hipSuccess) { (void)hipGetLastError(); c->gs_ok = false; }
@@ -492,12 +569,12 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
 		const size_t per_hit = 568 /* measured: 530-540 B/hit at 1 M and 12 M hits (PANGENE_TIMING reports the fit at destroy) */, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
 		const size_t want = ((size_t)N * per_hit + tables + (64u << 20) + (size_t)woff[(size_t)GL] * 4 + 255) & ~(size_t)255;
-		void *a = nullptr;
-		if (getenv("PANGENE_NO_POOL_ARENA") == nullptr && hipMalloc(&a, want) == hipSuccess) { // else: slot by slot
-			c->pool.arena = (char *)a, c->pool.arena_cap = want, c->pool.arena_off = 0;
-			if (poison_on()) (void)hipMemset(a, 0x5a, want);
+		size_t got = 0;
+		void *a = getenv("PANGENE_NO_POOL_ARENA") == nullptr ? dev_big_alloc(want, &got) : nullptr;
+		if (a) { // else: slot by slot
+			c->pool.arena = (char *)a, c->pool.arena_cap = got, c->pool.arena_off = 0;
+			if (poison_on()) (void)hipMemset(a, 0x5a, got);
 		}
-		else (void)hipGetLastError();
 	}
 	const double t1 = now();
 	// the blocks as they are (one DMA per genome out of pinned memory), then one kernel spreads them into flat file-order arrays
@@ -576,7 +653,9 @@ extern "C" int pga_begin(pga_ctx_t *c)
 		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr };
 		static const bool gs_prof = getenv("PANGENE_GS_PROF") != nullptr;
 		if (gs_prof) { gs.prof = (long long *)c->pool.get(S_SCRATCH, sizeof(long long) * 32 * (size_t)GL); if (gs.prof) HIPCHK(hipMemsetAsync(gs.prof, 0, sizeof(long long) * 32 * (size_t)GL, c->st)); }
-		if (c->gs_np <= GS_K_SMALL * GS_T) hipLaunchKernelGGL(k_genome_sort, dim3((unsigned)GL), dim3(GS_T), gs_lds_bytes(c->gs_np), c->st, gs);
+		if (c->gs2 == 1 && !gs_prof) hipLaunchKernelGGL(k_genome_sort2, dim3((unsigned)GL), dim3(GS2_T), gs2_lds_bytes(c->gs_np, GS2_T), c->st, gs);
+		else if (c->gs2 == 2 && !gs_prof) hipLaunchKernelGGL(k_genome_sort2b, dim3((unsigned)GL), dim3(512), gs2_lds_bytes(c->gs_np, 512), c->st, gs);
+		else if (c->gs_np <= GS_K_SMALL * GS_T) hipLaunchKernelGGL(k_genome_sort, dim3((unsigned)GL), dim3(GS_T), gs_lds_bytes(c->gs_np), c->st, gs);
 		else hipLaunchKernelGGL(k_genome_sort_big, dim3((unsigned)GL), dim3(GS_T), gs_lds_bytes(c->gs_np), c->st, gs);
 		c->inv_valid = false;
 		if (gs.prof) { // mean cycles per phase over the workgroups (100 MHz constant counter: 10 ns per tick)
@@ -675,18 +754,22 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 		unsigned long long *tbest = c->gf_ok ? nullptr : (unsigned long long *)c->pool.get(S_TAB_D, sizeof(uint64_t) * (size_t)TQ);
 		uint8_t *noiso = c->gf_ok ? nullptr : (uint8_t *)c->pool.get(S_TAB_A, (size_t)TP + 16); // byte (genome, protein): the protein has a hit there without flt_iso_ov
 		if (!c->gf_ok && (!tbest || !noiso)) return PGA_ERR_NOMEM;
+		// read.c:248-254.  Default: ONE sweep for pg_shadow(cal_dom_sc=1), the reset behind it and pg_flt_ov_isoform (k_sweep<3>: they walk the
+		// same pairs); PANGENE_STAGE_A_TWO_SWEEPS=1 keeps the two-launch form of round 3 (tests)
+		static const bool two_sweeps = getenv("PANGENE_STAGE_A_TWO_SWEEPS") != nullptr;
+		const int fused = two_sweeps ? 0 : 1;
 		c->sweep_init = true;
-		const int rc_sw = launch_sweep<1>(c, 0); // pg_shadow(cal_dom_sc=1), read.c:248 -- "K1", the hit-filter+overlap kernel
+		const int rc_sw = fused ? launch_sweep<3>(c, 0) : launch_sweep<1>(c, 0); // "K1", the hit-filter+overlap kernel
 		c->sweep_init = false;
 		TRY(rc_sw);
-		TRY(launch_sweep<2>(c, 1)); // pg_flt_ov_isoform, read.c:254 (reads neither the shadow flags nor pid_dom: read.c:249-253 follows, in k_iso_apply)
+		if (!fused) TRY(launch_sweep<2>(c, 1)); // pg_flt_ov_isoform, read.c:254 (reads neither the shadow flags nor pid_dom: read.c:249-253 follows, in k_iso_apply)
 		if (c->gf_ok) { // read.c:249-256 per genome, the tables in LDS
-			GenomeFilters gf = { c->flags, c->pid, c->gid, c->rank, c->sadj, c->pdom, c->pdom0, c->goff, c->recA, P, Q, d_stats, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP) };
+			GenomeFilters gf = { c->flags, c->pid, c->gid, c->rank, c->sadj, c->pdom, c->pdom0, c->goff, c->recA, P, Q, d_stats, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP), fused };
 			if (!gf.hz_list) return PGA_ERR_NOMEM;
 			hipLaunchKernelGGL(k_genome_filters, dim3((unsigned)GL), dim3(GF_T), gf_lds_bytes(P, Q), c->st, gf);
 		} else {
 		HIPCHK(hipMemsetAsync(noiso, 0, (size_t)TP, c->st));
-		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, c->pdom, c->pdom0, N, P, noiso, d_stats);
+		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, c->pdom, c->pdom0, N, P, noiso, d_stats, fused);
 		hipLaunchKernelGGL(k_chain, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pdom0, N, P, noiso, d_stats);
 		HIPCHK(hipMemsetAsync(tbest, 0, sizeof(uint64_t) * (size_t)TQ, c->st));
 		hipLaunchKernelGGL(k_subopt1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->sadj, c->goff, N, Q, tbest);
@@ -1872,12 +1955,49 @@ extern "C" int pga_timing_get(pga_ctx_t *c, int32_t which, double *total_ms, int
 	return 0;
 }
 
+// The HBM bandwidth a plain copy reaches on THIS device in THIS process ("calibrate with a copy kernel in the same
+// run"): 16 bytes per lane, grid-stride, `bytes` read and `bytes` written per repetition, timed with HIP events; GB/s of read + write.
+__global__ __launch_bounds__(BLOCK) void k_copy16(const int4 *__restrict__ src, int4 *__restrict__ dst, size_t n16)
+{
+	for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * BLOCK) dst[i] = src[i];
+}
+
+extern "C" int pga_copy_gbps(size_t bytes, int32_t reps, double *gbps)
+{
+	int ndev = 0;
+	if (gbps == nullptr || hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PGA_ERR_NO_DEVICE;
+	bytes = std::max<size_t>(bytes & ~(size_t)15, (size_t)1 << 20);
+	reps = std::max(1, reps);
+	void *a = nullptr, *b = nullptr;
+	if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { (void)hipGetLastError(); if (a) (void)hipFree(a); return PGA_ERR_NOMEM; }
+	hipStream_t st; hipEvent_t e0, e1;
+	HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+	HIPCHK(hipMemsetAsync(a, 1, bytes, st));
+	const size_t n16 = bytes / 16;
+	const unsigned grid = (unsigned)std::min<size_t>((n16 + BLOCK - 1) / BLOCK, (size_t)256 * 32);
+	hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(BLOCK), 0, st, (const int4 *)a, (int4 *)b, n16); // warm
+	double best = 0;
+	for (int r = 0; r < reps; ++r) {
+		HIPCHK(hipEventRecord(e0, st));
+		hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(BLOCK), 0, st, (const int4 *)a, (int4 *)b, n16);
+		HIPCHK(hipEventRecord(e1, st));
+		HIPCHK(hipEventSynchronize(e1));
+		float ms = 0;
+		HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+		if (ms > 0) best = std::max(best, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
+	(void)hipFree(a); (void)hipFree(b);
+	*gbps = best;
+	return 0;
+}
+
 extern "C" const pga_backend_t *pga_backend(void)
 {
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count, pga_arc_round_x
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count, pga_arc_round_x, pga_copy_gbps
 	};
 	return &b;
 }

@@ -1425,6 +1425,14 @@ int pg_backend_is_device(void) { return backend_default()->is_device(); }
 int pg_set_device(int32_t device) { const pga_backend_t *be = backend_default(); return be->set_device ? be->set_device(device) : 0; }
 int pg_device_count(void) { const pga_backend_t *be = backend_default(); return be->device_count ? be->device_count() : 0; }
 
+double pg_device_copy_gbps(size_t bytes, int32_t reps) // < 0: no device / not supported by the backend
+{
+	const pga_backend_t *be = backend_default();
+	double g = -1.0;
+	if (be->copy_gbps == nullptr || be->copy_gbps(bytes, reps, &g) != 0) return -1.0;
+	return g;
+}
+
 void pg_trim_host_cache(size_t keep_bytes) { trim_host_caches(keep_bytes); } // page-locked memory the library keeps for its next upload
 
 int pg_shard_counts(const pg_data_t *d, int64_t *n_hit, int64_t *n_exon)

@@ -110,7 +110,7 @@ def _run_with_env(tmp_path, env, mode, variant, files):
 
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
 @pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1", "PANGENE_LOOP_NO_PRE": "1"},
-                                 {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1", "PANGENE_FILTERS_GLOBAL": "1"}, {"PANGENE_LOOP_NO_FINAL": "1"}])
+                                 {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1", "PANGENE_FILTERS_GLOBAL": "1"}, {"PANGENE_LOOP_NO_FINAL": "1", "PANGENE_STAGE_A_TWO_SWEEPS": "1"}])
 def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
     (the path of rounds in which a hub gene overflows the per-gene LDS table).  Forcing the sort path, and shrinking the table to 4
@@ -125,7 +125,8 @@ def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     bytes: the default of round 2) and stage A's orders by the multi-workgroup radix sort instead of k_genome_sort (the path of
     genomes with more than 25 600 hits), and read.c:249-256 by the four kernels with their tables in HBM instead of k_genome_filters (the
     path of shards whose P + 8 Q bytes do not fit the LDS).  Fifth setting: the last branch round and the arc round of the graph that is written driven by the
-    host behind the queued rounds (the default queues them too and renumbers segments and arcs on the host at the end)."""
+    host behind the queued rounds (the default queues them too and renumbers segments and arcs on the host at the end); and stage A's two
+    sweeps as two launches (k_sweep<1> + k_sweep<2>, the round-3 form) instead of the fused k_sweep<3>."""
     out = _run_with_env(tmp_path, env, 2, variant, golden_files(name))
     assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
 
@@ -291,6 +292,45 @@ def test_config4_per_gpu_shard_full_size_md5(hip, tmp_path):
     assert len(out) == e["bytes"] and hashlib.md5(out).hexdigest() == e["md5"]
 
 
+def _need_room(path, disk_gb, ram_gb):
+    import shutil
+    free = shutil.disk_usage(str(path)).free / 2**30
+    ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2**30
+    if free < disk_gb or ram < ram_gb:
+        pytest.skip("a full-size configuration needs %d GB of scratch disk and %d GB of host memory; this box has %.0f / %.0f" % (disk_gb, ram_gb, free, ram))
+
+
+def test_config3_full_size_md5(hip, tmp_path):
+    """BASELINE configs[3] at its FULL stated size on ONE MI355X (it fits: < 2^30 hits, ~100 GB of HBM): 10 000 bacterial genomes x 5 000
+    proteins, ~97 M hits.  md5 of the GFA (S, L and the 10 000 W-lines) equal to the untouched reference's, which took hours of one core in
+    the build container (tests/golden/expected_large.json: reference_wall_s)."""
+    import shutil
+    e = _expected_large("bact10000x5k", "")
+    _need_room(tmp_path, 24, 96)
+    files = synth.write_files_parallel("bact", str(tmp_path / "c3full"), G=10000, P=5000, seed=1)
+    hip.pg_set_exact_mode(1)
+    try:
+        out = capi.run(hip, files, [])
+    finally:
+        shutil.rmtree(str(tmp_path / "c3full"), ignore_errors=True)
+    assert len(out) == e["bytes"] and hashlib.md5(out).hexdigest() == e["md5"]
+
+
+def test_config4_full_size_md5(hip, tmp_path):
+    """BASELINE configs[4] at its FULL stated size on ONE MI355X: 200 human-shaped assemblies x 20 k genes x 5.5 isoforms (~110 k
+    proteins, ~22 M multi-exon hits, genomes of ~110 k hits each), -p0 -a1: md5 of the GFA equal to the untouched reference's"""
+    import shutil
+    e = _expected_large("human200x20k_iso5.5", "-p0 -a1")
+    _need_room(tmp_path, 12, 64)
+    files = synth.write_files_parallel("human", str(tmp_path / "c4full"), G=200, Q=20000, iso=5.5, seed=1, frag=True)
+    hip.pg_set_exact_mode(1)
+    try:
+        out = capi.run(hip, files, ["-p0", "-a1"])
+    finally:
+        shutil.rmtree(str(tmp_path / "c4full"), ignore_errors=True)
+    assert len(out) == e["bytes"] and hashlib.md5(out).hexdigest() == e["md5"]
+
+
 def test_empty_and_degenerate_inputs(hip, ora, tmp_path):
     p = tmp_path / "e"
     p.mkdir()
@@ -383,14 +423,14 @@ dist.destroy_process_group()
     assert open(outp, "rb").read() == capi.run(lib, files, [])
 
 
-def _rank_on_shared_gpu(rank, world, port, files, variant, cuts, q):
+def _rank_on_shared_gpu(rank, world, port, files, variant, cuts, q, verbose=None):
     import torch, torch.distributed as dist
     sys.path.insert(0, ROOT)
     from pangene_amd import capi as capi2, exchange
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     torch.cuda.set_device(0)
     lib = capi2.load()
-    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    C.c_int.in_dll(lib, "pg_verbose").value = verbose[rank] if verbose else 0
     keep = exchange.install(lib, device=torch.device("cuda", 0))
     n = len(files)
     out = capi2.run(lib, files, variant, scan_only=[not (cuts[rank] <= k < cuts[rank + 1]) for k in range(n)])
@@ -401,16 +441,24 @@ def _rank_on_shared_gpu(rank, world, port, files, variant, cuts, q):
 
 
 @pytest.mark.parametrize("name,variant,cuts", [("bact20", "", [0, 10, 20]), ("human8f", "-p0 -a1", [0, 3, 8]), ("bact20", "", [0, 7, 13, 20]), ("fuzz2", "-F", [0, 2, 2, 99]),
-                                               ("bact20", "host-driven", [0, 10, 20]), ("human8", "", [0, 2, 5, 8]), ("C4", "", [0, 16, 99])])
-def test_sharded_hip_ranks_on_one_gpu(built, expected, name, variant, cuts, monkeypatch):
+                                               ("bact20", "host-driven", [0, 10, 20]), ("human8", "", [0, 2, 5, 8]), ("C4", "", [0, 16, 99]),
+                                               # EIGHT ranks (the node's width), one of them without a genome
+                                               ("bact20", "", [0, 3, 6, 6, 9, 12, 15, 18, 20]), ("human8f", "", [0, 1, 2, 3, 3, 4, 5, 6, 8]),
+                                               # ranks with different log levels: the routes (and with them the collectives) follow one level all ranks agree on
+                                               ("bact20", "verbose 3 0 1", [0, 7, 13, 20]), ("human8f", "verbose 0 3", [0, 3, 8])])
+def test_sharded_hip_ranks_on_one_gpu(built, expected, name, variant, cuts, monkeypatch, capfd):
     """The whole sharded HIP path with W > 1 (id scan, partial vectors, cross-shard arc merge on the device, n_local sums; the branch
     rounds queued on every rank with their two collectives per round in between -- each waits for the stream first here):
     several ranks share this box's one GPU and exchange through gloo with host staging (RCCL will not put two ranks on
     one device).  Their combined output must be the reference's single-process GFA."""
     import socket
     import torch.multiprocessing as mp
+    verbose = None
     if variant == "host-driven":  # the branch rounds of the sharded run driven by the host, not queued (sharded pga_branch_loop)
         monkeypatch.setenv("PANGENE_SHARDED_LOOP_HOST", "1")
+        variant = ""
+    elif variant.startswith("verbose"):
+        verbose = [int(x) for x in variant.split()[1:]]
         variant = ""
     files = golden_files(name)
     cuts = [min(c, len(files)) for c in cuts]
@@ -418,13 +466,14 @@ def test_sharded_hip_ranks_on_one_gpu(built, expected, name, variant, cuts, monk
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_on_shared_gpu, args=(r, world, port, files, variant.split(), cuts, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_on_shared_gpu, args=(r, world, port, files, variant.split(), cuts, q, verbose)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    capfd.readouterr()  # (the level-3 ranks' log)
     sl = [b"\n".join(l for l in res[r].split(b"\n") if l[:1] in (b"S", b"L")) for r in range(world)]
     assert all(x == sl[0] for x in sl)
     w = b"\n".join(l for r in range(world) for l in res[r].split(b"\n") if l[:1] == b"W")
