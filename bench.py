@@ -568,11 +568,14 @@ def main():
     if solo and not a.no_extra_legs and os.path.exists(exe):
         try:
             t0 = time.time()
-            r = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            r = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, PANGENE_CLI_TIMING="1"))
             t_cli = time.time() - t0
             cli = {"wall_s": round(t_cli, 3), "M_hits_per_s": round(n_hits / t_cli / 1e6, 2), "rc": r.returncode, "gfa_md5": hashlib.md5(r.stdout).hexdigest(),
                    "same_bytes_as_the_library_run": hashlib.md5(r.stdout).hexdigest() == hashlib.md5(gfa).hexdigest(),
                    "what": "pangene_amd/bin/pangene <%d files> > pipe: process start + HIP initialisation + code-object load + parsing + path + GFA text" % len(files)}
+            m = re.search(rb"\[cli_timing\] (\{.*\})", r.stderr)
+            if m:
+                cli["parts"] = json.loads(m.group(1).decode())
         except Exception as ex:
             cli = {"error": str(ex)[:300]}
 

@@ -265,6 +265,10 @@ int64_t pg_collective_count(void);
  * alive; 256 MiB after the last pg_data_destroy).  A long-lived host calls this to give back what exceeds keep_bytes (0 = all). */
 void pg_trim_host_cache(size_t keep_bytes);
 
+/* Bring the device runtime up and load the library's kernels ahead of the first pg_post_process (a command line calls it on a
+ * helper thread while the PAF files are parsed); a no-op on backends without a device */
+int pg_device_warm(void);
+
 /* HBM bandwidth a plain copy kernel reaches on the current device, GB/s of read + write (measurement support: the calibration
  * SURVEY.md 8d asks for beside the spec peak); negative without a device */
 double pg_device_copy_gbps(size_t bytes, int32_t reps);

@@ -321,6 +321,7 @@ typedef struct {
 	int  (*device_count)(void);  /* may be NULL */
 	int  (*arc_round_x)(pga_ctx_t *, int32_t, int32_t, const struct pga_loop_xchg_s *, int32_t *, int32_t *, int64_t *); /* may be NULL */
 	int  (*copy_gbps)(size_t, int32_t, double *); /* may be NULL */
+	int  (*warm)(void); /* may be NULL */
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);
@@ -362,6 +363,9 @@ int pga_device_count(void);
 /* Measurement support (SURVEY.md 8d asks for a copy kernel beside the spec figure): the bandwidth, GB/s of read + write, that a
  * 16-byte-per-lane copy of `bytes` reaches on the current device; best of `reps`. */
 int pga_copy_gbps(size_t bytes, int32_t reps, double *gbps);
+/* Bring the HIP runtime up and load this library's code object (a first launch does both, ~0.1-0.3 s): a command line calls it on a
+ * helper thread while its PAF files are parsed, so that the first pga_create finds the device ready. */
+int pga_warm(void);
 
 typedef struct pga_branch_par_s {
 	double branch_diff, branch_diff_dist, branch_diff_cut; int32_t local_dist, local_count, frag_mode, use_ori;

@@ -89,17 +89,32 @@ static int main_gfa2matrix(int argc, char *argv[]) // pangene.js:1168-1183
 // ---------------------------------------------------------------------------------------------------------------
 struct Output { int matrix = 0; };
 
-static int run_path(pg_opt_t &opt, int n_files, char **files, const uint8_t *ids_only, const Output &o, bool graph_lines, bool own_lines)
+static int run_path(pg_opt_t &opt, int n_files, char **files, const uint8_t *ids_only, const Output &o, bool graph_lines, bool own_lines, int device = -1)
 {
+	// PANGENE_CLI_TIMING=1: where the wall time of the command goes (stderr), for bench.py's cli leg
+	const bool timing = std::getenv("PANGENE_CLI_TIMING") != nullptr;
+	const double t0 = pg_realtime();
+	// (Tried: HIP initialisation + code-object load on a helper thread while the files are parsed -- pg_device_warm().  The runtime's
+	// start-up maps and registers memory for ~0.3 s and every one of those calls stalls the page faults of the parser threads of the
+	// same address space: parsing 100 files took 0.30 s instead of 0.05 s and the command got slower, 0.55 s against 0.46 s.  So the
+	// device comes up when pg_post_process first needs it; `device_warm_s` below is that start-up, measured on its own.)
 	pg_data_t *d = pg_data_init();
 	pg_read_paf_batch(&opt, d, n_files, files, ids_only, 0); // parallel parse, ids as in sequential pg_read_paf calls
+	const double t1 = pg_realtime();
+	if (device >= 0) pg_set_device(device);
+	if (timing) pg_device_warm(); // (only to itemise it: pg_post_process would pay it otherwise)
+	const double t2 = pg_realtime();
+	const double t_warm = t2 - t1;
 	pg_post_process(&opt, d);
+	const double t3 = pg_realtime();
+	double t4 = t3;
 	int rc = 0;
 	if (pg_last_error()) rc = 2;
 	else if (opt.flag & PG_F_WRITE_BED_RAW) { if (own_lines) pg_write_bed(d, 0); }
 	else {
 		pg_graph_t *g = pg_graph_init(d);
 		pg_graph_gen(&opt, g);
+		t4 = pg_realtime();
 		if (pg_last_error()) rc = 2;
 		else if (o.matrix) pg_write_matrix(g, o.matrix == 2);
 		else if (opt.flag & PG_F_WRITE_BED_WALK) { if (own_lines) pg_write_bed(d, 1); }
@@ -110,7 +125,11 @@ static int run_path(pg_opt_t &opt, int n_files, char **files, const uint8_t *ids
 		}
 		pg_graph_destroy(g);
 	}
+	std::fflush(stdout);
+	const double t5 = pg_realtime();
 	pg_data_destroy(d);
+	if (timing) std::fprintf(stderr, "[cli_timing] {\"parse_s\": %.4f, \"device_warm_s\": %.4f, \"post_process_s\": %.4f, \"graph_gen_s\": %.4f, \"write_s\": %.4f, \"teardown_s\": %.4f}\n",
+	                         t1 - t0, t_warm, t3 - t2, t4 - t3, t5 - t4, pg_realtime() - t5);
 	return rc;
 }
 
@@ -257,7 +276,7 @@ static int run_sharded(pg_opt_t &opt, int W, int n_files, char **files, const Ou
 	if (const char *fr = std::getenv("PANGENE_FAULT_RANK")) if (std::atoi(fr) == rank) { std::fprintf(stderr, "[E::pangene] rank %d: injected fault (PANGENE_FAULT_RANK)\n", rank); rc = 7; } // (tests: a rank that fails alone)
 	if (rc == 0) {
 		if (rank) { if (pg_set_output(tmp[(size_t)rank].c_str()) != 0) rc = 3; }
-		if (rc == 0) rc = run_path(opt, n_files, files, ids_only.data(), o, rank == 0, true);
+		if (rc == 0) rc = run_path(opt, n_files, files, ids_only.data(), o, rank == 0, true, dev ? rank : -1);
 		if (rank) pg_set_output(nullptr);
 	}
 	if (rank) { // (no RCCL teardown on a failed rank: the others may be inside a collective -- rank 0's watchdog ends them)

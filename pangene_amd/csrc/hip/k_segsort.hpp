@@ -37,6 +37,7 @@ struct GenomeSort {
 	int cs_bits, cm_bits, ctg_bits, np, n_genome;
 	HitArrays o; int32_t *yperm, *headpos; int4 *A, *B, *C;
 	long long *prof; // tuning aid (PANGENE_GS_PROF=1): 16 time stamps per workgroup
+	const int32_t *glist; // k_segsort2.hpp: the genomes this launch sorts (workgroup b takes glist[b]); NULL = genome b
 };
 
 struct GsLds { uint16_t *cur, *alt; uint8_t *dig; uint32_t *whist, *stage, *wtot; unsigned long long *head, *tie; int2 *wagg; };

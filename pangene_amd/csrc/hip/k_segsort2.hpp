@@ -14,6 +14,7 @@
 #pragma once
 
 constexpr int GS2_T = 1024, GS2_K = 10, GS2_NP_MAX = GS2_K * GS2_T; // 10 240
+constexpr int GS2_K_BIG = 14, GS2_NP_BIG = GS2_K_BIG * GS2_T;        // 14 336
 
 template <int T, int K>
 __device__ __forceinline__ void gs2_sort_bits(GsLds &L, const int n, const uint32_t (&key)[K], const int bits)
@@ -69,9 +70,9 @@ __device__ __forceinline__ void gs2_sort_bits(GsLds &L, const int n, const uint3
 	}
 }
 
-static inline size_t gs2_lds_bytes(int np, int threads)
+static inline size_t gs2_lds_bytes(int np)
 {
-	const size_t s = std::max<size_t>(3 * (size_t)np + sizeof(uint32_t) * (size_t)(threads / WAVE) * 256, 4 * (size_t)np);
+	const size_t s = std::max<size_t>(3 * (size_t)np + sizeof(uint32_t) * (size_t)(GS2_T / WAVE) * 256, 4 * (size_t)np);
 	return 2 * (size_t)np + s + (size_t)np / 4 + 256;
 }
 
@@ -79,7 +80,7 @@ template <int T, int K>
 __device__ __forceinline__ void gs2_body(const GenomeSort &a, unsigned char *gs_mem)
 {
 	constexpr int NW = T / WAVE;
-	const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int g = a.glist ? a.glist[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int gb = a.goff[g], n = a.goff[g + 1] - gb, np = a.np;
 	if (tid == 0) { a.headpos[g] = gb; if (g == a.n_genome - 1) a.headpos[g + 1] = gb + n; }
 	if (n == 0) return;
@@ -100,7 +101,7 @@ __device__ __forceinline__ void gs2_body(const GenomeSort &a, unsigned char *gs_
 	// registers (file order) -> staging area; then the plane in X order: V[u] = value of the hit at X position tid + u * T
 #define GS2_STAGE(R) do { _Pragma("unroll") for (int u = 0; u < K; ++u) { const int i = tid + u * T; if (i < n) st[i] = (R)[u]; } gs_bar(); } while (0)
 #ifndef GS2_PREFETCH
-#define GS2_PREFETCH 0
+#define GS2_PREFETCH 1
 #endif
 #if GS2_PREFETCH // the next plane's loads fly while this one is gathered (ten more live registers)
 #define GS2_BEGIN(cur, next) do { GS2_STAGE(R); if ((next) >= 0) GS2_LOAD(R, next); } while (0)
@@ -282,9 +283,10 @@ __global__ __launch_bounds__(GS2_T, 8) void k_genome_sort2(GenomeSort a)
 	extern __shared__ __attribute__((aligned(16))) unsigned char gs2_mem[];
 	gs2_body<GS2_T, GS2_K>(a, gs2_mem);
 }
-// the same genome sizes with 512 threads and 20 items per thread at up to 128 VGPRs: also two workgroups per CU (16 waves instead of 32)
-__global__ __launch_bounds__(512, 4) void k_genome_sort2b(GenomeSort a)
+// up to 14 items per thread (np <= 14 336: what the largest genomes of the bacterial sets need), 128 VGPRs: one workgroup per CU like the
+// round-3 kernel, but 6 radix passes instead of 8 at these sizes and no patch-up pass
+__global__ __launch_bounds__(GS2_T, 4) void k_genome_sort2d(GenomeSort a)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char gs2b_mem[];
-	gs2_body<512, 20>(a, gs2b_mem);
+	extern __shared__ __attribute__((aligned(16))) unsigned char gs2d_mem[];
+	gs2_body<GS2_T, GS2_K_BIG>(a, gs2d_mem);
 }

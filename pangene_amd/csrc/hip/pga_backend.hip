@@ -171,7 +171,7 @@ struct PinArena {
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_BIGLIST, S_STAGE_SID, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK, S_XG_BUF, S_XG_OUT, S_XG_OUT2, S_XSTAT,
+	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_BIGLIST, S_STAGE_SID, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK, S_XG_BUF, S_XG_OUT, S_XG_OUT2, S_XSTAT, S_GS2LIST,
 	S_COUNT
 };
 
@@ -200,7 +200,8 @@ struct pga_ctx {
 	int cs_bits = 1, cm_bits = 1, seg_bits = 1, ctg_bits = 1;
 	bool inv_valid = false;  // inv[] (file index -> X position) matches the current order: built on demand (pga_set_head)
 	bool sweep_init = false; // the next pg_shadow(cal_dom_sc=1) also initialises pid_dom / score_dom of the filtered hits (pga_ingest)
-	int gs2 = 0; // 1 / 2: stage A's orders by k_genome_sort2 / k_genome_sort2b (k_segsort2.hpp: genomes of up to 10 240 hits, two workgroups per CU)
+	int gs2 = 0; // stage A's orders by the kernels of k_segsort2.hpp: genomes of up to 10 240 hits by k_genome_sort2 (two workgroups per CU), the others (up to 14 336) by k_genome_sort2d
+	int32_t *gs2_list = nullptr; int gs2_n_small = 0, gs2_n_big = 0, gs2_np_small = 64; // the two lists of genomes: [small..., big...]
 	bool gs_ok = false; int gs_np = 64; // stage A's orders by k_genome_sort (one workgroup per genome, keys in LDS): every genome fits
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors
@@ -550,12 +551,31 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->gs_np = std::max(64, (max_hit + 63) & ~63);
 	c->gs_ok = c->gs_np <= GS_NP_MAX && c->rk_shift >= 0 && getenv("PANGENE_GLOBAL_SORT") == nullptr;
 	c->gs2 = 0;
-	if (c->gs_ok && c->gs_np <= GS2_NP_MAX) {
-		static const int want = [] { const char *e = getenv("PANGENE_GS2"); return e ? (*e == '0' ? 0 : *e == 'b' ? 2 : 1) : 1; }(); // (tests / tuning: 0 = the round-3 kernel, b = the 512-thread form)
+	if (c->gs_ok && c->gs_np <= GS2_NP_BIG) {
+		static const int want = [] { const char *e = getenv("PANGENE_GS2"); return e ? (*e == '0' ? 0 : *e == 'd' ? 2 : 1) : 1; }(); // (tests / tuning: 0 = the round-3 kernel, d = every genome by the 14-items form)
 		c->gs2 = want;
+		std::vector<int32_t> small, big;
+		int np_small = 64;
+		for (int g = 0; g < GL; ++g) {
+			const int nh = sh->block[g].n_hit;
+			if (nh <= GS2_NP_MAX && c->gs2 == 1) small.push_back(g), np_small = std::max(np_small, (nh + 63) & ~63);
+			else big.push_back(g);
+		}
+		// (a) a shard that cannot even fill the CUs once gains nothing from two workgroups per CU, and two half-empty launches in a row
+		// cost more than one: everything by the 14-items form then; (b) the largest genomes first: the tail of a launch is then made
+		// of the short ones
+		if ((int)small.size() < 2 * c->n_cu) { big.insert(big.end(), small.begin(), small.end()); small.clear(); np_small = 64; }
+		auto by_size = [&](int32_t x, int32_t y) { return sh->block[x].n_hit != sh->block[y].n_hit ? sh->block[x].n_hit > sh->block[y].n_hit : x < y; };
+		std::sort(small.begin(), small.end(), by_size), std::sort(big.begin(), big.end(), by_size);
+		c->gs2_n_small = (int)small.size(), c->gs2_n_big = (int)big.size(), c->gs2_np_small = np_small;
+		small.insert(small.end(), big.begin(), big.end());
+		if (c->gs2 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_genome_sort2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs2_lds_bytes(GS2_NP_MAX)) != hipSuccess) { (void)hipGetLastError(); c->gs2 = 0; }
+		if (c->gs2 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_genome_sort2d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs2_lds_bytes(GS2_NP_BIG)) != hipSuccess) { (void)hipGetLastError(); c->gs2 = 0; }
 		if (c->gs2) {
-			const void *kf2 = c->gs2 == 2 ? reinterpret_cast<const void *>(k_genome_sort2b) : reinterpret_cast<const void *>(k_genome_sort2);
-			if (hipFuncSetAttribute(kf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs2_lds_bytes(c->gs_np, c->gs2 == 2 ? 512 : GS2_T)) != hipSuccess) { (void)hipGetLastError(); c->gs2 = 0; }
+			c->gs2_list = (int32_t *)c->pool.get(S_GS2LIST, sizeof(int32_t) * (size_t)std::max(1, GL));
+			if (!c->gs2_list) return PGA_ERR_NOMEM;
+			if (GL) HIPCHK(hipMemcpyAsync(c->gs2_list, small.data(), sizeof(int32_t) * (size_t)GL, hipMemcpyHostToDevice, c->st));
+			HIPCHK(hipStreamSynchronize(c->st)); // (the list is a local)
 		}
 	}
 	if (c->gs_ok) {
@@ -650,11 +670,13 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	if (c->gs_ok) { // one launch: both orders, every per-hit constant, the packed records (k_segsort.hpp)
 		HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->rk, c->flags };
 		GenomeSort gs = { up, (int64_t)N, c->goff, c->ctg_base, c->cs_bits, c->cm_bits, c->ctg_bits, c->gs_np, GL,
-		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr };
+		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr, nullptr };
 		static const bool gs_prof = getenv("PANGENE_GS_PROF") != nullptr;
 		if (gs_prof) { gs.prof = (long long *)c->pool.get(S_SCRATCH, sizeof(long long) * 32 * (size_t)GL); if (gs.prof) HIPCHK(hipMemsetAsync(gs.prof, 0, sizeof(long long) * 32 * (size_t)GL, c->st)); }
-		if (c->gs2 == 1 && !gs_prof) hipLaunchKernelGGL(k_genome_sort2, dim3((unsigned)GL), dim3(GS2_T), gs2_lds_bytes(c->gs_np, GS2_T), c->st, gs);
-		else if (c->gs2 == 2 && !gs_prof) hipLaunchKernelGGL(k_genome_sort2b, dim3((unsigned)GL), dim3(512), gs2_lds_bytes(c->gs_np, 512), c->st, gs);
+		if (c->gs2 && !gs_prof) {
+			if (c->gs2_n_small) { GenomeSort g1 = gs; g1.glist = c->gs2_list, g1.np = c->gs2_np_small; hipLaunchKernelGGL(k_genome_sort2, dim3((unsigned)c->gs2_n_small), dim3(GS2_T), gs2_lds_bytes(c->gs2_np_small), c->st, g1); }
+			if (c->gs2_n_big) { GenomeSort g2 = gs; g2.glist = c->gs2_list + c->gs2_n_small; hipLaunchKernelGGL(k_genome_sort2d, dim3((unsigned)c->gs2_n_big), dim3(GS2_T), gs2_lds_bytes(c->gs_np), c->st, g2); }
+		}
 		else if (c->gs_np <= GS_K_SMALL * GS_T) hipLaunchKernelGGL(k_genome_sort, dim3((unsigned)GL), dim3(GS_T), gs_lds_bytes(c->gs_np), c->st, gs);
 		else hipLaunchKernelGGL(k_genome_sort_big, dim3((unsigned)GL), dim3(GS_T), gs_lds_bytes(c->gs_np), c->st, gs);
 		c->inv_valid = false;
@@ -1992,12 +2014,24 @@ extern "C" int pga_copy_gbps(size_t bytes, int32_t reps, double *gbps)
 	return 0;
 }
 
+extern "C" int pga_warm(void)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PGA_ERR_NO_DEVICE;
+	int32_t *p = nullptr;
+	HIPCHK(hipMalloc((void **)&p, 256));
+	hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(BLOCK), 0, 0, p, (int64_t)16, 0); // the first launch loads the code object
+	HIPCHK(hipDeviceSynchronize());
+	(void)hipFree(p);
+	return 0;
+}
+
 extern "C" const pga_backend_t *pga_backend(void)
 {
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count, pga_arc_round_x, pga_copy_gbps
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count, pga_arc_round_x, pga_copy_gbps, pga_warm
 	};
 	return &b;
 }
@@ -2045,6 +2079,86 @@ extern "C" int pga_selftest_merge(const pga_arc_part_t *gathered, const int64_t 
 	c.pool.release();
 	(void)hipStreamDestroy(c.st);
 	return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Calibration of the rocprofv3 memory counters (profiles/tools/calibrate.py): kernels with KNOWN byte counts in the access patterns the
+// path's kernels use -- coalesced streams of 4 and 16 bytes per lane, 4- and 16-byte gathers / scatters through a permutation (inside
+// windows of `window` items, or over the whole array) -- so that FETCH_SIZE / WRITE_SIZE can be turned into bytes per pattern instead
+// of by one factor for everything (MI355X_MICROARCH.md calibrates the factor 2 of FETCH_SIZE for wide coalesced reads only).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t cal_perm(int64_t i, int64_t n, int64_t window) // a bijection of [0, n) that permutes inside windows (a power of two)
+{
+	const int64_t base = i & ~(window - 1), span = base + window <= n ? window : 0; // (the last, partial window stays in place)
+	return span ? base + (((i - base) * 40503 + 12345) & (window - 1)) : i;
+}
+__global__ __launch_bounds__(BLOCK) void k_cal_read16(const int4 *__restrict__ src, int64_t n, int32_t *sink)
+{
+	int acc = 0;
+	for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) { const int4 v = src[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+	if (acc == 0x7fffffff) sink[0] = acc;
+}
+__global__ __launch_bounds__(BLOCK) void k_cal_read4(const int32_t *__restrict__ src, int64_t n, int32_t *sink)
+{
+	int acc = 0;
+	for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) acc ^= src[i];
+	if (acc == 0x7fffffff) sink[0] = acc;
+}
+__global__ __launch_bounds__(BLOCK) void k_cal_gather4(const int32_t *__restrict__ src, int64_t n, int64_t window, int32_t *sink)
+{
+	int acc = 0;
+	for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) acc ^= src[cal_perm(i, n, window)];
+	if (acc == 0x7fffffff) sink[0] = acc;
+}
+__global__ __launch_bounds__(BLOCK) void k_cal_gather16(const int4 *__restrict__ src, int64_t n, int64_t window, int32_t *sink)
+{
+	int acc = 0;
+	for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) { const int4 v = src[cal_perm(i, n, window)]; acc ^= v.x ^ v.w; }
+	if (acc == 0x7fffffff) sink[0] = acc;
+}
+__global__ __launch_bounds__(BLOCK) void k_cal_write16(int4 *__restrict__ dst, int64_t n)
+{
+	for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = make_int4((int)i, 1, 2, 3);
+}
+__global__ __launch_bounds__(BLOCK) void k_cal_write4(int32_t *__restrict__ dst, int64_t n)
+{
+	for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = (int)i;
+}
+__global__ __launch_bounds__(BLOCK) void k_cal_scatter4(int32_t *__restrict__ dst, int64_t n, int64_t window)
+{
+	for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[cal_perm(i, n, window)] = (int)i;
+}
+__global__ __launch_bounds__(BLOCK) void k_cal_scatter16(int4 *__restrict__ dst, int64_t n, int64_t window)
+{
+	for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[cal_perm(i, n, window)] = make_int4((int)i, 1, 2, 3);
+}
+
+// runs every pattern once over n items (n * 16 bytes must be past the 256 MiB Infinity Cache to mean anything); the names of the
+// kernels carry the pattern, the caller knows the bytes: read16 16 n, read4 4 n, gather4 4 n, gather16 16 n, write16 16 n,
+// write4 4 n, scatter4 4 n, scatter16 16 n.  window: a power of two (a genome's worth of items), or 0 = the whole array (rounded down).
+extern "C" int pga_selftest_traffic(int64_t n, int64_t window)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PGA_ERR_NO_DEVICE;
+	if (n < 1024) return PGA_ERR_ARG;
+	if (window <= 0) { window = 1; while (window * 2 <= n) window *= 2; }
+	if (window & (window - 1)) return PGA_ERR_ARG;
+	int4 *a = nullptr, *b = nullptr; int32_t *sink = nullptr;
+	HIPCHK(hipMalloc((void **)&a, sizeof(int4) * (size_t)n)); HIPCHK(hipMalloc((void **)&b, sizeof(int4) * (size_t)n)); HIPCHK(hipMalloc((void **)&sink, 256));
+	HIPCHK(hipMemset(a, 1, sizeof(int4) * (size_t)n)); HIPCHK(hipMemset(b, 2, sizeof(int4) * (size_t)n));
+	HIPCHK(hipDeviceSynchronize());
+	const unsigned grid = (unsigned)std::min<int64_t>((n + BLOCK - 1) / BLOCK, (int64_t)256 * 64);
+	hipLaunchKernelGGL(k_cal_read16, dim3(grid), dim3(BLOCK), 0, 0, (const int4 *)a, n, sink);
+	hipLaunchKernelGGL(k_cal_read4, dim3(grid), dim3(BLOCK), 0, 0, (const int32_t *)b, n, sink);
+	hipLaunchKernelGGL(k_cal_gather4, dim3(grid), dim3(BLOCK), 0, 0, (const int32_t *)a, n, window, sink);
+	hipLaunchKernelGGL(k_cal_gather16, dim3(grid), dim3(BLOCK), 0, 0, (const int4 *)b, n, window, sink);
+	hipLaunchKernelGGL(k_cal_write16, dim3(grid), dim3(BLOCK), 0, 0, a, n);
+	hipLaunchKernelGGL(k_cal_write4, dim3(grid), dim3(BLOCK), 0, 0, (int32_t *)b, n);
+	hipLaunchKernelGGL(k_cal_scatter4, dim3(grid), dim3(BLOCK), 0, 0, (int32_t *)a, n, window);
+	hipLaunchKernelGGL(k_cal_scatter16, dim3(grid), dim3(BLOCK), 0, 0, b, n, window);
+	HIPCHK(hipDeviceSynchronize());
+	(void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
+	return 0;
 }
 
 // mode 0: exclusive sum; 1: exclusive max (identity -1); 2: segmented inclusive max with seg[]

@@ -365,11 +365,26 @@ int exact_sort(DataExt *ext, int by_cm)
 		so.push_back((int64_t)fi.size());
 	}
 	if (sg.empty()) return 0;
-	ext->pos_valid = false; // the backend's orders change: the host copy of them is stale
+	ext->order_touched = true; // the backend's orders change: sync_host compares what the tracked contigs hold now with what its copy was taken from (order_signature)
 	return ext->be->override_order(ext->ctx, by_cm, (int32_t)sg.size(), sg.data(), ss.data(), so.data(), fi.data());
 }
 
 void exact_shutdown(DataExt *ext) { exact_wait(ext); }
+
+// What the orders of the fully tracked contigs are right now, as one number: a repeated run over a resident shard goes through
+// the same overrides and ends with the same orders, and the host's copy of the two orders (pos_x, y_file: 8 bytes a hit to
+// fetch and to turn around) is still good then.
+uint64_t order_signature(const DataExt *ext)
+{
+	uint64_t h = 1469598103934665603ull;
+	auto mix = [&h](uint64_t x) { h = (h ^ x) * 1099511628211ull; };
+	for (const ExactSeg &s : ext->xsegs) {
+		if (!s.full) continue;
+		mix((uint64_t)(uint32_t)s.k << 32 | (uint32_t)s.start);
+		for (int b = 0; b < 2; ++b) { mix(s.pushed[b].size()); for (int32_t v : s.pushed[b]) mix((uint64_t)(uint32_t)v); }
+	}
+	return h;
+}
 
 // Would the next n sorts of each kind (hit.c:29-64) need nothing from the host?  True when the hit at array index 0 of every
 // genome stays the one the backend holds through the next n cs sorts, and every contig tracked in full keeps the two orders the

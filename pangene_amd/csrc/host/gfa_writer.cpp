@@ -6,7 +6,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <regex>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include "pg_internal.hpp"
 
@@ -146,6 +148,19 @@ void pg_write_graph(const pg_graph_t *q) // format.c:120-157
 // W-lines (format.c:183-225): per genome, contigs in id order, surviving hits in cm order.  The host records stay where they
 // are (file order, or cs order after a full sync); the cm order comes from the backend's Y permutation as file indices
 // (DataExt::y_file) and flt from the bit vector of the last sync (indexed by X position).
+// Genomes are independent: host threads format them side by side into buffers of their own (names copied with their known
+// lengths, no per-line allocation), and the buffers go to the stream in genome order, a window of genomes at a time.
+static inline char *cat_i32(char *p, int32_t c)
+{
+	char buf[16];
+	int l = 0;
+	uint32_t x = c >= 0 ? (uint32_t)c : (uint32_t)(-(int64_t)c);
+	do { buf[l++] = (char)('0' + x % 10); x /= 10; } while (x > 0);
+	if (c < 0) buf[l++] = '-';
+	while (l > 0) *p++ = buf[--l];
+	return p;
+}
+
 void pg_write_walk(pg_graph_t *q)
 {
 	pg_data_t *d = q->d;
@@ -153,45 +168,87 @@ void pg_write_walk(pg_graph_t *q)
 	DataExt *ext = ext_of(d, false);
 	if (ext == nullptr || ext->ctx == nullptr) { set_error(PGA_ERR_ARG, "pg_write_walk: pg_graph_gen has not run on this data set"); return; }
 	FILE *fp = out_stream();
-	std::string o, sample;
 	std::vector<int64_t> goff_of((size_t)d->n_genome, -1);
 	for (size_t k = 0; k < ext->local_genomes.size(); ++k) goff_of[(size_t)ext->local_genomes[k]] = ext->hit_off[k];
 	for (int32_t j = 0; j < d->n_genome; ++j) {
 		const pg_genome_t *g = &d->genome[j];
 		if (g->n_hit == 0) continue;
+		if (goff_of[(size_t)j] < 0 || (size_t)j >= ext->y_file.size() || ext->y_file[(size_t)j].size() != (size_t)g->n_hit) { set_error(PGA_ERR_ARG, "pg_write_walk: genome without backend state"); return; }
+	}
+	std::vector<uint32_t> gene_len((size_t)d->n_gene);
+	for (int32_t i = 0; i < d->n_gene; ++i) gene_len[(size_t)i] = (uint32_t)std::strlen(d->gene[i].name);
+	const uint64_t *fb = ext->flt_bits.data();
+	auto format_genome = [&](int32_t j, std::vector<char> &out) {
+		out.clear();
+		const pg_genome_t *g = &d->genome[j];
+		if (g->n_hit == 0) return;
 		const int64_t goff = goff_of[(size_t)j];
-		if (goff < 0 || (size_t)j >= ext->y_file.size() || ext->y_file[(size_t)j].size() != (size_t)g->n_hit) { set_error(PGA_ERR_ARG, "pg_write_walk: genome without backend state"); return; }
 		const int32_t *yf = ext->y_file[(size_t)j].data();
 		const int32_t *hof = ext->hits_sorted[(size_t)j] ? ext->host_of_file[(size_t)j].data() : nullptr;
 		const int32_t *px = ext->pos_x.data() + goff;
-		const uint64_t *fb = ext->flt_bits.data();
 		auto hit_of = [&](int32_t k) -> const pg_hit_t * { const int32_t f = yf[k]; return &g->hit[hof ? hof[f] : f]; };
 		auto is_flt = [&](int32_t k) { const int64_t b = goff + px[yf[k]]; return (fb[b >> 6] >> (b & 63) & 1) != 0; };
+		std::string sample;
 		for (int32_t i0 = 0, i = 1; i <= g->n_hit; ++i) {
 			if (i != g->n_hit && hit_of(i)->cid == hit_of(i0)->cid) continue;
-			int32_t cid = hit_of(i0)->cid, n = 0;
-			int32_t hap = parse_sample(sample, g->ctg[cid].name);
-			o.clear();
-			if (hap >= 0) { o += "W\t"; o += sample; o += '\t'; put_i32(o, hap); }
-			else if (g->label) { o += "W\t"; o += g->label; o += "\t0"; }
-			else { o += "W\t"; put_i32(o, j); o += "\t0"; }
-			o += '\t'; o += g->ctg[cid].name; o += "\t*\t*\t";
+			const int32_t cid = hit_of(i0)->cid;
+			// the surviving hits of the contig, and the room their two lists take
+			size_t need = 0;
+			int32_t n = 0;
 			for (int32_t k = i0; k < i; ++k) {
 				if (is_flt(k)) continue;
-				const pg_hit_t *a = hit_of(k);
-				o += "><"[a->rev]; o += d->gene[d->prot[a->pid].gid].name;
+				need += 1 + gene_len[(size_t)d->prot[hit_of(k)->pid].gid] + 12;
 				++n;
 			}
 			if (n > 0) {
-				o += "\tlf:B:i";
+				const char *cname = g->ctg[cid].name;
+				const size_t lc = std::strlen(cname), ll = g->label ? std::strlen(g->label) : 0;
+				const int32_t hap = parse_sample(sample, cname);
+				const size_t at = out.size();
+				out.resize(at + need + lc + ll + sample.size() + 64);
+				char *p = out.data() + at;
+				*p++ = 'W', *p++ = '\t';
+				if (hap >= 0) { std::memcpy(p, sample.data(), sample.size()), p += sample.size(); *p++ = '\t'; p = cat_i32(p, hap); }
+				else if (g->label) { std::memcpy(p, g->label, ll), p += ll; *p++ = '\t', *p++ = '0'; }
+				else { p = cat_i32(p, j); *p++ = '\t', *p++ = '0'; }
+				*p++ = '\t';
+				std::memcpy(p, cname, lc), p += lc;
+				std::memcpy(p, "\t*\t*\t", 5), p += 5;
 				for (int32_t k = i0; k < i; ++k) {
 					if (is_flt(k)) continue;
-					o += ','; put_i32(o, hit_of(k)->lof);
+					const pg_hit_t *a = hit_of(k);
+					const int32_t gid = d->prot[a->pid].gid;
+					*p++ = "><"[a->rev];
+					std::memcpy(p, d->gene[gid].name, gene_len[(size_t)gid]), p += gene_len[(size_t)gid];
 				}
-				o += '\n';
-				std::fwrite(o.data(), 1, o.size(), fp);
+				std::memcpy(p, "\tlf:B:i", 7), p += 7;
+				for (int32_t k = i0; k < i; ++k) {
+					if (is_flt(k)) continue;
+					*p++ = ',';
+					p = cat_i32(p, hit_of(k)->lof);
+				}
+				*p++ = '\n';
+				out.resize((size_t)(p - out.data()));
 			}
 			i0 = i;
+		}
+	};
+	unsigned nt = ext->n_hit_local > 200000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u) : 1u;
+	if (nt > (unsigned)d->n_genome) nt = (unsigned)std::max(1, d->n_genome);
+	if (nt <= 1) {
+		std::vector<char> buf;
+		for (int32_t j = 0; j < d->n_genome; ++j) { format_genome(j, buf); if (!buf.empty()) std::fwrite(buf.data(), 1, buf.size(), fp); }
+	} else {
+		const int32_t window = (int32_t)nt * 8; // genomes formatted side by side before their bytes are written (bounds the memory)
+		std::vector<std::vector<char>> bufs((size_t)window);
+		for (int32_t j0 = 0; j0 < d->n_genome; j0 += window) {
+			const int32_t j1 = std::min(d->n_genome, j0 + window);
+			std::atomic<int32_t> next{j0};
+			std::vector<std::thread> th;
+			for (unsigned t = 0; t < nt; ++t)
+				th.emplace_back([&]() { for (;;) { const int32_t j = next.fetch_add(1); if (j >= j1) break; format_genome(j, bufs[(size_t)(j - j0)]); } });
+			for (auto &x : th) x.join();
+			for (int32_t j = j0; j < j1; ++j) if (!bufs[(size_t)(j - j0)].empty()) std::fwrite(bufs[(size_t)(j - j0)].data(), 1, bufs[(size_t)(j - j0)].size(), fp);
 		}
 	}
 	std::fflush(fp);

@@ -223,8 +223,14 @@ static const size_t SLAB_CACHE_MAX = (size_t)4 << 30;   // while a data set is a
 static std::condition_variable g_slab_cv;
 static int g_prefetch_left = 0; // slabs the helper has still to deliver (guarded by g_slab_mu)
 
+// Page-locked block memory only once the device runtime is up in this process (after the first upload): the runtime's start-up,
+// triggered by a first hipHostMalloc in the middle of a batch read, maps and registers memory for ~0.3 s and stalls the page faults
+// of every parser thread meanwhile (a `pangene` command parsed its 100 files in 0.30 s instead of 0.05 s).
+static std::atomic<bool> g_device_up{false};
+
 static HostSlab slab_get(size_t min_bytes, bool allow_pin = true)
 {
+	allow_pin = allow_pin && g_device_up.load();
 	{
 		std::unique_lock<std::mutex> lk(g_slab_mu);
 		for (;;) {
@@ -253,7 +259,8 @@ static HostSlab slab_get(size_t min_bytes, bool allow_pin = true)
 void slab_prefetch(size_t bytes, std::thread *helper) // *helper is joined by the caller when its reads are done
 {
 	const pga_backend_t *be = backend_default();
-	if (be->host_alloc == nullptr || !be->is_device()) return;
+	if (be->host_alloc == nullptr || !be->is_device() || !g_device_up.load()) return;
+	{ const char *e = std::getenv("PANGENE_PIN_BUDGET_MB"); if (e && std::atoi(e) <= 0) return; }
 	size_t have = 0;
 	int n = 0;
 	{
@@ -289,7 +296,7 @@ static void *block_alloc(DataExt *ext, size_t bytes)
 		// Page-locking costs ~1 ms per MB (measured: 580 MB of blocks for 12 M hits = 0.5 s, twice the parsing itself) and the DMA
 		// it buys saves ~0.1 ms per MB on the one upload.  What the cache holds is used; beyond PIN_BUDGET of freshly locked
 		// memory a read takes plain pages (the runtime stages those uploads).
-		static const size_t PIN_BUDGET = (size_t)192 << 20;
+		static const size_t PIN_BUDGET = [] { const char *e = std::getenv("PANGENE_PIN_BUDGET_MB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 192) << 20; }(); // (tuning: 0 = no page-locking while files are read)
 		size_t fresh = 0;
 		for (const HostSlab &x : ext->slabs) if (x.pinned && x.fresh) fresh += x.cap;
 		HostSlab ns = slab_get(bytes, fresh + SLAB_BYTES <= PIN_BUDGET);
@@ -351,7 +358,7 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	ext->local_genomes.clear();
 	ext->is_local.resize((size_t)d->n_genome, 1);
 	ext->hits_sorted.resize((size_t)d->n_genome, 0); // genomes a previous sync_host put into cs order stay marked: their file order is in file_of_host
-	ext->pos_valid = false, ext->host_full = false;
+	ext->pos_valid = false, ext->host_full = false, ext->order_touched = false, ext->pos_sig = 0;
 	for (int32_t j = 0; j < d->n_genome; ++j)
 		if (ext->is_local[(size_t)j]) ext->local_genomes.push_back(j);
 	const int32_t nl = (int32_t)ext->local_genomes.size();
@@ -387,6 +394,7 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	static const bool timing = std::getenv("PANGENE_TIMING") != nullptr;
 	const double t1 = now_sec();
 	const int rc = ext->be->create(&ext->ctx, &sh, &par); // returns when the blocks have been read
+	if (rc == 0) g_device_up.store(true);
 	const double t2 = now_sec();
 	size_t n_pin = 0, n_plain = 0, n_fresh = 0;
 	for (const HostSlab &x : ext->slabs) { if (x.pinned) ++n_pin; else ++n_plain; if (x.fresh) ++n_fresh; }
@@ -410,6 +418,12 @@ int sync_host(pg_data_t *d, bool full)
 	if (!ext->host_stale && !(full && !ext->host_full)) return g_err;
 	Phase ph(PH_SYNC_HOST);
 	const int64_t N = ext->n_hit_local;
+	uint64_t sig_now = ext->pos_sig;
+	if (ext->order_touched) { // overrides were handed over since the last sync: do the tracked contigs hold other orders than the copy was taken from?
+		sig_now = order_signature(ext);
+		if (sig_now != ext->pos_sig) ext->pos_valid = false;
+		ext->order_touched = false;
+	}
 	const bool need_pos = !ext->pos_valid;
 	// The arrays land in one of the pinned slabs the genome blocks were uploaded from (idle by now, kept in the process-wide
 	// cache): megabytes copied into pageable memory make the runtime pin and unpin the destination, which costs milliseconds and
@@ -487,6 +501,7 @@ int sync_host(pg_data_t *d, bool full)
 		}
 	}
 	if (move) ext->host_order_valid = true;
+	if (need_pos) ext->pos_sig = sig_now;
 	ext->pos_valid = true;
 	ext->host_stale = false;
 	ext->host_full = full;
@@ -1424,6 +1439,8 @@ double pg_last_pack_seconds(void) { return g_pack_sec; }
 int pg_backend_is_device(void) { return backend_default()->is_device(); }
 int pg_set_device(int32_t device) { const pga_backend_t *be = backend_default(); return be->set_device ? be->set_device(device) : 0; }
 int pg_device_count(void) { const pga_backend_t *be = backend_default(); return be->device_count ? be->device_count() : 0; }
+
+int pg_device_warm(void) { const pga_backend_t *be = backend_default(); return be->warm ? be->warm() : 0; }
 
 double pg_device_copy_gbps(size_t bytes, int32_t reps) // < 0: no device / not supported by the backend
 {

@@ -3,7 +3,10 @@
 // "must be rebuilt on host"); what matters here is that ids, ranks, exon lists, cm and score_adj come
 // out exactly as the reference's reader produces them (read.c:107-236, hit.c:14-27), because
 // pg_hash_uint32(pid) and the first-seen numbering are score-relevant downstream.
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <cctype>
 #include <cmath>
@@ -87,15 +90,56 @@ private:
 	bool eof_ = false;
 };
 
+// A plain (not gzipped) PAF file wholly in memory: one read() into a buffer the thread keeps from file to file (no allocation, no
+// mapping per file: in a process with a hundred parser threads every mmap / munmap is a TLB shoot-down for all of them), its lines
+// parsed IN PLACE (the parser writes its terminators into the buffer).  Same line semantics as LineSource: a line ends at '\n', a last
+// line without one counts when it is not empty, a trailing '\r' is dropped from lines longer than one character.
+class WholeFile {
+public:
+	explicit WholeFile(const char *fn) {
+		if (fn == nullptr || std::strcmp(fn, "-") == 0) return;
+		const int fd = open(fn, O_RDONLY);
+		if (fd < 0) return;
+		unsigned char magic[2] = { 0, 0 };
+		struct stat sb;
+		if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || pread(fd, magic, 2, 0) < 0 || (magic[0] == 0x1f && magic[1] == 0x8b)) { close(fd); return; } // gzipped, a pipe, ...: LineSource
+		static thread_local std::vector<char> tl_buf;
+		const size_t n = (size_t)sb.st_size;
+		if (tl_buf.size() < n + 2) tl_buf.resize(n + n / 4 + 4096);
+		size_t got = 0;
+		while (got < n) { const ssize_t k = read(fd, tl_buf.data() + got, n - got); if (k <= 0) break; got += (size_t)k; }
+		close(fd);
+		p_ = tl_buf.data(), end_ = p_ + got, ok_ = true;
+	}
+	bool ok() const { return ok_; }
+	bool next(char *&line, size_t &len) { // the line is followed by a byte the caller may overwrite
+		if (p_ >= end_) return false;
+		char *nl = (char *)std::memchr(p_, '\n', (size_t)(end_ - p_));
+		char *e = nl ? nl : end_;
+		line = p_, len = (size_t)(e - p_);
+		p_ = e + 1;
+		if (len > 1 && line[len - 1] == '\r') --len;
+		return true;
+	}
+private:
+	char *p_ = nullptr, *end_ = nullptr;
+	bool ok_ = false;
+};
+
 // strtol(q, 0, 10) for the digit strings of a PAF line: optional blanks and sign, then digits (anything else ends the number)
 static inline int64_t parse_i64(const char *q)
 {
 	while (*q == ' ') ++q;
 	bool neg = false;
 	if (*q == '-') neg = true, ++q; else if (*q == '+') ++q;
-	int64_t v = 0;
-	while ((unsigned)(*q - '0') < 10u) v = v * 10 + (*q - '0'), ++q;
-	return neg ? -v : v;
+	uint64_t v = 0;
+	bool sat = false;
+	while ((unsigned)(*q - '0') < 10u) {
+		if (v > (uint64_t)INT64_MAX / 10) sat = true; // strtol saturates at LONG_MAX / LONG_MIN
+		v = v * 10 + (uint64_t)(*q - '0'), ++q;
+	}
+	if (sat || v > (uint64_t)INT64_MAX) return neg ? INT64_MIN : INT64_MAX;
+	return neg ? -(int64_t)v : (int64_t)v;
 }
 
 // grow helpers keeping the reference's malloc/realloc ownership (pg_data_destroy frees with free())
@@ -200,17 +244,37 @@ struct FileParse {
 	~FileParse() { std::free(hits); std::free(exons); std::free(label); }
 };
 
-template <class T> static inline void push_raw(T *&a, int32_t &n, int32_t &m, const T &v)
+template <class T> static inline bool push_raw(T *&a, int32_t &n, int32_t &m, const T &v)
 {
-	if (n == m) { m = m ? m + (m >> 1) : 4096; a = (T *)std::realloc((void *)a, sizeof(T) * (size_t)m); }
+	if (n == m || a == nullptr) {
+		const int32_t m2 = (m && a) ? m + (m >> 1) : 4096;
+		T *b = (T *)std::realloc((void *)a, sizeof(T) * (size_t)m2);
+		if (b == nullptr) return false; // out of memory: the element is dropped (the caller reports it)
+		a = b, m = m2;
+	}
 	a[n++] = v;
+	return true;
+}
+
+// big arrays a genome keeps: ask for huge pages where the kernel hands them out on request only (fewer page faults while the
+// parser threads fill them side by side)
+static inline void *big_malloc(size_t bytes)
+{
+	void *p = std::malloc(bytes);
+	if (p && bytes >= ((size_t)4 << 20)) {
+		const uintptr_t a = ((uintptr_t)p + 0x1fffff) & ~(uintptr_t)0x1fffff, e = ((uintptr_t)p + bytes) & ~(uintptr_t)0x1fffff;
+		if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+	}
+	return p;
 }
 
 static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileParse &fp)
 {
-	LineSource src(fn);
+	WholeFile whole(fn); // plain files: one read, lines parsed in place; everything else (gzip, stdin) through zlib
+	std::unique_ptr<LineSource> src;
+	if (!whole.ok()) src.reset(new LineSource(fn));
 	fp.ids_only = ids_only;
-	if (!src.ok()) return;
+	if (!whole.ok() && !src->ok()) return;
 	fp.opened = true;
 	fp.label = file_label(fn);
 	if (!ids_only && fn && std::strcmp(fn, "-") != 0) { // room for the whole file at once (~150 bytes of text a line; a .gz holds 4-5 times its size)
@@ -227,18 +291,23 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 	std::vector<pg_exon_t> ex;
 	std::string line, last_name;
 	int32_t last_pid = -1, last_gid = -1;
-	while (src.next(line)) {
+	bool oom = false;
+	for (;;) {
+		char *s;
+		size_t line_len;
+		if (whole.ok()) { if (!whole.next(s, line_len)) break; }
+		else { if (!src->next(line)) break; s = line.data(), line_len = line.size(); }
+		s[line_len] = 0; // (the byte behind a line is the parser's: the '\n' of the file buffer, the terminator of the string)
 		++fp.n_tot;
 		pg_hit_t hit;
 		std::memset(&hit, 0, sizeof(hit));
 		hit.pid = hit.pid_dom = hit.cid = hit.off_exon = hit.n_exon = -1;
 		int32_t pid = -1, gid = -1, n_fs = -1, n_stop = -1, cig_fs = 0;
 		bool have_exons = false;
-		char *s = line.data();
 		char *q = s;
 		int32_t col = 0;
 		bool dropped = false;
-		char *const line_end = s + line.size();
+		char *const line_end = s + line_len;
 		for (char *p = s;; ++p) {
 			p = (char *)std::memchr(p, '\t', (size_t)(line_end - p));
 			if (p == nullptr) p = line_end;
@@ -319,9 +388,10 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 		int32_t lof = (n_fs > 0 ? n_fs : 0) + (n_stop > 0 ? n_stop : 0); // read.c:230-231
 		if (hit.lof < lof) hit.lof = lof;
 		hit.cm = middle_cds(hit.cs, fp.exons + hit.off_exon, hit.n_exon);
-		if (hit.cm < 0) continue;
-		push_raw(fp.hits, fp.n_hit, fp.m_hit, hit);
+		if (hit.cm < 0 || oom) continue;
+		if (!push_raw(fp.hits, fp.n_hit, fp.m_hit, hit)) oom = true;
 	}
+	if (oom && pg_verbose >= 1) std::fprintf(stderr, "[E::%s] out of memory while reading '%s': hits were dropped\n", __func__, fn ? fn : "-");
 }
 
 // Names that are in the global dictionaries already get their ids before the commit, from a frozen SNAPSHOT of the dictionaries
@@ -415,6 +485,9 @@ static void finalize_genome(pg_data_t *d, FileParse &fp)
 	if (!fp.opened || fp.ids_only || fp.genome < 0) return;
 	pg_genome_t *g = &d->genome[fp.genome];
 	for (int32_t i = 0; i < fp.n_hit; ++i) fp.hits[i].pid = fp.pmap[(size_t)fp.hits[i].pid];
+	// (an estimate that was far too generous -- a .gz that compressed badly -- is given back: realloc in place, no copy)
+	if (fp.hits && (size_t)fp.m_hit > (size_t)fp.n_hit * 2 + 4096) { pg_hit_t *t = (pg_hit_t *)std::realloc((void *)fp.hits, sizeof(pg_hit_t) * (size_t)(fp.n_hit + 1)); if (t) fp.hits = t, fp.m_hit = fp.n_hit + 1; }
+	if (fp.exons && (size_t)fp.m_exon > (size_t)fp.n_exon * 2 + 4096) { pg_exon_t *t = (pg_exon_t *)std::realloc((void *)fp.exons, sizeof(pg_exon_t) * (size_t)(fp.n_exon + 1)); if (t) fp.exons = t, fp.m_exon = fp.n_exon + 1; }
 	g->n_hit = fp.n_hit, g->m_hit = fp.m_hit > 0 ? fp.m_hit : 1;
 	g->hit = fp.hits ? fp.hits : (pg_hit_t *)std::malloc(sizeof(pg_hit_t));
 	g->n_exon = fp.n_exon, g->m_exon = fp.m_exon > 0 ? fp.m_exon : 1;
@@ -515,7 +588,8 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 			if (k >= n || state[(size_t)k].load() != 1) break;
 			const double tc0 = timing ? now_sec() : 0.0;
 			if (commit_ids(d, fp[(size_t)k]) != 0) n_fail.fetch_add(1);
-			if (d->n_gene + d->n_prot >= snap_names + 1000 || (k == 0 && d->n_gene + d->n_prot > 0)) snap_refresh(d, snap), snap_names = d->n_gene + d->n_prot;
+			// (a rebuild copies every name: geometrically spaced, so that files that all bring new names do not make the commits quadratic)
+			if (d->n_gene + d->n_prot >= snap_names + std::max(1000, snap_names / 4) || (k == 0 && d->n_gene + d->n_prot > 0)) snap_refresh(d, snap), snap_names = d->n_gene + d->n_prot;
 			if (timing) us_commit.fetch_add((int64_t)((now_sec() - tc0) * 1e6));
 			state[(size_t)k].store(2);
 			n_commit.store(k + 1);

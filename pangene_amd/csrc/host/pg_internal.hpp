@@ -98,6 +98,8 @@ struct DataExt {
 	bool rerun = false;                // pg_rerun_resident(): keep the backend context, skip pack + upload
 	bool host_full = false;            // the last sync also fetched rank / score_dom / dominators
 	bool pos_valid = false;            // pos_x / y_order on the host match the backend's current orders
+	bool order_touched = false;        // an order override has been handed to the backend since the last sync (exact_sort)
+	uint64_t pos_sig = 0;              // order_signature() of the orders pos_x / y_file were fetched from
 	std::vector<uint64_t> flt_bits;    // bit (shard hit offset of the genome + host index) = flt, refreshed by every sync
 	std::vector<int32_t> pos_x;        // per local hit (file order): position inside its genome in cs order
 	std::vector<std::vector<int32_t>> file_of_host, host_of_file; // per genome whose records were moved into cs order (hits_sorted): host array index <-> file index
@@ -140,6 +142,7 @@ int exact_sort(DataExt *ext, int by_cm);
 void exact_shutdown(DataExt *ext);
 bool exact_quiet(DataExt *ext, int n);
 void exact_skip(DataExt *ext, int n);
+uint64_t order_signature(const DataExt *ext);
 
 // phase accounting of the host driver (seconds, accumulated over the last run)
 enum { PH_BEGIN, PH_EXACT, PH_INGEST, PH_POST, PH_VTX, PH_ARC_DEV, PH_ARC_HOST, PH_BRANCH_HOST, PH_NLOCAL, PH_MARK_HITS, PH_FLT, PH_SYNC_HOST, PH_COUNT };
