@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -228,7 +229,7 @@ static char *file_label(const char *fn) // read.c:92-105
 // One parsed PAF file, self-contained (no global ids yet): parsing is thread-safe and files can be parsed in
 // parallel; commit_file() then assigns the global ids sequentially in command-line order, which reproduces the
 // reference's first-seen numbering (read.c:151-168) -- pg_hash_uint32(pid) makes the numbering score-relevant.
-struct FileParse {
+struct alignas(128) FileParse { // (files next to each other on the command line are parsed side by side: no cache line shared between two of these)
 	bool opened = false, ids_only = false;
 	char *label = nullptr;
 	int32_t n_tot = 0;
@@ -282,8 +283,10 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 		if (stat(fn, &sb) == 0 && sb.st_size > 0) {
 			const size_t len = std::strlen(fn);
 			const size_t text = (size_t)sb.st_size * (len > 3 && std::strcmp(fn + len - 3, ".gz") == 0 ? 5 : 1);
-			fp.m_hit = (int32_t)std::min<size_t>(text / 120 + 64, (size_t)1 << 30), fp.hits = (pg_hit_t *)std::malloc(sizeof(pg_hit_t) * (size_t)fp.m_hit);
-			fp.m_exon = (int32_t)std::min<size_t>(text / 100 + 64, (size_t)1 << 30), fp.exons = (pg_exon_t *)std::malloc(sizeof(pg_exon_t) * (size_t)fp.m_exon);
+			fp.m_hit = (int32_t)std::min<size_t>(text / 120 + 64, (size_t)1 << 30), fp.hits = (pg_hit_t *)big_malloc(sizeof(pg_hit_t) * (size_t)fp.m_hit);
+			fp.m_exon = (int32_t)std::min<size_t>(text / 100 + 64, (size_t)1 << 30), fp.exons = (pg_exon_t *)big_malloc(sizeof(pg_exon_t) * (size_t)fp.m_exon);
+			if (fp.hits == nullptr) fp.m_hit = 0; // (no room for the estimate: grow on demand)
+			if (fp.exons == nullptr) fp.m_exon = 0;
 		}
 	}
 	const NameDict *excl = (const NameDict *)opt->excl, *incl = (const NameDict *)opt->incl, *pref = (const NameDict *)opt->preferred;
@@ -292,13 +295,17 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 	std::string line, last_name;
 	int32_t last_pid = -1, last_gid = -1;
 	bool oom = false;
+	// the growing arrays and their counters as locals while the file is parsed (written back once, at the end)
+	pg_hit_t *hits = fp.hits; int32_t n_hit = fp.n_hit, m_hit = fp.m_hit;
+	pg_exon_t *exons = fp.exons; int32_t n_exon = fp.n_exon, m_exon = fp.m_exon;
+	int32_t n_tot = 0;
 	for (;;) {
 		char *s;
 		size_t line_len;
 		if (whole.ok()) { if (!whole.next(s, line_len)) break; }
 		else { if (!src->next(line)) break; s = line.data(), line_len = line.size(); }
 		s[line_len] = 0; // (the byte behind a line is the parser's: the '\n' of the file buffer, the terminator of the string)
-		++fp.n_tot;
+		++n_tot;
 		pg_hit_t hit;
 		std::memset(&hit, 0, sizeof(hit));
 		hit.pid = hit.pid_dom = hit.cid = hit.off_exon = hit.n_exon = -1;
@@ -373,11 +380,11 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 				else if (std::strncmp(q, "st:i:", 5) == 0) n_stop = (int32_t)parse_i64(q + 5);
 				else if (std::strncmp(q, "cg:Z:", 5) == 0) {
 					if (cigar_to_exons(q + 5, hit.rev, hit.ce - hit.cs, ex, &cig_fs)) {
-						hit.n_exon = (int32_t)ex.size(), hit.off_exon = fp.n_exon, hit.lof = cig_fs;
-						for (const pg_exon_t &e : ex) push_raw(fp.exons, fp.n_exon, fp.m_exon, e);
+						hit.n_exon = (int32_t)ex.size(), hit.off_exon = n_exon, hit.lof = cig_fs;
+						for (const pg_exon_t &e : ex) if (!push_raw(exons, n_exon, m_exon, e)) oom = true;
 						have_exons = true;
 					} else if (pg_verbose >= 1) {
-						std::fprintf(stderr, "[W::%s] CIGAR of line %d in '%s' does not span the alignment; hit dropped\n", __func__, fp.n_tot, fn ? fn : "-");
+						std::fprintf(stderr, "[W::%s] CIGAR of line %d in '%s' does not span the alignment; hit dropped\n", __func__, n_tot, fn ? fn : "-");
 					}
 				}
 			}
@@ -387,10 +394,11 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 		if (dropped || !have_exons || hit.n_exon < 1) continue;
 		int32_t lof = (n_fs > 0 ? n_fs : 0) + (n_stop > 0 ? n_stop : 0); // read.c:230-231
 		if (hit.lof < lof) hit.lof = lof;
-		hit.cm = middle_cds(hit.cs, fp.exons + hit.off_exon, hit.n_exon);
+		hit.cm = middle_cds(hit.cs, exons + hit.off_exon, hit.n_exon);
 		if (hit.cm < 0 || oom) continue;
-		if (!push_raw(fp.hits, fp.n_hit, fp.m_hit, hit)) oom = true;
+		if (!push_raw(hits, n_hit, m_hit, hit)) oom = true;
 	}
+	fp.hits = hits, fp.n_hit = n_hit, fp.m_hit = m_hit, fp.exons = exons, fp.n_exon = n_exon, fp.m_exon = m_exon, fp.n_tot = n_tot;
 	if (oom && pg_verbose >= 1) std::fprintf(stderr, "[E::%s] out of memory while reading '%s': hits were dropped\n", __func__, fn ? fn : "-");
 }
 
@@ -628,8 +636,11 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 				continue;
 			}
 			if (next_final.load() >= n) break;
-			try_commit();
-			if (!try_final()) std::this_thread::yield();
+			// nothing left to parse: help with what is ready, else SLEEP -- a hundred threads spinning on yield() here slowed the one
+			// that commits (and everybody's page faults) several times over on a 256-thread host
+			const int32_t kc = n_commit.load();
+			if (kc < n && state[(size_t)kc].load() == 1) try_commit();
+			if (!try_final()) std::this_thread::sleep_for(std::chrono::microseconds(100));
 		}
 	};
 	std::vector<std::thread> th;

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """HBM-side bytes per launch of every kernel from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same command.
-rocprofv3 reports both in KB (1 unit = 1024 B); on gfx950 FETCH_SIZE tallies 64 B per 128-B request of a wide coalesced read, so
-it is doubled (MI355X_MICROARCH.md, HBM section; scattered 4-byte traffic is therefore over-estimated by up to 2x -- said so in the
-output).  A command launches each kernel on several data sizes (warm-up set, workload): only the dispatches within a factor 2 of
+rocprofv3 reports both in KB (1 unit = 1024 B); on gfx950 FETCH_SIZE tallies 64 B per request and a request is a 128-byte L2 line,
+so it is doubled.  Calibrated this round with kernels of known byte counts (profiles/r04_counter_calibration.txt): x 2.000 for coalesced
+reads of 4 and of 16 bytes per lane, x 1.000 for WRITE_SIZE of coalesced writes; a gather through a permutation makes one request
+per L2 miss whatever the item's width, so x 2 gives the FABRIC-side bytes of a gather kernel too -- which the 256 MiB Infinity Cache
+may serve: for kernels that gather (marked "gather" below) the figure is an upper bound of the HBM traffic.  A command launches each kernel on several data sizes (warm-up set, workload): only the dispatches within a factor 2 of
 the kernel's largest counter value are averaged (= the launches on the large shard).
 usage: pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <hits per launch> [min KB]"""
 import glob, os, sqlite3, sys
@@ -43,7 +45,9 @@ for name in sorted(set(f) | set(w)):
     if 2 * fk + wk < min_kb:
         continue
     rows.append((2 * fk + wk, name, fk, wk, nf, nw))
-print("# HBM-side traffic per launch on the large shard (%d hits): read = 2 x FETCH_SIZE KB (gfx950 correction), write = WRITE_SIZE KB" % hits)
+GATHER = ("k_zrec", "k_rep_fill", "k_n_local", "k_mark_hits_z", "k_gene_arcs", "OutHalfArcs", "k_to_file", "k_zpos_y", "k_pack_yrec", "rs_scatter", "k_vtx", "k_post_part", "k_genome_sort", "k_unblock")
+print("# L2 <-> fabric traffic per launch on the large shard (%d hits): read = 2 x FETCH_SIZE KB, write = WRITE_SIZE KB (factors calibrated: profiles/r04_counter_calibration.txt)" % hits)
+print("# 'gather': the kernel gathers / scatters through a permutation -- one 128-byte line per L2 miss, possibly served by the Infinity Cache: an UPPER bound of its HBM bytes")
 print("# %-80s %10s %10s %8s %8s %6s" % ("kernel", "read MB", "write MB", "rd B/hit", "wr B/hit", "n"))
 for tot, name, fk, wk, nf, nw in sorted(rows, reverse=True):
-    print("%-82s %10.1f %10.1f %8.1f %8.1f %3d/%-3d" % (name[:82], 2 * fk / 1024, wk / 1024, 2 * fk * 1024 / hits, wk * 1024 / hits, nf, nw))
+    print("%-82s %10.1f %10.1f %8.1f %8.1f %3d/%-3d %s" % (name[:82], 2 * fk / 1024, wk / 1024, 2 * fk * 1024 / hits, wk * 1024 / hits, nf, nw, "gather" if any(g in name for g in GATHER) else ""))
