@@ -221,6 +221,9 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 			}
 		}
 	}
+	// (Tried in round 4: the lanes' last runs combined per wave before they reach the table -- one set of atomics per (wave, key) instead
+	// of one per lane.  Slower: k_gene_arcs_big 273 -> 292 us at 12 M hits, configs[1] 5.58 -> 6.11 ms per pass.  The LDS serialises
+	// same-address atomics cheaply; five wave reductions per key cost more than they save.)
 #pragma unroll
 	for (int dir = 0; dir < 2; ++dir)
 		if (pk[dir] != 0xffffffffu && !ga_flush<CAP>(T, cap, cap_log2, pk[dir], png[dir], ptot[dir], psd[dir], ps1[dir], ps2[dir])) T.over = 1;

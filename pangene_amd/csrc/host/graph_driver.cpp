@@ -7,6 +7,7 @@
 // With an exchange hook installed (pg_set_exchange) the same code runs on every rank of a sharded run:
 // partial vectors are all-reduced / all-gathered in backend memory (RCCL) and every rank then takes
 // the identical host-side decisions, so no broadcast is needed.
+#include <sys/mman.h>
 #include <sys/time.h>
 #include <sys/resource.h>
 #include <algorithm>
@@ -250,7 +251,12 @@ static HostSlab slab_get(size_t min_bytes, bool allow_pin = true)
 	const pga_backend_t *be = backend_default();
 	void *q = nullptr;
 	if (allow_pin && be->host_alloc && be->host_alloc(s.cap, &q) == 0) s.pinned = true;
-	else q = std::malloc(s.cap), s.pinned = false; // beyond the budget of freshly page-locked memory (block_alloc), or no device at all
+	else { // beyond the budget of freshly page-locked memory (block_alloc), or no device (yet): plain pages -- huge ones where the kernel hands them out on request (64 MiB = 32 faults instead of 16 384 while the packer threads fill the slab)
+		void *m = nullptr;
+		if (posix_memalign(&m, (size_t)2 << 20, s.cap) == 0) { (void)madvise(m, s.cap, MADV_HUGEPAGE); q = m; }
+		else q = std::malloc(s.cap);
+		s.pinned = false;
+	}
 	s.p = (char *)q;
 	s.fresh = true;
 	return s;

@@ -259,12 +259,23 @@ template <class T> static inline bool push_raw(T *&a, int32_t &n, int32_t &m, co
 
 // big arrays a genome keeps: ask for huge pages where the kernel hands them out on request only (fewer page faults while the
 // parser threads fill them side by side)
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23 /* Linux 5.14 */
+#endif
 static inline void *big_malloc(size_t bytes)
 {
 	void *p = std::malloc(bytes);
-	if (p && bytes >= ((size_t)4 << 20)) {
+	if (p == nullptr) return nullptr;
+	if (bytes >= ((size_t)4 << 20)) {
 		const uintptr_t a = ((uintptr_t)p + 0x1fffff) & ~(uintptr_t)0x1fffff, e = ((uintptr_t)p + bytes) & ~(uintptr_t)0x1fffff;
 		if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+	}
+	// A hundred parser threads filling fresh arrays take page faults at the rate ONE address space sustains (measured: the summed parse
+	// time doubles from 64 to 128 threads, the wall time stays).  The whole array in one call instead of one trap per 4 KiB page
+	// (kernels before 5.14 answer EINVAL: nothing lost).
+	if (bytes >= ((size_t)128 << 10)) {
+		const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+		if (e > a) (void)madvise((void *)a, e - a, MADV_POPULATE_WRITE);
 	}
 	return p;
 }
