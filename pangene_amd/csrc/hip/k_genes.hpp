@@ -36,16 +36,27 @@ __global__ __launch_bounds__(BLOCK) void k_zkey(const int32_t *gid, int n, uint6
 //   zx[z] = X position; zy[z] = local genome << 1 | rev, bit 31 = the only hit of its gene in its genome (nearly all are: the
 //   group logic of the gene kernels has nothing to do for it); zg[z] = gene; zst[z] = {cm, contig segment} (static);  zpos[x] = z
 struct ZIndex { int32_t *zx, *zy, *zg; int2 *zst; int32_t *zpos; };
-__global__ __launch_bounds__(BLOCK) void k_zrec(const uint32_t *perm, const uint64_t *ks, const int32_t *gnm, const uint32_t *flags, const int32_t *cm, const int32_t *seg, int n, ZIndex o)
+__global__ __launch_bounds__(BLOCK) void k_zrec(const uint32_t *perm, const uint64_t *ks, const int32_t *ctg_base, int n_genome, const uint32_t *flags, const int32_t *cm, const int32_t *seg, int n, ZIndex o)
 {
-	int z = blockIdx.x * BLOCK + threadIdx.x;
-	if (z >= n) return;
-	const int x = (int)perm[z];
-	const int gn = gnm[x];
-	const bool grp_prev = z > 0 && ks[z - 1] == ks[z] && gnm[(int)perm[z - 1]] == gn, grp_next = z + 1 < n && ks[z + 1] == ks[z] && gnm[(int)perm[z + 1]] == gn;
-	o.zx[z] = x, o.zg[z] = (int)ks[z];
+	// Three gathers through the permutation per hit (flags, cm, seg: a 128-byte line each; round 3 made seven and moved 717 B/hit): the
+	// genome follows from the contig segment (a search in the small ctg_base table), and the neighbours' (gene, genome) -- "is this hit
+	// alone in its group?" -- come from the neighbouring LANES; only the wave's two border lanes fetch theirs.
+	const int z = blockIdx.x * BLOCK + threadIdx.x, lane = threadIdx.x & 63;
+	const bool v = z < n;
+	const int x = v ? (int)perm[z] : 0;
+	const int sg = v ? seg[x] : 0;
+	const int gn = v ? genome_of(ctg_base, n_genome, sg) : -1;
+	const unsigned long long kz = v ? ks[z] : ~0ull;
+	int gn_p = __shfl_up(gn, 1, WAVE), gn_n = __shfl_down(gn, 1, WAVE);
+	unsigned long long k_p = (unsigned long long)(unsigned)__shfl_up((int)(unsigned)(kz >> 32), 1, WAVE) << 32 | (unsigned)__shfl_up((int)(unsigned)kz, 1, WAVE);
+	unsigned long long k_n = (unsigned long long)(unsigned)__shfl_down((int)(unsigned)(kz >> 32), 1, WAVE) << 32 | (unsigned)__shfl_down((int)(unsigned)kz, 1, WAVE);
+	if (lane == 0) { const bool h = v && z > 0; k_p = h ? ks[z - 1] : ~0ull; gn_p = h ? genome_of(ctg_base, n_genome, seg[(int)perm[z - 1]]) : -1; }
+	if (lane == 63) { const bool h = v && z + 1 < n; k_n = h ? ks[z + 1] : ~0ull; gn_n = h ? genome_of(ctg_base, n_genome, seg[(int)perm[z + 1]]) : -1; }
+	if (!v) return;
+	const bool grp_prev = z > 0 && k_p == kz && gn_p == gn, grp_next = z + 1 < n && k_n == kz && gn_n == gn;
+	o.zx[z] = x, o.zg[z] = (int)kz;
 	o.zy[z] = gn << 1 | ((flags[x] & PGA_F_REV) ? 1 : 0) | ((grp_prev || grp_next) ? 0 : (int)0x80000000);
-	o.zst[z] = make_int2(cm[x], seg[x]);
+	o.zst[z] = make_int2(cm[x], sg);
 	o.zpos[x] = z;
 }
 

@@ -11,7 +11,10 @@ __global__ __launch_bounds__(BLOCK) void k_post_part(const uint32_t *flags, cons
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
 	int p = pid[h];
-	atomicMax(&max_ori[p], sori[h]);
+	// pg_cap_score_dom's table (hit.c:230-238).  A protein has thousands of hits in a shard and one maximum: look before asking the L2 for
+	// an atomic -- the value only grows, so a stale (smaller) reading costs a redundant atomic, never a missed one
+	const int so = sori[h];
+	if (max_ori[p] < so) atomicMax(&max_ori[p], so);
 	if (rank[h] == 0 && !(flags[h] & PGA_F_FLT)) {
 		int w = nex[h] == 1 ? 0 : 1;
 		atomicAdd(&sums[p], (unsigned long long)(long long)sadj[h]);

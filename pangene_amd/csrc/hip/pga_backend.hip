@@ -988,7 +988,7 @@ static int ensure_z(pga_ctx *c)
 	hipLaunchKernelGGL(k_zkey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gid, N, key, val);
 	uint64_t *ks; uint32_t *vs;
 	TRY(radix_sort_pool(c, key, val, N, bits_for((uint32_t)std::max(1, c->Q)), &ks, &vs));
-	hipLaunchKernelGGL(k_zrec, dim3(nblk(N)), dim3(BLOCK), 0, c->st, vs, ks, c->gnm, c->flags, c->cm, c->seg, N, ZIndex{c->zx, c->zy, c->zg, c->zst, c->zpos});
+	hipLaunchKernelGGL(k_zrec, dim3(nblk(N)), dim3(BLOCK), 0, c->st, vs, ks, c->ctg_base, c->n_genome, c->flags, c->cm, c->seg, N, ZIndex{c->zx, c->zy, c->zg, c->zst, c->zpos});
 	hipLaunchKernelGGL(k_zoff, dim3(nblk(c->Q + 1)), dim3(BLOCK), 0, c->st, ks, N, c->Q, c->zoff);
 	hipLaunchKernelGGL(k_zpos_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, c->zpos, N, c->zposy);
 	c->z_valid = true, c->ha_valid = false;
