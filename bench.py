@@ -27,7 +27,7 @@ A tiny data set is run first so that kernel code objects are loaded.
 Legs of the default run (N = 1 only; each brings its own data set and context, one context at a time):
   roofline / big_shard  K1 = the stage-A interval-dominance sweep, and all of stage A, on a shard past the 256 MiB Infinity
                         Cache (1250 x 5 k = the per-GPU shard of configs[3], ~12 M hits; SURVEY 8d asks for >= 10 M hits)
-  human_shard           the same on a human-shaped shard (multi-exon hits, fragmented contigs: the k_sweep<1, true> flavour)
+  human_shard           the same on a human-shaped shard (multi-exon hits, fragmented contigs: the k_sweep<3, true> flavour)
   exchange_overhead     the timed steps once more in a fresh process with every collective of the sharded route issued
                         (world size 1, native RCCL on the kernels' stream): what the exchange plumbing costs by itself
   cli                   `pangene_amd/bin/pangene files > /dev/null` in a fresh process (process start, HIP initialisation,
@@ -348,9 +348,11 @@ def main():
         tot_hits, t_cold_all = n_hits, t_cold + t_pack
         ranks_agree = None
 
-    # ---- roofline of K1 = the stage-A interval-dominance sweep pg_shadow(cal_dom_sc=1), read.c:248 / overlap.c:101-178.
+    # ---- roofline of K1 = the stage-A interval-dominance sweep: pg_shadow(cal_dom_sc=1), read.c:248 / overlap.c:101-178, which since round 4
+    # also does the reset behind it (read.c:249-253) and pg_flt_ov_isoform (overlap.c:58-93) in the same launch (k_sweep<3>).
     # Algorithmic bytes of THIS kernel: SURVEY 8(d) gives 56 + 8E B/hit for a pg_shadow sweep (reads cs ce cid pid gid score_adj rank
-    # flags n/off_exon + exons, writes flags pid_dom); the cal_dom_sc=1 flavour also reads score_ori and writes score_dom => 64 + 8E.
+    # flags n/off_exon + exons, writes flags pid_dom); the cal_dom_sc=1 flavour also reads score_ori and writes score_dom => 64 + 8E
+    # (kept for the fused kernel, which does strictly more: it also writes pid_dom0 and the isoform marks).
     # Stage A as a whole (SURVEY 8d "K1 = ingest stage A"): 72 + 8E B/hit, timed from the first kernel of pga_begin to the last of
     # pga_ingest (both orders + per-hit records, pg_flag_pseudo, both sweeps, isoform / chain / sub-optimal filters).
     def roofline_of(dd, hits, exons, note):
@@ -362,7 +364,7 @@ def main():
         bph = 64 + 8 * E
         avg_ms = ms / nl
         ach = bph * (units / nl) / (avg_ms * 1e-3) / 1e9
-        r = {"bound": "hbm", "kernel": "k_sweep<1, %s> (pg_shadow cal_dom_sc=1, stage A)" % ("true" if multi else "false"), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+        r = {"bound": "hbm", "kernel": "k_sweep<3, %s> (stage A's fused sweep: pg_shadow cal_dom_sc=1 + the reset of read.c:249-253 + pg_flt_ov_isoform)" % ("true" if multi else "false"), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(units // nl, "true" if multi else "false"), "avg_launch_ms": round(avg_ms, 4), "launches": nl,
              "timing": "per-dispatch HIP start/stop events (hipExtLaunchKernelGGL) on the library's stream",
              "algorithmic_bytes_per_hit": round(bph, 1), "hits_per_launch": units // nl, "shard": note}

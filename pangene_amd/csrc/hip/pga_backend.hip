@@ -1876,6 +1876,9 @@ extern "C" int pga_fetch(pga_ctx_t *c, void *dst_host, const void *src_backend, 
 extern "C" int pga_put(pga_ctx_t *c, void *dst_backend, const void *src_host, size_t nbytes)
 {
 	if (nbytes == 0) return 0;
+	// src_host is caller memory.  Small pieces (the votes, counts and sizes a sharded run puts in front of its collectives) go through
+	// the pinned staging area: the bytes are the library's when the call returns, the copy runs in stream order, nobody waits
+	if (nbytes <= ((size_t)64 << 10)) return stage_upload(c, dst_backend, src_host, nbytes);
 	HIPCHK(hipMemcpyAsync(dst_backend, src_host, nbytes, hipMemcpyHostToDevice, c->st));
 	return sync_st(c);
 }

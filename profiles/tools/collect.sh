@@ -4,10 +4,13 @@
 #   stage stats   rocprofv3 --kernel-trace --stats of the bench workload, the 12 M-hit shard and the sharded route (forced exchange)
 #   stage pmc     FETCH_SIZE / WRITE_SIZE passes: K1 per shard size and flavour (k1_pmc_traffic.json), every kernel of the 12 M-hit shard
 #   stage extra   configs[2] stand-in, fresh-seed HIP-vs-oracle sweep, two ranks sharing the GPU over gloo
+#   stage human   rocprofv3 --kernel-trace --stats with the human-shaped leg left in
+#   stage cal     calibration of FETCH_SIZE / WRITE_SIZE with kernels of known byte counts (profiles/tools/calibrate.py)
+#   stage full    BASELINE configs[3] / configs[4] at their full stated size on this one GPU (bench.py --workload config3 | config4)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 tag=${1:-rXX}; shift; out=gpurun_out; mkdir -p $out
-Q="--no-cpu-baseline --roofline-genomes 0 --human-genomes 0 --no-extra-legs"
+Q="--no-cpu-baseline --roofline-genomes 0 --human-genomes 0 --no-extra-legs --cold-sets 0"
 for stage in "$@"; do case $stage in
 tests)
 	t0=$(date +%s)
@@ -24,7 +27,7 @@ stats)
 	python profiles/tools/kernel_stats.py $out/prof_x > $out/${tag}_kernel_stats_forced_exchange.txt; rm -rf $out/prof_x
 	head -n 14 $out/${tag}_kernel_stats_bench_default.txt; tail -n 3 $out/${tag}_kernel_stats_bench_default.txt; head -n 12 $out/${tag}_kernel_stats_big_shard_1250x5k.txt; tail -n 3 $out/${tag}_kernel_stats_forced_exchange.txt;;
 pmc1|pmc)
-	B="python bench.py --no-cpu-baseline --no-extra-legs --steps 1 --warmup 0"
+	B="python bench.py --no-cpu-baseline --no-extra-legs --cold-sets 0 --steps 1 --warmup 0"
 	rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/prof_fetch -o f -- $B > /dev/null 2>&1
 	rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/prof_write -o w -- $B > /dev/null 2>&1
 	J=$out/${tag}_bench_default.json; [ -f $J ] || J=profiles/${tag}_bench_default.json  # (a fresh box only has what the repository holds)
@@ -42,4 +45,25 @@ extra)
 	( echo "# python tests/fuzz_hip_vs_oracle.py 7600 ${FUZZ_SEEDS:-16}  (HIP vs oracle backend on fresh seeds: fuzz / bacterial / human-shaped / mutated sets, both tie-order modes, 12 option variants)"; timeout 900 python tests/fuzz_hip_vs_oracle.py 7600 ${FUZZ_SEEDS:-16} 2>&1 | grep -v "^\[" | tail -n 5 ) > $out/${tag}_fuzz_sweep.txt
 	PANGENE_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 2 --no-cpu-baseline --roofline-genomes 0 --human-genomes 0 --no-extra-legs 2>/dev/null | tail -n 1 > $out/${tag}_bench_two_ranks_one_gpu_gloo.json
 	cut -c1-300 $out/${tag}_bench_human47.json; cat $out/${tag}_fuzz_sweep.txt; cut -c1-400 $out/${tag}_bench_two_ranks_one_gpu_gloo.json;;
+human)
+	rocprofv3 --kernel-trace --stats -d $out/prof_h -o s -- python bench.py --no-cpu-baseline --roofline-genomes 0 --no-extra-legs --cold-sets 0 --steps 2 --warmup 1 > $out/${tag}_bench_human_shard_under_rocprof.json 2>/dev/null
+	python profiles/tools/kernel_stats.py $out/prof_h > $out/${tag}_kernel_stats_human_shard_500x20k.txt; rm -rf $out/prof_h
+	head -n 16 $out/${tag}_kernel_stats_human_shard_500x20k.txt;;
+cal)
+	N=33554432
+	for w in 16384 0; do
+		rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/cal_f -o f -- python profiles/tools/calibrate.py run $N $w > /dev/null 2>&1
+		rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/cal_w -o w -- python profiles/tools/calibrate.py run $N $w > /dev/null 2>&1
+		( echo "# pga_selftest_traffic($N items, window $w)"; python profiles/tools/calibrate.py table $out/cal_f $out/cal_w $N | head -n 10 ) > $out/${tag}_calibration_window_$w.txt
+		rm -rf $out/cal_f $out/cal_w; cat $out/${tag}_calibration_window_$w.txt
+	done;;
+full)
+	for wl in ${FULL_WORKLOADS:-config4 config3}; do
+		PANGENE_TIMING=1 timeout 1500 python bench.py --workload $wl --steps 3 --warmup 1 > $out/${tag}_bench_${wl}_full_size.json 2> $out/${tag}_bench_${wl}_full_size.stderr
+		python - <<PY
+import json
+b = json.loads([l for l in open("$out/${tag}_bench_${wl}_full_size.json") if l.startswith("{")][-1])
+print("$wl", json.dumps(b.get("full_size"))[:1500])
+PY
+	done;;
 esac; done

@@ -11,12 +11,12 @@ print("# %-88s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "a
 for r in rows:
     print("%-90s %7d %12.1f %10.2f %10.2f %10.2f %6.2f" % (r[0][:90], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot))
 
-# K1 (k_sweep<1, *>) on the shard itself: the run starts with a tiny warm-up data set (kernel loading), whose launch is left out
+# K1 (k_sweep<3, *>: stage A's fused sweep) on the shard itself: the run starts with a tiny warm-up data set (kernel loading), whose launch is left out
 try:
-    k1 = [r[0] for r in cur.execute("SELECT duration FROM kernels WHERE name LIKE '%k_sweep<1,%'").fetchall()]
+    k1 = [r[0] for r in cur.execute("SELECT duration FROM kernels WHERE name LIKE '%k_sweep<3,%'").fetchall()]
     if k1:
         full = [d for d in k1 if d > 0.6 * max(k1)]
-        print("# K1 k_sweep<1, *>: %d launches on the shard (of %d), mean %.2f us" % (len(full), len(k1), sum(full) / len(full) / 1e3))
+        print("# K1 k_sweep<3, *>: %d launches on the shard (of %d), mean %.2f us" % (len(full), len(k1), sum(full) / len(full) / 1e3))
 except Exception as ex:
     print("# (no K1 line: %s)" % ex)
 
