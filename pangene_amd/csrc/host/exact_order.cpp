@@ -50,7 +50,9 @@ void set_exact_mode(int m) { g_exact_mode = m; }
 //        group with two hits of different genes (or, under -S, of different strands).
 //   H3   first-wins ties: the dominator arg-max (overlap.c:150,153: equal 64-bit scores = one protein, one score_adj) and
 //        pg_flt_subopt_isoform (hit.c:116: equal score_adj of two proteins of one gene); array order only decides between hits
-//        of one (contig, cs) tie group.  Superset: two hits with one (contig, cs, gene, score_adj).
+//        of one (contig, cs) tie group.  Superset: two hits with one (contig, cs, score_adj) that are one protein, or -- under -S
+//        only -- two proteins of one gene on opposite strands (same-strand isoforms sharing their start share a CDS base: one of
+//        them is filtered by pg_flt_ov_isoform before hit.c:116 runs).
 // Such contigs follow the reference's exact order from stage A on (ExactSeg::full), so a run needs ONE attempt where the
 // round-3 design ran stages A-C, collected the hazard events and ran them again.  The dynamic detection on the backend stays:
 // it covers H2b (the local_count boundary, not predictable from the keys) and anything this prediction would miss; an event
@@ -132,6 +134,12 @@ static void static_tie_contigs(const pg_data_t *d, const pg_genome_t *g, bool ch
 				// H3: first-wins ties between two hits of one (contig, cs) group -- equal 64-bit scores (one protein, one score_adj: the
 				// dominator arg-max, overlap.c:150,153) or equal score_adj of two proteins of one gene (hit.c:116)
 				if (b->cs != a->cs || b->score_adj != a->score_adj || d->prot[b->pid].gid != ga) continue;
+				// one protein twice (duplicate alignments): both can be the dominator of a third hit in stage A's pg_shadow, which runs
+				// before anything filters one of them.  Two proteins of the gene: they share their first CDS base, so pg_flt_ov_isoform
+				// (read.c:254) has filtered one before pg_flt_subopt_isoform (read.c:256) looks -- unless -S keeps pairs of opposite
+				// strands apart (overlap.c:77).  (Isoform-rich sets are full of such pairs: marking them all made every pass of the
+				// 200 x 110 k-isoform set replay thousands of contigs, 2.8 s of host time.)
+				if (b->pid != a->pid && !(check_strand && b->rev != a->rev)) continue;
 				marked[(size_t)a->cid] = 1;
 				if (dbg) std::fprintf(stderr, "[static] cs tie: contig %d cs %ld gene %d: proteins %d and %d, score_adj %d\n", a->cid, (long)a->cs, ga, a->pid, b->pid, a->score_adj);
 				break;
