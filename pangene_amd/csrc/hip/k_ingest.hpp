@@ -145,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void k_pseudo2(const int32_t *gnm, const int
 	if (!(mx > 1 && (mn == 1 || mn * 2 <= mx))) return; // hit.c:84
 	if (ne == 1 || ne * 2 <= mx) {
 		flags[h] |= PGA_F_PSEUDO | PGA_F_FLT; // hit.c:89 + PG_SET_FILTER(pseudo), read.c:246
-		atomicAdd(&stats[gnm[h] * 4 + 0], 1);
+		if (stats) atomicAdd(&stats[gnm[h] * 4 + 0], 1);
 	} else atomicMin(&tr1[t], rank[h]);
 }
 
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int3
 	uint32_t nf = f & ~PGA_F_SHADOW;
 	if (f & PGA_F_ISO_OV) {
 		nf |= PGA_F_FLT;
-		atomicAdd(&stats[gnm[h] * 4 + 1], 1);
+		if (stats) atomicAdd(&stats[gnm[h] * 4 + 1], 1);
 	} else {
 		noiso[(int64_t)gnm[h] * P + pid[h]] = 1; // (plain byte stores of the same value: no atomics needed)
 	}
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(uint32_t *flags, const int32_t 
 	if (p0 < 0) return;
 	if (!noiso[(int64_t)gnm[h] * P + p0]) {
 		flags[h] |= PGA_F_FLT | PGA_F_CHAIN;
-		atomicAdd(&stats[gnm[h] * 4 + 2], 1);
+		if (stats) atomicAdd(&stats[gnm[h] * 4 + 2], 1);
 	}
 }
 
@@ -380,6 +380,6 @@ __global__ __launch_bounds__(BLOCK) void k_subopt2(uint32_t *flags, const int32_
 	}
 	if (pid[h] != best_pid) {
 		flags[h] = f | PGA_F_FLT | PGA_F_ISO_SUB;
-		atomicAdd(&stats[g * 4 + 3], 1);
+		if (stats) atomicAdd(&stats[g * 4 + 3], 1);
 	}
 }

@@ -224,6 +224,7 @@ struct pga_ctx {
 	int32_t *zx = 0, *zy = 0, *zg = 0; int2 *zst = 0; int32_t *zpos = 0, *zposy = 0, *zoff = 0; // gene-major planes (k_genes.hpp)
 	uint32_t *hfk = 0, *hbk = 0; int4 *hfp = 0, *hbp = 0; // half-arc key words and payloads
 	bool z_valid = false, ha_valid = false; uint32_t round_tag = 0; int ha_ori = -1;
+	bool zposy_stale = false; // the gene-major index stands but the cm order (or the X numbering) changed: zposy has to be derived again (ensure_z)
 	const pga_arc_part_t *cur_tab = nullptr; int64_t cur_tab_n = 0; // the table of pga_arc_set_current
 	bool table_sparse = false; // the current arc table lives in the genes' stretches (arc_round_genes) and has not been compacted
 	int32_t *h_round = nullptr; size_t h_round_cap = 0; // pinned: segment counters + degrees of a round
@@ -646,7 +647,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 // per-hit constants in file order, X order (sort + gather), running max of ce, Y order; resets all state
 extern "C" int pga_begin(pga_ctx_t *c)
 {
-	c->yrec_valid = false, c->z_valid = false;
+	c->yrec_valid = false, c->z_valid = false, c->zposy_stale = false;
 	const int N = c->N, GL = c->n_genome;
 	c->walk_valid = false, c->ha_valid = false;
 	if (c->x_arcs_run > 0) c->x_arcs_seen = c->x_arcs_run; // sharded rounds: what the run that just ended needed is what this one's exchange buffers hold
@@ -758,6 +759,9 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 	int32_t *d_stats = (int32_t *)c->pool.get(S_STATS, sizeof(int32_t) * 4 * (size_t)GL + 16);
 	if (!d_stats) return PGA_ERR_NOMEM;
 	HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(int32_t) * 4 * (size_t)GL + 16, c->st));
+	// the per-genome counts only feed a log line: the four-kernel form of the filters counts with one global atomic per filtered hit
+	// (17 M of them onto 200 addresses on the full-size configs[4] set: 33 ms), so they are only kept when somebody asked for them
+	int32_t *k_stats = stats ? d_stats : nullptr;
 	if (N) {
 		const int64_t TP = (int64_t)GL * P, TQ = (int64_t)GL * Q;
 		if (c->any_multi) { // pg_flag_pseudo (hit.c:66-105) only ever marks a protein that has a multi-exon hit (max_n > 1, hit.c:84)
@@ -769,7 +773,7 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 			hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tmin, TP, INT32_MAX);
 			hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tr1, TP, INT32_MAX);
 			hipLaunchKernelGGL(k_pseudo1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, N, P, tmax, tmin);
-			hipLaunchKernelGGL(k_pseudo2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, c->rank, c->flags, N, P, tmax, tmin, tr1, d_stats);
+			hipLaunchKernelGGL(k_pseudo2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, c->rank, c->flags, N, P, tmax, tmin, tr1, k_stats);
 			hipLaunchKernelGGL(k_pseudo3, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->rank, N, P, tmax, tmin, tr1);
 			hipLaunchKernelGGL(k_pack_rank, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->rank, N, c->recC); // rank changed
 		}
@@ -791,11 +795,11 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 			hipLaunchKernelGGL(k_genome_filters, dim3((unsigned)GL), dim3(GF_T), gf_lds_bytes(P, Q), c->st, gf);
 		} else {
 		HIPCHK(hipMemsetAsync(noiso, 0, (size_t)TP, c->st));
-		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, c->pdom, c->pdom0, N, P, noiso, d_stats, fused);
-		hipLaunchKernelGGL(k_chain, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pdom0, N, P, noiso, d_stats);
+		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, c->pdom, c->pdom0, N, P, noiso, k_stats, fused);
+		hipLaunchKernelGGL(k_chain, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pdom0, N, P, noiso, k_stats);
 		HIPCHK(hipMemsetAsync(tbest, 0, sizeof(uint64_t) * (size_t)TQ, c->st));
 		hipLaunchKernelGGL(k_subopt1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->sadj, c->goff, N, Q, tbest);
-		hipLaunchKernelGGL(k_subopt2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->pid, c->goff, N, Q, tbest, d_stats, c->rank, c->sadj, c->recA, c->dcnt,
+		hipLaunchKernelGGL(k_subopt2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->pid, c->goff, N, Q, tbest, k_stats, c->rank, c->sadj, c->recA, c->dcnt,
 		                   (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP));
 		}
 	}
@@ -980,7 +984,11 @@ static int walk_prev(pga_ctx *c, int32_t **val_out, int32_t **prev_out)
 // gene-major index: hits sorted by (gene, X position) -- X order is genome-major, so a gene's hits are grouped by genome
 static int ensure_z(pga_ctx *c)
 {
-	if (c->z_valid || c->N == 0) return 0;
+	if (c->N == 0) return 0;
+	if (c->z_valid) {
+		if (c->zposy_stale) { hipLaunchKernelGGL(k_zpos_y, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->yperm, c->zpos, c->N, c->zposy); c->zposy_stale = false; c->ha_valid = false; }
+		return 0;
+	}
 	const int N = c->N;
 	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, 0);
 	uint32_t *val = (uint32_t *)c->pool.get(S_VAL_A, 0);
@@ -991,7 +999,7 @@ static int ensure_z(pga_ctx *c)
 	hipLaunchKernelGGL(k_zrec, dim3(nblk(N)), dim3(BLOCK), 0, c->st, vs, ks, c->ctg_base, c->n_genome, c->flags, c->cm, c->seg, N, ZIndex{c->zx, c->zy, c->zg, c->zst, c->zpos});
 	hipLaunchKernelGGL(k_zoff, dim3(nblk(c->Q + 1)), dim3(BLOCK), 0, c->st, ks, N, c->Q, c->zoff);
 	hipLaunchKernelGGL(k_zpos_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, c->zpos, N, c->zposy);
-	c->z_valid = true, c->ha_valid = false;
+	c->z_valid = true, c->ha_valid = false, c->zposy_stale = false;
 	return 0;
 }
 
@@ -1780,7 +1788,15 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
                                   const int64_t *seg_off, const int32_t *file_idx)
 {
 	const int N = c->N;
-	c->walk_valid = false, c->ha_valid = false, c->yrec_valid = false, c->z_valid = false;
+	// The gene-major index (hits by (gene, genome, X position), k_genes.hpp) survives an override: a cm override leaves it alone (only
+	// zposy, the index by cm position, is derived again); a cs override moves hits inside (contig, cs) tie groups, so the X positions the
+	// index stores are renumbered and the ORDER of two hits of one (gene, genome) that share their start may go stale -- which nothing
+	// can see unless both are walkable, i.e. on opposite strands under -S (one gene's overlapping hits are filtered down to one
+	// otherwise): with -S the index is rebuilt.  (The full-size configs[4] run rebuilt it -- a sort and seven gathers over 22 M hits --
+	// 49 times per pass.)
+	const bool z_keep = c->z_valid && (which == 1 || !c->par.check_strand);
+	c->walk_valid = false, c->ha_valid = false, c->yrec_valid = false;
+	if (!z_keep) c->z_valid = false;
 	if (n_seg <= 0 || N == 0) return 0;
 	const int64_t T = seg_off[n_seg];
 	if (T == 0) return 0;
@@ -1797,6 +1813,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	hipLaunchKernelGGL(k_ov_inv, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, inv, remap);
 	if (which == 1) {
 		hipLaunchKernelGGL(k_ov_sety, dim3(nblk(T)), dim3(BLOCK), 0, c->st, d_pos, d_fil, T, inv, c->yperm);
+		if (z_keep) c->zposy_stale = true;
 		return sync_st(c);
 	}
 	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * (OV_PLANES + 12) * (size_t)T + 64);
@@ -1806,6 +1823,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	hipLaunchKernelGGL(k_ov_gather, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, inv, tmp, remap);
 	hipLaunchKernelGGL(k_ov_scatter, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, T, tmp, c->gnm, c->goff);
 	hipLaunchKernelGGL(k_ov_remap_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, N, remap);
+	if (z_keep) { hipLaunchKernelGGL(k_z_remap, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->zx, c->zpos, N, (const int32_t *)remap); c->zposy_stale = true; }
 	SegMax *tile = (SegMax *)c->pool.get(S_TILE, tile_buf_bytes(N));
 	device_scan<SegMax>(InSegMaxA{c->recA}, OutSegMaxA{c->recA}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st); // pm follows the new order
 	hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv);
