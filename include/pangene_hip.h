@@ -72,15 +72,26 @@ typedef struct {
 	int32_t any_neg_score_adj, any_multi_exon;
 	const int32_t *data;
 	size_t n_words;                          /* 10 * n_hit + (n_hit + 3) / 4 + 2 * n_exon */
+	/* 64-bit contig coordinates (pangene.h:71: int64_t cs, cm, ce) through a 32-bit device layout: VIRTUAL CONTIGS.  A contig whose
+	 * coordinates do not fit 31 bits is cut by the packer at hit-free gaps into pieces of < 2^30 bp plus one cluster of overlapping hits; the
+	 * block then counts the pieces as contigs (n_ctg, the contig plane) and stores cs / ce / cm relative to the piece's base.  No hit
+	 * spans a cut, so every overlap test, sort and filter works on the pieces unchanged; the steps that look ACROSS hits of one contig
+	 * -- the walk of pg_gen_arc (graph.c:113-121: same-contig test, dist = cm - vpos, which the reference itself truncates to int32_t,
+	 * graph.c:73) and pg_gen_rep_pos / pg_n_local (branch.c:6-46: same contig, 64-bit |cm1 - cm2|) -- put the pieces together again
+	 * with these two tables.  vfirst[v] = the first piece of the contig piece v belongs to (the contig's identity; v itself for a contig
+	 * that was not cut); vbase[v] = what was subtracted from the coordinates of piece v.  Both NULL: no contig of the genome was cut. */
+	const int32_t *vfirst;                   /* [n_ctg] or NULL */
+	const int64_t *vbase;                    /* [n_ctg] or NULL */
 } pga_genome_block_t;
 
 /* One shard = a set of genomes with all their hits (pg_hit_t pangene.h:61-72, pg_exon_t 44-46, pg_genome_t 79-87).
  * Every hit is checked on the device against what its block declares (contig id < n_ctg, 0 <= cs <= ce, cs <= max_cs, cm <= max_cm,
  * score_adj <= max_score_adj or any_neg_score_adj, exon range inside the block's exon list, n_exon > 1 only with any_multi_exon):
  * pga_create answers PGA_ERR_RANGE for a block that breaks its own declaration instead of indexing out of bounds later.
- * Device layout limits (PGA_ERR_RANGE otherwise): contig coordinates < 2^31 (pangene.h:71 has int64), < 2^30 hits and < 2^31
+ * Device layout limits (PGA_ERR_RANGE otherwise): coordinates inside a block < 2^31 (contigs beyond that arrive as virtual contigs,
+ * see pga_genome_block_t; what remains out of reach is a single cluster of overlapping hits spanning 2^30 bp), < 2^30 hits and < 2^31
  * exons per shard, < 2^20 genes, < 2^24 genomes. */
-#define PGA_ABI_VERSION 4u  /* bumped whenever a struct of this header or the order of pga_backend_t changes; pga_create refuses another */
+#define PGA_ABI_VERSION 5u  /* bumped whenever a struct of this header or the order of pga_backend_t changes; pga_create refuses another */
 typedef struct {
 	uint32_t abi_version;        /* = PGA_ABI_VERSION of the header the caller was compiled against (PGA_ERR_ARG otherwise) */
 	int32_t n_genome;            /* genomes in this shard (may include genomes with 0 hits) */

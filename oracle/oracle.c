@@ -31,7 +31,8 @@ struct pga_ctx {
 	int32_t *genome_global, *n_ctg;
 	/* per hit, X order (genome-major) */
 	int32_t *fidx;            /* file index inside the genome */
-	int32_t *pid, *gid, *cid, *rank, *score_ori, *score_adj, *score_dom, *n_exon_of, *off_exon, *cs, *ce, *cm, *cds;
+	int32_t *pid, *gid, *cid, *rank, *score_ori, *score_adj, *score_dom, *n_exon_of, *off_exon, *cds;
+	int64_t *cs, *ce, *cm;  /* pangene.h:71 has int64_t; a block with virtual contigs (pga_genome_block_t) is put together again at load time */
 	int32_t *pid_dom, *pid_dom0;
 	uint32_t *flags;
 	int32_t *yo;              /* Y order: yo[off[j]+k] = X position (global) of the k-th hit in cm order */
@@ -47,7 +48,7 @@ struct pga_ctx {
 	int32_t *g2s; int32_t n_seg;
 	int32_t *seg_cnt; pga_arc_part_t *arcs; int64_t n_arcs, m_arcs;
 	/* rep_pos: per local genome, per gene */
-	int64_t *rp_x; int32_t *rp_y;  /* rp_x = cid<<32|r or -1 */
+	int64_t *rp_x; int64_t *rp_y;  /* rp_x = cid<<32|r or -1 */
 	int32_t *rp_iv;           /* H2b: (#walkable hits of the representative's (contig, cs) tie group before it) << 16 | (#after it) */
 	int32_t *nl_cnt;
 	pga_hazard_t hz;
@@ -58,7 +59,7 @@ struct pga_ctx {
 	int32_t *def_sc, *def_deg; /* results of a deferred arc_round_local */
 	int64_t *head;            /* [n_genome] X position of the hit that plays "index 0" (never reset by pg_shadow) */
 	/* raw shard, file order (kept so that begin() can restart the run) */
-	int32_t *r_pid, *r_cid, *r_rank, *r_sori, *r_sadj, *r_nex, *r_offx, *r_cs, *r_ce, *r_cm; uint8_t *r_rev;
+	int32_t *r_pid, *r_cid, *r_rank, *r_sori, *r_sadj, *r_nex, *r_offx; int64_t *r_cs, *r_ce, *r_cm; uint8_t *r_rev;
 };
 
 int pgo_is_device(void) { return 0; }
@@ -167,7 +168,7 @@ int pgo_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
 	c->exon_os = MALLOC(int32_t, sh->n_exon); c->exon_oe = MALLOC(int32_t, sh->n_exon);
 	DUP(int32_t, c->prot_gid, sh->prot_gid, sh->n_prot); DUP(uint8_t, c->gene_pref, sh->gene_pref, sh->n_gene);
 	c->r_pid = MALLOC(int32_t, N); c->r_cid = MALLOC(int32_t, N); c->r_rank = MALLOC(int32_t, N); c->r_sori = MALLOC(int32_t, N); c->r_sadj = MALLOC(int32_t, N);
-	c->r_nex = MALLOC(int32_t, N); c->r_offx = MALLOC(int32_t, N); c->r_cs = MALLOC(int32_t, N); c->r_ce = MALLOC(int32_t, N); c->r_cm = MALLOC(int32_t, N);
+	c->r_nex = MALLOC(int32_t, N); c->r_offx = MALLOC(int32_t, N); c->r_cs = MALLOC(int64_t, N); c->r_ce = MALLOC(int64_t, N); c->r_cm = MALLOC(int64_t, N);
 	c->r_rev = MALLOC(uint8_t, N);
 	{ /* unpack the per-genome blocks (pga_genome_block_t) into flat file-order arrays; exon offsets become shard-wide */
 		int32_t g; int64_t hb = 0, eb = 0;
@@ -180,6 +181,10 @@ int pgo_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
 				c->r_pid[hb + i] = w[i], c->r_cid[hb + i] = w[n + i], c->r_rank[hb + i] = w[2 * n + i], c->r_sori[hb + i] = w[3 * n + i];
 				c->r_sadj[hb + i] = w[4 * n + i], c->r_nex[hb + i] = w[5 * n + i], c->r_offx[hb + i] = (int32_t)(eb + w[6 * n + i]);
 				c->r_cs[hb + i] = w[7 * n + i], c->r_ce[hb + i] = w[8 * n + i], c->r_cm[hb + i] = w[9 * n + i], c->r_rev[hb + i] = rev[i];
+				if (b->vfirst && b->vbase && w[n + i] >= 0 && w[n + i] < b->n_ctg) { /* a piece of a virtual contig: back to the contig and its own coordinates */
+					const int64_t base = b->vbase[w[n + i]];
+					c->r_cid[hb + i] = b->vfirst[w[n + i]], c->r_cs[hb + i] += base, c->r_ce[hb + i] += base, c->r_cm[hb + i] += base;
+				}
 			}
 			for (i = 0; i < b->n_exon; ++i) c->exon_os[eb + i] = ex[2 * i], c->exon_oe[eb + i] = ex[2 * i + 1];
 			c->off[g] = hb, c->n_ctg[g] = b->n_ctg;
@@ -191,7 +196,7 @@ int pgo_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_params_t *par)
 	c->fidx = MALLOC(int32_t, N); c->pid = MALLOC(int32_t, N); c->gid = MALLOC(int32_t, N); c->cid = MALLOC(int32_t, N);
 	c->rank = MALLOC(int32_t, N); c->score_ori = MALLOC(int32_t, N); c->score_adj = MALLOC(int32_t, N);
 	c->score_dom = CALLOC(int32_t, N); c->n_exon_of = MALLOC(int32_t, N); c->off_exon = MALLOC(int32_t, N);
-	c->cs = MALLOC(int32_t, N); c->ce = MALLOC(int32_t, N); c->cm = MALLOC(int32_t, N); c->cds = MALLOC(int32_t, N);
+	c->cs = MALLOC(int64_t, N); c->ce = MALLOC(int64_t, N); c->cm = MALLOC(int64_t, N); c->cds = MALLOC(int32_t, N);
 	c->pid_dom = MALLOC(int32_t, N); c->pid_dom0 = CALLOC(int32_t, N); c->flags = CALLOC(uint32_t, N);
 	c->yo = MALLOC(int32_t, N);
 	c->head = MALLOC(int64_t, sh->n_genome);
@@ -601,7 +606,7 @@ int pgo_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_
 	cnt = MALLOC(int32_t, S);
 	for (j = 0; j < c->n_genome; ++j) {
 		uint32_t w, v = (uint32_t)-1;
-		int32_t vpos = -1, vcid = -1, si = -1;
+		int64_t vpos = -1; int32_t vcid = -1, si = -1;
 		shadow_genome(c, j, 0, 0); /* graph.c:102 */
 		n1 = 0;
 		memset(cnt, 0, S * sizeof(int32_t));
@@ -618,8 +623,8 @@ int pgo_arc_round(pga_ctx_t *c, int32_t use_ori, int32_t **seg_cnt_out, pga_arc_
 			if (v != (uint32_t)-1) {
 				if (c->cm[a] == vpos) { c->hz.h2_cm_tie++; hz_note(c, j, c->cid[a]); } /* hazard H2a: the order of the two decides the arc */
 				if (n1 + 2 > m1) { m1 = m1 ? m1 * 2 : 1024; arc1 = (tmparc_t*)realloc(arc1, m1 * sizeof(tmparc_t)); }
-				arc1[n1].x = (uint64_t)v << 32 | w, arc1[n1].dist = c->cm[a] - vpos, arc1[n1].s1 = si, arc1[n1].s2 = sc, arc1[n1].n = 0, ++n1;
-				arc1[n1].x = (uint64_t)(w^1) << 32 | (v^1), arc1[n1].dist = c->cm[a] - vpos, arc1[n1].s1 = sc, arc1[n1].s2 = si, arc1[n1].n = 0, ++n1;
+				arc1[n1].x = (uint64_t)v << 32 | w, arc1[n1].dist = (int32_t)(c->cm[a] - vpos), arc1[n1].s1 = si, arc1[n1].s2 = sc, arc1[n1].n = 0, ++n1;
+				arc1[n1].x = (uint64_t)(w^1) << 32 | (v^1), arc1[n1].dist = (int32_t)(c->cm[a] - vpos), arc1[n1].s1 = sc, arc1[n1].s2 = si, arc1[n1].n = 0, ++n1;
 			}
 			v = w, vpos = c->cm[a], vcid = c->cid[a], si = sc;
 		}
@@ -704,7 +709,7 @@ int pgo_rep_pos(pga_ctx_t *c)
 {
 	int64_t Q = c->n_gene, i, n = Q * c->n_genome;
 	int32_t j;
-	if (c->rp_x == 0) c->rp_x = MALLOC(int64_t, n), c->rp_y = MALLOC(int32_t, n), c->rp_iv = MALLOC(int32_t, n);
+	if (c->rp_x == 0) c->rp_x = MALLOC(int64_t, n), c->rp_y = MALLOC(int64_t, n), c->rp_iv = MALLOC(int32_t, n);
 	for (i = 0; i < n; ++i) c->rp_x[i] = -1, c->rp_y[i] = 0, c->rp_iv[i] = 0;
 	for (j = 0; j < c->n_genome; ++j) {
 		int32_t r = 0;
@@ -741,7 +746,7 @@ int pgo_n_local(pga_ctx_t *c, const int32_t *pairs, int64_t n, int32_t local_dis
 			int32_t cc, iv1 = c->rp_iv[j * Q + g1], iv2 = c->rp_iv[j * Q + g2];
 			if (x1 == -1 || x2 == -1) continue;
 			if (!frag_mode && x1 >> 32 != x2 >> 32) continue;
-			d = (int64_t)c->rp_y[j * Q + g1] - (int64_t)c->rp_y[j * Q + g2];
+			d = c->rp_y[j * Q + g1] - c->rp_y[j * Q + g2];
 			cc = (int32_t)x1 - (int32_t)x2;
 			if ((d >= -local_dist && d <= local_dist) || (cc >= -local_count && cc <= local_count)) ++n_local;
 			if ((iv1 | iv2) && !(d >= -local_dist && d <= local_dist)) { /* H2b: is |r1 - r2| <= local_count the same for every tie order? */
@@ -986,7 +991,7 @@ int pgo_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, const int32_t
 			for (k = 0; k < n; ++k) remap[inv[fl[k]] - st] = (int32_t)(p0 + k);
 			PERM_ARR(int32_t, pid); PERM_ARR(int32_t, gid); PERM_ARR(int32_t, cid); PERM_ARR(int32_t, rank);
 			PERM_ARR(int32_t, score_ori); PERM_ARR(int32_t, score_adj); PERM_ARR(int32_t, score_dom); PERM_ARR(int32_t, n_exon_of);
-			PERM_ARR(int32_t, off_exon); PERM_ARR(int32_t, cs); PERM_ARR(int32_t, ce); PERM_ARR(int32_t, cm); PERM_ARR(int32_t, cds);
+			PERM_ARR(int32_t, off_exon); PERM_ARR(int64_t, cs); PERM_ARR(int64_t, ce); PERM_ARR(int64_t, cm); PERM_ARR(int32_t, cds);
 			PERM_ARR(int32_t, pid_dom); PERM_ARR(int32_t, pid_dom0); PERM_ARR(uint32_t, flags);
 			PERM_ARR(int32_t, fidx); /* last: inv[] was built from it */
 #undef PERM_ARR

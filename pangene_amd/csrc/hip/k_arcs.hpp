@@ -32,14 +32,20 @@ struct InKeyHead { const uint64_t *key; __device__ __forceinline__ I32 operator(
 // Static per-hit fields in Y (cm) order, packed once per run: the arc kernels walk the hits in that order and would otherwise
 // gather every field through yperm.   YA = {seg, gid, genome, cm}   YB = {score_ori, score_dom, gene of pid_dom0's protein
 // (-1: none), X position << 1 | rev}
+// With virtual contigs (pga_genome_block_t; vfirst != NULL) "seg" is the segment id of the contig's FIRST piece -- the walk's "same
+// contig" test (graph.c:114, branch.c:124) then sees the contig, not the piece -- and "cm" the low 32 bits of the true 64-bit cm: the
+// walk only ever takes the difference of two of them into an int32_t (graph.c:73,117: p->dist = a->cm - vpos), and the low word of a
+// difference is the difference of the low words.  (Equal low words of different cm -- 2^32 bp apart -- raise a needless H2a hazard.)
 __global__ __launch_bounds__(BLOCK) void k_pack_yrec(const int32_t *yperm, const int32_t *seg, const int32_t *gid, const int32_t *gnm, const int32_t *cm,
                                                        const int32_t *sori, const int32_t *sdom, const int32_t *pdom0, const int32_t *prot_gid, const uint32_t *flags,
-                                                       int n, int4 *YA, int4 *YB)
+                                                       int n, int4 *YA, int4 *YB, const int32_t *vfirst, const int64_t *vbase)
 {
 	int y = blockIdx.x * BLOCK + threadIdx.x;
 	if (y >= n) return;
 	const int a = yperm[y], p0 = pdom0[a];
-	YA[y] = make_int4(seg[a], gid[a], gnm[a], cm[a]);
+	int sg = seg[a], cmv = cm[a];
+	if (vfirst) { cmv = (int)(unsigned)((unsigned long long)vbase[sg] + (unsigned long long)(long long)cmv); sg = vfirst[sg]; }
+	YA[y] = make_int4(sg, gid[a], gnm[a], cmv);
 	YB[y] = make_int4(sori[a], sdom[a], p0 < 0 ? -1 : prot_gid[p0], a << 1 | (flags[a] & PGA_F_REV ? 1 : 0));
 }
 
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(BLOCK) void k_arc_emit(ArcEmit e)
 	uint32_t v = (uint32_t)e.g2s[bA.y] << 1 | (uint32_t)(bB.w & 1);
 	int sa = arc_score(aB, e.ori, e.g2s);
 	int sb = arc_score(bB, e.ori, e.g2s);
-	int d = aA.w - bA.w, g = aA.z;
+	int d = (int)((unsigned)aA.w - (unsigned)bA.w), g = aA.z; // (unsigned: with virtual contigs the words are the low halves of 64-bit coordinates)
 	int64_t o = (int64_t)e.slot[y] * 2;
 	e.key[o] = (uint64_t)v << e.vbits | w;           e.idx[o] = (uint32_t)o;         // v -> w      (graph.c:117)
 	e.pay[o] = make_int4(d, sb, sa, g);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(BLOCK) void k_arc_l1(const uint64_t *key, int64_t m
 		m2 = m2 > q.z ? m2 : q.z;
 		++n;
 	}
-	const int dg = (int32_t)((double)sd / n + .499); // graph.c:141
+	const int dg = cvt_i32_x86((double)sd / n + .499); // graph.c:141 (sd: uint64_t as there)
 	o_n[i] = n, o_dn[i] = (uint64_t)(int64_t)dg * (uint64_t)n, o_s1[i] = m1, o_s2[i] = m2;
 }
 

@@ -21,6 +21,9 @@ struct OutRank {
 // the genome's array order (branch.c:22-23 overwrite).  COMPACT (every genome has < 4096 contigs and < 2^20 hits, decided once in
 // create): 8 bytes {cm, local contig << 20 | rank}, half the L2 traffic of pg_n_local, which reads two records per (pair, genome);
 // otherwise 16 bytes {global contig, rank, cm, interval}.  Absent: -1.
+// WIDE (a genome of the shard came with virtual contigs, pga_genome_block_t: coordinates of 64 bits): 16 bytes {contig = the segment id of
+// the contig's first piece, rank | bit 31 "has an interval", low and high word of the true cm}, the interval in iv[] as in the compact form.
+constexpr int RP_FULL = 0, RP_COMPACT = 1, RP_WIDE = 2;
 //
 // Filled from the gene-major index: the hits of (gene, genome) are adjacent there, in array order, so the last hit of each
 // group finds the group's last walkable hit (walkable = its half-arc record carries the round's tag) and also writes the "absent"
@@ -36,21 +39,22 @@ struct RepFill {
 	int64_t n_ent; int GL, Q, N; const int32_t *zx, *zy, *zg; const int2 *zst; const int32_t *zoff; const uint32_t *hbk; uint32_t tag;
 	const int4 *A; const int32_t *gid; const uint32_t *flags; const int32_t *rx, *goff, *ctg_base;
 	void *rp_out; int32_t *iv; int64_t *dcnt; int32_t *hz_list;
+	const int32_t *vfirst; const int64_t *vbase; // [contig segments] of the shard (RP_WIDE only)
 };
 
-template <bool COMPACT>
+template <int FORM>
 __device__ __forceinline__ void rep_absent(const RepFill &a, int64_t e0, int n)
 {
 	for (int k = 0; k < n; ++k) {
-		if (COMPACT) ((int2 *)a.rp_out)[e0 + k] = make_int2(0, -1); else ((int4 *)a.rp_out)[e0 + k] = make_int4(-1, 0, 0, 0);
+		if (FORM == RP_COMPACT) ((int2 *)a.rp_out)[e0 + k] = make_int2(0, -1); else ((int4 *)a.rp_out)[e0 + k] = make_int4(-1, 0, 0, 0);
 	}
 }
 
-template <bool COMPACT>
+template <int FORM>
 __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 {
 	const int t = blockIdx.x * BLOCK + threadIdx.x;
-	if (t < a.Q && a.zoff[t] == a.zoff[t + 1]) rep_absent<COMPACT>(a, (int64_t)t * a.GL, a.GL); // a gene without hits in this shard
+	if (t < a.Q && a.zoff[t] == a.zoff[t + 1]) rep_absent<FORM>(a, (int64_t)t * a.GL, a.GL); // a gene without hits in this shard
 	if (t >= a.N) return;
 	const int z = t;
 	// the loads are issued in as few dependent rounds as possible, from 4-byte planes in gene-major order (the kernel is bound by
@@ -67,12 +71,12 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 	// the genomes without a hit of this gene: before the first group, and between this group and the next
 	int gs = z;
 	if (gp == g && (yp >> 1) == j) { gs = z - 1; while (gs > z0 && ((a.zy[gs - 1] & 0x7fffffff) >> 1) == j) --gs; }
-	if (gs == z0 && j > 0) rep_absent<COMPACT>(a, (int64_t)g * a.GL, j);
+	if (gs == z0 && j > 0) rep_absent<FORM>(a, (int64_t)g * a.GL, j);
 	const int jn = gn == g ? (yn >> 1) : a.GL;
-	if (jn > j + 1) rep_absent<COMPACT>(a, e + 1, jn - j - 1);
+	if (jn > j + 1) rep_absent<FORM>(a, e + 1, jn - j - 1);
 	int q = z;
 	if (!hx_walk(kb, a.tag)) { q = z - 1; while (q >= gs && !hx_walk(a.hbk[q], a.tag)) --q; } // the group's last walkable hit
-	if (q < gs) { rep_absent<COMPACT>(a, e, 1); return; }
+	if (q < gs) { rep_absent<FORM>(a, e, 1); return; }
 	const int h = q == z ? xz : a.zx[q];
 	const int2 st = q == z ? st_z : a.zst[q];
 	// round 3: the one gather into cs order -- the hit's rank among the walkable hits (and the rank at the genome's start)
@@ -96,8 +100,12 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 		}
 	}
 	const int cmw = st.x | (ivl ? (int)0x80000000 : 0);
-	if (COMPACT) {
+	if (FORM == RP_COMPACT) {
 		((int2 *)a.rp_out)[e] = make_int2(cmw, (st.y - cb) << 20 | r);
+		if (ivl) a.iv[e] = ivl;
+	} else if (FORM == RP_WIDE) {
+		const long long cm64 = (long long)st.x + a.vbase[st.y]; // the piece's base back on (branch.c:23 keeps 64 bits)
+		((int4 *)a.rp_out)[e] = make_int4(a.vfirst[st.y], r | (ivl ? (int)0x80000000 : 0), (int)(unsigned)(unsigned long long)cm64, (int)((unsigned long long)cm64 >> 32));
 		if (ivl) a.iv[e] = ivl;
 	} else ((int4 *)a.rp_out)[e] = make_int4(st.y, r, cmw, ivl);
 }
@@ -124,7 +132,7 @@ __device__ __noinline__ bool nl_hazard(const NLocalHz &z, int cc, int iv1, int i
 // pairs per wave; as a rule the first step settles a pair, so the cost no longer grows with the number of genomes.
 constexpr int NL_PAIRS = 4, NL_LANES = 16;
 
-template <bool COMPACT>
+template <int FORM>
 __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_cap, const int64_t *np_dev, int GL, const void *rp_in,
                                                      int local_dist, int local_count, int frag_mode, int32_t *cnt, NLocalHz hz)
 {
@@ -145,7 +153,16 @@ __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t
 			const bool in = open && j < GL;
 			const int jj = j < GL ? j : 0;
 			bool hit = false, sure = false;
-			if (COMPACT) {
+			if (FORM == RP_WIDE) {
+				const int4 a = ((const int4 *)rp_in)[g1 + jj], b = ((const int4 *)rp_in)[g2 + jj]; // {contig, rank | bit 31, cm low, cm high}
+				const long long d = (long long)((unsigned long long)(unsigned)a.w << 32 | (unsigned)a.z) - (long long)((unsigned long long)(unsigned)b.w << 32 | (unsigned)b.z); // branch.c:40
+				const int cc = (a.y & 0x7fffffff) - (b.y & 0x7fffffff);
+				const bool cmp = in && a.x >= 0 && b.x >= 0 && (frag_mode || a.x == b.x);
+				const bool near = d >= -(long long)local_dist && d <= (long long)local_dist;
+				hit = cmp && (near || (cc >= -local_count && cc <= local_count));
+				sure = hit;
+				if (cmp && !near && (a.y | b.y) < 0) sure = nl_hazard(hz, cc, a.y < 0 ? hz.iv[g1 + jj] : 0, b.y < 0 ? hz.iv[g2 + jj] : 0, a.x, b.x, local_count) && hit;
+			} else if (FORM == RP_COMPACT) {
 				const int2 a = ((const int2 *)rp_in)[g1 + jj], b = ((const int2 *)rp_in)[g2 + jj];
 				const int d = (a.x & 0x7fffffff) - (b.x & 0x7fffffff); // cm < 2^31: the difference fits
 				const int cc = (a.y & 0xfffff) - (b.y & 0xfffff);

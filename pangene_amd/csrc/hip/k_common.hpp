@@ -2,6 +2,12 @@
 // Included by pga_backend.hip (one translation unit); uses the context types, BLOCK / WAVE and dev_prims.hpp from there.
 #pragma once
 
+// (int32_t)double as the reference's build does it (x86-64 cvttsd2si: truncation, and 0x80000000 for anything that does not fit).  The
+// hardware conversion here saturates instead.  It only matters for the averaged arc distance of graph.c:141 once contig coordinates
+// pass 32 bits: graph.c:73 narrows a distance to int32_t, a negative one goes into the uint64_t sum of graph.c:131-133 sign-extended,
+// and the average of THAT no longer fits (the reference prints ad:i:-2147483647 for such arcs; tests/test_abi.py holds one).
+__device__ __forceinline__ int32_t cvt_i32_x86(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000; }
+
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------

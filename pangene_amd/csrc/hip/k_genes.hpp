@@ -100,7 +100,7 @@ struct OutHalfArcs {
 		uint32_t key = tag << HA_TAG_SHIFT | HA_NONE;
 		if (p >= 0 && bA.x == aA.x) { // same contig: adjacency p -> i (graph.c:113-121)
 			const uint32_t w = (uint32_t)aA.y << 1 | (uint32_t)(aB.w & 1), v = (uint32_t)bA.y << 1 | (uint32_t)(bB.w & 1);
-			const int sa = arc_score(aB, ori, g2s), sb = arc_score(bB, ori, g2s), d = aA.w - bA.w;
+			const int sa = arc_score(aB, ori, g2s), sb = arc_score(bB, ori, g2s), d = (int)((unsigned)aA.w - (unsigned)bA.w); // (k_pack_yrec: low words of 64-bit coordinates when the shard has virtual contigs)
 			if (aA.w == bA.w) { atomicAdd((unsigned long long *)&dcnt[5], 1ull); hz_note(&dcnt[14], hz_list, aA.x); } // hazard H2a: equal cm
 			hfk[zp] = tag << HA_TAG_SHIFT | w, hfp[zp] = make_int4(d, sb, sa, 0); // v -> w,     s1 = score(v), s2 = score(w) (graph.c:117)
 			key = tag << HA_TAG_SHIFT | (v ^ 1u), hbp[zi] = make_int4(d, sa, sb, 0); // w^1 -> v^1, s1 = score(w), s2 = score(v) (graph.c:119)
@@ -227,7 +227,7 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 						}
 					}
 				m1 = m1 > 0 ? m1 : 0, m2 = m2 > 0 ? m2 : 0; // the reference's running maxima start at 0 (graph.c:133)
-				const int dg = (int32_t)((double)(long long)sd / n + .499); // graph.c:141
+				const int dg = cvt_i32_x86((double)sd / n + .499); // graph.c:141: the sum is a uint64_t there, and so is its conversion
 				// level 2 (graph.c:153-169): sums over the genomes, LDS table keyed by (orientation, target).  A lane's hits lie in
 				// different genomes and mostly have the same neighbour: runs of one key are summed in registers and reach the table
 				// as ONE set of atomics (a gene with 2 400 hits and ten neighbours would otherwise send 24 000 atomics to ten slots).

@@ -192,7 +192,8 @@ struct pga_ctx {
 	int rk_shift = -1;      // >= 0: the key fits 32 bits as score_adj << rk_shift | preferred << (rk_shift - 1) | (rank of hash(pid) among the proteins): no sort
 	int32_t *hrank = 0;     // [P] rank of hash(pid) + 1 (0 for a hash of 0)
 	bool any_multi = true;  // some hit has more than one exon
-	bool rp_compact = false; // 8-byte (gene, genome) position records (see k_rep_fill)
+	int rp_form = 0;         // form of the (gene, genome) position records (see k_rep_fill)
+	int32_t *vfirst = 0; int64_t *vbase = 0; // virtual contigs (pga_genome_block_t), per contig segment of the shard: segment of the contig's first piece, the piece's base; NULL = no genome has any
 	int4 *recA = 0, *recB = 0, *recC = 0; // packed sweep records (derived from the arrays above, see k_pack_rec)
 	// dynamic per hit
 	int32_t *rank = 0, *sdom = 0, *pdom = 0, *pdom0 = 0; uint32_t *flags = 0;
@@ -516,13 +517,24 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(dalloc(c, &c->hfk, N)); TRY(dalloc(c, &c->hbk, N)); TRY(dalloc(c, &c->hfp, N)); TRY(dalloc(c, &c->hbp, N));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q)); TRY(dalloc(c, &c->hrank, c->P));
 	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
+	bool vsplit = false; // some genome arrives with virtual contigs (64-bit coordinates)
+	int64_t n_vseg = 0;
+	for (int g = 0; g < GL; ++g) {
+		const pga_genome_block_t &b = sh->block[g];
+		if (b.n_ctg < 0 || (b.vfirst == nullptr) != (b.vbase == nullptr)) return PGA_ERR_ARG;
+		vsplit = vsplit || b.vfirst != nullptr, n_vseg += b.n_ctg;
+	}
+	if (n_vseg >= INT32_MAX) return PGA_ERR_RANGE;
+	if (vsplit) { TRY(dalloc(c, &c->vfirst, (size_t)n_vseg + 1)); TRY(dalloc(c, &c->vbase, (size_t)n_vseg + 1)); }
 	TRY(dalloc_commit(c));
 
 	// host-side small tables (genome-sized)
 	std::vector<int32_t> ctg_base((size_t)GL + 1, 0), eoff((size_t)GL + 1, 0);
 	std::vector<int64_t> woff((size_t)GL + 1, 0);
 	c->h_goff.assign((size_t)GL + 1, 0);
-	c->rp_compact = true;
+	c->rp_form = vsplit ? RP_WIDE : RP_COMPACT;
+	std::vector<int32_t> h_vfirst; std::vector<int64_t> h_vbase;
+	if (vsplit) h_vfirst.assign((size_t)n_vseg + 1, 0), h_vbase.assign((size_t)n_vseg + 1, 0);
 	uint32_t max_cs = 0, max_cm = 0, max_sadj = 0;
 	int32_t max_hit = 0, max_ctg = 1;
 	bool neg_sadj = false, multi = false;
@@ -531,7 +543,18 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		if (b.n_hit < 0 || b.n_exon < 0 || b.n_ctg < 0 || b.n_words != (size_t)PGA_BLOCK_PLANES * b.n_hit + ((size_t)b.n_hit + 3) / 4 + 2 * (size_t)b.n_exon) return PGA_ERR_ARG;
 		c->h_goff[(size_t)g + 1] = c->h_goff[(size_t)g] + b.n_hit, eoff[(size_t)g + 1] = eoff[(size_t)g] + b.n_exon;
 		ctg_base[(size_t)g + 1] = ctg_base[(size_t)g] + b.n_ctg, woff[(size_t)g + 1] = woff[(size_t)g] + (int64_t)b.n_words;
-		if (b.n_ctg >= 4096 || b.n_hit >= (1 << 20)) c->rp_compact = false;
+		if ((b.n_ctg >= 4096 || b.n_hit >= (1 << 20)) && c->rp_form == RP_COMPACT) c->rp_form = RP_FULL;
+		if (vsplit) { // the shard-wide tables; a genome without its own: every contig is its own first piece, base 0
+			const int32_t cb = ctg_base[(size_t)g];
+			for (int32_t v = 0; v < b.n_ctg; ++v) {
+				const int32_t f = b.vfirst ? b.vfirst[v] : v;
+				const int64_t base = b.vbase ? b.vbase[v] : 0;
+				// the pieces of a contig are consecutive and in coordinate order (pangene_hip.h): the (contig, cs) and (contig, cm) orders of
+				// the pieces are then the orders of the contig
+				if (f < 0 || f > v || base < 0 || (f != v && (b.vfirst[v - 1] != f || base < b.vbase[v - 1]))) return PGA_ERR_ARG;
+				h_vfirst[(size_t)cb + (size_t)v] = cb + f, h_vbase[(size_t)cb + (size_t)v] = base;
+			}
+		}
 		max_cs = std::max(max_cs, (uint32_t)b.max_cs), max_cm = std::max(max_cm, (uint32_t)b.max_cm), max_sadj = std::max(max_sadj, (uint32_t)b.max_score_adj);
 		neg_sadj = neg_sadj || b.any_neg_score_adj, multi = multi || b.any_multi_exon;
 		max_hit = std::max(max_hit, b.n_hit), max_ctg = std::max(max_ctg, b.n_ctg);
@@ -607,6 +630,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(upload(c, c->goff, c->h_goff.data(), (size_t)GL + 1)); TRY(upload(c, c->ggl, c->h_ggl.data(), GL));
 	TRY(upload(c, c->ctg_base, ctg_base.data(), (size_t)GL + 1)); TRY(upload(c, c->eoff, eoff.data(), (size_t)GL + 1)); TRY(upload(c, c->woff, woff.data(), (size_t)GL + 1));
 	TRY(upload(c, c->prot_gid, sh->prot_gid, c->P)); TRY(upload(c, c->gene_pref, sh->gene_pref, c->Q));
+	if (vsplit) { TRY(upload(c, c->vfirst, h_vfirst.data(), (size_t)n_vseg + 1)); TRY(upload(c, c->vbase, h_vbase.data(), (size_t)n_vseg + 1)); } // (locals: the sync at the end of this function comes before they go)
 	// half-arc records are validated by a round tag: none may survive from an earlier context whose memory this one inherited
 	if (N) { HIPCHK(hipMemsetAsync(c->hfk, 0xff, sizeof(uint32_t) * (size_t)N, c->st)); HIPCHK(hipMemsetAsync(c->hbk, 0xff, sizeof(uint32_t) * (size_t)N, c->st)); }
 	HIPCHK(hipMemsetAsync(c->dcnt, 0, 16 * sizeof(int64_t), c->st));
@@ -962,7 +986,7 @@ static void ensure_yrec(pga_ctx *c)
 {
 	if (c->yrec_valid || c->N == 0) return;
 	hipLaunchKernelGGL(k_pack_yrec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->yperm, c->seg, c->gid, c->gnm, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags,
-	                   c->N, c->yrecA, c->yrecB);
+	                   c->N, c->yrecA, c->yrecB, c->vfirst, c->vbase);
 	c->yrec_valid = true;
 }
 
@@ -1324,10 +1348,11 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		if (!rx || !tile) return PGA_ERR_NOMEM;
 		TRY(ensure_half_arcs(c, c->ha_ori < 0 ? 0 : c->ha_ori)); // which hits are walkable, gene-major (normally left by the arc round just before)
 		device_scan<I32>(InWalkX{c->flags}, OutRank{rx, c->flags}, N, tile, OpSum{}, I32{0}, c->st); // rank among the walkable hits, cs order
-		RepFill rf = { n_ent, GL, Q, N, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl };
+		RepFill rf = { n_ent, GL, Q, N, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl, c->vfirst, c->vbase };
 		const unsigned nb = nblk(std::max(N, Q));
-		if (c->rp_compact) hipLaunchKernelGGL((k_rep_fill<true>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
-		else hipLaunchKernelGGL((k_rep_fill<false>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+		if (c->rp_form == RP_COMPACT) hipLaunchKernelGGL((k_rep_fill<RP_COMPACT>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+		else if (c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_rep_fill<RP_WIDE>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+		else hipLaunchKernelGGL((k_rep_fill<RP_FULL>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
 	} else if (n_ent) {
 		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(4 * n_ent)), dim3(BLOCK), 0, c->st, (int32_t *)rp, 4 * n_ent, -1); // "absent" in either record form
 	}
@@ -1346,8 +1371,9 @@ static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, const int6
 	// the grid follows the last known number of pairs (the kernel strides over whatever there is)
 	const int64_t est = np_dev ? (c->br_np_seen > 0 ? c->br_np_seen : std::min<int64_t>(n, 1 << 18)) : n;
 	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nblk(est, BLOCK / WAVE * NL_PAIRS), 1 << 20));
-	if (n && c->rp_compact) hipLaunchKernelGGL((k_n_local<true>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
-	else if (n) hipLaunchKernelGGL((k_n_local<false>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
+	if (n && c->rp_form == RP_COMPACT) hipLaunchKernelGGL((k_n_local<RP_COMPACT>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
+	else if (n && c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_n_local<RP_WIDE>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
+	else if (n) hipLaunchKernelGGL((k_n_local<RP_FULL>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
 	return 0;
 }
 

@@ -262,11 +262,21 @@ void pg_write_matrix(pg_graph_t *q, int32_t copy_number)
 	pg_data_t *d = q->d;
 	DataExt *ext = ext_of(d, false);
 	if (ext == nullptr || ext->ctx == nullptr) { set_error(PGA_ERR_ARG, "pg_write_matrix: pg_graph_gen has not run on this data set"); return; }
-	size_t n_ctg = 0;
-	for (int32_t j : ext->local_genomes) n_ctg += (size_t)d->genome[j].n_ctg;
-	std::vector<int32_t> cnt(n_ctg + 1, 0), col(n_ctg + 1, -1);
-	int rc = ext->be->ctg_counts(ext->ctx, cnt.data());
+	// the backend counts per contig AS IT SEES THEM (pieces of virtual contigs, pga_genome_block_t): v_of[] = its numbering
+	size_t n_ctg = 0, n_v = 0;
+	for (size_t k = 0; k < ext->local_genomes.size(); ++k) n_ctg += (size_t)d->genome[ext->local_genomes[k]].n_ctg, n_v += (size_t)(k < ext->n_vctg.size() ? ext->n_vctg[k] : d->genome[ext->local_genomes[k]].n_ctg);
+	std::vector<int32_t> vcnt(n_v + 1, 0), cnt(n_ctg + 1, 0), col(n_ctg + 1, -1), real_of(n_v + 1, 0);
+	int rc = ext->be->ctg_counts(ext->ctx, vcnt.data());
 	if (rc != 0) { set_error(rc, "ctg_counts"); return; }
+	{
+		size_t rb = 0, vb = 0;
+		for (size_t kk = 0; kk < ext->local_genomes.size(); ++kk) {
+			const int32_t nr = d->genome[ext->local_genomes[kk]].n_ctg, nv = kk < ext->n_vctg.size() ? ext->n_vctg[kk] : nr;
+			const std::vector<int32_t> *vr = (kk < ext->vreal.size() && !ext->vreal[kk].empty()) ? &ext->vreal[kk] : nullptr;
+			for (int32_t v = 0; v < nv; ++v) { const size_t r = rb + (size_t)(vr ? (*vr)[(size_t)v] : v); real_of[vb + (size_t)v] = (int32_t)r, cnt[r] += vcnt[vb + (size_t)v]; }
+			rb += (size_t)nr, vb += (size_t)nv;
+		}
+	}
 	std::vector<std::string> names;
 	std::unordered_map<std::string, int32_t> idx;
 	std::string sample, key;
@@ -287,7 +297,9 @@ void pg_write_matrix(pg_graph_t *q, int32_t copy_number)
 	}
 	const int32_t n_asm = (int32_t)names.size();
 	std::vector<int32_t> mat((size_t)q->n_seg * (size_t)n_asm + 1, 0);
-	rc = ext->be->gene_matrix(ext->ctx, col.data(), n_asm, q->n_seg, mat.data());
+	std::vector<int32_t> vcol(n_v + 1, -1); // column of every contig as the backend numbers them
+	for (size_t v = 0; v < n_v; ++v) vcol[v] = col[(size_t)real_of[v]];
+	rc = ext->be->gene_matrix(ext->ctx, vcol.data(), n_asm, q->n_seg, mat.data());
 	if (rc != 0) { set_error(rc, "gene_matrix"); return; }
 	FILE *fp = out_stream();
 	std::string o = "Gene\t";

@@ -131,6 +131,35 @@ static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int6
 static void *block_alloc(DataExt *ext, size_t bytes);
 static uint64_t genome_signature(const pg_genome_t *g);
 
+// Contigs whose coordinates do not fit 31 bits (pangene.h:71 has int64_t; the reference handles any length) reach the backend as VIRTUAL
+// contigs (pga_genome_block_t): cut at hit-free gaps into pieces of < 2^30 bp (+ the cluster of overlapping hits the cut has to wait
+// for), coordinates relative to the piece.  piece_of[h] = piece of hit h; returns false when a single cluster spans too much.
+static bool virtual_contigs(const pg_genome_t *g, std::vector<int32_t> &piece_of, std::vector<int32_t> &vfirst, std::vector<int32_t> &vreal, std::vector<int64_t> &vbase)
+{
+	static const int64_t PIECE = [] { const char *e = std::getenv("PANGENE_VCTG_PIECE"); return e && std::atoll(e) > 0 ? std::atoll(e) : (int64_t)1 << 30; }(); // (tests shrink it to cut ordinary contigs)
+	const int32_t n = g->n_hit;
+	std::vector<int32_t> ord((size_t)n);
+	for (int32_t i = 0; i < n; ++i) ord[(size_t)i] = i;
+	std::sort(ord.begin(), ord.end(), [g](int32_t x, int32_t y) { const pg_hit_t &a = g->hit[x], &b = g->hit[y]; return a.cid != b.cid ? a.cid < b.cid : a.cs != b.cs ? a.cs < b.cs : x < y; });
+	piece_of.assign((size_t)n, 0), vfirst.clear(), vreal.clear(), vbase.clear();
+	int32_t k = 0;
+	for (int32_t c = 0; c < g->n_ctg; ++c) { // (contigs without hits keep one piece: the numbering of the others must not depend on them... it does not: pieces are numbered in contig order)
+		const int32_t first = (int32_t)vfirst.size();
+		int64_t base = 0, reach = -1; // reach: the largest ce so far = where the current cluster of overlapping hits ends
+		bool open = false;
+		vfirst.push_back(first), vreal.push_back(c), vbase.push_back(0);
+		for (; k < n && g->hit[ord[(size_t)k]].cid == c; ++k) {
+			const pg_hit_t &a = g->hit[ord[(size_t)k]];
+			if (!open) { base = a.cs >= INT32_MAX / 2 ? a.cs : 0, vbase.back() = base, open = true; } // (a contig that fits keeps its coordinates)
+			else if (a.cs > reach && a.cs - base >= PIECE) { base = a.cs; vfirst.push_back(first), vreal.push_back(c), vbase.push_back(base); } // a gap (strictly: no cm of the next piece can equal one of this piece), and the piece is long enough: cut
+			if (a.ce - base >= INT32_MAX - 1) return false;
+			reach = std::max(reach, a.ce);
+			piece_of[(size_t)ord[(size_t)k]] = (int32_t)vfirst.size() - 1;
+		}
+	}
+	return true;
+}
+
 static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 {
 	GenomePack &pk = ext->packs[(size_t)j];
@@ -146,22 +175,38 @@ static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 	const bool sorted = (size_t)j < ext->hits_sorted.size() && ext->hits_sorted[(size_t)j] && (size_t)j < ext->file_of_host.size();
 	const int32_t *fof = sorted ? ext->file_of_host[(size_t)j].data() : nullptr;
 	int32_t max_cs = 0, max_cm = 0, max_sadj = 0, neg = 0, multi = 0;
+	// 64-bit coordinates: does any hit of the genome need a virtual contig?
+	static const bool force_v = std::getenv("PANGENE_VCTG_PIECE") != nullptr;
+	bool wide = force_v;
+	for (int64_t h = 0; h < n && !wide; ++h) wide = g->hit[h].ce >= INT32_MAX - 1 || g->hit[h].cm >= INT32_MAX - 1;
+	std::vector<int32_t> piece_of;
+	if (wide) {
+		bool ok = true;
+		for (int64_t h = 0; h < n; ++h) { const pg_hit_t *a = &g->hit[h]; if (a->cs < 0 || a->cm < a->cs || a->ce < a->cs || a->cid < 0 || a->cid >= g->n_ctg) ok = false; }
+		if (!ok || !virtual_contigs(g, piece_of, pk.vfirst, pk.vreal, pk.vbase)) { pk.err = PGA_ERR_RANGE; wide = false; }
+	}
 	for (int64_t h = 0; h < n; ++h) {
 		const pg_hit_t *a = &g->hit[h];
 		const int64_t f = fof ? fof[h] : h;
-		if (a->cs < 0 || a->ce >= INT32_MAX || a->cm < 0 || a->cm >= INT32_MAX || a->ce < a->cs || a->cid < 0) { pk.err = PGA_ERR_RANGE; continue; }
-		w[f] = a->pid, w[n + f] = a->cid, w[2 * n + f] = a->rank, w[3 * n + f] = a->score_ori, w[4 * n + f] = a->score_adj;
-		w[5 * n + f] = a->n_exon, w[6 * n + f] = a->off_exon, w[7 * n + f] = (int32_t)a->cs, w[8 * n + f] = (int32_t)a->ce, w[9 * n + f] = (int32_t)a->cm;
+		if (pk.err) continue;
+		int32_t cid = a->cid;
+		int64_t cs = a->cs, ce = a->ce, cm = a->cm;
+		if (wide) { cid = piece_of[(size_t)h]; const int64_t base = pk.vbase[(size_t)cid]; cs -= base, ce -= base, cm -= base; }
+		if (cs < 0 || ce >= INT32_MAX || cm < 0 || cm >= INT32_MAX || ce < cs || cid < 0) { pk.err = PGA_ERR_RANGE; continue; }
+		w[f] = a->pid, w[n + f] = cid, w[2 * n + f] = a->rank, w[3 * n + f] = a->score_ori, w[4 * n + f] = a->score_adj;
+		w[5 * n + f] = a->n_exon, w[6 * n + f] = a->off_exon, w[7 * n + f] = (int32_t)cs, w[8 * n + f] = (int32_t)ce, w[9 * n + f] = (int32_t)cm;
 		rev[f] = a->rev;
-		max_cs = std::max(max_cs, (int32_t)a->cs), max_cm = std::max(max_cm, (int32_t)a->cm);
+		max_cs = std::max(max_cs, (int32_t)cs), max_cm = std::max(max_cm, (int32_t)cm);
 		if (a->score_adj < 0) neg = 1; else max_sadj = std::max(max_sadj, a->score_adj);
 		multi |= a->n_exon != 1;
 	}
 	for (int64_t e = 0; e < ne; ++e) ex[2 * e] = g->exon[e].os, ex[2 * e + 1] = g->exon[e].oe;
 	pga_genome_block_t &b = pk.blk;
-	b.n_hit = (int32_t)n, b.n_exon = (int32_t)ne, b.n_ctg = g->n_ctg;
+	b.n_hit = (int32_t)n, b.n_exon = (int32_t)ne, b.n_ctg = wide ? (int32_t)pk.vfirst.size() : g->n_ctg;
 	b.max_cs = max_cs, b.max_cm = max_cm, b.max_score_adj = max_sadj, b.any_neg_score_adj = neg, b.any_multi_exon = multi;
 	b.data = w, b.n_words = nw;
+	b.vfirst = wide ? pk.vfirst.data() : nullptr, b.vbase = wide ? pk.vbase.data() : nullptr;
+	if (!wide) pk.vfirst.clear(), pk.vreal.clear(), pk.vbase.clear();
 	pk.sig = sorted ? 0 : genome_signature(g);
 }
 
@@ -378,6 +423,22 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 		blk[(size_t)k] = pk.blk;
 		N += pk.blk.n_hit, E += pk.blk.n_exon;
 		ext->hit_off[(size_t)k + 1] = N;
+	}
+	ext->vreal.assign((size_t)nl, std::vector<int32_t>()), ext->n_vctg.assign((size_t)nl, 0);
+	for (int32_t k = 0; k < nl; ++k) { // contigs as the backend counts them (virtual contigs: the pieces of the long ones)
+		const GenomePack &pk = ext->packs[(size_t)ext->local_genomes[(size_t)k]];
+		ext->n_vctg[(size_t)k] = pk.blk.n_ctg;
+		if (!pk.vreal.empty()) ext->vreal[(size_t)k] = pk.vreal;
+	}
+	if (pg_verbose >= 3) {
+		int64_t n_cut = 0, n_piece = 0, n_g = 0;
+		for (int32_t k = 0; k < nl; ++k) {
+			const GenomePack &pk = ext->packs[(size_t)ext->local_genomes[(size_t)k]];
+			if (pk.vreal.empty()) continue;
+			++n_g;
+			for (size_t v = 0; v < pk.vfirst.size(); ++v) n_piece += pk.vfirst[v] != (int32_t)v, n_cut += v + 1 < pk.vfirst.size() && pk.vfirst[v] == (int32_t)v && pk.vfirst[v + 1] == (int32_t)v;
+		}
+		if (n_g) std::fprintf(stderr, "[M::%s] 64-bit coordinates: %lld genome(s) with virtual contigs, %lld contig(s) cut, %lld extra piece(s)\n", __func__, (long long)n_g, (long long)n_cut, (long long)n_piece);
 	}
 	if (d->n_gene >= (1 << 20) || d->n_genome >= (1 << 24) || E >= INT32_MAX || N >= INT32_MAX) return PGA_ERR_RANGE;
 	std::vector<int32_t> pgid((size_t)d->n_prot);
@@ -1330,13 +1391,15 @@ static int hazards_review(DataExt *ext, bool *need, bool *give_up)
 		if (n_total > n_got) flags[0] = flags[1] = 1;
 		// contig-segment id -> (local genome, contig): the shard lists the contigs genome-major
 		std::vector<int32_t> base(ext->local_genomes.size() + 1, 0);
-		for (size_t k = 0; k < ext->local_genomes.size(); ++k) base[k + 1] = base[k] + ext->q_d->genome[ext->local_genomes[k]].n_ctg;
+		for (size_t k = 0; k < ext->local_genomes.size(); ++k) base[k + 1] = base[k] + (k < ext->n_vctg.size() ? ext->n_vctg[k] : ext->q_d->genome[ext->local_genomes[k]].n_ctg);
 		std::sort(segs.begin(), segs.begin() + n_got);
 		int64_t n_new = 0;
 		for (int64_t i = 0; i < n_got; ++i) {
 			if (i && segs[(size_t)i] == segs[(size_t)i - 1]) continue;
 			const size_t k = (size_t)(std::upper_bound(base.begin(), base.end(), segs[(size_t)i]) - base.begin()) - 1;
-			const std::pair<int32_t, int32_t> gc((int32_t)k, segs[(size_t)i] - base[k]);
+			int32_t ctg_local = segs[(size_t)i] - base[k];
+			if (k < ext->vreal.size() && !ext->vreal[k].empty() && (size_t)ctg_local < ext->vreal[k].size()) ctg_local = ext->vreal[k][(size_t)ctg_local]; // a piece of a virtual contig -> the contig
+			const std::pair<int32_t, int32_t> gc((int32_t)k, ctg_local);
 			if (std::binary_search(ext->static_ctgs.begin(), ext->static_ctgs.end(), gc)) continue; // follows the exact order already (static prediction)
 			auto it = std::lower_bound(ext->extra_ctgs.begin(), ext->extra_ctgs.end(), gc);
 			if (it == ext->extra_ctgs.end() || *it != gc) ext->extra_ctgs.insert(it, gc), ++n_new;

@@ -59,6 +59,9 @@ struct GenomePack {
 	void *buf = nullptr;
 	int err = 0;                              // PGA_ERR_RANGE: a coordinate does not fit the device layout
 	uint64_t sig = 0;                         // what the genome looked like when it was packed (graph_driver.cpp: genome_signature)
+	// virtual contigs (pga_genome_block_t): empty unless a contig of the genome had to be cut
+	std::vector<int32_t> vfirst, vreal;       // per piece: first piece of its contig; the contig's own id (pg_hit_t::cid)
+	std::vector<int64_t> vbase;               // per piece: the base its coordinates are relative to
 };
 struct HostSlab { char *p = nullptr; size_t cap = 0, off = 0; bool pinned = false, fresh = false; }; // fresh: page-locked for this very read (not taken from the cache)
 
@@ -70,6 +73,8 @@ struct DataExt {
 	pga_ctx_t *ctx = nullptr;          // backend context (owns the HBM-resident shard)
 	std::vector<int32_t> local_genomes; // global index of each genome in the shard
 	std::vector<int64_t> hit_off;      // shard hit offsets
+	std::vector<std::vector<int32_t>> vreal; // per local genome: piece -> contig id, for genomes with virtual contigs (empty: the backend's contigs are the genome's)
+	std::vector<int32_t> n_vctg;       // per local genome: contigs as the backend counts them (pieces)
 	std::vector<std::vector<int32_t>> y_file;  // per genome: FILE index of the k-th hit in cm order
 	std::vector<ExactSeg> xsegs;
 	std::vector<int32_t> deg;          // out-degree of every oriented vertex of the round's arc table

@@ -472,6 +472,38 @@ def mutate(gen: Iterator[Tuple[str, str]], seed: int, p_score: float = 0.06, p_d
         yield (name, "".join(x + "\n" for x in out))
 
 
+def widen(gen: Iterator[Tuple[str, str]], seed: int, p_gap: float = 0.15, p_shift: float = 0.5) -> Iterator[Tuple[str, str]]:
+    """Contig coordinates beyond 32 bits (pangene.h:71 keeps cs / cm / ce in int64_t; read.c:202-204 parses them with strtol): every
+    contig is stretched at some of its HIT-FREE gaps by 1.3e9, 2.2e9 or 4.7e9 bp -- so that distances between neighbouring hits pass
+    2^31 (graph.c:73 narrows them to int32_t) and 2^32 -- and about half of the contigs start beyond 2^31 as a whole.  Hits keep
+    their lengths, their order and their overlaps."""
+    jumps = [1_300_000_000, 2_200_000_000, 4_700_000_000, (1 << 32)]
+    for j, (name, text) in enumerate(gen):
+        r = _rng(seed, 7000 + j)
+        lines = [l.split("\t") for l in text.splitlines()]
+        per_ctg = {}
+        for i, f in enumerate(lines):
+            if len(f) > 8 and f[7].isdigit() and f[8].isdigit():
+                per_ctg.setdefault(f[5], []).append(i)
+        for ctg, idx in per_ctg.items():
+            idx.sort(key=lambda i: (int(lines[i][7]), int(lines[i][8])))
+            off = int(r.choice([2_500_000_000, 5_000_000_000])) if r.random() < p_shift else 0
+            reach = -1
+            new = {}
+            for i in idx:
+                cs, ce = int(lines[i][7]), int(lines[i][8])
+                if reach >= 0 and cs > reach and r.random() < p_gap:
+                    off += int(r.choice(jumps))
+                reach = max(reach, ce)
+                new[i] = (cs + off, ce + off)
+            end = max(int(lines[idx[-1]][6]) + off, max(e for _, e in new.values()) + 1) if lines[idx[-1]][6].isdigit() else None
+            for i in idx:
+                lines[i][7], lines[i][8] = str(new[i][0]), str(new[i][1])
+                if end is not None:
+                    lines[i][6] = str(end)
+        yield (name, "".join("\t".join(f) + "\n" for f in lines))
+
+
 def write_files(gen: Iterator[Tuple[str, str]], out_dir: str, gz: bool = False) -> List[str]:
     os.makedirs(out_dir, exist_ok=True)
     paths = []

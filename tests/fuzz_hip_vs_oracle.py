@@ -20,6 +20,10 @@ def sets_of(s, human=True, mutated=True):
         sets["mutfuzz"] = synth.mutate(synth.fuzz(s + 500000, harsh=bool(s & 2)), s)
         if s % 3 == 0:
             sets["mutbact"] = synth.mutate(synth.bact(5 + s % 4, 120 + 29 * (s % 5), seed=s + 1), s + 1)
+    # contig coordinates beyond 32 bits (synth.widen): virtual contigs in the packer, the wide record forms on the device
+    sets["widefuzz"] = synth.widen(synth.fuzz(s + 700000, harsh=bool(s & 1)), s, p_gap=0.3)
+    if human and s % 4 == 2:
+        sets["widehuman"] = synth.widen(synth.human(4 + s % 3, 100, iso=2.0, seed=s + 7, n_chr=3, frag=bool(s & 8)), s + 1)
     return sets
 
 

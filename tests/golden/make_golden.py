@@ -40,6 +40,12 @@ SETS["fuzz7126"] = lambda: synth.fuzz(7126, harsh=False)
 SETS["mut0"] = lambda: synth.mutate(synth.fuzz(100, harsh=False), 1)
 SETS["mut1"] = lambda: synth.mutate(synth.bact(12, 200, seed=5), 2)
 SETS["mut2"] = lambda: synth.mutate(synth.human(6, 150, iso=2.0, seed=3, n_chr=3, frag=True), 3)
+# contig coordinates beyond 32 bits (pangene.h:71: int64_t cs, cm, ce): the device layout keeps 32-bit planes and cuts such contigs into
+# virtual contigs (include/pangene_hip.h, pga_genome_block_t)
+SETS["wide0"] = lambda: synth.widen(synth.human(8, 300, iso=3.0, seed=4, n_chr=5), 1)
+SETS["wide1"] = lambda: synth.widen(synth.bact(12, 300, seed=7), 2, p_gap=0.02)
+SETS["wide2"] = lambda: synth.widen(synth.fuzz(3, harsh=True), 3, p_gap=0.3)
+SETS["wide3"] = lambda: synth.widen(synth.mutate(synth.human(6, 200, iso=2.0, seed=9, n_chr=3, frag=True), 4), 4, p_gap=0.3)
 
 
 def files_of(name):

@@ -95,9 +95,11 @@ def test_reference_main_c_builds_and_runs_on_this_library(built, expected, tmp_p
 
 
 def test_device_layout_limits_are_reported_not_asserted(tmp_path):
-    """include/pangene_hip.h documents the device layout limits (contig coordinates < 2^31: pangene.h:71 has int64).  A PAF beyond
-    them must come back as PGA_ERR_RANGE from the packing step -- on any backend, before a device is touched -- and as
-    pg_last_error() != 0 with an empty graph, never as an abort or a silent truncation."""
+    """include/pangene_hip.h documents the device layout limits.  Contig coordinates beyond 2^31 (pangene.h:71 has int64) are NOT one
+    of them any more: the packer cuts such contigs into virtual contigs and the GFA is the reference's (the wide* fixtures; here a
+    3 Gb contig).  What remains out of reach is ONE cluster of overlapping hits that spans more than 2^31 bp: that must come back as
+    PGA_ERR_RANGE from the packing step -- on any backend, before a device is touched -- and as pg_last_error() != 0 with an empty
+    graph, never as an abort or a silent truncation."""
     import ctypes as C
     from pangene_amd import capi
     lib = capi.load(oracle_host=True)
@@ -106,6 +108,20 @@ def test_device_layout_limits_are_reported_not_asserted(tmp_path):
     p = tmp_path / "big.paf"
     p.write_text("g1\t100\t0\t100\t+\tc1\t%d\t%d\t%d\t300\t300\t0\tms:i:400\tcg:Z:100M\n" % (big + 1000, big, big + 300)
                  + "g2\t100\t0\t100\t+\tc1\t%d\t10\t310\t300\t300\t0\tms:i:410\tcg:Z:100M\n" % (big + 1000))
+    out = capi.run(lib, [str(p)], ["-p0", "-a1"])
+    assert lib.pg_last_error() == 0
+    # what oracle/_ref/pangene_ref prints for this file (the distance 2 999 999 990 goes through graph.c:73's int32_t and the
+    # double -> int32_t conversion of graph.c:141)
+    assert out == (b"S\tg1\t*\tLN:i:100\tng:i:1\tnc:i:1\tc1:i:1\tc2:i:0\tpp:Z:g1\nS\tg2\t*\tLN:i:100\tng:i:1\tnc:i:1\tc1:i:1\tc2:i:0\tpp:Z:g2\n"
+                   b"L\tg1\t-\tg2\t-\t0M\tng:i:1\tnc:i:1\tad:i:-2147483647\ts1:i:400\ts2:i:410\nL\tg2\t+\tg1\t+\t0M\tng:i:1\tnc:i:1\tad:i:-2147483647\ts1:i:410\ts2:i:400\n"
+                   b"W\tbig\t0\tc1\t*\t*\t>g2>g1\tlf:B:i,0,0\n")
+    # three hits of 1e9 bp each (one huge intron), each overlapping the next: a cluster of 2.4e9 bp that no cut can divide
+    span = 1_000_000_000
+    lines = ""
+    for k in range(3):
+        st = 10 + k * 700_000_000
+        lines += "h%d\t100\t0\t100\t+\tc1\t%d\t%d\t%d\t300\t300\t0\tms:i:400\tcg:Z:50M%dN50M\n" % (k, 4 * span, st, st + span, span - 300)
+    p.write_text(lines)
     with pytest.raises(RuntimeError, match="status -2"):
         capi.run(lib, [str(p)], [])
     assert lib.pg_last_error() == -2

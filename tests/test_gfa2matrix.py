@@ -32,7 +32,7 @@ def _matrix_checks(lib, tmp_path, name, variant):
         assert out.read_text() == want
 
 
-@pytest.mark.parametrize("name,variant", [("C4", ""), ("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("manydoms", "")])
+@pytest.mark.parametrize("name,variant", [("C4", ""), ("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("manydoms", ""), ("wide0", ""), ("wide3", "-S")])
 def test_matrix_from_memory_and_from_file_equal_the_restatement(built, tmp_path, name, variant):
     lib = capi.load(oracle_host=True)
     C.c_int.in_dll(lib, "pg_verbose").value = 0
@@ -40,7 +40,7 @@ def test_matrix_from_memory_and_from_file_equal_the_restatement(built, tmp_path,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,variant", [("C4", ""), ("bact20", ""), ("human8f", "-p0 -a1"), ("human8", "-S")])
+@pytest.mark.parametrize("name,variant", [("C4", ""), ("bact20", ""), ("human8f", "-p0 -a1"), ("human8", "-S"), ("wide0", ""), ("wide3", "-S")])
 def test_matrix_on_the_gpu(built, tmp_path, name, variant):
     lib = capi.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0

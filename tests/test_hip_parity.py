@@ -537,7 +537,7 @@ def test_pga_create_checks_abi_version_and_block_contents(hip):
     abi = int(re.search(r"#define PGA_ABI_VERSION (\d+)u", hdr).group(1))
 
     class Block(C.Structure):
-        _fields_ = [(k, C.c_int32) for k in ("n_hit", "n_exon", "n_ctg", "max_cs", "max_cm", "max_score_adj", "any_neg", "any_multi")] + [("data", C.c_void_p), ("n_words", C.c_size_t)]
+        _fields_ = [(k, C.c_int32) for k in ("n_hit", "n_exon", "n_ctg", "max_cs", "max_cm", "max_score_adj", "any_neg", "any_multi")] + [("data", C.c_void_p), ("n_words", C.c_size_t), ("vfirst", C.c_void_p), ("vbase", C.c_void_p)]
 
     class Shard(C.Structure):
         _fields_ = [("abi_version", C.c_uint32), ("n_genome", C.c_int32), ("n_genome_global", C.c_int32), ("genome_global", C.c_void_p), ("n_prot", C.c_int32),
@@ -546,13 +546,15 @@ def test_pga_create_checks_abi_version_and_block_contents(hip):
     class Par(C.Structure):
         _fields_ = [("min_ov_ratio", C.c_double), ("check_strand", C.c_int32), ("drop_sgl_exon", C.c_int32), ("reserved", C.c_int32 * 4)]
 
-    def attempt(version=abi, cid=0, cs=100, offx=0):
+    def attempt(version=abi, cid=0, cs=100, offx=0, vfirst=None, vbase=None):
         n, ne = 2, 2
         planes = np.zeros((10, n), np.int32)  # pid, contig, rank, score_ori, score_adj, n_exon, off_exon, cs, ce, cm
         planes[0] = [0, 1]; planes[1] = [0, cid]; planes[3] = planes[4] = 50; planes[5] = 1; planes[6] = [0, offx]
         planes[7] = [10, cs]; planes[8] = planes[7] + 90; planes[9] = planes[7] + 45
         words = np.concatenate([planes.ravel(), np.zeros(1, np.int32), np.array([0, 90, 0, 90], np.int32)])
-        blk = Block(n, ne, 1, 100, 145, 50, 0, 0, words.ctypes.data, words.size)
+        vf = np.asarray(vfirst, np.int32) if vfirst is not None else None
+        vb = np.asarray(vbase, np.int64) if vbase is not None else None
+        blk = Block(n, ne, 1 if vf is None else len(vf), 100, 145, 50, 0, 0, words.ctypes.data, words.size, vf.ctypes.data if vf is not None else None, vb.ctypes.data if vb is not None else None)
         gg, pg, pref = np.zeros(1, np.int32), np.array([0, 1], np.int32), np.zeros(2, np.uint8)
         sh = Shard(version, 1, 1, gg.ctypes.data, 2, 2, n, ne, C.addressof(blk), pg.ctypes.data, pref.ctypes.data)
         par, ctx = Par(0.5, 0, 0), C.c_void_p()
@@ -568,6 +570,12 @@ def test_pga_create_checks_abi_version_and_block_contents(hip):
     assert attempt(cid=1) == -2            # PGA_ERR_RANGE: contig 1 of a genome with one contig
     assert attempt(cs=101) == -2           # beyond the declared max_cs: the sort key would lose its top bit
     assert attempt(offx=2) == -2           # exon range outside the genome's exon list
+    # virtual contigs (64-bit coordinates): both tables or none, pieces of a contig consecutive and in coordinate order
+    assert attempt(cid=1, vfirst=[0, 0], vbase=[0, 1 << 40]) == 0
+    assert attempt(cid=1, vfirst=[0, 0]) == -3
+    assert attempt(cid=1, vfirst=[0, 0], vbase=[1 << 40, 0]) == -3   # bases go backwards
+    assert attempt(cid=1, vfirst=[0, 2], vbase=[0, 0]) == -3         # a first piece that comes later
+    assert attempt(cid=1, vfirst=[0, 1], vbase=[0, -1]) == -3
 
 
 _XLOOP_CODE = r'''
