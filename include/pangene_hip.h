@@ -79,7 +79,10 @@ typedef struct {
 	 * -- the walk of pg_gen_arc (graph.c:113-121: same-contig test, dist = cm - vpos, which the reference itself truncates to int32_t,
 	 * graph.c:73) and pg_gen_rep_pos / pg_n_local (branch.c:6-46: same contig, 64-bit |cm1 - cm2|) -- put the pieces together again
 	 * with these two tables.  vfirst[v] = the first piece of the contig piece v belongs to (the contig's identity; v itself for a contig
-	 * that was not cut); vbase[v] = what was subtracted from the coordinates of piece v.  Both NULL: no contig of the genome was cut. */
+	 * that was not cut); vbase[v] = what was subtracted from the coordinates of piece v.  Both NULL: no contig of the genome was cut.
+	 * The pieces of a contig are consecutive and in coordinate order (vfirst[v] <= v, vfirst[v] == vfirst[v - 1] or v, vbase not decreasing
+	 * inside a contig: PGA_ERR_ARG otherwise), and every hit of piece v + 1 starts AFTER the last base of piece v (the packer's rule:
+	 * graph_driver.cpp, virtual_contigs) -- the (contig, cs) and (contig, cm) orders of the pieces are then those of the contig. */
 	const int32_t *vfirst;                   /* [n_ctg] or NULL */
 	const int64_t *vbase;                    /* [n_ctg] or NULL */
 } pga_genome_block_t;
