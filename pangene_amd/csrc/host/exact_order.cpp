@@ -219,7 +219,7 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 	};
 	int64_t tot = 0;
 	for (size_t k = 0; k < ng; ++k) tot += d->genome[ext->local_genomes[k]].n_hit;
-	unsigned nt = tot > 200000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+	unsigned nt = tot > 200000 ? host_threads(16u) : 1u;
 	if (nt > ng) nt = (unsigned)ng;
 	if (nt <= 1) { for (size_t k = 0; k < ng; ++k) do_genome(k); }
 	else {
@@ -300,7 +300,7 @@ static void spawn_replay(DataExt *ext)
 	const bool all = exact_mode() == 2;
 	size_t tot = 0;
 	for (const ExactSeg &s : ext->xsegs) tot += s.file.size();
-	unsigned nt = tot > 50000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+	unsigned nt = tot > 50000 ? host_threads(16u) : 1u;
 	if (nt > ext->xsegs.size()) nt = (unsigned)ext->xsegs.size();
 	ext->xnext.store(0);
 	for (unsigned t = 0; t < nt; ++t)

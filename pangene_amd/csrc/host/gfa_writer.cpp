@@ -233,7 +233,7 @@ void pg_write_walk(pg_graph_t *q)
 			i0 = i;
 		}
 	};
-	unsigned nt = ext->n_hit_local > 200000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u) : 1u;
+	unsigned nt = ext->n_hit_local > 200000 ? host_threads(32u) : 1u;
 	if (nt > (unsigned)d->n_genome) nt = (unsigned)std::max(1, d->n_genome);
 	if (nt <= 1) {
 		std::vector<char> buf;

@@ -239,7 +239,7 @@ void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, doub
 		if (pk.buf != nullptr && (pk.blk.n_hit != d->genome[j].n_hit || pk.blk.n_exon != d->genome[j].n_exon || (!sorted && pk.sig != genome_signature(&d->genome[j])))) pk = GenomePack(); // stale: the slab keeps the old bytes until the upload is over
 		if (pk.buf == nullptr) todo.push_back(j), hits += d->genome[j].n_hit;
 	}
-	unsigned nt = hits > 100000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u) : 1u;
+	unsigned nt = hits > 100000 ? host_threads(64u) : 1u;
 	if (nt > todo.size()) nt = (unsigned)todo.size();
 	if (nt <= 1) { for (int32_t j : todo) pack_one(d, ext, j); }
 	else {
@@ -534,7 +534,7 @@ int sync_host(pg_data_t *d, bool full)
 				const int32_t *old = ext->file_of_host[(size_t)j].data(); // host index -> file index
 				for (int32_t h = 0; h < g->n_hit; ++h) a[px[(size_t)(off + old[h])]] = g->hit[h];
 			}
-			std::free(g->hit);
+			if (!ext->arena_owns(g->hit)) std::free(g->hit); // (a batch read's arrays lie in its arena)
 			g->hit = a, g->m_hit = g->n_hit;
 			ext->hits_sorted[(size_t)j] = 1;
 			ext->file_of_host[(size_t)j].assign((size_t)g->n_hit, 0);
@@ -557,7 +557,7 @@ int sync_host(pg_data_t *d, bool full)
 	};
 	if (need_pos || full) { // genomes are independent and the 88-byte records are scattered: spread them over host threads
 		const size_t ng = ext->local_genomes.size();
-		unsigned nt = N > 200000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+		unsigned nt = N > 200000 ? host_threads(16u) : 1u;
 		if (nt > ng) nt = (unsigned)ng;
 		if (nt <= 1) { for (size_t k = 0; k < ng; ++k) do_genome(k); }
 		else {

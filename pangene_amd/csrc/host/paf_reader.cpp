@@ -5,7 +5,9 @@
 // pg_hash_uint32(pid) and the first-seen numbering are score-relevant downstream.
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
+#include <sched.h>
 #include <unistd.h>
 #include <zlib.h>
 #include <cctype>
@@ -24,6 +26,28 @@ namespace pgx {
 
 static std::unordered_map<const pg_data_t *, DataExt *> g_ext;
 static std::mutex g_ext_mu;
+
+unsigned host_threads(unsigned cap)
+{
+	static const unsigned budget = [] {
+		unsigned n = std::max(1u, std::thread::hardware_concurrency());
+		cpu_set_t set;
+		if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min<unsigned>(n, (unsigned)c); }
+		long long quota = -1, period = -1;
+		if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota|max> <period>"
+			char q[32] = {0};
+			if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atoll(q);
+			std::fclose(f);
+		} else { // cgroup v1
+			if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%lld", &quota) != 1) quota = -1; std::fclose(g); }
+			if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%lld", &period) != 1) period = -1; std::fclose(g); }
+		}
+		if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+		if (const char *e = std::getenv("PANGENE_HOST_THREADS")) if (std::atoi(e) > 0) n = (unsigned)std::atoi(e);
+		return n;
+	}();
+	return std::max(1u, std::min(budget, cap));
+}
 
 DataExt *ext_of(const pg_data_t *d, bool create)
 {
@@ -45,6 +69,7 @@ void ext_drop(const pg_data_t *d)
 	exact_shutdown(e);
 	if (e->ctx && e->be) e->be->destroy(e->ctx);
 	free_packs(e, true);
+	for (DataExt::HostArena &a : e->arenas) if (a.map) munmap(a.map, a.map_bytes);
 	delete e;
 	g_ext.erase(it);
 	if (g_ext.empty()) trim_host_caches((size_t)256 << 20); // no data set left: most of the page-locked memory goes back
@@ -113,6 +138,12 @@ public:
 		p_ = tl_buf.data(), end_ = p_ + got, ok_ = true;
 	}
 	bool ok() const { return ok_; }
+	size_t count_lines() const { // an upper bound of the hits the file holds
+		size_t n = 0;
+		for (const char *q = p_; q < end_;) { const char *nl = (const char *)std::memchr(q, '\n', (size_t)(end_ - q)); ++n; if (!nl) break; q = nl + 1; }
+		return n;
+	}
+	size_t text_bytes() const { return (size_t)(end_ - p_); }
 	bool next(char *&line, size_t &len) { // the line is followed by a byte the caller may overwrite
 		if (p_ >= end_) return false;
 		char *nl = (char *)std::memchr(p_, '\n', (size_t)(end_ - p_));
@@ -126,6 +157,19 @@ private:
 	char *p_ = nullptr, *end_ = nullptr;
 	bool ok_ = false;
 };
+
+// read.c:216: score_adj = (int32_t)(score_ori * expl(x) + .499), long double arithmetic.  expl costs ~250 cycles a line -- a fifth of the
+// whole parse -- and only the INTEGER part of the result is kept: exp() in double (error < 1 ulp) gives the same integer unless the
+// value lies within a few 1e-16 (relative) of a whole number; only then (about once in 1e7 lines) the long double route decides.
+static inline int32_t score_adjusted(int32_t score_ori, double x)
+{
+	const double t = (double)score_ori * std::exp(x) + .499, a = std::fabs(t);
+	if (a < 2.0e9 && std::isfinite(t)) {
+		const double nearest = std::nearbyint(t), band = a * 4.0e-15 + 1.0e-12; // (double rounding of exp, of the product and of the sum: < 4 ulp of t, with room)
+		if (std::fabs(t - nearest) > band) return (int32_t)t;
+	}
+	return (int32_t)(score_ori * expl(x) + .499);
+}
 
 // strtol(q, 0, 10) for the digit strings of a PAF line: optional blanks and sign, then digits (anything else ends the number)
 static inline int64_t parse_i64(const char *q)
@@ -178,8 +222,15 @@ static bool cigar_to_exons(const char *cg, bool rev, int64_t span, std::vector<p
 	int32_t fs = 0;
 	const char *p = cg;
 	while (*p) {
-		char *r;
-		int64_t l = std::strtol(p, &r, 10);
+		const char *r = p;
+		int64_t l = 0;
+		if ((unsigned)(*r - '0') < 10u) { // the usual op: plain digits (strtol's other forms -- blanks, a sign -- below)
+			uint64_t v = 0;
+			int nd = 0;
+			while ((unsigned)(*r - '0') < 10u && nd < 18) v = v * 10 + (uint64_t)(*r - '0'), ++r, ++nd;
+			l = (int64_t)v;
+			if ((unsigned)(*r - '0') < 10u) { char *e; l = std::strtol(p, &e, 10); r = e; } // 19+ digits: strtol's saturation
+		} else { char *e; l = std::strtol(p, &e, 10); r = e; }
 		char op = *r;
 		if (op == 'N' || op == 'U' || op == 'V') {
 			int64_t st, en;
@@ -200,13 +251,14 @@ static bool cigar_to_exons(const char *cg, bool rev, int64_t span, std::vector<p
 	ex.back().oe = (int32_t)x;
 	*n_fs = fs;
 	if (x != span) return false;
-	if (rev) { // flip to ascending contig coordinates
-		std::vector<pg_exon_t> t(ex.size());
-		for (size_t i = 0; i < ex.size(); ++i) {
-			const pg_exon_t &s = ex[ex.size() - 1 - i];
-			t[i].os = (int32_t)(x - s.oe), t[i].oe = (int32_t)(x - s.os);
+	if (rev) { // flip to ascending contig coordinates (in place: element i <-> n - 1 - i)
+		const size_t n = ex.size();
+		for (size_t i = 0; i < n / 2; ++i) {
+			const pg_exon_t a = ex[i], b = ex[n - 1 - i];
+			ex[i].os = (int32_t)(x - b.oe), ex[i].oe = (int32_t)(x - b.os);
+			ex[n - 1 - i].os = (int32_t)(x - a.oe), ex[n - 1 - i].oe = (int32_t)(x - a.os);
 		}
-		ex.swap(t);
+		if (n & 1) { const pg_exon_t a = ex[n / 2]; ex[n / 2].os = (int32_t)(x - a.oe), ex[n / 2].oe = (int32_t)(x - a.os); }
 	}
 	return true;
 }
@@ -226,6 +278,55 @@ static char *file_label(const char *fn) // read.c:92-105
 	return label;
 }
 
+// Names that are in the global dictionaries already get their ids before the commit, from a frozen SNAPSHOT of the dictionaries
+// (an immutable map published by the committing thread after the first file and whenever a thousand names have come since):
+// look-ups need no lock and never wait for a commit, the commit never waits for a reader.  A pangenome's files share nearly all
+// their names, so the sequential part of a batch read shrinks from "every name of every file" to the names a file is the first
+// to bring (names missing from the snapshot are resolved by the commit itself).
+// The snapshot also keeps the ATTRIBUTES the commit would assign (gene: preferred / included / len, protein: gene / len; read.c:147-177):
+// an entry of a file that would assign exactly what is there already is left out of the commit altogether.  What the commits change
+// after a snapshot goes into a change log (ChangeLog, appended under the commit lock); a file resolved against a snapshot that is
+// `k` changes old re-applies its own entries for those k ids -- the sequential part of a batch read is then "the names and values a
+// file is the first to bring", not "every name of every file" (0.16-0.47 s of a 0.5 s read of 1250 files before).
+struct DictSnap {
+	FlatIndex genes, prots; // (the names themselves stay in the global dictionaries: they never move)
+	std::vector<uint8_t> g_pref, g_incl; std::vector<uint32_t> g_len; std::vector<int32_t> p_gid, p_len;
+	int64_t log_pos = 0;
+};
+struct ChangeLog { std::vector<std::pair<uint8_t, int32_t>> v; }; // (0 gene | 1 protein, global id): an attribute of an id that existed before got another value
+// A file's genes (or proteins) under LOCAL ids = the order the file saw them first.  A name the snapshot holds is never copied or hashed
+// into a table of the file's own -- its local id hangs on its global id through an array -- only names new to the snapshot go into a
+// small dictionary.  (A bacterial genome brings 10 000 names, all but a few known after the first file: building two dictionaries
+// per file was a fifth of the parse.)
+struct LocalNames {
+	const FlatIndex *known = nullptr;     // the snapshot's index at parse time (its ids are global ids), or NULL
+	std::vector<int32_t> lid_of_global;   // [known->size()] local id, -1 = not seen in this file
+	NameDict fresh;                       // the names `known` does not hold, first-seen order
+	std::vector<int32_t> lid_of_fresh;    // fresh id -> local id
+	std::vector<int32_t> global;          // local id -> global id, -1 = not known yet (resolved by preresolve() or the commit)
+	std::vector<int32_t> fresh_of;        // local id -> fresh id, -1 = a known name
+	int32_t size() const { return (int32_t)global.size(); }
+	void bind(const FlatIndex *k) { known = k; lid_of_global.assign(k ? (size_t)k->size() : 0, -1); }
+	int32_t put(std::string_view s, int32_t known_id, bool *absent) { // known_id: what known->find(s) gave (the caller has looked)
+		if (known_id >= 0) {
+			int32_t &l = lid_of_global[(size_t)known_id];
+			*absent = l < 0;
+			if (l < 0) l = (int32_t)global.size(), global.push_back(known_id), fresh_of.push_back(-1);
+			return l;
+		}
+		const int32_t f = fresh.put(s, absent);
+		if (*absent) lid_of_fresh.push_back((int32_t)global.size()), global.push_back(-1), fresh_of.push_back(f);
+		return lid_of_fresh[(size_t)f];
+	}
+	std::string_view view(int32_t lid) const { return fresh_of[(size_t)lid] >= 0 ? fresh.view(fresh_of[(size_t)lid]) : known->view(global[(size_t)lid]); }
+	const char *name(int32_t lid) const { return fresh_of[(size_t)lid] >= 0 ? fresh.name(fresh_of[(size_t)lid]) : known->name(global[(size_t)lid]); }
+	int32_t local_of(int32_t gid, std::string_view nm) const { // the file's entry for global id `gid` (whose name is nm), -1 = none
+		if ((size_t)gid < lid_of_global.size()) return lid_of_global[(size_t)gid];
+		const int32_t f = fresh.get(nm);
+		return f < 0 ? -1 : lid_of_fresh[(size_t)f];
+	}
+};
+
 // One parsed PAF file, self-contained (no global ids yet): parsing is thread-safe and files can be parsed in
 // parallel; commit_file() then assigns the global ids sequentially in command-line order, which reproduces the
 // reference's first-seen numbering (read.c:151-168) -- pg_hash_uint32(pid) makes the numbering score-relevant.
@@ -233,23 +334,34 @@ struct alignas(128) FileParse { // (files next to each other on the command line
 	bool opened = false, ids_only = false;
 	char *label = nullptr;
 	int32_t n_tot = 0;
-	NameDict genes, prots, ctgs;              // local first-seen ids
+	LocalNames genes, prots;                   // local first-seen ids
+	NameDict ctgs;
+	std::shared_ptr<const DictSnap> snap;      // what genes / prots are bound to
 	std::vector<uint8_t> g_pref, g_incl;      // per local gene (read.c:147-150,158-159)
 	std::vector<int32_t> g_len, p_gene, p_len; // gene.len = max protein len (read.c:177); prot.gid, prot.len of the last line
 	std::vector<int64_t> ctg_len;
 	// pid / cid are LOCAL ids.  Plain malloc'ed arrays: they become the genome's own g->hit / g->exon (freed by pg_data_destroy)
 	pg_hit_t *hits = nullptr; int32_t n_hit = 0, m_hit = 0;
 	pg_exon_t *exons = nullptr; int32_t n_exon = 0, m_exon = 0;
-	std::vector<int32_t> gmap, pmap;          // local -> global ids, -1 = not known yet (resolved at commit time)
+	bool hits_arena = false, exons_arena = false; // the array lies in the batch read's arena (DataExt::arenas): never free()'d or realloc'ed
+	DataExt::HostArena *arena = nullptr;       // where a batch read's files take their arrays from (NULL: malloc)
+	// what preresolve() left for the commit: the local genes / proteins whose names or attributes the dictionary snapshot does not
+	// already hold exactly as this file would set them; snap_log = position of the change log the snapshot was taken at (-1: no snapshot)
+	std::vector<int32_t> todo_g, todo_p;
+	int64_t snap_log = -1;
 	int32_t genome = -1;                      // index of the genome the commit appended
-	~FileParse() { std::free(hits); std::free(exons); std::free(label); }
+	~FileParse() { if (!hits_arena) std::free(hits); if (!exons_arena) std::free(exons); std::free(label); }
 };
 
-template <class T> static inline bool push_raw(T *&a, int32_t &n, int32_t &m, const T &v)
+template <class T> static inline bool push_raw(T *&a, int32_t &n, int32_t &m, const T &v, bool &in_arena)
 {
 	if (n == m || a == nullptr) {
 		const int32_t m2 = (m && a) ? m + (m >> 1) : 4096;
-		T *b = (T *)std::realloc((void *)a, sizeof(T) * (size_t)m2);
+		T *b;
+		if (in_arena && a) { // an arena slice that turned out too small: the array moves to the heap (the slice is left behind)
+			b = (T *)std::malloc(sizeof(T) * (size_t)m2);
+			if (b) std::memcpy((void *)b, (const void *)a, sizeof(T) * (size_t)n), in_arena = false;
+		} else b = (T *)std::realloc((void *)a, sizeof(T) * (size_t)m2);
 		if (b == nullptr) return false; // out of memory: the element is dropped (the caller reports it)
 		a = b, m = m2;
 	}
@@ -280,8 +392,10 @@ static inline void *big_malloc(size_t bytes)
 	return p;
 }
 
-static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileParse &fp)
+static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileParse &fp, const std::shared_ptr<const DictSnap> &snap_now = nullptr)
 {
+	fp.snap = snap_now;
+	fp.genes.bind(fp.snap ? &fp.snap->genes : nullptr), fp.prots.bind(fp.snap ? &fp.snap->prots : nullptr);
 	WholeFile whole(fn); // plain files: one read, lines parsed in place; everything else (gzip, stdin) through zlib
 	std::unique_ptr<LineSource> src;
 	if (!whole.ok()) src.reset(new LineSource(fn));
@@ -294,8 +408,15 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 		if (stat(fn, &sb) == 0 && sb.st_size > 0) {
 			const size_t len = std::strlen(fn);
 			const size_t text = (size_t)sb.st_size * (len > 3 && std::strcmp(fn + len - 3, ".gz") == 0 ? 5 : 1);
-			fp.m_hit = (int32_t)std::min<size_t>(text / 120 + 64, (size_t)1 << 30), fp.hits = (pg_hit_t *)big_malloc(sizeof(pg_hit_t) * (size_t)fp.m_hit);
-			fp.m_exon = (int32_t)std::min<size_t>(text / 100 + 64, (size_t)1 << 30), fp.exons = (pg_exon_t *)big_malloc(sizeof(pg_exon_t) * (size_t)fp.m_exon);
+			fp.m_hit = (int32_t)std::min<size_t>(text / 120 + 64, (size_t)1 << 30), fp.m_exon = (int32_t)std::min<size_t>(text / 100 + 64, (size_t)1 << 30);
+			if (fp.arena && whole.ok()) { // a batch read: slices of its huge-page arena, the hits' by the exact number of lines
+				fp.m_hit = (int32_t)std::min<size_t>(whole.count_lines() + 1, (size_t)1 << 30);
+				const size_t hb = (sizeof(pg_hit_t) * (size_t)fp.m_hit + 63) & ~(size_t)63, eb = (sizeof(pg_exon_t) * (size_t)fp.m_exon + 63) & ~(size_t)63;
+				const size_t at = fp.arena->used.fetch_add(hb + eb);
+				if (at + hb + eb <= fp.arena->bytes) fp.hits = (pg_hit_t *)(fp.arena->base + at), fp.exons = (pg_exon_t *)(fp.arena->base + at + hb), fp.hits_arena = fp.exons_arena = true;
+			}
+			if (fp.hits == nullptr) fp.hits = (pg_hit_t *)big_malloc(sizeof(pg_hit_t) * (size_t)fp.m_hit);
+			if (fp.exons == nullptr) fp.exons = (pg_exon_t *)big_malloc(sizeof(pg_exon_t) * (size_t)fp.m_exon);
 			if (fp.hits == nullptr) fp.m_hit = 0; // (no room for the estimate: grow on demand)
 			if (fp.exons == nullptr) fp.m_exon = 0;
 		}
@@ -309,6 +430,7 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 	// the growing arrays and their counters as locals while the file is parsed (written back once, at the end)
 	pg_hit_t *hits = fp.hits; int32_t n_hit = fp.n_hit, m_hit = fp.m_hit;
 	pg_exon_t *exons = fp.exons; int32_t n_exon = fp.n_exon, m_exon = fp.m_exon;
+	bool hits_arena = fp.hits_arena, exons_arena = fp.exons_arena;
 	int32_t n_tot = 0;
 	for (;;) {
 		char *s;
@@ -327,8 +449,7 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 		bool dropped = false;
 		char *const line_end = s + line_len;
 		for (char *p = s;; ++p) {
-			p = (char *)std::memchr(p, '\t', (size_t)(line_end - p));
-			if (p == nullptr) p = line_end;
+			while (p < line_end && *p != '\t') ++p; // (fields are a few bytes long: a loop beats a call)
 			char term = *p;
 			*p = 0;
 			if (col == 0 && last_pid >= 0 && (size_t)(p - q) == last_name.size() && std::memcmp(q, last_name.data(), last_name.size()) == 0) {
@@ -347,11 +468,19 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 				if (excl && excl->get(q) >= 0) { dropped = true; break; }
 				int32_t is_pref = pref && pref->get(q) >= 0, is_incl = incl && incl->get(q) >= 0;
 				bool absent;
-				gid = fp.genes.put(q, &absent);
 				if (has_delim) *r = (char)opt->gene_delim;
+				const std::string_view gv(q, (size_t)(r - q)), pv(q, (size_t)(p - q));
+				// the protein first: the snapshot knows its gene (the same name gives the same gene: checked against the prefix)
+				int32_t kp = -1, kg = -1;
+				if (fp.snap) {
+					kp = fp.snap->prots.find(pv);
+					if (kp >= 0) { const int32_t g0 = fp.snap->p_gid[(size_t)kp]; if (g0 >= 0 && g0 < fp.snap->genes.size() && fp.snap->genes.view(g0) == gv) kg = g0; }
+					if (kg < 0) kg = fp.snap->genes.find(gv);
+				}
+				gid = fp.genes.put(gv, kg, &absent);
 				if (absent) fp.g_pref.push_back(0), fp.g_incl.push_back(0), fp.g_len.push_back(0);
 				fp.g_pref[(size_t)gid] = (uint8_t)is_pref, fp.g_incl[(size_t)gid] = (uint8_t)is_incl;
-				pid = fp.prots.put(q, &absent);
+				pid = fp.prots.put(pv, kp, &absent);
 				if (absent) fp.p_gene.push_back(0), fp.p_len.push_back(0), rank_of.push_back(-1);
 				fp.p_gene[(size_t)pid] = gid;
 				fp.p_len[(size_t)pid] = 0; // read.c:168
@@ -382,17 +511,19 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 				hit.blen = (int32_t)parse_i64(q);
 				if (hit.mlen < hit.blen * opt->min_prot_iden) { dropped = true; break; }
 			} else if (col >= 12) {
-				if (std::strncmp(q, "ms:i:", 5) == 0) { // read.c:212-216: long double exp, then truncation
+				const bool tag5 = p - q >= 5 && q[2] == ':' && q[4] == ':';
+				if (!tag5) { }
+				else if (q[0] == 'm' && q[1] == 's' && q[3] == 'i') { // read.c:212-216: long double exp, then truncation
 					double div = 1.0 - (double)hit.mlen / hit.blen;
 					double uncov = 1.0 - (double)(hit.qe - hit.qs) / fp.p_len[(size_t)pid];
 					hit.score_ori = (int32_t)parse_i64(q + 5);
-					hit.score_adj = (int32_t)(hit.score_ori * expl(-opt->score_adj_coef * (div + uncov)) + .499);
-				} else if (std::strncmp(q, "fs:i:", 5) == 0) n_fs = (int32_t)parse_i64(q + 5);
-				else if (std::strncmp(q, "st:i:", 5) == 0) n_stop = (int32_t)parse_i64(q + 5);
-				else if (std::strncmp(q, "cg:Z:", 5) == 0) {
+					hit.score_adj = score_adjusted(hit.score_ori, -opt->score_adj_coef * (div + uncov));
+				} else if (q[0] == 'f' && q[1] == 's' && q[3] == 'i') n_fs = (int32_t)parse_i64(q + 5);
+				else if (q[0] == 's' && q[1] == 't' && q[3] == 'i') n_stop = (int32_t)parse_i64(q + 5);
+				else if (q[0] == 'c' && q[1] == 'g' && q[3] == 'Z') {
 					if (cigar_to_exons(q + 5, hit.rev, hit.ce - hit.cs, ex, &cig_fs)) {
 						hit.n_exon = (int32_t)ex.size(), hit.off_exon = n_exon, hit.lof = cig_fs;
-						for (const pg_exon_t &e : ex) if (!push_raw(exons, n_exon, m_exon, e)) oom = true;
+						for (const pg_exon_t &e : ex) if (!push_raw(exons, n_exon, m_exon, e, exons_arena)) oom = true;
 						have_exons = true;
 					} else if (pg_verbose >= 1) {
 						std::fprintf(stderr, "[W::%s] CIGAR of line %d in '%s' does not span the alignment; hit dropped\n", __func__, n_tot, fn ? fn : "-");
@@ -407,41 +538,50 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 		if (hit.lof < lof) hit.lof = lof;
 		hit.cm = middle_cds(hit.cs, exons + hit.off_exon, hit.n_exon);
 		if (hit.cm < 0 || oom) continue;
-		if (!push_raw(hits, n_hit, m_hit, hit)) oom = true;
+		if (!push_raw(hits, n_hit, m_hit, hit, hits_arena)) oom = true;
 	}
 	fp.hits = hits, fp.n_hit = n_hit, fp.m_hit = m_hit, fp.exons = exons, fp.n_exon = n_exon, fp.m_exon = m_exon, fp.n_tot = n_tot;
+	fp.hits_arena = hits_arena, fp.exons_arena = exons_arena;
 	if (oom && pg_verbose >= 1) std::fprintf(stderr, "[E::%s] out of memory while reading '%s': hits were dropped\n", __func__, fn ? fn : "-");
 }
 
-// Names that are in the global dictionaries already get their ids before the commit, from a frozen SNAPSHOT of the dictionaries
-// (an immutable map published by the committing thread after the first file and whenever a thousand names have come since):
-// look-ups need no lock and never wait for a commit, the commit never waits for a reader.  A pangenome's files share nearly all
-// their names, so the sequential part of a batch read shrinks from "every name of every file" to the names a file is the first
-// to bring (names missing from the snapshot are resolved by the commit itself).
-struct DictSnap { std::unordered_map<std::string_view, int32_t> genes, prots; };
 static std::shared_mutex g_dict_mu; // writers of pg_data_t's growing arrays (batch and single-file reads)
 
-static void snap_refresh(const pg_data_t *d, std::shared_ptr<const DictSnap> &slot)
+static void snap_refresh(const pg_data_t *d, std::shared_ptr<const DictSnap> &slot, int64_t log_pos)
 {
 	const NameDict *dg = (const NameDict *)d->d_gene, *dp = (const NameDict *)d->d_prot;
 	auto s = std::make_shared<DictSnap>();
-	s->genes.reserve((size_t)dg->size() * 2), s->prots.reserve((size_t)dp->size() * 2);
-	for (int32_t i = 0; i < dg->size(); ++i) s->genes.emplace(std::string_view(dg->name(i)), i);
-	for (int32_t i = 0; i < dp->size(); ++i) s->prots.emplace(std::string_view(dp->name(i)), i);
+	const size_t ng = (size_t)dg->size(), np = (size_t)dp->size();
+	s->genes.reserve(ng), s->prots.reserve(np);
+	s->g_pref.resize(ng), s->g_incl.resize(ng), s->g_len.resize(ng), s->p_gid.resize(np), s->p_len.resize(np);
+	for (int32_t i = 0; i < dg->size(); ++i) s->genes.add(dg->name(i), dg->view(i).size(), FlatIndex::hash(dg->view(i))), s->g_pref[(size_t)i] = d->gene[i].preferred, s->g_incl[(size_t)i] = d->gene[i].included, s->g_len[(size_t)i] = d->gene[i].len;
+	for (int32_t i = 0; i < dp->size(); ++i) s->prots.add(dp->name(i), dp->view(i).size(), FlatIndex::hash(dp->view(i))), s->p_gid[(size_t)i] = d->prot[i].gid, s->p_len[(size_t)i] = d->prot[i].len;
+	s->log_pos = log_pos;
 	std::atomic_store(&slot, std::shared_ptr<const DictSnap>(s));
 }
 
 static void preresolve(const std::shared_ptr<const DictSnap> &slot, FileParse &fp)
 {
-	fp.gmap.assign((size_t)fp.genes.size(), -1), fp.pmap.assign((size_t)fp.prots.size(), -1);
-	const std::shared_ptr<const DictSnap> s = std::atomic_load(&slot);
+	fp.todo_g.clear(), fp.todo_p.clear(), fp.snap_log = -1;
+	const std::shared_ptr<const DictSnap> s = std::atomic_load(&slot); // the newest one (the file was parsed against fp.snap, the same or an older one: ids never change)
 	if (!s) return;
-	for (int32_t i = 0; i < fp.genes.size(); ++i) { auto it = s->genes.find(std::string_view(fp.genes.name(i))); if (it != s->genes.end()) fp.gmap[(size_t)i] = it->second; }
-	for (int32_t i = 0; i < fp.prots.size(); ++i) { auto it = s->prots.find(std::string_view(fp.prots.name(i))); if (it != s->prots.end()) fp.pmap[(size_t)i] = it->second; }
+	for (int32_t i = 0; i < fp.genes.size(); ++i) {
+		int32_t &g = fp.genes.global[(size_t)i];
+		if (g < 0) g = s->genes.find(fp.genes.view(i));
+		// what commit_ids would do to this gene changes nothing: preferred / included are assigned (read.c:158-159), len only grows (read.c:177)
+		if (g < 0 || s->g_pref[(size_t)g] != fp.g_pref[(size_t)i] || s->g_incl[(size_t)g] != fp.g_incl[(size_t)i] || (int32_t)s->g_len[(size_t)g] < fp.g_len[(size_t)i]) fp.todo_g.push_back(i);
+	}
+	for (int32_t i = 0; i < fp.prots.size(); ++i) {
+		int32_t &q = fp.prots.global[(size_t)i];
+		if (q < 0) q = s->prots.find(fp.prots.view(i));
+		const int32_t g = fp.genes.global[(size_t)fp.p_gene[(size_t)i]];
+		if (q < 0 || g < 0 || s->p_gid[(size_t)q] != g || s->p_len[(size_t)q] != fp.p_len[(size_t)i]) fp.todo_p.push_back(i);
+	}
+	fp.snap_log = s->log_pos;
 }
 
 // sequential part: global ids in first-seen order (the numbering of per-line dict_put calls, read.c:151-168), genome appended to `d`
-static int32_t commit_ids(pg_data_t *d, FileParse &fp)
+static int32_t commit_ids(pg_data_t *d, FileParse &fp, ChangeLog *log = nullptr)
 {
 	if (!fp.opened) return -1;
 	NameDict *dg = (NameDict *)d->d_gene, *dp = (NameDict *)d->d_prot, *dc = (NameDict *)d->d_ctg;
@@ -455,32 +595,54 @@ static int32_t commit_ids(pg_data_t *d, FileParse &fp)
 	if (ext->is_local.size() < (size_t)d->n_genome) ext->is_local.resize((size_t)d->n_genome, 0);
 	if (ext->hits_sorted.size() < (size_t)d->n_genome) ext->hits_sorted.resize((size_t)d->n_genome, 0);
 	ext->is_local[(size_t)d->n_genome - 1] = fp.ids_only ? 0 : 1;
-	if (fp.gmap.size() != (size_t)fp.genes.size()) fp.gmap.assign((size_t)fp.genes.size(), -1);
-	if (fp.pmap.size() != (size_t)fp.prots.size()) fp.pmap.assign((size_t)fp.prots.size(), -1);
-	// genes then proteins, each in the order this file saw them first
-	for (int32_t i = 0; i < fp.genes.size(); ++i) {
-		int32_t gid = fp.gmap[(size_t)i];
+	// genes then proteins, each in the order this file saw them first (an id's attributes depend on this file's entry for THAT id
+	// only, so any subset of the entries can be applied on its own)
+	auto one_gene = [&](int32_t i) {
+		int32_t gid = fp.genes.global[(size_t)i];
+		bool fresh = false;
 		if (gid < 0) {
 			bool absent;
 			gid = dg->put(fp.genes.name(i), &absent);
-			if (absent) { d->n_gene++; grow0(d->gene, gid, d->m_gene); }
+			if (absent) { d->n_gene++; grow0(d->gene, gid, d->m_gene); fresh = true; }
 			d->gene[gid].name = dg->name(gid);
-			fp.gmap[(size_t)i] = gid;
+			fp.genes.global[(size_t)i] = gid;
 		}
+		const bool longer = (int32_t)d->gene[gid].len < fp.g_len[(size_t)i];
+		if (log && !fresh && (d->gene[gid].preferred != fp.g_pref[(size_t)i] || d->gene[gid].included != fp.g_incl[(size_t)i] || longer)) log->v.emplace_back((uint8_t)0, gid);
 		d->gene[gid].preferred = fp.g_pref[(size_t)i], d->gene[gid].included = fp.g_incl[(size_t)i];
-		if ((int32_t)d->gene[gid].len < fp.g_len[(size_t)i]) d->gene[gid].len = (uint32_t)fp.g_len[(size_t)i];
-	}
-	for (int32_t i = 0; i < fp.prots.size(); ++i) {
-		int32_t pid = fp.pmap[(size_t)i];
+		if (longer) d->gene[gid].len = (uint32_t)fp.g_len[(size_t)i];
+	};
+	auto one_prot = [&](int32_t i) {
+		int32_t pid = fp.prots.global[(size_t)i];
+		bool fresh = false;
 		if (pid < 0) {
 			bool absent;
 			pid = dp->put(fp.prots.name(i), &absent);
-			if (absent) { d->n_prot++; grow0(d->prot, pid, d->m_prot); }
+			if (absent) { d->n_prot++; grow0(d->prot, pid, d->m_prot); fresh = true; }
 			d->prot[pid].name = dp->name(pid);
-			fp.pmap[(size_t)i] = pid;
+			fp.prots.global[(size_t)i] = pid;
 		}
-		d->prot[pid].gid = fp.gmap[(size_t)fp.p_gene[(size_t)i]];
+		const int32_t gid = fp.genes.global[(size_t)fp.p_gene[(size_t)i]];
+		if (log && !fresh && (d->prot[pid].gid != gid || d->prot[pid].len != fp.p_len[(size_t)i])) log->v.emplace_back((uint8_t)1, pid);
+		d->prot[pid].gid = gid;
 		d->prot[pid].len = fp.p_len[(size_t)i];
+	};
+	const int64_t behind = (log && fp.snap_log >= 0) ? (int64_t)log->v.size() - fp.snap_log : -1;
+	if (behind >= 0 && behind <= 256) {
+		// the entries the snapshot did not settle, and this file's entries for the ids somebody changed since the snapshot
+		const int64_t l0 = fp.snap_log, l1 = (int64_t)log->v.size(); // (the entries applied here may append to the log: not looked at again)
+		for (int32_t i : fp.todo_g) one_gene(i);
+		for (int64_t k = l0; k < l1; ++k) if (log->v[(size_t)k].first == 0) { const int32_t li = fp.genes.local_of(log->v[(size_t)k].second, dg->view(log->v[(size_t)k].second)); if (li >= 0) one_gene(li); }
+		for (int32_t i : fp.todo_p) one_prot(i);
+		for (int64_t k = l0; k < l1; ++k) {
+			const std::pair<uint8_t, int32_t> c = log->v[(size_t)k];
+			if (c.first == 1) { const int32_t li = fp.prots.local_of(c.second, dp->view(c.second)); if (li >= 0) one_prot(li); }
+			else { // a gene whose id this file's proteins point at did not move (ids never change): nothing to do for them
+			}
+		}
+	} else {
+		for (int32_t i = 0; i < fp.genes.size(); ++i) one_gene(i);
+		for (int32_t i = 0; i < fp.prots.size(); ++i) one_prot(i);
 	}
 	if (!fp.ids_only) {
 		g->n_ctg = g->m_ctg = fp.ctgs.size();
@@ -503,15 +665,15 @@ static void finalize_genome(pg_data_t *d, FileParse &fp)
 {
 	if (!fp.opened || fp.ids_only || fp.genome < 0) return;
 	pg_genome_t *g = &d->genome[fp.genome];
-	for (int32_t i = 0; i < fp.n_hit; ++i) fp.hits[i].pid = fp.pmap[(size_t)fp.hits[i].pid];
+	for (int32_t i = 0; i < fp.n_hit; ++i) fp.hits[i].pid = fp.prots.global[(size_t)fp.hits[i].pid];
 	// (an estimate that was far too generous -- a .gz that compressed badly -- is given back: realloc in place, no copy)
-	if (fp.hits && (size_t)fp.m_hit > (size_t)fp.n_hit * 2 + 4096) { pg_hit_t *t = (pg_hit_t *)std::realloc((void *)fp.hits, sizeof(pg_hit_t) * (size_t)(fp.n_hit + 1)); if (t) fp.hits = t, fp.m_hit = fp.n_hit + 1; }
-	if (fp.exons && (size_t)fp.m_exon > (size_t)fp.n_exon * 2 + 4096) { pg_exon_t *t = (pg_exon_t *)std::realloc((void *)fp.exons, sizeof(pg_exon_t) * (size_t)(fp.n_exon + 1)); if (t) fp.exons = t, fp.m_exon = fp.n_exon + 1; }
+	if (fp.hits && !fp.hits_arena && (size_t)fp.m_hit > (size_t)fp.n_hit * 2 + 4096) { pg_hit_t *t = (pg_hit_t *)std::realloc((void *)fp.hits, sizeof(pg_hit_t) * (size_t)(fp.n_hit + 1)); if (t) fp.hits = t, fp.m_hit = fp.n_hit + 1; }
+	if (fp.exons && !fp.exons_arena && (size_t)fp.m_exon > (size_t)fp.n_exon * 2 + 4096) { pg_exon_t *t = (pg_exon_t *)std::realloc((void *)fp.exons, sizeof(pg_exon_t) * (size_t)(fp.n_exon + 1)); if (t) fp.exons = t, fp.m_exon = fp.n_exon + 1; }
 	g->n_hit = fp.n_hit, g->m_hit = fp.m_hit > 0 ? fp.m_hit : 1;
 	g->hit = fp.hits ? fp.hits : (pg_hit_t *)std::malloc(sizeof(pg_hit_t));
 	g->n_exon = fp.n_exon, g->m_exon = fp.m_exon > 0 ? fp.m_exon : 1;
 	g->exon = fp.exons ? fp.exons : (pg_exon_t *)std::malloc(sizeof(pg_exon_t));
-	fp.hits = nullptr, fp.exons = nullptr, fp.n_hit = fp.m_hit = fp.n_exon = fp.m_exon = 0;
+	fp.hits = nullptr, fp.exons = nullptr, fp.n_hit = fp.m_hit = fp.n_exon = fp.m_exon = 0, fp.hits_arena = fp.exons_arena = false;
 }
 
 static int32_t read_paf_impl(const pg_opt_t *opt, pg_data_t *d, const char *fn, bool ids_only)
@@ -540,11 +702,14 @@ pg_data_t *pg_data_init(void)
 void pg_data_destroy(pg_data_t *d)
 {
 	if (d == nullptr) return;
-	ext_drop(d);
+	const DataExt *ext = ext_of(d, false);
 	for (int32_t i = 0; i < d->n_genome; ++i) {
 		pg_genome_t *g = &d->genome[i];
-		std::free(g->ctg); std::free(g->hit); std::free(g->exon); std::free(g->label);
+		std::free(g->ctg); std::free(g->label);
+		if (!(ext && ext->arena_owns(g->hit))) std::free(g->hit);   // (arrays inside a batch read's arena go with the arena: ext_drop)
+		if (!(ext && ext->arena_owns(g->exon))) std::free(g->exon);
 	}
+	ext_drop(d);
 	std::free(d->genome); std::free(d->gene); std::free(d->prot);
 	delete (NameDict *)d->d_ctg; delete (NameDict *)d->d_gene; delete (NameDict *)d->d_prot;
 	std::free(d);
@@ -564,7 +729,7 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 	if (n <= 0) return 0;
 	if (n_threads <= 0) {
 		const char *e = std::getenv("PANGENE_READ_THREADS");
-		n_threads = e && std::atoi(e) > 0 ? std::atoi(e) : (int32_t)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u); // (beyond that the threads of one address space get in each other's way: page faults, allocator)
+		n_threads = e && std::atoi(e) > 0 ? std::atoi(e) : (int32_t)host_threads(64u); // (the CPU budget of the process, see host_threads; beyond 64 the threads of one address space get in each other's way: page faults, allocator)
 	}
 	if (n_threads > n) n_threads = n;
 	DataExt *ext = ext_of(d, true);
@@ -590,15 +755,41 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 		if (text > ((size_t)64 << 20)) slab_prefetch(std::min<size_t>(text / 5 * 2, (size_t)192 << 20), &slab_helper); // (up to the budget of freshly locked memory: block_alloc)
 	}
 	std::vector<FileParse> fp((size_t)n);
+	{ // the hit / exon arrays of the plain files come out of one mapping on huge pages (DataExt::HostArena says why); reserved for the
+	  // worst case -- a PAF line of miniprot has >= 60 bytes, a hit record 88 -- and only touched where the parsers write
+		size_t plain = 0;
+		for (int32_t i = 0; i < n; ++i) {
+			struct stat sb;
+			const size_t len = fns[i] ? std::strlen(fns[i]) : 0;
+			if (!(ids_only && ids_only[i]) && fns[i] && !(len > 3 && std::strcmp(fns[i] + len - 3, ".gz") == 0) && stat(fns[i], &sb) == 0 && S_ISREG(sb.st_mode)) plain += (size_t)sb.st_size;
+		}
+		static const bool no_arena = std::getenv("PANGENE_NO_READ_ARENA") != nullptr;
+		if (plain >= ((size_t)8 << 20) && !no_arena) {
+			const size_t huge = (size_t)2 << 20, want = ((plain / 60 + (size_t)n) * sizeof(pg_hit_t) + (plain / 100 + 64 * (size_t)n) * sizeof(pg_exon_t) + 128 * (size_t)n + huge - 1) & ~(huge - 1);
+			void *m = mmap(nullptr, want + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+			if (m != MAP_FAILED) {
+				ext->arenas.emplace_back();
+				DataExt::HostArena &a = ext->arenas.back();
+				a.map = (char *)m, a.map_bytes = want + huge;
+				a.base = (char *)(((uintptr_t)m + huge - 1) & ~(uintptr_t)(huge - 1)), a.bytes = want;
+				(void)madvise(a.base, a.bytes, MADV_HUGEPAGE);
+				for (int32_t i = 0; i < n; ++i) fp[(size_t)i].arena = &a;
+			}
+		}
+	}
 	std::vector<std::atomic<uint8_t>> state((size_t)n); // 0 new, 1 parsed, 2 committed (ids final), 3 being / has been finished
 	for (auto &x : state) x.store(0);
 	std::atomic<int32_t> next_parse{0}, n_commit{0}, next_final{0}, n_fail{0};
 	static const bool timing = std::getenv("PANGENE_TIMING") != nullptr;
 	std::atomic<int64_t> us_parse{0}, us_resolve{0}, us_commit{0}, us_final{0};
 	const double t_batch0 = now_sec();
+	struct rusage ru0; getrusage(RUSAGE_SELF, &ru0);
 	std::mutex commit_mu;
 	std::shared_ptr<const DictSnap> snap; // published with atomic_store by whoever commits
 	int32_t snap_names = 0;
+	ChangeLog chg;                         // (commit lock)
+	int64_t snap_chg = 0;
+	std::atomic<int32_t> n_fast{0};
 	auto try_commit = [&]() {
 		std::unique_lock<std::mutex> lk(commit_mu, std::try_to_lock);
 		if (!lk.owns_lock()) return; // somebody else is at it (and will see what this thread just parsed: it re-checks before it leaves)
@@ -606,9 +797,12 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 			const int32_t k = n_commit.load();
 			if (k >= n || state[(size_t)k].load() != 1) break;
 			const double tc0 = timing ? now_sec() : 0.0;
-			if (commit_ids(d, fp[(size_t)k]) != 0) n_fail.fetch_add(1);
-			// (a rebuild copies every name: geometrically spaced, so that files that all bring new names do not make the commits quadratic)
-			if (d->n_gene + d->n_prot >= snap_names + std::max(1000, snap_names / 4) || (k == 0 && d->n_gene + d->n_prot > 0)) snap_refresh(d, snap), snap_names = d->n_gene + d->n_prot;
+			if (fp[(size_t)k].snap_log >= 0 && (int64_t)chg.v.size() - fp[(size_t)k].snap_log <= 256) n_fast.fetch_add(1);
+			if (commit_ids(d, fp[(size_t)k], &chg) != 0) n_fail.fetch_add(1);
+			// (a rebuild copies every name: geometrically spaced, so that files that all bring new names do not make the commits quadratic;
+			// attribute changes: a new snapshot once 64 have come, or the files behind it would carry them along one by one)
+			if (d->n_gene + d->n_prot >= snap_names + std::max(1000, snap_names / 4) || (k == 0 && d->n_gene + d->n_prot > 0) || (int64_t)chg.v.size() - snap_chg >= 64)
+				snap_refresh(d, snap, (int64_t)chg.v.size()), snap_names = d->n_gene + d->n_prot, snap_chg = (int64_t)chg.v.size();
 			if (timing) us_commit.fetch_add((int64_t)((now_sec() - tc0) * 1e6));
 			state[(size_t)k].store(2);
 			n_commit.store(k + 1);
@@ -623,7 +817,7 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 			const double tf0 = timing ? now_sec() : 0.0;
 			finalize_genome(d, f);
 			if (f.opened && !f.ids_only && f.genome >= 0) pack_genomes(d, ext, f.genome, f.genome + 1, 1.0 / n_threads); // (one genome: on this thread)
-			{ FileParse done; std::swap(done.genes, f.genes), std::swap(done.prots, f.prots), std::swap(done.ctgs, f.ctgs); } // the names are not needed any more
+			{ FileParse done; std::swap(done.genes, f.genes), std::swap(done.prots, f.prots), std::swap(done.ctgs, f.ctgs), std::swap(done.snap, f.snap); } // the names are not needed any more
 			if (timing) us_final.fetch_add((int64_t)((now_sec() - tf0) * 1e6));
 			state[(size_t)k].store(3);
 			return true;
@@ -633,8 +827,11 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 		for (;;) {
 			const int32_t i = next_parse.fetch_add(1);
 			if (i < n) {
+				// the first wave of files would be parsed before the first commit has published a snapshot -- every name of theirs hashed into
+				// dictionaries of their own and left to the sequential part: better wait for it (the time one file takes; asleep, not spinning)
+				for (int spin = 0; i > 0 && spin < 400 && !std::atomic_load(&snap) && n_commit.load() < 1; ++spin) std::this_thread::sleep_for(std::chrono::microseconds(50));
 				const double tp0 = timing ? now_sec() : 0.0;
-				parse_file(opt, fns[i], ids_only && ids_only[i], fp[(size_t)i]);
+				parse_file(opt, fns[i], ids_only && ids_only[i], fp[(size_t)i], std::atomic_load(&snap));
 				const double tp1 = timing ? now_sec() : 0.0;
 				if (fp[(size_t)i].opened) preresolve(snap, fp[(size_t)i]);
 				if (timing) us_parse.fetch_add((int64_t)((tp1 - tp0) * 1e6)), us_resolve.fetch_add((int64_t)((now_sec() - tp1) * 1e6));
@@ -660,8 +857,8 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 	for (auto &x : th) x.join();
 	const double t_joined = now_sec();
 	if (slab_helper.joinable()) slab_helper.join();
-	if (timing) std::fprintf(stderr, "[pg_read_paf_batch] %d files on %d threads: %.1f ms wall (+ %.1f ms for the slab helper); summed over the threads: parsing %.1f ms, name look-ups %.1f ms, finishing (ids in place + SoA block) %.1f ms; the sequential commits %.1f ms\n",
-	                         n, n_threads, (t_joined - t_batch0) * 1e3, (now_sec() - t_joined) * 1e3, us_parse.load() * 1e-3, us_resolve.load() * 1e-3, us_final.load() * 1e-3, us_commit.load() * 1e-3);
+	if (timing) std::fprintf(stderr, "[pg_read_paf_batch] %d files on %d threads: %.1f ms wall (+ %.1f ms for the slab helper); summed over the threads: parsing %.1f ms, name look-ups %.1f ms, finishing (ids in place + SoA block) %.1f ms; the sequential commits %.1f ms (%d of them only the file's own news: %lld attribute change(s) logged); %.2f M minor page faults\n",
+	                         n, n_threads, (t_joined - t_batch0) * 1e3, (now_sec() - t_joined) * 1e3, us_parse.load() * 1e-3, us_resolve.load() * 1e-3, us_final.load() * 1e-3, us_commit.load() * 1e-3, n_fast.load(), (long long)chg.v.size(), [&] { struct rusage r; getrusage(RUSAGE_SELF, &r); return (double)(r.ru_minflt - ru0.ru_minflt) * 1e-6; }());
 	ext->check_strand = !!(opt->flag & PG_F_CHECK_STRAND), ext->min_ov_ratio = opt->min_ov_ratio;
 	exact_prefetch(d, ext); // the replay of the reference's tie order starts in the background
 	return -n_fail.load();

@@ -2,7 +2,10 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
+#include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <atomic>
@@ -17,27 +20,84 @@ namespace pgx {
 
 // name -> first-seen id map that owns its strings (the reference's dict.c:29-91; ids are insertion
 // order, which is what read.c:151-168 relies on).  c_str() pointers stay valid for the dict's life.
-class NameDict {
+// How many threads are worth starting: the hardware threads this process may use, capped by the CPU bandwidth its control group grants.
+// (The GPU boxes of this project show 256 hardware threads and grant 16 cores of CPU time -- cpu.max "1600000 100000": a pool of 64
+// threads runs no faster than one of 16, it only burns the quota in a quarter of every 100 ms period and then ALL threads of the process,
+// the one feeding the GPU included, stand still until the next period; profiles/r04_cpu_scaling_box.txt.)
+unsigned host_threads(unsigned cap);
+
+// Name -> id.  Open addressing over (32-bit hash, id) slots, names in blocks that never move (pg_gene_t / pg_prot_t / pg_ctg_t keep
+// `const char *` into them).  A batch read builds three of these per FILE (10 000 names each for a bacterial genome): with
+// std::unordered_map + std::deque<std::string> that was a node and often a string allocation per name -- a sixth of the parse.
+class FlatIndex { // the table alone: names live elsewhere (NameDict's blocks, or another dictionary: the snapshots of the batch reader)
 public:
-	int32_t size() const { return (int32_t)names_.size(); }
-	int32_t get(std::string_view s) const {
-		auto it = map_.find(s);
-		return it == map_.end() ? -1 : it->second;
+	static inline uint64_t hash(std::string_view s) {
+		uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)s.size();
+		const char *p = s.data();
+		size_t n = s.size();
+		for (; n >= 8; p += 8, n -= 8) { uint64_t w; std::memcpy(&w, p, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 29; }
+		if (n) { uint64_t w = 0; std::memcpy(&w, p, n); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 29; }
+		return h ^ (h >> 32);
 	}
-	// returns id; *absent tells whether the name was new
-	int32_t put(std::string_view s, bool *absent) {
-		auto it = map_.find(s);
-		if (it != map_.end()) { if (absent) *absent = false; return it->second; }
-		names_.emplace_back(s);
-		int32_t id = (int32_t)names_.size() - 1;
-		map_.emplace(std::string_view(names_.back()), id);
-		if (absent) *absent = true;
+	int32_t size() const { return (int32_t)ptr_.size(); }
+	void reserve(size_t n) { ptr_.reserve(n), len_.reserve(n); size_t cap = 16; while (cap < 2 * n + 2) cap <<= 1; if (cap > tab_.size()) rehash(cap); }
+	int32_t find(std::string_view s, uint64_t h) const {
+		if (tab_.empty()) return -1;
+		const size_t mask = tab_.size() - 1;
+		for (size_t k = (size_t)h & mask;; k = (k + 1) & mask) {
+			const Slot &t = tab_[k];
+			if (t.id < 0) return -1;
+			if (t.h == (uint32_t)(h >> 32) && len_[(size_t)t.id] == (uint32_t)s.size() && std::memcmp(ptr_[(size_t)t.id], s.data(), s.size()) == 0) return t.id;
+		}
+	}
+	int32_t find(std::string_view s) const { return find(s, hash(s)); }
+	// the caller has looked (find() < 0) and has put the name where it stays: the next id
+	int32_t add(const char *stable, size_t len, uint64_t h) {
+		if (2 * (ptr_.size() + 1) > tab_.size()) rehash(tab_.empty() ? 16 : tab_.size() * 2);
+		const int32_t id = (int32_t)ptr_.size();
+		ptr_.push_back(stable), len_.push_back((uint32_t)len), hs_.push_back(h);
+		place(h, id);
 		return id;
 	}
-	const char *name(int32_t id) const { return names_[id].c_str(); }
+	const char *name(int32_t id) const { return ptr_[(size_t)id]; }
+	std::string_view view(int32_t id) const { return std::string_view(ptr_[(size_t)id], len_[(size_t)id]); }
 private:
-	std::deque<std::string> names_;
-	std::unordered_map<std::string_view, int32_t> map_;
+	struct Slot { uint32_t h; int32_t id; };
+	void place(uint64_t h, int32_t id) { const size_t mask = tab_.size() - 1; size_t k = (size_t)h & mask; while (tab_[k].id >= 0) k = (k + 1) & mask; tab_[k] = Slot{(uint32_t)(h >> 32), id}; }
+	void rehash(size_t cap) { tab_.assign(cap, Slot{0, -1}); for (size_t i = 0; i < ptr_.size(); ++i) place(hs_[i], (int32_t)i); }
+	std::vector<Slot> tab_;
+	std::vector<const char *> ptr_; std::vector<uint32_t> len_; std::vector<uint64_t> hs_;
+};
+
+class NameDict {
+public:
+	int32_t size() const { return ix_.size(); }
+	int32_t get(std::string_view s) const { return ix_.find(s); }
+	// returns id; *absent tells whether the name was new
+	int32_t put(std::string_view s, bool *absent) {
+		const uint64_t h = FlatIndex::hash(s);
+		const int32_t id = ix_.find(s, h);
+		if (id >= 0) { if (absent) *absent = false; return id; }
+		if (absent) *absent = true;
+		return ix_.add(keep(s), s.size(), h);
+	}
+	const char *name(int32_t id) const { return ix_.name(id); }          // NUL-terminated, never moves
+	std::string_view view(int32_t id) const { return ix_.view(id); }
+private:
+	const char *keep(std::string_view s) {
+		if (s.size() + 1 > left_) {
+			const size_t b = std::max<size_t>(s.size() + 1, (size_t)64 << 10);
+			blocks_.emplace_back(new char[b]);
+			at_ = blocks_.back().get(), left_ = b;
+		}
+		char *p = at_;
+		std::memcpy(p, s.data(), s.size()), p[s.size()] = 0;
+		at_ += s.size() + 1, left_ -= s.size() + 1;
+		return p;
+	}
+	FlatIndex ix_;
+	std::vector<std::unique_ptr<char[]>> blocks_;
+	char *at_ = nullptr; size_t left_ = 0;
 };
 
 // one contig segment whose exact (reference, unstable-sort) order is replayed on the host, exact_order.cpp
@@ -68,6 +128,13 @@ struct HostSlab { char *p = nullptr; size_t cap = 0, off = 0; bool pinned = fals
 // host-private companion of a pg_data_t (struct layout of pg_data_t itself must not change)
 struct DataExt {
 	std::vector<uint8_t> is_local;     // per genome: hits live in this process
+	// Memory of a batch read that the genomes' hit / exon arrays point into: ONE mapping on huge pages, carved by the parser threads
+	// (paf_reader.cpp).  A hundred threads filling malloc'ed arrays take 4 KiB page faults at the rate ONE address space sustains
+	// (measured on the 256-thread GPU box: 15 GB/s of fresh memory whatever the thread count, 120-140 GB/s on huge pages;
+	// profiles/r04_pagefault_box.txt).  Arrays inside are not free()'d one by one: arena_owns() tells, ext_drop unmaps.
+	struct HostArena { char *map = nullptr; size_t map_bytes = 0; char *base = nullptr; size_t bytes = 0; std::atomic<size_t> used{0}; };
+	std::deque<HostArena> arenas;
+	bool arena_owns(const void *p) const { for (const HostArena &a : arenas) if ((const char *)p >= a.base && (const char *)p < a.base + a.bytes) return true; return false; }
 	std::vector<uint8_t> hits_sorted;  // per genome: host AoS already in X (cs) order
 	const pga_backend_t *be = nullptr;
 	pga_ctx_t *ctx = nullptr;          // backend context (owns the HBM-resident shard)
