@@ -519,13 +519,26 @@ def write_files(gen: Iterator[Tuple[str, str]], out_dir: str, gz: bool = False) 
     return paths
 
 
+def _cpu_budget() -> int:
+    """cores this process may really use: the affinity mask, capped by the control group's CPU quota (a box that shows 256 hardware
+    threads may grant 16 cores of CPU time: more workers than that only get the whole group throttled)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def write_files_parallel(kind: str, out_dir: str, n_proc: int = 0, **kw) -> List[str]:
     """write_files for the big sets, by a few fresh interpreters side by side (every genome is seeded on its own, so any split of
     [0, G) gives the same files; fresh processes -- not forks -- because the caller may hold a GPU context).
     kind: "bact" (G, P, seed) or "human" (G, Q, iso, seed, frag)."""
     import subprocess, sys
     G = int(kw["G"])
-    n_proc = n_proc or max(1, min(G, min(os.cpu_count() or 1, 64)))
+    n_proc = n_proc or max(1, min(G, min(_cpu_budget(), 64)))
     os.makedirs(out_dir, exist_ok=True)
     procs = []
     for k in range(n_proc):
