@@ -187,8 +187,10 @@ int pg_set_output(const char *path);
  * first-seen id numbering (read.c:151-168) is identical on every rank.  Adds an empty genome. */
 int32_t pg_scan_paf_ids(const pg_opt_t *opt, pg_data_t *d, const char *fn);
 
-/* Parse n PAFs on host threads (n_threads <= 0: up to 16) and append them in the given order; gene / protein / contig
- * ids come out exactly as after n sequential pg_read_paf calls.  ids_only (may be NULL): per file, non-zero = register
+/* Parse n PAFs on host threads (n_threads <= 0: as many as the process may really use -- the affinity mask capped by the control
+ * group's CPU quota -- and at most 64) and append them in the given order; gene / protein / contig ids and every attribute of every
+ * gene and protein come out exactly as after n sequential pg_read_paf calls (tests/test_reader.py).  The hit / exon arrays of plain
+ * (not gzipped) files lie in one huge-page mapping owned by `d`: pg_data_destroy releases it, nobody else may free() them.  ids_only (may be NULL): per file, non-zero = register
  * the names only, as pg_scan_paf_ids does.  Returns minus the number of files that could not be opened. */
 int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const char *const *fns, const uint8_t *ids_only, int32_t n_threads);
 
