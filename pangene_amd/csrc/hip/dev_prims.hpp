@@ -15,6 +15,15 @@ namespace pgd {
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;
 
+// A launch that may turn out to have nothing to do.  pga_branch_loop queues the fifteen rounds of graph.c:301-314 without asking the
+// host in between; once a round marks no hit and deletes no segment, the state is a fixed point of the round function -- every later
+// round would recompute what is there already (the thresholds of pg_flt_high_occ still tighten: that test runs every round, and when
+// it deletes something the rounds are live again).  w[0] = the last round in which a segment was deleted, w[1] = the last round in
+// which a hit's weak_br was raised (-1: none); a launch of round r passes min = r - 1 (branch steps: nothing changed in the round
+// before) or r (the arc round: nothing changed in this one).  w == NULL: always open.
+struct Gate { const int32_t *w; int32_t min; };
+__device__ __forceinline__ bool gate_closed(const Gate g) { return g.w != nullptr && (g.w[0] > g.w[1] ? g.w[0] : g.w[1]) < g.min; }
+
 // ------------------------------------------------------------------------------------------------
 // wave-level inclusive scan with an arbitrary associative operator
 // ------------------------------------------------------------------------------------------------
@@ -80,9 +89,10 @@ __device__ __forceinline__ T block_scan_excl(T thread_total, Op op, T identity, 
 }
 
 template <class T, class Op, class In>
-__global__ __launch_bounds__(BLOCK) void scan_tile_reduce(In in, int64_t n, T *tile_sum, Op op, T identity)
+__global__ __launch_bounds__(BLOCK) void scan_tile_reduce(In in, int64_t n, T *tile_sum, Op op, T identity, Gate gate)
 {
 	__shared__ T wave_tot[BLOCK / WAVE];
+	if (gate_closed(gate)) return;
 	const int64_t base = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * IPT;
 	T acc = identity;
 #pragma unroll
@@ -97,9 +107,10 @@ __global__ __launch_bounds__(BLOCK) void scan_tile_reduce(In in, int64_t n, T *t
 // other, unlike a loop of 256-wide steps with a carried sum: 36 us -> a few us for the 6000 tiles of a 12 M-hit shard); chunks are
 // in order, so Op need not commute.
 template <class T, class Op>
-__global__ __launch_bounds__(BLOCK) void scan_tile_sums(T *tile_sum, int64_t n_tile, Op op, T identity)
+__global__ __launch_bounds__(BLOCK) void scan_tile_sums(T *tile_sum, int64_t n_tile, Op op, T identity, Gate gate)
 {
 	__shared__ T wave_tot[BLOCK / WAVE];
+	if (gate_closed(gate)) return;
 	const int64_t chunk = (n_tile + BLOCK - 1) / BLOCK, lo = (int64_t)threadIdx.x * chunk, hi = lo + chunk < n_tile ? lo + chunk : n_tile;
 	T a = identity;
 	for (int64_t i = lo; i < hi; ++i) a = op(a, tile_sum[i]);
@@ -115,9 +126,10 @@ __global__ __launch_bounds__(BLOCK) void scan_tile_sums(T *tile_sum, int64_t n_t
 // FUSED: tile_excl holds the raw tile sums and every workgroup reduces the ones before its tile itself (in order: Op need
 // not commute) -- one launch less, worth it while there are few tiles
 template <bool FUSED, class T, class Op, class In, class Out>
-__global__ __launch_bounds__(BLOCK) void scan_tile_apply(In in, Out out, int64_t n, const T *tile_excl, Op op, T identity)
+__global__ __launch_bounds__(BLOCK) void scan_tile_apply(In in, Out out, int64_t n, const T *tile_excl, Op op, T identity, Gate gate)
 {
 	__shared__ T wave_tot[BLOCK / WAVE];
+	if (gate_closed(gate)) return;
 	T carry_in;
 	if (FUSED) {
 		const int64_t nt = blockIdx.x, chunk = (nt + BLOCK - 1) / BLOCK, lo = (int64_t)threadIdx.x * chunk, hi = lo + chunk < nt ? lo + chunk : nt;
@@ -147,16 +159,16 @@ __global__ __launch_bounds__(BLOCK) void scan_tile_apply(In in, Out out, int64_t
 
 // host-side driver; tile_buf must hold ceil(n/TILE) elements of T
 template <class T, class Op, class In, class Out>
-static inline void device_scan(In in, Out out, int64_t n, T *tile_buf, Op op, T identity, hipStream_t st)
+static inline void device_scan(In in, Out out, int64_t n, T *tile_buf, Op op, T identity, hipStream_t st, Gate gate = Gate{nullptr, 0})
 {
 	if (n <= 0) return;
 	const int64_t n_tile = (n + TILE - 1) / TILE;
-	hipLaunchKernelGGL((scan_tile_reduce<T, Op, In>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, n, tile_buf, op, identity);
+	hipLaunchKernelGGL((scan_tile_reduce<T, Op, In>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, n, tile_buf, op, identity, gate);
 	if (n_tile <= 2048) {
-		hipLaunchKernelGGL((scan_tile_apply<true, T, Op, In, Out>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, out, n, tile_buf, op, identity);
+		hipLaunchKernelGGL((scan_tile_apply<true, T, Op, In, Out>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, out, n, tile_buf, op, identity, gate);
 	} else {
-		hipLaunchKernelGGL((scan_tile_sums<T, Op>), dim3(1), dim3(BLOCK), 0, st, tile_buf, n_tile, op, identity);
-		hipLaunchKernelGGL((scan_tile_apply<false, T, Op, In, Out>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, out, n, tile_buf, op, identity);
+		hipLaunchKernelGGL((scan_tile_sums<T, Op>), dim3(1), dim3(BLOCK), 0, st, tile_buf, n_tile, op, identity, gate);
+		hipLaunchKernelGGL((scan_tile_apply<false, T, Op, In, Out>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, out, n, tile_buf, op, identity, gate);
 	}
 }
 static inline int64_t scan_tiles(int64_t n) { return (n + TILE - 1) / TILE + 1; }

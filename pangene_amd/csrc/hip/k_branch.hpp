@@ -40,6 +40,7 @@ struct RepFill {
 	const int4 *A; const int32_t *gid; const uint32_t *flags; const int32_t *rx, *goff, *ctg_base;
 	void *rp_out; int32_t *iv; int64_t *dcnt; int32_t *hz_list;
 	const int32_t *vfirst; const int64_t *vbase; // [contig segments] of the shard (RP_WIDE only)
+	Gate gate;
 };
 
 template <int FORM>
@@ -53,6 +54,7 @@ __device__ __forceinline__ void rep_absent(const RepFill &a, int64_t e0, int n)
 template <int FORM>
 __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 {
+	if (gate_closed(a.gate)) return;
 	const int t = blockIdx.x * BLOCK + threadIdx.x;
 	if (t < a.Q && a.zoff[t] == a.zoff[t + 1]) rep_absent<FORM>(a, (int64_t)t * a.GL, a.GL); // a gene without hits in this shard
 	if (t >= a.N) return;
@@ -134,8 +136,9 @@ constexpr int NL_PAIRS = 4, NL_LANES = 16;
 
 template <int FORM>
 __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_cap, const int64_t *np_dev, int GL, const void *rp_in,
-                                                     int local_dist, int local_count, int frag_mode, int32_t *cnt, NLocalHz hz)
+                                                     int local_dist, int local_count, int frag_mode, int32_t *cnt, NLocalHz hz, Gate gate)
 {
+	if (gate_closed(gate)) return;
 	const int lane = threadIdx.x & 63, grp = lane >> 4, sub = lane & (NL_LANES - 1);
 	int64_t n_pair = np_dev ? *np_dev : n_cap; // the count may still be on its way to the host: it is read here
 	if (n_pair > n_cap) return; // more pairs than the list holds: some stretches of it were never written, and the host repeats the step with room
@@ -259,10 +262,10 @@ __global__ __launch_bounds__(BLOCK) void k_deg(const int32_t *vs, const int32_t 
 }
 
 // number of pg_n_local calls of vertex v: n_max * n_weak (branch.c:70-75) + n(n-1)/2 (branch.c:83-88)
-__global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1, double bd, int32_t *pc)
+__global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1, double bd, int32_t *pc, Gate gate)
 {
 	const int v = blockIdx.x * BLOCK + threadIdx.x;
-	if (v >= n_vtx) return;
+	if (v >= n_vtx || gate_closed(gate)) return;
 	const int a0 = vs[v], n = ve[v] - a0;
 	if (n < 2) { pc[v] = 0; return; }
 	int max_s1 = 0, n_max = 0, n_weak = 0;
@@ -278,9 +281,10 @@ __global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs
 // general scan costs two launches plus one more for the total.  The total goes to dcnt[15] and, with the other counters, to the
 // host's mailbox.  (Graphs beyond PO_THREADS * PO_MAX_ITEMS vertices take the general scan.)
 constexpr int PO_THREADS = 1024, PO_MAX_ITEMS = 64;
-__global__ __launch_bounds__(PO_THREADS) void k_pair_offsets(const int32_t *pc, int n, int32_t *poff, int64_t *dcnt, int64_t *host_box, long long cap /* room in the pair list, or < 0 */)
+__global__ __launch_bounds__(PO_THREADS) void k_pair_offsets(const int32_t *pc, int n, int32_t *poff, int64_t *dcnt, int64_t *host_box, long long cap /* room in the pair list, or < 0 */, Gate gate)
 {
 	__shared__ int32_t part[PO_THREADS];
+	if (gate_closed(gate)) return; // (uniform: the whole workgroup leaves)
 	const int t = threadIdx.x, per = (n + PO_THREADS - 1) / PO_THREADS, i0 = t * per, i1 = i0 + per < n ? i0 + per : n;
 	int32_t s = 0;
 	for (int i = i0; i < i1; ++i) s += pc[i];
@@ -340,10 +344,10 @@ template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
                                                      const int32_t *poff, int32_t *pairs, int64_t pair_cap /* MODE 1: room in pairs[] */, const int32_t *pcnt /* MODE 1: pairs of each vertex */, const int32_t *cnt, double bdist, double bcut,
                                                      uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, uint8_t *vwk /* MODE 2: vertex has a weak arc */,
-                                                     const int64_t *np_dev = nullptr /* MODE 2: the number of pairs, when the list has a capacity (pair_cap) */)
+                                                     const int64_t *np_dev = nullptr /* MODE 2: the number of pairs, when the list has a capacity (pair_cap) */, Gate gate = Gate{nullptr, 0})
 {
 	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-	if (v >= n_vtx) return;
+	if (v >= n_vtx || gate_closed(gate)) return;
 	if (MODE == 2 && np_dev && *np_dev > pair_cap) return; // the list overflowed: there are no counts to read, the host repeats the step with room
 	const int a0 = vs[v], n = ve[v] - a0;
 	if (n < 2) { if (MODE == 2 && lane == 0) ndl[v] = 0; return; } // (every n_dist_loci entry is written: nothing to clear beforehand)
@@ -412,13 +416,15 @@ __global__ __launch_bounds__(BLOCK) void k_round_filter(int S, const int32_t *se
 
 // pga_branch_loop: k_round_filter's tests and their consequences in one launch.  A deleted segment keeps its number: its gene loses its
 // vertex, its two vertices their arcs and counters (nothing refers to them from then on: hits of the gene are filtered next).
-__global__ __launch_bounds__(BLOCK) void k_round_del(int S, const int32_t *ndl, int max_tot_cnt, int max_degree, int max_dist_loci, const int32_t *seg_gid, int32_t *g2s, int32_t *vs, int32_t *ve, int32_t *deg, int32_t *seg_cnt, uint8_t *vwk, uint8_t *alive, int4 *gmeta /* or NULL */)
+__global__ __launch_bounds__(BLOCK) void k_round_del(int S, const int32_t *ndl, int max_tot_cnt, int max_degree, int max_dist_loci, const int32_t *seg_gid, int32_t *g2s, int32_t *vs, int32_t *ve, int32_t *deg, int32_t *seg_cnt, uint8_t *vwk, uint8_t *alive, int4 *gmeta /* or NULL */,
+                 int32_t *stamp = nullptr /* Gate::w, or NULL */, int round = 0)
 {
 	const int s = blockIdx.x * BLOCK + threadIdx.x;
 	if (s >= S || !alive[s]) return;
 	const int l0 = ndl[2 * s], l1 = ndl[2 * s + 1];
 	if (!(seg_cnt[S + s] > max_tot_cnt || deg[2 * s] > max_degree || deg[2 * s + 1] > max_degree || (l0 > l1 ? l0 : l1) > max_dist_loci)) return; // k_round_filter's tests
 	alive[s] = 0;
+	if (stamp) stamp[0] = round; // the state of the loop changed in this round (every writer of the round writes the same value)
 	g2s[seg_gid[s]] = -1;
 	vs[2 * s] = ve[2 * s] = vs[2 * s + 1] = ve[2 * s + 1] = 0;
 	deg[2 * s] = deg[2 * s + 1] = 0;

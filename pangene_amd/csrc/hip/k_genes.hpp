@@ -126,6 +126,7 @@ struct GeneArcs {
 	int32_t *h_round;                   // pinned host memory (or NULL): seg_cnt[2S] then deg[2S] for the host, written straight from here
 	int32_t *big_list;                  // [Q] 1 = the gene is left to the workgroup kernel
 	int64_t *dcnt;                      // [3] invariant, [9] genes that overflowed GA_CAP
+	Gate gate; int32_t *tag_out;        // (pga_branch_loop) the round may have nothing to do; tag_out: where a round that does run leaves its tag
 };
 
 
@@ -294,6 +295,7 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 __global__ __launch_bounds__(BLOCK) void k_gene_arcs_wave(GeneArcs a)
 {
 	__shared__ GeneTable<GA_CAP_WAVE, GA_WAVE_HITS> T;
+	if (gate_closed(a.gate)) return;
 	const int g = blockIdx.x, tid = threadIdx.x;
 	const int sid = a.g2s[g], z0 = a.zoff[g], z1 = a.zoff[g + 1];
 	if (sid < 0) { // not a vertex: none of its hits may be walkable (graph.c:111)
@@ -310,6 +312,8 @@ __global__ __launch_bounds__(BLOCK) void k_gene_arcs_wave(GeneArcs a)
 __global__ __launch_bounds__(BLOCK) void k_gene_arcs_big(GeneArcs a)
 {
 	__shared__ GeneTable<GA_CAP, GA_BIG_STAGE> T;
+	if (gate_closed(a.gate)) return;
+	if (a.tag_out && blockIdx.x == 0 && threadIdx.x == 0) *a.tag_out = (int32_t)a.tag;
 	for (int g = blockIdx.x; g < a.Q; g += gridDim.x) { // the genes the wave kernel left (a flag per gene: no list, no counter)
 		if (!a.big_list[g]) continue;
 		const int sid = a.g2s[g];
@@ -363,10 +367,11 @@ __global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const i
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_mark_hits_z(const int32_t *zx, const int32_t *zy, const int32_t *zg, const uint32_t *hfk, const uint32_t *hbk, uint32_t tag, int n, const int32_t *g2s,
                                                         const uint64_t *ax, const uint8_t *aw, const int32_t *vs, const int32_t *ve, const uint8_t *vwk,
-                                                        uint32_t *flags, int64_t *cnt, int then_filter)
+                                                        uint32_t *flags, int64_t *cnt, int then_filter, Gate gate, int32_t *stamp /* Gate::w of the loop, or NULL */, int round)
 {
 	int z = blockIdx.x * BLOCK + threadIdx.x;
 	bool marked = false;
+	if (gate_closed(gate)) return; // (uniform; a round that counts for the log never comes with a gate)
 	if (z < n) {
 		const uint32_t kb = hbk[z], kf = hfk[z]; // 16 bytes a hit, all independent loads
 		const int y = zy[z], g = zg[z];
@@ -387,7 +392,10 @@ __global__ __launch_bounds__(BLOCK) void k_mark_hits_z(const int32_t *zx, const 
 				const int x = zx[z];
 				const uint32_t f = flags[x];
 				// (then_filter: PG_SET_FILTER(weak_br == 2), graph.c:309 -- only a hit marked here can newly have weak_br == 2)
-				if (nw > (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT)) flags[x] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT | ((then_filter && nw == 2) ? PGA_F_FLT : 0u);
+				if (nw > (int)((f & PGA_F_WEAK_MASK) >> PGA_F_WEAK_SHIFT)) {
+					flags[x] = (f & ~PGA_F_WEAK_MASK) | (uint32_t)nw << PGA_F_WEAK_SHIFT | ((then_filter && nw == 2) ? PGA_F_FLT : 0u);
+					if (stamp) stamp[1] = round; // a hit's weak_br went up: the state of the loop changed in this round
+				}
 				marked = true;
 			}
 		}

@@ -61,6 +61,7 @@ struct SweepView {
 	long long *prof; // PGA_SW_PROFILE builds only
 	int32_t *hz_list; // hz[10] (= dcnt[14]) counts its entries
 	int init_dom; // MODE 1, first sweep of a run: filtered hits get pid_dom = -1, score_dom = 0 (read.c:133-134) here, nobody wrote them before
+	Gate gate; // the pg_shadow of an arc round inside pga_branch_loop may have nothing to do (no flag changed since the last one)
 };
 
 // CDS intersection of hit a (exons ea[na], start ca) and hit b: pg_hit_overlap, overlap.c:6-42
@@ -214,6 +215,7 @@ __device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl
 template <int MODE, bool STAGE_C>
 __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 {
+	if (gate_closed(v.gate)) return; // (k_sweep_slow then finds an empty list and only resets the next sweep's counter)
 	static_assert(2 * SW_HALO == 64 && SW_NW == 4 && SW_LDS <= 1024 && 64 + 2 * SW_HALO <= 128, "the slots past SW_TILE are staged one array per wave; window-relative slot ids are packed in 7 bits, winner slots in 10");
 	constexpr bool STAGE_ORI = (MODE == 1 || MODE == 3) && !STAGE_C; // score_dom needs score_ori: out of the C records when they are staged, else staged alone
 	__shared__ int4 sA[SW_LDS + 4], sB[SW_LDS], sC[STAGE_C ? SW_LDS : 1]; // sA: four sentinel slots close the array

@@ -80,8 +80,9 @@ __global__ __launch_bounds__(BLOCK) void k_vtx_compact(const int32_t *dom_tab, c
 	}
 }
 
-__global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32_t *gid, int n, const int32_t *g2s, int then_filter) // graph.c:61-69 (+ PG_SET_FILTER(vtx == 0))
+__global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32_t *gid, int n, const int32_t *g2s, int then_filter, Gate gate = Gate{nullptr, 0}) // graph.c:61-69 (+ PG_SET_FILTER(vtx == 0))
 {
+	if (gate_closed(gate)) return;
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
 	uint32_t f = flags[h], nf = g2s[gid[h]] >= 0 ? (f | PGA_F_VTX) : (f & ~PGA_F_VTX);

@@ -225,6 +225,10 @@ struct pga_ctx {
 	int32_t *zx = 0, *zy = 0, *zg = 0; int2 *zst = 0; int32_t *zpos = 0, *zposy = 0, *zoff = 0; // gene-major planes (k_genes.hpp)
 	uint32_t *hfk = 0, *hbk = 0; int4 *hfp = 0, *hbp = 0; // half-arc key words and payloads
 	bool z_valid = false, ha_valid = false; uint32_t round_tag = 0; int ha_ori = -1;
+	Gate gate = Gate{nullptr, 0};     // what the launches of the moment carry (pga_branch_loop sets it per phase; open everywhere else)
+	int32_t *loopctl = nullptr;       // [4] device: Gate::w[0..1], [2] = tag of the last arc round of the loop that ran
+	int loop_round = 0;               // the round the launches of the moment belong to (stamps)
+	int32_t *h_loopctl = nullptr;     // pinned mirror of loopctl (bump-allocated once per context)
 	bool zposy_stale = false; // the gene-major index stands but the cm order (or the X numbering) changed: zposy has to be derived again (ensure_z)
 	const pga_arc_part_t *cur_tab = nullptr; int64_t cur_tab_n = 0; // the table of pga_arc_set_current
 	bool table_sparse = false; // the current arc table lives in the genes' stretches (arc_round_genes) and has not been compacted
@@ -360,6 +364,7 @@ static int make_sweep_view(pga_ctx *c, SweepView *v)
 	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->sori = c->sori, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom, v->pdom0 = c->pdom0;
 	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4, v->stage_c = c->any_multi;
 	v->init_dom = c->sweep_init ? 1 : 0;
+	v->gate = c->gate;
 	v->slow_cnt = nullptr, v->slow_list = (int32_t *)c->pool.get(S_SLOW, sizeof(int32_t) * (size_t)c->N);
 	v->hz_list = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
 	if (!v->slow_list || !v->hz_list) return PGA_ERR_NOMEM;
@@ -505,7 +510,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	if (!c->h_cnt) return PGA_ERR_NOMEM;
 	memset(c->h_cnt, 0, 16 * sizeof(int64_t));
 	HIPCHK(hipHostGetDevicePointer((void **)&c->h_box, c->h_cnt, 0));
-	TRY(dalloc(c, &c->dcnt, 16));
+	TRY(dalloc(c, &c->dcnt, 16)); TRY(dalloc(c, &c->loopctl, 4));
 	// persistent arrays
 	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
 	TRY(dalloc(c, &c->cs, N)); TRY(dalloc(c, &c->ce, N)); TRY(dalloc(c, &c->cm, N)); TRY(dalloc(c, &c->cds, N)); TRY(dalloc(c, &c->nex, N));
@@ -1066,7 +1071,7 @@ static int ensure_half_arcs(pga_ctx *c, int use_ori)
 	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(c->N));
 	int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
 	if (!tile || !hzl) return PGA_ERR_NOMEM;
-	device_scan<I32>(InWalk{c->flags, c->yperm}, OutHalfArcs{c->yrecA, c->yrecB, c->zposy, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->dcnt, hzl}, c->N, tile, OpMax{}, I32{-1}, c->st);
+	device_scan<I32>(InWalk{c->flags, c->yperm}, OutHalfArcs{c->yrecA, c->yrecB, c->zposy, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->dcnt, hzl}, c->N, tile, OpMax{}, I32{-1}, c->st, c->gate);
 	c->ha_valid = true, c->ha_ori = use_ori;
 	return 0;
 }
@@ -1109,7 +1114,7 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	if (!big) return PGA_ERR_NOMEM;
 	static const int cap_log2 = [] { const char *e = getenv("PANGENE_GENE_TABLE_LOG2"); const int v = e ? atoi(e) : 9; return v < 1 ? 1 : v > 9 ? 9 : v; }();
 	GeneArcs ga = { c->zy, c->zoff, c->hfk, c->hbk, c->hfp, c->hbp, c->g2s, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta,
-	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt };
+	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt, c->gate, c->gate.w ? c->loopctl + 2 : (int32_t *)nullptr };
 	hipLaunchKernelGGL(k_gene_arcs_wave, dim3((unsigned)c->Q), dim3(BLOCK), 0, c->st, ga);
 	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 8 * c->n_cu)), dim3(BLOCK), 0, c->st, ga);
 	if (mail) hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box, h_round_dev ? h_round_dev + 4 * (size_t)S : (int32_t *)nullptr); // invariant / overflow counters for the host; the overflow counter starts again
@@ -1371,8 +1376,8 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
 		if (!rx || !tile) return PGA_ERR_NOMEM;
 		TRY(ensure_half_arcs(c, c->ha_ori < 0 ? 0 : c->ha_ori)); // which hits are walkable, gene-major (normally left by the arc round just before)
-		device_scan<I32>(InWalkX{c->flags}, OutRank{rx, c->flags}, N, tile, OpSum{}, I32{0}, c->st); // rank among the walkable hits, cs order
-		RepFill rf = { n_ent, GL, Q, N, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl, c->vfirst, c->vbase };
+		device_scan<I32>(InWalkX{c->flags}, OutRank{rx, c->flags}, N, tile, OpSum{}, I32{0}, c->st, c->gate); // rank among the walkable hits, cs order
+		RepFill rf = { n_ent, GL, Q, N, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl, c->vfirst, c->vbase, c->gate };
 		const unsigned nb = nblk(std::max(N, Q));
 		if (c->rp_form == RP_COMPACT) hipLaunchKernelGGL((k_rep_fill<RP_COMPACT>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
 		else if (c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_rep_fill<RP_WIDE>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
@@ -1395,9 +1400,9 @@ static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, const int6
 	// the grid follows the last known number of pairs (the kernel strides over whatever there is)
 	const int64_t est = np_dev ? (c->br_np_seen > 0 ? c->br_np_seen : std::min<int64_t>(n, 1 << 18)) : n;
 	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nblk(est, BLOCK / WAVE * NL_PAIRS), 1 << 20));
-	if (n && c->rp_form == RP_COMPACT) hipLaunchKernelGGL((k_n_local<RP_COMPACT>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
-	else if (n && c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_n_local<RP_WIDE>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
-	else if (n) hipLaunchKernelGGL((k_n_local<RP_FULL>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz);
+	if (n && c->rp_form == RP_COMPACT) hipLaunchKernelGGL((k_n_local<RP_COMPACT>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz, c->gate);
+	else if (n && c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_n_local<RP_WIDE>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz, c->gate);
+	else if (n) hipLaunchKernelGGL((k_n_local<RP_FULL>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz, c->gate);
 	return 0;
 }
 
@@ -1419,7 +1424,7 @@ static int branch_enumerate(pga_ctx *c, int32_t **cnt)
 	int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)c->br_cap + 16);
 	if (!pairs || !s1 || !agid || !vs || !ve || !poff) return PGA_ERR_NOMEM;
 	hipLaunchKernelGGL((k_br_wave<1>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, c->br_par.diff, poff, pairs, c->br_cap, (const int32_t *)c->pool.get(S_BR_PC, 0),
-	                   (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt, (uint8_t *)nullptr);
+	                   (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt, (uint8_t *)nullptr, (const int64_t *)nullptr, c->gate);
 	return n_local_dev(c, pairs, c->br_cap, c->dcnt + 15, c->br_par.local_dist, c->br_par.local_count, c->br_par.frag_mode, cnt);
 }
 
@@ -1448,11 +1453,11 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	}
 	static const bool general_scan = getenv("PANGENE_PAIR_SCAN_GENERAL") != nullptr; // (tests: the path of graphs with more than 65536 vertices)
 	const bool one_wg = n_vtx <= PO_THREADS * PO_MAX_ITEMS && !general_scan;
-	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc);
-	if (one_wg) hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(PO_THREADS), 0, c->st, (const int32_t *)pc, n_vtx, poff, c->dcnt, c->h_box, n_pairs ? -1ll : (long long)std::max<int64_t>(c->br_cap, 4 * (int64_t)n_vtx)); // offsets, and dcnt[15] = number of pairs
+	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc, c->gate);
+	if (one_wg) hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(PO_THREADS), 0, c->st, (const int32_t *)pc, n_vtx, poff, c->dcnt, c->h_box, n_pairs ? -1ll : (long long)std::max<int64_t>(c->br_cap, 4 * (int64_t)n_vtx), c->gate); // offsets, and dcnt[15] = number of pairs
 	else {
 		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_vtx));
-		device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st);
+		device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st, c->gate);
 		hipLaunchKernelGGL(k_mail_pairs, dim3(1), dim3(64), 0, c->st, poff + (n_vtx - 1), pc + (n_vtx - 1), c->dcnt, c->h_box);
 	}
 	if (n_pairs) { // somebody outside needs the count (the all-reduce of a sharded run): wait for it and size the buffers exactly
@@ -1717,7 +1722,19 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		TRY(arc_round_genes(c, par->use_ori, &sc2, &deg2, nullptr, false));
 		c->br_n = 2 * (int64_t)N + 2, c->br_S = S, c->br_np = 0;
 	}
+	// The fixed point (dev_prims.hpp: Gate).  Inside this loop the tie orders stand still (the caller asked exact_quiet), so a round that
+	// marks no hit and deletes no segment leaves a state every later round reproduces: their kernels are queued all the same -- the
+	// host does not look -- and leave at once.  Human-shaped shards reach it after three or four of the fifteen rounds; bacterial ones
+	// as a rule do not.  Sharded runs keep every round: their collectives are queued by the host, and "nothing changed" would have to
+	// hold on every rank.
+	static const bool no_skip = getenv("PANGENE_LOOP_NO_SKIP") != nullptr;
+	const bool gated = x == nullptr && !no_skip && (int64_t)c->round_tag + n_round + 4 < (int64_t)HA_TAG_MAX;
+	struct GateScope { pga_ctx *c; ~GateScope() { c->gate = Gate{nullptr, 0}; } } gate_scope{c}; // (every way out of this function leaves the launches open)
+	const uint32_t tag_before = c->round_tag;
+	if (gated) HIPCHK(hipMemsetAsync(c->loopctl, 0xff, 4 * sizeof(int32_t), c->st)); // -1: nothing has happened yet; round 0 runs (its branch steps ask for a change in round -1 or later)
 	for (int r = 0; r < n_round; ++r) {
+		c->loop_round = r;
+		c->gate = gated ? Gate{c->loopctl, r - 1} : Gate{nullptr, 0}; // the branch steps of round r: something changed in round r - 1
 		// pg_mark_branch_flt_arc (branch.c:48-106)
 		TRY(pga_rep_pos(c));
 		int32_t *cnt;
@@ -1731,13 +1748,15 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 			int32_t *sg = (int32_t *)c->pool.get(S_BR_SEGGID, 0), *dg = (int32_t *)c->pool.get(S_DEG, 0), *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, 0);
 			if (!aw || !vwk || !s1 || !agid || !vs || !ve || !poff || !grp || !sg || !dg || !seg_cnt) return PGA_ERR_NOMEM;
 			hipLaunchKernelGGL((k_br_wave<2>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, par->branch_diff, poff, (int32_t *)nullptr, (int64_t)c->br_cap, (const int32_t *)nullptr, (const int32_t *)c->pool.get(S_NLCNT, 0),
-			                   par->branch_diff_dist, par->branch_diff_cut, aw, grp, ndl, (int64_t *)nullptr, vwk, c->dcnt + 15);
+			                   par->branch_diff_dist, par->branch_diff_cut, aw, grp, ndl, (int64_t *)nullptr, vwk, c->dcnt + 15, c->gate);
 			// pg_mark_branch_flt_hit + PG_SET_FILTER(weak_br == 2) (branch.c:108-145, graph.c:309): with the numbering the arcs were made with
 			TRY(pga_mark_hits(c, nullptr, nullptr, 0, nullptr, 1));
-			if (r > 0) { // pg_flt_high_occ + pg_hard_delete + PG_SET_FILTER(vtx == 0) (graph.c:219-263, 312)
+			c->gate = gated ? Gate{c->loopctl, r} : Gate{nullptr, 0}; // from here on: something changed in THIS round
+			if (r > 0) { // pg_flt_high_occ + pg_hard_delete + PG_SET_FILTER(vtx == 0) (graph.c:219-263, 312): the thresholds tighten every round, so this test always runs
 				hipLaunchKernelGGL(k_round_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)ndl, max_tot_cnt[r], max_degree[r], max_dist_loci[r], (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive,
-				                   (x || par->final_on) ? (int4 *)c->pool.get(S_GMETA, 0) : (int4 *)nullptr); // (whoever compacts the genes' stretches afterwards must find a deleted one empty)
-				hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1);
+				                   (x || par->final_on) ? (int4 *)c->pool.get(S_GMETA, 0) : (int4 *)nullptr, // (whoever compacts the genes' stretches afterwards must find a deleted one empty)
+				                   gated ? c->loopctl : (int32_t *)nullptr, r);
+				hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1, c->gate);
 				c->walk_valid = false, c->ha_valid = false;
 			}
 		}
@@ -1748,7 +1767,15 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 			if (x) { TRY(loop_exchange_table(c, L)); c->br_n = L.ecap; }
 		}
 	}
+	c->gate = Gate{nullptr, 0};
 	c->arc_deferred = false, c->arc_done = false;
+	int32_t *h_ctl = nullptr;
+	if (gated) {
+		if (!c->h_loopctl) c->h_loopctl = (int32_t *)c->pin.get(64);
+		h_ctl = c->h_loopctl;
+		if (!h_ctl) return PGA_ERR_NOMEM;
+		HIPCHK(hipMemcpyAsync(h_ctl, c->loopctl, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+	}
 	const size_t fetch_need = (size_t)S + 128 + (par->final_on ? 4 * sizeof(int32_t) * (size_t)S + 64 : 0);
 	if (c->h_fetch_cap < fetch_need) {
 		c->h_fetch = c->pin.get(fetch_need + fetch_need / 2 + 512);
@@ -1772,6 +1799,10 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	}
 	hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
 	TRY(sync_st(c));
+	if (gated) { // the half-arc records carry the tag of the last arc round that RAN (a round that found nothing to do wrote none)
+		c->round_tag = h_ctl[2] >= 0 ? (uint32_t)h_ctl[2] : tag_before;
+		if (getenv("PANGENE_DEBUG_LOOP") || getenv("PANGENE_TIMING")) fprintf(stderr, "[pga_branch_loop] %d rounds queued; the last round that deleted a segment: %d, that marked a hit: %d (-1: none) -- the rounds after both found their kernels closed\n", n_round, h_ctl[0], h_ctl[1]);
+	}
 	c->br_np_seen = std::max<int64_t>(c->br_np_seen, c->h_cnt[15]);
 	if (getenv("PANGENE_DEBUG_LOOP")) fprintf(stderr, "[pga_branch_loop] counters after %d rounds: invariant %lld, table overflows (last round) %lld, sticky %lld, pairs (last round) %lld of capacity %lld\n", n_round, (long long)c->h_cnt[3], (long long)c->h_cnt[9], (long long)c->h_cnt[11], (long long)c->h_cnt[15], (long long)c->br_cap);
 	if (x) {
@@ -1809,7 +1840,7 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 		if (!ax || !aw || !vs || !ve || !vwk) return PGA_ERR_NOMEM;
 		if (n_marked) HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
 		hipLaunchKernelGGL(k_mark_hits_z, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->zx, c->zy, c->zg, c->hfk, c->hbk, c->round_tag, N, c->g2s, ax, aw, vs, ve, vwk, c->flags,
-		                   n_marked ? c->dcnt + 2 : (int64_t *)nullptr, then_filter);
+		                   n_marked ? c->dcnt + 2 : (int64_t *)nullptr, then_filter, n_marked ? Gate{nullptr, 0} : c->gate, c->gate.w ? c->loopctl : (int32_t *)nullptr, c->loop_round);
 		if (then_filter) c->walk_valid = false, c->ha_valid = false; // else: weak_br does not enter the walkable test, the half-arcs stay valid
 	} else {
 		uint64_t *ax = (uint64_t *)c->pool.get(S_ARCX, sizeof(uint64_t) * (size_t)n_arc + 16);
