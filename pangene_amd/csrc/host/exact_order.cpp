@@ -155,6 +155,7 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 	exact_shutdown(ext); // nobody may still be replaying the segments that go away
 	ext->xsegs.clear();
 	ext->xreplayed = false, ext->xsegs_n_genome = d->n_genome;
+	++ext->xsegs_gen;
 	const int mode = exact_mode();
 	if (mode == 0) return;
 	// genomes are independent: host threads collect their segments, which are then appended in genome order
@@ -276,6 +277,16 @@ static void replay(ExactSeg &s, bool keep_orders)
 		if (keep_orders) s.hy.push_back(cur);
 	}
 	if (keep_orders) s.hx.swap(hist);
+	// identities of the stored orders (a contig's X orders are distinct up to the cycle by construction, its Y orders need not be)
+	auto ident = [](const std::vector<std::vector<int32_t>> &h, std::vector<int32_t> &id) {
+		id.assign(h.size(), 0);
+		for (size_t i = 0; i < h.size(); ++i) {
+			id[i] = (int32_t)i;
+			for (size_t j = 0; j < i; ++j) if (h[j] == h[i]) { id[i] = (int32_t)j; break; }
+		}
+	};
+	ident(s.hx, s.xid), ident(s.hy, s.yid);
+	s.pushed_id[0] = s.pushed_id[1] = -1;
 }
 
 static inline size_t order_index(const ExactSeg &s, int t, size_t n_stored) // which stored order the t-th sort (1-based) produced
@@ -323,7 +334,7 @@ void exact_begin(DataExt *ext)
 	if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[exact_begin] waited %.3f ms for the order replay the reader started\n", (now_sec() - t0) * 1e3);
 	ext->head_file.assign(ext->local_genomes.size(), -1);
 	ext->x_sorts[0] = ext->x_sorts[1] = 0;
-	for (ExactSeg &s : ext->xsegs) s.pushed[0].clear(), s.pushed[1].clear();
+	for (ExactSeg &s : ext->xsegs) s.pushed_id[0] = s.pushed_id[1] = -1;
 	spawn_replay(ext);
 }
 
@@ -365,9 +376,11 @@ int exact_sort(DataExt *ext, int by_cm)
 		if (!s.full) continue;
 		const std::vector<std::vector<int32_t>> &h = by_cm ? s.hy : s.hx;
 		if (h.empty()) continue;
-		const std::vector<int32_t> &ord = h[order_index(s, t, h.size())];
-		if (ord == s.pushed[by_cm]) continue;
-		s.pushed[by_cm] = ord;
+		const size_t oi = order_index(s, t, h.size());
+		const int32_t id = (by_cm ? s.yid : s.xid)[oi];
+		if (id == s.pushed_id[by_cm]) continue;
+		s.pushed_id[by_cm] = id;
+		const std::vector<int32_t> &ord = h[oi];
 		sg.push_back(s.k), ss.push_back(s.start);
 		for (int32_t i : ord) fi.push_back(s.file[(size_t)i]);
 		so.push_back((int64_t)fi.size());
@@ -386,10 +399,11 @@ uint64_t order_signature(const DataExt *ext)
 {
 	uint64_t h = 1469598103934665603ull;
 	auto mix = [&h](uint64_t x) { h = (h ^ x) * 1099511628211ull; };
+	mix(ext->xsegs_gen);
 	for (const ExactSeg &s : ext->xsegs) {
 		if (!s.full) continue;
 		mix((uint64_t)(uint32_t)s.k << 32 | (uint32_t)s.start);
-		for (int b = 0; b < 2; ++b) { mix(s.pushed[b].size()); for (int32_t v : s.pushed[b]) mix((uint64_t)(uint32_t)v); }
+		mix((uint64_t)(uint32_t)s.pushed_id[0] << 32 | (uint32_t)s.pushed_id[1]); // (identities inside this set of segments: xsegs_gen tells the sets apart)
 	}
 	return h;
 }
@@ -411,7 +425,7 @@ bool exact_quiet(DataExt *ext, int n)
 				for (int t = ext->x_sorts[by_cm] + 1; t <= ext->x_sorts[by_cm] + n; ++t) {
 					const size_t i = order_index(s, t, h.size());
 					if (i == last) continue; // (compared already)
-					if (h[i] != s.pushed[by_cm]) return false;
+					if ((by_cm ? s.yid : s.xid)[i] != s.pushed_id[by_cm]) return false;
 					last = i;
 				}
 			}
