@@ -69,15 +69,6 @@ __global__ __launch_bounds__(BLOCK) void k_zoff(const uint64_t *ks, int n, int Q
 	zoff[g] = lo;
 }
 
-// after a cs-order override renumbered X positions (remap: old -> new): the index keeps its order, its X references follow
-__global__ __launch_bounds__(BLOCK) void k_z_remap(int32_t *zx, int32_t *zpos, int n, const int32_t *remap)
-{
-	int z = blockIdx.x * BLOCK + threadIdx.x;
-	if (z >= n) return;
-	const int x = remap[zx[z]];
-	zx[z] = x, zpos[x] = z;
-}
-
 __global__ __launch_bounds__(BLOCK) void k_zpos_y(const int32_t *yperm, const int32_t *zpos, int n, int32_t *zposy)
 {
 	int y = blockIdx.x * BLOCK + threadIdx.x;

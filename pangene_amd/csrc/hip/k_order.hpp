@@ -21,16 +21,11 @@ __global__ __launch_bounds__(BLOCK) void k_to_file(const int32_t *fidx, const in
 
 // ------------------------------------------------------------------------------------------------
 // exact-order overrides (pangene_hip.h): re-permute contig segments of the physical (X) order, or
-// rewrite slices of the Y permutation.  Rare (a few calls per run), not tuned.
+// rewrite slices of the Y permutation.  Every step works on the t hits of the overridden contigs only (a contig occupies the same
+// index range in both orders, so what refers to its hits -- yperm, the gene-major index, inv, pm, the tie marks -- is found through
+// the override's own position list): an isoform-rich shard overrides a million hits of twenty-two 67 times a pass, and eight
+// shard-wide kernels per override were 110 of the 163 ms of its pass.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_ov_inv(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, int n, int32_t *inv, int32_t *remap)
-{
-	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	inv[goff[gnm[h]] + fidx[h]] = h;
-	remap[h] = h;
-}
-
 __global__ __launch_bounds__(BLOCK) void k_ov_sety(const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv, int32_t *yperm)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -60,12 +55,13 @@ constexpr int OV_PLANES = 12, OV_FLAGS = 10;
 struct PermArrays { int32_t *a[OV_PLANES]; int4 *r[3]; };
 
 __global__ __launch_bounds__(BLOCK) void k_ov_gather(PermArrays p, const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv,
-                                                       int32_t *tmp, int32_t *remap)
+                                                       int32_t *tmp, int32_t *remap, const int32_t *zpos /* or NULL */)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= t) return;
 	int src = inv[ov_file[i]];
-	remap[src] = ov_pos[i];
+	remap[src] = ov_pos[i]; // (defined for the hits of the overridden contigs: nobody asks for another)
+	if (zpos) tmp[(int64_t)(OV_PLANES + 12) * t + i] = zpos[src]; // the hit's place in the gene-major index moves with it
 #pragma unroll
 	for (int k = 0; k < OV_PLANES; ++k) tmp[(int64_t)k * t + i] = p.a[k][src];
 	int4 *tr = (int4 *)(tmp + (int64_t)OV_PLANES * t);
@@ -73,12 +69,14 @@ __global__ __launch_bounds__(BLOCK) void k_ov_gather(PermArrays p, const int32_t
 	for (int k = 0; k < 3; ++k) tr[(int64_t)k * t + i] = p.r[k][src];
 }
 
-__global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_t *ov_pos, int64_t t, const int32_t *tmp,
-                                                        const int32_t *gnm, const int32_t *goff)
+__global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *tmp,
+                                                        const int32_t *gnm, const int32_t *goff, int32_t *inv, int32_t *zx, int32_t *zpos /* or NULL */)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= t) return;
 	int pos = ov_pos[i];
+	inv[ov_file[i]] = pos; // (k_ov_gather, the launch before, was the last reader of the old entries)
+	if (zpos) { const int z = tmp[(int64_t)(OV_PLANES + 12) * t + i]; zx[z] = pos, zpos[pos] = z; }
 #pragma unroll
 	for (int k = 0; k < OV_PLANES; ++k) {
 		int32_t v = tmp[(int64_t)k * t + i];
@@ -94,11 +92,31 @@ __global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_
 	for (int k = 0; k < 3; ++k) p.r[k][pos] = tr[(int64_t)k * t + i];
 }
 
-__global__ __launch_bounds__(BLOCK) void k_ov_remap_y(int32_t *yperm, int n, const int32_t *remap)
+// the Y positions of an overridden contig are its X positions (same index range): their entries point into the contig
+__global__ __launch_bounds__(BLOCK) void k_ov_remap_y(int32_t *yperm, const int32_t *ov_pos, int64_t t, const int32_t *remap)
 {
-	int y = blockIdx.x * BLOCK + threadIdx.x;
-	if (y < n) yperm[y] = remap[yperm[y]];
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i < t) { const int y = ov_pos[i]; yperm[y] = remap[yperm[y]]; }
 }
+
+// the static tie marks of the cs order (k_cstie) for the listed positions only
+__global__ __launch_bounds__(BLOCK) void k_cstie_list(const int4 *A, const int32_t *ov_pos, int64_t t, int n, uint32_t *flags)
+{
+	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= t) return;
+	const int h = ov_pos[i];
+	const int4 a = A[h];
+	bool tie = false;
+	if (h > 0) { const int4 p = A[h - 1]; tie = p.y == a.y && p.x == a.x; }
+	if (!tie && h + 1 < n) { const int4 q = A[h + 1]; tie = q.y == a.y && q.x == a.x; }
+	const uint32_t f = flags[h], nf = tie ? f | F_CSTIE : f & ~F_CSTIE;
+	if (nf != f) flags[h] = nf;
+}
+
+// pm (record A, word 3) over the listed positions: a contig's positions are consecutive in the list, and a running maximum never
+// crosses from one contig into the next (segmented by the contig id)
+struct InSegMaxList { const int4 *A; const int32_t *pos; __device__ __forceinline__ SegMax operator()(int64_t i) const { const int4 a = A[pos[i]]; return SegMax{a.y, a.z}; } };
+struct OutSegMaxList { int4 *A; const int32_t *pos; __device__ __forceinline__ void operator()(int64_t i, SegMax in, SegMax) const { ((int32_t *)&A[pos[i]])[3] = in.v; } };
 
 __global__ __launch_bounds__(BLOCK) void k_flt_bits(const uint32_t *flags, int n, unsigned long long *bits)
 {

@@ -229,6 +229,7 @@ struct pga_ctx {
 	int32_t *loopctl = nullptr;       // [4] device: Gate::w[0..1], [2] = tag of the last arc round of the loop that ran
 	int loop_round = 0;               // the round the launches of the moment belong to (stamps)
 	int32_t *h_loopctl = nullptr;     // pinned mirror of loopctl (bump-allocated once per context)
+	int32_t *h_ov = nullptr; size_t h_ov_cap = 0; // pinned: position / file-index lists of an order override
 	bool zposy_stale = false; // the gene-major index stands but the cm order (or the X numbering) changed: zposy has to be derived again (ensure_z)
 	const pga_arc_part_t *cur_tab = nullptr; int64_t cur_tab_n = 0; // the table of pga_arc_set_current
 	bool table_sparse = false; // the current arc table lives in the genes' stretches (arc_round_genes) and has not been compacted
@@ -1881,35 +1882,42 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	if (n_seg <= 0 || N == 0) return 0;
 	const int64_t T = seg_off[n_seg];
 	if (T == 0) return 0;
-	std::vector<int32_t> pos((size_t)T), fil((size_t)T);
+	// positions and file indices of the overridden hits, built in page-locked memory (a real DMA; from a std::vector the runtime stages)
+	const size_t ov_bytes = sizeof(int32_t) * 2 * (size_t)T;
+	if (c->h_ov_cap < ov_bytes) {
+		if (c->h_ov) HIPCHK(hipStreamSynchronize(c->st));
+		c->h_ov = (int32_t *)c->pin.get(ov_bytes + ov_bytes / 2 + 256);
+		if (!c->h_ov) return PGA_ERR_NOMEM;
+		c->h_ov_cap = ov_bytes + ov_bytes / 2 + 256;
+	}
+	int32_t *pos = c->h_ov, *fil = c->h_ov + T;
 	for (int32_t s = 0; s < n_seg; ++s) {
 		const int32_t g = seg_genome[s], base = c->h_goff[(size_t)g];
 		for (int64_t k = seg_off[s]; k < seg_off[s + 1]; ++k)
 			pos[(size_t)k] = base + seg_start[s] + (int32_t)(k - seg_off[s]), fil[(size_t)k] = base + file_idx[k];
 	}
 	int32_t *d_pos = (int32_t *)c->pool.get(S_OVPOS, sizeof(int32_t) * (size_t)T), *d_fil = (int32_t *)c->pool.get(S_OVFILE, sizeof(int32_t) * (size_t)T);
-	int32_t *inv = (int32_t *)c->pool.get(S_I32_A, sizeof(int32_t) * (size_t)N), *remap = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
-	if (!d_pos || !d_fil || !inv || !remap) return PGA_ERR_NOMEM;
-	TRY(upload(c, d_pos, pos.data(), (size_t)T)); TRY(upload(c, d_fil, fil.data(), (size_t)T));
-	hipLaunchKernelGGL(k_ov_inv, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, inv, remap);
+	int32_t *remap = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
+	if (!d_pos || !d_fil || !remap) return PGA_ERR_NOMEM;
+	TRY(upload(c, d_pos, pos, (size_t)T)); TRY(upload(c, d_fil, fil, (size_t)T));
+	if (!c->inv_valid) { hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv); c->inv_valid = true; } // (then kept current by the overrides themselves)
 	if (which == 1) {
-		hipLaunchKernelGGL(k_ov_sety, dim3(nblk(T)), dim3(BLOCK), 0, c->st, d_pos, d_fil, T, inv, c->yperm);
+		hipLaunchKernelGGL(k_ov_sety, dim3(nblk(T)), dim3(BLOCK), 0, c->st, d_pos, d_fil, T, c->inv, c->yperm);
 		if (z_keep) c->zposy_stale = true;
-		return sync_st(c);
+		return sync_st(c); // (the staging area is the next override's too)
 	}
-	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * (OV_PLANES + 12) * (size_t)T + 64);
+	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * (OV_PLANES + 13) * (size_t)T + 64);
 	if (!tmp) return PGA_ERR_NOMEM;
 	PermArrays p = { { c->fidx, c->pid, c->gid, c->cm, c->nex, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, (int32_t *)c->flags, c->sori }, { c->recA, c->recB, c->recC } };
 	static_assert(OV_FLAGS == 10, "the flag word's place in PermArrays");
-	hipLaunchKernelGGL(k_ov_gather, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, inv, tmp, remap);
-	hipLaunchKernelGGL(k_ov_scatter, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, T, tmp, c->gnm, c->goff);
-	hipLaunchKernelGGL(k_ov_remap_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, N, remap);
-	if (z_keep) { hipLaunchKernelGGL(k_z_remap, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->zx, c->zpos, N, (const int32_t *)remap); c->zposy_stale = true; }
-	SegMax *tile = (SegMax *)c->pool.get(S_TILE, tile_buf_bytes(N));
-	device_scan<SegMax>(InSegMaxA{c->recA}, OutSegMaxA{c->recA}, N, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st); // pm follows the new order
-	hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv);
-	c->inv_valid = true;
-	hipLaunchKernelGGL(k_cstie, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->recA, N, c->flags);
+	hipLaunchKernelGGL(k_ov_gather, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, c->inv, tmp, remap, z_keep ? (const int32_t *)c->zpos : (const int32_t *)nullptr);
+	hipLaunchKernelGGL(k_ov_scatter, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, tmp, c->gnm, c->goff, c->inv, c->zx, z_keep ? c->zpos : (int32_t *)nullptr);
+	hipLaunchKernelGGL(k_ov_remap_y, dim3(nblk(T)), dim3(BLOCK), 0, c->st, c->yperm, d_pos, T, remap);
+	if (z_keep) c->zposy_stale = true;
+	SegMax *tile = (SegMax *)c->pool.get(S_TILE, tile_buf_bytes(T));
+	if (!tile) return PGA_ERR_NOMEM;
+	device_scan<SegMax>(InSegMaxList{c->recA, d_pos}, OutSegMaxList{c->recA, d_pos}, T, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st); // pm follows the new order
+	hipLaunchKernelGGL(k_cstie_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, c->recA, d_pos, T, N, c->flags);
 	return sync_st(c);
 }
 

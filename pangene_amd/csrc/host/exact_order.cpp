@@ -370,8 +370,10 @@ int exact_sort(DataExt *ext, int by_cm)
 		if (changed) { const int rc = ext->be->set_head(ext->ctx, ext->head_file.data()); if (rc) return rc; }
 	}
 	// fully tracked contigs: the whole order
-	std::vector<int32_t> sg, ss, fi;
-	std::vector<int64_t> so(1, 0);
+	const double t_list0 = now_sec();
+	static thread_local std::vector<int32_t> sg, ss, fi; // (reused: a million entries per call on isoform-rich shards)
+	static thread_local std::vector<int64_t> so;
+	sg.clear(), ss.clear(), fi.clear(), so.assign(1, 0);
 	for (ExactSeg &s : ext->xsegs) {
 		if (!s.full) continue;
 		const std::vector<std::vector<int32_t>> &h = by_cm ? s.hy : s.hx;
@@ -382,12 +384,18 @@ int exact_sort(DataExt *ext, int by_cm)
 		s.pushed_id[by_cm] = id;
 		const std::vector<int32_t> &ord = h[oi];
 		sg.push_back(s.k), ss.push_back(s.start);
-		for (int32_t i : ord) fi.push_back(s.file[(size_t)i]);
+		const size_t at = fi.size();
+		fi.resize(at + ord.size());
+		const int32_t *fl = s.file.data();
+		for (size_t k = 0; k < ord.size(); ++k) fi[at + k] = fl[(size_t)ord[k]];
 		so.push_back((int64_t)fi.size());
 	}
 	if (sg.empty()) return 0;
 	ext->order_touched = true; // the backend's orders change: sync_host compares what the tracked contigs hold now with what its copy was taken from (order_signature)
-	return ext->be->override_order(ext->ctx, by_cm, (int32_t)sg.size(), sg.data(), ss.data(), so.data(), fi.data());
+	const double t_be0 = now_sec();
+	const int rc = ext->be->override_order(ext->ctx, by_cm, (int32_t)sg.size(), sg.data(), ss.data(), so.data(), fi.data());
+	ext->ov_calls += 1, ext->ov_hits += (int64_t)fi.size(), ext->ov_list_s += t_be0 - t_list0, ext->ov_backend_s += now_sec() - t_be0;
+	return rc;
 }
 
 void exact_shutdown(DataExt *ext) { exact_wait(ext); }

@@ -1489,6 +1489,8 @@ void pg_graph_gen(const pg_opt_t *opt, pg_graph_t *q)
 		std::fprintf(stderr, "[phases]");
 		for (int i = 0; i < PH_COUNT; ++i) std::fprintf(stderr, " %s %.2f", pg_phase_name(i), g_phase[i] * 1e3);
 		std::fprintf(stderr, " | path %.2f ms (%d attempt%s; pg_post_process %.2f, pg_graph_gen's first attempt %.2f, hazard review %.2f ms)\n", g_path_sec * 1e3, n_attempt, n_attempt > 1 ? "s: tie-order hazards" : "", path_before * 1e3, t_first * 1e3, t_review * 1e3);
+		if (ext && ext->ov_calls) std::fprintf(stderr, "[exact_sort] %lld order override(s) of %lld hits in all: lists %.2f ms, backend (copy + kernels + wait) %.2f ms\n", (long long)ext->ov_calls, (long long)ext->ov_hits, ext->ov_list_s * 1e3, ext->ov_backend_s * 1e3);
+		if (ext) ext->ov_calls = ext->ov_hits = 0, ext->ov_list_s = ext->ov_backend_s = 0;
 	}
 }
 

@@ -178,6 +178,7 @@ struct DataExt {
 	bool host_full = false;            // the last sync also fetched rank / score_dom / dominators
 	bool pos_valid = false;            // pos_x / y_order on the host match the backend's current orders
 	bool order_touched = false;        // an order override has been handed to the backend since the last sync (exact_sort)
+	int64_t ov_calls = 0, ov_hits = 0; double ov_list_s = 0, ov_backend_s = 0; // (PANGENE_TIMING) order overrides of the run: how many, how many hits, where the time went
 	uint64_t pos_sig = 0;              // order_signature() of the orders pos_x / y_file were fetched from
 	std::vector<uint64_t> flt_bits;    // bit (shard hit offset of the genome + host index) = flt, refreshed by every sync
 	std::vector<int32_t> pos_x;        // per local hit (file order): position inside its genome in cs order
