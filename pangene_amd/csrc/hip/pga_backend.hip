@@ -229,7 +229,8 @@ struct pga_ctx {
 	int32_t *loopctl = nullptr;       // [4] device: Gate::w[0..1], [2] = tag of the last arc round of the loop that ran
 	int loop_round = 0;               // the round the launches of the moment belong to (stamps)
 	int32_t *h_loopctl = nullptr;     // pinned mirror of loopctl (bump-allocated once per context)
-	int32_t *h_ov = nullptr; size_t h_ov_cap = 0; // pinned: position / file-index lists of an order override
+	int32_t *h_ov = nullptr; size_t h_ov_cap = 0; // pinned: position / file-index lists of an order override, two halves used in turn
+	hipEvent_t ov_ev[2] = { nullptr, nullptr }; bool ov_ev_used[2] = { false, false }; unsigned ov_seq = 0; // a half is free again when the copy out of it has happened
 	bool zposy_stale = false; // the gene-major index stands but the cm order (or the X numbering) changed: zposy has to be derived again (ensure_z)
 	const pga_arc_part_t *cur_tab = nullptr; int64_t cur_tab_n = 0; // the table of pga_arc_set_current
 	bool table_sparse = false; // the current arc table lives in the genes' stretches (arc_round_genes) and has not been compacted
@@ -455,6 +456,7 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 	for (void *q : c->owned) (void)hipFree(q);
 	dev_big_free(c->arena, c->arena_cap), c->arena = nullptr;
 	c->pool.release();
+	for (int k = 0; k < 2; ++k) if (c->ov_ev[k]) { (void)hipEventDestroy(c->ov_ev[k]); c->ov_ev[k] = nullptr; }
 	c->pin.release(); // h_cnt, h_stage, h_g2s, h_round, h_ndl live there
 	if (c->g2s_done) (void)hipEventDestroy(c->g2s_done);
 	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
@@ -1883,14 +1885,20 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	const int64_t T = seg_off[n_seg];
 	if (T == 0) return 0;
 	// positions and file indices of the overridden hits, built in page-locked memory (a real DMA; from a std::vector the runtime stages)
-	const size_t ov_bytes = sizeof(int32_t) * 2 * (size_t)T;
+	// (nothing waits at the end of an override any more -- sixty-six of them per pass each found the device still at the round queued
+	// before -- so the lists must not be overwritten while their copy is under way: two halves, an event each)
+	const size_t ov_bytes = (sizeof(int32_t) * 2 * (size_t)T + 255) & ~(size_t)255;
 	if (c->h_ov_cap < ov_bytes) {
 		if (c->h_ov) HIPCHK(hipStreamSynchronize(c->st));
-		c->h_ov = (int32_t *)c->pin.get(ov_bytes + ov_bytes / 2 + 256);
+		const size_t cap = ov_bytes + ov_bytes / 2 + 256;
+		c->h_ov = (int32_t *)c->pin.get(2 * cap);
 		if (!c->h_ov) return PGA_ERR_NOMEM;
-		c->h_ov_cap = ov_bytes + ov_bytes / 2 + 256;
+		c->h_ov_cap = cap, c->ov_ev_used[0] = c->ov_ev_used[1] = false;
 	}
-	int32_t *pos = c->h_ov, *fil = c->h_ov + T;
+	const int half = (int)(c->ov_seq++ & 1u);
+	if (!c->ov_ev[half]) HIPCHK(hipEventCreateWithFlags(&c->ov_ev[half], hipEventDisableTiming));
+	if (c->ov_ev_used[half]) HIPCHK(hipEventSynchronize(c->ov_ev[half]));
+	int32_t *pos = (int32_t *)((char *)c->h_ov + (size_t)half * c->h_ov_cap), *fil = pos + T;
 	for (int32_t s = 0; s < n_seg; ++s) {
 		const int32_t g = seg_genome[s], base = c->h_goff[(size_t)g];
 		for (int64_t k = seg_off[s]; k < seg_off[s + 1]; ++k)
@@ -1900,11 +1908,12 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	int32_t *remap = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
 	if (!d_pos || !d_fil || !remap) return PGA_ERR_NOMEM;
 	TRY(upload(c, d_pos, pos, (size_t)T)); TRY(upload(c, d_fil, fil, (size_t)T));
+	HIPCHK(hipEventRecord(c->ov_ev[half], c->st)); c->ov_ev_used[half] = true;
 	if (!c->inv_valid) { hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv); c->inv_valid = true; } // (then kept current by the overrides themselves)
 	if (which == 1) {
 		hipLaunchKernelGGL(k_ov_sety, dim3(nblk(T)), dim3(BLOCK), 0, c->st, d_pos, d_fil, T, c->inv, c->yperm);
 		if (z_keep) c->zposy_stale = true;
-		return sync_st(c); // (the staging area is the next override's too)
+		return 0;
 	}
 	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * (OV_PLANES + 13) * (size_t)T + 64);
 	if (!tmp) return PGA_ERR_NOMEM;
@@ -1918,7 +1927,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	if (!tile) return PGA_ERR_NOMEM;
 	device_scan<SegMax>(InSegMaxList{c->recA, d_pos}, OutSegMaxList{c->recA, d_pos}, T, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st); // pm follows the new order
 	hipLaunchKernelGGL(k_cstie_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, c->recA, d_pos, T, N, c->flags);
-	return sync_st(c);
+	return 0;
 }
 
 extern "C" int pga_set_head(pga_ctx_t *c, const int32_t *head_file)
