@@ -144,6 +144,14 @@ public:
 		return n;
 	}
 	size_t text_bytes() const { return (size_t)(end_ - p_); }
+	// exons per line, from the head of the file: every intron operation of a CIGAR (N, U, V) opens one (names hold such letters
+	// too: the estimate errs on the generous side, which is the side that costs nothing)
+	double exons_per_line() const {
+		const char *e = end_ - p_ > (64 << 10) ? p_ + (64 << 10) : end_;
+		size_t ops = 0, lines = 1;
+		for (const char *q = p_; q < e; ++q) { const char ch = *q; ops += ch == 'N' || ch == 'U' || ch == 'V'; lines += ch == '\n'; }
+		return 1.0 + (double)ops / (double)lines;
+	}
 	bool next(char *&line, size_t &len) { // the line is followed by a byte the caller may overwrite
 		if (p_ >= end_) return false;
 		char *nl = (char *)std::memchr(p_, '\n', (size_t)(end_ - p_));
@@ -411,6 +419,7 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 			fp.m_hit = (int32_t)std::min<size_t>(text / 120 + 64, (size_t)1 << 30), fp.m_exon = (int32_t)std::min<size_t>(text / 100 + 64, (size_t)1 << 30);
 			if (fp.arena && whole.ok()) { // a batch read: slices of its huge-page arena, the hits' by the exact number of lines
 				fp.m_hit = (int32_t)std::min<size_t>(whole.count_lines() + 1, (size_t)1 << 30);
+				fp.m_exon = (int32_t)std::min<size_t>((size_t)((double)fp.m_hit * whole.exons_per_line() * 1.15) + 1024, (size_t)1 << 30);
 				const size_t hb = (sizeof(pg_hit_t) * (size_t)fp.m_hit + 63) & ~(size_t)63, eb = (sizeof(pg_exon_t) * (size_t)fp.m_exon + 63) & ~(size_t)63;
 				const size_t at = fp.arena->used.fetch_add(hb + eb);
 				if (at + hb + eb <= fp.arena->bytes) fp.hits = (pg_hit_t *)(fp.arena->base + at), fp.exons = (pg_exon_t *)(fp.arena->base + at + hb), fp.hits_arena = fp.exons_arena = true;
@@ -765,7 +774,7 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 		}
 		static const bool no_arena = std::getenv("PANGENE_NO_READ_ARENA") != nullptr;
 		if (plain >= ((size_t)8 << 20) && !no_arena) {
-			const size_t huge = (size_t)2 << 20, want = ((plain / 60 + (size_t)n) * sizeof(pg_hit_t) + (plain / 100 + 64 * (size_t)n) * sizeof(pg_exon_t) + 128 * (size_t)n + huge - 1) & ~(huge - 1);
+			const size_t huge = (size_t)2 << 20, want = ((plain / 60 + (size_t)n) * sizeof(pg_hit_t) + (plain / 3 + 2048 * (size_t)n) * sizeof(pg_exon_t) + 128 * (size_t)n + huge - 1) & ~(huge - 1);
 			void *m = mmap(nullptr, want + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
 			if (m != MAP_FAILED) {
 				ext->arenas.emplace_back();
