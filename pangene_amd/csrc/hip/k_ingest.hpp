@@ -199,14 +199,21 @@ __global__ __launch_bounds__(BLOCK) void k_count_shadow(const uint32_t *flags, c
 // ------------------------------------------------------------------------------------------------
 constexpr int GF_T = 1024;
 struct GenomeFilters { uint32_t *flags; const int32_t *pid, *gid, *rank, *sadj; int32_t *pdom, *pdom0; const int32_t *goff; const int4 *A; int P, Q; int32_t *stats; int64_t *dcnt; int32_t *hz_list;
-                       int fused; /* the sweep before was k_sweep<3>: read.c:249-253 is done, flt_iso_ov is set; what is left of phase 1 is its consequence (overlap.c:89-91) and the protein table */ };
-static inline size_t gf_lds_bytes(int P, int Q) { return 8 * (size_t)Q + (((size_t)P + 7) & ~(size_t)7) + 64; }
+                       int fused; /* the sweep before was k_sweep<3>: read.c:249-253 is done, flt_iso_ov is set; what is left of phase 1 is its consequence (overlap.c:89-91) and the protein table */
+                       int pos_bits; /* K32: bits of a position inside a genome */ };
+// K32: no score_adj of the shard is negative and score_adj and a position inside a genome fit 32 bits together -- the per-gene `best`
+// entries are 4 bytes then, and the tables of a 20 000-gene, 55 000-protein human annotation fit the LDS (8 Q + P bytes did not: those
+// shards took four kernels over (genome x gene / protein) tables in HBM instead)
+static inline size_t gf_lds_bytes(int P, int Q, bool k32 = false) { return (k32 ? 4 : 8) * (((size_t)Q + 1) & ~(size_t)1) + (((size_t)P + 7) & ~(size_t)7) + 64; }
 
+template <bool K32>
 __global__ __launch_bounds__(GF_T) void k_genome_filters(GenomeFilters a)
 {
+	typedef typename std::conditional<K32, uint32_t, unsigned long long>::type best_t;
 	extern __shared__ unsigned long long gf_lds[];
-	unsigned long long *best = gf_lds;                                  // [Q] hit.c:111 `best`: score_adj << 32 | (first position wins)
-	uint8_t *noiso = (uint8_t *)(best + a.Q);                            // [P] the protein has a hit here without flt_iso_ov (= !flag[] of hit.c:134-138)
+	best_t *best = (best_t *)gf_lds;                                      // [Q] hit.c:111 `best`: score_adj, then the first position wins
+	uint8_t *noiso = (uint8_t *)(best + (((size_t)a.Q + 1) & ~(size_t)1)); // [P] the protein has a hit here without flt_iso_ov (= !flag[] of hit.c:134-138)
+	const uint32_t pmask = K32 ? (1u << a.pos_bits) - 1u : 0xffffffffu;
 	int32_t *cnt = (int32_t *)(noiso + (((size_t)a.P + 7) & ~(size_t)7)); // [4] the genome's counts for the log line (read.c:257)
 	const int g = blockIdx.x, tid = threadIdx.x, h0 = a.goff[g], h1 = a.goff[g + 1];
 	for (int k = tid; k < a.Q; k += GF_T) best[k] = 0;
@@ -258,8 +265,9 @@ __global__ __launch_bounds__(GF_T) void k_genome_filters(GenomeFilters a)
 			if (p0[u] >= 0 && !noiso[p0[u]]) f |= PGA_F_FLT | PGA_F_CHAIN, a.flags[h] = f, ++n_chain;
 			if ((f & PGA_F_FLT) || rk[u] > 0) continue;
 			const uint32_t pos = (uint32_t)(h - h0);
-			if (sa[u] > 0) atomicMax(&best[gi[u]], (unsigned long long)(uint32_t)sa[u] << 32 | (0xffffffffu - pos));
-			else if (sa[u] < 0) atomicMax(&best[gi[u]], 1ull << 63 | pos);
+			if (K32) { if (sa[u] > 0) atomicMax((uint32_t *)&best[gi[u]], (uint32_t)sa[u] << a.pos_bits | (pmask - pos)); }
+			else if (sa[u] > 0) atomicMax((unsigned long long *)&best[gi[u]], (unsigned long long)(uint32_t)sa[u] << 32 | (0xffffffffu - pos));
+			else if (sa[u] < 0) atomicMax((unsigned long long *)&best[gi[u]], 1ull << 63 | pos);
 		}
 	}
 	__syncthreads();
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(GF_T) void k_genome_filters(GenomeFilters a)
 			kk[u] = 0, bp[u] = 0; // hit.c:111: calloc'ed best => pid 0 when the gene has no candidate
 			if (h < h1 && !(fl[u] & PGA_F_FLT)) {
 				kk[u] = best[gi[u]];
-				if (kk[u]) bp[u] = a.pid[h0 + (int)((kk[u] >> 63) ? (uint32_t)kk[u] : 0xffffffffu - (uint32_t)kk[u])];
+				if (kk[u]) bp[u] = a.pid[h0 + (int)(K32 ? pmask - ((uint32_t)kk[u] & pmask) : (kk[u] >> 63) ? (uint32_t)kk[u] : 0xffffffffu - (uint32_t)kk[u])];
 			}
 		}
 #pragma unroll
@@ -284,8 +292,8 @@ __global__ __launch_bounds__(GF_T) void k_genome_filters(GenomeFilters a)
 			const unsigned long long k = kk[u];
 			if (k && pi[u] != bp[u] && a.rank[h] == 0) { // a losing candidate: could it have been first?
 				const int s = a.sadj[h];
-				if ((k >> 63) ? s < 0 : (s > 0 && (uint32_t)s == (uint32_t)(k >> 32))) {
-					const int w = h0 + (int)((k >> 63) ? (uint32_t)k : 0xffffffffu - (uint32_t)k);
+				if (K32 ? (s > 0 && (uint32_t)s == (uint32_t)k >> a.pos_bits) : (k >> 63) ? s < 0 : (s > 0 && (uint32_t)s == (uint32_t)(k >> 32))) {
+					const int w = h0 + (int)(K32 ? pmask - ((uint32_t)k & pmask) : (k >> 63) ? (uint32_t)k : 0xffffffffu - (uint32_t)k);
 					const int4 ah = a.A[h], aw = a.A[w];
 					if (ah.x == aw.x && ah.y == aw.y) { atomicAdd((unsigned long long *)&a.dcnt[7], 1ull); hz_note(&a.dcnt[14], a.hz_list, ah.y); }
 				}

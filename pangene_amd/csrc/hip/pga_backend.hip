@@ -209,6 +209,7 @@ struct pga_ctx {
 	int32_t *max_ori = 0; int64_t *sums = 0; int32_t *vtx_cnt = 0; int32_t *g2s = 0; int32_t n_seg = 0;
 	uint64_t sync_epoch_reset = 0;
 	bool gf_ok = false; // k_genome_filters: the per-genome tables of read.c:254-256 fit the LDS
+	bool gf_k32 = false; int gf_pos_bits = 0; // ... with 4-byte `best` entries (score_adj and a position inside a genome in 32 bits)
 	bool x_redo = false; // pga_arc_round_x gave the round up: the next pga_arc_round repeats it on the sort path
 	int64_t x_pairs_seen = 0, x_arcs_seen = 0; // sharded rounds: the longest pair list / the largest local arc table of any rank in the PREVIOUS run over this context (pga_begin shifts)
 	int64_t x_pairs_run = 0, x_arcs_run = 0;   // ... and in the run under way
@@ -640,8 +641,11 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes(c->gs_np)) != hipSuccess) { (void)hipGetLastError(); c->gs_ok = false; }
 	}
 
-	c->gf_ok = gf_lds_bytes(c->P, c->Q) <= (size_t)150 << 10 && getenv("PANGENE_FILTERS_GLOBAL") == nullptr;
-	if (c->gf_ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_genome_filters), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gf_lds_bytes(c->P, c->Q)) != hipSuccess) { (void)hipGetLastError(); c->gf_ok = false; }
+	c->gf_pos_bits = bits_for((uint32_t)std::max(1, max_hit - 1));
+	c->gf_k32 = !neg_sadj && bits_for(max_sadj) + c->gf_pos_bits <= 32 && getenv("PANGENE_FILTERS_K64") == nullptr && (gf_lds_bytes(c->P, c->Q) > (size_t)64 << 10 || getenv("PANGENE_FILTERS_K32") != nullptr); // (small tables: the 8-byte form, as before; tests force the other)
+	c->gf_ok = gf_lds_bytes(c->P, c->Q, c->gf_k32) <= (size_t)150 << 10 && getenv("PANGENE_FILTERS_GLOBAL") == nullptr;
+	if (c->gf_ok && hipFuncSetAttribute(c->gf_k32 ? reinterpret_cast<const void *>(k_genome_filters<true>) : reinterpret_cast<const void *>(k_genome_filters<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+	                                    (int)gf_lds_bytes(c->P, c->Q, c->gf_k32)) != hipSuccess) { (void)hipGetLastError(); c->gf_ok = false; }
 
 	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
 		const size_t per_hit = 568 /* measured: 530-540 B/hit at 1 M and 12 M hits (PANGENE_TIMING reports the fit at destroy) */, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
@@ -846,9 +850,10 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 		TRY(rc_sw);
 		if (!fused) TRY(launch_sweep<2>(c, 1)); // pg_flt_ov_isoform, read.c:254 (reads neither the shadow flags nor pid_dom: read.c:249-253 follows, in k_iso_apply)
 		if (c->gf_ok) { // read.c:249-256 per genome, the tables in LDS
-			GenomeFilters gf = { c->flags, c->pid, c->gid, c->rank, c->sadj, c->pdom, c->pdom0, c->goff, c->recA, P, Q, d_stats, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP), fused };
+			GenomeFilters gf = { c->flags, c->pid, c->gid, c->rank, c->sadj, c->pdom, c->pdom0, c->goff, c->recA, P, Q, d_stats, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP), fused, c->gf_pos_bits };
 			if (!gf.hz_list) return PGA_ERR_NOMEM;
-			hipLaunchKernelGGL(k_genome_filters, dim3((unsigned)GL), dim3(GF_T), gf_lds_bytes(P, Q), c->st, gf);
+			if (c->gf_k32) hipLaunchKernelGGL(k_genome_filters<true>, dim3((unsigned)GL), dim3(GF_T), gf_lds_bytes(P, Q, true), c->st, gf);
+			else hipLaunchKernelGGL(k_genome_filters<false>, dim3((unsigned)GL), dim3(GF_T), gf_lds_bytes(P, Q, false), c->st, gf);
 		} else {
 		HIPCHK(hipMemsetAsync(noiso, 0, (size_t)TP, c->st));
 		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, c->pdom, c->pdom0, N, P, noiso, k_stats, fused);
