@@ -458,9 +458,21 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 		bool dropped = false;
 		char *const line_end = s + line_len;
 		for (char *p = s;; ++p) {
-			while (p < line_end && *p != '\t') ++p; // (fields are a few bytes long: a loop beats a call)
+			// the numeric columns (2-4, 7-11), as they nearly always are -- digits up to the tab: value and field end in one walk
+			// (anything else -- blanks, a sign, 19 digits, digits followed by something -- takes the general way: strtol's rules)
+			int64_t num = 0;
+			bool have_num = false;
+			if (col >= 1 && col <= 10 && col != 4 && col != 5 && (unsigned)(*p - '0') < 10u) {
+				const char *r = p;
+				uint64_t v = 0;
+				int nd = 0;
+				while ((unsigned)(*r - '0') < 10u && nd < 18) v = v * 10 + (uint64_t)(*r - '0'), ++r, ++nd;
+				if (r == line_end || *r == '\t') p = (char *)r, num = (int64_t)v, have_num = true;
+			}
+			if (!have_num) while (p < line_end && *p != '\t') ++p; // (fields are a few bytes long: a loop beats a call)
 			char term = *p;
 			*p = 0;
+#define PAF_NUM(q_) (have_num ? num : parse_i64(q_))
 			if (col == 0 && last_pid >= 0 && (size_t)(p - q) == last_name.size() && std::memcmp(q, last_name.data(), last_name.size()) == 0) {
 				// the same protein as the line before (PAF files are grouped by protein as a rule): the ids are known, and what the
 				// dictionary calls would do again -- preferred / included marks, prot.gid, prot.len = 0 -- has the same outcome
@@ -497,13 +509,13 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 				hit.rank = ++rank_of[(size_t)pid];
 				last_pid = pid, last_gid = gid, last_name.assign(q, (size_t)(p - q));
 			} else if (col == 1) {
-				int32_t len = (int32_t)parse_i64(q);
+				int32_t len = (int32_t)PAF_NUM(q);
 				fp.p_len[(size_t)pid] = len;
 				if (fp.g_len[(size_t)gid] < len) fp.g_len[(size_t)gid] = len;
 				if (ids_only) { dropped = true; break; }
-			} else if (col == 2) hit.qs = (int32_t)parse_i64(q);
+			} else if (col == 2) hit.qs = (int32_t)PAF_NUM(q);
 			else if (col == 3) {
-				hit.qe = (int32_t)parse_i64(q);
+				hit.qe = (int32_t)PAF_NUM(q);
 				if (hit.qe - hit.qs < fp.p_len[(size_t)pid] * opt->min_prot_ratio) { dropped = true; break; }
 			} else if (col == 4) {
 				if (*q != '+' && *q != '-') { dropped = true; break; }
@@ -512,12 +524,12 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 				bool a2;
 				hit.cid = fp.ctgs.put(q, &a2);
 				if (a2) fp.ctg_len.push_back(0);
-			} else if (col == 6) fp.ctg_len[(size_t)hit.cid] = parse_i64(q);
-			else if (col == 7) hit.cs = parse_i64(q);
-			else if (col == 8) hit.ce = parse_i64(q);
-			else if (col == 9) hit.mlen = (int32_t)parse_i64(q);
+			} else if (col == 6) fp.ctg_len[(size_t)hit.cid] = PAF_NUM(q);
+			else if (col == 7) hit.cs = PAF_NUM(q);
+			else if (col == 8) hit.ce = PAF_NUM(q);
+			else if (col == 9) hit.mlen = (int32_t)PAF_NUM(q);
 			else if (col == 10) {
-				hit.blen = (int32_t)parse_i64(q);
+				hit.blen = (int32_t)PAF_NUM(q);
 				if (hit.mlen < hit.blen * opt->min_prot_iden) { dropped = true; break; }
 			} else if (col >= 12) {
 				const bool tag5 = p - q >= 5 && q[2] == ':' && q[4] == ':';
@@ -539,6 +551,7 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 					}
 				}
 			}
+#undef PAF_NUM
 			q = p + 1, ++col;
 			if (term == 0) break;
 		}
