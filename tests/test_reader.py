@@ -140,3 +140,80 @@ def test_score_adj_fast_path_is_the_long_double_route(built, tmp_path):
             assert got[i] == want, (i, got[i], want)
     finally:
         lib.pg_data_destroy(d)
+
+
+def _adversarial_lines(rng, n_ctg=2):
+    """PAF lines the format allows and no generator of synth.py emits: numbers the way strtol takes them (blanks, signs, trailing
+    junk, 19+ digits), tags in any order / twice / cut short, every CIGAR operation of miniprot (M I D N U V F G X =), CIGARs that
+    with zero-length operations, '*' strands, blank and short lines, CR LF, names that hold the intron letters N U V"""
+    lines = []
+    for i in range(260):
+        g = "GENE%d" % (i % 37)
+        name = "%s:UV%dN" % (g, i % 3)                       # gene<delim>protein; intron letters in names
+        plen = 40 + ((i % 37) * 7 + (i % 3) * 11) % 300      # one length per protein name (read.c:175 asserts it)
+        qs, qe = (i % 5), plen - (i % 3)
+        strand = "+-"[i % 2] if i % 53 else "*"
+        ctg = "ctgN%d" % (i % n_ctg)
+        cs = 1000 + 977 * i
+        kind = i % 11
+        if kind == 0:   cg, span = "%dM" % plen, 3 * plen
+        elif kind == 1: cg, span = "%dM30N%dM" % (plen // 2, plen - plen // 2), 3 * plen + 30
+        elif kind == 2: cg, span = "%dM31U%dM" % (plen // 2, plen - plen // 2), 3 * plen + 31
+        elif kind == 3: cg, span = "%dM32V%dM" % (plen // 2, plen - plen // 2), 3 * plen + 32
+        elif kind == 4: cg, span = "%dM1F%dM" % (plen // 2, plen - plen // 2), 3 * plen + 1
+        elif kind == 5: cg, span = "%dM2G%dM" % (plen // 2, plen - plen // 2), 3 * plen + 2
+        elif kind == 6: cg, span = "%dM3I2D%dM" % (plen // 2, plen - plen // 2), 3 * plen + 6
+        elif kind == 7: cg, span = "%dX%d=" % (plen // 2, plen - plen // 2), 3 * plen
+        elif kind == 8: cg, span = "%dM40N%dM50N%dM" % (plen // 3, plen // 3, plen - 2 * (plen // 3)), 3 * plen + 90
+        elif kind == 9: cg, span = "0M%dM00N1I" % plen, 3 * plen          # zero-length operations (a CIGAR that does not span the alignment is an assert in the reference, read.c:75: not fed)
+        else:           cg, span = "%dM" % plen, 3 * plen
+        ce = cs + span
+        mlen, blen = span - (i % 7), span
+        ms = [str(50 + (i * 13) % 900), "+%d" % (60 + i), " %d" % (70 + i), "-%d" % (5 + i % 9), "0", "%d junk" % (80 + i), "99999999999999999999"][i % 7]
+        num = lambda v, k: [str(v), "+%d" % v, " %d" % v, "%dx" % v, "%d " % v, "0%d" % v][k % 6] if (i % 17 == 3) else str(v)
+        cols = [name, num(plen, i), num(qs, i + 1), num(qe, i + 2), strand, ctg, ("123456789012345678901" if i % 17 == 5 else "0000000000000000005000000" if i % 17 == 6 else num(5_000_000, i + 3)), num(cs, i + 4), num(ce, i + 5), num(mlen, i + 1), num(blen, i + 2), "0"]
+        tags = ["ms:i:" + ms, "cg:Z:" + cg]
+        if i % 13 == 1: tags.append("fs:i:%d" % (i % 3))
+        if i % 19 == 2: tags.append("st:i:1")
+        if i % 5 == 0: tags.reverse()
+        if i % 29 == 4: tags.append("ms:i:7")                  # a second score tag: the last one counts (read.c:212)
+        if i % 31 == 5: tags = ["ms:i", "cg:"] + tags           # cut short
+        if i % 37 == 6: tags = tags[:1]                          # no CIGAR: dropped
+        if i % 23 == 7: tags.insert(0, "AS:i:12")
+        line = "\t".join(cols + tags)
+        if i % 41 == 8: line = "\t".join(cols[:7])              # a short line
+        if i % 43 == 9: line = ""
+        if i % 47 == 10: line += "\t"
+        lines.append(line + ("\r\n" if i % 9 == 0 else "\n"))
+    order = rng.permutation(len(lines)) if rng is not None else range(len(lines))
+    return "".join(lines[k] for k in order)
+
+
+@pytest.mark.parametrize("variant", [[], ["-S"], ["-p0", "-a1"], ["--bed=raw"], ["-e", "0.3", "-l", "0.2"]])
+def test_adversarial_paf_lines_against_the_reference_binary(built, tmp_path, variant):
+    """the reader's short cuts (digits parsed and delimited in one walk, tags told apart by their bytes, CIGAR numbers without strtol,
+    exp() with a guard band, names resolved against a snapshot) on lines written to miss them, against what the untouched reference
+    prints for the same files -- through the batch reader (plain and gzipped) and the per-file reader"""
+    import gzip
+    import subprocess
+    from conftest import ROOT
+    ref = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/pangene_ref not built")
+    lib = capi.load(oracle_host=True)
+    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    files = []
+    for j in range(4):
+        text = _adversarial_lines(np.random.default_rng(100 + j) if j % 2 else None)
+        p = tmp_path / ("a%d.paf" % j)
+        p.write_text(text, newline="")
+        files.append(str(p))
+        if j == 3:
+            with gzip.open(str(p) + ".gz", "wt", newline="") as f:
+                f.write(text)
+            files[-1] = str(p) + ".gz"
+    want = subprocess.run([ref] + variant + files, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    assert want.returncode == 0 and len(want.stdout) > 500
+    lib.pg_set_exact_mode(2)
+    assert capi.run(lib, files, variant, batch=True) == want.stdout
+    assert capi.run(lib, files, variant, batch=False) == want.stdout
