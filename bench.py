@@ -598,8 +598,8 @@ def main():
         done = re.findall(rb"\[M::pg_graph_gen::([0-9.]+)\*[0-9.]+\] round-3", r.stderr)
         t_path = float(done[-1]) if done else t_ref  # read+ingest are interleaved in the reference: count from 0
         cpu = {"value": round(n_hits / t_path / 1e6, 4), "unit": "M hits/s", "cores": 1, "kind": "reference",
-               "sample": "whole workload (%d genomes, %d hits kept): reference binary wall until 'round-3 graph' %.2f s incl. its PAF parsing (stage A is interleaved with parsing there); host has %d cores, the reference is single-threaded"
-                         % (G, n_hits, t_path, os.cpu_count() or 0),
+               "sample": "whole workload (%d genomes, %d hits kept): reference binary wall until 'round-3 graph' %.2f s incl. its PAF parsing (stage A is interleaved with parsing there); host shows %d hardware threads and grants this process %d cores of CPU time, the reference is single-threaded"
+                         % (G, n_hits, t_path, os.cpu_count() or 0, synth._cpu_budget()),
                "total_wall_s": round(t_ref, 2)}
         if cli and "wall_s" in cli:
             cli["reference_wall_s"] = round(t_ref, 2)
