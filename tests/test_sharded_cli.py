@@ -24,7 +24,8 @@ def _run(exe, n, files, variant, env=None):
 
 @pytest.mark.parametrize("n", [2, 3, 40])
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("bact20", "-p0 -a1"), ("human8f", ""), ("human8f", "-S -D 600 -C 3"), ("fuzz0", "-F"), ("mut1", ""), ("C4", "-w"),
-                                          ("manydoms", "-G"), ("human8", "--bed=walk"), ("fuzz3", "--bed=flag"), ("bact20", "--bed=raw")])
+                                          ("manydoms", "-G"), ("human8", "--bed=walk"), ("fuzz3", "--bed=flag"), ("bact20", "--bed=raw"),
+                                          ("wide0", ""), ("wide3", "-S"), ("wide1", "-D 300 -C 2")])  # (64-bit coordinates: virtual contigs on every rank)
 def test_sharded_command_on_the_oracle_host(built, expected, name, variant, n):
     """2, 3 and 40 processes (more than files: empty ranks), shared-memory exchange: the reference's bytes (mode all pins the line
     order of the BED outputs too)"""
@@ -78,7 +79,7 @@ def test_files_are_cut_by_size_not_by_count(built, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [2, 4])
-@pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz7126", "-D 300 -C 2"), ("human8", "--bed=walk")])
+@pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz7126", "-D 300 -C 2"), ("human8", "--bed=walk"), ("wide0", "")])
 def test_sharded_command_on_gpus(built, expected, name, variant, n):
     """the product command over native RCCL, one process per device; needs n devices"""
     import torch

@@ -58,6 +58,7 @@ def _sharded(files, variant, world, cuts=None, verbose=None):
     ("bact20", "", 3, None),             # uneven shards
     ("bact20", "", 2, [0, 20, 20]),      # a rank that owns no genome still takes part in every exchange
     ("human8", "", 3, [0, 0, 5, 8]),
+    ("wide0", "", 2, None), ("wide3", "-S", 3, None),  # contig coordinates beyond 32 bits: every rank cuts its own contigs into virtual ones
 ])
 def test_ranks_equal_single_process(built, expected, name, variant, world, cuts):
     files = golden_files(name)
