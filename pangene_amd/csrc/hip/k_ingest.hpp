@@ -49,7 +49,7 @@ struct FileHits { const int32_t *pid, *cid, *rank, *sori, *sadj, *nex, *offx, *c
 __global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int32_t *goff, int n_genome, const int32_t *ctg_base,
                                                      const int2 *exon, const int32_t *prot_gid, const uint8_t *gene_pref,
                                                      int32_t *gnm_f, int32_t *seg_f, int32_t *gid_f, int32_t *cds_f, uint64_t *key, uint32_t *val,
-                                                     int rk_shift, const int32_t *hrank, int32_t *rk_f, int32_t *fl_f)
+                                                     int rk_shift, const int32_t *hrank, int32_t *rk_f, int32_t *fl_f, int64_t *irregular = nullptr)
 {
 	int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
@@ -58,7 +58,10 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(FileHits f, int n, const int3
 	int sg = ctg_base[g] + f.cid[i];
 	int gid = prot_gid[f.pid[i]];
 	int len = 0, ne = f.nex[i], ox = f.offx[i];
-	for (int e = 0; e < ne; ++e) { int2 x = exon[ox + e]; len += x.y - x.x; } // pg_cds_len, overlap.c:45-51
+	bool odd = false; int prev = INT32_MIN;
+	for (int e = 0; e < ne; ++e) { int2 x = exon[ox + e]; len += x.y - x.x; odd = odd || x.y < x.x || x.x < prev; prev = x.y; } // pg_cds_len, overlap.c:45-51
+	// an exon list that is not sorted and disjoint (a U / V intron shorter than 3 bp, read.c:59-62): the sweeps then merge step by step (cds_inter_ref)
+	if (odd && irregular) atomicAdd((unsigned long long *)irregular, 1ull);
 	gnm_f[i] = g, seg_f[i] = sg, gid_f[i] = gid, cds_f[i] = len;
 	fl_f[i] = (int32_t)((f.rev[i] ? PGA_F_REV : 0u) | (ne != 1 ? F_MULTI : 0u)); // the static bits of the flag word
 	if (rk_shift >= 0) { // the same order in 32 bits (see pga_ctx::rk_shift): 0 exactly when the 64-bit key is 0

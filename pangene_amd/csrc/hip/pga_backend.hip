@@ -200,6 +200,7 @@ struct pga_ctx {
 	int rk_shift = -1;      // >= 0: the key fits 32 bits as score_adj << rk_shift | preferred << (rk_shift - 1) | (rank of hash(pid) among the proteins): no sort
 	int32_t *hrank = 0;     // [P] rank of hash(pid) + 1 (0 for a hash of 0)
 	bool any_multi = true;  // some hit has more than one exon
+	bool exon_regular = true; // every exon list is sorted and disjoint (k_prepare): the sweeps may take the shortcuts of cds_inter_t
 	int rp_form = 0;         // form of the (gene, genome) position records (see k_rep_fill)
 	int32_t *vfirst = 0; int64_t *vbase = 0; // virtual contigs (pga_genome_block_t), per contig segment of the shard: segment of the contig's first piece, the piece's base; NULL = no genome has any
 	int4 *recA = 0, *recB = 0, *recC = 0; // packed sweep records (derived from the arrays above, see k_pack_rec)
@@ -375,6 +376,7 @@ static int make_sweep_view(pga_ctx *c, SweepView *v)
 	v->A = c->recA, v->B = c->recB, v->C = c->recC, v->sori = c->sori, v->exon = c->exon, v->flags = c->flags, v->pdom = c->pdom, v->sdom = c->sdom, v->pdom0 = c->pdom0;
 	v->n = c->N, v->min_ov = c->par.min_ov_ratio, v->check_strand = c->par.check_strand, v->hz = c->dcnt + 4, v->stage_c = c->any_multi;
 	v->init_dom = c->sweep_init ? 1 : 0;
+	v->literal = c->exon_regular && getenv("PANGENE_MERGE_LITERAL") == nullptr ? 0 : 1;
 	v->gate = c->gate;
 	v->slow_cnt = nullptr, v->slow_list = (int32_t *)c->pool.get(S_SLOW, sizeof(int32_t) * (size_t)c->N);
 	v->hz_list = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
@@ -403,9 +405,10 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 	}
 	c->walk_valid = false, c->ha_valid = false;
 	const int nt = (int)nblk(c->N, SW_TILE);
-	v.prof = nullptr;
+	v.prof = nullptr; v.dbg = 0;
 #ifdef PGA_SW_PROFILE
-	HIPCHK(hipMalloc((void **)&v.prof, sizeof(long long) * 8 * SW_NW * (size_t)nt));
+	{ const char *e = getenv("PGA_SW_DBG"); v.dbg = e ? atoi(e) : 0; }
+	HIPCHK(hipMalloc((void **)&v.prof, sizeof(long long) * SW_NSTAMP * SW_NW * (size_t)nt)); HIPCHK(hipMemset(v.prof, 0, sizeof(long long) * SW_NSTAMP * SW_NW * (size_t)nt));
 #endif
 	for (int rep = 0; rep < reps; ++rep) {
 		v.slow_cnt = c->dcnt + 12 + (c->sweep_seq & 1);
@@ -414,20 +417,22 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 		hipEvent_t ea = timed && reps == 1 ? t.a : nullptr, eb = timed && reps == 1 ? t.b : nullptr;
 		if (c->any_multi) hipExtLaunchKernelGGL((k_sweep<MODE, true>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
 		else hipExtLaunchKernelGGL((k_sweep<MODE, false>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
-		hipLaunchKernelGGL((k_sweep_slow<MODE>), dim3(64), dim3(BLOCK), 0, c->st, v, (long long *)(c->dcnt + 12 + ((c->sweep_seq + 1) & 1)));
+		hipLaunchKernelGGL((k_sweep_slow<MODE>), dim3((unsigned)std::min<int64_t>(2 * c->n_cu, std::max<int64_t>(64, nblk(c->N)))), dim3(BLOCK), 0, c->st, v, (long long *)(c->dcnt + 12 + ((c->sweep_seq + 1) & 1))); // (grid-stride over a list whose length only the device knows)
 		++c->sweep_seq;
 	}
 #ifdef PGA_SW_PROFILE
 	{
-		std::vector<long long> hp((size_t)8 * SW_NW * nt);
+		std::vector<long long> hp((size_t)SW_NSTAMP * SW_NW * nt);
 		HIPCHK(hipStreamSynchronize(c->st));
 		HIPCHK(hipMemcpy(hp.data(), v.prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
 		(void)hipFree(v.prof);
-		double d[8] = { 0 };
+		double d[SW_NSTAMP] = { 0 };
 		for (size_t w = 0; w < (size_t)SW_NW * nt; ++w)
-			for (int k = 1; k < 8; ++k) d[k] += (double)(hp[w * 8 + k] - hp[w * 8 + k - 1]);
-		fprintf(stderr, "[sweep<%d> profile, cycles/wave] load+put %.0f | barrier %.0f | count+scan %.0f | list %.0f | eval %.0f | - %.0f | finish %.0f\n", MODE,
-		        d[1] / (SW_NW * nt), d[2] / (SW_NW * nt), d[3] / (SW_NW * nt), d[4] / (SW_NW * nt), d[5] / (SW_NW * nt), d[6] / (SW_NW * nt), d[7] / (SW_NW * nt));
+			for (int k = 1; k < 10; ++k) { const long long x = hp[w * SW_NSTAMP + k], y = hp[w * SW_NSTAMP + k - 1]; if (x && y) d[k] += (double)(x - y); }
+		const double q = 1.0 / ((double)SW_NW * nt);
+		{ double mx = 0, sm = 0; for (size_t w = 0; w < (size_t)SW_NW * nt; ++w) mx += (double)hp[w * SW_NSTAMP + 10], sm += (double)hp[w * SW_NSTAMP + 11]; fprintf(stderr, "[sweep<%d> epilogue merges: steps of the longest lane %.1f, of all lanes %.1f per wave]\n", MODE, mx * q, sm * q); }
+		fprintf(stderr, "[sweep<%d> profile, n %d, ticks/wave] records->LDS %.0f | barrier %.0f | want+scan %.0f | barrier+offsets+sources %.0f | barrier+gather %.0f | barrier %.0f | runs %.0f | list+eval %.0f | finish %.0f\n", MODE, c->N,
+		        d[1] * q, d[2] * q, d[3] * q, d[4] * q, d[5] * q, d[6] * q, d[7] * q, d[8] * q, d[9] * q);
 	}
 #endif
 	if (timed) {
@@ -700,7 +705,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		               up + 9 * (size_t)N, (const uint8_t *)(up + 14 * (size_t)N) };
 		hipLaunchKernelGGL(k_prepare, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, N, c->goff, GL, c->ctg_base, c->exon, c->prot_gid, c->gene_pref,
 		                   up + 10 * (size_t)N, up + 11 * (size_t)N, up + 12 * (size_t)N, up + 13 * (size_t)N, (uint64_t *)c->pool.get(S_KEY_A, 0), (uint32_t *)c->pool.get(S_VAL_A, 0),
-		                   c->rk_shift, c->hrank, up + 15 * (size_t)N, up + 16 * (size_t)N);
+		                   c->rk_shift, c->hrank, up + 15 * (size_t)N, up + 16 * (size_t)N, c->dcnt + 9);
 	}
 	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
 	int rc = sync_st(c); // the caller's blocks and tables have been read
@@ -708,6 +713,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		fprintf(stderr, "[E::pga_create] %lld hit(s) with coordinates, contig ids or scores outside what their genome block declares\n", (long long)c->h_cnt[8]);
 		rc = PGA_ERR_RANGE;
 	}
+	c->exon_regular = rc != 0 || c->h_cnt[9] == 0; // (dcnt[9] is the rounds' overflow counter later on; pga_begin clears it)
 	if (timing) fprintf(stderr, "[pga_create] allocations %.3f ms, upload of %.1f MB in %zu copy command(s) + unpack %.3f ms\n", (t1 - t0) * 1e3, woff[(size_t)GL] * 4e-6, runs.size(), (now() - t1) * 1e3);
 	return rc;
 }

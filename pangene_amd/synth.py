@@ -26,7 +26,7 @@ from typing import Iterator, List, Tuple
 
 import numpy as np
 
-__all__ = ["bact", "human", "fuzz", "write_files"]
+__all__ = ["bact", "human", "fuzz", "odd_exons", "write_files"]
 
 
 def _rng(seed: int, *stream: int) -> np.random.Generator:
@@ -386,6 +386,46 @@ def fuzz(seed: int, harsh: bool = True) -> Iterator[Tuple[str, str]]:
                 hits.sort(key=lambda t: -t[0])
                 lines.extend(t[1] for t in hits)
         yield ("f%02d.paf" % j, "".join(lines))
+
+
+def odd_exons(seed: int) -> Iterator[Tuple[str, str]]:
+    """Exon lists that are NOT sorted and disjoint: U / V introns shorter than 3 bp make the next exon start before the last one ends
+    (read.c:59-62: st = x + 1, en = x + l - 2), zero-length introns make exons touch, `0M` between two introns makes an exon of no
+    length.  miniprot does not write such lines; the reference takes them (its pg_hit_overlap only asserts l_inter <= l_union), and the
+    device path must then merge step by step like it (cds_inter_ref) instead of taking its shortcuts.  Piles of overlapping
+    multi-exon isoforms of few genes, so that most pairs are evaluated."""
+    r = _rng(seed, -7)
+    G = int(r.integers(3, 7))
+    n_gene = int(r.integers(6, 15))
+    genes = [(int(r.integers(2, 5)), int(r.integers(2, 7))) for _ in range(n_gene)]
+    for j in range(G):
+        rj = _rng(seed, j)
+        lines = []
+        for g, (n_iso, ne) in enumerate(genes):
+            base = 1000 + 900 * int(rj.integers(0, 12))
+            strand = int(rj.integers(0, 2))
+            for k in range(n_iso):
+                for h in range(int(rj.integers(1, 3))):
+                    e = int(rj.integers(1, ne + 1))
+                    ops, span = [], 0
+                    for a in range(e):
+                        L = int(rj.choice([0, 10, 20, 40]))
+                        ops.append("%dM" % L); span += 3 * L
+                        if a + 1 < e:
+                            il = int(rj.choice([0, 1, 2, 3, 60, 300]))
+                            ops.append("%d%s" % (il, "NUV"[int(rj.integers(0, 3))])); span += il
+                    if span == 0:
+                        ops, span = ["10M"], 30
+                    if strand:
+                        ops = ops[::-1]
+                    plen = max(1, sum(int(o[:-1]) for o in ops if o[-1] == "M"))
+                    x = base + 30 * int(rj.integers(0, 6))
+                    mlen = int(3 * plen * float(rj.choice([1.0, 0.9])))
+                    ms = int(1.6 * mlen)
+                    lines.append((g, -ms, "G%03d:T%d\t%d\t0\t%d\t%s\tS%d#1#c0\t%d\t%d\t%d\t%d\t%d\t0\tms:i:%d\tcg:Z:%s\n" % (
+                        g, k, plen, plen, "+-"[strand], j, 400000, x, x + span, mlen, 3 * plen, ms, "".join(ops))))
+        lines.sort(key=lambda t: (t[0], t[1]))
+        yield ("o%02d.paf" % j, "".join(t[2] for t in lines))
 
 
 def dense(seed: int = 1, G: int = 4, n_small: int = 700, pile: int = 48) -> Iterator[Tuple[str, str]]:

@@ -24,7 +24,9 @@ except Exception as ex:
 # idle time is distributed (launch gaps vs host waits); the last `--steps` passes are delimited by the k_prepare launches
 try:
     ev = cur.execute("SELECT name, start, end FROM kernels ORDER BY start").fetchall()
-    starts = [i for i, e in enumerate(ev) if e[0].startswith("k_genome_sort") and not (i and ev[i - 1][0].startswith("k_genome_sort"))] or [i for i, e in enumerate(ev) if e[0].startswith("k_prepare")]  # first big kernel of pga_begin (stage A's orders may take two launches: k_genome_sort2 + k_genome_sort2d)
+    # first big kernel of pga_begin: k_genome_sort* (stage A's orders may take two launches: k_genome_sort2 + k_genome_sort2d) or, for
+    # genomes beyond the per-genome sorts (the 110 k-hit assemblies of configs[4]), k_prepare in front of the multi-workgroup radix sort
+    starts = [i for i, e in enumerate(ev) if (e[0].startswith("k_genome_sort") and not (i and ev[i - 1][0].startswith("k_genome_sort"))) or e[0].startswith("k_prepare")]
     if len(starts) >= 3:
         a, b = starts[-2], starts[-1]  # one whole pass: from one k_prepare to the next
         seg = ev[a:b]

@@ -230,6 +230,28 @@ def test_hip_equals_oracle(hip, ora, name, variant, mode):
     assert a == b
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", ["", "-p0 -a1", "-f 0.3", "--bed=flag"])
+def test_irregular_exon_lists_hip_equals_oracle(hip, ora, tmp_path, seed, variant):
+    """synth.odd_exons: U / V introns shorter than 3 bp, zero-length introns and exons -- exon lists that are not sorted and disjoint
+    (the reference itself aborts on most of them: overlap.c:135 asserts cov_short <= 1).  The sweep's merges then may not take their
+    shortcuts (early exit, shared exons in one step, bisection to the first overlapping exon: k_sweep.hpp cds_inter_t): k_prepare
+    notices and every merge takes the reference's steps one by one (cds_inter_ref); HIP and oracle must agree byte for byte."""
+    files = synth.write_files(synth.odd_exons(seed), str(tmp_path))
+    for mode in (0, 2):
+        hip.pg_set_exact_mode(mode), ora.pg_set_exact_mode(mode)
+        assert capi.run(hip, files, variant.split()) == capi.run(ora, files, variant.split())
+
+
+@pytest.mark.parametrize("name,variant", [("human8f", "-p0 -a1"), ("human8", ""), ("human8f", "-f 0.2"), ("mut1", "-S")])
+def test_literal_merge_on_regular_lists_changes_nothing(hip, expected, tmp_path, name, variant):
+    """PANGENE_MERGE_LITERAL=1: the step-by-step merge of overlap.c:17-33 instead of cds_inter_t's shortcuts, on ordinary data: same bytes"""
+    if variant not in expected[name]:
+        pytest.skip("no such golden variant")
+    out = _run_with_env(tmp_path, {"PANGENE_MERGE_LITERAL": "1"}, 2, variant, golden_files(name))
+    assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
+
+
 def _expected_large(name, variant):
     p = os.path.join(ROOT, "tests", "golden", "expected_large.json")
     if not os.path.exists(p):
