@@ -16,9 +16,8 @@
  *                                            main.c calls pg_post_process next)
  *   pg_post_process        graph.c:7-32     (+ the deferred read.c:243-260) -> HIP kernels.  The hits are taken as pg_read_paf
  *                                            left them (each genome is packed for the device while the next file is parsed);
- *                                            a genome edited in between is packed again when its hit / exon count changed or a
- *                                            sample of its records (every 257th, the first, the last) did -- other in-place
- *                                            edits of g->hit between the two calls are not seen
+ *                                            a genome edited in between is packed again: the pack carries a signature over
+ *                                            every field of every hit and exon it was made from, checked by pg_post_process
  *   pg_graph_init/gen/destroy graph.c:34-47, 280-322 -> HIP kernels + host round driver
  *   pg_write_bed/graph/walk format.c:113-225
  *   pg_read_list_dict, pg_dict_destroy  read.c:305-318, dict.c:38-49 (main.c:73-75,140-142 need them)

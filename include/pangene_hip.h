@@ -411,7 +411,10 @@ void *pga_active_stream(void);
 
 /* Kernel timing hooks for bench.py: HIP events bracket every launch of the named kernel class on the
  * library's stream, from the first pga_timing_reset on.  which: 0 = "k1" (stage A sweep, the hit-filter+overlap kernel),
- * 1 = the pg_flt_ov_isoform sweep, 2 = the other pg_shadow sweeps, 3 = the whole of stage A (pga_begin + pga_ingest). */
+ * 1 = the pg_flt_ov_isoform sweep, 2 = the other pg_shadow sweeps, 3 = the whole of stage A (pga_begin + pga_ingest), 4 = host waits
+ * (count only); with PANGENE_TIME_ROUNDS=1 in the environment at pga_timing_reset also 5 = every pg_gen_arc round (graph.c:87-177: sweep, walk,
+ * temp arcs, collapse -- two more events per round, so for a pass that is not itself timed) and 6 = its walk scan alone.
+ * which | (k + 1) << 8 selects the k-th timed launch of the class alone. */
 int pga_timing_reset(pga_ctx_t *ctx);
 int pga_timing_get(pga_ctx_t *ctx, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
 

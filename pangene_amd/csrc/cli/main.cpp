@@ -233,7 +233,7 @@ static int run_sharded(pg_opt_t &opt, int W, int n_files, char **files, const Ou
 		}
 		for (int r = 1; r < W; ++r) { unsigned char s = 0; if (!read_all(st_pipe[(size_t)r * 2], &s, 1) || !s) ok = 0; }
 		for (int r = 1; r < W; ++r) write_all(id_pipe[(size_t)r * 2 + 1], &ok, 1); // go / no go
-		if (!ok) { for (int r = 1; r < W; ++r) { int st; waitpid(kid[(size_t)r], &st, 0); } take_down(true); return 3; }
+		if (!ok) { for (int r = 1; r < W; ++r) { int st; waitpid(kid[(size_t)r], &st, 0); kid[(size_t)r] = 0; } take_down(true); return 3; } // (reaped: take_down must not signal a pid the system may have given to somebody else)
 	} else {
 		close(id_pipe[(size_t)rank * 2 + 1]), close(st_pipe[(size_t)rank * 2]);
 		unsigned char ok = 0, go = 0, mine = rc == 0 ? 1 : 0;

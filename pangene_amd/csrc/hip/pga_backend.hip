@@ -252,6 +252,7 @@ struct pga_ctx {
 	struct { double diff; int32_t local_dist, local_count, frag_mode; } br_par = { 0, 0, 0, 0 };
 	int32_t *h_ndl = nullptr; size_t h_ndl_cap = 0; // pinned: n_dist_loci of a round
 	std::vector<TimedLaunch> timed; bool timing_on = false; // HIP-event timing of kernel classes, switched on by pga_timing_reset (bench.py)
+	bool timing_rounds = false; // ... also every pg_gen_arc round (class 5: sweep + walk scan + gene kernels = SURVEY 8(d)'s K2) and its walk scan alone (class 6); PANGENE_TIME_ROUNDS=1 at pga_timing_reset: two more events per round, so only for a pass that is not itself timed
 	hipEvent_t span_a = nullptr; // start of stage A (pga_begin), paired with an event at the end of pga_ingest
 	std::vector<void *> owned; void *arena = nullptr; size_t arena_cap = 0; // owned: allocations of their own (PANGENE_NO_ARENA); arena: the one block the persistent arrays are carved from
 	std::vector<std::pair<void **, size_t>> plan; // persistent arrays waiting for the arena (create)
@@ -1078,6 +1079,12 @@ static int ensure_z(pga_ctx *c)
 	return 0;
 }
 
+static void time_mark(pga_ctx *c, TimedLaunch *t, int which, bool end)
+{
+	if (!end) { t->which = which, t->units = c->N; (void)hipEventCreate(&t->a); (void)hipEventCreate(&t->b); (void)hipEventRecord(t->a, c->st); }
+	else { (void)hipEventRecord(t->b, c->st); c->timed.push_back(*t); }
+}
+
 // (A) of k_genes.hpp: walk the cm order once, leave every walkable hit's two half-arc records
 static int ensure_half_arcs(pga_ctx *c, int use_ori)
 {
@@ -1093,7 +1100,9 @@ static int ensure_half_arcs(pga_ctx *c, int use_ori)
 	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(c->N));
 	int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
 	if (!tile || !hzl) return PGA_ERR_NOMEM;
+	TimedLaunch tw; if (c->timing_rounds) time_mark(c, &tw, 6, false);
 	device_scan<I32>(InWalk{c->flags, c->yperm}, OutHalfArcs{c->yrecA, c->yrecB, c->zposy, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->dcnt, hzl}, c->N, tile, OpMax{}, I32{-1}, c->st, c->gate);
+	if (c->timing_rounds) time_mark(c, &tw, 6, true);
 	c->ha_valid = true, c->ha_ori = use_ori;
 	return 0;
 }
@@ -1126,9 +1135,11 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	TRY(cur_table(c, cap, S, &t));
 	*seg_cnt_out = seg_cnt, *deg_out = t.dg;
 	c->table_sparse = true;
+	TimedLaunch tr; if (c->timing_rounds) time_mark(c, &tr, 5, false);
 	TRY(launch_sweep<0>(c, 2)); // graph.c:102
 	TRY(ensure_half_arcs(c, use_ori));
 	if (S == 0) { // nothing to build; the round's tail still has to be written (the pinned buffer is recycled memory)
+		if (c->timing_rounds) time_mark(c, &tr, 5, true);
 		hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box, h_round_dev);
 		return 0;
 	}
@@ -1139,6 +1150,7 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt, c->gate, c->gate.w ? c->loopctl + 2 : (int32_t *)nullptr };
 	hipLaunchKernelGGL(k_gene_arcs_wave, dim3((unsigned)c->Q), dim3(BLOCK), 0, c->st, ga);
 	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 8 * c->n_cu)), dim3(BLOCK), 0, c->st, ga);
+	if (c->timing_rounds) time_mark(c, &tr, 5, true);
 	if (mail) hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box, h_round_dev ? h_round_dev + 4 * (size_t)S : (int32_t *)nullptr); // invariant / overflow counters for the host; the overflow counter starts again
 	return 0;
 }
@@ -2090,6 +2102,7 @@ extern "C" int pga_timing_reset(pga_ctx_t *c)
 	for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	c->timed.clear();
 	c->timing_on = true;
+	{ const char *e = getenv("PANGENE_TIME_ROUNDS"); c->timing_rounds = e && *e == '1'; }
 	return 0;
 }
 
@@ -2102,9 +2115,12 @@ extern "C" int pga_timing_get(pga_ctx_t *c, int32_t which, double *total_ms, int
 		return 0;
 	}
 	TRY(sync_st(c));
-	double ms = 0; int64_t n = 0, u = 0;
+	const int only = which >> 8; // (class | (k + 1) << 8: the k-th timed launch of the class alone)
+	which &= 255;
+	double ms = 0; int64_t n = 0, u = 0; int k = 0;
 	for (auto &t : c->timed) {
 		if (t.which != which) continue;
+		if (only && ++k != only) continue;
 		float f = 0;
 		HIPCHK(hipEventElapsedTime(&f, t.a, t.b));
 		ms += f, ++n, u += t.units;
@@ -2116,10 +2132,24 @@ extern "C" int pga_timing_get(pga_ctx_t *c, int32_t which, double *total_ms, int
 }
 
 // The HBM bandwidth a plain copy reaches on THIS device in THIS process ("calibrate with a copy kernel in the same
-// run"): 16 bytes per lane, grid-stride, `bytes` read and `bytes` written per repetition, timed with HIP events; GB/s of read + write.
-__global__ __launch_bounds__(BLOCK) void k_copy16(const int4 *__restrict__ src, int4 *__restrict__ dst, size_t n16)
+// run"): 16 bytes per lane and U of them in flight per lane (the loads of a step are all issued before its stores), `bytes` read and
+// `bytes` written per repetition, timed with HIP events; GB/s of read + write.  Round 4's form (one 16-byte item per lane per step,
+// grid-stride, at most 8192 workgroups) reached 4.7 TB/s where the guide measured 6.3 with a float4 copy: a calibration that
+// undersells the device makes every fraction "of measured" look better than it is, so the best of a few shapes is what is reported.
+typedef int pga_v4i __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_copy16(const int4 *__restrict__ src_, int4 *__restrict__ dst_, size_t n16)
 {
-	for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * BLOCK) dst[i] = src[i];
+	const pga_v4i *__restrict__ src = reinterpret_cast<const pga_v4i *>(src_);
+	pga_v4i *__restrict__ dst = reinterpret_cast<pga_v4i *>(dst_);
+	const size_t step = (size_t)gridDim.x * BLOCK * U;
+	for (size_t i0 = (size_t)blockIdx.x * BLOCK * U + threadIdx.x; i0 < n16; i0 += step) {
+		pga_v4i v[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) if (i0 + (size_t)u * BLOCK < n16) v[u] = NT ? __builtin_nontemporal_load(&src[i0 + (size_t)u * BLOCK]) : src[i0 + (size_t)u * BLOCK];
+#pragma unroll
+		for (int u = 0; u < U; ++u) if (i0 + (size_t)u * BLOCK < n16) { if (NT) __builtin_nontemporal_store(v[u], &dst[i0 + (size_t)u * BLOCK]); else dst[i0 + (size_t)u * BLOCK] = v[u]; }
+	}
 }
 
 extern "C" int pga_copy_gbps(size_t bytes, int32_t reps, double *gbps)
@@ -2134,17 +2164,28 @@ extern "C" int pga_copy_gbps(size_t bytes, int32_t reps, double *gbps)
 	HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
 	HIPCHK(hipMemsetAsync(a, 1, bytes, st));
 	const size_t n16 = bytes / 16;
-	const unsigned grid = (unsigned)std::min<size_t>((n16 + BLOCK - 1) / BLOCK, (size_t)256 * 32);
-	hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(BLOCK), 0, st, (const int4 *)a, (int4 *)b, n16); // warm
+	int ncu = 256;
+	{ int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v; }
 	double best = 0;
-	for (int r = 0; r < reps; ++r) {
-		HIPCHK(hipEventRecord(e0, st));
-		hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(BLOCK), 0, st, (const int4 *)a, (int4 *)b, n16);
-		HIPCHK(hipEventRecord(e1, st));
-		HIPCHK(hipEventSynchronize(e1));
-		float ms = 0;
-		HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-		if (ms > 0) best = std::max(best, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+	static const bool verbose = getenv("PANGENE_TIMING") != nullptr;
+	for (int shape = 0; shape < 8; ++shape) {
+		const int U = shape & 1 ? 8 : 4, per_cu = shape & 2 ? 16 : 8; const bool nt = (shape & 4) != 0;
+		const unsigned grid = (unsigned)std::min<size_t>((n16 + (size_t)BLOCK * U - 1) / ((size_t)BLOCK * U), (size_t)ncu * per_cu);
+		double top = 0;
+		for (int r = 0; r < reps + 1; ++r) { // (the first one warms)
+			HIPCHK(hipEventRecord(e0, st));
+			if (U == 4 && !nt) hipLaunchKernelGGL((k_copy16<4, false>), dim3(grid), dim3(BLOCK), 0, st, (const int4 *)a, (int4 *)b, n16);
+			else if (U == 8 && !nt) hipLaunchKernelGGL((k_copy16<8, false>), dim3(grid), dim3(BLOCK), 0, st, (const int4 *)a, (int4 *)b, n16);
+			else if (U == 4) hipLaunchKernelGGL((k_copy16<4, true>), dim3(grid), dim3(BLOCK), 0, st, (const int4 *)a, (int4 *)b, n16);
+			else hipLaunchKernelGGL((k_copy16<8, true>), dim3(grid), dim3(BLOCK), 0, st, (const int4 *)a, (int4 *)b, n16);
+			HIPCHK(hipEventRecord(e1, st));
+			HIPCHK(hipEventSynchronize(e1));
+			float ms = 0;
+			HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+			if (r > 0 && ms > 0) top = std::max(top, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+		}
+		if (verbose) fprintf(stderr, "[pga_copy_gbps] %d items per lane, %d workgroups per CU, %s stores: %.0f GB/s\n", U, per_cu, nt ? "nontemporal" : "plain", top);
+		best = std::max(best, top);
 	}
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
 	(void)hipFree(a); (void)hipFree(b);

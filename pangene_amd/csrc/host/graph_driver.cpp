@@ -211,19 +211,23 @@ static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 }
 
 // A pack made when the genome was read is only good while the genome still is what it was then.  The public pg_data_t may be
-// edited between pg_read_paf and pg_post_process (the reference reads g->hit at post-process time): a changed hit or exon count,
-// or a change in a sample of the records, makes the block stale and it is packed again.  (Edits that keep the counts and miss
-// the sample -- every 257th record, the first and the last -- are not seen: see include/pangene_amd.h, pg_post_process.)
+// edited between pg_read_paf and pg_post_process (the reference reads g->hit at post-process time, graph.c:7-32): a changed hit or
+// exon count, or a change in ANY field of ANY record that the pack carries, makes the block stale and it is packed again.  (Round 4
+// sampled every 257th record; one pass over the records costs a fraction of the pack it may save -- four independent multiply chains
+// keep it at memory speed -- and an edit can no longer slip through.)
 static uint64_t genome_signature(const pg_genome_t *g)
 {
-	uint64_t h = 1469598103934665603ull ^ (uint64_t)(uint32_t)g->n_hit ^ (uint64_t)(uint32_t)g->n_exon << 32;
-	auto mix = [&h](const pg_hit_t &a) {
-		const uint64_t w[4] = { (uint64_t)(uint32_t)a.pid << 32 | (uint32_t)a.cid, (uint64_t)a.cs, (uint64_t)a.ce ^ (uint64_t)a.cm << 1, (uint64_t)(uint32_t)a.score_adj << 32 | (uint32_t)a.n_exon << 1 | (uint32_t)a.rev };
-		for (uint64_t x : w) h = (h ^ x) * 1099511628211ull;
-	};
-	for (int32_t i = 0; i < g->n_hit; i += 257) mix(g->hit[i]);
-	if (g->n_hit > 0) mix(g->hit[g->n_hit - 1]);
-	return h;
+	uint64_t h[4] = { 1469598103934665603ull ^ (uint64_t)(uint32_t)g->n_hit, 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)g->n_exon, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull };
+	for (int32_t i = 0; i < g->n_hit; ++i) {
+		const pg_hit_t &a = g->hit[i];
+		uint64_t &x = h[i & 3];
+		x = (x ^ ((uint64_t)(uint32_t)a.pid << 32 | (uint32_t)a.cid)) * 1099511628211ull;
+		x = (x ^ (uint64_t)a.cs ^ (uint64_t)a.ce << 21 ^ (uint64_t)a.cm << 42) * 1099511628211ull;
+		x = (x ^ ((uint64_t)(uint32_t)a.score_adj << 32 | (uint32_t)a.score_ori)) * 1099511628211ull;
+		x = (x ^ ((uint64_t)(uint32_t)a.off_exon << 32 | (uint32_t)a.n_exon << 8 | (uint32_t)a.rev << 7 | (uint32_t)(a.rank & 0x7f) ^ (uint64_t)(uint32_t)a.rank << 40)) * 1099511628211ull;
+	}
+	for (int32_t i = 0; i < g->n_exon; ++i) { uint64_t &x = h[i & 3]; x = (x ^ ((uint64_t)(uint32_t)g->exon[i].os << 32 | (uint32_t)g->exon[i].oe)) * 0x100000001b3ull; }
+	return (h[0] * 31 + h[1]) * 31 + (h[2] * 31 + h[3]);
 }
 
 void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, double time_share)
@@ -534,7 +538,11 @@ int sync_host(pg_data_t *d, bool full)
 				const int32_t *old = ext->file_of_host[(size_t)j].data(); // host index -> file index
 				for (int32_t h = 0; h < g->n_hit; ++h) a[px[(size_t)(off + old[h])]] = g->hit[h];
 			}
-			if (!ext->arena_owns(g->hit)) std::free(g->hit); // (a batch read's arrays lie in its arena)
+			if (!ext->arena_owns(g->hit)) std::free(g->hit);
+			else { // a batch read's arrays lie in its arena: the pages of this slice go back now (the mapping itself at ext_drop), or a full sync would hold every hit twice
+				const uintptr_t a0 = ((uintptr_t)g->hit + 4095) & ~(uintptr_t)4095, a1 = ((uintptr_t)g->hit + sizeof(pg_hit_t) * (size_t)g->m_hit) & ~(uintptr_t)4095;
+				if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_DONTNEED);
+			}
 			g->hit = a, g->m_hit = g->n_hit;
 			ext->hits_sorted[(size_t)j] = 1;
 			ext->file_of_host[(size_t)j].assign((size_t)g->n_hit, 0);
@@ -623,6 +631,7 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 {
 	DataExt *ext = ext_of(d, true);
 	double t0 = now_sec();
+	if (ext->read_failed) { set_error(PGA_ERR_NOMEM, "pg_post_process: a pg_read_paf ran out of memory, the data set is incomplete"); return PGA_ERR_NOMEM; }
 	if (!(ext->rerun && ext->ctx)) {
 		g_pack_sec = ext->pack_sec, ext->pack_sec = 0.0; // what the reader spent on the blocks of this upload
 		BE_CALL(build_backend(opt, d, ext), "create"); // (rest of the) pack + allocation + H2D

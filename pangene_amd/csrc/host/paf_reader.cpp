@@ -4,6 +4,7 @@
 // out exactly as the reference's reader produces them (read.c:107-236, hit.c:14-27), because
 // pg_hash_uint32(pid) and the first-seen numbering are score-relevant downstream.
 #include <fcntl.h>
+#include <cerrno>
 #include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
@@ -133,8 +134,9 @@ public:
 		const size_t n = (size_t)sb.st_size;
 		if (tl_buf.size() < n + 2) tl_buf.resize(n + n / 4 + 4096);
 		size_t got = 0;
-		while (got < n) { const ssize_t k = read(fd, tl_buf.data() + got, n - got); if (k <= 0) break; got += (size_t)k; }
+		while (got < n) { const ssize_t k = read(fd, tl_buf.data() + got, n - got); if (k < 0 && errno == EINTR) continue; if (k <= 0) break; got += (size_t)k; }
 		close(fd);
+		if (got != n) return; // a short or failed read: not "the file" -- LineSource reads it line by line and reports what it finds
 		p_ = tl_buf.data(), end_ = p_ + got, ok_ = true;
 	}
 	bool ok() const { return ok_; }
@@ -306,20 +308,44 @@ struct ChangeLog { std::vector<std::pair<uint8_t, int32_t>> v; }; // (0 gene | 1
 // into a table of the file's own -- its local id hangs on its global id through an array -- only names new to the snapshot go into a
 // small dictionary.  (A bacterial genome brings 10 000 names, all but a few known after the first file: building two dictionaries
 // per file was a fifth of the parse.)
+// global id -> local id, open addressing over 32-bit keys (the table a file needs is as large as the file's own list of names, whatever the
+// size of the dictionary: an array over the whole snapshot per file was O(files x names) of memset and of memory for files in flight)
+struct IdMap {
+	std::vector<int32_t> key, val; size_t n = 0;
+	void clear() { key.clear(), val.clear(), n = 0; }
+	static size_t h(int32_t k, size_t mask) { return ((uint32_t)k * 2654435761u >> 7) & mask; }
+	int32_t get(int32_t k) const {
+		if (key.empty()) return -1;
+		const size_t mask = key.size() - 1;
+		for (size_t i = h(k, mask);; i = (i + 1) & mask) { if (key[i] == k) return val[i]; if (key[i] < 0) return -1; }
+	}
+	void put(int32_t k, int32_t v) { // k is not in the table
+		if (2 * (n + 1) > key.size()) {
+			std::vector<int32_t> ok, ov; ok.swap(key), ov.swap(val);
+			const size_t cap = ok.empty() ? 1024 : 2 * ok.size();
+			key.assign(cap, -1), val.assign(cap, -1);
+			for (size_t i = 0; i < ok.size(); ++i) if (ok[i] >= 0) { size_t j = h(ok[i], cap - 1); while (key[j] >= 0) j = (j + 1) & (cap - 1); key[j] = ok[i], val[j] = ov[i]; }
+		}
+		const size_t mask = key.size() - 1;
+		size_t i = h(k, mask);
+		while (key[i] >= 0) i = (i + 1) & mask;
+		key[i] = k, val[i] = v, ++n;
+	}
+};
 struct LocalNames {
 	const FlatIndex *known = nullptr;     // the snapshot's index at parse time (its ids are global ids), or NULL
-	std::vector<int32_t> lid_of_global;   // [known->size()] local id, -1 = not seen in this file
+	IdMap lid_of_global;                  // global id -> local id for the names of `known` this file has seen (sized by the file, not by the dictionary)
 	NameDict fresh;                       // the names `known` does not hold, first-seen order
 	std::vector<int32_t> lid_of_fresh;    // fresh id -> local id
 	std::vector<int32_t> global;          // local id -> global id, -1 = not known yet (resolved by preresolve() or the commit)
 	std::vector<int32_t> fresh_of;        // local id -> fresh id, -1 = a known name
 	int32_t size() const { return (int32_t)global.size(); }
-	void bind(const FlatIndex *k) { known = k; lid_of_global.assign(k ? (size_t)k->size() : 0, -1); }
+	void bind(const FlatIndex *k) { known = k; lid_of_global.clear(); }
 	int32_t put(std::string_view s, int32_t known_id, bool *absent) { // known_id: what known->find(s) gave (the caller has looked)
 		if (known_id >= 0) {
-			int32_t &l = lid_of_global[(size_t)known_id];
+			int32_t l = lid_of_global.get(known_id);
 			*absent = l < 0;
-			if (l < 0) l = (int32_t)global.size(), global.push_back(known_id), fresh_of.push_back(-1);
+			if (l < 0) l = (int32_t)global.size(), lid_of_global.put(known_id, l), global.push_back(known_id), fresh_of.push_back(-1);
 			return l;
 		}
 		const int32_t f = fresh.put(s, absent);
@@ -329,7 +355,7 @@ struct LocalNames {
 	std::string_view view(int32_t lid) const { return fresh_of[(size_t)lid] >= 0 ? fresh.view(fresh_of[(size_t)lid]) : known->view(global[(size_t)lid]); }
 	const char *name(int32_t lid) const { return fresh_of[(size_t)lid] >= 0 ? fresh.name(fresh_of[(size_t)lid]) : known->name(global[(size_t)lid]); }
 	int32_t local_of(int32_t gid, std::string_view nm) const { // the file's entry for global id `gid` (whose name is nm), -1 = none
-		if ((size_t)gid < lid_of_global.size()) return lid_of_global[(size_t)gid];
+		if (known && gid < known->size()) return lid_of_global.get(gid);
 		const int32_t f = fresh.get(nm);
 		return f < 0 ? -1 : lid_of_fresh[(size_t)f];
 	}
@@ -340,6 +366,7 @@ struct LocalNames {
 // reference's first-seen numbering (read.c:151-168) -- pg_hash_uint32(pid) makes the numbering score-relevant.
 struct alignas(128) FileParse { // (files next to each other on the command line are parsed side by side: no cache line shared between two of these)
 	bool opened = false, ids_only = false;
+	bool failed = false; // out of memory while the arrays grew: hits are missing, the file must not be committed as if it were whole
 	char *label = nullptr;
 	int32_t n_tot = 0;
 	LocalNames genes, prots;                   // local first-seen ids
@@ -564,7 +591,10 @@ static void parse_file(const pg_opt_t *opt, const char *fn, bool ids_only, FileP
 	}
 	fp.hits = hits, fp.n_hit = n_hit, fp.m_hit = m_hit, fp.exons = exons, fp.n_exon = n_exon, fp.m_exon = m_exon, fp.n_tot = n_tot;
 	fp.hits_arena = hits_arena, fp.exons_arena = exons_arena;
-	if (oom && pg_verbose >= 1) std::fprintf(stderr, "[E::%s] out of memory while reading '%s': hits were dropped\n", __func__, fn ? fn : "-");
+	if (oom) {
+		fp.failed = true;
+		if (pg_verbose >= 1) std::fprintf(stderr, "[E::%s] out of memory while reading '%s'\n", __func__, fn ? fn : "-");
+	}
 }
 
 static std::shared_mutex g_dict_mu; // writers of pg_data_t's growing arrays (batch and single-file reads)
@@ -606,6 +636,11 @@ static void preresolve(const std::shared_ptr<const DictSnap> &slot, FileParse &f
 static int32_t commit_ids(pg_data_t *d, FileParse &fp, ChangeLog *log = nullptr)
 {
 	if (!fp.opened) return -1;
+	if (fp.failed) { // a truncated genome would build a wrong graph with exit status 0: the read fails and pg_post_process refuses to run
+		set_error(PGA_ERR_NOMEM, "pg_read_paf: out of memory");
+		ext_of(d, true)->read_failed = true;
+		return -1;
+	}
 	NameDict *dg = (NameDict *)d->d_gene, *dp = (NameDict *)d->d_prot, *dc = (NameDict *)d->d_ctg;
 	DataExt *ext = ext_of(d, true);
 	std::unique_lock<std::shared_mutex> lk(g_dict_mu);

@@ -175,6 +175,7 @@ struct DataExt {
 	bool no_branch_loop = false;       // the queued branch rounds (pga_branch_loop) met something they cannot handle on this data set: host-driven rounds from now on
 	bool arc_pending = false;          // a deferred arc round whose host results have not been collected (arc_collect)
 	bool rerun = false;                // pg_rerun_resident(): keep the backend context, skip pack + upload
+	bool read_failed = false;          // a pg_read_paf ran out of memory half way through a file: the data set is not what the files hold
 	bool host_full = false;            // the last sync also fetched rank / score_dom / dominators
 	bool pos_valid = false;            // pos_x / y_order on the host match the backend's current orders
 	bool order_touched = false;        // an order override has been handed to the backend since the last sync (exact_sort)

@@ -128,3 +128,66 @@ def test_device_layout_limits_are_reported_not_asserted(tmp_path):
     q = tmp_path / "ok.paf"  # and the library is usable afterwards
     q.write_text("g1\t100\t0\t100\t+\tc1\t1000\t10\t310\t300\t300\t0\tms:i:400\tcg:Z:100M\n")
     assert capi.run(lib, [str(q)], []).startswith(b"S\tg1")
+
+
+def test_in_place_edit_between_read_and_post_process_is_seen(built, tmp_path):
+    """pg_read_paf packs every genome for the device while the next file is parsed; the reference reads g->hit at pg_post_process time
+    (graph.c:7-32), so a caller may edit the public pg_data_t in between.  The pack carries a signature over EVERY record it was made
+    from (round 4 sampled every 257th): an edit of one field of one hit -- here hit 3's score_adj, then an exon boundary -- must give
+    the output of a run that read the edited values, not the stale pack's."""
+    import ctypes as C
+    from pangene_amd import capi
+
+    class Hit(C.Structure):
+        _fields_ = [("pid", C.c_int32), ("qs", C.c_int32), ("qe", C.c_int32), ("cid", C.c_int32), ("mlen", C.c_int32), ("blen", C.c_int32), ("lof", C.c_int32),
+                    ("rank", C.c_int32), ("score_ori", C.c_int32), ("score_adj", C.c_int32), ("score_dom", C.c_int32), ("n_exon", C.c_int32), ("off_exon", C.c_int32),
+                    ("pid_dom", C.c_int32), ("pid_dom0", C.c_int32), ("bits", C.c_uint32), ("cs", C.c_int64), ("cm", C.c_int64), ("ce", C.c_int64)]
+
+    class Genome(C.Structure):
+        _fields_ = [("n_ctg", C.c_int32), ("m_ctg", C.c_int32), ("ctg", C.c_void_p), ("n_hit", C.c_int32), ("m_hit", C.c_int32), ("hit", C.POINTER(Hit)),
+                    ("n_exon", C.c_int32), ("m_exon", C.c_int32), ("exon", C.POINTER(C.c_int32)), ("label", C.c_void_p)]
+
+    class Data(C.Structure):
+        _fields_ = [("d_ctg", C.c_void_p), ("d_gene", C.c_void_p), ("d_prot", C.c_void_p), ("n_genome", C.c_int32), ("m_genome", C.c_int32), ("genome", C.POINTER(Genome)),
+                    ("n_gene", C.c_int32), ("m_gene", C.c_int32), ("gene", C.c_void_p), ("n_prot", C.c_int32), ("m_prot", C.c_int32), ("prot", C.c_void_p)]
+
+    assert C.sizeof(Hit) == 88 and C.sizeof(Genome) == 56 and C.sizeof(Data) == 72
+    lib = capi.load(oracle_host=True)
+    C.c_int.in_dll(lib, "pg_verbose").value = 0
+    files = golden_files("human8f")
+
+    n_run = [0]
+
+    def run(edit):
+        opt = capi.parse_args(lib, ["--bed=raw"])
+        n_run[0] += 1
+        out = str(tmp_path / ("o%d.bed" % n_run[0]))
+        lib.pg_set_output(out.encode())
+        d = lib.pg_data_init()
+        try:
+            capi.read_files(lib, opt, d, files)
+            if edit:
+                edit(C.cast(d, C.POINTER(Data)).contents)
+            lib.pg_post_process(C.byref(opt), d)
+            assert lib.pg_last_error() == 0
+            lib.pg_write_bed(d, 0)
+        finally:
+            lib.pg_data_destroy(d)
+            lib.pg_set_output(None)
+        return open(out, "rb").read()
+
+    base = run(None)
+
+    def bump_score(dd):  # a hit of a multi-isoform gene loses most of its score: it is no longer the isoform that survives
+        g = dd.genome[1]
+        assert g.n_hit > 300
+        g.hit[3].score_adj = 1
+
+    def move_exon(dd):  # the first exon of hit 5 of genome 2 shrinks to one base: CDS lengths and overlaps change
+        g = dd.genome[2]
+        h = g.hit[5]
+        g.exon[2 * h.off_exon + 1] = g.exon[2 * h.off_exon] + 1
+
+    a, b = run(bump_score), run(move_exon)
+    assert a != base and b != base and a != b
+    assert len(a.split(b"\n")) == len(base.split(b"\n")) == len(b.split(b"\n"))  # (the same hits, other flags and scores)
