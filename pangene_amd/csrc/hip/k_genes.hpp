@@ -69,36 +69,88 @@ __global__ __launch_bounds__(BLOCK) void k_zoff(const uint64_t *ks, int n, int Q
 	zoff[g] = lo;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_zpos_y(const int32_t *yperm, const int32_t *zpos, int n, int32_t *zposy)
+// What the walk reads of a hit, in Y (cm) order, ONE 32-byte record: W0 = {contig segment, vertex = gene << 1 | rev, cm, score_ori},
+// W1 = {score_dom, gene of pid_dom0's protein (-1: none), gene-major position z, 0}.  Round 4 read two 16-byte records out of two
+// arrays and the position out of a third: with one hit in five walkable (the late rounds of a bacterial shard) that is three 128-byte
+// lines per walkable hit for 36 useful bytes -- 103 B/hit read where ~45 are needed.  With virtual contigs (vfirst != NULL) "segment" is the
+// contig's FIRST piece and "cm" the low word of the true 64-bit cm (k_pack_yrec in k_arcs.hpp says why that is enough).
+__global__ __launch_bounds__(BLOCK) void k_pack_wrec(const int32_t *yperm, const int32_t *seg, const int32_t *gid, const int32_t *cm, const int32_t *sori, const int32_t *sdom,
+                                                       const int32_t *pdom0, const int32_t *prot_gid, const uint32_t *flags, const int32_t *zpos, int n, int4 *W,
+                                                       const int32_t *vfirst, const int64_t *vbase)
 {
 	int y = blockIdx.x * BLOCK + threadIdx.x;
-	if (y < n) zposy[y] = zpos[yperm[y]];
+	if (y >= n) return;
+	const int a = yperm[y], p0 = pdom0[a];
+	int sg = seg[a], cmv = cm[a];
+	if (vfirst) { cmv = (int)(unsigned)((unsigned long long)vbase[sg] + (unsigned long long)(long long)cmv); sg = vfirst[sg]; }
+	W[2 * (int64_t)y] = make_int4(sg, gid[a] << 1 | ((flags[a] & PGA_F_REV) ? 1 : 0), cmv, sori[a]);
+	W[2 * (int64_t)y + 1] = make_int4(sdom[a], p0 < 0 ? -1 : prot_gid[p0], zpos[a], 0);
 }
 
 // ------------------------------------------------------------------------------------------------
-// (A) output step of the walk scan (cm order): previous walkable hit -> half-arc records
+// (A) the walk (graph.c:103-122), cm order: previous walkable hit -> the two half-arc records of every walkable hit
 // ------------------------------------------------------------------------------------------------
-struct OutHalfArcs {
-	const int4 *__restrict__ YA, *__restrict__ YB; const int32_t *__restrict__ zposy, *__restrict__ g2s;
+// One launch (round 5; rounds 2-4: a three-launch scan -- reduce, tile sums, output step -- that read every flag twice).  The previous
+// walkable hit of a position is the running maximum of the walkable marks before it; what a tile needs from the tiles in front of it is
+// ONE number, the last walkable position before its first, and with walkable hits every few positions that is a glance backwards
+// (wave 0 looks at 64 positions at a time while the other waves load the tile's own flags), not a scan.
+constexpr int WK_IPT = 4, WK_TILE = BLOCK * WK_IPT;
+struct Walk {
+	const uint32_t *__restrict__ flags; const int32_t *__restrict__ yperm; const int4 *__restrict__ W; const int32_t *__restrict__ g2s;
 	uint32_t *__restrict__ hfk, *__restrict__ hbk; int4 *__restrict__ hfp, *__restrict__ hbp; // key word / payload {distance, score of this hit, score of the other, 0} of the two half-arcs
-	uint32_t tag; int ori; int64_t *dcnt; int32_t *hz_list;
-	__device__ __forceinline__ void operator()(int64_t i, I32 incl, I32 ex) const
-	{
-		if (incl.v == ex.v) return; // not walkable (graph.c:108)
-		const int p = ex.v, pp = p >= 0 ? p : (int)i;
-		const int4 aA = YA[i], aB = YB[i], bA = YA[pp], bB = YB[pp]; // {seg, gid, genome, cm}, {score_ori, score_dom, gene of pid_dom0, X position << 1 | rev}: one round of loads
-		const int zi = zposy[i], zp = zposy[pp];
-		uint32_t key = tag << HA_TAG_SHIFT | HA_NONE;
-		if (p >= 0 && bA.x == aA.x) { // same contig: adjacency p -> i (graph.c:113-121)
-			const uint32_t w = (uint32_t)aA.y << 1 | (uint32_t)(aB.w & 1), v = (uint32_t)bA.y << 1 | (uint32_t)(bB.w & 1);
-			const int sa = arc_score(aB, ori, g2s), sb = arc_score(bB, ori, g2s), d = (int)((unsigned)aA.w - (unsigned)bA.w); // (k_pack_yrec: low words of 64-bit coordinates when the shard has virtual contigs)
-			if (aA.w == bA.w) { atomicAdd((unsigned long long *)&dcnt[5], 1ull); hz_note(&dcnt[14], hz_list, aA.x); } // hazard H2a: equal cm
-			hfk[zp] = tag << HA_TAG_SHIFT | w, hfp[zp] = make_int4(d, sb, sa, 0); // v -> w,     s1 = score(v), s2 = score(w) (graph.c:117)
-			key = tag << HA_TAG_SHIFT | (v ^ 1u), hbp[zi] = make_int4(d, sa, sb, 0); // w^1 -> v^1, s1 = score(w), s2 = score(v) (graph.c:119)
-		}
-		hbk[zi] = key; // written for EVERY walkable hit: "carries the round's tag" = "is walkable in this round"
-	}
+	uint32_t tag; int ori; int n; int64_t *dcnt; int32_t *hz_list; Gate gate;
 };
+__device__ __forceinline__ int walk_score(const int4 w0, const int4 w1, int ori, const int32_t *g2s)
+{ // pg_get_score, graph.c:82-85: score_ori unless the dominator's gene is not a vertex and score_dom is at least as large
+	return (ori || w0.w > w1.x || w1.y < 0 || g2s[w1.y] >= 0) ? w0.w : w1.x;
+}
+__global__ __launch_bounds__(BLOCK) void k_walk(Walk a)
+{
+	__shared__ int32_t s_wave[BLOCK / WAVE], s_carry;
+	if (gate_closed(a.gate)) return;
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int64_t tile0 = (int64_t)blockIdx.x * WK_TILE, base = tile0 + (int64_t)tid * WK_IPT;
+	int mark[WK_IPT];
+#pragma unroll
+	for (int k = 0; k < WK_IPT; ++k) { const int64_t i = base + k; mark[k] = (i < a.n && !(a.flags[a.yperm[i]] & (PGA_F_FLT | PGA_F_SHADOW))) ? (int)i : -1; } // graph.c:108
+	if (w == 0) { // the last walkable position in front of the tile
+		int carry = -1;
+		for (int64_t j0 = tile0 - 1; j0 >= 0 && carry < 0; j0 -= 64) {
+			const int64_t j = j0 - lane;
+			const bool ok = j >= 0 && !(a.flags[a.yperm[j]] & (PGA_F_FLT | PGA_F_SHADOW));
+			const unsigned long long mk = __ballot(ok);
+			if (mk) carry = (int)(j0 - (__ffsll((long long)mk) - 1));
+		}
+		if (lane == 0) s_carry = carry;
+	}
+	int t_max = mark[0];
+#pragma unroll
+	for (int k = 1; k < WK_IPT; ++k) t_max = t_max > mark[k] ? t_max : mark[k];
+	I32 incl = wave_scan_incl(I32{t_max}, OpMax{}, lane);
+	if (lane == 63) s_wave[w] = incl.v;
+	__syncthreads();
+	int run = s_carry; // exclusive running maximum in front of this thread's items
+	for (int k = 0; k < w; ++k) run = run > s_wave[k] ? run : s_wave[k];
+	{ const int pv = incl.shfl_up(1).v; if (lane > 0) run = run > pv ? run : pv; }
+#pragma unroll
+	for (int k = 0; k < WK_IPT; ++k) {
+		const int i = mark[k];
+		if (i < 0) continue;
+		const int p = run, pp = p >= 0 ? p : i;
+		run = i;
+		const int4 a0 = a.W[2 * (int64_t)i], a1 = a.W[2 * (int64_t)i + 1], b0 = a.W[2 * (int64_t)pp], b1 = a.W[2 * (int64_t)pp + 1];
+		const int zi = a1.z, zp = b1.z;
+		uint32_t key = a.tag << HA_TAG_SHIFT | HA_NONE;
+		if (p >= 0 && b0.x == a0.x) { // same contig: adjacency p -> i (graph.c:113-121)
+			const uint32_t wv = (uint32_t)a0.y, v = (uint32_t)b0.y;
+			const int sa = walk_score(a0, a1, a.ori, a.g2s), sb = walk_score(b0, b1, a.ori, a.g2s), d = (int)((unsigned)a0.z - (unsigned)b0.z); // (low words of 64-bit coordinates when the shard has virtual contigs)
+			if (a0.z == b0.z) { atomicAdd((unsigned long long *)&a.dcnt[5], 1ull); hz_note(&a.dcnt[14], a.hz_list, a0.x); } // hazard H2a: equal cm
+			a.hfk[zp] = a.tag << HA_TAG_SHIFT | wv, a.hfp[zp] = make_int4(d, sb, sa, 0); // v -> w,     s1 = score(v), s2 = score(w) (graph.c:117)
+			key = a.tag << HA_TAG_SHIFT | (v ^ 1u), a.hbp[zi] = make_int4(d, sa, sb, 0); // w^1 -> v^1, s1 = score(w), s2 = score(v) (graph.c:119)
+		}
+		a.hbk[zi] = key; // written for EVERY walkable hit: "carries the round's tag" = "is walkable in this round"
+	}
+}
 
 // ------------------------------------------------------------------------------------------------
 // (B) one wave per gene (one workgroup for a gene with many hits or many neighbours)

@@ -232,7 +232,8 @@ struct pga_ctx {
 	DevPool pool; PinArena pin;
 	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
 	// gene-major index (k_genes.hpp): hits by (gene, genome, X position); half-arc records of the current walk
-	int32_t *zx = 0, *zy = 0, *zg = 0; int2 *zst = 0; int32_t *zpos = 0, *zposy = 0, *zoff = 0; // gene-major planes (k_genes.hpp)
+	int32_t *zx = 0, *zy = 0, *zg = 0; int2 *zst = 0; int32_t *zpos = 0, *zoff = 0; // gene-major planes (k_genes.hpp)
+	int4 *wrec = 0; bool wrec_valid = false; // the walk's 32-byte records in cm order (k_pack_wrec): they carry the gene-major position, so a new index or a new cm order makes them stale
 	uint32_t *hfk = 0, *hbk = 0; int4 *hfp = 0, *hbp = 0; // half-arc key words and payloads
 	bool z_valid = false, ha_valid = false; uint32_t round_tag = 0; int ha_ori = -1;
 	Gate gate = Gate{nullptr, 0};     // what the launches of the moment carry (pga_branch_loop sets it per phase; open everywhere else)
@@ -241,7 +242,7 @@ struct pga_ctx {
 	int32_t *h_loopctl = nullptr;     // pinned mirror of loopctl (bump-allocated once per context)
 	int32_t *h_ov = nullptr; size_t h_ov_cap = 0; // pinned: position / file-index lists of an order override, two halves used in turn
 	hipEvent_t ov_ev[2] = { nullptr, nullptr }; bool ov_ev_used[2] = { false, false }; unsigned ov_seq = 0; // a half is free again when the copy out of it has happened
-	bool zposy_stale = false; // the gene-major index stands but the cm order (or the X numbering) changed: zposy has to be derived again (ensure_z)
+	bool zposy_stale = false; // the gene-major index stands but the cm order (or the X numbering) changed: the walk's records have to be packed again (ensure_z)
 	const pga_arc_part_t *cur_tab = nullptr; int64_t cur_tab_n = 0; // the table of pga_arc_set_current
 	bool table_sparse = false; // the current arc table lives in the genes' stretches (arc_round_genes) and has not been compacted
 	int32_t *h_round = nullptr; size_t h_round_cap = 0; // pinned: segment counters + degrees of a round
@@ -536,7 +537,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(dalloc(c, &c->rank, N)); TRY(dalloc(c, &c->sdom, N)); TRY(dalloc(c, &c->pdom, N)); TRY(dalloc(c, &c->pdom0, N)); TRY(dalloc(c, &c->flags, N));
 	TRY(dalloc(c, &c->yperm, N)); TRY(dalloc(c, &c->goff, GL + 1)); TRY(dalloc(c, &c->ggl, GL)); TRY(dalloc(c, &c->ctg_base, GL + 1)); TRY(dalloc(c, &c->inv, N)); TRY(dalloc(c, &c->headpos, GL + 1)); TRY(dalloc(c, &c->exon, E));
 	TRY(dalloc(c, &c->eoff, GL + 1)); TRY(dalloc(c, &c->woff, GL + 1));
-	TRY(dalloc(c, &c->zx, N)); TRY(dalloc(c, &c->zy, N)); TRY(dalloc(c, &c->zg, N)); TRY(dalloc(c, &c->zst, N)); TRY(dalloc(c, &c->zpos, N)); TRY(dalloc(c, &c->zposy, N)); TRY(dalloc(c, &c->zoff, (size_t)c->Q + 2));
+	TRY(dalloc(c, &c->zx, N)); TRY(dalloc(c, &c->zy, N)); TRY(dalloc(c, &c->zg, N)); TRY(dalloc(c, &c->zst, N)); TRY(dalloc(c, &c->zpos, N)); TRY(dalloc(c, &c->wrec, 2 * (size_t)N)); TRY(dalloc(c, &c->zoff, (size_t)c->Q + 2));
 	TRY(dalloc(c, &c->hfk, N)); TRY(dalloc(c, &c->hbk, N)); TRY(dalloc(c, &c->hfp, N)); TRY(dalloc(c, &c->hbp, N));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q)); TRY(dalloc(c, &c->hrank, c->P));
 	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
@@ -722,7 +723,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 // per-hit constants in file order, X order (sort + gather), running max of ce, Y order; resets all state
 extern "C" int pga_begin(pga_ctx_t *c)
 {
-	c->yrec_valid = false, c->z_valid = false, c->zposy_stale = false;
+	c->yrec_valid = false, c->wrec_valid = false, c->z_valid = false, c->zposy_stale = false;
 	const int N = c->N, GL = c->n_genome;
 	c->walk_valid = false, c->ha_valid = false;
 	if (c->x_arcs_run > 0) c->x_arcs_seen = c->x_arcs_run; // sharded rounds: what the run that just ended needed is what this one's exchange buffers hold
@@ -829,7 +830,7 @@ extern "C" int pga_create(pga_ctx_t **out, const pga_shard_t *sh, const pga_para
 // stage A (read.c:243-260) for all genomes of the shard
 extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 {
-	c->yrec_valid = false;
+	c->yrec_valid = false, c->wrec_valid = false;
 	const int N = c->N, GL = c->n_genome, P = c->P, Q = c->Q;
 	int32_t *d_stats = (int32_t *)c->pool.get(S_STATS, sizeof(int32_t) * 4 * (size_t)GL + 16);
 	if (!d_stats) return PGA_ERR_NOMEM;
@@ -903,7 +904,7 @@ extern "C" int pga_post_partials(pga_ctx_t *c, int32_t **max_ori, int64_t **sums
 
 extern "C" int pga_post_apply(pga_ctx_t *c, const uint8_t *prot_rep, const uint8_t *prot_pj, int64_t *n_pseudo)
 {
-	c->yrec_valid = false;
+	c->yrec_valid = false, c->wrec_valid = false;
 	uint8_t *d = (uint8_t *)c->pool.get(S_MISC, 2 * (size_t)c->P + 16);
 	if (!d) return PGA_ERR_NOMEM;
 	c->walk_valid = false, c->ha_valid = false;
@@ -920,7 +921,7 @@ extern "C" int pga_post_apply(pga_ctx_t *c, const uint8_t *prot_rep, const uint8
 
 extern "C" int pga_shadow(pga_ctx_t *c, int32_t cal_dom_sc, int32_t *stats)
 {
-	c->yrec_valid = false;
+	c->yrec_valid = false, c->wrec_valid = false;
 	if (cal_dom_sc) TRY(launch_sweep<1>(c, -1)); else TRY(launch_sweep<0>(c, 2));
 	if (stats) {
 		int32_t *d_stats = (int32_t *)c->pool.get(S_STATS, sizeof(int32_t) * 4 * (size_t)c->n_genome + 16);
@@ -1062,7 +1063,7 @@ static int ensure_z(pga_ctx *c)
 {
 	if (c->N == 0) return 0;
 	if (c->z_valid) {
-		if (c->zposy_stale) { hipLaunchKernelGGL(k_zpos_y, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->yperm, c->zpos, c->N, c->zposy); c->zposy_stale = false; c->ha_valid = false; }
+		if (c->zposy_stale) c->wrec_valid = false, c->zposy_stale = false, c->ha_valid = false;
 		return 0;
 	}
 	const int N = c->N;
@@ -1074,8 +1075,7 @@ static int ensure_z(pga_ctx *c)
 	TRY(radix_sort_pool(c, key, val, N, bits_for((uint32_t)std::max(1, c->Q)), &ks, &vs));
 	hipLaunchKernelGGL(k_zrec, dim3(nblk(N)), dim3(BLOCK), 0, c->st, vs, ks, c->ctg_base, c->n_genome, c->flags, c->cm, c->seg, N, ZIndex{c->zx, c->zy, c->zg, c->zst, c->zpos});
 	hipLaunchKernelGGL(k_zoff, dim3(nblk(c->Q + 1)), dim3(BLOCK), 0, c->st, ks, N, c->Q, c->zoff);
-	hipLaunchKernelGGL(k_zpos_y, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->yperm, c->zpos, N, c->zposy);
-	c->z_valid = true, c->ha_valid = false, c->zposy_stale = false;
+	c->z_valid = true, c->ha_valid = false, c->zposy_stale = false, c->wrec_valid = false;
 	return 0;
 }
 
@@ -1090,18 +1090,20 @@ static int ensure_half_arcs(pga_ctx *c, int use_ori)
 {
 	if (c->N == 0) return 0;
 	TRY(ensure_z(c));
-	ensure_yrec(c);
+	if (!c->wrec_valid) {
+		hipLaunchKernelGGL(k_pack_wrec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->yperm, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->N, c->wrec, c->vfirst, c->vbase);
+		c->wrec_valid = true;
+	}
 	if (c->ha_valid && c->ha_ori == use_ori) return 0;
 	if (++c->round_tag > HA_TAG_MAX) { // tags wrap: forget every old record
 		HIPCHK(hipMemsetAsync(c->hfk, 0xff, sizeof(uint32_t) * (size_t)c->N, c->st));
 		HIPCHK(hipMemsetAsync(c->hbk, 0xff, sizeof(uint32_t) * (size_t)c->N, c->st));
 		c->round_tag = 1;
 	}
-	I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(c->N));
 	int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
-	if (!tile || !hzl) return PGA_ERR_NOMEM;
+	if (!hzl) return PGA_ERR_NOMEM;
 	TimedLaunch tw; if (c->timing_rounds) time_mark(c, &tw, 6, false);
-	device_scan<I32>(InWalk{c->flags, c->yperm}, OutHalfArcs{c->yrecA, c->yrecB, c->zposy, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->dcnt, hzl}, c->N, tile, OpMax{}, I32{-1}, c->st, c->gate);
+	hipLaunchKernelGGL(k_walk, dim3(nblk(c->N, WK_TILE)), dim3(BLOCK), 0, c->st, Walk{c->flags, c->yperm, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->N, c->dcnt, hzl, c->gate});
 	if (c->timing_rounds) time_mark(c, &tw, 6, true);
 	c->ha_valid = true, c->ha_ori = use_ori;
 	return 0;
@@ -1910,7 +1912,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	// otherwise): with -S the index is rebuilt.  (The full-size configs[4] run rebuilt it -- a sort and seven gathers over 22 M hits --
 	// 49 times per pass.)
 	const bool z_keep = c->z_valid && (which == 1 || !c->par.check_strand);
-	c->walk_valid = false, c->ha_valid = false, c->yrec_valid = false;
+	c->walk_valid = false, c->ha_valid = false, c->yrec_valid = false, c->wrec_valid = false;
 	if (!z_keep) c->z_valid = false;
 	if (n_seg <= 0 || N == 0) return 0;
 	const int64_t T = seg_off[n_seg];
