@@ -506,6 +506,39 @@ def test_sharded_hip_ranks_on_one_gpu(built, expected, name, variant, cuts, monk
     assert hashlib.md5(whole).hexdigest() == expected[name][variant]["md5"]
 
 
+@pytest.mark.parametrize("shape,key,variant", [("bact", "bact1250x5k", ""), ("human", "human25x20k_iso5.5", "-p0 -a1")])
+def test_sharded_hip_eight_ranks_at_size_on_one_gpu(built, tmp_path, shape, key, variant):
+    """W = 8 (the node's width) AT SIZE: the per-GPU shard of BASELINE configs[3] (1 250 bacterial genomes, 12.1 M hits) and of
+    configs[4] (25 isoform-rich assemblies, 2.7 M hits, -p0 -a1), cut into eight ranks that share this box's one GPU and exchange over
+    gloo -- device-resident slot merges of tens of thousands of arcs, pair lists of hundreds of thousands of pairs, the learned
+    capacities, eight contexts side by side in HBM.  S/L lines of all ranks agree; with every rank's W lines they are the bytes
+    whose md5 the untouched reference gave for the whole set (tests/golden/expected_large.json)."""
+    import socket
+    import torch.multiprocessing as mp
+    e = _expected_large(key, variant)
+    if shape == "bact":
+        files = synth.write_files_parallel("bact", str(tmp_path / "s"), G=1250, P=5000, seed=1)
+    else:
+        files = synth.write_files_parallel("human", str(tmp_path / "s"), G=25, Q=20000, iso=5.5, seed=1, frag=True)
+    world = 8
+    cuts = [len(files) * r // world for r in range(world + 1)]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_on_shared_gpu, args=(r, world, port, files, variant.split(), cuts, q, None)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=1200) for _ in procs)
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    sl = [b"\n".join(l for l in res[r].split(b"\n") if l[:1] in (b"S", b"L")) for r in range(world)]
+    assert all(x == sl[0] for x in sl)
+    w = b"\n".join(l for r in range(world) for l in res[r].split(b"\n") if l[:1] == b"W")
+    whole = sl[0] + b"\n" + w + b"\n"
+    assert len(whole) == e["bytes"] and hashlib.md5(whole).hexdigest() == e["md5"]
+
+
 def _rank_native_rccl(rank, world, port, files, variant, cuts, q):
     import torch, torch.distributed as dist
     sys.path.insert(0, ROOT)
