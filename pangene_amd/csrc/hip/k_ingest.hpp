@@ -99,6 +99,14 @@ __global__ __launch_bounds__(BLOCK) void k_xkey(const int32_t *seg_f, const int3
 	if (i < n) key[i] = (uint64_t)seg_f[i] << cs_bits | (uint32_t)cs_f[i], val[i] = (uint32_t)i;
 }
 
+// the 64-bit score keys of overlap.c:137 alone (shards whose key does not fit 32 bits rank them by a sort every pass): everything else
+// k_prepare computes -- gene, CDS length (a walk over the exon list), static flag bits -- stands from the upload on
+__global__ __launch_bounds__(BLOCK) void k_score_key(const int32_t *pid_f, const int32_t *sadj_f, const int32_t *gid_f, const uint8_t *gene_pref, int n, uint64_t *key, uint32_t *val)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n) key[i] = (uint64_t)(int64_t)sadj_f[i] << 33 | (uint64_t)gene_pref[gid_f[i]] << 32 | hash_u32((uint32_t)pid_f[i]), val[i] = (uint32_t)i;
+}
+
 struct HitArrays {
 	int32_t *fidx, *gnm, *seg, *pid, *gid, *cs, *ce, *cm, *cds, *nex, *offx, *sori, *sadj, *rank, *sdom, *pdom, *pdom0;
 	int32_t *rk; uint32_t *flags;

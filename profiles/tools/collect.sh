@@ -7,6 +7,8 @@
 #   stage human   rocprofv3 --kernel-trace --stats with the human-shaped leg left in
 #   stage cal     calibration of FETCH_SIZE / WRITE_SIZE with kernels of known byte counts (profiles/tools/calibrate.py)
 #   stage full    BASELINE configs[3] / configs[4] at their full stated size on this one GPU (bench.py --workload config3 | config4)
+#   stage full4   configs[4] at full size under the profiler: kernel stats with the pass timeline, FETCH_SIZE / WRITE_SIZE per kernel, SQ counters of K1
+#   stage ranks8  eight ranks sharing the one GPU over gloo on the configs[3] / configs[4] per-GPU shards (pytest), with the wall time
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 tag=${1:-rXX}; shift; out=gpurun_out; mkdir -p $out
@@ -66,4 +68,21 @@ b = json.loads([l for l in open("$out/${tag}_bench_${wl}_full_size.json") if l.s
 print("$wl", json.dumps(b.get("full_size"))[:1500])
 PY
 	done;;
+full4)
+	B="python bench.py --workload config4 --steps 3 --warmup 1"
+	PANGENE_TIMING=1 rocprofv3 --kernel-trace --stats -d $out/prof_c4 -o s -- $B > $out/${tag}_bench_config4_under_rocprof.json 2> $out/${tag}_bench_config4_under_rocprof.stderr
+	python profiles/tools/kernel_stats.py $out/prof_c4 > $out/${tag}_kernel_stats_config4_full_size.txt; rm -rf $out/prof_c4
+	B1="python bench.py --workload config4 --steps 1 --warmup 0"
+	rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/prof_fetch -o f -- $B1 > /dev/null 2>&1
+	rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/prof_write -o w -- $B1 > /dev/null 2>&1
+	python profiles/tools/pmc_traffic.py $out/prof_fetch $out/prof_write 21920400 > $out/${tag}_pmc_traffic_config4_full_size.txt
+	python profiles/tools/k1_traffic.py $out/prof_fetch $out/prof_write $out/${tag}_bench_config4_under_rocprof.json > $out/k1_pmc_traffic_config4.json 2>/dev/null
+	rm -rf $out/prof_fetch $out/prof_write
+	rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace -d $out/prof_sq -o q -- $B1 > /dev/null 2>&1
+	python profiles/tools/pmc_summary.py $out/prof_sq "k_sweep<3" > $out/${tag}_pmc_sq_k1_config4.txt 2>&1; rm -rf $out/prof_sq
+	rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace -d $out/prof_sq -o q -- $B1 > /dev/null 2>&1
+	python profiles/tools/pmc_summary.py $out/prof_sq "k_sweep<3" | grep -v "^dur" >> $out/${tag}_pmc_sq_k1_config4.txt 2>&1; rm -rf $out/prof_sq
+	head -n 30 $out/${tag}_kernel_stats_config4_full_size.txt | cut -c1-160; head -n 12 $out/${tag}_pmc_traffic_config4_full_size.txt | cut -c1-160; cat $out/${tag}_pmc_sq_k1_config4.txt;;
+ranks8)
+	( time timeout 1500 python -m pytest tests/test_hip_parity.py -m gpu -q -k "eight_ranks_at_size" ) > $out/${tag}_pytest_eight_ranks_at_size.log 2>&1; tail -n 6 $out/${tag}_pytest_eight_ranks_at_size.log;;
 esac; done

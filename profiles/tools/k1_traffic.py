@@ -45,6 +45,9 @@ if "also_at_bench_size" in b["roofline"]:
     want["false"].insert(0, b["roofline"]["also_at_bench_size"]["hits_per_launch"])
 if b.get("human_shard") and b["human_shard"].get("roofline"):
     want["true"].append(b["human_shard"]["roofline"]["hits_per_launch"])
+if b.get("full_size") and b["full_size"].get("roofline"):  # bench.py --workload config3 | config4: the full-size leg behind the default workload
+    fr = b["full_size"]["roofline"]
+    want["true" if "<3, true>" in fr["kernel"] else "false"].append(fr["hits_per_launch"])
 out = []
 for flavour, sizes in want.items():
     if not sizes:
