@@ -74,17 +74,25 @@ __global__ __launch_bounds__(BLOCK) void k_zoff(const uint64_t *ks, int n, int Q
 // arrays and the position out of a third: with one hit in five walkable (the late rounds of a bacterial shard) that is three 128-byte
 // lines per walkable hit for 36 useful bytes -- 103 B/hit read where ~45 are needed.  With virtual contigs (vfirst != NULL) "segment" is the
 // contig's FIRST piece and "cm" the low word of the true 64-bit cm (k_pack_yrec in k_arcs.hpp says why that is enough).
-__global__ __launch_bounds__(BLOCK) void k_pack_wrec(const int32_t *yperm, const int32_t *seg, const int32_t *gid, const int32_t *cm, const int32_t *sori, const int32_t *sdom,
-                                                       const int32_t *pdom0, const int32_t *prot_gid, const uint32_t *flags, const int32_t *zpos, int n, int4 *W,
-                                                       const int32_t *vfirst, const int64_t *vbase)
+struct WrecSrc { const int32_t *yperm, *seg, *gid, *cm, *sori, *sdom, *pdom0, *prot_gid; const uint32_t *flags; const int32_t *zpos; const int32_t *vfirst; const int64_t *vbase; };
+__device__ __forceinline__ void pack_wrec_one(const WrecSrc &s, int64_t y, int4 *W)
 {
-	int y = blockIdx.x * BLOCK + threadIdx.x;
-	if (y >= n) return;
-	const int a = yperm[y], p0 = pdom0[a];
-	int sg = seg[a], cmv = cm[a];
-	if (vfirst) { cmv = (int)(unsigned)((unsigned long long)vbase[sg] + (unsigned long long)(long long)cmv); sg = vfirst[sg]; }
-	W[2 * (int64_t)y] = make_int4(sg, gid[a] << 1 | ((flags[a] & PGA_F_REV) ? 1 : 0), cmv, sori[a]);
-	W[2 * (int64_t)y + 1] = make_int4(sdom[a], p0 < 0 ? -1 : prot_gid[p0], zpos[a], 0);
+	const int a = s.yperm[y], p0 = s.pdom0[a];
+	int sg = s.seg[a], cmv = s.cm[a];
+	if (s.vfirst) { cmv = (int)(unsigned)((unsigned long long)s.vbase[sg] + (unsigned long long)(long long)cmv); sg = s.vfirst[sg]; }
+	W[2 * y] = make_int4(sg, s.gid[a] << 1 | ((s.flags[a] & PGA_F_REV) ? 1 : 0), cmv, s.sori[a]);
+	W[2 * y + 1] = make_int4(s.sdom[a], p0 < 0 ? -1 : s.prot_gid[p0], s.zpos[a], 0);
+}
+__global__ __launch_bounds__(BLOCK) void k_pack_wrec(WrecSrc s, int n, int4 *W)
+{
+	const int y = blockIdx.x * BLOCK + threadIdx.x;
+	if (y < n) pack_wrec_one(s, y, W);
+}
+// ... of the positions an order override moved hits to or from (whole contigs: a contig has the same index range in both orders)
+__global__ __launch_bounds__(BLOCK) void k_pack_wrec_list(WrecSrc s, const int32_t *pos, int64_t T, int4 *W)
+{
+	const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (t < T) pack_wrec_one(s, pos[t], W);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -150,6 +158,39 @@ __global__ __launch_bounds__(BLOCK) void k_walk(Walk a)
 		}
 		a.hbk[zi] = key; // written for EVERY walkable hit: "carries the round's tag" = "is walkable in this round"
 	}
+}
+
+// The walk again for the contigs an order override has just rearranged (pga_override_order: whole contigs, a few thousand hits of
+// millions), with the tag of the walk that stands: every listed position writes its OWN two records -- the adjacency with its nearest
+// walkable predecessor and with its nearest walkable successor inside the contig, found by looking along the contig -- or, when it is
+// not walkable, the tag 0 that no round carries.  Round 4 walked the whole shard again after every override: 109 walks per pass of
+// the isoform-rich 200-assembly set, 47 of them in front of an arc round that needs one anyway.
+__global__ __launch_bounds__(BLOCK) void k_walk_list(Walk a, const int32_t *pos, int64_t T)
+{
+	const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (t >= T) return;
+	const int i = pos[t];
+	auto walkable = [&](int y) { return !(a.flags[a.yperm[y]] & (PGA_F_FLT | PGA_F_SHADOW)); };
+	const int4 a0 = a.W[2 * (int64_t)i], a1 = a.W[2 * (int64_t)i + 1];
+	const int zi = a1.z;
+	if (!walkable(i)) { a.hbk[zi] = 0, a.hfk[zi] = 0; return; }
+	int p = -1, q = -1;
+	for (int j = i - 1; j >= 0; --j) { if (a.W[2 * (int64_t)j].x != a0.x) break; if (walkable(j)) { p = j; break; } }
+	for (int j = i + 1; j < a.n; ++j) { if (a.W[2 * (int64_t)j].x != a0.x) break; if (walkable(j)) { q = j; break; } }
+	const int sa = walk_score(a0, a1, a.ori, a.g2s);
+	uint32_t key = a.tag << HA_TAG_SHIFT | HA_NONE;
+	if (p >= 0) { // adjacency p -> i as the later hit sees it (graph.c:119)
+		const int4 b0 = a.W[2 * (int64_t)p], b1 = a.W[2 * (int64_t)p + 1];
+		const int sb = walk_score(b0, b1, a.ori, a.g2s), d = (int)((unsigned)a0.z - (unsigned)b0.z);
+		if (a0.z == b0.z) { atomicAdd((unsigned long long *)&a.dcnt[5], 1ull); hz_note(&a.dcnt[14], a.hz_list, a0.x); } // hazard H2a: equal cm
+		key = a.tag << HA_TAG_SHIFT | ((uint32_t)b0.y ^ 1u), a.hbp[zi] = make_int4(d, sa, sb, 0);
+	}
+	a.hbk[zi] = key;
+	if (q >= 0) { // adjacency i -> q as the earlier hit sees it (graph.c:117)
+		const int4 c0 = a.W[2 * (int64_t)q], c1 = a.W[2 * (int64_t)q + 1];
+		const int sc = walk_score(c0, c1, a.ori, a.g2s), d = (int)((unsigned)c0.z - (unsigned)a0.z);
+		a.hfk[zi] = a.tag << HA_TAG_SHIFT | (uint32_t)c0.y, a.hfp[zi] = make_int4(d, sa, sc, 0);
+	} else a.hfk[zi] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

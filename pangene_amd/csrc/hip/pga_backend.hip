@@ -1092,11 +1092,11 @@ static int ensure_half_arcs(pga_ctx *c, int use_ori)
 	if (c->N == 0) return 0;
 	TRY(ensure_z(c));
 	if (!c->wrec_valid) {
-		hipLaunchKernelGGL(k_pack_wrec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->yperm, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->N, c->wrec, c->vfirst, c->vbase);
+		hipLaunchKernelGGL(k_pack_wrec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, WrecSrc{c->yperm, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->vfirst, c->vbase}, c->N, c->wrec);
 		c->wrec_valid = true;
 	}
 	if (c->ha_valid && c->ha_ori == use_ori) return 0;
-	if (++c->round_tag > HA_TAG_MAX) { // tags wrap: forget every old record
+	if (++c->round_tag >= HA_TAG_MAX) { // tags wrap: forget every old record (HA_TAG_MAX itself is never a tag: it is what the cleared key words carry)
 		HIPCHK(hipMemsetAsync(c->hfk, 0xff, sizeof(uint32_t) * (size_t)c->N, c->st));
 		HIPCHK(hipMemsetAsync(c->hbk, 0xff, sizeof(uint32_t) * (size_t)c->N, c->st));
 		c->round_tag = 1;
@@ -1913,11 +1913,23 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	// otherwise): with -S the index is rebuilt.  (The full-size configs[4] run rebuilt it -- a sort and seven gathers over 22 M hits --
 	// 49 times per pass.)
 	const bool z_keep = c->z_valid && (which == 1 || !c->par.check_strand);
+	// The half-arc records of the walk that stands survive too when the override is small: only the overridden contigs are walked again
+	// (k_walk_list), with the tag that stands.  Not with virtual contigs (a piece's neighbours in the walk may lie in the piece next to it).
+	static const bool partial_on = getenv("PANGENE_OVERRIDE_FULL_WALK") == nullptr;
+	const bool partial = partial_on && c->ha_valid && c->wrec_valid && z_keep && !c->zposy_stale && c->vfirst == nullptr && n_seg > 0 && seg_off[n_seg] * 8 <= (int64_t)N;
 	c->walk_valid = false, c->ha_valid = false, c->yrec_valid = false, c->wrec_valid = false;
 	if (!z_keep) c->z_valid = false;
 	if (n_seg <= 0 || N == 0) return 0;
 	const int64_t T = seg_off[n_seg];
-	if (T == 0) return 0;
+	if (T == 0) { if (partial) c->ha_valid = true, c->wrec_valid = true; return 0; }
+	auto walk_again = [&](const int32_t *d_pos) -> int { // (after the override's own kernels, on the same stream)
+		int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
+		if (!hzl) return PGA_ERR_NOMEM;
+		hipLaunchKernelGGL(k_pack_wrec_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, WrecSrc{c->yperm, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->vfirst, c->vbase}, d_pos, T, c->wrec);
+		hipLaunchKernelGGL(k_walk_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, Walk{c->flags, c->yperm, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, c->ha_ori, c->N, c->dcnt, hzl, Gate{nullptr, 0}}, d_pos, T);
+		c->ha_valid = true, c->wrec_valid = true, c->zposy_stale = false;
+		return 0;
+	};
 	// positions and file indices of the overridden hits, built in page-locked memory (a real DMA; from a std::vector the runtime stages)
 	// (nothing waits at the end of an override any more -- sixty-six of them per pass each found the device still at the round queued
 	// before -- so the lists must not be overwritten while their copy is under way: two halves, an event each)
@@ -1947,6 +1959,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	if (which == 1) {
 		hipLaunchKernelGGL(k_ov_sety, dim3(nblk(T)), dim3(BLOCK), 0, c->st, d_pos, d_fil, T, c->inv, c->yperm);
 		if (z_keep) c->zposy_stale = true;
+		if (partial) TRY(walk_again(d_pos));
 		return 0;
 	}
 	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * (OV_PLANES + 13) * (size_t)T + 64);
@@ -1961,6 +1974,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	if (!tile) return PGA_ERR_NOMEM;
 	device_scan<SegMax>(InSegMaxList{c->recA, d_pos}, OutSegMaxList{c->recA, d_pos}, T, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st); // pm follows the new order
 	hipLaunchKernelGGL(k_cstie_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, c->recA, d_pos, T, N, c->flags);
+	if (partial) TRY(walk_again(d_pos));
 	return 0;
 }
 
