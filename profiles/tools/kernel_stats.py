@@ -26,7 +26,14 @@ try:
     ev = cur.execute("SELECT name, start, end FROM kernels ORDER BY start").fetchall()
     # first big kernel of pga_begin: k_genome_sort* (stage A's orders may take two launches: k_genome_sort2 + k_genome_sort2d) or, for
     # genomes beyond the per-genome sorts (the 110 k-hit assemblies of configs[4]), k_prepare in front of the multi-workgroup radix sort
-    starts = [i for i, e in enumerate(ev) if (e[0].startswith("k_genome_sort") and not (i and ev[i - 1][0].startswith("k_genome_sort"))) or e[0].startswith("k_prepare")]
+    # (round 5: k_prepare runs once per upload; the multi-workgroup path of pga_begin now opens with k_score_key -- 64-bit score keys -- or k_xkey)
+    def first_of_begin(i):
+        n = ev[i][0]
+        if n.startswith("k_genome_sort"): return not (i and ev[i - 1][0].startswith("k_genome_sort"))
+        if n.startswith("k_score_key"): return True
+        if n.startswith("k_xkey"): return not any(ev[j][0].startswith("k_score_key") for j in range(max(0, i - 80), i))
+        return False
+    starts = [i for i in range(len(ev)) if first_of_begin(i)]
     if len(starts) >= 3:
         a, b = starts[-2], starts[-1]  # one whole pass: from one k_prepare to the next
         seg = ev[a:b]
