@@ -640,6 +640,29 @@ static int trace_state(DataExt *ext, const char *step, int round, bool first = f
 	std::vector<int32_t> rank(N + 1), sdom(N + 1), pdom(N + 1), pdom0(N + 1), px(N + 1), py(N + 1);
 	pga_hit_state_t st = { flags.data(), rank.data(), sdom.data(), pdom.data(), pdom0.data(), px.data(), py.data(), nullptr };
 	BE_CALL(ext->be->download(ext->ctx, &st), "download(trace)");
+	// PANGENE_TRACE_DIFF=1: how much of the per-hit state a step changed (hits whose walkable test -- flt or shadow --, whose weak_br,
+	// whose flag word changed; the 256-hit tiles of the cs order that hold such a hit): what "rounds that cost what changed" would have to touch
+	static const bool diff_on = std::getenv("PANGENE_TRACE_DIFF") != nullptr;
+	if (diff_on) {
+		static std::vector<uint32_t> prev;
+		if (prev.size() == N && !first) {
+			int64_t n_any = 0, n_walk = 0, n_weak = 0, n_flt = 0;
+			std::vector<uint8_t> tile((N + 255) / 256 + 1, 0);
+			size_t k = 0;
+			for (size_t f = 0; f < N; ++f) {
+				const uint32_t x = (flags[f] ^ prev[f]) & 0x7ffu;
+				if (!x) continue;
+				++n_any, n_walk += (x & (PGA_F_FLT | PGA_F_SHADOW)) != 0, n_weak += (x & PGA_F_WEAK_MASK) != 0, n_flt += (x & PGA_F_FLT) != 0;
+				while (k + 1 < ext->hit_off.size() && (int64_t)f >= ext->hit_off[k + 1]) ++k;
+				tile[(size_t)(ext->hit_off[k] + px[f]) >> 8] = 1;
+			}
+			int64_t n_tile = 0;
+			for (uint8_t t : tile) n_tile += t;
+			std::fprintf(stderr, "[trace_diff] %-18s %3d: %lld of %zu hits changed their flag word (walkable test %lld, flt %lld, weak_br %lld); %lld of %zu tiles of 256 hits dirty\n", step, round,
+			             (long long)n_any, N, (long long)n_walk, (long long)n_flt, (long long)n_weak, (long long)n_tile, tile.size());
+		}
+		prev.assign(flags.begin(), flags.begin() + (long)N);
+	}
 	std::FILE *fp = std::fopen(trace_path(), first ? "w" : "a");
 	if (fp == nullptr) return 0;
 	std::fprintf(fp, "%s\t%d\tflags=%016llx\trank=%016llx\tscore_dom=%016llx\tpid_dom=%016llx\tpid_dom0=%016llx\tpos_x=%016llx\tpos_y=%016llx\n", step, round,
