@@ -258,6 +258,7 @@ int pg_rerun_resident(pg_data_t *d);
  * sweep, 2 = (not timed any more: the stage-C sweeps), 3 = all of stage A (sorts, per-hit constants, pg_flag_pseudo, sweeps, filters),
  * 4 = no kernel class: n_launch = the number of times the host waited for the backend's stream since the reset. */
 int pg_kernel_timing(pg_data_t *d, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
+double pg_last_reserve_seconds(void); /* what the last pg_read_paf_batch spent reserving device memory before it parsed (large data sets: pga_reserve) */
 int pg_kernel_timing_reset(pg_data_t *d);
 /* collectives the driver has issued through the exchange callbacks so far, in this process (bench.py: per pass of a sharded run) */
 int64_t pg_collective_count(void);

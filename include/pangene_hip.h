@@ -336,6 +336,7 @@ typedef struct {
 	int  (*arc_round_x)(pga_ctx_t *, int32_t, int32_t, const struct pga_loop_xchg_s *, int32_t *, int32_t *, int64_t *); /* may be NULL */
 	int  (*copy_gbps)(size_t, int32_t, double *); /* may be NULL */
 	int  (*warm)(void); /* may be NULL */
+	int  (*reserve)(int64_t, int64_t, int32_t, int32_t, int32_t, int64_t); /* may be NULL */
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);
@@ -415,6 +416,11 @@ void *pga_active_stream(void);
  * (count only); with PANGENE_TIME_ROUNDS=1 in the environment at pga_timing_reset also 5 = every pg_gen_arc round (graph.c:87-177: sweep, walk,
  * temp arcs, collapse -- two more events per round, so for a pass that is not itself timed) and 6 = its walk scan alone.
  * which | (k + 1) << 8 selects the k-th timed launch of the class alone. */
+/* Optional, before pga_create: the device memory a shard of about this size will ask for (hits, exons, proteins, genes, genomes, words of
+ * packed blocks), allocated now and kept for the pga_create that follows -- hipMalloc of tens of gigabytes takes seconds, and a reader
+ * that knows its files' sizes can have it done while it parses (pg_read_paf_batch does).  Too small an estimate costs nothing but the
+ * attempt; blocks nobody claims go back with pga_host_trim(0).  Safe to call from any thread. */
+int pga_reserve(int64_t n_hit, int64_t n_exon, int32_t n_prot, int32_t n_gene, int32_t n_genome, int64_t raw_words);
 int pga_timing_reset(pga_ctx_t *ctx);
 int pga_timing_get(pga_ctx_t *ctx, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
 

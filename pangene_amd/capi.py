@@ -67,6 +67,7 @@ _API = {
     "pg_trim_host_cache": (None, [C.c_size_t]),
     "pg_last_upload_seconds": (C.c_double, []),
     "pg_last_pack_seconds": (C.c_double, []),
+    "pg_last_reserve_seconds": (C.c_double, []),
     "pg_shard_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pg_rerun_resident": (C.c_int, [C.c_void_p]),
     "pg_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -20,6 +20,8 @@
 #include <time.h>
 #include <vector>
 #include <mutex>
+#include <atomic>
+#include <condition_variable>
 #include <algorithm>
 #include "pangene_hip.h"
 #include "dev_prims.hpp"
@@ -50,18 +52,23 @@ static inline unsigned nblk(int64_t n, int per = BLOCK) { return (unsigned)((n +
 // bench's cold passes) pays for the memory once.  Bounded: two blocks are kept (one context's worth); a block is reused for a
 // request it fits without wasting more than half of it.  pga_host_trim(0) (pg_trim_host_cache) gives them back.
 // ------------------------------------------------------------------------------------------------
-struct DevBlock { void *p; size_t cap; };
+struct DevBlock { void *p; size_t cap; int dev; };
+static std::atomic<int> g_last_dev{-1}; // the device of the last context (or pga_set_device): where a pga_reserve on another thread allocates
+static int cur_dev() { int d = 0; return hipGetDevice(&d) == hipSuccess ? d : 0; }
 static std::mutex g_dev_mu;
 static std::vector<DevBlock> g_dev_cache;
+static std::condition_variable g_dev_cv; static int g_dev_reserving = 0; // pga_reserve calls under way: whoever wants a big block waits for them first (the block is probably theirs)
 static bool dev_cache_on() { static const bool on = [] { const char *e = getenv("PANGENE_DEV_CACHE"); return !(e && *e == '0'); }(); return on; }
 
 static void *dev_big_alloc(size_t want, size_t *got)
 {
 	{
-		std::lock_guard<std::mutex> lk(g_dev_mu);
+		std::unique_lock<std::mutex> lk(g_dev_mu);
+		g_dev_cv.wait(lk, [] { return g_dev_reserving == 0; });
 		size_t best = (size_t)-1;
+		const int dev = cur_dev();
 		for (size_t i = 0; i < g_dev_cache.size(); ++i)
-			if (g_dev_cache[i].cap >= want && g_dev_cache[i].cap <= 2 * want + ((size_t)64 << 20) && (best == (size_t)-1 || g_dev_cache[i].cap < g_dev_cache[best].cap)) best = i;
+			if (g_dev_cache[i].dev == dev && g_dev_cache[i].cap >= want && g_dev_cache[i].cap <= 2 * want + ((size_t)64 << 20) && (best == (size_t)-1 || g_dev_cache[i].cap < g_dev_cache[best].cap)) best = i;
 		if (best != (size_t)-1) {
 			DevBlock b = g_dev_cache[best];
 			g_dev_cache.erase(g_dev_cache.begin() + (long)best);
@@ -103,7 +110,7 @@ static void dev_big_free(void *p, size_t cap)
 			(void)hipFree(g_dev_cache[small].p);
 			g_dev_cache.erase(g_dev_cache.begin() + (long)small);
 		}
-		g_dev_cache.push_back(DevBlock{p, cap});
+		g_dev_cache.push_back(DevBlock{p, cap, cur_dev()});
 		return;
 	}
 	(void)hipFree(p);
@@ -296,7 +303,7 @@ extern "C" int pga_host_alloc(size_t nbytes, void **ptr)
 }
 extern "C" void pga_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
 
-extern "C" int pga_set_device(int32_t device) { return hipSetDevice(device) == hipSuccess ? 0 : PGA_ERR_NO_DEVICE; }
+extern "C" int pga_set_device(int32_t device) { if (hipSetDevice(device) != hipSuccess) return PGA_ERR_NO_DEVICE; g_last_dev.store(device); return 0; }
 extern "C" int pga_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
 extern "C" void pga_host_trim(size_t keep_bytes)
@@ -512,23 +519,16 @@ template <class T> static int upload(pga_ctx *c, T *dst, const T *src, size_t n)
 
 static int stage_upload(pga_ctx *c, void *d0, const void *s0, size_t n0, void *d1 = nullptr, const void *s1 = nullptr, size_t n1 = 0);
 
-static int create_impl(pga_ctx *c, const pga_shard_t *sh)
+static size_t pool_want(int64_t N, int64_t GL, int64_t P, int64_t Q, int64_t raw_words)
+{
+	const size_t per_hit = 568 /* measured: 530-540 B/hit at 1 M and 12 M hits (PANGENE_TIMING reports the fit at destroy) */, tables = (size_t)GL * ((size_t)P * 12 + (size_t)Q * 36) + (size_t)Q * 512 + (size_t)P * 64;
+	return ((size_t)N * per_hit + tables + (64u << 20) + (size_t)raw_words * 4 + 255) & ~(size_t)255;
+}
+
+// the persistent arrays of a context (one allocation: dalloc_commit); also what pga_reserve sizes its first block by
+static int plan_persistent(pga_ctx *c)
 {
 	const int N = c->N, E = c->E, GL = c->n_genome;
-	static const bool timing = getenv("PANGENE_TIMING") != nullptr;
-	auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
-	const double t0 = now();
-	HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
-	g_active_stream = c->st;
-	{
-		int dev = 0, ncu = 0;
-		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) c->n_cu = ncu;
-	}
-	c->own_stream = true;
-	c->h_cnt = (int64_t *)c->pin.get(16 * sizeof(int64_t));
-	if (!c->h_cnt) return PGA_ERR_NOMEM;
-	memset(c->h_cnt, 0, 16 * sizeof(int64_t));
-	HIPCHK(hipHostGetDevicePointer((void **)&c->h_box, c->h_cnt, 0));
 	TRY(dalloc(c, &c->dcnt, 16)); TRY(dalloc(c, &c->loopctl, 4));
 	// persistent arrays
 	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
@@ -541,6 +541,28 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	TRY(dalloc(c, &c->hfk, N)); TRY(dalloc(c, &c->hbk, N)); TRY(dalloc(c, &c->hfp, N)); TRY(dalloc(c, &c->hbp, N));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q)); TRY(dalloc(c, &c->hrank, c->P));
 	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
+	return 0;
+}
+
+static int create_impl(pga_ctx *c, const pga_shard_t *sh)
+{
+	const int N = c->N, E = c->E, GL = c->n_genome;
+	static const bool timing = getenv("PANGENE_TIMING") != nullptr;
+	auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+	const double t0 = now();
+	HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+	g_active_stream = c->st;
+	{
+		int dev = 0, ncu = 0;
+		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) c->n_cu = ncu;
+		g_last_dev.store(dev);
+	}
+	c->own_stream = true;
+	c->h_cnt = (int64_t *)c->pin.get(16 * sizeof(int64_t));
+	if (!c->h_cnt) return PGA_ERR_NOMEM;
+	memset(c->h_cnt, 0, 16 * sizeof(int64_t));
+	HIPCHK(hipHostGetDevicePointer((void **)&c->h_box, c->h_cnt, 0));
+	TRY(plan_persistent(c));
 	bool vsplit = false; // some genome arrives with virtual contigs (64-bit coordinates)
 	int64_t n_vseg = 0;
 	for (int g = 0; g < GL; ++g) {
@@ -663,8 +685,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	                                    (int)gf_lds_bytes(c->P, c->Q, c->gf_k32)) != hipSuccess) { (void)hipGetLastError(); c->gf_ok = false; }
 
 	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
-		const size_t per_hit = 568 /* measured: 530-540 B/hit at 1 M and 12 M hits (PANGENE_TIMING reports the fit at destroy) */, tables = (size_t)GL * ((size_t)c->P * 12 + (size_t)c->Q * 36) + (size_t)c->Q * 512 + (size_t)c->P * 64;
-		const size_t want = ((size_t)N * per_hit + tables + (64u << 20) + (size_t)woff[(size_t)GL] * 4 + 255) & ~(size_t)255;
+		const size_t want = pool_want(N, GL, c->P, c->Q, woff[(size_t)GL]);
 		size_t got = 0;
 		void *a = getenv("PANGENE_NO_POOL_ARENA") == nullptr ? dev_big_alloc(want, &got) : nullptr;
 		if (a) { // else: slot by slot
@@ -2210,6 +2231,49 @@ extern "C" int pga_copy_gbps(size_t bytes, int32_t reps, double *gbps)
 	return 0;
 }
 
+extern "C" int pga_reserve(int64_t n_hit, int64_t n_exon, int32_t n_prot, int32_t n_gene, int32_t n_genome, int64_t raw_words)
+{
+	int ndev = 0;
+	if (!dev_cache_on() || n_hit <= 0 || n_hit >= (1 << 30) || n_exon < 0 || n_exon >= INT32_MAX || hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PGA_ERR_ARG;
+	if (g_last_dev.load() >= 0) (void)hipSetDevice(g_last_dev.load()); // (the current device is a property of the thread)
+	size_t want[2];
+	{
+		pga_ctx tmp;
+		tmp.N = (int32_t)n_hit, tmp.E = (int32_t)n_exon, tmp.P = n_prot, tmp.Q = n_gene, tmp.n_genome = n_genome;
+		(void)plan_persistent(&tmp);
+		size_t tot = 0;
+		for (auto &e : tmp.plan) tot += e.second;
+		want[0] = tot, want[1] = pool_want(n_hit, n_genome, n_prot, n_gene, raw_words);
+	}
+	static const bool timing = getenv("PANGENE_TIMING") != nullptr;
+	timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+	int made = 0;
+	{ std::lock_guard<std::mutex> lk(g_dev_mu); ++g_dev_reserving; }
+	struct Done { ~Done() { { std::lock_guard<std::mutex> lk(g_dev_mu); --g_dev_reserving; } g_dev_cv.notify_all(); } } done;
+	for (int k = 1; k >= 0; --k) { // (the larger one first)
+		{
+			std::lock_guard<std::mutex> lk(g_dev_mu);
+			bool have = false;
+			for (const DevBlock &b : g_dev_cache) have = have || (b.dev == cur_dev() && b.cap >= want[k] && b.cap <= 2 * want[k] + ((size_t)64 << 20));
+			if (have) continue;
+		}
+		const size_t padded = (want[k] + want[k] / 8 + ((size_t)64 << 20) - 1) & ~(((size_t)64 << 20) - 1);
+		void *q = nullptr;
+		if (hipMalloc(&q, padded) != hipSuccess) { (void)hipGetLastError(); continue; }
+		++made;
+		std::lock_guard<std::mutex> lk(g_dev_mu);
+		if (g_dev_cache.size() >= 2) { // the cache holds one context's worth: the smallest block that is not the one just asked for makes room
+			size_t small = 0;
+			for (size_t i = 1; i < g_dev_cache.size(); ++i) if (g_dev_cache[i].cap < g_dev_cache[small].cap) small = i;
+			(void)hipFree(g_dev_cache[small].p);
+			g_dev_cache.erase(g_dev_cache.begin() + (long)small);
+		}
+		g_dev_cache.push_back(DevBlock{q, padded, cur_dev()});
+	}
+	if (timing) { timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); fprintf(stderr, "[pga_reserve] %lld hits: %.1f + %.1f GB asked for, %d block(s) allocated in %.1f ms\n", (long long)n_hit, want[0] / 1073741824.0, want[1] / 1073741824.0, made, ((t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9) * 1e3); }
+	return 0;
+}
+
 extern "C" int pga_warm(void)
 {
 	int ndev = 0;
@@ -2227,7 +2291,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count, pga_arc_round_x, pga_copy_gbps, pga_warm
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count, pga_arc_round_x, pga_copy_gbps, pga_warm, pga_reserve
 	};
 	return &b;
 }

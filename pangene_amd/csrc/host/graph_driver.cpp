@@ -299,6 +299,7 @@ static int g_prefetch_left = 0; // slabs the helper has still to deliver (guarde
 // triggered by a first hipHostMalloc in the middle of a batch read, maps and registers memory for ~0.3 s and stalls the page faults
 // of every parser thread meanwhile (a `pangene` command parsed its 100 files in 0.30 s instead of 0.05 s).
 static std::atomic<bool> g_device_up{false};
+bool device_is_up() { return g_device_up.load(); }
 
 static HostSlab slab_get(size_t min_bytes, bool allow_pin = true)
 {

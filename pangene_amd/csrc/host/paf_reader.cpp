@@ -781,9 +781,13 @@ int32_t pg_scan_paf_ids(const pg_opt_t *opt, pg_data_t *d, const char *fn) { ret
 // finds the next file of the command line parsed commits its ids (sequential, but short: only new names are inserted); a
 // committed file's hits are then finished -- global protein ids, the SoA block in pinned memory for the backend -- by any
 // thread.  Memory holds the files that are parsed but not finished yet, not the whole batch twice.
+static double g_reserve_sec = 0.0; // what the last batch read spent reserving device memory before it parsed (pg_last_reserve_seconds)
+double pg_last_reserve_seconds(void) { return g_reserve_sec; }
+
 int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const char *const *fns, const uint8_t *ids_only, int32_t n_threads)
 {
 	if (n <= 0) return 0;
+	g_reserve_sec = 0.0;
 	if (n_threads <= 0) {
 		const char *e = std::getenv("PANGENE_READ_THREADS");
 		n_threads = e && std::atoi(e) > 0 ? std::atoi(e) : (int32_t)host_threads(64u); // (the CPU budget of the process, see host_threads; beyond 64 the threads of one address space get in each other's way: page faults, allocator)
@@ -810,6 +814,47 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 			if (!(ids_only && ids_only[i]) && fns[i] && stat(fns[i], &sb) == 0) text += (size_t)sb.st_size;
 		}
 		if (text > ((size_t)64 << 20)) slab_prefetch(std::min<size_t>(text / 5 * 2, (size_t)192 << 20), &slab_helper); // (up to the budget of freshly locked memory: block_alloc)
+	}
+	size_t local_text = 0; int32_t n_local = 0; // (what pga_reserve's estimate is made of)
+	for (int32_t i = 0; i < n; ++i) {
+		struct stat sb;
+		const size_t len = fns[i] ? std::strlen(fns[i]) : 0;
+		if (!(ids_only && ids_only[i]) && fns[i] && stat(fns[i], &sb) == 0) local_text += (size_t)sb.st_size * (len > 3 && std::strcmp(fns[i] + len - 3, ".gz") == 0 ? 5 : 1), ++n_local;
+	}
+	// A large data set has the device memory its upload will ask for allocated NOW, before a parser thread runs: hipMalloc of configs[3]'s
+	// ~90 GB takes 1.9 s, and while it runs every page fault of the process waits (tried: on a helper thread beside the parsers the
+	// parse took 3.3 s instead of 1.3 and the packing 2 s instead of 0.1 -- the time moved, it did not go away).  The estimate comes from
+	// the files' sizes and the head of the first local plain file (lines per byte, introns per line); a wrong one costs the attempt.
+	if (std::getenv("PANGENE_NO_RESERVE") == nullptr && local_text >= ((size_t)1 << 30)) {
+		const pga_backend_t *be = backend_default();
+		for (int32_t i = 0; be && be->reserve && i < n; ++i) {
+			const size_t len = fns[i] ? std::strlen(fns[i]) : 0;
+			if ((ids_only && ids_only[i]) || !fns[i] || (len > 3 && std::strcmp(fns[i] + len - 3, ".gz") == 0)) continue;
+			const int fd = open(fns[i], O_RDONLY);
+			if (fd < 0) continue;
+			std::vector<char> head((size_t)256 << 10);
+			const ssize_t got = read(fd, head.data(), head.size());
+			close(fd);
+			if (got <= 0) break;
+			int64_t lines = 0, introns = 0;
+			bool in_cg = false;
+			for (ssize_t q = 0; q < got; ++q) {
+				const char ch = head[(size_t)q];
+				if (ch == '\n') ++lines, in_cg = false;
+				else if (ch == '\t') in_cg = q + 5 < got && std::memcmp(&head[(size_t)q + 1], "cg:Z:", 5) == 0;
+				else if (in_cg && (ch == 'N' || ch == 'U' || ch == 'V')) ++introns;
+			}
+			if (lines < 8) break;
+			const double per_byte = (double)lines / (double)got, ex_per_hit = 1.0 + (double)introns / (double)lines;
+			const int64_t hits = (int64_t)((double)local_text * per_byte * 1.05) + 4096, exons = (int64_t)((double)hits * ex_per_hit * 1.05) + 4096;
+			struct stat sb;
+			const int64_t first_lines = stat(fns[i], &sb) == 0 ? (int64_t)((double)sb.st_size * per_byte) + 64 : lines;
+			const double tr0 = now_sec();
+			if (hits < ((int64_t)1 << 30) && exons < INT32_MAX)
+				(void)be->reserve(hits, exons, (int32_t)std::min<int64_t>(first_lines, 1 << 24), (int32_t)std::min<int64_t>(first_lines, (1 << 20) - 1), n_local, hits * 11 + hits / 4 + exons * 2 + 64 * (int64_t)n_local);
+			g_reserve_sec = now_sec() - tr0;
+			break;
+		}
 	}
 	std::vector<FileParse> fp((size_t)n);
 	{ // the hit / exon arrays of the plain files come out of one mapping on huge pages (DataExt::HostArena says why); reserved for the

@@ -25,6 +25,7 @@ namespace pgx {
 // threads runs no faster than one of 16, it only burns the quota in a quarter of every 100 ms period and then ALL threads of the process,
 // the one feeding the GPU included, stand still until the next period; profiles/r04_cpu_scaling_box.txt.)
 unsigned host_threads(unsigned cap);
+bool device_is_up(); // the backend's runtime has been started in this process (graph_driver.cpp)
 
 // Name -> id.  Open addressing over (32-bit hash, id) slots, names in blocks that never move (pg_gene_t / pg_prot_t / pg_ctg_t keep
 // `const char *` into them).  A batch read builds three of these per FILE (10 000 names each for a bacterial genome): with
