@@ -618,7 +618,7 @@ def main():
             walls = []
             for _ in range(3):  # a fresh process each time: device start-up alone varies between 0.08 and 0.25 s on this box (profiles/r04_cli_probe.txt)
                 t0 = time.time()
-                r1 = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, PANGENE_CLI_TIMING="1"))
+                r1 = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, PANGENE_TIMING="1"))
                 walls.append(time.time() - t0)
                 if walls[-1] == min(walls):
                     r = r1

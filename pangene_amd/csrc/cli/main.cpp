@@ -91,8 +91,8 @@ struct Output { int matrix = 0; };
 
 static int run_path(pg_opt_t &opt, int n_files, char **files, const uint8_t *ids_only, const Output &o, bool graph_lines, bool own_lines, int device = -1)
 {
-	// PANGENE_CLI_TIMING=1: where the wall time of the command goes (stderr), for bench.py's cli leg
-	const bool timing = std::getenv("PANGENE_CLI_TIMING") != nullptr;
+	// PANGENE_TIMING=1: where the wall time of the command goes (stderr: the line bench.py's cli leg reads), beside the library's own lines
+	const bool timing = std::getenv("PANGENE_TIMING") != nullptr;
 	const double t0 = pg_realtime();
 	// (Tried: HIP initialisation + code-object load on a helper thread while the files are parsed -- pg_device_warm().  The runtime's
 	// start-up maps and registers memory for ~0.3 s and every one of those calls stalls the page faults of the parser threads of the

@@ -206,11 +206,10 @@ __global__ __launch_bounds__(BLOCK) void k_count_shadow(const uint32_t *flags, c
 // A genome's hits are one contiguous block of the cs order; what the four kernels below keep in (genome x protein) bytes and
 // (genome x gene) 64-bit words of HBM -- cleared and re-read every pass -- is P bytes + Q words of LDS here, and the hits are read
 // once per step by the same thread (36 B/hit of traffic instead of ~140).  Used when P + 8 Q fits the LDS (k_iso_apply .. k_subopt2
-// otherwise, and under PANGENE_FILTERS_GLOBAL=1).
+// otherwise, and under PANGENE_FILTERS=global).
 // ------------------------------------------------------------------------------------------------
 constexpr int GF_T = 1024;
 struct GenomeFilters { uint32_t *flags; const int32_t *pid, *gid, *rank, *sadj; int32_t *pdom, *pdom0; const int32_t *goff; const int4 *A; int P, Q; int32_t *stats; int64_t *dcnt; int32_t *hz_list;
-                       int fused; /* the sweep before was k_sweep<3>: read.c:249-253 is done, flt_iso_ov is set; what is left of phase 1 is its consequence (overlap.c:89-91) and the protein table */
                        int pos_bits; /* K32: bits of a position inside a genome */ };
 // K32: no score_adj of the shard is negative and score_adj and a position inside a genome fit 32 bits together -- the per-gene `best`
 // entries are 4 bytes then, and the tables of a 20 000-gene, 55 000-protein human annotation fit the LDS (8 Q + P bytes did not: those
@@ -233,8 +232,8 @@ __global__ __launch_bounds__(GF_T) void k_genome_filters(GenomeFilters a)
 	__syncthreads();
 	int n_iso = 0, n_chain = 0, n_sub = 0;
 	constexpr int U = 4; // hits a thread has in flight per step: the loads of a step are issued together (the phases are latency-bound otherwise)
-	if (a.fused) {
-		for (int hb = h0 + tid; hb < h1; hb += U * GF_T) { // overlap.c:89-91 (the marks come from k_sweep<3>) + the first loop of hit.c:136-138
+	{
+		for (int hb = h0 + tid; hb < h1; hb += U * GF_T) { // overlap.c:89-91 (the marks come from k_sweep<3>, which has done read.c:249-253 itself) + the first loop of hit.c:136-138
 			int32_t pi[U]; uint32_t fl[U];
 #pragma unroll
 			for (int u = 0; u < U; ++u) { const int h = hb + u * GF_T; if (h < h1) fl[u] = a.flags[h], pi[u] = a.pid[h]; }
@@ -245,22 +244,6 @@ __global__ __launch_bounds__(GF_T) void k_genome_filters(GenomeFilters a)
 				if (fl[u] & PGA_F_ISO_OV) a.flags[h] = fl[u] | PGA_F_FLT, ++n_iso;
 				else noiso[pi[u]] = 1;
 			}
-		}
-	} else
-	for (int hb = h0 + tid; hb < h1; hb += U * GF_T) { // read.c:249-253 + overlap.c:89-91
-		int32_t pd[U], pi[U]; uint32_t fl[U];
-#pragma unroll
-		for (int u = 0; u < U; ++u) { const int h = hb + u * GF_T; if (h < h1) pd[u] = a.pdom[h], fl[u] = a.flags[h], pi[u] = a.pid[h]; }
-#pragma unroll
-		for (int u = 0; u < U; ++u) {
-			const int h = hb + u * GF_T;
-			if (h >= h1) break;
-			a.pdom0[h] = pd[u];
-			a.pdom[h] = -1;
-			uint32_t nf = fl[u] & ~PGA_F_SHADOW;
-			if (fl[u] & PGA_F_ISO_OV) nf |= PGA_F_FLT, ++n_iso;
-			else noiso[pi[u]] = 1; // (plain byte stores of the same value)
-			if (nf != fl[u]) a.flags[h] = nf;
 		}
 	}
 	__syncthreads();
@@ -321,14 +304,10 @@ __global__ __launch_bounds__(GF_T) void k_genome_filters(GenomeFilters a)
 // read.c:249-253 (pid_dom0 = pid_dom, pid_dom = -1, shadow = 0) + tail of pg_flt_ov_isoform (overlap.c:89-91) + first loop of
 // pg_flt_chain_shadow (hit.c:136-138).  noiso: one byte per (genome, protein), set when the protein has a hit in the genome that
 // does not carry flt_iso_ov (the complement of hit.c:134-138's flag[], for the proteins that occur at all -- pid_dom0 always does).
-__global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int32_t *gnm, const int32_t *pid, int32_t *pdom, int32_t *pdom0, int n, int P, uint8_t *noiso, int32_t *stats, int fused)
+__global__ __launch_bounds__(BLOCK) void k_iso_apply(uint32_t *flags, const int32_t *gnm, const int32_t *pid, int32_t *pdom, int32_t *pdom0, int n, int P, uint8_t *noiso, int32_t *stats)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	if (!fused) { // (k_sweep<3> has done read.c:249-253 itself)
-		pdom0[h] = pdom[h];
-		pdom[h] = -1;
-	}
+	if (h >= n) return; // (k_sweep<3> has done read.c:249-253 itself)
 	const uint32_t f = flags[h];
 	uint32_t nf = f & ~PGA_F_SHADOW;
 	if (f & PGA_F_ISO_OV) {

@@ -162,7 +162,6 @@ __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBe
 	ok = ok && !(fp & PGA_F_FLT);
 	if (v.check_strand) ok = ok && !((fp ^ t.fl) & PGA_F_REV);
 	const bool same_gene = b.y == t.gid;
-	if (MODE == 2) ok = ok && same_gene;
 	const int x = !ok ? 0 : EARLIER ? cds_inter(v.exon, v.literal, c.z, c.y, a.y, a.z, t.offx, t.nex, t.cs, t.ce)
 	                                : cds_inter(v.exon, v.literal, t.offx, t.nex, t.cs, t.ce, c.z, c.y, a.y, a.z);
 	ok = ok && x > 0; // overlap.c:132
@@ -171,7 +170,7 @@ __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBe
 	const uint32_t s_i = EARLIER ? t.sc : sp, s_j = EARLIER ? sp : t.sc;
 	const int rk_i = EARLIER ? t.rank : c.x, rk_j = EARLIER ? c.x : t.rank;
 	bool i_loses = s_i < s_j || (s_i == s_j && rk_i > rk_j);
-	if (MODE != 2) {
+	{
 		const int m = t.cds < b.z ? t.cds : b.z;
 		// cov_short < min_ov_ratio (overlap.c:134-136).  For the default 0.5 the test is exactly 2x < m: x/m is within
 		// 2^-32 of 0.5 only when it equals it, far above double rounding; other ratios take the IEEE division.
@@ -186,7 +185,6 @@ __device__ __forceinline__ void sw_pair(const SweepView &v, const SwHit &t, SwBe
 	const bool t_loses = ok && (EARLIER ? i_loses : !i_loses);
 	r.lose = r.lose || t_loses;
 	if (MODE == 3) r.iso = r.iso || (t_loses && same_gene); // pg_flt_ov_isoform's pairs are pg_shadow's same-gene pairs, with the same loser (overlap.c:76-87 vs 126-147)
-	if (MODE == 2) return;
 	// dominator = best-scoring winner, first in array order on ties (overlap.c:150,153).  Earlier partners are visited in
 	// DEscending index order, so an equal score replaces; later partners in ascending order, so it does not.
 	const bool upd = t_loses && (EARLIER ? (sp > 0 && sp >= r.best) : (sp > r.best));
@@ -239,7 +237,7 @@ __device__ __forceinline__ int wave_scan_small(int c, int *total)
 // hits of one gene -- isoforms of a pile mostly share their first exon --, half of the shorter CDS otherwise), and the pairs of
 // different genes, whose merges are the long ones, are set aside and evaluated together afterwards: a batch of 64 lanes takes
 // as long as its longest merge.
-// MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1); 2: pg_flt_ov_isoform;
+// MODE 0: pg_shadow(cal_dom_sc=0); 1: pg_shadow(cal_dom_sc=1) (pg_post_process); (2 was pg_flt_ov_isoform alone: the two-launch form of stage A, retired in round 5)
 // 3: stage A's two sweeps in ONE (read.c:248-254): pg_shadow(cal_dom_sc=1), the reset of read.c:249-253 and pg_flt_ov_isoform.  Both
 //    enumerate the same overlapping pairs over the same flt flags (nothing between them sets flt); a same-gene pair has the same
 //    loser in both (overlap.c:139 ignores weak_br and min_ov_ratio for one gene, and both compare score then rank), so the isoform
@@ -268,10 +266,6 @@ constexpr int SW_NSTAMP = 12;
 template <int MODE>
 __device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl, bool lose, bool has_dom, int pid_w, int ov, int cds_h, int cds_w, int sori_h, int sori_w, bool iso = false)
 {
-	if (MODE == 2) {
-		if (lose) v.flags[h] = fl | PGA_F_ISO_OV;
-		return;
-	}
 	if (MODE == 3) {
 		const uint32_t nf = (fl & ~PGA_F_SHADOW) | (iso ? PGA_F_ISO_OV : 0u); // read.c:252; overlap.c:83,85
 		if (nf != fl) v.flags[h] = nf;
@@ -441,7 +435,6 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 		bool ok = !((fj | fi) & PGA_F_FLT);
 		if (v.check_strand) ok = ok && !((fj ^ fi) & PGA_F_REV);
 		const bool same_gene = bj.y == bi.y;
-		if (MODE == 2) ok = ok && same_gene;
 		int x;
 		{
 			const int s0 = csj > csi ? csj : csi, e0 = cej < cei ? cej : cei;
@@ -453,9 +446,9 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 		// min_ov_ratio (134-136): for the default 0.5 that is exactly 2x < min(cds) -- x/m is within 2^-32 of 0.5 only when it
 		// equals it, far above double rounding --, for a ratio <= 0 never; other ratios take the IEEE division on the exact length.
 		const int mn = bi.z < bj.z ? bi.z : bj.z;
-		const bool thr = MODE == 2 || same_gene || ovmode != 2;
+		const bool thr = same_gene || ovmode != 2;
 		int need = 1;
-		if (MODE != 2 && !same_gene) {
+		if (!same_gene) {
 			const uint32_t half = ((uint32_t)mn >> 1) + ((uint32_t)mn & 1u);
 			need = ovmode == 0 ? (half > 0x7fffffffu ? INT32_MAX : (half > 1u ? (int)half : 1)) : ovmode == 1 ? 1 : INT32_MAX;
 		}
@@ -484,7 +477,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 		}
 		if (thr) ok = ok && x >= need;
 		else ok = ok && x > 0 && !((double)x / (mn > 0 ? mn : 1) < v.min_ov);
-		if (MODE != 2) {
+		{
 			const uint32_t wk_i = fi & PGA_F_WEAK_MASK, wk_j = fj & PGA_F_WEAK_MASK;
 			i_loses = (!same_gene && wk_i != wk_j) ? wk_i > wk_j : i_loses; // overlap.c:139-147
 		}
@@ -494,7 +487,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 			const unsigned long long key = (unsigned long long)rw << 32 | 0x80000000u | (uint32_t)(1023 - W);
 			const unsigned long long old = atomicMax(&sKey[Lt], key);
 			if (MODE == 3 && same_gene) sIso[Lt] = 1u; // (plain stores of one value)
-			if (MODE != 2 && rw != 0 && (uint32_t)(old >> 32) == rw && sA[1023 - (int)((uint32_t)old & 1023u)].x == sA[W].x) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, sA[L].y); } // hazard H3: two winners with one key; array order only decides between members of one (contig, cs) tie group
+			if (rw != 0 && (uint32_t)(old >> 32) == rw && sA[1023 - (int)((uint32_t)old & 1023u)].x == sA[W].x) { atomicAdd((unsigned long long *)&v.hz[3], 1ull); hz_note(&v.hz[10], v.hz_list, sA[L].y); } // hazard H3: two winners with one key; array order only decides between members of one (contig, cs) tie group
 		}
 		return false;
 	};
@@ -556,7 +549,7 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 				v.slow_list[at] = h;
 			} else {
 				const unsigned long long key = sKey[lane];
-				const bool lose = key != 0, has_dom = MODE != 2 && (key >> 32) != 0;
+				const bool lose = key != 0, has_dom = (key >> 32) != 0;
 				int pid_w = -1, ov = 0, cds_w = 1, so_w = 0, so_h = 0, cds_h = 1;
 				if (has_dom) {
 					const int W = 1023 - (int)(key & 1023u);

@@ -33,6 +33,23 @@ using namespace pgd;
 
 // debugging aid: PANGENE_POISON=1 fills every fresh device / pinned allocation with a pattern, so that a read of memory nobody
 // wrote shows up the same way in every run (recycled memory otherwise holds whatever the previous context left there)
+// a switch that takes a comma-separated list of words (PANGENE_FILTERS=k32,global  PANGENE_LOOP=nopre,nofinal,noskip)
+static bool env_has(const char *name, const char *word)
+{
+	const char *e = getenv(name);
+	const size_t n = strlen(word);
+	for (; e && *e; ) { const char *c = strchr(e, ','); const size_t len = c ? (size_t)(c - e) : strlen(e); if (len == n && strncmp(e, word, n) == 0) return true; e = c ? c + 1 : nullptr; }
+	return false;
+}
+// PANGENE_XLOOP_CAP=pairs[,arcs] (tests: exchange buffers of the sharded queued rounds that are too small at first; 0 or absent = as learned)
+static long long xloop_cap(int which)
+{
+	const char *e = getenv("PANGENE_XLOOP_CAP");
+	if (!e) return 0;
+	if (which == 0) return atoll(e);
+	const char *c = strchr(e, ',');
+	return c ? atoll(c + 1) : 0;
+}
 static bool poison_on() { static const bool f = getenv("PANGENE_POISON") != nullptr; return f; }
 
 #define F_HEAD 0x80000000u   // static: first hit of its genome in X order (index-0 quirk, overlap.c:108)
@@ -405,8 +422,8 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 	if (c->N == 0) return 0;
 	{ const int rc = make_sweep_view(c, &v); if (rc) return rc; }
 	TimedLaunch t; t.which = timed_which; t.units = c->N;
-	static const int reps = [] { const char *e = getenv("PGA_SW_REPS"); return e && atoi(e) > 0 ? atoi(e) : 1; }(); // tuning aid: the sweep is idempotent
-	static_assert(MODE >= 0 && MODE <= 3, "sweep modes");
+	constexpr int reps = 1;
+	static_assert(MODE == 0 || MODE == 1 || MODE == 3, "sweep modes");
 	const bool timed = (timed_which == 0 || timed_which == 1) && c->timing_on; // (the stage-C sweeps are not timed one by one: two events per launch cost ~10 us of queue time)
 	if (timed) {
 		HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
@@ -647,8 +664,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->gs_ok = c->gs_np <= GS_NP_MAX && c->rk_shift >= 0 && getenv("PANGENE_GLOBAL_SORT") == nullptr;
 	c->gs2 = 0;
 	if (c->gs_ok && c->gs_np <= GS2_NP_BIG) {
-		static const int want = [] { const char *e = getenv("PANGENE_GS2"); return e ? (*e == '0' ? 0 : *e == 'd' ? 2 : 1) : 1; }(); // (tests / tuning: 0 = the round-3 kernel, d = every genome by the 14-items form)
-		c->gs2 = want;
+		c->gs2 = 1;
 		std::vector<int32_t> small, big;
 		int np_small = 64;
 		for (int g = 0; g < GL; ++g) {
@@ -679,15 +695,15 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	}
 
 	c->gf_pos_bits = bits_for((uint32_t)std::max(1, max_hit - 1));
-	c->gf_k32 = !neg_sadj && bits_for(max_sadj) + c->gf_pos_bits <= 32 && getenv("PANGENE_FILTERS_K64") == nullptr && (gf_lds_bytes(c->P, c->Q) > (size_t)64 << 10 || getenv("PANGENE_FILTERS_K32") != nullptr); // (small tables: the 8-byte form, as before; tests force the other)
-	c->gf_ok = gf_lds_bytes(c->P, c->Q, c->gf_k32) <= (size_t)150 << 10 && getenv("PANGENE_FILTERS_GLOBAL") == nullptr;
+	c->gf_k32 = !neg_sadj && bits_for(max_sadj) + c->gf_pos_bits <= 32 && !env_has("PANGENE_FILTERS", "k64") && (gf_lds_bytes(c->P, c->Q) > (size_t)64 << 10 || env_has("PANGENE_FILTERS", "k32")); // (small tables: the 8-byte form, as before; tests force the other)
+	c->gf_ok = gf_lds_bytes(c->P, c->Q, c->gf_k32) <= (size_t)150 << 10 && !env_has("PANGENE_FILTERS", "global");
 	if (c->gf_ok && hipFuncSetAttribute(c->gf_k32 ? reinterpret_cast<const void *>(k_genome_filters<true>) : reinterpret_cast<const void *>(k_genome_filters<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
 	                                    (int)gf_lds_bytes(c->P, c->Q, c->gf_k32)) != hipSuccess) { (void)hipGetLastError(); c->gf_ok = false; }
 
 	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
 		const size_t want = pool_want(N, GL, c->P, c->Q, woff[(size_t)GL]);
 		size_t got = 0;
-		void *a = getenv("PANGENE_NO_POOL_ARENA") == nullptr ? dev_big_alloc(want, &got) : nullptr;
+		void *a = getenv("PANGENE_NO_ARENA") == nullptr ? dev_big_alloc(want, &got) : nullptr;
 		if (a) { // else: slot by slot
 			c->pool.arena = (char *)a, c->pool.arena_cap = got, c->pool.arena_off = 0;
 			if (poison_on()) (void)hipMemset(a, 0x5a, got);
@@ -878,23 +894,19 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 		unsigned long long *tbest = c->gf_ok ? nullptr : (unsigned long long *)c->pool.get(S_TAB_D, sizeof(uint64_t) * (size_t)TQ);
 		uint8_t *noiso = c->gf_ok ? nullptr : (uint8_t *)c->pool.get(S_TAB_A, (size_t)TP + 16); // byte (genome, protein): the protein has a hit there without flt_iso_ov
 		if (!c->gf_ok && (!tbest || !noiso)) return PGA_ERR_NOMEM;
-		// read.c:248-254.  Default: ONE sweep for pg_shadow(cal_dom_sc=1), the reset behind it and pg_flt_ov_isoform (k_sweep<3>: they walk the
-		// same pairs); PANGENE_STAGE_A_TWO_SWEEPS=1 keeps the two-launch form of round 3 (tests)
-		static const bool two_sweeps = getenv("PANGENE_STAGE_A_TWO_SWEEPS") != nullptr;
-		const int fused = two_sweeps ? 0 : 1;
+		// read.c:248-254: ONE sweep for pg_shadow(cal_dom_sc=1), the reset behind it and pg_flt_ov_isoform (k_sweep<3>: they walk the same pairs)
 		c->sweep_init = true;
-		const int rc_sw = fused ? launch_sweep<3>(c, 0) : launch_sweep<1>(c, 0); // "K1", the hit-filter+overlap kernel
+		const int rc_sw = launch_sweep<3>(c, 0); // "K1", the hit-filter+overlap kernel
 		c->sweep_init = false;
 		TRY(rc_sw);
-		if (!fused) TRY(launch_sweep<2>(c, 1)); // pg_flt_ov_isoform, read.c:254 (reads neither the shadow flags nor pid_dom: read.c:249-253 follows, in k_iso_apply)
 		if (c->gf_ok) { // read.c:249-256 per genome, the tables in LDS
-			GenomeFilters gf = { c->flags, c->pid, c->gid, c->rank, c->sadj, c->pdom, c->pdom0, c->goff, c->recA, P, Q, d_stats, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP), fused, c->gf_pos_bits };
+			GenomeFilters gf = { c->flags, c->pid, c->gid, c->rank, c->sadj, c->pdom, c->pdom0, c->goff, c->recA, P, Q, d_stats, c->dcnt, (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP), c->gf_pos_bits };
 			if (!gf.hz_list) return PGA_ERR_NOMEM;
 			if (c->gf_k32) hipLaunchKernelGGL(k_genome_filters<true>, dim3((unsigned)GL), dim3(GF_T), gf_lds_bytes(P, Q, true), c->st, gf);
 			else hipLaunchKernelGGL(k_genome_filters<false>, dim3((unsigned)GL), dim3(GF_T), gf_lds_bytes(P, Q, false), c->st, gf);
 		} else {
 		HIPCHK(hipMemsetAsync(noiso, 0, (size_t)TP, c->st));
-		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, c->pdom, c->pdom0, N, P, noiso, k_stats, fused);
+		hipLaunchKernelGGL(k_iso_apply, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pid, c->pdom, c->pdom0, N, P, noiso, k_stats);
 		hipLaunchKernelGGL(k_chain, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->pdom0, N, P, noiso, k_stats);
 		HIPCHK(hipMemsetAsync(tbest, 0, sizeof(uint64_t) * (size_t)TQ, c->st));
 		hipLaunchKernelGGL(k_subopt1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->sadj, c->goff, N, Q, tbest);
@@ -1662,7 +1674,7 @@ extern "C" int pga_arc_round_x(pga_ctx_t *c, int32_t use_ori, int32_t n_seg, con
 	if (c->x_arcs_seen <= 0 && x->arc_cap_hint <= 0) return 2;
 	LoopX L = { x, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr };
 	L.arc_cap = x_arc_cap(c, x);
-	{ const char *ea = getenv("PANGENE_XLOOP_ARC_CAP"); if (ea && c->x_arcs_seen == 0) L.arc_cap = std::max<int64_t>(atoll(ea), 1); }
+	{ const long long ea = xloop_cap(1); if (ea && c->x_arcs_seen == 0) L.arc_cap = std::max<int64_t>(ea, 1); }
 	if ((int64_t)x->world * L.arc_cap >= ((int64_t)1 << 31)) return 2; // (entries of the gathered tables are numbered in 32 bits)
 	L.ecap = std::max<int64_t>(2 * (int64_t)N + 2, (int64_t)x->world * L.arc_cap);
 	L.slot_words = xs_slot_words(S, L.arc_cap);
@@ -1736,9 +1748,9 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		L.pair_cap = std::max<int64_t>(std::max<int64_t>(L.pair_cap, std::min<int64_t>(worst, c->x_pair_floor)), 4 * (int64_t)n_vtx); // (pga_branch_pairs never works with less)
 		L.arc_cap = x_arc_cap(c, x); // (every slot travels at its capacity)
 		if (c->x_pairs_seen == 0) { // (tests: start with buffers that are too small, to reach status 3 and the learned capacities)
-			const char *ep = getenv("PANGENE_XLOOP_PAIR_CAP"), *ea = getenv("PANGENE_XLOOP_ARC_CAP");
-			if (ep) L.pair_cap = std::max<int64_t>(atoll(ep), 4 * (int64_t)n_vtx);
-			if (ea && c->x_arcs_seen == 0) L.arc_cap = std::max<int64_t>(atoll(ea), 1);
+			const long long ep = xloop_cap(0), ea = xloop_cap(1);
+			if (ep) L.pair_cap = std::max<int64_t>(ep, 4 * (int64_t)n_vtx);
+			if (ea && c->x_arcs_seen == 0) L.arc_cap = std::max<int64_t>(ea, 1);
 		}
 		c->br_cap = L.pair_cap; // what k_pair_offsets tests and k_br_wave / k_n_local stride over
 		if ((int64_t)x->world * L.arc_cap >= ((int64_t)1 << 31)) return 2; // (entries of the gathered tables are numbered in 32 bits)
@@ -1785,7 +1797,7 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	// host does not look -- and leave at once.  Human-shaped shards reach it after three or four of the fifteen rounds; bacterial ones
 	// as a rule do not.  Sharded runs keep every round: their collectives are queued by the host, and "nothing changed" would have to
 	// hold on every rank.
-	static const bool no_skip = getenv("PANGENE_LOOP_NO_SKIP") != nullptr;
+	static const bool no_skip = env_has("PANGENE_LOOP", "noskip");
 	const bool gated = x == nullptr && !no_skip && (int64_t)c->round_tag + n_round + 4 < (int64_t)HA_TAG_MAX;
 	struct GateScope { pga_ctx *c; ~GateScope() { c->gate = Gate{nullptr, 0}; } } gate_scope{c}; // (every way out of this function leaves the launches open)
 	const uint32_t tag_before = c->round_tag;
@@ -1859,10 +1871,10 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	TRY(sync_st(c));
 	if (gated) { // the half-arc records carry the tag of the last arc round that RAN (a round that found nothing to do wrote none)
 		c->round_tag = h_ctl[2] >= 0 ? (uint32_t)h_ctl[2] : tag_before;
-		if (getenv("PANGENE_DEBUG_LOOP") || getenv("PANGENE_TIMING")) fprintf(stderr, "[pga_branch_loop] %d rounds queued; the last round that deleted a segment: %d, that marked a hit: %d (-1: none) -- the rounds after both found their kernels closed\n", n_round, h_ctl[0], h_ctl[1]);
+		if (getenv("PANGENE_TIMING")) fprintf(stderr, "[pga_branch_loop] %d rounds queued; the last round that deleted a segment: %d, that marked a hit: %d (-1: none) -- the rounds after both found their kernels closed\n", n_round, h_ctl[0], h_ctl[1]);
 	}
 	c->br_np_seen = std::max<int64_t>(c->br_np_seen, c->h_cnt[15]);
-	if (getenv("PANGENE_DEBUG_LOOP")) fprintf(stderr, "[pga_branch_loop] counters after %d rounds: invariant %lld, table overflows (last round) %lld, sticky %lld, pairs (last round) %lld of capacity %lld\n", n_round, (long long)c->h_cnt[3], (long long)c->h_cnt[9], (long long)c->h_cnt[11], (long long)c->h_cnt[15], (long long)c->br_cap);
+	if (getenv("PANGENE_TIMING")) fprintf(stderr, "[pga_branch_loop] counters after %d rounds: invariant %lld, table overflows (last round) %lld, sticky %lld, pairs (last round) %lld of capacity %lld\n", n_round, (long long)c->h_cnt[3], (long long)c->h_cnt[9], (long long)c->h_cnt[11], (long long)c->h_cnt[15], (long long)c->br_cap);
 	if (x) {
 		const int32_t *f = (const int32_t *)h_x;
 		c->x_pairs_run = std::max<int64_t>(c->x_pairs_run, h_x[2]), c->x_arcs_run = std::max<int64_t>(c->x_arcs_run, h_x[3]); // the next run's capacities (every round's list travels at its capacity: a margin above what was needed, not more)
@@ -1874,7 +1886,7 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		else if (!f[0]) c->x_pair_floor = 0, c->x_arc_floor = 0; // a run that went through: its statistics are the next run's capacities
 		c->br_np_seen = std::max<int64_t>(c->br_np_seen, h_x[2]);
 		c->br_cap = std::max<int64_t>(br_cap_before, c->br_cap);
-		if (getenv("PANGENE_DEBUG_LOOP")) fprintf(stderr, "[pga_branch_loop] sharded over %d ranks: flags (summed) void %d invariant %d capacity %d hub %d; longest pair list %lld of %lld, largest local table %lld of %lld\n", x->world, f[0], f[1], f[2], f[3],
+		if (getenv("PANGENE_TIMING")) fprintf(stderr, "[pga_branch_loop] sharded over %d ranks: flags (summed) void %d invariant %d capacity %d hub %d; longest pair list %lld of %lld, largest local table %lld of %lld\n", x->world, f[0], f[1], f[2], f[3],
 		                                          (long long)h_x[2], (long long)L.pair_cap, (long long)h_x[3], (long long)L.arc_cap);
 		if (f[1]) return PGA_ERR_INVARIANT;
 		if (f[0]) return (f[2] && !f[3]) ? 3 : 1;
@@ -1936,8 +1948,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	const bool z_keep = c->z_valid && (which == 1 || !c->par.check_strand);
 	// The half-arc records of the walk that stands survive too when the override is small: only the overridden contigs are walked again
 	// (k_walk_list), with the tag that stands.  Not with virtual contigs (a piece's neighbours in the walk may lie in the piece next to it).
-	static const bool partial_on = getenv("PANGENE_OVERRIDE_FULL_WALK") == nullptr;
-	const bool partial = partial_on && c->ha_valid && c->wrec_valid && z_keep && !c->zposy_stale && c->vfirst == nullptr && n_seg > 0 && seg_off[n_seg] * 8 <= (int64_t)N;
+	const bool partial = c->ha_valid && c->wrec_valid && z_keep && !c->zposy_stale && c->vfirst == nullptr && n_seg > 0 && seg_off[n_seg] * 8 <= (int64_t)N;
 	c->walk_valid = false, c->ha_valid = false, c->yrec_valid = false, c->wrec_valid = false;
 	if (!z_keep) c->z_valid = false;
 	if (n_seg <= 0 || N == 0) return 0;

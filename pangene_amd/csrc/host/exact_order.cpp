@@ -94,7 +94,7 @@ static void static_tie_contigs(const pg_data_t *d, const pg_genome_t *g, bool ch
 	// open addressing, one table for both kinds of key: slot = index of the group's first hit + 1; the members of a group are chained
 	static thread_local std::vector<int32_t> tab, nxt;
 	std::vector<uint8_t> marked((size_t)g->n_ctg, 0);
-	static const bool dbg = std::getenv("PANGENE_DEBUG_STATIC") != nullptr;
+	static const bool dbg = std::getenv("PANGENE_TIMING") != nullptr && std::getenv("PANGENE_TIMING")[0] == '2'; // (PANGENE_TIMING=2: also which tie marked which contig -- a line per contig)
 	auto mix = [](uint64_t a, uint64_t b) { uint64_t h = (a + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull; h ^= h >> 29; h = (h + b) * 0x94d049bb133111ebull; h ^= h >> 32; return h; };
 	for (int kind = 0; kind < 2; ++kind) {
 		tab.assign(cap, 0);
@@ -233,7 +233,7 @@ void exact_init(const pg_data_t *d, DataExt *ext)
 		for (ExactSeg &s : per[k]) ext->xsegs.push_back(std::move(s));
 		for (int32_t c : per_static[k]) ext->static_ctgs.emplace_back((int32_t)k, c); // (sorted: genomes ascending, contigs ascending inside)
 	}
-	if (std::getenv("PANGENE_DEBUG_HAZARDS")) {
+	if (std::getenv("PANGENE_TIMING")) {
 		size_t n_full = 0, n_full_hits = 0;
 		for (const ExactSeg &s : ext->xsegs) if (s.full) ++n_full, n_full_hits += s.file.size();
 		std::fprintf(stderr, "[exact_init] mode %d: %zu tracked contig(s), %zu of them in full (%zu hits); %zu by the static tie prediction\n", mode, ext->xsegs.size(), n_full, n_full_hits, ext->static_ctgs.size());

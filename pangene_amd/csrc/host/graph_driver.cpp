@@ -919,7 +919,7 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 				}
 		}
 	}
-	if (std::getenv("PANGENE_VTX_TIMING")) std::fprintf(stderr, "[vtx] partials %.3f ms, fetch %.3f ms (records %ld / %ld), greedy %.3f ms\n", (tv1 - tv0) * 1e3, (tv2 - tv1) * 1e3, (long)n_tri, (long)n_rec, (now_sec() - tv2) * 1e3);
+	if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[vtx] partials %.3f ms, fetch %.3f ms (records %ld / %ld), greedy %.3f ms\n", (tv1 - tv0) * 1e3, (tv2 - tv1) * 1e3, (long)n_tri, (long)n_rec, (now_sec() - tv2) * 1e3);
 	// segments by gene id (vertex.c:85-94; keys unique, any sort gives the reference's order)
 	{ // (gene ids are unique and < Q: one placement pass instead of a comparison sort)
 		std::vector<int32_t> at((size_t)Q, -1);
@@ -1219,7 +1219,7 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	if (shd && ext->skip_loop_once) { ext->skip_loop_once = false; return 0; } // the repeated run after status 3
 	if ((pre || fin) && shd) return 0;
 	const int n_sorts = 2 * R - 1 + (pre ? 1 : 0) + (fin ? 1 : 0); // of each kind: one pair per pg_mark_branch_flt_hit (branch.c:116,140), one per pg_gen_arc (graph.c:103,123)
-	static const bool dbg = std::getenv("PANGENE_DEBUG_LOOP") != nullptr;
+	static const bool dbg = std::getenv("PANGENE_TIMING") != nullptr;
 	bool quiet;
 	{ Phase ph(PH_EXACT); quiet = exact_quiet(ext, n_sorts); }
 	if (shd) { // every rank queues the rounds, or none does: the ranks vote (a rank without hits or segments cannot; one whose hit order needs the host neither)
@@ -1308,7 +1308,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	BE_CALL(trace_state(ext, "gen_vtx+flag_vtx", 0), "trace");
 	// Graphs 2 and 3 as ONE queue when the backend can (pga_branch_loop with its pre-step): graph 1's arc round is left running, the
 	// loop starts with graph 2's pg_flt_high_occ + pg_gen_arc and goes on with the branch rounds -- no wait between graph 1 and round n-2.
-	static const bool no_pre = std::getenv("PANGENE_LOOP_NO_PRE") != nullptr; // (tests: graph 2 host-driven in front of the queued rounds)
+	static const bool no_pre = env_word("PANGENE_LOOP", "nopre"); // (tests: graph 2 host-driven in front of the queued rounds)
 	const bool try_pre = !no_pre && opt->n_branch_flt >= 2 && ext->be->branch_loop != nullptr && !sharded() && route_v(ext) < 3 && trace_path() == nullptr && !ext->no_branch_loop;
 	BE_CALL(gen_arc(opt, q, ext, try_pre), "gen_arc");
 	BE_CALL(trace_state(ext, "gen_arc", 1), "trace");
@@ -1318,7 +1318,7 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	bool queued_all = false;
 	ext->seg_renumber.clear();
 	if (try_pre) {
-		static const bool no_fin = std::getenv("PANGENE_LOOP_NO_FINAL") != nullptr; // (tests: the last round host-driven behind the queued ones)
+		static const bool no_fin = env_word("PANGENE_LOOP", "nofinal"); // (tests: the last round host-driven behind the queued ones)
 		if (!no_fin) { // every round and the arc round of the graph that is written
 			const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt, &queued_all, true, true);
 			if (rc) return rc;
@@ -1469,7 +1469,7 @@ static int hazards_review(DataExt *ext, bool *need, bool *give_up)
 			if (std::binary_search(ext->static_ctgs.begin(), ext->static_ctgs.end(), gc)) continue; // follows the exact order already (static prediction)
 			auto it = std::lower_bound(ext->extra_ctgs.begin(), ext->extra_ctgs.end(), gc);
 			if (it == ext->extra_ctgs.end() || *it != gc) ext->extra_ctgs.insert(it, gc), ++n_new;
-			if (std::getenv("PANGENE_DEBUG_HAZARDS")) std::fprintf(stderr, "[hazard] local genome %d contig %d\n", gc.first, gc.second);
+			if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[hazard] local genome %d contig %d\n", gc.first, gc.second);
 		}
 		if (n_new) flags[0] = 1;
 		if (pg_verbose >= 2)

@@ -825,7 +825,7 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 	// ~90 GB takes 1.9 s, and while it runs every page fault of the process waits (tried: on a helper thread beside the parsers the
 	// parse took 3.3 s instead of 1.3 and the packing 2 s instead of 0.1 -- the time moved, it did not go away).  The estimate comes from
 	// the files' sizes and the head of the first local plain file (lines per byte, introns per line); a wrong one costs the attempt.
-	if (std::getenv("PANGENE_NO_RESERVE") == nullptr && local_text >= ((size_t)1 << 30)) {
+	if (local_text >= ((size_t)1 << 30)) {
 		const pga_backend_t *be = backend_default();
 		for (int32_t i = 0; be && be->reserve && i < n; ++i) {
 			const size_t len = fns[i] ? std::strlen(fns[i]) : 0;
@@ -865,7 +865,7 @@ int32_t pg_read_paf_batch(const pg_opt_t *opt, pg_data_t *d, int32_t n, const ch
 			const size_t len = fns[i] ? std::strlen(fns[i]) : 0;
 			if (!(ids_only && ids_only[i]) && fns[i] && !(len > 3 && std::strcmp(fns[i] + len - 3, ".gz") == 0) && stat(fns[i], &sb) == 0 && S_ISREG(sb.st_mode)) plain += (size_t)sb.st_size;
 		}
-		static const bool no_arena = std::getenv("PANGENE_NO_READ_ARENA") != nullptr;
+		static const bool no_arena = std::getenv("PANGENE_NO_ARENA") != nullptr;
 		if (plain >= ((size_t)8 << 20) && !no_arena) {
 			const size_t huge = (size_t)2 << 20, want = ((plain / 60 + (size_t)n) * sizeof(pg_hit_t) + (plain / 3 + 2048 * (size_t)n) * sizeof(pg_exon_t) + 128 * (size_t)n + huge - 1) & ~(huge - 1);
 			void *m = mmap(nullptr, want + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);

@@ -25,6 +25,14 @@ namespace pgx {
 // threads runs no faster than one of 16, it only burns the quota in a quarter of every 100 ms period and then ALL threads of the process,
 // the one feeding the GPU included, stand still until the next period; profiles/r04_cpu_scaling_box.txt.)
 unsigned host_threads(unsigned cap);
+// a switch that takes a comma-separated list of words (PANGENE_LOOP=nopre,nofinal)
+inline bool env_word(const char *name, const char *word)
+{
+	const char *e = std::getenv(name);
+	const size_t n = std::strlen(word);
+	while (e && *e) { const char *c = std::strchr(e, ','); const size_t len = c ? (size_t)(c - e) : std::strlen(e); if (len == n && std::strncmp(e, word, n) == 0) return true; e = c ? c + 1 : nullptr; }
+	return false;
+}
 bool device_is_up(); // the backend's runtime has been started in this process (graph_driver.cpp)
 
 // Name -> id.  Open addressing over (32-bit hash, id) slots, names in blocks that never move (pg_gene_t / pg_prot_t / pg_ctg_t keep

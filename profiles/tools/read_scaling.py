@@ -19,7 +19,7 @@ for rep in range(3):
     t = time.time(); capi.read_files(lib, opt, dd, fs); dt = time.time() - t
     best = dt if best is None or dt < best else best
     lib.pg_data_destroy(dd)
-print("RESULT %%s threads=%%s arena=%%s best_of_3 %%.3f s" %% (os.environ.get("TAG", ""), os.environ.get("PANGENE_READ_THREADS", "default"), "no" if os.environ.get("PANGENE_NO_READ_ARENA") else "yes", best))
+print("RESULT %%s threads=%%s arena=%%s best_of_3 %%.3f s" %% (os.environ.get("TAG", ""), os.environ.get("PANGENE_READ_THREADS", "default"), "no" if os.environ.get("PANGENE_NO_ARENA") else "yes", best))
 ''' % ROOT
 if __name__ == "__main__":
     G = int(sys.argv[1]) if len(sys.argv) > 1 else 1250
@@ -35,7 +35,7 @@ if __name__ == "__main__":
         for th in ("8", "16", "32", "64") if arena else ("16",):
             env = dict(os.environ, PANGENE_READ_THREADS=th, PANGENE_TIMING="1")
             if not arena:
-                env["PANGENE_NO_READ_ARENA"] = "1"
+                env["PANGENE_NO_ARENA"] = "1"
             r = subprocess.run([sys.executable, "-c", CHILD, d], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             err = [l for l in r.stderr.decode().split("\n") if l.startswith("[pg_read_paf_batch]")]
             print(r.stdout.decode().strip().split("\n")[-1] if r.returncode == 0 else "FAILED: " + r.stderr.decode()[-500:], flush=True)

@@ -109,9 +109,9 @@ def _run_with_env(tmp_path, env, mode, variant, files):
 
 
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
-@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1", "PANGENE_LOOP_NO_PRE": "1"},
-                                 {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1", "PANGENE_FILTERS_GLOBAL": "1"}, {"PANGENE_LOOP_NO_FINAL": "1", "PANGENE_STAGE_A_TWO_SWEEPS": "1"},
-                                 {"PANGENE_FILTERS_K32": "1", "PANGENE_LOOP_NO_SKIP": "1"}])
+@pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1", "PANGENE_LOOP": "nopre"},
+                                 {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1", "PANGENE_FILTERS": "global"}, {"PANGENE_LOOP": "nofinal", "PANGENE_MERGE_LITERAL": "1"},
+                                 {"PANGENE_FILTERS": "k32", "PANGENE_LOOP": "noskip"}])
 def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
     (the path of rounds in which a hub gene overflows the per-gene LDS table).  Forcing the sort path, and shrinking the table to 4
@@ -126,8 +126,8 @@ def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     bytes: the default of round 2) and stage A's orders by the multi-workgroup radix sort instead of k_genome_sort (the path of
     genomes with more than 25 600 hits), and read.c:249-256 by the four kernels with their tables in HBM instead of k_genome_filters (the
     path of shards whose P + 8 Q bytes do not fit the LDS).  Fifth setting: the last branch round and the arc round of the graph that is written driven by the
-    host behind the queued rounds (the default queues them too and renumbers segments and arcs on the host at the end); and stage A's two
-    sweeps as two launches (k_sweep<1> + k_sweep<2>, the round-3 form) instead of the fused k_sweep<3>.  Sixth setting: the 4-byte `best`
+    host behind the queued rounds (the default queues them too and renumbers segments and arcs on the host at the end); and every exon-list
+    merge of the sweeps by the reference's literal steps (cds_inter_ref) instead of the shortcuts of cds_inter_t.  Sixth setting: the 4-byte `best`
     entries of k_genome_filters (the form of shards whose gene tables would not fit the LDS with 8-byte entries: 20 000-gene human
     annotations) on these small shards too, and every queued branch round run in full (no fixed-point gates)."""
     out = _run_with_env(tmp_path, env, 2, variant, golden_files(name))
@@ -641,7 +641,7 @@ import sys, os, ctypes as C, hashlib, json
 sys.path.insert(0, %r)
 import torch, torch.distributed as dist
 from pangene_amd import capi, exchange
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], RANK="0", WORLD_SIZE="1", PANGENE_FORCE_EXCHANGE="1", PANGENE_DEBUG_LOOP="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], RANK="0", WORLD_SIZE="1", PANGENE_FORCE_EXCHANGE="1", PANGENE_TIMING="1")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 lib = capi.load(); C.c_int.in_dll(lib, "pg_verbose").value = 0
@@ -708,7 +708,7 @@ def test_sharded_branch_loop_learns_its_capacities(built, expected, tmp_path):
     jobs = [[golden_files("bact20"), [], 3]]
     (tmp_path / "jobs.json").write_text(json.dumps(jobs))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    for envx in ({"PANGENE_XLOOP_PAIR_CAP": "64"}, {"PANGENE_XLOOP_ARC_CAP": "100"}):
+    for envx in ({"PANGENE_XLOOP_CAP": "64"}, {"PANGENE_XLOOP_CAP": "0,100"}):
         r = subprocess.run([sys.executable, "-c", _XLOOP_CODE, str(port), "native", str(tmp_path / "jobs.json"), str(tmp_path / "res.json")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
                            env=dict(os.environ, **envx))
         err = r.stderr.decode()
