@@ -618,15 +618,16 @@ def main():
             walls = []
             for _ in range(3):  # a fresh process each time: device start-up alone varies between 0.08 and 0.25 s on this box (profiles/r04_cli_probe.txt)
                 t0 = time.time()
-                r1 = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, PANGENE_TIMING="1"))
+                r1 = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
                 walls.append(time.time() - t0)
                 if walls[-1] == min(walls):
                     r = r1
             t_cli = min(walls)
+            rp = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, PANGENE_TIMING="1"))  # one more, not timed: the wall time by parts
             cli = {"wall_s": round(t_cli, 3), "wall_s_each": [round(w, 3) for w in walls], "wall_s_is": "the fastest of three fresh processes", "M_hits_per_s": round(n_hits / t_cli / 1e6, 2), "rc": r.returncode, "gfa_md5": hashlib.md5(r.stdout).hexdigest(),
                    "same_bytes_as_the_library_run": hashlib.md5(r.stdout).hexdigest() == hashlib.md5(gfa).hexdigest(),
                    "what": "pangene_amd/bin/pangene <%d files> > pipe: process start + HIP initialisation + code-object load + parsing + path + GFA text" % len(files)}
-            m = re.search(rb"\[cli_timing\] (\{.*\})", r.stderr)
+            m = re.search(rb"\[cli_timing\] (\{.*\})", rp.stderr)
             if m:
                 cli["parts"] = json.loads(m.group(1).decode())
         except Exception as ex:
