@@ -1391,7 +1391,11 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	if (exact_mode() == 0 && be->hazards(ctx, &hz) == 0 && (hz.h1_head_tie | hz.h2_cm_tie | hz.h3_dom_tie | hz.h2_cs_tie) && pg_verbose >= 2)
 		std::fprintf(stderr, "[W::%s] tie-order hazards seen (head-tie %ld, cm-tie %ld, dominator-tie %ld, cs-tie at the local_count boundary %ld): output may differ from the reference's unstable sort order\n",
 		             "pg_graph_gen", (long)hz.h1_head_tie, (long)hz.h2_cm_tie, (long)hz.h3_dom_tie, (long)hz.h2_cs_tie);
-	return sync_host(q->d, false);
+	// (What the writers need of the per-hit state -- one flt bit per hit and, once per order epoch, the two orders -- is fetched by the
+	// writer that asks first, pg_write_walk / pg_write_bed / pg_write_matrix through sync_host: it is the device-side counterpart of the two
+	// sorts per genome the reference does INSIDE pg_write_walk, format.c:183-225, not a step of pg_graph_gen.  Rounds 2-4 fetched it here,
+	// eagerly: 16-21 ms of a 12 M-hit first pass.)
+	return g_err;
 }
 
 } // namespace pgx
