@@ -664,7 +664,7 @@ def main():
             "attempts_per_step": attempts / max(1, a.steps),
             # SURVEY 8(d)'s metric as the survey words it (device upload included), over data sets the process has never seen
             "upload_inclusive": (dict(upl, first_pass_of_the_process_ms=round(t_cold_all * 1e3, 2),
-                                      includes="block packing in the reader threads + allocation, H2D and order-replay set-up + stages A+B+C; excludes PAF text parsing and GFA printing; every data set has its own seed: nothing is resident or cached except the device memory blocks the previous data set gave back (the library keeps two)")
+                                      includes="block packing in the reader threads + allocation, H2D and order-replay set-up + stages A+B+C; excludes PAF text parsing and GFA printing (round 5: and with the printing what the WRITERS fetch of the per-hit state -- one flt bit per hit and the two orders -- which pg_write_walk asks for itself, as the reference sorts inside pg_write_walk: gfa_write_s carries it now); every data set has its own seed: nothing is resident or cached except the device memory blocks the previous data set gave back (the library keeps two)")
                                  if upl else None),
             "full_size": full_leg,
             "cold_pass": {"value": round(tot_hits / t_cold_all / 1e6, 3), "unit": "M hits/s", "ms": round(t_cold_all * 1e3, 2),
