@@ -8,6 +8,7 @@
 #   stage cal     calibration of FETCH_SIZE / WRITE_SIZE with kernels of known byte counts (profiles/tools/calibrate.py)
 #   stage full    BASELINE configs[3] / configs[4] at their full stated size on this one GPU (bench.py --workload config3 | config4)
 #   stage full4   configs[4] at full size under the profiler: kernel stats with the pass timeline, FETCH_SIZE / WRITE_SIZE per kernel, SQ counters of K1
+#   stage full3   configs[3] at full size under the profiler (kernel stats with the pass timeline)
 #   stage ranks8  eight ranks sharing the one GPU over gloo on the configs[3] / configs[4] per-GPU shards (pytest), with the wall time
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
@@ -83,6 +84,10 @@ full4)
 	rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace -d $out/prof_sq -o q -- $B1 > /dev/null 2>&1
 	python profiles/tools/pmc_summary.py $out/prof_sq "k_sweep<3" | grep -v "^dur" >> $out/${tag}_pmc_sq_k1_config4.txt 2>&1; rm -rf $out/prof_sq
 	head -n 30 $out/${tag}_kernel_stats_config4_full_size.txt | cut -c1-160; head -n 12 $out/${tag}_pmc_traffic_config4_full_size.txt | cut -c1-160; cat $out/${tag}_pmc_sq_k1_config4.txt;;
+full3)
+	PANGENE_TIMING=1 rocprofv3 --kernel-trace --stats -d $out/prof_c3 -o s -- python bench.py --workload config3 --steps 2 --warmup 1 > $out/${tag}_bench_config3_under_rocprof.json 2> $out/${tag}_bench_config3_under_rocprof.stderr
+	python profiles/tools/kernel_stats.py $out/prof_c3 > $out/${tag}_kernel_stats_config3_full_size.txt; rm -rf $out/prof_c3
+	head -n 24 $out/${tag}_kernel_stats_config3_full_size.txt | cut -c1-160;;
 ranks8)
 	( time timeout 1500 python -m pytest tests/test_hip_parity.py -m gpu -q -k "eight_ranks_at_size" ) > $out/${tag}_pytest_eight_ranks_at_size.log 2>&1; tail -n 6 $out/${tag}_pytest_eight_ranks_at_size.log;;
 esac; done
