@@ -364,10 +364,15 @@ def main():
         bph = 64 + 8 * E
         avg_ms = ms / nl
         ach = bph * (units / nl) / (avg_ms * 1e-3) / 1e9
-        r = {"bound": "hbm", "kernel": "k_sweep<3, %s> (stage A's fused sweep: pg_shadow cal_dom_sc=1 + the reset of read.c:249-253 + pg_flt_ov_isoform)" % ("true" if multi else "false"), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(units // nl, "true" if multi else "false"), "avg_launch_ms": round(avg_ms, 4), "launches": nl,
+        dens, in_lds, tiles = k_timing(dd, 7)  # which build of K1 this upload got (pangene_hip.h): the lists of multi-exon hits in LDS, or left in global memory
+        flavour = "false" if not multi else ("lean" if in_lds == 0 else "true")
+        kname = "k_sweep_lean<3>" if flavour == "lean" else "k_sweep<3, %s>" % flavour
+        r = {"bound": "hbm", "kernel": kname + " (stage A's fused sweep: pg_shadow cal_dom_sc=1 + the reset of read.c:249-253 + pg_flt_ov_isoform)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(units // nl, flavour), "avg_launch_ms": round(avg_ms, 4), "launches": nl,
              "timing": "per-dispatch HIP start/stop events (hipExtLaunchKernelGGL) on the library's stream",
              "algorithmic_bytes_per_hit": round(bph, 1), "hits_per_launch": units // nl, "shard": note}
+        if multi and tiles:
+            r["exon_lists"] = {"staged_in_lds": bool(in_lds), "exons_a_tile_to_stage": round(dens, 1), "tiles_sampled": tiles, "rule": "k_sweep (lists in LDS) from 1024 exons a tile on, k_sweep_lean below"}
         if r["traffic"]:  # what the kernel really moves (PMC passes of the same source), against the same peak: the honest fraction when the algorithmic bytes exceed it
             r["frac_by_counters"] = round(r["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         ms3, nl3, u3 = k_timing(dd, 3)

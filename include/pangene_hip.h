@@ -415,7 +415,9 @@ void *pga_active_stream(void);
  * 1 = the pg_flt_ov_isoform sweep, 2 = the other pg_shadow sweeps, 3 = the whole of stage A (pga_begin + pga_ingest), 4 = host waits
  * (count only); with PANGENE_TIME_ROUNDS=1 in the environment at pga_timing_reset also 5 = every pg_gen_arc round (graph.c:87-177: sweep, walk,
  * temp arcs, collapse -- two more events per round, so for a pass that is not itself timed) and 6 = its walk scan alone.
- * which | (k + 1) << 8 selects the k-th timed launch of the class alone. */
+ * which | (k + 1) << 8 selects the k-th timed launch of the class alone.  7 is not a timing: which build of K1 the sweeps of stage A and
+ * pg_post_process run on this upload -- n_launch = 1 k_sweep (the tile's exon lists staged in LDS), 0 k_sweep_lean (read where they are),
+ * -1 not decided yet; total_ms = the exons a tile would stage, as sampled (units = tiles sampled; 0 when PANGENE_SWEEP_LISTS fixed the choice). */
 /* Optional, before pga_create: the device memory a shard of about this size will ask for (hits, exons, proteins, genes, genomes, words of
  * packed blocks), allocated now and kept for the pga_create that follows -- hipMalloc of tens of gigabytes takes seconds, and a reader
  * that knows its files' sizes can have it done while it parses (pg_read_paf_batch does).  Too small an estimate costs nothing but the

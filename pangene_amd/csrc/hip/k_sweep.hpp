@@ -284,8 +284,8 @@ __device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl
 	}
 }
 
-template <int MODE, bool STAGE_C>
-__global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
+template <int MODE, bool STAGE_C, bool LISTS_IN_LDS>
+__device__ __forceinline__ void sweep_tile(const SweepView &v)
 {
 	if (gate_closed(v.gate)) return; // (k_sweep_slow then finds an empty list and only resets the next sweep's counter)
 	static_assert(2 * SW_HALO == 64 && SW_NW == 4 && SW_LDS <= 1024 && 64 + 2 * SW_HALO <= 128 && SW_WCAP >= 64 + 3 * SW_HALO, "the slots past SW_TILE are staged one array per wave; window-relative slot ids are packed in 7 bits, winner slots in 10; a level of the pair list has at most 64 + SW_HALO entries");
@@ -294,7 +294,10 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 	// exact overlap).  The sweeps of the arc rounds (MODE 0) see what the filters left -- one isoform a gene -- and merge a few lists per tile:
 	// they read them where they are and keep the smaller footprint (six workgroups per CU instead of three: 113 us against 33 on the
 	// 2.7 M-hit isoform-rich shard when they staged as well).
-	constexpr bool STAGE_X = STAGE_C && (MODE == 1 || MODE == 3);
+	// Staging them costs LDS: three workgroups on a CU instead of six.  Where few hits overlap a neighbour at all (one isoform a gene) the
+	// kernel is made of the record loads and little else, and the occupancy is worth more than the lists in LDS: k_sweep_lean (same code,
+	// LISTS_IN_LDS = false) runs there -- the host picks by the shard's measured density, see k_list_density.
+	constexpr bool STAGE_X = STAGE_C && LISTS_IN_LDS && (MODE == 1 || MODE == 3);
 	__shared__ int4 sA[SW_LDS + 4], sB[SW_LDS], sC[STAGE_C ? SW_LDS : 1]; // sA: four sentinel slots close the array
 	__shared__ uint32_t sF[SW_LDS];
 	__shared__ int32_t sOri[STAGE_ORI ? SW_LDS : 1];
@@ -581,6 +584,27 @@ __global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v)
 	{ const int mx = wave_max(n_steps), sm = wave_sum(n_steps); if (v.prof && lane == 0) v.prof[((long long)blockIdx.x * SW_NW + wave) * SW_NSTAMP + 10] = mx, v.prof[((long long)blockIdx.x * SW_NW + wave) * SW_NSTAMP + 11] = sm; }
 #endif
 	SW_STAMP(9);
+}
+
+template <int MODE, bool STAGE_C>
+__global__ __launch_bounds__(SW_TILE) void k_sweep(SweepView v) { sweep_tile<MODE, STAGE_C, true>(v); }
+// the sweeps of stage A and pg_post_process on a shard of multi-exon hits that rarely overlap: the exon lists stay in global memory
+template <int MODE>
+__global__ __launch_bounds__(SW_TILE) void k_sweep_lean(SweepView v) { sweep_tile<MODE, true, false>(v); }
+
+// What k_sweep would stage, measured on a sample: the exons of the hits that overlap an X-order neighbour (the `want` test of sweep_tile), summed
+// over every `stride`-th tile (one workgroup a CU: one round of cold loads).  Once per upload (the keys never change); the host reads the sum and picks k_sweep or k_sweep_lean.
+__global__ __launch_bounds__(SW_TILE) void k_list_density(const int4 *A, const int4 *C, int n, int stride, int64_t *sum)
+{
+	const int h = blockIdx.x * stride * SW_TILE + threadIdx.x;
+	int ne = 0;
+	if (h < n) { // (four independent loads: a sampled tile is cold in every cache and in the TLB)
+		const int4 a = A[h], nx = A[h + 1 < n ? h + 1 : h], pv = A[h > 0 ? h - 1 : h], c = C[h];
+		const bool near = (h + 1 < n && nx.y == a.y && nx.x < a.z) || (h > 0 && pv.y == a.y && pv.w > a.x);
+		ne = near ? c.y : 0;
+	}
+	ne = wave_sum(ne);
+	if ((threadIdx.x & 63) == 0 && ne) atomicAdd((unsigned long long *)sum, (unsigned long long)ne);
 }
 
 // The rare hits k_sweep could not finish inside its LDS window: one thread per listed hit walks all its partners in

@@ -50,6 +50,26 @@ static int make_sweep_view(pga_ctx *c, SweepView *v)
 	return 0;
 }
 
+// Which K1 the sweeps of stage A and pg_post_process run on this upload: k_list_density adds up, over a sample of ~256 tiles, the
+// exons k_sweep would copy into LDS.  Fewer than SW_LEAN_BELOW a tile on average: the lists stay in global memory (k_sweep_lean, twice the
+// workgroups on a CU).  The keys of an upload never change, so this is asked once (one host wait, ~20 us); the results are the same either way.
+// PANGENE_SWEEP_LISTS=lds|global fixes the choice (tests run every case both ways).
+constexpr int SW_LEAN_BELOW = 1024;
+static int measure_list_density(pga_ctx *c)
+{
+	c->density_known = true;
+	const char *e = getenv("PANGENE_SWEEP_LISTS");
+	if (e && (strcmp(e, "lds") == 0 || strcmp(e, "global") == 0)) { c->lists_in_lds = e[0] == 'l'; return 0; }
+	const int nt = (int)nblk(c->N, SW_TILE), stride = std::max(1, nt / 256), ns = (nt + stride - 1) / stride;
+	HIPCHK(hipMemsetAsync(c->dcnt + 16, 0, sizeof(int64_t), c->st));
+	hipLaunchKernelGGL(k_list_density, dim3(ns), dim3(SW_TILE), 0, c->st, c->recA, c->recC, c->N, stride, c->dcnt + 16);
+	HIPCHK(hipMemcpyAsync(c->h_cnt + 16, c->dcnt + 16, sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
+	{ const int rc = sync_st(c); if (rc) return rc; }
+	c->lists_in_lds = c->h_cnt[16] >= (int64_t)SW_LEAN_BELOW * ns, c->list_density = (double)c->h_cnt[16] / ns, c->density_tiles = ns;
+	if (getenv("PANGENE_TIMING")) fprintf(stderr, "[pga] exon lists of the sweeps: %.0f a tile to stage (%d tiles sampled) -> %s\n", (double)c->h_cnt[16] / ns, ns, c->lists_in_lds ? "LDS (k_sweep)" : "global memory (k_sweep_lean)");
+	return 0;
+}
+
 static void pack_records(pga_ctx *c)
 {
 	if (c->N) hipLaunchKernelGGL(k_pack_rec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->seg, c->cs, c->ce, c->pm, c->rk, c->gid, c->cds, c->rank, c->nex, c->offx,
@@ -81,7 +101,8 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 		// a timed launch carries its own start/stop events: they take the dispatch's begin and end time stamps, i.e. the
 		// duration of k_sweep itself, the figure rocprofv3 --kernel-trace reports for it
 		hipEvent_t ea = timed && reps == 1 ? t.a : nullptr, eb = timed && reps == 1 ? t.b : nullptr;
-		if (c->any_multi) hipExtLaunchKernelGGL((k_sweep<MODE, true>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
+		if (c->any_multi && MODE != 0 && !c->lists_in_lds) hipExtLaunchKernelGGL((k_sweep_lean<MODE == 0 ? 1 : MODE>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
+		else if (c->any_multi) hipExtLaunchKernelGGL((k_sweep<MODE, true>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
 		else hipExtLaunchKernelGGL((k_sweep<MODE, false>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
 		hipLaunchKernelGGL((k_sweep_slow<MODE>), dim3((unsigned)std::min<int64_t>(2 * c->n_cu, std::max<int64_t>(64, nblk(c->N)))), dim3(BLOCK), 0, c->st, v, (long long *)(c->dcnt + 12 + ((c->sweep_seq + 1) & 1))); // (grid-stride over a list whose length only the device knows)
 		++c->sweep_seq;

@@ -171,6 +171,8 @@ struct pga_ctx {
 	int32_t *hrank = 0;     // [P] rank of hash(pid) + 1 (0 for a hash of 0)
 	bool any_multi = true;  // some hit has more than one exon
 	bool exon_regular = true; // every exon list is sorted and disjoint (k_prepare): the sweeps may take the shortcuts of cds_inter_t
+	double list_density = 0; int64_t density_tiles = 0; // (what k_list_density found: exons a tile, tiles sampled)
+	bool lists_in_lds = true, density_known = false; // K1 of stage A / pg_post_process stages the exon lists (k_sweep) or leaves them where they are (k_sweep_lean): by k_list_density, once per upload
 	int rp_form = 0;         // form of the (gene, genome) position records (see k_rep_fill)
 	int32_t *vfirst = 0; int64_t *vbase = 0; // virtual contigs (pga_genome_block_t), per contig segment of the shard: segment of the contig's first piece, the piece's base; NULL = no genome has any
 	int4 *recA = 0, *recB = 0, *recC = 0; // packed sweep records (derived from the arrays above, see k_pack_rec)

@@ -133,6 +133,12 @@ extern "C" int pga_timing_get(pga_ctx_t *c, int32_t which, double *total_ms, int
 		if (units) *units = 0;
 		return 0;
 	}
+	if (which == 7) { // which K1 the sweeps of stage A / pg_post_process run on this upload (measure_list_density): not a timing either
+		if (total_ms) *total_ms = c->list_density;
+		if (n_launch) *n_launch = c->density_known ? (c->lists_in_lds ? 1 : 0) : -1;
+		if (units) *units = c->density_tiles;
+		return 0;
+	}
 	TRY(sync_st(c));
 	const int only = which >> 8; // (class | (k + 1) << 8: the k-th timed launch of the class alone)
 	which &= 255;

@@ -13,7 +13,7 @@ static size_t pool_want(int64_t N, int64_t GL, int64_t P, int64_t Q, int64_t raw
 static int plan_persistent(pga_ctx *c)
 {
 	const int N = c->N, E = c->E, GL = c->n_genome;
-	TRY(dalloc(c, &c->dcnt, 16)); TRY(dalloc(c, &c->loopctl, 4));
+	TRY(dalloc(c, &c->dcnt, 24)); TRY(dalloc(c, &c->loopctl, 4));
 	// persistent arrays
 	TRY(dalloc(c, &c->fidx, N)); TRY(dalloc(c, &c->gnm, N)); TRY(dalloc(c, &c->seg, N)); TRY(dalloc(c, &c->pid, N)); TRY(dalloc(c, &c->gid, N));
 	TRY(dalloc(c, &c->cs, N)); TRY(dalloc(c, &c->ce, N)); TRY(dalloc(c, &c->cm, N)); TRY(dalloc(c, &c->cds, N)); TRY(dalloc(c, &c->nex, N));
@@ -42,9 +42,9 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		g_last_dev.store(dev);
 	}
 	c->own_stream = true;
-	c->h_cnt = (int64_t *)c->pin.get(16 * sizeof(int64_t));
+	c->h_cnt = (int64_t *)c->pin.get(24 * sizeof(int64_t));
 	if (!c->h_cnt) return PGA_ERR_NOMEM;
-	memset(c->h_cnt, 0, 16 * sizeof(int64_t));
+	memset(c->h_cnt, 0, 24 * sizeof(int64_t));
 	HIPCHK(hipHostGetDevicePointer((void **)&c->h_box, c->h_cnt, 0));
 	TRY(plan_persistent(c));
 	bool vsplit = false; // some genome arrives with virtual contigs (64-bit coordinates)
@@ -125,7 +125,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		const int pb = bits_for((uint32_t)std::max(1, c->P)), sb = bits_for(max_sadj);
 		c->rk_shift = (!neg_sadj && sb + 1 + pb <= 32 && getenv("PANGENE_RANK_BY_SORT") == nullptr) ? pb + 1 : -1;
 	}
-	c->any_multi = multi;
+	c->any_multi = multi, c->density_known = false, c->lists_in_lds = true;
 	c->ctg_bits = bits_for((uint32_t)(max_ctg - 1));
 	c->gs_np = std::max(64, (max_hit + 63) & ~63);
 	c->gs_ok = c->gs_np <= GS_NP_MAX && c->rk_shift >= 0 && getenv("PANGENE_GLOBAL_SORT") == nullptr;
@@ -362,6 +362,7 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 		uint8_t *noiso = c->gf_ok ? nullptr : (uint8_t *)c->pool.get(S_TAB_A, (size_t)TP + 16); // byte (genome, protein): the protein has a hit there without flt_iso_ov
 		if (!c->gf_ok && (!tbest || !noiso)) return PGA_ERR_NOMEM;
 		// read.c:248-254: ONE sweep for pg_shadow(cal_dom_sc=1), the reset behind it and pg_flt_ov_isoform (k_sweep<3>: they walk the same pairs)
+		if (c->any_multi && !c->density_known) TRY(measure_list_density(c));
 		c->sweep_init = true;
 		const int rc_sw = launch_sweep<3>(c, 0); // "K1", the hit-filter+overlap kernel
 		c->sweep_init = false;

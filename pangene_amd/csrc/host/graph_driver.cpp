@@ -224,7 +224,7 @@ static uint64_t genome_signature(const pg_genome_t *g)
 		x = (x ^ ((uint64_t)(uint32_t)a.pid << 32 | (uint32_t)a.cid)) * 1099511628211ull;
 		x = (x ^ (uint64_t)a.cs ^ (uint64_t)a.ce << 21 ^ (uint64_t)a.cm << 42) * 1099511628211ull;
 		x = (x ^ ((uint64_t)(uint32_t)a.score_adj << 32 | (uint32_t)a.score_ori)) * 1099511628211ull;
-		x = (x ^ ((uint64_t)(uint32_t)a.off_exon << 32 | (uint32_t)a.n_exon << 8 | (uint32_t)a.rev << 7 | (uint32_t)(a.rank & 0x7f) ^ (uint64_t)(uint32_t)a.rank << 40)) * 1099511628211ull;
+		x = (x ^ ((uint64_t)(uint32_t)a.off_exon << 32 | (uint32_t)a.n_exon << 8 | (uint32_t)a.rev << 7 | ((uint32_t)(a.rank & 0x7f) ^ (uint64_t)(uint32_t)a.rank << 40))) * 1099511628211ull;
 	}
 	for (int32_t i = 0; i < g->n_exon; ++i) { uint64_t &x = h[i & 3]; x = (x ^ ((uint64_t)(uint32_t)g->exon[i].os << 32 | (uint32_t)g->exon[i].oe)) * 0x100000001b3ull; }
 	return (h[0] * 31 + h[1]) * 31 + (h[2] * 31 + h[3]);

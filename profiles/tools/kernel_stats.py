@@ -13,10 +13,10 @@ for r in rows:
 
 # K1 (k_sweep<3, *>: stage A's fused sweep) on the shard itself: the run starts with a tiny warm-up data set (kernel loading), whose launch is left out
 try:
-    k1 = [r[0] for r in cur.execute("SELECT duration FROM kernels WHERE name LIKE '%k_sweep<3,%'").fetchall()]
+    k1 = [r[0] for r in cur.execute("SELECT duration FROM kernels WHERE name LIKE '%k_sweep<3,%' OR name LIKE '%k_sweep_lean<3>%'").fetchall()]
     if k1:
         full = [d for d in k1 if d > 0.6 * max(k1)]
-        print("# K1 k_sweep<3, *>: %d launches on the shard (of %d), mean %.2f us" % (len(full), len(k1), sum(full) / len(full) / 1e3))
+        print("# K1 k_sweep<3, *> / k_sweep_lean<3>: %d launches on the shard (of %d), mean %.2f us" % (len(full), len(k1), sum(full) / len(full) / 1e3))
 except Exception as ex:
     print("# (no K1 line: %s)" % ex)
 

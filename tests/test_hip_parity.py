@@ -110,8 +110,8 @@ def _run_with_env(tmp_path, env, mode, variant, files):
 
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
 @pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1", "PANGENE_LOOP": "nopre"},
-                                 {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1", "PANGENE_FILTERS": "global"}, {"PANGENE_LOOP": "nofinal", "PANGENE_MERGE_LITERAL": "1"},
-                                 {"PANGENE_FILTERS": "k32", "PANGENE_LOOP": "noskip"}])
+                                 {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1", "PANGENE_FILTERS": "global"}, {"PANGENE_LOOP": "nofinal", "PANGENE_MERGE_LITERAL": "1", "PANGENE_SWEEP_LISTS": "global"},
+                                 {"PANGENE_FILTERS": "k32", "PANGENE_LOOP": "noskip", "PANGENE_SWEEP_LISTS": "lds"}])
 def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
     (the path of rounds in which a hub gene overflows the per-gene LDS table).  Forcing the sort path, and shrinking the table to 4
@@ -249,6 +249,18 @@ def test_literal_merge_on_regular_lists_changes_nothing(hip, expected, tmp_path,
     if variant not in expected[name]:
         pytest.skip("no such golden variant")
     out = _run_with_env(tmp_path, {"PANGENE_MERGE_LITERAL": "1"}, 2, variant, golden_files(name))
+    assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
+
+
+@pytest.mark.parametrize("lists", ["lds", "global"])
+@pytest.mark.parametrize("name,variant", [("human8f", "-p0 -a1"), ("human8f", ""), ("human8", "-f 0.2"), ("mut1", "-S"), ("dense", ""), ("fuzz3", "-S"), ("manydoms", "-G")])
+def test_sweep_exon_lists_in_lds_or_global_same_bytes(hip, expected, tmp_path, name, variant, lists):
+    """K1 of stage A / pg_post_process comes in two builds of one body: k_sweep copies the tile's exon lists into LDS, k_sweep_lean reads them
+    where they are (more workgroups on a CU); the host picks by the measured density of overlapping hits (k_list_density).
+    PANGENE_SWEEP_LISTS fixes the choice: both give the reference's bytes on every case, whichever the density would have picked."""
+    if variant not in expected[name]:
+        pytest.skip("no such golden variant")
+    out = _run_with_env(tmp_path, {"PANGENE_SWEEP_LISTS": lists}, 2, variant, golden_files(name))
     assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
 
 
