@@ -8,6 +8,7 @@
 #   stage cal     calibration of FETCH_SIZE / WRITE_SIZE with kernels of known byte counts (profiles/tools/calibrate.py)
 #   stage full    BASELINE configs[3] / configs[4] at their full stated size on this one GPU (bench.py --workload config3 | config4)
 #   stage full4   configs[4] at full size under the profiler: kernel stats with the pass timeline, FETCH_SIZE / WRITE_SIZE per kernel, SQ counters of K1
+#   stage k1full4  only K1's FETCH_SIZE / WRITE_SIZE at configs[4]'s full size (the entry of k1_pmc_traffic.json for that shard, after an edit of k_sweep.hpp)
 #   stage full3   configs[3] at full size under the profiler (kernel stats with the pass timeline)
 #   stage ranks8  eight ranks sharing the one GPU over gloo on the configs[3] / configs[4] per-GPU shards (pytest), with the wall time
 set -u
@@ -84,6 +85,13 @@ full4)
 	rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace -d $out/prof_sq -o q -- $B1 > /dev/null 2>&1
 	python profiles/tools/pmc_summary.py $out/prof_sq "k_sweep<3" | grep -v "^dur" >> $out/${tag}_pmc_sq_k1_config4.txt 2>&1; rm -rf $out/prof_sq
 	head -n 30 $out/${tag}_kernel_stats_config4_full_size.txt | cut -c1-160; head -n 12 $out/${tag}_pmc_traffic_config4_full_size.txt | cut -c1-160; cat $out/${tag}_pmc_sq_k1_config4.txt;;
+k1full4)
+	B1="python bench.py --workload config4 --steps 1 --warmup 0"
+	$B1 > $out/${tag}_bench_config4_one_step.json 2>/dev/null
+	rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/prof_fetch -o f -- $B1 > /dev/null 2>&1
+	rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/prof_write -o w -- $B1 > /dev/null 2>&1
+	python profiles/tools/k1_traffic.py $out/prof_fetch $out/prof_write $out/${tag}_bench_config4_one_step.json > $out/k1_pmc_traffic_config4.json 2>/dev/null
+	rm -rf $out/prof_fetch $out/prof_write; cat $out/k1_pmc_traffic_config4.json;;
 full3)
 	PANGENE_TIMING=1 rocprofv3 --kernel-trace --stats -d $out/prof_c3 -o s -- python bench.py --workload config3 --steps 2 --warmup 1 > $out/${tag}_bench_config3_under_rocprof.json 2> $out/${tag}_bench_config3_under_rocprof.stderr
 	python profiles/tools/kernel_stats.py $out/prof_c3 > $out/${tag}_kernel_stats_config3_full_size.txt; rm -rf $out/prof_c3
