@@ -58,6 +58,7 @@ constexpr int SW_LEAN_BELOW = 1024;
 static int measure_list_density(pga_ctx *c)
 {
 	c->density_known = true;
+	if (c->N == 0) return 0;
 	const char *e = getenv("PANGENE_SWEEP_LISTS");
 	if (e && (strcmp(e, "lds") == 0 || strcmp(e, "global") == 0)) { c->lists_in_lds = e[0] == 'l'; return 0; }
 	const int nt = (int)nblk(c->N, SW_TILE), stride = std::max(1, nt / 256), ns = (nt + stride - 1) / stride;
