@@ -140,18 +140,31 @@ __global__ __launch_bounds__(BLOCK) void k_walk(Walk a)
 	int run = s_carry; // exclusive running maximum in front of this thread's items
 	for (int k = 0; k < w; ++k) run = run > s_wave[k] ? run : s_wave[k];
 	{ const int pv = incl.shfl_up(1).v; if (lane > 0) run = run > pv ? run : pv; }
+	// every item's predecessor first (registers only), then the records of all items in flight together, then the gene lookups of the
+	// scores, then the stores: four dependent trips to memory instead of two per item
+	int prev[WK_IPT];
+#pragma unroll
+	for (int k = 0; k < WK_IPT; ++k) { prev[k] = run; run = mark[k] >= 0 ? mark[k] : run; }
+	int4 A0[WK_IPT], A1[WK_IPT], B0[WK_IPT], B1[WK_IPT];
 #pragma unroll
 	for (int k = 0; k < WK_IPT; ++k) {
-		const int i = mark[k];
-		if (i < 0) continue;
-		const int p = run, pp = p >= 0 ? p : i;
-		run = i;
-		const int4 a0 = a.W[2 * (int64_t)i], a1 = a.W[2 * (int64_t)i + 1], b0 = a.W[2 * (int64_t)pp], b1 = a.W[2 * (int64_t)pp + 1];
+		const int i = mark[k] >= 0 ? mark[k] : 0, pp = prev[k] >= 0 ? prev[k] : i;
+		if (mark[k] >= 0) A0[k] = a.W[2 * (int64_t)i], A1[k] = a.W[2 * (int64_t)i + 1], B0[k] = a.W[2 * (int64_t)pp], B1[k] = a.W[2 * (int64_t)pp + 1];
+	}
+	int SA[WK_IPT], SB[WK_IPT];
+#pragma unroll
+	for (int k = 0; k < WK_IPT; ++k)
+		if (mark[k] >= 0 && prev[k] >= 0 && B0[k].x == A0[k].x) SA[k] = walk_score(A0[k], A1[k], a.ori, a.g2s), SB[k] = walk_score(B0[k], B1[k], a.ori, a.g2s);
+#pragma unroll
+	for (int k = 0; k < WK_IPT; ++k) {
+		if (mark[k] < 0) continue;
+		const int p = prev[k];
+		const int4 a0 = A0[k], a1 = A1[k], b0 = B0[k], b1 = B1[k];
 		const int zi = a1.z, zp = b1.z;
 		uint32_t key = a.tag << HA_TAG_SHIFT | HA_NONE;
 		if (p >= 0 && b0.x == a0.x) { // same contig: adjacency p -> i (graph.c:113-121)
 			const uint32_t wv = (uint32_t)a0.y, v = (uint32_t)b0.y;
-			const int sa = walk_score(a0, a1, a.ori, a.g2s), sb = walk_score(b0, b1, a.ori, a.g2s), d = (int)((unsigned)a0.z - (unsigned)b0.z); // (low words of 64-bit coordinates when the shard has virtual contigs)
+			const int sa = SA[k], sb = SB[k], d = (int)((unsigned)a0.z - (unsigned)b0.z); // (low words of 64-bit coordinates when the shard has virtual contigs)
 			if (a0.z == b0.z) { atomicAdd((unsigned long long *)&a.dcnt[5], 1ull); hz_note(&a.dcnt[14], a.hz_list, a0.x); } // hazard H2a: equal cm
 			a.hfk[zp] = a.tag << HA_TAG_SHIFT | wv, a.hfp[zp] = make_int4(d, sb, sa, 0); // v -> w,     s1 = score(v), s2 = score(w) (graph.c:117)
 			key = a.tag << HA_TAG_SHIFT | (v ^ 1u), a.hbp[zi] = make_int4(d, sa, sb, 0); // w^1 -> v^1, s1 = score(w), s2 = score(v) (graph.c:119)
@@ -297,7 +310,8 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 					}
 				}
 				if (!leader) continue;
-				const int4 h = dir ? a.hbp[z] : a.hfp[z]; // the payload: distance and the two scores
+				const int4 h = dir ? a.hbp[z] : a.hfp[z]; // the payload: distance and the two scores (tried: asked for with the staged words, by the thread
+				// that will evaluate the hit -- one trip to memory less per workgroup, but every hit's payloads instead of the walkable leaders': 48 -> 52 us)
 				int m1 = h.y, m2 = h.z;
 				unsigned long long sd = (unsigned long long)(long long)h.x;
 				if (n > 1) // rare: the same adjacency twice in one genome
@@ -375,21 +389,24 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 	return true;
 }
 
-// one workgroup per gene: at the usual sizes (a few hundred hits of a gene in the shard) its 256 threads see every hit in one go
-__global__ __launch_bounds__(BLOCK) void k_gene_arcs_wave(GeneArcs a)
+// one workgroup per gene: at the usual sizes (a few hundred hits of a gene in the shard) its threads see every hit in one or two goes
+// (128 threads: a workgroup is a chain of dependent loads whatever its width, and a CU holds 14 of these against 8 of 256 threads -- a shard of
+// 20 000 genes x 137 hits 218 -> 170 us, configs[1] 49.6 -> 47.9; one wave a gene, which the CU holds no more of -- the LDS tables -- 62)
+constexpr int GA_WAVE_NT = 128;
+__global__ __launch_bounds__(GA_WAVE_NT) void k_gene_arcs_wave(GeneArcs a)
 {
 	__shared__ GeneTable<GA_CAP_WAVE, GA_WAVE_HITS> T;
 	if (gate_closed(a.gate)) return;
 	const int g = blockIdx.x, tid = threadIdx.x;
 	const int sid = a.g2s[g], z0 = a.zoff[g], z1 = a.zoff[g + 1];
 	if (sid < 0) { // not a vertex: none of its hits may be walkable (graph.c:111)
-		for (int z = z0 + tid; z < z1; z += BLOCK)
+		for (int z = z0 + tid; z < z1; z += GA_WAVE_NT)
 			if (hx_walk(a.hbk[z], a.tag)) atomicAdd((unsigned long long *)&a.dcnt[3], 1ull), a.dcnt[11] = 1; // ([11]: sticky, for rounds nobody looks at one by one: pga_branch_loop)
 		if (tid == 0) a.big_list[g] = 0;
 		return;
 	}
 	const int cl = a.cap_log2 < 7 ? a.cap_log2 : 7;
-	const bool done = z1 - z0 <= GA_WAVE_HITS && gene_arcs_one<BLOCK, GA_CAP_WAVE, GA_WAVE_HITS>(a, T, g, sid, tid, cl);
+	const bool done = z1 - z0 <= GA_WAVE_HITS && gene_arcs_one<GA_WAVE_NT, GA_CAP_WAVE, GA_WAVE_HITS>(a, T, g, sid, tid, cl);
 	if (tid == 0) a.big_list[g] = done ? 0 : 1; // many hits, or many neighbours: the second kernel takes it
 }
 
