@@ -102,7 +102,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_wrec_list(WrecSrc s, const int32
 // walkable hit of a position is the running maximum of the walkable marks before it; what a tile needs from the tiles in front of it is
 // ONE number, the last walkable position before its first, and with walkable hits every few positions that is a glance backwards
 // (wave 0 looks at 64 positions at a time while the other waves load the tile's own flags), not a scan.
-constexpr int WK_IPT = 4, WK_TILE = BLOCK * WK_IPT;
+constexpr int WK_IPT = 1, WK_TILE = BLOCK * WK_IPT; // (positions a thread: 8 / 4 / 2 / 1 -> 277 / 246 / 227 / 214 us at 12.1 M hits, 31 / 27 / 25 / 23 us at 955 k -- more workgroups in flight beat fewer carries)
 struct Walk {
 	const uint32_t *__restrict__ flags; const int32_t *__restrict__ yperm; const int4 *__restrict__ W; const int32_t *__restrict__ g2s;
 	uint32_t *__restrict__ hfk, *__restrict__ hbk; int4 *__restrict__ hfp, *__restrict__ hbp; // key word / payload {distance, score of this hit, score of the other, 0} of the two half-arcs
