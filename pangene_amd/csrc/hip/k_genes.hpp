@@ -410,7 +410,10 @@ __global__ __launch_bounds__(GA_WAVE_NT) void k_gene_arcs_wave(GeneArcs a)
 	if (tid == 0) a.big_list[g] = done ? 0 : 1; // many hits, or many neighbours: the second kernel takes it
 }
 
-__global__ __launch_bounds__(BLOCK) void k_gene_arcs_big(GeneArcs a)
+// (512 threads a gene: the LDS tables allow three of these workgroups on a CU whatever their width -- 12 waves of 256 threads, 24 of 512; 328 -> 258 us
+// at 12.1 M hits, where every gene comes here; 1 024 threads: two workgroups a CU, 305 us; a shard that sends nothing here pays 1-4 us more for the empty pass)
+constexpr int GA_BIG_NT = 512;
+__global__ __launch_bounds__(GA_BIG_NT) void k_gene_arcs_big(GeneArcs a)
 {
 	__shared__ GeneTable<GA_CAP, GA_BIG_STAGE> T;
 	if (gate_closed(a.gate)) return;
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(BLOCK) void k_gene_arcs_big(GeneArcs a)
 	for (int g = blockIdx.x; g < a.Q; g += gridDim.x) { // the genes the wave kernel left (a flag per gene: no list, no counter)
 		if (!a.big_list[g]) continue;
 		const int sid = a.g2s[g];
-		if (!gene_arcs_one<BLOCK, GA_CAP, GA_BIG_STAGE>(a, T, g, sid, threadIdx.x, a.cap_log2) && threadIdx.x == 0) // a hub gene: this round is redone on the sort path
+		if (!gene_arcs_one<GA_BIG_NT, GA_CAP, GA_BIG_STAGE>(a, T, g, sid, threadIdx.x, a.cap_log2) && threadIdx.x == 0) // a hub gene: this round is redone on the sort path
 			atomicAdd((unsigned long long *)&a.dcnt[9], 1ull), a.dcnt[11] = 1, a.gmeta[sid] = make_int4(0, 0, 0, 0); // (the whole round is repeated: nothing else to leave behind)
 		__syncthreads();
 	}

@@ -128,7 +128,7 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	GeneArcs ga = { c->zy, c->zoff, c->hfk, c->hbk, c->hfp, c->hbp, c->g2s, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta,
 	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt, c->gate, c->gate.w ? c->loopctl + 2 : (int32_t *)nullptr };
 	hipLaunchKernelGGL(k_gene_arcs_wave, dim3((unsigned)c->Q), dim3(GA_WAVE_NT), 0, c->st, ga);
-	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 8 * c->n_cu)), dim3(BLOCK), 0, c->st, ga);
+	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 8 * c->n_cu)), dim3(GA_BIG_NT), 0, c->st, ga);
 	if (c->timing_rounds) time_mark(c, &tr, 5, true);
 	if (mail) hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box, h_round_dev ? h_round_dev + 4 * (size_t)S : (int32_t *)nullptr); // invariant / overflow counters for the host; the overflow counter starts again
 	return 0;
