@@ -102,7 +102,10 @@ __global__ __launch_bounds__(BLOCK) void k_pack_wrec_list(WrecSrc s, const int32
 // walkable hit of a position is the running maximum of the walkable marks before it; what a tile needs from the tiles in front of it is
 // ONE number, the last walkable position before its first, and with walkable hits every few positions that is a glance backwards
 // (wave 0 looks at 64 positions at a time while the other waves load the tile's own flags), not a scan.
-constexpr int WK_IPT = 1, WK_TILE = BLOCK * WK_IPT; // (positions a thread: 8 / 4 / 2 / 1 -> 277 / 246 / 227 / 214 us at 12.1 M hits, 31 / 27 / 25 / 23 us at 955 k -- more workgroups in flight beat fewer carries)
+// Positions a thread (WK_IPT): 8 / 4 / 2 / 1 -> 277 / 246 / 227 / 214 us at 12.1 M hits, 31 / 27 / 25 / 23 us at 955 k -- more workgroups in flight beat
+// fewer carries --, but at 96.6 M hits (configs[3] on one GPU: rounds in which few hits are walkable, so the look backwards for the carry is
+// most of a workgroup's work) one position a thread took 891 us a launch where four take 439.  The host picks by the shard's size (WK_FEW_FROM).
+constexpr int WK_FEW_FROM = 1 << 25; // hits from which a thread takes four positions
 struct Walk {
 	const uint32_t *__restrict__ flags; const int32_t *__restrict__ yperm; const int4 *__restrict__ W; const int32_t *__restrict__ g2s;
 	uint32_t *__restrict__ hfk, *__restrict__ hbk; int4 *__restrict__ hfp, *__restrict__ hbp; // key word / payload {distance, score of this hit, score of the other, 0} of the two half-arcs
@@ -112,8 +115,10 @@ __device__ __forceinline__ int walk_score(const int4 w0, const int4 w1, int ori,
 { // pg_get_score, graph.c:82-85: score_ori unless the dominator's gene is not a vertex and score_dom is at least as large
 	return (ori || w0.w > w1.x || w1.y < 0 || g2s[w1.y] >= 0) ? w0.w : w1.x;
 }
+template <int WK_IPT>
 __global__ __launch_bounds__(BLOCK) void k_walk(Walk a)
 {
+	constexpr int WK_TILE = BLOCK * WK_IPT;
 	__shared__ int32_t s_wave[BLOCK / WAVE], s_carry;
 	if (gate_closed(a.gate)) return;
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

@@ -80,7 +80,9 @@ static int ensure_half_arcs(pga_ctx *c, int use_ori)
 	int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
 	if (!hzl) return PGA_ERR_NOMEM;
 	TimedLaunch tw; if (c->timing_rounds) time_mark(c, &tw, 6, false);
-	hipLaunchKernelGGL(k_walk, dim3(nblk(c->N, WK_TILE)), dim3(BLOCK), 0, c->st, Walk{c->flags, c->yperm, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->N, c->dcnt, hzl, c->gate});
+	const Walk wk = {c->flags, c->yperm, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->N, c->dcnt, hzl, c->gate};
+	if (c->N >= WK_FEW_FROM) hipLaunchKernelGGL(k_walk<4>, dim3(nblk(c->N, BLOCK * 4)), dim3(BLOCK), 0, c->st, wk);
+	else hipLaunchKernelGGL(k_walk<1>, dim3(nblk(c->N, BLOCK)), dim3(BLOCK), 0, c->st, wk);
 	if (c->timing_rounds) time_mark(c, &tw, 6, true);
 	c->ha_valid = true, c->ha_ori = use_ori;
 	return 0;
