@@ -757,6 +757,7 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 		BE_CALL(be->fetch(ctx, sm.data(), b_sum, sizeof(int64_t) * (size_t)P * 6), "fetch");
 		std::memcpy(mx.data(), mx_view, sizeof(int32_t) * (size_t)P);
 	}
+	const double tp0 = now_sec();
 	// pg_cap_score_dom's table (hit.c:230-238) and pg_flag_representative's protein part (hit.c:205-217)
 	std::vector<pg128_t> z((size_t)P);
 	for (int32_t i = 0; i < d->n_gene; ++i) d->gene[i].rep_pid = -1;
@@ -785,6 +786,7 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 			pj[(size_t)i] = a || b;
 		}
 	}
+	if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[post] host step between the fetch of the protein sums and post_apply: %.3f ms (%d proteins)\n", (now_sec() - tp0) * 1e3, P);
 	int64_t n_pj = 0;
 	BE_CALL(be->post_apply(ctx, rep.data(), pj.data(), (!(opt->flag & PG_F_NO_JOINT_PSEUDO) && pg_verbose >= 3) ? &n_pj : nullptr), "post_apply");
 	if (!(opt->flag & PG_F_NO_JOINT_PSEUDO) && pg_verbose >= 3)
@@ -1051,13 +1053,21 @@ static int fetch_arcs(pg_graph_t *q, DataExt *ext)
 		BE_CALL(ext->be->arc_table(ext->ctx, &ext->cur_arcs, &n), "arc_table");
 		q->n_arc = (int32_t)n;
 	}
-	std::vector<pga_arc_part_t> part((size_t)q->n_arc);
-	if (q->n_arc) BE_CALL(ext->be->fetch(ext->ctx, part.data(), ext->cur_arcs, sizeof(pga_arc_part_t) * part.size()), "fetch");
-	if ((int64_t)part.size() > q->m_arc) {
-		q->m_arc = (int32_t)part.size() + ((int32_t)part.size() >> 1) + 16;
+	// read where the backend lands it (its pinned staging area: fetch_later + one wait), not out of a zeroed vector the table was copied
+	// into -- configs[1]'s 46 k arcs are 2.2 MB, just beyond what pga_fetch stages, and went to pageable memory by the runtime's slow path
+	const pga_arc_part_t *part = nullptr;
+	const size_t n_part = (size_t)q->n_arc;
+	if (n_part) {
+		const void *view = nullptr;
+		BE_CALL(ext->be->fetch_later(ext->ctx, ext->cur_arcs, sizeof(pga_arc_part_t) * n_part, &view), "fetch_later");
+		BE_CALL(ext->be->sync(ext->ctx), "sync");
+		part = (const pga_arc_part_t *)view;
+	}
+	if ((int64_t)n_part > q->m_arc) {
+		q->m_arc = (int32_t)n_part + ((int32_t)n_part >> 1) + 16;
 		q->arc = (pg_arc_t *)std::realloc(q->arc, sizeof(pg_arc_t) * (size_t)q->m_arc);
 	}
-	for (size_t i = 0; i < part.size(); ++i) {
+	for (size_t i = 0; i < n_part; ++i) {
 		pg_arc_t *p = &q->arc[i];
 		std::memset(p, 0, sizeof(*p));
 		p->x = part[i].x, p->n_genome = part[i].n_genome, p->tot_cnt = part[i].tot_cnt;
