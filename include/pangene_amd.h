@@ -256,7 +256,9 @@ int pg_rerun_resident(pg_data_t *d);
 /* HIP-event timing of kernel classes of the runs since the last pg_kernel_timing_reset (which also switches the
  * timing on): which 0 = stage-A sweep pg_shadow(cal_dom_sc=1) ("K1", the hit-filter+overlap kernel), 1 = pg_flt_ov_isoform
  * sweep, 2 = (not timed any more: the stage-C sweeps), 3 = all of stage A (sorts, per-hit constants, pg_flag_pseudo, sweeps, filters),
- * 4 = no kernel class: n_launch = the number of times the host waited for the backend's stream since the reset. */
+ * 4 = no kernel class: n_launch = the number of times the host waited for the backend's stream since the reset; 5 / 6 (with PANGENE_TIME_ROUNDS=1 at
+ * the reset) = every pg_gen_arc round / its walk alone, which | (k + 1) << 8 = the k-th timed launch of the class alone; 7 = no timing: which
+ * build of K1 the upload got (n_launch 1 = exon lists staged in LDS, 0 = read in place, -1 = not decided), total_ms = the sampled exons a tile. */
 int pg_kernel_timing(pg_data_t *d, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
 double pg_last_reserve_seconds(void); /* what the last pg_read_paf_batch spent reserving device memory before it parsed (large data sets: pga_reserve) */
 int pg_kernel_timing_reset(pg_data_t *d);
