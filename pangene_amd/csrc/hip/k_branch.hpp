@@ -36,19 +36,24 @@ constexpr int RP_FULL = 0, RP_COMPACT = 1, RP_WIDE = 2;
 // table iv[] in the compact form); k_n_local raises the hazard where it matters.  Two walkable hits of ONE gene in a group
 // (-S: opposite strands) make the choice of the representative itself order-dependent (branch.c:22-23): hazard at once.
 struct RepFill {
-	int64_t n_ent; int GL, Q, N; const int32_t *zx, *zy, *zg; const int2 *zst; const int32_t *zoff; const uint32_t *hbk; uint32_t tag;
+	int64_t n_ent; int GL, Q, N /* hits of the shard (X positions) */, NZ /* entries of the gene-major index: N, or the members of the live lists */; const int32_t *zx, *zy, *zg; const int2 *zst; const int32_t *zoff; const uint32_t *hbk; uint32_t tag;
 	const int4 *A; const int32_t *gid; const uint32_t *flags; const int32_t *rx, *goff, *ctg_base;
 	void *rp_out; int32_t *iv; int64_t *dcnt; int32_t *hz_list;
 	const int32_t *vfirst; const int64_t *vbase; // [contig segments] of the shard (RP_WIDE only)
 	Gate gate;
 };
 
+// every record "absent" first, as one coalesced fill (round 6).  Rounds 3-5 had the last hit of every (gene, genome) group write the absent records of
+// the genomes up to the next group, one thread in a loop -- nothing was cleared, nothing written twice; but once the index holds the live hits
+// only, a gene that lost its vertex has no entry at all and ONE thread wrote the records of all its genomes: 1 250 scattered stores in a row
+// for each of 2 673 genes of the 12.1 M-hit shard, the kernel 0.19 -> ~1 ms.  The fill is 50 MB there: ~15 us.
 template <int FORM>
-__device__ __forceinline__ void rep_absent(const RepFill &a, int64_t e0, int n)
+__global__ __launch_bounds__(BLOCK) void k_rep_clear(void *rp_out, int64_t n_ent, Gate gate)
 {
-	for (int k = 0; k < n; ++k) {
-		if (FORM == RP_COMPACT) ((int2 *)a.rp_out)[e0 + k] = make_int2(0, -1); else ((int4 *)a.rp_out)[e0 + k] = make_int4(-1, 0, 0, 0);
-	}
+	if (gate_closed(gate)) return;
+	const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (e >= n_ent) return;
+	if (FORM == RP_COMPACT) ((int2 *)rp_out)[e] = make_int2(0, -1); else ((int4 *)rp_out)[e] = make_int4(-1, 0, 0, 0);
 }
 
 template <int FORM>
@@ -56,29 +61,26 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 {
 	if (gate_closed(a.gate)) return;
 	const int t = blockIdx.x * BLOCK + threadIdx.x;
-	if (t < a.Q && a.zoff[t] == a.zoff[t + 1]) rep_absent<FORM>(a, (int64_t)t * a.GL, a.GL); // a gene without hits in this shard
-	if (t >= a.N) return;
+	if (t >= a.NZ) return;
 	const int z = t;
 	// the loads are issued in as few dependent rounds as possible, from 4-byte planes in gene-major order (the kernel is bound by
 	// latency and sectors, not by arithmetic): round 1 = genome / gene of z and of its two neighbours, z's walkable mark
 	const int g = a.zg[z], y = a.zy[z] & 0x7fffffff, j = y >> 1;
-	const bool has_n = z + 1 < a.N, has_p = z > 0;
-	const int gn = has_n ? a.zg[z + 1] : -1, yn = has_n ? (a.zy[z + 1] & 0x7fffffff) : 0, gp = has_p ? a.zg[z - 1] : -1, yp = has_p ? (a.zy[z - 1] & 0x7fffffff) : 0;
+	const bool has_n = z + 1 < a.NZ;
+	const int gn = has_n ? a.zg[z + 1] : -1, yn = has_n ? (a.zy[z + 1] & 0x7fffffff) : 0;
 	const uint32_t kb = a.hbk[z];
 	if (gn == g && (yn >> 1) == j) return; // not the last hit of its (gene, genome) group
 	// round 2: everything that hangs on the gene, the genome or the hit itself
 	const int z0 = a.zoff[g], gj = a.goff[j], cb = a.ctg_base[j], xz = a.zx[z];
 	const int2 st_z = a.zst[z]; // {cm, contig segment}
 	const int64_t e = (int64_t)g * a.GL + j;
-	// the genomes without a hit of this gene: before the first group, and between this group and the next
-	int gs = z;
-	if (gp == g && (yp >> 1) == j) { gs = z - 1; while (gs > z0 && ((a.zy[gs - 1] & 0x7fffffff) >> 1) == j) --gs; }
-	if (gs == z0 && j > 0) rep_absent<FORM>(a, (int64_t)g * a.GL, j);
-	const int jn = gn == g ? (yn >> 1) : a.GL;
-	if (jn > j + 1) rep_absent<FORM>(a, e + 1, jn - j - 1);
+	// (the records of the genomes without a hit of this gene, and of the groups without a walkable hit, are "absent" already: k_rep_clear)
 	int q = z;
-	if (!hx_walk(kb, a.tag)) { q = z - 1; while (q >= gs && !hx_walk(a.hbk[q], a.tag)) --q; } // the group's last walkable hit
-	if (q < gs) { rep_absent<FORM>(a, e, 1); return; }
+	if (!hx_walk(kb, a.tag)) { // the group's last walkable hit
+		q = z - 1;
+		while (q >= z0 && ((a.zy[q] & 0x7fffffff) >> 1) == j && !hx_walk(a.hbk[q], a.tag)) --q;
+		if (q < z0 || ((a.zy[q] & 0x7fffffff) >> 1) != j) return;
+	}
 	const int h = q == z ? xz : a.zx[q];
 	const int2 st = q == z ? st_z : a.zst[q];
 	// round 3: the one gather into cs order -- the hit's rank among the walkable hits (and the rank at the genome's start)

@@ -32,6 +32,34 @@ __global__ __launch_bounds__(BLOCK) void k_zkey(const int32_t *gid, int n, uint6
 	if (h < n) key[h] = (uint64_t)(uint32_t)gid[h], val[h] = (uint32_t)h;
 }
 
+// LIVE LISTS (pga_ctx::live_on): the index and the walk's list over the hits that are not filtered when they are built.  One scan over the X order
+// marks the members (F_MEMBER travels with the hit from then on) and numbers them (lx[x] = members before x, lx[n] = their number), a second one
+// over the cm order writes their X positions in that order (ylist); the sort keys of the index are emitted for members only.
+struct InLiveX { const uint32_t *flags; __device__ __forceinline__ I32 operator()(int64_t i) const { return I32{(flags[i] & PGA_F_FLT) ? 0 : 1}; } };
+struct OutLiveX {
+	uint32_t *flags; int32_t *lx; const int32_t *gid; uint64_t *key; uint32_t *val; int64_t n;
+	__device__ __forceinline__ void operator()(int64_t i, I32 in, I32 ex) const
+	{
+		const uint32_t f = flags[i], nf = (f & PGA_F_FLT) ? (f & ~F_MEMBER) : (f | F_MEMBER);
+		if (nf != f) flags[i] = nf;
+		lx[i] = ex.v;
+		if (!(f & PGA_F_FLT)) key[ex.v] = (uint64_t)(uint32_t)gid[i], val[ex.v] = (uint32_t)i;
+		if (i == n - 1) lx[n] = in.v;
+	}
+};
+struct InLiveY { const uint32_t *flags; const int32_t *yperm; __device__ __forceinline__ I32 operator()(int64_t y) const { return I32{(flags[yperm[y]] & PGA_F_FLT) ? 0 : 1}; } };
+struct OutLiveY {
+	const uint32_t *flags; const int32_t *yperm; int32_t *ylist;
+	__device__ __forceinline__ void operator()(int64_t y, I32, I32 ex) const { const int x = yperm[y]; if (!(flags[x] & PGA_F_FLT)) ylist[ex.v] = x; }
+};
+// the members' number for the host (dcnt[10]) with the other counters
+__global__ void k_mail_live(const int32_t *lx, int64_t n, int64_t *dcnt, int64_t *host_box)
+{
+	if (threadIdx.x == 0) dcnt[10] = lx[n];
+	__syncthreads();
+	if (threadIdx.x < 16) sys_store(&host_box[threadIdx.x], dcnt[threadIdx.x]);
+}
+
 // The gene-major index as separate 4-byte planes (each kernel reads only the planes it needs):
 //   zx[z] = X position; zy[z] = local genome << 1 | rev, bit 31 = the only hit of its gene in its genome (nearly all are: the
 //   group logic of the gene kernels has nothing to do for it); zg[z] = gene; zst[z] = {cm, contig segment} (static);  zpos[x] = z
@@ -92,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_wrec(WrecSrc s, int n, int4 *W)
 __global__ __launch_bounds__(BLOCK) void k_pack_wrec_list(WrecSrc s, const int32_t *pos, int64_t T, int4 *W)
 {
 	const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (t < T) pack_wrec_one(s, pos[t], W);
+	if (t < T && pos[t] >= 0) pack_wrec_one(s, pos[t], W); // (< 0: a listed hit that is not in the live lists)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -188,6 +216,7 @@ __global__ __launch_bounds__(BLOCK) void k_walk_list(Walk a, const int32_t *pos,
 	const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (t >= T) return;
 	const int i = pos[t];
+	if (i < 0) return; // a listed hit that is not in the live lists
 	auto walkable = [&](int y) { return !(a.flags[a.yperm[y]] & (PGA_F_FLT | PGA_F_SHADOW)); };
 	const int4 a0 = a.W[2 * (int64_t)i], a1 = a.W[2 * (int64_t)i + 1];
 	const int zi = a1.z;

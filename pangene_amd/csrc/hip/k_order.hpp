@@ -26,10 +26,33 @@ __global__ __launch_bounds__(BLOCK) void k_to_file(const int32_t *fidx, const in
 // the override's own position list): an isoform-rich shard overrides a million hits of twenty-two 67 times a pass, and eight
 // shard-wide kernels per override were 110 of the 163 ms of its pass.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_ov_sety(const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv, int32_t *yperm)
+__global__ __launch_bounds__(BLOCK) void k_ov_sety(const int32_t *ov_pos, const int32_t *ov_file, int64_t t, const int32_t *inv, int32_t *yperm, const int32_t *lpos /* or NULL */, int32_t *ylist)
 {
 	int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i < t) yperm[ov_pos[i]] = inv[ov_file[i]];
+	if (i >= t) return;
+	const int x = inv[ov_file[i]];
+	yperm[ov_pos[i]] = x;
+	if (lpos && lpos[i] >= 0) ylist[lpos[i]] = x; // the members' list in cm order follows
+}
+
+// With live lists (pga_ctx::live_on) an override also has to be told in the lists' coordinates.  A contig keeps its index range in both orders
+// and the same members, so its stretch of the members' list starts at lx[first position of the contig] in either order, and the k-th listed hit
+// that is a member takes the place (members listed before it in its contig) behind that: a scan over the override's list.  lpos[k] = that
+// place, or -1 for a hit that is not a member.  ov_first[k] = the list index of the first entry of k's contig.
+struct InOvMember { const uint32_t *flags; const int32_t *inv, *ov_file; __device__ __forceinline__ I32 operator()(int64_t k) const { return I32{(flags[inv[ov_file[k]]] & F_MEMBER) ? 1 : 0}; } };
+__global__ __launch_bounds__(BLOCK) void k_ovl_pos(const int32_t *ex, const uint32_t *flags, const int32_t *inv, const int32_t *ov_pos, const int32_t *ov_file, const int32_t *ov_first, int64_t t, const int32_t *lx, int32_t *lpos)
+{
+	const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (k >= t) return;
+	const int f = ov_first[k];
+	lpos[k] = (flags[inv[ov_file[k]]] & F_MEMBER) ? lx[ov_pos[f]] + (ex[k] - ex[f]) : -1;
+}
+// after a cs override: the entries of the members' cm-order list that lie in the overridden contigs (every place of those stretches is some
+// lpos[k]) hold X positions inside those contigs, which were renumbered
+__global__ __launch_bounds__(BLOCK) void k_ovl_remap_ylist(int32_t *ylist, const int32_t *lpos, int64_t t, const int32_t *remap)
+{
+	const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (k < t && lpos[k] >= 0) ylist[lpos[k]] = remap[ylist[lpos[k]]];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_inv_only(const int32_t *fidx, const int32_t *gnm, const int32_t *goff, int n, int32_t *inv)
@@ -76,7 +99,7 @@ __global__ __launch_bounds__(BLOCK) void k_ov_scatter(PermArrays p, const int32_
 	if (i >= t) return;
 	int pos = ov_pos[i];
 	inv[ov_file[i]] = pos; // (k_ov_gather, the launch before, was the last reader of the old entries)
-	if (zpos) { const int z = tmp[(int64_t)(OV_PLANES + 12) * t + i]; zx[z] = pos, zpos[pos] = z; }
+	if (zpos) { const int z = tmp[(int64_t)(OV_PLANES + 12) * t + i]; zpos[pos] = z; if (z >= 0) zx[z] = pos; } // (z < 0: not in the index -- live lists)
 #pragma unroll
 	for (int k = 0; k < OV_PLANES; ++k) {
 		int32_t v = tmp[(int64_t)k * t + i];

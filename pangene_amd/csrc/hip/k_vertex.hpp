@@ -6,11 +6,15 @@
 // pg_gen_vtx, per-genome part (vertex.c:28-51)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_vtx1(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *pdom,
-                                                  int n, int Q, int32_t *cnt, uint32_t *dombits, int64_t words_per_genome, int64_t *dcnt)
+                                                  int n, int Q, int32_t *cnt, uint32_t *dombits, int64_t words_per_genome, int64_t *dcnt, int64_t *live_cnt)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
+	const uint32_t f = h < n ? flags[h] : (uint32_t)PGA_F_FLT;
+	if (live_cnt) { // the hits that are not filtered (one atomic a wave, spread over LIVE_CNT_N words) -- what the rounds behind this step still have to look at (ensure_z)
+		const unsigned long long live = __ballot(!(f & PGA_F_FLT));
+		if (live && (threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&live_cnt[(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) & (LIVE_CNT_N - 1)], (unsigned long long)__popcll(live));
+	}
 	if (h >= n) return;
-	uint32_t f = flags[h];
 	if ((f & PGA_F_FLT) || rank[h] != 0) return;
 	int g = gid[h];
 	if (f & PGA_F_SHADOW) {
@@ -80,12 +84,31 @@ __global__ __launch_bounds__(BLOCK) void k_vtx_compact(const int32_t *dom_tab, c
 	}
 }
 
-__global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32_t *gid, int n, const int32_t *g2s, int then_filter, Gate gate = Gate{nullptr, 0}) // graph.c:61-69 (+ PG_SET_FILTER(vtx == 0))
+// live_cnt (or NULL): += the hits that are not filtered afterwards (one atomic a wave): pga_branch_loop asks now and then whether the live lists are worth building again
+__global__ __launch_bounds__(BLOCK) void k_flag_vtx(uint32_t *flags, const int32_t *gid, int n, const int32_t *g2s, int then_filter, Gate gate = Gate{nullptr, 0}, int64_t *live_cnt = nullptr) // graph.c:61-69 (+ PG_SET_FILTER(vtx == 0))
 {
 	if (gate_closed(gate)) return;
 	int h = blockIdx.x * BLOCK + threadIdx.x;
-	if (h >= n) return;
-	uint32_t f = flags[h], nf = g2s[gid[h]] >= 0 ? (f | PGA_F_VTX) : (f & ~PGA_F_VTX);
-	if (then_filter && !(nf & PGA_F_VTX)) nf |= PGA_F_FLT;
-	if (nf != f) flags[h] = nf;
+	uint32_t nf = PGA_F_FLT;
+	if (h < n) {
+		const uint32_t f = flags[h];
+		nf = g2s[gid[h]] >= 0 ? (f | PGA_F_VTX) : (f & ~PGA_F_VTX);
+		if (then_filter && !(nf & PGA_F_VTX)) nf |= PGA_F_FLT;
+		if (nf != f) flags[h] = nf;
+	}
+	if (live_cnt) {
+		const unsigned long long live = __ballot(!(nf & PGA_F_FLT));
+		if (live && (threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&live_cnt[(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) & (LIVE_CNT_N - 1)], (unsigned long long)__popcll(live));
+	}
+}
+// dcnt[8] = the sum of the partial counts
+__global__ __launch_bounds__(BLOCK) void k_live_sum(const int64_t *live_cnt, int64_t *dcnt)
+{
+	__shared__ long long part[BLOCK / WAVE];
+	long long s = 0;
+	for (int i = threadIdx.x; i < LIVE_CNT_N; i += BLOCK) s += live_cnt[i];
+	s = (long long)wave_sum64((unsigned long long)s);
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) { long long t = 0; for (int k = 0; k < BLOCK / WAVE; ++k) t += part[k]; dcnt[8] = t; }
 }

@@ -55,6 +55,7 @@ static bool poison_on() { static const bool f = getenv("PANGENE_POISON") != null
 #define F_HEAD 0x80000000u   // static: first hit of its genome in X order (index-0 quirk, overlap.c:108)
 #define F_MULTI 0x40000000u  // static: the hit has more than one exon (lets the sweep skip the exon records)
 #define F_CSTIE 0x20000000u  // static: an X-order neighbour shares (contig, cs) -- member of a tie group of the cs sort (hazard H2b; set by k_pack_rec)
+#define F_MEMBER 0x10000000u // the hit is in the live lists (pga_ctx::live_on): it was not filtered when they were built; travels with the hit through order overrides
 #define F_PUBLIC 0x7ffu
 
 #include "pga_host_context.hpp"

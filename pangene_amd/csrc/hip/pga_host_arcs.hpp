@@ -36,6 +36,8 @@ static int walk_prev(pga_ctx *c, int32_t **val_out, int32_t **prev_out)
 }
 
 // gene-major index: hits sorted by (gene, X position) -- X order is genome-major, so a gene's hits are grouped by genome
+// known_live >= 0: the caller has just counted the hits without flt (and nothing was filtered since): the live lists are built, without a wait
+static int build_z(pga_ctx *c, int64_t known_live);
 static int ensure_z(pga_ctx *c)
 {
 	if (c->N == 0) return 0;
@@ -43,15 +45,38 @@ static int ensure_z(pga_ctx *c)
 		if (c->zposy_stale) c->wrec_valid = false, c->zposy_stale = false, c->ha_valid = false;
 		return 0;
 	}
+	return build_z(c, -1);
+}
+static int build_z(pga_ctx *c, int64_t known_live)
+{
 	const int N = c->N;
 	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, 0);
 	uint32_t *val = (uint32_t *)c->pool.get(S_VAL_A, 0);
 	if (!key || !val) return PGA_ERR_NOMEM;
-	hipLaunchKernelGGL(k_zkey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gid, N, key, val);
-	uint64_t *ks; uint32_t *vs;
-	TRY(radix_sort_pool(c, key, val, N, bits_for((uint32_t)std::max(1, c->Q)), &ks, &vs));
-	hipLaunchKernelGGL(k_zrec, dim3(nblk(N)), dim3(BLOCK), 0, c->st, vs, ks, c->ctg_base, c->n_genome, c->flags, c->cm, c->seg, N, ZIndex{c->zx, c->zy, c->zg, c->zst, c->zpos});
-	hipLaunchKernelGGL(k_zoff, dim3(nblk(c->Q + 1)), dim3(BLOCK), 0, c->st, ks, N, c->Q, c->zoff);
+	// Live lists (pga_host_context.hpp): worth their two scans and one host wait when at most three hits in four are left -- the vertex step
+	// counted them (live_hint) before graph.c:285-288 filtered some more.  PANGENE_LIVE_LISTS=0 never, =1 whenever the count is known.
+	static const int live_env = [] { const char *e = getenv("PANGENE_LIVE_LISTS"); return e ? atoi(e) : -1; }();
+	const bool want_live = live_env != 0 && (known_live >= 0 || (c->live_hint >= 0 && (live_env == 1 || c->live_hint * 4 <= (int64_t)N * 3)));
+	int n = N;
+	if (want_live) {
+		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
+		if (!tile) return PGA_ERR_NOMEM;
+		device_scan<I32>(InLiveX{c->flags}, OutLiveX{c->flags, c->lx, c->gid, key, val, (int64_t)N}, N, tile, OpSum{}, I32{0}, c->st);
+		hipLaunchKernelGGL(k_mail_live, dim3(1), dim3(64), 0, c->st, c->lx, (int64_t)N, c->dcnt, c->h_box);
+		device_scan<I32>(InLiveY{c->flags, c->yperm}, OutLiveY{c->flags, c->yperm, c->ylist_buf}, N, tile, OpSum{}, I32{0}, c->st);
+		HIPCHK(hipMemsetAsync(c->zpos, 0xff, sizeof(int32_t) * (size_t)N, c->st)); // -1: not in the index
+		if (known_live < 0) TRY(sync_st(c)); // the grids of everything that follows are sized by the members' number
+		n = known_live < 0 ? (int)c->h_cnt[10] : (int)known_live;
+		c->live_on = true, c->NL = n, c->ylist = c->ylist_buf;
+		if (getenv("PANGENE_TIMING")) fprintf(stderr, "[pga] live lists: %d of %d hits (%.3f) are not filtered; the walk and the gene-major index hold those\n", n, N, (double)n / N);
+	} else {
+		c->live_on = false, c->NL = N, c->ylist = c->yperm;
+		hipLaunchKernelGGL(k_zkey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gid, N, key, val);
+	}
+	uint64_t *ks = key; uint32_t *vs = val;
+	if (n) TRY(radix_sort_pool(c, key, val, n, bits_for((uint32_t)std::max(1, c->Q)), &ks, &vs));
+	if (n) hipLaunchKernelGGL(k_zrec, dim3(nblk(n)), dim3(BLOCK), 0, c->st, vs, ks, c->ctg_base, c->n_genome, c->flags, c->cm, c->seg, n, ZIndex{c->zx, c->zy, c->zg, c->zst, c->zpos});
+	hipLaunchKernelGGL(k_zoff, dim3(nblk(c->Q + 1)), dim3(BLOCK), 0, c->st, ks, n, c->Q, c->zoff);
 	c->z_valid = true, c->ha_valid = false, c->zposy_stale = false, c->wrec_valid = false;
 	return 0;
 }
@@ -68,7 +93,7 @@ static int ensure_half_arcs(pga_ctx *c, int use_ori)
 	if (c->N == 0) return 0;
 	TRY(ensure_z(c));
 	if (!c->wrec_valid) {
-		hipLaunchKernelGGL(k_pack_wrec, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, WrecSrc{c->yperm, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->vfirst, c->vbase}, c->N, c->wrec);
+		if (c->NL) hipLaunchKernelGGL(k_pack_wrec, dim3(nblk(c->NL)), dim3(BLOCK), 0, c->st, WrecSrc{c->ylist, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->vfirst, c->vbase}, c->NL, c->wrec);
 		c->wrec_valid = true;
 	}
 	if (c->ha_valid && c->ha_ori == use_ori) return 0;
@@ -80,9 +105,9 @@ static int ensure_half_arcs(pga_ctx *c, int use_ori)
 	int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
 	if (!hzl) return PGA_ERR_NOMEM;
 	TimedLaunch tw; if (c->timing_rounds) time_mark(c, &tw, 6, false);
-	const Walk wk = {c->flags, c->yperm, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->N, c->dcnt, hzl, c->gate};
-	if (c->N >= WK_FEW_FROM) hipLaunchKernelGGL(k_walk<4>, dim3(nblk(c->N, BLOCK * 4)), dim3(BLOCK), 0, c->st, wk);
-	else hipLaunchKernelGGL(k_walk<1>, dim3(nblk(c->N, BLOCK)), dim3(BLOCK), 0, c->st, wk);
+	const Walk wk = {c->flags, c->ylist, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->NL, c->dcnt, hzl, c->gate};
+	if (c->NL >= WK_FEW_FROM) hipLaunchKernelGGL(k_walk<4>, dim3(nblk(c->NL, BLOCK * 4)), dim3(BLOCK), 0, c->st, wk);
+	else if (c->NL) hipLaunchKernelGGL(k_walk<1>, dim3(nblk(c->NL, BLOCK)), dim3(BLOCK), 0, c->st, wk);
 	if (c->timing_rounds) time_mark(c, &tw, 6, true);
 	c->ha_valid = true, c->ha_ori = use_ori;
 	return 0;
@@ -128,7 +153,7 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	if (!big) return PGA_ERR_NOMEM;
 	static const int cap_log2 = [] { const char *e = getenv("PANGENE_GENE_TABLE_LOG2"); const int v = e ? atoi(e) : 9; return v < 1 ? 1 : v > 9 ? 9 : v; }();
 	GeneArcs ga = { c->zy, c->zoff, c->hfk, c->hbk, c->hfp, c->hbp, c->g2s, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta,
-	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt, c->gate, c->gate.w ? c->loopctl + 2 : (int32_t *)nullptr };
+	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt, c->gate, (c->gate.w || c->loop_gated) ? c->loopctl + 2 : (int32_t *)nullptr };
 	hipLaunchKernelGGL(k_gene_arcs_wave, dim3((unsigned)c->Q), dim3(GA_WAVE_NT), 0, c->st, ga);
 	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 8 * c->n_cu)), dim3(GA_BIG_NT), 0, c->st, ga);
 	if (c->timing_rounds) time_mark(c, &tr, 5, true);

@@ -17,11 +17,16 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		if (!rx || !tile) return PGA_ERR_NOMEM;
 		TRY(ensure_half_arcs(c, c->ha_ori < 0 ? 0 : c->ha_ori)); // which hits are walkable, gene-major (normally left by the arc round just before)
 		device_scan<I32>(InWalkX{c->flags}, OutRank{rx, c->flags}, N, tile, OpSum{}, I32{0}, c->st, c->gate); // rank among the walkable hits, cs order
-		RepFill rf = { n_ent, GL, Q, N, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl, c->vfirst, c->vbase, c->gate };
-		const unsigned nb = nblk(std::max(N, Q));
-		if (c->rp_form == RP_COMPACT) hipLaunchKernelGGL((k_rep_fill<RP_COMPACT>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
-		else if (c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_rep_fill<RP_WIDE>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
-		else hipLaunchKernelGGL((k_rep_fill<RP_FULL>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+		RepFill rf = { n_ent, GL, Q, N, c->NL, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl, c->vfirst, c->vbase, c->gate };
+		const unsigned nb = nblk(std::max(c->NL, 1));
+		if (c->rp_form == RP_COMPACT) {
+			if (n_ent) hipLaunchKernelGGL((k_rep_clear<RP_COMPACT>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, (void *)rp, n_ent, c->gate);
+			hipLaunchKernelGGL((k_rep_fill<RP_COMPACT>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+		} else {
+			if (n_ent) hipLaunchKernelGGL((k_rep_clear<RP_FULL>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, (void *)rp, n_ent, c->gate);
+			if (c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_rep_fill<RP_WIDE>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+			else hipLaunchKernelGGL((k_rep_fill<RP_FULL>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+		}
 	} else if (n_ent) {
 		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(4 * n_ent)), dim3(BLOCK), 0, c->st, (int32_t *)rp, 4 * n_ent, -1); // "absent" in either record form
 	}
@@ -369,11 +374,19 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	// hold on every rank.
 	static const bool no_skip = env_has("PANGENE_LOOP", "noskip");
 	const bool gated = x == nullptr && !no_skip && (int64_t)c->round_tag + n_round + 4 < (int64_t)HA_TAG_MAX;
-	struct GateScope { pga_ctx *c; ~GateScope() { c->gate = Gate{nullptr, 0}; } } gate_scope{c}; // (every way out of this function leaves the launches open)
+	struct GateScope { pga_ctx *c; ~GateScope() { c->gate = Gate{nullptr, 0}, c->loop_gated = false; } } gate_scope{c}; // (every way out of this function leaves the launches open)
+	c->loop_gated = gated;
 	const uint32_t tag_before = c->round_tag;
 	if (gated) HIPCHK(hipMemsetAsync(c->loopctl, 0xff, 4 * sizeof(int32_t), c->st)); // -1: nothing has happened yet; round 0 runs (its branch steps ask for a change in round -1 or later)
+	// Live lists inside the queue.  pg_flt_high_occ's first rounds delete segments wholesale on many-genome shards (1 250 bacterial
+	// genomes: 98.5 % of the hits are without flt before the test of round 1, 38.5 % after it), so on shards where a wait is small beside a round
+	// the loop asks after the deletions of rounds 1, 2, 4 and 8 how many hits are left (k_flag_vtx counts them) and, when a quarter of what the
+	// lists hold has gone, builds them again before the round's pg_gen_arc.  PANGENE_LIVE_LISTS=0: never; =2: ask in every round, whatever the size.
+	static const int live_env = [] { const char *e = getenv("PANGENE_LIVE_LISTS"); return e ? atoi(e) : -1; }();
+	const bool live_ask = live_env != 0 && (live_env == 2 || N >= (1 << 21));
 	for (int r = 0; r < n_round; ++r) {
 		c->loop_round = r;
+		bool rebuilt = false;
 		c->gate = gated ? Gate{c->loopctl, r - 1} : Gate{nullptr, 0}; // the branch steps of round r: something changed in round r - 1
 		// pg_mark_branch_flt_arc (branch.c:48-106)
 		TRY(pga_rep_pos(c));
@@ -396,12 +409,28 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 				hipLaunchKernelGGL(k_round_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)ndl, max_tot_cnt[r], max_degree[r], max_dist_loci[r], (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive,
 				                   (x || par->final_on) ? (int4 *)c->pool.get(S_GMETA, 0) : (int4 *)nullptr, // (whoever compacts the genes' stretches afterwards must find a deleted one empty)
 				                   gated ? c->loopctl : (int32_t *)nullptr, r);
-				hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1, c->gate);
+				const bool ask = live_ask && (live_env == 2 || r == 1 || r == 2 || r == 4 || r == 8) && (r + 1 < n_round || par->final_on);
+				if (ask) HIPCHK(hipMemsetAsync(c->live_cnt, 0, sizeof(int64_t) * LIVE_CNT_N, c->st));
+				hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1, c->gate, ask ? c->live_cnt : (int64_t *)nullptr);
 				c->walk_valid = false, c->ha_valid = false;
+				if (ask) {
+					hipLaunchKernelGGL(k_live_sum, dim3(1), dim3(BLOCK), 0, c->st, (const int64_t *)c->live_cnt, c->dcnt);
+					hipLaunchKernelGGL(k_mail_flush, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box);
+					TRY(sync_st(c));
+					const int64_t left = c->h_cnt[8]; // (0: the round's kernels found their gate closed -- nothing was counted, nothing has changed)
+					if (left > 0 && left * 4 <= (int64_t)c->NL * 3) {
+						if (getenv("PANGENE_TIMING")) fprintf(stderr, "[pga_branch_loop] round %d: %lld of %d hits are without flt, the lists hold %d: built again\n", r, (long long)left, N, c->NL);
+						TRY(build_z(c, left));
+						rebuilt = true;
+					}
+				}
 			}
 		}
 		if (r + 1 < n_round || par->final_on) { // pg_gen_arc (graph.c:313)
 			int32_t *seg_cnt, *deg;
+			// (new lists renumber the index: the half-arc records of the last walk mean nothing any more, so this arc round runs whatever the gate says --
+			// it is open anyway when hits were filtered in this round, but the quarter may have gone over several rounds)
+			if (rebuilt) c->gate = Gate{nullptr, 0};
 			TRY(arc_round_genes(c, par->use_ori, &seg_cnt, &deg, nullptr, false)); // (no mail: the kernels raise the sticky flag themselves)
 			c->br_n = 2 * (int64_t)N + 2, c->br_S = S, c->br_np = 0;
 			if (x) { TRY(loop_exchange_table(c, L)); c->br_n = L.ecap; }
@@ -479,7 +508,7 @@ extern "C" int pga_mark_hits(pga_ctx_t *c, const uint64_t *arc_x, const uint8_t 
 		const uint8_t *vwk = (const uint8_t *)c->pool.get(S_VWK, 0);
 		if (!ax || !aw || !vs || !ve || !vwk) return PGA_ERR_NOMEM;
 		if (n_marked) HIPCHK(hipMemsetAsync(c->dcnt + 2, 0, sizeof(int64_t), c->st));
-		hipLaunchKernelGGL(k_mark_hits_z, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->zx, c->zy, c->zg, c->hfk, c->hbk, c->round_tag, N, c->g2s, ax, aw, vs, ve, vwk, c->flags,
+		if (c->NL) hipLaunchKernelGGL(k_mark_hits_z, dim3(nblk(c->NL)), dim3(BLOCK), 0, c->st, c->zx, c->zy, c->zg, c->hfk, c->hbk, c->round_tag, c->NL, c->g2s, ax, aw, vs, ve, vwk, c->flags,
 		                   n_marked ? c->dcnt + 2 : (int64_t *)nullptr, then_filter, n_marked ? Gate{nullptr, 0} : c->gate, c->gate.w ? c->loopctl : (int32_t *)nullptr, c->loop_round);
 		if (then_filter) c->walk_valid = false, c->ha_valid = false; // else: weak_br does not enter the walkable test, the half-arcs stay valid
 	} else {

@@ -153,6 +153,7 @@ enum { // pool slots
 	S_COUNT
 };
 
+constexpr int LIVE_CNT_N = 1024;
 struct TimedLaunch { hipEvent_t a, b; int which; int64_t units; };
 
 struct pga_ctx {
@@ -205,12 +206,24 @@ struct pga_ctx {
 	bool walk_valid = false; // S_WALK_VAL / S_WALK_PREV match the current flags and cm order
 	// gene-major index (k_genes.hpp): hits by (gene, genome, X position); half-arc records of the current walk
 	int32_t *zx = 0, *zy = 0, *zg = 0; int2 *zst = 0; int32_t *zpos = 0, *zoff = 0; // gene-major planes (k_genes.hpp)
+	// LIVE LISTS: flt is monotone and everything but the BED writers skips filtered hits, so when few hits are left the structures the
+	// rounds iterate over -- the cm-order list of the walk and the gene-major index with its half-arc records -- are built over the hits without
+	// flt only (ensure_z, at the first pg_gen_arc of a run: stage A, pg_post_process and graph.c:285-288 have filtered by then).  The X order
+	// itself (records, flags, every plane) is not compacted: members carry F_MEMBER, ylist / zx hold X positions.
+	bool live_on = false;    // the lists of this run hold members only; false: every hit (ylist == yperm, NL == N)
+	int32_t NL = 0;          // entries of the cm-order list and of the gene-major index
+	int32_t *lx = 0;         // [N + 1] members before X position x when the lists were built (a contig keeps its range and its count through order overrides: valid at contig starts)
+	int32_t *ylist_buf = 0;  // [N] storage of the members' list in cm order
+	const int32_t *ylist = 0;// what the walk reads: ylist_buf, or yperm when the lists hold every hit
+	int64_t *live_cnt = 0;   // [LIVE_CNT_N] partial counts of the hits without flt (k_vtx1 / k_flag_vtx spread their atomics: 190 000 waves onto ONE word cost 1.9 ms at 12.1 M hits), summed into dcnt[8] by k_live_sum
+	int64_t live_hint = -1;  // hits without flt as the vertex step counted them (k_vtx1): decides whether the lists are worth building; -1 not known
 	int4 *wrec = 0; bool wrec_valid = false; // the walk's 32-byte records in cm order (k_pack_wrec): they carry the gene-major position, so a new index or a new cm order makes them stale
 	uint32_t *hfk = 0, *hbk = 0; int4 *hfp = 0, *hbp = 0; // half-arc key words and payloads
 	bool z_valid = false, ha_valid = false; uint32_t round_tag = 0; int ha_ori = -1;
 	Gate gate = Gate{nullptr, 0};     // what the launches of the moment carry (pga_branch_loop sets it per phase; open everywhere else)
 	int32_t *loopctl = nullptr;       // [4] device: Gate::w[0..1], [2] = tag of the last arc round of the loop that ran
 	int loop_round = 0;               // the round the launches of the moment belong to (stamps)
+	bool loop_gated = false;          // pga_branch_loop runs with gates: an arc round that runs leaves its tag in loopctl[2], whether its own gate is open or not
 	int32_t *h_loopctl = nullptr;     // pinned mirror of loopctl (bump-allocated once per context)
 	int32_t *h_ov = nullptr; size_t h_ov_cap = 0; // pinned: position / file-index lists of an order override, two halves used in turn
 	hipEvent_t ov_ev[2] = { nullptr, nullptr }; bool ov_ev_used[2] = { false, false }; unsigned ov_seq = 0; // a half is free again when the copy out of it has happened

@@ -23,18 +23,19 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	if (n_seg <= 0 || N == 0) return 0;
 	const int64_t T = seg_off[n_seg];
 	if (T == 0) { if (partial) c->ha_valid = true, c->wrec_valid = true; return 0; }
-	auto walk_again = [&](const int32_t *d_pos) -> int { // (after the override's own kernels, on the same stream)
+	auto walk_again = [&](const int32_t *d_pos) -> int { // (after the override's own kernels, on the same stream; d_pos: places in the walk's list -- cm positions, or places in the members' list)
 		int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
 		if (!hzl) return PGA_ERR_NOMEM;
-		hipLaunchKernelGGL(k_pack_wrec_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, WrecSrc{c->yperm, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->vfirst, c->vbase}, d_pos, T, c->wrec);
-		hipLaunchKernelGGL(k_walk_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, Walk{c->flags, c->yperm, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, c->ha_ori, c->N, c->dcnt, hzl, Gate{nullptr, 0}}, d_pos, T);
+		hipLaunchKernelGGL(k_pack_wrec_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, WrecSrc{c->ylist, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->vfirst, c->vbase}, d_pos, T, c->wrec);
+		hipLaunchKernelGGL(k_walk_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, Walk{c->flags, c->ylist, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, c->ha_ori, c->NL, c->dcnt, hzl, Gate{nullptr, 0}}, d_pos, T);
 		c->ha_valid = true, c->wrec_valid = true, c->zposy_stale = false;
 		return 0;
 	};
+	const bool live = c->live_on && z_keep; // the lists stand and have to follow the override (an index that is dropped is built again, lists and all)
 	// positions and file indices of the overridden hits, built in page-locked memory (a real DMA; from a std::vector the runtime stages)
 	// (nothing waits at the end of an override any more -- sixty-six of them per pass each found the device still at the round queued
 	// before -- so the lists must not be overwritten while their copy is under way: two halves, an event each)
-	const size_t ov_bytes = (sizeof(int32_t) * 2 * (size_t)T + 255) & ~(size_t)255;
+	const size_t ov_bytes = (sizeof(int32_t) * 3 * (size_t)T + 255) & ~(size_t)255;
 	if (c->h_ov_cap < ov_bytes) {
 		if (c->h_ov) HIPCHK(hipStreamSynchronize(c->st));
 		const size_t cap = ov_bytes + ov_bytes / 2 + 256;
@@ -45,22 +46,30 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	const int half = (int)(c->ov_seq++ & 1u);
 	if (!c->ov_ev[half]) HIPCHK(hipEventCreateWithFlags(&c->ov_ev[half], hipEventDisableTiming));
 	if (c->ov_ev_used[half]) HIPCHK(hipEventSynchronize(c->ov_ev[half]));
-	int32_t *pos = (int32_t *)((char *)c->h_ov + (size_t)half * c->h_ov_cap), *fil = pos + T;
+	int32_t *pos = (int32_t *)((char *)c->h_ov + (size_t)half * c->h_ov_cap), *fil = pos + T, *fst = fil + T;
 	for (int32_t s = 0; s < n_seg; ++s) {
 		const int32_t g = seg_genome[s], base = c->h_goff[(size_t)g];
 		for (int64_t k = seg_off[s]; k < seg_off[s + 1]; ++k)
-			pos[(size_t)k] = base + seg_start[s] + (int32_t)(k - seg_off[s]), fil[(size_t)k] = base + file_idx[k];
+			pos[(size_t)k] = base + seg_start[s] + (int32_t)(k - seg_off[s]), fil[(size_t)k] = base + file_idx[k], fst[(size_t)k] = (int32_t)seg_off[s];
 	}
-	int32_t *d_pos = (int32_t *)c->pool.get(S_OVPOS, sizeof(int32_t) * (size_t)T), *d_fil = (int32_t *)c->pool.get(S_OVFILE, sizeof(int32_t) * (size_t)T);
+	int32_t *d_pos = (int32_t *)c->pool.get(S_OVPOS, sizeof(int32_t) * 4 * (size_t)T + 64), *d_fil = (int32_t *)c->pool.get(S_OVFILE, sizeof(int32_t) * (size_t)T);
 	int32_t *remap = (int32_t *)c->pool.get(S_I32_B, sizeof(int32_t) * (size_t)N);
 	if (!d_pos || !d_fil || !remap) return PGA_ERR_NOMEM;
+	int32_t *d_fst = d_pos + (size_t)T, *d_ex = d_pos + 2 * (size_t)T, *d_lpos = d_pos + 3 * (size_t)T; // (live lists) first entry of the entry's contig, members listed before it, its place in the lists
 	TRY(upload(c, d_pos, pos, (size_t)T)); TRY(upload(c, d_fil, fil, (size_t)T));
+	if (live) TRY(upload(c, d_fst, fst, (size_t)T));
 	HIPCHK(hipEventRecord(c->ov_ev[half], c->st)); c->ov_ev_used[half] = true;
 	if (!c->inv_valid) { hipLaunchKernelGGL(k_inv_only, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->fidx, c->gnm, c->goff, N, c->inv); c->inv_valid = true; } // (then kept current by the overrides themselves)
+	if (live) { // the override in the lists' coordinates (k_order.hpp); before anything moves: inv and the flag words are those of the order that is being replaced
+		I32 *tl = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(T));
+		if (!tl) return PGA_ERR_NOMEM;
+		device_scan<I32>(InOvMember{c->flags, c->inv, d_fil}, OutExclI32{d_ex}, T, tl, OpSum{}, I32{0}, c->st);
+		hipLaunchKernelGGL(k_ovl_pos, dim3(nblk(T)), dim3(BLOCK), 0, c->st, (const int32_t *)d_ex, (const uint32_t *)c->flags, (const int32_t *)c->inv, (const int32_t *)d_pos, (const int32_t *)d_fil, (const int32_t *)d_fst, T, (const int32_t *)c->lx, d_lpos);
+	}
 	if (which == 1) {
-		hipLaunchKernelGGL(k_ov_sety, dim3(nblk(T)), dim3(BLOCK), 0, c->st, d_pos, d_fil, T, c->inv, c->yperm);
+		hipLaunchKernelGGL(k_ov_sety, dim3(nblk(T)), dim3(BLOCK), 0, c->st, d_pos, d_fil, T, c->inv, c->yperm, live ? (const int32_t *)d_lpos : (const int32_t *)nullptr, c->ylist_buf);
 		if (z_keep) c->zposy_stale = true;
-		if (partial) TRY(walk_again(d_pos));
+		if (partial) TRY(walk_again(live ? d_lpos : d_pos));
 		return 0;
 	}
 	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * (OV_PLANES + 13) * (size_t)T + 64);
@@ -70,12 +79,13 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	hipLaunchKernelGGL(k_ov_gather, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, c->inv, tmp, remap, z_keep ? (const int32_t *)c->zpos : (const int32_t *)nullptr);
 	hipLaunchKernelGGL(k_ov_scatter, dim3(nblk(T)), dim3(BLOCK), 0, c->st, p, d_pos, d_fil, T, tmp, c->gnm, c->goff, c->inv, c->zx, z_keep ? c->zpos : (int32_t *)nullptr);
 	hipLaunchKernelGGL(k_ov_remap_y, dim3(nblk(T)), dim3(BLOCK), 0, c->st, c->yperm, d_pos, T, remap);
+	if (live) hipLaunchKernelGGL(k_ovl_remap_ylist, dim3(nblk(T)), dim3(BLOCK), 0, c->st, c->ylist_buf, (const int32_t *)d_lpos, T, (const int32_t *)remap);
 	if (z_keep) c->zposy_stale = true;
 	SegMax *tile = (SegMax *)c->pool.get(S_TILE, tile_buf_bytes(T));
 	if (!tile) return PGA_ERR_NOMEM;
 	device_scan<SegMax>(InSegMaxList{c->recA, d_pos}, OutSegMaxList{c->recA, d_pos}, T, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st); // pm follows the new order
 	hipLaunchKernelGGL(k_cstie_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, c->recA, d_pos, T, N, c->flags);
-	if (partial) TRY(walk_again(d_pos));
+	if (partial) TRY(walk_again(live ? d_lpos : d_pos));
 	return 0;
 }
 

@@ -78,9 +78,11 @@ extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records,
 		unsigned long long *pbits = (unsigned long long *)(blk + 2 * b_tab), *rec = (unsigned long long *)(blk + 2 * b_tab + b_bits);
 		zero_multi(c, bits, sizeof(uint32_t) * (size_t)(wpg * GL) + 16, c->vtx_cnt, sizeof(int32_t) * 2 * (size_t)std::max(1, Q), c->dcnt, sizeof(int64_t), pbits, b_bits);
 		HIPCHK(hipMemsetAsync(dom_tab, 0xff, b_tab, c->st)); // every slot empty (-1)
+		HIPCHK(hipMemsetAsync(c->live_cnt, 0, sizeof(int64_t) * LIVE_CNT_N, c->st)); // k_vtx1 counts the hits without flt there
 		*records = (uint64_t *)rec;
 		if (N == 0) return sync_st(c);
-		hipLaunchKernelGGL(k_vtx1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt);
+		hipLaunchKernelGGL(k_vtx1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt, c->live_cnt);
+		hipLaunchKernelGGL(k_live_sum, dim3(1), dim3(BLOCK), 0, c->st, (const int64_t *)c->live_cnt, c->dcnt);
 		hipLaunchKernelGGL(k_vtx_fold, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, c->prot_gid, c->ggl, N, bits, wpg,
 		                   dom_tab, pbits, nw, rec + n_slot * (1 + nw), ovf_cap, c->dcnt);
 		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_slot));
@@ -89,6 +91,7 @@ extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records,
 		hipLaunchKernelGGL(k_vtx_compact, dim3(nblk(n_slot)), dim3(BLOCK), 0, c->st, dom_tab, slot, n_slot, pbits, nw, rec, c->dcnt, c->h_box);
 		TRY(sync_st(c));
 		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
+		c->live_hint = c->h_cnt[8];
 		const int64_t n_rec = c->h_cnt[10], n_ovf = c->h_cnt[0];
 		if (n_ovf > ovf_cap) { // more spilled (genome, gene) cells than there was room for: once more, with room (the reference has no such limit)
 			// which dominators win a gene's slots is a race, so the number of spilled cells may differ a little between attempts:

@@ -659,8 +659,15 @@ static int trace_state(DataExt *ext, const char *step, int round, bool first = f
 			}
 			int64_t n_tile = 0;
 			for (uint8_t t : tile) n_tile += t;
-			std::fprintf(stderr, "[trace_diff] %-18s %3d: %lld of %zu hits changed their flag word (walkable test %lld, flt %lld, weak_br %lld); %lld of %zu tiles of 256 hits dirty\n", step, round,
-			             (long long)n_any, N, (long long)n_walk, (long long)n_flt, (long long)n_weak, (long long)n_tile, tile.size());
+			int64_t n_live = 0, n_wk = 0; // what a step that skips filtered hits still has to look at: hits without flt, and the walkable ones among them
+			for (size_t f = 0; f < N; ++f) n_live += !(flags[f] & PGA_F_FLT), n_wk += !(flags[f] & (PGA_F_FLT | PGA_F_SHADOW));
+			std::fprintf(stderr, "[trace_diff] %-18s %3d: %lld of %zu hits changed their flag word (walkable test %lld, flt %lld, weak_br %lld); %lld of %zu tiles of 256 hits dirty; live (flt == 0) %lld = %.3f, walkable %lld = %.3f\n", step, round,
+			             (long long)n_any, N, (long long)n_walk, (long long)n_flt, (long long)n_weak, (long long)n_tile, tile.size(), (long long)n_live, (double)n_live / (double)(N ? N : 1), (long long)n_wk, (double)n_wk / (double)(N ? N : 1));
+		}
+		else { // the first step of a run: nothing to compare with
+			int64_t n_live = 0, n_wk = 0;
+			for (size_t f = 0; f < N; ++f) n_live += !(flags[f] & PGA_F_FLT), n_wk += !(flags[f] & (PGA_F_FLT | PGA_F_SHADOW));
+			std::fprintf(stderr, "[trace_diff] %-18s %3d: %zu hits; live (flt == 0) %lld = %.3f, walkable %lld = %.3f\n", step, round, N, (long long)n_live, (double)n_live / (double)(N ? N : 1), (long long)n_wk, (double)n_wk / (double)(N ? N : 1));
 		}
 		prev.assign(flags.begin(), flags.begin() + (long)N);
 	}
