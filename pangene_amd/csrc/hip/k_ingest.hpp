@@ -107,6 +107,19 @@ __global__ __launch_bounds__(BLOCK) void k_score_key(const int32_t *pid_f, const
 	if (i < n) key[i] = (uint64_t)(int64_t)sadj_f[i] << 33 | (uint64_t)gene_pref[gid_f[i]] << 32 | hash_u32((uint32_t)pid_f[i]), val[i] = (uint32_t)i;
 }
 
+// CONTIG BINS (k_segsort.hpp: GenomeSort::bins): the file-order planes of the upload, grouped by contig once per upload.  perm = the file-order
+// indices sorted (stably) by contig segment; plane 17 of the result = the hit's file index inside its genome.  Plane 14 holds bytes (rev).
+__global__ __launch_bounds__(BLOCK) void k_cgroup(const int32_t *up, const uint32_t *perm, int64_t n, const int32_t *goff, int32_t *out)
+{
+	const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= n) return;
+	const int64_t s = perm[c];
+#pragma unroll
+	for (int f = 0; f < 17; ++f) if (f != 14) out[(int64_t)f * n + c] = up[(int64_t)f * n + s];
+	((uint8_t *)(out + 14 * n))[c] = ((const uint8_t *)(up + 14 * n))[s];
+	out[17 * n + c] = (int32_t)(s - goff[up[10 * n + s]]);
+}
+
 struct HitArrays {
 	int32_t *fidx, *gnm, *seg, *pid, *gid, *cs, *ce, *cm, *cds, *nex, *offx, *sori, *sadj, *rank, *sdom, *pdom, *pdom0;
 	int32_t *rk; uint32_t *flags;

@@ -38,6 +38,12 @@ struct GenomeSort {
 	HitArrays o; int32_t *yperm, *headpos; int4 *A, *B, *C;
 	long long *prof; // tuning aid (PANGENE_GS_PROF=1): 16 time stamps per workgroup
 	const int32_t *glist; // k_segsort2.hpp: the genomes this launch sorts (workgroup b takes glist[b]); NULL = genome b
+	// k_segsort2.hpp, round 6 -- CONTIG BINS: a workgroup's unit is a run of consecutive contigs of one genome instead of a whole genome, so that
+	// genomes beyond what the LDS holds (a human assembly: 110 000 hits in a few hundred contigs) are still sorted there ("contig-segmented radix
+	// sort", hit.c:37-53 buckets by contig first as well).  The planes in `up` are then grouped by contig (pga_create: stable, once per upload --
+	// file order inside a contig stands, which is all the tie order needs), a unit is one contiguous range of them and of the X order, and
+	// plane 17 holds each hit's file index.  bins[b] = {first position, hits, genome | bit 31 = the genome's first bin, first contig (local id)}.
+	const int4 *bins;
 };
 
 struct GsLds { uint16_t *cur, *alt; uint8_t *dig; uint32_t *whist, *stage, *wtot; unsigned long long *head, *tie; int2 *wagg; };

@@ -80,9 +80,13 @@ template <int T, int K>
 __device__ __forceinline__ void gs2_body(const GenomeSort &a, unsigned char *gs_mem)
 {
 	constexpr int NW = T / WAVE;
-	const int g = a.glist ? a.glist[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	const int gb = a.goff[g], n = a.goff[g + 1] - gb, np = a.np;
-	if (tid == 0) { a.headpos[g] = gb; if (g == a.n_genome - 1) a.headpos[g + 1] = gb + n; }
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, np = a.np;
+	int g, gb, n, c0 = 0; bool first = true; // the unit: a genome, or (contig bins) consecutive contigs c0 ... of genome g -- `first`: from the genome's first hit on
+	if (a.bins) { const int4 b = a.bins[blockIdx.x]; gb = b.x, n = b.y, g = b.z & 0x7fffffff, first = b.z < 0, c0 = b.w; } // (headpos: the host copies goff)
+	else {
+		g = a.glist ? a.glist[blockIdx.x] : (int)blockIdx.x, gb = a.goff[g], n = a.goff[g + 1] - gb;
+		if (tid == 0) { a.headpos[g] = gb; if (g == a.n_genome - 1) a.headpos[g + 1] = gb + n; }
+	}
 	if (n == 0) return;
 	const size_t s_bytes = 3 * (size_t)np + sizeof(uint32_t) * NW * 256 > 4 * (size_t)np ? 3 * (size_t)np + sizeof(uint32_t) * NW * 256 : 4 * (size_t)np;
 	uint16_t *const idx0 = (uint16_t *)gs_mem;
@@ -122,13 +126,15 @@ __device__ __forceinline__ void gs2_body(const GenomeSort &a, unsigned char *gs_
 			uint32_t cg[K];
 			GS2_LOAD(cg, 1);
 #pragma unroll
-			for (int u = 0; u < K; ++u) key[u] |= a.cs_bits < 32 ? cg[u] << a.cs_bits : 0u;
+			for (int u = 0; u < K; ++u) key[u] |= a.cs_bits < 32 ? (cg[u] - (uint32_t)c0) << a.cs_bits : 0u;
 			gs_bar();
 			gs2_sort_bits<T, K>(L, n, key, a.cs_bits + a.ctg_bits);
 		} else {
 			gs_bar();
 			gs2_sort_bits<T, K>(L, n, key, a.cs_bits);
 			GS2_LOAD(key, 1);
+#pragma unroll
+			for (int u = 0; u < K; ++u) key[u] -= (uint32_t)c0;
 			gs2_sort_bits<T, K>(L, n, key, a.ctg_bits);
 		}
 	}
@@ -243,15 +249,17 @@ __device__ __forceinline__ void gs2_body(const GenomeSort &a, unsigned char *gs_
 	gs_bar();
 	// plane 4, score_adj; plane 16, the static flag bits (+ head of the genome, + member of a cs tie group); file index, genome
 	GS2_BEGIN(4, 16); GS2_GET(V); GS2_OUT(a.o.sadj, V); gs_bar();
-	GS2_BEGIN(16, 9); GS2_GET(V);
+	GS2_BEGIN(16, a.bins ? 17 : 9); GS2_GET(V);
 #pragma unroll
 	for (int u = 0; u < K; ++u) {
 		const int x = tid + u * T;
 		if (x >= n) break;
-		a.o.flags[gb + x] = V[u] | (x == 0 ? F_HEAD : 0u) | (((L.tie[x >> 6] >> (x & 63)) & 1ull) ? F_CSTIE : 0u);
-		a.o.fidx[gb + x] = (int32_t)idx0[x], a.o.gnm[gb + x] = g;
+		a.o.flags[gb + x] = V[u] | ((x == 0 && first) ? F_HEAD : 0u) | (((L.tie[x >> 6] >> (x & 63)) & 1ull) ? F_CSTIE : 0u);
+		a.o.gnm[gb + x] = g;
+		if (!a.bins) a.o.fidx[gb + x] = (int32_t)idx0[x];
 	}
 	gs_bar();
+	if (a.bins) { GS2_BEGIN(17, 9); GS2_GET(V); GS2_OUT(a.o.fidx, V); gs_bar(); } // the file index travels as a plane of its own (the input is grouped by contig)
 	// ---- Y order: pg_hit_sort(g, 1) = by (contig, cm), ties in X order; the items are X positions now, the keys cm and contig in X order ----
 	GS2_BEGIN(9, 1); GS2_GET(W0); GS2_OUT(a.o.cm, W0); gs_bar();
 	GS2_BEGIN(1, -1); GS2_GET(W1); gs_bar(); // contig, once more (cheaper than ten registers held since the first plane)
@@ -263,6 +271,8 @@ __device__ __forceinline__ void gs2_body(const GenomeSort &a, unsigned char *gs_
 	L.cur = idx0, L.alt = (uint16_t *)S;
 #pragma unroll
 	for (int u = 0; u < K; ++u) { const int x = tid + u * T; if (x < n) L.cur[x] = (uint16_t)x; }
+#pragma unroll
+	for (int u = 0; u < K; ++u) W1[u] -= (uint32_t)c0;
 	if (a.ctg_bits + a.cm_bits <= 32) {
 #pragma unroll
 		for (int u = 0; u < K; ++u) W0[u] |= a.cm_bits < 32 ? W1[u] << a.cm_bits : 0u;

@@ -149,7 +149,7 @@ struct PinArena {
 enum { // pool slots
 	S_KEY_A, S_KEY_B, S_VAL_A, S_VAL_B, S_TABLE, S_TILE, S_I32_A, S_I32_B, S_I32_C, S_TAB_A, S_TAB_B, S_TAB_C, S_TAB_D,
 	S_TDIST, S_TS1, S_TS2, S_TGEN, S_SDIST, S_SS1, S_SS2, S_SGEN, S_HEAD, S_SLOT, S_ARCS, S_SEGCNT, S_BITS, S_TRIPLES,
-	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_BIGLIST, S_STAGE_SID, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK, S_XG_BUF, S_XG_OUT, S_XG_OUT2, S_XSTAT, S_GS2LIST,
+	S_WALK_VAL, S_WALK_PREV, S_PERM, S_OVPOS, S_OVFILE, S_RUNSTART, S_CDN, S_MG_KEY, S_MG_VAL, S_MG_SRC, S_MG_OUT, S_MG_HEAD, S_MG_SLOT, S_MG_RUN, S_BR_S1, S_BR_GID, S_BR_VS, S_BR_VE, S_BR_PC, S_BR_POFF, S_BR_GRP, S_BR_NDL, S_BR_SEGGID, S_PAIRS, S_NLCNT, S_ARCX, S_ARCW, S_WEAKNEW, S_RP_SEG, S_RP_R, S_RP_CM, S_RP_POS, S_RP_IV, S_DL, S_SCRATCH, S_UPLOAD, S_RAW, S_ARC_STAGE, S_GMETA, S_GOFF, S_DEG, S_BIGLIST, S_STAGE_SID, S_STATS, S_G2S, S_MISC, S_SLOW, S_HZLIST, S_VWK, S_XG_BUF, S_XG_OUT, S_XG_OUT2, S_XSTAT, S_GS2LIST, S_UPLOAD2, S_BINS,
 	S_COUNT
 };
 
@@ -185,6 +185,8 @@ struct pga_ctx {
 	bool sweep_init = false; // the next pg_shadow(cal_dom_sc=1) also initialises pid_dom / score_dom of the filtered hits (pga_ingest)
 	int gs2 = 0; // stage A's orders by the kernels of k_segsort2.hpp: genomes of up to 10 240 hits by k_genome_sort2 (two workgroups per CU), the others (up to 14 336) by k_genome_sort2d
 	int32_t *gs2_list = nullptr; int gs2_n_small = 0, gs2_n_big = 0, gs2_np_small = 64; // the two lists of genomes: [small..., big...]
+	// contig bins (k_segsort.hpp: GenomeSort::bins): genomes too large for one workgroup's LDS, every contig of which fits, are sorted bin by bin
+	bool bin_on = false; int32_t *up_grouped = nullptr; int4 *bins = nullptr; int bin_n_small = 0, bin_n_big = 0, bin_np_small = 64, bin_np_big = 64, bin_ctg_bits = 1;
 	bool gs_ok = false; int gs_np = 64; // stage A's orders by k_genome_sort (one workgroup per genome, keys in LDS): every genome fits
 	int2 *exon = 0; int32_t *prot_gid = 0; uint8_t *gene_pref = 0;
 	// exchange vectors

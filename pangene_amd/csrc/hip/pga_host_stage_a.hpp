@@ -129,7 +129,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	c->any_multi = multi, c->density_known = false, c->lists_in_lds = true;
 	c->ctg_bits = bits_for((uint32_t)(max_ctg - 1));
 	c->gs_np = std::max(64, (max_hit + 63) & ~63);
-	c->gs_ok = c->gs_np <= GS_NP_MAX && c->rk_shift >= 0 && getenv("PANGENE_GLOBAL_SORT") == nullptr;
+	c->gs_ok = c->gs_np <= GS_NP_MAX && getenv("PANGENE_GLOBAL_SORT") == nullptr; // (plane 15 holds a 32-bit comparison key either way: rk_shift < 0 = its dense rank, made below)
 	c->gs2 = 0;
 	if (c->gs_ok && c->gs_np <= GS2_NP_BIG) {
 		c->gs2 = 1;
@@ -169,7 +169,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	                                    (int)gf_lds_bytes(c->P, c->Q, c->gf_k32)) != hipSuccess) { (void)hipGetLastError(); c->gf_ok = false; }
 
 	{ // every temporary of a run comes out of one allocation: sorts and scans of 2N temp arcs, (genome x protein / gene) tables, ...
-		const size_t want = pool_want(N, GL, c->P, c->Q, woff[(size_t)GL]);
+		const size_t want = pool_want(N, GL, c->P, c->Q, woff[(size_t)GL]) + ((max_hit > GS2_NP_BIG && max_ctg > 1) ? (size_t)N * 76 : 0); // (+ the planes once more, grouped by contig: contig bins)
 		size_t got = 0;
 		void *a = getenv("PANGENE_NO_ARENA") == nullptr ? dev_big_alloc(want, &got) : nullptr;
 		if (a) { // else: slot by slot
@@ -213,6 +213,83 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		hipLaunchKernelGGL(k_prepare, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f, N, c->goff, GL, c->ctg_base, c->exon, c->prot_gid, c->gene_pref,
 		                   up + 10 * (size_t)N, up + 11 * (size_t)N, up + 12 * (size_t)N, up + 13 * (size_t)N, (uint64_t *)c->pool.get(S_KEY_A, 0), (uint32_t *)c->pool.get(S_VAL_A, 0),
 		                   c->rk_shift, c->hrank, up + 15 * (size_t)N, up + 16 * (size_t)N, c->dcnt + 9);
+		if (c->rk_shift < 0) {
+			// The comparison key of overlap.c:137 (score_adj, preferred, hash(pid)) does not fit 32 bits here: the sweeps compare its dense RANK over the
+			// shard instead (k_rank_scatter).  The key is made of what the upload brought -- nothing a pass changes --, so like the gene, the CDS length
+			// and the static flag bits it is ranked once per upload (rounds 1-5 sorted the N 64-bit keys again in every pga_begin: 8 radix passes, 3.4 ms
+			// of the 14.4 ms of stage A at the 21.9 M hits of configs[4]).
+			int32_t *head = (int32_t *)c->pool.get(S_HEAD, sizeof(int32_t) * ((size_t)N + 1)), *incl = (int32_t *)c->pool.get(S_SLOT, sizeof(int32_t) * ((size_t)N + 1));
+			I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
+			if (!head || !incl || !tile) return PGA_ERR_NOMEM;
+			uint64_t *ks; uint32_t *vs;
+			TRY(radix_sort_pool(c, (uint64_t *)c->pool.get(S_KEY_A, 0), (uint32_t *)c->pool.get(S_VAL_A, 0), N, c->sc_bits, &ks, &vs));
+			hipLaunchKernelGGL(k_arc_head, dim3(nblk(N)), dim3(BLOCK), 0, c->st, ks, (int64_t)N, head);
+			device_scan<I32>(InI32{head}, OutInclI32{incl}, N, tile, OpSum{}, I32{0}, c->st);
+			hipLaunchKernelGGL(k_rank_scatter, dim3(nblk(N)), dim3(BLOCK), 0, c->st, ks, vs, incl, N, up + 15 * (size_t)N);
+		}
+	}
+	// CONTIG BINS (k_segsort.hpp).  A genome beyond what one workgroup's LDS sorts (14 336 hits) whose contigs all fit is sorted bin by bin -- a bin
+	// = consecutive contigs of the genome, as many as fit.  For that the planes are grouped by contig here, once per upload: a stable sort of the
+	// file-order indices by contig segment, one gather, and the contigs' sizes fetched for the host to cut the bins.  PANGENE_BINS=0: never;
+	// PANGENE_BIN_CAP=n (tests): bins of at most n hits even where a genome would fit whole.
+	c->bin_on = false;
+	{
+		static const int bins_env = [] { const char *e = getenv("PANGENE_BINS"); return e ? atoi(e) : -1; }();
+		static const int cap_env = [] { const char *e = getenv("PANGENE_BIN_CAP"); return e ? atoi(e) : 0; }();
+		const int cap_small = cap_env > 0 ? std::min(cap_env, GS2_NP_MAX) : GS2_NP_MAX, cap_big = cap_env > 0 ? cap_small : GS2_NP_BIG;
+		if (N && bins_env != 0 && getenv("PANGENE_GLOBAL_SORT") == nullptr && (cap_env > 0 || (max_hit > GS2_NP_BIG && max_ctg > 1))) {
+			uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, 0); uint32_t *val = (uint32_t *)c->pool.get(S_VAL_A, 0);
+			const int n_sc = c->n_seg_ctg;
+			int32_t *d_coff = (int32_t *)c->pool.get(S_BINS, sizeof(int4) * ((size_t)n_sc + (size_t)GL + 4)); // (first the contigs' offsets, then the bins: never more bins than contigs)
+			if (!key || !val || !d_coff) return PGA_ERR_NOMEM;
+			hipLaunchKernelGGL(k_zkey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, (const int32_t *)(up + 11 * (size_t)N), N, key, val); // key = contig segment, val = file-order index
+			uint64_t *ks; uint32_t *vs;
+			TRY(radix_sort_pool(c, key, val, N, c->seg_bits, &ks, &vs));
+			hipLaunchKernelGGL(k_zoff, dim3(nblk(n_sc + 1)), dim3(BLOCK), 0, c->st, (const uint64_t *)ks, N, n_sc, d_coff);
+			std::vector<int32_t> coff((size_t)n_sc + 1);
+			HIPCHK(hipMemcpyAsync(coff.data(), d_coff, sizeof(int32_t) * ((size_t)n_sc + 1), hipMemcpyDeviceToHost, c->st));
+			TRY(sync_st(c));
+			int32_t max_c = 0;
+			for (int s = 0; s < n_sc; ++s) max_c = std::max(max_c, coff[(size_t)s + 1] - coff[(size_t)s]);
+			if (max_c <= cap_big) {
+				struct Bin { int32_t start, n, gz, c0, nc; };
+				std::vector<Bin> small, big;
+				int max_nc = 1, np_small = 64, np_big = 64;
+				for (int g = 0; g < GL; ++g) {
+					const int s0 = ctg_base[(size_t)g], s1 = ctg_base[(size_t)g + 1];
+					bool first = true;
+					for (int s = s0; s < s1;) { // as many consecutive contigs as fit a lean bin; a contig beyond that alone in a wide one
+						int e = s, tot = 0;
+						while (e < s1 && (tot + (coff[(size_t)e + 1] - coff[(size_t)e]) <= cap_small || e == s)) tot += coff[(size_t)e + 1] - coff[(size_t)e], ++e;
+						if (tot > 0) {
+							const Bin b = { coff[(size_t)s], tot, (int32_t)((uint32_t)g | (first ? 0x80000000u : 0u)), s - s0, e - s };
+							(tot <= cap_small ? small : big).push_back(b);
+							(tot <= cap_small ? np_small : np_big) = std::max(tot <= cap_small ? np_small : np_big, (tot + 63) & ~63);
+							max_nc = std::max(max_nc, e - s), first = false;
+						}
+						s = e;
+					}
+				}
+				auto by_size = [](const Bin &x, const Bin &y) { return x.n != y.n ? x.n > y.n : x.start < y.start; };
+				std::sort(small.begin(), small.end(), by_size), std::sort(big.begin(), big.end(), by_size);
+				bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_genome_sort2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs2_lds_bytes(GS2_NP_MAX)) == hipSuccess &&
+				          hipFuncSetAttribute(reinterpret_cast<const void *>(k_genome_sort2d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs2_lds_bytes(GS2_NP_BIG)) == hipSuccess;
+				if (!ok) (void)hipGetLastError();
+				int32_t *upc = ok ? (int32_t *)c->pool.get(S_UPLOAD2, sizeof(int32_t) * (size_t)N * 18 + 64) : nullptr;
+				if (ok && upc) {
+					hipLaunchKernelGGL(k_cgroup, dim3(nblk(N)), dim3(BLOCK), 0, c->st, (const int32_t *)up, (const uint32_t *)vs, (int64_t)N, (const int32_t *)c->goff, upc);
+					std::vector<int4> hb;
+					for (const Bin &b : small) hb.push_back(make_int4(b.start, b.n, b.gz, b.c0));
+					for (const Bin &b : big) hb.push_back(make_int4(b.start, b.n, b.gz, b.c0));
+					c->bins = (int4 *)d_coff; // (the offsets have been fetched)
+					if (!hb.empty()) HIPCHK(hipMemcpyAsync(c->bins, hb.data(), sizeof(int4) * hb.size(), hipMemcpyHostToDevice, c->st));
+					HIPCHK(hipStreamSynchronize(c->st)); // (hb is a local)
+					c->bin_on = true, c->up_grouped = upc, c->bin_n_small = (int)small.size(), c->bin_n_big = (int)big.size(), c->bin_np_small = np_small, c->bin_np_big = np_big;
+					c->bin_ctg_bits = bits_for((uint32_t)(max_nc - 1));
+					if (timing) fprintf(stderr, "[pga_create] contig bins: %zu of up to %d hits + %zu of up to %d (largest contig %d hits, at most %d contigs a bin)\n", small.size(), np_small, big.size(), np_big, max_c, max_nc);
+				}
+			}
+		}
 	}
 	HIPCHK(hipMemcpyAsync(c->h_cnt, c->dcnt, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
 	int rc = sync_st(c); // the caller's blocks and tables have been read
@@ -250,10 +327,20 @@ extern "C" int pga_begin(pga_ctx_t *c)
 		*f_gnm = up + 10 * (size_t)N, *f_seg = up + 11 * (size_t)N, *f_gid = up + 12 * (size_t)N, *f_cds = up + 13 * (size_t)N;
 	uint8_t *f_rev = (uint8_t *)(up + 14 * (size_t)N);
 	if (!up) return PGA_ERR_NOMEM;
+	if (c->bin_on) { // contig bins (k_segsort.hpp): both orders, every per-hit constant, the packed records -- a workgroup per bin, its keys in LDS
+		HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->rk, c->flags };
+		GenomeSort gs = { c->up_grouped, (int64_t)N, c->goff, c->ctg_base, c->cs_bits, c->cm_bits, c->bin_ctg_bits, c->bin_np_small, GL,
+		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr, nullptr, c->bins };
+		if (c->bin_n_small) hipLaunchKernelGGL(k_genome_sort2, dim3((unsigned)c->bin_n_small), dim3(GS2_T), gs2_lds_bytes(c->bin_np_small), c->st, gs);
+		if (c->bin_n_big) { GenomeSort g2 = gs; g2.bins = c->bins + c->bin_n_small, g2.np = c->bin_np_big; hipLaunchKernelGGL(k_genome_sort2d, dim3((unsigned)c->bin_n_big), dim3(GS2_T), gs2_lds_bytes(c->bin_np_big), c->st, g2); }
+		HIPCHK(hipMemcpyAsync(c->headpos, c->goff, sizeof(int32_t) * ((size_t)GL + 1), hipMemcpyDeviceToDevice, c->st));
+		c->inv_valid = false;
+		return 0;
+	}
 	if (c->gs_ok) { // one launch: both orders, every per-hit constant, the packed records (k_segsort.hpp)
 		HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->rk, c->flags };
 		GenomeSort gs = { up, (int64_t)N, c->goff, c->ctg_base, c->cs_bits, c->cm_bits, c->ctg_bits, c->gs_np, GL,
-		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr, nullptr };
+		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr, nullptr, nullptr };
 		static const bool gs_prof = getenv("PANGENE_GS_PROF") != nullptr;
 		if (gs_prof) { gs.prof = (long long *)c->pool.get(S_SCRATCH, sizeof(long long) * 32 * (size_t)GL); if (gs.prof) HIPCHK(hipMemsetAsync(gs.prof, 0, sizeof(long long) * 32 * (size_t)GL, c->st)); }
 		if (c->gs2 && !gs_prof) {
@@ -278,21 +365,12 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	}
 	// (the per-hit constants -- genome, segment, gene, CDS length, static flag bits and, when it fits 32 bits, the comparison key -- were
 	// computed once, at the upload: create_impl's k_prepare.  Round 4 ran it again every pass here: 1.2 ms of exon-list walks at 21.9 M hits.)
-	int32_t *rk_f = c->rk_shift >= 0 ? up + 15 * (size_t)N : (int32_t *)c->pool.get(S_TAB_A, sizeof(uint64_t) * (size_t)N);
-	int32_t *head = (int32_t *)c->pool.get(S_HEAD, sizeof(int32_t) * ((size_t)N + 1)), *incl = (int32_t *)c->pool.get(S_SLOT, sizeof(int32_t) * ((size_t)N + 1));
+	int32_t *rk_f = up + 15 * (size_t)N; // the comparison key in 32 bits, or its dense rank over the shard: either way made once per upload (create_impl)
 	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, 0);
 	uint32_t *val = (uint32_t *)c->pool.get(S_VAL_A, 0);
-	if (!up || !rk_f || !head || !incl || !key || !val) return PGA_ERR_NOMEM;
+	if (!up || !key || !val) return PGA_ERR_NOMEM;
 	FileHits f = { f_pid, f_cid, f_rank, f_sori, f_sadj, f_nex, f_offx, f_cs, f_ce, f_cm, f_rev };
-	if (c->rk_shift < 0) hipLaunchKernelGGL(k_score_key, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f_pid, f_sadj, f_gid, c->gene_pref, N, key, val);
 	uint64_t *ks; uint32_t *vs;
-	if (c->rk_shift < 0) { // dense rank of the 64-bit score keys (see k_rank_scatter)
-		TRY(radix_sort_pool(c, key, val, N, c->sc_bits, &ks, &vs));
-		hipLaunchKernelGGL(k_arc_head, dim3(nblk(N)), dim3(BLOCK), 0, c->st, ks, (int64_t)N, head);
-		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
-		device_scan<I32>(InI32{head}, OutInclI32{incl}, N, tile, OpSum{}, I32{0}, c->st);
-		hipLaunchKernelGGL(k_rank_scatter, dim3(nblk(N)), dim3(BLOCK), 0, c->st, ks, vs, incl, N, rk_f);
-	}
 	// X order: pg_hit_sort(g, 0), hit.c:29-64, for every genome at once; stable => ties keep file order
 	key = (uint64_t *)c->pool.get(S_KEY_A, 0), val = (uint32_t *)c->pool.get(S_VAL_A, 0);
 	hipLaunchKernelGGL(k_xkey, dim3(nblk(N)), dim3(BLOCK), 0, c->st, f_seg, f_cs, N, c->cs_bits, key, val);
