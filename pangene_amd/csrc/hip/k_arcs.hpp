@@ -261,9 +261,14 @@ struct XSlots {
 // order (every rank's table arrives sorted by x with distinct keys: binary searches in the other tables, equal keys keep rank order)
 // and, by thread 0, off[r] = entries of ranks < r for the kernels that follow (a table beyond its slot raises the sticky flag: the
 // round, and with it the run, is void), the largest table and the longest pair list seen (the next run's capacities), the ranks' flags.
-__global__ __launch_bounds__(BLOCK) void k_xs_sum_rank(XSlots X, int32_t *seg_cnt, int64_t *off, int64_t *dcnt, int64_t *xstat, uint64_t *key, uint32_t *val)
+__global__ __launch_bounds__(BLOCK) void k_xs_sum_rank(XSlots X, int32_t *seg_cnt, int64_t *off, int64_t *dcnt, int64_t *xstat, uint64_t *key, uint32_t *val, int32_t *stamp = nullptr /* Gate::w of the queued rounds, or NULL */, int round = 0)
 {
 	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i == 0 && stamp) { // some rank marked a hit in this round (header word 3, k_xs_mark): the state of the loop changed for everybody
+		bool any = false;
+		for (int r = 0; r < X.W; ++r) any = any || X.all[r * X.slot_words + 3] != 0;
+		if (any) stamp[1] = round;
+	}
 	if (i < 2 * X.S) {
 		int32_t t = 0;
 		for (int r = 0; r < X.W; ++r) t += X.all[r * X.slot_words + XS_HDR + i];

@@ -17,6 +17,31 @@ struct OutRank {
 	}
 };
 
+// The same ranks per GENOME in one launch: k_rep_fill only ever uses a hit's rank inside its genome (rx[h] - rx[first hit of the genome]), so no
+// carry has to cross a genome and the scan needs no second launch -- one workgroup a genome, 1024 hits a step, the wave ranks by ballots.
+// (rx[first hit of a genome] = 0 here.)  Used while no genome is long enough for its workgroup to become the launch's tail (pga_rep_pos).
+constexpr int RK_T = 1024;
+__global__ __launch_bounds__(RK_T) void k_rank_genome(const uint32_t *flags, const int32_t *goff, int32_t *rx, Gate gate)
+{
+	__shared__ int wtot[2][RK_T / WAVE];
+	if (gate_closed(gate)) return;
+	const int g = blockIdx.x, h0 = goff[g], h1 = goff[g + 1], tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	int carry = 0, par = 0;
+	for (int base = h0; base < h1; base += RK_T, par ^= 1) { // (two sets of wave totals used in turn: one barrier a step)
+		const int i = base + tid;
+		const uint32_t f = i < h1 ? flags[i] : (uint32_t)PGA_F_FLT;
+		const unsigned long long m = __ballot(!(f & (PGA_F_FLT | PGA_F_SHADOW)));
+		if (lane == 0) wtot[par][w] = __popcll(m);
+		__syncthreads();
+		int pre = carry, tot = 0;
+#pragma unroll
+		for (int k = 0; k < RK_T / WAVE; ++k) { const int t = wtot[par][k]; tot += t; if (k < w) pre += t; }
+		if (i < h1) rx[i] = (pre + __popcll(m & lt)) | ((f & F_CSTIE) ? (int32_t)0x80000000 : 0);
+		carry += tot;
+	}
+}
+
 // Position record of (gene, genome): {contig, rank among the walkable hits of the genome, cm} of the gene's LAST walkable hit in
 // the genome's array order (branch.c:22-23 overwrite).  COMPACT (every genome has < 4096 contigs and < 2^20 hits, decided once in
 // create): 8 bytes {cm, local contig << 20 | rank}, half the L2 traffic of pg_n_local, which reads two records per (pair, genome);
@@ -43,7 +68,14 @@ struct RepFill {
 	Gate gate;
 };
 
-// every record "absent" first, as one coalesced fill (round 6).  Rounds 3-5 had the last hit of every (gene, genome) group write the absent records of
+template <int FORM>
+__device__ __forceinline__ void rep_absent(const RepFill &a, int64_t e0, int n)
+{
+	for (int k = 0; k < n; ++k) {
+		if (FORM == RP_COMPACT) ((int2 *)a.rp_out)[e0 + k] = make_int2(0, -1); else ((int4 *)a.rp_out)[e0 + k] = make_int4(-1, 0, 0, 0);
+	}
+}
+// With live lists (CLEARED): every record "absent" first, as one coalesced fill (round 6).  Rounds 3-5 had the last hit of every (gene, genome) group write the absent records of
 // the genomes up to the next group, one thread in a loop -- nothing was cleared, nothing written twice; but once the index holds the live hits
 // only, a gene that lost its vertex has no entry at all and ONE thread wrote the records of all its genomes: 1 250 scattered stores in a row
 // for each of 2 673 genes of the 12.1 M-hit shard, the kernel 0.19 -> ~1 ms.  The fill is 50 MB there: ~15 us.
@@ -56,11 +88,13 @@ __global__ __launch_bounds__(BLOCK) void k_rep_clear(void *rp_out, int64_t n_ent
 	if (FORM == RP_COMPACT) ((int2 *)rp_out)[e] = make_int2(0, -1); else ((int4 *)rp_out)[e] = make_int4(-1, 0, 0, 0);
 }
 
-template <int FORM>
+// CLEARED: k_rep_clear ran first (live lists); otherwise this kernel writes every record itself, the absent ones too (one launch a round less)
+template <int FORM, bool CLEARED>
 __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 {
 	if (gate_closed(a.gate)) return;
 	const int t = blockIdx.x * BLOCK + threadIdx.x;
+	if (!CLEARED && t < a.Q && a.zoff[t] == a.zoff[t + 1]) rep_absent<FORM>(a, (int64_t)t * a.GL, a.GL); // a gene without hits in this shard
 	if (t >= a.NZ) return;
 	const int z = t;
 	// the loads are issued in as few dependent rounds as possible, from 4-byte planes in gene-major order (the kernel is bound by
@@ -74,12 +108,19 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 	const int z0 = a.zoff[g], gj = a.goff[j], cb = a.ctg_base[j], xz = a.zx[z];
 	const int2 st_z = a.zst[z]; // {cm, contig segment}
 	const int64_t e = (int64_t)g * a.GL + j;
-	// (the records of the genomes without a hit of this gene, and of the groups without a walkable hit, are "absent" already: k_rep_clear)
+	// (CLEARED: the records of the genomes without a hit of this gene, and of the groups without a walkable hit, are "absent" already)
+	if (!CLEARED) { // the genomes without a hit of this gene: before the first group, and between this group and the next
+		int gs = z;
+		while (gs > z0 && ((a.zy[gs - 1] & 0x7fffffff) >> 1) == j) --gs;
+		if (gs == z0 && j > 0) rep_absent<FORM>(a, (int64_t)g * a.GL, j);
+		const int jn = gn == g ? (yn >> 1) : a.GL;
+		if (jn > j + 1) rep_absent<FORM>(a, e + 1, jn - j - 1);
+	}
 	int q = z;
 	if (!hx_walk(kb, a.tag)) { // the group's last walkable hit
 		q = z - 1;
 		while (q >= z0 && ((a.zy[q] & 0x7fffffff) >> 1) == j && !hx_walk(a.hbk[q], a.tag)) --q;
-		if (q < z0 || ((a.zy[q] & 0x7fffffff) >> 1) != j) return;
+		if (q < z0 || ((a.zy[q] & 0x7fffffff) >> 1) != j) { if (!CLEARED) rep_absent<FORM>(a, e, 1); return; }
 	}
 	const int h = q == z ? xz : a.zx[q];
 	const int2 st = q == z ? st_z : a.zst[q];
@@ -92,7 +133,7 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 		int ta = h, tb = h + 1;
 		while (ta > lo) { const int4 ap = a.A[ta - 1]; if (ap.y != ah.y || ap.x != ah.x) break; --ta; }
 		while (tb < hi) { const int4 ap = a.A[tb]; if (ap.y != ah.y || ap.x != ah.x) break; ++tb; }
-		const int re = tb < a.N ? (a.rx[tb] & 0x7fffffff) : (a.rx[tb - 1] & 0x7fffffff) + ((a.flags[tb - 1] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1);
+		const int re = tb < hi ? (a.rx[tb] & 0x7fffffff) : (a.rx[tb - 1] & 0x7fffffff) + ((a.flags[tb - 1] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1); // (tb < hi: the ranks may be per genome, k_rank_genome)
 		const int nb = (rxh & 0x7fffffff) - (a.rx[ta] & 0x7fffffff), na = re - (rxh & 0x7fffffff) - 1;
 		if (nb + na > 0) { // rare: walkable hits do share this start
 			bool same_gene = false; // two walkable hits of ONE gene in the group: the representative itself depends on the tie order

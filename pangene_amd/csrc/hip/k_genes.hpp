@@ -427,20 +427,22 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 // (128 threads: a workgroup is a chain of dependent loads whatever its width, and a CU holds 14 of these against 8 of 256 threads -- a shard of
 // 20 000 genes x 137 hits 218 -> 170 us, configs[1] 49.6 -> 47.9; one wave a gene, which the CU holds no more of -- the LDS tables -- 62)
 constexpr int GA_WAVE_NT = 128;
-__global__ __launch_bounds__(GA_WAVE_NT) void k_gene_arcs_wave(GeneArcs a)
+// (a template over its three sizes so that other shapes can be measured side by side: PANGENE_GA_WAVE picks one, arc_round_genes)
+template <int NT, int CAP, int HITS, int CAP_LOG2>
+__global__ __launch_bounds__(NT) void k_gene_arcs_wave_t(GeneArcs a)
 {
-	__shared__ GeneTable<GA_CAP_WAVE, GA_WAVE_HITS> T;
+	__shared__ GeneTable<CAP, HITS> T;
 	if (gate_closed(a.gate)) return;
 	const int g = blockIdx.x, tid = threadIdx.x;
 	const int sid = a.g2s[g], z0 = a.zoff[g], z1 = a.zoff[g + 1];
 	if (sid < 0) { // not a vertex: none of its hits may be walkable (graph.c:111)
-		for (int z = z0 + tid; z < z1; z += GA_WAVE_NT)
+		for (int z = z0 + tid; z < z1; z += NT)
 			if (hx_walk(a.hbk[z], a.tag)) atomicAdd((unsigned long long *)&a.dcnt[3], 1ull), a.dcnt[11] = 1; // ([11]: sticky, for rounds nobody looks at one by one: pga_branch_loop)
 		if (tid == 0) a.big_list[g] = 0;
 		return;
 	}
-	const int cl = a.cap_log2 < 7 ? a.cap_log2 : 7;
-	const bool done = z1 - z0 <= GA_WAVE_HITS && gene_arcs_one<GA_WAVE_NT, GA_CAP_WAVE, GA_WAVE_HITS>(a, T, g, sid, tid, cl);
+	const int cl = a.cap_log2 < CAP_LOG2 ? a.cap_log2 : CAP_LOG2;
+	const bool done = z1 - z0 <= HITS && gene_arcs_one<NT, CAP, HITS>(a, T, g, sid, tid, cl);
 	if (tid == 0) a.big_list[g] = done ? 0 : 1; // many hits, or many neighbours: the second kernel takes it
 }
 
@@ -483,8 +485,10 @@ __global__ __launch_bounds__(BLOCK) void k_arc_compact(const int4 *gmeta, const 
 }
 
 // the same into the rank's slot of a sharded round's all-gather (k_arcs.hpp, XS_HDR): the table, the segment counters and the table's size
-__global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const int32_t *off, int S, const pga_arc_part_t *stage, const int32_t *seg_cnt, int32_t *slot, int64_t arc_cap, const int64_t *dcnt)
+// (gate: a queued round of a sharded run whose own arc round found nothing to do leaves its slot as the round before left it)
+__global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const int32_t *off, int S, const pga_arc_part_t *stage, const int32_t *seg_cnt, int32_t *slot, int64_t arc_cap, const int64_t *dcnt, Gate gate = Gate{nullptr, 0})
 {
+	if (gate_closed(gate)) return;
 	const int lane = threadIdx.x & 63;
 	int32_t *segc = slot + XS_HDR;
 	pga_arc_part_t *arcs = (pga_arc_part_t *)(slot + XS_HDR + xs_seg_words(S));
@@ -495,9 +499,16 @@ __global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const i
 			for (int i = lane; i < n; i += WAVE) arcs[o + i] = stage[m.x + i];
 		if (lane == 0) {
 			segc[sid] = seg_cnt[sid], segc[S + sid] = seg_cnt[S + sid];
-			if (sid == S - 1) { slot[0] = o + n, slot[1] = dcnt[9] != 0, slot[2] = dcnt[3] != 0; for (int t = 3; t < XS_HDR; ++t) slot[t] = 0; } // [1] a hub gene overflowed its LDS table, [2] an invariant was violated
+			if (sid == S - 1) { slot[0] = o + n, slot[1] = dcnt[9] != 0, slot[2] = dcnt[3] != 0; for (int t = 4; t < XS_HDR; ++t) slot[t] = 0; } // ([3]: k_xs_mark) // [1] a hub gene overflowed its LDS table, [2] an invariant was violated
 		}
 	}
+}
+
+// header word 3 of the rank's slot: did this rank raise a hit's weak_br in this round (Gate::w[1] == round)?  The fixed point of the queued rounds
+// (dev_prims.hpp: Gate) is a property of ALL ranks' hits: k_xs_sum_rank ORs the ranks' words and stamps the round for everybody.
+__global__ void k_xs_mark(int32_t *slot, const int32_t *stamp /* Gate::w, or NULL */, int round)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) slot[3] = (stamp && stamp[1] == round) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

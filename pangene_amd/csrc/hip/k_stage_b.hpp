@@ -18,10 +18,14 @@ __global__ __launch_bounds__(BLOCK) void k_post_part(const uint32_t *flags, cons
 	if (rank[h] == 0 && !(flags[h] & PGA_F_FLT)) {
 		int w = nex[h] == 1 ? 0 : 1;
 		atomicAdd(&sums[p], (unsigned long long)(long long)sadj[h]);
-		atomicAdd(&sums[(int64_t)P + p], 1ull);
-		atomicAdd(&sums[(int64_t)(2 + w) * P + p], 1ull);
+		atomicAdd(&sums[(int64_t)(2 + w) * P + p], 1ull); // (the count of hit.c:201 is c[0] + c[1] of hit.c:165: k_post_count adds them up -- one atomic a hit less)
 		atomicAdd(&sums[(int64_t)(4 + w) * P + p], (unsigned long long)(long long)sori[h]);
 	}
+}
+__global__ __launch_bounds__(BLOCK) void k_post_count(unsigned long long *sums, int P)
+{
+	const int p = blockIdx.x * BLOCK + threadIdx.x;
+	if (p < P) sums[(int64_t)P + p] = sums[(int64_t)2 * P + p] + sums[(int64_t)3 * P + p];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_post_apply(uint32_t *flags, const int32_t *pid, const int32_t *nex, int32_t *sdom, int n,

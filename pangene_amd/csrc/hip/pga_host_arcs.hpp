@@ -154,7 +154,9 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	static const int cap_log2 = [] { const char *e = getenv("PANGENE_GENE_TABLE_LOG2"); const int v = e ? atoi(e) : 9; return v < 1 ? 1 : v > 9 ? 9 : v; }();
 	GeneArcs ga = { c->zy, c->zoff, c->hfk, c->hbk, c->hfp, c->hbp, c->g2s, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta,
 	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt, c->gate, (c->gate.w || c->loop_gated) ? c->loopctl + 2 : (int32_t *)nullptr };
-	hipLaunchKernelGGL(k_gene_arcs_wave, dim3((unsigned)c->Q), dim3(GA_WAVE_NT), 0, c->st, ga);
+	// (round 6, measured side by side at configs[1] / human 47 x 20 k, ms per pass: <128 threads, 128 keys, 512 hits> 5.26 / 5.11 -- kept; <64, 64, 256> 5.83 / 4.98;
+	// <128, 64, 256> 5.65 / 5.08; <64, 128, 512> 5.49 / 5.13; <64, 32, 256> 5.90 / 5.05: smaller tables put more genes on a CU and send more of them to the second kernel)
+	hipLaunchKernelGGL((k_gene_arcs_wave_t<GA_WAVE_NT, GA_CAP_WAVE, GA_WAVE_HITS, 7>), dim3((unsigned)c->Q), dim3(GA_WAVE_NT), 0, c->st, ga);
 	hipLaunchKernelGGL(k_gene_arcs_big, dim3((unsigned)std::min(c->Q, 8 * c->n_cu)), dim3(GA_BIG_NT), 0, c->st, ga);
 	if (c->timing_rounds) time_mark(c, &tr, 5, true);
 	if (mail) hipLaunchKernelGGL(k_mail_round, dim3(1), dim3(64), 0, c->st, c->dcnt, c->h_box, h_round_dev ? h_round_dev + 4 * (size_t)S : (int32_t *)nullptr); // invariant / overflow counters for the host; the overflow counter starts again

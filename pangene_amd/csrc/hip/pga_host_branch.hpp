@@ -16,16 +16,25 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
 		if (!rx || !tile) return PGA_ERR_NOMEM;
 		TRY(ensure_half_arcs(c, c->ha_ori < 0 ? 0 : c->ha_ori)); // which hits are walkable, gene-major (normally left by the arc round just before)
-		device_scan<I32>(InWalkX{c->flags}, OutRank{rx, c->flags}, N, tile, OpSum{}, I32{0}, c->st, c->gate); // rank among the walkable hits, cs order
+		static const bool rank_scan = env_has("PANGENE_RANK", "scan"); // (tests: the general scan on shards of short genomes too)
+		if (c->gs_np <= (1 << 15) && !rank_scan) hipLaunchKernelGGL(k_rank_genome, dim3((unsigned)GL), dim3(RK_T), 0, c->st, (const uint32_t *)c->flags, (const int32_t *)c->goff, rx, c->gate); // rank among the walkable hits of the genome, cs order
+		else device_scan<I32>(InWalkX{c->flags}, OutRank{rx, c->flags}, N, tile, OpSum{}, I32{0}, c->st, c->gate); // rank among the walkable hits, cs order
 		RepFill rf = { n_ent, GL, Q, N, c->NL, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl, c->vfirst, c->vbase, c->gate };
-		const unsigned nb = nblk(std::max(c->NL, 1));
-		if (c->rp_form == RP_COMPACT) {
-			if (n_ent) hipLaunchKernelGGL((k_rep_clear<RP_COMPACT>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, (void *)rp, n_ent, c->gate);
-			hipLaunchKernelGGL((k_rep_fill<RP_COMPACT>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+		if (c->live_on) { // the index holds the live hits only: genes and (gene, genome) groups without an entry are many -- their records by one coalesced fill
+			const unsigned nb = nblk(std::max(c->NL, 1));
+			if (c->rp_form == RP_COMPACT) {
+				if (n_ent) hipLaunchKernelGGL((k_rep_clear<RP_COMPACT>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, (void *)rp, n_ent, c->gate);
+				hipLaunchKernelGGL((k_rep_fill<RP_COMPACT, true>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+			} else {
+				if (n_ent) hipLaunchKernelGGL((k_rep_clear<RP_FULL>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, (void *)rp, n_ent, c->gate);
+				if (c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_rep_fill<RP_WIDE, true>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+				else hipLaunchKernelGGL((k_rep_fill<RP_FULL, true>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+			}
 		} else {
-			if (n_ent) hipLaunchKernelGGL((k_rep_clear<RP_FULL>), dim3(nblk(n_ent)), dim3(BLOCK), 0, c->st, (void *)rp, n_ent, c->gate);
-			if (c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_rep_fill<RP_WIDE>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
-			else hipLaunchKernelGGL((k_rep_fill<RP_FULL>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+			const unsigned nb = nblk(std::max(c->NL, Q));
+			if (c->rp_form == RP_COMPACT) hipLaunchKernelGGL((k_rep_fill<RP_COMPACT, false>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+			else if (c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_rep_fill<RP_WIDE, false>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
+			else hipLaunchKernelGGL((k_rep_fill<RP_FULL, false>), dim3(nb), dim3(BLOCK), 0, c->st, rf);
 		}
 	} else if (n_ent) {
 		hipLaunchKernelGGL(k_fill_i32, dim3(nblk(4 * n_ent)), dim3(BLOCK), 0, c->st, (int32_t *)rp, 4 * n_ent, -1); // "absent" in either record form
@@ -206,7 +215,8 @@ static int64_t x_arc_cap(const pga_ctx *c, const pga_loop_xchg_t *x)
 // all-gather, pga_arc_merge and pga_arc_set_current with every count left in device memory
 struct LoopX { const pga_loop_xchg_t *x; int64_t arc_cap, pair_cap, ecap; int32_t *gbuf; int64_t slot_words; pga_arc_part_t *merged; int64_t *xstat, *d_off; };
 
-static int loop_exchange_table(pga_ctx *c, const LoopX &L)
+// local_gate: the gate of this rank's own arc round (it may have found nothing to do: the slot then stands as it is); stamp / round: the loop's fixed-point words
+static int loop_exchange_table(pga_ctx *c, const LoopX &L, Gate local_gate = Gate{nullptr, 0}, int32_t *stamp = nullptr, int round = 0)
 {
 	const int S = c->n_seg, n_vtx = 2 * S, W = L.x->world;
 	const int64_t mcap = (int64_t)W * L.arc_cap;
@@ -220,13 +230,14 @@ static int loop_exchange_table(pga_ctx *c, const LoopX &L)
 	int32_t *slot = (int32_t *)c->pool.get(S_MG_SLOT, sizeof(int32_t) * (size_t)mcap + 64);
 	if (!goff || !tile || !key || !val || !slot || (c->N && (!stage || !gmeta || !seg_cnt))) return PGA_ERR_NOMEM;
 	if (c->N) {
-		device_scan<I32>(InGmeta{gmeta}, OutExclI32{goff}, S, tile, OpSum{}, I32{0}, c->st);
-		hipLaunchKernelGGL(k_xs_compact, dim3(nblk(S, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gmeta, goff, S, stage, seg_cnt, L.gbuf, L.arc_cap, (const int64_t *)c->dcnt);
+		device_scan<I32>(InGmeta{gmeta}, OutExclI32{goff}, S, tile, OpSum{}, I32{0}, c->st, local_gate);
+		hipLaunchKernelGGL(k_xs_compact, dim3(nblk(S, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gmeta, goff, S, stage, seg_cnt, L.gbuf, L.arc_cap, (const int64_t *)c->dcnt, local_gate);
+		hipLaunchKernelGGL(k_xs_mark, dim3(1), dim3(64), 0, c->st, L.gbuf, (const int32_t *)stamp, round);
 	}
 	else HIPCHK(hipMemsetAsync(L.gbuf, 0, sizeof(int32_t) * (size_t)(XS_HDR + xs_seg_words(S)), c->st)); // a rank without hits: an empty table, no counts
 	{ const int rc = L.x->allgather(L.x->user, L.gbuf, L.gbuf + L.slot_words, L.slot_words * (int64_t)sizeof(int32_t)); if (rc) return rc; }
 	XSlots X = { L.gbuf + L.slot_words, L.slot_words, L.arc_cap, W, S };
-	hipLaunchKernelGGL(k_xs_sum_rank, dim3(nblk(std::max<int64_t>(mcap, n_vtx))), dim3(BLOCK), 0, c->st, X, seg_cnt, L.d_off, c->dcnt, L.xstat, key, val);
+	hipLaunchKernelGGL(k_xs_sum_rank, dim3(nblk(std::max<int64_t>(mcap, n_vtx))), dim3(BLOCK), 0, c->st, X, seg_cnt, L.d_off, c->dcnt, L.xstat, key, val, stamp, round);
 	device_scan<I32>(InMgHeadN{key, L.d_off + W}, OutExclI32{slot}, mcap, tile, OpSum{}, I32{0}, c->st);
 	hipLaunchKernelGGL(k_mgx_heads_sum, dim3(nblk(mcap)), dim3(BLOCK), 0, c->st, X, (const uint64_t *)key, (const uint32_t *)val, (const int32_t *)slot, (const int64_t *)(L.d_off + W), L.merged, c->dcnt + 10);
 	CurTable t;
@@ -298,7 +309,7 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	static const bool off = getenv("PANGENE_BRANCH_LOOP_HOST") != nullptr; // (tests: keep the host-driven rounds exercised)
 	const int S = c->n_seg, n_vtx = 2 * S, N = c->N;
 	if (off || n_round <= 0 || par == nullptr || seg_alive == nullptr || N == 0 || S == 0 || c->br_S != S || n_vtx > PO_THREADS * PO_MAX_ITEMS) return 2;
-	if (par->final_on && (x != nullptr || seg_cnt_host == nullptr || ndl_host == nullptr)) return 2;
+	if (par->final_on && (seg_cnt_host == nullptr || ndl_host == nullptr)) return 2;
 	if (x == nullptr ? !(c->arc_deferred && !c->arc_done && c->table_sparse) : (c->table_sparse || c->arc_deferred || x->world < 1 || x->allgather == nullptr || x->allreduce_i32_sum == nullptr)) return 2;
 	uint8_t *alive = (uint8_t *)c->pool.get(S_MISC, (size_t)S + 64);
 	int32_t *ndl = (int32_t *)c->pool.get(S_BR_NDL, sizeof(int32_t) * (size_t)n_vtx + 16);
@@ -353,19 +364,22 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		hipLaunchKernelGGL(k_deg, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, t.vs, t.ve, n_vtx, t.dg);
 		c->br_n = L.ecap;
 	}
+	bool first_x = true; // the first exchange of this call writes the rank's slot whatever the gates say (what the buffer holds from an earlier call is no slot of this layout)
 	if (par->pre_on) { // graph 2 (graph.c:293-296): pg_flt_high_occ on graph 1's table (no branch step has run: n_dist_loci = 0), PG_SET_FILTER(vtx == 0), pg_gen_arc
-		if (x) return 2;
+		// (sharded, round 6: the caller's table came through pga_arc_round_x, so the segment counters in device memory are the global ones and the
+		// degrees those of the merged table -- every rank deletes the same segments)
 		HIPCHK(hipMemsetAsync(ndl, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
 		int32_t *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0), *sg = (int32_t *)c->pool.get(S_BR_SEGGID, 0), *dg = (int32_t *)c->pool.get(S_DEG, 0), *seg_cnt = (int32_t *)c->pool.get(S_SEGCNT, 0);
 		uint8_t *vwk = (uint8_t *)c->pool.get(S_VWK, (size_t)n_vtx + 16);
 		if (!vs || !ve || !sg || !dg || !seg_cnt || !vwk) return PGA_ERR_NOMEM;
 		hipLaunchKernelGGL(k_round_del, dim3(nblk(S)), dim3(BLOCK), 0, c->st, S, (const int32_t *)ndl, par->pre_max_tot_cnt, par->pre_max_degree, par->pre_max_dist_loci, (const int32_t *)sg, c->g2s, vs, ve, dg, seg_cnt, vwk, alive,
-		                   par->final_on ? (int4 *)c->pool.get(S_GMETA, 0) : (int4 *)nullptr);
+		                   (x || par->final_on) ? (int4 *)c->pool.get(S_GMETA, 0) : (int4 *)nullptr);
 		hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1);
 		c->walk_valid = false, c->ha_valid = false;
 		int32_t *sc2, *deg2;
 		TRY(arc_round_genes(c, par->use_ori, &sc2, &deg2, nullptr, false));
 		c->br_n = 2 * (int64_t)N + 2, c->br_S = S, c->br_np = 0;
+		if (x) { TRY(loop_exchange_table(c, L)); c->br_n = L.ecap; first_x = false; }
 	}
 	// The fixed point (dev_prims.hpp: Gate).  Inside this loop the tie orders stand still (the caller asked exact_quiet), so a round that
 	// marks no hit and deletes no segment leaves a state every later round reproduces: their kernels are queued all the same -- the
@@ -373,7 +387,10 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	// as a rule do not.  Sharded runs keep every round: their collectives are queued by the host, and "nothing changed" would have to
 	// hold on every rank.
 	static const bool no_skip = env_has("PANGENE_LOOP", "noskip");
-	const bool gated = x == nullptr && !no_skip && (int64_t)c->round_tag + n_round + 4 < (int64_t)HA_TAG_MAX;
+	// Sharded (round 6): the stamps become a property of all ranks -- deletions are global anyway (every rank holds the merged table), the marks travel
+	// in the header of the round's all-gather (k_xs_mark) and k_xs_sum_rank stamps the round on every rank when any rank marked; a rank's own arc
+	// round follows its own hits (nothing changed here: its slot stands as it is, k_xs_compact leaves), the collectives are queued all the same.
+	const bool gated = !no_skip && (int64_t)c->round_tag + n_round + 4 < (int64_t)HA_TAG_MAX;
 	struct GateScope { pga_ctx *c; ~GateScope() { c->gate = Gate{nullptr, 0}, c->loop_gated = false; } } gate_scope{c}; // (every way out of this function leaves the launches open)
 	c->loop_gated = gated;
 	const uint32_t tag_before = c->round_tag;
@@ -430,10 +447,12 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 			int32_t *seg_cnt, *deg;
 			// (new lists renumber the index: the half-arc records of the last walk mean nothing any more, so this arc round runs whatever the gate says --
 			// it is open anyway when hits were filtered in this round, but the quarter may have gone over several rounds)
-			if (rebuilt) c->gate = Gate{nullptr, 0};
+			// (sharded: so does the first arc round of the call -- the slot it fills must hold THIS rank's counters, and what the caller left in device
+			// memory are the global ones)
+			if (rebuilt || (x && first_x)) c->gate = Gate{nullptr, 0};
 			TRY(arc_round_genes(c, par->use_ori, &seg_cnt, &deg, nullptr, false)); // (no mail: the kernels raise the sticky flag themselves)
 			c->br_n = 2 * (int64_t)N + 2, c->br_S = S, c->br_np = 0;
-			if (x) { TRY(loop_exchange_table(c, L)); c->br_n = L.ecap; }
+			if (x) { TRY(loop_exchange_table(c, L, first_x ? Gate{nullptr, 0} : c->gate, gated ? c->loopctl : (int32_t *)nullptr, r)); c->br_n = L.ecap; first_x = false; }
 		}
 	}
 	c->gate = Gate{nullptr, 0};
@@ -474,6 +493,7 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	}
 	c->br_np_seen = std::max<int64_t>(c->br_np_seen, c->h_cnt[15]);
 	if (getenv("PANGENE_TIMING")) fprintf(stderr, "[pga_branch_loop] counters after %d rounds: invariant %lld, table overflows (last round) %lld, sticky %lld, pairs (last round) %lld of capacity %lld\n", n_round, (long long)c->h_cnt[3], (long long)c->h_cnt[9], (long long)c->h_cnt[11], (long long)c->h_cnt[15], (long long)c->br_cap);
+	if (x && par->final_on) c->cur_tab = L.merged, c->cur_tab_n = c->h_cnt[10], c->table_sparse = false; // the merged table of the last queued arc round is the graph's (pga_arc_table)
 	if (x) {
 		const int32_t *f = (const int32_t *)h_x;
 		c->x_pairs_run = std::max<int64_t>(c->x_pairs_run, h_x[2]), c->x_arcs_run = std::max<int64_t>(c->x_arcs_run, h_x[3]); // the next run's capacities (every round's list travels at its capacity: a margin above what was needed, not more)

@@ -17,18 +17,26 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	const bool z_keep = c->z_valid && (which == 1 || !c->par.check_strand);
 	// The half-arc records of the walk that stands survive too when the override is small: only the overridden contigs are walked again
 	// (k_walk_list), with the tag that stands.  Not with virtual contigs (a piece's neighbours in the walk may lie in the piece next to it).
-	const bool partial = c->ha_valid && c->wrec_valid && z_keep && !c->zposy_stale && c->vfirst == nullptr && n_seg > 0 && seg_off[n_seg] * 8 <= (int64_t)N;
+	// The walk's 32-byte records (k_pack_wrec) stand as well except for the overridden hits: those are packed again here, whether a walk stands or not
+	// (round 5 packed the whole shard again after every override that found no walk standing: 13 of 145 us per pass of the full-size configs[4] set).
+	const bool wrec_ok = c->wrec_valid && z_keep && !c->zposy_stale && n_seg > 0;
+	const bool partial = c->ha_valid && wrec_ok && c->vfirst == nullptr && seg_off[n_seg] * 8 <= (int64_t)N;
 	c->walk_valid = false, c->ha_valid = false, c->yrec_valid = false, c->wrec_valid = false;
 	if (!z_keep) c->z_valid = false;
 	if (n_seg <= 0 || N == 0) return 0;
 	const int64_t T = seg_off[n_seg];
-	if (T == 0) { if (partial) c->ha_valid = true, c->wrec_valid = true; return 0; }
+	if (T == 0) { if (wrec_ok) c->wrec_valid = true; if (partial) c->ha_valid = true; return 0; }
 	auto walk_again = [&](const int32_t *d_pos) -> int { // (after the override's own kernels, on the same stream; d_pos: places in the walk's list -- cm positions, or places in the members' list)
 		int32_t *hzl = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
 		if (!hzl) return PGA_ERR_NOMEM;
-		hipLaunchKernelGGL(k_pack_wrec_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, WrecSrc{c->ylist, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->vfirst, c->vbase}, d_pos, T, c->wrec);
-		hipLaunchKernelGGL(k_walk_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, Walk{c->flags, c->ylist, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, c->ha_ori, c->NL, c->dcnt, hzl, Gate{nullptr, 0}}, d_pos, T);
-		c->ha_valid = true, c->wrec_valid = true, c->zposy_stale = false;
+		if (wrec_ok) {
+			hipLaunchKernelGGL(k_pack_wrec_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, WrecSrc{c->ylist, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->vfirst, c->vbase}, d_pos, T, c->wrec);
+			c->wrec_valid = true, c->zposy_stale = false;
+		}
+		if (partial) {
+			hipLaunchKernelGGL(k_walk_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, Walk{c->flags, c->ylist, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, c->ha_ori, c->NL, c->dcnt, hzl, Gate{nullptr, 0}}, d_pos, T);
+			c->ha_valid = true;
+		}
 		return 0;
 	};
 	const bool live = c->live_on && z_keep; // the lists stand and have to follow the override (an index that is dropped is built again, lists and all)
@@ -69,7 +77,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	if (which == 1) {
 		hipLaunchKernelGGL(k_ov_sety, dim3(nblk(T)), dim3(BLOCK), 0, c->st, d_pos, d_fil, T, c->inv, c->yperm, live ? (const int32_t *)d_lpos : (const int32_t *)nullptr, c->ylist_buf);
 		if (z_keep) c->zposy_stale = true;
-		if (partial) TRY(walk_again(live ? d_lpos : d_pos));
+		if (wrec_ok) TRY(walk_again(live ? d_lpos : d_pos));
 		return 0;
 	}
 	int32_t *tmp = (int32_t *)c->pool.get(S_PERM, sizeof(int32_t) * (OV_PLANES + 13) * (size_t)T + 64);
@@ -85,7 +93,7 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	if (!tile) return PGA_ERR_NOMEM;
 	device_scan<SegMax>(InSegMaxList{c->recA, d_pos}, OutSegMaxList{c->recA, d_pos}, T, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st); // pm follows the new order
 	hipLaunchKernelGGL(k_cstie_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, c->recA, d_pos, T, N, c->flags);
-	if (partial) TRY(walk_again(live ? d_lpos : d_pos));
+	if (wrec_ok) TRY(walk_again(live ? d_lpos : d_pos));
 	return 0;
 }
 

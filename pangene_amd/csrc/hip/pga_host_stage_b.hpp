@@ -8,6 +8,7 @@ extern "C" int pga_post_partials(pga_ctx_t *c, int32_t **max_ori, int64_t **sums
 	zero_multi(c, c->max_ori, sizeof(int32_t) * (size_t)std::max(1, c->P), c->sums, sizeof(int64_t) * 6 * (size_t)std::max(1, c->P));
 	if (c->N) hipLaunchKernelGGL(k_post_part, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->rank, c->sori, c->sadj, c->nex, c->N, c->P,
 	                             c->max_ori, (unsigned long long *)c->sums);
+	if (c->N && c->P) hipLaunchKernelGGL(k_post_count, dim3(nblk(c->P)), dim3(BLOCK), 0, c->st, (unsigned long long *)c->sums, c->P);
 	*max_ori = c->max_ori, *sums = c->sums;
 	return 0; // no wait: a consumer that is not on this stream calls pga_sync first
 }

@@ -964,6 +964,7 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer 
 	}
 	std::vector<int32_t> sc((size_t)S * 2 + 1);
 	ext->deg.assign((size_t)S * 2 + 1, 0);
+	ext->arc_via_x = false;
 	static const bool no_x = std::getenv("PANGENE_SHARDED_LOOP_HOST") != nullptr; // (tests: the host-driven exchange of a sharded run)
 	if (sharded() && !no_x && be->arc_round_x && be->is_device() && ext->x_arc_slot > 0 && S > 0 && route_v(ext) < 3) {
 		// every rank's table in a slot of a capacity all ranks share (no size exchange), merged on the backend, ONE wait
@@ -977,6 +978,7 @@ static int gen_arc(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, bool defer 
 			{ Phase ph(PH_EXACT); BE_CALL(exact_sort(ext, 0), "override_order"); } // graph.c:123
 			for (int32_t i = 0; i < S; ++i) q->seg[i].n_genome = sc[(size_t)i], q->seg[i].tot_cnt = sc[(size_t)S + (size_t)i];
 			ext->cur_arcs = nullptr, q->n_arc = (int32_t)n_arc; // (fetch_arcs asks the backend for the table)
+			ext->arc_via_x = true;
 			return 0;
 		}
 		// 1: void on some rank (all ranks were told), 2: not applicable -- the host-driven exchange below
@@ -1234,7 +1236,7 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	static const bool no_x = std::getenv("PANGENE_SHARDED_LOOP_HOST") != nullptr; // (tests: the host-driven rounds of a sharded run)
 	if (shd && (no_x || !be->is_device())) return 0;
 	if (shd && ext->skip_loop_once) { ext->skip_loop_once = false; return 0; } // the repeated run after status 3
-	if ((pre || fin) && shd) return 0;
+	if (pre && shd && !ext->arc_via_x) return 0; // (sharded: graph 2's tests read the GLOBAL segment counters in device memory: only pga_arc_round_x leaves those)
 	const int n_sorts = 2 * R - 1 + (pre ? 1 : 0) + (fin ? 1 : 0); // of each kind: one pair per pg_mark_branch_flt_hit (branch.c:116,140), one per pg_gen_arc (graph.c:103,123)
 	static const bool dbg = std::getenv("PANGENE_TIMING") != nullptr;
 	bool quiet;
@@ -1326,7 +1328,10 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	// Graphs 2 and 3 as ONE queue when the backend can (pga_branch_loop with its pre-step): graph 1's arc round is left running, the
 	// loop starts with graph 2's pg_flt_high_occ + pg_gen_arc and goes on with the branch rounds -- no wait between graph 1 and round n-2.
 	static const bool no_pre = env_word("PANGENE_LOOP", "nopre"); // (tests: graph 2 host-driven in front of the queued rounds)
-	const bool try_pre = !no_pre && opt->n_branch_flt >= 2 && ext->be->branch_loop != nullptr && !sharded() && route_v(ext) < 3 && trace_path() == nullptr && !ext->no_branch_loop;
+	static const bool no_fin = env_word("PANGENE_LOOP", "nofinal"); // (tests: the last round host-driven behind the queued ones)
+	// (sharded, round 6: the same one queue, behind a graph-1 round that came through pga_arc_round_x -- from the second run over a data set on, when the slot capacity is known)
+	const bool try_pre = !no_pre && opt->n_branch_flt >= 2 && ext->be->branch_loop != nullptr && route_v(ext) < 3 && trace_path() == nullptr && !ext->no_branch_loop &&
+	                     (!sharded() || (ext->be->arc_round_x != nullptr && ext->be->is_device() && ext->x_arc_slot > 0 && std::getenv("PANGENE_SHARDED_LOOP_HOST") == nullptr));
 	BE_CALL(gen_arc(opt, q, ext, try_pre), "gen_arc");
 	BE_CALL(trace_state(ext, "gen_arc", 1), "trace");
 	if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-1 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
@@ -1335,7 +1340,6 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 	bool queued_all = false;
 	ext->seg_renumber.clear();
 	if (try_pre) {
-		static const bool no_fin = env_word("PANGENE_LOOP", "nofinal"); // (tests: the last round host-driven behind the queued ones)
 		if (!no_fin) { // every round and the arc round of the graph that is written
 			const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt, &queued_all, true, true);
 			if (rc) return rc;
@@ -1356,9 +1360,16 @@ static int graph_gen_impl(const pg_opt_t *opt, pg_graph_t *q)
 		BE_CALL(trace_state(ext, "gen_arc", 2), "trace");
 		if (pg_verbose >= 3) std::fprintf(stderr, "[M::%s::%s] round-2 graph: %d genes and %d arcs\n", "pg_graph_gen", stamp(), q->n_seg, q->n_arc);
 		// graph 3: branch filtering (graph.c:300-315)
-		if (opt->n_branch_flt >= 2) { // all rounds but the last one in one go, when the backend can (the last one fills the public fields of pg_seg_t)
-			const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt - 1, &queued);
-			if (rc) return rc;
+		if (opt->n_branch_flt >= 2) { // every round in one go when the backend can (round 6: also behind a host-driven graph 2), or all but the last one
+			if (!no_fin && !no_pre) {
+				const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt, &queued_all, false, true);
+				if (rc) return rc;
+				queued = queued_all;
+			}
+			if (!queued) {
+				const int rc = branch_loop_fast(opt, q, ext, opt->n_branch_flt - 1, &queued);
+				if (rc) return rc;
+			}
 		}
 	}
 	if (queued_all) i_first = opt->n_branch_flt; // nothing left to drive

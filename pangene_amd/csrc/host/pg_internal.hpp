@@ -182,6 +182,7 @@ struct DataExt {
 	bool skip_loop_once = false;       // sharded pga_branch_loop asked for a repeated run because an exchange buffer was too small (status 3): that run is host-driven, later ones queue again
 	int64_t x_arc_slot = 0;            // sharded runs: the largest local arc table of any host-driven round so far, over all ranks
 	bool no_branch_loop = false;       // the queued branch rounds (pga_branch_loop) met something they cannot handle on this data set: host-driven rounds from now on
+	bool arc_via_x = false;            // (sharded) the last pg_gen_arc came through pga_arc_round_x: the backend holds the GLOBAL segment counters and the merged table's degrees
 	bool arc_pending = false;          // a deferred arc round whose host results have not been collected (arc_collect)
 	bool rerun = false;                // pg_rerun_resident(): keep the backend context, skip pack + upload
 	bool read_failed = false;          // a pg_read_paf ran out of memory half way through a file: the data set is not what the files hold
