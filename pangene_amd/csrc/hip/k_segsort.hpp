@@ -44,6 +44,7 @@ struct GenomeSort {
 	// file order inside a contig stands, which is all the tie order needs), a unit is one contiguous range of them and of the X order, and
 	// plane 17 holds each hit's file index.  bins[b] = {first position, hits, genome | bit 31 = the genome's first bin, first contig (local id)}.
 	const int4 *bins;
+	int y_fixup; // k_segsort2.hpp: the cm order by transpositions out of the cs order (gs2_body) -- 0: always by radix passes
 };
 
 struct GsLds { uint16_t *cur, *alt; uint8_t *dig; uint32_t *whist, *stage, *wtot; unsigned long long *head, *tie; int2 *wagg; };

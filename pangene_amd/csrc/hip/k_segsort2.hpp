@@ -15,6 +15,7 @@
 
 constexpr int GS2_T = 1024, GS2_K = 10, GS2_NP_MAX = GS2_K * GS2_T; // 10 240
 constexpr int GS2_K_BIG = 14, GS2_NP_BIG = GS2_K_BIG * GS2_T;        // 14 336
+constexpr int GS2_FIX_IT = 6;                                        // double passes of the cm order's transposition fix-up before the radix passes take over
 
 template <int T, int K>
 __device__ __forceinline__ void gs2_sort_bits(GsLds &L, const int n, const uint32_t (&key)[K], const int bits)
@@ -76,7 +77,33 @@ static inline size_t gs2_lds_bytes(int np)
 	return 2 * (size_t)np + s + (size_t)np / 4 + 256;
 }
 
-template <int T, int K>
+// the transposition passes of the cm order (gs2_body): true = a double pass moved nothing, the order stands
+template <int T>
+__device__ __forceinline__ bool gs2_fixup(uint32_t *yk, uint16_t *cur, volatile uint32_t *flag, const int n)
+{
+	const int tid = threadIdx.x;
+	bool settled = false;
+	for (int it = 0; it < GS2_FIX_IT && !settled; ++it) {
+		bool moved = false;
+		for (int ph = 0; ph < 2; ++ph) {
+			for (int i = 2 * tid + ph; i + 1 < n; i += 2 * T) {
+				const uint32_t ka = yk[i], kb = yk[i + 1];
+				if (ka > kb) { const uint16_t ia = cur[i], ib = cur[i + 1]; yk[i] = kb, yk[i + 1] = ka, cur[i] = ib, cur[i + 1] = ia, moved = true; }
+			}
+			gs_bar();
+		}
+		if (moved) flag[it % 3] = 1;
+		if (tid == 0) flag[(it + 1) % 3] = 0; // (the word of the pass after next: nobody reads it now -- its last readers left two barriers ago)
+		gs_bar();
+		settled = flag[it % 3] == 0;
+	}
+	return settled;
+}
+
+// FIX: the cm order by transpositions out of the cs order where the host asks for it (GenomeSort::y_fixup).  Only the 14-items form is built with it:
+// in the 10-items form -- 64 VGPRs, two workgroups a CU -- the mere presence of the loop cost the kernel 30 spilled registers inlined and a stack
+// frame as a call, 327 -> 535-570 us at 12.1 M hits either way (round 6, profiles/r06e_*).
+template <int T, int K, bool FIX>
 __device__ __forceinline__ void gs2_body(const GenomeSort &a, unsigned char *gs_mem)
 {
 	constexpr int NW = T / WAVE;
@@ -277,7 +304,31 @@ __device__ __forceinline__ void gs2_body(const GenomeSort &a, unsigned char *gs_
 #pragma unroll
 		for (int u = 0; u < K; ++u) W0[u] |= a.cm_bits < 32 ? W1[u] << a.cm_bits : 0u;
 		gs_bar();
-		gs2_sort_bits<T, K>(L, n, W0, a.cm_bits + a.ctg_bits);
+		// Round 6: the cm order is the cs order up to inversions between OVERLAPPING hits (cs_i <= cs_j and cm_i > cm_j: hit i reaches past the start
+		// of j), so it is a few transpositions away from the order the unit is in -- odd-even transposition passes over (key, position) in LDS, stable
+		// (equal keys are never exchanged, so ties keep the X order), until a double pass moves nothing; piles deeper than GS2_FIX_IT double passes
+		// (synth.dense) go on with the radix passes from where the transpositions left them (any permutation is a valid start of a stable LSD sort).
+		bool settled = false;
+		if (FIX && a.y_fixup) {
+			uint32_t *const yk = (uint32_t *)S; // (the staging area is free: 4 np bytes)
+			volatile uint32_t *const flag = L.wtot; // [3] used in turn
+#pragma unroll
+			for (int u = 0; u < K; ++u) { const int x = tid + u * T; if (x < n) yk[x] = W0[u]; }
+			if (tid < 3) flag[tid] = 0;
+			gs_bar();
+			// (the keys need not stay in registers through the passes -- 64 VGPRs are all this kernel has: should the radix passes be needed after
+			// all, the keys come back out of the planes this workgroup has just written: cm and the contig segment in X order)
+			settled = gs2_fixup<T>(yk, L.cur, flag, n);
+			if (!settled) {
+				__syncthreads(); // (the stores of the two planes have to have landed)
+#pragma unroll
+				for (int u = 0; u < K; ++u) {
+					const int x = tid + u * T;
+					W0[u] = x < n ? ((uint32_t)a.o.cm[gb + x] | (a.cm_bits < 32 ? ((uint32_t)(a.o.seg[gb + x] - cb) - (uint32_t)c0) << a.cm_bits : 0u)) : 0u;
+				}
+			}
+		}
+		if (!settled) gs2_sort_bits<T, K>(L, n, W0, a.cm_bits + a.ctg_bits);
 	} else {
 		gs_bar();
 		gs2_sort_bits<T, K>(L, n, W0, a.cm_bits);
@@ -291,12 +342,12 @@ __device__ __forceinline__ void gs2_body(const GenomeSort &a, unsigned char *gs_
 __global__ __launch_bounds__(GS2_T, 8) void k_genome_sort2(GenomeSort a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char gs2_mem[];
-	gs2_body<GS2_T, GS2_K>(a, gs2_mem);
+	gs2_body<GS2_T, GS2_K, false>(a, gs2_mem);
 }
 // up to 14 items per thread (np <= 14 336: what the largest genomes of the bacterial sets need), 128 VGPRs: one workgroup per CU like the
 // round-3 kernel, but 6 radix passes instead of 8 at these sizes and no patch-up pass
 __global__ __launch_bounds__(GS2_T, 4) void k_genome_sort2d(GenomeSort a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char gs2d_mem[];
-	gs2_body<GS2_T, GS2_K_BIG>(a, gs2d_mem);
+	gs2_body<GS2_T, GS2_K_BIG, true>(a, gs2d_mem);
 }

@@ -302,6 +302,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	return rc;
 }
 
+static int y_fixup_on() { static const int on = [] { const char *e = getenv("PANGENE_Y_FIXUP"); return (e && *e == '0') ? 0 : 1; }(); return on; } // (k_segsort2.hpp: the cm order out of the cs order by transpositions; 0 = by radix passes, as rounds 3-5)
 // per-hit constants in file order, X order (sort + gather), running max of ce, Y order; resets all state
 extern "C" int pga_begin(pga_ctx_t *c)
 {
@@ -330,7 +331,7 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	if (c->bin_on) { // contig bins (k_segsort.hpp): both orders, every per-hit constant, the packed records -- a workgroup per bin, its keys in LDS
 		HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->rk, c->flags };
 		GenomeSort gs = { c->up_grouped, (int64_t)N, c->goff, c->ctg_base, c->cs_bits, c->cm_bits, c->bin_ctg_bits, c->bin_np_small, GL,
-		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr, nullptr, c->bins };
+		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr, nullptr, c->bins, y_fixup_on() };
 		if (c->bin_n_small) hipLaunchKernelGGL(k_genome_sort2, dim3((unsigned)c->bin_n_small), dim3(GS2_T), gs2_lds_bytes(c->bin_np_small), c->st, gs);
 		if (c->bin_n_big) { GenomeSort g2 = gs; g2.bins = c->bins + c->bin_n_small, g2.np = c->bin_np_big; hipLaunchKernelGGL(k_genome_sort2d, dim3((unsigned)c->bin_n_big), dim3(GS2_T), gs2_lds_bytes(c->bin_np_big), c->st, g2); }
 		HIPCHK(hipMemcpyAsync(c->headpos, c->goff, sizeof(int32_t) * ((size_t)GL + 1), hipMemcpyDeviceToDevice, c->st));
@@ -340,7 +341,7 @@ extern "C" int pga_begin(pga_ctx_t *c)
 	if (c->gs_ok) { // one launch: both orders, every per-hit constant, the packed records (k_segsort.hpp)
 		HitArrays o = { c->fidx, c->gnm, c->seg, c->pid, c->gid, c->cs, c->ce, c->cm, c->cds, c->nex, c->offx, c->sori, c->sadj, c->rank, c->sdom, c->pdom, c->pdom0, c->rk, c->flags };
 		GenomeSort gs = { up, (int64_t)N, c->goff, c->ctg_base, c->cs_bits, c->cm_bits, c->ctg_bits, c->gs_np, GL,
-		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr, nullptr, nullptr };
+		                  o, c->yperm, c->headpos, c->recA, c->recB, c->recC, nullptr, nullptr, nullptr, y_fixup_on() };
 		static const bool gs_prof = getenv("PANGENE_GS_PROF") != nullptr;
 		if (gs_prof) { gs.prof = (long long *)c->pool.get(S_SCRATCH, sizeof(long long) * 32 * (size_t)GL); if (gs.prof) HIPCHK(hipMemsetAsync(gs.prof, 0, sizeof(long long) * 32 * (size_t)GL, c->st)); }
 		if (c->gs2 && !gs_prof) {
