@@ -75,6 +75,19 @@ def _pmc_traffic(hits_per_launch, flavour):
     return None
 
 
+def _k2_pmc(hits):
+    """HBM bytes per launch of the arc round's kernels on a shard of `hits` hits (profiles/k2_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes, profiles/tools/k2_traffic.py), while k_genes.hpp is the source they were measured with; {} otherwise."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "k2_pmc_traffic.json")) as f:
+            t = json.load(f)
+        with open(os.path.join(ROOT, "pangene_amd", "csrc", "hip", "k_genes.hpp"), "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()[:16]
+        return {e["kernel"]: int(e["bytes_per_launch"]) for e in t if e.get("hits_of_the_shard") == hits and e.get("k_genes_sha16") == sha}
+    except Exception:
+        return {}
+
+
 def _gen_range(args):
     kind, base, a, b, G, proteins, seed = args
     from pangene_amd import synth
@@ -417,6 +430,15 @@ def main():
             bw = 48 + 40 * w  # yperm + flag word + the two Y records + the gene-major position in; two 4-byte keys and two 16-byte payloads per walkable hit out
             out["walk_scan"] = {"what": "the walk scan alone (reduce / sums / output step): the time-dominant kernels of a pass", "ms": round(ev[6][0], 4), "algorithmic_bytes_per_hit": round(bw, 1),
                                 "achieved": round(bw * hits / (ev[6][0] * 1e-3) / 1e9, 1), "frac": round(bw * hits / (ev[6][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            pmc = _k2_pmc(hits)  # what the counters saw of these kernels (mean over the launches of a pass), over the walk's own time
+            if "walk_scan" in pmc:
+                out["walk_scan"]["traffic"] = pmc["walk_scan"]
+                out["walk_scan"]["frac_by_counters"] = round(pmc["walk_scan"] / (ev[6][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if pmc:
+                out["traffic_by_kernel"] = {k: v for k, v in pmc.items()}
+                tot = sum(v for k, v in pmc.items() if k in ("walk_scan", "gene_arcs_big", "gene_arcs_wave", "sweep0"))
+                out["traffic"] = tot
+                out["frac_by_counters"] = round(tot / (ev[5][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         return out
 
     roof = roofline_of(d, nh.value, ne.value, "the bench workload itself (fits the 256 MiB Infinity Cache: an L3 figure)")

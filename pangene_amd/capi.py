@@ -1,8 +1,8 @@
 """ctypes bindings of the C ABI in include/pangene_amd.h (the pangene.h-compatible surface).
 
-Nothing here computes: every call goes into libpangene_amd.so (HIP backend).  `load(oracle_host=True)`
-loads tests/_build/libpangene_oraclehost.so instead -- the same host driver linked against the plain-C
-oracle -- and is used by tests only (checker), never by the product path.
+Nothing here computes: every call goes into libpangene_amd.so (HIP backend).  (The checker build of the same host
+driver -- linked against the plain-C oracle -- is loaded by tests/oracle_host.py, which hands its own path to load();
+nothing in this package knows where it is.)
 """
 from __future__ import annotations
 
@@ -14,7 +14,6 @@ from typing import List, Sequence
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_HIP = os.path.join(ROOT, "pangene_amd", "lib", "libpangene_amd.so")
-LIB_ORACLE_HOST = os.path.join(ROOT, "tests", "_build", "libpangene_oraclehost.so")
 
 PG_F_WRITE_BED_RAW, PG_F_WRITE_BED_WALK, PG_F_WRITE_BED_FLAG, PG_F_WRITE_NO_WALK = 0x1, 0x2, 0x4, 0x8
 PG_F_WRITE_VTX_SEL, PG_F_FRAG_MODE, PG_F_NO_JOINT_PSEUDO, PG_F_ORI_FOR_BRANCH = 0x10, 0x20, 0x40, 0x80
@@ -87,15 +86,16 @@ _API_HIP_ONLY = {
 }
 
 
-def load(oracle_host: bool = False) -> C.CDLL:
-    path = LIB_ORACLE_HOST if oracle_host else LIB_HIP
+def load(path: str = LIB_HIP) -> C.CDLL:
+    """The product library (default), or another build of the pangene.h surface at `path` (tests: the checker build)."""
+    hip = os.path.abspath(path) == os.path.abspath(LIB_HIP)
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first" % path)
     lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
     for name, (res, args) in _API.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if not oracle_host:
+    if hip:
         for name, (res, args) in _API_HIP_ONLY.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args

@@ -60,7 +60,22 @@ constexpr int RP_FULL = 0, RP_COMPACT = 1, RP_WIDE = 2;
 // the canonical order).  Representatives with nb + na > 0 carry bit 31 of their cm word and the interval nb << 16 | na (side
 // table iv[] in the compact form); k_n_local raises the hazard where it matters.  Two walkable hits of ONE gene in a group
 // (-S: opposite strands) make the choice of the representative itself order-dependent (branch.c:22-23): hazard at once.
+// The (contig, cs) tie groups of the cs order are static -- a cs override only permutes hits INSIDE a group --, so where a member's group begins and
+// ends is looked up once per pass here instead of in every round by every representative (k_rep_fill walked the 16-byte records to either side: on
+// isoform-rich data nearly every live hit shares its start with five filtered isoforms -- ~300 us a round at the 21.9 M hits of configs[4]).
+__global__ __launch_bounds__(BLOCK) void k_tie_bounds(const int4 *A, const uint32_t *flags, int n, int2 *tg)
+{
+	const int x = blockIdx.x * BLOCK + threadIdx.x;
+	if (x >= n || !(flags[x] & F_CSTIE)) return;
+	const int4 ah = A[x]; // {cs, seg, ce, pm}
+	int ta = x, tb = x + 1;
+	while (ta > 0) { const int4 ap = A[ta - 1]; if (ap.y != ah.y || ap.x != ah.x) break; --ta; }
+	while (tb < n) { const int4 ap = A[tb]; if (ap.y != ah.y || ap.x != ah.x) break; ++tb; }
+	tg[x] = make_int2(ta, tb);
+}
+
 struct RepFill {
+	const int2 *tg; // [N] k_tie_bounds (members of a tie group only)
 	int64_t n_ent; int GL, Q, N /* hits of the shard (X positions) */, NZ /* entries of the gene-major index: N, or the members of the live lists */; const int32_t *zx, *zy, *zg; const int2 *zst; const int32_t *zoff; const uint32_t *hbk; uint32_t tag;
 	const int4 *A; const int32_t *gid; const uint32_t *flags; const int32_t *rx, *goff, *ctg_base;
 	void *rp_out; int32_t *iv; int64_t *dcnt; int32_t *hz_list;
@@ -128,11 +143,9 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 	const int rxh = a.rx[h], r = (rxh & 0x7fffffff) - (a.rx[gj] & 0x7fffffff);
 	int ivl = 0;
 	if (rxh < 0) { // member of a static tie group [ta, tb): its walkable members on either side, from the walkable ranks at the group's ends
-		const int lo = gj, hi = a.goff[j + 1];
-		const int4 ah = a.A[h]; // {cs, seg, ce, pm}
-		int ta = h, tb = h + 1;
-		while (ta > lo) { const int4 ap = a.A[ta - 1]; if (ap.y != ah.y || ap.x != ah.x) break; --ta; }
-		while (tb < hi) { const int4 ap = a.A[tb]; if (ap.y != ah.y || ap.x != ah.x) break; ++tb; }
+		const int hi = a.goff[j + 1];
+		const int2 tgb = a.tg[h];
+		const int ta = tgb.x, tb = tgb.y; // (a contig never crosses a genome: gj <= ta, tb <= hi)
 		const int re = tb < hi ? (a.rx[tb] & 0x7fffffff) : (a.rx[tb - 1] & 0x7fffffff) + ((a.flags[tb - 1] & (PGA_F_FLT | PGA_F_SHADOW)) ? 0 : 1); // (tb < hi: the ranks may be per genome, k_rank_genome)
 		const int nb = (rxh & 0x7fffffff) - (a.rx[ta] & 0x7fffffff), na = re - (rxh & 0x7fffffff) - 1;
 		if (nb + na > 0) { // rare: walkable hits do share this start

@@ -19,7 +19,8 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		static const bool rank_scan = env_has("PANGENE_RANK", "scan"); // (tests: the general scan on shards of short genomes too)
 		if (c->gs_np <= (1 << 15) && !rank_scan) hipLaunchKernelGGL(k_rank_genome, dim3((unsigned)GL), dim3(RK_T), 0, c->st, (const uint32_t *)c->flags, (const int32_t *)c->goff, rx, c->gate); // rank among the walkable hits of the genome, cs order
 		else device_scan<I32>(InWalkX{c->flags}, OutRank{rx, c->flags}, N, tile, OpSum{}, I32{0}, c->st, c->gate); // rank among the walkable hits, cs order
-		RepFill rf = { n_ent, GL, Q, N, c->NL, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl, c->vfirst, c->vbase, c->gate };
+		if (!c->tg_valid) { hipLaunchKernelGGL(k_tie_bounds, dim3(nblk(N)), dim3(BLOCK), 0, c->st, (const int4 *)c->recA, (const uint32_t *)c->flags, N, c->tg); c->tg_valid = true; }
+		RepFill rf = { c->tg, n_ent, GL, Q, N, c->NL, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl, c->vfirst, c->vbase, c->gate };
 		if (c->live_on) { // the index holds the live hits only: genes and (gene, genome) groups without an entry are many -- their records by one coalesced fill
 			const unsigned nb = nblk(std::max(c->NL, 1));
 			if (c->rp_form == RP_COMPACT) {

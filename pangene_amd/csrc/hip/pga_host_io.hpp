@@ -235,13 +235,15 @@ extern "C" int pga_reserve(int64_t n_hit, int64_t n_exon, int32_t n_prot, int32_
 	static const bool timing = getenv("PANGENE_TIMING") != nullptr;
 	timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
 	int made = 0;
+	void *mine[2] = { nullptr, nullptr }; // what this call has put into the cache, or found there fitting: not to be evicted by its own second block
 	{ std::lock_guard<std::mutex> lk(g_dev_mu); ++g_dev_reserving; }
 	struct Done { ~Done() { { std::lock_guard<std::mutex> lk(g_dev_mu); --g_dev_reserving; } g_dev_cv.notify_all(); } } done;
 	for (int k = 1; k >= 0; --k) { // (the larger one first)
 		{
 			std::lock_guard<std::mutex> lk(g_dev_mu);
 			bool have = false;
-			for (const DevBlock &b : g_dev_cache) have = have || (b.dev == cur_dev() && b.cap >= want[k] && b.cap <= 2 * want[k] + ((size_t)64 << 20));
+			for (const DevBlock &b : g_dev_cache)
+				if (!have && b.p != mine[1 - k] && b.dev == cur_dev() && b.cap >= want[k] && b.cap <= 2 * want[k] + ((size_t)64 << 20)) have = true, mine[k] = b.p;
 			if (have) continue;
 		}
 		const size_t padded = (want[k] + want[k] / 8 + ((size_t)64 << 20) - 1) & ~(((size_t)64 << 20) - 1);
@@ -249,13 +251,14 @@ extern "C" int pga_reserve(int64_t n_hit, int64_t n_exon, int32_t n_prot, int32_
 		if (hipMalloc(&q, padded) != hipSuccess) { (void)hipGetLastError(); continue; }
 		++made;
 		std::lock_guard<std::mutex> lk(g_dev_mu);
-		if (g_dev_cache.size() >= 2) { // the cache holds one context's worth: the smallest block that is not the one just asked for makes room
-			size_t small = 0;
-			for (size_t i = 1; i < g_dev_cache.size(); ++i) if (g_dev_cache[i].cap < g_dev_cache[small].cap) small = i;
-			(void)hipFree(g_dev_cache[small].p);
-			g_dev_cache.erase(g_dev_cache.begin() + (long)small);
+		if (g_dev_cache.size() >= 2) { // the cache holds one context's worth: the smallest block that is not one of this call's makes room
+			size_t small = (size_t)-1;
+			for (size_t i = 0; i < g_dev_cache.size(); ++i)
+				if (g_dev_cache[i].p != mine[0] && g_dev_cache[i].p != mine[1] && (small == (size_t)-1 || g_dev_cache[i].cap < g_dev_cache[small].cap)) small = i;
+			if (small != (size_t)-1) { (void)hipFree(g_dev_cache[small].p); g_dev_cache.erase(g_dev_cache.begin() + (long)small); }
 		}
 		g_dev_cache.push_back(DevBlock{q, padded, cur_dev()});
+		mine[k] = q;
 	}
 	if (timing) { timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); fprintf(stderr, "[pga_reserve] %lld hits: %.1f + %.1f GB asked for, %d block(s) allocated in %.1f ms\n", (long long)n_hit, want[0] / 1073741824.0, want[1] / 1073741824.0, made, ((t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9) * 1e3); }
 	return 0;

@@ -23,7 +23,7 @@ static int plan_persistent(pga_ctx *c)
 	TRY(dalloc(c, &c->eoff, GL + 1)); TRY(dalloc(c, &c->woff, GL + 1));
 	TRY(dalloc(c, &c->zx, N)); TRY(dalloc(c, &c->zy, N)); TRY(dalloc(c, &c->zg, N)); TRY(dalloc(c, &c->zst, N)); TRY(dalloc(c, &c->zpos, N)); TRY(dalloc(c, &c->wrec, 2 * (size_t)N)); TRY(dalloc(c, &c->zoff, (size_t)c->Q + 2));
 	TRY(dalloc(c, &c->hfk, N)); TRY(dalloc(c, &c->hbk, N)); TRY(dalloc(c, &c->hfp, N)); TRY(dalloc(c, &c->hbp, N));
-	TRY(dalloc(c, &c->lx, (size_t)N + 1)); TRY(dalloc(c, &c->ylist_buf, N)); TRY(dalloc(c, &c->live_cnt, LIVE_CNT_N));
+	TRY(dalloc(c, &c->lx, (size_t)N + 1)); TRY(dalloc(c, &c->ylist_buf, N)); TRY(dalloc(c, &c->live_cnt, LIVE_CNT_N)); TRY(dalloc(c, &c->tg, N));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q)); TRY(dalloc(c, &c->hrank, c->P));
 	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
 	return 0;
@@ -307,6 +307,7 @@ static int y_fixup_on() { static const int on = [] { const char *e = getenv("PAN
 extern "C" int pga_begin(pga_ctx_t *c)
 {
 	c->yrec_valid = false, c->wrec_valid = false, c->z_valid = false, c->zposy_stale = false;
+	c->tg_valid = false;
 	c->live_on = false, c->NL = c->N, c->ylist = c->yperm, c->live_hint = -1; // (the flag words are written afresh: no F_MEMBER survives)
 	const int N = c->N, GL = c->n_genome;
 	c->walk_valid = false, c->ha_valid = false;

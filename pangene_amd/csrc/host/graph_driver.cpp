@@ -214,15 +214,18 @@ static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 // edited between pg_read_paf and pg_post_process (the reference reads g->hit at post-process time, graph.c:7-32): a changed hit or
 // exon count, or a change in ANY field of ANY record that the pack carries, makes the block stale and it is packed again.  (Round 4
 // sampled every 257th record; one pass over the records costs a fraction of the pack it may save -- four independent multiply chains
-// keep it at memory speed -- and an edit can no longer slip through.)
+// keep it at memory speed.  A 64-bit hash, not a proof: an edit is missed with probability ~2^-64; genomes whose records a sync_host has
+// already moved into cs order are not compared -- their pack was made from the order the signature was taken in.)
 static uint64_t genome_signature(const pg_genome_t *g)
 {
-	uint64_t h[4] = { 1469598103934665603ull ^ (uint64_t)(uint32_t)g->n_hit, 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)g->n_exon, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull };
+	uint64_t h[4] = { 1469598103934665603ull ^ (uint64_t)(uint32_t)g->n_hit, 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)g->n_exon, 0xc2b2ae3d27d4eb4full ^ (uint64_t)(uint32_t)g->n_ctg, 0x165667b19e3779f9ull };
 	for (int32_t i = 0; i < g->n_hit; ++i) {
 		const pg_hit_t &a = g->hit[i];
 		uint64_t &x = h[i & 3];
 		x = (x ^ ((uint64_t)(uint32_t)a.pid << 32 | (uint32_t)a.cid)) * 1099511628211ull;
-		x = (x ^ (uint64_t)a.cs ^ (uint64_t)a.ce << 21 ^ (uint64_t)a.cm << 42) * 1099511628211ull;
+		x = (x ^ (uint64_t)a.cs) * 1099511628211ull; // (each 64-bit coordinate through a multiply of its own: shifted into one word they aliased -- cs bit 21 with ce bit 0)
+		x = (x ^ (uint64_t)a.ce) * 0x9e3779b97f4a7c15ull;
+		x = (x ^ (uint64_t)a.cm) * 1099511628211ull;
 		x = (x ^ ((uint64_t)(uint32_t)a.score_adj << 32 | (uint32_t)a.score_ori)) * 1099511628211ull;
 		x = (x ^ ((uint64_t)(uint32_t)a.off_exon << 32 | (uint32_t)a.n_exon << 8 | (uint32_t)a.rev << 7 | ((uint32_t)(a.rank & 0x7f) ^ (uint64_t)(uint32_t)a.rank << 40))) * 1099511628211ull;
 	}
@@ -436,7 +439,10 @@ void free_packs(DataExt *ext, bool wait)
 	}
 	auto drop = [](std::vector<HostSlab> pl, std::vector<GenomePack> pk) { for (HostSlab &s : pl) std::free(s.p); pk.clear(); };
 	if (wait || (plain.empty() && old_packs.size() < 64)) { drop(std::move(plain), std::move(old_packs)); return; }
-	std::thread(drop, std::move(plain), std::move(old_packs)).detach(); // (it owns what it frees; nothing else refers to it)
+	// (a helper thread owns what it frees; nothing else refers to it.  At the thread limit std::thread throws: free here then -- an exception must
+	// not cross the extern "C" entry points above this)
+	try { std::thread(drop, plain, old_packs).detach(); }
+	catch (const std::system_error &) { drop(std::move(plain), std::move(old_packs)); }
 }
 
 static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
@@ -1070,7 +1076,8 @@ static int fetch_arcs(pg_graph_t *q, DataExt *ext)
 		const void *view = nullptr;
 		BE_CALL(ext->be->fetch_later(ext->ctx, ext->cur_arcs, sizeof(pga_arc_part_t) * n_part, &view), "fetch_later");
 		BE_CALL(ext->be->sync(ext->ctx), "sync");
-		part = (const pga_arc_part_t *)view;
+		part = (const pga_arc_part_t *)view; // LIFETIME: the backend's staging area -- valid until the next fetch_later (pangene_hip.h).  The conversion loop below
+		// makes NO backend call; whoever adds one has to copy the table out first.
 	}
 	if ((int64_t)n_part > q->m_arc) {
 		q->m_arc = (int32_t)n_part + ((int32_t)n_part >> 1) + 16;

@@ -3,6 +3,7 @@
 #   stage tests   the whole `pytest -m gpu` suite (log tail + wall time) and the default `python bench.py` line
 #   stage stats   rocprofv3 --kernel-trace --stats of the bench workload, the 12 M-hit shard and the sharded route (forced exchange)
 #   stage pmc     FETCH_SIZE / WRITE_SIZE passes: K1 per shard size and flavour (k1_pmc_traffic.json), every kernel of the 12 M-hit shard
+#   stage pmc2    FETCH_SIZE / WRITE_SIZE of the arc round's kernels on the 12 M-hit shard (k2_pmc_traffic.json for bench.py's roofline.k2.*.frac_by_counters) + the per-kernel table
 #   stage extra   configs[2] stand-in, fresh-seed HIP-vs-oracle sweep, two ranks sharing the GPU over gloo
 #   stage human   rocprofv3 --kernel-trace --stats with the human-shaped leg left in
 #   stage cal     calibration of FETCH_SIZE / WRITE_SIZE with kernels of known byte counts (profiles/tools/calibrate.py)
@@ -44,6 +45,14 @@ pmc1|pmc)
 	python profiles/tools/pmc_traffic.py $out/prof_fetch $out/prof_write 12121149 > $out/${tag}_pmc_traffic_big_shard_1250x5k.txt
 	rm -rf $out/prof_fetch $out/prof_write
 	cat $out/k1_pmc_traffic.json; head -n 30 $out/${tag}_pmc_traffic_big_shard_1250x5k.txt;;
+pmc2)
+	B="python bench.py $Q --genomes-per-gpu 1250 --steps 1 --warmup 0"
+	rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/prof_fetch -o f -- $B > /dev/null 2>&1
+	rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/prof_write -o w -- $B > /dev/null 2>&1
+	python profiles/tools/pmc_traffic.py $out/prof_fetch $out/prof_write 12121149 > $out/${tag}_pmc_traffic_big_shard_1250x5k.txt
+	python profiles/tools/k2_traffic.py $out/prof_fetch $out/prof_write 12121149 > $out/k2_pmc_traffic.json
+	rm -rf $out/prof_fetch $out/prof_write
+	cat $out/k2_pmc_traffic.json; head -n 30 $out/${tag}_pmc_traffic_big_shard_1250x5k.txt;;
 extra)
 	python bench.py --workload human47 --no-cpu-baseline --roofline-genomes 0 --human-genomes 0 --no-extra-legs --steps 5 --warmup 2 > $out/${tag}_bench_human47.json 2>/dev/null
 	( echo "# python tests/fuzz_hip_vs_oracle.py 7600 ${FUZZ_SEEDS:-16}  (HIP vs oracle backend on fresh seeds: fuzz / bacterial / human-shaped / mutated sets, both tie-order modes, 12 option variants)"; timeout 900 python tests/fuzz_hip_vs_oracle.py 7600 ${FUZZ_SEEDS:-16} 2>&1 | grep -v "^\[" | tail -n 5 ) > $out/${tag}_fuzz_sweep.txt

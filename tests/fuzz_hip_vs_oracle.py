@@ -5,8 +5,9 @@ on any); tests/test_hip_parity.py runs a bounded slice of it inside `pytest -m g
     python tests/fuzz_hip_vs_oracle.py [first_seed] [n_seeds]"""
 import ctypes as C, hashlib, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from pangene_amd import capi, synth
+import oracle_host
 
 VARIANTS = [[], ["-p0", "-a1"], ["-S"], ["-F"], ["-E"], ["-b", "0.2", "-B", "0.1", "-y", "0.3"], ["--bed=flag"], ["-f", "0.2"],
             ["-D", "300", "-C", "2"], ["-D", "1000", "-C", "1", "-p0", "-a1"], ["-D", "600", "-C", "3", "-F"], ["-S", "-D", "600", "-C", "3"]]
@@ -60,7 +61,7 @@ def sweep(hip, ora, first, n, base, variants=VARIANTS, modes=(1, 2), human=True,
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    hip, ora = capi.load(), capi.load(oracle_host=True)
+    hip, ora = capi.load(), oracle_host.load()
     for lib in (hip, ora):
         C.c_int.in_dll(lib, "pg_verbose").value = 0
     tot, bad = sweep(hip, ora, first, n, tempfile.mkdtemp(prefix="pg_fuzz_"), log=lambda m: print(m, flush=True))

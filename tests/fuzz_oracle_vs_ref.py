@@ -9,8 +9,9 @@ Prints one line per mismatch and a summary; exit code 1 on any mismatch.
 Needs /root/reference to have been compiled into oracle/_ref (this container; `make -C oracle ref`)."""
 import ctypes as C, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from pangene_amd import capi, synth
+import oracle_host
 
 VARIANTS = [[], ["-p0", "-a1"], ["-S"], ["-D", "300", "-C", "2"], ["-D", "1000", "-C", "1", "-p0", "-a1"], ["-D", "600", "-C", "3", "-F"],
             ["-S", "-D", "600", "-C", "3"]]
@@ -18,7 +19,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
 
 
 def sweep(first, n, modes=(1, 2), variants=VARIANTS, shapes=(False, True), verbose=True):
-    ora = capi.load(oracle_host=True)
+    ora = oracle_host.load()
     C.c_int.in_dll(ora, "pg_verbose").value = 0
     bad, tot = [], 0
     with tempfile.TemporaryDirectory(prefix="pg_fuzz_ref_") as base:

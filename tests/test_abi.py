@@ -10,6 +10,7 @@ import tempfile
 import pytest
 
 from conftest import ROOT, golden_files
+import oracle_host  # tests/oracle_host.py: the checker build of the host driver
 
 SIZES = {"pg_opt_t": 128, "pg_hit_t": 88, "pg_exon_t": 8, "pg_prot_t": 32, "pg_gene_t": 16, "pg_ctg_t": 16, "pg_genome_t": 56,
          "pg_data_t": 72, "pg_seg_t": 32, "pg_arc_t": 32, "pg_graph_t": 56, "pg128_t": 16, "pga_arc_part_t": 40}
@@ -106,7 +107,7 @@ def test_device_layout_limits_are_reported_not_asserted(tmp_path):
     graph, never as an abort or a silent truncation."""
     import ctypes as C
     from pangene_amd import capi
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     big = 3_000_000_000
     p = tmp_path / "big.paf"
@@ -156,7 +157,7 @@ def test_in_place_edit_between_read_and_post_process_is_seen(built, tmp_path):
                     ("n_gene", C.c_int32), ("m_gene", C.c_int32), ("gene", C.c_void_p), ("n_prot", C.c_int32), ("m_prot", C.c_int32), ("prot", C.c_void_p)]
 
     assert C.sizeof(Hit) == 88 and C.sizeof(Genome) == 56 and C.sizeof(Data) == 72
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     files = golden_files("human8f")
 

@@ -9,6 +9,7 @@ import sys
 import pytest
 
 from conftest import ROOT, GOLD, golden_files
+import oracle_host  # tests/oracle_host.py: the checker build of the host driver
 from pangene_amd import capi
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -34,7 +35,7 @@ def _matrix_checks(lib, tmp_path, name, variant):
 
 @pytest.mark.parametrize("name,variant", [("C4", ""), ("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("manydoms", ""), ("wide0", ""), ("wide3", "-S")])
 def test_matrix_from_memory_and_from_file_equal_the_restatement(built, tmp_path, name, variant):
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     _matrix_checks(lib, tmp_path, name, variant)
 
@@ -64,7 +65,7 @@ def test_c4_entries_counted_by_hand():
 
 def test_cluster_file_merges_paralogs(built, tmp_path):
     """-d: the members of a CD-HIT cluster are added to its representative and not printed (pangene.js:1198-1234)"""
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     gfa = os.path.join(GOLD, "C4.gfa.gz")
     cl = tmp_path / "x.clstr"
     cl.write_text(">Cluster 0\n0\t1744aa, >C4A:ENSP1... *\n1\t1744aa, >C4B:ENSP2... at 99.43%\n>Cluster 1\n0\t500aa, >DXO:P... *\n")
@@ -103,7 +104,7 @@ def _file_matrix(lib, tmp_path, gfa, cn, clstr=None, print_cd=False):
 
 @pytest.fixture(scope="module")
 def ora_lib(built):
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     return lib
 

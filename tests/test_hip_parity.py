@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, all_cases, golden_files
+import oracle_host  # tests/oracle_host.py: the checker build of the host driver
 from pangene_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
@@ -25,7 +26,7 @@ def hip(built):
 
 @pytest.fixture(scope="module")
 def ora(built):
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     return lib
 

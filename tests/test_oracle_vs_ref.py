@@ -14,12 +14,13 @@ import subprocess
 import pytest
 
 from conftest import ROOT, all_cases, golden_files
+import oracle_host  # tests/oracle_host.py: the checker build of the host driver
 from pangene_amd import capi, synth
 
 
 @pytest.fixture(scope="module")
 def ora(built):
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     return lib
 
@@ -101,7 +102,7 @@ def test_dense_shape_against_reference_binary(ora, tmp_path):
 @pytest.mark.parametrize("name", ["C4", "bact20", "human8f", "fuzz3"])
 def test_batch_reader_equals_sequential_reader(built, name):
     """pg_read_paf_batch (threads + ordered commit) numbers genes/proteins exactly like per-file pg_read_paf calls."""
-    ora = capi.load(oracle_host=True)
+    ora = oracle_host.load()
     fs = golden_files(name)
     for args in ([], ["-w"], ["--bed=flag"]):
         assert capi.run(ora, fs, args, batch=True) == capi.run(ora, fs, args, batch=False)

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from pangene_amd import capi, synth
+import oracle_host  # tests/oracle_host.py: the checker build of the host driver
 
 
 class Prot(C.Structure):
@@ -87,7 +88,7 @@ def moving_set(tmp_path, n_files=36, n_prot=2500):
 
 @pytest.mark.parametrize("argv", [[], ["-P", "P000003,P000007"], ["-d", ":"]])
 def test_batch_state_equals_sequential_state(built, tmp_path, argv):
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     files = moving_set(tmp_path)
     assert sum(os.path.getsize(f) for f in files) > (8 << 20)  # the arena is in play
@@ -107,7 +108,7 @@ def test_score_adj_fast_path_is_the_long_double_route(built, tmp_path):
     from decimal import Decimal, getcontext
     getcontext().prec = 60
     rng = np.random.default_rng(9)
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     n = 20000
     plen = rng.integers(50, 3000, n)
@@ -200,7 +201,7 @@ def test_adversarial_paf_lines_against_the_reference_binary(built, tmp_path, var
     ref = os.path.join(ROOT, "oracle", "_ref", "pangene_ref")
     if not os.path.exists(ref):
         pytest.skip("oracle/_ref/pangene_ref not built")
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     files = []
     for j in range(4):

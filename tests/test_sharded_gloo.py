@@ -16,10 +16,11 @@ from conftest import ROOT, golden_files
 def _worker(rank, world, port, files, variant, q, cuts=None, verbose=None):
     import ctypes as C
     import torch.distributed as dist
-    sys.path.insert(0, ROOT)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     from pangene_amd import capi, exchange
+    import oracle_host
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    lib = capi.load(oracle_host=True)
+    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = verbose[rank] if verbose else 0
     keep = exchange.install(lib)
     n = len(files)

@@ -12,12 +12,13 @@ from conftest import ROOT, golden_files
 
 _RUN = r'''
 import sys, ctypes as C
-sys.path.insert(0, %r)
+sys.path.insert(0, %r); sys.path.insert(0, %r)
 from pangene_amd import capi
-lib = capi.load(oracle_host=(sys.argv[1] == "oracle")); C.c_int.in_dll(lib, "pg_verbose").value = 0
+import oracle_host
+lib = (oracle_host.load() if sys.argv[1] == "oracle" else capi.load()); C.c_int.in_dll(lib, "pg_verbose").value = 0
 lib.pg_set_exact_mode(int(sys.argv[2]))
 capi.run(lib, sys.argv[4:], sys.argv[3].split())
-''' % ROOT
+''' % (ROOT, os.path.join(ROOT, "tests"))
 
 FIELDS = ["flags", "rank", "score_dom", "pid_dom", "pid_dom0", "pos_x", "pos_y"]
 

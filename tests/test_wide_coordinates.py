@@ -19,8 +19,8 @@ import sys, os, ctypes as C, hashlib, json, io, gzip
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle")); sys.path.insert(0, os.path.join(%r, "tests"))
 from conftest import golden_files, GOLD
 from pangene_amd import capi
-import gfa2matrix_ref as ref
-lib = capi.load(oracle_host=(sys.argv[1] == "oracle"))
+import gfa2matrix_ref as ref, oracle_host
+lib = (oracle_host.load() if sys.argv[1] == "oracle" else capi.load())
 C.c_int.in_dll(lib, "pg_verbose").value = 0
 exp = json.load(open(os.path.join(GOLD, "expected.json")))
 bad = []
