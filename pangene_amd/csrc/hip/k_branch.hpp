@@ -393,6 +393,66 @@ __device__ void br_vertex_seq(int a0, int n, const int32_t *s1, const int32_t *a
 	if (MODE == 2) *ndl_out = n_group;
 }
 
+// A vertex with more than 64 arcs (a hub of a many-genome shard before pg_flt_high_occ has thinned the graph: the 12.1 M-hit shard has vertices with
+// hundreds in its first rounds), by the whole wave instead of one lane (br_vertex_seq: 1.2 ms for one such launch): the arcs in chunks of 64, the
+// same pair numbering.  Part 2's grouping is sequential in i by definition (the first i that is local with j names j's group); what a lane keeps of it
+// is the group mark of its own j's, in the wave's slice of LDS (BR_WIDE_CAP arcs; beyond that the sequential form).
+constexpr int BR_WIDE_CAP = 2048;
+template <int MODE>
+__device__ void br_vertex_wide(const int lane, int a0, int n, const int32_t *s1, const int32_t *agid, double bd, int64_t k0, int32_t *pairs, const int32_t *cnt,
+                               double bdist, double bcut, uint8_t *weak, uint16_t *grp /* LDS, [n] */, int32_t *ndl_out, int64_t *dcnt)
+{
+	const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	int max_s1 = 0;
+	for (int c = 0; c < n; c += WAVE) { const int j = c + lane; const int v = j < n ? s1[a0 + j] : 0; max_s1 = max_s1 > v ? max_s1 : v; }
+	max_s1 = wave_max(max_s1);
+	int n_max = 0;
+	for (int c = 0; c < n; c += WAVE) { const int j = c + lane; n_max += __popcll(__ballot(j < n && s1[a0 + j] == max_s1)); }
+	// part 1 (branch.c:70-77): every weak arc i (ascending) against every best-scoring arc j (ascending)
+	int64_t k = k0;
+	for (int ci = 0; ci < n; ci += WAVE) {
+		const int ii = ci + lane;
+		const double r_l = ii < n ? 1.0 - (double)s1[a0 + ii] / max_s1 : 0.0;
+		unsigned long long m_weak = __ballot(ii < n && r_l > bd);
+		for (; m_weak; m_weak &= m_weak - 1, k += n_max) {
+			const int bit = __ffsll((long long)m_weak) - 1, i = ci + bit;
+			const int gid_i = agid[a0 + i];
+			bool any_local = false;
+			int base = 0;
+			for (int cj = 0; cj < n; cj += WAVE) {
+				const int j = cj + lane;
+				const bool is_max = j < n && s1[a0 + j] == max_s1;
+				const unsigned long long mm = __ballot(is_max);
+				const int64_t kk = k + base + __popcll(mm & lt);
+				if (MODE == 1) { if (is_max) pairs[2 * kk] = agid[a0 + j], pairs[2 * kk + 1] = gid_i; }
+				else any_local = any_local || __ballot(is_max && cnt[kk] != 0) != 0;
+				base += __popcll(mm);
+			}
+			if (MODE == 2 && lane == bit) {
+				const int wk = ((!any_local && r_l > bdist) || r_l > bcut) ? 2 : 1;
+				weak[a0 + i] = (uint8_t)wk;
+				if (dcnt) atomicAdd((unsigned long long *)&dcnt[wk - 1], 1ull); // log only
+			}
+		}
+	}
+	// part 2 (branch.c:82-90): all i < j pairs, row i behind i * n - i (i + 1) / 2 earlier pairs
+	if (MODE == 2) { for (int j = lane; j < n; j += WAVE) grp[j] = 0; wave_sync(); }
+	int n_group = 0;
+	for (int i = 0; i < n; ++i) {
+		const int64_t row = k + (int64_t)i * n - (int64_t)i * (i + 1) / 2 - i - 1; // + j = the pair (i, j)
+		if (MODE == 1) {
+			const int gid_i = agid[a0 + i];
+			for (int j = i + 1 + lane; j < n; j += WAVE) pairs[2 * (row + j)] = gid_i, pairs[2 * (row + j) + 1] = agid[a0 + j];
+		} else {
+			int gi = grp[i]; // (wave-uniform)
+			if (gi == 0) { gi = ++n_group; if (lane == 0) grp[i] = (uint16_t)gi; }
+			for (int j = i + 1 + lane; j < n; j += WAVE) if (grp[j] == 0 && cnt[row + j] > 0) grp[j] = (uint16_t)gi;
+			wave_sync(); // (the marks of this row are read by the next one)
+		}
+	}
+	if (MODE == 2 && lane == 0) *ndl_out = n_group;
+}
+
 // One WAVE per oriented vertex; lane j holds arc j (score, target gene, group mark) in registers and arcs are
 // broadcast with shuffles, so the O(n^2) pair loops of branch.c:70-90 touch memory only for the pair list
 // (coalesced stores, MODE 1) or the all-reduced counts (coalesced loads, MODE 2).
@@ -402,6 +462,7 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
                                                      uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, uint8_t *vwk /* MODE 2: vertex has a weak arc */,
                                                      const int64_t *np_dev = nullptr /* MODE 2: the number of pairs, when the list has a capacity (pair_cap) */, Gate gate = Gate{nullptr, 0})
 {
+	__shared__ uint16_t s_grp[MODE == 2 ? (BLOCK / WAVE) * BR_WIDE_CAP : 1];
 	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (v >= n_vtx || gate_closed(gate)) return;
 	if (MODE == 2 && np_dev && *np_dev > pair_cap) return; // the list overflowed: there are no counts to read, the host repeats the step with room
@@ -409,6 +470,12 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 	if (n < 2) { if (MODE == 2 && lane == 0) ndl[v] = 0; return; } // (every n_dist_loci entry is written: nothing to clear beforehand)
 	const int64_t k0 = poff[v];
 	if (MODE == 1 && k0 + pcnt[v] > pair_cap) return; // would run past the list: left out -- the total then exceeds the capacity too, the host sees that and repeats the round with room
+	if (n > WAVE && n <= BR_WIDE_CAP) {
+		int32_t g = 0;
+		br_vertex_wide<MODE>(lane, a0, n, s1g, agidg, bd, k0, pairs, cnt, bdist, bcut, weak, MODE == 2 ? s_grp + (threadIdx.x >> 6) * BR_WIDE_CAP : (uint16_t *)nullptr, &g, dcnt);
+		if (MODE == 2 && lane == 0) ndl[v] = g, vwk[v] = 1;
+		return;
+	}
 	if (n > WAVE) {
 		if (lane == 0) {
 			int32_t g = 0;
