@@ -52,6 +52,26 @@ struct OutLiveY {
 	const uint32_t *flags; const int32_t *yperm; int32_t *ylist;
 	__device__ __forceinline__ void operator()(int64_t y, I32, I32 ex) const { const int x = yperm[y]; if (!(flags[x] & PGA_F_FLT)) ylist[ex.v] = x; }
 };
+// the sweep's records of the members, compact (SweepView::xmap): record i = the member with lx == i
+__global__ __launch_bounds__(BLOCK) void k_live_records(const uint32_t *flags, const int32_t *lx, const int4 *A, const int4 *B, const int4 *C, int n, int4 *cA, int4 *cB, int4 *cC, int32_t *cx)
+{
+	const int x = blockIdx.x * BLOCK + threadIdx.x;
+	if (x >= n || !(flags[x] & F_MEMBER)) return;
+	const int i = lx[x];
+	cA[i] = A[x], cB[i] = B[x], cC[i] = C[x], cx[i] = x;
+}
+// ... of the hits an order override has moved (lpos: their places among the members, k_ovl_pos; -1: not a member)
+__global__ __launch_bounds__(BLOCK) void k_ovl_records(const int32_t *ov_pos, const int32_t *lpos, int64_t t, const int4 *A, const int4 *B, const int4 *C, int4 *cA, int4 *cB, int4 *cC, int32_t *cx)
+{
+	const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (k >= t || lpos[k] < 0) return;
+	const int i = lpos[k], x = ov_pos[k];
+	cA[i] = A[x], cB[i] = B[x], cC[i] = C[x], cx[i] = x;
+}
+// pm of the compact records over the listed places (a contig's members are consecutive in the list's order of places; -1 entries are no-ops)
+struct InSegMaxListL { const int4 *A; const int32_t *lpos; __device__ __forceinline__ SegMax operator()(int64_t i) const { const int p = lpos[i]; if (p < 0) return SegMax{SEG_EMPTY, 0}; const int4 a = A[p]; return SegMax{a.y, a.z}; } };
+struct OutSegMaxListL { int4 *A; const int32_t *lpos; __device__ __forceinline__ void operator()(int64_t i, SegMax in, SegMax) const { const int p = lpos[i]; if (p >= 0) ((int32_t *)&A[p])[3] = in.v; } };
+
 // the members' number for the host (dcnt[10]) with the other counters
 __global__ void k_mail_live(const int32_t *lx, int64_t n, int64_t *dcnt, int64_t *host_box)
 {
@@ -255,7 +275,8 @@ struct GeneArcs {
 	// what the branch steps read, at the same (sparse) positions: x, rounded s1 (graph.c:171), target gene, weak_br = 0; per oriented vertex its range, degree, "has a weak arc" = 0
 	uint64_t *ax; int32_t *s1, *agid; uint8_t *aw; int32_t *vs, *ve, *deg; uint8_t *vwk;
 	int32_t *h_round;                   // pinned host memory (or NULL): seg_cnt[2S] then deg[2S] for the host, written straight from here
-	int32_t *big_list;                  // [Q] 1 = the gene is left to the workgroup kernel
+	int32_t *big_list;                  // [Q] the genes left to the workgroup kernel, in the order the first kernel's workgroups gave up on them
+	int32_t *big_ctl;                   // [2] their number; how many of them have been taken (both cleared by the k_sweep_slow in front of every arc round)
 	int64_t *dcnt;                      // [3] invariant, [9] genes that overflowed GA_CAP
 	Gate gate; int32_t *tag_out;        // (pga_branch_loop) the round may have nothing to do; tag_out: where a round that does run leaves its tag
 };
@@ -438,12 +459,11 @@ __global__ __launch_bounds__(NT) void k_gene_arcs_wave_t(GeneArcs a)
 	if (sid < 0) { // not a vertex: none of its hits may be walkable (graph.c:111)
 		for (int z = z0 + tid; z < z1; z += NT)
 			if (hx_walk(a.hbk[z], a.tag)) atomicAdd((unsigned long long *)&a.dcnt[3], 1ull), a.dcnt[11] = 1; // ([11]: sticky, for rounds nobody looks at one by one: pga_branch_loop)
-		if (tid == 0) a.big_list[g] = 0;
 		return;
 	}
 	const int cl = a.cap_log2 < CAP_LOG2 ? a.cap_log2 : CAP_LOG2;
 	const bool done = z1 - z0 <= HITS && gene_arcs_one<NT, CAP, HITS>(a, T, g, sid, tid, cl);
-	if (tid == 0) a.big_list[g] = done ? 0 : 1; // many hits, or many neighbours: the second kernel takes it
+	if (tid == 0 && !done) a.big_list[atomicAdd(&a.big_ctl[0], 1)] = g; // many hits, or many neighbours: the second kernel takes it
 }
 
 // (512 threads a gene: the LDS tables allow three of these workgroups on a CU whatever their width -- 12 waves of 256 threads, 24 of 512; 328 -> 258 us
@@ -454,12 +474,22 @@ __global__ __launch_bounds__(GA_BIG_NT) void k_gene_arcs_big(GeneArcs a)
 	__shared__ GeneTable<GA_CAP, GA_BIG_STAGE> T;
 	if (gate_closed(a.gate)) return;
 	if (a.tag_out && blockIdx.x == 0 && threadIdx.x == 0) *a.tag_out = (int32_t)a.tag;
-	for (int g = blockIdx.x; g < a.Q; g += gridDim.x) { // the genes the wave kernel left (a flag per gene: no list, no counter)
-		if (!a.big_list[g]) continue;
+	// The genes the wave kernel left, handed out one at a time (round 6).  Rounds 3-5 gave workgroup b the genes b, b + grid, ... and skipped the small
+	// ones by a flag: on the 12.1 M-hit shard, where 2 327 of 5 000 genes come here at ~70 us each and 768 workgroups fit the chip, the luck of
+	// that draw decided the launch's length.
+	// (Workgroup b starts with item b; only who finishes one asks the counter for the next -- a returning atomic on ONE word costs ~50 ns each at
+	// the memory side: 2 048 workgroups asking at once made an otherwise empty launch take 115 us.)
+	__shared__ int s_next;
+	const int n_big = a.big_ctl[0];
+	for (int at = blockIdx.x; at < n_big; ) {
+		const int g = a.big_list[at];
 		const int sid = a.g2s[g];
 		if (!gene_arcs_one<GA_BIG_NT, GA_CAP, GA_BIG_STAGE>(a, T, g, sid, threadIdx.x, a.cap_log2) && threadIdx.x == 0) // a hub gene: this round is redone on the sort path
 			atomicAdd((unsigned long long *)&a.dcnt[9], 1ull), a.dcnt[11] = 1, a.gmeta[sid] = make_int4(0, 0, 0, 0); // (the whole round is repeated: nothing else to leave behind)
+		if (threadIdx.x == 0) s_next = (int)gridDim.x + atomicAdd(&a.big_ctl[1], 1);
 		__syncthreads();
+		at = s_next;
+		__syncthreads(); // (s_next is written again one item on)
 	}
 }
 

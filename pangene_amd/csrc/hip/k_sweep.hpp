@@ -64,7 +64,12 @@ struct SweepView {
 	int32_t *hz_list; // hz[10] (= dcnt[14]) counts its entries
 	int init_dom; // MODE 1, first sweep of a run: filtered hits get pid_dom = -1, score_dom = 0 (read.c:133-134) here, nobody wrote them before
 	Gate gate; // the pg_shadow of an arc round inside pga_branch_loop may have nothing to do (no flag changed since the last one)
+	// Round 6, live lists: the sweeps of the rounds (MODE 0) run over COMPACT copies of the records -- the hits without flt when the lists were built,
+	// in X order, pm recomputed over them -- and reach the per-hit state (flag word, pid_dom) at the hit's X position through xmap; NULL: A / B / C
+	// are the X-order records themselves.  A filtered hit takes no part in any pair (overlap.c:112,127), so the pairs are the same.
+	const int32_t *xmap;
 };
+#define SW_X(v, h) ((v).xmap ? (v).xmap[h] : (h)) /* where the state of the hit at (compact) position h lives */
 
 // pg_hit_overlap (overlap.c:6-42) step by step as the reference takes them: for shards with an exon list that is not sorted and disjoint
 // (k_prepare looks), where the shortcuts of cds_inter_t would not add up to the same number
@@ -275,8 +280,9 @@ __device__ __forceinline__ void sw_finish(const SweepView &v, int h, uint32_t fl
 	}
 	uint32_t nf = (fl & F_HEAD) ? fl : (fl & ~PGA_F_SHADOW);
 	if (lose) nf |= PGA_F_SHADOW;
-	if (nf != fl) v.flags[h] = nf;
-	v.pdom[h] = has_dom ? pid_w : -1;
+	const int hx = MODE == 0 ? SW_X(v, h) : h; // (only the sweeps of the rounds run on the compact records)
+	if (nf != fl) v.flags[hx] = nf;
+	v.pdom[hx] = has_dom ? pid_w : -1;
 	if (MODE == 1) {
 		int sd = -1;
 		if (has_dom) sd = (int32_t)(sori_h * (1.0 - (double)ov / cds_h) + sori_w * ((double)ov / cds_w) + .499); // overlap.c:170
@@ -319,7 +325,7 @@ __device__ __forceinline__ void sweep_tile(const SweepView &v)
 		uint32_t f = PGA_F_FLT;
 		int32_t so = 0;
 		if (g >= 0 && g < v.n) {
-			a = v.A[g], b = v.B[g], f = v.flags[g];
+			a = v.A[g], b = v.B[g], f = v.flags[MODE == 0 ? SW_X(v, g) : g];
 			if (STAGE_C) c = v.C[g];
 			if (STAGE_ORI) so = v.sori[g];
 		}
@@ -328,7 +334,7 @@ __device__ __forceinline__ void sweep_tile(const SweepView &v)
 		const bool in2 = lane < 2 * SW_HALO && g2 >= 0 && g2 < v.n;
 		if (wave == 0) sA[l2] = in2 ? v.A[g2] : make_int4(0, -2, 0, 0);
 		else if (wave == 1) sB[l2] = in2 ? v.B[g2] : make_int4(0, 0, 0, 0);
-		else if (wave == 2) sF[l2] = in2 ? v.flags[g2] : PGA_F_FLT;
+		else if (wave == 2) sF[l2] = in2 ? v.flags[MODE == 0 ? SW_X(v, g2) : g2] : PGA_F_FLT;
 		else if (STAGE_C) sC[l2] = in2 ? v.C[g2] : make_int4(0, 0, 0, 0);
 		else if (STAGE_ORI) sOri[l2] = in2 ? v.sori[g2] : 0;
 		sA[tid] = a, sB[tid] = b, sF[tid] = f;
@@ -610,13 +616,13 @@ __global__ __launch_bounds__(SW_TILE) void k_list_density(const int4 *A, const i
 // The rare hits k_sweep could not finish inside its LDS window: one thread per listed hit walks all its partners in
 // global memory, in both directions (the plain thread-per-hit formulation of the sweep).
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *next_cnt)
+__global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *next_cnt, int32_t *clear2 = nullptr /* two more words to clear: the hand-out counters of the gene kernels behind the arc rounds' sweep */)
 {
 	const long long n_slow = *v.slow_cnt;
-	if (blockIdx.x == 0 && threadIdx.x == 0) *next_cnt = 0; // the counter the NEXT sweep will use (ping-pong; nobody reads it now)
+	if (blockIdx.x == 0 && threadIdx.x == 0) { *next_cnt = 0; if (clear2) clear2[0] = 0, clear2[1] = 0; } // the counter the NEXT sweep will use (ping-pong; nobody reads it now)
 	for (long long q = blockIdx.x * (long long)BLOCK + threadIdx.x; q < n_slow; q += (long long)gridDim.x * BLOCK) {
 		const int h = v.slow_list[q];
-		const uint32_t fl = v.flags[h];
+		const uint32_t fl = v.flags[MODE == 0 ? SW_X(v, h) : h];
 		SwHit t;
 		const int4 ch = v.C[h];
 		{
@@ -631,13 +637,13 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_slow(SweepView v, long long *ne
 		for (int j = h - 1; j >= 0; --j) {
 			const int4 a = sw_scse(v.A[j]);
 			if (a.x != t.sg || a.w <= t.cs) break;
-			sw_pair<MODE, true>(v, t, r, a, v.flags[j], v.B[j], v.C[j], j, a.z > t.cs);
+			sw_pair<MODE, true>(v, t, r, a, v.flags[MODE == 0 ? SW_X(v, j) : j], v.B[j], v.C[j], j, a.z > t.cs);
 		}
 		// partners after h: every i with cs_i < ce_h
 		for (int i = h + 1; i < v.n; ++i) {
 			const int4 a = sw_scse(v.A[i]);
 			if (a.x != t.sg || a.y >= t.ce) break;
-			sw_pair<MODE, false>(v, t, r, a, v.flags[i], v.B[i], v.C[i], i, true);
+			sw_pair<MODE, false>(v, t, r, a, v.flags[MODE == 0 ? SW_X(v, i) : i], v.B[i], v.C[i], i, true);
 		}
 		sw_finish<MODE>(v, h, fl, r.lose, r.best > 0, r.pid, r.ov, t.cds, r.cds, ch.w, (MODE == 1 || MODE == 3) && r.best > 0 ? v.C[r.j].w : 0, r.iso);
 	}

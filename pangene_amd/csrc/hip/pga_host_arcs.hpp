@@ -68,6 +68,9 @@ static int build_z(pga_ctx *c, int64_t known_live)
 		if (known_live < 0) TRY(sync_st(c)); // the grids of everything that follows are sized by the members' number
 		n = known_live < 0 ? (int)c->h_cnt[10] : (int)known_live;
 		c->live_on = true, c->NL = n, c->ylist = c->ylist_buf;
+		// the sweeps of the rounds run over the members' records (SweepView::xmap): compact copies, pm over the members
+		hipLaunchKernelGGL(k_live_records, dim3(nblk(N)), dim3(BLOCK), 0, c->st, (const uint32_t *)c->flags, (const int32_t *)c->lx, (const int4 *)c->recA, (const int4 *)c->recB, (const int4 *)c->recC, N, c->cA, c->cB, c->cC, c->cx);
+		if (n) device_scan<SegMax>(InSegMaxA{c->cA}, OutSegMaxA{c->cA}, n, (SegMax *)c->pool.get(S_TILE, tile_buf_bytes(N)), OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
 		if (getenv("PANGENE_TIMING")) fprintf(stderr, "[pga] live lists: %d of %d hits (%.3f) are not filtered; the walk and the gene-major index hold those\n", n, N, (double)n / N);
 	} else {
 		c->live_on = false, c->NL = N, c->ylist = c->yperm;
@@ -153,7 +156,7 @@ static int arc_round_genes(pga_ctx *c, int use_ori, int32_t **seg_cnt_out, int32
 	if (!big) return PGA_ERR_NOMEM;
 	static const int cap_log2 = [] { const char *e = getenv("PANGENE_GENE_TABLE_LOG2"); const int v = e ? atoi(e) : 9; return v < 1 ? 1 : v > 9 ? 9 : v; }();
 	GeneArcs ga = { c->zy, c->zoff, c->hfk, c->hbk, c->hfp, c->hbp, c->g2s, c->Q, S, c->round_tag, cap_log2, seg_cnt, t.sg, stage, gmeta,
-	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->dcnt, c->gate, (c->gate.w || c->loop_gated) ? c->loopctl + 2 : (int32_t *)nullptr };
+	                t.ax, t.s1, t.agid, t.aw, t.vs, t.ve, t.dg, t.vwk, h_round_dev, big, c->ga_ctl, c->dcnt, c->gate, (c->gate.w || c->loop_gated) ? c->loopctl + 2 : (int32_t *)nullptr };
 	// (round 6, measured side by side at configs[1] / human 47 x 20 k, ms per pass: <128 threads, 128 keys, 512 hits> 5.26 / 5.11 -- kept; <64, 64, 256> 5.83 / 4.98;
 	// <128, 64, 256> 5.65 / 5.08; <64, 128, 512> 5.49 / 5.13; <64, 32, 256> 5.90 / 5.05: smaller tables put more genes on a CU and send more of them to the second kernel)
 	hipLaunchKernelGGL((k_gene_arcs_wave_t<GA_WAVE_NT, GA_CAP_WAVE, GA_WAVE_HITS, 7>), dim3((unsigned)c->Q), dim3(GA_WAVE_NT), 0, c->st, ga);

@@ -44,6 +44,7 @@ static int make_sweep_view(pga_ctx *c, SweepView *v)
 	v->init_dom = c->sweep_init ? 1 : 0;
 	v->literal = c->exon_regular && getenv("PANGENE_MERGE_LITERAL") == nullptr ? 0 : 1;
 	v->gate = c->gate;
+	v->xmap = nullptr;
 	v->slow_cnt = nullptr, v->slow_list = (int32_t *)c->pool.get(S_SLOW, sizeof(int32_t) * (size_t)c->N);
 	v->hz_list = (int32_t *)c->pool.get(S_HZLIST, sizeof(int32_t) * PGA_HAZARD_CAP);
 	if (!v->slow_list || !v->hz_list) return PGA_ERR_NOMEM;
@@ -85,13 +86,16 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 	TimedLaunch t; t.which = timed_which; t.units = c->N;
 	constexpr int reps = 1;
 	static_assert(MODE == 0 || MODE == 1 || MODE == 3, "sweep modes");
+	static const bool no_compact = env_has("PANGENE_LIVE", "fullsweep"); // (tests: live lists, but the sweeps over every record)
+	if (MODE == 0 && c->live_on && c->z_valid && !no_compact) v.A = c->cA, v.B = c->cB, v.C = c->cC, v.n = c->NL, v.xmap = c->cx; // the sweeps of the rounds: the members' records (see SweepView::xmap; z_valid: a cs override under -S drops the lists -- until they are built again the compact records are not what the X order holds)
+	const int n_sw = v.n; // (0: one workgroup of sentinels -- the k_sweep_slow behind it still has counters to clear)
 	const bool timed = (timed_which == 0 || timed_which == 1) && c->timing_on; // (the stage-C sweeps are not timed one by one: two events per launch cost ~10 us of queue time)
 	if (timed) {
 		HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
 		if (reps != 1) HIPCHK(hipEventRecord(t.a, c->st));
 	}
 	c->walk_valid = false, c->ha_valid = false;
-	const int nt = (int)nblk(c->N, SW_TILE);
+	const int nt = std::max(1, (int)nblk(n_sw, SW_TILE));
 	v.prof = nullptr; v.dbg = 0;
 #ifdef PGA_SW_PROFILE
 	{ const char *e = getenv("PGA_SW_DBG"); v.dbg = e ? atoi(e) : 0; }
@@ -105,7 +109,7 @@ template <int MODE> static int launch_sweep(pga_ctx *c, int timed_which)
 		if (c->any_multi && MODE != 0 && !c->lists_in_lds) hipExtLaunchKernelGGL((k_sweep_lean<MODE == 0 ? 1 : MODE>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
 		else if (c->any_multi) hipExtLaunchKernelGGL((k_sweep<MODE, true>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
 		else hipExtLaunchKernelGGL((k_sweep<MODE, false>), dim3(nt), dim3(SW_TILE), 0, c->st, ea, eb, 0, v);
-		hipLaunchKernelGGL((k_sweep_slow<MODE>), dim3((unsigned)std::min<int64_t>(2 * c->n_cu, std::max<int64_t>(64, nblk(c->N)))), dim3(BLOCK), 0, c->st, v, (long long *)(c->dcnt + 12 + ((c->sweep_seq + 1) & 1))); // (grid-stride over a list whose length only the device knows)
+		hipLaunchKernelGGL((k_sweep_slow<MODE>), dim3((unsigned)std::min<int64_t>(2 * c->n_cu, std::max<int64_t>(64, nblk(n_sw)))), dim3(BLOCK), 0, c->st, v, (long long *)(c->dcnt + 12 + ((c->sweep_seq + 1) & 1)), MODE == 0 ? c->ga_ctl : (int32_t *)nullptr); // (grid-stride over a list whose length only the device knows)
 		++c->sweep_seq;
 	}
 #ifdef PGA_SW_PROFILE

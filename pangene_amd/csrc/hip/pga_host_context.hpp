@@ -217,6 +217,8 @@ struct pga_ctx {
 	int32_t *lx = 0;         // [N + 1] members before X position x when the lists were built (a contig keeps its range and its count through order overrides: valid at contig starts)
 	int32_t *ylist_buf = 0;  // [N] storage of the members' list in cm order
 	const int32_t *ylist = 0;// what the walk reads: ylist_buf, or yperm when the lists hold every hit
+	int32_t *ga_ctl = 0; // [2] k_gene_arcs_big's hand-out counters (cleared by the k_sweep_slow of the arc round's sweep)
+	int4 *cA = 0, *cB = 0, *cC = 0; int32_t *cx = 0; // [N] live lists: the sweep's records of the members, compact, in X order (pm over the members), and each member's X position
 	int2 *tg = 0; bool tg_valid = false; // [N] where the (contig, cs) tie group of a hit begins and ends in the cs order (k_tie_bounds: once per pass, members only)
 	int64_t *live_cnt = 0;   // [LIVE_CNT_N] partial counts of the hits without flt (k_vtx1 / k_flag_vtx spread their atomics: 190 000 waves onto ONE word cost 1.9 ms at 12.1 M hits), summed into dcnt[8] by k_live_sum
 	int64_t live_hint = -1;  // hits without flt as the vertex step counted them (k_vtx1): decides whether the lists are worth building; -1 not known

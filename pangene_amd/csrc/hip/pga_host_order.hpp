@@ -93,6 +93,10 @@ extern "C" int pga_override_order(pga_ctx_t *c, int32_t which, int32_t n_seg, co
 	if (!tile) return PGA_ERR_NOMEM;
 	device_scan<SegMax>(InSegMaxList{c->recA, d_pos}, OutSegMaxList{c->recA, d_pos}, T, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st); // pm follows the new order
 	hipLaunchKernelGGL(k_cstie_list, dim3(nblk(T)), dim3(BLOCK), 0, c->st, c->recA, d_pos, T, N, c->flags);
+	if (live) { // the members' compact records follow (SweepView::xmap), and their pm
+		hipLaunchKernelGGL(k_ovl_records, dim3(nblk(T)), dim3(BLOCK), 0, c->st, (const int32_t *)d_pos, (const int32_t *)d_lpos, T, (const int4 *)c->recA, (const int4 *)c->recB, (const int4 *)c->recC, c->cA, c->cB, c->cC, c->cx);
+		device_scan<SegMax>(InSegMaxListL{c->cA, d_lpos}, OutSegMaxListL{c->cA, d_lpos}, T, tile, OpSegMax{}, SegMax{SEG_EMPTY, 0}, c->st);
+	}
 	if (wrec_ok) TRY(walk_again(live ? d_lpos : d_pos));
 	return 0;
 }

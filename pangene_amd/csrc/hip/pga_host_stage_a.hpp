@@ -24,6 +24,8 @@ static int plan_persistent(pga_ctx *c)
 	TRY(dalloc(c, &c->zx, N)); TRY(dalloc(c, &c->zy, N)); TRY(dalloc(c, &c->zg, N)); TRY(dalloc(c, &c->zst, N)); TRY(dalloc(c, &c->zpos, N)); TRY(dalloc(c, &c->wrec, 2 * (size_t)N)); TRY(dalloc(c, &c->zoff, (size_t)c->Q + 2));
 	TRY(dalloc(c, &c->hfk, N)); TRY(dalloc(c, &c->hbk, N)); TRY(dalloc(c, &c->hfp, N)); TRY(dalloc(c, &c->hbp, N));
 	TRY(dalloc(c, &c->lx, (size_t)N + 1)); TRY(dalloc(c, &c->ylist_buf, N)); TRY(dalloc(c, &c->live_cnt, LIVE_CNT_N)); TRY(dalloc(c, &c->tg, N));
+	TRY(dalloc(c, &c->ga_ctl, 4));
+	TRY(dalloc(c, &c->cA, N)); TRY(dalloc(c, &c->cB, N)); TRY(dalloc(c, &c->cC, N)); TRY(dalloc(c, &c->cx, N));
 	TRY(dalloc(c, &c->prot_gid, c->P)); TRY(dalloc(c, &c->gene_pref, c->Q)); TRY(dalloc(c, &c->hrank, c->P));
 	TRY(dalloc(c, &c->max_ori, c->P)); TRY(dalloc(c, &c->sums, 6 * (size_t)c->P)); TRY(dalloc(c, &c->vtx_cnt, 2 * (size_t)c->Q)); TRY(dalloc(c, &c->g2s, c->Q));
 	return 0;

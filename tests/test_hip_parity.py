@@ -112,7 +112,7 @@ def _run_with_env(tmp_path, env, mode, variant, files):
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
 @pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1", "PANGENE_LOOP": "nopre"},
                                  {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1", "PANGENE_FILTERS": "global"}, {"PANGENE_LOOP": "nofinal", "PANGENE_MERGE_LITERAL": "1", "PANGENE_SWEEP_LISTS": "global"},
-                                 {"PANGENE_FILTERS": "k32", "PANGENE_LOOP": "noskip", "PANGENE_SWEEP_LISTS": "lds"}, {"PANGENE_BIN_CAP": "256", "PANGENE_LIVE_LISTS": "2"}, {"PANGENE_BIN_CAP": "2048", "PANGENE_BINS": "1"}])
+                                 {"PANGENE_FILTERS": "k32", "PANGENE_LOOP": "noskip", "PANGENE_SWEEP_LISTS": "lds"}, {"PANGENE_BIN_CAP": "256", "PANGENE_LIVE_LISTS": "2"}, {"PANGENE_BIN_CAP": "2048", "PANGENE_BINS": "1"}, {"PANGENE_LIVE_LISTS": "1", "PANGENE_LIVE": "fullsweep", "PANGENE_RANK": "scan", "PANGENE_Y_FIXUP": "0"}])
 def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
     (the path of rounds in which a hub gene overflows the per-gene LDS table).  Forcing the sort path, and shrinking the table to 4
@@ -134,7 +134,9 @@ def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     stage A's orders by CONTIG BINS (k_segsort.hpp: the planes grouped by contig at the upload, a workgroup per run of consecutive contigs -- the
     path of genomes beyond one workgroup's LDS, a human assembly) with bins of at most 256 / 2048 hits, so that these small genomes are cut into
     several bins or sorted as one bin out of the grouped planes; the seventh also asks in every queued round whether the live lists are worth
-    building again (PANGENE_LIVE_LISTS=2)."""
+    building again (PANGENE_LIVE_LISTS=2).  Ninth setting: live lists, but the sweeps of the rounds over every record instead of the members' compact
+    records (SweepView::xmap), the walkable ranks of pg_gen_rep_pos by the general scan instead of k_rank_genome, the cm order by radix passes
+    instead of transpositions."""
     out = _run_with_env(tmp_path, env, 2, variant, golden_files(name))
     assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
 
