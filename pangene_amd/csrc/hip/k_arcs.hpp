@@ -264,7 +264,7 @@ struct XSlots {
 __global__ __launch_bounds__(BLOCK) void k_xs_sum_rank(XSlots X, int32_t *seg_cnt, int64_t *off, int64_t *dcnt, int64_t *xstat, uint64_t *key, uint32_t *val, int32_t *stamp = nullptr /* Gate::w of the queued rounds, or NULL */, int round = 0)
 {
 	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i == 0 && stamp) { // some rank marked a hit in this round (header word 3, k_xs_mark): the state of the loop changed for everybody
+	if (i == 0 && stamp) { // some rank marked a hit in this round (header word 3, written by k_xs_compact): the state of the loop changed for everybody
 		bool any = false;
 		for (int r = 0; r < X.W; ++r) any = any || X.all[r * X.slot_words + 3] != 0;
 		if (any) stamp[1] = round;

@@ -516,8 +516,12 @@ __global__ __launch_bounds__(BLOCK) void k_arc_compact(const int4 *gmeta, const 
 
 // the same into the rank's slot of a sharded round's all-gather (k_arcs.hpp, XS_HDR): the table, the segment counters and the table's size
 // (gate: a queued round of a sharded run whose own arc round found nothing to do leaves its slot as the round before left it)
-__global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const int32_t *off, int S, const pga_arc_part_t *stage, const int32_t *seg_cnt, int32_t *slot, int64_t arc_cap, const int64_t *dcnt, Gate gate = Gate{nullptr, 0})
+// Header word 3 of the slot: did this rank raise a hit's weak_br in this round (stamp[1] == round)?  The fixed point of the queued rounds (dev_prims.hpp:
+// Gate) is a property of ALL ranks' hits: k_xs_sum_rank ORs the ranks' words and stamps the round for everybody.  Written whether the gate is open or not.
+__global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const int32_t *off, int S, const pga_arc_part_t *stage, const int32_t *seg_cnt, int32_t *slot, int64_t arc_cap, const int64_t *dcnt, Gate gate = Gate{nullptr, 0},
+                                                        const int32_t *stamp = nullptr /* Gate::w, or NULL */, int round = 0)
 {
+	if (blockIdx.x == 0 && threadIdx.x == 0) slot[3] = (stamp && stamp[1] == round) ? 1 : 0;
 	if (gate_closed(gate)) return;
 	const int lane = threadIdx.x & 63;
 	int32_t *segc = slot + XS_HDR;
@@ -529,16 +533,9 @@ __global__ __launch_bounds__(BLOCK) void k_xs_compact(const int4 *gmeta, const i
 			for (int i = lane; i < n; i += WAVE) arcs[o + i] = stage[m.x + i];
 		if (lane == 0) {
 			segc[sid] = seg_cnt[sid], segc[S + sid] = seg_cnt[S + sid];
-			if (sid == S - 1) { slot[0] = o + n, slot[1] = dcnt[9] != 0, slot[2] = dcnt[3] != 0; for (int t = 4; t < XS_HDR; ++t) slot[t] = 0; } // ([3]: k_xs_mark) // [1] a hub gene overflowed its LDS table, [2] an invariant was violated
+			if (sid == S - 1) { slot[0] = o + n, slot[1] = dcnt[9] != 0, slot[2] = dcnt[3] != 0; for (int t = 4; t < XS_HDR; ++t) slot[t] = 0; } // ([3]: this kernel's first thread, above) // [1] a hub gene overflowed its LDS table, [2] an invariant was violated
 		}
 	}
-}
-
-// header word 3 of the rank's slot: did this rank raise a hit's weak_br in this round (Gate::w[1] == round)?  The fixed point of the queued rounds
-// (dev_prims.hpp: Gate) is a property of ALL ranks' hits: k_xs_sum_rank ORs the ranks' words and stamps the round for everybody.
-__global__ void k_xs_mark(int32_t *slot, const int32_t *stamp /* Gate::w, or NULL */, int round)
-{
-	if (threadIdx.x == 0 && blockIdx.x == 0) slot[3] = (stamp && stamp[1] == round) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

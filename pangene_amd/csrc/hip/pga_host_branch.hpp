@@ -232,8 +232,7 @@ static int loop_exchange_table(pga_ctx *c, const LoopX &L, Gate local_gate = Gat
 	if (!goff || !tile || !key || !val || !slot || (c->N && (!stage || !gmeta || !seg_cnt))) return PGA_ERR_NOMEM;
 	if (c->N) {
 		device_scan<I32>(InGmeta{gmeta}, OutExclI32{goff}, S, tile, OpSum{}, I32{0}, c->st, local_gate);
-		hipLaunchKernelGGL(k_xs_compact, dim3(nblk(S, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gmeta, goff, S, stage, seg_cnt, L.gbuf, L.arc_cap, (const int64_t *)c->dcnt, local_gate);
-		hipLaunchKernelGGL(k_xs_mark, dim3(1), dim3(64), 0, c->st, L.gbuf, (const int32_t *)stamp, round);
+		hipLaunchKernelGGL(k_xs_compact, dim3(nblk(S, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, gmeta, goff, S, stage, seg_cnt, L.gbuf, L.arc_cap, (const int64_t *)c->dcnt, local_gate, (const int32_t *)stamp, round);
 	}
 	else HIPCHK(hipMemsetAsync(L.gbuf, 0, sizeof(int32_t) * (size_t)(XS_HDR + xs_seg_words(S)), c->st)); // a rank without hits: an empty table, no counts
 	{ const int rc = L.x->allgather(L.x->user, L.gbuf, L.gbuf + L.slot_words, L.slot_words * (int64_t)sizeof(int32_t)); if (rc) return rc; }
@@ -389,7 +388,7 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	// hold on every rank.
 	static const bool no_skip = env_has("PANGENE_LOOP", "noskip");
 	// Sharded (round 6): the stamps become a property of all ranks -- deletions are global anyway (every rank holds the merged table), the marks travel
-	// in the header of the round's all-gather (k_xs_mark) and k_xs_sum_rank stamps the round on every rank when any rank marked; a rank's own arc
+	// in the header of the round's all-gather (k_xs_compact writes the word whether its gate is open or not) and k_xs_sum_rank stamps the round on every rank when any rank marked; a rank's own arc
 	// round follows its own hits (nothing changed here: its slot stands as it is, k_xs_compact leaves), the collectives are queued all the same.
 	const bool gated = !no_skip && (int64_t)c->round_tag + n_round + 4 < (int64_t)HA_TAG_MAX;
 	struct GateScope { pga_ctx *c; ~GateScope() { c->gate = Gate{nullptr, 0}, c->loop_gated = false; } } gate_scope{c}; // (every way out of this function leaves the launches open)
