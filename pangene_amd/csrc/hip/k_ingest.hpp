@@ -150,21 +150,38 @@ __global__ __launch_bounds__(BLOCK) void k_ykey(const int32_t *seg, const int32_
 // ------------------------------------------------------------------------------------------------
 // pg_flag_pseudo (hit.c:66-105) with a (genome, protein) table instead of a sort by pid<<32|rank
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_pseudo1(const int32_t *gnm, const int32_t *pid, const int32_t *nex, int n, int P, int32_t *tmax, int32_t *tmin)
+// Round 6: only a protein with SEVERAL hits in the genome can be marked (one hit: max_n == min_n, and hit.c:84 wants max_n > 1 with min_n == 1 or
+// 2 min_n <= max_n), and two hits of one protein in one file never share a rank (read.c counts the protein's lines): such a protein has a hit of
+// rank >= 1.  So the hits of rank >= 1 name the (genome, protein) cells that matter -- a bit each in a (genome x protein) bitmap that stays in the L2
+// (3.4 MB for 500 x 55 k) -- and initialise those cells of the three tables themselves; every other hit tests its bit and leaves.  Rounds 1-5 filled the
+// three tables (3 x 110 MB on the human-shaped shard) and sent two atomics per hit into them: 0.9 ms of that shard's 1.95 ms of stage A.
+__global__ __launch_bounds__(BLOCK) void k_pseudo0(const int32_t *gnm, const int32_t *pid, const int32_t *rank, int n, int P, uint32_t *bits, int32_t *tmax, int32_t *tmin, int32_t *tr1)
+{
+	int h = blockIdx.x * BLOCK + threadIdx.x;
+	if (h >= n || rank[h] < 1) return;
+	const int64_t t = (int64_t)gnm[h] * P + pid[h];
+	atomicOr(&bits[t >> 5], 1u << (t & 31));
+	tmax[t] = 0, tmin[t] = INT32_MAX, tr1[t] = INT32_MAX; // (the same three values from every writer of the cell; the atomics on them come with the next launch)
+}
+__device__ __forceinline__ bool ps_cell(const uint32_t *bits, int64_t t) { return (bits[t >> 5] >> (t & 31)) & 1u; }
+
+__global__ __launch_bounds__(BLOCK) void k_pseudo1(const int32_t *gnm, const int32_t *pid, const int32_t *nex, int n, int P, const uint32_t *bits, int32_t *tmax, int32_t *tmin)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
 	int64_t t = (int64_t)gnm[h] * P + pid[h];
+	if (!ps_cell(bits, t)) return;
 	atomicMax(&tmax[t], nex[h]);
 	atomicMin(&tmin[t], nex[h]);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_pseudo2(const int32_t *gnm, const int32_t *pid, const int32_t *nex, const int32_t *rank, uint32_t *flags,
-                                                     int n, int P, const int32_t *tmax, const int32_t *tmin, int32_t *tr1, int32_t *stats)
+                                                     int n, int P, const uint32_t *bits, const int32_t *tmax, const int32_t *tmin, int32_t *tr1, int32_t *stats)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
 	int64_t t = (int64_t)gnm[h] * P + pid[h];
+	if (!ps_cell(bits, t)) return;
 	int mx = tmax[t], mn = tmin[t], ne = nex[h];
 	if (!(mx > 1 && (mn == 1 || mn * 2 <= mx))) return; // hit.c:84
 	if (ne == 1 || ne * 2 <= mx) {
@@ -173,17 +190,19 @@ __global__ __launch_bounds__(BLOCK) void k_pseudo2(const int32_t *gnm, const int
 	} else atomicMin(&tr1[t], rank[h]);
 }
 
+// (C: the sweep's record C carries a copy of the rank -- the few ranks that change are patched here instead of by a pass over every record)
 __global__ __launch_bounds__(BLOCK) void k_pseudo3(const int32_t *gnm, const int32_t *pid, int32_t *rank, int n, int P,
-                                                     const int32_t *tmax, const int32_t *tmin, const int32_t *tr1)
+                                                     const uint32_t *bits, const int32_t *tmax, const int32_t *tmin, const int32_t *tr1, int4 *C)
 {
 	int h = blockIdx.x * BLOCK + threadIdx.x;
 	if (h >= n) return;
 	int64_t t = (int64_t)gnm[h] * P + pid[h];
+	if (!ps_cell(bits, t)) return;
 	int mx = tmax[t], mn = tmin[t], r1 = tr1[t];
 	if (!(mx > 1 && (mn == 1 || mn * 2 <= mx)) || r1 == INT32_MAX || r1 == 0) return;
 	int r = rank[h];
-	if (r < r1) rank[h] = r + 1; // hit.c:95-97
-	else if (r == r1) rank[h] = 0;
+	if (r < r1) rank[h] = r + 1, ((int32_t *)&C[h])[0] = r + 1; // hit.c:95-97
+	else if (r == r1) rank[h] = 0, ((int32_t *)&C[h])[0] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

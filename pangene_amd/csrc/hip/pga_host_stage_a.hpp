@@ -433,14 +433,13 @@ extern "C" int pga_ingest(pga_ctx_t *c, int32_t *stats)
 			int32_t *tmax = (int32_t *)c->pool.get(S_TAB_A, sizeof(int32_t) * (size_t)TP);
 			int32_t *tmin = (int32_t *)c->pool.get(S_TAB_B, sizeof(int32_t) * (size_t)TP);
 			int32_t *tr1 = (int32_t *)c->pool.get(S_TAB_C, sizeof(int32_t) * (size_t)TP);
-			if (!tmax || !tmin || !tr1) return PGA_ERR_NOMEM;
-			HIPCHK(hipMemsetAsync(tmax, 0, sizeof(int32_t) * (size_t)TP, c->st));
-			hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tmin, TP, INT32_MAX);
-			hipLaunchKernelGGL(k_fill_i32, dim3(nblk(TP)), dim3(BLOCK), 0, c->st, tr1, TP, INT32_MAX);
-			hipLaunchKernelGGL(k_pseudo1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, N, P, tmax, tmin);
-			hipLaunchKernelGGL(k_pseudo2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, c->rank, c->flags, N, P, tmax, tmin, tr1, k_stats);
-			hipLaunchKernelGGL(k_pseudo3, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->rank, N, P, tmax, tmin, tr1);
-			hipLaunchKernelGGL(k_pack_rank, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->rank, N, c->recC); // rank changed
+			uint32_t *pbits = (uint32_t *)c->pool.get(S_TAB_D, sizeof(uint32_t) * (size_t)((TP + 31) / 32) + 64); // (S_TAB_D: the filters' table of the four-kernel form, which comes later)
+			if (!tmax || !tmin || !tr1 || !pbits) return PGA_ERR_NOMEM;
+			HIPCHK(hipMemsetAsync(pbits, 0, sizeof(uint32_t) * (size_t)((TP + 31) / 32), c->st));
+			hipLaunchKernelGGL(k_pseudo0, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->rank, N, P, pbits, tmax, tmin, tr1); // the cells that matter, initialised by the hits that name them
+			hipLaunchKernelGGL(k_pseudo1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, N, P, (const uint32_t *)pbits, tmax, tmin);
+			hipLaunchKernelGGL(k_pseudo2, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->nex, c->rank, c->flags, N, P, (const uint32_t *)pbits, tmax, tmin, tr1, k_stats);
+			hipLaunchKernelGGL(k_pseudo3, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->gnm, c->pid, c->rank, N, P, (const uint32_t *)pbits, tmax, tmin, tr1, c->recC); // (the ranks that change are patched in record C too)
 		}
 		unsigned long long *tbest = c->gf_ok ? nullptr : (unsigned long long *)c->pool.get(S_TAB_D, sizeof(uint64_t) * (size_t)TQ);
 		uint8_t *noiso = c->gf_ok ? nullptr : (uint8_t *)c->pool.get(S_TAB_A, (size_t)TP + 16); // byte (genome, protein): the protein has a hit there without flt_iso_ov
