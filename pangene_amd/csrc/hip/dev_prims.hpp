@@ -157,11 +157,39 @@ __global__ __launch_bounds__(BLOCK) void scan_tile_apply(In in, Out out, int64_t
 	}
 }
 
+// A short scan in ONE launch (round 6): one workgroup, thread t over a contiguous chunk -- reduce, scan of the 256 partial results, apply.  The lists of an
+// order override (a few thousand entries, three scans an override, sixty-six overrides a pass of the isoform-rich 200-assembly set) and the per-segment
+// scans took two launches each through the tiled form.
+constexpr int SCAN_ONE_IPT = 16;
+constexpr int64_t SCAN_ONE_MAX = (int64_t)BLOCK * SCAN_ONE_IPT; // 4 096
+template <class T, class Op, class In, class Out>
+__global__ __launch_bounds__(BLOCK) void scan_one_block(In in, Out out, int64_t n, Op op, T identity, Gate gate)
+{
+	__shared__ T wave_tot[BLOCK / WAVE];
+	if (gate_closed(gate)) return;
+	const int64_t lo = (int64_t)threadIdx.x * SCAN_ONE_IPT;
+	T v[SCAN_ONE_IPT]; // (every input of the thread asked for before any is combined: the inputs are gathers as a rule)
+#pragma unroll
+	for (int k = 0; k < SCAN_ONE_IPT; ++k) v[k] = lo + k < n ? in(lo + k) : identity;
+	T acc = identity;
+#pragma unroll
+	for (int k = 0; k < SCAN_ONE_IPT; ++k) acc = op(acc, v[k]);
+	T run = block_scan_excl(acc, op, identity, wave_tot, (T *)nullptr);
+#pragma unroll
+	for (int k = 0; k < SCAN_ONE_IPT; ++k) {
+		if (lo + k >= n) break;
+		const T before = run;
+		run = op(run, v[k]);
+		out(lo + k, run, before);
+	}
+}
+
 // host-side driver; tile_buf must hold ceil(n/TILE) elements of T
 template <class T, class Op, class In, class Out>
 static inline void device_scan(In in, Out out, int64_t n, T *tile_buf, Op op, T identity, hipStream_t st, Gate gate = Gate{nullptr, 0})
 {
 	if (n <= 0) return;
+	if (n <= SCAN_ONE_MAX) { hipLaunchKernelGGL((scan_one_block<T, Op, In, Out>), dim3(1), dim3(BLOCK), 0, st, in, out, n, op, identity, gate); return; }
 	const int64_t n_tile = (n + TILE - 1) / TILE;
 	hipLaunchKernelGGL((scan_tile_reduce<T, Op, In>), dim3((unsigned)n_tile), dim3(BLOCK), 0, st, in, n, tile_buf, op, identity, gate);
 	if (n_tile <= 2048) {
