@@ -271,8 +271,7 @@ def test_sweep_exon_lists_in_lds_or_global_same_bytes(hip, expected, tmp_path, n
     assert hashlib.md5(out).hexdigest() == expected[name][variant]["md5"]
 
 
-@pytest.mark.parametrize("live", ["1", "0"])
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode,live", [(1, "1"), (2, "1"), (2, "0")])
 @pytest.mark.parametrize("name,variant", [("human8f", "-p0 -a1"), ("human8f", "-S"), ("human8", ""), ("bact20", ""), ("bact20", "-S"), ("mut1", "-S"), ("dense", ""), ("fuzz3", "-S"), ("fuzz7126", "-D 300 -C 2"),
                                           ("manydoms", "-G"), ("wide1", "-p0 -a1"), ("C4", ""), ("human8", "--bed=flag")])
 def test_live_lists_same_bytes(hip, expected, tmp_path, name, variant, mode, live):
