@@ -783,7 +783,7 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 		d->prot[i].avg_score_adj = d->prot[i].n ? (int32_t)((double)(z[(size_t)i].x >> 32) / d->prot[i].n + .499) : 0;
 	}
 	const double tp1 = now_sec();
-	ksort_exact_mt(z.data(), z.size(), [](const pg128_t &a) { return a.x; }, host_threads(8u)); // unstable in the reference; ties reach LN/pp (threads from 32 768 proteins on: the buckets of the first pass side by side, the same element moves)
+	ksort_exact(z.data(), z.size(), [](const pg128_t &a) { return a.x; }); // unstable in the reference; ties reach LN/pp
 	const double tp2 = now_sec();
 	for (int32_t i = P - 1; i >= 0; --i) {
 		int32_t pid = (int32_t)z[(size_t)i].y, gid = d->prot[pid].gid;

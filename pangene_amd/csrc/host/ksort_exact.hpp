@@ -9,10 +9,6 @@
 #include <cstdint>
 #include <cstring>
 #include <utility>
-#include <atomic>
-#include <system_error>
-#include <thread>
-#include <vector>
 
 namespace pgx {
 
@@ -46,10 +42,8 @@ static int ks_skip_levels(const T *a, size_t n, int shift, KeyFn key)
 	return top / 8 * 8;
 }
 
-// nt > 1: the buckets of THIS pass are handed to nt threads afterwards (they are disjoint ranges and a bucket's sort touches nothing else, so
-// the element moves inside every bucket are those of the sequential recursion): ksort_exact_mt
 template <class T, class KeyFn>
-static void ks_flag_pass(T *a, size_t n, int shift, KeyFn key, unsigned nt = 1)
+static void ks_flag_pass(T *a, size_t n, int shift, KeyFn key)
 {
 	// The reference walks all 256 buckets; empty ones are skipped there without effect, so only the occupied
 	// digits (kept in a 256-bit set) are visited here -- same element moves, far fewer iterations for the small
@@ -86,26 +80,6 @@ static void ks_flag_pass(T *a, size_t n, int shift, KeyFn key, unsigned nt = 1)
 	}
 	if (shift == 0) return;
 	int next = shift > 8 ? shift - 8 : 0;
-	if (nt > 1) {
-		size_t off[257];
-		off[0] = 0;
-		for (int t = 0; t < nd; ++t) off[t + 1] = off[t] + cnt[digits[t]];
-		std::atomic<int> cursor{0};
-		auto work = [&]() {
-			for (;;) {
-				const int t = cursor.fetch_add(1);
-				if (t >= nd) break;
-				const size_t m = off[t + 1] - off[t];
-				if (m > 64) { const int nx = m * 2 > n ? ks_skip_levels(a + off[t], m, next, key) : next; if (nx >= 0) ks_flag_pass(a + off[t], m, nx, key); }
-				else if (m > 1) ks_insertion(a + off[t], m, key);
-			}
-		};
-		std::vector<std::thread> th;
-		try { for (unsigned k = 1; k < nt; ++k) th.emplace_back(work); } catch (const std::system_error &) { } // (no thread to be had: this one does what is left)
-		work();
-		for (std::thread &x : th) x.join();
-		return;
-	}
 	size_t st = 0;
 	for (int t = 0; t < nd; ++t) {
 		size_t m = cnt[digits[t]];
@@ -128,19 +102,6 @@ static void ksort_exact(T *a, size_t n, KeyFn key)
 	int top = 63;
 	while (!(diff >> top & 1)) --top;
 	ks_flag_pass(a, n, top / 8 * 8, key);
-}
-
-// the same order by several threads: the first pass alone, its buckets side by side (for the long sorts: 100 000 proteins by their score sums)
-template <class T, class KeyFn>
-static void ksort_exact_mt(T *a, size_t n, KeyFn key, unsigned nt)
-{
-	if (nt <= 1 || n < 32768) { ksort_exact(a, n, key); return; }
-	uint64_t diff = 0, k0 = key(a[0]);
-	for (size_t i = 1; i < n; ++i) diff |= key(a[i]) ^ k0;
-	if (diff == 0) return;
-	int top = 63;
-	while (!(diff >> top & 1)) --top;
-	ks_flag_pass(a, n, top / 8 * 8, key, nt);
 }
 
 } // namespace pgx

@@ -26,14 +26,6 @@ int main()
 				++n_case;
 				for (size_t i = 0; i < n; ++i)
 					if (a[i].x != b[i].x || a[i].y != b[i].y) { ++n_bad; std::printf("MISMATCH n=%zu bits=%d rep=%d at %zu\n", n, bits, rep, i); break; }
-				if (n >= 32768) { // the threaded form (the first pass alone, its buckets side by side): the same permutation
-					std::vector<t128_t> in(n); // (b is sorted: the input back from the indices)
-					for (size_t i = 0; i < n; ++i) in[b[i].y] = b[i];
-					pgx::ksort_exact_mt(in.data(), n, [](const t128_t &e) { return e.x; }, 4);
-					++n_case;
-					for (size_t i = 0; i < n; ++i)
-						if (a[i].x != in[i].x || a[i].y != in[i].y) { ++n_bad; std::printf("MISMATCH (threads) n=%zu bits=%d rep=%d at %zu\n", n, bits, rep, i); break; }
-				}
 			}
 	std::printf("ksort check: %ld cases, %ld mismatches\n", n_case, n_bad);
 	return n_bad != 0;
