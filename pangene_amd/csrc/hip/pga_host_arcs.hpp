@@ -37,7 +37,7 @@ static int walk_prev(pga_ctx *c, int32_t **val_out, int32_t **prev_out)
 
 // gene-major index: hits sorted by (gene, X position) -- X order is genome-major, so a gene's hits are grouped by genome
 // known_live >= 0: the caller has just counted the hits without flt (and nothing was filtered since): the live lists are built, without a wait
-static int build_z(pga_ctx *c, int64_t known_live);
+static int build_z(pga_ctx *c, int64_t known_live, bool may_wait = true);
 static int ensure_z(pga_ctx *c)
 {
 	if (c->N == 0) return 0;
@@ -47,7 +47,7 @@ static int ensure_z(pga_ctx *c)
 	}
 	return build_z(c, -1);
 }
-static int build_z(pga_ctx *c, int64_t known_live)
+static int build_z(pga_ctx *c, int64_t known_live, bool may_wait) // may_wait = false: nothing is built when building would mean a host wait (the live lists' count)
 {
 	const int N = c->N;
 	uint64_t *key = (uint64_t *)c->pool.get(S_KEY_A, 0);
@@ -58,6 +58,7 @@ static int build_z(pga_ctx *c, int64_t known_live)
 	static const int live_env = [] { const char *e = getenv("PANGENE_LIVE_LISTS"); return e ? atoi(e) : -1; }();
 	const bool want_live = live_env != 0 && (known_live >= 0 || (c->live_hint >= 0 && (live_env == 1 || c->live_hint * 4 <= (int64_t)N * 3)));
 	int n = N;
+	if (want_live && known_live < 0 && !may_wait) return 0;
 	if (want_live) {
 		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(N));
 		if (!tile) return PGA_ERR_NOMEM;
@@ -81,6 +82,19 @@ static int build_z(pga_ctx *c, int64_t known_live)
 	if (n) hipLaunchKernelGGL(k_zrec, dim3(nblk(n)), dim3(BLOCK), 0, c->st, vs, ks, c->ctg_base, c->n_genome, c->flags, c->cm, c->seg, n, ZIndex{c->zx, c->zy, c->zg, c->zst, c->zpos});
 	hipLaunchKernelGGL(k_zoff, dim3(nblk(c->Q + 1)), dim3(BLOCK), 0, c->st, ks, n, c->Q, c->zoff);
 	c->z_valid = true, c->ha_valid = false, c->zposy_stale = false, c->wrec_valid = false;
+	return 0;
+}
+
+// the index (and the walk's records) queued now, behind whatever the stream holds: see pga_ctx::z_early
+static int early_index(pga_ctx *c)
+{
+	c->z_early = false;
+	if (c->N == 0 || c->z_valid) return 0;
+	TRY(build_z(c, -1, false));
+	if (c->z_valid && !c->wrec_valid && c->NL) {
+		hipLaunchKernelGGL(k_pack_wrec, dim3(nblk(c->NL)), dim3(BLOCK), 0, c->st, WrecSrc{c->ylist, c->seg, c->gid, c->cm, c->sori, c->sdom, c->pdom0, c->prot_gid, c->flags, c->zpos, c->vfirst, c->vbase}, c->NL, c->wrec);
+		c->wrec_valid = true;
+	}
 	return 0;
 }
 

@@ -165,6 +165,7 @@ extern "C" void pga_destroy(pga_ctx_t *c)
 	for (int k = 0; k < 2; ++k) if (c->ov_ev[k]) { (void)hipEventDestroy(c->ov_ev[k]); c->ov_ev[k] = nullptr; }
 	c->pin.release(); // h_cnt, h_stage, h_g2s, h_round, h_ndl live there
 	if (c->g2s_done) (void)hipEventDestroy(c->g2s_done);
+	if (c->z_ev) (void)hipEventDestroy(c->z_ev);
 	if (c->own_stream && c->st) (void)hipStreamDestroy(c->st);
 	delete c;
 }

@@ -217,6 +217,10 @@ struct pga_ctx {
 	int32_t *lx = 0;         // [N + 1] members before X position x when the lists were built (a contig keeps its range and its count through order overrides: valid at contig starts)
 	int32_t *ylist_buf = 0;  // [N] storage of the members' list in cm order
 	const int32_t *ylist = 0;// what the walk reads: ylist_buf, or yperm when the lists hold every hit
+	// The gene-major index behind the vertex greedy (round 6): pg_gen_vtx's host part (the greedy over genes, ~0.3-0.7 ms) leaves the device idle, and the
+	// index of the first pg_gen_arc (a sort and three gathers: 0.1 ms at configs[1], 1.2 ms at 12.1 M hits) only needs what the upload and stage A left.
+	// pga_vtx_partials arms this; the host's next fetch queues the index behind its copy and waits for the COPY alone (an event), not for the stream.
+	bool z_early = false; hipEvent_t z_ev = nullptr;
 	int32_t *ga_ctl = 0; // [2] k_gene_arcs_big's hand-out counters (cleared by the k_sweep_slow of the arc round's sweep)
 	int4 *cA = 0, *cB = 0, *cC = 0; int32_t *cx = 0; // [N] live lists: the sweep's records of the members, compact, in X order (pm over the members), and each member's X position
 	int2 *tg = 0; bool tg_valid = false; // [N] where the (contig, cs) tie group of a hit begins and ends in the cs order (k_tie_bounds: once per pass, members only)

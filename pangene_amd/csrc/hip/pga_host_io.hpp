@@ -3,7 +3,12 @@
 #pragma once
 
 
-extern "C" int pga_sync(pga_ctx_t *c) { return sync_st(c); }
+extern "C" int pga_sync(pga_ctx_t *c)
+{
+	TRY(sync_st(c));
+	if (c->z_early) TRY(early_index(c)); // (the host computes next: the device may as well)
+	return 0;
+}
 
 extern "C" int pga_fetch_later(pga_ctx_t *c, const void *src_backend, size_t nbytes, const void **host_view)
 {
@@ -15,6 +20,28 @@ extern "C" int pga_fetch_later(pga_ctx_t *c, const void *src_backend, size_t nby
 	}
 	*host_view = c->h_stage;
 	if (nbytes) HIPCHK(hipMemcpyAsync(c->h_stage, src_backend, nbytes, hipMemcpyDeviceToHost, c->st));
+	return 0;
+}
+
+// the wait of a fetch.  Armed by pga_vtx_partials (pga_ctx::z_early): the gene-major index is queued behind the copy, and the wait is for the copy alone
+static int fetch_wait(pga_ctx *c)
+{
+	if (!c->z_early) return sync_st(c);
+	if (!c->z_ev) HIPCHK(hipEventCreateWithFlags(&c->z_ev, hipEventDisableTiming));
+	HIPCHK(hipEventRecord(c->z_ev, c->st));
+	TRY(early_index(c)); // (sync_epoch stays: nobody has waited for the STREAM)
+	for (unsigned long long it = 1;; ++it) { // (as sync_st: poll for a while, then park)
+		const hipError_t e = hipEventQuery(c->z_ev);
+		if (e == hipSuccess) return 0;
+		if (e != hipErrorNotReady) HIPCHK(e);
+		__builtin_ia32_pause();
+		if ((it & 0x3ff) == 0) {
+			static thread_local timespec t0 = { 0, 0 }; timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+			if (it == 0x400) t0 = t;
+			if ((t.tv_sec - t0.tv_sec) + (t.tv_nsec - t0.tv_nsec) * 1e-9 > 200e-6) break;
+		}
+	}
+	HIPCHK(hipEventSynchronize(c->z_ev));
 	return 0;
 }
 
@@ -31,12 +58,12 @@ extern "C" int pga_fetch(pga_ctx_t *c, void *dst_host, const void *src_backend, 
 			c->h_fetch_cap = nbytes + nbytes / 2 + 256;
 		}
 		HIPCHK(hipMemcpyAsync(c->h_fetch, src_backend, nbytes, hipMemcpyDeviceToHost, c->st));
-		TRY(sync_st(c));
+		TRY(fetch_wait(c));
 		memcpy(dst_host, c->h_fetch, nbytes);
 		return 0;
 	}
 	HIPCHK(hipMemcpyAsync(dst_host, src_backend, nbytes, hipMemcpyDeviceToHost, c->st));
-	return sync_st(c);
+	return fetch_wait(c);
 }
 
 extern "C" int pga_put(pga_ctx_t *c, void *dst_backend, const void *src_host, size_t nbytes)

@@ -309,7 +309,7 @@ static int y_fixup_on() { static const int on = [] { const char *e = getenv("PAN
 extern "C" int pga_begin(pga_ctx_t *c)
 {
 	c->yrec_valid = false, c->wrec_valid = false, c->z_valid = false, c->zposy_stale = false;
-	c->tg_valid = false;
+	c->tg_valid = false, c->z_early = false;
 	c->live_on = false, c->NL = c->N, c->ylist = c->yperm, c->live_hint = -1; // (the flag words are written afresh: no F_MEMBER survives)
 	const int N = c->N, GL = c->n_genome;
 	c->walk_valid = false, c->ha_valid = false;

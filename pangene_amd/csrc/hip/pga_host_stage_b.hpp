@@ -106,6 +106,7 @@ extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records,
 			TRY(sync_st(c));
 		}
 		*n_records = n_rec + n_ovf;
+		c->z_early = !c->z_valid; // (the caller fetches the records next and then computes for a while: pga_fetch)
 		return 0;
 	}
 }
