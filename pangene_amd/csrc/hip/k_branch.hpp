@@ -21,11 +21,9 @@ struct OutRank {
 // carry has to cross a genome and the scan needs no second launch -- one workgroup a genome, 1024 hits a step, the wave ranks by ballots.
 // (rx[first hit of a genome] = 0 here.)  Used while no genome is long enough for its workgroup to become the launch's tail (pga_rep_pos).
 constexpr int RK_T = 1024;
-__global__ __launch_bounds__(RK_T) void k_rank_genome(const uint32_t *flags, const int32_t *goff, int32_t *rx, Gate gate)
+__device__ __forceinline__ void rank_genome_body(const uint32_t *flags, const int32_t *goff, int32_t *rx, const int g, int (*wtot)[RK_T / WAVE])
 {
-	__shared__ int wtot[2][RK_T / WAVE];
-	if (gate_closed(gate)) return;
-	const int g = blockIdx.x, h0 = goff[g], h1 = goff[g + 1], tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int h0 = goff[g], h1 = goff[g + 1], tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 	int carry = 0, par = 0;
 	for (int base = h0; base < h1; base += RK_T, par ^= 1) { // (two sets of wave totals used in turn: one barrier a step)
@@ -40,6 +38,12 @@ __global__ __launch_bounds__(RK_T) void k_rank_genome(const uint32_t *flags, con
 		if (i < h1) rx[i] = (pre + __popcll(m & lt)) | ((f & F_CSTIE) ? (int32_t)0x80000000 : 0);
 		carry += tot;
 	}
+}
+__global__ __launch_bounds__(RK_T) void k_rank_genome(const uint32_t *flags, const int32_t *goff, int32_t *rx, Gate gate)
+{
+	__shared__ int wtot[2][RK_T / WAVE];
+	if (gate_closed(gate)) return;
+	rank_genome_body(flags, goff, rx, blockIdx.x, wtot);
 }
 
 // Position record of (gene, genome): {contig, rank among the walkable hits of the genome, cm} of the gene's LAST walkable hit in
@@ -105,10 +109,8 @@ __global__ __launch_bounds__(BLOCK) void k_rep_clear(void *rp_out, int64_t n_ent
 
 // CLEARED: k_rep_clear ran first (live lists); otherwise this kernel writes every record itself, the absent ones too (one launch a round less)
 template <int FORM, bool CLEARED>
-__global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
+__device__ __forceinline__ void rep_fill_body(const RepFill &a, const int t)
 {
-	if (gate_closed(a.gate)) return;
-	const int t = blockIdx.x * BLOCK + threadIdx.x;
 	if (!CLEARED && t < a.Q && a.zoff[t] == a.zoff[t + 1]) rep_absent<FORM>(a, (int64_t)t * a.GL, a.GL); // a gene without hits in this shard
 	if (t >= a.NZ) return;
 	const int z = t;
@@ -166,6 +168,12 @@ __global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
 		((int4 *)a.rp_out)[e] = make_int4(a.vfirst[st.y], r | (ivl ? (int)0x80000000 : 0), (int)(unsigned)(unsigned long long)cm64, (int)((unsigned long long)cm64 >> 32));
 		if (ivl) a.iv[e] = ivl;
 	} else ((int4 *)a.rp_out)[e] = make_int4(st.y, r, cmw, ivl);
+}
+template <int FORM, bool CLEARED>
+__global__ __launch_bounds__(BLOCK) void k_rep_fill(RepFill a)
+{
+	if (gate_closed(a.gate)) return;
+	rep_fill_body<FORM, CLEARED>(a, blockIdx.x * BLOCK + threadIdx.x);
 }
 
 // hazard H2b inside pg_n_local: the pair's distance test failed, so the count test |r1 - r2| <= local_count decides, and at
@@ -318,19 +326,23 @@ __global__ __launch_bounds__(BLOCK) void k_deg(const int32_t *vs, const int32_t 
 }
 
 // number of pg_n_local calls of vertex v: n_max * n_weak (branch.c:70-75) + n(n-1)/2 (branch.c:83-88)
-__global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1, double bd, int32_t *pc, Gate gate)
+__device__ __forceinline__ int br_count_one(const int v, const int32_t *vs, const int32_t *ve, const int32_t *s1, const double bd)
 {
-	const int v = blockIdx.x * BLOCK + threadIdx.x;
-	if (v >= n_vtx || gate_closed(gate)) return;
 	const int a0 = vs[v], n = ve[v] - a0;
-	if (n < 2) { pc[v] = 0; return; }
+	if (n < 2) return 0;
 	int max_s1 = 0, n_max = 0, n_weak = 0;
 	for (int i = 0; i < n; ++i) max_s1 = max_s1 > s1[a0 + i] ? max_s1 : s1[a0 + i];
 	for (int i = 0; i < n; ++i) {
 		n_max += s1[a0 + i] == max_s1;
 		n_weak += (1.0 - (double)s1[a0 + i] / max_s1) > bd; // branch.c:71-72
 	}
-	pc[v] = n_max * n_weak + n * (n - 1) / 2;
+	return n_max * n_weak + n * (n - 1) / 2;
+}
+__global__ __launch_bounds__(BLOCK) void k_br_count(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1, double bd, int32_t *pc, Gate gate)
+{
+	const int v = blockIdx.x * BLOCK + threadIdx.x;
+	if (v >= n_vtx || gate_closed(gate)) return;
+	pc[v] = br_count_one(v, vs, ve, s1, bd);
 }
 
 // Exclusive prefix sums of the vertices' pair counts in ONE workgroup: a graph has thousands of vertices, not millions, and the
@@ -457,18 +469,12 @@ __device__ void br_vertex_wide(const int lane, int a0, int n, const int32_t *s1,
 // broadcast with shuffles, so the O(n^2) pair loops of branch.c:70-90 touch memory only for the pair list
 // (coalesced stores, MODE 1) or the all-reduced counts (coalesced loads, MODE 2).
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
-                                                     const int32_t *poff, int32_t *pairs, int64_t pair_cap /* MODE 1: room in pairs[] */, const int32_t *pcnt /* MODE 1: pairs of each vertex */, const int32_t *cnt, double bdist, double bcut,
-                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, uint8_t *vwk /* MODE 2: vertex has a weak arc */,
-                                                     const int64_t *np_dev = nullptr /* MODE 2: the number of pairs, when the list has a capacity (pair_cap) */, Gate gate = Gate{nullptr, 0})
+__device__ __forceinline__ void br_wave_body(const int v, const int lane, uint16_t *s_grp /* MODE 2: the workgroup's */, const int64_t k0 /* poff[v] */, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
+                                             int32_t *pairs, int64_t pair_cap, const int32_t *pcnt, const int32_t *cnt, double bdist, double bcut,
+                                             uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, uint8_t *vwk)
 {
-	__shared__ uint16_t s_grp[MODE == 2 ? (BLOCK / WAVE) * BR_WIDE_CAP : 1];
-	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-	if (v >= n_vtx || gate_closed(gate)) return;
-	if (MODE == 2 && np_dev && *np_dev > pair_cap) return; // the list overflowed: there are no counts to read, the host repeats the step with room
 	const int a0 = vs[v], n = ve[v] - a0;
 	if (n < 2) { if (MODE == 2 && lane == 0) ndl[v] = 0; return; } // (every n_dist_loci entry is written: nothing to clear beforehand)
-	const int64_t k0 = poff[v];
 	if (MODE == 1 && k0 + pcnt[v] > pair_cap) return; // would run past the list: left out -- the total then exceeds the capacity too, the host sees that and repeats the round with room
 	if (n > WAVE && n <= BR_WIDE_CAP) {
 		int32_t g = 0;
@@ -525,6 +531,79 @@ __global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs,
 		}
 	}
 	if (MODE == 2 && lane == 0) ndl[v] = n_group; // (pinned host memory in the unsharded path: plain stores, released when the host asks the runtime about the stream)
+}
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_br_wave(int n_vtx, const int32_t *vs, const int32_t *ve, const int32_t *s1g, const int32_t *agidg, double bd,
+                                                     const int32_t *poff, int32_t *pairs, int64_t pair_cap /* MODE 1: room in pairs[] */, const int32_t *pcnt /* MODE 1: pairs of each vertex */, const int32_t *cnt, double bdist, double bcut,
+                                                     uint8_t *weak, int32_t *grpg, int32_t *ndl, int64_t *dcnt, uint8_t *vwk /* MODE 2: vertex has a weak arc */,
+                                                     const int64_t *np_dev = nullptr /* MODE 2: the number of pairs, when the list has a capacity (pair_cap) */, Gate gate = Gate{nullptr, 0})
+{
+	__shared__ uint16_t s_grp[MODE == 2 ? (BLOCK / WAVE) * BR_WIDE_CAP : 1];
+	const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (v >= n_vtx || gate_closed(gate)) return;
+	if (MODE == 2 && np_dev && *np_dev > pair_cap) return; // the list overflowed: there are no counts to read, the host repeats the step with room
+	br_wave_body<MODE>(v, lane, s_grp, poff[v], vs, ve, s1g, agidg, bd, pairs, pair_cap, pcnt, cnt, bdist, bcut, weak, grpg, ndl, dcnt, vwk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The front of a queued branch round in two launches instead of five (round 6; pga_branch_loop).  pg_gen_rep_pos (ranks -> records) and the pair
+// enumeration (counts -> offsets -> list) are two chains that share nothing until pg_n_local reads both: the links of the same depth go
+// into one launch, workgroups of either kind side by side.
+//   k_loop_front1 (RK_T threads):  [0, nbc)      pair counts of 1 024 vertices + their offsets INSIDE the workgroup + the workgroup's total (btot)
+//                                  [nbc, +GL)    k_rank_genome's workgroup of genome b - nbc
+//                                  the rest      k_rep_clear (live lists only)
+//   k_loop_front2 (BLOCK threads): [0, nb_rep)   k_rep_fill
+//                                  the rest      k_br_wave<1>, every wave adding the totals of the workgroups in front of its vertex's (at most 64:
+//                                                the loop takes graphs of up to 65 536 vertices) -- there is no launch for the offsets any more
+// ------------------------------------------------------------------------------------------------
+struct LoopFront {
+	int n_vtx, nbc, GL; const int32_t *vs, *ve, *s1; double bd; int32_t *pc, *poff, *btot; // counts
+	const uint32_t *flags; const int32_t *goff; int32_t *rx;                                 // ranks
+	void *rp_out; int64_t n_ent; int clear_bytes;                                            // clear (0: none, 8 / 16: record size)
+	Gate gate;
+};
+__global__ __launch_bounds__(RK_T) void k_loop_front1(LoopFront a)
+{
+	__shared__ int wtot[2][RK_T / WAVE];
+	if (gate_closed(a.gate)) return;
+	const int b = blockIdx.x, tid = threadIdx.x;
+	if (b < a.nbc) {
+		const int v = b * RK_T + tid, lane = tid & 63, w = tid >> 6;
+		const int pc = v < a.n_vtx ? br_count_one(v, a.vs, a.ve, a.s1, a.bd) : 0;
+		const I32 incl = wave_scan_incl(I32{pc}, OpSum{}, lane);
+		if (lane == 63) wtot[0][w] = incl.v;
+		__syncthreads();
+		int pre = 0, tot = 0;
+#pragma unroll
+		for (int k = 0; k < RK_T / WAVE; ++k) { const int t = wtot[0][k]; tot += t; if (k < w) pre += t; }
+		if (v < a.n_vtx) a.pc[v] = pc, a.poff[v] = pre + incl.v - pc;
+		if (tid == 0) a.btot[b] = tot;
+	} else if (b < a.nbc + a.GL) {
+		rank_genome_body(a.flags, a.goff, a.rx, b - a.nbc, wtot);
+	} else {
+		const int64_t e = (int64_t)(b - a.nbc - a.GL) * RK_T + tid;
+		if (e < a.n_ent) { if (a.clear_bytes == 8) ((int2 *)a.rp_out)[e] = make_int2(0, -1); else ((int4 *)a.rp_out)[e] = make_int4(-1, 0, 0, 0); }
+	}
+}
+struct LoopFront2 {
+	int nb_rep, n_vtx, nbc; const int32_t *vs, *ve, *s1, *agid; double bd; int32_t *poff; const int32_t *btot, *pc; int32_t *pairs; int64_t pair_cap; int64_t *dcnt;
+};
+template <int FORM, bool CLEARED>
+__global__ __launch_bounds__(BLOCK) void k_loop_front2(RepFill rf, LoopFront2 a)
+{
+	if (gate_closed(rf.gate)) return;
+	if ((int)blockIdx.x < a.nb_rep) { rep_fill_body<FORM, CLEARED>(rf, blockIdx.x * BLOCK + threadIdx.x); return; }
+	const int v = (blockIdx.x - a.nb_rep) * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (v >= a.n_vtx) return;
+	const int part = lane < a.nbc ? a.btot[lane] : 0, bv = v / RK_T;
+	const int base = wave_sum(lane < bv ? part : 0);
+	const int64_t k0 = (int64_t)base + a.poff[v];
+	if (lane == 0) a.poff[v] = (int32_t)k0; // (what k_br_wave<2> reads; only this wave touches the entry)
+	if (v == 0) { // k_pair_offsets' other results: the number of pairs, and "a queued round could not be completed" (a list beyond its capacity)
+		const int tot = wave_sum(part);
+		if (lane == 0) { a.dcnt[15] = tot; if (tot > a.pair_cap) a.dcnt[11] = 1; }
+	}
+	br_wave_body<1>(v, lane, nullptr, k0, a.vs, a.ve, a.s1, a.agid, a.bd, a.pairs, a.pair_cap, a.pc, nullptr, 0.0, 0.0, nullptr, nullptr, nullptr, a.dcnt, nullptr);
 }
 
 // pg_flt_high_occ's three tests (graph.c:226-258) for every segment of the round, from what the round left on the device:

@@ -3,9 +3,13 @@
 #pragma once
 
 
-extern "C" int pga_rep_pos(pga_ctx_t *c)
+// (pga_branch_loop) the launches of pg_gen_rep_pos left to the fused launches of the round's front (k_loop_front1 / 2, k_branch.hpp): what they need
+struct RepDefer { bool on; RepFill rf; int32_t *rx; unsigned nb; bool cleared; };
+
+static int rep_pos_impl(pga_ctx *c, RepDefer *df)
 {
 	const int N = c->N, GL = c->n_genome, Q = c->Q;
+	if (df) df->on = false;
 	const int64_t n_ent = (int64_t)Q * GL;
 	int4 *rp = (int4 *)c->pool.get(S_RP_SEG, sizeof(int4) * (size_t)n_ent);
 	int32_t *iv = (int32_t *)c->pool.get(S_RP_IV, sizeof(int32_t) * (size_t)n_ent);
@@ -17,10 +21,13 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 		if (!rx || !tile) return PGA_ERR_NOMEM;
 		TRY(ensure_half_arcs(c, c->ha_ori < 0 ? 0 : c->ha_ori)); // which hits are walkable, gene-major (normally left by the arc round just before)
 		static const bool rank_scan = env_has("PANGENE_RANK", "scan"); // (tests: the general scan on shards of short genomes too)
-		if (c->gs_np <= (1 << 15) && !rank_scan) hipLaunchKernelGGL(k_rank_genome, dim3((unsigned)GL), dim3(RK_T), 0, c->st, (const uint32_t *)c->flags, (const int32_t *)c->goff, rx, c->gate); // rank among the walkable hits of the genome, cs order
+		const bool defer = df && c->gs_np <= (1 << 15) && !rank_scan;
+		if (defer) ; // (k_loop_front1)
+		else if (c->gs_np <= (1 << 15) && !rank_scan) hipLaunchKernelGGL(k_rank_genome, dim3((unsigned)GL), dim3(RK_T), 0, c->st, (const uint32_t *)c->flags, (const int32_t *)c->goff, rx, c->gate); // rank among the walkable hits of the genome, cs order
 		else device_scan<I32>(InWalkX{c->flags}, OutRank{rx, c->flags}, N, tile, OpSum{}, I32{0}, c->st, c->gate); // rank among the walkable hits, cs order
 		if (!c->tg_valid) { hipLaunchKernelGGL(k_tie_bounds, dim3(nblk(N)), dim3(BLOCK), 0, c->st, (const int4 *)c->recA, (const uint32_t *)c->flags, N, c->tg); c->tg_valid = true; }
 		RepFill rf = { c->tg, n_ent, GL, Q, N, c->NL, c->zx, c->zy, c->zg, c->zst, c->zoff, c->hbk, c->round_tag, c->recA, c->gid, c->flags, rx, c->goff, c->ctg_base, (void *)rp, iv, c->dcnt, hzl, c->vfirst, c->vbase, c->gate };
+		if (defer) { df->on = true, df->rf = rf, df->rx = rx, df->cleared = c->live_on, df->nb = nblk(c->live_on ? std::max(c->NL, 1) : std::max(c->NL, Q)); return 0; }
 		if (c->live_on) { // the index holds the live hits only: genes and (gene, genome) groups without an entry are many -- their records by one coalesced fill
 			const unsigned nb = nblk(std::max(c->NL, 1));
 			if (c->rp_form == RP_COMPACT) {
@@ -42,6 +49,8 @@ extern "C" int pga_rep_pos(pga_ctx_t *c)
 	}
 	return 0;
 }
+
+extern "C" int pga_rep_pos(pga_ctx_t *c) { return rep_pos_impl(c, nullptr); }
 
 // n = number of pairs, or (np_dev != NULL) the capacity of d_pairs with the actual number in device memory
 static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, const int64_t *np_dev, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt)
@@ -70,21 +79,57 @@ extern "C" int pga_n_local(pga_ctx_t *c, const int32_t *pairs, int64_t n, int32_
 	return sync_st(c); // pairs is caller memory; the exchange may run on another stream
 }
 
+static inline size_t loop_btot_at(int n_vtx) { return ((size_t)n_vtx + 7) & ~(size_t)3; } // the totals of k_loop_front1's workgroups, behind the vertices' counts in S_BR_PC
+
+// pg_gen_rep_pos unfused after all (the launches rep_pos_impl left out)
+static void rep_launch_deferred(pga_ctx *c, const RepDefer &d)
+{
+	const RepFill &rf = d.rf;
+	hipLaunchKernelGGL(k_rank_genome, dim3((unsigned)rf.GL), dim3(RK_T), 0, c->st, rf.flags, rf.goff, d.rx, rf.gate);
+	const int form = c->rp_form;
+	if (d.cleared) {
+		if (rf.n_ent && form == RP_COMPACT) hipLaunchKernelGGL((k_rep_clear<RP_COMPACT>), dim3(nblk(rf.n_ent)), dim3(BLOCK), 0, c->st, rf.rp_out, rf.n_ent, rf.gate);
+		else if (rf.n_ent) hipLaunchKernelGGL((k_rep_clear<RP_FULL>), dim3(nblk(rf.n_ent)), dim3(BLOCK), 0, c->st, rf.rp_out, rf.n_ent, rf.gate);
+		if (form == RP_COMPACT) hipLaunchKernelGGL((k_rep_fill<RP_COMPACT, true>), dim3(d.nb), dim3(BLOCK), 0, c->st, rf);
+		else if (form == RP_WIDE) hipLaunchKernelGGL((k_rep_fill<RP_WIDE, true>), dim3(d.nb), dim3(BLOCK), 0, c->st, rf);
+		else hipLaunchKernelGGL((k_rep_fill<RP_FULL, true>), dim3(d.nb), dim3(BLOCK), 0, c->st, rf);
+	} else {
+		if (form == RP_COMPACT) hipLaunchKernelGGL((k_rep_fill<RP_COMPACT, false>), dim3(d.nb), dim3(BLOCK), 0, c->st, rf);
+		else if (form == RP_WIDE) hipLaunchKernelGGL((k_rep_fill<RP_WIDE, false>), dim3(d.nb), dim3(BLOCK), 0, c->st, rf);
+		else hipLaunchKernelGGL((k_rep_fill<RP_FULL, false>), dim3(d.nb), dim3(BLOCK), 0, c->st, rf);
+	}
+}
+
 // enumerate the pairs and count them (k_br_wave<1>, k_n_local) for the pair count in dcnt[15] (capacity c->br_cap)
-static int branch_enumerate(pga_ctx *c, int32_t **cnt)
+static int branch_enumerate(pga_ctx *c, int32_t **cnt, const RepDefer *df = nullptr)
 {
 	const int n_vtx = 2 * c->br_S;
 	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, 0), *agid = (int32_t *)c->pool.get(S_BR_GID, 0), *vs = (int32_t *)c->pool.get(S_BR_VS, 0), *ve = (int32_t *)c->pool.get(S_BR_VE, 0);
 	int32_t *poff = (int32_t *)c->pool.get(S_BR_POFF, 0);
 	int32_t *pairs = (int32_t *)c->pool.get(S_PAIRS, sizeof(int32_t) * 2 * (size_t)c->br_cap + 16);
 	if (!pairs || !s1 || !agid || !vs || !ve || !poff) return PGA_ERR_NOMEM;
+	if (df) { // the records of pg_gen_rep_pos and the pair list in one launch (k_loop_front1 ran: ranks, counts, offsets inside each workgroup of 1 024 vertices)
+		const int32_t *pc = (const int32_t *)c->pool.get(S_BR_PC, 0);
+		const LoopFront2 a = { (int)df->nb, n_vtx, (n_vtx + RK_T - 1) / RK_T, vs, ve, s1, agid, c->br_par.diff, poff, pc + loop_btot_at(n_vtx), pc, pairs, c->br_cap, c->dcnt };
+		const dim3 grid(df->nb + nblk(n_vtx, BLOCK / WAVE));
+		const int form = c->rp_form;
+		if (df->cleared) {
+			if (form == RP_COMPACT) hipLaunchKernelGGL((k_loop_front2<RP_COMPACT, true>), grid, dim3(BLOCK), 0, c->st, df->rf, a);
+			else if (form == RP_WIDE) hipLaunchKernelGGL((k_loop_front2<RP_WIDE, true>), grid, dim3(BLOCK), 0, c->st, df->rf, a);
+			else hipLaunchKernelGGL((k_loop_front2<RP_FULL, true>), grid, dim3(BLOCK), 0, c->st, df->rf, a);
+		} else {
+			if (form == RP_COMPACT) hipLaunchKernelGGL((k_loop_front2<RP_COMPACT, false>), grid, dim3(BLOCK), 0, c->st, df->rf, a);
+			else if (form == RP_WIDE) hipLaunchKernelGGL((k_loop_front2<RP_WIDE, false>), grid, dim3(BLOCK), 0, c->st, df->rf, a);
+			else hipLaunchKernelGGL((k_loop_front2<RP_FULL, false>), grid, dim3(BLOCK), 0, c->st, df->rf, a);
+		}
+	} else
 	hipLaunchKernelGGL((k_br_wave<1>), dim3(nblk(n_vtx, BLOCK / WAVE)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, agid, c->br_par.diff, poff, pairs, c->br_cap, (const int32_t *)c->pool.get(S_BR_PC, 0),
 	                   (const int32_t *)nullptr, 0.0, 0.0, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, c->dcnt, (uint8_t *)nullptr, (const int64_t *)nullptr, c->gate);
 	return n_local_dev(c, pairs, c->br_cap, c->dcnt + 15, c->br_par.local_dist, c->br_par.local_count, c->br_par.frag_mode, cnt);
 }
 
-extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg,
-                                double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs)
+static int branch_pairs_impl(pga_ctx *c, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg,
+                             double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs, const RepDefer *df)
 {
 	if (arc_x == nullptr) n_arc = c->br_n, n_seg = c->br_S; // the table of pga_arc_set_current
 	const int n_vtx = 2 * n_seg;
@@ -92,14 +137,15 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	uint8_t *aw = (uint8_t *)c->pool.get(S_ARCW, (size_t)n_arc + 16);
 	int32_t *s1 = (int32_t *)c->pool.get(S_BR_S1, sizeof(int32_t) * (size_t)n_arc + 16), *agid = (int32_t *)c->pool.get(S_BR_GID, sizeof(int32_t) * (size_t)n_arc + 16);
 	int32_t *vs = (int32_t *)c->pool.get(S_BR_VS, sizeof(int32_t) * (size_t)n_vtx + 16), *ve = (int32_t *)c->pool.get(S_BR_VE, sizeof(int32_t) * (size_t)n_vtx + 16);
-	int32_t *pc = (int32_t *)c->pool.get(S_BR_PC, sizeof(int32_t) * (size_t)n_vtx + 16), *poff = (int32_t *)c->pool.get(S_BR_POFF, sizeof(int32_t) * (size_t)n_vtx + 16);
+	int32_t *pc = (int32_t *)c->pool.get(S_BR_PC, sizeof(int32_t) * (loop_btot_at(n_vtx) + 64) + 16), *poff = (int32_t *)c->pool.get(S_BR_POFF, sizeof(int32_t) * (size_t)n_vtx + 16);
 	int32_t *sg = (int32_t *)c->pool.get(S_BR_SEGGID, sizeof(int32_t) * (size_t)n_seg + 16);
 	if (!ax || !aw || !s1 || !agid || !vs || !ve || !pc || !poff || !sg) return PGA_ERR_NOMEM;
 	c->br_n = n_arc, c->br_S = n_seg, c->br_np = -1;
 	c->br_par.diff = branch_diff, c->br_par.local_dist = local_dist, c->br_par.local_count = local_count, c->br_par.frag_mode = frag_mode;
 	if (n_pairs) *n_pairs = 0;
 	*cnt = (int32_t *)c->pool.get(S_NLCNT, 16);
-	if (n_arc == 0 || n_vtx == 0) { c->br_np = 0; return sync_st(c); }
+	if (df && !df->on) df = nullptr;
+	if (n_arc == 0 || n_vtx == 0) { if (df) rep_launch_deferred(c, *df); c->br_np = 0; return sync_st(c); }
 	if (arc_x) {
 		TRY(upload(c, ax, arc_x, (size_t)n_arc)); TRY(upload(c, s1, arc_s1, (size_t)n_arc)); TRY(upload(c, sg, seg_gid, (size_t)n_seg));
 		HIPCHK(hipMemsetAsync(vs, 0, sizeof(int32_t) * (size_t)n_vtx, c->st)); HIPCHK(hipMemsetAsync(ve, 0, sizeof(int32_t) * (size_t)n_vtx, c->st));
@@ -108,6 +154,16 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	}
 	static const bool general_scan = getenv("PANGENE_PAIR_SCAN_GENERAL") != nullptr; // (tests: the path of graphs with more than 65536 vertices)
 	const bool one_wg = n_vtx <= PO_THREADS * PO_MAX_ITEMS && !general_scan;
+	if (df && !(one_wg && n_pairs == nullptr)) { rep_launch_deferred(c, *df); df = nullptr; }
+	if (df) { // (pga_branch_loop) the counts, their offsets inside workgroups of 1 024 vertices, the ranks of pg_gen_rep_pos and its clear in ONE launch
+		const int nbc = (n_vtx + RK_T - 1) / RK_T; // <= 64 (one_wg)
+		const RepFill &rf = df->rf;
+		const int64_t n_clear = df->cleared ? rf.n_ent : 0;
+		const LoopFront a = { n_vtx, nbc, rf.GL, vs, ve, s1, branch_diff, pc, poff, pc + loop_btot_at(n_vtx), rf.flags, rf.goff, df->rx, rf.rp_out, n_clear, c->rp_form == RP_COMPACT ? 8 : 16, c->gate };
+		hipLaunchKernelGGL(k_loop_front1, dim3((unsigned)(nbc + rf.GL + (n_clear + RK_T - 1) / RK_T)), dim3(RK_T), 0, c->st, a);
+		if (c->br_cap < 4 * (int64_t)n_vtx) c->br_cap = 4 * (int64_t)n_vtx;
+		return branch_enumerate(c, cnt, df);
+	}
 	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc, c->gate);
 	if (one_wg) hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(PO_THREADS), 0, c->st, (const int32_t *)pc, n_vtx, poff, c->dcnt, c->h_box, n_pairs ? -1ll : (long long)std::max<int64_t>(c->br_cap, 4 * (int64_t)n_vtx), c->gate); // offsets, and dcnt[15] = number of pairs
 	else {
@@ -125,6 +181,12 @@ extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32
 	// it has to wait for its own results anyway and repeats the enumeration in the (first-round) case that it was not
 	if (c->br_cap < 4 * (int64_t)n_vtx) c->br_cap = 4 * (int64_t)n_vtx;
 	return branch_enumerate(c, cnt);
+}
+
+extern "C" int pga_branch_pairs(pga_ctx_t *c, const uint64_t *arc_x, const int32_t *arc_s1, int64_t n_arc, const int32_t *seg_gid, int32_t n_seg,
+                                double branch_diff, int32_t local_dist, int32_t local_count, int32_t frag_mode, int32_t **cnt, int64_t *n_pairs)
+{
+	return branch_pairs_impl(c, arc_x, arc_s1, n_arc, seg_gid, n_seg, branch_diff, local_dist, local_count, frag_mode, cnt, n_pairs, nullptr);
 }
 
 // pg_flt_high_occ's three tests (graph.c:226-258) on the device, so that a branch round's bulk results need not travel
@@ -406,9 +468,12 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		bool rebuilt = false;
 		c->gate = gated ? Gate{c->loopctl, r - 1} : Gate{nullptr, 0}; // the branch steps of round r: something changed in round r - 1
 		// pg_mark_branch_flt_arc (branch.c:48-106)
-		TRY(pga_rep_pos(c));
+		// (round 6: the five launches of these two steps' fronts as two, k_loop_front1 / 2 in k_branch.hpp; PANGENE_LOOP_FUSE=0: one by one as before)
+		static const bool fuse = !env_has("PANGENE_LOOP_FUSE", "0");
+		RepDefer df;
+		TRY(rep_pos_impl(c, fuse ? &df : nullptr));
 		int32_t *cnt;
-		TRY(pga_branch_pairs(c, nullptr, nullptr, 0, nullptr, S, par->branch_diff, par->local_dist, par->local_count, par->frag_mode, &cnt, nullptr));
+		TRY(branch_pairs_impl(c, nullptr, nullptr, 0, nullptr, S, par->branch_diff, par->local_dist, par->local_count, par->frag_mode, &cnt, nullptr, fuse ? &df : nullptr));
 		if (x) { const int rc = x->allreduce_i32_sum(x->user, cnt, L.pair_cap); if (rc) return rc; } // n_local over every rank's genomes (entries beyond the list's end: whatever they were)
 		{
 			const int64_t n_arc = c->br_n;
