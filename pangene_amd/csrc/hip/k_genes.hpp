@@ -450,7 +450,7 @@ __device__ __forceinline__ bool gene_arcs_one(const GeneArcs &a, GeneTable<CAP, 
 constexpr int GA_WAVE_NT = 128;
 // (a template over its three sizes so that other shapes can be measured side by side: PANGENE_GA_WAVE picks one, arc_round_genes)
 template <int NT, int CAP, int HITS, int CAP_LOG2>
-__global__ __launch_bounds__(NT) void k_gene_arcs_wave_t(GeneArcs a)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7))) void k_gene_arcs_wave_t(GeneArcs a)
 {
 	__shared__ GeneTable<CAP, HITS> T;
 	if (gate_closed(a.gate)) return;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(NT) void k_gene_arcs_wave_t(GeneArcs a)
 // (512 threads a gene: the LDS tables allow three of these workgroups on a CU whatever their width -- 12 waves of 256 threads, 24 of 512; 328 -> 258 us
 // at 12.1 M hits, where every gene comes here; 1 024 threads: two workgroups a CU, 305 us; a shard that sends nothing here pays 1-4 us more for the empty pass)
 constexpr int GA_BIG_NT = 512;
-__global__ __launch_bounds__(GA_BIG_NT) void k_gene_arcs_big(GeneArcs a)
+__global__ __launch_bounds__(GA_BIG_NT) __attribute__((amdgpu_waves_per_eu(6))) void k_gene_arcs_big(GeneArcs a)
 {
 	__shared__ GeneTable<GA_CAP, GA_BIG_STAGE> T;
 	if (gate_closed(a.gate)) return;
