@@ -196,14 +196,19 @@ __device__ __noinline__ bool nl_hazard(const NLocalHz &z, int cc, int iv1, int i
 // order -- hazard H2b -- does not stop it); cnt[k] = the hits seen until then: > 0 iff pg_n_local > 0, and sums over shards keep
 // that property.  Sixteen lanes work on one pair (sixteen genomes per step, one coalesced 128-byte read per record table), four
 // pairs per wave; as a rule the first step settles a pair, so the cost no longer grows with the number of genomes.
-constexpr int NL_PAIRS = 4, NL_LANES = 16;
+// (Lanes a pair, measured in round 6 -- 8 / 16 / 32 / 64: configs[1], 100 genomes, 4.62 / 4.58 / 4.73 / 5.00 ms a pass; the shard of 1 250 genomes
+// 24.6 / 23.1 / 22.4 / 22.3: where a gene is absent from most genomes the first sixteen settle little.  The host picks by the number of genomes.
+// Tried the other way too, four pairs a group in flight with their loads batched: k_n_local 31 -> 43 us at configs[1]; more waves beat longer ones.)
+constexpr int nl_lanes_for(int GL) { return GL <= 256 ? 16 : GL <= 640 ? 32 : 64; }
 
-template <int FORM>
+template <int FORM, int NL_LANES>
 __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t n_cap, const int64_t *np_dev, int GL, const void *rp_in,
                                                      int local_dist, int local_count, int frag_mode, int32_t *cnt, NLocalHz hz, Gate gate)
 {
+	constexpr int NL_PAIRS = WAVE / NL_LANES;
+	constexpr unsigned long long NL_MASK = NL_LANES == 64 ? ~0ull : ((1ull << (NL_LANES & 63)) - 1);
 	if (gate_closed(gate)) return;
-	const int lane = threadIdx.x & 63, grp = lane >> 4, sub = lane & (NL_LANES - 1);
+	const int lane = threadIdx.x & 63, grp = lane / NL_LANES, sub = lane & (NL_LANES - 1);
 	int64_t n_pair = np_dev ? *np_dev : n_cap; // the count may still be on its way to the host: it is read here
 	if (n_pair > n_cap) return; // more pairs than the list holds: some stretches of it were never written, and the host repeats the step with room
 	const int64_t stride = (int64_t)gridDim.x * (BLOCK / WAVE) * NL_PAIRS;
@@ -250,8 +255,8 @@ __global__ __launch_bounds__(BLOCK) void k_n_local(const int32_t *pairs, int64_t
 				if (cmp && !near && (a.z | b.z) < 0) sure = nl_hazard(hz, cc, a.w, b.w, a.x, b.x, local_count) && hit;
 			}
 			const unsigned long long mh = __ballot(hit), ms = __ballot(sure);
-			c += __popcll((mh >> (grp * NL_LANES)) & 0xffffull);
-			if ((ms >> (grp * NL_LANES)) & 0xffffull) open = false;
+			c += __popcll((mh >> (grp * NL_LANES)) & NL_MASK);
+			if ((ms >> (grp * NL_LANES)) & NL_MASK) open = false;
 		}
 		if (have && sub == 0) cnt[k] = c;
 	}

@@ -63,10 +63,15 @@ static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, const int6
 	if (!hz.iv || !hz.list) return PGA_ERR_NOMEM;
 	// the grid follows the last known number of pairs (the kernel strides over whatever there is)
 	const int64_t est = np_dev ? (c->br_np_seen > 0 ? c->br_np_seen : std::min<int64_t>(n, 1 << 18)) : n;
-	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nblk(est, BLOCK / WAVE * NL_PAIRS), 1 << 20));
-	if (n && c->rp_form == RP_COMPACT) hipLaunchKernelGGL((k_n_local<RP_COMPACT>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz, c->gate);
-	else if (n && c->rp_form == RP_WIDE) hipLaunchKernelGGL((k_n_local<RP_WIDE>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz, c->gate);
-	else if (n) hipLaunchKernelGGL((k_n_local<RP_FULL>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz, c->gate);
+	const int lanes = nl_lanes_for(c->n_genome);
+	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nblk(est, BLOCK / WAVE * (WAVE / lanes)), 1 << 20));
+#define NL_LAUNCH(FORM, LANES) hipLaunchKernelGGL((k_n_local<FORM, LANES>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz, c->gate)
+#define NL_FORM(FORM) do { if (lanes == 16) NL_LAUNCH(FORM, 16); else if (lanes == 32) NL_LAUNCH(FORM, 32); else NL_LAUNCH(FORM, 64); } while (0)
+	if (n && c->rp_form == RP_COMPACT) NL_FORM(RP_COMPACT);
+	else if (n && c->rp_form == RP_WIDE) NL_FORM(RP_WIDE);
+	else if (n) NL_FORM(RP_FULL);
+#undef NL_FORM
+#undef NL_LAUNCH
 	return 0;
 }
 
