@@ -253,7 +253,7 @@ void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, doub
 			const bool sorted = (size_t)j < ext->hits_sorted.size() && ext->hits_sorted[(size_t)j]; // (records moved into cs order by a sync_host: the signature was taken in file order)
 			stale[i] = pk.blk.n_hit != d->genome[j].n_hit || pk.blk.n_exon != d->genome[j].n_exon || (!sorted && pk.sig != genome_signature(&d->genome[j]));
 		};
-		unsigned nc = hh > 200000 ? host_threads(64u) : 1u;
+		unsigned nc = hh > 200000 ? std::min<unsigned>(host_threads(64u), (unsigned)(hh / 40000)) : 1u; // (a thread costs ~15 us to start and hashes a hit in ~5 ns: 64 of them for a million hits spend their time being started)
 		if (nc > have.size()) nc = (unsigned)have.size();
 		if (nc <= 1) { for (size_t i = 0; i < have.size(); ++i) check(i); }
 		else {
