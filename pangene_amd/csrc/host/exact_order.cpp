@@ -327,14 +327,19 @@ static void spawn_replay(DataExt *ext)
 // start of a run: the arrays are in file order (read.c:232-234).  The replay depends on the keys only: it runs on background
 // threads, started as early as the reader (exact_prefetch) or here, while the GPU does stages A and B; the first consumer joins
 // them.  A repeated run on the same shard (pg_rerun_resident) finds the replay done.
+// (Round 6: a replay the reader started is NOT waited for here -- on a 12.1 M-hit shard it was 9-33 ms of an upload-inclusive pass of 60-80, spent
+// in front of stage A, which needs nothing of it (mode "auto": the hand-over is in pg_graph_gen; mode "all": exact_sort waits as every consumer
+// does).  The workers leave every segment as this function would -- pushed_id = -1, replay()'s last line -- and touch nothing else of the data set.)
 void exact_begin(DataExt *ext)
 {
+	const bool in_flight = !ext->xworkers.empty();
+	static const bool wait_here = std::getenv("PANGENE_EXACT_WAIT") != nullptr; // (tests / timing: the old order of things)
 	const double t0 = now_sec();
-	exact_wait(ext);
-	if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[exact_begin] waited %.3f ms for the order replay the reader started\n", (now_sec() - t0) * 1e3);
+	if (wait_here) exact_wait(ext);
+	if (std::getenv("PANGENE_TIMING")) std::fprintf(stderr, "[exact_begin] waited %.3f ms for the order replay the reader started%s\n", (now_sec() - t0) * 1e3, in_flight && !wait_here ? " (it goes on beside stages A and B: its first consumer waits)" : "");
 	ext->head_file.assign(ext->local_genomes.size(), -1);
 	ext->x_sorts[0] = ext->x_sorts[1] = 0;
-	for (ExactSeg &s : ext->xsegs) s.pushed_id[0] = s.pushed_id[1] = -1;
+	if (!in_flight || wait_here) for (ExactSeg &s : ext->xsegs) s.pushed_id[0] = s.pushed_id[1] = -1;
 	spawn_replay(ext);
 }
 

@@ -129,7 +129,33 @@ static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int6
 // to hand the blocks to the backend: the upload is then plain DMA out of pinned memory.
 // ---------------------------------------------------------------------------------------------
 static void *block_alloc(DataExt *ext, size_t bytes);
-static uint64_t genome_signature(const pg_genome_t *g);
+// (the signature of a genome's records: what it is for is said above stale_packs)
+struct SigState { uint64_t h[4]; };
+static inline void sig_begin(SigState &s, const pg_genome_t *g)
+{
+	s.h[0] = 1469598103934665603ull ^ (uint64_t)(uint32_t)g->n_hit, s.h[1] = 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)g->n_exon, s.h[2] = 0xc2b2ae3d27d4eb4full ^ (uint64_t)(uint32_t)g->n_ctg, s.h[3] = 0x165667b19e3779f9ull;
+}
+static inline void sig_hit(SigState &s, int64_t i, const pg_hit_t &a)
+{
+	uint64_t &x = s.h[i & 3];
+	x = (x ^ ((uint64_t)(uint32_t)a.pid << 32 | (uint32_t)a.cid)) * 1099511628211ull;
+	x = (x ^ (uint64_t)a.cs) * 1099511628211ull; // (each 64-bit coordinate through a multiply of its own: shifted into one word they aliased -- cs bit 21 with ce bit 0)
+	x = (x ^ (uint64_t)a.ce) * 0x9e3779b97f4a7c15ull;
+	x = (x ^ (uint64_t)a.cm) * 1099511628211ull;
+	x = (x ^ ((uint64_t)(uint32_t)a.score_adj << 32 | (uint32_t)a.score_ori)) * 1099511628211ull;
+	x = (x ^ ((uint64_t)(uint32_t)a.off_exon << 32 | (uint32_t)a.n_exon << 8 | (uint32_t)a.rev << 7 | ((uint32_t)(a.rank & 0x7f) ^ (uint64_t)(uint32_t)a.rank << 40))) * 1099511628211ull;
+}
+static inline void sig_exon(SigState &s, int64_t i, const pg_exon_t &e) { uint64_t &x = s.h[i & 3]; x = (x ^ ((uint64_t)(uint32_t)e.os << 32 | (uint32_t)e.oe)) * 0x100000001b3ull; }
+static inline uint64_t sig_end(const SigState &s) { return (s.h[0] * 31 + s.h[1]) * 31 + (s.h[2] * 31 + s.h[3]); }
+static uint64_t genome_signature(const pg_genome_t *g)
+{
+	SigState s;
+	sig_begin(s, g);
+	for (int32_t i = 0; i < g->n_hit; ++i) sig_hit(s, i, g->hit[i]);
+	for (int32_t i = 0; i < g->n_exon; ++i) sig_exon(s, i, g->exon[i]);
+	return sig_end(s);
+}
+
 
 // Contigs whose coordinates do not fit 31 bits (pangene.h:71 has int64_t; the reference handles any length) reach the backend as VIRTUAL
 // contigs (pga_genome_block_t): cut at hit-free gaps into pieces of < 2^30 bp (+ the cluster of overlapping hits the cut has to wait
@@ -176,10 +202,15 @@ static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 	const int32_t *fof = sorted ? ext->file_of_host[(size_t)j].data() : nullptr;
 	int32_t max_cs = 0, max_cm = 0, max_sadj = 0, neg = 0, multi = 0;
 	// 64-bit coordinates: does any hit of the genome need a virtual contig?
+	// (round 6: ONE pass over the records -- the test for coordinates beyond 31 bits and the signature ride with the copy; a genome that does
+	// need virtual contigs is found out on the way and starts again as such)
 	static const bool force_v = std::getenv("PANGENE_VCTG_PIECE") != nullptr;
 	bool wide = force_v;
-	for (int64_t h = 0; h < n && !wide; ++h) wide = g->hit[h].ce >= INT32_MAX - 1 || g->hit[h].cm >= INT32_MAX - 1;
 	std::vector<int32_t> piece_of;
+	SigState sig;
+again:
+	sig_begin(sig, g);
+	max_cs = 0, max_cm = 0, max_sadj = 0, neg = 0, multi = 0;
 	if (wide) {
 		bool ok = true;
 		for (int64_t h = 0; h < n; ++h) { const pg_hit_t *a = &g->hit[h]; if (a->cs < 0 || a->cm < a->cs || a->ce < a->cs || a->cid < 0 || a->cid >= g->n_ctg) ok = false; }
@@ -188,7 +219,9 @@ static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 	for (int64_t h = 0; h < n; ++h) {
 		const pg_hit_t *a = &g->hit[h];
 		const int64_t f = fof ? fof[h] : h;
+		if (!sorted) sig_hit(sig, h, *a);
 		if (pk.err) continue;
+		if (!wide && (a->ce >= INT32_MAX - 1 || a->cm >= INT32_MAX - 1)) { wide = true; goto again; }
 		int32_t cid = a->cid;
 		int64_t cs = a->cs, ce = a->ce, cm = a->cm;
 		if (wide) { cid = piece_of[(size_t)h]; const int64_t base = pk.vbase[(size_t)cid]; cs -= base, ce -= base, cm -= base; }
@@ -200,14 +233,14 @@ static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 		if (a->score_adj < 0) neg = 1; else max_sadj = std::max(max_sadj, a->score_adj);
 		multi |= a->n_exon != 1;
 	}
-	for (int64_t e = 0; e < ne; ++e) ex[2 * e] = g->exon[e].os, ex[2 * e + 1] = g->exon[e].oe;
+	for (int64_t e = 0; e < ne; ++e) { ex[2 * e] = g->exon[e].os, ex[2 * e + 1] = g->exon[e].oe; if (!sorted) sig_exon(sig, e, g->exon[e]); }
 	pga_genome_block_t &b = pk.blk;
 	b.n_hit = (int32_t)n, b.n_exon = (int32_t)ne, b.n_ctg = wide ? (int32_t)pk.vfirst.size() : g->n_ctg;
 	b.max_cs = max_cs, b.max_cm = max_cm, b.max_score_adj = max_sadj, b.any_neg_score_adj = neg, b.any_multi_exon = multi;
 	b.data = w, b.n_words = nw;
 	b.vfirst = wide ? pk.vfirst.data() : nullptr, b.vbase = wide ? pk.vbase.data() : nullptr;
 	if (!wide) pk.vfirst.clear(), pk.vreal.clear(), pk.vbase.clear();
-	pk.sig = sorted ? 0 : genome_signature(g);
+	pk.sig = sorted ? 0 : sig_end(sig);
 }
 
 // A pack made when the genome was read is only good while the genome still is what it was then.  The public pg_data_t may be
@@ -216,53 +249,45 @@ static void pack_one(const pg_data_t *d, DataExt *ext, int32_t j)
 // sampled every 257th record; one pass over the records costs a fraction of the pack it may save -- four independent multiply chains
 // keep it at memory speed.  A 64-bit hash, not a proof: an edit is missed with probability ~2^-64; genomes whose records a sync_host has
 // already moved into cs order are not compared -- their pack was made from the order the signature was taken in.)
-static uint64_t genome_signature(const pg_genome_t *g)
+// which packs of [j0, j1) no longer match their genome?  The signatures read every record once (88 bytes a hit: 0.1 s for 12 M hits on one core), so the genomes are shared out
+static void stale_packs(const pg_data_t *d, const DataExt *ext, int32_t j0, int32_t j1, std::vector<int32_t> &out, const std::vector<uint8_t> *only = nullptr)
 {
-	uint64_t h[4] = { 1469598103934665603ull ^ (uint64_t)(uint32_t)g->n_hit, 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)g->n_exon, 0xc2b2ae3d27d4eb4full ^ (uint64_t)(uint32_t)g->n_ctg, 0x165667b19e3779f9ull };
-	for (int32_t i = 0; i < g->n_hit; ++i) {
-		const pg_hit_t &a = g->hit[i];
-		uint64_t &x = h[i & 3];
-		x = (x ^ ((uint64_t)(uint32_t)a.pid << 32 | (uint32_t)a.cid)) * 1099511628211ull;
-		x = (x ^ (uint64_t)a.cs) * 1099511628211ull; // (each 64-bit coordinate through a multiply of its own: shifted into one word they aliased -- cs bit 21 with ce bit 0)
-		x = (x ^ (uint64_t)a.ce) * 0x9e3779b97f4a7c15ull;
-		x = (x ^ (uint64_t)a.cm) * 1099511628211ull;
-		x = (x ^ ((uint64_t)(uint32_t)a.score_adj << 32 | (uint32_t)a.score_ori)) * 1099511628211ull;
-		x = (x ^ ((uint64_t)(uint32_t)a.off_exon << 32 | (uint32_t)a.n_exon << 8 | (uint32_t)a.rev << 7 | ((uint32_t)(a.rank & 0x7f) ^ (uint64_t)(uint32_t)a.rank << 40))) * 1099511628211ull;
+	std::vector<int32_t> have;
+	int64_t hh = 0;
+	for (int32_t j = j0; j < j1 && (size_t)j < ext->packs.size(); ++j) {
+		if (only && !(*only)[(size_t)j]) continue;
+		if ((size_t)j < ext->is_local.size() && !ext->is_local[(size_t)j]) continue;
+		if (ext->packs[(size_t)j].buf != nullptr) have.push_back(j), hh += d->genome[j].n_hit;
 	}
-	for (int32_t i = 0; i < g->n_exon; ++i) { uint64_t &x = h[i & 3]; x = (x ^ ((uint64_t)(uint32_t)g->exon[i].os << 32 | (uint32_t)g->exon[i].oe)) * 0x100000001b3ull; }
-	return (h[0] * 31 + h[1]) * 31 + (h[2] * 31 + h[3]);
+	std::vector<uint8_t> stale(have.size(), 0);
+	auto check = [&](size_t i) {
+		const int32_t j = have[i];
+		const GenomePack &pk = ext->packs[(size_t)j];
+		const bool sorted = (size_t)j < ext->hits_sorted.size() && ext->hits_sorted[(size_t)j]; // (records moved into cs order by a sync_host: the signature was taken in file order)
+		stale[i] = pk.blk.n_hit != d->genome[j].n_hit || pk.blk.n_exon != d->genome[j].n_exon || (!sorted && pk.sig != genome_signature(&d->genome[j]));
+	};
+	unsigned nc = hh > 200000 ? std::min<unsigned>(host_threads(64u), (unsigned)(hh / 40000)) : 1u; // (a thread costs ~15 us to start and hashes a hit in ~5 ns: 64 of them for a million hits spend their time being started)
+	if (nc > have.size()) nc = (unsigned)have.size();
+	std::vector<std::thread> th;
+	std::atomic<size_t> next{0};
+	auto work = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= have.size()) break; check(i); } };
+	try { for (unsigned t = 1; t < nc; ++t) th.emplace_back(work); } catch (const std::system_error &) {} // (at the thread limit: with the threads there are)
+	work();
+	for (auto &x : th) x.join();
+	out.clear();
+	for (size_t i = 0; i < have.size(); ++i) if (stale[i]) out.push_back(have[i]);
 }
 
-void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, double time_share)
+void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, double time_share, bool verify)
 {
 	const double t0 = now_sec();
 	if (ext->packs.size() < (size_t)d->n_genome) ext->packs.resize((size_t)d->n_genome); // (batch reads reserve the entries before their threads start)
 	std::vector<int32_t> todo;
 	int64_t hits = 0;
-	{ // which packs still stand?  The signatures read every record once (88 bytes a hit: 0.1 s for 12 M hits on one core), so the genomes are shared out
-		std::vector<int32_t> have;
-		int64_t hh = 0;
-		for (int32_t j = j0; j < j1; ++j) {
-			if ((size_t)j < ext->is_local.size() && !ext->is_local[(size_t)j]) continue;
-			if (ext->packs[(size_t)j].buf != nullptr) have.push_back(j), hh += d->genome[j].n_hit;
-		}
-		std::vector<uint8_t> stale(have.size(), 0);
-		auto check = [&](size_t i) {
-			const int32_t j = have[i];
-			const GenomePack &pk = ext->packs[(size_t)j];
-			const bool sorted = (size_t)j < ext->hits_sorted.size() && ext->hits_sorted[(size_t)j]; // (records moved into cs order by a sync_host: the signature was taken in file order)
-			stale[i] = pk.blk.n_hit != d->genome[j].n_hit || pk.blk.n_exon != d->genome[j].n_exon || (!sorted && pk.sig != genome_signature(&d->genome[j]));
-		};
-		unsigned nc = hh > 200000 ? std::min<unsigned>(host_threads(64u), (unsigned)(hh / 40000)) : 1u; // (a thread costs ~15 us to start and hashes a hit in ~5 ns: 64 of them for a million hits spend their time being started)
-		if (nc > have.size()) nc = (unsigned)have.size();
-		if (nc <= 1) { for (size_t i = 0; i < have.size(); ++i) check(i); }
-		else {
-			std::atomic<size_t> next{0};
-			std::vector<std::thread> th;
-			for (unsigned t = 0; t < nc; ++t) th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= have.size()) break; check(i); } });
-			for (auto &x : th) x.join();
-		}
-		for (size_t i = 0; i < have.size(); ++i) if (stale[i]) ext->packs[(size_t)have[i]] = GenomePack(); // stale: the slab keeps the old bytes until the upload is over
+	if (verify) { // which packs still stand?
+		std::vector<int32_t> st;
+		stale_packs(d, ext, j0, j1, st);
+		for (int32_t j : st) ext->packs[(size_t)j] = GenomePack(); // stale: the slab keeps the old bytes until the upload is over
 	}
 	for (int32_t j = j0; j < j1; ++j) {
 		if ((size_t)j < ext->is_local.size() && !ext->is_local[(size_t)j]) continue;
@@ -456,56 +481,96 @@ static int build_backend(const pg_opt_t *opt, pg_data_t *d, DataExt *ext)
 	for (int32_t j = 0; j < d->n_genome; ++j)
 		if (ext->is_local[(size_t)j]) ext->local_genomes.push_back(j);
 	const int32_t nl = (int32_t)ext->local_genomes.size();
-	pack_genomes(d, ext, 0, d->n_genome); // only those the reader has not packed already (or whose pack was released after an earlier upload)
-	int64_t N = 0, E = 0;
-	ext->hit_off.assign((size_t)nl + 1, 0);
-	std::vector<pga_genome_block_t> blk((size_t)nl);
-	for (int32_t k = 0; k < nl; ++k) {
-		const GenomePack &pk = ext->packs[(size_t)ext->local_genomes[(size_t)k]];
-		if (pk.err) { const int e = pk.err; free_packs(ext, false); return e; }
-		blk[(size_t)k] = pk.blk;
-		N += pk.blk.n_hit, E += pk.blk.n_exon;
-		ext->hit_off[(size_t)k + 1] = N;
+	// Are the packs the reader made still what the genomes are (a caller may edit the public pg_data_t between pg_read_paf and here)?  The check reads
+	// every record once (0.8 ms of a 9 ms upload-inclusive pass at configs[1], 5-7 ms of 80 at 12.1 M hits) and nothing in the upload needs its answer
+	// before the end: it runs on threads of its own WHILE the blocks are copied to the device (round 6), and a pack that turns out stale -- no caller
+	// of the reference's CLI ever makes one -- costs a second upload.  PANGENE_PACK_CHECK=first: the check in front of the upload, as before.
+	static const bool check_first = [] { const char *e = std::getenv("PANGENE_PACK_CHECK"); return e && std::strcmp(e, "first") == 0; }();
+	if (ext->packs.size() < (size_t)d->n_genome) ext->packs.resize((size_t)d->n_genome);
+	std::vector<uint8_t> had((size_t)d->n_genome, 0); // packs that exist already: the ones to check (those made below are new)
+	for (int32_t j = 0; j < d->n_genome; ++j) had[(size_t)j] = ext->packs[(size_t)j].buf != nullptr;
+	std::vector<int32_t> stale;
+	std::thread checker;
+	struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{checker}; // (every way out of this function waits for the check)
+	if (check_first) pack_genomes(d, ext, 0, d->n_genome); // check, then pack what is missing or stale
+	else {
+		try { checker = std::thread([&]() { stale_packs(d, ext, 0, d->n_genome, stale, &had); }); }
+		catch (const std::system_error &) { stale_packs(d, ext, 0, d->n_genome, stale, &had); }
+		pack_genomes(d, ext, 0, d->n_genome, 1.0, false); // only those the reader has not packed already (or whose pack was released after an earlier upload)
 	}
-	ext->vreal.assign((size_t)nl, std::vector<int32_t>()), ext->n_vctg.assign((size_t)nl, 0);
-	for (int32_t k = 0; k < nl; ++k) { // contigs as the backend counts them (virtual contigs: the pieces of the long ones)
-		const GenomePack &pk = ext->packs[(size_t)ext->local_genomes[(size_t)k]];
-		ext->n_vctg[(size_t)k] = pk.blk.n_ctg;
-		if (!pk.vreal.empty()) ext->vreal[(size_t)k] = pk.vreal;
-	}
-	if (pg_verbose >= 3) {
-		int64_t n_cut = 0, n_piece = 0, n_g = 0;
-		for (int32_t k = 0; k < nl; ++k) {
-			const GenomePack &pk = ext->packs[(size_t)ext->local_genomes[(size_t)k]];
-			if (pk.vreal.empty()) continue;
-			++n_g;
-			for (size_t v = 0; v < pk.vfirst.size(); ++v) n_piece += pk.vfirst[v] != (int32_t)v, n_cut += v + 1 < pk.vfirst.size() && pk.vfirst[v] == (int32_t)v && pk.vfirst[v + 1] == (int32_t)v;
-		}
-		if (n_g) std::fprintf(stderr, "[M::%s] 64-bit coordinates: %lld genome(s) with virtual contigs, %lld contig(s) cut, %lld extra piece(s)\n", __func__, (long long)n_g, (long long)n_cut, (long long)n_piece);
-	}
-	if (d->n_gene >= (1 << 20) || d->n_genome >= (1 << 24) || E >= INT32_MAX || N >= INT32_MAX) return PGA_ERR_RANGE;
-	std::vector<int32_t> pgid((size_t)d->n_prot);
-	std::vector<uint8_t> gpref((size_t)d->n_gene);
-	for (int32_t p = 0; p < d->n_prot; ++p) pgid[(size_t)p] = d->prot[p].gid;
-	for (int32_t q = 0; q < d->n_gene; ++q) gpref[(size_t)q] = d->gene[q].preferred;
-	pga_shard_t sh;
-	std::memset(&sh, 0, sizeof(sh));
-	sh.abi_version = PGA_ABI_VERSION;
-	sh.n_genome = nl, sh.n_genome_global = d->n_genome, sh.genome_global = ext->local_genomes.data();
-	sh.n_prot = d->n_prot, sh.n_gene = d->n_gene, sh.n_hit = N, sh.n_exon = E;
-	sh.block = blk.data(), sh.prot_gid = pgid.data(), sh.gene_pref = gpref.data();
-	pga_params_t par;
-	std::memset(&par, 0, sizeof(par));
-	par.min_ov_ratio = opt->min_ov_ratio;
-	par.check_strand = !!(opt->flag & PG_F_CHECK_STRAND);
-	par.drop_sgl_exon = !!(opt->flag & PG_F_DROP_SGL_EXON);
-	if (ext->ctx) ext->be->destroy(ext->ctx), ext->ctx = nullptr;
-	ext->n_hit_local = N;
 	static const bool timing = std::getenv("PANGENE_TIMING") != nullptr;
-	const double t1 = now_sec();
-	const int rc = ext->be->create(&ext->ctx, &sh, &par); // returns when the blocks have been read
-	if (rc == 0) g_device_up.store(true);
-	const double t2 = now_sec();
+	double t1 = t_bb0, t2 = t_bb0;
+	int rc = 0;
+	for (int attempt = 0;; ++attempt) {
+		// (attempt 0 may work with a stale pack: whatever goes wrong with it is looked at again once the check has spoken)
+		auto verdict = [&]() -> bool { // true: some pack was stale and has been made again -- go round once more
+			if (attempt > 0 || check_first) return false;
+			if (checker.joinable()) checker.join();
+			if (stale.empty()) return false;
+			if (ext->ctx) ext->be->destroy(ext->ctx), ext->ctx = nullptr;
+			for (int32_t j : stale) ext->packs[(size_t)j] = GenomePack(); // (the slab keeps the old bytes until the upload is over)
+			pack_genomes(d, ext, 0, d->n_genome, 1.0, false);
+			if (timing) std::fprintf(stderr, "[build_backend] %zu pack(s) no longer matched their genome: packed and uploaded again\n", stale.size());
+			return true;
+		};
+		int64_t N = 0, E = 0;
+		ext->hit_off.assign((size_t)nl + 1, 0);
+		std::vector<pga_genome_block_t> blk((size_t)nl);
+		int err = 0;
+		bool limit = false;
+		for (int32_t k = 0; k < nl && !err; ++k) {
+			const GenomePack &pk = ext->packs[(size_t)ext->local_genomes[(size_t)k]];
+			if (pk.err) { err = pk.err; break; }
+			blk[(size_t)k] = pk.blk;
+			N += pk.blk.n_hit, E += pk.blk.n_exon;
+			ext->hit_off[(size_t)k + 1] = N;
+		}
+		if (!err && (d->n_gene >= (1 << 20) || d->n_genome >= (1 << 24) || E >= INT32_MAX || N >= INT32_MAX)) err = PGA_ERR_RANGE, limit = true;
+		if (err) {
+			if (verdict()) continue;
+			if (!limit) free_packs(ext, false); // (a pack's own error: its blocks go; the limits of the shard leave them, as before)
+			return err;
+		}
+		ext->vreal.assign((size_t)nl, std::vector<int32_t>()), ext->n_vctg.assign((size_t)nl, 0);
+		for (int32_t k = 0; k < nl; ++k) { // contigs as the backend counts them (virtual contigs: the pieces of the long ones)
+			const GenomePack &pk = ext->packs[(size_t)ext->local_genomes[(size_t)k]];
+			ext->n_vctg[(size_t)k] = pk.blk.n_ctg;
+			if (!pk.vreal.empty()) ext->vreal[(size_t)k] = pk.vreal;
+		}
+		if (pg_verbose >= 3) {
+			int64_t n_cut = 0, n_piece = 0, n_g = 0;
+			for (int32_t k = 0; k < nl; ++k) {
+				const GenomePack &pk = ext->packs[(size_t)ext->local_genomes[(size_t)k]];
+				if (pk.vreal.empty()) continue;
+				++n_g;
+				for (size_t v = 0; v < pk.vfirst.size(); ++v) n_piece += pk.vfirst[v] != (int32_t)v, n_cut += v + 1 < pk.vfirst.size() && pk.vfirst[v] == (int32_t)v && pk.vfirst[v + 1] == (int32_t)v;
+			}
+			if (n_g) std::fprintf(stderr, "[M::%s] 64-bit coordinates: %lld genome(s) with virtual contigs, %lld contig(s) cut, %lld extra piece(s)\n", __func__, (long long)n_g, (long long)n_cut, (long long)n_piece);
+		}
+		std::vector<int32_t> pgid((size_t)d->n_prot);
+		std::vector<uint8_t> gpref((size_t)d->n_gene);
+		for (int32_t p = 0; p < d->n_prot; ++p) pgid[(size_t)p] = d->prot[p].gid;
+		for (int32_t q = 0; q < d->n_gene; ++q) gpref[(size_t)q] = d->gene[q].preferred;
+		pga_shard_t sh;
+		std::memset(&sh, 0, sizeof(sh));
+		sh.abi_version = PGA_ABI_VERSION;
+		sh.n_genome = nl, sh.n_genome_global = d->n_genome, sh.genome_global = ext->local_genomes.data();
+		sh.n_prot = d->n_prot, sh.n_gene = d->n_gene, sh.n_hit = N, sh.n_exon = E;
+		sh.block = blk.data(), sh.prot_gid = pgid.data(), sh.gene_pref = gpref.data();
+		pga_params_t par;
+		std::memset(&par, 0, sizeof(par));
+		par.min_ov_ratio = opt->min_ov_ratio;
+		par.check_strand = !!(opt->flag & PG_F_CHECK_STRAND);
+		par.drop_sgl_exon = !!(opt->flag & PG_F_DROP_SGL_EXON);
+		if (ext->ctx) ext->be->destroy(ext->ctx), ext->ctx = nullptr;
+		ext->n_hit_local = N;
+		t1 = now_sec();
+		rc = ext->be->create(&ext->ctx, &sh, &par); // returns when the blocks have been read
+		if (rc == 0) g_device_up.store(true);
+		t2 = now_sec();
+		if (verdict()) continue;
+		break;
+	}
 	size_t n_pin = 0, n_plain = 0, n_fresh = 0;
 	for (const HostSlab &x : ext->slabs) { if (x.pinned) ++n_pin; else ++n_plain; if (x.fresh) ++n_fresh; }
 	free_packs(ext, false);
@@ -530,6 +595,7 @@ int sync_host(pg_data_t *d, bool full)
 	const int64_t N = ext->n_hit_local;
 	uint64_t sig_now = ext->pos_sig;
 	if (ext->order_touched) { // overrides were handed over since the last sync: do the tracked contigs hold other orders than the copy was taken from?
+		exact_shutdown(ext); // (a replay nobody has asked for yet)
 		sig_now = order_signature(ext);
 		if (sig_now != ext->pos_sig) ext->pos_valid = false;
 		ext->order_touched = false;

@@ -205,7 +205,7 @@ struct DataExt {
 
 DataExt *ext_of(const pg_data_t *d, bool create);
 // pack the genomes [j0, j1) that have no pack yet (host threads); called by the reader after the commit and by the driver as a fallback
-void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, double time_share = 1.0); // time_share: fraction of the call's wall time booked as packing time (calls that run side by side on n threads: 1 / n)
+void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, double time_share = 1.0, bool verify = true); // time_share: fraction of the call's wall time booked as packing time (calls that run side by side on n threads: 1 / n)
 void trim_host_caches(size_t keep_bytes);
 void slab_prefetch(size_t bytes, std::thread *helper); // page-lock about `bytes` of block memory ahead, on a helper thread the caller joins
 void free_packs(DataExt *ext, bool wait);

@@ -135,11 +135,8 @@ def test_device_layout_limits_are_reported_not_asserted(tmp_path):
     assert capi.run(lib, [str(q)], []).startswith(b"S\tg1")
 
 
-def test_in_place_edit_between_read_and_post_process_is_seen(built, tmp_path):
-    """pg_read_paf packs every genome for the device while the next file is parsed; the reference reads g->hit at pg_post_process time
-    (graph.c:7-32), so a caller may edit the public pg_data_t in between.  The pack carries a signature over EVERY record it was made
-    from (round 4 sampled every 257th): an edit of one field of one hit -- here hit 3's score_adj, then an exon boundary -- must give
-    the output of a run that read the edited values, not the stale pack's."""
+def _in_place_edit_runs(lib, tmp_path, tag=""):
+    """(base, after bump_score, after move_exon): --bed=raw of human8f, with one field of one record edited between pg_read_paf and pg_post_process"""
     import ctypes as C
     from pangene_amd import capi
 
@@ -157,16 +154,14 @@ def test_in_place_edit_between_read_and_post_process_is_seen(built, tmp_path):
                     ("n_gene", C.c_int32), ("m_gene", C.c_int32), ("gene", C.c_void_p), ("n_prot", C.c_int32), ("m_prot", C.c_int32), ("prot", C.c_void_p)]
 
     assert C.sizeof(Hit) == 88 and C.sizeof(Genome) == 56 and C.sizeof(Data) == 72
-    lib = oracle_host.load()
     C.c_int.in_dll(lib, "pg_verbose").value = 0
     files = golden_files("human8f")
-
     n_run = [0]
 
     def run(edit):
         opt = capi.parse_args(lib, ["--bed=raw"])
         n_run[0] += 1
-        out = str(tmp_path / ("o%d.bed" % n_run[0]))
+        out = str(tmp_path / ("o%s%d.bed" % (tag, n_run[0])))
         lib.pg_set_output(out.encode())
         d = lib.pg_data_init()
         try:
@@ -181,8 +176,6 @@ def test_in_place_edit_between_read_and_post_process_is_seen(built, tmp_path):
             lib.pg_set_output(None)
         return open(out, "rb").read()
 
-    base = run(None)
-
     def bump_score(dd):  # a hit of a multi-isoform gene loses most of its score: it is no longer the isoform that survives
         g = dd.genome[1]
         assert g.n_hit > 300
@@ -193,6 +186,25 @@ def test_in_place_edit_between_read_and_post_process_is_seen(built, tmp_path):
         h = g.hit[5]
         g.exon[2 * h.off_exon + 1] = g.exon[2 * h.off_exon] + 1
 
-    a, b = run(bump_score), run(move_exon)
+    return run(None), run(bump_score), run(move_exon)
+
+
+@pytest.mark.gpu
+def test_in_place_edit_is_seen_by_the_device_path(built, tmp_path):
+    """The same on the HIP backend (round 6: the signature check runs WHILE the blocks travel to the device, and a stale pack costs a
+    second upload): byte for byte what the checker build prints for the same edits."""
+    from pangene_amd import capi
+    want = _in_place_edit_runs(oracle_host.load(), tmp_path, "c")
+    got = _in_place_edit_runs(capi.load(), tmp_path, "g")
+    assert want[0] != want[1] and want[0] != want[2]
+    assert got == want
+
+
+def test_in_place_edit_between_read_and_post_process_is_seen(built, tmp_path):
+    """pg_read_paf packs every genome for the device while the next file is parsed; the reference reads g->hit at pg_post_process time
+    (graph.c:7-32), so a caller may edit the public pg_data_t in between.  The pack carries a signature over EVERY record it was made
+    from (round 4 sampled every 257th): an edit of one field of one hit -- here hit 3's score_adj, then an exon boundary -- must give
+    the output of a run that read the edited values, not the stale pack's."""
+    base, a, b = _in_place_edit_runs(oracle_host.load(), tmp_path)
     assert a != base and b != base and a != b
     assert len(a.split(b"\n")) == len(base.split(b"\n")) == len(b.split(b"\n"))  # (the same hits, other flags and scores)
