@@ -354,6 +354,8 @@ const pga_backend_t *pga_backend(void);
  * overflowed its LDS table, the pair list its capacity): the shard's state is then undefined and the caller repeats the
  * run with host-driven rounds; 2 = not applicable here (nothing was queued); 3 (sharded form only) = an exchange buffer
  * was too small: state undefined as with 1, but the capacities have been raised and a later run can queue its rounds again.
+ * 4 (unsharded form) = a pair list was longer than the room the loop had reserved, and nothing else went wrong: state undefined as with 1,
+ * the room has been made (up to 2^27 pairs) and the caller repeats the run WITH queued rounds.
  *
  * Sharded form (x != NULL): behind pga_arc_set_current (the merged table of a host-driven round), every rank queues the same
  * rounds; where the host-driven route exchanges (graph_driver.cpp gen_arc / mark_branch_flt_arc) the backend calls x's two

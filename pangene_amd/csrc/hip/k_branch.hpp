@@ -371,7 +371,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pair_offsets(const int32_t *pc, 
 	}
 	int32_t run = part[t] - s;
 	for (int i = i0; i < i1; ++i) { poff[i] = run; run += pc[i]; }
-	if (t == PO_THREADS - 1) { dcnt[15] = part[t]; if (cap >= 0 && part[t] > cap) dcnt[11] = 1; } // [11]: sticky "a queued round could not be completed" (pga_branch_loop)
+	if (t == PO_THREADS - 1) { dcnt[15] = part[t]; if (cap >= 0 && part[t] > cap) { dcnt[11] = 1; if (part[t] > dcnt[16]) dcnt[16] = part[t]; } } // [11]: sticky "a queued round could not be completed" (pga_branch_loop); [16]: the longest list that did not fit
 	__syncthreads();
 	if (t < 16) sys_store(&host_box[t], dcnt[t]);
 }
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(BLOCK) void k_loop_front2(RepFill rf, LoopFront2 a)
 	if (lane == 0) a.poff[v] = (int32_t)k0; // (what k_br_wave<2> reads; only this wave touches the entry)
 	if (v == 0) { // k_pair_offsets' other results: the number of pairs, and "a queued round could not be completed" (a list beyond its capacity)
 		const int tot = wave_sum(part);
-		if (lane == 0) { a.dcnt[15] = tot; if (tot > a.pair_cap) a.dcnt[11] = 1; }
+		if (lane == 0) { a.dcnt[15] = tot; if (tot > a.pair_cap) { a.dcnt[11] = 1; if (tot > a.dcnt[16]) a.dcnt[16] = tot; } } // ([16]: the longest list that did not fit -- pga_branch_loop's next attempt makes room)
 	}
 	br_wave_body<1>(v, lane, nullptr, k0, a.vs, a.ve, a.s1, a.agid, a.bd, a.pairs, a.pair_cap, a.pc, nullptr, 0.0, 0.0, nullptr, nullptr, nullptr, a.dcnt, nullptr);
 }

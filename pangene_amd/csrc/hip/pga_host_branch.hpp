@@ -84,6 +84,7 @@ extern "C" int pga_n_local(pga_ctx_t *c, const int32_t *pairs, int64_t n, int32_
 	return sync_st(c); // pairs is caller memory; the exchange may run on another stream
 }
 
+static inline bool loop_cap_forced(const pga_ctx *c) { static const bool on = getenv("PANGENE_LOOP_PAIR_CAP") != nullptr; return on && c->in_loop && !c->loop_room_given; }
 static inline size_t loop_btot_at(int n_vtx) { return ((size_t)n_vtx + 7) & ~(size_t)3; } // the totals of k_loop_front1's workgroups, behind the vertices' counts in S_BR_PC
 
 // pg_gen_rep_pos unfused after all (the launches rep_pos_impl left out)
@@ -166,11 +167,11 @@ static int branch_pairs_impl(pga_ctx *c, const uint64_t *arc_x, const int32_t *a
 		const int64_t n_clear = df->cleared ? rf.n_ent : 0;
 		const LoopFront a = { n_vtx, nbc, rf.GL, vs, ve, s1, branch_diff, pc, poff, pc + loop_btot_at(n_vtx), rf.flags, rf.goff, df->rx, rf.rp_out, n_clear, c->rp_form == RP_COMPACT ? 8 : 16, c->gate };
 		hipLaunchKernelGGL(k_loop_front1, dim3((unsigned)(nbc + rf.GL + (n_clear + RK_T - 1) / RK_T)), dim3(RK_T), 0, c->st, a);
-		if (c->br_cap < 4 * (int64_t)n_vtx) c->br_cap = 4 * (int64_t)n_vtx;
+		if (c->br_cap < 4 * (int64_t)n_vtx && !loop_cap_forced(c)) c->br_cap = 4 * (int64_t)n_vtx;
 		return branch_enumerate(c, cnt, df);
 	}
 	hipLaunchKernelGGL(k_br_count, dim3(nblk(n_vtx)), dim3(BLOCK), 0, c->st, n_vtx, vs, ve, s1, branch_diff, pc, c->gate);
-	if (one_wg) hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(PO_THREADS), 0, c->st, (const int32_t *)pc, n_vtx, poff, c->dcnt, c->h_box, n_pairs ? -1ll : (long long)std::max<int64_t>(c->br_cap, 4 * (int64_t)n_vtx), c->gate); // offsets, and dcnt[15] = number of pairs
+	if (one_wg) hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(PO_THREADS), 0, c->st, (const int32_t *)pc, n_vtx, poff, c->dcnt, c->h_box, n_pairs ? -1ll : loop_cap_forced(c) ? (long long)c->br_cap : (long long)std::max<int64_t>(c->br_cap, 4 * (int64_t)n_vtx), c->gate); // offsets, and dcnt[15] = number of pairs
 	else {
 		I32 *tile = (I32 *)c->pool.get(S_TILE, tile_buf_bytes(n_vtx));
 		device_scan<I32>(InI32{pc}, OutExclI32{poff}, n_vtx, tile, OpSum{}, I32{0}, c->st, c->gate);
@@ -184,7 +185,7 @@ static int branch_pairs_impl(pga_ctx *c, const uint64_t *arc_x, const int32_t *a
 	}
 	// otherwise nothing waits: the buffers keep the capacity that was enough so far, pga_branch_decide checks the count when
 	// it has to wait for its own results anyway and repeats the enumeration in the (first-round) case that it was not
-	if (c->br_cap < 4 * (int64_t)n_vtx) c->br_cap = 4 * (int64_t)n_vtx;
+	if (c->br_cap < 4 * (int64_t)n_vtx && !loop_cap_forced(c)) c->br_cap = 4 * (int64_t)n_vtx;
 	return branch_enumerate(c, cnt);
 }
 
@@ -390,6 +391,8 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		int64_t dmax = 8;
 		for (int r = 1; r < n_round; ++r) dmax = std::max<int64_t>(dmax, max_degree[r]);
 		c->br_cap = std::max<int64_t>(c->br_cap, std::min<int64_t>((int64_t)n_vtx * dmax * dmax, (int64_t)1 << 26));
+		static const long long cap_env = [] { const char *e = getenv("PANGENE_LOOP_PAIR_CAP"); return e ? atoll(e) : 0ll; }(); // (tests: a first attempt with this little room -> status 4 -> a second one with what was needed)
+		if (cap_env > 0 && !c->loop_room_given) c->br_cap = cap_env;
 	} else {
 		// Capacities all ranks share: they follow from the merged tables (identical everywhere) and from the slots of earlier all-gathers.
 		// The pair list's worst case (above) is too much to all-reduce every round: what earlier runs over this shard saw, with a
@@ -458,9 +461,10 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 	// in the header of the round's all-gather (k_xs_compact writes the word whether its gate is open or not) and k_xs_sum_rank stamps the round on every rank when any rank marked; a rank's own arc
 	// round follows its own hits (nothing changed here: its slot stands as it is, k_xs_compact leaves), the collectives are queued all the same.
 	const bool gated = !no_skip && (int64_t)c->round_tag + n_round + 4 < (int64_t)HA_TAG_MAX;
-	struct GateScope { pga_ctx *c; ~GateScope() { c->gate = Gate{nullptr, 0}, c->loop_gated = false; } } gate_scope{c}; // (every way out of this function leaves the launches open)
-	c->loop_gated = gated;
+	struct GateScope { pga_ctx *c; ~GateScope() { c->gate = Gate{nullptr, 0}, c->loop_gated = false, c->in_loop = false; } } gate_scope{c}; // (every way out of this function leaves the launches open)
+	c->loop_gated = gated, c->in_loop = true;
 	const uint32_t tag_before = c->round_tag;
+	HIPCHK(hipMemsetAsync(c->dcnt + 16, 0, sizeof(int64_t), c->st)); // the longest pair list that did not fit (k_loop_front2 / k_pair_offsets)
 	if (gated) HIPCHK(hipMemsetAsync(c->loopctl, 0xff, 4 * sizeof(int32_t), c->st)); // -1: nothing has happened yet; round 0 runs (its branch steps ask for a change in round -1 or later)
 	// Live lists inside the queue.  pg_flt_high_occ's first rounds delete segments wholesale on many-genome shards (1 250 bacterial
 	// genomes: 98.5 % of the hits are without flt before the test of round 1, 38.5 % after it), so on shards where a wait is small beside a round
@@ -534,13 +538,15 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		if (!h_ctl) return PGA_ERR_NOMEM;
 		HIPCHK(hipMemcpyAsync(h_ctl, c->loopctl, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
 	}
-	const size_t fetch_need = (size_t)S + 128 + (par->final_on ? 4 * sizeof(int32_t) * (size_t)S + 64 : 0);
+	const size_t fetch_need = (((size_t)S + 128 + (par->final_on ? 4 * sizeof(int32_t) * (size_t)S + 64 : 0) + 15) & ~(size_t)15) + 64 + 16;
 	if (c->h_fetch_cap < fetch_need) {
 		c->h_fetch = c->pin.get(fetch_need + fetch_need / 2 + 512);
 		if (!c->h_fetch) return PGA_ERR_NOMEM;
 		c->h_fetch_cap = fetch_need + fetch_need / 2 + 512;
 	}
 	HIPCHK(hipMemcpyAsync(c->h_fetch, alive, (size_t)S, hipMemcpyDeviceToHost, c->st));
+	int64_t *h_need = (int64_t *)((char *)c->h_fetch + fetch_need - 16); // (the last 16 bytes of what was asked for)
+	HIPCHK(hipMemcpyAsync(h_need, c->dcnt + 16, sizeof(int64_t), hipMemcpyDeviceToHost, c->st));
 	int32_t *h_fin = (int32_t *)((char *)c->h_fetch + (((size_t)S + 127) & ~(size_t)63)); // (final_on) the last arc round's segment counters, the last branch step's n_dist_loci
 	if (par->final_on) {
 		HIPCHK(hipMemcpyAsync(h_fin, (const int32_t *)c->pool.get(S_SEGCNT, 0), sizeof(int32_t) * (size_t)n_vtx, hipMemcpyDeviceToHost, c->st));
@@ -580,7 +586,16 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 		if (f[1]) return PGA_ERR_INVARIANT;
 		if (f[0]) return (f[2] && !f[3]) ? 3 : 1;
 	}
-	else if (c->h_cnt[11]) return c->h_cnt[3] ? PGA_ERR_INVARIANT : 1;
+	else if (c->h_cnt[11]) {
+		if (c->h_cnt[3]) return PGA_ERR_INVARIANT;
+		// A pair list beyond its capacity and nothing else (no hub gene beyond its LDS table): the next attempt gets the room -- status 4, the caller runs the
+		// queue again (round 6: a shard of 10 000 genomes lists 10^7 pairs in round 0, before pg_flt_high_occ has seen the graph; the queue gave
+		// up for good and every pass of configs[3] at full size ran its fifteen rounds host-driven).  Lists beyond 2^26 pairs: status 1 as before.
+		const int64_t need = *h_need;
+		if (getenv("PANGENE_TIMING")) fprintf(stderr, "[pga_branch_loop] the longest pair list that did not fit: %lld (capacity %lld)\n", (long long)need, (long long)c->br_cap);
+		if (need > c->br_cap && c->h_cnt[9] == 0 && need + need / 4 <= ((int64_t)1 << 27)) { c->br_cap = need + need / 4, c->loop_room_given = true; return 4; }
+		return 1;
+	}
 	memcpy(seg_alive, c->h_fetch, (size_t)S);
 	if (par->final_on) memcpy(seg_cnt_host, h_fin, sizeof(int32_t) * (size_t)n_vtx), memcpy(ndl_host, h_fin + n_vtx, sizeof(int32_t) * (size_t)n_vtx);
 	return 0;

@@ -232,6 +232,8 @@ struct pga_ctx {
 	Gate gate = Gate{nullptr, 0};     // what the launches of the moment carry (pga_branch_loop sets it per phase; open everywhere else)
 	int32_t *loopctl = nullptr;       // [4] device: Gate::w[0..1], [2] = tag of the last arc round of the loop that ran
 	int loop_round = 0;               // the round the launches of the moment belong to (stamps)
+	bool in_loop = false;             // inside pga_branch_loop
+	bool loop_room_given = false;     // pga_branch_loop returned status 4 once on this context (tests: PANGENE_LOOP_PAIR_CAP applies until then)
 	bool loop_gated = false;          // pga_branch_loop runs with gates: an arc round that runs leaves its tag in loopctl[2], whether its own gate is open or not
 	int32_t *h_loopctl = nullptr;     // pinned mirror of loopctl (bump-allocated once per context)
 	int32_t *h_ov = nullptr; size_t h_ov_cap = 0; // pinned: position / file-index lists of an order override, two halves used in turn

@@ -1352,6 +1352,7 @@ static int branch_loop_fast(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext, in
 	if (rc == 2) return 0;
 	if (rc == 1) { ext->no_branch_loop = true; return RC_REDO; }
 	if (rc == 3) { ext->skip_loop_once = true; return RC_REDO; }
+	if (rc == 4) { if (++ext->loop_room_retries > 2) ext->no_branch_loop = true; return RC_REDO; } // a pair list beyond its capacity: the backend has made room, the queue runs again
 	if (rc != 0) { set_error(rc, "branch_loop"); return rc; }
 	ext->arc_pending = false;
 	exact_skip(ext, n_sorts);

@@ -181,6 +181,7 @@ struct DataExt {
 	int route_verbose = -1;            // sharded runs: the log level every rank's ROUTING decisions follow (max over the ranks, agreed at upload time); -1 = pg_verbose
 	bool skip_loop_once = false;       // sharded pga_branch_loop asked for a repeated run because an exchange buffer was too small (status 3): that run is host-driven, later ones queue again
 	int64_t x_arc_slot = 0;            // sharded runs: the largest local arc table of any host-driven round so far, over all ranks
+	int loop_room_retries = 0;         // status 4 of pga_branch_loop on this data set (a pair list beyond its capacity: the run is repeated with room; after a few of them the rounds are host-driven)
 	bool no_branch_loop = false;       // the queued branch rounds (pga_branch_loop) met something they cannot handle on this data set: host-driven rounds from now on
 	bool arc_via_x = false;            // (sharded) the last pg_gen_arc came through pga_arc_round_x: the backend holds the GLOBAL segment counters and the merged table's degrees
 	bool arc_pending = false;          // a deferred arc round whose host results have not been collected (arc_collect)
