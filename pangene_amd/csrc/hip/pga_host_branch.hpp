@@ -63,7 +63,8 @@ static int n_local_dev(pga_ctx *c, const int32_t *d_pairs, int64_t n, const int6
 	if (!hz.iv || !hz.list) return PGA_ERR_NOMEM;
 	// the grid follows the last known number of pairs (the kernel strides over whatever there is)
 	const int64_t est = np_dev ? (c->br_np_seen > 0 ? c->br_np_seen : std::min<int64_t>(n, 1 << 18)) : n;
-	const int lanes = nl_lanes_for(c->n_genome);
+	static const int lanes_env = [] { const char *e = getenv("PANGENE_NL_LANES"); return e ? atoi(e) : 0; }(); // (measurements: 16 / 32 / 64 whatever the number of genomes)
+	const int lanes = (lanes_env == 16 || lanes_env == 32 || lanes_env == 64) ? lanes_env : nl_lanes_for(c->n_genome);
 	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nblk(est, BLOCK / WAVE * (WAVE / lanes)), 1 << 20));
 #define NL_LAUNCH(FORM, LANES) hipLaunchKernelGGL((k_n_local<FORM, LANES>), dim3(grid), dim3(BLOCK), 0, c->st, d_pairs, n, np_dev, c->n_genome, (const void *)rp, local_dist, local_count, frag_mode, d_cnt, hz, c->gate)
 #define NL_FORM(FORM) do { if (lanes == 16) NL_LAUNCH(FORM, 16); else if (lanes == 32) NL_LAUNCH(FORM, 32); else NL_LAUNCH(FORM, 64); } while (0)
