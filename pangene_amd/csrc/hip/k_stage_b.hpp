@@ -22,6 +22,48 @@ __global__ __launch_bounds__(BLOCK) void k_post_part(const uint32_t *flags, cons
 		atomicAdd(&sums[(int64_t)(4 + w) * P + p], (unsigned long long)(long long)sori[h]);
 	}
 }
+// The same sums with the atomics in LDS (round 6).  The device executes global atomics at ~30 G/s whatever their addresses, and a hit contributes three: 0.74 ms at
+// 12.1 M hits, 6.7 ms at configs[3]'s 96.6 M.  What there is to reduce is one contribution per (genome, protein): a workgroup that reads the hits of MANY genomes holds the
+// proteins' sums of its stretch in LDS -- 28 bytes a protein (three 64-bit sums, the two counts in the halves of one word, emptied into the global table when half full), the
+// proteins in p_tiles ranges when they do not fit (workgroup b: range b % p_tiles, stretch b / p_tiles) -- and sends what is not zero to the global tables at the end.
+// max_ori stays as it was (a look, rarely an atomic).  Same integers, another order of additions.
+constexpr int PP_T = 1024;
+__global__ __launch_bounds__(PP_T) void k_post_part_lds(const uint32_t *flags, const int32_t *pid, const int32_t *rank, const int32_t *sori, const int32_t *sadj,
+                                                          const int32_t *nex, int n, int P, int p_tiles, int PT /* proteins a range */, int32_t *max_ori, unsigned long long *sums)
+{
+	extern __shared__ unsigned long long pp_lds[];
+	unsigned long long *s_adj = pp_lds, *s_o0 = pp_lds + PT, *s_o1 = pp_lds + 2 * (size_t)PT;
+	unsigned int *s_cnt = (unsigned int *)(pp_lds + 3 * (size_t)PT);
+	const int t = blockIdx.x % p_tiles, chunk = blockIdx.x / p_tiles, n_chunk = gridDim.x / p_tiles;
+	const int p0 = t * PT, p1 = p0 + PT < P ? p0 + PT : P;
+	for (int i = threadIdx.x; i < PT; i += PP_T) s_adj[i] = 0, s_o0[i] = 0, s_o1[i] = 0, s_cnt[i] = 0;
+	__syncthreads();
+	const int64_t per = ((int64_t)n + n_chunk - 1) / n_chunk, h0 = (int64_t)chunk * per, h1 = h0 + per < n ? h0 + per : n;
+	for (int64_t h = h0 + threadIdx.x; h < h1; h += PP_T) {
+		const int p = pid[h], so = sori[h];
+		if (t == 0 && max_ori[p] < so) atomicMax(&max_ori[p], so); // pg_cap_score_dom's table (hit.c:230-238), as k_post_part
+		if (p < p0 || p >= p1 || rank[h] != 0 || (flags[h] & PGA_F_FLT)) continue;
+		const int w = nex[h] == 1 ? 0 : 1, i = p - p0;
+		atomicAdd(&s_adj[i], (unsigned long long)(long long)sadj[h]);
+		{ // (a count that fills half of its sixteen bits moves on to the global table at once: any number of rank-0 hits of one protein is counted exactly --
+		  // at most 1 023 other additions are on their way while the 2^15 are taken out again)
+			const unsigned old = atomicAdd(&s_cnt[i], w ? 65536u : 1u);
+			if ((w ? old >> 16 : old & 0xffffu) == 0x7fffu) { atomicAdd(&sums[(int64_t)(2 + w) * P + p], 0x8000ull); atomicSub(&s_cnt[i], w ? 0x80000000u : 0x8000u); }
+		}
+		atomicAdd(w ? &s_o1[i] : &s_o0[i], (unsigned long long)(long long)so);
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < p1 - p0; i += PP_T) {
+		const unsigned int cw = s_cnt[i];
+		const unsigned long long a = s_adj[i], o0 = s_o0[i], o1 = s_o1[i];
+		const int p = p0 + i;
+		if (a) atomicAdd(&sums[p], a); // (what is zero adds nothing: most proteins of most stretches)
+		if (cw & 0xffffu) atomicAdd(&sums[(int64_t)2 * P + p], (unsigned long long)(cw & 0xffffu));
+		if (cw >> 16) atomicAdd(&sums[(int64_t)3 * P + p], (unsigned long long)(cw >> 16));
+		if (o0) atomicAdd(&sums[(int64_t)4 * P + p], o0);
+		if (o1) atomicAdd(&sums[(int64_t)5 * P + p], o1);
+	}
+}
 __global__ __launch_bounds__(BLOCK) void k_post_count(unsigned long long *sums, int P)
 {
 	const int p = blockIdx.x * BLOCK + threadIdx.x;

@@ -6,7 +6,28 @@
 extern "C" int pga_post_partials(pga_ctx_t *c, int32_t **max_ori, int64_t **sums)
 {
 	zero_multi(c, c->max_ori, sizeof(int32_t) * (size_t)std::max(1, c->P), c->sums, sizeof(int64_t) * 6 * (size_t)std::max(1, c->P));
-	if (c->N) hipLaunchKernelGGL(k_post_part, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->rank, c->sori, c->sadj, c->nex, c->N, c->P,
+	// (round 6) the sums through LDS where the proteins fit in one or two ranges and a workgroup's stretch is long enough to hold several genomes
+	static const bool pp_atomics = env_has("PANGENE_POST", "atomics"); // (tests: the one-atomic-a-contribution form on every shard)
+	static const bool pp_force = env_has("PANGENE_POST", "lds");       // (tests: the LDS form on small shards too)
+	bool lds_done = false;
+	if (c->N && c->P && !pp_atomics && (c->N >= (1 << 19) || pp_force)) {
+		const size_t room = (size_t)144 << 10;
+		const int p_tiles = (size_t)c->P * 28 <= room ? 1 : (size_t)((c->P + 1) / 2) * 28 <= room ? 2 : 0;
+		if (p_tiles) {
+			const int PT = (c->P + p_tiles - 1) / p_tiles;
+			const size_t lds = (size_t)PT * 28 + 16;
+			static size_t lds_set = 0;
+			bool ok = true;
+			if (lds > lds_set) { ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_post_part_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; if (ok) lds_set = lds; else (void)hipGetLastError(); }
+			if (ok) {
+				const int n_chunk = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu, c->N / 32768)); // (a stretch of >= 32 k hits: the reduction is what the launch is for)
+				hipLaunchKernelGGL(k_post_part_lds, dim3((unsigned)(n_chunk * p_tiles)), dim3(PP_T), lds, c->st, c->flags, c->pid, c->rank, c->sori, c->sadj, c->nex, c->N, c->P, p_tiles, PT,
+				                   c->max_ori, (unsigned long long *)c->sums);
+				lds_done = true;
+			}
+		}
+	}
+	if (c->N && !lds_done) hipLaunchKernelGGL(k_post_part, dim3(nblk(c->N)), dim3(BLOCK), 0, c->st, c->flags, c->pid, c->rank, c->sori, c->sadj, c->nex, c->N, c->P,
 	                             c->max_ori, (unsigned long long *)c->sums);
 	if (c->N && c->P) hipLaunchKernelGGL(k_post_count, dim3(nblk(c->P)), dim3(BLOCK), 0, c->st, (unsigned long long *)c->sums, c->P);
 	*max_ori = c->max_ori, *sums = c->sums;
