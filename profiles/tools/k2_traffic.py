@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 hits = int(sys.argv[3])
 sha = hashlib.sha256(open(os.path.join(ROOT, "pangene_amd", "csrc", "hip", "k_genes.hpp"), "rb").read()).hexdigest()[:16]
 out = []
-for key, pat in (("walk_scan", "k_walk<"), ("gene_arcs_big", "k_gene_arcs_big"), ("gene_arcs_wave", "k_gene_arcs_wave"), ("sweep0", "k_sweep<0"), ("rep_fill", "k_loop_front2")  # (the branch step's records: k_rep_fill inside the queued rounds' second front launch, with k_br_wave<1>)):
+for key, pat in (("walk_scan", "k_walk<"), ("gene_arcs_big", "k_gene_arcs_big"), ("gene_arcs_wave", "k_gene_arcs_wave"), ("sweep0", "k_sweep<0"), ("rep_fill", "k_loop_front2")):  # (rep_fill: the branch step's records -- k_rep_fill inside the queued rounds' second front launch, with k_br_wave<1>)
     f, w = per_dispatch(sys.argv[1], "FETCH_SIZE", pat), per_dispatch(sys.argv[2], "WRITE_SIZE", pat)
     if not f or not w:
         continue
