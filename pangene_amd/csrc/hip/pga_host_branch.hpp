@@ -503,6 +503,10 @@ extern "C" int pga_branch_loop(pga_ctx_t *c, int32_t n_round, const pga_branch_p
 				                   gated ? c->loopctl : (int32_t *)nullptr, r);
 				const bool ask = live_ask && (live_env == 2 || r == 1 || r == 2 || r == 4 || r == 8) && (r + 1 < n_round || par->final_on);
 				if (ask) HIPCHK(hipMemsetAsync(c->live_cnt, 0, sizeof(int64_t) * LIVE_CNT_N, c->st));
+				static const bool fv_x = env_has("PANGENE_FLAG_VTX", "x"); // (tests: every hit in every round, as before)
+				if (c->live_on && c->z_valid && !fv_x && (int64_t)c->NL * 5 < (int64_t)N) // few members: along the index (40 bytes a member against 8 a hit)
+					hipLaunchKernelGGL(k_flag_vtx_z, dim3(nblk(std::max(c->NL, 1))), dim3(BLOCK), 0, c->st, c->flags, (const int32_t *)c->zx, (const int32_t *)c->zg, c->NL, (const int32_t *)c->g2s, c->gate, ask ? c->live_cnt : (int64_t *)nullptr);
+				else
 				hipLaunchKernelGGL(k_flag_vtx, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gid, N, c->g2s, 1, c->gate, ask ? c->live_cnt : (int64_t *)nullptr);
 				c->walk_valid = false, c->ha_valid = false;
 				if (ask) {

@@ -112,7 +112,7 @@ def _run_with_env(tmp_path, env, mode, variant, files):
 @pytest.mark.parametrize("name,variant", [("bact20", ""), ("human8f", "-p0 -a1"), ("fuzz3", "-S"), ("dense", ""), ("manydoms", "-G"), ("human8", "--bed=flag"), ("fuzz7126", "-D 300 -C 2")])
 @pytest.mark.parametrize("env", [{"PANGENE_ARC_SORT_PATH": "1", "PANGENE_WAIT": "sync"}, {"PANGENE_GENE_TABLE_LOG2": "2", "PANGENE_ROUND_FILTER_HOST": "1"}, {"PANGENE_VTX_SPILL_CAP": "3", "PANGENE_RANK_BY_SORT": "1", "PANGENE_PAIR_SCAN_GENERAL": "1", "PANGENE_LOOP": "nopre"},
                                  {"PANGENE_BRANCH_LOOP_HOST": "1", "PANGENE_GLOBAL_SORT": "1", "PANGENE_FILTERS": "global"}, {"PANGENE_LOOP": "nofinal", "PANGENE_MERGE_LITERAL": "1", "PANGENE_SWEEP_LISTS": "global"},
-                                 {"PANGENE_FILTERS": "k32", "PANGENE_LOOP": "noskip", "PANGENE_SWEEP_LISTS": "lds"}, {"PANGENE_BIN_CAP": "256", "PANGENE_LIVE_LISTS": "2"}, {"PANGENE_BIN_CAP": "2048", "PANGENE_BINS": "1", "PANGENE_LOOP_FUSE": "0", "PANGENE_LOOP_PAIR_CAP": "8"}, {"PANGENE_LOOP_PAIR_CAP": "24", "PANGENE_POST": "lds"}, {"PANGENE_LIVE_LISTS": "1", "PANGENE_LIVE": "fullsweep", "PANGENE_RANK": "scan", "PANGENE_Y_FIXUP": "0"}])
+                                 {"PANGENE_FILTERS": "k32", "PANGENE_LOOP": "noskip", "PANGENE_SWEEP_LISTS": "lds"}, {"PANGENE_BIN_CAP": "256", "PANGENE_LIVE_LISTS": "2"}, {"PANGENE_BIN_CAP": "2048", "PANGENE_BINS": "1", "PANGENE_LOOP_FUSE": "0", "PANGENE_LOOP_PAIR_CAP": "8"}, {"PANGENE_LOOP_PAIR_CAP": "24", "PANGENE_POST": "lds"}, {"PANGENE_LIVE_LISTS": "1", "PANGENE_LIVE": "fullsweep", "PANGENE_RANK": "scan", "PANGENE_Y_FIXUP": "0", "PANGENE_FLAG_VTX": "x"}])
 def test_arc_round_paths_agree(hip, expected, tmp_path, name, variant, env):
     """pg_gen_arc has two formulations on the device: the gene-major one (k_genes.hpp, the default) and the reference's global sort
     (the path of rounds in which a hub gene overflows the per-gene LDS table).  Forcing the sort path, and shrinking the table to 4
