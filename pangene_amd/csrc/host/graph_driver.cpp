@@ -828,8 +828,9 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 	BE_CALL(be->post_partials(ctx, &b_max, &b_sum), "post_partials");
 	BE_CALL(xreduce(be, ext->ctx, b_max, P, PG_X_I32, PG_X_MAX), "allreduce(max_score_ori)");
 	BE_CALL(xreduce(be, ext->ctx, b_sum, 6 * (int64_t)P, PG_X_I64, PG_X_SUM), "allreduce(protein sums)");
-	std::vector<int32_t> mx((size_t)P);
-	std::vector<int64_t> sm((size_t)P * 6);
+	static thread_local std::vector<int32_t> mx; // (reused from pass to pass, as gen_vtx's)
+	static thread_local std::vector<int64_t> sm;
+	mx.resize((size_t)P), sm.resize((size_t)P * 6);
 	if (P) { // one wait for both vectors: the first copy rides with the second one's
 		const void *mx_view = nullptr;
 		BE_CALL(be->fetch_later(ctx, b_max, sizeof(int32_t) * (size_t)P, &mx_view), "fetch_later");
@@ -838,7 +839,8 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 	}
 	const double tp0 = now_sec();
 	// pg_cap_score_dom's table (hit.c:230-238) and pg_flag_representative's protein part (hit.c:205-217)
-	std::vector<pg128_t> z((size_t)P);
+	static thread_local std::vector<pg128_t> z;
+	z.resize((size_t)P);
 	for (int32_t i = 0; i < d->n_gene; ++i) d->gene[i].rep_pid = -1;
 	for (int32_t i = 0; i < P; ++i) {
 		d->prot[i].max_score_ori = mx[(size_t)i];
@@ -855,7 +857,8 @@ static int post_process_impl(const pg_opt_t *opt, pg_data_t *d)
 		int32_t pid = (int32_t)z[(size_t)i].y, gid = d->prot[pid].gid;
 		if (d->gene[gid].rep_pid < 0) d->gene[gid].rep_pid = pid, d->prot[pid].rep = 1;
 	}
-	std::vector<uint8_t> rep((size_t)P), pj((size_t)P, 0);
+	static thread_local std::vector<uint8_t> rep, pj;
+	rep.resize((size_t)P), pj.assign((size_t)P, 0);
 	for (int32_t i = 0; i < P; ++i) rep[(size_t)i] = (uint8_t)d->prot[i].rep;
 	if (!(opt->flag & PG_F_NO_JOINT_PSEUDO)) { // per-protein predicate of hit.c:176-181 (doubles, no contraction)
 		for (int32_t i = 0; i < P; ++i) {
@@ -919,7 +922,8 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	BE_CALL(be->vtx_partials(ext->ctx, &b_cnt, &b_tri, &n_tri), "vtx_partials");
 	const double tv1 = now_sec();
 	BE_CALL(xreduce(be, ext->ctx, b_cnt, 2 * (int64_t)Q, PG_X_I32, PG_X_SUM), "allreduce(n_dom,n_sub)");
-	std::vector<int32_t> cntv((size_t)Q * 2);
+	static thread_local std::vector<int32_t> cntv; // (these buffers are reused from pass to pass: fresh vectors of a few hundred KB are mmap'ed and page-faulted every time, ~0.1 ms of a 4.6 ms pass)
+	cntv.assign((size_t)Q * 2, 0);
 	const void *cntv_view = nullptr; // copied out behind the next wait (the fetch of the pair records, or the explicit one below)
 	if (Q) BE_CALL(be->fetch_later(ext->ctx, b_cnt, sizeof(int32_t) * (size_t)Q * 2, &cntv_view), "fetch_later");
 	// What the greedy needs is, per (sub, dom) gene pair, the SET of genomes in which sub is sub-ordinate to a dominant dom: a
@@ -928,7 +932,8 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	// the number of hits.
 	const uint64_t m20 = (1u << 20) - 1;
 	const int64_t nw = ((int64_t)G + 63) / 64; // words of a genome bitset
-	std::vector<uint64_t> pairs((size_t)(n_tri * (1 + nw))); // records of 1 + nw words: key = sub << 20 | dom, then the genome bits
+	static thread_local std::vector<uint64_t> pairs; // records of 1 + nw words: key = sub << 20 | dom, then the genome bits
+	pairs.resize((size_t)(n_tri * (1 + nw)));
 	if (n_tri && !sharded()) BE_CALL(be->fetch(ext->ctx, pairs.data(), b_tri, sizeof(uint64_t) * pairs.size()), "fetch");
 	const double tv2 = now_sec();
 	if (sharded()) { // every rank's records, concatenated in rank order; a pair may come from several ranks (disjoint genome bits)
@@ -940,19 +945,19 @@ static int gen_vtx(const pg_opt_t *opt, pg_graph_t *q, DataExt *ext)
 	}
 	// group the records by sub gene (counting sort on the key's sub field keeps it linear)
 	const int64_t n_rec = (int64_t)(pairs.size() / (size_t)(1 + nw));
-	std::vector<int64_t> sub_off((size_t)Q + 1, 0);
+	static thread_local std::vector<int64_t> sub_off, sub_rec, cur;
+	sub_off.assign((size_t)Q + 1, 0);
 	for (int64_t r = 0; r < n_rec; ++r) ++sub_off[(size_t)(pairs[(size_t)(r * (1 + nw))] >> 20) + 1];
 	for (int32_t g = 0; g < Q; ++g) sub_off[(size_t)g + 1] += sub_off[(size_t)g];
-	std::vector<int64_t> sub_rec((size_t)n_rec);
+	sub_rec.resize((size_t)n_rec);
 	{
-		std::vector<int64_t> cur(sub_off.begin(), sub_off.end() - 1);
+		cur.assign(sub_off.begin(), sub_off.end() - 1);
 		for (int64_t r = 0; r < n_rec; ++r) sub_rec[(size_t)cur[(size_t)(pairs[(size_t)(r * (1 + nw))] >> 20)]++] = r;
 	}
-	std::vector<uint64_t> marked; // genome bitset per dom gene, allocated on first use
-	std::vector<int32_t> mark_slot((size_t)Q, -1);
-	std::vector<int32_t> ycnt((size_t)Q, 0); // #genomes where the gene is dominant and already marked
-
-	std::vector<pg128_t> cnt((size_t)Q);
+	static thread_local std::vector<uint64_t> marked; // genome bitset per dom gene, allocated on first use
+	static thread_local std::vector<int32_t> mark_slot, ycnt; // ycnt: #genomes where the gene is dominant and already marked
+	static thread_local std::vector<pg128_t> cnt;
+	marked.clear(), mark_slot.assign((size_t)Q, -1), ycnt.assign((size_t)Q, 0), cnt.resize((size_t)Q);
 	for (int32_t i = 0; i < Q; ++i) { // vertex.c:18-19,47-56
 		cnt[(size_t)i].x = (uint64_t)(int64_t)d->prot[d->gene[i].rep_pid].avg_score_adj;
 		cnt[(size_t)i].y = (uint64_t)i;
