@@ -337,6 +337,8 @@ typedef struct {
 	int  (*copy_gbps)(size_t, int32_t, double *); /* may be NULL */
 	int  (*warm)(void); /* may be NULL */
 	int  (*reserve)(int64_t, int64_t, int32_t, int32_t, int32_t, int64_t); /* may be NULL */
+	int  (*stage)(const void *, size_t); /* may be NULL */
+	void (*stage_drop)(const void *);    /* may be NULL */
 } pga_backend_t;
 
 const pga_backend_t *pga_backend(void);
@@ -425,6 +427,14 @@ void *pga_active_stream(void);
  * that knows its files' sizes can have it done while it parses (pg_read_paf_batch does).  Too small an estimate costs nothing but the
  * attempt; blocks nobody claims go back with pga_host_trim(0).  Safe to call from any thread. */
 int pga_reserve(int64_t n_hit, int64_t n_exon, int32_t n_prot, int32_t n_gene, int32_t n_genome, int64_t raw_words);
+/* Blocks on their way before there is a context (round 6; SURVEY 8(d): "device upload included").  The reader packs the genomes into slabs of page-locked host
+ * memory (host_alloc) while later files are still parsed; a slab that is full and completely written is handed over here: its first `bytes` bytes are copied to a
+ * device buffer of the library's on a stream of its own, and nothing waits.  pga_create() takes the blocks it finds inside such a slab from that copy (device to
+ * device, behind the copy's event) instead of across the host link again.  The caller promises not to write to [host, host + bytes) until pga_stage_drop(host),
+ * which it calls before the slab is reused or freed (it waits for a copy still in flight).  Safe to call from any thread; 0 or an error code -- a slab that was
+ * not staged is simply uploaded by pga_create() as before. */
+int pga_stage_h2d(const void *host, size_t bytes);
+void pga_stage_drop(const void *host);
 int pga_timing_reset(pga_ctx_t *ctx);
 int pga_timing_get(pga_ctx_t *ctx, int32_t which, double *total_ms, int64_t *n_launch, int64_t *units);
 

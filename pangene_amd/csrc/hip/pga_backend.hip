@@ -126,7 +126,7 @@ extern "C" const pga_backend_t *pga_backend(void)
 	static const pga_backend_t b = {
 		"hip-gfx950", pga_create, pga_destroy, pga_begin, pga_ingest, pga_post_partials, pga_post_apply, pga_shadow, pga_set_filter,
 		pga_vtx_partials, pga_flag_vtx, pga_arc_round, pga_arc_merge, pga_arc_set_current, pga_rep_pos, pga_n_local, pga_branch_pairs, pga_branch_decide, pga_mark_hits, pga_override_order, pga_set_head, pga_fetch, pga_put, pga_copy, pga_scratch,
-		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count, pga_arc_round_x, pga_copy_gbps, pga_warm, pga_reserve
+		pga_download, pga_hazards, pga_is_device, pga_strerror, pga_timing_reset, pga_timing_get, pga_sync, pga_fetch_later, pga_hazard_segs, pga_host_alloc, pga_host_free, pga_arc_round_local, pga_ctg_counts, pga_gene_matrix, pga_arc_table, pga_arc_round_finish, pga_branch_decide_filter, pga_branch_loop, pga_host_trim, pga_set_device, pga_device_count, pga_arc_round_x, pga_copy_gbps, pga_warm, pga_reserve, pga_stage_h2d, pga_stage_drop
 	};
 	return &b;
 }

@@ -291,6 +291,73 @@ extern "C" int pga_reserve(int64_t n_hit, int64_t n_exon, int32_t n_prot, int32_
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// blocks staged before there is a context (include/pangene_hip.h: pga_stage_h2d)
+// ------------------------------------------------------------------------------------------------
+struct StageEnt { const char *host; size_t bytes; char *dev; size_t cap; hipEvent_t ev; int devno; };
+static std::mutex g_stage_mu;
+static std::vector<StageEnt> g_stage;      // slabs whose copy stands
+static std::vector<StageEnt> g_stage_idle; // device buffers (and their events) waiting for the next slab
+static hipStream_t g_stage_st = nullptr; static int g_stage_st_dev = -1;
+static const size_t STAGE_IDLE_MAX = 24;   // buffers kept between data sets (64 MiB each as a rule)
+
+extern "C" int pga_stage_h2d(const void *host, size_t bytes)
+{
+	static const bool off = env_has("PANGENE_STAGE", "0");
+	if (off || host == nullptr || bytes == 0) return PGA_ERR_ARG;
+	if (g_last_dev.load() >= 0) (void)hipSetDevice(g_last_dev.load()); // (the current device is a property of the thread)
+	StageEnt e = { (const char *)host, bytes, nullptr, 0, nullptr, cur_dev() };
+	{
+		std::lock_guard<std::mutex> lk(g_stage_mu);
+		if (g_stage_st == nullptr || g_stage_st_dev != e.devno) {
+			if (g_stage_st) (void)hipStreamDestroy(g_stage_st);
+			g_stage_st = nullptr;
+			if (hipStreamCreateWithFlags(&g_stage_st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); g_stage_st = nullptr; return PGA_ERR_NO_DEVICE; }
+			g_stage_st_dev = e.devno;
+		}
+		for (size_t i = 0; i < g_stage_idle.size(); ++i)
+			if (g_stage_idle[i].devno == e.devno && g_stage_idle[i].cap >= bytes) { e.dev = g_stage_idle[i].dev, e.cap = g_stage_idle[i].cap, e.ev = g_stage_idle[i].ev; g_stage_idle.erase(g_stage_idle.begin() + (long)i); break; }
+	}
+	if (e.dev == nullptr) {
+		const size_t cap = (bytes + ((size_t)64 << 20) - 1) & ~(((size_t)64 << 20) - 1);
+		if (hipMalloc((void **)&e.dev, cap) != hipSuccess) { (void)hipGetLastError(); return PGA_ERR_NOMEM; }
+		e.cap = cap;
+		if (hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(e.dev); return PGA_ERR_NO_DEVICE; }
+	}
+	std::lock_guard<std::mutex> lk(g_stage_mu); // (one stream: the copies and their events are queued in one order)
+	if (hipMemcpyAsync(e.dev, host, bytes, hipMemcpyHostToDevice, g_stage_st) != hipSuccess || hipEventRecord(e.ev, g_stage_st) != hipSuccess) {
+		(void)hipGetLastError(); (void)hipStreamSynchronize(g_stage_st); (void)hipEventDestroy(e.ev); (void)hipFree(e.dev);
+		return PGA_ERR_NO_DEVICE;
+	}
+	g_stage.push_back(e);
+	return 0;
+}
+
+extern "C" void pga_stage_drop(const void *host)
+{
+	std::vector<StageEnt> gone;
+	{
+		std::lock_guard<std::mutex> lk(g_stage_mu);
+		for (size_t i = 0; i < g_stage.size();)
+			if (g_stage[i].host == (const char *)host) { gone.push_back(g_stage[i]); g_stage.erase(g_stage.begin() + (long)i); } else ++i;
+	}
+	for (StageEnt &e : gone) {
+		(void)hipEventSynchronize(e.ev); // (a copy still reading the slab, or a context's copy out of the buffer queued behind it: over before either is used again)
+		std::lock_guard<std::mutex> lk(g_stage_mu);
+		if (g_stage_idle.size() < STAGE_IDLE_MAX) g_stage_idle.push_back(e);
+		else { (void)hipEventDestroy(e.ev); (void)hipFree(e.dev); }
+	}
+}
+
+// the staged copy that holds [p, p + n), if any (pga_create)
+static bool stage_lookup(const char *p, size_t n, const char **dev, hipEvent_t *ev)
+{
+	std::lock_guard<std::mutex> lk(g_stage_mu);
+	for (const StageEnt &e : g_stage)
+		if (e.devno == cur_dev() && p >= e.host && p + n <= e.host + e.bytes) { *dev = e.dev + (p - e.host), *ev = e.ev; return true; }
+	return false;
+}
+
 extern "C" int pga_warm(void)
 {
 	int ndev = 0;

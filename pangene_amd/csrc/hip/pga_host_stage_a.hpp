@@ -1,6 +1,7 @@
 // pga_host_stage_a.hpp -- pga_create / pga_begin / pga_ingest: upload, per-hit constants, stage A (read.c:243-260).
 // Host side of the device ABI (include/pangene_hip.h); included by pga_backend.hip (one translation unit), in this order.
 #pragma once
+static bool stage_lookup(const char *p, size_t n, const char **dev, hipEvent_t *ev); // (pga_host_io.hpp)
 
 
 static size_t pool_want(int64_t N, int64_t GL, int64_t P, int64_t Q, int64_t raw_words)
@@ -184,7 +185,15 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 	int32_t *raw = (int32_t *)c->pool.get(S_RAW, sizeof(int32_t) * (size_t)woff[(size_t)GL] + 64);
 	int32_t *up = (int32_t *)c->pool.get(S_UPLOAD, sizeof(int32_t) * (size_t)N * 18 + 64); // stays resident: begin() restarts a run without PCIe traffic
 	if (!raw || !up) return PGA_ERR_NOMEM;
-	for (const Run &r : runs) HIPCHK(hipMemcpyAsync(raw + r.dev_word, r.base, r.bytes, hipMemcpyHostToDevice, c->st));
+	size_t n_staged = 0, b_staged = 0;
+	for (const Run &r : runs) { // (a run inside a slab the reader has staged already -- pga_stage_h2d -- comes out of that copy, behind its event)
+		const char *dv = nullptr; hipEvent_t ev = nullptr;
+		if (stage_lookup(r.base, r.bytes, &dv, &ev)) {
+			HIPCHK(hipStreamWaitEvent(c->st, ev, 0));
+			HIPCHK(hipMemcpyAsync(raw + r.dev_word, dv, r.bytes, hipMemcpyDeviceToDevice, c->st));
+			++n_staged, b_staged += r.bytes;
+		} else HIPCHK(hipMemcpyAsync(raw + r.dev_word, r.base, r.bytes, hipMemcpyHostToDevice, c->st));
+	}
 	TRY(upload(c, c->goff, c->h_goff.data(), (size_t)GL + 1)); TRY(upload(c, c->ggl, c->h_ggl.data(), GL));
 	TRY(upload(c, c->ctg_base, ctg_base.data(), (size_t)GL + 1)); TRY(upload(c, c->eoff, eoff.data(), (size_t)GL + 1)); TRY(upload(c, c->woff, woff.data(), (size_t)GL + 1));
 	TRY(upload(c, c->prot_gid, sh->prot_gid, c->P)); TRY(upload(c, c->gene_pref, sh->gene_pref, c->Q));
@@ -300,7 +309,7 @@ static int create_impl(pga_ctx *c, const pga_shard_t *sh)
 		rc = PGA_ERR_RANGE;
 	}
 	c->exon_regular = rc != 0 || c->h_cnt[9] == 0; // (dcnt[9] is the rounds' overflow counter later on; pga_begin clears it)
-	if (timing) fprintf(stderr, "[pga_create] allocations %.3f ms, upload of %.1f MB in %zu copy command(s) + unpack %.3f ms\n", (t1 - t0) * 1e3, woff[(size_t)GL] * 4e-6, runs.size(), (now() - t1) * 1e3);
+	if (timing) fprintf(stderr, "[pga_create] allocations %.3f ms, upload of %.1f MB in %zu copy command(s) (%zu of them, %.1f MB, out of slabs staged while the files were read) + unpack %.3f ms\n", (t1 - t0) * 1e3, woff[(size_t)GL] * 4e-6, runs.size(), n_staged, b_staged * 1e-6, (now() - t1) * 1e3);
 	return rc;
 }
 

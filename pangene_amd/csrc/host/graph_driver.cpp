@@ -129,6 +129,7 @@ static int xgather(const pga_backend_t *be, pga_ctx_t *ctx, const T *local, int6
 // to hand the blocks to the backend: the upload is then plain DMA out of pinned memory.
 // ---------------------------------------------------------------------------------------------
 static void *block_alloc(DataExt *ext, size_t bytes);
+static void block_done(DataExt *ext, const void *buf);
 // (the signature of a genome's records: what it is for is said above stale_packs)
 struct SigState { uint64_t h[4]; };
 static inline void sig_begin(SigState &s, const pg_genome_t *g)
@@ -241,6 +242,7 @@ again:
 	b.vfirst = wide ? pk.vfirst.data() : nullptr, b.vbase = wide ? pk.vbase.data() : nullptr;
 	if (!wide) pk.vfirst.clear(), pk.vreal.clear(), pk.vbase.clear();
 	pk.sig = sorted ? 0 : sig_end(sig);
+	block_done(ext, pk.buf);
 }
 
 // A pack made when the genome was read is only good while the genome still is what it was then.  The public pg_data_t may be
@@ -313,7 +315,7 @@ void pack_genomes(const pg_data_t *d, DataExt *ext, int32_t j0, int32_t j1, doub
 static std::mutex g_slab_mu;
 static std::vector<HostSlab> g_slab_cache;
 static size_t g_slab_cached = 0;
-static const size_t SLAB_BYTES = (size_t)64 << 20;
+static const size_t SLAB_BYTES = [] { const char *e = std::getenv("PANGENE_SLAB_MB"); return (size_t)(e && std::atoi(e) > 0 ? std::atoi(e) : 64) << 20; }(); // (tests shrink it: slabs that fill up -- and are staged -- on small data sets)
 static const size_t SLAB_CACHE_MAX = (size_t)4 << 30;   // while a data set is alive (its upload and its downloads reuse the slabs)
 // (when no data set is left a process keeps 256 MiB page-locked: ext_drop, paf_reader.cpp; pg_trim_host_cache(0) releases that too)
 
@@ -339,7 +341,7 @@ static HostSlab slab_get(size_t min_bytes, bool allow_pin = true)
 				if (g_slab_cache[i].cap >= min_bytes) {
 					HostSlab s = g_slab_cache[i];
 					g_slab_cache.erase(g_slab_cache.begin() + (long)i);
-					g_slab_cached -= s.cap, s.off = 0, s.fresh = false;
+					g_slab_cached -= s.cap, s.off = 0, s.fresh = false, s.pending = 0, s.closed = false, s.staged = false;
 					return s;
 				}
 			if (g_prefetch_left <= 0 || min_bytes > SLAB_BYTES) break;
@@ -394,24 +396,63 @@ void slab_prefetch(size_t bytes, std::thread *helper) // *helper is joined by th
 	});
 }
 
+// A slab that no more blocks will be carved out of and whose blocks have all been written goes on its way to the device at once (round 6: the DMA
+// runs while later files are still parsed; pga_create() takes its blocks out of that copy).  Page-locked slabs only, and only once the device is up.
+static void stage_slab(DataExt *ext, char *p, size_t n)
+{
+	const pga_backend_t *be = backend_default();
+	static const bool off = [] { const char *e = std::getenv("PANGENE_STAGE"); return e && *e == '0'; }();
+	bool ok = !off && be->stage != nullptr && be->is_device() && g_device_up.load() && n > 0 && be->stage(p, n) == 0;
+	if (ok) return;
+	std::lock_guard<std::mutex> lk(ext->slab_mu);
+	for (HostSlab &x : ext->slabs) if (x.p == p) x.staged = false; // (uploaded by pga_create as before)
+}
+
 static void *block_alloc(DataExt *ext, size_t bytes)
 {
 	bytes = (bytes + 255) & ~(size_t)255;
-	std::lock_guard<std::mutex> lk(ext->slab_mu);
-	if (ext->slabs.empty() || ext->slabs.back().off + bytes > ext->slabs.back().cap) {
-		// Page-locking costs ~1 ms per MB (measured: 580 MB of blocks for 12 M hits = 0.5 s, twice the parsing itself) and the DMA
-		// it buys saves ~0.1 ms per MB on the one upload.  What the cache holds is used; beyond PIN_BUDGET of freshly locked
-		// memory a read takes plain pages (the runtime stages those uploads).
-		static const size_t PIN_BUDGET = [] { const char *e = std::getenv("PANGENE_PIN_BUDGET_MB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 192) << 20; }(); // (tuning: 0 = no page-locking while files are read)
-		size_t fresh = 0;
-		for (const HostSlab &x : ext->slabs) if (x.pinned && x.fresh) fresh += x.cap;
-		HostSlab ns = slab_get(bytes, fresh + SLAB_BYTES <= PIN_BUDGET);
-		ext->slabs.push_back(ns);
+	char *st_p = nullptr; size_t st_n = 0;
+	void *r;
+	{
+		std::lock_guard<std::mutex> lk(ext->slab_mu);
+		if (ext->slabs.empty() || ext->slabs.back().off + bytes > ext->slabs.back().cap) {
+			if (!ext->slabs.empty()) { // the slab in use so far is closed: staged now if nobody is still writing into it, else by the last writer (block_done)
+				HostSlab &prev = ext->slabs.back();
+				prev.closed = true;
+				if (prev.pending == 0 && prev.pinned && !prev.staged && prev.off) prev.staged = true, st_p = prev.p, st_n = prev.off;
+			}
+			// Page-locking costs ~1 ms per MB (measured: 580 MB of blocks for 12 M hits = 0.5 s, twice the parsing itself) and the DMA
+			// it buys saves ~0.1 ms per MB on the one upload.  What the cache holds is used; beyond PIN_BUDGET of freshly locked
+			// memory a read takes plain pages (the runtime stages those uploads).
+			static const size_t PIN_BUDGET = [] { const char *e = std::getenv("PANGENE_PIN_BUDGET_MB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 192) << 20; }(); // (tuning: 0 = no page-locking while files are read)
+			size_t fresh = 0;
+			for (const HostSlab &x : ext->slabs) if (x.pinned && x.fresh) fresh += x.cap;
+			HostSlab ns = slab_get(bytes, fresh + SLAB_BYTES <= PIN_BUDGET);
+			ext->slabs.push_back(ns);
+		}
+		HostSlab &s = ext->slabs.back();
+		r = s.p + s.off;
+		s.off += bytes;
+		++s.pending;
 	}
-	HostSlab &s = ext->slabs.back();
-	void *r = s.p + s.off;
-	s.off += bytes;
+	if (st_p) stage_slab(ext, st_p, st_n);
 	return r;
+}
+
+// the block at `buf` has been written completely (pack_one)
+static void block_done(DataExt *ext, const void *buf)
+{
+	char *st_p = nullptr; size_t st_n = 0;
+	{
+		std::lock_guard<std::mutex> lk(ext->slab_mu);
+		for (HostSlab &x : ext->slabs)
+			if (x.p && (const char *)buf >= x.p && (const char *)buf < x.p + x.cap) {
+				if (x.pending > 0) --x.pending;
+				if (x.closed && x.pending == 0 && x.pinned && !x.staged && x.off) x.staged = true, st_p = x.p, st_n = x.off;
+				break;
+			}
+	}
+	if (st_p) stage_slab(ext, st_p, st_n);
 }
 
 static void slab_put(HostSlab &s) // back into the process-wide cache (or to the system)
@@ -451,6 +492,8 @@ void free_packs(DataExt *ext, bool wait)
 	old_packs.swap(ext->packs); // (their vectors of virtual-contig tables: freed with the rest)
 	ext->packs.resize(old_packs.size());
 	std::vector<HostSlab> plain;
+	for (HostSlab &s : ext->slabs) // (a staged copy of a slab ends here: before the slab can be written again)
+		if (s.p && s.staged) { if (backend_default()->stage_drop) backend_default()->stage_drop(s.p); s.staged = false; }
 	{
 		std::lock_guard<std::mutex> lk(g_slab_mu);
 		const pga_backend_t *be = backend_default();

@@ -138,7 +138,8 @@ struct GenomePack {
 	std::vector<int32_t> vfirst, vreal;       // per piece: first piece of its contig; the contig's own id (pg_hit_t::cid)
 	std::vector<int64_t> vbase;               // per piece: the base its coordinates are relative to
 };
-struct HostSlab { char *p = nullptr; size_t cap = 0, off = 0; bool pinned = false, fresh = false; }; // fresh: page-locked for this very read (not taken from the cache)
+struct HostSlab { char *p = nullptr; size_t cap = 0, off = 0; bool pinned = false, fresh = false; // fresh: page-locked for this very read (not taken from the cache)
+	int pending = 0; bool closed = false, staged = false; }; // blocks handed out and not yet written; no more blocks will come; its bytes are on their way to the device (pga_stage_h2d)
 
 // host-private companion of a pg_data_t (struct layout of pg_data_t itself must not change)
 struct DataExt {
