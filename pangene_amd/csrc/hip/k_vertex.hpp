@@ -27,6 +27,37 @@ __global__ __launch_bounds__(BLOCK) void k_vtx1(const uint32_t *flags, const int
 	}
 }
 
+// The same with the genes' counts through LDS (round 6, as k_post_part_lds: one contribution per (genome, gene) is what there is to reduce -- a workgroup reads a stretch
+// of many genomes and sends what is not zero at the end; the (genome, gene) bits have nothing to reduce and stay global atomics): 8 bytes a gene, shards from 0.5 M hits.
+constexpr int VX_T = 1024;
+__global__ __launch_bounds__(VX_T) void k_vtx1_lds(const uint32_t *flags, const int32_t *gnm, const int32_t *gid, const int32_t *rank, const int32_t *pdom,
+                                                     int n, int Q, int32_t *cnt, uint32_t *dombits, int64_t words_per_genome, int64_t *dcnt, int64_t *live_cnt)
+{
+	extern __shared__ int vx_cnt[]; // [2 Q]
+	for (int i = threadIdx.x; i < 2 * Q; i += VX_T) vx_cnt[i] = 0;
+	__syncthreads();
+	const int64_t per = (((int64_t)n + gridDim.x - 1) / gridDim.x + 63) & ~(int64_t)63, h0 = (int64_t)blockIdx.x * per, h1 = h0 + per < n ? h0 + per : n; // (whole waves: the ballots)
+	long long n_live = 0;
+	for (int64_t b = h0; b < h1; b += VX_T) {
+		const int64_t h = b + threadIdx.x;
+		const uint32_t f = h < h1 ? flags[h] : (uint32_t)PGA_F_FLT;
+		if (live_cnt) n_live += __popcll(__ballot(!(f & PGA_F_FLT)));
+		if (h >= h1 || (f & PGA_F_FLT) || rank[h] != 0) continue;
+		const int g = gid[h];
+		if (f & PGA_F_SHADOW) {
+			if (pdom[h] < 0) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // vertex.c:38
+			atomicAdd(&vx_cnt[Q + g], 1);
+		} else {
+			atomicAdd(&vx_cnt[g], 1);
+			const uint32_t old = atomicOr(&dombits[(int64_t)gnm[h] * words_per_genome + (g >> 5)], 1u << (g & 31));
+			if (old & (1u << (g & 31))) atomicAdd((unsigned long long *)&dcnt[3], 1ull); // two rank-0 hits of one gene: cannot happen after hit.c:107-128
+		}
+	}
+	if (live_cnt && (threadIdx.x & 63) == 0 && n_live) atomicAdd((unsigned long long *)&live_cnt[(blockIdx.x * (VX_T / WAVE) + (threadIdx.x >> 6)) & (LIVE_CNT_N - 1)], (unsigned long long)n_live);
+	__syncthreads();
+	for (int i = threadIdx.x; i < 2 * Q; i += VX_T) { const int v = vx_cnt[i]; if (v) atomicAdd(&cnt[i], v); }
+}
+
 // Fold of the (genome, sub gene, dom gene) relation into one genome bitset per (sub, dom) pair, the form the host greedy
 // consumes (vertex.c:60-80 marks cell (genome, dom) for every genome of the pair).  A sub gene has very few distinct dom
 // genes, so each gene owns VTX_K slots: a slot is claimed for a dom gene with atomicCAS, the genome bit is an atomicOr.

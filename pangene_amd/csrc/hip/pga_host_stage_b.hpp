@@ -103,7 +103,18 @@ extern "C" int pga_vtx_partials(pga_ctx_t *c, int32_t **cnt, uint64_t **records,
 		HIPCHK(hipMemsetAsync(c->live_cnt, 0, sizeof(int64_t) * LIVE_CNT_N, c->st)); // k_vtx1 counts the hits without flt there
 		*records = (uint64_t *)rec;
 		if (N == 0) return sync_st(c);
-		hipLaunchKernelGGL(k_vtx1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt, c->live_cnt);
+		{ // (round 6) the genes' counts through LDS on shards whose stretches hold several genomes (PANGENE_POST=atomics / lds as for k_post_part_lds)
+			static const bool vx_atomics = env_has("PANGENE_POST", "atomics"), vx_force = env_has("PANGENE_POST", "lds");
+			const size_t lds = sizeof(int) * 2 * (size_t)std::max(1, Q);
+			static size_t lds_set = 0;
+			bool ok = !vx_atomics && (N >= (1 << 19) || vx_force) && lds <= ((size_t)144 << 10);
+			if (ok && lds > lds_set) { ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_vtx1_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; if (ok) lds_set = lds; else (void)hipGetLastError(); }
+			if (ok) {
+				const int n_chunk = (int)std::max<int64_t>(1, std::min<int64_t>(2 * c->n_cu, N / 32768));
+				hipLaunchKernelGGL(k_vtx1_lds, dim3((unsigned)n_chunk), dim3(VX_T), lds, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt, c->live_cnt);
+			} else
+			hipLaunchKernelGGL(k_vtx1, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, N, Q, c->vtx_cnt, bits, wpg, c->dcnt, c->live_cnt);
+		}
 		hipLaunchKernelGGL(k_live_sum, dim3(1), dim3(BLOCK), 0, c->st, (const int64_t *)c->live_cnt, c->dcnt);
 		hipLaunchKernelGGL(k_vtx_fold, dim3(nblk(N)), dim3(BLOCK), 0, c->st, c->flags, c->gnm, c->gid, c->rank, c->pdom, c->prot_gid, c->ggl, N, bits, wpg,
 		                   dom_tab, pbits, nw, rec + n_slot * (1 + nw), ovf_cap, c->dcnt);
