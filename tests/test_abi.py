@@ -200,6 +200,20 @@ def test_in_place_edit_is_seen_by_the_device_path(built, tmp_path):
     assert got == want
 
 
+@pytest.mark.gpu
+def test_forty_thousand_rank0_hits_of_one_protein_are_counted_exactly(built, tmp_path):
+    """Stage B's per-protein sums through LDS (k_post_part_lds) keep a workgroup's two counts in the halves of one 32-bit word and empty a half into
+    the global table when it reaches 2^15: 40 000 rank-0 hits of ONE protein in one workgroup's stretch (ranks edited in place, as the public
+    pg_data_t allows) must give what the checker build prints.  tests/support/rank0_flood.py, in processes of their own (PANGENE_POST is read once)."""
+    md5 = {}
+    for which in ("oracle", "hip"):
+        env = dict(os.environ, PANGENE_POST="lds")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "support", "rank0_flood.py"), which, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        md5[which] = [ln for ln in r.stdout.splitlines() if ln.startswith("md5 ")][-1]
+    assert md5["hip"] == md5["oracle"]
+
+
 def test_in_place_edit_between_read_and_post_process_is_seen(built, tmp_path):
     """pg_read_paf packs every genome for the device while the next file is parsed; the reference reads g->hit at pg_post_process time
     (graph.c:7-32), so a caller may edit the public pg_data_t in between.  The pack carries a signature over EVERY record it was made
