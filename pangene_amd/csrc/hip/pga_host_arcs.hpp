@@ -123,7 +123,8 @@ static int ensure_half_arcs(pga_ctx *c, int use_ori)
 	if (!hzl) return PGA_ERR_NOMEM;
 	TimedLaunch tw; if (c->timing_rounds) time_mark(c, &tw, 6, false);
 	const Walk wk = {c->flags, c->ylist, c->wrec, c->g2s, c->hfk, c->hbk, c->hfp, c->hbp, c->round_tag, use_ori, c->NL, c->dcnt, hzl, c->gate};
-	if (c->NL >= WK_FEW_FROM) hipLaunchKernelGGL(k_walk<4>, dim3(nblk(c->NL, BLOCK * 4)), dim3(BLOCK), 0, c->st, wk);
+	static const int ipt_env = [] { const char *e = getenv("PANGENE_WALK_IPT"); return e ? atoi(e) : 0; }(); // (measurements: 1 / 4 positions a thread whatever the size)
+	if (ipt_env == 4 || (ipt_env != 1 && c->NL >= WK_FEW_FROM)) hipLaunchKernelGGL(k_walk<4>, dim3(nblk(c->NL, BLOCK * 4)), dim3(BLOCK), 0, c->st, wk);
 	else if (c->NL) hipLaunchKernelGGL(k_walk<1>, dim3(nblk(c->NL, BLOCK)), dim3(BLOCK), 0, c->st, wk);
 	if (c->timing_rounds) time_mark(c, &tw, 6, true);
 	c->ha_valid = true, c->ha_ori = use_ori;
